@@ -1,0 +1,507 @@
+// ref_harness -- TEST INFRASTRUCTURE ONLY (never linked into or called by the product).
+//
+// Our own main() linked against the *unmodified* reference objects (everything in
+// /root/reference/src except reseek_main.cpp; recipe: oracle/Makefile.ref).  It calls the
+// reference's own classes/functions and dumps (a) per-chain inputs of the -search hot
+// path, (b) per-pair intermediates, (c) known-answer vectors for the scalar kernels that
+// have no live caller, (d) the in-memory constant tables.  Outputs are *data* fixtures
+// (tests/golden/) -- no reference source text is emitted.
+//
+// Reference entry points exercised (file:line are relative to /root/reference/src):
+//   DSS::GetProfile/GetMuLetters/GetMuKmers   dss.cpp:716,700,659
+//   GetSelfRevScore                           alignpair.cpp:7
+//   DSSAligner::SetQuery/SetTarget/...        dssaligner.cpp:674,701,929
+//   parasail_sw_striped_profile_avx2_256_8    parasail.cpp:515
+//   SWFastPinopGapless / SWFastPinop          swfastpinopgapless.cpp:6 / swfastpinop.cpp:6
+//   SWFastGapless_Int                         swgaplessint.cpp:7
+//   SWFast                                    sw.cpp:79
+//   DSSParams::ApplyWeights                   dssparams.cpp:344
+//
+// usage: ref_harness <subcmd> <args...> [-- <reseek options, e.g. -sensitive>]
+//   tables   <out.h>
+//   db       <in.bca> <out.rskdb>            [-- -sensitive|-fast|-verysensitive]
+//   pairs    <in.bca> <out.bin> <maxchains>  [-- mode]
+//   mukat    <in.mu.fa> <first> <count> <out.bin>
+//   randkat  <seed> <npairs> <out.bin>
+
+#include "myutils.h"
+#include "dss.h"
+#include "dssaligner.h"
+#include "chainreader2.h"
+#include "parasail.h"
+#include "mumx.h"
+#include "xdpmem.h"
+#include "mx.h"
+#include "seqdb.h"
+#include "alpha.h"
+#include <cstdio>
+#include <cstring>
+
+int g_Frame = 0;
+string g_Arg1;
+
+float GetSelfRevScore(DSSAligner &DA, DSS &D, const PDBChain &Chain,
+  const vector<vector<byte> > &Profile, const vector<byte> *ptrMuLetters,
+  const vector<uint> *ptrMuKmers);
+uint SWFastPinopGapless(const int8_t * const *AP, uint LA, const int8_t *B, uint LB);
+uint SWFastPinop(XDPMem &Mem, const int8_t * const *AP, uint LA, const int8_t *B, uint LB,
+  int8_t Open, int8_t Ext);
+int SWFastGapless_Int(XDPMem &Mem, const Mx<int8_t> &SMx, uint LA, uint LB,
+  uint &Besti, uint &Bestj);
+float SWFast(XDPMem &Mem, const float * const *SMxData, uint LA, uint LB,
+  float Open, float Ext, uint &Loi, uint &Loj, uint &Leni, uint &Lenj, string &Path);
+extern parasail_matrix_t parasail_mu_matrix;
+
+static void w32(FILE *f, uint32_t v) { fwrite(&v, 4, 1, f); }
+static void wi32(FILE *f, int32_t v) { fwrite(&v, 4, 1, f); }
+static void wf32(FILE *f, float v) { fwrite(&v, 4, 1, f); }
+static void wbytes(FILE *f, const void *p, size_t n) { if (n) fwrite(p, 1, n, f); }
+
+static void InitOpts(int argc, char **argv, int first_opt)
+	{
+	// Build a fake reseek command line so the reference option globals are initialised.
+	vector<string> Args;
+	Args.push_back("reseek");
+	Args.push_back("-search");
+	Args.push_back("dummy");
+	Args.push_back("-threads");
+	Args.push_back("1");
+	Args.push_back("-quiet");
+	for (int i = first_opt; i < argc; ++i)
+		Args.push_back(argv[i]);
+	vector<char *> av;
+	for (size_t i = 0; i < Args.size(); ++i)
+		av.push_back(strdup(Args[i].c_str()));
+	MyCmdLine((int) av.size(), av.data());
+	}
+
+struct ChainData
+	{
+	PDBChain *Chain = 0;
+	vector<vector<byte> > Profile;
+	vector<byte> Mu;
+	vector<uint> Kmers;
+	float SelfRev = 0;
+	};
+
+// Same per-chain precompute as ProfileLoader::ThreadBody (profileloader.cpp:18-70).
+static void LoadChains(const string &FN, const DSSParams &Params,
+  vector<ChainData *> &CDs, uint MaxChains)
+	{
+	ChainReader2 CR;
+	CR.Open(FN);
+	DSS D;
+	D.SetParams(Params);
+	DSSAligner DA;
+	DSSParams DA_Params = Params;
+	DA_Params.m_UsePara = false;
+	DA_Params.m_Omega = 0;
+	DA_Params.m_OwnScoreMxs = false;
+	DA.SetParams(DA_Params);
+	for (;;)
+		{
+		if (SIZE(CDs) >= MaxChains)
+			break;
+		PDBChain *Chain = CR.GetNext();
+		if (Chain == 0)
+			break;
+		ChainData *CD = new ChainData;
+		CD->Chain = Chain;
+		D.Init(*Chain);
+		D.GetProfile(CD->Profile);
+		D.GetMuLetters(CD->Mu);
+		D.GetMuKmers(CD->Mu, CD->Kmers, Params.m_MKFPatternStr);
+		CD->SelfRev = GetSelfRevScore(DA, D, *Chain, CD->Profile, &CD->Mu, &CD->Kmers);
+		Chain->m_Idx = SIZE(CDs);
+		CDs.push_back(CD);
+		}
+	}
+
+static void cmd_tables(const string &OutFN)
+	{
+	DSSParams Params;
+	Params.SetDSSParams(DM_AlwaysSensitive);
+	FILE *f = fopen(OutFN.c_str(), "w");
+	asserta(f != 0);
+	fprintf(f, "// GENERATED DATA -- do not edit.  Produced by oracle/ref_harness `tables` from the\n");
+	fprintf(f, "// reference's in-memory constant tables (values, not source):\n");
+	fprintf(f, "//   rsk_feature_mx[f] = w_f * g_ScoreMxs2[F_f]   (dssparams.cpp:344-362, weights namedparams.cpp:36-43)\n");
+	fprintf(f, "//   rsk_mu_int        = IntScoreMx_Mu == parasail_mu_ (mumx_data.cpp:42, parasail_mu.cpp:23-60)\n");
+	fprintf(f, "//   rsk_mu_s8         = Mu_S_ij_i8 (mumx_data.cpp:81)\n");
+	fprintf(f, "//   rsk_mu_f32        = ScoreMx_Mu (mumx_data.cpp:3)\n");
+	fprintf(f, "// Floats are written as exact hex-float literals.\n");
+	const uint FC = Params.GetFeatureCount();
+	fprintf(f, "#define RSK_NFEATURES %u\n", FC);
+	fprintf(f, "static const unsigned rsk_feature_alpha[RSK_NFEATURES] = {");
+	for (uint k = 0; k < FC; ++k)
+		fprintf(f, "%s%u", k ? ", " : "", g_AlphaSizes2[Params.m_Features[k]]);
+	fprintf(f, "};\n");
+	fprintf(f, "static const char *const rsk_feature_name[RSK_NFEATURES] = {");
+	for (uint k = 0; k < FC; ++k)
+		fprintf(f, "%s\"%s\"", k ? ", " : "", FeatureToStr(Params.m_Features[k]));
+	fprintf(f, "};\n");
+	fprintf(f, "static const float rsk_feature_weight[RSK_NFEATURES] = {");
+	for (uint k = 0; k < FC; ++k)
+		fprintf(f, "%s%af", k ? ", " : "", Params.m_Weights[k]);
+	fprintf(f, "};\n");
+	// all feature matrices are stored padded to 20x20 (row-major), unused = 0
+	fprintf(f, "#define RSK_FEATURE_DIM 20\n");
+	fprintf(f, "static const float rsk_feature_mx[RSK_NFEATURES][RSK_FEATURE_DIM*RSK_FEATURE_DIM] = {\n");
+	for (uint k = 0; k < FC; ++k)
+		{
+		FEATURE F = Params.m_Features[k];
+		uint AS = g_AlphaSizes2[F];
+		fprintf(f, " { // %s alpha=%u\n", FeatureToStr(F), AS);
+		for (uint a = 0; a < 20; ++a)
+			{
+			fprintf(f, "  ");
+			for (uint b = 0; b < 20; ++b)
+				{
+				float v = (a < AS && b < AS) ? Params.m_ScoreMxs[F][a][b] : 0.0f;
+				fprintf(f, "%af,", v);
+				}
+			fprintf(f, "\n");
+			}
+		fprintf(f, " },\n");
+		}
+	fprintf(f, "};\n");
+	fprintf(f, "static const float rsk_gap_open = %af; // m_GapOpen namedparams.cpp:45\n", Params.m_GapOpen);
+	fprintf(f, "static const float rsk_gap_ext = %af;  // m_GapExt namedparams.cpp:46\n", Params.m_GapExt);
+	fprintf(f, "static const signed char rsk_mu_int[36*36] = {\n");
+	for (uint a = 0; a < 36; ++a)
+		{
+		fprintf(f, " ");
+		for (uint b = 0; b < 36; ++b)
+			{
+			asserta(IntScoreMx_Mu[a][b] == parasail_mu_matrix.matrix[a*36+b]);
+			fprintf(f, "%d,", (int) IntScoreMx_Mu[a][b]);
+			}
+		fprintf(f, "\n");
+		}
+	fprintf(f, "};\n");
+	fprintf(f, "static const signed char rsk_mu_s8[36*36] = {\n");
+	for (uint a = 0; a < 36; ++a)
+		{
+		fprintf(f, " ");
+		for (uint b = 0; b < 36; ++b)
+			fprintf(f, "%d,", (int) Mu_S_ij_i8[a][b]);
+		fprintf(f, "\n");
+		}
+	fprintf(f, "};\n");
+	fprintf(f, "static const float rsk_mu_f32[36*36] = {\n");
+	for (uint a = 0; a < 36; ++a)
+		{
+		fprintf(f, " ");
+		for (uint b = 0; b < 36; ++b)
+			fprintf(f, "%af,", ScoreMx_Mu[a][b]);
+		fprintf(f, "\n");
+		}
+	fprintf(f, "};\n");
+	fclose(f);
+	}
+
+// rskdb fixture: "RSKDB1\0\0", u32 n, u32 nfeat, then per chain:
+// u32 L, u32 labellen, label, seq[L], mu[L], prof[nfeat][L], x[L] y[L] z[L] (f32), selfrev f32,
+// u32 nkmers, kmers u32[nkmers]
+static void cmd_db(const string &InFN, const string &OutFN)
+	{
+	DSSParams Params;
+	Params.SetDSSParams(DM_UseCommandLineOption);
+	vector<ChainData *> CDs;
+	LoadChains(InFN, Params, CDs, UINT_MAX);
+	FILE *f = fopen(OutFN.c_str(), "wb");
+	asserta(f != 0);
+	wbytes(f, "RSKDB1\0\0", 8);
+	w32(f, SIZE(CDs));
+	w32(f, Params.GetFeatureCount());
+	for (uint i = 0; i < SIZE(CDs); ++i)
+		{
+		const ChainData &CD = *CDs[i];
+		const PDBChain &C = *CD.Chain;
+		uint L = C.GetSeqLength();
+		w32(f, L);
+		w32(f, SIZE(C.m_Label));
+		wbytes(f, C.m_Label.data(), C.m_Label.size());
+		wbytes(f, C.m_Seq.data(), L);
+		asserta(SIZE(CD.Mu) == L);
+		wbytes(f, CD.Mu.data(), L);
+		for (uint k = 0; k < SIZE(CD.Profile); ++k)
+			{
+			asserta(SIZE(CD.Profile[k]) == L);
+			wbytes(f, CD.Profile[k].data(), L);
+			}
+		wbytes(f, C.m_Xs.data(), 4*L);
+		wbytes(f, C.m_Ys.data(), 4*L);
+		wbytes(f, C.m_Zs.data(), 4*L);
+		wf32(f, CD.SelfRev);
+		w32(f, SIZE(CD.Kmers));
+		wbytes(f, CD.Kmers.data(), 4*CD.Kmers.size());
+		}
+	fclose(f);
+	fprintf(stderr, "db: %u chains -> %s\n", SIZE(CDs), OutFN.c_str());
+	}
+
+static int ParaRaw(const parasail_profile_t *prof, const vector<byte> &B, int Open, int Ext, int &Sat)
+	{
+	parasail_result_t *r = parasail_sw_striped_profile_avx2_256_8(prof,
+	  (const char *) B.data(), (int) B.size(), Open, Ext);
+	int s = r->score;
+	Sat = (r->flag & PARASAIL_FLAG_SATURATED) ? 1 : 0;
+	parasail_result_free(r);
+	return s;
+	}
+
+// Per-pair record (all little-endian 32-bit unless noted):
+// u32 i, j, LA, LB
+// i32 para_fwd_raw, para_fwd_sat, para_rev_raw, para_rev_sat   (parasail.cpp:515 on A / reversed A vs B)
+// f32 mufilter  (AlignMuQP_Para under the mode's Omega/OmegaFwd; parasail_mu.cpp:120)
+// i32 gapless_fwd, gapless_rev                                 (SWFastPinopGapless)
+// i32 gli_score; u32 gli_besti, gli_bestj                       (SWFastGapless_Int)
+// i32 pinop                                                    (SWFastPinop Open=-2 Ext=-1)
+// f32 sw_score; u32 loA, loB, pathlen; char path[pathlen]      (SetSMx_NoRev+SWFast)
+// u32 hiA, hiB, ids, gaps; f32 lddt, ts, pvalue, evalue, qual    (CalcEvalue; FLT_MAX when skipped)
+static void cmd_pairs(const string &InFN, const string &OutFN, uint MaxChains)
+	{
+	DSSParams Params;
+	Params.SetDSSParams(DM_UseCommandLineOption);
+	vector<ChainData *> CDs;
+	LoadChains(InFN, Params, CDs, MaxChains);
+	const uint N = SIZE(CDs);
+	FILE *f = fopen(OutFN.c_str(), "wb");
+	asserta(f != 0);
+	wbytes(f, "RSKPR1\0\0", 8);
+	w32(f, N);
+	w32(f, N*(N+1)/2);
+
+	// Params with the Mu filter as configured by the mode, para on
+	DSSAligner DA;
+	DA.SetParams(Params);
+	// An aligner with MKF/Omega off so Align_NoAccel is reachable for every pair
+	DSSParams PNo = Params;
+	PNo.m_OwnScoreMxs = false;
+	PNo.m_Omega = 0;
+	PNo.m_MKFL = 999999;
+	DSSAligner DN;
+	DN.SetParams(PNo);
+	XDPMem Mem;
+	const int Open = Params.m_ParaMuGapOpen;
+	const int Ext = Params.m_ParaMuGapExt;
+
+	for (uint i = 0; i < N; ++i)
+		{
+		const ChainData &A = *CDs[i];
+		const uint LA = A.Chain->GetSeqLength();
+		parasail_profile_t *ProfF = parasail_profile_create_avx_256_8(
+		  (const char *) A.Mu.data(), LA, &parasail_mu_matrix);
+		vector<byte> RevA(A.Mu.rbegin(), A.Mu.rend());
+		parasail_profile_t *ProfR = parasail_profile_create_avx_256_8(
+		  (const char *) RevA.data(), LA, &parasail_mu_matrix);
+		vector<const int8_t *> APf(LA), APr(LA);
+		for (uint p = 0; p < LA; ++p)
+			{
+			APf[p] = IntScoreMx_Mu[A.Mu[p]];
+			APr[LA-p-1] = IntScoreMx_Mu[A.Mu[p]];
+			}
+		DA.SetQuery(*A.Chain, &A.Profile, &A.Mu, &A.Kmers, A.SelfRev);
+		DN.SetQuery(*A.Chain, &A.Profile, &A.Mu, 0, A.SelfRev);
+		for (uint j = i; j < N; ++j)
+			{
+			const ChainData &B = *CDs[j];
+			const uint LB = B.Chain->GetSeqLength();
+			w32(f, i); w32(f, j); w32(f, LA); w32(f, LB);
+			int SatF, SatR;
+			int RawF = ParaRaw(ProfF, B.Mu, Open, Ext, SatF);
+			int RawR = ParaRaw(ProfR, B.Mu, Open, Ext, SatR);
+			wi32(f, RawF); wi32(f, SatF); wi32(f, RawR); wi32(f, SatR);
+
+			DA.SetTarget(*B.Chain, &B.Profile, &B.Mu, &B.Kmers, B.SelfRev);
+			float MuF = 0;
+			if (Params.m_Omega > 0)
+				MuF = DA.AlignMuQP_Para();
+			wf32(f, MuF);
+
+			int GF = (int) SWFastPinopGapless(APf.data(), LA, (const int8_t *) B.Mu.data(), LB);
+			int GR = (int) SWFastPinopGapless(APr.data(), LA, (const int8_t *) B.Mu.data(), LB);
+			wi32(f, GF); wi32(f, GR);
+
+			Mx<int8_t> SMx;
+			SMx.Alloc(LA, LB, __FILE__, __LINE__);
+			for (uint p = 0; p < LA; ++p)
+				for (uint q = 0; q < LB; ++q)
+					SMx.m_Data[p][q] = IntScoreMx_Mu[A.Mu[p]][B.Mu[q]];
+			uint Besti, Bestj;
+			int GLI = SWFastGapless_Int(Mem, SMx, LA, LB, Besti, Bestj);
+			wi32(f, GLI); w32(f, Besti); w32(f, Bestj);
+
+			int Pin = (int) SWFastPinop(Mem, APf.data(), LA, (const int8_t *) B.Mu.data(), LB, -2, -1);
+			wi32(f, Pin);
+
+			DN.SetTarget(*B.Chain, &B.Profile, &B.Mu, 0, B.SelfRev);
+			DN.Align_NoAccel();
+			wf32(f, DN.m_AlnFwdScore);
+			w32(f, DN.m_LoA); w32(f, DN.m_LoB);
+			w32(f, SIZE(DN.m_Path));
+			wbytes(f, DN.m_Path.data(), DN.m_Path.size());
+			w32(f, DN.m_HiA); w32(f, DN.m_HiB); w32(f, DN.m_Ids); w32(f, DN.m_Gaps);
+			float LDDT = FLT_MAX;
+			if (DN.m_EvalueA != FLT_MAX)
+				LDDT = DN.GetLDDT();
+			wf32(f, LDDT);
+			wf32(f, DN.m_NewTestStatisticA);
+			wf32(f, DN.m_PvalueA);
+			wf32(f, DN.m_EvalueA);
+			wf32(f, DN.m_QualityA);
+			}
+		parasail_profile_free(ProfF);
+		parasail_profile_free(ProfR);
+		}
+	fclose(f);
+	fprintf(stderr, "pairs: %u chains -> %s\n", N, OutFN.c_str());
+	}
+
+// Mu-only KATs on sequences [first, first+count) of a Mu FASTA, all ordered pairs incl. self.
+// Header "RSKMK1\0\0", u32 count; per seq u32 L, bytes; then count*count records of
+// i32 para_raw, para_sat, gapless, pinop   (query = row, target = column)
+static void cmd_mukat(const string &FaFN, uint First, uint Count, const string &OutFN)
+	{
+	SeqDB DB;
+	DB.FromFasta(FaFN);
+	DB.ToLetters(g_CharToLetterMu);
+	asserta(First + Count <= DB.GetSeqCount());
+	FILE *f = fopen(OutFN.c_str(), "wb");
+	asserta(f != 0);
+	wbytes(f, "RSKMK1\0\0", 8);
+	w32(f, Count);
+	vector<vector<byte> > Seqs(Count);
+	for (uint k = 0; k < Count; ++k)
+		{
+		const string &S = DB.GetSeq(First + k);
+		Seqs[k].assign(S.begin(), S.end());
+		w32(f, SIZE(Seqs[k]));
+		wbytes(f, Seqs[k].data(), Seqs[k].size());
+		}
+	XDPMem Mem;
+	for (uint i = 0; i < Count; ++i)
+		{
+		const vector<byte> &A = Seqs[i];
+		const uint LA = SIZE(A);
+		parasail_profile_t *Prof = parasail_profile_create_avx_256_8(
+		  (const char *) A.data(), LA, &parasail_mu_matrix);
+		vector<const int8_t *> AP(LA);
+		for (uint p = 0; p < LA; ++p)
+			AP[p] = IntScoreMx_Mu[A[p]];
+		for (uint j = 0; j < Count; ++j)
+			{
+			const vector<byte> &B = Seqs[j];
+			int Sat;
+			int Raw = ParaRaw(Prof, B, 2, 1, Sat);
+			int G = (int) SWFastPinopGapless(AP.data(), LA, (const int8_t *) B.data(), SIZE(B));
+			int P = (int) SWFastPinop(Mem, AP.data(), LA, (const int8_t *) B.data(), SIZE(B), -2, -1);
+			wi32(f, Raw); wi32(f, Sat); wi32(f, G); wi32(f, P);
+			}
+		parasail_profile_free(Prof);
+		}
+	fclose(f);
+	}
+
+static uint64_t s_rng;
+static uint64_t splitmix64()
+	{
+	uint64_t z = (s_rng += 0x9E3779B97F4A7C15ull);
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+	return z ^ (z >> 31);
+	}
+
+// Random + adversarial Mu pairs (low-complexity repeats force saturation and long gaps).
+// "RSKRK1\0\0", u32 npairs; per pair: u32 LA, A, u32 LB, B, i32 para_raw, para_sat, gapless, pinop
+static void cmd_randkat(uint64_t Seed, uint NPairs, const string &OutFN)
+	{
+	s_rng = Seed;
+	FILE *f = fopen(OutFN.c_str(), "wb");
+	asserta(f != 0);
+	wbytes(f, "RSKRK1\0\0", 8);
+	w32(f, NPairs);
+	XDPMem Mem;
+	for (uint n = 0; n < NPairs; ++n)
+		{
+		uint kind = n % 4;
+		uint LA = 1 + splitmix64() % (kind == 3 ? 700 : 300);
+		vector<byte> A(LA);
+		uint alpha = (kind == 1) ? 3 : 36;   // kind 1: tiny alphabet -> high scores / saturation
+		for (uint p = 0; p < LA; ++p)
+			A[p] = byte(splitmix64() % alpha);
+		vector<byte> B;
+		if (kind == 2 || kind == 3)
+			{
+			// mutated copy: sub 0.3 / ins 0.1 / del 0.1 (cf. test_para.cpp:150-174)
+			for (uint p = 0; p < LA; ++p)
+				{
+				uint r = splitmix64() % 100;
+				if (r < 10) continue;
+				if (r < 20) B.push_back(byte(splitmix64() % 36));
+				if (r < 50) B.push_back(byte(splitmix64() % 36));
+				else B.push_back(A[p]);
+				}
+			if (B.empty()) B.push_back(0);
+			}
+		else
+			{
+			uint LB = 1 + splitmix64() % 300;
+			B.resize(LB);
+			for (uint p = 0; p < LB; ++p)
+				B[p] = byte(splitmix64() % alpha);
+			}
+		parasail_profile_t *Prof = parasail_profile_create_avx_256_8(
+		  (const char *) A.data(), LA, &parasail_mu_matrix);
+		vector<const int8_t *> AP(LA);
+		for (uint p = 0; p < LA; ++p)
+			AP[p] = IntScoreMx_Mu[A[p]];
+		int Sat;
+		int Raw = ParaRaw(Prof, B, 2, 1, Sat);
+		int G = (int) SWFastPinopGapless(AP.data(), LA, (const int8_t *) B.data(), SIZE(B));
+		int P = (int) SWFastPinop(Mem, AP.data(), LA, (const int8_t *) B.data(), SIZE(B), -2, -1);
+		parasail_profile_free(Prof);
+		w32(f, LA); wbytes(f, A.data(), LA);
+		w32(f, SIZE(B)); wbytes(f, B.data(), B.size());
+		wi32(f, Raw); wi32(f, Sat); wi32(f, G); wi32(f, P);
+		}
+	fclose(f);
+	}
+
+int main(int argc, char **argv)
+	{
+	if (argc < 2)
+		{
+		fprintf(stderr, "usage: ref_harness tables|db|pairs|mukat|randkat ...\n");
+		return 2;
+		}
+	int dd = argc;
+	for (int i = 1; i < argc; ++i)
+		if (!strcmp(argv[i], "--"))
+			{
+			dd = i;
+			break;
+			}
+	InitOpts(argc, argv, dd + 1);
+	string Cmd = argv[1];
+	vector<string> A;
+	for (int i = 2; i < dd; ++i)
+		A.push_back(argv[i]);
+	if (Cmd == "tables" && A.size() == 1)
+		cmd_tables(A[0]);
+	else if (Cmd == "db" && A.size() == 2)
+		cmd_db(A[0], A[1]);
+	else if (Cmd == "pairs" && A.size() == 3)
+		cmd_pairs(A[0], A[1], (uint) atoi(A[2].c_str()));
+	else if (Cmd == "mukat" && A.size() == 4)
+		cmd_mukat(A[0], (uint) atoi(A[1].c_str()), (uint) atoi(A[2].c_str()), A[3]);
+	else if (Cmd == "randkat" && A.size() == 3)
+		cmd_randkat(strtoull(A[0].c_str(), 0, 0), (uint) atoi(A[1].c_str()), A[2]);
+	else
+		{
+		fprintf(stderr, "bad subcommand/args\n");
+		return 2;
+		}
+	return 0;
+	}

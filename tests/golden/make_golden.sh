@@ -1,0 +1,71 @@
+#!/bin/bash
+# Regenerates every fixture in tests/golden/ from the reference itself, run in THIS container:
+#   oracle/_ref/reseek       = unmodified reference binary   (oracle/Makefile.ref)
+#   oracle/_ref/ref_harness  = our main() linked against the reference objects (oracle/ref_harness.cpp)
+# Fixtures are data only (inputs + the reference's outputs).  /root/reference is needed to run
+# this script but never at test time.
+set -euo pipefail
+cd "$(dirname "$0")/../.."
+make -f oracle/Makefile.ref -j8 >/dev/null
+R=oracle/_ref/reseek
+H=oracle/_ref/ref_harness
+T=/root/reference/test_data
+G=tests/golden
+TMP=$(mktemp -d)
+COLS=query+target+qlo+qhi+ql+tlo+thi+tl+pctid+pvalue+evalue+cigar+dpscore+lddt+newts+ids+gaps+aq
+
+# 1. constant tables -> product header (generated data)
+$H tables reseek_amd/csrc/rsk_tables_data.h
+
+# 2. per-chain inputs (profile bytes, Mu letters, 3-mers, CA coords, self-rev) per mode
+for m in sensitive verysensitive fast; do
+  $H db $T/q100.bca $TMP/q100_$m.rskdb -- -$m
+  gzip -9n < $TMP/q100_$m.rskdb > $G/q100_$m.rskdb.gz
+done
+$H db $T/q10.bca $TMP/q10.rskdb -- -sensitive
+gzip -9n < $TMP/q10.rskdb > $G/q10_sensitive.rskdb.gz
+$H db $T/palms.bca $TMP/palms.rskdb -- -sensitive
+gzip -9n < $TMP/palms.rskdb > $G/palms_sensitive.rskdb.gz
+
+# 3. per-pair intermediates (all i<=j pairs)
+$H pairs $T/q100.bca $TMP/pairs_q100_sensitive.bin 100 -- -sensitive
+gzip -9n < $TMP/pairs_q100_sensitive.bin > $G/pairs_q100_sensitive.bin.gz
+$H pairs $T/q100.bca $TMP/pairs_q32_verysensitive.bin 32 -- -verysensitive
+gzip -9n < $TMP/pairs_q32_verysensitive.bin > $G/pairs_q32_verysensitive.bin.gz
+
+# 4. end-to-end hit tables of the reference binary (sorted; -threads 1)
+for m in sensitive verysensitive fast; do
+  $R -search $T/q100.bca -$m -columns $COLS -output $TMP/q100_$m.tsv -threads 1 -quiet >/dev/null 2>&1
+  sort $TMP/q100_$m.tsv | gzip -9n > $G/hits_q100_$m.tsv.gz
+  $R -search $T/q100.bca -$m -output $TMP/q100_${m}_std.tsv -threads 1 -quiet >/dev/null 2>&1
+  sort $TMP/q100_${m}_std.tsv | gzip -9n > $G/hits_q100_${m}_std.tsv.gz
+done
+$R -search $T/q10.bca -sensitive -columns $COLS -output $TMP/q10.tsv -threads 1 -quiet >/dev/null 2>&1
+sort $TMP/q10.tsv > $G/hits_q10_sensitive.tsv
+$R -search $T/palms.bca -sensitive -columns $COLS -output $TMP/palms.tsv -threads 1 -quiet >/dev/null 2>&1
+sort $TMP/palms.tsv | gzip -9n > $G/hits_palms_sensitive.tsv.gz
+$R -search $T/q100.bca -db $T/q100.bca -sensitive -columns $COLS -output $TMP/q100db.tsv -threads 1 -quiet >/dev/null 2>&1
+sort $TMP/q100db.tsv | gzip -9n > $G/hits_q100_db_q100_sensitive.tsv.gz
+
+# 5. Mu-letter known answers: real SCOP40 Mu sequences (first 160 of the reference's own
+#    test_data/scop40.mu.fa, all ordered pairs) and seeded random/adversarial pairs
+$H mukat $T/scop40.mu.fa 0 160 $TMP/mukat_scop40_160.bin
+gzip -9n < $TMP/mukat_scop40_160.bin > $G/mukat_scop40_160.bin.gz
+$H randkat 0x5EED5EEC 3000 $TMP/randkat_3000.bin
+gzip -9n < $TMP/randkat_3000.bin > $G/randkat_3000.bin.gz
+
+# 6. the empirical SCOP40 chain-length list (used by the synthetic generator)
+python3 - <<EOF
+import gzip
+L=[]; n=0
+for line in open("$T/scop40.mu.fa"):
+    if line.startswith(">"):
+        if n: L.append(n)
+        n=0
+    else: n+=len(line.strip())
+L.append(n)
+open("$G/scop40_lengths.txt","w").write("\n".join(map(str,L))+"\n")
+print(len(L), sum(L))
+EOF
+rm -rf $TMP
+ls -la $G
