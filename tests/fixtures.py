@@ -1,0 +1,136 @@
+"""Readers for the binary fixtures under tests/golden/ (formats: oracle/ref_harness.cpp)."""
+import gzip
+import os
+import struct
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _open(name):
+    path = os.path.join(GOLDEN, name)
+    if name.endswith(".gz"):
+        return gzip.open(path, "rb")
+    return open(path, "rb")
+
+
+class Chain:
+    __slots__ = ("label", "seq", "mu", "prof", "x", "y", "z", "selfrev", "kmers")
+
+    @property
+    def L(self):
+        return len(self.mu)
+
+
+def read_rskdb(name):
+    """-> list[Chain]; prof is uint8 [8, L] (feature-major)."""
+    with _open(name) as f:
+        buf = f.read()
+    assert buf[:8] == b"RSKDB1\0\0"
+    n, nfeat = struct.unpack_from("<II", buf, 8)
+    p = 16
+    chains = []
+    for _ in range(n):
+        L, ll = struct.unpack_from("<II", buf, p)
+        p += 8
+        c = Chain()
+        c.label = buf[p:p + ll].decode()
+        p += ll
+        c.seq = buf[p:p + L].decode()
+        p += L
+        c.mu = np.frombuffer(buf, np.uint8, L, p).copy()
+        p += L
+        c.prof = np.frombuffer(buf, np.uint8, nfeat * L, p).reshape(nfeat, L).copy()
+        p += nfeat * L
+        c.x = np.frombuffer(buf, np.float32, L, p).copy()
+        p += 4 * L
+        c.y = np.frombuffer(buf, np.float32, L, p).copy()
+        p += 4 * L
+        c.z = np.frombuffer(buf, np.float32, L, p).copy()
+        p += 4 * L
+        (c.selfrev,) = struct.unpack_from("<f", buf, p)
+        p += 4
+        (nk,) = struct.unpack_from("<I", buf, p)
+        p += 4
+        c.kmers = np.frombuffer(buf, np.uint32, nk, p).copy()
+        p += 4 * nk
+        chains.append(c)
+    assert p == len(buf)
+    return chains
+
+
+def read_pairs(name):
+    """-> (nchains, list[dict]) per-pair reference intermediates (all i<=j)."""
+    with _open(name) as f:
+        buf = f.read()
+    assert buf[:8] == b"RSKPR1\0\0"
+    n, npairs = struct.unpack_from("<II", buf, 8)
+    p = 16
+    recs = []
+    for _ in range(npairs):
+        (i, j, LA, LB, pf, pfs, pr, prs, muf, gf, gr, gli, gbi, gbj, pin, sw, loA, loB, plen) = struct.unpack_from(
+            "<IIIIiiiifiiiIIifIII", buf, p)
+        p += 19 * 4
+        path = buf[p:p + plen].decode()
+        p += plen
+        hiA, hiB, ids, gaps, lddt, ts, pv, ev, qual = struct.unpack_from("<IIIIfffff", buf, p)
+        p += 9 * 4
+        recs.append(dict(i=i, j=j, LA=LA, LB=LB, para_fwd=pf, para_fwd_sat=pfs, para_rev=pr, para_rev_sat=prs,
+                         mufilter=muf, gapless_fwd=gf, gapless_rev=gr, gli=gli, gli_besti=gbi, gli_bestj=gbj,
+                         pinop=pin, sw=sw, loA=loA, loB=loB, path=path, hiA=hiA, hiB=hiB, ids=ids, gaps=gaps,
+                         lddt=lddt, ts=ts, pvalue=pv, evalue=ev, qual=qual))
+    assert p == len(buf)
+    return n, recs
+
+
+def read_mukat(name):
+    """-> (seqs list[np.uint8], table int32 [n, n, 4] = para_raw, para_sat, gapless, pinop)."""
+    with _open(name) as f:
+        buf = f.read()
+    assert buf[:8] == b"RSKMK1\0\0"
+    (n,) = struct.unpack_from("<I", buf, 8)
+    p = 12
+    seqs = []
+    for _ in range(n):
+        (L,) = struct.unpack_from("<I", buf, p)
+        p += 4
+        seqs.append(np.frombuffer(buf, np.uint8, L, p).copy())
+        p += L
+    tab = np.frombuffer(buf, np.int32, n * n * 4, p).reshape(n, n, 4).copy()
+    return seqs, tab
+
+
+def read_randkat(name):
+    """-> list of (A, B, para_raw, para_sat, gapless, pinop)."""
+    with _open(name) as f:
+        buf = f.read()
+    assert buf[:8] == b"RSKRK1\0\0"
+    (n,) = struct.unpack_from("<I", buf, 8)
+    p = 12
+    out = []
+    for _ in range(n):
+        (LA,) = struct.unpack_from("<I", buf, p)
+        p += 4
+        A = np.frombuffer(buf, np.uint8, LA, p).copy()
+        p += LA
+        (LB,) = struct.unpack_from("<I", buf, p)
+        p += 4
+        B = np.frombuffer(buf, np.uint8, LB, p).copy()
+        p += LB
+        raw, sat, g, pin = struct.unpack_from("<iiii", buf, p)
+        p += 16
+        out.append((A, B, raw, sat, g, pin))
+    assert p == len(buf)
+    return out
+
+
+def read_tsv(name):
+    with _open(name) as f:
+        txt = f.read().decode()
+    return [ln.split("\t") for ln in txt.splitlines() if ln]
+
+
+def scop40_lengths():
+    with open(os.path.join(GOLDEN, "scop40_lengths.txt")) as f:
+        return np.array([int(x) for x in f.read().split()], dtype=np.int64)
