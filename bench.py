@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py -- reseek -search hot-path benchmark on MI355X (driver contract: one JSON line on rank 0).
+
+Workload (BASELINE.json configs[1]): SCOP40-shaped all-vs-all, "swgaplessint kernel only":
+11,211 synthetic Mu-letter chains (lengths = the empirical SCOP40 length list, letters iid from the
+SCOP40 Mu frequency table, planted homologs), every pair i <= j scored with the gapless integer
+kernel (SWFastGapless_Int, swgaplessint.cpp:7) -> uint16 score matrix in HBM.
+One "step" = one full all-vs-all pass with the chain set already resident in HBM.
+
+metric = aligned DP cells/s (sum LA*LB over scored pairs / wall), chain-pairs/s reported beside it.
+N > 1 (one process per GPU, torchrun): each rank owns an independent SCOP40-shaped shard (seed +
+rank) -- weak scaling; the only exchange is an RCCL all_gather of the per-rank hit summary.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# SCOP40 Mu letter frequencies A..Z a..j (measured from test_data/scop40.mu.fa)
+MU_FREQ = np.array([
+    0.0220, 0.0025, 0.0102, 0.0084, 0.0472, 0.0239, 0.0174, 0.0196, 0.0436, 0.0761, 0.0082, 0.0448, 0.0266,
+    0.0510, 0.0474, 0.0645, 0.0299, 0.1021, 0.0248, 0.0031, 0.0212, 0.0082, 0.0110, 0.0162, 0.0205, 0.0086,
+    0.0385, 0.0368, 0.0039, 0.0297, 0.0100, 0.0120, 0.0206, 0.0263, 0.0104, 0.0530])
+MU_CHARS = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghij"
+
+PEAK_VALU_LANEOPS = 256 * 4 * 32 * 2.4e9      # 256 CUs x 4 SIMD32 x 2.4 GHz (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+
+
+def scop40_lengths():
+    with open(os.path.join(ROOT, "tests", "golden", "scop40_lengths.txt")) as f:
+        return np.array([int(x) for x in f.read().split()], dtype=np.int64)
+
+
+def synth_mu_chains(seed, nchains=None):
+    """SCOP40-shaped synthetic Mu chains, sorted by length; ~10% are mutated copies (sub .3/ins .1/del .1,
+    cf. test_para.cpp:150-174) of another chain so that a realistic fraction of pairs scores high."""
+    rng = np.random.default_rng(seed)
+    lens = scop40_lengths()
+    if nchains is not None:
+        lens = lens[rng.choice(len(lens), nchains, replace=nchains > len(lens))]
+    p = MU_FREQ / MU_FREQ.sum()
+    seqs = [rng.choice(36, int(L), p=p).astype(np.uint8) for L in lens]
+    nhom = len(seqs) // 10
+    for k in rng.choice(len(seqs), nhom, replace=False):
+        src = seqs[int(rng.integers(0, len(seqs)))]
+        r = rng.random(len(src))
+        out = []
+        for c, u in zip(src, r):
+            if u < 0.1:
+                continue
+            if u < 0.2:
+                out.append(int(rng.integers(0, 36)))
+            out.append(int(rng.integers(0, 36)) if u < 0.5 else int(c))
+        L = len(seqs[k])
+        out = (out * (L // max(1, len(out)) + 1))[:L] if len(out) < L else out[:L]
+        seqs[k] = np.array(out, np.uint8)
+    order = np.argsort([len(s) for s in seqs], kind="stable")
+    return [seqs[i] for i in order]
+
+
+def cpu_baseline(seqs, seconds_target=15.0):
+    """Reference CPU kernels timed on this box's host cores on a bounded sample of the same pairs.
+    kind "reference": oracle/_ref/ref_harness (the unmodified reference objects, built from
+    /root/reference by oracle/Makefile.ref) runs SWFastPinopGapless on a strided sample of the
+    triangle; falls back to the C restatement ("port", 1 core) if that binary did not travel."""
+    cores = os.cpu_count() or 1
+    harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    if os.path.exists(harness):
+        with tempfile.TemporaryDirectory() as td:
+            fa = os.path.join(td, "bench.mu.fa")
+            with open(fa, "w") as f:
+                for i, s in enumerate(seqs):
+                    f.write(">c%d\n%s\n" % (i, "".join(MU_CHARS[c] for c in s)))
+            # ~0.12 Gcells/s/thread scalar: size the sample for ~seconds_target
+            mean_cells = float(np.mean([len(s) for s in seqs])) ** 2
+            npairs = int(max(2000, seconds_target * 0.12e9 * cores / mean_cells))
+            try:
+                out = subprocess.run([harness, "benchmu", fa, str(npairs), str(cores)], capture_output=True, text=True,
+                                     timeout=600, check=True).stdout.strip().splitlines()[-1]
+                r = json.loads(out)
+                return {"value": r["cells"] / r["gapless_secs"], "unit": "cells/s", "cores": cores, "kind": "reference",
+                        "sample": "%d pairs strided over the all-vs-all triangle (%.3g cells), SWFastPinopGapless "
+                                  "(swfastpinopgapless.cpp:6) via oracle/_ref/ref_harness, %d std::threads; same binary's "
+                                  "AVX2 parasail fwd filter: %.3g cells/s" % (r["pairs"], r["cells"], cores,
+                                                                              r["cells"] / r["parasail_fwd_secs"])}
+            except Exception as e:  # noqa: BLE001
+                sys.stderr.write("cpu_baseline: reference harness failed (%s); using the C port\n" % e)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    rng = np.random.default_rng(1)
+    n = len(seqs)
+    npairs = 20000
+    ia = rng.integers(0, n, npairs)
+    ib = rng.integers(0, n, npairs)
+    t0 = time.perf_counter()
+    ol.mu_gapless_pairs(seqs, ia, ib)
+    dt = time.perf_counter() - t0
+    cells = float(sum(len(seqs[a]) * len(seqs[b]) for a, b in zip(ia, ib)))
+    return {"value": cells / dt, "unit": "cells/s", "cores": 1, "kind": "port",
+            "sample": "%d random pairs (%.3g cells), oracle/rsk_oracle.c rsko_mu_gapless, 1 thread" % (npairs, cells)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--chains", type=int, default=0, help="0 = the full SCOP40-shaped set (11,211)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import reseek_amd
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (librsk has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    seqs = synth_mu_chains(0x5EED5EEC + rank, args.chains or None)
+    n = len(seqs)
+    stream = torch.cuda.current_stream()
+    ctx = reseek_amd.Ctx(local, stream=stream.cuda_stream)
+    db = reseek_amd.Db.from_mu_seqs(ctx, seqs)          # inputs resident in HBM before the timed region
+    out = torch.zeros((n, n), dtype=torch.int16, device="cuda")
+    summary = torch.zeros(2, dtype=torch.int64, device="cuda")
+
+    def step():
+        ctx.mu_gapless_matrix_dev(db, db, True, out.data_ptr(), n)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        # HIP events recorded by the library on this same stream around its launches
+    if dist is not None:
+        # hit summary exchange (the path's only collective): count of pairs >= 50 and a checksum
+        tri = torch.triu(out.to(torch.int64) & 0xFFFF)
+        summary[0] = (tri >= 50).sum()
+        summary[1] = tri.sum()
+        gathered = [torch.zeros_like(summary) for _ in range(world)]
+        dist.all_gather(gathered, summary)
+    barrier()
+    dt = time.perf_counter() - t0
+    # per-launch kernel time of the last step from the library's HIP events (same stream)
+    kernel_ms = ctx.last_kernel_ms()
+    pairs, cells, slots = ctx.mu_gapless_last_work()
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([float(cells), float(pairs)], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    dt = float(tmax.item())
+    total_cells, total_pairs = float(tot[0].item()), float(tot[1].item())
+
+    if rank == 0:
+        cells_per_s = total_cells * args.steps / dt
+        k_cells_per_s = cells / (kernel_ms * 1e-3)
+        nres = float(sum(len(s) for s in seqs))
+        # algorithmic HBM bytes per launch: (LA + LB + 8) per pair, score-only
+        alg_bytes = sum(len(s) * (n - i) for i, s in enumerate(seqs)) + \
+            float(np.cumsum([len(s) for s in seqs][::-1])[::-1].sum()) + 8.0 * pairs
+        res = {
+            "metric": "aligned cells/sec (SCOP40-shaped all-vs-all, gapless int Mu kernel)",
+            "value": cells_per_s, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int16", "data": "synthetic",
+            "chain_pairs_per_sec": total_pairs * args.steps / dt,
+            "config": {"workload": "BASELINE configs[1]: SCOP40-shaped (%d chains, %d residues per GPU) all-vs-all "
+                                   "i<=j, swgaplessint kernel only" % (n, int(nres)),
+                       "pairs_per_gpu": pairs, "cells_per_gpu": cells, "sharding": "one independent shard per GPU"},
+            "roofline": {
+                "bound": "valu", "kernel": "k_gapless_ring<8,16> (+<4,8>)",
+                "achieved": k_cells_per_s / 1e12, "peak": PEAK_VALU_LANEOPS / 1e12, "unit": "T lane-ops/s",
+                "frac": k_cells_per_s / PEAK_VALU_LANEOPS,
+                "note": "algorithmic work = 1 packed-int16 VALU lane-op per DP cell (v_pk_add_i16 clamp + v_pk_max_i16 "
+                        "per 2 cells); LDS 2 B/cell; kernel time from HIP events on the launch stream",
+                "kernel_ms": kernel_ms, "cell_slots_issued": slots, "slot_efficiency": cells / max(1, slots),
+                "hbm": {"bound": "hbm", "achieved": alg_bytes / (kernel_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
+                        "unit": "GB/s", "frac": alg_bytes / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                        "algorithmic_bytes": alg_bytes, "traffic": None},
+                "traffic": None},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(seqs)
+        print(json.dumps(res))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

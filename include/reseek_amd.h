@@ -1,0 +1,97 @@
+/* reseek_amd.h -- C-ABI of librsk.so: the MI355X (gfx950) implementation of reseek's -search hot path.
+ *
+ * The reference (rcedgar/reseek v2.8) has no plugin/FFI layer; its boundary for this path is the
+ * public surface of three C++ classes (DBSearcher dbsearcher.h:14, DSSAligner dssaligner.h:18,
+ * MuKmerFilter mukmerfilter.h:10) that work one pair at a time on caller-owned std::vectors.
+ * A GPU cannot be fed one pair at a time, so each entry point below is the *batch* form of one
+ * reference method: plain pointers + sizes in, plain arrays out, no C++/torch types.  The C++
+ * classes in reseek_amd/csrc/host/ keep the reference's names/signatures and forward to these
+ * calls (INTEGRATION.md shows the binding a reseek maintainer would add).
+ *
+ * Conventions
+ *   - every function returns RSK_OK (0) or a negative RSK_E_* code; rsk_last_error() gives text.
+ *     (The reference Die()s on error, myutils.cpp:785; a library must not exit the host process.)
+ *   - "d_" pointers are device (HBM) pointers owned by the caller (e.g. a torch tensor's
+ *     data_ptr); all other pointers are host memory.
+ *   - work is enqueued on the context's HIP stream (rsk_ctx_set_stream); functions that return
+ *     host data synchronise that stream, the *_dev forms do not.
+ *   - there is NO CPU fallback: without a usable gfx950 device rsk_ctx_create fails.
+ *   - file:line citations are relative to /root/reference/src.
+ */
+#ifndef RESEEK_AMD_H
+#define RESEEK_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RSK_OK 0
+#define RSK_E_INVALID (-1)   /* bad argument */
+#define RSK_E_DEVICE (-2)    /* HIP error / no gfx950 device */
+#define RSK_E_NOMEM (-3)
+#define RSK_E_RANGE (-4)     /* chain too long for the requested kernel */
+
+#define RSK_NFEAT 8          /* profile rows per chain: AA,NENDist,Conf,NENConf,RENDist,DstNxtHlx,StrandDens,NormDens
+                                (namedparams.cpp:36-43; summation order of SetSMx_NoRev dssaligner.cpp:529) */
+#define RSK_MU_ALPHA 36      /* Mu alphabet (dss.cpp:700) */
+#define RSK_NO_POS 0xFFFFFFFFu
+
+typedef struct rsk_ctx rsk_ctx;   /* one per process/GPU: device, stream, scratch */
+typedef struct rsk_db rsk_db;     /* a chain set resident in HBM as SoA */
+
+const char *rsk_version(void);
+const char *rsk_last_error(void);
+
+/* ---- context ------------------------------------------------------------------------------- */
+int rsk_ctx_create(int device, rsk_ctx **out);
+void rsk_ctx_destroy(rsk_ctx *ctx);
+/* hipStream_t to enqueue on (NULL = default stream).  Pass torch.cuda.current_stream().cuda_stream
+ * so torch events/timers see the kernels. */
+int rsk_ctx_set_stream(rsk_ctx *ctx, void *hip_stream);
+int rsk_ctx_sync(rsk_ctx *ctx);
+/* Average duration (ms) of the device work enqueued by the last compute call, measured with HIP
+ * events on the context stream; < 0 if none. */
+float rsk_ctx_last_kernel_ms(rsk_ctx *ctx);
+
+/* ---- chain set (replaces DBSearcher's in-RAM vectors m_DBChains/m_DBProfiles/m_DBMuLettersVec/
+ *      m_DBSelfRevScores, dbsearcher.h:26-33, filled by ProfileLoader::Load profileloader.cpp:73) --
+ * lengths[n]; mu = all chains' Mu letters back to back (sum L bytes, values 0..35);
+ * prof = per chain 8 rows x L bytes back to back (chain-major, feature-major inside a chain) or NULL;
+ * x,y,z = CA coordinates back to back (sum L floats each) or NULL; selfrev[n] or NULL (=> FLT_MAX).
+ * The data is copied to HBM (SoA, chains padded); host buffers may be freed afterwards. */
+int rsk_db_create(rsk_ctx *ctx, uint32_t nchains, const uint32_t *lengths, const uint8_t *mu,
+                  const uint8_t *prof, const float *x, const float *y, const float *z,
+                  const float *selfrev, rsk_db **out);
+void rsk_db_destroy(rsk_db *db);
+uint32_t rsk_db_nchains(const rsk_db *db);
+uint64_t rsk_db_nresidues(const rsk_db *db);
+uint64_t rsk_db_hbm_bytes(const rsk_db *db);
+
+/* ---- D1: gapless integer Mu score ------------------------------------------------------------
+ * Batch form of SWFastGapless_Int (swgaplessint.cpp:7) == SWFastPinopGapless
+ * (swfastpinopgapless.cpp:6): H(i,j) = max(0,H(i-1,j-1)) + IntScoreMx_Mu[a_i][b_j], best cell.
+ *
+ * Dense block: every query of q against every target of t -> d_scores[iq*ldo + it] (uint16,
+ * device memory, ldo >= nt).  With self_triangle != 0 (q == t, all-vs-all) only pairs the
+ * reference's RunSelf enumerates (it >= iq, runself.cpp:72-99) are guaranteed to be written;
+ * other cells may or may not be.  Asynchronous on the context stream.
+ * Chains longer than 16383 residues return RSK_E_RANGE. */
+int rsk_mu_gapless_matrix_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int self_triangle,
+                              uint16_t *d_scores, size_t ldo);
+/* Pair-list form with the position of the first strict maximum in row-major order (Besti/Bestj of
+ * SWFastGapless_Int; RSK_NO_POS when the score is 0).  besti/bestj may be NULL.  Synchronous. */
+int rsk_mu_gapless_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, const uint32_t *iq,
+                         const uint32_t *it, size_t npairs, int32_t *scores, uint32_t *besti,
+                         uint32_t *bestj);
+/* Work accounting for the last rsk_mu_gapless_matrix_dev call: real DP cells (sum LA*LB over the
+ * pairs the call is responsible for) and cell slots actually issued by the kernel (>= cells:
+ * ring padding, triangle overshoot). */
+int rsk_mu_gapless_last_work(rsk_ctx *ctx, uint64_t *pairs, uint64_t *cells, uint64_t *cell_slots);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

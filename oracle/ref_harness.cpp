@@ -23,6 +23,7 @@
 //   pairs    <in.bca> <out.bin> <maxchains>  [-- mode]
 //   mukat    <in.mu.fa> <first> <count> <out.bin>
 //   randkat  <seed> <npairs> <out.bin>
+//   benchmu  <in.mu.fa> <npairs> <threads>    (times the reference kernels; bench.py cpu_baseline)
 
 #include "myutils.h"
 #include "dss.h"
@@ -469,6 +470,96 @@ static void cmd_randkat(uint64_t Seed, uint NPairs, const string &OutFN)
 	fclose(f);
 	}
 
+// CPU baseline for bench.py: time the reference's own scalar/AVX2 kernels on the first
+// npairs pairs (row-major upper triangle order of RunSelf, runself.cpp:72-99) of a Mu FASTA.
+// Prints one JSON line: cells, seconds per kernel.
+#include <thread>
+#include <chrono>
+static void cmd_benchmu(const string &FaFN, uint64_t NPairs, uint Threads)
+	{
+	SeqDB DB;
+	DB.FromFasta(FaFN);
+	DB.ToLetters(g_CharToLetterMu);
+	const uint N = DB.GetSeqCount();
+	vector<vector<byte> > Seqs(N);
+	for (uint k = 0; k < N; ++k)
+		{
+		const string &S = DB.GetSeq(k);
+		Seqs[k].assign(S.begin(), S.end());
+		}
+	vector<pair<uint,uint> > Pairs;
+	for (uint i = 0; i < N && Pairs.size() < NPairs; ++i)
+		for (uint j = i; j < N && Pairs.size() < NPairs; ++j)
+			Pairs.push_back(make_pair(i, j));
+	// deterministic spread over the whole set: stride through the triangle instead of its first rows
+	uint64_t Total = uint64_t(N)*(N+1)/2;
+	if (Total > NPairs)
+		{
+		Pairs.clear();
+		uint64_t Step = Total/NPairs;
+		uint64_t Next = 0, Idx = 0;
+		for (uint i = 0; i < N && Pairs.size() < NPairs; ++i)
+			{
+			uint64_t RowLen = N - i;
+			while (Next < Idx + RowLen && Pairs.size() < NPairs)
+				{
+				Pairs.push_back(make_pair(i, uint(i + (Next - Idx))));
+				Next += Step;
+				}
+			Idx += RowLen;
+			}
+		}
+	double Cells = 0;
+	for (size_t p = 0; p < Pairs.size(); ++p)
+		Cells += double(Seqs[Pairs[p].first].size())*double(Seqs[Pairs[p].second].size());
+	double Secs[2] = {0, 0};
+	uint64_t Check[2] = {0, 0};
+	for (int Kernel = 0; Kernel < 2; ++Kernel)
+		{
+		vector<uint64_t> Sums(Threads, 0);
+		auto t0 = std::chrono::steady_clock::now();
+		vector<std::thread> ts;
+		for (uint T = 0; T < Threads; ++T)
+			ts.emplace_back([&, T]()
+				{
+				uint64_t Sum = 0;
+				uint PrevQ = UINT_MAX;
+				vector<const int8_t *> AP;
+				parasail_profile_t *Prof = 0;
+				for (size_t p = T; p < Pairs.size(); p += Threads)
+					{
+					const vector<byte> &A = Seqs[Pairs[p].first];
+					const vector<byte> &B = Seqs[Pairs[p].second];
+					if (Pairs[p].first != PrevQ)
+						{
+						PrevQ = Pairs[p].first;
+						AP.resize(A.size());
+						for (size_t k = 0; k < A.size(); ++k)
+							AP[k] = IntScoreMx_Mu[A[k]];
+						if (Prof) parasail_profile_free(Prof);
+						Prof = parasail_profile_create_avx_256_8((const char *) A.data(), (int) A.size(), &parasail_mu_matrix);
+						}
+					if (Kernel == 0)
+						Sum += SWFastPinopGapless(AP.data(), SIZE(A), (const int8_t *) B.data(), SIZE(B));
+					else
+						{
+						int Sat;
+						Sum += (uint64_t) ParaRaw(Prof, B, 2, 1, Sat);
+						}
+					}
+				if (Prof) parasail_profile_free(Prof);
+				Sums[T] = Sum;
+				});
+		for (auto &t : ts) t.join();
+		auto t1 = std::chrono::steady_clock::now();
+		Secs[Kernel] = std::chrono::duration<double>(t1 - t0).count();
+		for (uint T = 0; T < Threads; ++T) Check[Kernel] += Sums[T];
+		}
+	printf("{\"pairs\": %zu, \"cells\": %.0f, \"threads\": %u, \"gapless_secs\": %.4f, \"parasail_fwd_secs\": %.4f, "
+	  "\"gapless_checksum\": %llu, \"parasail_checksum\": %llu}\n",
+	  Pairs.size(), Cells, Threads, Secs[0], Secs[1], (unsigned long long) Check[0], (unsigned long long) Check[1]);
+	}
+
 int main(int argc, char **argv)
 	{
 	if (argc < 2)
@@ -498,6 +589,8 @@ int main(int argc, char **argv)
 		cmd_mukat(A[0], (uint) atoi(A[1].c_str()), (uint) atoi(A[2].c_str()), A[3]);
 	else if (Cmd == "randkat" && A.size() == 3)
 		cmd_randkat(strtoull(A[0].c_str(), 0, 0), (uint) atoi(A[1].c_str()), A[2]);
+	else if (Cmd == "benchmu" && A.size() == 3)
+		cmd_benchmu(A[0], strtoull(A[1].c_str(), 0, 0), (uint) atoi(A[2].c_str()));
 	else
 		{
 		fprintf(stderr, "bad subcommand/args\n");

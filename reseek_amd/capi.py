@@ -1,0 +1,151 @@
+"""ctypes binding of include/reseek_amd.h (librsk.so).  No compute happens in Python."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "librsk.so")
+
+_lib = None
+
+u8p = C.POINTER(C.c_uint8)
+u16p = C.POINTER(C.c_uint16)
+u32p = C.POINTER(C.c_uint32)
+i32p = C.POINTER(C.c_int32)
+u64p = C.POINTER(C.c_uint64)
+f32p = C.POINTER(C.c_float)
+
+# every symbol include/reseek_amd.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "rsk_version": (C.c_char_p, []),
+    "rsk_last_error": (C.c_char_p, []),
+    "rsk_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "rsk_ctx_destroy": (None, [C.c_void_p]),
+    "rsk_ctx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rsk_ctx_sync": (C.c_int, [C.c_void_p]),
+    "rsk_ctx_last_kernel_ms": (C.c_float, [C.c_void_p]),
+    "rsk_db_create": (C.c_int, [C.c_void_p, C.c_uint32, u32p, u8p, u8p, f32p, f32p, f32p, f32p, C.POINTER(C.c_void_p)]),
+    "rsk_db_destroy": (None, [C.c_void_p]),
+    "rsk_db_nchains": (C.c_uint32, [C.c_void_p]),
+    "rsk_db_nresidues": (C.c_uint64, [C.c_void_p]),
+    "rsk_db_hbm_bytes": (C.c_uint64, [C.c_void_p]),
+    "rsk_mu_gapless_matrix_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
+    "rsk_mu_gapless_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, u32p, u32p, C.c_size_t, i32p, u32p, u32p]),
+    "rsk_mu_gapless_last_work": (C.c_int, [C.c_void_p, u64p, u64p, u64p]),
+}
+
+
+class RskError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load librsk.so.  Raises if the HIP extension has not been built -- never falls back."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RskError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc --offload-arch=gfx950). reseek_amd has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise RskError(f"librsk error {rc}: {lib().rsk_last_error().decode()}")
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t) if a is not None else None
+
+
+class Ctx:
+    def __init__(self, device=0, stream=None):
+        h = C.c_void_p()
+        _check(lib().rsk_ctx_create(device, C.byref(h)))
+        self.h = h
+        if stream is not None:
+            self.set_stream(stream)
+
+    def set_stream(self, stream):
+        _check(lib().rsk_ctx_set_stream(self.h, C.c_void_p(stream)))
+
+    def sync(self):
+        _check(lib().rsk_ctx_sync(self.h))
+
+    def last_kernel_ms(self):
+        return lib().rsk_ctx_last_kernel_ms(self.h)
+
+    def close(self):
+        if self.h:
+            lib().rsk_ctx_destroy(self.h)
+            self.h = None
+
+    # ---- D1 gapless -------------------------------------------------------------------------
+    def mu_gapless_matrix_dev(self, q, t, self_triangle, d_scores_ptr, ldo):
+        _check(lib().rsk_mu_gapless_matrix_dev(self.h, q.h, t.h, int(self_triangle), C.c_void_p(d_scores_ptr), ldo))
+
+    def mu_gapless_pairs(self, q, t, iq, it, positions=False):
+        iq = np.ascontiguousarray(iq, np.uint32)
+        it = np.ascontiguousarray(it, np.uint32)
+        n = len(iq)
+        sc = np.zeros(n, np.int32)
+        bi = np.zeros(n, np.uint32) if positions else None
+        bj = np.zeros(n, np.uint32) if positions else None
+        _check(lib().rsk_mu_gapless_pairs(self.h, q.h, t.h, _p(iq, u32p), _p(it, u32p), n, _p(sc, i32p),
+                                          _p(bi, u32p), _p(bj, u32p)))
+        return (sc, bi, bj) if positions else sc
+
+    def mu_gapless_last_work(self):
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _check(lib().rsk_mu_gapless_last_work(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+
+class Db:
+    """A chain set uploaded to HBM (rsk_db)."""
+
+    def __init__(self, ctx, lengths, mu=None, prof=None, xyz=None, selfrev=None):
+        lengths = np.ascontiguousarray(lengths, np.uint32)
+        mu = None if mu is None else np.ascontiguousarray(mu, np.uint8)
+        prof = None if prof is None else np.ascontiguousarray(prof, np.uint8)
+        x = y = z = None
+        if xyz is not None:
+            x, y, z = (np.ascontiguousarray(a, np.float32) for a in xyz)
+        selfrev = None if selfrev is None else np.ascontiguousarray(selfrev, np.float32)
+        h = C.c_void_p()
+        _check(lib().rsk_db_create(ctx.h, len(lengths), _p(lengths, u32p), _p(mu, u8p), _p(prof, u8p),
+                                   _p(x, f32p), _p(y, f32p), _p(z, f32p), _p(selfrev, f32p), C.byref(h)))
+        self.h = h
+        self.ctx = ctx
+        self.lengths = lengths
+
+    @classmethod
+    def from_mu_seqs(cls, ctx, seqs):
+        lengths = np.array([len(s) for s in seqs], np.uint32)
+        return cls(ctx, lengths, mu=np.concatenate(seqs).astype(np.uint8))
+
+    @classmethod
+    def from_chains(cls, ctx, chains):
+        """chains: objects with .mu, .prof [8,L], .x/.y/.z, .selfrev (tests/fixtures.py Chain)."""
+        lengths = np.array([len(c.mu) for c in chains], np.uint32)
+        mu = np.concatenate([c.mu for c in chains])
+        prof = np.concatenate([np.ascontiguousarray(c.prof).reshape(-1) for c in chains])
+        xyz = tuple(np.concatenate([getattr(c, k) for c in chains]) for k in "xyz")
+        selfrev = np.array([c.selfrev for c in chains], np.float32)
+        return cls(ctx, lengths, mu=mu, prof=prof, xyz=xyz, selfrev=selfrev)
+
+    @property
+    def n(self):
+        return lib().rsk_db_nchains(self.h)
+
+    def close(self):
+        if self.h:
+            lib().rsk_db_destroy(self.h)
+            self.h = None

@@ -1,0 +1,444 @@
+// k_mu_gapless.hip -- gapless integer Mu-letter local score on gfx950.
+//
+// Reference semantics (bit-exact): SWFastGapless_Int swgaplessint.cpp:7 == SWFastPinopGapless
+// swfastpinopgapless.cpp:6:  x(i,j) = max(0, x(i-1,j-1)) + IntScoreMx_Mu[a_i][b_j], best = max x.
+// Because best starts at 0 and only x > 0 matters, H = max(0, H_prev + s) gives the same best.
+//
+// MI355X design ("ring" kernel; the path is VALU/LDS bound, there is no GEMM in it):
+//   * Every diagonal of a gapless DP is independent.  Several query chains are laid out, each
+//     preceded by one separator row, on a circular array ("ring") of P = 128*D row slots.  A wave
+//     holds the P running diagonal values as packed int16 pairs: lane l owns ring dwords
+//     w = 256*m + 4*l + i (m < D/4, i < 4), i.e. D VGPRs of state.
+//   * One wave walks ONE target chain; the target letter is wave-uniform (scalar loads), so the
+//     score row for that letter is read from an LDS-resident query profile with perfectly
+//     contiguous ds_read_b128 (no bank conflicts): prof[c][slot] = IntScoreMx_Mu[c][ring row].
+//   * Values live in a biased domain G = H - 32768: v_pk_add_i16 ... clamp is then both the add
+//     and the max(0, .) floor; separator rows / pad letters hold -32768 and reset a diagonal.
+//     v_pk_max_i16 tracks the best per ring slot.  => 2 packed VALU ops per 2 cells.
+//   * A diagonal moves one row per target letter.  Letters are processed in pairs: the second
+//     letter of a pair reads a copy of the profile shifted by one row (no data movement); after
+//     the pair every value moves up one dword = a register rename plus ONE v_mov_b32_dpp
+//     wave_ror:1 per 4 dwords.
+//   * Per target the per-slot bests are reduced per query (in-lane, then LDS atomic max), and the
+//     uint16 scores go to out[query][target].
+// A simple per-pair kernel covers chains too long for a ring and returns best-cell positions.
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "rsk_internal.h"
+#include "rsk_tables_data.h"
+
+typedef short v2s __attribute__((ext_vector_type(2)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+__device__ __constant__ signed char c_mu_int[36 * 36];
+static bool g_tables_uploaded[16] = { false };
+
+static int upload_tables(rsk_ctx *ctx)
+{
+    if (ctx->device < 16 && g_tables_uploaded[ctx->device]) return RSK_OK;
+    RSK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_mu_int), rsk_mu_int, sizeof(rsk_mu_int)));
+    if (ctx->device < 16) g_tables_uploaded[ctx->device] = true;
+    return RSK_OK;
+}
+
+#define FLOOR2 ((int) 0x80008000)
+#define FLOOR32 (-32768)
+#define RING_MAX_BLOCK 1024   // largest query block (1 + L rounded up to 8) that fits a D = 8 ring
+
+// ---------------------------------------------------------------------------------------------
+// host: pack queries onto rings
+// ---------------------------------------------------------------------------------------------
+static inline uint32_t qblock(uint32_t L) { return (1 + L + 7) / 8 * 8; }
+
+int rsk_build_rings(rsk_db *db)
+{
+    const uint32_t n = db->n;
+    std::vector<uint8_t> letters, laneq;
+    std::vector<uint32_t> qids;
+    std::vector<rsk_ring> rings;
+    db->long_q.clear();
+    uint32_t i = 0;
+    static const uint32_t Ds[2] = { 4, 8 };
+    while (i < n) {
+        if (qblock(db->len[i]) > RING_MAX_BLOCK) { db->long_q.push_back(i); ++i; continue; }
+        // choose the ring size with the best fill for the run of queries starting at i
+        uint32_t bestD = 0, bestCnt = 0;
+        double bestFill = -1;
+        for (uint32_t D : Ds) {
+            uint32_t cap = 128 * D, used = 0, cnt = 0;
+            uint64_t real = 0;
+            for (uint32_t j = i; j < n; ++j) {
+                uint32_t b = qblock(db->len[j]);
+                if (b > RING_MAX_BLOCK || used + b > cap) break;
+                used += b; real += db->len[j]; ++cnt;
+            }
+            if (cnt == 0) continue;
+            double fill = (double) real / cap;
+            if (fill >= bestFill) { bestFill = fill; bestD = D; bestCnt = cnt; }
+        }
+        rsk_ring r;
+        r.D = bestD;
+        r.nq = bestCnt;
+        r.min_q = i;
+        r.letters_off = (uint32_t) letters.size();
+        r.laneq_off = (uint32_t) laneq.size();
+        r.qid_off = (uint32_t) qids.size();
+        const uint32_t P = 128 * bestD;
+        letters.resize(letters.size() + P, 0xFF);
+        laneq.resize(laneq.size() + (bestD / 4) * 64, 0xFF);
+        uint8_t *rl = &letters[r.letters_off];
+        uint8_t *lq = &laneq[r.laneq_off];
+        uint32_t s = 0;
+        for (uint32_t k = 0; k < bestCnt; ++k) {
+            const uint32_t q = i + k, L = db->len[q], b = qblock(L);
+            memcpy(rl + s + 1, &db->h_mu[db->off[q]], L);     // slot s = separator, then the L rows
+            for (uint32_t g = s / 8; g < (s + b) / 8; ++g) lq[g] = (uint8_t) k;   // granule g = slots [8g, 8g+8)
+            qids.push_back(q);
+            s += b;
+        }
+        rings.push_back(r);
+        i += bestCnt;
+    }
+    // sort by D so each class is one launch
+    std::stable_sort(rings.begin(), rings.end(), [](const rsk_ring &a, const rsk_ring &b) { return a.D < b.D; });
+    db->rings = rings;
+    db->ring_slots_total = 0;
+    for (auto &r : rings) db->ring_slots_total += 128ull * r.D;
+    auto up = [&](void **d, const void *h, size_t bytes) -> int {
+        *d = nullptr;
+        if (!bytes) return RSK_OK;
+        RSK_HIP(hipMalloc(d, bytes));
+        RSK_HIP(hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice));
+        db->hbm_bytes += bytes;
+        return RSK_OK;
+    };
+    int rc;
+    if ((rc = up((void **) &db->d_ring_tab, rings.data(), rings.size() * sizeof(rsk_ring))) != RSK_OK) return rc;
+    if ((rc = up((void **) &db->d_ring_letters, letters.data(), letters.size())) != RSK_OK) return rc;
+    if ((rc = up((void **) &db->d_ring_laneq, laneq.data(), laneq.size())) != RSK_OK) return rc;
+    if ((rc = up((void **) &db->d_ring_qid, qids.data(), qids.size() * 4)) != RSK_OK) return rc;
+    db->rings_built = true;
+    return RSK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ring kernel
+// ---------------------------------------------------------------------------------------------
+template <int D> struct RingGeom {
+    static constexpr int P = 128 * D;          // row slots on the ring
+    static constexpr int RSB = 2 * P;          // bytes per profile row
+    static constexpr int NROWS = 37;           // 36 letters + the pad letter (all -32768)
+    static constexpr int PROF_BYTES = NROWS * RSB;
+    static constexpr int NQMAX = P / 8;        // a query block is >= 8 slots
+    static constexpr int M = D / 4;            // b128 groups per lane
+};
+
+template <int D, int NW> constexpr size_t ring_lds_bytes()
+{
+    return 2 * (size_t) RingGeom<D>::PROF_BYTES + (size_t) NW * RingGeom<D>::NQMAX * 4 + 1312 + RingGeom<D>::P;
+}
+
+__device__ __forceinline__ int pk_addsat(int a, int b)
+{
+    return __builtin_bit_cast(int, __builtin_elementwise_add_sat(__builtin_bit_cast(v2s, a), __builtin_bit_cast(v2s, b)));
+}
+__device__ __forceinline__ int pk_max(int a, int b)
+{
+    return __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(v2s, a), __builtin_bit_cast(v2s, b)));
+}
+__device__ __forceinline__ int dpp_wave_ror1(int x)
+{
+    return __builtin_amdgcn_update_dpp(x, x, 0x13C /* wave_ror:1 */, 0xF, 0xF, false);
+}
+
+// One pair of target letters (c0, c1) with compile-time rotation state R (0..3).
+// Logical dword i of group m lives in physical register G[m][(i - R) & 3].
+template <int D, int R>
+__device__ __forceinline__ void ring_pairstep(int (&G)[D / 4][4], int (&E)[D / 4][4], int (&O)[D / 4][4],
+                                              const char *lane_p1, const char *lane_p2, unsigned c0, unsigned c1,
+                                              bool lane0)
+{
+    constexpr int M = D / 4;
+    constexpr int RSB = RingGeom<D>::RSB;
+    v4i S[M], T[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        S[m] = *(const v4i *) (lane_p1 + c0 * RSB + m * 1024);
+        T[m] = *(const v4i *) (lane_p2 + c1 * RSB + m * 1024);
+    }
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = (i - R) & 3;
+            G[m][p] = pk_addsat(G[m][p], S[m][i]);
+            E[m][i] = pk_max(E[m][i], G[m][p]);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = (i - R) & 3;
+            G[m][p] = pk_addsat(G[m][p], T[m][i]);
+            O[m][i] = pk_max(O[m][i], G[m][p]);
+        }
+    }
+    // every value moves up one ring dword: logical 3 of each group crosses to the next lane
+    constexpr int p3 = (3 - R) & 3;
+    int r[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) r[m] = dpp_wave_ror1(G[m][p3]);
+    if (M == 1) {
+        G[0][p3] = r[0];
+    } else {
+        // lane 0 receives lane 63's value of the PREVIOUS group (ring dword 256*m - 1)
+#pragma unroll
+        for (int m = 0; m < M; ++m) G[m][p3] = lane0 ? r[(m + M - 1) % M] : r[m];
+    }
+}
+
+template <int D, int NW>
+__global__ __launch_bounds__(64 * NW) void k_gapless_ring(const rsk_ring *__restrict__ rings,
+                                                          const uint8_t *__restrict__ ring_letters,
+                                                          const uint8_t *__restrict__ ring_laneq,
+                                                          const uint32_t *__restrict__ ring_qid,
+                                                          const uint8_t *__restrict__ t_mu,
+                                                          const uint32_t *__restrict__ t_off,
+                                                          const uint32_t *__restrict__ t_len, uint32_t nt,
+                                                          uint32_t tb_size, int self_triangle,
+                                                          uint16_t *__restrict__ out, size_t ldo)
+{
+    typedef RingGeom<D> Gm;
+    constexpr int P = Gm::P, RSB = Gm::RSB, NQMAX = Gm::NQMAX, M = Gm::M;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    short *prof1 = (short *) smem;
+    short *prof2 = (short *) (smem + Gm::PROF_BYTES);
+    int *res = (int *) (smem + 2 * Gm::PROF_BYTES);
+    signed char *mat = (signed char *) (res + NW * NQMAX);
+    unsigned char *rl = (unsigned char *) (mat + 1312);
+
+    const int tid = threadIdx.x;
+    const int nthreads = 64 * NW;
+    const rsk_ring rg = rings[blockIdx.y];
+    const uint32_t t0 = blockIdx.x * tb_size;
+    const uint32_t t1 = min(nt, t0 + tb_size);
+    if (self_triangle && t1 <= rg.min_q) return;
+
+    for (int i = tid; i < 1296; i += nthreads) mat[i] = c_mu_int[i];
+    for (int i = tid; i < P; i += nthreads) rl[i] = ring_letters[rg.letters_off + i];
+    for (int i = tid; i < NW * NQMAX; i += nthreads) res[i] = FLOOR32;
+    __syncthreads();
+    // build both profile copies, 8 slots (16 bytes) per store
+    for (int idx = tid; idx < Gm::NROWS * (P / 8); idx += nthreads) {
+        const int c = idx / (P / 8), g = idx - c * (P / 8);
+        short v1[8], v2[8];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int s = (8 * g + k) & (P - 1);
+            const unsigned l = rl[s];
+            const short v = (c == 36 || l == 0xFF) ? (short) -32768 : (short) mat[c * 36 + l];
+            if (k < 8) v1[k] = v;
+            if (k > 0) v2[k - 1] = v;
+        }
+        *(v4i *) (prof1 + (size_t) c * P + 8 * g) = *(const v4i *) v1;
+        *(v4i *) (prof2 + (size_t) c * P + 8 * g) = *(const v4i *) v2;
+    }
+    __syncthreads();
+
+    const int wave = tid >> 6, lane = tid & 63;
+    const bool lane0 = (lane == 0);
+    const char *lane_p1 = (const char *) prof1 + lane * 16;
+    const char *lane_p2 = (const char *) prof2 + lane * 16;
+    int *wres = res + wave * NQMAX;
+    int lq[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) lq[m] = ring_laneq[rg.laneq_off + m * 64 + lane];
+
+    for (uint32_t t = t0 + wave; t < t1; t += NW) {
+        if (self_triangle && t < rg.min_q) continue;
+        const uint32_t toff = __builtin_amdgcn_readfirstlane(t_off[t]);
+        const uint32_t tlen = __builtin_amdgcn_readfirstlane(t_len[t]);
+        const uint2 *lp = (const uint2 *) (t_mu + toff);
+        const uint32_t nch = (tlen + 7) >> 3;
+        int G[M][4], E[M][4], O[M][4];
+#pragma unroll
+        for (int m = 0; m < M; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { G[m][i] = FLOOR2; E[m][i] = FLOOR2; O[m][i] = FLOOR2; }
+        uint2 L = lp[0];
+        for (uint32_t ch = 0; ch < nch; ++ch) {
+            const uint2 Lc = L;
+            L = lp[ch + 1];   // prefetch (the chain set has >= 64 bytes of tail padding)
+            ring_pairstep<D, 0>(G, E, O, lane_p1, lane_p2, Lc.x & 0xFF, (Lc.x >> 8) & 0xFF, lane0);
+            ring_pairstep<D, 1>(G, E, O, lane_p1, lane_p2, (Lc.x >> 16) & 0xFF, Lc.x >> 24, lane0);
+            ring_pairstep<D, 2>(G, E, O, lane_p1, lane_p2, Lc.y & 0xFF, (Lc.y >> 8) & 0xFF, lane0);
+            ring_pairstep<D, 3>(G, E, O, lane_p1, lane_p2, (Lc.y >> 16) & 0xFF, Lc.y >> 24, lane0);
+        }
+        // per-query reduction
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            int b = pk_max(pk_max(E[m][0], E[m][1]), pk_max(E[m][2], E[m][3]));
+            b = pk_max(b, pk_max(pk_max(O[m][0], O[m][1]), pk_max(O[m][2], O[m][3])));
+            const int lo = (int) (short) (b & 0xFFFF), hi = b >> 16;
+            const int v = max(lo, hi);
+            if (lq[m] != 0xFF) atomicMax(&wres[lq[m]], v);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        for (uint32_t k = lane; k < rg.nq; k += 64) {
+            const int v = wres[k];
+            wres[k] = FLOOR32;
+            out[(size_t) ring_qid[rg.qid_off + k] * ldo + t] = (uint16_t) (v + 32768);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-pair kernel: one wave per pair, lanes stride over the LA+LB-1 diagonals.  Any length; also
+// returns the first strict maximum in row-major order (Besti/Bestj of SWFastGapless_Int).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gapless_pairs(const uint8_t *__restrict__ q_mu, const uint32_t *__restrict__ q_off,
+                                                       const uint32_t *__restrict__ q_len,
+                                                       const uint8_t *__restrict__ t_mu, const uint32_t *__restrict__ t_off,
+                                                       const uint32_t *__restrict__ t_len,
+                                                       const uint32_t *__restrict__ iq, const uint32_t *__restrict__ it,
+                                                       uint32_t npairs, int32_t *__restrict__ scores,
+                                                       uint32_t *__restrict__ besti, uint32_t *__restrict__ bestj,
+                                                       uint16_t *__restrict__ out16, size_t ldo)
+{
+    __shared__ signed char mat[1296];
+    for (int i = threadIdx.x; i < 1296; i += blockDim.x) mat[i] = c_mu_int[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const uint32_t p = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (p >= npairs) return;
+    const uint32_t a = iq[p], b = it[p];
+    const uint8_t *A = q_mu + q_off[a];
+    const uint8_t *B = t_mu + t_off[b];
+    const int LA = (int) q_len[a], LB = (int) t_len[b];
+    unsigned long long best = 0;   // (score << 48) | (0xFFFFFF - i) << 24 | (0xFFFFFF - j)
+    const int ndiag = LA + LB - 1;
+    for (int d = lane; d < ndiag; d += 64) {
+        int i = d < LB ? 0 : d - LB + 1;
+        int j = d < LB ? LB - 1 - d : 0;
+        int x = 0;
+        for (; i < LA && j < LB; ++i, ++j) {
+            x = max(x, 0) + mat[A[i] * 36 + B[j]];
+            if (x > 0) {
+                const unsigned long long key = ((unsigned long long) x << 48) | ((unsigned long long) (0xFFFFFF - i) << 24) |
+                                               (unsigned long long) (0xFFFFFF - j);
+                if (key > best) best = key;
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        const unsigned long long o = __shfl_xor(best, s, 64);
+        if (o > best) best = o;
+    }
+    if (lane == 0) {
+        const int sc = (int) (best >> 48);
+        if (scores) scores[p] = sc;
+        if (besti) besti[p] = sc ? (uint32_t) (0xFFFFFF - ((best >> 24) & 0xFFFFFF)) : RSK_NO_POS;
+        if (bestj) bestj[p] = sc ? (uint32_t) (0xFFFFFF - (best & 0xFFFFFF)) : RSK_NO_POS;
+        if (out16) out16[(size_t) a * ldo + b] = (uint16_t) min(sc, 65535);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+template <int D, int NW>
+static int launch_ring_class(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, uint32_t first, uint32_t count,
+                             int self_triangle, uint16_t *d_scores, size_t ldo, uint32_t tb_size)
+{
+    if (count == 0) return RSK_OK;
+    constexpr size_t lds = ring_lds_bytes<D, NW>();
+    static bool attr_set = false;
+    if (!attr_set) {
+        RSK_HIP(hipFuncSetAttribute((const void *) k_gapless_ring<D, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+        attr_set = true;
+    }
+    dim3 grid((t->n + tb_size - 1) / tb_size, count);
+    hipLaunchKernelGGL((k_gapless_ring<D, NW>), grid, dim3(64 * NW), lds, ctx->stream, q->d_ring_tab + first,
+                       q->d_ring_letters, q->d_ring_laneq, q->d_ring_qid, t->d_mu, t->d_off, t->d_len, t->n, tb_size,
+                       self_triangle, d_scores, ldo);
+    RSK_HIP(hipGetLastError());
+    return RSK_OK;
+}
+
+int rsk_launch_gapless_rings(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int self_triangle,
+                             uint16_t *d_scores, size_t ldo)
+{
+    int rc = upload_tables(ctx);
+    if (rc != RSK_OK) return rc;
+    // work accounting (host side, O(rings))
+    std::vector<uint64_t> pre_len(t->n + 1, 0), pre_slots(t->n + 1, 0);
+    for (uint32_t i = 0; i < t->n; ++i) {
+        pre_len[i + 1] = pre_len[i] + t->len[i];
+        pre_slots[i + 1] = pre_slots[i] + (uint64_t) ((t->len[i] + 7) / 8 * 8);
+    }
+    uint64_t pairs = 0, cells = 0, slots = 0;
+    for (uint32_t i = 0; i < q->n; ++i) {
+        const uint32_t ts = self_triangle ? i : 0;
+        pairs += t->n - ts;
+        cells += (uint64_t) q->len[i] * (pre_len[t->n] - pre_len[ts]);
+    }
+    uint32_t nD4 = 0, nD8 = 0;
+    for (auto &r : q->rings) {
+        (r.D == 4 ? nD4 : nD8)++;
+        const uint32_t ts = self_triangle ? r.min_q : 0;
+        slots += 128ull * r.D * (pre_slots[t->n] - pre_slots[ts]);
+    }
+    for (uint32_t lqi : q->long_q) {
+        const uint32_t ts = self_triangle ? lqi : 0;
+        slots += (uint64_t) q->len[lqi] * (pre_len[t->n] - pre_len[ts]);
+    }
+    ctx->gl_pairs = pairs; ctx->gl_cells = cells; ctx->gl_slots = slots;
+
+    RSK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    rc = launch_ring_class<4, 8>(ctx, q, t, 0, nD4, self_triangle, d_scores, ldo, 128);
+    if (rc != RSK_OK) return rc;
+    rc = launch_ring_class<8, 16>(ctx, q, t, nD4, nD8, self_triangle, d_scores, ldo, 256);
+    if (rc != RSK_OK) return rc;
+    // queries too long for a ring: per-pair kernel over (long q) x targets
+    if (!q->long_q.empty()) {
+        std::vector<uint32_t> iq, it;
+        for (uint32_t lqi : q->long_q)
+            for (uint32_t j = self_triangle ? lqi : 0; j < t->n; ++j) { iq.push_back(lqi); it.push_back(j); }
+        uint32_t *d_iq = nullptr, *d_it = nullptr;
+        RSK_HIP(hipMalloc((void **) &d_iq, iq.size() * 4));
+        RSK_HIP(hipMalloc((void **) &d_it, it.size() * 4));
+        RSK_HIP(hipMemcpyAsync(d_iq, iq.data(), iq.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        RSK_HIP(hipMemcpyAsync(d_it, it.data(), it.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        const uint32_t np = (uint32_t) iq.size();
+        hipLaunchKernelGGL(k_gapless_pairs, dim3((np + 3) / 4), dim3(256), 0, ctx->stream, q->d_mu, q->d_off, q->d_len,
+                           t->d_mu, t->d_off, t->d_len, d_iq, d_it, np, (int32_t *) nullptr, (uint32_t *) nullptr,
+                           (uint32_t *) nullptr, d_scores, ldo);
+        RSK_HIP(hipGetLastError());
+        RSK_HIP(hipStreamSynchronize(ctx->stream));   // host vectors / temp buffers must outlive the copies
+        (void) hipFree(d_iq);
+        (void) hipFree(d_it);
+    }
+    RSK_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    return RSK_OK;
+}
+
+int rsk_launch_gapless_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, const uint32_t *d_iq,
+                             const uint32_t *d_it, size_t npairs, int32_t *d_scores, uint32_t *d_besti,
+                             uint32_t *d_bestj)
+{
+    int rc = upload_tables(ctx);
+    if (rc != RSK_OK) return rc;
+    RSK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    hipLaunchKernelGGL(k_gapless_pairs, dim3((unsigned) ((npairs + 3) / 4)), dim3(256), 0, ctx->stream, q->d_mu, q->d_off,
+                       q->d_len, t->d_mu, t->d_off, t->d_len, d_iq, d_it, (uint32_t) npairs, d_scores, d_besti, d_bestj,
+                       (uint16_t *) nullptr, (size_t) 0);
+    RSK_HIP(hipGetLastError());
+    RSK_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    return RSK_OK;
+}

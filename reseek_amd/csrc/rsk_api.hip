@@ -1,0 +1,242 @@
+// rsk_api.hip -- host side of the C-ABI (include/reseek_amd.h): context, HBM chain sets.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <cfloat>
+
+#include "rsk_internal.h"
+
+static thread_local char g_err[512] = "";
+
+void rsk_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int rsk_hip_fail(hipError_t e, const char *what, const char *file, int line)
+{
+    rsk_set_error("HIP error %d (%s) at %s:%d in %s", (int) e, hipGetErrorString(e), file, line, what);
+    return RSK_E_DEVICE;
+}
+
+extern "C" const char *rsk_version(void) { return "reseek_amd 0.1 (gfx950)"; }
+extern "C" const char *rsk_last_error(void) { return g_err; }
+
+extern "C" int rsk_ctx_create(int device, rsk_ctx **out)
+{
+    if (!out) { rsk_set_error("rsk_ctx_create: out is NULL"); return RSK_E_INVALID; }
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        rsk_set_error("rsk_ctx_create: no HIP device available (librsk has no CPU fallback)");
+        return RSK_E_DEVICE;
+    }
+    if (device < 0 || device >= ndev) { rsk_set_error("rsk_ctx_create: device %d out of range", device); return RSK_E_INVALID; }
+    RSK_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    RSK_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        rsk_set_error("rsk_ctx_create: device %d is %s; librsk is built for gfx950 only", device, prop.gcnArchName);
+        return RSK_E_DEVICE;
+    }
+    rsk_ctx *c = new rsk_ctx;
+    c->device = device;
+    c->num_cus = prop.multiProcessorCount;
+    RSK_HIP(hipEventCreate(&c->ev0));
+    RSK_HIP(hipEventCreate(&c->ev1));
+    *out = c;
+    return RSK_OK;
+}
+
+extern "C" void rsk_ctx_destroy(rsk_ctx *ctx)
+{
+    if (!ctx) return;
+    if (ctx->ev0) (void) hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void) hipEventDestroy(ctx->ev1);
+    delete ctx;
+}
+
+extern "C" int rsk_ctx_set_stream(rsk_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) { rsk_set_error("rsk_ctx_set_stream: ctx is NULL"); return RSK_E_INVALID; }
+    ctx->stream = (hipStream_t) hip_stream;
+    return RSK_OK;
+}
+
+extern "C" int rsk_ctx_sync(rsk_ctx *ctx)
+{
+    if (!ctx) { rsk_set_error("rsk_ctx_sync: ctx is NULL"); return RSK_E_INVALID; }
+    RSK_HIP(hipStreamSynchronize(ctx->stream));
+    return RSK_OK;
+}
+
+extern "C" float rsk_ctx_last_kernel_ms(rsk_ctx *ctx)
+{
+    if (!ctx || !ctx->ev0) return -1.0f;
+    if (hipEventSynchronize(ctx->ev1) != hipSuccess) return -1.0f;
+    float ms = -1.0f;
+    if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) != hipSuccess) return -1.0f;
+    return ms;
+}
+
+template <class T>
+static int dev_upload(T **d, const T *h, size_t count, uint64_t &bytes)
+{
+    *d = nullptr;
+    if (count == 0) return RSK_OK;
+    RSK_HIP(hipMalloc((void **) d, count * sizeof(T)));
+    RSK_HIP(hipMemcpy(*d, h, count * sizeof(T), hipMemcpyHostToDevice));
+    bytes += count * sizeof(T);
+    return RSK_OK;
+}
+
+extern "C" int rsk_db_create(rsk_ctx *ctx, uint32_t n, const uint32_t *lengths, const uint8_t *mu,
+                             const uint8_t *prof, const float *x, const float *y, const float *z,
+                             const float *selfrev, rsk_db **out)
+{
+    if (!ctx || !out || (n && !lengths)) { rsk_set_error("rsk_db_create: NULL argument"); return RSK_E_INVALID; }
+    *out = nullptr;
+    if ((x || y || z) && !(x && y && z)) { rsk_set_error("rsk_db_create: x,y,z must be given together"); return RSK_E_INVALID; }
+    RSK_HIP(hipSetDevice(ctx->device));
+    rsk_db *db = new rsk_db;
+    db->ctx = ctx;
+    db->n = n;
+    db->len.assign(lengths, lengths + n);
+    db->off.resize((size_t) n + 1);
+    uint64_t o = 0, nres = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (lengths[i] == 0 || lengths[i] >= 65535) {   // uint16 positions, mukmerfilter.cpp:211
+            rsk_set_error("rsk_db_create: chain %u has length %u (must be 1..65534)", i, lengths[i]);
+            delete db;
+            return RSK_E_RANGE;
+        }
+        db->off[i] = (uint32_t) o;
+        o += (lengths[i] + RSK_CHAIN_PAD - 1) / RSK_CHAIN_PAD * RSK_CHAIN_PAD;
+        nres += lengths[i];
+        if (o >= 0xFFFF0000ull) { rsk_set_error("rsk_db_create: chain set too large for 32-bit offsets"); delete db; return RSK_E_RANGE; }
+    }
+    db->off[n] = (uint32_t) o;
+    db->nres = nres;
+    db->npad = o;
+    int rc;
+    if ((rc = dev_upload(&db->d_len, db->len.data(), n, db->hbm_bytes)) != RSK_OK) return rc;
+    if ((rc = dev_upload(&db->d_off, db->off.data(), (size_t) n + 1, db->hbm_bytes)) != RSK_OK) return rc;
+    if (mu) {
+        db->h_mu.assign((size_t) o + 64, (uint8_t) RSK_MU_NULL);
+        uint64_t src = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            for (uint32_t k = 0; k < lengths[i]; ++k) {
+                uint8_t c = mu[src + k];
+                if (c >= RSK_MU_ALPHA) { rsk_set_error("rsk_db_create: Mu letter %u out of range in chain %u", c, i); delete db; return RSK_E_INVALID; }
+                db->h_mu[db->off[i] + k] = c;
+            }
+            src += lengths[i];
+        }
+        if ((rc = dev_upload(&db->d_mu, db->h_mu.data(), db->h_mu.size(), db->hbm_bytes)) != RSK_OK) return rc;
+    }
+    if (prof) {
+        std::vector<uint8_t> hp((size_t) RSK_NFEAT * o, 0);
+        uint64_t src = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            for (int f = 0; f < RSK_NFEAT; ++f)
+                memcpy(&hp[(size_t) f * o + db->off[i]], prof + src + (size_t) f * lengths[i], lengths[i]);
+            src += (uint64_t) RSK_NFEAT * lengths[i];
+        }
+        if ((rc = dev_upload(&db->d_prof, hp.data(), hp.size(), db->hbm_bytes)) != RSK_OK) return rc;
+    }
+    if (x) {
+        std::vector<float> hx((size_t) o, 0.f), hy((size_t) o, 0.f), hz((size_t) o, 0.f);
+        uint64_t src = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            memcpy(&hx[db->off[i]], x + src, 4 * (size_t) lengths[i]);
+            memcpy(&hy[db->off[i]], y + src, 4 * (size_t) lengths[i]);
+            memcpy(&hz[db->off[i]], z + src, 4 * (size_t) lengths[i]);
+            src += lengths[i];
+        }
+        if ((rc = dev_upload(&db->d_x, hx.data(), hx.size(), db->hbm_bytes)) != RSK_OK) return rc;
+        if ((rc = dev_upload(&db->d_y, hy.data(), hy.size(), db->hbm_bytes)) != RSK_OK) return rc;
+        if ((rc = dev_upload(&db->d_z, hz.data(), hz.size(), db->hbm_bytes)) != RSK_OK) return rc;
+    }
+    {
+        std::vector<float> sr(n, FLT_MAX);
+        if (selfrev) sr.assign(selfrev, selfrev + n);
+        if ((rc = dev_upload(&db->d_selfrev, sr.data(), n, db->hbm_bytes)) != RSK_OK) return rc;
+    }
+    *out = db;
+    return RSK_OK;
+}
+
+extern "C" void rsk_db_destroy(rsk_db *db)
+{
+    if (!db) return;
+    void *ptrs[] = { db->d_len, db->d_off, db->d_mu, db->d_prof, db->d_x, db->d_y, db->d_z, db->d_selfrev,
+                     db->d_ring_tab, db->d_ring_letters, db->d_ring_laneq, db->d_ring_qid };
+    for (void *p : ptrs)
+        if (p) (void) hipFree(p);
+    delete db;
+}
+
+extern "C" uint32_t rsk_db_nchains(const rsk_db *db) { return db ? db->n : 0; }
+extern "C" uint64_t rsk_db_nresidues(const rsk_db *db) { return db ? db->nres : 0; }
+extern "C" uint64_t rsk_db_hbm_bytes(const rsk_db *db) { return db ? db->hbm_bytes : 0; }
+
+// ---- D1 gapless -----------------------------------------------------------------------------
+
+extern "C" int rsk_mu_gapless_matrix_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int self_triangle,
+                                         uint16_t *d_scores, size_t ldo)
+{
+    if (!ctx || !q || !t || !d_scores) { rsk_set_error("rsk_mu_gapless_matrix_dev: NULL argument"); return RSK_E_INVALID; }
+    if (!q->d_mu || !t->d_mu) { rsk_set_error("rsk_mu_gapless_matrix_dev: chain set has no Mu letters"); return RSK_E_INVALID; }
+    if (ldo < t->n) { rsk_set_error("rsk_mu_gapless_matrix_dev: ldo < number of targets"); return RSK_E_INVALID; }
+    if (self_triangle && q != t) { rsk_set_error("rsk_mu_gapless_matrix_dev: self_triangle needs q == t"); return RSK_E_INVALID; }
+    RSK_HIP(hipSetDevice(ctx->device));
+    if (!q->rings_built) {
+        int rc = rsk_build_rings(const_cast<rsk_db *>(q));
+        if (rc != RSK_OK) return rc;
+    }
+    return rsk_launch_gapless_rings(ctx, q, t, self_triangle, d_scores, ldo);
+}
+
+extern "C" int rsk_mu_gapless_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, const uint32_t *iq,
+                                    const uint32_t *it, size_t npairs, int32_t *scores, uint32_t *besti,
+                                    uint32_t *bestj)
+{
+    if (!ctx || !q || !t || (npairs && (!iq || !it || !scores))) { rsk_set_error("rsk_mu_gapless_pairs: NULL argument"); return RSK_E_INVALID; }
+    if (!q->d_mu || !t->d_mu) { rsk_set_error("rsk_mu_gapless_pairs: chain set has no Mu letters"); return RSK_E_INVALID; }
+    for (size_t p = 0; p < npairs; ++p)
+        if (iq[p] >= q->n || it[p] >= t->n) { rsk_set_error("rsk_mu_gapless_pairs: pair %zu out of range", p); return RSK_E_INVALID; }
+    if (npairs == 0) return RSK_OK;
+    RSK_HIP(hipSetDevice(ctx->device));
+    uint32_t *d_iq = nullptr, *d_it = nullptr, *d_bi = nullptr, *d_bj = nullptr;
+    int32_t *d_sc = nullptr;
+    RSK_HIP(hipMalloc((void **) &d_iq, npairs * 4));
+    RSK_HIP(hipMalloc((void **) &d_it, npairs * 4));
+    RSK_HIP(hipMalloc((void **) &d_sc, npairs * 4));
+    RSK_HIP(hipMalloc((void **) &d_bi, npairs * 4));
+    RSK_HIP(hipMalloc((void **) &d_bj, npairs * 4));
+    RSK_HIP(hipMemcpyAsync(d_iq, iq, npairs * 4, hipMemcpyHostToDevice, ctx->stream));
+    RSK_HIP(hipMemcpyAsync(d_it, it, npairs * 4, hipMemcpyHostToDevice, ctx->stream));
+    int rc = rsk_launch_gapless_pairs(ctx, q, t, d_iq, d_it, npairs, d_sc, d_bi, d_bj);
+    if (rc == RSK_OK) {
+        RSK_HIP(hipMemcpyAsync(scores, d_sc, npairs * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (besti) RSK_HIP(hipMemcpyAsync(besti, d_bi, npairs * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (bestj) RSK_HIP(hipMemcpyAsync(bestj, d_bj, npairs * 4, hipMemcpyDeviceToHost, ctx->stream));
+        RSK_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    (void) hipFree(d_iq); (void) hipFree(d_it); (void) hipFree(d_sc); (void) hipFree(d_bi); (void) hipFree(d_bj);
+    return rc;
+}
+
+extern "C" int rsk_mu_gapless_last_work(rsk_ctx *ctx, uint64_t *pairs, uint64_t *cells, uint64_t *cell_slots)
+{
+    if (!ctx) { rsk_set_error("rsk_mu_gapless_last_work: ctx is NULL"); return RSK_E_INVALID; }
+    if (pairs) *pairs = ctx->gl_pairs;
+    if (cells) *cells = ctx->gl_cells;
+    if (cell_slots) *cell_slots = ctx->gl_slots;
+    return RSK_OK;
+}

@@ -1,0 +1,76 @@
+// rsk_internal.h -- shared host-side definitions of librsk.so (not part of the C-ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/reseek_amd.h"
+
+#define RSK_MU_NULL 36          // pad letter: its profile row resets every diagonal (score -32768)
+#define RSK_CHAIN_PAD 16        // chains are padded to a multiple of 16 residues in HBM
+
+void rsk_set_error(const char *fmt, ...);
+int rsk_hip_fail(hipError_t e, const char *what, const char *file, int line);
+
+#define RSK_HIP(call)                                                          \
+    do {                                                                       \
+        hipError_t e_ = (call);                                                \
+        if (e_ != hipSuccess) return rsk_hip_fail(e_, #call, __FILE__, __LINE__); \
+    } while (0)
+
+struct rsk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float last_ms = -1.0f;
+    // accounting of the last gapless matrix call
+    uint64_t gl_pairs = 0, gl_cells = 0, gl_slots = 0;
+    int num_cus = 0;
+};
+
+// One "ring" of the gapless kernel: several query chains laid out on a circular array of
+// 128*D diagonal slots (see k_mu_gapless.hip).
+struct rsk_ring {
+    uint32_t D;            // dwords of diagonal state per lane (ring = 128*D slots)
+    uint32_t nq;           // queries in the ring
+    uint32_t min_q;        // smallest query index (triangle skipping)
+    uint32_t letters_off;  // byte offset into d_ring_letters (128*D bytes; 0xFF = separator row)
+    uint32_t laneq_off;    // offset into d_ring_laneq ((D/4)*64 bytes: local query of each lane group; 0xFF none)
+    uint32_t qid_off;      // offset into d_ring_qid (nq uint32: global query index)
+};
+
+struct rsk_db {
+    rsk_ctx *ctx = nullptr;
+    uint32_t n = 0;
+    uint64_t nres = 0;         // sum of lengths
+    uint64_t npad = 0;         // sum of padded lengths
+    std::vector<uint32_t> len; // host copies
+    std::vector<uint32_t> off; // n+1 padded residue offsets
+    std::vector<uint8_t> h_mu; // padded host copy (ring construction)
+    uint32_t *d_len = nullptr;
+    uint32_t *d_off = nullptr;
+    uint8_t *d_mu = nullptr;   // npad bytes, pad = RSK_MU_NULL
+    uint8_t *d_prof = nullptr; // [RSK_NFEAT][npad]
+    float *d_x = nullptr, *d_y = nullptr, *d_z = nullptr;
+    float *d_selfrev = nullptr;
+    uint64_t hbm_bytes = 0;
+    // gapless ring cache (built lazily when the chain set is used as the query side)
+    bool rings_built = false;
+    std::vector<rsk_ring> rings;        // sorted by D
+    std::vector<uint32_t> ring_first;   // first ring index per D class
+    rsk_ring *d_ring_tab = nullptr;
+    uint8_t *d_ring_letters = nullptr;
+    uint8_t *d_ring_laneq = nullptr;
+    uint32_t *d_ring_qid = nullptr;
+    std::vector<uint32_t> long_q;       // queries too long for a ring (handled by the per-pair kernel)
+    uint64_t ring_slots_total = 0;      // sum of 128*D over rings
+};
+
+// kernels (k_mu_gapless.hip)
+int rsk_launch_gapless_rings(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int self_triangle,
+                             uint16_t *d_scores, size_t ldo);
+int rsk_launch_gapless_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, const uint32_t *d_iq,
+                             const uint32_t *d_it, size_t npairs, int32_t *d_scores,
+                             uint32_t *d_besti, uint32_t *d_bestj);
+int rsk_build_rings(rsk_db *db);
