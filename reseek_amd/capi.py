@@ -47,6 +47,12 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RskError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(hipcc --offload-arch=gfx950). reseek_amd has no CPU fallback.")
+        try:
+            # load torch's HIP runtime first so librsk.so (NEEDED libamdhip64.so) binds to the same
+            # copy -- two HIP runtimes in one process do not see the device.
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)

@@ -1,0 +1,65 @@
+// ubench_valu.hip -- measures issue rates of the instructions the gapless ring kernel is made of
+// (packed int16 add/max, DPP move, ds_read_b128) on the current GPU.  Build: hipcc --offload-arch=gfx950 -O3.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+typedef short v2s __attribute__((ext_vector_type(2)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+#define N_ITERS 4096
+template <int MODE> __global__ __launch_bounds__(256) void k(int *out, int seed)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int a[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = seed + i + threadIdx.x;
+    int s = seed | 1;
+    const char *p = smem + (threadIdx.x & 63) * 16;
+    for (int it = 0; it < N_ITERS; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (MODE == 0) a[i] = __builtin_bit_cast(int, __builtin_elementwise_add_sat(__builtin_bit_cast(v2s, a[i]), __builtin_bit_cast(v2s, s)));
+            if (MODE == 1) a[i] = __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(v2s, a[i]), __builtin_bit_cast(v2s, s)));
+            if (MODE == 2) a[i] = a[i] + s;                       // v_add_u32
+            if (MODE == 3) a[i] = max(a[i], s);                   // v_max_i32
+            if (MODE == 4) a[i] = __builtin_amdgcn_update_dpp(a[i], a[i], 0x13C, 0xF, 0xF, false);
+            if (MODE == 5) asm volatile("v_pk_add_i16 %0, %0, %1 clamp\n\tv_pk_max_i16 %0, %0, %1" : "+v"(a[i]) : "v"(s));
+        }
+        if (MODE == 6) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v4i v = *(const volatile v4i *) (p + ((it + i) & 15) * 1024);
+                a[i * 4] += v.x; a[i * 4 + 1] += v.y; a[i * 4 + 2] += v.z; a[i * 4 + 3] += v.w;
+            }
+        }
+        if (MODE != 6) asm volatile("" : "+v"(s));
+    }
+    int r = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r ^= a[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+template <int MODE> void run(const char *name, double ops_per_iter, int blocks_per_cu)
+{
+    int *d; hipMalloc(&d, 256 * 256 * 8 * 4 * 4);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    dim3 grid(256 * blocks_per_cu), blk(256);
+    hipLaunchKernelGGL(k<MODE>, grid, blk, 32768, 0, d, 3);
+    hipEventRecord(e0);
+    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(k<MODE>, grid, blk, 32768, 0, d, 3);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+    double lane_ops = (double) grid.x * 256 * N_ITERS * ops_per_iter;
+    printf("%-28s %8.3f ms  %8.2f T lane-ops/s  (%.1f lane-ops/clk/CU @2.4GHz)\n", name, ms, lane_ops / ms / 1e9,
+           lane_ops / (ms * 1e-3) / 256 / 2.4e9);
+    hipFree(d);
+}
+int main()
+{
+    run<0>("v_pk_add_i16 clamp", 16, 8);
+    run<1>("v_pk_max_i16", 16, 8);
+    run<2>("v_add_u32", 16, 8);
+    run<3>("v_max_i32", 16, 8);
+    run<4>("v_mov_b32_dpp wave_ror:1", 16, 8);
+    run<5>("pk_add+pk_max dep pair", 32, 8);
+    run<6>("ds_read_b128 (B per lane=16)", 4, 4);
+    return 0;
+}
