@@ -31,7 +31,10 @@ MU_FREQ = np.array([
     0.0385, 0.0368, 0.0039, 0.0297, 0.0100, 0.0120, 0.0206, 0.0263, 0.0104, 0.0530])
 MU_CHARS = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghij"
 
-PEAK_VALU_LANEOPS = 256 * 4 * 32 * 2.4e9      # 256 CUs x 4 SIMD32 x 2.4 GHz (MI355X_MICROARCH.md)
+# Packed-int16 VALU peak: 256 CUs x 4 SIMDs x 64 lanes / 4 cycles x 2.4 GHz.  VOP3P (v_pk_*) issues at one
+# wave64 instruction per 4 cycles per SIMD on gfx950 (tools/ubench_valu.hip measures 36-37 T lane-ops/s;
+# 32-bit VOP2 ops run at twice that).  One lane-op (add or max of a packed pair) per DP cell.
+PEAK_VALU_LANEOPS = 256 * 4 * 16 * 2.4e9
 PEAK_HBM_GBS = 8000.0
 
 
@@ -199,7 +202,8 @@ def main():
                 "achieved": k_cells_per_s / 1e12, "peak": PEAK_VALU_LANEOPS / 1e12, "unit": "T lane-ops/s",
                 "frac": k_cells_per_s / PEAK_VALU_LANEOPS,
                 "note": "algorithmic work = 1 packed-int16 VALU lane-op per DP cell (v_pk_add_i16 clamp + v_pk_max_i16 "
-                        "per 2 cells); LDS 2 B/cell; kernel time from HIP events on the launch stream",
+                        "per 2 cells); peak = VOP3P issue rate 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz (ubench: 36-37); "
+                        "LDS 2 B/cell; kernel time from HIP events on the launch stream",
                 "kernel_ms": kernel_ms, "cell_slots_issued": slots, "slot_efficiency": cells / max(1, slots),
                 "hbm": {"bound": "hbm", "achieved": alg_bytes / (kernel_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
                         "unit": "GB/s", "frac": alg_bytes / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,

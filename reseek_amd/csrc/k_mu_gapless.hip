@@ -138,7 +138,7 @@ template <int D> struct RingGeom {
 
 template <int D, int NW> constexpr size_t ring_lds_bytes()
 {
-    return 2 * (size_t) RingGeom<D>::PROF_BYTES + (size_t) NW * RingGeom<D>::NQMAX * 4 + 1312 + RingGeom<D>::P;
+    return 2 * (size_t) RingGeom<D>::PROF_BYTES + (size_t) NW * RingGeom<D>::NQMAX * 4 + 1312 + RingGeom<D>::P + 16;
 }
 
 __device__ __forceinline__ int pk_addsat(int a, int b)
@@ -203,6 +203,7 @@ __device__ __forceinline__ void ring_pairstep(int (&G)[D / 4][4], int (&E)[D / 4
 
 template <int D, int NW>
 __global__ __launch_bounds__(64 * NW) void k_gapless_ring(const rsk_ring *__restrict__ rings,
+                                                          const uint2 *__restrict__ work,   // (ring index, first target)
                                                           const uint8_t *__restrict__ ring_letters,
                                                           const uint8_t *__restrict__ ring_laneq,
                                                           const uint32_t *__restrict__ ring_qid,
@@ -220,13 +221,15 @@ __global__ __launch_bounds__(64 * NW) void k_gapless_ring(const rsk_ring *__rest
     int *res = (int *) (smem + 2 * Gm::PROF_BYTES);
     signed char *mat = (signed char *) (res + NW * NQMAX);
     unsigned char *rl = (unsigned char *) (mat + 1312);
+    uint32_t &next_t = *(uint32_t *) (rl + P);   // all LDS lives in the dynamic region (keeps it 16-byte aligned)
 
     const int tid = threadIdx.x;
     const int nthreads = 64 * NW;
-    const rsk_ring rg = rings[blockIdx.y];
-    const uint32_t t0 = blockIdx.x * tb_size;
-    const uint32_t t1 = min(nt, t0 + tb_size);
-    if (self_triangle && t1 <= rg.min_q) return;
+    const uint2 wk = work[blockIdx.x];
+    const rsk_ring rg = rings[wk.x];
+    const uint32_t t0 = (self_triangle && wk.y < rg.min_q) ? rg.min_q : wk.y;
+    const uint32_t t1 = min(nt, wk.y + tb_size);
+    if (tid == 0) next_t = t0;
 
     for (int i = tid; i < 1296; i += nthreads) mat[i] = c_mu_int[i];
     for (int i = tid; i < P; i += nthreads) rl[i] = ring_letters[rg.letters_off + i];
@@ -258,8 +261,11 @@ __global__ __launch_bounds__(64 * NW) void k_gapless_ring(const rsk_ring *__rest
 #pragma unroll
     for (int m = 0; m < M; ++m) lq[m] = ring_laneq[rg.laneq_off + m * 64 + lane];
 
-    for (uint32_t t = t0 + wave; t < t1; t += NW) {
-        if (self_triangle && t < rg.min_q) continue;
+    for (;;) {
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(&next_t, 1u);
+        t = __builtin_amdgcn_readfirstlane(t);
+        if (t >= t1) break;
         const uint32_t toff = __builtin_amdgcn_readfirstlane(t_off[t]);
         const uint32_t tlen = __builtin_amdgcn_readfirstlane(t_len[t]);
         const uint2 *lp = (const uint2 *) (t_mu + toff);
@@ -301,28 +307,29 @@ __global__ __launch_bounds__(64 * NW) void k_gapless_ring(const rsk_ring *__rest
 // per-pair kernel: one wave per pair, lanes stride over the LA+LB-1 diagonals.  Any length; also
 // returns the first strict maximum in row-major order (Besti/Bestj of SWFastGapless_Int).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_gapless_pairs(const uint8_t *__restrict__ q_mu, const uint32_t *__restrict__ q_off,
-                                                       const uint32_t *__restrict__ q_len,
-                                                       const uint8_t *__restrict__ t_mu, const uint32_t *__restrict__ t_off,
-                                                       const uint32_t *__restrict__ t_len,
-                                                       const uint32_t *__restrict__ iq, const uint32_t *__restrict__ it,
-                                                       uint32_t npairs, int32_t *__restrict__ scores,
-                                                       uint32_t *__restrict__ besti, uint32_t *__restrict__ bestj,
-                                                       uint16_t *__restrict__ out16, size_t ldo)
+__global__ __launch_bounds__(1024) void k_gapless_pairs(const uint8_t *__restrict__ q_mu, const uint32_t *__restrict__ q_off,
+                                                        const uint32_t *__restrict__ q_len,
+                                                        const uint8_t *__restrict__ t_mu, const uint32_t *__restrict__ t_off,
+                                                        const uint32_t *__restrict__ t_len,
+                                                        const uint32_t *__restrict__ iq, const uint32_t *__restrict__ it,
+                                                        uint32_t npairs, int32_t *__restrict__ scores,
+                                                        uint32_t *__restrict__ besti, uint32_t *__restrict__ bestj,
+                                                        uint16_t *__restrict__ out16, size_t ldo)
 {
+    // one workgroup (64..1024 threads) per pair
     __shared__ signed char mat[1296];
+    __shared__ unsigned long long wbest[16];
     for (int i = threadIdx.x; i < 1296; i += blockDim.x) mat[i] = c_mu_int[i];
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const uint32_t p = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (p >= npairs) return;
+    const uint32_t p = blockIdx.x;
     const uint32_t a = iq[p], b = it[p];
     const uint8_t *A = q_mu + q_off[a];
     const uint8_t *B = t_mu + t_off[b];
     const int LA = (int) q_len[a], LB = (int) t_len[b];
     unsigned long long best = 0;   // (score << 48) | (0xFFFFFF - i) << 24 | (0xFFFFFF - j)
     const int ndiag = LA + LB - 1;
-    for (int d = lane; d < ndiag; d += 64) {
+    for (int d = threadIdx.x; d < ndiag; d += blockDim.x) {
         int i = d < LB ? 0 : d - LB + 1;
         int j = d < LB ? LB - 1 - d : 0;
         int x = 0;
@@ -340,7 +347,11 @@ __global__ __launch_bounds__(256) void k_gapless_pairs(const uint8_t *__restrict
         const unsigned long long o = __shfl_xor(best, s, 64);
         if (o > best) best = o;
     }
-    if (lane == 0) {
+    if (lane == 0) wbest[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (unsigned w = 1; w < (blockDim.x >> 6); ++w)
+            if (wbest[w] > best) best = wbest[w];
         const int sc = (int) (best >> 48);
         if (scores) scores[p] = sc;
         if (besti) besti[p] = sc ? (uint32_t) (0xFFFFFF - ((best >> 24) & 0xFFFFFF)) : RSK_NO_POS;
@@ -353,18 +364,17 @@ __global__ __launch_bounds__(256) void k_gapless_pairs(const uint8_t *__restrict
 // launchers
 // ---------------------------------------------------------------------------------------------
 template <int D, int NW>
-static int launch_ring_class(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, uint32_t first, uint32_t count,
+static int launch_ring_class(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, const uint2 *d_work, uint32_t nwork,
                              int self_triangle, uint16_t *d_scores, size_t ldo, uint32_t tb_size)
 {
-    if (count == 0) return RSK_OK;
+    if (nwork == 0) return RSK_OK;
     constexpr size_t lds = ring_lds_bytes<D, NW>();
     static bool attr_set = false;
     if (!attr_set) {
         RSK_HIP(hipFuncSetAttribute((const void *) k_gapless_ring<D, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
         attr_set = true;
     }
-    dim3 grid((t->n + tb_size - 1) / tb_size, count);
-    hipLaunchKernelGGL((k_gapless_ring<D, NW>), grid, dim3(64 * NW), lds, ctx->stream, q->d_ring_tab + first,
+    hipLaunchKernelGGL((k_gapless_ring<D, NW>), dim3(nwork), dim3(64 * NW), lds, ctx->stream, q->d_ring_tab, d_work,
                        q->d_ring_letters, q->d_ring_laneq, q->d_ring_qid, t->d_mu, t->d_off, t->d_len, t->n, tb_size,
                        self_triangle, d_scores, ldo);
     RSK_HIP(hipGetLastError());
@@ -400,10 +410,47 @@ int rsk_launch_gapless_rings(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int
     }
     ctx->gl_pairs = pairs; ctx->gl_cells = cells; ctx->gl_slots = slots;
 
+    // work list: one workgroup per (ring, block of targets); only blocks that contain work, the
+    // expensive ones first.  Cached per (target set, triangle flag) in the query chain set.
+    rsk_db *qm = const_cast<rsk_db *>(q);
+    if (qm->work_for != t->uid || qm->work_tri != self_triangle) {
+        const uint32_t TB[2] = { 128, 256 };   // targets per workgroup for D = 4 / 8
+        std::vector<uint2> w[2];
+        std::vector<uint64_t> cost[2];
+        for (uint32_t ri = 0; ri < q->rings.size(); ++ri) {
+            const rsk_ring &r = q->rings[ri];
+            const int c = r.D == 4 ? 0 : 1;
+            const uint32_t ts = self_triangle ? (r.min_q / TB[c]) * TB[c] : 0;
+            for (uint32_t t0 = ts; t0 < t->n; t0 += TB[c]) {
+                const uint32_t lo = std::max(t0, self_triangle ? r.min_q : 0u), hi = std::min(t->n, t0 + TB[c]);
+                w[c].push_back(make_uint2(ri, t0));
+                cost[c].push_back(128ull * r.D * (pre_slots[hi] - pre_slots[lo]));
+            }
+        }
+        std::vector<uint2> all;
+        for (int c = 0; c < 2; ++c) {
+            std::vector<uint32_t> order(w[c].size());
+            for (uint32_t k = 0; k < order.size(); ++k) order[k] = k;
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[c][a] > cost[c][b]; });
+            qm->work_count[c] = (uint32_t) order.size();
+            for (uint32_t k : order) all.push_back(w[c][k]);
+        }
+        if (qm->d_work) (void) hipFree(qm->d_work);
+        qm->d_work = nullptr;
+        if (!all.empty()) {
+            RSK_HIP(hipMalloc((void **) &qm->d_work, all.size() * sizeof(uint2)));
+            RSK_HIP(hipMemcpy(qm->d_work, all.data(), all.size() * sizeof(uint2), hipMemcpyHostToDevice));
+        }
+        qm->work_for = t->uid;
+        qm->work_tri = self_triangle;
+    }
+    (void) nD4; (void) nD8;
+
     RSK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-    rc = launch_ring_class<4, 8>(ctx, q, t, 0, nD4, self_triangle, d_scores, ldo, 128);
+    rc = launch_ring_class<8, 16>(ctx, q, t, (const uint2 *) q->d_work + q->work_count[0], q->work_count[1], self_triangle,
+                                  d_scores, ldo, 256);
     if (rc != RSK_OK) return rc;
-    rc = launch_ring_class<8, 16>(ctx, q, t, nD4, nD8, self_triangle, d_scores, ldo, 256);
+    rc = launch_ring_class<4, 8>(ctx, q, t, (const uint2 *) q->d_work, q->work_count[0], self_triangle, d_scores, ldo, 128);
     if (rc != RSK_OK) return rc;
     // queries too long for a ring: per-pair kernel over (long q) x targets
     if (!q->long_q.empty()) {
@@ -416,7 +463,7 @@ int rsk_launch_gapless_rings(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int
         RSK_HIP(hipMemcpyAsync(d_iq, iq.data(), iq.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         RSK_HIP(hipMemcpyAsync(d_it, it.data(), it.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         const uint32_t np = (uint32_t) iq.size();
-        hipLaunchKernelGGL(k_gapless_pairs, dim3((np + 3) / 4), dim3(256), 0, ctx->stream, q->d_mu, q->d_off, q->d_len,
+        hipLaunchKernelGGL(k_gapless_pairs, dim3(np), dim3(1024), 0, ctx->stream, q->d_mu, q->d_off, q->d_len,
                            t->d_mu, t->d_off, t->d_len, d_iq, d_it, np, (int32_t *) nullptr, (uint32_t *) nullptr,
                            (uint32_t *) nullptr, d_scores, ldo);
         RSK_HIP(hipGetLastError());
@@ -435,7 +482,7 @@ int rsk_launch_gapless_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, con
     int rc = upload_tables(ctx);
     if (rc != RSK_OK) return rc;
     RSK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-    hipLaunchKernelGGL(k_gapless_pairs, dim3((unsigned) ((npairs + 3) / 4)), dim3(256), 0, ctx->stream, q->d_mu, q->d_off,
+    hipLaunchKernelGGL(k_gapless_pairs, dim3((unsigned) npairs), dim3(npairs > 4096 ? 64 : 1024), 0, ctx->stream, q->d_mu, q->d_off,
                        q->d_len, t->d_mu, t->d_off, t->d_len, d_iq, d_it, (uint32_t) npairs, d_scores, d_besti, d_bestj,
                        (uint16_t *) nullptr, (size_t) 0);
     RSK_HIP(hipGetLastError());

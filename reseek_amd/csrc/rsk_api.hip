@@ -3,6 +3,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
 #include <cfloat>
 
 #include "rsk_internal.h"
@@ -103,8 +104,10 @@ extern "C" int rsk_db_create(rsk_ctx *ctx, uint32_t n, const uint32_t *lengths, 
     *out = nullptr;
     if ((x || y || z) && !(x && y && z)) { rsk_set_error("rsk_db_create: x,y,z must be given together"); return RSK_E_INVALID; }
     RSK_HIP(hipSetDevice(ctx->device));
+    static std::atomic<uint64_t> next_uid{1};
     rsk_db *db = new rsk_db;
     db->ctx = ctx;
+    db->uid = next_uid.fetch_add(1);
     db->n = n;
     db->len.assign(lengths, lengths + n);
     db->off.resize((size_t) n + 1);
@@ -175,7 +178,7 @@ extern "C" void rsk_db_destroy(rsk_db *db)
 {
     if (!db) return;
     void *ptrs[] = { db->d_len, db->d_off, db->d_mu, db->d_prof, db->d_x, db->d_y, db->d_z, db->d_selfrev,
-                     db->d_ring_tab, db->d_ring_letters, db->d_ring_laneq, db->d_ring_qid };
+                     db->d_ring_tab, db->d_ring_letters, db->d_ring_laneq, db->d_ring_qid, db->d_work };
     for (void *p : ptrs)
         if (p) (void) hipFree(p);
     delete db;

@@ -42,6 +42,7 @@ struct rsk_ring {
 
 struct rsk_db {
     rsk_ctx *ctx = nullptr;
+    uint64_t uid = 0;          // unique per rsk_db_create (cache keys)
     uint32_t n = 0;
     uint64_t nres = 0;         // sum of lengths
     uint64_t npad = 0;         // sum of padded lengths
@@ -63,6 +64,11 @@ struct rsk_db {
     uint8_t *d_ring_letters = nullptr;
     uint8_t *d_ring_laneq = nullptr;
     uint32_t *d_ring_qid = nullptr;
+    // gapless work list cache (valid for one target set + triangle flag)
+    uint64_t work_for = 0;              // uid of the target set the list was built for
+    int work_tri = -1;
+    void *d_work = nullptr;             // uint2 (ring, first target) entries, D = 4 class first
+    uint32_t work_count[2] = { 0, 0 };
     std::vector<uint32_t> long_q;       // queries too long for a ring (handled by the per-pair kernel)
     uint64_t ring_slots_total = 0;      // sum of 128*D over rings
 };

@@ -21,6 +21,18 @@ template <int MODE> __global__ __launch_bounds__(256) void k(int *out, int seed)
             if (MODE == 2) a[i] = a[i] + s;                       // v_add_u32
             if (MODE == 3) a[i] = max(a[i], s);                   // v_max_i32
             if (MODE == 4) a[i] = __builtin_amdgcn_update_dpp(a[i], a[i], 0x13C, 0xF, 0xF, false);
+            if (MODE == 7) asm volatile("v_max3_i16 %0, %0, %1, %2" : "+v"(a[i]) : "v"(s), "v"(seed));
+            if (MODE == 8) asm volatile("v_max3_i16 %0, %0, %1, %2 op_sel:[1,1,1,1]" : "+v"(a[i]) : "v"(s), "v"(seed));
+            if (MODE == 9) asm volatile("v_add_i16 %0, %0, %1 clamp" : "+v"(a[i]) : "v"(s));
+            if (MODE == 10) asm volatile("v_add_i32 %0, %0, %1 clamp" : "+v"(a[i]) : "v"(s));
+            if (MODE == 11) asm volatile("v_max3_i32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(s), "v"(seed));
+            if (MODE == 12) asm volatile("v_pk_mad_i16 %0, %0, %1, %2 clamp" : "+v"(a[i]) : "v"(s), "v"(seed));
+            if (MODE == 13) asm volatile("v_alignbit_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(s), "v"(seed));
+            if (MODE == 14) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(s));
+            if (MODE == 15) asm volatile("v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a[i]));
+            if (MODE == 16) asm volatile("v_max_i16 %0, %0, %1" : "+v"(a[i]) : "v"(s));
+            if (MODE == 17) asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(a[i]) : "v"(s));
+            if (MODE == 18) asm volatile("v_pk_sub_u16 %0, %0, %1 clamp" : "+v"(a[i]) : "v"(s));
             if (MODE == 5) asm volatile("v_pk_add_i16 %0, %0, %1 clamp\n\tv_pk_max_i16 %0, %0, %1" : "+v"(a[i]) : "v"(s));
         }
         if (MODE == 6) {
@@ -61,5 +73,17 @@ int main()
     run<4>("v_mov_b32_dpp wave_ror:1", 16, 8);
     run<5>("pk_add+pk_max dep pair", 32, 8);
     run<6>("ds_read_b128 (B per lane=16)", 4, 4);
+    run<7>("v_max3_i16", 16, 8);
+    run<8>("v_max3_i16 op_sel hi", 16, 8);
+    run<9>("v_add_i16 clamp (vop3)", 16, 8);
+    run<10>("v_add_i32 clamp", 16, 8);
+    run<11>("v_max3_i32", 16, 8);
+    run<12>("v_pk_mad_i16 clamp", 16, 8);
+    run<13>("v_alignbit_b32", 16, 8);
+    run<14>("v_cndmask_b32", 16, 8);
+    run<15>("v_mov_b32_dpp row_shr:1", 16, 8);
+    run<16>("v_max_i16 (vop2)", 16, 8);
+    run<17>("v_pk_add_u16", 16, 8);
+    run<18>("v_pk_sub_u16 clamp", 16, 8);
     return 0;
 }
