@@ -91,6 +91,30 @@ int rsk_mu_gapless_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, const u
  * ring padding, triangle overshoot). */
 int rsk_mu_gapless_last_work(rsk_ctx *ctx, uint64_t *pairs, uint64_t *cells, uint64_t *cell_slots);
 
+/* ---- P3/P4: Mu-letter affine SW filter -------------------------------------------------------
+ * Batch form of DSSAligner::SetMuQP_Para (parasail_mu.cpp:163, query profiles are built inside the
+ * kernel) + AlignMuQP_Para (parasail_mu.cpp:120) + MuFilter (dssaligner.cpp:619).
+ *
+ * rsk_mu_sw_matrix_dev: the raw score parasail_sw_striped_profile_avx2_256_8 (parasail.cpp:515)
+ * returns for query iq (reversed if reverse_query) vs target it: d_scores[iq*ldo + it] in 0..250, or
+ * 255 = saturated.  gap_open = cost of the first gap residue, gap_ext = each further one
+ * (m_ParaMuGapOpen/Ext = 2/1, dssparams.h:45-46).  Same triangle convention as the gapless call. */
+int rsk_mu_sw_matrix_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int self_triangle,
+                         int reverse_query, int gap_open, int gap_ext, uint8_t *d_scores, size_t ldo);
+/* The whole filter on the device: forward scores of every enumerated pair -> d_fwd (as above);
+ * pairs with fwd >= omega_fwd (fwd = 777 if saturated) are re-scored against the reversed query;
+ * pairs with fwd - rev >= omega (rev = 255 if saturated) are appended, in no particular order, to
+ * d_pairs_q/d_pairs_t (+ d_pairs_fwd/d_pairs_rev if not NULL).  *d_npairs (device) receives the
+ * number of survivors; entries beyond `capacity` are dropped (check *d_npairs <= capacity).
+ * Presets: Fast omega 22 / omega_fwd 50, Sensitive 12 / 20 (dssparams.cpp:52-71). */
+int rsk_mu_filter_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int self_triangle, int gap_open,
+                      int gap_ext, float omega, float omega_fwd, uint8_t *d_fwd, size_t ldo,
+                      uint32_t *d_pairs_q, uint32_t *d_pairs_t, int32_t *d_pairs_fwd,
+                      int32_t *d_pairs_rev, size_t capacity, uint32_t *d_npairs);
+/* Counters of the last rsk_mu_filter_dev call (m_MuFilterInputCount and the number of pairs that
+ * needed the reverse pass, cf. dssaligner.h:90-96). */
+int rsk_mu_filter_last_work(rsk_ctx *ctx, uint64_t *pairs, uint64_t *candidates);
+
 #ifdef __cplusplus
 }
 #endif

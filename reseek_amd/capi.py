@@ -33,6 +33,12 @@ SIGNATURES = {
     "rsk_mu_gapless_matrix_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
     "rsk_mu_gapless_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, u32p, u32p, C.c_size_t, i32p, u32p, u32p]),
     "rsk_mu_gapless_last_work": (C.c_int, [C.c_void_p, u64p, u64p, u64p]),
+    "rsk_mu_sw_matrix_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                       C.c_size_t]),
+    "rsk_mu_filter_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                    C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                    C.c_void_p]),
+    "rsk_mu_filter_last_work": (C.c_int, [C.c_void_p, u64p, u64p]),
 }
 
 
@@ -107,6 +113,22 @@ class Ctx:
         _check(lib().rsk_mu_gapless_pairs(self.h, q.h, t.h, _p(iq, u32p), _p(it, u32p), n, _p(sc, i32p),
                                           _p(bi, u32p), _p(bj, u32p)))
         return (sc, bi, bj) if positions else sc
+
+    # ---- P4 Mu SW filter ---------------------------------------------------------------------
+    def mu_sw_matrix_dev(self, q, t, self_triangle, reverse_query, d_scores_ptr, ldo, gap_open=2, gap_ext=1):
+        _check(lib().rsk_mu_sw_matrix_dev(self.h, q.h, t.h, int(self_triangle), int(reverse_query), gap_open, gap_ext,
+                                          C.c_void_p(d_scores_ptr), ldo))
+
+    def mu_filter_dev(self, q, t, self_triangle, omega, omega_fwd, d_fwd, ldo, d_pq, d_pt, d_pf, d_pr, capacity, d_n,
+                      gap_open=2, gap_ext=1):
+        _check(lib().rsk_mu_filter_dev(self.h, q.h, t.h, int(self_triangle), gap_open, gap_ext, omega, omega_fwd,
+                                       C.c_void_p(d_fwd), ldo, C.c_void_p(d_pq), C.c_void_p(d_pt), C.c_void_p(d_pf),
+                                       C.c_void_p(d_pr), capacity, C.c_void_p(d_n)))
+
+    def mu_filter_last_work(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        _check(lib().rsk_mu_filter_last_work(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def mu_gapless_last_work(self):
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()

@@ -27,22 +27,10 @@
 
 #include <algorithm>
 
-#include "rsk_internal.h"
-#include "rsk_tables_data.h"
+#include "rsk_dev_tables.h"
 
 typedef short v2s __attribute__((ext_vector_type(2)));
 typedef int v4i __attribute__((ext_vector_type(4)));
-
-__device__ __constant__ signed char c_mu_int[36 * 36];
-static bool g_tables_uploaded[16] = { false };
-
-static int upload_tables(rsk_ctx *ctx)
-{
-    if (ctx->device < 16 && g_tables_uploaded[ctx->device]) return RSK_OK;
-    RSK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_mu_int), rsk_mu_int, sizeof(rsk_mu_int)));
-    if (ctx->device < 16) g_tables_uploaded[ctx->device] = true;
-    return RSK_OK;
-}
 
 #define FLOOR2 ((int) 0x80008000)
 #define FLOOR32 (-32768)
@@ -384,7 +372,7 @@ static int launch_ring_class(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, con
 int rsk_launch_gapless_rings(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int self_triangle,
                              uint16_t *d_scores, size_t ldo)
 {
-    int rc = upload_tables(ctx);
+    int rc = rsk_upload_mu_tables(ctx);
     if (rc != RSK_OK) return rc;
     // work accounting (host side, O(rings))
     std::vector<uint64_t> pre_len(t->n + 1, 0), pre_slots(t->n + 1, 0);
@@ -479,7 +467,7 @@ int rsk_launch_gapless_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, con
                              const uint32_t *d_it, size_t npairs, int32_t *d_scores, uint32_t *d_besti,
                              uint32_t *d_bestj)
 {
-    int rc = upload_tables(ctx);
+    int rc = rsk_upload_mu_tables(ctx);
     if (rc != RSK_OK) return rc;
     RSK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     hipLaunchKernelGGL(k_gapless_pairs, dim3((unsigned) npairs), dim3(npairs > 4096 ? 64 : 1024), 0, ctx->stream, q->d_mu, q->d_off,

@@ -1,0 +1,614 @@
+// k_mu_sw.hip -- Mu-letter affine local SW score and the Mu filter (the live -search filter;
+// SURVEY.md 8a rows P3/P4).
+//
+// Reference semantics (bit-exact on the integer score): DSSAligner::AlignMuQP_Para
+// parasail_mu.cpp:120 -> parasail_sw_striped_profile_avx2_256_8 parasail.cpp:515 == plain Gotoh
+//   H(i,j) = max(0, H(i-1,j-1)+s, E(i,j), F(i,j));  E(i,j+1) = max(E(i,j)-ext, H(i,j)-open);
+//   F(i+1,j) = max(F(i,j)-ext, H(i,j)-open);  s = IntScoreMx_Mu (mumx_data.cpp:42), open 2, ext 1.
+//   "saturated" iff best > 250 (parasail.cpp:725-737): the raw result is then 255.
+//   Filter (parasail_mu.cpp:120-161, dssaligner.cpp:619-631): fwd = sat ? 777 : raw;
+//   fwd < OmegaFwd -> 0; rev = raw score of the REVERSED query (255 if saturated); pass iff
+//   fwd - rev >= Omega.
+//
+// MI355X design (integer VALU bound; no GEMM, almost no HBM traffic):
+//   * one workgroup = one query chain x a batch of target chains.  The query profile
+//     prof[c][i] = s(c, a_i) (int32, 37 letter rows, padded stride) lives in LDS (replaces the
+//     striped int8 AVX2 profile of SetMuQP_Para parasail_mu.cpp:163).
+//   * the query is cut into strips of R = 32 rows; a strip's H/E values stay in VGPRs.  The
+//     g = ceil(LQ/32) strips of ONE pair sit on g CONSECUTIVE LANES that run one column behind
+//     each other (systolic array): lane k hands the bottom-row (H, F) of its strip to lane k+1 with
+//     a single v_mov_b32_dpp wave_shr:1 per column -- no scratch memory, no LDS hand-off.
+//     A wave therefore works on floor(64/g) targets at once.
+//   * per column a lane fetches its 32 profile scores with eight ds_read_b128 (row = its target
+//     letter; the row stride LQpad+4 dwords starts different letters on different bank groups).
+//   * all per-cell ops are 32-bit VOP2 (full issue rate on gfx950; VOP3/VOP3P issue at half rate).
+//   * persistent workgroups pull (query, target batch) items from a device-side queue that is
+//     also built on the device (the reverse pass runs on data-dependent survivor lists).
+#include <algorithm>
+#include <vector>
+
+#include "rsk_dev_tables.h"
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+
+#define MUSW_R 32
+#define MUSW_WAVES 4
+#define MUSW_PADSCORE (-1000)      // pad rows / pad letters: never part of an alignment
+#define MUSW_LDS_MAX_LQPAD 1056    // 37*(1056+4)*4 + 1.4 KB < 160 KB
+#define MUSW_MAX_LQ 2048           // 64 strips of 32 rows (one pair per wave)
+
+__device__ __forceinline__ int dpp_wave_shr1(int x)
+{
+    // lane l <- lane l-1 (lane 0 keeps its own value; callers ignore it there)
+    return __builtin_amdgcn_update_dpp(x, x, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+}
+
+struct musw_args {
+    const uint8_t *q_mu; const uint32_t *q_off; const uint32_t *q_len;
+    const uint8_t *t_mu; const uint32_t *t_off; const uint32_t *t_len;
+    const uint2 *items;         // (query, first list position) per workgroup item
+    const uint32_t *nitems;     // device-side item count
+    const uint32_t *cnt;        // listed targets per query
+    const uint32_t *first;      // implicit lists: first target index of query q
+    const uint32_t *list;       // explicit lists (CSR): list[rowstart[q] + k]; NULL => implicit first[q] + k
+    const uint32_t *rowstart;   // CSR row starts (explicit lists)
+    int reverse;                // 1: use the reversed query (m_MuRevA, parasail_mu.cpp:174-179)
+    int open, ext;
+    uint8_t *out;               // raw score min(best,255) with 255 = saturated
+    size_t ldo;                 // dense: out[q*ldo + t];  CSR: out[rowstart[q] + k]
+    uint32_t *counter;          // work counter (persistent workgroups)
+    int *gprof;                 // GLOBAL variant: per-workgroup profile storage
+    size_t gprof_stride;        // ints per workgroup
+};
+
+template <bool GLOBAL_PROF>
+__global__ __launch_bounds__(64 * MUSW_WAVES) void k_mu_sw(musw_args a, uint32_t lqpad_max)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int *prof;
+    signed char *mat;
+    if (GLOBAL_PROF) {
+        prof = a.gprof + (size_t) blockIdx.x * a.gprof_stride;
+        mat = (signed char *) smem;
+    } else {
+        prof = (int *) smem;
+        mat = (signed char *) (prof + 37 * (lqpad_max + 4));
+    }
+    uint32_t *wg_item = (uint32_t *) (mat + 1312);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    for (int i = tid; i < 1296; i += blockDim.x) mat[i] = c_mu_int[i];
+    uint32_t cur_q = 0xFFFFFFFFu;
+    uint32_t LQ = 0, g = 1, RS = 4;
+    const uint32_t nitems = *a.nitems;
+
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) wg_item[0] = atomicAdd(a.counter, 1u);
+        __syncthreads();
+        const uint32_t item = wg_item[0];
+        if (item >= nitems) break;
+        const uint2 it = a.items[item];
+        const uint32_t q = it.x;
+        if (q != cur_q) {
+            cur_q = q;
+            LQ = a.q_len[q];
+            g = (LQ + MUSW_R - 1) / MUSW_R;
+            RS = g * MUSW_R + 4;
+            const uint8_t *Q = a.q_mu + a.q_off[q];
+            // prof[c][i] = s(c, a_i); pad rows (i >= LQ) and the pad-letter row 36 = PADSCORE
+            for (uint32_t idx = tid; idx < 37 * RS; idx += blockDim.x) {
+                const uint32_t c = idx / RS, i = idx - c * RS;
+                int v = MUSW_PADSCORE;
+                if (c < 36 && i < LQ) {
+                    const uint32_t qi = a.reverse ? (LQ - 1 - i) : i;
+                    v = mat[c * 36 + Q[qi]];
+                }
+                prof[idx] = v;
+            }
+            if (GLOBAL_PROF) __threadfence_block();
+            __syncthreads();
+        }
+        const uint32_t ppw = 64 / g;                 // pairs per wave (g <= 64 guaranteed by the host)
+        const uint32_t k0 = it.y + wave * ppw;       // first list position of this wave
+        const uint32_t cnt = a.cnt[q];
+        const uint32_t pr = lane / g, st = lane - pr * g;     // pair slot and strip of this lane
+        const bool active = (pr < ppw) && (k0 + pr < cnt);
+        uint32_t t = 0, LB = 0;
+        const uint8_t *B = a.t_mu;
+        if (active) {
+            const uint32_t k = k0 + pr;
+            t = a.list ? a.list[a.rowstart[q] + k] : (a.first[q] + k);
+            LB = a.t_len[t];
+            B = a.t_mu + a.t_off[t];
+        }
+        // columns this wave must run: max over lanes of LB + strip delay
+        uint32_t ncol = active ? (LB + st) : 0;
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) ncol = max(ncol, (uint32_t) __shfl_xor((int) ncol, s, 64));
+        if (ncol == 0) continue;
+
+        int H[MUSW_R], E[MUSW_R];
+#pragma unroll
+        for (int r = 0; r < MUSW_R; ++r) { H[r] = 0; E[r] = 0; }
+        int best = 0;
+        int hand = 0;          // (F << 16) | H of the bottom row of this strip at its previous column
+        int diag_in = 0;       // H(i0-1, j-1) for the top row
+        const int open = a.open, ext = a.ext;
+        const int *lane_prof = prof + st * MUSW_R;
+        unsigned lw = active ? *(const unsigned *) B : 0u;    // letters j..j+3 (chains are padded to 16 in HBM)
+        unsigned lw_next = 0;
+
+        for (uint32_t col = 0; col < ncol; ++col) {
+            const int j = (int) col - (int) st;     // this lane's target column at this step
+            // bottom row of the strip above at the same column j (it computed it one step earlier)
+            const int inc = dpp_wave_shr1(hand);
+            int up_h = 0, up_f = 0;
+            if (st != 0) { up_h = inc & 0xFFFF; up_f = (int) ((unsigned) inc >> 16); }
+            unsigned c = 36;
+            if (j >= 0 && (uint32_t) j < LB) {
+                const int jm = j & 3;
+                if (jm == 0) {
+                    if (j) lw = lw_next;
+                    lw_next = *(const unsigned *) (B + j + 4);   // prefetch the next 4 letters
+                }
+                c = (lw >> (8 * jm)) & 0xFF;
+            }
+            const int *row = lane_prof + c * RS;
+            v4i S[MUSW_R / 4];
+#pragma unroll
+            for (int k = 0; k < MUSW_R / 4; ++k) S[k] = *(const v4i *) (row + 4 * k);
+            int diag = diag_in;
+            int F = up_f;
+            diag_in = up_h;
+#pragma unroll
+            for (int r = 0; r < MUSW_R; ++r) {
+                int h = diag + S[r >> 2][r & 3];
+                h = max(h, 0);
+                h = max(h, E[r]);
+                h = max(h, F);
+                diag = H[r];
+                H[r] = h;
+                best = max(best, h);
+                const int ho = h - open;
+                E[r] = max(E[r] - ext, ho);
+                F = max(F - ext, ho);
+            }
+            // bottom row of this strip -> next lane (16 bits each: anything above 250 saturates anyway)
+            hand = (min(max(F, 0), 0x7FFF) << 16) | min(H[MUSW_R - 1], 0xFFFF);
+        }
+        // best over the g strips of each pair (lanes pr*g .. pr*g+g-1); the first lane of a group collects
+        int red = best;
+        for (uint32_t d = 1; d < g; ++d) {
+            const int o = __shfl(best, (int) ((lane + d) & 63), 64);
+            if (st + d < g) red = max(red, o);
+        }
+        if (active && st == 0) {
+            const uint8_t v = (uint8_t) (red > 250 ? 255 : red);
+            if (a.list) a.out[a.rowstart[q] + k0 + pr] = v;
+            else a.out[(size_t) q * a.ldo + t] = v;
+        }
+    }
+}
+
+// Any length: one thread per pair, DP rows in global scratch (rare: both chains > 2048).
+__global__ void k_mu_sw_slow(musw_args a, const uint2 *pairs, const uint32_t *pair_k, uint32_t npairs, int *scratch,
+                             size_t scratch_stride)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npairs) return;
+    const uint32_t q = pairs[p].x, t = pairs[p].y;
+    const uint8_t *A = a.q_mu + a.q_off[q];
+    const uint8_t *B = a.t_mu + a.t_off[t];
+    const int LA = (int) a.q_len[q], LB = (int) a.t_len[t];
+    int *Hc = scratch + (size_t) p * scratch_stride;
+    int *Ec = Hc + LA;
+    for (int i = 0; i < LA; ++i) { Hc[i] = 0; Ec[i] = 0; }
+    int best = 0;
+    for (int j = 0; j < LB; ++j) {
+        int diag = 0, F = 0;
+        const int b = B[j];
+        for (int i = 0; i < LA; ++i) {
+            const int ai = a.reverse ? A[LA - 1 - i] : A[i];
+            int h = diag + c_mu_int[b * 36 + ai];
+            h = max(h, 0); h = max(h, Ec[i]); h = max(h, F);
+            diag = Hc[i];
+            Hc[i] = h;
+            best = max(best, h);
+            const int ho = h - a.open;
+            Ec[i] = max(Ec[i] - a.ext, ho);
+            F = max(F - a.ext, ho);
+        }
+    }
+    const uint8_t v = (uint8_t) (best > 250 ? 255 : best);
+    if (a.list) a.out[a.rowstart[q] + pair_k[p]] = v;
+    else a.out[(size_t) q * a.ldo + t] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device-side queue construction
+// ---------------------------------------------------------------------------------------------
+// class of a query by its padded length: 0: <=224, 1: <=416, 2: <=1056 (LDS profile), 3: <=2048 (global profile), 4: slow
+__device__ __forceinline__ int musw_class(uint32_t LQ)
+{
+    const uint32_t lp = (LQ + MUSW_R - 1) / MUSW_R * MUSW_R;
+    if (lp <= 224) return 0;
+    if (lp <= 416) return 1;
+    if (lp <= MUSW_LDS_MAX_LQPAD) return 2;
+    if (LQ <= MUSW_MAX_LQ) return 3;
+    return 4;
+}
+
+// implicit lists: first[q], cnt[q]
+__global__ void k_musw_setup_implicit(uint32_t nq, uint32_t nt, int self_triangle, uint32_t *first, uint32_t *cnt)
+{
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    first[q] = self_triangle ? q : 0;
+    cnt[q] = self_triangle ? (nt > q ? nt - q : 0) : nt;
+}
+
+// Single workgroup: for class `cls` compute per-query item counts, exclusive scan, write item_start[q] and *nitems.
+__global__ __launch_bounds__(1024) void k_musw_scan_items(const uint32_t *q_len, const uint32_t *cnt, uint32_t nq, int cls,
+                                                          uint32_t *item_start, uint32_t *nitems)
+{
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nq; base += 1024) {
+        const uint32_t q = base + tid;
+        uint32_t v = 0;
+        if (q < nq && musw_class(q_len[q]) == cls && cnt[q]) {
+            const uint32_t LQ = q_len[q];
+            if (cls == 4) v = cnt[q];                          // slow path: one item per pair
+            else {
+                const uint32_t g = (LQ + MUSW_R - 1) / MUSW_R;
+                const uint32_t per_wg = (64 / g) * MUSW_WAVES;
+                v = (cnt[q] + per_wg - 1) / per_wg;
+            }
+        }
+        // inclusive scan within wave
+        uint32_t x = v;
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) {
+            const uint32_t o = (uint32_t) __shfl_up((int) x, s, 64);
+            if (lane >= s) x += o;
+        }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wsum[w];
+        const uint32_t excl = carry + woff + x - v;
+        if (q < nq) item_start[q] = excl;
+        __syncthreads();
+        if (tid == 1023) carry = excl + v;
+        __syncthreads();
+    }
+    if (tid == 0) { item_start[nq] = carry; *nitems = carry; }
+}
+
+__global__ void k_musw_fill_items(const uint32_t *q_len, const uint32_t *cnt, const uint32_t *first, const uint32_t *list,
+                                  const uint32_t *rowstart, uint32_t nq, int cls, const uint32_t *item_start, uint2 *items,
+                                  uint32_t *pair_k)
+{
+    const uint32_t q = blockIdx.x;
+    if (q >= nq || musw_class(q_len[q]) != cls) return;
+    const uint32_t n = item_start[q + 1] - item_start[q];
+    const uint32_t LQ = q_len[q];
+    if (cls == 4) {
+        for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) {
+            const uint32_t t = list ? list[rowstart[q] + k] : first[q] + k;
+            items[item_start[q] + k] = make_uint2(q, t);
+            pair_k[item_start[q] + k] = k;
+        }
+        return;
+    }
+    const uint32_t g = (LQ + MUSW_R - 1) / MUSW_R;
+    const uint32_t per_wg = (64 / g) * MUSW_WAVES;
+    for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) items[item_start[q] + k] = make_uint2(q, k * per_wg);
+}
+
+// ---------------------------------------------------------------------------------------------
+// filter plumbing: candidate lists (CSR) and the final survivor list
+// ---------------------------------------------------------------------------------------------
+// one wave per query row: count (pass 0) or write (pass 1) targets with fwd' >= omega_fwd
+__global__ __launch_bounds__(256) void k_musw_candidates(const uint8_t *fwd, size_t ldo, const uint32_t *first, const uint32_t *cnt,
+                                                         uint32_t nq, float omega_fwd, int pass, uint32_t *ccnt,
+                                                         const uint32_t *rowstart, uint32_t *list)
+{
+    const uint32_t q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t f0 = first[q], n = cnt[q];
+    uint32_t run = 0;
+    for (uint32_t k = 0; k < n; k += 64) {
+        const uint32_t kk = k + lane;
+        bool c = false;
+        if (kk < n) {
+            const int raw = fwd[(size_t) q * ldo + f0 + kk];
+            const float f = raw == 255 ? 777.0f : (float) raw;     // parasail_mu.cpp:135-139
+            c = !(f < omega_fwd);                                    // :141-146
+        }
+        const unsigned long long m = __ballot(c);
+        if (pass == 1 && c) list[rowstart[q] + run + __popcll(m & ((1ull << lane) - 1ull))] = f0 + kk;
+        run += (uint32_t) __popcll(m);
+    }
+    if (pass == 0 && lane == 0) ccnt[q] = run;
+}
+
+// exclusive scan of cnt[0..n) -> out[0..n], single workgroup
+__global__ __launch_bounds__(1024) void k_exclusive_scan_u32(const uint32_t *in, uint32_t n, uint32_t *out)
+{
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t i = base + tid;
+        const uint32_t v = i < n ? in[i] : 0;
+        uint32_t x = v;
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) {
+            const uint32_t o = (uint32_t) __shfl_up((int) x, s, 64);
+            if (lane >= s) x += o;
+        }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wsum[w];
+        const uint32_t excl = carry + woff + x - v;
+        if (i < n) out[i] = excl;
+        __syncthreads();
+        if (tid == 1023) carry = excl + v;
+        __syncthreads();
+    }
+    if (tid == 0) out[n] = carry;
+}
+
+// one wave per query row: survivors = candidates with fwd' - rev >= omega  (dssaligner.cpp:626-629)
+__global__ __launch_bounds__(256) void k_musw_survivors(const uint8_t *fwd, size_t ldo, const uint32_t *ccnt, const uint32_t *rowstart,
+                                                        const uint32_t *list, const uint8_t *rev, uint32_t nq, float omega,
+                                                        uint32_t *pairs_q, uint32_t *pairs_t, int32_t *pairs_fwd, int32_t *pairs_rev,
+                                                        uint32_t capacity, uint32_t *npairs)
+{
+    const uint32_t q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t n = ccnt[q], rs = rowstart[q];
+    for (uint32_t k = 0; k < n; k += 64) {
+        const uint32_t kk = k + lane;
+        bool c = false;
+        uint32_t t = 0;
+        int f = 0, r = 0;
+        if (kk < n) {
+            t = list[rs + kk];
+            const int raw = fwd[(size_t) q * ldo + t];
+            f = raw == 255 ? 777 : raw;
+            r = rev[rs + kk];                   // 255 when saturated (parasail_mu.cpp:152 read before the fix-up)
+            const float sc = (float) f - (float) r;
+            c = !(sc < omega);                  // MuFilter: MuScore < MCS -> reject (dssaligner.cpp:626-628)
+        }
+        const unsigned long long m = __ballot(c);
+        const uint32_t tot = (uint32_t) __popcll(m);
+        uint32_t base = 0;
+        if (lane == 0 && tot) base = atomicAdd(npairs, tot);
+        base = (uint32_t) __shfl((int) base, 0, 64);
+        if (c) {
+            const uint32_t pos = base + (uint32_t) __popcll(m & ((1ull << lane) - 1ull));
+            if (pos < capacity) {
+                pairs_q[pos] = q; pairs_t[pos] = t;
+                if (pairs_fwd) pairs_fwd[pos] = f;
+                if (pairs_rev) pairs_rev[pos] = r;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host orchestration
+// ---------------------------------------------------------------------------------------------
+
+struct musw_ws {               // per-call device workspace
+    uint32_t *first = nullptr, *cnt = nullptr, *item_start = nullptr, *nitems = nullptr, *counter = nullptr, *pair_k = nullptr;
+    uint2 *items = nullptr;
+    int *gprof = nullptr;
+    int *slow_scratch = nullptr;
+    std::vector<void *> all;
+    ~musw_ws() { for (void *p : all) (void) hipFree(p); }
+    template <class T> int alloc(T **p, size_t n)
+    {
+        RSK_HIP(hipMalloc((void **) p, std::max<size_t>(n, 1) * sizeof(T)));
+        all.push_back(*p);
+        return RSK_OK;
+    }
+};
+
+// Runs the SW kernel for every class over lists described by (cnt, first | list+rowstart).
+static int run_mu_sw_lists(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, musw_args base, uint32_t max_items_hint,
+                           musw_ws &ws)
+{
+    const uint32_t nq = q->n;
+    int rc;
+    if ((rc = ws.alloc(&ws.item_start, (size_t) nq + 1)) != RSK_OK) return rc;
+    if ((rc = ws.alloc(&ws.nitems, 1)) != RSK_OK) return rc;
+    if ((rc = ws.alloc(&ws.counter, 1)) != RSK_OK) return rc;
+    if ((rc = ws.alloc(&ws.items, (size_t) max_items_hint)) != RSK_OK) return rc;
+    uint32_t maxLQ = 0;
+    bool has_class[5] = { false, false, false, false, false };
+    uint32_t class_lqpad[4] = { 224, 416, MUSW_LDS_MAX_LQPAD, MUSW_MAX_LQ };
+    for (uint32_t i = 0; i < nq; ++i) {
+        const uint32_t L = q->len[i], lp = (L + MUSW_R - 1) / MUSW_R * MUSW_R;
+        maxLQ = std::max(maxLQ, L);
+        const int c = lp <= 224 ? 0 : lp <= 416 ? 1 : lp <= MUSW_LDS_MAX_LQPAD ? 2 : L <= MUSW_MAX_LQ ? 3 : 4;
+        has_class[c] = true;
+    }
+    for (int cls = 0; cls < 5; ++cls) {
+        if (!has_class[cls]) continue;
+        RSK_HIP(hipMemsetAsync(ws.counter, 0, 4, ctx->stream));
+        hipLaunchKernelGGL(k_musw_scan_items, dim3(1), dim3(1024), 0, ctx->stream, q->d_len, base.cnt, nq, cls, ws.item_start,
+                           ws.nitems);
+        if (cls == 4 && !ws.pair_k) { if ((rc = ws.alloc(&ws.pair_k, (size_t) max_items_hint)) != RSK_OK) return rc; }
+        hipLaunchKernelGGL(k_musw_fill_items, dim3(nq), dim3(64), 0, ctx->stream, q->d_len, base.cnt, base.first, base.list,
+                           base.rowstart, nq, cls, ws.item_start, ws.items, ws.pair_k);
+        musw_args a = base;
+        a.items = ws.items;
+        a.nitems = ws.nitems;
+        a.counter = ws.counter;
+        if (cls <= 2) {
+            const uint32_t lq = class_lqpad[cls];
+            const size_t lds = (size_t) 37 * (lq + 4) * 4 + 1312 + 16;
+            static bool attr_set = false;
+            if (!attr_set) {
+                RSK_HIP(hipFuncSetAttribute((const void *) k_mu_sw<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+                attr_set = true;
+            }
+            const int wg_per_cu = std::max(1, std::min(4, (int) (163840 / lds)));
+            hipLaunchKernelGGL((k_mu_sw<false>), dim3(ctx->num_cus * wg_per_cu), dim3(64 * MUSW_WAVES), lds, ctx->stream, a, lq);
+        } else if (cls == 3) {
+            const uint32_t nwg = ctx->num_cus * 2;
+            a.gprof_stride = (size_t) 37 * (MUSW_MAX_LQ + 4);
+            if (!ws.gprof) { if ((rc = ws.alloc(&ws.gprof, a.gprof_stride * nwg)) != RSK_OK) return rc; }
+            a.gprof = ws.gprof;
+            hipLaunchKernelGGL((k_mu_sw<true>), dim3(nwg), dim3(64 * MUSW_WAVES), 1312 + 16, ctx->stream, a, 0u);
+        } else {
+            // slow path: needs the item count on the host to size the launch
+            uint32_t n = 0;
+            RSK_HIP(hipMemcpyAsync(&n, ws.nitems, 4, hipMemcpyDeviceToHost, ctx->stream));
+            RSK_HIP(hipStreamSynchronize(ctx->stream));
+            if (n) {
+                const size_t stride = 2 * (size_t) maxLQ;
+                if ((rc = ws.alloc(&ws.slow_scratch, stride * n)) != RSK_OK) return rc;
+                hipLaunchKernelGGL(k_mu_sw_slow, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, a, (const uint2 *) ws.items,
+                                   (const uint32_t *) ws.pair_k, n, ws.slow_scratch, stride);
+            }
+        }
+        RSK_HIP(hipGetLastError());
+    }
+    return RSK_OK;
+}
+
+static uint32_t item_exact_implicit(const rsk_db *q, uint32_t nt, int self_triangle)
+{
+    uint64_t n = 16;
+    for (uint32_t i = 0; i < q->n; ++i) {
+        const uint32_t L = q->len[i];
+        const uint64_t cnt = self_triangle ? (nt > i ? nt - i : 0) : nt;
+        if (L > MUSW_MAX_LQ) { n += cnt; continue; }
+        const uint32_t g = (L + MUSW_R - 1) / MUSW_R, per_wg = (64 / g) * MUSW_WAVES;
+        n += (cnt + per_wg - 1) / per_wg;
+    }
+    return (uint32_t) std::min<uint64_t>(n, 0xFFFFFFF0ull);
+}
+
+static uint32_t item_upper_bound(const rsk_db *q, uint64_t total_listed)
+{
+    // every item covers >= 1 pair (slow path) ... typical >= 4; bound by pairs/1 is too large, so:
+    // items <= sum_q ceil(cnt_q / per_wg_q) <= total/ per_wg_min + nq, per_wg_min = 4 (g = 64) .. slow path cnt.
+    uint64_t ub = total_listed / 4 + q->n + 16;
+    bool any_slow = false;
+    for (uint32_t L : q->len) if (L > MUSW_MAX_LQ) { any_slow = true; break; }
+    if (any_slow) ub = total_listed + q->n + 16;
+    return (uint32_t) std::min<uint64_t>(ub, 0xFFFFFFF0ull);
+}
+
+extern "C" int rsk_mu_sw_matrix_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int self_triangle, int reverse_query,
+                                    int gap_open, int gap_ext, uint8_t *d_scores, size_t ldo)
+{
+    if (!ctx || !q || !t || !d_scores) { rsk_set_error("rsk_mu_sw_matrix_dev: NULL argument"); return RSK_E_INVALID; }
+    if (!q->d_mu || !t->d_mu) { rsk_set_error("rsk_mu_sw_matrix_dev: chain set has no Mu letters"); return RSK_E_INVALID; }
+    if (ldo < t->n) { rsk_set_error("rsk_mu_sw_matrix_dev: ldo < number of targets"); return RSK_E_INVALID; }
+    if (self_triangle && q != t) { rsk_set_error("rsk_mu_sw_matrix_dev: self_triangle needs q == t"); return RSK_E_INVALID; }
+    if (gap_open < 0 || gap_ext < 0) { rsk_set_error("rsk_mu_sw_matrix_dev: gap costs must be >= 0"); return RSK_E_INVALID; }
+    RSK_HIP(hipSetDevice(ctx->device));
+    int rc = rsk_upload_mu_tables(ctx);
+    if (rc != RSK_OK) return rc;
+    musw_ws ws;
+    if ((rc = ws.alloc(&ws.first, q->n)) != RSK_OK) return rc;
+    if ((rc = ws.alloc(&ws.cnt, q->n)) != RSK_OK) return rc;
+    RSK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    hipLaunchKernelGGL(k_musw_setup_implicit, dim3((q->n + 255) / 256), dim3(256), 0, ctx->stream, q->n, t->n, self_triangle,
+                       ws.first, ws.cnt);
+    musw_args a = {};
+    a.q_mu = q->d_mu; a.q_off = q->d_off; a.q_len = q->d_len;
+    a.t_mu = t->d_mu; a.t_off = t->d_off; a.t_len = t->d_len;
+    a.cnt = ws.cnt; a.first = ws.first; a.list = nullptr; a.rowstart = nullptr;
+    a.reverse = reverse_query ? 1 : 0; a.open = gap_open; a.ext = gap_ext;
+    a.out = d_scores; a.ldo = ldo;
+    rc = run_mu_sw_lists(ctx, q, t, a, item_exact_implicit(q, t->n, self_triangle), ws);
+    if (rc != RSK_OK) return rc;
+    RSK_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    RSK_HIP(hipStreamSynchronize(ctx->stream));   // workspace is freed on return
+    return RSK_OK;
+}
+
+extern "C" int rsk_mu_filter_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int self_triangle, int gap_open, int gap_ext,
+                                 float omega, float omega_fwd, uint8_t *d_fwd, size_t ldo, uint32_t *d_pairs_q,
+                                 uint32_t *d_pairs_t, int32_t *d_pairs_fwd, int32_t *d_pairs_rev, size_t capacity,
+                                 uint32_t *d_npairs)
+{
+    if (!ctx || !q || !t || !d_fwd || !d_pairs_q || !d_pairs_t || !d_npairs) { rsk_set_error("rsk_mu_filter_dev: NULL argument"); return RSK_E_INVALID; }
+    if (!q->d_mu || !t->d_mu) { rsk_set_error("rsk_mu_filter_dev: chain set has no Mu letters"); return RSK_E_INVALID; }
+    if (ldo < t->n) { rsk_set_error("rsk_mu_filter_dev: ldo < number of targets"); return RSK_E_INVALID; }
+    if (self_triangle && q != t) { rsk_set_error("rsk_mu_filter_dev: self_triangle needs q == t"); return RSK_E_INVALID; }
+    if (capacity > 0xFFFFFFFFull) capacity = 0xFFFFFFFFull;
+    RSK_HIP(hipSetDevice(ctx->device));
+    int rc = rsk_upload_mu_tables(ctx);
+    if (rc != RSK_OK) return rc;
+    const uint32_t nq = q->n;
+    musw_ws ws, ws2;
+    if ((rc = ws.alloc(&ws.first, nq)) != RSK_OK) return rc;
+    if ((rc = ws.alloc(&ws.cnt, nq)) != RSK_OK) return rc;
+    RSK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    RSK_HIP(hipMemsetAsync(d_npairs, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(k_musw_setup_implicit, dim3((nq + 255) / 256), dim3(256), 0, ctx->stream, nq, t->n, self_triangle, ws.first,
+                       ws.cnt);
+    musw_args a = {};
+    a.q_mu = q->d_mu; a.q_off = q->d_off; a.q_len = q->d_len;
+    a.t_mu = t->d_mu; a.t_off = t->d_off; a.t_len = t->d_len;
+    a.cnt = ws.cnt; a.first = ws.first;
+    a.reverse = 0; a.open = gap_open; a.ext = gap_ext;
+    a.out = d_fwd; a.ldo = ldo;
+    const uint64_t total = self_triangle ? (uint64_t) nq * (nq + 1) / 2 : (uint64_t) nq * t->n;
+    if ((rc = run_mu_sw_lists(ctx, q, t, a, item_exact_implicit(q, t->n, self_triangle), ws)) != RSK_OK) return rc;
+    // candidates with fwd' >= OmegaFwd -> CSR lists
+    uint32_t *ccnt = nullptr, *rowstart = nullptr, *list = nullptr;
+    uint8_t *rev = nullptr;
+    if ((rc = ws.alloc(&ccnt, nq)) != RSK_OK) return rc;
+    if ((rc = ws.alloc(&rowstart, (size_t) nq + 1)) != RSK_OK) return rc;
+    hipLaunchKernelGGL(k_musw_candidates, dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, d_fwd, ldo, ws.first, ws.cnt, nq, omega_fwd,
+                       0, ccnt, (const uint32_t *) nullptr, (uint32_t *) nullptr);
+    hipLaunchKernelGGL(k_exclusive_scan_u32, dim3(1), dim3(1024), 0, ctx->stream, ccnt, nq, rowstart);
+    uint32_t ncand = 0;
+    RSK_HIP(hipMemcpyAsync(&ncand, rowstart + nq, 4, hipMemcpyDeviceToHost, ctx->stream));
+    RSK_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->mf_pairs = total;
+    ctx->mf_candidates = ncand;
+    if (ncand) {
+        if ((rc = ws.alloc(&list, ncand)) != RSK_OK) return rc;
+        if ((rc = ws.alloc(&rev, ncand)) != RSK_OK) return rc;
+        hipLaunchKernelGGL(k_musw_candidates, dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, d_fwd, ldo, ws.first, ws.cnt, nq,
+                           omega_fwd, 1, ccnt, rowstart, list);
+        musw_args b = a;
+        b.cnt = ccnt; b.first = nullptr; b.list = list; b.rowstart = rowstart;
+        b.reverse = 1; b.out = rev;
+        if ((rc = run_mu_sw_lists(ctx, q, t, b, item_upper_bound(q, ncand), ws2)) != RSK_OK) return rc;
+        hipLaunchKernelGGL(k_musw_survivors, dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, d_fwd, ldo, ccnt, rowstart, list, rev, nq,
+                           omega, d_pairs_q, d_pairs_t, d_pairs_fwd, d_pairs_rev, (uint32_t) capacity, d_npairs);
+    }
+    RSK_HIP(hipGetLastError());
+    RSK_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    RSK_HIP(hipStreamSynchronize(ctx->stream));   // workspace is freed on return
+    return RSK_OK;
+}
+
+extern "C" int rsk_mu_filter_last_work(rsk_ctx *ctx, uint64_t *pairs, uint64_t *candidates)
+{
+    if (!ctx) { rsk_set_error("rsk_mu_filter_last_work: ctx is NULL"); return RSK_E_INVALID; }
+    if (pairs) *pairs = ctx->mf_pairs;
+    if (candidates) *candidates = ctx->mf_candidates;
+    return RSK_OK;
+}

@@ -26,6 +26,7 @@ struct rsk_ctx {
     float last_ms = -1.0f;
     // accounting of the last gapless matrix call
     uint64_t gl_pairs = 0, gl_cells = 0, gl_slots = 0;
+    uint64_t mf_pairs = 0, mf_candidates = 0;   // last Mu filter call
     int num_cus = 0;
 };
 

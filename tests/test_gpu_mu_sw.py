@@ -1,0 +1,146 @@
+"""GPU parity: Mu-letter affine SW score + the Mu filter through the C-ABI
+vs the reference's own outputs (tests/golden) and the CPU oracle."""
+import numpy as np
+import pytest
+
+import fixtures as fx
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+    import reseek_amd
+    assert torch.cuda.is_available()
+    c = reseek_amd.Ctx(0, stream=torch.cuda.current_stream().cuda_stream)
+    yield c
+    c.close()
+
+
+def run_sw_matrix(ctx, seqs_q, seqs_t=None, tri=False, reverse=False):
+    import torch
+    import reseek_amd
+    q = reseek_amd.Db.from_mu_seqs(ctx, seqs_q)
+    t = q if seqs_t is None else reseek_amd.Db.from_mu_seqs(ctx, seqs_t)
+    nq, nt = len(seqs_q), (len(seqs_q) if seqs_t is None else len(seqs_t))
+    out = torch.full((nq, nt), 77, dtype=torch.uint8, device="cuda")
+    ctx.mu_sw_matrix_dev(q, t, tri, reverse, out.data_ptr(), nt)
+    torch.cuda.synchronize()
+    res = out.cpu().numpy().astype(np.int32)
+    q.close()
+    if t is not q:
+        t.close()
+    return res
+
+
+def run_filter(ctx, seqs, omega, omega_fwd, tri=True, seqs_t=None):
+    import torch
+    import reseek_amd
+    q = reseek_amd.Db.from_mu_seqs(ctx, seqs)
+    t = q if seqs_t is None else reseek_amd.Db.from_mu_seqs(ctx, seqs_t)
+    nq, nt = q.n, t.n
+    fwd = torch.zeros((nq, nt), dtype=torch.uint8, device="cuda")
+    cap = nq * nt
+    pq = torch.zeros(cap, dtype=torch.int32, device="cuda")
+    pt = torch.zeros(cap, dtype=torch.int32, device="cuda")
+    pf = torch.zeros(cap, dtype=torch.int32, device="cuda")
+    pr = torch.zeros(cap, dtype=torch.int32, device="cuda")
+    n = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ctx.mu_filter_dev(q, t, tri, omega, omega_fwd, fwd.data_ptr(), nt, pq.data_ptr(), pt.data_ptr(), pf.data_ptr(),
+                      pr.data_ptr(), cap, n.data_ptr())
+    torch.cuda.synchronize()
+    k = int(n.item())
+    res = {(int(a), int(b)): (int(f), int(r)) for a, b, f, r in zip(pq[:k].cpu(), pt[:k].cpu(), pf[:k].cpu(), pr[:k].cpu())}
+    assert len(res) == k
+    work = ctx.mu_filter_last_work()
+    q.close()
+    if t is not q:
+        t.close()
+    return res, fwd.cpu().numpy().astype(np.int32), work
+
+
+def test_q100_raw_scores_match_reference(ctx):
+    chains = fx.read_rskdb("q100_sensitive.rskdb.gz")
+    _, recs = fx.read_pairs("pairs_q100_sensitive.bin.gz")
+    seqs = [c.mu for c in chains]
+    fwd = run_sw_matrix(ctx, seqs, tri=True)
+    rev = run_sw_matrix(ctx, seqs, tri=True, reverse=True)
+    nsat = 0
+    for r in recs:
+        assert fwd[r["i"], r["j"]] == r["para_fwd"], (r["i"], r["j"], r["LA"], r["LB"])
+        assert rev[r["i"], r["j"]] == r["para_rev"]
+        nsat += r["para_fwd_sat"]
+    assert nsat >= 100
+
+
+def test_q100_filter_matches_reference_sensitive_and_fast(ctx):
+    chains = fx.read_rskdb("q100_sensitive.rskdb.gz")
+    _, recs = fx.read_pairs("pairs_q100_sensitive.bin.gz")
+    seqs = [c.mu for c in chains]
+    # the fixture's mufilter value was produced with OmegaFwd = 20 (Sensitive); pass iff >= Omega = 12
+    res, fwd, work = run_filter(ctx, seqs, 12.0, 20.0)
+    want = {(r["i"], r["j"]) for r in recs if r["mufilter"] >= 12.0}
+    assert set(res) == want
+    for r in recs:
+        key = (r["i"], r["j"])
+        if key in res:
+            f, rv = res[key]
+            assert f == (777 if r["para_fwd_sat"] else r["para_fwd"])
+            assert rv == r["para_rev"]             # 255 when saturated
+            assert float(f - rv) == r["mufilter"]
+    assert work[0] == 5050 and work[1] == sum(1 for r in recs if (777 if r["para_fwd_sat"] else r["para_fwd"]) >= 20)
+    # Fast preset (22 / 50) from the raw scores
+    res2, _, _ = run_filter(ctx, seqs, 22.0, 50.0)
+    want2 = set()
+    for r in recs:
+        f = 777 if r["para_fwd_sat"] else r["para_fwd"]
+        if f >= 50 and f - r["para_rev"] >= 22:
+            want2.add((r["i"], r["j"]))
+    assert set(res2) == want2
+
+
+def test_scop40_real_sequences_full_matrix(ctx):
+    seqs, tab = fx.read_mukat("mukat_scop40_160.bin.gz")
+    got = run_sw_matrix(ctx, seqs, seqs)
+    assert np.array_equal(got, tab[:, :, 0])
+    assert (tab[:, :, 1] == (tab[:, :, 0] == 255)).all()
+
+
+def test_random_and_adversarial_pairs_vs_reference_kat(ctx):
+    kat = fx.read_randkat("randkat_3000.bin.gz")[:600]
+    qs = [k[0] for k in kat]
+    ts = [k[1] for k in kat]
+    got = run_sw_matrix(ctx, qs, ts)
+    for i, k in enumerate(kat):
+        assert got[i, i] == k[2], (i, len(k[0]), len(k[1]))
+
+
+def test_lengths_edge_cases_vs_oracle(ctx):
+    rng = np.random.default_rng(3)
+    lens = [1, 2, 31, 32, 33, 63, 64, 65, 224, 225, 416, 417, 700, 1056, 1057, 1500, 2048, 2049, 2300]
+    seqs = [rng.integers(0, 36, L).astype(np.uint8) for L in lens]
+    seqs += [rng.integers(0, 4, L).astype(np.uint8) for L in (40, 300, 1200)]     # low complexity -> saturation
+    got = run_sw_matrix(ctx, seqs, tri=True)
+    rev = run_sw_matrix(ctx, seqs, tri=True, reverse=True)
+    n = len(seqs)
+    for i in range(n):
+        for j in range(i, n):
+            assert got[i, j] == ol.mu_sw(seqs[i], seqs[j])[0], (lens[i] if i < len(lens) else -1, j)
+            assert rev[i, j] == ol.mu_sw(seqs[i][::-1].copy(), seqs[j])[0]
+
+
+def test_rectangular_and_unsorted_targets(ctx):
+    rng = np.random.default_rng(9)
+    qs = [rng.integers(0, 36, int(L)).astype(np.uint8) for L in rng.integers(10, 500, 23)]
+    ts = [rng.integers(0, 36, int(L)).astype(np.uint8) for L in rng.integers(3, 900, 157)]
+    got = run_sw_matrix(ctx, qs, ts)
+    f, _, _ = ol.mu_filter_pairs(qs + ts, np.repeat(np.arange(23), 157), np.tile(np.arange(157), 23) + 23, 1e9)
+    f = np.where(f == 777, 255, f).reshape(23, 157)
+    assert np.array_equal(got, f)
+    res, fwd, _ = run_filter(ctx, qs, 3.0, 10.0, tri=False, seqs_t=ts)
+    ff, rr, ss = ol.mu_filter_pairs(qs + ts, np.repeat(np.arange(23), 157), np.tile(np.arange(157), 23) + 23, 10.0)
+    want = {(int(a), int(b)) for a, b, f1, s1 in zip(np.repeat(np.arange(23), 157), np.tile(np.arange(157), 23), ff, ss)
+            if f1 >= 10 and s1 >= 3.0}
+    assert set(res) == want and len(want) > 5
