@@ -115,6 +115,36 @@ int rsk_mu_filter_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int self_t
  * needed the reverse pass, cf. dssaligner.h:90-96). */
 int rsk_mu_filter_last_work(rsk_ctx *ctx, uint64_t *pairs, uint64_t *candidates);
 
+/* ---- P5/P6/P7: the main alignment --------------------------------------------------------------
+ * Batch form of DSSAligner::Align_NoAccel (dssaligner.cpp:929): SetSMx_NoRev (:529, fused) + SWFast
+ * (sw.cpp:79) + TraceBackBitSW (sw.cpp:8) + CalcEvalue (:852; LDDT lddt.cpp:63, StatSig
+ * statsig.cpp:27-50).  One record per pair; fields are the reference's result members
+ * (dssaligner.h:46-69).  "No alignment" is path_len == 0 / evalue == FLT_MAX, as in the reference
+ * (m_Path.empty(), m_EvalueA == FLT_MAX). */
+typedef struct rsk_aln {
+    float score;            /* m_AlnFwdScore (bit-exact) */
+    uint32_t lo_a, lo_b;    /* m_LoA, m_LoB (0-based; RSK_NO_POS if score == 0) */
+    uint32_t hi_a, hi_b;    /* m_HiA, m_HiB (RSK_NO_POS when CalcEvalue was skipped) */
+    uint32_t ids, gaps;     /* m_Ids (M columns), m_Gaps (D + I) */
+    uint32_t path_len;      /* strlen(m_Path) */
+    uint64_t path_off;      /* offset of the NUL-terminated path (chars M/D/I) in `paths` */
+    float lddt, ts;         /* GetLDDT(), m_NewTestStatisticA (-FLT_MAX if skipped) */
+    float pvalue, evalue, qual; /* m_PvalueA, m_EvalueA, m_QualityA (FLT_MAX if skipped) */
+} rsk_aln;
+/* Bytes the `paths` buffer of rsk_align_pairs must hold for this pair list. */
+size_t rsk_align_paths_bytes(const rsk_db *a, const rsk_db *b, const uint32_t *ia, const uint32_t *ib,
+                             size_t npairs);
+/* Aligns chain ia[p] of set a (rows, "A"/query of the reference) with chain ib[p] of set b.
+ * gap_open/gap_ext are the reference's m_GapOpen/m_GapExt (<= 0; defaults -0.685533/-0.051881,
+ * namedparams.cpp:45-46).  min_fwd_score = m_MinFwdScore (7.0; 0 for -verysensitive): pairs scoring
+ * below it keep evalue = FLT_MAX (dssaligner.cpp:861).  Statistics need coordinates and self-rev
+ * scores in both chain sets and a non-NULL `paths`.  Synchronous. */
+int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *a, const rsk_db *b, const uint32_t *ia, const uint32_t *ib,
+                    size_t npairs, float gap_open, float gap_ext, float min_fwd_score, rsk_aln *out,
+                    char *paths, size_t paths_bytes);
+/* Pairs, DP cells (sum LA*LB) and trace bytes written to HBM by the last rsk_align_pairs call. */
+int rsk_align_last_work(rsk_ctx *ctx, uint64_t *pairs, uint64_t *cells, uint64_t *tb_bytes);
+
 #ifdef __cplusplus
 }
 #endif

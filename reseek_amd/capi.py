@@ -42,6 +42,22 @@ SIGNATURES = {
 }
 
 
+class Aln(C.Structure):
+    _fields_ = [("score", C.c_float), ("lo_a", C.c_uint32), ("lo_b", C.c_uint32), ("hi_a", C.c_uint32),
+                ("hi_b", C.c_uint32), ("ids", C.c_uint32), ("gaps", C.c_uint32), ("path_len", C.c_uint32),
+                ("path_off", C.c_uint64), ("lddt", C.c_float), ("ts", C.c_float), ("pvalue", C.c_float),
+                ("evalue", C.c_float), ("qual", C.c_float)]
+
+
+SIGNATURES["rsk_align_paths_bytes"] = (C.c_size_t, [C.c_void_p, C.c_void_p, u32p, u32p, C.c_size_t])
+SIGNATURES["rsk_align_pairs"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, u32p, u32p, C.c_size_t, C.c_float, C.c_float,
+                                           C.c_float, C.POINTER(Aln), C.c_char_p, C.c_size_t])
+SIGNATURES["rsk_align_last_work"] = (C.c_int, [C.c_void_p, u64p, u64p, u64p])
+
+GAP_OPEN = -0.685533     # namedparams.cpp:45
+GAP_EXT = -0.051881      # namedparams.cpp:46
+
+
 class RskError(RuntimeError):
     pass
 
@@ -129,6 +145,25 @@ class Ctx:
         a, b = C.c_uint64(), C.c_uint64()
         _check(lib().rsk_mu_filter_last_work(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    # ---- P5/P6/P7 main alignment ---------------------------------------------------------------
+    def align_pairs(self, a, b, ia, ib, min_fwd_score=7.0, gap_open=GAP_OPEN, gap_ext=GAP_EXT):
+        """-> list of (Aln, path str)"""
+        ia = np.ascontiguousarray(ia, np.uint32)
+        ib = np.ascontiguousarray(ib, np.uint32)
+        n = len(ia)
+        nbytes = lib().rsk_align_paths_bytes(a.h, b.h, _p(ia, u32p), _p(ib, u32p), n)
+        buf = C.create_string_buffer(max(1, nbytes))
+        out = (Aln * max(1, n))()
+        _check(lib().rsk_align_pairs(self.h, a.h, b.h, _p(ia, u32p), _p(ib, u32p), n, gap_open, gap_ext, min_fwd_score,
+                                     out, buf, nbytes))
+        raw = buf.raw
+        return [(out[k], raw[out[k].path_off:out[k].path_off + out[k].path_len].decode()) for k in range(n)]
+
+    def align_last_work(self):
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _check(lib().rsk_align_last_work(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     def mu_gapless_last_work(self):
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()

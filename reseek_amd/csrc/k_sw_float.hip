@@ -1,0 +1,563 @@
+// k_sw_float.hip -- the main alignment of reseek -search on gfx950:
+//   P5 DSSAligner::SetSMx_NoRev dssaligner.cpp:529  S(i,j) = ((((((M0+M1)+M2)+M3)+M4)+M5)+M6)+M7, fp32
+//   P6 SWFast sw.cpp:79 + TraceBackBitSW sw.cpp:8   3-state affine local SW, 1 trace byte per cell
+//   P7 GetLDDT_mu_fast lddt.cpp:63 (+ the test statistic of CalcEvalue dssaligner.cpp:852-889)
+// Bit-exact: every fp32 operation of the reference is executed with the same operands in the same
+// order (this file is compiled with -ffp-contract=off; no FMA, no reassociation).
+//
+// The reference evaluates one DP "grid point" (i,j) at a time (sw.cpp:119-197):
+//   in : m = DPM[i][j], d = DPD[i][j], n = DPI[i][j], S(i,j)
+//   out: DPM[i+1][j+1] = max*(m, d, n, 0) + S      (max* = the reference's tie order M, D(>), I(>), 0(>=))
+//        DPD[i+1][j]   = max(m + Open (>=), d + Ext),   DPI[i][j+1] = max(m + Open (>=), n + Ext)
+//        TB[i][j]      = how each of the three was chosen.
+// A point depends only on its up-left / up / left neighbours, so any evaluation order gives the
+// same bits.  Layout on the GPU (same systolic scheme as the Mu filter, k_mu_sw.hip):
+//   * chain A is cut into strips of R = 16 rows that live in the VGPRs of one lane (DPM-diagonal and
+//     DPI per row); the g = ceil(LA/16) strips of a pair sit on g consecutive lanes, one column behind
+//     each other; the bottom row (DPM, DPD) moves to the next lane with two v_mov_b32_dpp wave_shr:1.
+//     A wave works on floor(64/g) pairs at once.
+//   * S(i,j) is fused: the 8 weighted feature tables (8.8 KB) sit in LDS; each lane keeps the table
+//     row offsets of its 16 A-rows packed in registers, the B column contributes 8 byte offsets.
+//   * trace bytes of the 16 rows of a lane are one 16-byte store into a column-major TB[j][i] block
+//     in HBM (the only HBM-heavy stream of the path: 1 B per cell).
+//   * a second kernel walks the trace (one thread per pair), a third computes LDDT over the aligned
+//     columns (one wave per pair).
+#include <algorithm>
+#include <cfloat>
+#include <cstring>
+#include <cmath>
+#include <numeric>
+#include <vector>
+
+#include "rsk_internal.h"
+#include "rsk_tables_data.h"
+
+#define SWF_R 16
+#define SWF_WAVES 4
+#define SWF_MINUS_INF (-9e9f)        // xdpmem.h:6
+#define TB_DM 0x01                   // tracebit.h:4-8
+#define TB_IM 0x02
+#define TB_MD 0x04
+#define TB_MI 0x08
+#define TB_SM 0x10
+
+// feature tables in LDS: table f at float offset swf_toff[f], row stride = alphabet size; then a pad row
+struct swf_tables {
+    float t[400 + 7 * 256 + 32];
+};
+static __device__ __constant__ swf_tables c_swf_tables;
+static const int h_swf_toff[8] = { 0, 400, 656, 912, 1168, 1424, 1680, 1936 };
+#define SWF_PAD_OFF 2192            // 20 floats of -1e30 (rows beyond LA)
+#define SWF_TABLE_FLOATS (2192 + 32)
+
+static int swf_upload_tables(rsk_ctx *ctx)
+{
+    static bool done[64] = { false };
+    if (ctx->device < 64 && done[ctx->device]) return RSK_OK;
+    swf_tables h;
+    for (int i = 0; i < SWF_TABLE_FLOATS; ++i) h.t[i] = -1e30f;
+    for (int f = 0; f < RSK_NFEATURES; ++f) {
+        const int as = (int) rsk_feature_alpha[f];
+        for (int a = 0; a < as; ++a)
+            for (int b = 0; b < as; ++b) h.t[h_swf_toff[f] + a * as + b] = rsk_feature_mx[f][a * RSK_FEATURE_DIM + b];
+    }
+    RSK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_swf_tables), &h, sizeof(h)));
+    if (ctx->device < 64) done[ctx->device] = true;
+    return RSK_OK;
+}
+
+struct swf_item {            // one wave's work: pairs [first, first+count), g lanes per pair
+    uint32_t first, count, g, pad;
+};
+
+struct swf_args {
+    const uint8_t *a_prof;   // [8][npadA] feature-major
+    const uint32_t *a_off, *a_len;
+    const uint16_t *b_cb;    // [npadB][8] byte offsets (letter*4) per residue
+    const uint32_t *b_off, *b_len;
+    const uint32_t *ia, *ib; // pair lists (sorted order used by the items)
+    size_t a_npad;
+    const swf_item *items;
+    uint32_t nitems;
+    float open, ext;
+    uint8_t *tb;             // trace blocks, pair p at tb + tb_off[p], layout [j][LApad]
+    const uint64_t *tb_off;
+    float *score;            // per pair
+    uint32_t *besti, *bestj;
+};
+
+__device__ __forceinline__ float dpp_shr1_f(float x)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x),
+                                                                  0x138 /* wave_shr:1 */, 0xF, 0xF, false));
+}
+
+__global__ __launch_bounds__(64 * SWF_WAVES) void k_sw_float(swf_args a)
+{
+    __shared__ __attribute__((aligned(16))) float tab[SWF_TABLE_FLOATS];
+    for (int i = threadIdx.x; i < SWF_TABLE_FLOATS; i += blockDim.x) tab[i] = c_swf_tables.t[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const uint32_t item_id = blockIdx.x * SWF_WAVES + (threadIdx.x >> 6);
+    if (item_id >= a.nitems) return;
+    const swf_item it = a.items[item_id];
+    const uint32_t g = it.g;
+    const uint32_t pr = lane / g, st = lane - pr * g;
+    const bool active = pr < it.count;
+    const uint32_t p = it.first + (active ? pr : 0);
+    const uint32_t A = a.ia[p], B = a.ib[p];
+    const uint32_t LA = a.a_len[A], LB = a.b_len[B];
+    const uint32_t LApad = (LA + 15) & ~15u;
+    const uint32_t i0 = st * SWF_R;
+    const bool lane_has_rows = active && i0 < LA;
+
+    // table row offsets (bytes) of this lane's 16 rows, two features per dword
+    const int toffb[8] = { 0 * 4, 400 * 4, 656 * 4, 912 * 4, 1168 * 4, 1424 * 4, 1680 * 4, 1936 * 4 };
+    const int asz[8] = { 20, 16, 16, 16, 16, 16, 16, 16 };
+    uint32_t ro[SWF_R][4];
+#pragma unroll
+    for (int r = 0; r < SWF_R; ++r)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ro[r][k] = (uint32_t) (SWF_PAD_OFF * 4) * 0x10001u;
+    if (lane_has_rows) {
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+            const uint8_t *src = a.a_prof + (size_t) f * a.a_npad + a.a_off[A] + i0;   // 16-byte aligned (chains padded to 16)
+            const uint4 w = *(const uint4 *) src;
+            const uint32_t ww[4] = { w.x, w.y, w.z, w.w };
+#pragma unroll
+            for (int r = 0; r < SWF_R; ++r) {
+                const uint32_t letter = (ww[r >> 2] >> (8 * (r & 3))) & 0xFF;
+                uint32_t off = (uint32_t) toffb[f] + letter * (uint32_t) (asz[f] * 4);
+                if (i0 + r >= LA) off = SWF_PAD_OFF * 4;
+                if (f & 1) ro[r][f >> 1] = (ro[r][f >> 1] & 0xFFFFu) | (off << 16);
+                else ro[r][f >> 1] = (ro[r][f >> 1] & 0xFFFF0000u) | off;
+            }
+        }
+    }
+
+    float Md[SWF_R], In[SWF_R];      // DPM[i][j] (diagonal input of row r at the next column), DPI[i][j]
+#pragma unroll
+    for (int r = 0; r < SWF_R; ++r) { Md[r] = SWF_MINUS_INF; In[r] = SWF_MINUS_INF; }
+    if (st == 0) Md[0] = 0.0f;        // DPM[0][0] = 0 (sw.cpp:117)
+    float best = 0.0f;
+    uint32_t bi = 0xFFFFFFFFu, bj = 0xFFFFFFFFu;
+    float hand_m = SWF_MINUS_INF, hand_d = SWF_MINUS_INF;   // bottom row of this strip at its previous column
+    float carry_in = SWF_MINUS_INF;                         // DPM[i0][j] from the lane above (arrives one step early)
+    const float Open = a.open, Ext = a.ext;
+    const uint16_t *bcb = a.b_cb + (size_t) a.b_off[B] * 8;
+    uint8_t *tbp = a.tb + a.tb_off[p] + i0;
+    const char *tabb = (const char *) tab;
+
+    uint32_t ncol = lane_has_rows ? (LB + st) : 0;
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) ncol = max(ncol, (uint32_t) __shfl_xor((int) ncol, s, 64));
+
+    uint4 cbn = make_uint4(0, 0, 0, 0);
+    if (lane_has_rows) cbn = *(const uint4 *) bcb;
+
+    for (uint32_t col = 0; col < ncol; ++col) {
+        const int j = (int) col - (int) st;
+        // bottom row of the strip above: its DPD chain value for this column j and its new DPM (for column j+1)
+        const float in_m = dpp_shr1_f(hand_m);
+        const float in_d = dpp_shr1_f(hand_d);
+        if (lane_has_rows && j >= 0 && (uint32_t) j < LB) {
+            const uint4 cb = cbn;
+            cbn = *(const uint4 *) (bcb + (size_t) (j + 1) * 8);      // prefetch (chain set has tail padding)
+            const uint32_t cbw[4] = { cb.x, cb.y, cb.z, cb.w };
+            uint32_t cbo[8];
+#pragma unroll
+            for (int f = 0; f < 8; ++f) cbo[f] = (f & 1) ? (cbw[f >> 1] >> 16) : (cbw[f >> 1] & 0xFFFFu);
+            // row 0 inputs
+            float d = (st == 0) ? SWF_MINUS_INF : in_d;                 // DPD[i0][j]
+            if (st != 0) Md[0] = carry_in;                              // DPM[i0][j] = bottom DPM of the strip above at column j-1
+            else if (j > 0) Md[0] = SWF_MINUS_INF;                      // DPM[0][j>0] = -inf (sw.cpp:102-111)
+            float carry = SWF_MINUS_INF;                                // DPM[i0+r][j+1] produced by row r-1
+            uint32_t tbw[4] = { 0, 0, 0, 0 };
+#pragma unroll
+            for (int r = 0; r < SWF_R; ++r) {
+                // S(i,j): features summed 0 -> 7 (dssaligner.cpp:553-597)
+                float S = *(const float *) (tabb + ((ro[r][0] & 0xFFFFu) + cbo[0]));
+                S += *(const float *) (tabb + ((ro[r][0] >> 16) + cbo[1]));
+                S += *(const float *) (tabb + ((ro[r][1] & 0xFFFFu) + cbo[2]));
+                S += *(const float *) (tabb + ((ro[r][1] >> 16) + cbo[3]));
+                S += *(const float *) (tabb + ((ro[r][2] & 0xFFFFu) + cbo[4]));
+                S += *(const float *) (tabb + ((ro[r][2] >> 16) + cbo[5]));
+                S += *(const float *) (tabb + ((ro[r][3] & 0xFFFFu) + cbo[6]));
+                S += *(const float *) (tabb + ((ro[r][3] >> 16) + cbo[7]));
+                const float m = Md[r];
+                const float n = In[r];
+                Md[r] = carry;                      // becomes this row's diagonal input at the next column
+                // MATCH (sw.cpp:123-155)
+                float xM = m;
+                uint32_t t = 0;
+                if (d > xM) { xM = d; t = TB_DM; }
+                if (n > xM) { xM = n; t = TB_IM; }
+                if (0.0f >= xM) { xM = 0.0f; t = TB_SM; }
+                xM += S;
+                if (xM >= best) {
+                    const uint32_t ii = i0 + r, jj = (uint32_t) j;
+                    if (xM > best || (best > 0.0f && (ii < bi || (ii == bi && jj < bj)))) { best = xM; bi = ii; bj = jj; }
+                }
+                carry = xM;
+                // DELETE (sw.cpp:163-176): DPD[i+1][j]
+                const float md = m + Open;
+                float dd = d + Ext;
+                if (md >= dd) { dd = md; t |= TB_MD; }
+                d = dd;
+                // INSERT (sw.cpp:178-191): DPI[i][j+1]
+                float ni = n + Ext;
+                if (md >= ni) { ni = md; t |= TB_MI; }
+                In[r] = ni;
+                tbw[r >> 2] |= t << (8 * (r & 3));
+            }
+            hand_m = carry;      // DPM[i0+16][j+1]
+            hand_d = d;          // DPD[i0+16][j]
+            *(uint4 *) (tbp + (size_t) j * LApad) = make_uint4(tbw[0], tbw[1], tbw[2], tbw[3]);
+        }
+        carry_in = in_m;         // value sent by the lane above at this step is for its column j+1 == our next column
+    }
+    // reduce (best, bi, bj) over the strips of each pair with the row-major-first rule (sw.cpp:153-158)
+    for (uint32_t dlt = 1; dlt < g; ++dlt) {
+        const int src = (lane + dlt) & 63;
+        const float ob = __shfl(best, src, 64);
+        const uint32_t oi = (uint32_t) __shfl((int) bi, src, 64), oj = (uint32_t) __shfl((int) bj, src, 64);
+        if (st + dlt < g) {
+            if (ob > best || (ob == best && ob > 0.0f && (oi < bi || (oi == bi && oj < bj)))) { best = ob; bi = oi; bj = oj; }
+        }
+    }
+    if (active && st == 0) {
+        a.score[p] = best;
+        a.besti[p] = bi;
+        a.bestj[p] = bj;
+    }
+}
+
+// TraceBackBitSW sw.cpp:8-77.  One thread per pair; path chars are written backwards into
+// paths[path_end[p]-1 ...]; path_start/path_len describe the result.
+__global__ void k_traceback(const uint8_t *tb, const uint64_t *tb_off, const uint32_t *ia, const uint32_t *a_len,
+                            const float *score, const uint32_t *besti, const uint32_t *bestj, uint32_t npairs,
+                            char *paths, const uint64_t *path_end, uint64_t *path_start, uint32_t *path_len,
+                            uint32_t *lo_a, uint32_t *lo_b)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npairs) return;
+    path_len[p] = 0;
+    path_start[p] = path_end[p];
+    lo_a[p] = RSK_NO_POS;
+    lo_b[p] = RSK_NO_POS;
+    if (score[p] == 0.0f) return;                     // sw.cpp:200-201
+    const uint32_t LApad = (a_len[ia[p]] + 15) & ~15u;
+    const uint8_t *T = tb + tb_off[p];
+    uint32_t i = besti[p] + 1, j = bestj[p] + 1;      // 1-based
+    const uint32_t Besti = i, Bestj = j;
+    uint64_t w = path_end[p];
+    int state = 0;                                    // 0 M, 1 D, 2 I
+    uint32_t n = 0;
+    for (;;) {
+        paths[--w] = state == 0 ? 'M' : (state == 1 ? 'D' : 'I');
+        ++n;
+        if (state == 0) {
+            const uint8_t t = T[(size_t) (j - 1) * LApad + (i - 1)];
+            if (t & TB_DM) state = 1;
+            else if (t & TB_IM) state = 2;
+            else if (t & TB_SM) break;
+            --i; --j;
+        } else if (state == 1) {
+            const uint8_t t = T[(size_t) j * LApad + (i - 1)];
+            state = (t & TB_MD) ? 0 : 1;
+            --i;
+        } else {
+            const uint8_t t = T[(size_t) (j - 1) * LApad + i];
+            state = (t & TB_MI) ? 0 : 2;
+            --j;
+        }
+    }
+    path_start[p] = w;
+    path_len[p] = n;
+    const uint32_t leni = Besti - i + 1, lenj = Bestj - j + 1;
+    lo_a[p] = Besti - leni;
+    lo_b[p] = Bestj - lenj;
+}
+
+// GetLDDT_mu_fast lddt.cpp:63-124 over the M columns of a path (GetPosABs dssaligner.cpp:1282).
+// One wave per pair.  The reference's symmetric accumulation over column pairs c < c' equals, per
+// column, the sum over all other columns (integer counts), so each lane owns whole columns.
+__global__ __launch_bounds__(256) void k_lddt(const char *paths, const uint64_t *path_start, const uint32_t *path_len,
+                                              const uint32_t *lo_a, const uint32_t *lo_b, const uint32_t *ia, const uint32_t *ib,
+                                              const uint32_t *a_off, const uint32_t *b_off,
+                                              const float *ax, const float *ay, const float *az,
+                                              const float *bx, const float *by, const float *bz,
+                                              uint32_t npairs, uint32_t *scratch_pos, const uint64_t *scratch_off,
+                                              float *frac_scratch, float *lddt_out, uint32_t *counts_out)
+{
+    const uint32_t p = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (p >= npairs) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t len = path_len[p];
+    uint32_t *posA = scratch_pos + 2 * scratch_off[p];
+    uint32_t *posB = posA + (scratch_off[p + 1] - scratch_off[p]);
+    float *frac = frac_scratch + scratch_off[p];
+    // lane 0 expands the path (sequential, short)
+    uint32_t ncols = 0, nM = 0, nD = 0, nI = 0;
+    if (lane == 0) {
+        const char *P = paths + path_start[p];
+        uint32_t pa = lo_a[p], pb = lo_b[p];
+        for (uint32_t c = 0; c < len; ++c) {
+            const char ch = P[c];
+            if (ch == 'M') { posA[nM] = pa++; posB[nM] = pb++; ++nM; }
+            else if (ch == 'D') { ++pa; ++nD; }
+            else { ++pb; ++nI; }
+        }
+        ncols = nM;
+        if (counts_out) { counts_out[3 * p] = nM; counts_out[3 * p + 1] = nD; counts_out[3 * p + 2] = nI; }
+    }
+    ncols = (uint32_t) __shfl((int) ncols, 0, 64);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    if (ncols == 0) { if (lane == 0) lddt_out[p] = 0.0f; return; }
+    const float *AX = ax + a_off[ia[p]], *AY = ay + a_off[ia[p]], *AZ = az + a_off[ia[p]];
+    const float *BX = bx + b_off[ib[p]], *BY = by + b_off[ib[p]], *BZ = bz + b_off[ib[p]];
+    const float R0sq = 15.0f * 15.0f;
+    for (uint32_t ci = lane; ci < ncols; ci += 64) {
+        const uint32_t a1 = posA[ci], b1 = posB[ci];
+        const float x1 = AX[a1], y1 = AY[a1], z1 = AZ[a1], u1 = BX[b1], v1 = BY[b1], w1 = BZ[b1];
+        uint32_t cons = 0, pres = 0;
+        for (uint32_t cj = 0; cj < ncols; ++cj) {
+            if (cj == ci) continue;
+            const uint32_t a2 = posA[cj], b2 = posB[cj];
+            // (x1-x2)^2 == (x2-x1)^2 exactly, so the reference's (lower column) - (higher column) order is immaterial
+            const float dx = x1 - AX[a2], dy = y1 - AY[a2], dz = z1 - AZ[a2];
+            const float ex = u1 - BX[b2], ey = v1 - BY[b2], ez = w1 - BZ[b2];
+            float d1s = dx * dx; d1s += dy * dy; d1s += dz * dz;       // pdbchain.cpp:320-335: dx*dx + dy*dy + dz*dz
+            float d2s = ex * ex; d2s += ey * ey; d2s += ez * ez;
+            if (d1s > R0sq && d2s > R0sq) continue;
+            const float d1 = sqrtf(d1s), d2 = sqrtf(d2s);
+            const float diff = fabsf(d1 - d2);
+            pres += (diff <= 0.5f) + (diff <= 1.0f) + (diff <= 2.0f) + (diff <= 4.0f);
+            cons += 4;
+        }
+        frac[ci] = cons > 0 ? (float) pres / (float) cons : 0.0f;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    if (lane == 0) {
+        float total = 0.0f;
+        for (uint32_t c = 0; c < ncols; ++c) total += frac[c];      // sequential, column order (lddt.cpp:111-121)
+        lddt_out[p] = total / (float) ncols;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host
+// ---------------------------------------------------------------------------------------------
+static double swf_pvalue(double ts)   // StatSig::GetPvalue statsig.cpp:27-44
+{
+    const double l = (ts < 0.11) ? (-80.0 * ts + -0.58) : (-52.0 * ts + -3.7);
+    double p = pow(10, l);
+    if (p > 1) p = 1;
+    return p;
+}
+static double swf_qual(double ts)     // StatSig::GetQual statsig.h:8-25
+{
+    const double logE = 5.0 + -40.0 * ts;
+    if (logE < -20) return 1;
+    const double x = pow(10, logE / 10);
+    return 1 / (1 + x / 2);
+}
+
+extern "C" size_t rsk_align_paths_bytes(const rsk_db *a, const rsk_db *b, const uint32_t *ia, const uint32_t *ib, size_t n)
+{
+    if (!a || !b || (n && (!ia || !ib))) return 0;
+    size_t tot = 0;
+    for (size_t p = 0; p < n; ++p) {
+        if (ia[p] >= a->n || ib[p] >= b->n) return 0;
+        tot += (size_t) a->len[ia[p]] + b->len[ib[p]] + 1;
+    }
+    return tot;
+}
+
+extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *dbb, const uint32_t *ia, const uint32_t *ib,
+                               size_t npairs, float gap_open, float gap_ext, float min_fwd_score, rsk_aln *out, char *paths,
+                               size_t paths_bytes)
+{
+    if (!ctx || !dba || !dbb || (npairs && (!ia || !ib || !out))) { rsk_set_error("rsk_align_pairs: NULL argument"); return RSK_E_INVALID; }
+    if (!dba->d_prof || !dbb->d_prof) { rsk_set_error("rsk_align_pairs: chain set has no profiles"); return RSK_E_INVALID; }
+    if (gap_open > 0 || gap_ext > 0) { rsk_set_error("rsk_align_pairs: gap penalties must be <= 0 (sw.cpp:86-87)"); return RSK_E_INVALID; }
+    if (npairs == 0) return RSK_OK;
+    if (npairs > 0x7FFFFFFFull) { rsk_set_error("rsk_align_pairs: too many pairs in one call"); return RSK_E_RANGE; }
+    const bool want_stats = dba->d_x && dbb->d_x;
+    size_t need = 0;
+    for (size_t p = 0; p < npairs; ++p) {
+        if (ia[p] >= dba->n || ib[p] >= dbb->n) { rsk_set_error("rsk_align_pairs: pair %zu out of range", p); return RSK_E_INVALID; }
+        if (dba->len[ia[p]] > 64 * SWF_R) {
+            rsk_set_error("rsk_align_pairs: chain A of pair %zu has %u residues; this build aligns A up to %d", p, dba->len[ia[p]], 64 * SWF_R);
+            return RSK_E_RANGE;
+        }
+        need += (size_t) dba->len[ia[p]] + dbb->len[ib[p]] + 1;
+    }
+    if (paths && paths_bytes < need) { rsk_set_error("rsk_align_pairs: paths buffer too small (%zu < %zu)", paths_bytes, need); return RSK_E_INVALID; }
+    RSK_HIP(hipSetDevice(ctx->device));
+    int rc = swf_upload_tables(ctx);
+    if (rc != RSK_OK) return rc;
+
+    // order pairs by LA (descending) so the pairs of a wave have the same strip count
+    std::vector<uint32_t> order(npairs);
+    std::iota(order.begin(), order.end(), 0u);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return dba->len[ia[x]] > dba->len[ia[y]]; });
+    std::vector<uint32_t> sia(npairs), sib(npairs);
+    std::vector<uint64_t> tb_off(npairs + 1), path_end(npairs), sc_off(npairs + 1);
+    uint64_t tbo = 0, pe = 0, so = 0;
+    for (size_t k = 0; k < npairs; ++k) {
+        const uint32_t p = order[k];
+        sia[k] = ia[p]; sib[k] = ib[p];
+        const uint32_t LA = dba->len[ia[p]], LB = dbb->len[ib[p]];
+        tb_off[k] = tbo;
+        tbo += (uint64_t) ((LA + 15) & ~15u) * LB;
+        pe += (uint64_t) LA + LB + 1;
+        path_end[k] = pe;
+        sc_off[k] = so;
+        so += std::min(LA, LB);
+    }
+    tb_off[npairs] = tbo;
+    sc_off[npairs] = so;
+    std::vector<swf_item> items;
+    for (size_t k = 0; k < npairs;) {
+        const uint32_t g = (dba->len[sia[k]] + SWF_R - 1) / SWF_R;
+        const uint32_t cnt = (uint32_t) std::min<size_t>(64 / g, npairs - k);
+        items.push_back(swf_item{ (uint32_t) k, cnt, g, 0 });
+        k += cnt;
+    }
+    struct ws_t {
+        std::vector<void *> all;
+        ~ws_t() { for (void *p : all) (void) hipFree(p); }
+    } ws;
+    auto dalloc = [&](void **p, size_t bytes) -> int {
+        RSK_HIP(hipMalloc(p, std::max<size_t>(bytes, 16)));
+        ws.all.push_back(*p);
+        return RSK_OK;
+    };
+    auto dup = [&](void **p, const void *h, size_t bytes) -> int {
+        int r = dalloc(p, bytes);
+        if (r != RSK_OK) return r;
+        RSK_HIP(hipMemcpyAsync(*p, h, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return RSK_OK;
+    };
+    uint32_t *d_ia, *d_ib, *d_bi, *d_bj, *d_plen, *d_loa, *d_lob, *d_pos = nullptr, *d_counts = nullptr;
+    uint64_t *d_tboff, *d_pend, *d_pstart, *d_scoff = nullptr;
+    swf_item *d_items;
+    uint8_t *d_tb;
+    float *d_score, *d_lddt = nullptr, *d_frac = nullptr;
+    char *d_paths;
+    if ((rc = dup((void **) &d_ia, sia.data(), npairs * 4)) != RSK_OK) return rc;
+    if ((rc = dup((void **) &d_ib, sib.data(), npairs * 4)) != RSK_OK) return rc;
+    if ((rc = dup((void **) &d_tboff, tb_off.data(), (npairs + 1) * 8)) != RSK_OK) return rc;
+    if ((rc = dup((void **) &d_pend, path_end.data(), npairs * 8)) != RSK_OK) return rc;
+    if ((rc = dup((void **) &d_items, items.data(), items.size() * sizeof(swf_item))) != RSK_OK) return rc;
+    if ((rc = dalloc((void **) &d_tb, tbo + 64)) != RSK_OK) return rc;
+    if ((rc = dalloc((void **) &d_score, npairs * 4)) != RSK_OK) return rc;
+    if ((rc = dalloc((void **) &d_bi, npairs * 4)) != RSK_OK) return rc;
+    if ((rc = dalloc((void **) &d_bj, npairs * 4)) != RSK_OK) return rc;
+    if ((rc = dalloc((void **) &d_plen, npairs * 4)) != RSK_OK) return rc;
+    if ((rc = dalloc((void **) &d_loa, npairs * 4)) != RSK_OK) return rc;
+    if ((rc = dalloc((void **) &d_lob, npairs * 4)) != RSK_OK) return rc;
+    if ((rc = dalloc((void **) &d_pstart, npairs * 8)) != RSK_OK) return rc;
+    if ((rc = dalloc((void **) &d_paths, pe + 16)) != RSK_OK) return rc;
+
+    swf_args a = {};
+    a.a_prof = dba->d_prof; a.a_off = dba->d_off; a.a_len = dba->d_len; a.a_npad = dba->npad;
+    a.b_cb = dbb->d_prof_cb; a.b_off = dbb->d_off; a.b_len = dbb->d_len;
+    a.ia = d_ia; a.ib = d_ib;
+    a.items = d_items; a.nitems = (uint32_t) items.size();
+    a.open = gap_open; a.ext = gap_ext;
+    a.tb = d_tb; a.tb_off = d_tboff;
+    a.score = d_score; a.besti = d_bi; a.bestj = d_bj;
+    RSK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    hipLaunchKernelGGL(k_sw_float, dim3((a.nitems + SWF_WAVES - 1) / SWF_WAVES), dim3(64 * SWF_WAVES), 0, ctx->stream, a);
+    RSK_HIP(hipGetLastError());
+    RSK_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    hipLaunchKernelGGL(k_traceback, dim3((unsigned) ((npairs + 63) / 64)), dim3(64), 0, ctx->stream, d_tb, d_tboff, d_ia, dba->d_len,
+                       d_score, d_bi, d_bj, (uint32_t) npairs, d_paths, d_pend, d_pstart, d_plen, d_loa, d_lob);
+    RSK_HIP(hipGetLastError());
+    if (want_stats) {
+        if ((rc = dup((void **) &d_scoff, sc_off.data(), (npairs + 1) * 8)) != RSK_OK) return rc;
+        if ((rc = dalloc((void **) &d_pos, 2 * so * 4)) != RSK_OK) return rc;
+        if ((rc = dalloc((void **) &d_frac, so * 4)) != RSK_OK) return rc;
+        if ((rc = dalloc((void **) &d_lddt, npairs * 4)) != RSK_OK) return rc;
+        if ((rc = dalloc((void **) &d_counts, npairs * 12)) != RSK_OK) return rc;
+        hipLaunchKernelGGL(k_lddt, dim3((unsigned) ((npairs + 3) / 4)), dim3(256), 0, ctx->stream, d_paths, d_pstart, d_plen, d_loa, d_lob,
+                           d_ia, d_ib, dba->d_off, dbb->d_off, dba->d_x, dba->d_y, dba->d_z, dbb->d_x, dbb->d_y, dbb->d_z,
+                           (uint32_t) npairs, d_pos, d_scoff, d_frac, d_lddt, d_counts);
+        RSK_HIP(hipGetLastError());
+    }
+    std::vector<float> h_score(npairs), h_lddt(npairs, 0.0f);
+    std::vector<uint32_t> h_loa(npairs), h_lob(npairs), h_plen(npairs);
+    std::vector<uint64_t> h_pstart(npairs);
+    std::vector<char> h_paths;
+    RSK_HIP(hipMemcpyAsync(h_score.data(), d_score, npairs * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RSK_HIP(hipMemcpyAsync(h_loa.data(), d_loa, npairs * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RSK_HIP(hipMemcpyAsync(h_lob.data(), d_lob, npairs * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RSK_HIP(hipMemcpyAsync(h_plen.data(), d_plen, npairs * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RSK_HIP(hipMemcpyAsync(h_pstart.data(), d_pstart, npairs * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (want_stats) RSK_HIP(hipMemcpyAsync(h_lddt.data(), d_lddt, npairs * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (paths) {
+        h_paths.resize(pe + 16);
+        RSK_HIP(hipMemcpyAsync(h_paths.data(), d_paths, pe, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    RSK_HIP(hipStreamSynchronize(ctx->stream));
+
+    // results back in the caller's pair order; paths packed in that order as NUL-terminated strings
+    std::vector<size_t> slot(npairs);
+    for (size_t k = 0; k < npairs; ++k) slot[order[k]] = k;
+    size_t wpos = 0;
+    for (size_t p = 0; p < npairs; ++p) {
+        const size_t k = slot[p];
+        rsk_aln &o = out[p];
+        const uint32_t LA = dba->len[ia[p]], LB = dbb->len[ib[p]];
+        o.score = h_score[k];
+        o.lo_a = h_loa[k]; o.lo_b = h_lob[k];
+        o.path_len = h_plen[k];
+        o.hi_a = o.hi_b = o.ids = o.gaps = RSK_NO_POS;
+        o.lddt = o.pvalue = o.evalue = o.qual = FLT_MAX;
+        o.ts = -FLT_MAX;
+        o.path_off = wpos;
+        uint32_t nM = 0, nD = 0, nI = 0;
+        if (paths) {
+            const char *src = h_paths.data() + h_pstart[k];
+            memcpy(paths + wpos, src, o.path_len);
+            paths[wpos + o.path_len] = 0;
+            for (uint32_t c = 0; c < o.path_len; ++c) { nM += src[c] == 'M'; nD += src[c] == 'D'; nI += src[c] == 'I'; }
+            wpos += (size_t) o.path_len + 1;
+        }
+        // CalcEvalue dssaligner.cpp:852-904 (the double-precision pow stays on the host: libm)
+        if (want_stats && paths && !(o.score < min_fwd_score)) {
+            o.hi_a = o.lo_a + nM + nD - 1;
+            o.hi_b = o.lo_b + nM + nI - 1;
+            o.ids = nM;
+            o.gaps = nD + nI;
+            const float sra = dba->h_selfrev[ia[p]], srb = dbb->h_selfrev[ib[p]];
+            float rev = 0;
+            if (sra != FLT_MAX && srb != FLT_MAX) rev = (sra + srb) / 2;
+            const float L = float(LA + LB) / 2;
+            const float dpw = 1.7f, lddtw = 0.13f, ladd = 250.0f, revtsw = 2.0f;
+            float ts = lddtw * h_lddt[k];
+            ts += (dpw * o.score - revtsw * rev) / (L + ladd);
+            o.lddt = h_lddt[k];
+            o.ts = ts;
+            o.pvalue = (float) swf_pvalue(ts);
+            o.qual = (float) swf_qual(ts);
+            o.evalue = (float) (swf_pvalue(ts) * 8340.0);      // SCOP40c_DBSIZE statsig.h:3
+        }
+    }
+    uint64_t cells = 0;
+    for (size_t p = 0; p < npairs; ++p) cells += (uint64_t) dba->len[ia[p]] * dbb->len[ib[p]];
+    ctx->al_pairs = npairs; ctx->al_cells = cells; ctx->al_tb_bytes = tbo;
+    return RSK_OK;
+}
+
+extern "C" int rsk_align_last_work(rsk_ctx *ctx, uint64_t *pairs, uint64_t *cells, uint64_t *tb_bytes)
+{
+    if (!ctx) { rsk_set_error("rsk_align_last_work: ctx is NULL"); return RSK_E_INVALID; }
+    if (pairs) *pairs = ctx->al_pairs;
+    if (cells) *cells = ctx->al_cells;
+    if (tb_bytes) *tb_bytes = ctx->al_tb_bytes;
+    return RSK_OK;
+}

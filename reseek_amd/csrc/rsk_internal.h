@@ -27,6 +27,7 @@ struct rsk_ctx {
     // accounting of the last gapless matrix call
     uint64_t gl_pairs = 0, gl_cells = 0, gl_slots = 0;
     uint64_t mf_pairs = 0, mf_candidates = 0;   // last Mu filter call
+    uint64_t al_pairs = 0, al_cells = 0, al_tb_bytes = 0;   // last rsk_align_pairs call
     int num_cus = 0;
 };
 
@@ -54,6 +55,8 @@ struct rsk_db {
     uint32_t *d_off = nullptr;
     uint8_t *d_mu = nullptr;   // npad bytes, pad = RSK_MU_NULL
     uint8_t *d_prof = nullptr; // [RSK_NFEAT][npad]
+    uint16_t *d_prof_cb = nullptr; // [npad + 64][8]: per residue, letter*4 of each feature (float SW column offsets)
+    std::vector<float> h_selfrev;
     float *d_x = nullptr, *d_y = nullptr, *d_z = nullptr;
     float *d_selfrev = nullptr;
     uint64_t hbm_bytes = 0;
