@@ -43,12 +43,12 @@
 
 // feature tables in LDS: table f at float offset swf_toff[f], row stride = alphabet size; then a pad row
 struct swf_tables {
-    float t[400 + 7 * 256 + 32];
+    float t[400 + 7 * 256 + 400];
 };
 static __device__ __constant__ swf_tables c_swf_tables;
 static const int h_swf_toff[8] = { 0, 400, 656, 912, 1168, 1424, 1680, 1936 };
-#define SWF_PAD_OFF 2192            // 20 floats of -1e30 (rows beyond LA)
-#define SWF_TABLE_FLOATS (2192 + 32)
+#define SWF_PAD_OFF 2192            // 400 floats of -1e30 (strip rows beyond the chain end, any step offset)
+#define SWF_TABLE_FLOATS (2192 + 400)
 
 static int swf_upload_tables(rsk_ctx *ctx)
 {
@@ -66,17 +66,21 @@ static int swf_upload_tables(rsk_ctx *ctx)
     return RSK_OK;
 }
 
-struct swf_item {            // one wave's work: pairs [first, first+count), g lanes per pair
-    uint32_t first, count, g, pad;
+struct swf_item {            // one wave's work: pairs [first, first+count), g lanes per pair, row groups of g strips
+    uint32_t first, count, g, ngroups;
 };
 
 struct swf_args {
-    const uint8_t *a_prof;   // [8][npadA] feature-major
+    // "strip" chain set (rows kept in registers) and "step" chain set (one residue per step).
+    // normal orientation: strip = A (query rows), step = B; transposed: strip = B, step = A.
+    const uint8_t *a_prof;   // A: [8][npadA] feature-major letters
     const uint32_t *a_off, *a_len;
-    const uint16_t *b_cb;    // [npadB][8] byte offsets (letter*4) per residue
+    const uint16_t *a_ra;    // A: [npadA][8] table ROW offsets in bytes (letter * alphabet * 4)
+    const uint8_t *b_prof;   // B: [8][npadB]
+    const uint16_t *b_cb;    // B: [npadB][8] table COLUMN offsets in bytes (letter*4)
     const uint32_t *b_off, *b_len;
     const uint32_t *ia, *ib; // pair lists (sorted order used by the items)
-    size_t a_npad;
+    size_t a_npad, b_npad;
     const swf_item *items;
     uint32_t nitems;
     float open, ext;
@@ -84,6 +88,8 @@ struct swf_args {
     const uint64_t *tb_off;
     float *score;            // per pair
     uint32_t *besti, *bestj;
+    int *bnd;                // boundary rows of multi-group pairs: 2 ints (float bits) per step, at bnd + bnd_off[p]
+    const uint64_t *bnd_off;
 };
 
 __device__ __forceinline__ float dpp_shr1_f(float x)
@@ -92,7 +98,10 @@ __device__ __forceinline__ float dpp_shr1_f(float x)
                                                                   0x138 /* wave_shr:1 */, 0xF, 0xF, false));
 }
 
-__global__ __launch_bounds__(64 * SWF_WAVES) void k_sw_float(swf_args a)
+// T = false: strips along A (rows), the wave steps over the columns of B; trace block TB[j][LApad].
+// T = true : strips along B (columns), the wave steps over the rows of A;  trace block TB[i][LBpad].
+template <bool T>
+__global__ __launch_bounds__(64 * SWF_WAVES) void k_sw_float(swf_args a, uint32_t item_base)
 {
     __shared__ __attribute__((aligned(16))) float tab[SWF_TABLE_FLOATS];
     for (int i = threadIdx.x; i < SWF_TABLE_FLOATS; i += blockDim.x) tab[i] = c_swf_tables.t[i];
@@ -100,20 +109,34 @@ __global__ __launch_bounds__(64 * SWF_WAVES) void k_sw_float(swf_args a)
     const int lane = threadIdx.x & 63;
     const uint32_t item_id = blockIdx.x * SWF_WAVES + (threadIdx.x >> 6);
     if (item_id >= a.nitems) return;
-    const swf_item it = a.items[item_id];
+    const swf_item it = a.items[item_base + item_id];
     const uint32_t g = it.g;
     const uint32_t pr = lane / g, st = lane - pr * g;
     const bool active = pr < it.count;
     const uint32_t p = it.first + (active ? pr : 0);
     const uint32_t A = a.ia[p], B = a.ib[p];
-    const uint32_t LA = a.a_len[A], LB = a.b_len[B];
+    const uint32_t LA0 = a.a_len[A], LB0 = a.b_len[B];
+    // from here on "LA"/rows/i refer to the strip chain and "LB"/columns/j to the step chain
+    const uint32_t LA = T ? LB0 : LA0, LB = T ? LA0 : LB0;
     const uint32_t LApad = (LA + 15) & ~15u;
-    const uint32_t i0 = st * SWF_R;
-    const bool lane_has_rows = active && i0 < LA;
-
-    // table row offsets (bytes) of this lane's 16 rows, two features per dword
+    const float Open = a.open, Ext = a.ext;
+    const uint16_t *bcb = T ? (a.a_ra + (size_t) a.a_off[A] * 8) : (a.b_cb + (size_t) a.b_off[B] * 8);
+    const char *tabb = (const char *) tab;
     const int toffb[8] = { 0 * 4, 400 * 4, 656 * 4, 912 * 4, 1168 * 4, 1424 * 4, 1680 * 4, 1936 * 4 };
     const int asz[8] = { 20, 16, 16, 16, 16, 16, 16, 16 };
+    float best = 0.0f;
+    uint32_t bi = 0xFFFFFFFFu, bj = 0xFFFFFFFFu;
+    int *bnd = a.bnd ? a.bnd + a.bnd_off[p] : nullptr;     // only multi-group pairs (one pair per wave) use it
+
+    // Chains with more than 64 strips are processed in row groups of 64 strips; the bottom row of a
+    // group goes through `bnd` (HBM, agent-scope accesses: written by lane 63, read by lane 0 later).
+    for (uint32_t rg = 0; rg < it.ngroups; ++rg) {
+    const uint32_t i0 = (rg * g + st) * SWF_R;
+    const bool lane_has_rows = active && i0 < LA;
+    const bool writes_bnd = (rg + 1 < it.ngroups) && st == g - 1;
+    const bool reads_bnd = rg > 0 && st == 0;
+
+    // table row offsets (bytes) of this lane's 16 rows, two features per dword
     uint32_t ro[SWF_R][4];
 #pragma unroll
     for (int r = 0; r < SWF_R; ++r)
@@ -122,13 +145,15 @@ __global__ __launch_bounds__(64 * SWF_WAVES) void k_sw_float(swf_args a)
     if (lane_has_rows) {
 #pragma unroll
         for (int f = 0; f < 8; ++f) {
-            const uint8_t *src = a.a_prof + (size_t) f * a.a_npad + a.a_off[A] + i0;   // 16-byte aligned (chains padded to 16)
+            const uint8_t *src = T ? (a.b_prof + (size_t) f * a.b_npad + a.b_off[B] + i0)
+                                   : (a.a_prof + (size_t) f * a.a_npad + a.a_off[A] + i0);   // 16-byte aligned (chains padded to 16)
             const uint4 w = *(const uint4 *) src;
             const uint32_t ww[4] = { w.x, w.y, w.z, w.w };
 #pragma unroll
             for (int r = 0; r < SWF_R; ++r) {
                 const uint32_t letter = (ww[r >> 2] >> (8 * (r & 3))) & 0xFF;
-                uint32_t off = (uint32_t) toffb[f] + letter * (uint32_t) (asz[f] * 4);
+                // strip part of the table address: row offset (normal) or column offset (transposed)
+                uint32_t off = (uint32_t) toffb[f] + letter * (uint32_t) (T ? 4 : asz[f] * 4);
                 if (i0 + r >= LA) off = SWF_PAD_OFF * 4;
                 if (f & 1) ro[r][f >> 1] = (ro[r][f >> 1] & 0xFFFFu) | (off << 16);
                 else ro[r][f >> 1] = (ro[r][f >> 1] & 0xFFFF0000u) | off;
@@ -139,15 +164,10 @@ __global__ __launch_bounds__(64 * SWF_WAVES) void k_sw_float(swf_args a)
     float Md[SWF_R], In[SWF_R];      // DPM[i][j] (diagonal input of row r at the next column), DPI[i][j]
 #pragma unroll
     for (int r = 0; r < SWF_R; ++r) { Md[r] = SWF_MINUS_INF; In[r] = SWF_MINUS_INF; }
-    if (st == 0) Md[0] = 0.0f;        // DPM[0][0] = 0 (sw.cpp:117)
-    float best = 0.0f;
-    uint32_t bi = 0xFFFFFFFFu, bj = 0xFFFFFFFFu;
+    if (st == 0 && rg == 0) Md[0] = 0.0f;   // DPM[0][0] = 0 (sw.cpp:117)
     float hand_m = SWF_MINUS_INF, hand_d = SWF_MINUS_INF;   // bottom row of this strip at its previous column
     float carry_in = SWF_MINUS_INF;                         // DPM[i0][j] from the lane above (arrives one step early)
-    const float Open = a.open, Ext = a.ext;
-    const uint16_t *bcb = a.b_cb + (size_t) a.b_off[B] * 8;
     uint8_t *tbp = a.tb + a.tb_off[p] + i0;
-    const char *tabb = (const char *) tab;
 
     uint32_t ncol = lane_has_rows ? (LB + st) : 0;
 #pragma unroll
@@ -159,8 +179,14 @@ __global__ __launch_bounds__(64 * SWF_WAVES) void k_sw_float(swf_args a)
     for (uint32_t col = 0; col < ncol; ++col) {
         const int j = (int) col - (int) st;
         // bottom row of the strip above: its DPD chain value for this column j and its new DPM (for column j+1)
-        const float in_m = dpp_shr1_f(hand_m);
-        const float in_d = dpp_shr1_f(hand_d);
+        float in_m = dpp_shr1_f(hand_m);
+        float in_d = dpp_shr1_f(hand_d);
+        if (reads_bnd && j >= 0 && (uint32_t) j < LB) {
+            // previous group: bnd[2j] = DPM[i0][j+1] (after its column j), bnd[2j+1] = DPD[i0][j]
+            in_d = __builtin_bit_cast(float, __hip_atomic_load(bnd + 2 * j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            carry_in = j > 0 ? __builtin_bit_cast(float, __hip_atomic_load(bnd + 2 * (j - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                             : SWF_MINUS_INF;
+        }
         if (lane_has_rows && j >= 0 && (uint32_t) j < LB) {
             const uint4 cb = cbn;
             cbn = *(const uint4 *) (bcb + (size_t) (j + 1) * 8);      // prefetch (chain set has tail padding)
@@ -169,8 +195,9 @@ __global__ __launch_bounds__(64 * SWF_WAVES) void k_sw_float(swf_args a)
 #pragma unroll
             for (int f = 0; f < 8; ++f) cbo[f] = (f & 1) ? (cbw[f >> 1] >> 16) : (cbw[f >> 1] & 0xFFFFu);
             // row 0 inputs
-            float d = (st == 0) ? SWF_MINUS_INF : in_d;                 // DPD[i0][j]
-            if (st != 0) Md[0] = carry_in;                              // DPM[i0][j] = bottom DPM of the strip above at column j-1
+            // chain state entering row 0 of the strip: DPD[i0][j] (normal) / DPI[i][j0] (transposed)
+            float ch = (st == 0 && rg == 0) ? SWF_MINUS_INF : in_d;
+            if (st != 0 || rg != 0) Md[0] = carry_in;                   // DPM[i0][j] = bottom DPM of the strip above at column j-1
             else if (j > 0) Md[0] = SWF_MINUS_INF;                      // DPM[0][j>0] = -inf (sw.cpp:102-111)
             float carry = SWF_MINUS_INF;                                // DPM[i0+r][j+1] produced by row r-1
             uint32_t tbw[4] = { 0, 0, 0, 0 };
@@ -186,8 +213,9 @@ __global__ __launch_bounds__(64 * SWF_WAVES) void k_sw_float(swf_args a)
                 S += *(const float *) (tabb + ((ro[r][3] & 0xFFFFu) + cbo[6]));
                 S += *(const float *) (tabb + ((ro[r][3] >> 16) + cbo[7]));
                 const float m = Md[r];
-                const float n = In[r];
-                Md[r] = carry;                      // becomes this row's diagonal input at the next column
+                const float d = T ? In[r] : ch;     // DPD of this grid point
+                const float n = T ? ch : In[r];     // DPI of this grid point
+                Md[r] = carry;                      // becomes this register's diagonal input at the next step
                 // MATCH (sw.cpp:123-155)
                 float xM = m;
                 uint32_t t = 0;
@@ -196,7 +224,7 @@ __global__ __launch_bounds__(64 * SWF_WAVES) void k_sw_float(swf_args a)
                 if (0.0f >= xM) { xM = 0.0f; t = TB_SM; }
                 xM += S;
                 if (xM >= best) {
-                    const uint32_t ii = i0 + r, jj = (uint32_t) j;
+                    const uint32_t ii = T ? (uint32_t) j : i0 + r, jj = T ? i0 + r : (uint32_t) j;
                     if (xM > best || (best > 0.0f && (ii < bi || (ii == bi && jj < bj)))) { best = xM; bi = ii; bj = jj; }
                 }
                 carry = xM;
@@ -204,19 +232,28 @@ __global__ __launch_bounds__(64 * SWF_WAVES) void k_sw_float(swf_args a)
                 const float md = m + Open;
                 float dd = d + Ext;
                 if (md >= dd) { dd = md; t |= TB_MD; }
-                d = dd;
                 // INSERT (sw.cpp:178-191): DPI[i][j+1]
                 float ni = n + Ext;
                 if (md >= ni) { ni = md; t |= TB_MI; }
-                In[r] = ni;
+                if (T) { ch = ni; In[r] = dd; }
+                else { ch = dd; In[r] = ni; }
                 tbw[r >> 2] |= t << (8 * (r & 3));
             }
             hand_m = carry;      // DPM[i0+16][j+1]
-            hand_d = d;          // DPD[i0+16][j]
+            hand_d = ch;         // DPD[i0+16][j] (normal) / DPI[i][j0+16] (transposed)
             *(uint4 *) (tbp + (size_t) j * LApad) = make_uint4(tbw[0], tbw[1], tbw[2], tbw[3]);
+            if (writes_bnd) {
+                __hip_atomic_store(bnd + 2 * j, __builtin_bit_cast(int, hand_m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(bnd + 2 * j + 1, __builtin_bit_cast(int, hand_d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
-        carry_in = in_m;         // value sent by the lane above at this step is for its column j+1 == our next column
+        if (!reads_bnd) carry_in = in_m;   // value sent by the lane above at this step is for its column j+1 == our next column
     }
+    if (it.ngroups > 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // boundary stores of this group have left the wave
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    }
+    }   // row groups
     // reduce (best, bi, bj) over the strips of each pair with the row-major-first rule (sw.cpp:153-158)
     for (uint32_t dlt = 1; dlt < g; ++dlt) {
         const int src = (lane + dlt) & 63;
@@ -236,6 +273,7 @@ __global__ __launch_bounds__(64 * SWF_WAVES) void k_sw_float(swf_args a)
 // TraceBackBitSW sw.cpp:8-77.  One thread per pair; path chars are written backwards into
 // paths[path_end[p]-1 ...]; path_start/path_len describe the result.
 __global__ void k_traceback(const uint8_t *tb, const uint64_t *tb_off, const uint32_t *ia, const uint32_t *a_len,
+                            const uint32_t *ib, const uint32_t *b_len, uint32_t first_transposed,
                             const float *score, const uint32_t *besti, const uint32_t *bestj, uint32_t npairs,
                             char *paths, const uint64_t *path_end, uint64_t *path_start, uint32_t *path_len,
                             uint32_t *lo_a, uint32_t *lo_b)
@@ -247,7 +285,10 @@ __global__ void k_traceback(const uint8_t *tb, const uint64_t *tb_off, const uin
     lo_a[p] = RSK_NO_POS;
     lo_b[p] = RSK_NO_POS;
     if (score[p] == 0.0f) return;                     // sw.cpp:200-201
-    const uint32_t LApad = (a_len[ia[p]] + 15) & ~15u;
+    const bool tr = p >= first_transposed;
+    // element (i,j) of the trace block: normal T[j*LApad + i]; transposed T[i*LBpad + j]
+    const uint32_t ld = tr ? ((b_len[ib[p]] + 15) & ~15u) : ((a_len[ia[p]] + 15) & ~15u);
+    const uint32_t si = tr ? ld : 1u, sj = tr ? 1u : ld;
     const uint8_t *T = tb + tb_off[p];
     uint32_t i = besti[p] + 1, j = bestj[p] + 1;      // 1-based
     const uint32_t Besti = i, Bestj = j;
@@ -258,17 +299,17 @@ __global__ void k_traceback(const uint8_t *tb, const uint64_t *tb_off, const uin
         paths[--w] = state == 0 ? 'M' : (state == 1 ? 'D' : 'I');
         ++n;
         if (state == 0) {
-            const uint8_t t = T[(size_t) (j - 1) * LApad + (i - 1)];
+            const uint8_t t = T[(size_t) (j - 1) * sj + (size_t) (i - 1) * si];
             if (t & TB_DM) state = 1;
             else if (t & TB_IM) state = 2;
             else if (t & TB_SM) break;
             --i; --j;
         } else if (state == 1) {
-            const uint8_t t = T[(size_t) j * LApad + (i - 1)];
+            const uint8_t t = T[(size_t) j * sj + (size_t) (i - 1) * si];
             state = (t & TB_MD) ? 0 : 1;
             --i;
         } else {
-            const uint8_t t = T[(size_t) (j - 1) * LApad + i];
+            const uint8_t t = T[(size_t) (j - 1) * sj + (size_t) i * si];
             state = (t & TB_MI) ? 0 : 2;
             --j;
         }
@@ -388,10 +429,6 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
     size_t need = 0;
     for (size_t p = 0; p < npairs; ++p) {
         if (ia[p] >= dba->n || ib[p] >= dbb->n) { rsk_set_error("rsk_align_pairs: pair %zu out of range", p); return RSK_E_INVALID; }
-        if (dba->len[ia[p]] > 64 * SWF_R) {
-            rsk_set_error("rsk_align_pairs: chain A of pair %zu has %u residues; this build aligns A up to %d", p, dba->len[ia[p]], 64 * SWF_R);
-            return RSK_E_RANGE;
-        }
         need += (size_t) dba->len[ia[p]] + dbb->len[ib[p]] + 1;
     }
     if (paths && paths_bytes < need) { rsk_set_error("rsk_align_pairs: paths buffer too small (%zu < %zu)", paths_bytes, need); return RSK_E_INVALID; }
@@ -402,16 +439,27 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
     // order pairs by LA (descending) so the pairs of a wave have the same strip count
     std::vector<uint32_t> order(npairs);
     std::iota(order.begin(), order.end(), 0u);
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return dba->len[ia[x]] > dba->len[ia[y]]; });
+    // orientation: strips along A unless A is too long (then along B); normal pairs first
+    auto transposed = [&](uint32_t x) { return dba->len[ia[x]] > 64 * SWF_R && dbb->len[ib[x]] <= 64 * SWF_R; };
+    auto striplen = [&](uint32_t x) { return transposed(x) ? dbb->len[ib[x]] : dba->len[ia[x]]; };
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+        const bool tx = transposed(x), ty = transposed(y);
+        if (tx != ty) return ty;
+        return striplen(x) > striplen(y);
+    });
+    size_t first_tr = npairs;
+    for (size_t k = 0; k < npairs; ++k) if (transposed(order[k])) { first_tr = k; break; }
     std::vector<uint32_t> sia(npairs), sib(npairs);
-    std::vector<uint64_t> tb_off(npairs + 1), path_end(npairs), sc_off(npairs + 1);
-    uint64_t tbo = 0, pe = 0, so = 0;
+    std::vector<uint64_t> tb_off(npairs + 1), path_end(npairs), sc_off(npairs + 1), bnd_off(npairs + 1);
+    uint64_t tbo = 0, pe = 0, so = 0, bno = 0;
     for (size_t k = 0; k < npairs; ++k) {
         const uint32_t p = order[k];
         sia[k] = ia[p]; sib[k] = ib[p];
         const uint32_t LA = dba->len[ia[p]], LB = dbb->len[ib[p]];
+        bnd_off[k] = bno;
+        if (k < first_tr && LA > 64 * SWF_R) bno += 2 * (uint64_t) LB;      // multi-group pair: 2 words per step
         tb_off[k] = tbo;
-        tbo += (uint64_t) ((LA + 15) & ~15u) * LB;
+        tbo += k >= first_tr ? (uint64_t) ((LB + 15) & ~15u) * LA : (uint64_t) ((LA + 15) & ~15u) * LB;
         pe += (uint64_t) LA + LB + 1;
         path_end[k] = pe;
         sc_off[k] = so;
@@ -420,10 +468,16 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
     tb_off[npairs] = tbo;
     sc_off[npairs] = so;
     std::vector<swf_item> items;
+    uint32_t nitems_normal = 0;
     for (size_t k = 0; k < npairs;) {
-        const uint32_t g = (dba->len[sia[k]] + SWF_R - 1) / SWF_R;
-        const uint32_t cnt = (uint32_t) std::min<size_t>(64 / g, npairs - k);
-        items.push_back(swf_item{ (uint32_t) k, cnt, g, 0 });
+        const bool tr = k >= first_tr;
+        const size_t lim = tr ? npairs : first_tr;
+        uint32_t g = ((tr ? dbb->len[sib[k]] : dba->len[sia[k]]) + SWF_R - 1) / SWF_R;
+        uint32_t ngroups = 1;
+        if (g > 64) { ngroups = (g + 63) / 64; g = 64; }
+        const uint32_t cnt = (uint32_t) std::min<size_t>(64 / g, lim - k);
+        items.push_back(swf_item{ (uint32_t) k, cnt, g, ngroups });
+        if (!tr) ++nitems_normal;
         k += cnt;
     }
     struct ws_t {
@@ -442,7 +496,8 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
         return RSK_OK;
     };
     uint32_t *d_ia, *d_ib, *d_bi, *d_bj, *d_plen, *d_loa, *d_lob, *d_pos = nullptr, *d_counts = nullptr;
-    uint64_t *d_tboff, *d_pend, *d_pstart, *d_scoff = nullptr;
+    uint64_t *d_tboff, *d_pend, *d_pstart, *d_scoff = nullptr, *d_bndoff = nullptr;
+    int *d_bnd = nullptr;
     swf_item *d_items;
     uint8_t *d_tb;
     float *d_score, *d_lddt = nullptr, *d_frac = nullptr;
@@ -453,6 +508,10 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
     if ((rc = dup((void **) &d_pend, path_end.data(), npairs * 8)) != RSK_OK) return rc;
     if ((rc = dup((void **) &d_items, items.data(), items.size() * sizeof(swf_item))) != RSK_OK) return rc;
     if ((rc = dalloc((void **) &d_tb, tbo + 64)) != RSK_OK) return rc;
+    if (bno) {
+        if ((rc = dup((void **) &d_bndoff, bnd_off.data(), (npairs + 1) * 8)) != RSK_OK) return rc;
+        if ((rc = dalloc((void **) &d_bnd, bno * 4)) != RSK_OK) return rc;
+    }
     if ((rc = dalloc((void **) &d_score, npairs * 4)) != RSK_OK) return rc;
     if ((rc = dalloc((void **) &d_bi, npairs * 4)) != RSK_OK) return rc;
     if ((rc = dalloc((void **) &d_bj, npairs * 4)) != RSK_OK) return rc;
@@ -463,19 +522,29 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
     if ((rc = dalloc((void **) &d_paths, pe + 16)) != RSK_OK) return rc;
 
     swf_args a = {};
-    a.a_prof = dba->d_prof; a.a_off = dba->d_off; a.a_len = dba->d_len; a.a_npad = dba->npad;
+    a.a_prof = dba->d_prof; a.a_off = dba->d_off; a.a_len = dba->d_len; a.a_npad = dba->npad; a.a_ra = dba->d_prof_ra;
+    a.b_prof = dbb->d_prof; a.b_npad = dbb->npad;
     a.b_cb = dbb->d_prof_cb; a.b_off = dbb->d_off; a.b_len = dbb->d_len;
     a.ia = d_ia; a.ib = d_ib;
-    a.items = d_items; a.nitems = (uint32_t) items.size();
+    a.items = d_items;
     a.open = gap_open; a.ext = gap_ext;
     a.tb = d_tb; a.tb_off = d_tboff;
     a.score = d_score; a.besti = d_bi; a.bestj = d_bj;
+    a.bnd = d_bnd; a.bnd_off = d_bndoff;
     RSK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-    hipLaunchKernelGGL(k_sw_float, dim3((a.nitems + SWF_WAVES - 1) / SWF_WAVES), dim3(64 * SWF_WAVES), 0, ctx->stream, a);
+    if (nitems_normal) {
+        a.nitems = nitems_normal;
+        hipLaunchKernelGGL(k_sw_float<false>, dim3((a.nitems + SWF_WAVES - 1) / SWF_WAVES), dim3(64 * SWF_WAVES), 0, ctx->stream, a, 0u);
+    }
+    if (items.size() > nitems_normal) {
+        a.nitems = (uint32_t) items.size() - nitems_normal;
+        hipLaunchKernelGGL(k_sw_float<true>, dim3((a.nitems + SWF_WAVES - 1) / SWF_WAVES), dim3(64 * SWF_WAVES), 0, ctx->stream, a,
+                           nitems_normal);
+    }
     RSK_HIP(hipGetLastError());
     RSK_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     hipLaunchKernelGGL(k_traceback, dim3((unsigned) ((npairs + 63) / 64)), dim3(64), 0, ctx->stream, d_tb, d_tboff, d_ia, dba->d_len,
-                       d_score, d_bi, d_bj, (uint32_t) npairs, d_paths, d_pend, d_pstart, d_plen, d_loa, d_lob);
+                       d_ib, dbb->d_len, (uint32_t) first_tr, d_score, d_bi, d_bj, (uint32_t) npairs, d_paths, d_pend, d_pstart, d_plen, d_loa, d_lob);
     RSK_HIP(hipGetLastError());
     if (want_stats) {
         if ((rc = dup((void **) &d_scoff, sc_off.data(), (npairs + 1) * 8)) != RSK_OK) return rc;

@@ -151,15 +151,17 @@ extern "C" int rsk_db_create(rsk_ctx *ctx, uint32_t n, const uint32_t *lengths, 
             src += (uint64_t) RSK_NFEAT * lengths[i];
         }
         if ((rc = dev_upload(&db->d_prof, hp.data(), hp.size(), db->hbm_bytes)) != RSK_OK) return rc;
-        std::vector<uint16_t> cb(((size_t) o + 64) * 8, 0);
+        std::vector<uint16_t> cb(((size_t) o + 64) * 8, 0), ra(((size_t) o + 64) * 8, 0);
         for (uint32_t i = 0; i < n; ++i)
             for (uint32_t k = 0; k < lengths[i]; ++k)
                 for (int f = 0; f < RSK_NFEAT; ++f) {
                     const uint8_t c = hp[(size_t) f * o + db->off[i] + k];
                     if (c >= (f == 0 ? 20 : 16)) { rsk_set_error("rsk_db_create: profile letter %u out of range (chain %u feature %d)", c, i, f); delete db; return RSK_E_INVALID; }
                     cb[((size_t) db->off[i] + k) * 8 + f] = (uint16_t) (c * 4);
+                    ra[((size_t) db->off[i] + k) * 8 + f] = (uint16_t) (c * (f == 0 ? 20 : 16) * 4);
                 }
         if ((rc = dev_upload(&db->d_prof_cb, cb.data(), cb.size(), db->hbm_bytes)) != RSK_OK) return rc;
+        if ((rc = dev_upload(&db->d_prof_ra, ra.data(), ra.size(), db->hbm_bytes)) != RSK_OK) return rc;
     }
     if (x) {
         std::vector<float> hx((size_t) o, 0.f), hy((size_t) o, 0.f), hz((size_t) o, 0.f);
@@ -188,7 +190,7 @@ extern "C" void rsk_db_destroy(rsk_db *db)
 {
     if (!db) return;
     void *ptrs[] = { db->d_len, db->d_off, db->d_mu, db->d_prof, db->d_x, db->d_y, db->d_z, db->d_selfrev,
-                     db->d_ring_tab, db->d_ring_letters, db->d_ring_laneq, db->d_ring_qid, db->d_work, db->d_prof_cb };
+                     db->d_ring_tab, db->d_ring_letters, db->d_ring_laneq, db->d_ring_qid, db->d_work, db->d_prof_cb, db->d_prof_ra };
     for (void *p : ptrs)
         if (p) (void) hipFree(p);
     delete db;

@@ -56,6 +56,7 @@ struct rsk_db {
     uint8_t *d_mu = nullptr;   // npad bytes, pad = RSK_MU_NULL
     uint8_t *d_prof = nullptr; // [RSK_NFEAT][npad]
     uint16_t *d_prof_cb = nullptr; // [npad + 64][8]: per residue, letter*4 of each feature (float SW column offsets)
+    uint16_t *d_prof_ra = nullptr; // [npad + 64][8]: letter*alphabet*4 (table row offsets, transposed float SW)
     std::vector<float> h_selfrev;
     float *d_x = nullptr, *d_y = nullptr, *d_z = nullptr;
     float *d_selfrev = nullptr;

@@ -29,7 +29,6 @@ def ctx():
 def check_against_records(ctx, chains, recs, min_fwd):
     import reseek_amd
     db = reseek_amd.Db.from_chains(ctx, chains)
-    recs = [r for r in recs if r["LA"] <= 1024]
     ia = [r["i"] for r in recs]
     ib = [r["j"] for r in recs]
     res = ctx.align_pairs(db, db, ia, ib, min_fwd_score=min_fwd)
@@ -78,6 +77,32 @@ def test_role_order_matters_and_is_respected(ctx):
         assert bits(al.score) == bits(s) and path == opath
         if path:
             assert (al.lo_a, al.lo_b) == (lo_i, lo_j)
+    db.close()
+
+
+def test_both_chains_longer_than_one_strip_group(ctx):
+    """> 1024 rows on both sides: the kernel runs several 64-strip row groups (boundary via HBM)."""
+    import copy
+    import reseek_amd
+    base = fx.read_rskdb("q100_sensitive.rskdb.gz")[0]
+    rng = np.random.default_rng(0)
+    cs = []
+    for L in (1100, 2300):
+        c = copy.copy(base)
+        c.mu = rng.integers(0, 36, L).astype(np.uint8)
+        c.prof = np.concatenate([rng.integers(0, 20, (1, L)), rng.integers(0, 16, (7, L))]).astype(np.uint8)
+        c.prof[:, 100:400] = c.prof[:, 500:800]          # internal repeat -> ties / long paths
+        c.x = np.cumsum(rng.normal(0, 2.2, L)).astype(np.float32)
+        c.y = np.cumsum(rng.normal(0, 2.2, L)).astype(np.float32)
+        c.z = np.cumsum(rng.normal(0, 2.2, L)).astype(np.float32)
+        cs.append(c)
+    db = reseek_amd.Db.from_chains(ctx, cs)
+    res = ctx.align_pairs(db, db, [0, 0, 1, 1], [0, 1, 0, 1], min_fwd_score=0.0)
+    for (a, b), (al, path) in zip([(0, 0), (0, 1), (1, 0), (1, 1)], res):
+        s, lo_i, lo_j, opath = ol.align_pair(cs[a].prof, cs[b].prof)
+        assert bits(al.score) == bits(s) and path == opath and (al.lo_a, al.lo_b) == (lo_i, lo_j), (a, b)
+        ok, st = ol.calc_evalue(s, 0.0, opath, lo_i, lo_j, cs[a], cs[b])
+        assert bits(al.lddt) == bits(st.lddt) and bits(al.evalue) == bits(st.evalue)
     db.close()
 
 
