@@ -145,6 +145,20 @@ int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *a, const rsk_db *b, const uint32
 /* Pairs, DP cells (sum LA*LB) and trace bytes written to HBM by the last rsk_align_pairs call. */
 int rsk_align_last_work(rsk_ctx *ctx, uint64_t *pairs, uint64_t *cells, uint64_t *tb_bytes);
 
+/* ---- P1/P2/P13: the search drivers ---------------------------------------------------------------
+ * `reseek -search Q [-db DB] -fast|-sensitive|-verysensitive -output F [-columns C] [-evalue E] [-noself]`
+ * (cmd_search search.cpp:62 -> SelfSearch :20 / Search_NoMuFilter :39), driven by the C++ mirror
+ * classes in reseek_amd/csrc/host/ (DBSearcher::LoadDB/Setup/RunSelf/RunQuery/BaseOnAln, DSSAligner).
+ * Chain sets are read from ".rskdb" containers (per-chain DSS profile, Mu letters, CA coordinates,
+ * self-rev score) -- reading .bca and computing the DSS features is row (f) "next".
+ * db_rskdb == NULL/"" => self search (all-vs-all, both orientations of every hit are written, as
+ * runself.cpp:59-68).  evalue < 0 => the mode's default (10; none for -verysensitive).
+ * stats8 (optional, 8 values): pairs, m_AlnCount, m_MuFilterInputCount, m_MuFilterDiscardCount,
+ * MKF pairs, full alignments, hits, 0. */
+int rsk_search_rskdb(rsk_ctx *ctx, const char *query_rskdb, const char *db_rskdb, const char *mode,
+                     const char *columns, double evalue, int noself, const char *out_tsv, uint64_t *nhits,
+                     uint64_t *stats8);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,6 +54,9 @@ SIGNATURES["rsk_align_pairs"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, u
                                            C.c_float, C.POINTER(Aln), C.c_char_p, C.c_size_t])
 SIGNATURES["rsk_align_last_work"] = (C.c_int, [C.c_void_p, u64p, u64p, u64p])
 
+SIGNATURES["rsk_search_rskdb"] = (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_double, C.c_int,
+                                            C.c_char_p, u64p, u64p])
+
 GAP_OPEN = -0.685533     # namedparams.cpp:45
 GAP_EXT = -0.051881      # namedparams.cpp:46
 
@@ -164,6 +167,15 @@ class Ctx:
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
         _check(lib().rsk_align_last_work(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
+
+    # ---- P1/P2/P13 search driver -------------------------------------------------------------------
+    def search_rskdb(self, query, out_tsv, mode, db=None, columns=None, evalue=-1.0, noself=False):
+        n = C.c_uint64()
+        st = (C.c_uint64 * 8)()
+        _check(lib().rsk_search_rskdb(self.h, query.encode(), db.encode() if db else None, mode.encode(),
+                                      columns.encode() if columns else None, evalue, int(noself), out_tsv.encode(),
+                                      C.byref(n), st))
+        return n.value, list(st)
 
     def mu_gapless_last_work(self):
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()

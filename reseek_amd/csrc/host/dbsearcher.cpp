@@ -1,0 +1,385 @@
+// dbsearcher.cpp -- host mirror of DBSearcher (dbsearcher.cpp, runself.cpp, runquery.cpp,
+// profileloader.cpp) and the C-ABI entry points that stand for `reseek -search` (search.cpp:20-111).
+//
+// The reference hands one pair at a time to one DSSAligner per thread (runself.cpp:13-70).  Here
+// the pair space is enumerated in the same order but scored in GPU batches through the C-ABI:
+//   Mu filter (rsk_mu_filter_dev)  ->  survivors  ->  rsk_align_pairs  ->  hit records,
+// then every hit is replayed through DSSAligner + BaseOnAln so Reject/-evalue/-mints, OnAln
+// subclasses and -columns behave as in the reference.  Pairs that take the long-chain MKF path
+// (DoMKF, dssaligner.cpp:715) are aligned on the host (row P9, not yet on the GPU).
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstring>
+#include <stdexcept>
+
+#include "reseek_host.h"
+
+namespace reseek_amd {
+
+static void check(int rc, const char *what)
+{
+    if (rc != RSK_OK) throw std::runtime_error(std::string(what) + ": " + rsk_last_error());
+}
+
+DBSearcher::~DBSearcher()
+{
+    for (auto p : m_DBChains) delete p;
+    for (auto p : m_DBProfiles) delete p;
+    for (auto p : m_DBMuLettersVec) delete p;
+    for (auto p : m_DBMuKmersVec) delete p;
+    if (m_Db) rsk_db_destroy(m_Db);
+}
+
+void DBSearcher::AddChain(PDBChain *ptrChain, std::vector<std::vector<byte> > *ptrProfile, std::vector<byte> *ptrMuLetters)
+{
+    ptrChain->m_Idx = (uint) m_DBChains.size();
+    m_DBChains.push_back(ptrChain);
+    m_DBProfiles.push_back(ptrProfile);
+    m_DBMuLettersVec.push_back(ptrMuLetters);
+}
+
+// Mu 3-mers with pattern "111" (DSS::GetMuKmers dss.cpp:659-682): base-36 code of 3 consecutive letters.
+static void GetMuKmers(const std::vector<byte> &Mu, std::vector<uint> &Kmers)
+{
+    Kmers.clear();
+    const size_t L = Mu.size();
+    for (size_t i = 0; i + 3 <= L; ++i) Kmers.push_back(((uint) Mu[i] * 36 + Mu[i + 1]) * 36 + Mu[i + 2]);
+}
+
+void DBSearcher::LoadDB(const std::string &DBFN)
+{
+    FILE *f = fopen(DBFN.c_str(), "rb");
+    if (!f) throw std::runtime_error("LoadDB: cannot open " + DBFN);
+    auto rd = [&](void *p, size_t n) { if (n && fread(p, 1, n, f) != n) { fclose(f); throw std::runtime_error("LoadDB: truncated " + DBFN); } };
+    char magic[8];
+    rd(magic, 8);
+    if (memcmp(magic, "RSKDB1\0\0", 8) != 0) { fclose(f); throw std::runtime_error("LoadDB: " + DBFN + " is not an RSKDB1 container"); }
+    uint32_t n, nfeat;
+    rd(&n, 4); rd(&nfeat, 4);
+    if (nfeat != RSK_NFEAT) { fclose(f); throw std::runtime_error("LoadDB: feature count mismatch"); }
+    for (uint32_t k = 0; k < n; ++k) {
+        uint32_t L, ll;
+        rd(&L, 4); rd(&ll, 4);
+        PDBChain *C = new PDBChain;
+        C->m_Label.resize(ll); rd(&C->m_Label[0], ll);
+        C->m_Seq.resize(L); rd(&C->m_Seq[0], L);
+        auto *Mu = new std::vector<byte>(L);
+        rd(Mu->data(), L);
+        auto *Prof = new std::vector<std::vector<byte> >(nfeat, std::vector<byte>(L));
+        for (uint32_t fi = 0; fi < nfeat; ++fi) rd((*Prof)[fi].data(), L);
+        C->m_Xs.resize(L); C->m_Ys.resize(L); C->m_Zs.resize(L);
+        rd(C->m_Xs.data(), 4 * (size_t) L); rd(C->m_Ys.data(), 4 * (size_t) L); rd(C->m_Zs.data(), 4 * (size_t) L);
+        float selfrev;
+        rd(&selfrev, 4);
+        uint32_t nk;
+        rd(&nk, 4);
+        std::vector<uint> stored(nk);
+        rd(stored.data(), 4 * (size_t) nk);
+        auto *Kmers = new std::vector<uint>;
+        GetMuKmers(*Mu, *Kmers);
+        if (*Kmers != stored) { fclose(f); throw std::runtime_error("LoadDB: stored Mu k-mers disagree with the letters"); }
+        AddChain(C, Prof, Mu);
+        m_DBMuKmersVec.push_back(Kmers);
+        m_DBSelfRevScores.push_back(m_Opts.selfrev0 ? 0.0f : selfrev);
+    }
+    fclose(f);
+}
+
+void DBSearcher::Setup()
+{
+    if (m_Opts.evalue_set) m_MaxEvalue = m_Opts.evalue;
+    else m_MaxEvalue = (m_Opts.mode == AM_VerySensitive) ? DBL_MAX : 10;
+    m_HitCount = 0;
+    m_ProcessedPairCount = 0;
+    m_DA.SetParams(*m_Params);
+    m_DA.SetColumns(m_Opts.columns);
+    m_DA.m_Ctx = m_Ctx;
+    OnSetup();
+}
+
+bool DBSearcher::Reject(DSSAligner &DA, bool Up) const
+{
+    if (!m_Opts.scores_are_not_evalues && DA.GetEvalue(Up) > m_MaxEvalue) return true;
+    if (m_Opts.mints_set && DA.GetNewTestStatistic(Up) < m_Opts.mints) return true;
+    return false;
+}
+
+void DBSearcher::BaseOnAln(DSSAligner &DA, bool Up)
+{
+    if (Reject(DA, Up)) return;
+    std::lock_guard<std::mutex> g(m_Lock);
+    ++m_HitCount;
+    DA.ToTsv(m_fTsv, Up, m_Opts.noself);
+    OnAln(DA, Up);
+}
+
+void DBSearcher::UploadToGpu()
+{
+    if (m_Db) return;
+    if (!m_Ctx) throw std::runtime_error("DBSearcher: no GPU context");
+    const uint n = GetDBChainCount();
+    std::vector<uint32_t> len(n);
+    size_t tot = 0;
+    for (uint i = 0; i < n; ++i) { len[i] = m_DBChains[i]->GetSeqLength(); tot += len[i]; }
+    std::vector<uint8_t> mu(tot), prof(tot * RSK_NFEAT);
+    std::vector<float> x(tot), y(tot), z(tot);
+    size_t o = 0;
+    for (uint i = 0; i < n; ++i) {
+        const uint L = len[i];
+        memcpy(&mu[o], m_DBMuLettersVec[i]->data(), L);
+        for (int f = 0; f < RSK_NFEAT; ++f) memcpy(&prof[o * RSK_NFEAT + (size_t) f * L], (*m_DBProfiles[i])[f].data(), L);
+        memcpy(&x[o], m_DBChains[i]->m_Xs.data(), 4 * (size_t) L);
+        memcpy(&y[o], m_DBChains[i]->m_Ys.data(), 4 * (size_t) L);
+        memcpy(&z[o], m_DBChains[i]->m_Zs.data(), 4 * (size_t) L);
+        o += L;
+    }
+    check(rsk_db_create(m_Ctx, n, len.data(), mu.data(), prof.data(), x.data(), y.data(), z.data(), m_DBSelfRevScores.data(), &m_Db),
+          "rsk_db_create");
+}
+
+// Align a batch of (ia, ib) pairs of one chain set on the GPU and replay the hits.
+static void AlignAndReplay(DBSearcher &S, rsk_ctx *ctx, DBSearcher &SrcA, DBSearcher &SrcB, const std::vector<uint32_t> &ia,
+                           const std::vector<uint32_t> &ib, bool Self)
+{
+    const DSSParams &P = *S.m_Params;
+    const size_t n = ia.size();
+    if (n == 0) return;
+    std::vector<rsk_aln> out(n);
+    const size_t bytes = rsk_align_paths_bytes(SrcA.m_Db, SrcB.m_Db, ia.data(), ib.data(), n);
+    std::vector<char> paths(bytes + 1);
+    check(rsk_align_pairs(ctx, SrcA.m_Db, SrcB.m_Db, ia.data(), ib.data(), n, P.m_GapOpen, P.m_GapExt, P.m_MinFwdScore, out.data(),
+                          paths.data(), bytes),
+          "rsk_align_pairs");
+    DSSAligner &DA = S.m_DA;
+    for (size_t p = 0; p < n; ++p) {
+        ++S.m_SWCount;
+        if (out[p].path_len == 0) continue;                                  // runself.cpp:61 / runquery.cpp:72
+        const uint i = ia[p], j = ib[p];
+        DA.m_ChainA = SrcA.m_DBChains[i]; DA.m_ProfileA = SrcA.m_DBProfiles[i];
+        DA.m_ChainB = SrcB.m_DBChains[j]; DA.m_ProfileB = SrcB.m_DBProfiles[j];
+        DA.m_SelfRevScoreA = SrcA.m_DBSelfRevScores[i]; DA.m_SelfRevScoreB = SrcB.m_DBSelfRevScores[j];
+        DA.SetFromAln(out[p], paths.data() + out[p].path_off);
+        if (Self) {
+            S.BaseOnAln(DA, true);
+            if (i != j) S.BaseOnAln(DA, false);
+        } else
+            S.BaseOnAln(DA, false);                                          // runquery.cpp:73: A = DB chain, B = query
+    }
+}
+
+// Shared body of RunSelf / RunQuery: A-side chains come from SrcA, B-side from *this.
+static void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self)
+{
+    const DSSParams &P = *S.m_Params;
+    rsk_ctx *ctx = S.m_Ctx;
+    const uint NA = SrcA.GetDBChainCount(), NB = S.GetDBChainCount();
+    const bool UseMu = P.m_Omega > 0;            // LoadDB keeps Mu letters only when Omega > 0 (dbsearcher.cpp:249-251)
+    auto IsMKF = [&](uint i, uint j) {           // DSSAligner::DoMKF dssaligner.cpp:715-732
+        if (!UseMu) return false;
+        if (SrcA.m_DBMuKmersVec[i]->empty() || S.m_DBMuKmersVec[j]->empty()) return false;
+        return SrcA.m_DBChains[i]->GetSeqLength() >= P.m_MKFL || S.m_DBChains[j]->GetSeqLength() >= P.m_MKFL;
+    };
+    auto Skip = [&](uint i, uint j) {
+        if (!S.m_Opts.noself) return false;
+        return Self ? (i == j) : (SrcA.m_DBChains[i]->m_Label == S.m_DBChains[j]->m_Label);
+    };
+    std::vector<uint32_t> ia, ib;                // pairs for the full alignment
+    std::vector<std::pair<uint32_t, uint32_t> > mkf;
+    uint64_t npairs = 0;
+    if (UseMu) {
+        // Mu filter over the whole enumerated pair space on the GPU
+        const size_t ldo = NB;
+        uint8_t *d_fwd = nullptr;
+        uint32_t *d_pq = nullptr, *d_pt = nullptr, *d_n = nullptr;
+        const uint64_t total = Self ? (uint64_t) NA * (NA + 1) / 2 : (uint64_t) NA * NB;
+        size_t cap = (size_t) std::min<uint64_t>(total, 1ull << 31);
+        auto hipok = [](hipError_t e, const char *w) { if (e != hipSuccess) throw std::runtime_error(std::string(w) + ": " + hipGetErrorString(e)); };
+        hipok(hipMalloc((void **) &d_fwd, (size_t) NA * ldo), "hipMalloc fwd");
+        hipok(hipMalloc((void **) &d_pq, cap * 4), "hipMalloc pairs");
+        hipok(hipMalloc((void **) &d_pt, cap * 4), "hipMalloc pairs");
+        hipok(hipMalloc((void **) &d_n, 4), "hipMalloc n");
+        check(rsk_mu_filter_dev(ctx, SrcA.m_Db, S.m_Db, Self ? 1 : 0, P.m_ParaMuGapOpen, P.m_ParaMuGapExt, P.m_Omega, P.m_OmegaFwd, d_fwd, ldo,
+                                d_pq, d_pt, nullptr, nullptr, cap, d_n),
+              "rsk_mu_filter_dev");
+        uint32_t ns = 0;
+        hipok(hipMemcpy(&ns, d_n, 4, hipMemcpyDeviceToHost), "copy n");
+        if (ns > cap) throw std::runtime_error("Mu filter survivor list overflow");
+        std::vector<uint32_t> pq(ns), pt(ns);
+        hipok(hipMemcpy(pq.data(), d_pq, (size_t) ns * 4, hipMemcpyDeviceToHost), "copy pairs");
+        hipok(hipMemcpy(pt.data(), d_pt, (size_t) ns * 4, hipMemcpyDeviceToHost), "copy pairs");
+        (void) hipFree(d_fwd); (void) hipFree(d_pq); (void) hipFree(d_pt); (void) hipFree(d_n);
+        // deterministic order (the device list is unordered)
+        std::vector<uint32_t> ord(ns);
+        for (uint32_t k = 0; k < ns; ++k) ord[k] = k;
+        std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return pq[a] != pq[b] ? pq[a] < pq[b] : pt[a] < pt[b]; });
+        uint64_t nmkf = 0, nskip = 0;
+        for (uint32_t k : ord) {
+            const uint i = pq[k], j = pt[k];
+            if (Skip(i, j) || IsMKF(i, j)) continue;
+            ia.push_back(i); ib.push_back(j);
+        }
+        for (uint i = 0; i < NA; ++i)
+            for (uint j = Self ? i : 0; j < NB; ++j) {
+                if (Skip(i, j)) { ++nskip; continue; }
+                if (IsMKF(i, j)) { mkf.emplace_back(i, j); ++nmkf; }
+            }
+        npairs = total - nskip;
+        S.m_MKFPairCount = nmkf;
+        S.m_MuFilterInputCount = npairs - nmkf;
+        S.m_MuFilterDiscardCount = S.m_MuFilterInputCount - ia.size();
+    } else {
+        for (uint i = 0; i < NA; ++i)
+            for (uint j = Self ? i : 0; j < NB; ++j) {
+                if (Skip(i, j)) continue;
+                ia.push_back(i); ib.push_back(j);
+                ++npairs;
+            }
+    }
+    S.m_ProcessedPairCount = npairs;
+    S.m_AlnCount = npairs - mkf.size();
+    const size_t B = std::max<size_t>(1, S.m_Opts.batch_pairs);
+    for (size_t b = 0; b < ia.size(); b += B) {
+        const size_t e = std::min(ia.size(), b + B);
+        AlignAndReplay(S, ctx, SrcA, S, std::vector<uint32_t>(ia.begin() + b, ia.begin() + e), std::vector<uint32_t>(ib.begin() + b, ib.begin() + e), Self);
+    }
+    // long-chain pairs: host MKF path (dssaligner.cpp:809-813)
+    DSSAligner &DA = S.m_DA;
+    uint prev = UINT_MAX;
+    for (auto &pr : mkf) {
+        const uint i = pr.first, j = pr.second;
+        if (i != prev) {
+            DA.SetQuery(*SrcA.m_DBChains[i], SrcA.m_DBProfiles[i], SrcA.m_DBMuLettersVec[i], SrcA.m_DBMuKmersVec[i], SrcA.m_DBSelfRevScores[i]);
+            prev = i;
+        }
+        DA.SetTarget(*S.m_DBChains[j], S.m_DBProfiles[j], S.m_DBMuLettersVec[j], S.m_DBMuKmersVec[j], S.m_DBSelfRevScores[j]);
+        DA.AlignMKF();
+        if (DA.m_Path.empty()) continue;
+        if (Self) {
+            S.BaseOnAln(DA, true);
+            if (i != j) S.BaseOnAln(DA, false);
+        } else
+            S.BaseOnAln(DA, false);
+    }
+    DA.UnsetQuery();
+}
+
+void DBSearcher::RunSelf()
+{
+    UploadToGpu();
+    RunPairs(*this, *this, true);
+}
+
+void DBSearcher::RunQuery(DBSearcher &DBChainsSource)
+{
+    UploadToGpu();
+    DBChainsSource.m_Ctx = m_Ctx;
+    DBChainsSource.UploadToGpu();
+    RunPairs(*this, DBChainsSource, false);
+}
+
+// One pair through the same GPU kernels (the reference's per-pair entry point, dssaligner.cpp:793).
+void DSSAligner::AlignQueryTarget()
+{
+    ClearAlign();
+    if (DoMKF()) { AlignMKF(); return; }
+    if (!m_Ctx) throw std::runtime_error("DSSAligner::AlignQueryTarget: no GPU context (set m_Ctx)");
+    auto mk = [&](const PDBChain &C, const std::vector<std::vector<byte> > &Prof, const std::vector<byte> *Mu, float SelfRev) {
+        const uint32_t L = C.GetSeqLength();
+        std::vector<uint8_t> prof((size_t) L * RSK_NFEAT);
+        for (int f = 0; f < RSK_NFEAT; ++f) memcpy(&prof[(size_t) f * L], Prof[f].data(), L);
+        rsk_db *db = nullptr;
+        check(rsk_db_create(m_Ctx, 1, &L, Mu ? Mu->data() : nullptr, prof.data(), C.m_Xs.data(), C.m_Ys.data(), C.m_Zs.data(), &SelfRev, &db),
+              "rsk_db_create");
+        return db;
+    };
+    rsk_db *a = mk(*m_ChainA, *m_ProfileA, m_MuLettersA, m_SelfRevScoreA), *b = mk(*m_ChainB, *m_ProfileB, m_MuLettersB, m_SelfRevScoreB);
+    bool pass = true;
+    if (m_Params->m_Omega > 0 && m_MuLettersA && m_MuLettersB) {
+        uint8_t *d_fwd; uint32_t *d_p;
+        hipMalloc((void **) &d_fwd, 16); hipMalloc((void **) &d_p, 16);
+        check(rsk_mu_filter_dev(m_Ctx, a, b, 0, m_Params->m_ParaMuGapOpen, m_Params->m_ParaMuGapExt, m_Params->m_Omega, m_Params->m_OmegaFwd, d_fwd, 1,
+                                d_p, d_p + 1, nullptr, nullptr, 1, d_p + 2),
+              "rsk_mu_filter_dev");
+        uint32_t n = 0;
+        hipMemcpy(&n, d_p + 2, 4, hipMemcpyDeviceToHost);
+        pass = n > 0;
+        hipFree(d_fwd); hipFree(d_p);
+    }
+    if (pass) {
+        const uint32_t z = 0;
+        rsk_aln out;
+        std::vector<char> paths(m_ChainA->GetSeqLength() + m_ChainB->GetSeqLength() + 2);
+        check(rsk_align_pairs(m_Ctx, a, b, &z, &z, 1, m_Params->m_GapOpen, m_Params->m_GapExt, m_Params->m_MinFwdScore, &out, paths.data(),
+                              paths.size()),
+              "rsk_align_pairs");
+        SetFromAln(out, paths.data() + out.path_off);
+    }
+    rsk_db_destroy(a);
+    rsk_db_destroy(b);
+}
+
+}   // namespace reseek_amd
+
+// ---------------------------------------------------------------------------------------------
+// C-ABI: `reseek -search Q [-db DB] -fast|-sensitive|-verysensitive -output F [-columns C] [-evalue E]`
+// ---------------------------------------------------------------------------------------------
+using namespace reseek_amd;
+
+static bool parse_mode(const char *mode, SearchOptions &o)
+{
+    const std::string m = mode ? mode : "";
+    if (m == "fast") o.mode = AM_Fast;
+    else if (m == "sensitive") o.mode = AM_Sensitive;
+    else if (m == "verysensitive") o.mode = AM_VerySensitive;
+    else return false;
+    return true;
+}
+
+void rsk_set_error(const char *fmt, ...);
+
+extern "C" int rsk_search_rskdb(rsk_ctx *ctx, const char *query_rskdb, const char *db_rskdb, const char *mode, const char *columns,
+                                double evalue, int noself, const char *out_tsv, uint64_t *nhits, uint64_t *stats8)
+{
+    if (!ctx || !query_rskdb || !out_tsv) { rsk_set_error("rsk_search_rskdb: NULL argument"); return RSK_E_INVALID; }
+    SearchOptions o;
+    if (!parse_mode(mode, o)) { rsk_set_error("rsk_search_rskdb: mode must be fast, sensitive or verysensitive"); return RSK_E_INVALID; }
+    if (columns) o.columns = columns;
+    if (evalue >= 0) { o.evalue_set = true; o.evalue = evalue; }
+    o.noself = noself != 0;
+    try {
+        DSSParams Params;
+        Params.SetDSSParams(o);
+        DBSearcher DBS;                       // SelfSearch search.cpp:20-37 / Search_NoMuFilter :39-60
+        DBS.m_Params = &Params;
+        DBS.m_Opts = o;
+        DBS.m_Ctx = ctx;
+        DBS.LoadDB(query_rskdb);
+        DBS.Setup();
+        for (USERFIELD u : DBS.m_DA.m_UFs)
+            if (u == UF_Undefined) { rsk_set_error("rsk_search_rskdb: invalid -columns field"); return RSK_E_INVALID; }
+        FILE *f = fopen(out_tsv, "w");
+        if (!f) { rsk_set_error("rsk_search_rskdb: cannot create %s", out_tsv); return RSK_E_INVALID; }
+        DBS.m_fTsv = f;
+        if (db_rskdb == nullptr || !*db_rskdb) DBS.RunSelf();
+        else {
+            DBSearcher Src;
+            Src.m_Params = &Params;
+            Src.m_Opts = o;
+            Src.m_Ctx = ctx;
+            Src.LoadDB(db_rskdb);
+            DBS.RunQuery(Src);
+        }
+        fclose(f);
+        if (nhits) *nhits = DBS.m_HitCount;
+        if (stats8) {
+            stats8[0] = DBS.m_ProcessedPairCount; stats8[1] = DBS.m_AlnCount; stats8[2] = DBS.m_MuFilterInputCount;
+            stats8[3] = DBS.m_MuFilterDiscardCount; stats8[4] = DBS.m_MKFPairCount; stats8[5] = DBS.m_SWCount;
+            stats8[6] = DBS.m_HitCount; stats8[7] = 0;
+        }
+    } catch (const std::exception &e) {
+        rsk_set_error("rsk_search_rskdb: %s", e.what());
+        return RSK_E_INVALID;
+    }
+    return RSK_OK;
+}

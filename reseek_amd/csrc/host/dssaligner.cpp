@@ -1,0 +1,831 @@
+// dssaligner.cpp -- host mirror of DSSParams / DSSAligner / MuKmerFilter (see reseek_host.h).
+// The per-pair DP of the common path runs on the GPU (k_mu_sw.hip, k_sw_float.hip); what lives here is
+//   * mode presets and option overrides                     dssparams.cpp:44-104, namedparams.cpp:32-53
+//   * result bookkeeping and the -columns / TSV formatting  dssaligner.cpp:100-136,1016, userfields.cpp, cigar.cpp:95
+//   * the long-chain MKF path, host resident for now: 3-mer seeds -> ungapped
+//     integer X-drop HSPs -> chain -> banded float X-drop from the best 8-mer
+//     (mukmerfilter.cpp:105-460, chainer.cpp:31, dssaligner.cpp:488,1387-1430, xdrophsp.cpp:42,
+//      xdropfwd.cpp:71, xdropbwd.cpp:28, mergefwdback.cpp:6)
+// Compiled with -ffp-contract=off: float results must match the reference's strict-IEEE build.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "reseek_host.h"
+#include "../rsk_tables_data.h"
+
+namespace reseek_amd {
+
+static const float MINUS_INFINITY = -9e9f;   // xdpmem.h:6
+static const byte TRACEBITS_DM = 0x01, TRACEBITS_IM = 0x02, TRACEBITS_MD = 0x04, TRACEBITS_MI = 0x08;
+
+std::mutex DSSAligner::m_OutputLock;
+
+// ---------------------------------------------------------------------------------------------
+// parameters
+// ---------------------------------------------------------------------------------------------
+void DSSParams::SetDefaults()
+{
+    m_GapOpen = rsk_gap_open;      // -0.685533f
+    m_GapExt = rsk_gap_ext;        // -0.051881f
+    m_MinFwdScore = 7.0f;
+    m_Omega = 29;
+    m_OmegaFwd = 29;
+    m_MKFPatternStr = "111";
+}
+
+void DSSParams::SetDSSParams(const SearchOptions &o)
+{
+    SetDefaults();
+    switch (o.mode) {
+    case AM_Fast:
+        m_Omega = 22; m_OmegaFwd = 50; m_MKFL = 500; m_MKF_X1 = 8; m_MKF_X2 = 8; m_MKF_MinHSPScore = 50; m_MKF_MinMegaHSPScore = -4;
+        break;
+    case AM_Sensitive:
+        m_Omega = 12; m_OmegaFwd = 20; m_MKFL = 600; m_MKF_X1 = 8; m_MKF_X2 = 8; m_MKF_MinHSPScore = 50; m_MKF_MinMegaHSPScore = -4;
+        break;
+    case AM_VerySensitive:
+        m_Omega = 0; m_OmegaFwd = 0; m_MKFL = 99999; m_MKF_X1 = 99999; m_MKF_X2 = 99999; m_MKF_MinHSPScore = 0;
+        m_MKF_MinMegaHSPScore = -99999; m_MinFwdScore = 0;
+        break;
+    default:
+        break;
+    }
+    if (o.omega_set) m_Omega = o.omega;
+    if (o.omegafwd_set) m_OmegaFwd = o.omegafwd;
+    if (o.minfwdscore_set) m_MinFwdScore = o.minfwdscore;
+    if (o.gapopen_set) { m_GapOpen = -o.gapopen; m_GapExt = -o.gapext; }   // -gapext only with -gapopen (dssparams.cpp:96-97)
+    if (o.mkfl_set) m_MKFL = o.mkfl;
+}
+
+USERFIELD StrToUF(const std::string &s)
+{
+    static const char *names[] = { "", "query", "target", "pvalue", "evalue", "qlo", "qhi", "tlo", "thi", "ql", "tl", "pctid",
+                                   "cigar", "qrow", "trow", "qrowg", "trowg", "ts", "newts", "dpscore", "lddt", "ids", "gaps", "aq",
+                                   "muhsp", "muchain", "gscore", "raw", "muscore", "qcovpct", "tcovpct" };
+    for (int k = 1; k <= (int) UF_tcovpct; ++k)
+        if (s == names[k]) return (USERFIELD) k;
+    return UF_Undefined;
+}
+
+// ---------------------------------------------------------------------------------------------
+// small path helpers
+// ---------------------------------------------------------------------------------------------
+void InvertPath(const std::string &Path, std::string &Inv)
+{
+    Inv.clear();
+    Inv.reserve(Path.size());
+    for (char c : Path) Inv += (c == 'D') ? 'I' : (c == 'I') ? 'D' : c;
+}
+
+void GetPathCounts(const std::string &Path, uint &M, uint &D, uint &I)
+{
+    M = D = I = 0;
+    for (char c : Path) {
+        if (c == 'M') ++M;
+        else if (c == 'D') ++D;
+        else if (c == 'I') ++I;
+    }
+}
+
+// cigar.cpp:95-140.  Run-length encode; D and I are exchanged unless FlipDI.
+void PathToCIGAR(const char *Path, std::string &CIGAR, bool FlipDI)
+{
+    CIGAR.clear();
+    auto emit = [&](uint n, char c) {
+        if (!FlipDI) c = (c == 'D') ? 'I' : (c == 'I') ? 'D' : c;
+        char tmp[32];
+        snprintf(tmp, sizeof(tmp), "%u%c", n, c);
+        CIGAR += tmp;
+    };
+    char last = *Path;
+    uint n = 1;
+    for (uint i = 1;; ++i) {
+        const char c = Path[i];
+        if (c == 0) break;
+        if (c == last) { ++n; continue; }
+        emit(n, last);
+        last = c;
+        n = 1;
+    }
+    if (n > 0) emit(n, last);
+}
+
+// ---------------------------------------------------------------------------------------------
+// DSSAligner: state
+// ---------------------------------------------------------------------------------------------
+DSSAligner::DSSAligner() { SetColumns(""); }
+
+void DSSAligner::SetColumns(const std::string &Columns)
+{
+    auto default_columns = [&]() {
+        static const USERFIELD d[] = { UF_query, UF_target, UF_qlo, UF_qhi, UF_ql, UF_tlo, UF_thi, UF_tl, UF_pctid, UF_pvalue };
+        for (USERFIELD u : d) m_UFs.push_back(u);
+    };
+    m_UFs.clear();
+    if (Columns.empty()) { default_columns(); return; }
+    size_t pos = 0;
+    while (pos <= Columns.size()) {
+        size_t e = Columns.find('+', pos);
+        if (e == std::string::npos) e = Columns.size();
+        const std::string f = Columns.substr(pos, e - pos);
+        if (f == "std") default_columns();
+        else if (!f.empty()) m_UFs.push_back(StrToUF(f));
+        pos = e + 1;
+    }
+}
+
+void DSSAligner::SetParams(const DSSParams &Params)
+{
+    m_Params = &Params;
+    m_MKF.SetParams(Params);
+}
+
+void DSSAligner::UnsetQuery()
+{
+    m_MKF.ResetQ();
+    m_ChainA = nullptr; m_ProfileA = nullptr; m_MuLettersA = nullptr; m_MuKmersA = nullptr;
+    m_SelfRevScoreA = 0;
+}
+
+void DSSAligner::SetQuery(const PDBChain &Chain, const std::vector<std::vector<byte> > *ptrProfile, const std::vector<byte> *ptrMuLetters,
+                          const std::vector<uint> *ptrMuKmers, float SelfRevScore)
+{
+    if (ptrMuKmers != nullptr && ptrMuLetters != nullptr) m_MKF.SetQ(Chain.m_Label, ptrMuLetters, ptrMuKmers);
+    m_ChainA = &Chain; m_ProfileA = ptrProfile; m_MuLettersA = ptrMuLetters; m_MuKmersA = ptrMuKmers;
+    m_SelfRevScoreA = SelfRevScore;
+    // the striped parasail profiles of SetMuQP_Para are built inside the GPU kernel
+}
+
+void DSSAligner::SetTarget(const PDBChain &Chain, const std::vector<std::vector<byte> > *ptrProfile, const std::vector<byte> *ptrMuLetters,
+                           const std::vector<uint> *ptrMuKmers, float SelfRevScore)
+{
+    m_ChainB = &Chain; m_ProfileB = ptrProfile; m_MuKmersB = ptrMuKmers; m_MuLettersB = ptrMuLetters;
+    m_SelfRevScoreB = SelfRevScore;
+}
+
+bool DSSAligner::DoMKF() const
+{
+    if (m_MuLettersA == nullptr || m_MuLettersB == nullptr) return false;
+    if (m_MuKmersA == nullptr || m_MuKmersB == nullptr) return false;
+    if (m_MuLettersA->empty() || m_MuLettersB->empty()) return false;
+    if (m_MuKmersA->empty() || m_MuKmersB->empty()) return false;
+    const uint LA = m_ChainA->GetSeqLength(), LB = m_ChainB->GetSeqLength();
+    return LA >= m_Params->m_MKFL || LB >= m_Params->m_MKFL;
+}
+
+void DSSAligner::ClearAlign()
+{
+    m_Path.clear();
+    m_LoA = m_LoB = m_HiA = m_HiB = UINT_MAX;
+    m_Ids = m_Gaps = UINT_MAX;
+    m_PvalueA = m_PvalueB = m_EvalueA = m_EvalueB = FLT_MAX;
+    m_TestStatisticA = m_TestStatisticB = -FLT_MAX;
+    m_NewTestStatisticA = m_NewTestStatisticB = -FLT_MAX;
+    m_AlnFwdScore = 0;
+    m_LDDT = FLT_MAX;
+}
+
+void DSSAligner::SetFromAln(const rsk_aln &a, const char *Path)
+{
+    ClearAlign();
+    m_AlnFwdScore = a.score;
+    m_Path.assign(Path, a.path_len);
+    m_LoA = a.lo_a; m_LoB = a.lo_b;
+    if (a.evalue != FLT_MAX) {
+        m_HiA = a.hi_a; m_HiB = a.hi_b; m_Ids = a.ids; m_Gaps = a.gaps;
+        m_LDDT = a.lddt;
+        m_NewTestStatisticA = m_NewTestStatisticB = a.ts;
+        m_PvalueA = m_PvalueB = a.pvalue;
+        m_EvalueA = m_EvalueB = a.evalue;
+        m_QualityA = m_QualityB = a.qual;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// statistics on the host (MKF path): lddt.cpp:63-124, statsig.cpp:27-50, dssaligner.cpp:852-904
+// ---------------------------------------------------------------------------------------------
+float DSSAligner::GetLDDT() const
+{
+    std::vector<uint> PosAs, PosBs;
+    uint PosA = m_LoA, PosB = m_LoB;
+    for (char c : m_Path) {
+        if (c == 'M') { PosAs.push_back(PosA++); PosBs.push_back(PosB++); }
+        else if (c == 'D') ++PosA;
+        else if (c == 'I') ++PosB;
+    }
+    const uint n = (uint) PosAs.size();
+    if (n == 0) return 0;
+    const PDBChain &Q = *m_ChainA, &T = *m_ChainB;
+    std::vector<uint> cons(n, 0), pres(n, 0);
+    const float R0sq = 15.0f * 15.0f;
+    for (uint ci = 0; ci < n; ++ci) {
+        for (uint cj = ci + 1; cj < n; ++cj) {
+            const float dx = Q.m_Xs[PosAs[ci]] - Q.m_Xs[PosAs[cj]], dy = Q.m_Ys[PosAs[ci]] - Q.m_Ys[PosAs[cj]],
+                        dz = Q.m_Zs[PosAs[ci]] - Q.m_Zs[PosAs[cj]];
+            const float d1s = dx * dx + dy * dy + dz * dz;
+            const float ex = T.m_Xs[PosBs[ci]] - T.m_Xs[PosBs[cj]], ey = T.m_Ys[PosBs[ci]] - T.m_Ys[PosBs[cj]],
+                        ez = T.m_Zs[PosBs[ci]] - T.m_Zs[PosBs[cj]];
+            const float d2s = ex * ex + ey * ey + ez * ez;
+            if (d1s > R0sq && d2s > R0sq) continue;
+            const float diff = fabsf(sqrtf(d1s) - sqrtf(d2s));
+            const uint k = (diff <= 0.5f) + (diff <= 1.0f) + (diff <= 2.0f) + (diff <= 4.0f);
+            pres[ci] += k; pres[cj] += k;
+            cons[ci] += 4; cons[cj] += 4;
+        }
+    }
+    float total = 0;
+    for (uint c = 0; c < n; ++c) {
+        float s = 0;
+        if (cons[c] > 0) s = float(pres[c]) / cons[c];
+        total += s;
+    }
+    return total / n;
+}
+
+static double StatSig_GetPvalue(double TS)
+{
+    const double l = (TS < 0.11) ? (-80.0 * TS + -0.58) : (-52.0 * TS + -3.7);
+    double P = pow(10, l);
+    if (P > 1) P = 1;
+    return P;
+}
+static double StatSig_GetQual(double TS)
+{
+    const double logE = 5.0 + -40.0 * TS;
+    if (logE < -20) return 1;
+    const double x = pow(10, logE / 10);
+    return 1 / (1 + x / 2);
+}
+
+void DSSAligner::CalcEvalue()
+{
+    if (m_AlnFwdScore < m_Params->m_MinFwdScore) return;
+    uint M, D, I;
+    GetPathCounts(m_Path, M, D, I);
+    m_HiA = m_LoA + M + D - 1;
+    m_HiB = m_LoB + M + I - 1;
+    m_Ids = M;
+    m_Gaps = D + I;
+    const float LDDT = GetLDDT();
+    m_LDDT = LDDT;
+    float RevDPScore = 0;
+    if (m_SelfRevScoreA != FLT_MAX && m_SelfRevScoreB != FLT_MAX) RevDPScore = (m_SelfRevScoreA + m_SelfRevScoreB) / 2;
+    const uint LA = m_ChainA->GetSeqLength(), LB = m_ChainB->GetSeqLength();
+    const float L = float(LA + LB) / 2;
+    const float dpw = 1.7f, lddtw = 0.13f, ladd = 250.0f, revtsw = 2.0f;
+    m_NewTestStatisticA = lddtw * LDDT;
+    m_NewTestStatisticA += (dpw * m_AlnFwdScore - revtsw * RevDPScore) / (L + ladd);
+    m_NewTestStatisticB = m_NewTestStatisticA;
+    const float Pval = (float) StatSig_GetPvalue(m_NewTestStatisticA);
+    const float Qual = (float) StatSig_GetQual(m_NewTestStatisticA);
+    const float E = (float) (StatSig_GetPvalue(m_NewTestStatisticA) * 8340);
+    m_QualityA = m_QualityB = Qual;
+    m_PvalueA = m_PvalueB = Pval;
+    m_EvalueA = m_EvalueB = E;
+}
+
+// ---------------------------------------------------------------------------------------------
+// MuKmerFilter (mukmerfilter.cpp)
+// ---------------------------------------------------------------------------------------------
+void MuKmerFilter::ResetQ()
+{
+    if (m_ptrMuKmersQ != nullptr) {
+        for (uint Kmer : *m_ptrMuKmersQ)
+            for (uint w = 0; w < HASHW; ++w) m_KmerHashTableQ[HASHW * Kmer + w] = 0xffff;
+        m_ptrMuKmersQ = nullptr;
+        m_ptrMuLettersQ = nullptr;
+    }
+}
+
+void MuKmerFilter::SetQ(const std::string &, const std::vector<byte> *ptrMuLettersQ, const std::vector<uint> *ptrMuKmersQ)
+{
+    if (m_KmerHashTableQ.empty()) m_KmerHashTableQ.assign((size_t) m_DictSize * HASHW, 0xffff);
+    else ResetQ();
+    m_ptrMuLettersQ = ptrMuLettersQ;
+    m_ptrMuKmersQ = ptrMuKmersQ;
+    const uint KmerCount = (uint) ptrMuKmersQ->size();
+    for (uint PosQ = 0; PosQ < KmerCount; ++PosQ) {          // first-come, at most HASHW positions per k-mer (:208-225)
+        const uint Kmer = (*ptrMuKmersQ)[PosQ];
+        for (uint w = 0; w < HASHW; ++w)
+            if (m_KmerHashTableQ[Kmer * HASHW + w] == 0xffff) { m_KmerHashTableQ[Kmer * HASHW + w] = (uint16_t) PosQ; break; }
+    }
+}
+
+int MuKmerFilter::MuXDrop(int PosQ, int LQ, int PosT, int LT, int X, int &Loi, int &Loj, int &Len) const
+{
+    Loi = PosQ; Loj = PosT; Len = 0;
+    const byte *Q = m_ptrMuLettersQ->data(), *T = m_ptrMuLettersT->data();
+    int i = PosQ, j = PosT, FwdScore = 0, BestFwdScore = 0, FwdLen = 0;
+    while (i < LQ && j < LT) {
+        FwdScore += rsk_mu_int[36 * Q[i++] + T[j++]];
+        if (FwdScore > BestFwdScore) { FwdLen = i - PosQ; BestFwdScore = FwdScore; }
+        else if (FwdScore + X < BestFwdScore) break;
+    }
+    int RevScore = 0, BestRevScore = 0, RevLen = 0;
+    i = PosQ - 1; j = PosT - 1;
+    while (i >= 0 && j >= 0) {
+        RevScore += rsk_mu_int[36 * Q[i] + T[j]];
+        if (RevScore > BestRevScore) { BestRevScore = RevScore; Loi = i; Loj = j; RevLen = PosQ - i; }
+        else if (RevScore + X < BestRevScore) break;
+        --i; --j;
+    }
+    Len = FwdLen + RevLen;
+    return BestFwdScore + BestRevScore;
+}
+
+void MuKmerFilter::Align(const std::vector<byte> &MuLettersT, const std::vector<uint> &MuKmersT)
+{
+    m_ptrMuLettersT = &MuLettersT;
+    const uint KmerCountT = (uint) MuKmersT.size();
+    const int LQ = (int) m_ptrMuLettersQ->size(), LT = (int) MuLettersT.size();
+    m_MuKmerHSPLois.clear(); m_MuKmerHSPLojs.clear(); m_MuKmerHSPLens.clear(); m_MuKmerHSPScores.clear();
+    m_ChainHSPLois.clear(); m_ChainHSPLojs.clear(); m_ChainHSPLens.clear();
+    m_BestChainScore = 0;
+    m_BestHSPScore = 0;
+    bool FoundHSP = false;
+    const int MinHSPScore = m_Params->m_MKF_MinHSPScore, X1 = m_Params->m_MKF_X1;
+    for (uint PosT = 0; PosT < KmerCountT; ++PosT) {
+        const uint KmerT = MuKmersT[PosT];
+        for (uint w = 0; w < HASHW; ++w) {
+            const uint PosQ = m_KmerHashTableQ[HASHW * KmerT + w];
+            if (PosQ == 0xffff) continue;
+            int Loi, Loj, Len;
+            const int Score = MuXDrop((int) PosQ, LQ, (int) PosT, LT, X1, Loi, Loj, Len);
+            if (Score < MinHSPScore) continue;
+            FoundHSP = true;
+            if (Score > m_BestHSPScore) {                 // kept only while strictly improving (:354-378)
+                m_BestHSPScore = Score;
+                bool Old = false;
+                for (int l : m_MuKmerHSPLois) if (l == Loi) { Old = true; break; }
+                if (!Old) {
+                    m_MuKmerHSPLois.push_back(Loi); m_MuKmerHSPLojs.push_back(Loj);
+                    m_MuKmerHSPLens.push_back(Len); m_MuKmerHSPScores.push_back(Score);
+                }
+            }
+        }
+    }
+    if (FoundHSP) ChainHSPs();
+}
+
+// Chainer::Chain chainer.cpp:31-178: best-scoring chain of non-overlapping [Lo,Hi] intervals.
+namespace {
+struct BPData { uint Index; bool IsLo; uint Pos; };
+int CmpBPs(const void *a, const void *b)      // ties: Los before His (chainer.cpp:11-29); not a total order -> libc qsort as the reference
+{
+    const BPData *x = (const BPData *) a, *y = (const BPData *) b;
+    if (x->Pos < y->Pos) return -1;
+    if (x->Pos > y->Pos) return 1;
+    if (x->IsLo != y->IsLo) return (x->IsLo && !y->IsLo) ? -1 : 1;
+    return 0;
+}
+float ChainIntervals(const std::vector<uint> &Los, const std::vector<uint> &His, const std::vector<float> &Scores, std::vector<uint> &Idxs)
+{
+    Idxs.clear();
+    const uint N = (uint) Los.size();
+    if (N == 0) return 0;
+    std::vector<BPData> BPs(2 * N);
+    for (uint i = 0; i < N; ++i) {
+        BPs[2 * i] = BPData{ i, true, Los[i] };
+        BPs[2 * i + 1] = BPData{ i, false, His[i] };
+    }
+    qsort(BPs.data(), 2 * N, sizeof(BPData), CmpBPs);
+    std::vector<uint> TB(N, UINT_MAX);
+    std::vector<float> ChainScores(N, MINUS_INFINITY);
+    uint BestChainEnd = UINT_MAX;
+    for (uint i = 0; i < 2 * N; ++i) {
+        const BPData &BP = BPs[i];
+        const float Score = Scores[BP.Index];
+        if (BP.IsLo) {
+            TB[BP.Index] = BestChainEnd;
+            ChainScores[BP.Index] = (BestChainEnd == UINT_MAX) ? Score : ChainScores[BestChainEnd] + Score;
+        } else if (BestChainEnd == UINT_MAX || ChainScores[BP.Index] > ChainScores[BestChainEnd])
+            BestChainEnd = BP.Index;
+    }
+    float Total = 0;
+    for (uint Index = BestChainEnd;;) {
+        Total += Scores[Index];
+        Idxs.push_back(Index);
+        Index = TB[Index];
+        if (Index == UINT_MAX) break;
+    }
+    return Total;
+}
+}   // namespace
+
+void MuKmerFilter::ChainHSPs()
+{
+    m_ChainHSPLois.clear(); m_ChainHSPLojs.clear(); m_ChainHSPLens.clear();
+    const uint N = (uint) m_MuKmerHSPLois.size();
+    std::vector<uint> Los, His, Idxs;
+    std::vector<float> Scores;
+    for (uint i = 0; i < N; ++i) {
+        const uint Lo = (uint) m_MuKmerHSPLois[i];
+        Los.push_back(Lo);
+        His.push_back(Lo + m_MuKmerHSPLens[i] - 1);
+        Scores.push_back((float) m_MuKmerHSPScores[i]);
+    }
+    m_BestChainScore = (int) ChainIntervals(Los, His, Scores, Idxs);
+    for (uint Idx : Idxs) {
+        m_ChainHSPLois.push_back(m_MuKmerHSPLois[Idx]);
+        m_ChainHSPLojs.push_back(m_MuKmerHSPLojs[Idx]);
+        m_ChainHSPLens.push_back(m_MuKmerHSPLens[Idx]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// gapped float X-drop (xdropfwd.cpp:71-390, xdropbwd.cpp:28, mergefwdback.cpp:6, xdrophsp.cpp:42)
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct XDropMem {
+    uint LA = 0, LB = 0, Cols = 0;
+    std::vector<byte> TB;
+    std::vector<float> M, D;
+    void Alloc(uint la, uint lb)
+    {
+        LA = la; LB = lb; Cols = lb + 8;
+        TB.assign((size_t) (la + 8) * Cols, 0);
+        M.assign(lb + 9, 0.0f);
+        D.assign(lb + 9, 0.0f);
+    }
+    byte &tb(uint i, uint j) { return TB[(size_t) i * Cols + j]; }
+    float *Mrow() { return M.data() + 1; }     // Mrow[-1] is valid
+    float *Drow() { return D.data() + 1; }
+};
+
+// Sub(PosA, PosB): substitution score of absolute positions
+template <class SubFn>
+float XDropFwd(XDropMem &Mem, float X, float Open, float Ext, SubFn Sub, uint LoA, uint aLA, uint LoB, uint aLB, uint *ptrSegLoA,
+               uint *ptrSegLoB, std::string &Path)
+{
+    *ptrSegLoA = UINT_MAX;
+    *ptrSegLoB = UINT_MAX;
+    const uint LA = aLA - LoA, LB = aLB - LoB;
+    Path.clear();
+    if (LA == 1 || LB == 1) {
+        const float Score = Sub(LoA, LoB);
+        if (Score > 0) Path.push_back('M');
+        return Score;
+    }
+    const float AbsOpen = -Open, AbsExt = -Ext;
+    Mem.Alloc(LA + 1, LB + 1);
+    float *Mrow = Mem.Mrow(), *Drow = Mem.Drow();
+    Mrow[-1] = MINUS_INFINITY;
+    Drow[0] = MINUS_INFINITY;
+    Drow[1] = MINUS_INFINITY;
+    float BestScore = 0;
+    uint Besti = 0, Bestj = 0;
+    uint prev_jlo = 0, prev_jhi = 0, jlo = 1, jhi = 1;
+    float M0 = BestScore;
+    for (uint i = 1; i <= LA; ++i) {
+        if (jlo == prev_jlo) { Mrow[jlo - 1] = MINUS_INFINITY; Drow[jlo] = MINUS_INFINITY; }
+        uint endj = std::min(prev_jhi + 1, LB);
+        for (uint j = endj + 1; j <= std::min(jhi + 1, LB); ++j) { Mrow[j - 1] = MINUS_INFINITY; Drow[j] = MINUS_INFINITY; }
+        uint next_jlo = UINT_MAX, next_jhi = UINT_MAX;
+        float I0 = MINUS_INFINITY;
+        for (uint j = jlo; j <= jhi; ++j) {
+            byte TraceBits = 0;
+            const float SavedM0 = M0;
+            // MATCH
+            float xM = M0;
+            if (Drow[j] > xM) { xM = Drow[j]; TraceBits = TRACEBITS_DM; }
+            if (I0 > xM) { xM = I0; TraceBits = TRACEBITS_IM; }
+            M0 = Mrow[j];
+            float s = Sub(LoA + i - 1, LoB + j - 1);
+            s += xM;
+            Mrow[j] = s;
+            float h = s - BestScore + X;
+            if (h > 0) { next_jlo = std::min(next_jlo, j + 1); next_jhi = j + 1; }
+            if (h > AbsOpen) next_jlo = std::min(next_jlo, j);
+            if (h > AbsExt && j == jhi && jhi + 1 < LB) {        // match-insert may extend the current row
+                ++jhi;
+                uint new_endj = std::max(std::min(jhi + 1, LB), endj);
+                for (uint j2 = endj + 1; j2 <= new_endj; ++j2) {
+                    if (j2 - 1 > j) Mrow[j2 - 1] = MINUS_INFINITY;
+                    Drow[j2] = MINUS_INFINITY;
+                }
+                endj = new_endj;
+            }
+            if (s >= BestScore) { BestScore = s; Besti = i; Bestj = j; }
+            // DELETE
+            if (j != jlo) {
+                const float md = SavedM0 + Open;
+                Drow[j] += Ext;
+                if (md >= Drow[j]) { Drow[j] = md; TraceBits |= TRACEBITS_MD; }
+                const float hd = Drow[j] - BestScore + X;
+                if (hd > 0) { next_jlo = std::min(next_jlo, j - 1); next_jhi = std::max(next_jhi, j - 1); }
+            }
+            // INSERT
+            {
+                const float mi = SavedM0 + Open;
+                I0 += Ext;
+                if (mi >= I0) { I0 = mi; TraceBits |= TRACEBITS_MI; }
+                const float hi = I0 - BestScore + X;
+                if (hi > 0) { next_jlo = std::min(next_jlo, j + 1); next_jhi = std::max(next_jhi, j + 1); }
+                if (hi > AbsExt && j == jhi && jhi + 1 < LB) {
+                    ++jhi;
+                    uint new_endj = std::max(std::min(jhi + 1, LB), endj);
+                    for (uint j2 = endj + 1; j2 <= new_endj; ++j2) { Mrow[j2 - 1] = MINUS_INFINITY; Drow[j2] = MINUS_INFINITY; }
+                    endj = new_endj;
+                }
+            }
+            Mem.tb(i, j) = TraceBits;
+        }
+        if (jhi < LB) {                                             // end of Drow[]
+            const uint jhi1 = jhi + 1;
+            Mem.tb(i, jhi1) = 0;
+            const float md = M0 + Open;
+            Drow[jhi1] += Ext;
+            if (md >= Drow[jhi1]) { Drow[jhi1] = md; Mem.tb(i, jhi1) = TRACEBITS_MD; }
+        }
+        if (next_jlo == UINT_MAX) break;
+        prev_jlo = jlo; prev_jhi = jhi;
+        jlo = next_jlo; jhi = next_jhi;
+        if (jlo > LB) jlo = LB;
+        if (jhi > LB) jhi = LB;
+        if (jlo == prev_jlo) { M0 = MINUS_INFINITY; Drow[jlo] = MINUS_INFINITY; }
+        else M0 = Mrow[jlo - 1];
+    }
+    if (BestScore <= 0.0f) return 0.0f;
+    // traceback (xdropfwd.cpp:10-67): stops when the first row or column is reached
+    {
+        uint i = Besti, j = Bestj;
+        char State = 'M';
+        for (;;) {
+            Path += State;
+            if (i == 1 || j == 1) break;
+            char Next;
+            if (State == 'M') {
+                const byte c = Mem.tb(i, j);
+                Next = (c & TRACEBITS_DM) ? 'D' : (c & TRACEBITS_IM) ? 'I' : 'M';
+                --i; --j;
+            } else if (State == 'D') {
+                Next = (Mem.tb(i, j + 1) & TRACEBITS_MD) ? 'M' : 'D';
+                --i;
+            } else {
+                Next = (Mem.tb(i + 1, j) & TRACEBITS_MI) ? 'M' : 'I';
+                --j;
+            }
+            State = Next;
+        }
+        std::reverse(Path.begin(), Path.end());
+    }
+    uint nM, nD, nI;
+    GetPathCounts(Path, nM, nD, nI);
+    *ptrSegLoA = LoA + Besti - nM - nD;
+    *ptrSegLoB = LoB + Bestj - nM - nI;
+    return BestScore;
+}
+
+template <class SubFn>
+float XDropBwd(XDropMem &Mem, float X, float Open, float Ext, SubFn Sub, uint HiA, uint, uint HiB, uint, uint *ptrSegLoA, uint *ptrSegLoB,
+               std::string &Path)
+{
+    *ptrSegLoA = UINT_MAX;
+    *ptrSegLoB = UINT_MAX;
+    const uint RLA = HiA + 1, RLB = HiB + 1;
+    auto RevSub = [&](uint RevPosA, uint RevPosB) { return Sub(RLA - RevPosA - 1, RLB - RevPosB - 1); };
+    uint SegLoA, SegLoB;
+    const float Score = XDropFwd(Mem, X, Open, Ext, RevSub, 0, HiA + 1, 0, HiB + 1, &SegLoA, &SegLoB, Path);
+    std::reverse(Path.begin(), Path.end());
+    return Score;
+}
+
+void MergeFwdBwd(uint, uint, uint FwdLoA, uint FwdLoB, const std::string &FwdPath, uint BwdHiA, uint BwdHiB, const std::string &BwdPath,
+                 uint &LoA, uint &LoB, uint &HiA, uint &HiB, std::string &Path)
+{
+    if (FwdPath.empty()) { HiA = BwdHiA; HiB = BwdHiB; }
+    else {
+        uint M, D, I;
+        GetPathCounts(FwdPath, M, D, I);
+        HiA = FwdLoA + (M + D) - 1;
+        HiB = FwdLoB + (M + I) - 1;
+    }
+    if (BwdPath.empty()) { LoA = FwdLoA; LoB = FwdLoB; }
+    else {
+        uint M, D, I;
+        GetPathCounts(BwdPath, M, D, I);
+        LoA = BwdHiA + 1 - (M + D);
+        LoB = BwdHiB + 1 - (M + I);
+    }
+    Path = BwdPath + FwdPath;
+}
+}   // namespace
+
+float DSSAligner::SubstScore(uint PosA, uint PosB)
+{
+    float Total = 0;
+    for (uint f = 0; f < RSK_NFEATURES; ++f)
+        Total += rsk_feature_mx[f][RSK_FEATURE_DIM * (*m_ProfileA)[f][PosA] + (*m_ProfileB)[f][PosB]];
+    return Total;
+}
+
+float DSSAligner::GetMegaHSPScore(uint Lo_i, uint Lo_j, uint Len)
+{
+    float Total = 0;
+    for (uint f = 0; f < RSK_NFEATURES; ++f) {
+        const std::vector<byte> &RowA = (*m_ProfileA)[f], &RowB = (*m_ProfileB)[f];
+        for (uint k = 0; k < Len; ++k) Total += rsk_feature_mx[f][RSK_FEATURE_DIM * RowA[Lo_i + k] + RowB[Lo_j + k]];
+    }
+    return Total;
+}
+
+float DSSAligner::XDropHSP(uint Loi_in, uint Loj_in, uint Len, uint &Loi_out, uint &Loj_out, uint &Hii_out, uint &Hij_out)
+{
+    Loi_out = Loj_out = Hii_out = Hij_out = UINT_MAX;
+    const float Open = m_Params->m_GapOpen, Ext = m_Params->m_GapExt, X = float(m_Params->m_MKF_X2);
+    const uint LA = m_ChainA->GetSeqLength(), LB = m_ChainB->GetSeqLength();
+    uint LoA = Loi_in + Len / 2, LoB = Loj_in + Len / 2;
+    const uint K = 8;                                            // highest-scoring 8-mer of the HSP
+    std::vector<float> v(Len);
+    for (uint Col = 0; Col < Len; ++Col) v[Col] = SubstScore(Loi_in + Col, Loj_in + Col);
+    float BestMerScore = 0;
+    for (uint MerStart = 0; MerStart + K <= Len; ++MerStart) {
+        float MerScore = 0;
+        for (uint k = 0; k < K; ++k) MerScore += v[MerStart + k];
+        if (MerScore > BestMerScore) { BestMerScore = MerScore; LoA = Loi_in + MerStart; LoB = Loj_in + MerStart; }
+    }
+    if (std::min(LoA, LoB) < K / 2) { LoA += K / 2; LoB += K / 2; }
+    static thread_local XDropMem Mem;
+    auto Sub = [this](uint a, uint b) { return SubstScore(a, b); };
+    std::string FwdPath, BwdPath;
+    uint s1, s2;
+    const float ScoreFwd = XDropFwd(Mem, X, Open, Ext, Sub, LoA, LA, LoB, LB, &s1, &s2, FwdPath);
+    const float ScoreBwd = XDropBwd(Mem, X, Open, Ext, Sub, LoA - 1, LA, LoB - 1, LB, &s1, &s2, BwdPath);
+    const float TotalScore = ScoreFwd + ScoreBwd;
+    if (TotalScore < 10) { m_XDropPath.clear(); return 0; }
+    MergeFwdBwd(LA, LB, LoA, LoB, FwdPath, LoA - 1, LoB - 1, BwdPath, Loi_out, Loj_out, Hii_out, Hij_out, m_XDropPath);
+    return TotalScore;
+}
+
+void DSSAligner::AlignMKF()
+{
+    ClearAlign();
+    m_MKF.Align(*m_MuLettersB, *m_MuKmersB);
+    PostAlignMKF();
+}
+
+void DSSAligner::PostAlignMKF()
+{
+    if (m_MKF.m_BestChainScore <= 0) return;
+    float MegaHSPTotal = 0, BestMegaScore = 0;
+    uint BestMegaIdx = 0;
+    const uint M = (uint) m_MKF.m_ChainHSPLois.size();
+    for (uint Idx = 0; Idx < M; ++Idx) {
+        const float MegaScore = GetMegaHSPScore((uint) m_MKF.m_ChainHSPLois[Idx], (uint) m_MKF.m_ChainHSPLojs[Idx], (uint) m_MKF.m_ChainHSPLens[Idx]);
+        if (MegaScore > BestMegaScore) { BestMegaScore = MegaScore; BestMegaIdx = Idx; }
+        MegaHSPTotal += MegaScore;
+    }
+    if (MegaHSPTotal < m_Params->m_MKF_MinMegaHSPScore) return;
+    m_XDropScore = XDropHSP((uint) m_MKF.m_ChainHSPLois[BestMegaIdx], (uint) m_MKF.m_ChainHSPLojs[BestMegaIdx],
+                            (uint) m_MKF.m_ChainHSPLens[BestMegaIdx], m_LoA, m_LoB, m_HiA, m_HiB);
+    m_AlnFwdScore = m_XDropScore;
+    m_Path = m_XDropPath;
+    uint nM, nD, nI;
+    GetPathCounts(m_Path, nM, nD, nI);
+    m_HiA = m_LoA + nM + nD - 1;
+    m_HiB = m_LoB + nM + nI - 1;
+    CalcEvalue();
+}
+
+// ---------------------------------------------------------------------------------------------
+// output (dssaligner.cpp:1016-1034, userfields.cpp:19-152, dssaligner.cpp:1119-1281,1325-1372)
+// ---------------------------------------------------------------------------------------------
+double DSSAligner::GetQCovPct(bool Top) const
+{
+    const uint QL = GetQL(Top);
+    if (QL == 0) return 0;
+    double Pct = (100.0 * (GetHi(Top) - GetLo(Top) + 1)) / QL;
+    if (Pct > 100) Pct = 100;
+    return Pct;
+}
+
+double DSSAligner::GetTCovPct(bool Top) const
+{
+    const uint TL = GetQL(Top);          // sic (dssaligner.cpp:1134)
+    double Pct = (100.0 * (GetHi(!Top) - GetLo(!Top) + 1)) / TL;
+    if (Pct > 100) Pct = 100;
+    return Pct;
+}
+
+float DSSAligner::GetPctId() const
+{
+    uint PosA = m_LoA, PosB = m_LoB, N = 0, n = 0;
+    const std::string &SeqA = m_ChainA->m_Seq, &SeqB = m_ChainB->m_Seq;
+    for (char c : m_Path) {
+        if (c == 'M') { if (SeqA[PosA] == SeqB[PosB]) ++n; ++PosA; ++PosB; ++N; }
+        else if (c == 'D') ++PosA;
+        else if (c == 'I') ++PosB;
+    }
+    return N == 0 ? 0 : (n * 100.0f) / N;
+}
+
+void DSSAligner::GetRow(bool Up, bool Top, bool Global, std::string &Row) const
+{
+    if (Up == Top) GetRow_A(Row, Global);
+    else GetRow_B(Row, Global);
+}
+
+void DSSAligner::GetRow_A(std::string &Row, bool Global) const
+{
+    Row.clear();
+    const std::string &SeqA = m_ChainA->m_Seq, &SeqB = m_ChainB->m_Seq;
+    const uint LA = (uint) SeqA.size(), LB = (uint) SeqB.size();
+    if (Global) {
+        for (uint i = m_LoA; i < m_LoB; ++i) Row += '.';
+        for (uint i = 0; i < m_LoA; ++i) Row += (char) tolower(SeqA[i]);
+    }
+    uint PosA = m_LoA, PosB = m_LoB;
+    for (char c : m_Path) {
+        if (c == 'M') { Row += SeqA[PosA++]; ++PosB; }
+        else if (c == 'D') Row += SeqA[PosA++];
+        else if (c == 'I') { Row += '-'; ++PosB; }
+    }
+    if (Global) {
+        while (PosA < LA) { Row += (char) tolower(SeqA[PosA++]); ++PosB; }
+        while (PosB++ < LB) Row += '.';
+    }
+}
+
+void DSSAligner::GetRow_B(std::string &Row, bool Global) const
+{
+    Row.clear();
+    const std::string &SeqA = m_ChainA->m_Seq, &SeqB = m_ChainB->m_Seq;
+    const uint LA = (uint) SeqA.size(), LB = (uint) SeqB.size();
+    if (Global) {
+        for (uint i = m_LoB; i < m_LoA; ++i) Row += '.';
+        for (uint i = 0; i < m_LoB; ++i) Row += (char) tolower(SeqB[i]);
+    }
+    uint PosA = m_LoA, PosB = m_LoB;
+    for (char c : m_Path) {
+        if (c == 'M') { ++PosA; Row += SeqB[PosB++]; }
+        else if (c == 'D') { ++PosA; Row += '-'; }
+        else if (c == 'I') Row += SeqB[PosB++];
+    }
+    if (Global) {
+        while (PosB < LB) { Row += (char) tolower(SeqB[PosB++]); ++PosA; }
+        while (PosA++ < LA) Row += '.';
+    }
+}
+
+static const char *EvalueToStr(double E, char *buf, size_t n)
+{
+    if (E > 10) E = 99;
+    if (E > 1) snprintf(buf, n, "%.1f", E);
+    else if (E > 0.001) snprintf(buf, n, "%.4f", E);
+    else snprintf(buf, n, "%.3g", E);
+    return buf;
+}
+
+void DSSAligner::WriteUserField(FILE *f, USERFIELD UF, bool Up)
+{
+    if (f == nullptr) return;
+    char tmp[64];
+    std::string s;
+    switch (UF) {
+    case UF_query: fputs(GetLabel(Up), f); break;
+    case UF_target: fputs(GetLabel(!Up), f); break;
+    case UF_evalue: fputs(EvalueToStr(GetEvalue(Up), tmp, sizeof(tmp)), f); break;
+    case UF_pvalue: fprintf(f, "%.3g", GetPvalue(Up)); break;
+    case UF_ql: fprintf(f, "%u", GetQL(Up)); break;
+    case UF_tl: fprintf(f, "%u", GetTL(Up)); break;
+    case UF_qlo: fprintf(f, "%u", GetLo(Up) + 1); break;
+    case UF_qhi: fprintf(f, "%u", GetHi(Up) + 1); break;
+    case UF_tlo: fprintf(f, "%u", GetLo(!Up) + 1); break;
+    case UF_thi: fprintf(f, "%u", GetHi(!Up) + 1); break;
+    case UF_qcovpct: fprintf(f, "%.1f", GetQCovPct(Up)); break;
+    case UF_tcovpct: fprintf(f, "%.1f", GetTCovPct(Up)); break;
+    case UF_pctid: fprintf(f, "%.1f", GetPctId()); break;
+    case UF_ts: fprintf(f, "%.3g", GetTestStatistic(Up)); break;
+    case UF_newts: fprintf(f, "%.3g", GetNewTestStatistic(Up)); break;
+    case UF_raw: fprintf(f, "%.3g", m_AlnFwdScore); break;
+    case UF_ids: fprintf(f, "%u", m_Ids); break;
+    case UF_gaps: fprintf(f, "%u", m_Gaps); break;
+    case UF_cigar: PathToCIGAR(m_Path.c_str(), s, Up); fputs(s.c_str(), f); break;
+    case UF_qrow: GetRow(Up, true, false, s); fputs(s.c_str(), f); break;
+    case UF_trow: GetRow(Up, false, false, s); fputs(s.c_str(), f); break;
+    case UF_qrowg: GetRow(Up, true, true, s); fputs(s.c_str(), f); break;
+    case UF_trowg: GetRow(Up, false, true, s); fputs(s.c_str(), f); break;
+    case UF_dpscore: fprintf(f, "%.4g", m_AlnFwdScore); break;
+    case UF_lddt: fprintf(f, "%.4g", m_LDDT != FLT_MAX ? m_LDDT : GetLDDT()); break;
+    case UF_aq: fprintf(f, "%.4f", GetAQ(Up)); break;
+    case UF_muhsp: fprintf(f, "%d", m_MKF.m_BestHSPScore); break;
+    case UF_muchain: fprintf(f, "%d", m_MKF.m_BestChainScore); break;
+    default: fputs("?", f); break;        // gscore / muscore belong to commands outside -search
+    }
+}
+
+void DSSAligner::ToTsv(FILE *f, bool Up, bool NoSelf)
+{
+    if (f == nullptr) return;
+    if (NoSelf && m_ChainA->m_Label == m_ChainB->m_Label) return;
+    std::lock_guard<std::mutex> g(m_OutputLock);
+    for (size_t i = 0; i < m_UFs.size(); ++i) {
+        if (i > 0) fputc('\t', f);
+        WriteUserField(f, m_UFs[i], Up);
+    }
+    fputc('\n', f);
+}
+
+}   // namespace reseek_amd

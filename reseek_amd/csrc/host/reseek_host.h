@@ -1,0 +1,215 @@
+// reseek_host.h -- host side above the C-ABI: C++ classes that keep the reference's names, call
+// signatures, result fields and -output/-columns semantics for the -search path, but run the
+// pair scoring in batches on the GPU through librsk's C-ABI (include/reseek_amd.h).
+//
+// Mirrors (file:line relative to /root/reference/src):
+//   DSSParams   dssparams.h:27, presets dssparams.cpp:44-104, defaults namedparams.cpp:32-53
+//   DSSAligner  dssaligner.h:18   (SetQuery/SetTarget/AlignQueryTarget, result fields, ToTsv)
+//   MuKmerFilter mukmerfilter.h:10 (long-chain seed-and-extend path, host resident for now)
+//   DBSearcher  dbsearcher.h:14   (LoadDB/Setup/RunSelf/RunQuery/BaseOnAln/OnAln)
+// The reference reads command-line options through global opt(x) macros (myutils.h:365-372); here
+// they are one explicit SearchOptions object.
+#pragma once
+
+#include <cfloat>
+#include <climits>
+#include <cstdint>
+#include <cstdio>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../../include/reseek_amd.h"
+
+namespace reseek_amd {
+
+typedef unsigned char byte;
+typedef unsigned int uint;
+
+enum ALGO_MODE { AM_Invalid, AM_Fast, AM_Sensitive, AM_VerySensitive };   // dssparams.h:8-14
+
+// user output fields, userfieldnames.h
+enum USERFIELD {
+    UF_Undefined, UF_query, UF_target, UF_pvalue, UF_evalue, UF_qlo, UF_qhi, UF_tlo, UF_thi, UF_ql, UF_tl, UF_pctid,
+    UF_cigar, UF_qrow, UF_trow, UF_qrowg, UF_trowg, UF_ts, UF_newts, UF_dpscore, UF_lddt, UF_ids, UF_gaps, UF_aq,
+    UF_muhsp, UF_muchain, UF_gscore, UF_raw, UF_muscore, UF_qcovpct, UF_tcovpct
+};
+USERFIELD StrToUF(const std::string &Str);       // userfields.cpp:11 (returns UF_Undefined instead of Die)
+
+// The options of the reference's -search command that influence the hot path (myopts.h).
+struct SearchOptions {
+    ALGO_MODE mode = AM_Invalid;        // -fast / -sensitive / -verysensitive
+    bool evalue_set = false;  double evalue = 10;      // -evalue
+    bool mints_set = false;   double mints = 0;        // -mints
+    bool noself = false;                               // -noself
+    bool scores_are_not_evalues = false;
+    std::string columns;                               // -columns a+b+c ("" = default 10 columns, "std" allowed)
+    bool omega_set = false;   float omega = 0;         // -omega
+    bool omegafwd_set = false; float omegafwd = 0;     // -omegafwd
+    bool minfwdscore_set = false; float minfwdscore = 0;
+    bool gapopen_set = false; float gapopen = 0;       // -gapopen (positive)
+    float gapext = 0;                                  // applied only when -gapopen is set (dssparams.cpp:96-97, kept)
+    bool mkfl_set = false;    uint mkfl = 0;           // -mkfl
+    bool selfrev0 = false;                             // -selfrev0
+    size_t batch_pairs = 1u << 16;                     // pairs per GPU alignment batch (bounds the trace memory)
+};
+
+class DSSParams {
+public:
+    float m_GapOpen = FLT_MAX, m_GapExt = FLT_MAX;
+    float m_MinFwdScore = FLT_MAX;
+    float m_Omega = FLT_MAX, m_OmegaFwd = FLT_MAX;
+    bool m_UsePara = true;
+    int m_ParaMuGapOpen = 2, m_ParaMuGapExt = 1;       // dssparams.h:45-46
+    uint m_MKFL = UINT_MAX;
+    int m_MKF_X1 = INT_MAX, m_MKF_X2 = INT_MAX, m_MKF_MinHSPScore = INT_MAX;
+    float m_MKF_MinMegaHSPScore = FLT_MAX;
+    std::string m_MKFPatternStr = "111";
+    void SetDefaults();                                 // namedparams.cpp:32
+    void SetDSSParams(const SearchOptions &Opts);       // dssparams.cpp:44 (DM_UseCommandLineOption)
+};
+
+class PDBChain {                                        // pdbchain.h:10 (the members the path uses)
+public:
+    std::string m_Label, m_Seq;
+    std::vector<float> m_Xs, m_Ys, m_Zs;
+    uint m_Idx = UINT_MAX;
+    uint GetSeqLength() const { return (uint) m_Seq.size(); }
+};
+
+class DSSAligner;
+
+class MuKmerFilter {                                    // mukmerfilter.h:10
+public:
+    static const uint HASHW = 4;
+    const DSSParams *m_Params = nullptr;
+    const std::vector<byte> *m_ptrMuLettersQ = nullptr;
+    const std::vector<uint> *m_ptrMuKmersQ = nullptr;
+    const std::vector<byte> *m_ptrMuLettersT = nullptr;
+    std::vector<uint16_t> m_KmerHashTableQ;             // 36^3 * HASHW slots of query positions, 0xffff = empty
+    uint m_DictSize = 36 * 36 * 36;
+    std::vector<int> m_MuKmerHSPLois, m_MuKmerHSPLojs, m_MuKmerHSPLens, m_MuKmerHSPScores;
+    int m_BestChainScore = 0, m_BestHSPScore = 0;
+    std::vector<int> m_ChainHSPLois, m_ChainHSPLojs, m_ChainHSPLens;
+
+    void SetParams(const DSSParams &Params) { m_Params = &Params; }
+    void ResetQ();
+    void SetQ(const std::string &LabelQ, const std::vector<byte> *ptrMuLettersQ, const std::vector<uint> *ptrMuKmersQ);
+    void Align(const std::vector<byte> &MuLettersT, const std::vector<uint> &MuKmersT);
+    int MuXDrop(int PosQ, int LQ, int PosT, int LT, int X, int &Loi, int &Loj, int &Len) const;
+    void ChainHSPs();
+};
+
+class DSSAligner {                                      // dssaligner.h:18
+    const DSSParams *m_Params = nullptr;
+
+public:
+    const PDBChain *m_ChainA = nullptr, *m_ChainB = nullptr;
+    const std::vector<std::vector<byte> > *m_ProfileA = nullptr, *m_ProfileB = nullptr;
+    const std::vector<byte> *m_MuLettersA = nullptr, *m_MuLettersB = nullptr;
+    const std::vector<uint> *m_MuKmersA = nullptr, *m_MuKmersB = nullptr;
+    MuKmerFilter m_MKF;
+    float m_XDropScore = 0;
+    std::string m_XDropPath;
+
+    std::string m_Path;
+    uint m_LoA = UINT_MAX, m_LoB = UINT_MAX, m_HiA = UINT_MAX, m_HiB = UINT_MAX;
+    float m_PvalueA = FLT_MAX, m_PvalueB = FLT_MAX, m_EvalueA = FLT_MAX, m_EvalueB = FLT_MAX;
+    float m_QualityA = FLT_MAX, m_QualityB = FLT_MAX;
+    float m_TestStatisticA = -FLT_MAX, m_TestStatisticB = -FLT_MAX;
+    float m_NewTestStatisticA = -FLT_MAX, m_NewTestStatisticB = -FLT_MAX;
+    uint m_Ids = UINT_MAX, m_Gaps = UINT_MAX;
+    float m_SelfRevScoreA = FLT_MAX, m_SelfRevScoreB = FLT_MAX;
+    float m_AlnFwdScore = 0;
+    float m_LDDT = FLT_MAX;
+    std::vector<USERFIELD> m_UFs;
+    rsk_ctx *m_Ctx = nullptr;                           // GPU context for the single-pair form of AlignQueryTarget
+
+    static std::mutex m_OutputLock;
+
+    DSSAligner();
+    void SetColumns(const std::string &Columns);        // -columns (dssaligner.cpp:114-136); "" = default_columns :100-112
+    void SetParams(const DSSParams &Params);
+    const DSSParams &GetParams() const { return *m_Params; }
+    void UnsetQuery();
+    void SetQuery(const PDBChain &Chain, const std::vector<std::vector<byte> > *ptrProfile, const std::vector<byte> *ptrMuLetters,
+                  const std::vector<uint> *ptrMuKmers, float SelfRevScore);
+    void SetTarget(const PDBChain &Chain, const std::vector<std::vector<byte> > *ptrProfile, const std::vector<byte> *ptrMuLetters,
+                   const std::vector<uint> *ptrMuKmers, float SelfRevScore);
+    bool DoMKF() const;                                 // dssaligner.cpp:715
+    void ClearAlign();                                  // dssaligner.cpp:906
+    void AlignQueryTarget();                            // dssaligner.cpp:793 (one pair; batch of 1 on the GPU)
+    void AlignMKF();                                    // dssaligner.cpp:1387
+    void PostAlignMKF();                                // dssaligner.cpp:1395
+    float GetMegaHSPScore(uint Lo_i, uint Lo_j, uint Len);   // dssaligner.cpp:488
+    float SubstScore(uint PosA, uint PosB);             // xdrophsp.cpp:8
+    float XDropHSP(uint Loi_in, uint Loj_in, uint Len, uint &Loi_out, uint &Loj_out, uint &Hii_out, uint &Hij_out);
+    void CalcEvalue();                                  // dssaligner.cpp:852 (host form, used by the MKF path)
+    float GetLDDT() const;                              // dssaligner.cpp:1313
+    void SetFromAln(const rsk_aln &Aln, const char *Path);   // fill the result fields from a GPU batch record
+
+    void ToTsv(FILE *f, bool Up, bool NoSelf = false);  // dssaligner.cpp:1016
+    void WriteUserField(FILE *f, USERFIELD UF, bool Up);
+    const char *GetLabel(bool Top) const { return Top ? m_ChainA->m_Label.c_str() : m_ChainB->m_Label.c_str(); }
+    uint GetQL(bool Top) const { return Top ? m_ChainA->GetSeqLength() : m_ChainB->GetSeqLength(); }
+    uint GetTL(bool Top) const { return Top ? m_ChainB->GetSeqLength() : m_ChainA->GetSeqLength(); }
+    uint GetLo(bool Top) const { return Top ? m_LoA : m_LoB; }
+    uint GetHi(bool Top) const { return Top ? m_HiA : m_HiB; }
+    float GetTestStatistic(bool Top) const { return Top ? m_TestStatisticA : m_TestStatisticB; }
+    float GetNewTestStatistic(bool Top) const { return Top ? m_NewTestStatisticA : m_NewTestStatisticB; }
+    float GetEvalue(bool Top) const { return Top ? m_EvalueA : m_EvalueB; }
+    float GetPvalue(bool Top) const { return Top ? m_PvalueA : m_PvalueB; }
+    float GetAQ(bool Top) const { return Top ? m_QualityA : m_QualityB; }
+    double GetQCovPct(bool Top) const;
+    double GetTCovPct(bool Top) const;
+    float GetPctId() const;                             // dssaligner.cpp:1325
+    void GetRow(bool Up, bool Top, bool Global, std::string &Row) const;
+    void GetRow_A(std::string &Row, bool Global) const;
+    void GetRow_B(std::string &Row, bool Global) const;
+};
+
+void InvertPath(const std::string &Path, std::string &InvPath);              // dssaligner.cpp:58
+void GetPathCounts(const std::string &Path, uint &M, uint &D, uint &I);      // dssaligner.cpp:75
+void PathToCIGAR(const char *Path, std::string &CIGAR, bool FlipDI);         // cigar.cpp:95
+
+class DBSearcher {                                      // dbsearcher.h:14
+public:
+    virtual ~DBSearcher();
+    std::mutex m_Lock;
+    const DSSParams *m_Params = nullptr;
+    SearchOptions m_Opts;
+    std::vector<PDBChain *> m_DBChains;
+    std::vector<std::vector<std::vector<byte> > *> m_DBProfiles;
+    std::vector<std::vector<byte> *> m_DBMuLettersVec;
+    std::vector<std::vector<uint> *> m_DBMuKmersVec;
+    std::vector<float> m_DBSelfRevScores;
+    double m_MaxEvalue = 10;
+    uint m_HitCount = 0;
+    uint64_t m_ProcessedPairCount = 0;
+    // run statistics (cf. DSSAligner::Stats dssaligner.cpp:1088)
+    uint64_t m_AlnCount = 0, m_MuFilterInputCount = 0, m_MuFilterDiscardCount = 0, m_MKFPairCount = 0, m_SWCount = 0;
+    FILE *m_fTsv = nullptr;                             // g_fTsv of output.cpp
+    rsk_ctx *m_Ctx = nullptr;
+    rsk_db *m_Db = nullptr;                             // the loaded chains in HBM
+    DSSAligner m_DA;                                    // the aligner the hits are replayed through
+
+    uint GetDBChainCount() const { return (uint) m_DBChains.size(); }
+    // Loads chains + per-chain features.  Stage 1 reads the ".rskdb" container (precomputed
+    // DSS profile / Mu letters / 3-mers / CA coordinates / self-rev score per chain, format in
+    // tests/fixtures.py and DESIGN.md); .bca + on-the-fly DSS featurisation is row (f) "next".
+    void LoadDB(const std::string &DBFN);
+    void AddChain(PDBChain *ptrChain, std::vector<std::vector<byte> > *ptrProfile, std::vector<byte> *ptrMuLetters);
+    void Setup();                                       // dbsearcher.cpp:73
+    void RunSelf();                                     // runself.cpp:101
+    void RunQuery(DBSearcher &DBChainsSource);          // runquery.cpp:82 (A = each chain of the source, B = our chains)
+    bool Reject(DSSAligner &DA, bool Up) const;         // dbsearcher.cpp:258
+    void BaseOnAln(DSSAligner &DA, bool Up);            // dbsearcher.cpp:267
+    virtual void OnSetup() {}
+    virtual void OnAln(DSSAligner &DA, bool Up) {}
+
+private:
+    void UploadToGpu();
+    void AlignPairBatch(const std::vector<uint32_t> &ia, const std::vector<uint32_t> &ib, bool Self);
+};
+
+}   // namespace reseek_amd

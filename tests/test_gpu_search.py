@@ -1,0 +1,82 @@
+"""End-to-end hit tables: `reseek -search` through DBSearcher/DSSAligner mirrors + GPU kernels vs the
+reference binary's own output (tests/golden/hits_*.tsv*, generated with -threads 1, compared sorted)."""
+import gzip
+import os
+import shutil
+import tempfile
+
+import pytest
+
+import fixtures as fx
+
+pytestmark = pytest.mark.gpu
+COLS = "query+target+qlo+qhi+ql+tlo+thi+tl+pctid+pvalue+evalue+cigar+dpscore+lddt+newts+ids+gaps+aq"
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+    import reseek_amd
+    assert torch.cuda.is_available()
+    c = reseek_amd.Ctx(0, stream=torch.cuda.current_stream().cuda_stream)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def tmpdir():
+    d = tempfile.mkdtemp(prefix="rsk_search_")
+    yield d
+    shutil.rmtree(d, ignore_errors=True)
+
+
+def unpack(name, tmpdir):
+    dst = os.path.join(tmpdir, name[:-3])
+    if not os.path.exists(dst):
+        with gzip.open(os.path.join(fx.GOLDEN, name), "rb") as f, open(dst, "wb") as g:
+            g.write(f.read())
+    return dst
+
+
+def run(ctx, tmpdir, dbname, mode, columns, golden, db2=None, **kw):
+    q = unpack(dbname, tmpdir)
+    out = os.path.join(tmpdir, "out_%s_%s.tsv" % (dbname, mode))
+    nhits, stats = ctx.search_rskdb(q, out, mode, db=unpack(db2, tmpdir) if db2 else None, columns=columns, **kw)
+    got = sorted(open(out).read().splitlines())
+    want = ["\t".join(r) for r in fx.read_tsv(golden)]
+    assert nhits == len(got)
+    if got != want:
+        gs, ws = set(got), set(want)
+        missing = sorted(ws - gs)[:5]
+        extra = sorted(gs - ws)[:5]
+        raise AssertionError("hit tables differ: %d vs %d rows\nmissing: %s\nextra: %s" % (len(got), len(want), missing, extra))
+    return stats
+
+
+def test_q100_verysensitive_all_columns(ctx, tmpdir):
+    st = run(ctx, tmpdir, "q100_verysensitive.rskdb.gz", "verysensitive", COLS, "hits_q100_verysensitive.tsv.gz")
+    assert st[0] == 5050 and st[4] == 0
+
+
+def test_q100_sensitive_all_columns(ctx, tmpdir):
+    st = run(ctx, tmpdir, "q100_sensitive.rskdb.gz", "sensitive", COLS, "hits_q100_sensitive.tsv.gz")
+    assert st[0] == 5050 and st[4] == 490          # 490 pairs take the MKF path (+5 self-rev calls = the 495 of SURVEY 3.4)
+    assert st[2] == 4560                           # m_MuFilterInputCount
+
+
+def test_q100_fast_all_columns(ctx, tmpdir):
+    run(ctx, tmpdir, "q100_fast.rskdb.gz", "fast", COLS, "hits_q100_fast.tsv.gz")
+
+
+def test_q100_default_columns(ctx, tmpdir):
+    run(ctx, tmpdir, "q100_sensitive.rskdb.gz", "sensitive", None, "hits_q100_sensitive_std.tsv.gz")
+    run(ctx, tmpdir, "q100_verysensitive.rskdb.gz", "verysensitive", None, "hits_q100_verysensitive_std.tsv.gz")
+
+
+def test_q10_sensitive(ctx, tmpdir):
+    run(ctx, tmpdir, "q10_sensitive.rskdb.gz", "sensitive", COLS, "hits_q10_sensitive.tsv")
+
+
+def test_palms_sensitive_long_chains_mkf(ctx, tmpdir):
+    st = run(ctx, tmpdir, "palms_sensitive.rskdb.gz", "sensitive", COLS, "hits_palms_sensitive.tsv.gz")
+    assert st[4] > 300      # lengths 418..2,099: most pairs take the MKF path
