@@ -161,12 +161,12 @@ def main():
         step()
         # HIP events recorded by the library on this same stream around its launches
     if dist is not None:
-        # hit summary exchange (the path's only collective): count of pairs >= 50 and a checksum
-        tri = torch.triu(out.to(torch.int64) & 0xFFFF)
-        summary[0] = (tri >= 50).sum()
-        summary[1] = tri.sum()
-        gathered = [torch.zeros_like(summary) for _ in range(world)]
-        dist.all_gather(gathered, summary)
+        # the path's only collective: gather of the per-rank hit buffers (query, target, score) onto rank 0
+        from reseek_amd import dist as rdist
+        hit = torch.nonzero(torch.triu((out.to(torch.int32) & 0xFFFF) >= 120))
+        rows = torch.cat([hit.to(torch.int32), (out[hit[:, 0], hit[:, 1]].to(torch.int32) & 0xFFFF)[:, None]], dim=1)
+        gathered = rdist.gather_rows(rows.cpu().numpy(), dst=0, device=torch.device("cuda", local))
+        summary[0] = 0 if gathered is None else gathered.shape[0]
     barrier()
     dt = time.perf_counter() - t0
     # per-launch kernel time of the last step from the library's HIP events (same stream)

@@ -1,0 +1,70 @@
+"""N > 1 plumbing on CPU (gloo, world_size 2): target sharding + the hit-buffer gather used by the
+multi-GPU path (bench.py --gpus N, one process per GPU over RCCL)."""
+import os
+import socket
+
+import numpy as np
+import torch.multiprocessing as mp
+
+from reseek_amd import dist as rdist
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lengths = np.random.default_rng(0).integers(5, 1400, 1000)
+    lo, hi = rdist.shard_by_residues(lengths, world)[rank]
+    # each rank "finds" a deterministic, rank-dependent number of hits inside its target shard
+    rng = np.random.default_rng(100 + rank)
+    n = 37 + 100 * rank
+    rows = np.stack([rng.integers(0, 256, n), rng.integers(lo, hi, n), rng.integers(0, 5000, n)], axis=1).astype(np.int32)
+    got = rdist.gather_rows(rows, dst=0)
+    # empty contribution from one rank must also work
+    got2 = rdist.gather_rows(rows[:0] if rank == 1 else rows, dst=0)
+    dist.barrier()
+    if rank == 0:
+        q.put((got, got2))
+    dist.destroy_process_group()
+
+
+def test_shards_cover_and_balance():
+    lengths = np.random.default_rng(1).integers(5, 1400, 11211)
+    for world in (1, 2, 4, 8):
+        sh = rdist.shard_by_residues(lengths, world)
+        assert sh[0][0] == 0 and sh[-1][1] == len(lengths)
+        assert all(sh[i][1] == sh[i + 1][0] for i in range(world - 1))
+        sums = [lengths[a:b].sum() for a, b in sh]
+        assert max(sums) - min(sums) <= 2 * lengths.max()
+
+
+def test_gather_rows_world2_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got, got2 = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    lengths = np.random.default_rng(0).integers(5, 1400, 1000)
+    want = []
+    for rank in range(world):
+        lo, hi = rdist.shard_by_residues(lengths, world)[rank]
+        rng = np.random.default_rng(100 + rank)
+        n = 37 + 100 * rank
+        want.append(np.stack([rng.integers(0, 256, n), rng.integers(lo, hi, n), rng.integers(0, 5000, n)], axis=1).astype(np.int32))
+    assert np.array_equal(got, np.concatenate(want))
+    assert np.array_equal(got2, want[0])
