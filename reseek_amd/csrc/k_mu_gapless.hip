@@ -48,11 +48,14 @@ int rsk_build_rings(rsk_db *db)
     std::vector<uint32_t> qids;
     std::vector<rsk_ring> rings;
     db->long_q.clear();
+    // Consecutive queries per ring (keeps a ring's smallest query index close to its members: the
+    // self-triangle skips all targets below it); ring size 512 or 1024 slots, whichever fills better.
+    // (First-fit-decreasing over windows was measured and is not better: chain sets sorted by length
+    // have near-equal blocks inside a window, the loss is the capacity quantum, not the packing order.)
     uint32_t i = 0;
     static const uint32_t Ds[2] = { 4, 8 };
     while (i < n) {
         if (qblock(db->len[i]) > RING_MAX_BLOCK) { db->long_q.push_back(i); ++i; continue; }
-        // choose the ring size with the best fill for the run of queries starting at i
         uint32_t bestD = 0, bestCnt = 0;
         double bestFill = -1;
         for (uint32_t D : Ds) {
@@ -152,10 +155,16 @@ __device__ __forceinline__ void ring_pairstep(int (&G)[D / 4][4], int (&E)[D / 4
     constexpr int M = D / 4;
     constexpr int RSB = RingGeom<D>::RSB;
     v4i S[M], T[M];
+    // row offsets are wave-uniform: shift on the scalar unit, then ONE 32-bit VOP2 add per address
+    // (v_lshl_add_u32 is a VOP3 op and issues at half rate on gfx950)
+    const unsigned o0 = (unsigned) __builtin_amdgcn_readfirstlane((int) (c0 * (unsigned) RSB));
+    const unsigned o1 = (unsigned) __builtin_amdgcn_readfirstlane((int) (c1 * (unsigned) RSB));
+    const char *a0 = lane_p1 + o0;
+    const char *a1 = lane_p2 + o1;
 #pragma unroll
     for (int m = 0; m < M; ++m) {
-        S[m] = *(const v4i *) (lane_p1 + c0 * RSB + m * 1024);
-        T[m] = *(const v4i *) (lane_p2 + c1 * RSB + m * 1024);
+        S[m] = *(const v4i *) (a0 + m * 1024);
+        T[m] = *(const v4i *) (a1 + m * 1024);
     }
 #pragma unroll
     for (int m = 0; m < M; ++m) {
