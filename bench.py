@@ -29,7 +29,7 @@ MU_FREQ = np.array([
     0.0220, 0.0025, 0.0102, 0.0084, 0.0472, 0.0239, 0.0174, 0.0196, 0.0436, 0.0761, 0.0082, 0.0448, 0.0266,
     0.0510, 0.0474, 0.0645, 0.0299, 0.1021, 0.0248, 0.0031, 0.0212, 0.0082, 0.0110, 0.0162, 0.0205, 0.0086,
     0.0385, 0.0368, 0.0039, 0.0297, 0.0100, 0.0120, 0.0206, 0.0263, 0.0104, 0.0530])
-MU_CHARS = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghij"
+MU_CHARS = "ABCDEFGHIJLKMNOPQRSTUVWXYZabcdefghij"   # sic: letter 10 = L, 11 = K (alpha.cpp g_LetterToCharMu)
 
 # Packed-int16 VALU peak: 256 CUs x 4 SIMDs x 64 lanes / 4 cycles x 2.4 GHz.  VOP3P (v_pk_*) issues at one
 # wave64 instruction per 4 cycles per SIMD on gfx950 (tools/ubench_valu.hip measures 36-37 T lane-ops/s;

@@ -134,3 +134,39 @@ def read_tsv(name):
 def scop40_lengths():
     with open(os.path.join(GOLDEN, "scop40_lengths.txt")) as f:
         return np.array([int(x) for x in f.read().split()], dtype=np.int64)
+
+
+MU_CHARS = "ABCDEFGHIJLKMNOPQRSTUVWXYZabcdefghij"   # sic: letter 10 = L, 11 = K (alpha.cpp g_LetterToCharMu)
+
+
+def read_mu_fasta(name, limit=None):
+    """-> (labels, seqs as uint8 letter arrays); char map g_CharToLetterMu alpha.cpp:3291 (note L = 10, K = 11)."""
+    lut = np.full(256, 255, np.uint8)
+    for i, c in enumerate(MU_CHARS):
+        lut[ord(c)] = i
+    labels, seqs, cur = [], [], []
+    with _open(name) as f:
+        for line in f.read().decode().splitlines():
+            if line.startswith(">"):
+                if labels:
+                    seqs.append(np.concatenate(cur) if cur else np.zeros(0, np.uint8))
+                if limit is not None and len(labels) == limit:
+                    return labels, seqs
+                labels.append(line[1:])
+                cur = []
+            elif line:
+                cur.append(lut[np.frombuffer(line.encode(), np.uint8)])
+    seqs.append(np.concatenate(cur) if cur else np.zeros(0, np.uint8))
+    return labels, seqs
+
+
+def prefilter_tmp_tsv(tq, tt, ntargets_header=True):
+    """Text of RankedScoresBag::ToTsv (rankedscoresbag.cpp:185-231) for a (q, t) pair set."""
+    by_t = {}
+    for q, t in sorted(zip(tq.tolist(), tt.tolist())):
+        by_t.setdefault(t, []).append(q)
+    lines = ["prefilter\t%d" % len(by_t)]
+    for t in sorted(by_t):
+        qs = by_t[t]
+        lines.append("%d\t%d\t%s" % (t, len(qs), "\t".join(map(str, qs))))
+    return "\n".join(lines) + "\n"

@@ -67,5 +67,18 @@ L.append(n)
 open("$G/scop40_lengths.txt","w").write("\n".join(map(str,L))+"\n")
 print(len(L), sum(L))
 EOF
+# 7. k-mer prefilter (exact k-mers; -threads 1 because -threads N is not deterministic):
+#    the reference's own test data file scop40.mu.fa (11,211 Mu sequences) travels as a fixture.
+gzip -9n < $T/scop40.mu.fa > $G/scop40.mu.fa.gz
+awk 'BEGIN{n=0} /^>/{n++} n<=1000' $T/scop40.mu.fa > $TMP/sub1000.mu.fa
+$R -prefilter_mu $TMP/sub1000.mu.fa -db $TMP/sub1000.mu.fa -output $TMP/t1000.tsv -output2 $TMP/s1000.tsv -threads 1 -quiet >/dev/null 2>&1
+$R -prefilter_mu $TMP/sub1000.mu.fa -db $TMP/sub1000.mu.fa -output $TMP/t1000_b50.tsv -output2 $TMP/s1000_b50.tsv -rsb_size 50 -threads 1 -quiet >/dev/null 2>&1
+gzip -9n < $TMP/t1000.tsv > $G/prefilter_sub1000_tmp.tsv.gz
+LC_ALL=C sort $TMP/s1000.tsv | gzip -9n > $G/prefilter_sub1000_scores.tsv.gz
+gzip -9n < $TMP/t1000_b50.tsv > $G/prefilter_sub1000_b50_tmp.tsv.gz
+LC_ALL=C sort $TMP/s1000_b50.tsv | gzip -9n > $G/prefilter_sub1000_b50_scores.tsv.gz
+$R -prefilter_mu $T/scop40.mu.fa -db $T/scop40.mu.fa -output $TMP/tfull.tsv -output2 $TMP/sfull.tsv -threads 1 -quiet >/dev/null 2>&1
+echo "lines $(wc -l < $TMP/sfull.tsv) sorted_scores_md5 $(LC_ALL=C sort $TMP/sfull.tsv | md5sum | cut -d' ' -f1) tmp_tsv_md5 $(md5sum < $TMP/tfull.tsv | cut -d' ' -f1)" > $G/prefilter_scop40_full.md5.txt
+cat $G/prefilter_scop40_full.md5.txt
 rm -rf $TMP
 ls -la $G

@@ -62,6 +62,10 @@ def lib():
         L.rsko_set_smx.argtypes = [u8p, C.c_int, u8p, C.c_int, f32p]
         L.rsko_sw_fast.restype = C.c_float
         L.rsko_sw_fast.argtypes = [f32p, C.c_int, C.c_int, C.c_float, C.c_float, u32p, u32p, C.c_char_p, u32p, u8p]
+        L.rsko_prefilter.restype = C.c_size_t
+        L.rsko_prefilter.argtypes = [u8p, u32p, C.c_uint32, u8p, u32p, C.c_uint32, u32p, u32p, u32p, C.c_size_t]
+        L.rsko_rsb.restype = C.c_size_t
+        L.rsko_rsb.argtypes = [u32p, u32p, u32p, C.c_size_t, C.c_uint32, C.c_uint32, u32p, u32p, u32p]
         _lib = L
     return _lib
 
@@ -141,3 +145,29 @@ def mu_filter_pairs(seqs, ia, ib, omega_fwd, open_=2, ext=1):
     lib().rsko_mu_filter_pairs(_p(mu, u8p), _p(off, u32p), _p(ia, u32p), _p(ib, u32p), len(ia), open_, ext,
                                omega_fwd, _p(f, i32p), _p(r, i32p), _p(s, f32p))
     return f, r, s
+
+
+def prefilter(qseqs, tseqs, cap=None):
+    """Exact-k-mer Mu prefilter (P10/P11): -> (q, t, score) arrays, targets in order."""
+    qmu, qoff = concat_mu(qseqs)
+    tmu, toff = concat_mu(tseqs)
+    cap = cap or max(1024, len(qseqs) * len(tseqs))
+    oq = np.zeros(cap, np.uint32)
+    ot = np.zeros(cap, np.uint32)
+    os_ = np.zeros(cap, np.uint32)
+    n = lib().rsko_prefilter(_p(qmu, u8p), _p(qoff, u32p), len(qseqs), _p(tmu, u8p), _p(toff, u32p), len(tseqs),
+                             _p(oq, u32p), _p(ot, u32p), _p(os_, u32p), cap)
+    assert n <= cap
+    return oq[:n], ot[:n], os_[:n]
+
+
+def rsb(q, t, score, nq, B):
+    """RankedScoresBag (P12): top-B per query with the reference's truncation/tie behaviour."""
+    q = np.ascontiguousarray(q, np.uint32)
+    t = np.ascontiguousarray(t, np.uint32)
+    score = np.ascontiguousarray(score, np.uint32)
+    oq = np.zeros(len(q), np.uint32)
+    ot = np.zeros(len(q), np.uint32)
+    os_ = np.zeros(len(q), np.uint32)
+    n = lib().rsko_rsb(_p(q, u32p), _p(t, u32p), _p(score, u32p), len(q), nq, B, _p(oq, u32p), _p(ot, u32p), _p(os_, u32p))
+    return oq[:n], ot[:n], os_[:n]
