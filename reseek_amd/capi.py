@@ -57,6 +57,11 @@ SIGNATURES["rsk_align_last_work"] = (C.c_int, [C.c_void_p, u64p, u64p, u64p])
 SIGNATURES["rsk_search_rskdb"] = (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_double, C.c_int,
                                             C.c_char_p, u64p, u64p])
 
+SIGNATURES["rsk_mu_prefilter_dev"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_size_t, C.c_void_p])
+SIGNATURES["rsk_rsb_select"] = (C.c_int, [u32p, u32p, u32p, C.c_size_t, C.c_uint32, C.c_uint32, u32p, u32p, u32p,
+                                          C.POINTER(C.c_size_t), C.c_char_p])
+
 GAP_OPEN = -0.685533     # namedparams.cpp:45
 GAP_EXT = -0.051881      # namedparams.cpp:46
 
@@ -177,6 +182,11 @@ class Ctx:
                                       C.byref(n), st))
         return n.value, list(st)
 
+    # ---- P10-P12 k-mer prefilter ---------------------------------------------------------------------
+    def mu_prefilter_dev(self, q, t, d_q, d_t, d_score, capacity, d_n):
+        _check(lib().rsk_mu_prefilter_dev(self.h, q.h, t.h, C.c_void_p(d_q), C.c_void_p(d_t), C.c_void_p(d_score), capacity,
+                                          C.c_void_p(d_n)))
+
     def mu_gapless_last_work(self):
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
         _check(lib().rsk_mu_gapless_last_work(self.h, C.byref(a), C.byref(b), C.byref(c)))
@@ -224,3 +234,19 @@ class Db:
         if self.h:
             lib().rsk_db_destroy(self.h)
             self.h = None
+
+
+def rsb_select(q, t, score, nqueries, rsb_size=1500, tmp_tsv_path=None):
+    """RankedScoresBag on host triples -> (q, t, score) survivors (host C++ in librsk, not Python)."""
+    q = np.ascontiguousarray(q, np.uint32)
+    t = np.ascontiguousarray(t, np.uint32)
+    score = np.ascontiguousarray(score, np.uint32)
+    n = len(q)
+    oq = np.zeros(max(n, 1), np.uint32)
+    ot = np.zeros(max(n, 1), np.uint32)
+    os_ = np.zeros(max(n, 1), np.uint32)
+    nout = C.c_size_t()
+    _check(lib().rsk_rsb_select(_p(q, u32p), _p(t, u32p), _p(score, u32p), n, nqueries, rsb_size, _p(oq, u32p), _p(ot, u32p),
+                                _p(os_, u32p), C.byref(nout), tmp_tsv_path.encode() if tmp_tsv_path else None))
+    m = nout.value
+    return oq[:m], ot[:m], os_[:m]

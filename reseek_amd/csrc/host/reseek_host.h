@@ -172,6 +172,20 @@ void InvertPath(const std::string &Path, std::string &InvPath);              // 
 void GetPathCounts(const std::string &Path, uint &M, uint &D, uint &I);      // dssaligner.cpp:75
 void PathToCIGAR(const char *Path, std::string &CIGAR, bool FlipDI);         // cigar.cpp:95
 
+class RankedScoresBag {                                 // rankedscoresbag.h:16
+public:
+    uint m_B = 1500;                                    // RSB_SIZE prefiltermuparams.h:15 (-rsb_size)
+    std::vector<std::vector<uint16_t> > m_QueryIdxToScoreVec;
+    std::vector<std::vector<uint> > m_QueryIdxToTargetIdxVec;
+    std::vector<uint16_t> m_QueryIdxToLoScore;
+    uint m_QueryCount = UINT_MAX;
+    void Init(uint QueryCount);
+    void TruncateVecs(uint QIdx);
+    void AddScore(uint QueryIdx, uint TargetIdx, uint16_t Score);
+    void Finish();                                      // the final TruncateVecs pass of ToTsv
+    void ToTsv(FILE *fTsv);                             // "prefilter\t<#targets>" + "TIdx\tK\tQIdx..." lines
+};
+
 class DBSearcher {                                      // dbsearcher.h:14
 public:
     virtual ~DBSearcher();

@@ -74,6 +74,11 @@ struct rsk_db {
     int work_tri = -1;
     void *d_work = nullptr;             // uint2 (ring, first target) entries, D = 4 class first
     uint32_t work_count[2] = { 0, 0 };
+    // k-mer prefilter index (built lazily when the chain set is the query side)
+    bool mudex_built = false;
+    void *d_pf_table = nullptr;         // uint2 [36^5] (start, count)
+    uint32_t *d_pf_postings = nullptr;  // q << 16 | pos
+    size_t pf_postings = 0;
     std::vector<uint32_t> long_q;       // queries too long for a ring (handled by the per-pair kernel)
     uint64_t ring_slots_total = 0;      // sum of 128*D over rings
 };
@@ -85,3 +90,4 @@ int rsk_launch_gapless_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, con
                              const uint32_t *d_it, size_t npairs, int32_t *d_scores,
                              uint32_t *d_besti, uint32_t *d_bestj);
 int rsk_build_rings(rsk_db *db);
+int rsk_build_mudex(rsk_db *db);

@@ -1,0 +1,108 @@
+"""GPU parity: Mu k-mer prefilter (exact k-mers) through the C-ABI vs
+`reseek -prefilter_mu` outputs of the reference binary and the CPU oracle."""
+import gzip
+import hashlib
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+import fixtures as fx
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+    import reseek_amd
+    assert torch.cuda.is_available()
+    c = reseek_amd.Ctx(0, stream=torch.cuda.current_stream().cuda_stream)
+    yield c
+    c.close()
+
+
+def run_prefilter(ctx, qseqs, tseqs=None, cap=20_000_000):
+    import torch
+    import reseek_amd
+    q = reseek_amd.Db.from_mu_seqs(ctx, qseqs)
+    t = q if tseqs is None else reseek_amd.Db.from_mu_seqs(ctx, tseqs)
+    dq = torch.zeros(cap, dtype=torch.int32, device="cuda")
+    dt = torch.zeros(cap, dtype=torch.int32, device="cuda")
+    ds = torch.zeros(cap, dtype=torch.int32, device="cuda")
+    dn = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ctx.mu_prefilter_dev(q, t, dq.data_ptr(), dt.data_ptr(), ds.data_ptr(), cap, dn.data_ptr())
+    torch.cuda.synchronize()
+    n = int(dn.item())
+    assert n <= cap
+    ms = ctx.last_kernel_ms()
+    q.close()
+    if t is not q:
+        t.close()
+    return dq[:n].cpu().numpy().astype(np.uint32), dt[:n].cpu().numpy().astype(np.uint32), ds[:n].cpu().numpy().astype(np.uint32), ms
+
+
+def as_set(q, t, s):
+    return set(zip(q.tolist(), t.tolist(), s.tolist()))
+
+
+def scores_text(labels, q, t, s):
+    lines = ["%s\t%s\t%d" % (labels[a], labels[b], c) for a, b, c in zip(q.tolist(), t.tolist(), s.tolist())]
+    lines.sort()
+    return "\n".join(lines) + "\n"
+
+
+def test_sub1000_triples_and_bags_match_reference(ctx):
+    import reseek_amd
+    labels, seqs = fx.read_mu_fasta("scop40.mu.fa.gz", limit=1000)
+    q, t, s, _ = run_prefilter(ctx, seqs)
+    oq, ot, os_ = ol.prefilter(seqs, seqs)
+    assert as_set(q, t, s) == as_set(oq, ot, os_)
+    for B, tag in ((1500, ""), (50, "_b50")):
+        with tempfile.TemporaryDirectory() as td:
+            tmp = os.path.join(td, "tmp.tsv")
+            rq, rt, rs = reseek_amd.capi.rsb_select(q, t, s, len(seqs), B, tmp_tsv_path=tmp)
+            want = gzip.open(os.path.join(fx.GOLDEN, "prefilter_sub1000%s_scores.tsv.gz" % tag)).read().decode()
+            assert scores_text(labels, rq, rt, rs) == want
+            want_tmp = gzip.open(os.path.join(fx.GOLDEN, "prefilter_sub1000%s_tmp.tsv.gz" % tag)).read().decode()
+            assert open(tmp).read() == want_tmp
+
+
+def test_scop40_full_checksums(ctx):
+    """BASELINE configs[2] shape: all 11,211 SCOP40 Mu sequences against themselves (125.7 M ordered pairs)."""
+    import reseek_amd
+    labels, seqs = fx.read_mu_fasta("scop40.mu.fa.gz")
+    q, t, s, ms = run_prefilter(ctx, seqs)
+    with tempfile.TemporaryDirectory() as td:
+        tmp = os.path.join(td, "tmp.tsv")
+        rq, rt, rs = reseek_amd.capi.rsb_select(q, t, s, len(seqs), 1500, tmp_tsv_path=tmp)
+        want = dict(zip(*[iter(open(os.path.join(fx.GOLDEN, "prefilter_scop40_full.md5.txt")).read().split())] * 2))
+        assert len(rq) == int(want["lines"])
+        assert hashlib.md5(scores_text(labels, rq, rt, rs).encode()).hexdigest() == want["sorted_scores_md5"]
+        assert hashlib.md5(open(tmp, "rb").read()).hexdigest() == want["tmp_tsv_md5"]
+    print("prefilter kernel ms", ms)
+
+
+def test_rectangular_edge_cases_vs_oracle(ctx):
+    rng = np.random.default_rng(4)
+    base = rng.integers(0, 36, 600).astype(np.uint8)
+    qs = [base[:L].copy() for L in (6, 7, 8, 50, 300, 600)] + [rng.integers(0, 36, int(L)).astype(np.uint8) for L in rng.integers(7, 400, 40)]
+    ts = [base[100:500].copy(), base[::-1].copy(), np.full(300, 17, np.uint8), base[:6].copy(), base[:7].copy()]
+    ts += [np.concatenate([base[50:250], rng.integers(0, 36, 100).astype(np.uint8), base[50:250]])]      # repeats -> many two-hit diagonals
+    ts += [rng.integers(0, 36, int(L)).astype(np.uint8) for L in rng.integers(7, 700, 30)]
+    q, t, s, _ = run_prefilter(ctx, qs, ts)
+    oq, ot, os_ = ol.prefilter(qs, ts)
+    assert as_set(q, t, s) == as_set(oq, ot, os_) and len(oq) >= 4
+
+
+def test_many_hits_forces_lds_chunking(ctx):
+    """Low-complexity chains: tens of thousands of postings hits per target -> several query-range chunks."""
+    rng = np.random.default_rng(6)
+    motif = rng.integers(0, 36, 40).astype(np.uint8)
+    qs = [np.tile(motif, 6)[: int(L)] for L in rng.integers(100, 240, 300)]
+    ts = [np.tile(motif, 8)[: int(L)] for L in rng.integers(150, 320, 6)]
+    q, t, s, _ = run_prefilter(ctx, qs, ts)
+    oq, ot, os_ = ol.prefilter(qs, ts)
+    assert as_set(q, t, s) == as_set(oq, ot, os_) and len(oq) == 300 * 6
