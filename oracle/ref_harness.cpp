@@ -19,7 +19,8 @@
 //
 // usage: ref_harness <subcmd> <args...> [-- <reseek options, e.g. -sensitive>]
 //   tables   <out.h>
-//   db       <in.bca> <out.rskdb>            [-- -sensitive|-fast|-verysensitive]
+//   db       <in.bca> <out.rskdb>            [-- -sensitive|-fast|-verysensitive]   (self-rev as DBSearcher::LoadDB)
+//   dbq      <in.bca> <out.rskdb>            [-- mode]   (self-rev as ThreadBodyQuery computes it for streamed -db chains)
 //   pairs    <in.bca> <out.bin> <maxchains>  [-- mode]
 //   mukat    <in.mu.fa> <first> <count> <out.bin>
 //   randkat  <seed> <npairs> <out.bin>
@@ -86,6 +87,8 @@ struct ChainData
 	};
 
 // Same per-chain precompute as ProfileLoader::ThreadBody (profileloader.cpp:18-70).
+static bool s_QueryModeSelfRev = false;
+
 static void LoadChains(const string &FN, const DSSParams &Params,
   vector<ChainData *> &CDs, uint MaxChains)
 	{
@@ -95,8 +98,13 @@ static void LoadChains(const string &FN, const DSSParams &Params,
 	D.SetParams(Params);
 	DSSAligner DA;
 	DSSParams DA_Params = Params;
-	DA_Params.m_UsePara = false;
-	DA_Params.m_Omega = 0;
+	if (!s_QueryModeSelfRev)
+		{
+	// LoadDB flavour (profileloader.cpp:23-26)
+		DA_Params.m_UsePara = false;
+		DA_Params.m_Omega = 0;
+		}
+	// else: RunQuery flavour: self-rev of a streamed -db chain uses the search params (runquery.cpp:43-44)
 	DA_Params.m_OwnScoreMxs = false;
 	DA.SetParams(DA_Params);
 	for (;;)
@@ -579,7 +587,12 @@ int main(int argc, char **argv)
 	vector<string> A;
 	for (int i = 2; i < dd; ++i)
 		A.push_back(argv[i]);
-	if (Cmd == "tables" && A.size() == 1)
+	if (Cmd == "dbq" && A.size() == 2)
+		{
+		s_QueryModeSelfRev = true;
+		cmd_db(A[0], A[1]);
+		}
+	else if (Cmd == "tables" && A.size() == 1)
 		cmd_tables(A[0]);
 	else if (Cmd == "db" && A.size() == 2)
 		cmd_db(A[0], A[1]);

@@ -22,6 +22,8 @@ for m in sensitive verysensitive fast; do
   $H db $T/q100.bca $TMP/q100_$m.rskdb -- -$m
   gzip -9n < $TMP/q100_$m.rskdb > $G/q100_$m.rskdb.gz
 done
+$H dbq $T/q100.bca $TMP/q100_sensitive_dbq.rskdb -- -sensitive
+gzip -9n < $TMP/q100_sensitive_dbq.rskdb > $G/q100_sensitive_dbq.rskdb.gz
 $H db $T/q10.bca $TMP/q10.rskdb -- -sensitive
 gzip -9n < $TMP/q10.rskdb > $G/q10_sensitive.rskdb.gz
 $H db $T/palms.bca $TMP/palms.rskdb -- -sensitive

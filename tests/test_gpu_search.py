@@ -80,3 +80,11 @@ def test_q10_sensitive(ctx, tmpdir):
 def test_palms_sensitive_long_chains_mkf(ctx, tmpdir):
     st = run(ctx, tmpdir, "palms_sensitive.rskdb.gz", "sensitive", COLS, "hits_palms_sensitive.tsv.gz")
     assert st[4] > 300      # lengths 418..2,099: most pairs take the MKF path
+
+
+def test_q100_vs_db_q100_sensitive(ctx, tmpdir):
+    """`reseek -search Q -db DB -sensitive` (Search_NoMuFilter search.cpp:39): A = streamed DB chain whose
+    self-rev score is computed under the search params (runquery.cpp:43-44), B = query chain."""
+    st = run(ctx, tmpdir, "q100_sensitive.rskdb.gz", "sensitive", COLS, "hits_q100_db_q100_sensitive.tsv.gz",
+             db2="q100_sensitive_dbq.rskdb.gz")
+    assert st[0] == 10000
