@@ -46,6 +46,37 @@ def main():
         p, c = ctx.mu_filter_last_work()
         res["mu_filter_" + preset] = {"ms": dt * 1e3, "pairs": p, "rev_candidates": c, "survivors": int(nn.item()),
                                       "pairs_per_s": pairs / dt}
+    # float SW + traceback + LDDT on synthetic profiles/coordinates for a sample of pairs
+    import ctypes as C
+    rng = np.random.default_rng(3)
+    nal = min(n, 3000)
+    lens_al = np.array([len(s) for s in seqs[:nal]], np.uint32)
+    tot = int(lens_al.sum())
+    prof = np.concatenate([np.concatenate([rng.integers(0, 20, (1, int(L))), rng.integers(0, 16, (7, int(L)))]).astype(np.uint8).reshape(-1)
+                           for L in lens_al])
+    xyz = tuple(np.cumsum(rng.normal(0, 2.2, tot)).astype(np.float32) for _ in range(3))
+    dba = reseek_amd.Db(ctx, lens_al, mu=np.concatenate(seqs[:nal]), prof=prof, xyz=xyz, selfrev=np.zeros(nal, np.float32))
+    npairs = 60000
+    ia = rng.integers(0, nal, npairs).astype(np.uint32)
+    ib = rng.integers(0, nal, npairs).astype(np.uint32)
+    t0 = time.perf_counter()
+    ctx.align_pairs(dba, dba, ia, ib, min_fwd_score=7.0)
+    dt = time.perf_counter() - t0
+    p_, cells_al, tb = ctx.align_last_work()
+    res["align_pairs"] = {"ms_total_incl_host": dt * 1e3, "sw_kernel_ms": ctx.last_kernel_ms(), "pairs": p_, "cells": cells_al,
+                          "Tcells_per_s_kernel": cells_al / (ctx.last_kernel_ms() * 1e-3) / 1e12, "trace_bytes": tb}
+    # k-mer prefilter (exact k-mers) on the same synthetic Mu set
+    cap = 30_000_000
+    dq = torch.zeros(cap, dtype=torch.int32, device="cuda")
+    dtt = torch.zeros(cap, dtype=torch.int32, device="cuda")
+    dsc = torch.zeros(cap, dtype=torch.int32, device="cuda")
+    dn = torch.zeros(1, dtype=torch.int32, device="cuda")
+    if n <= 65535:
+        ctx.mu_prefilter_dev(db, db, dq.data_ptr(), dtt.data_ptr(), dsc.data_ptr(), cap, dn.data_ptr())
+        t0 = time.perf_counter()
+        ctx.mu_prefilter_dev(db, db, dq.data_ptr(), dtt.data_ptr(), dsc.data_ptr(), cap, dn.data_ptr())
+        torch.cuda.synchronize()
+        res["mu_prefilter_exact"] = {"ms": (time.perf_counter() - t0) * 1e3, "kernel_ms": ctx.last_kernel_ms(), "triples": int(dn.item())}
     print(json.dumps(res, indent=1))
 
 
