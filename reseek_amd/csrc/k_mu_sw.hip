@@ -20,7 +20,7 @@
 //     a single v_mov_b32_dpp wave_shr:1 per column -- no scratch memory, no LDS hand-off.
 //     A wave therefore works on floor(64/g) targets at once.
 //   * per column a lane fetches its 32 profile scores with eight ds_read_b128 (row = its target
-//     letter; the row stride LQpad+4 dwords starts different letters on different bank groups).
+//     letter; every strip record is padded to 36 ints = 9 sixteen-byte slots so the strips of a pair hit distinct LDS banks).
 //   * all per-cell ops are 32-bit VOP2 (full issue rate on gfx950; VOP3/VOP3P issue at half rate).
 //   * persistent workgroups pull (query, target batch) items from a device-side queue that is
 //     also built on the device (the reverse pass runs on data-dependent survivor lists).
@@ -33,9 +33,10 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 
 
 #define MUSW_R 32
+#define MUSW_RP 36                 // ints per strip record in the LDS profile (32 + 4 pad: 9 slots, conflict-free strides)
 #define MUSW_WAVES 4
 #define MUSW_PADSCORE (-1000)      // pad rows / pad letters: never part of an alignment
-#define MUSW_LDS_MAX_LQPAD 1056    // 37*(1056+4)*4 + 1.4 KB < 160 KB
+#define MUSW_LDS_MAX_LQPAD 960     // 37*(960/32*36)*4 + 1.4 KB < 160 KB
 #define MUSW_MAX_LQ 2048           // 64 strips of 32 rows (one pair per wave)
 
 __device__ __forceinline__ int dpp_wave_shr1(int x)
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(64 * MUSW_WAVES) void k_mu_sw(musw_args a, uint32_t
         mat = (signed char *) smem;
     } else {
         prof = (int *) smem;
-        mat = (signed char *) (prof + 37 * (lqpad_max + 4));
+        mat = (signed char *) (prof + 37 * (lqpad_max / MUSW_R * MUSW_RP));
     }
     uint32_t *wg_item = (uint32_t *) (mat + 1312);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -95,11 +96,13 @@ __global__ __launch_bounds__(64 * MUSW_WAVES) void k_mu_sw(musw_args a, uint32_t
             cur_q = q;
             LQ = a.q_len[q];
             g = (LQ + MUSW_R - 1) / MUSW_R;
-            RS = g * MUSW_R + 4;
+            RS = g * MUSW_RP;
             const uint8_t *Q = a.q_mu + a.q_off[q];
             // prof[c][i] = s(c, a_i); pad rows (i >= LQ) and the pad-letter row 36 = PADSCORE
             for (uint32_t idx = tid; idx < 37 * RS; idx += blockDim.x) {
-                const uint32_t c = idx / RS, i = idx - c * RS;
+                const uint32_t c = idx / RS, w = idx - c * RS;
+                const uint32_t sst = w / MUSW_RP, r = w - sst * MUSW_RP;
+                const uint32_t i = r < MUSW_R ? sst * MUSW_R + r : 0xFFFFFFFFu;    // record padding -> PADSCORE
                 int v = MUSW_PADSCORE;
                 if (c < 36 && i < LQ) {
                     const uint32_t qi = a.reverse ? (LQ - 1 - i) : i;
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(64 * MUSW_WAVES) void k_mu_sw(musw_args a, uint32_t
         int hand = 0;          // (F << 16) | H of the bottom row of this strip at its previous column
         int diag_in = 0;       // H(i0-1, j-1) for the top row
         const int open = a.open, ext = a.ext;
-        const int *lane_prof = prof + st * MUSW_R;
+        const int *lane_prof = prof + st * MUSW_RP;
         unsigned lw = active ? *(const unsigned *) B : 0u;    // letters j..j+3 (chains are padded to 16 in HBM)
         unsigned lw_next = 0;
 
@@ -229,7 +232,7 @@ __global__ void k_mu_sw_slow(musw_args a, const uint2 *pairs, const uint32_t *pa
 // ---------------------------------------------------------------------------------------------
 // device-side queue construction
 // ---------------------------------------------------------------------------------------------
-// class of a query by its padded length: 0: <=224, 1: <=416, 2: <=1056 (LDS profile), 3: <=2048 (global profile), 4: slow
+// class of a query by its padded length: 0: <=224, 1: <=416, 2: <=960 (LDS profile), 3: <=2048 (global profile), 4: slow
 __device__ __forceinline__ int musw_class(uint32_t LQ)
 {
     const uint32_t lp = (LQ + MUSW_R - 1) / MUSW_R * MUSW_R;
@@ -417,11 +420,14 @@ struct musw_ws {               // per-call device workspace
     uint2 *items = nullptr;
     int *gprof = nullptr;
     int *slow_scratch = nullptr;
+    rsk_ctx *ctx = nullptr;
     std::vector<void *> all;
-    ~musw_ws() { for (void *p : all) (void) hipFree(p); }
+    explicit musw_ws(rsk_ctx *c) : ctx(c) {}
+    ~musw_ws() { for (void *p : all) rsk_pool_free(ctx, p); }
     template <class T> int alloc(T **p, size_t n)
     {
-        RSK_HIP(hipMalloc((void **) p, std::max<size_t>(n, 1) * sizeof(T)));
+        int r = rsk_pool_alloc(ctx, (void **) p, std::max<size_t>(n, 1) * sizeof(T));
+        if (r != RSK_OK) return r;
         all.push_back(*p);
         return RSK_OK;
     }
@@ -460,7 +466,7 @@ static int run_mu_sw_lists(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, musw_
         a.counter = ws.counter;
         if (cls <= 2) {
             const uint32_t lq = class_lqpad[cls];
-            const size_t lds = (size_t) 37 * (lq + 4) * 4 + 1312 + 16;
+            const size_t lds = (size_t) 37 * (lq / MUSW_R * MUSW_RP) * 4 + 1312 + 16;
             static bool attr_set = false;
             if (!attr_set) {
                 RSK_HIP(hipFuncSetAttribute((const void *) k_mu_sw<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
@@ -470,7 +476,7 @@ static int run_mu_sw_lists(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, musw_
             hipLaunchKernelGGL((k_mu_sw<false>), dim3(ctx->num_cus * wg_per_cu), dim3(64 * MUSW_WAVES), lds, ctx->stream, a, lq);
         } else if (cls == 3) {
             const uint32_t nwg = ctx->num_cus * 2;
-            a.gprof_stride = (size_t) 37 * (MUSW_MAX_LQ + 4);
+            a.gprof_stride = (size_t) 37 * (MUSW_MAX_LQ / MUSW_R * MUSW_RP);
             if (!ws.gprof) { if ((rc = ws.alloc(&ws.gprof, a.gprof_stride * nwg)) != RSK_OK) return rc; }
             a.gprof = ws.gprof;
             hipLaunchKernelGGL((k_mu_sw<true>), dim3(nwg), dim3(64 * MUSW_WAVES), 1312 + 16, ctx->stream, a, 0u);
@@ -526,7 +532,7 @@ extern "C" int rsk_mu_sw_matrix_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db 
     RSK_HIP(hipSetDevice(ctx->device));
     int rc = rsk_upload_mu_tables(ctx);
     if (rc != RSK_OK) return rc;
-    musw_ws ws;
+    musw_ws ws(ctx);
     if ((rc = ws.alloc(&ws.first, q->n)) != RSK_OK) return rc;
     if ((rc = ws.alloc(&ws.cnt, q->n)) != RSK_OK) return rc;
     RSK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
@@ -559,7 +565,7 @@ extern "C" int rsk_mu_filter_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t,
     int rc = rsk_upload_mu_tables(ctx);
     if (rc != RSK_OK) return rc;
     const uint32_t nq = q->n;
-    musw_ws ws, ws2;
+    musw_ws ws(ctx), ws2(ctx);
     if ((rc = ws.alloc(&ws.first, nq)) != RSK_OK) return rc;
     if ((rc = ws.alloc(&ws.cnt, nq)) != RSK_OK) return rc;
     RSK_HIP(hipEventRecord(ctx->ev0, ctx->stream));

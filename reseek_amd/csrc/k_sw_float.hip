@@ -481,11 +481,13 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
         k += cnt;
     }
     struct ws_t {
+        rsk_ctx *ctx;
         std::vector<void *> all;
-        ~ws_t() { for (void *p : all) (void) hipFree(p); }
-    } ws;
+        ~ws_t() { for (void *p : all) rsk_pool_free(ctx, p); }
+    } ws{ ctx, {} };
     auto dalloc = [&](void **p, size_t bytes) -> int {
-        RSK_HIP(hipMalloc(p, std::max<size_t>(bytes, 16)));
+        int r = rsk_pool_alloc(ctx, p, std::max<size_t>(bytes, 16));
+        if (r != RSK_OK) return r;
         ws.all.push_back(*p);
         return RSK_OK;
     };

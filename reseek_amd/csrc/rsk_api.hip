@@ -54,9 +54,49 @@ extern "C" int rsk_ctx_create(int device, rsk_ctx **out)
     return RSK_OK;
 }
 
+int rsk_pool_alloc(rsk_ctx *ctx, void **p, size_t bytes)
+{
+    size_t cls = 256;
+    while (cls < bytes) cls <<= 1;
+    if (cls > (1ull << 30)) cls = (bytes + (1ull << 28) - 1) / (1ull << 28) * (1ull << 28);   // >1 GiB: 256 MiB steps
+    auto it = ctx->pool_free.find(cls);
+    if (it != ctx->pool_free.end()) {
+        *p = it->second;
+        ctx->pool_free.erase(it);
+        ctx->pool_live[*p] = cls;
+        return RSK_OK;
+    }
+    hipError_t e = hipMalloc(p, cls);
+    if (e != hipSuccess) {
+        rsk_pool_release(ctx);                       // drop cached blocks and retry once
+        e = hipMalloc(p, cls);
+        if (e != hipSuccess) { rsk_set_error("out of device memory allocating %zu bytes", cls); *p = nullptr; return RSK_E_NOMEM; }
+    }
+    ctx->pool_live[*p] = cls;
+    ctx->pool_bytes += cls;
+    return RSK_OK;
+}
+
+void rsk_pool_free(rsk_ctx *ctx, void *p)
+{
+    if (!p) return;
+    auto it = ctx->pool_live.find(p);
+    if (it == ctx->pool_live.end()) { (void) hipFree(p); return; }
+    ctx->pool_free.insert({ it->second, p });
+    ctx->pool_live.erase(it);
+}
+
+void rsk_pool_release(rsk_ctx *ctx)
+{
+    for (auto &kv : ctx->pool_free) { (void) hipFree(kv.second); ctx->pool_bytes -= kv.first; }
+    ctx->pool_free.clear();
+}
+
 extern "C" void rsk_ctx_destroy(rsk_ctx *ctx)
 {
     if (!ctx) return;
+    rsk_pool_release(ctx);
+    for (auto &kv : ctx->pool_live) (void) hipFree(kv.first);
     if (ctx->ev0) (void) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void) hipEventDestroy(ctx->ev1);
     delete ctx;

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -29,7 +30,17 @@ struct rsk_ctx {
     uint64_t mf_pairs = 0, mf_candidates = 0;   // last Mu filter call
     uint64_t al_pairs = 0, al_cells = 0, al_tb_bytes = 0;   // last rsk_align_pairs call
     int num_cus = 0;
+    // caching device allocator (hipMalloc/hipFree cost ~0.1-1 ms each and synchronise; the batch
+    // entry points need a dozen temporaries per call): blocks are kept in size classes until the
+    // context is destroyed.
+    std::map<void *, size_t> pool_live;
+    std::multimap<size_t, void *> pool_free;
+    uint64_t pool_bytes = 0;
 };
+
+int rsk_pool_alloc(rsk_ctx *ctx, void **p, size_t bytes);
+void rsk_pool_free(rsk_ctx *ctx, void *p);
+void rsk_pool_release(rsk_ctx *ctx);
 
 // One "ring" of the gapless kernel: several query chains laid out on a circular array of
 // 128*D diagonal slots (see k_mu_gapless.hip).

@@ -59,6 +59,7 @@ def main():
     npairs = 60000
     ia = rng.integers(0, nal, npairs).astype(np.uint32)
     ib = rng.integers(0, nal, npairs).astype(np.uint32)
+    ctx.align_pairs(dba, dba, ia, ib, min_fwd_score=7.0)      # warm the allocator pool
     t0 = time.perf_counter()
     ctx.align_pairs(dba, dba, ia, ib, min_fwd_score=7.0)
     dt = time.perf_counter() - t0
