@@ -33,10 +33,9 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 
 
 #define MUSW_R 32
-#define MUSW_RP 36                 // ints per strip record in the LDS profile (32 + 4 pad: 9 slots, conflict-free strides)
 #define MUSW_WAVES 4
-#define MUSW_PADSCORE (-1000)      // pad rows / pad letters: never part of an alignment
-#define MUSW_LDS_MAX_LQPAD 960     // 37*(960/32*36)*4 + 1.4 KB < 160 KB
+#define MUSW_PADSCORE (-128)       // pad rows / pad letters: never part of an alignment (H stays below the H it came from)
+#define MUSW_CLASS0_LQPAD 1024     // profile 37*32*32 B = 37.9 KB: four workgroups per CU
 #define MUSW_MAX_LQ 2048           // 64 strips of 32 rows (one pair per wave)
 
 __device__ __forceinline__ int dpp_wave_shr1(int x)
@@ -51,7 +50,9 @@ struct musw_args {
     const uint2 *items;         // (query, first list position) per workgroup item
     const uint32_t *nitems;     // device-side item count
     const uint32_t *cnt;        // listed targets per query
-    const uint32_t *first;      // implicit lists: first target index of query q
+    const uint32_t *first;      // implicit lists: first position (in perm) of query q
+    const uint32_t *perm;       // implicit lists: target of position k is perm[first[q] + k] (targets by increasing length)
+    int tri;                    // self triangle: pair {q,t} is computed once and stored at out[min(q,t)][max(q,t)]
     const uint32_t *list;       // explicit lists (CSR): list[rowstart[q] + k]; NULL => implicit first[q] + k
     const uint32_t *rowstart;   // CSR row starts (explicit lists)
     int reverse;                // 1: use the reversed query (m_MuRevA, parasail_mu.cpp:174-179)
@@ -59,29 +60,31 @@ struct musw_args {
     uint8_t *out;               // raw score min(best,255) with 255 = saturated
     size_t ldo;                 // dense: out[q*ldo + t];  CSR: out[rowstart[q] + k]
     uint32_t *counter;          // work counter (persistent workgroups)
-    int *gprof;                 // GLOBAL variant: per-workgroup profile storage
-    size_t gprof_stride;        // ints per workgroup
 };
 
-template <bool GLOBAL_PROF>
-__global__ __launch_bounds__(64 * MUSW_WAVES) void k_mu_sw(musw_args a, uint32_t lqpad_max)
+// sign-extended byte K of w added to x in one VALU op (SDWA operand select)
+template <int K> __device__ __forceinline__ int musw_add_sbyte(int x, int w)
+{
+    int r;
+    if (K == 0) asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(x), "v"(w));
+    if (K == 1) asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(x), "v"(w));
+    if (K == 2) asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(x), "v"(w));
+    if (K == 3) asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(x), "v"(w));
+    return r;
+}
+
+__global__ __launch_bounds__(64 * MUSW_WAVES) void k_mu_sw(musw_args a, uint32_t gmax)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int *prof;
-    signed char *mat;
-    if (GLOBAL_PROF) {
-        prof = a.gprof + (size_t) blockIdx.x * a.gprof_stride;
-        mat = (signed char *) smem;
-    } else {
-        prof = (int *) smem;
-        mat = (signed char *) (prof + 37 * (lqpad_max / MUSW_R * MUSW_RP));
-    }
+    // int8 query profile: prof[c][h][st][16] = s(c, a_i) for rows i = 32*st + 16*h + (0..15); 37 letter rows
+    signed char *prof = (signed char *) smem;
+    signed char *mat = prof + (size_t) 37 * gmax * 32;
     uint32_t *wg_item = (uint32_t *) (mat + 1312);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    for (int i = tid; i < 1296; i += blockDim.x) mat[i] = c_mu_int[i];
+    for (int i = tid; i < 1296; i += blockDim.x) mat[i] = (signed char) c_mu_int[i];
     uint32_t cur_q = 0xFFFFFFFFu;
-    uint32_t LQ = 0, g = 1, RS = 4;
+    uint32_t LQ = 0, g = 1, RS = 32;
     const uint32_t nitems = *a.nitems;
 
     for (;;) {
@@ -96,21 +99,28 @@ __global__ __launch_bounds__(64 * MUSW_WAVES) void k_mu_sw(musw_args a, uint32_t
             cur_q = q;
             LQ = a.q_len[q];
             g = (LQ + MUSW_R - 1) / MUSW_R;
-            RS = g * MUSW_RP;
+            RS = g * 32;                                   // bytes per letter row
             const uint8_t *Q = a.q_mu + a.q_off[q];
-            // prof[c][i] = s(c, a_i); pad rows (i >= LQ) and the pad-letter row 36 = PADSCORE
-            for (uint32_t idx = tid; idx < 37 * RS; idx += blockDim.x) {
-                const uint32_t c = idx / RS, w = idx - c * RS;
-                const uint32_t sst = w / MUSW_RP, r = w - sst * MUSW_RP;
-                const uint32_t i = r < MUSW_R ? sst * MUSW_R + r : 0xFFFFFFFFu;    // record padding -> PADSCORE
-                int v = MUSW_PADSCORE;
-                if (c < 36 && i < LQ) {
-                    const uint32_t qi = a.reverse ? (LQ - 1 - i) : i;
-                    v = mat[c * 36 + Q[qi]];
+            // one dword (4 rows) per thread and step; pad rows (i >= LQ) and the pad-letter row 36 = PADSCORE
+            const uint32_t dw_per_row = g * 8;
+            for (uint32_t idx = tid; idx < 37 * dw_per_row; idx += blockDim.x) {
+                const uint32_t c = idx / dw_per_row, w = idx - c * dw_per_row;
+                const uint32_t h = w / (g * 4), rem = w - h * (g * 4);
+                const uint32_t sst = rem >> 2, k = rem & 3;
+                const uint32_t i0 = sst * MUSW_R + h * 16 + k * 4;
+                uint32_t packed = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const uint32_t i = i0 + b;
+                    int v = MUSW_PADSCORE;
+                    if (c < 36 && i < LQ) {
+                        const uint32_t qi = a.reverse ? (LQ - 1 - i) : i;
+                        v = mat[c * 36 + Q[qi]];
+                    }
+                    packed |= (uint32_t) (v & 0xFF) << (8 * b);
                 }
-                prof[idx] = v;
+                ((uint32_t *) prof)[idx] = packed;
             }
-            if (GLOBAL_PROF) __threadfence_block();
             __syncthreads();
         }
         const uint32_t ppw = 64 / g;                 // pairs per wave (g <= 64 guaranteed by the host)
@@ -122,7 +132,7 @@ __global__ __launch_bounds__(64 * MUSW_WAVES) void k_mu_sw(musw_args a, uint32_t
         const uint8_t *B = a.t_mu;
         if (active) {
             const uint32_t k = k0 + pr;
-            t = a.list ? a.list[a.rowstart[q] + k] : (a.first[q] + k);
+            t = a.list ? a.list[a.rowstart[q] + k] : a.perm[a.first[q] + k];
             LB = a.t_len[t];
             B = a.t_mu + a.t_off[t];
         }
@@ -139,7 +149,8 @@ __global__ __launch_bounds__(64 * MUSW_WAVES) void k_mu_sw(musw_args a, uint32_t
         int hand = 0;          // (F << 16) | H of the bottom row of this strip at its previous column
         int diag_in = 0;       // H(i0-1, j-1) for the top row
         const int open = a.open, ext = a.ext;
-        const int *lane_prof = prof + st * MUSW_RP;
+        const signed char *lane_prof = prof + st * 16;
+        const uint32_t half = g * 16;
         unsigned lw = active ? *(const unsigned *) B : 0u;    // letters j..j+3 (chains are padded to 16 in HBM)
         unsigned lw_next = 0;
 
@@ -158,16 +169,16 @@ __global__ __launch_bounds__(64 * MUSW_WAVES) void k_mu_sw(musw_args a, uint32_t
                 }
                 c = (lw >> (8 * jm)) & 0xFF;
             }
-            const int *row = lane_prof + c * RS;
-            v4i S[MUSW_R / 4];
-#pragma unroll
-            for (int k = 0; k < MUSW_R / 4; ++k) S[k] = *(const v4i *) (row + 4 * k);
+            const signed char *row = lane_prof + c * RS;
+            const v4i S0 = *(const v4i *) row, S1 = *(const v4i *) (row + half);
             int diag = diag_in;
             int F = up_f;
             diag_in = up_h;
 #pragma unroll
             for (int r = 0; r < MUSW_R; ++r) {
-                int h = diag + S[r >> 2][r & 3];
+                const int w = r < 16 ? S0[r >> 2] : S1[(r - 16) >> 2];
+                int h = (r & 3) == 0 ? musw_add_sbyte<0>(diag, w) : (r & 3) == 1 ? musw_add_sbyte<1>(diag, w)
+                      : (r & 3) == 2 ? musw_add_sbyte<2>(diag, w) : musw_add_sbyte<3>(diag, w);
                 h = max(h, 0);
                 h = max(h, E[r]);
                 h = max(h, F);
@@ -190,6 +201,7 @@ __global__ __launch_bounds__(64 * MUSW_WAVES) void k_mu_sw(musw_args a, uint32_t
         if (active && st == 0) {
             const uint8_t v = (uint8_t) (red > 250 ? 255 : red);
             if (a.list) a.out[a.rowstart[q] + k0 + pr] = v;
+            else if (a.tri) a.out[(size_t) min(q, t) * a.ldo + max(q, t)] = v;
             else a.out[(size_t) q * a.ldo + t] = v;
         }
     }
@@ -226,30 +238,33 @@ __global__ void k_mu_sw_slow(musw_args a, const uint2 *pairs, const uint32_t *pa
     }
     const uint8_t v = (uint8_t) (best > 250 ? 255 : best);
     if (a.list) a.out[a.rowstart[q] + pair_k[p]] = v;
+    else if (a.tri) a.out[(size_t) min(q, t) * a.ldo + max(q, t)] = v;
     else a.out[(size_t) q * a.ldo + t] = v;
 }
 
 // ---------------------------------------------------------------------------------------------
 // device-side queue construction
 // ---------------------------------------------------------------------------------------------
-// class of a query by its padded length: 0: <=224, 1: <=416, 2: <=960 (LDS profile), 3: <=2048 (global profile), 4: slow
+// class of a query by its padded length: 0: <= 1024, 1: <= 2048 (LDS int8 profile), 4: slow path
 __device__ __forceinline__ int musw_class(uint32_t LQ)
 {
     const uint32_t lp = (LQ + MUSW_R - 1) / MUSW_R * MUSW_R;
-    if (lp <= 224) return 0;
-    if (lp <= 416) return 1;
-    if (lp <= MUSW_LDS_MAX_LQPAD) return 2;
-    if (LQ <= MUSW_MAX_LQ) return 3;
+    if (lp <= MUSW_CLASS0_LQPAD) return 0;
+    if (LQ <= MUSW_MAX_LQ) return 1;
     return 4;
 }
 
 // implicit lists: first[q], cnt[q]
-__global__ void k_musw_setup_implicit(uint32_t nq, uint32_t nt, int self_triangle, uint32_t *first, uint32_t *cnt)
+// Self triangle: the Mu matrix and the gap costs are symmetric, so score(q,t) == score(t,q) (forward
+// and reversed-query alike); each unordered pair is computed once with the SHORTER chain (lower rank)
+// in the query role (fewer strips per pair, shorter systolic ramp), i.e. query q takes the targets of
+// rank >= rank[q].
+__global__ void k_musw_setup_implicit(uint32_t nq, uint32_t nt, int self_triangle, const uint32_t *rank, uint32_t *first, uint32_t *cnt)
 {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
-    first[q] = self_triangle ? q : 0;
-    cnt[q] = self_triangle ? (nt > q ? nt - q : 0) : nt;
+    first[q] = self_triangle ? rank[q] : 0;
+    cnt[q] = self_triangle ? nt - rank[q] : nt;
 }
 
 // Single workgroup: for class `cls` compute per-query item counts, exclusive scan, write item_start[q] and *nitems.
@@ -293,7 +308,7 @@ __global__ __launch_bounds__(1024) void k_musw_scan_items(const uint32_t *q_len,
     if (tid == 0) { item_start[nq] = carry; *nitems = carry; }
 }
 
-__global__ void k_musw_fill_items(const uint32_t *q_len, const uint32_t *cnt, const uint32_t *first, const uint32_t *list,
+__global__ void k_musw_fill_items(const uint32_t *q_len, const uint32_t *cnt, const uint32_t *first, const uint32_t *perm, const uint32_t *list,
                                   const uint32_t *rowstart, uint32_t nq, int cls, const uint32_t *item_start, uint2 *items,
                                   uint32_t *pair_k)
 {
@@ -303,7 +318,7 @@ __global__ void k_musw_fill_items(const uint32_t *q_len, const uint32_t *cnt, co
     const uint32_t LQ = q_len[q];
     if (cls == 4) {
         for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) {
-            const uint32_t t = list ? list[rowstart[q] + k] : first[q] + k;
+            const uint32_t t = list ? list[rowstart[q] + k] : perm[first[q] + k];
             items[item_start[q] + k] = make_uint2(q, t);
             pair_k[item_start[q] + k] = k;
         }
@@ -319,6 +334,7 @@ __global__ void k_musw_fill_items(const uint32_t *q_len, const uint32_t *cnt, co
 // ---------------------------------------------------------------------------------------------
 // one wave per query row: count (pass 0) or write (pass 1) targets with fwd' >= omega_fwd
 __global__ __launch_bounds__(256) void k_musw_candidates(const uint8_t *fwd, size_t ldo, const uint32_t *first, const uint32_t *cnt,
+                                                         const uint32_t *perm, int tri,
                                                          uint32_t nq, float omega_fwd, int pass, uint32_t *ccnt,
                                                          const uint32_t *rowstart, uint32_t *list)
 {
@@ -330,13 +346,15 @@ __global__ __launch_bounds__(256) void k_musw_candidates(const uint8_t *fwd, siz
     for (uint32_t k = 0; k < n; k += 64) {
         const uint32_t kk = k + lane;
         bool c = false;
+        uint32_t t = 0;
         if (kk < n) {
-            const int raw = fwd[(size_t) q * ldo + f0 + kk];
+            t = perm[f0 + kk];
+            const int raw = tri ? fwd[(size_t) min(q, t) * ldo + max(q, t)] : fwd[(size_t) q * ldo + t];
             const float f = raw == 255 ? 777.0f : (float) raw;     // parasail_mu.cpp:135-139
             c = !(f < omega_fwd);                                    // :141-146
         }
         const unsigned long long m = __ballot(c);
-        if (pass == 1 && c) list[rowstart[q] + run + __popcll(m & ((1ull << lane) - 1ull))] = f0 + kk;
+        if (pass == 1 && c) list[rowstart[q] + run + __popcll(m & ((1ull << lane) - 1ull))] = t;
         run += (uint32_t) __popcll(m);
     }
     if (pass == 0 && lane == 0) ccnt[q] = run;
@@ -373,7 +391,7 @@ __global__ __launch_bounds__(1024) void k_exclusive_scan_u32(const uint32_t *in,
 }
 
 // one wave per query row: survivors = candidates with fwd' - rev >= omega  (dssaligner.cpp:626-629)
-__global__ __launch_bounds__(256) void k_musw_survivors(const uint8_t *fwd, size_t ldo, const uint32_t *ccnt, const uint32_t *rowstart,
+__global__ __launch_bounds__(256) void k_musw_survivors(const uint8_t *fwd, size_t ldo, int tri, const uint32_t *ccnt, const uint32_t *rowstart,
                                                         const uint32_t *list, const uint8_t *rev, uint32_t nq, float omega,
                                                         uint32_t *pairs_q, uint32_t *pairs_t, int32_t *pairs_fwd, int32_t *pairs_rev,
                                                         uint32_t capacity, uint32_t *npairs)
@@ -389,7 +407,7 @@ __global__ __launch_bounds__(256) void k_musw_survivors(const uint8_t *fwd, size
         int f = 0, r = 0;
         if (kk < n) {
             t = list[rs + kk];
-            const int raw = fwd[(size_t) q * ldo + t];
+            const int raw = tri ? fwd[(size_t) min(q, t) * ldo + max(q, t)] : fwd[(size_t) q * ldo + t];
             f = raw == 255 ? 777 : raw;
             r = rev[rs + kk];                   // 255 when saturated (parasail_mu.cpp:152 read before the fix-up)
             const float sc = (float) f - (float) r;
@@ -403,7 +421,7 @@ __global__ __launch_bounds__(256) void k_musw_survivors(const uint8_t *fwd, size
         if (c) {
             const uint32_t pos = base + (uint32_t) __popcll(m & ((1ull << lane) - 1ull));
             if (pos < capacity) {
-                pairs_q[pos] = q; pairs_t[pos] = t;
+                pairs_q[pos] = tri ? min(q, t) : q; pairs_t[pos] = tri ? max(q, t) : t;
                 if (pairs_fwd) pairs_fwd[pos] = f;
                 if (pairs_rev) pairs_rev[pos] = r;
             }
@@ -418,7 +436,6 @@ __global__ __launch_bounds__(256) void k_musw_survivors(const uint8_t *fwd, size
 struct musw_ws {               // per-call device workspace
     uint32_t *first = nullptr, *cnt = nullptr, *item_start = nullptr, *nitems = nullptr, *counter = nullptr, *pair_k = nullptr;
     uint2 *items = nullptr;
-    int *gprof = nullptr;
     int *slow_scratch = nullptr;
     rsk_ctx *ctx = nullptr;
     std::vector<void *> all;
@@ -445,11 +462,11 @@ static int run_mu_sw_lists(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, musw_
     if ((rc = ws.alloc(&ws.items, (size_t) max_items_hint)) != RSK_OK) return rc;
     uint32_t maxLQ = 0;
     bool has_class[5] = { false, false, false, false, false };
-    uint32_t class_lqpad[4] = { 224, 416, MUSW_LDS_MAX_LQPAD, MUSW_MAX_LQ };
+    const uint32_t class_lqpad[2] = { MUSW_CLASS0_LQPAD, MUSW_MAX_LQ };
     for (uint32_t i = 0; i < nq; ++i) {
         const uint32_t L = q->len[i], lp = (L + MUSW_R - 1) / MUSW_R * MUSW_R;
         maxLQ = std::max(maxLQ, L);
-        const int c = lp <= 224 ? 0 : lp <= 416 ? 1 : lp <= MUSW_LDS_MAX_LQPAD ? 2 : L <= MUSW_MAX_LQ ? 3 : 4;
+        const int c = lp <= MUSW_CLASS0_LQPAD ? 0 : L <= MUSW_MAX_LQ ? 1 : 4;
         has_class[c] = true;
     }
     for (int cls = 0; cls < 5; ++cls) {
@@ -458,28 +475,22 @@ static int run_mu_sw_lists(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, musw_
         hipLaunchKernelGGL(k_musw_scan_items, dim3(1), dim3(1024), 0, ctx->stream, q->d_len, base.cnt, nq, cls, ws.item_start,
                            ws.nitems);
         if (cls == 4 && !ws.pair_k) { if ((rc = ws.alloc(&ws.pair_k, (size_t) max_items_hint)) != RSK_OK) return rc; }
-        hipLaunchKernelGGL(k_musw_fill_items, dim3(nq), dim3(64), 0, ctx->stream, q->d_len, base.cnt, base.first, base.list,
+        hipLaunchKernelGGL(k_musw_fill_items, dim3(nq), dim3(64), 0, ctx->stream, q->d_len, base.cnt, base.first, base.perm, base.list,
                            base.rowstart, nq, cls, ws.item_start, ws.items, ws.pair_k);
         musw_args a = base;
         a.items = ws.items;
         a.nitems = ws.nitems;
         a.counter = ws.counter;
-        if (cls <= 2) {
-            const uint32_t lq = class_lqpad[cls];
-            const size_t lds = (size_t) 37 * (lq / MUSW_R * MUSW_RP) * 4 + 1312 + 16;
+        if (cls <= 1) {
+            const uint32_t gmax = class_lqpad[cls] / MUSW_R;
+            const size_t lds = (size_t) 37 * gmax * 32 + 1312 + 16;
             static bool attr_set = false;
             if (!attr_set) {
-                RSK_HIP(hipFuncSetAttribute((const void *) k_mu_sw<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+                RSK_HIP(hipFuncSetAttribute((const void *) k_mu_sw, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
                 attr_set = true;
             }
             const int wg_per_cu = std::max(1, std::min(4, (int) (163840 / lds)));
-            hipLaunchKernelGGL((k_mu_sw<false>), dim3(ctx->num_cus * wg_per_cu), dim3(64 * MUSW_WAVES), lds, ctx->stream, a, lq);
-        } else if (cls == 3) {
-            const uint32_t nwg = ctx->num_cus * 2;
-            a.gprof_stride = (size_t) 37 * (MUSW_MAX_LQ / MUSW_R * MUSW_RP);
-            if (!ws.gprof) { if ((rc = ws.alloc(&ws.gprof, a.gprof_stride * nwg)) != RSK_OK) return rc; }
-            a.gprof = ws.gprof;
-            hipLaunchKernelGGL((k_mu_sw<true>), dim3(nwg), dim3(64 * MUSW_WAVES), 1312 + 16, ctx->stream, a, 0u);
+            hipLaunchKernelGGL(k_mu_sw, dim3(ctx->num_cus * wg_per_cu), dim3(64 * MUSW_WAVES), lds, ctx->stream, a, gmax);
         } else {
             // slow path: needs the item count on the host to size the launch
             uint32_t n = 0;
@@ -502,7 +513,7 @@ static uint32_t item_exact_implicit(const rsk_db *q, uint32_t nt, int self_trian
     uint64_t n = 16;
     for (uint32_t i = 0; i < q->n; ++i) {
         const uint32_t L = q->len[i];
-        const uint64_t cnt = self_triangle ? (nt > i ? nt - i : 0) : nt;
+        const uint64_t cnt = self_triangle ? nt - q->h_len_rank[i] : nt;
         if (L > MUSW_MAX_LQ) { n += cnt; continue; }
         const uint32_t g = (L + MUSW_R - 1) / MUSW_R, per_wg = (64 / g) * MUSW_WAVES;
         n += (cnt + per_wg - 1) / per_wg;
@@ -521,6 +532,22 @@ static uint32_t item_upper_bound(const rsk_db *q, uint64_t total_listed)
     return (uint32_t) std::min<uint64_t>(ub, 0xFFFFFFF0ull);
 }
 
+int rsk_build_len_perm(rsk_db *db)
+{
+    if (db->d_len_perm) return RSK_OK;
+    std::vector<uint32_t> perm(db->n), rank(db->n);
+    for (uint32_t i = 0; i < db->n; ++i) perm[i] = i;
+    std::stable_sort(perm.begin(), perm.end(), [&](uint32_t x, uint32_t y) { return db->len[x] < db->len[y]; });
+    for (uint32_t k = 0; k < db->n; ++k) rank[perm[k]] = k;
+    RSK_HIP(hipMalloc((void **) &db->d_len_perm, std::max<size_t>(db->n, 1) * 4));
+    RSK_HIP(hipMalloc((void **) &db->d_len_rank, std::max<size_t>(db->n, 1) * 4));
+    RSK_HIP(hipMemcpy(db->d_len_perm, perm.data(), (size_t) db->n * 4, hipMemcpyHostToDevice));
+    RSK_HIP(hipMemcpy(db->d_len_rank, rank.data(), (size_t) db->n * 4, hipMemcpyHostToDevice));
+    db->hbm_bytes += (uint64_t) db->n * 8;
+    db->h_len_rank.swap(rank);
+    return RSK_OK;
+}
+
 extern "C" int rsk_mu_sw_matrix_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int self_triangle, int reverse_query,
                                     int gap_open, int gap_ext, uint8_t *d_scores, size_t ldo)
 {
@@ -536,12 +563,14 @@ extern "C" int rsk_mu_sw_matrix_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db 
     if ((rc = ws.alloc(&ws.first, q->n)) != RSK_OK) return rc;
     if ((rc = ws.alloc(&ws.cnt, q->n)) != RSK_OK) return rc;
     RSK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    if ((rc = rsk_build_len_perm(const_cast<rsk_db *>(t))) != RSK_OK) return rc;
     hipLaunchKernelGGL(k_musw_setup_implicit, dim3((q->n + 255) / 256), dim3(256), 0, ctx->stream, q->n, t->n, self_triangle,
-                       ws.first, ws.cnt);
+                       t->d_len_rank, ws.first, ws.cnt);
     musw_args a = {};
     a.q_mu = q->d_mu; a.q_off = q->d_off; a.q_len = q->d_len;
     a.t_mu = t->d_mu; a.t_off = t->d_off; a.t_len = t->d_len;
     a.cnt = ws.cnt; a.first = ws.first; a.list = nullptr; a.rowstart = nullptr;
+    a.perm = t->d_len_perm; a.tri = self_triangle ? 1 : 0;
     a.reverse = reverse_query ? 1 : 0; a.open = gap_open; a.ext = gap_ext;
     a.out = d_scores; a.ldo = ldo;
     rc = run_mu_sw_lists(ctx, q, t, a, item_exact_implicit(q, t->n, self_triangle), ws);
@@ -570,12 +599,14 @@ extern "C" int rsk_mu_filter_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t,
     if ((rc = ws.alloc(&ws.cnt, nq)) != RSK_OK) return rc;
     RSK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     RSK_HIP(hipMemsetAsync(d_npairs, 0, 4, ctx->stream));
-    hipLaunchKernelGGL(k_musw_setup_implicit, dim3((nq + 255) / 256), dim3(256), 0, ctx->stream, nq, t->n, self_triangle, ws.first,
-                       ws.cnt);
+    if ((rc = rsk_build_len_perm(const_cast<rsk_db *>(t))) != RSK_OK) return rc;
+    hipLaunchKernelGGL(k_musw_setup_implicit, dim3((nq + 255) / 256), dim3(256), 0, ctx->stream, nq, t->n, self_triangle, t->d_len_rank,
+                       ws.first, ws.cnt);
     musw_args a = {};
     a.q_mu = q->d_mu; a.q_off = q->d_off; a.q_len = q->d_len;
     a.t_mu = t->d_mu; a.t_off = t->d_off; a.t_len = t->d_len;
     a.cnt = ws.cnt; a.first = ws.first;
+    a.perm = t->d_len_perm; a.tri = self_triangle ? 1 : 0;
     a.reverse = 0; a.open = gap_open; a.ext = gap_ext;
     a.out = d_fwd; a.ldo = ldo;
     const uint64_t total = self_triangle ? (uint64_t) nq * (nq + 1) / 2 : (uint64_t) nq * t->n;
@@ -585,7 +616,7 @@ extern "C" int rsk_mu_filter_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t,
     uint8_t *rev = nullptr;
     if ((rc = ws.alloc(&ccnt, nq)) != RSK_OK) return rc;
     if ((rc = ws.alloc(&rowstart, (size_t) nq + 1)) != RSK_OK) return rc;
-    hipLaunchKernelGGL(k_musw_candidates, dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, d_fwd, ldo, ws.first, ws.cnt, nq, omega_fwd,
+    hipLaunchKernelGGL(k_musw_candidates, dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, d_fwd, ldo, ws.first, ws.cnt, a.perm, a.tri, nq, omega_fwd,
                        0, ccnt, (const uint32_t *) nullptr, (uint32_t *) nullptr);
     hipLaunchKernelGGL(k_exclusive_scan_u32, dim3(1), dim3(1024), 0, ctx->stream, ccnt, nq, rowstart);
     uint32_t ncand = 0;
@@ -596,13 +627,13 @@ extern "C" int rsk_mu_filter_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t,
     if (ncand) {
         if ((rc = ws.alloc(&list, ncand)) != RSK_OK) return rc;
         if ((rc = ws.alloc(&rev, ncand)) != RSK_OK) return rc;
-        hipLaunchKernelGGL(k_musw_candidates, dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, d_fwd, ldo, ws.first, ws.cnt, nq,
+        hipLaunchKernelGGL(k_musw_candidates, dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, d_fwd, ldo, ws.first, ws.cnt, a.perm, a.tri, nq,
                            omega_fwd, 1, ccnt, rowstart, list);
         musw_args b = a;
         b.cnt = ccnt; b.first = nullptr; b.list = list; b.rowstart = rowstart;
         b.reverse = 1; b.out = rev;
         if ((rc = run_mu_sw_lists(ctx, q, t, b, item_upper_bound(q, ncand), ws2)) != RSK_OK) return rc;
-        hipLaunchKernelGGL(k_musw_survivors, dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, d_fwd, ldo, ccnt, rowstart, list, rev, nq,
+        hipLaunchKernelGGL(k_musw_survivors, dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, d_fwd, ldo, a.tri, ccnt, rowstart, list, rev, nq,
                            omega, d_pairs_q, d_pairs_t, d_pairs_fwd, d_pairs_rev, (uint32_t) capacity, d_npairs);
     }
     RSK_HIP(hipGetLastError());

@@ -24,10 +24,15 @@
 //     columns (one wave per pair).
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <cmath>
 #include <numeric>
 #include <vector>
+
+#include <hipcub/hipcub.hpp>
 
 #include "rsk_internal.h"
 #include "rsk_tables_data.h"
@@ -76,6 +81,7 @@ struct swf_args {
     const uint8_t *a_prof;   // A: [8][npadA] feature-major letters
     const uint32_t *a_off, *a_len;
     const uint16_t *a_ra;    // A: [npadA][8] table ROW offsets in bytes (letter * alphabet * 4)
+    const uint16_t *a_cb;    // A: [npadA][8] letter * 4 (k_sw_qp, strips along B)
     const uint8_t *b_prof;   // B: [8][npadB]
     const uint16_t *b_cb;    // B: [npadB][8] table COLUMN offsets in bytes (letter*4)
     const uint32_t *b_off, *b_len;
@@ -270,10 +276,206 @@ __global__ __launch_bounds__(64 * SWF_WAVES) void k_sw_float(swf_args a, uint32_
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// k_sw_qp: the same recurrence for GROUPS of pairs that share their strip chain (a query against
+// its filter survivors).  One workgroup = one group: it first expands the strip chain into a
+// "query profile" in LDS,
+//     QP[f][c][i] = feature table f, strip-chain letter of residue i, against step-chain letter c
+//     (132 (f,c) combinations x LApad floats = 528 B per residue: chains up to SWQ_MAX_L residues),
+// stored as records of R consecutive residues, so that a lane fetches the S-contributions of its
+// whole strip for one feature with R/4 ds_read_b128 and no per-cell address arithmetic
+// (the legacy kernel above spends 8 ds_read_b32 + 16 address ops per cell).  Waves claim batches
+// of floor(64/g) pairs from an LDS counter.  Trace: 5 comparison bits per cell, shifted into a
+// dword by v_cmp + v_addc_co (6 cells per dword), W = ceil(R/6) dwords per lane and column.
+// ---------------------------------------------------------------------------------------------
+#define SWQ_R 12
+#define SWQ_W ((SWQ_R + 5) / 6)
+#define SWQ_NW 16
+#define SWQ_NFC 132                               // 20 + 7 * 16 (feature, step letter) combinations
+#define SWQ_MAX_G ((163840 - 256) / (SWQ_NFC * SWQ_R * 4))
+#define SWQ_MAX_L (SWQ_MAX_G * SWQ_R)
+
+struct swq_item { uint32_t first, count; };
+
+// w = 2 * w + (x > y) / (x >= y): the comparison bit enters through the carry
+#define SWQ_BIT_GT(w, x, y) asm("v_cmp_gt_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(w) : "v"(x), "v"(y) : "vcc")
+#define SWQ_BIT_GE(w, x, y) asm("v_cmp_ge_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(w) : "v"(x), "v"(y) : "vcc")
+#define SWQ_BIT_0GE(w, y) asm("v_cmp_ge_f32_e32 vcc, 0, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(w) : "v"(y) : "vcc")
+
+template <bool T>
+__global__ __launch_bounds__(64 * SWQ_NW) void k_sw_qp(swf_args a, const swq_item *items)
+{
+    extern __shared__ __attribute__((aligned(16))) float qp[];
+    constexpr int R = SWQ_R;
+    const swq_item it = items[blockIdx.x];
+    const uint32_t strip_chain = T ? a.ib[it.first] : a.ia[it.first];
+    const uint32_t LA = T ? a.b_len[strip_chain] : a.a_len[strip_chain];     // strip chain length
+    const uint32_t g = (LA + R - 1) / R;
+    const uint32_t gs = g * R;                     // floats per (f,c) row of the profile
+    uint32_t *next_batch = (uint32_t *) (qp + (size_t) SWQ_NFC * gs);
+    {
+        const uint8_t *sp = T ? (a.b_prof + a.b_off[strip_chain]) : (a.a_prof + a.a_off[strip_chain]);
+        const size_t snpad = T ? a.b_npad : a.a_npad;
+        const uint32_t tot = SWQ_NFC * gs;
+        for (uint32_t idx = threadIdx.x; idx < tot; idx += blockDim.x) {
+            const uint32_t fc = idx / gs, i = idx - fc * gs;
+            const uint32_t f = fc < 20 ? 0 : ((fc - 20) >> 4) + 1;
+            const uint32_t c = fc < 20 ? fc : ((fc - 20) & 15);
+            const uint32_t as = f == 0 ? 20 : 16, tof = f == 0 ? 0 : 400 + (f - 1) * 256;
+            float v = f == 0 ? -1e30f : 0.0f;      // rows below the chain end: S = -1e30, never a maximum
+            if (i < LA) {
+                const uint32_t letter = sp[(size_t) f * snpad + i];
+                v = c_swf_tables.t[tof + (T ? c * as + letter : letter * as + c)];
+            }
+            qp[idx] = v;
+        }
+        if (threadIdx.x == 0) *next_batch = 0;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const uint32_t npw = 64 / g;                   // pairs per wave pass
+    const uint32_t nbatch = (it.count + npw - 1) / npw;
+    const uint32_t pr = lane / g, st = lane - pr * g;
+    const float Open = a.open, Ext = a.ext;
+    const uint32_t i0 = st * R;
+    const uint32_t gsb = gs * 4;                   // bytes per (f,c) row
+    const char *qpl = (const char *) qp + i0 * 4;  // this lane's record within a row
+    for (;;) {
+        uint32_t b = 0;
+        if (lane == 0) b = atomicAdd(next_batch, 1u);
+        b = (uint32_t) __builtin_amdgcn_readfirstlane((int) b);
+        if (b >= nbatch) break;
+        const uint32_t pidx = b * npw + pr;
+        const bool active = pr < npw && pidx < it.count;
+        const uint32_t p = it.first + (active ? pidx : 0);
+        const uint32_t step_chain = T ? a.ia[p] : a.ib[p];
+        const uint32_t LB = T ? a.a_len[step_chain] : a.b_len[step_chain];
+        const uint16_t *bcb = T ? (a.a_cb + (size_t) a.a_off[step_chain] * 8) : (a.b_cb + (size_t) a.b_off[step_chain] * 8);
+        uint32_t *tbp = (uint32_t *) (a.tb + a.tb_off[p]) + st * SWQ_W;
+
+        float Md[R], In[R], rb[R];
+        uint32_t rj[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { Md[r] = SWF_MINUS_INF; In[r] = SWF_MINUS_INF; rb[r] = 0.0f; rj[r] = 0; }
+        if (st == 0) Md[0] = 0.0f;
+        float hand_m = SWF_MINUS_INF, hand_d = SWF_MINUS_INF, carry_in = SWF_MINUS_INF;
+        uint32_t ncol = active ? (LB + st) : 0;
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) ncol = max(ncol, (uint32_t) __shfl_xor((int) ncol, s, 64));
+        uint4 cbn = make_uint4(0, 0, 0, 0);
+        if (active) cbn = *(const uint4 *) bcb;
+
+        for (uint32_t col = 0; col < ncol; ++col) {
+            const int j = (int) col - (int) st;
+            const float in_m = dpp_shr1_f(hand_m);
+            const float in_d = dpp_shr1_f(hand_d);
+            if (active && j >= 0 && (uint32_t) j < LB) {
+                const uint4 cb = cbn;
+                cbn = *(const uint4 *) (bcb + (size_t) (j + 1) * 8);
+                const uint32_t cbw[4] = { cb.x, cb.y, cb.z, cb.w };
+                const char *rec[8];
+#pragma unroll
+                for (int f = 0; f < 8; ++f) {
+                    const uint32_t c4 = (f & 1) ? (cbw[f >> 1] >> 16) : (cbw[f >> 1] & 0xFFFFu);      // letter * 4
+                    const uint32_t fcb = f == 0 ? 0 : 20 + (f - 1) * 16;
+                    rec[f] = qpl + (fcb * gsb + (c4 >> 2) * gsb);
+                }
+                float ch = st == 0 ? SWF_MINUS_INF : in_d;
+                if (st != 0) Md[0] = carry_in;
+                else if (j > 0) Md[0] = SWF_MINUS_INF;
+                float carry = SWF_MINUS_INF;
+                uint32_t w = 0;
+#pragma unroll
+                for (int q = 0; q < R / 4; ++q) {
+                    float4 v[8];
+#pragma unroll
+                    for (int f = 0; f < 8; ++f) v[f] = *(const float4 *) (rec[f] + q * 16);
+                    float S4[4];
+                    S4[0] = v[0].x; S4[1] = v[0].y; S4[2] = v[0].z; S4[3] = v[0].w;
+#pragma unroll
+                    for (int f = 1; f < 8; ++f) { S4[0] += v[f].x; S4[1] += v[f].y; S4[2] += v[f].z; S4[3] += v[f].w; }
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int r = q * 4 + rr;
+                        const float m = Md[r];
+                        const float d = T ? In[r] : ch;
+                        const float n = T ? ch : In[r];
+                        Md[r] = carry;
+                        SWQ_BIT_GT(w, d, m);                 // TB_DM candidate (sw.cpp:127)
+                        const float x1 = fmaxf(m, d);
+                        SWQ_BIT_GT(w, n, x1);                // TB_IM (sw.cpp:135)
+                        const float x2 = fmaxf(x1, n);
+                        SWQ_BIT_0GE(w, x2);                  // TB_SM (sw.cpp:143)
+                        const float xM = fmaxf(x2, 0.0f) + S4[rr];
+                        if (xM > rb[r]) { rb[r] = xM; rj[r] = (uint32_t) j; }
+                        carry = xM;
+                        const float md = m + Open;
+                        const float de = d + Ext;
+                        SWQ_BIT_GE(w, md, de);               // TB_MD (sw.cpp:166)
+                        const float dd = fmaxf(md, de);
+                        const float ne = n + Ext;
+                        SWQ_BIT_GE(w, md, ne);               // TB_MI (sw.cpp:181)
+                        const float ni = fmaxf(md, ne);
+                        if (T) { ch = ni; In[r] = dd; }
+                        else { ch = dd; In[r] = ni; }
+                        if (r % 6 == 5 || r == R - 1) tbp[(size_t) j * g * SWQ_W + r / 6] = w;
+                    }
+                }
+                hand_m = carry;
+                hand_d = ch;
+            }
+            carry_in = in_m;
+        }
+        // best cell of the pair: highest score, then smallest i, then smallest j (sw.cpp:153-158 scans row-major with >)
+        float best = 0.0f;
+        uint32_t bi = 0xFFFFFFFFu, bj = 0xFFFFFFFFu;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t ii = T ? rj[r] : i0 + r, jj = T ? i0 + r : rj[r];
+            if (rb[r] > best || (rb[r] == best && best > 0.0f && (ii < bi || (ii == bi && jj < bj)))) { best = rb[r]; bi = ii; bj = jj; }
+        }
+        for (uint32_t dlt = 1; dlt < g; ++dlt) {
+            const int src = (lane + dlt) & 63;
+            const float ob = __shfl(best, src, 64);
+            const uint32_t oi = (uint32_t) __shfl((int) bi, src, 64), oj = (uint32_t) __shfl((int) bj, src, 64);
+            if (st + dlt < g) {
+                if (ob > best || (ob == best && ob > 0.0f && (oi < bi || (oi == bi && oj < bj)))) { best = ob; bi = oi; bj = oj; }
+            }
+        }
+        if (active && st == 0) {
+            a.score[p] = best;
+            a.besti[p] = bi;
+            a.bestj[p] = bj;
+        }
+    }
+}
+
 // TraceBackBitSW sw.cpp:8-77.  One thread per pair; path chars are written backwards into
-// paths[path_end[p]-1 ...]; path_start/path_len describe the result.
+// paths[path_end[p]-1 ...]; path_start/path_len describe the result.  Pair classes (sorted order):
+// 0 = k_sw_qp strips along A, 1 = k_sw_qp strips along B, 2 = k_sw_float<false>, 3 = k_sw_float<true>.
+struct swf_classes { uint32_t first[5]; };
+
+__device__ __forceinline__ uint32_t swf_trace_flags(const uint8_t *T, uint32_t cls, uint32_t ld, uint32_t i, uint32_t j)
+{
+    if (cls >= 2) return cls == 2 ? T[(size_t) j * ld + i] : T[(size_t) i * ld + j];
+    const uint32_t srow = cls == 0 ? i : j, step = cls == 0 ? j : i;     // ld = g (strips of the pair)
+    const uint32_t st = srow / SWQ_R, r = srow - st * SWQ_R;
+    const uint32_t wd = r / 6, q = r - wd * 6;
+    const uint32_t k = (wd == SWQ_W - 1) ? (SWQ_R - 6 * (SWQ_W - 1)) : 6;
+    const uint32_t w = ((const uint32_t *) T)[((size_t) step * ld + st) * SWQ_W + wd];
+    const uint32_t bits = (w >> (5 * (k - 1 - q))) & 31u;
+    uint32_t t = 0;
+    if (bits & 4) t = TB_SM;
+    else if (bits & 8) t = TB_IM;
+    else if (bits & 16) t = TB_DM;
+    if (bits & 2) t |= TB_MD;
+    if (bits & 1) t |= TB_MI;
+    return t;
+}
+
 __global__ void k_traceback(const uint8_t *tb, const uint64_t *tb_off, const uint32_t *ia, const uint32_t *a_len,
-                            const uint32_t *ib, const uint32_t *b_len, uint32_t first_transposed,
+                            const uint32_t *ib, const uint32_t *b_len, swf_classes cl,
                             const float *score, const uint32_t *besti, const uint32_t *bestj, uint32_t npairs,
                             char *paths, const uint64_t *path_end, uint64_t *path_start, uint32_t *path_len,
                             uint32_t *lo_a, uint32_t *lo_b)
@@ -285,10 +487,10 @@ __global__ void k_traceback(const uint8_t *tb, const uint64_t *tb_off, const uin
     lo_a[p] = RSK_NO_POS;
     lo_b[p] = RSK_NO_POS;
     if (score[p] == 0.0f) return;                     // sw.cpp:200-201
-    const bool tr = p >= first_transposed;
-    // element (i,j) of the trace block: normal T[j*LApad + i]; transposed T[i*LBpad + j]
-    const uint32_t ld = tr ? ((b_len[ib[p]] + 15) & ~15u) : ((a_len[ia[p]] + 15) & ~15u);
-    const uint32_t si = tr ? ld : 1u, sj = tr ? 1u : ld;
+    const uint32_t cls = (p >= cl.first[1]) + (p >= cl.first[2]) + (p >= cl.first[3]);
+    const uint32_t LA = a_len[ia[p]], LB = b_len[ib[p]];
+    const uint32_t ld = cls == 0 ? (LA + SWQ_R - 1) / SWQ_R : cls == 1 ? (LB + SWQ_R - 1) / SWQ_R
+                      : cls == 2 ? ((LA + 15) & ~15u) : ((LB + 15) & ~15u);
     const uint8_t *T = tb + tb_off[p];
     uint32_t i = besti[p] + 1, j = bestj[p] + 1;      // 1-based
     const uint32_t Besti = i, Bestj = j;
@@ -299,17 +501,17 @@ __global__ void k_traceback(const uint8_t *tb, const uint64_t *tb_off, const uin
         paths[--w] = state == 0 ? 'M' : (state == 1 ? 'D' : 'I');
         ++n;
         if (state == 0) {
-            const uint8_t t = T[(size_t) (j - 1) * sj + (size_t) (i - 1) * si];
+            const uint32_t t = swf_trace_flags(T, cls, ld, i - 1, j - 1);
             if (t & TB_DM) state = 1;
             else if (t & TB_IM) state = 2;
             else if (t & TB_SM) break;
             --i; --j;
         } else if (state == 1) {
-            const uint8_t t = T[(size_t) j * sj + (size_t) (i - 1) * si];
+            const uint32_t t = swf_trace_flags(T, cls, ld, i - 1, j);
             state = (t & TB_MD) ? 0 : 1;
             --i;
         } else {
-            const uint8_t t = T[(size_t) (j - 1) * sj + (size_t) i * si];
+            const uint32_t t = swf_trace_flags(T, cls, ld, i, j - 1);
             state = (t & TB_MI) ? 0 : 2;
             --j;
         }
@@ -387,6 +589,26 @@ __global__ __launch_bounds__(256) void k_lddt(const char *paths, const uint64_t 
     }
 }
 
+
+// caller-order path packing: out_len[p] = path_len[slot[p]] + 1 is scanned on the device, then one
+// wave per pair copies its path (NUL-terminated) to its final offset.
+__global__ void k_path_sizes(const uint32_t *slot, const uint32_t *path_len, uint32_t npairs, uint64_t *sizes)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < npairs) sizes[p] = (uint64_t) path_len[slot[p]] + 1;
+}
+__global__ void k_path_pack(const uint32_t *slot, const uint32_t *path_len, const uint64_t *path_start, const char *paths,
+                            const uint64_t *out_off, uint32_t npairs, char *out)
+{
+    const uint32_t p = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (p >= npairs) return;
+    const uint32_t k = slot[p], len = path_len[k];
+    const char *src = paths + path_start[k];
+    char *dst = out + out_off[p];
+    for (uint32_t c = threadIdx.x & 63; c < len; c += 64) dst[c] = src[c];
+    if ((threadIdx.x & 63) == 0) dst[len] = 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // host
 // ---------------------------------------------------------------------------------------------
@@ -416,6 +638,28 @@ extern "C" size_t rsk_align_paths_bytes(const rsk_db *a, const rsk_db *b, const 
     return tot;
 }
 
+namespace {
+struct swf_timer {
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    swf_timer() : on(getenv("RSK_TRACE") != nullptr), t0(std::chrono::steady_clock::now()) {}
+    void lap(const char *what)
+    {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[rsk_align_pairs] %-18s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
+// host -> device staging of the small per-call arrays: one pinned blob, one copy
+struct swf_blob {
+    std::vector<std::pair<size_t, size_t>> sect;   // (offset, bytes)
+    size_t bytes = 0;
+    size_t add(size_t n) { const size_t o = bytes; sect.push_back({ o, n }); bytes = (bytes + n + 255) & ~(size_t) 255; return o; }
+};
+}   // namespace
+
 extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *dbb, const uint32_t *ia, const uint32_t *ib,
                                size_t npairs, float gap_open, float gap_ext, float min_fwd_score, rsk_aln *out, char *paths,
                                size_t paths_bytes)
@@ -426,6 +670,7 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
     if (npairs == 0) return RSK_OK;
     if (npairs > 0x7FFFFFFFull) { rsk_set_error("rsk_align_pairs: too many pairs in one call"); return RSK_E_RANGE; }
     const bool want_stats = dba->d_x && dbb->d_x;
+    swf_timer tm;
     size_t need = 0;
     for (size_t p = 0; p < npairs; ++p) {
         if (ia[p] >= dba->n || ib[p] >= dbb->n) { rsk_set_error("rsk_align_pairs: pair %zu out of range", p); return RSK_E_INVALID; }
@@ -436,50 +681,125 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
     int rc = swf_upload_tables(ctx);
     if (rc != RSK_OK) return rc;
 
-    // order pairs by LA (descending) so the pairs of a wave have the same strip count
-    std::vector<uint32_t> order(npairs);
-    std::iota(order.begin(), order.end(), 0u);
-    // orientation: strips along A unless A is too long (then along B); normal pairs first
-    auto transposed = [&](uint32_t x) { return dba->len[ia[x]] > 64 * SWF_R && dbb->len[ib[x]] <= 64 * SWF_R; };
-    auto striplen = [&](uint32_t x) { return transposed(x) ? dbb->len[ib[x]] : dba->len[ia[x]]; };
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
-        const bool tx = transposed(x), ty = transposed(y);
-        if (tx != ty) return ty;
-        return striplen(x) > striplen(y);
-    });
-    size_t first_tr = npairs;
-    for (size_t k = 0; k < npairs; ++k) if (transposed(order[k])) { first_tr = k; break; }
-    std::vector<uint32_t> sia(npairs), sib(npairs);
-    std::vector<uint64_t> tb_off(npairs + 1), path_end(npairs), sc_off(npairs + 1), bnd_off(npairs + 1);
-    uint64_t tbo = 0, pe = 0, so = 0, bno = 0;
+    // ---- classes: 0/1 = query-profile kernel (strips along A / along B), 2/3 = per-pair kernel --------
+    // A pair goes to the query-profile kernel when one of its chains fits the LDS profile and enough
+    // pairs of this call share that chain to fill a wave; everything else takes the per-pair kernel.
+    static const uint32_t min_group = getenv("RSK_SWQ_MIN_GROUP") ? (uint32_t) atoi(getenv("RSK_SWQ_MIN_GROUP")) : 4;
+    std::vector<uint32_t> cntA(dba->n, 0), cntB;
+    for (size_t p = 0; p < npairs; ++p) ++cntA[ia[p]];
+    bool anyB = false;
+    for (size_t p = 0; p < npairs && !anyB; ++p) anyB = dba->len[ia[p]] > SWQ_MAX_L || cntA[ia[p]] < min_group;
+    if (anyB) {
+        cntB.assign(dbb->n, 0);
+        for (size_t p = 0; p < npairs; ++p)
+            if (dba->len[ia[p]] > SWQ_MAX_L || cntA[ia[p]] < min_group) ++cntB[ib[p]];
+    }
+    struct keyed { uint64_t key; uint32_t idx; };
+    std::vector<keyed> ord(npairs);
+    for (size_t p = 0; p < npairs; ++p) {
+        const uint32_t LA = dba->len[ia[p]], LB = dbb->len[ib[p]];
+        uint64_t key;
+        if (LA > 0 && LA <= SWQ_MAX_L && cntA[ia[p]] >= min_group)
+            key = ((uint64_t) 0 << 62) | ((uint64_t) ia[p] << 24) | (0xFFFFFFu - std::min(LB, 0xFFFFFFu));
+        else if (LB > 0 && LB <= SWQ_MAX_L && cntB[ib[p]] >= min_group)
+            key = ((uint64_t) 1 << 62) | ((uint64_t) ib[p] << 24) | (0xFFFFFFu - std::min(LA, 0xFFFFFFu));
+        else if (!(LA > 64 * SWF_R && LB <= 64 * SWF_R))
+            key = ((uint64_t) 2 << 62) | ((uint64_t) (0xFFFFFFu - std::min(LA, 0xFFFFFFu)) << 32);
+        else
+            key = ((uint64_t) 3 << 62) | ((uint64_t) (0xFFFFFFu - std::min(LB, 0xFFFFFFu)) << 32);
+        ord[p] = keyed{ key, (uint32_t) p };
+    }
+    std::sort(ord.begin(), ord.end(), [](const keyed &x, const keyed &y) { return x.key != y.key ? x.key < y.key : x.idx < y.idx; });
+    swf_classes cl;
+    {
+        uint32_t cnt[4] = { 0, 0, 0, 0 };
+        for (size_t k = 0; k < npairs; ++k) ++cnt[ord[k].key >> 62];
+        cl.first[0] = 0;
+        for (int c = 0; c < 4; ++c) cl.first[c + 1] = cl.first[c] + cnt[c];
+    }
+    tm.lap("classify+sort");
+
+    // ---- per-pair offsets and work items ------------------------------------------------------------
+    swf_blob hb;
+    const size_t o_ia = hb.add(npairs * 4), o_ib = hb.add(npairs * 4), o_slot = hb.add(npairs * 4);
+    const size_t o_tboff = hb.add((npairs + 1) * 8), o_pend = hb.add(npairs * 8), o_scoff = hb.add((npairs + 1) * 8);
+    const size_t o_bndoff = hb.add((npairs + 1) * 8);
+    std::vector<swq_item> qitems[2];
+    std::vector<swf_item> items;
+    uint32_t nitems_normal = 0;
+    // items of the query-profile kernel: a group is cut into chunks of a few wave passes per workgroup
+    for (int c = 0; c < 2; ++c) {
+        const rsk_db *sdb = c == 0 ? dba : dbb;
+        size_t k = cl.first[c];
+        const size_t end = cl.first[c + 1];
+        while (k < end) {
+            const uint32_t chain = (uint32_t) ((ord[k].key >> 24) & 0xFFFFFFFFu);
+            size_t e = k;
+            while (e < end && (uint32_t) ((ord[e].key >> 24) & 0xFFFFFFFFu) == chain) ++e;
+            const uint32_t g = (sdb->len[chain] + SWQ_R - 1) / SWQ_R;
+            const uint32_t npw = 64 / g;
+            const size_t chunk = (size_t) npw * SWQ_NW * 2;
+            for (size_t s = k; s < e; s += chunk) qitems[c].push_back(swq_item{ (uint32_t) s, (uint32_t) std::min(chunk, e - s) });
+            k = e;
+        }
+        // longest-running workgroups first
+        std::stable_sort(qitems[c].begin(), qitems[c].end(), [&](const swq_item &x, const swq_item &y) {
+            const uint32_t cx = c == 0 ? ia[ord[x.first].idx] : ib[ord[x.first].idx], cy = c == 0 ? ia[ord[y.first].idx] : ib[ord[y.first].idx];
+            return (uint64_t) x.count * sdb->len[cx] > (uint64_t) y.count * sdb->len[cy];
+        });
+    }
+    for (int c = 2; c < 4; ++c) {
+        const bool tr = c == 3;
+        for (size_t k = cl.first[c]; k < cl.first[c + 1];) {
+            const uint32_t p = ord[k].idx;
+            uint32_t g = ((tr ? dbb->len[ib[p]] : dba->len[ia[p]]) + SWF_R - 1) / SWF_R;
+            if (g == 0) g = 1;
+            uint32_t ngroups = 1;
+            if (g > 64) { ngroups = (g + 63) / 64; g = 64; }
+            const uint32_t cnt = (uint32_t) std::min<size_t>(64 / g, cl.first[c + 1] - k);
+            items.push_back(swf_item{ (uint32_t) k, cnt, g, ngroups });
+            if (!tr) ++nitems_normal;
+            k += cnt;
+        }
+    }
+    const size_t o_items = hb.add(items.size() * sizeof(swf_item) + 16);
+    const size_t o_q0 = hb.add(qitems[0].size() * sizeof(swq_item) + 16), o_q1 = hb.add(qitems[1].size() * sizeof(swq_item) + 16);
+    void *hpin = nullptr;
+    if ((rc = rsk_pinned(ctx, 0, hb.bytes, &hpin)) != RSK_OK) return rc;
+    char *H = (char *) hpin;
+    uint32_t *sia = (uint32_t *) (H + o_ia), *sib = (uint32_t *) (H + o_ib), *slot = (uint32_t *) (H + o_slot);
+    uint64_t *tb_off = (uint64_t *) (H + o_tboff), *path_end = (uint64_t *) (H + o_pend), *sc_off = (uint64_t *) (H + o_scoff);
+    uint64_t *bnd_off = (uint64_t *) (H + o_bndoff);
+    uint64_t tbo = 0, pe = 0, so = 0, bno = 0, cells = 0;
     for (size_t k = 0; k < npairs; ++k) {
-        const uint32_t p = order[k];
+        const uint32_t p = ord[k].idx;
+        const uint32_t c = (uint32_t) (ord[k].key >> 62);
         sia[k] = ia[p]; sib[k] = ib[p];
+        slot[p] = (uint32_t) k;
         const uint32_t LA = dba->len[ia[p]], LB = dbb->len[ib[p]];
         bnd_off[k] = bno;
-        if (k < first_tr && LA > 64 * SWF_R) bno += 2 * (uint64_t) LB;      // multi-group pair: 2 words per step
         tb_off[k] = tbo;
-        tbo += k >= first_tr ? (uint64_t) ((LB + 15) & ~15u) * LA : (uint64_t) ((LA + 15) & ~15u) * LB;
+        if (c == 0) tbo += (uint64_t) LB * ((LA + SWQ_R - 1) / SWQ_R) * (SWQ_W * 4);
+        else if (c == 1) tbo += (uint64_t) LA * ((LB + SWQ_R - 1) / SWQ_R) * (SWQ_W * 4);
+        else if (c == 2) {
+            if (LA > 64 * SWF_R) bno += 2 * (uint64_t) LB;      // multi-group pair: 2 words per step
+            tbo += (uint64_t) ((LA + 15) & ~15u) * LB;
+        } else tbo += (uint64_t) ((LB + 15) & ~15u) * LA;
+        tbo = (tbo + 15) & ~(uint64_t) 15;
         pe += (uint64_t) LA + LB + 1;
         path_end[k] = pe;
         sc_off[k] = so;
         so += std::min(LA, LB);
+        cells += (uint64_t) LA * LB;
     }
     tb_off[npairs] = tbo;
     sc_off[npairs] = so;
-    std::vector<swf_item> items;
-    uint32_t nitems_normal = 0;
-    for (size_t k = 0; k < npairs;) {
-        const bool tr = k >= first_tr;
-        const size_t lim = tr ? npairs : first_tr;
-        uint32_t g = ((tr ? dbb->len[sib[k]] : dba->len[sia[k]]) + SWF_R - 1) / SWF_R;
-        uint32_t ngroups = 1;
-        if (g > 64) { ngroups = (g + 63) / 64; g = 64; }
-        const uint32_t cnt = (uint32_t) std::min<size_t>(64 / g, lim - k);
-        items.push_back(swf_item{ (uint32_t) k, cnt, g, ngroups });
-        if (!tr) ++nitems_normal;
-        k += cnt;
-    }
+    bnd_off[npairs] = bno;
+    memcpy(H + o_items, items.data(), items.size() * sizeof(swf_item));
+    memcpy(H + o_q0, qitems[0].data(), qitems[0].size() * sizeof(swq_item));
+    memcpy(H + o_q1, qitems[1].data(), qitems[1].size() * sizeof(swq_item));
+    tm.lap("offsets+items");
+
     struct ws_t {
         rsk_ctx *ctx;
         std::vector<void *> all;
@@ -491,49 +811,68 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
         ws.all.push_back(*p);
         return RSK_OK;
     };
-    auto dup = [&](void **p, const void *h, size_t bytes) -> int {
-        int r = dalloc(p, bytes);
-        if (r != RSK_OK) return r;
-        RSK_HIP(hipMemcpyAsync(*p, h, bytes, hipMemcpyHostToDevice, ctx->stream));
-        return RSK_OK;
-    };
-    uint32_t *d_ia, *d_ib, *d_bi, *d_bj, *d_plen, *d_loa, *d_lob, *d_pos = nullptr, *d_counts = nullptr;
-    uint64_t *d_tboff, *d_pend, *d_pstart, *d_scoff = nullptr, *d_bndoff = nullptr;
+    char *D = nullptr;
+    if ((rc = dalloc((void **) &D, hb.bytes)) != RSK_OK) return rc;
+    RSK_HIP(hipMemcpyAsync(D, H, hb.bytes, hipMemcpyHostToDevice, ctx->stream));
+    uint32_t *d_ia = (uint32_t *) (D + o_ia), *d_ib = (uint32_t *) (D + o_ib), *d_slot = (uint32_t *) (D + o_slot);
+    uint64_t *d_tboff = (uint64_t *) (D + o_tboff), *d_pend = (uint64_t *) (D + o_pend), *d_scoff = (uint64_t *) (D + o_scoff);
+    uint64_t *d_bndoff = (uint64_t *) (D + o_bndoff);
+    // device results: one blob, copied back in one piece
+    swf_blob rb;
+    const size_t r_score = rb.add(npairs * 4), r_loa = rb.add(npairs * 4), r_lob = rb.add(npairs * 4), r_plen = rb.add(npairs * 4);
+    const size_t r_lddt = rb.add(npairs * 4), r_counts = rb.add(npairs * 12), r_outoff = rb.add((npairs + 1) * 8);
+    char *RD = nullptr;
+    if ((rc = dalloc((void **) &RD, rb.bytes)) != RSK_OK) return rc;
+    float *d_score = (float *) (RD + r_score), *d_lddt = (float *) (RD + r_lddt);
+    uint32_t *d_loa = (uint32_t *) (RD + r_loa), *d_lob = (uint32_t *) (RD + r_lob), *d_plen = (uint32_t *) (RD + r_plen);
+    uint32_t *d_counts = (uint32_t *) (RD + r_counts);
+    uint64_t *d_outoff = (uint64_t *) (RD + r_outoff);
+    uint32_t *d_bi, *d_bj, *d_pos = nullptr;
+    uint64_t *d_pstart, *d_sizes;
     int *d_bnd = nullptr;
-    swf_item *d_items;
     uint8_t *d_tb;
-    float *d_score, *d_lddt = nullptr, *d_frac = nullptr;
-    char *d_paths;
-    if ((rc = dup((void **) &d_ia, sia.data(), npairs * 4)) != RSK_OK) return rc;
-    if ((rc = dup((void **) &d_ib, sib.data(), npairs * 4)) != RSK_OK) return rc;
-    if ((rc = dup((void **) &d_tboff, tb_off.data(), (npairs + 1) * 8)) != RSK_OK) return rc;
-    if ((rc = dup((void **) &d_pend, path_end.data(), npairs * 8)) != RSK_OK) return rc;
-    if ((rc = dup((void **) &d_items, items.data(), items.size() * sizeof(swf_item))) != RSK_OK) return rc;
+    float *d_frac = nullptr;
+    char *d_paths, *d_packed = nullptr;
     if ((rc = dalloc((void **) &d_tb, tbo + 64)) != RSK_OK) return rc;
-    if (bno) {
-        if ((rc = dup((void **) &d_bndoff, bnd_off.data(), (npairs + 1) * 8)) != RSK_OK) return rc;
-        if ((rc = dalloc((void **) &d_bnd, bno * 4)) != RSK_OK) return rc;
-    }
-    if ((rc = dalloc((void **) &d_score, npairs * 4)) != RSK_OK) return rc;
+    if (bno && (rc = dalloc((void **) &d_bnd, bno * 4)) != RSK_OK) return rc;
     if ((rc = dalloc((void **) &d_bi, npairs * 4)) != RSK_OK) return rc;
     if ((rc = dalloc((void **) &d_bj, npairs * 4)) != RSK_OK) return rc;
-    if ((rc = dalloc((void **) &d_plen, npairs * 4)) != RSK_OK) return rc;
-    if ((rc = dalloc((void **) &d_loa, npairs * 4)) != RSK_OK) return rc;
-    if ((rc = dalloc((void **) &d_lob, npairs * 4)) != RSK_OK) return rc;
     if ((rc = dalloc((void **) &d_pstart, npairs * 8)) != RSK_OK) return rc;
+    if ((rc = dalloc((void **) &d_sizes, (npairs + 1) * 8)) != RSK_OK) return rc;
     if ((rc = dalloc((void **) &d_paths, pe + 16)) != RSK_OK) return rc;
+    tm.lap("alloc+h2d");
 
     swf_args a = {};
-    a.a_prof = dba->d_prof; a.a_off = dba->d_off; a.a_len = dba->d_len; a.a_npad = dba->npad; a.a_ra = dba->d_prof_ra;
+    a.a_prof = dba->d_prof; a.a_off = dba->d_off; a.a_len = dba->d_len; a.a_npad = dba->npad; a.a_ra = dba->d_prof_ra; a.a_cb = dba->d_prof_cb;
     a.b_prof = dbb->d_prof; a.b_npad = dbb->npad;
     a.b_cb = dbb->d_prof_cb; a.b_off = dbb->d_off; a.b_len = dbb->d_len;
     a.ia = d_ia; a.ib = d_ib;
-    a.items = d_items;
+    a.items = (const swf_item *) (D + o_items);
     a.open = gap_open; a.ext = gap_ext;
     a.tb = d_tb; a.tb_off = d_tboff;
     a.score = d_score; a.besti = d_bi; a.bestj = d_bj;
     a.bnd = d_bnd; a.bnd_off = d_bndoff;
     RSK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    static bool attr_done = false;
+    if (!attr_done) {
+        RSK_HIP(hipFuncSetAttribute((const void *) k_sw_qp<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+        RSK_HIP(hipFuncSetAttribute((const void *) k_sw_qp<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+        attr_done = true;
+    }
+    for (int c = 0; c < 2; ++c) {
+        if (qitems[c].empty()) continue;
+        // LDS of a launch = the longest strip chain among its groups
+        uint32_t gmax = 1;
+        const rsk_db *sdb = c == 0 ? dba : dbb;
+        for (const swq_item &q : qitems[c]) {
+            const uint32_t chain = c == 0 ? sia[q.first] : sib[q.first];
+            gmax = std::max(gmax, (sdb->len[chain] + SWQ_R - 1) / SWQ_R);
+        }
+        const size_t lds = (size_t) SWQ_NFC * gmax * SWQ_R * 4 + 16;
+        const swq_item *d_q = (const swq_item *) (D + (c == 0 ? o_q0 : o_q1));
+        if (c == 0) hipLaunchKernelGGL(k_sw_qp<false>, dim3((unsigned) qitems[c].size()), dim3(64 * SWQ_NW), lds, ctx->stream, a, d_q);
+        else hipLaunchKernelGGL(k_sw_qp<true>, dim3((unsigned) qitems[c].size()), dim3(64 * SWQ_NW), lds, ctx->stream, a, d_q);
+    }
     if (nitems_normal) {
         a.nitems = nitems_normal;
         hipLaunchKernelGGL(k_sw_float<false>, dim3((a.nitems + SWF_WAVES - 1) / SWF_WAVES), dim3(64 * SWF_WAVES), 0, ctx->stream, a, 0u);
@@ -546,39 +885,45 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
     RSK_HIP(hipGetLastError());
     RSK_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     hipLaunchKernelGGL(k_traceback, dim3((unsigned) ((npairs + 63) / 64)), dim3(64), 0, ctx->stream, d_tb, d_tboff, d_ia, dba->d_len,
-                       d_ib, dbb->d_len, (uint32_t) first_tr, d_score, d_bi, d_bj, (uint32_t) npairs, d_paths, d_pend, d_pstart, d_plen, d_loa, d_lob);
+                       d_ib, dbb->d_len, cl, d_score, d_bi, d_bj, (uint32_t) npairs, d_paths, d_pend, d_pstart, d_plen, d_loa, d_lob);
     RSK_HIP(hipGetLastError());
     if (want_stats) {
-        if ((rc = dup((void **) &d_scoff, sc_off.data(), (npairs + 1) * 8)) != RSK_OK) return rc;
         if ((rc = dalloc((void **) &d_pos, 2 * so * 4)) != RSK_OK) return rc;
         if ((rc = dalloc((void **) &d_frac, so * 4)) != RSK_OK) return rc;
-        if ((rc = dalloc((void **) &d_lddt, npairs * 4)) != RSK_OK) return rc;
-        if ((rc = dalloc((void **) &d_counts, npairs * 12)) != RSK_OK) return rc;
         hipLaunchKernelGGL(k_lddt, dim3((unsigned) ((npairs + 3) / 4)), dim3(256), 0, ctx->stream, d_paths, d_pstart, d_plen, d_loa, d_lob,
                            d_ia, d_ib, dba->d_off, dbb->d_off, dba->d_x, dba->d_y, dba->d_z, dbb->d_x, dbb->d_y, dbb->d_z,
                            (uint32_t) npairs, d_pos, d_scoff, d_frac, d_lddt, d_counts);
         RSK_HIP(hipGetLastError());
     }
-    std::vector<float> h_score(npairs), h_lddt(npairs, 0.0f);
-    std::vector<uint32_t> h_loa(npairs), h_lob(npairs), h_plen(npairs);
-    std::vector<uint64_t> h_pstart(npairs);
-    std::vector<char> h_paths;
-    RSK_HIP(hipMemcpyAsync(h_score.data(), d_score, npairs * 4, hipMemcpyDeviceToHost, ctx->stream));
-    RSK_HIP(hipMemcpyAsync(h_loa.data(), d_loa, npairs * 4, hipMemcpyDeviceToHost, ctx->stream));
-    RSK_HIP(hipMemcpyAsync(h_lob.data(), d_lob, npairs * 4, hipMemcpyDeviceToHost, ctx->stream));
-    RSK_HIP(hipMemcpyAsync(h_plen.data(), d_plen, npairs * 4, hipMemcpyDeviceToHost, ctx->stream));
-    RSK_HIP(hipMemcpyAsync(h_pstart.data(), d_pstart, npairs * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (want_stats) RSK_HIP(hipMemcpyAsync(h_lddt.data(), d_lddt, npairs * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (paths) {
-        h_paths.resize(pe + 16);
-        RSK_HIP(hipMemcpyAsync(h_paths.data(), d_paths, pe, hipMemcpyDeviceToHost, ctx->stream));
+        // pack the paths in the caller's order on the device
+        hipLaunchKernelGGL(k_path_sizes, dim3((unsigned) ((npairs + 255) / 256)), dim3(256), 0, ctx->stream, d_slot, d_plen, (uint32_t) npairs, d_sizes);
+        size_t tmp_bytes = 0;
+        RSK_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_sizes, d_outoff, (int) npairs + 1, ctx->stream));
+        void *d_tmp = nullptr;
+        if ((rc = dalloc(&d_tmp, tmp_bytes)) != RSK_OK) return rc;
+        RSK_HIP(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_sizes, d_outoff, (int) npairs + 1, ctx->stream));
+        if ((rc = dalloc((void **) &d_packed, need + 16)) != RSK_OK) return rc;
+        hipLaunchKernelGGL(k_path_pack, dim3((unsigned) ((npairs + 3) / 4)), dim3(256), 0, ctx->stream, d_slot, d_plen, d_pstart, d_paths,
+                           d_outoff, (uint32_t) npairs, d_packed);
+        RSK_HIP(hipGetLastError());
     }
+    void *rpin = nullptr;
+    if ((rc = rsk_pinned(ctx, 1, rb.bytes, &rpin)) != RSK_OK) return rc;
+    RSK_HIP(hipMemcpyAsync(rpin, RD, rb.bytes, hipMemcpyDeviceToHost, ctx->stream));
     RSK_HIP(hipStreamSynchronize(ctx->stream));
+    tm.lap("kernels+d2h");
+    const char *RH = (const char *) rpin;
+    const float *h_score = (const float *) (RH + r_score), *h_lddt = (const float *) (RH + r_lddt);
+    const uint32_t *h_loa = (const uint32_t *) (RH + r_loa), *h_lob = (const uint32_t *) (RH + r_lob), *h_plen = (const uint32_t *) (RH + r_plen);
+    const uint32_t *h_counts = (const uint32_t *) (RH + r_counts);
+    const uint64_t *h_outoff = (const uint64_t *) (RH + r_outoff);
+    if (paths) {
+        const uint64_t total = h_outoff[npairs];
+        RSK_HIP(hipMemcpy(paths, d_packed, total, hipMemcpyDeviceToHost));
+        tm.lap("paths d2h");
+    }
 
-    // results back in the caller's pair order; paths packed in that order as NUL-terminated strings
-    std::vector<size_t> slot(npairs);
-    for (size_t k = 0; k < npairs; ++k) slot[order[k]] = k;
-    size_t wpos = 0;
     for (size_t p = 0; p < npairs; ++p) {
         const size_t k = slot[p];
         rsk_aln &o = out[p];
@@ -589,17 +934,10 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
         o.hi_a = o.hi_b = o.ids = o.gaps = RSK_NO_POS;
         o.lddt = o.pvalue = o.evalue = o.qual = FLT_MAX;
         o.ts = -FLT_MAX;
-        o.path_off = wpos;
-        uint32_t nM = 0, nD = 0, nI = 0;
-        if (paths) {
-            const char *src = h_paths.data() + h_pstart[k];
-            memcpy(paths + wpos, src, o.path_len);
-            paths[wpos + o.path_len] = 0;
-            for (uint32_t c = 0; c < o.path_len; ++c) { nM += src[c] == 'M'; nD += src[c] == 'D'; nI += src[c] == 'I'; }
-            wpos += (size_t) o.path_len + 1;
-        }
+        o.path_off = paths ? h_outoff[p] : 0;
         // CalcEvalue dssaligner.cpp:852-904 (the double-precision pow stays on the host: libm)
         if (want_stats && paths && !(o.score < min_fwd_score)) {
+            const uint32_t nM = h_counts[3 * k], nD = h_counts[3 * k + 1], nI = h_counts[3 * k + 2];
             o.hi_a = o.lo_a + nM + nD - 1;
             o.hi_b = o.lo_b + nM + nI - 1;
             o.ids = nM;
@@ -613,13 +951,13 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
             ts += (dpw * o.score - revtsw * rev) / (L + ladd);
             o.lddt = h_lddt[k];
             o.ts = ts;
-            o.pvalue = (float) swf_pvalue(ts);
+            const double pv = swf_pvalue(ts);
+            o.pvalue = (float) pv;
             o.qual = (float) swf_qual(ts);
-            o.evalue = (float) (swf_pvalue(ts) * 8340.0);      // SCOP40c_DBSIZE statsig.h:3
+            o.evalue = (float) (pv * 8340.0);      // SCOP40c_DBSIZE statsig.h:3
         }
     }
-    uint64_t cells = 0;
-    for (size_t p = 0; p < npairs; ++p) cells += (uint64_t) dba->len[ia[p]] * dbb->len[ib[p]];
+    tm.lap("host stats");
     ctx->al_pairs = npairs; ctx->al_cells = cells; ctx->al_tb_bytes = tbo;
     return RSK_OK;
 }

@@ -92,9 +92,28 @@ void rsk_pool_release(rsk_ctx *ctx)
     ctx->pool_free.clear();
 }
 
+int rsk_pinned(rsk_ctx *ctx, int slot, size_t bytes, void **p)
+{
+    if (ctx->pin_bytes[slot] < bytes) {
+        if (ctx->pin[slot]) (void) hipHostFree(ctx->pin[slot]);
+        ctx->pin[slot] = nullptr;
+        ctx->pin_bytes[slot] = 0;
+        size_t cap = 1 << 20;
+        while (cap < bytes) cap <<= 1;
+        if (hipHostMalloc(&ctx->pin[slot], cap, hipHostMallocDefault) != hipSuccess) {
+            rsk_set_error("out of pinned host memory allocating %zu bytes", cap);
+            return RSK_E_NOMEM;
+        }
+        ctx->pin_bytes[slot] = cap;
+    }
+    *p = ctx->pin[slot];
+    return RSK_OK;
+}
+
 extern "C" void rsk_ctx_destroy(rsk_ctx *ctx)
 {
     if (!ctx) return;
+    for (int s = 0; s < 4; ++s) if (ctx->pin[s]) (void) hipHostFree(ctx->pin[s]);
     rsk_pool_release(ctx);
     for (auto &kv : ctx->pool_live) (void) hipFree(kv.first);
     if (ctx->ev0) (void) hipEventDestroy(ctx->ev0);
@@ -230,7 +249,7 @@ extern "C" void rsk_db_destroy(rsk_db *db)
 {
     if (!db) return;
     void *ptrs[] = { db->d_len, db->d_off, db->d_mu, db->d_prof, db->d_x, db->d_y, db->d_z, db->d_selfrev,
-                     db->d_ring_tab, db->d_ring_letters, db->d_ring_laneq, db->d_ring_qid, db->d_work, db->d_prof_cb, db->d_prof_ra, db->d_pf_table, db->d_pf_postings };
+                     db->d_ring_tab, db->d_ring_letters, db->d_ring_laneq, db->d_ring_qid, db->d_work, db->d_prof_cb, db->d_prof_ra, db->d_pf_table, db->d_pf_postings, db->d_len_perm, db->d_len_rank };
     for (void *p : ptrs)
         if (p) (void) hipFree(p);
     delete db;

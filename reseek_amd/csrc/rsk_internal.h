@@ -36,11 +36,15 @@ struct rsk_ctx {
     std::map<void *, size_t> pool_live;
     std::multimap<size_t, void *> pool_free;
     uint64_t pool_bytes = 0;
+    // grow-only pinned host staging buffers (slot 0: host->device blob, 1: device->host results)
+    void *pin[4] = { nullptr, nullptr, nullptr, nullptr };
+    size_t pin_bytes[4] = { 0, 0, 0, 0 };
 };
 
 int rsk_pool_alloc(rsk_ctx *ctx, void **p, size_t bytes);
 void rsk_pool_free(rsk_ctx *ctx, void *p);
 void rsk_pool_release(rsk_ctx *ctx);
+int rsk_pinned(rsk_ctx *ctx, int slot, size_t bytes, void **p);
 
 // One "ring" of the gapless kernel: several query chains laid out on a circular array of
 // 128*D diagonal slots (see k_mu_gapless.hip).
@@ -85,6 +89,10 @@ struct rsk_db {
     int work_tri = -1;
     void *d_work = nullptr;             // uint2 (ring, first target) entries, D = 4 class first
     uint32_t work_count[2] = { 0, 0 };
+    // chains by increasing length (Mu SW filter: the targets a wave works on at once have similar lengths)
+    uint32_t *d_len_perm = nullptr;     // perm[k] = chain index of rank k
+    uint32_t *d_len_rank = nullptr;     // rank[chain]
+    std::vector<uint32_t> h_len_rank;
     // k-mer prefilter index (built lazily when the chain set is the query side)
     bool mudex_built = false;
     void *d_pf_table = nullptr;         // uint2 [36^5] (start, count)
@@ -102,3 +110,4 @@ int rsk_launch_gapless_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, con
                              uint32_t *d_besti, uint32_t *d_bestj);
 int rsk_build_rings(rsk_db *db);
 int rsk_build_mudex(rsk_db *db);
+int rsk_build_len_perm(rsk_db *db);

@@ -46,19 +46,20 @@ def main():
         p, c = ctx.mu_filter_last_work()
         res["mu_filter_" + preset] = {"ms": dt * 1e3, "pairs": p, "rev_candidates": c, "survivors": int(nn.item()),
                                       "pairs_per_s": pairs / dt}
-    # float SW + traceback + LDDT on synthetic profiles/coordinates for a sample of pairs
-    import ctypes as C
+    # float SW + traceback + LDDT on synthetic profiles/coordinates, for the pairs that survived the
+    # "sensitive" Mu filter above (the list DBSearcher hands to rsk_align_pairs)
+    ctx.mu_filter_dev(db, db, True, 12.0, 20.0, out8.data_ptr(), n, pq.data_ptr(), pt.data_ptr(), 0, 0, cap, nn.data_ptr())
+    torch.cuda.synchronize()
+    ns = int(nn.item())
+    ia = pq[:ns].cpu().numpy().astype(np.uint32)
+    ib = pt[:ns].cpu().numpy().astype(np.uint32)
     rng = np.random.default_rng(3)
-    nal = min(n, 3000)
-    lens_al = np.array([len(s) for s in seqs[:nal]], np.uint32)
+    lens_al = np.array([len(s) for s in seqs], np.uint32)
     tot = int(lens_al.sum())
     prof = np.concatenate([np.concatenate([rng.integers(0, 20, (1, int(L))), rng.integers(0, 16, (7, int(L)))]).astype(np.uint8).reshape(-1)
                            for L in lens_al])
     xyz = tuple(np.cumsum(rng.normal(0, 2.2, tot)).astype(np.float32) for _ in range(3))
-    dba = reseek_amd.Db(ctx, lens_al, mu=np.concatenate(seqs[:nal]), prof=prof, xyz=xyz, selfrev=np.zeros(nal, np.float32))
-    npairs = 60000
-    ia = rng.integers(0, nal, npairs).astype(np.uint32)
-    ib = rng.integers(0, nal, npairs).astype(np.uint32)
+    dba = reseek_amd.Db(ctx, lens_al, mu=np.concatenate(seqs), prof=prof, xyz=xyz, selfrev=np.zeros(n, np.float32))
     ctx.align_pairs(dba, dba, ia, ib, min_fwd_score=7.0)      # warm the allocator pool
     t0 = time.perf_counter()
     ctx.align_pairs(dba, dba, ia, ib, min_fwd_score=7.0)

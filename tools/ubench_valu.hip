@@ -33,6 +33,27 @@ template <int MODE> __global__ __launch_bounds__(256) void k(int *out, int seed)
             if (MODE == 16) asm volatile("v_max_i16 %0, %0, %1" : "+v"(a[i]) : "v"(s));
             if (MODE == 17) asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(a[i]) : "v"(s));
             if (MODE == 18) asm volatile("v_pk_sub_u16 %0, %0, %1 clamp" : "+v"(a[i]) : "v"(s));
+            if (MODE == 19) asm volatile("v_add_u32_sdwa %0, %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "+v"(a[i]) : "v"(s));
+            if (MODE == 20) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(s));
+            if (MODE == 21) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(s));
+            if (MODE == 22) asm volatile("v_bfe_i32 %0, %1, 8, 8" : "+v"(a[i]) : "v"(s));
+            if (MODE == 23) asm volatile("v_cmp_gt_f32 vcc, %0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(a[i]) : "v"(s) : "vcc");
+            if (MODE == 24) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(a[i]) : "v"(s));
+            if (MODE == 25) asm volatile("v_max_u32 %0, %0, %1" : "+v"(a[i]) : "v"(s));
+            if (MODE == 26) asm volatile("v_max_i32_sdwa %0, %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "+v"(a[i]) : "v"(s));
+            if (MODE == 27) asm volatile("v_sub_u16 %0, %0, %1" : "+v"(a[i]) : "v"(s));
+            if (MODE == 28) asm volatile("v_max_u16 %0, %0, %1" : "+v"(a[i]) : "v"(s));
+            if (MODE == 29) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[0]) : "v"(s));
+            if (MODE == 30) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i & 1]) : "v"(s));
+            if (MODE == 31) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i & 3]) : "v"(s));
+            if (MODE == 40) asm volatile("v_add_u32 %0, %1, %2" : "=v"(a[i]) : "v"(a[(i + 1) & 15]), "v"(s));
+            if (MODE == 41) { if (i & 1) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(s)); else asm volatile("v_max_i32 %0, %0, %1" : "+v"(a[i]) : "v"(s)); }
+            if (MODE == 42) asm volatile("v_subrev_u32 %0, %1, %0" : "+v"(a[i]) : "s"(seed));
+            if (MODE == 43) asm volatile("v_max_i32 %0, 0, %0" : "+v"(a[i]));
+            if (MODE == 44) { asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(s)); }
+            if (MODE == 45) asm volatile("v_add_u32 %0, %1, %2" : "=v"(a[i]) : "v"(a[(i + 5) & 15]), "v"(a[(i + 9) & 15]));
+            if (MODE == 46) asm volatile("v_max_i32 %0, %1, %2" : "=v"(a[i]) : "v"(a[(i + 5) & 15]), "v"(a[(i + 9) & 15]));
+            if (MODE == 47) asm volatile("v_add_u32 %0, %0, %1\n\tv_max_i32 %0, %0, %2\n\tv_subrev_u32 %0, %3, %0" : "+v"(a[i]) : "v"(s), "v"(a[(i + 3) & 15]), "s"(seed));
             if (MODE == 5) asm volatile("v_pk_add_i16 %0, %0, %1 clamp\n\tv_pk_max_i16 %0, %0, %1" : "+v"(a[i]) : "v"(s));
         }
         if (MODE == 6) {
@@ -78,6 +99,32 @@ int main()
     run<9>("v_add_i16 clamp (vop3)", 16, 8);
     run<10>("v_add_i32 clamp", 16, 8);
     run<11>("v_max3_i32", 16, 8);
+    run<29>("v_add_u32 1 chain, 8 w/SIMD", 16, 8);
+    run<29>("v_add_u32 1 chain, 4 w/SIMD", 16, 4);
+    run<29>("v_add_u32 1 chain, 1 w/SIMD", 16, 1);
+    run<30>("v_add_u32 2 chains, 4 w/SIMD", 16, 4);
+    run<30>("v_add_u32 2 chains, 1 w/SIMD", 16, 1);
+    run<31>("v_add_u32 4 chains, 4 w/SIMD", 16, 4);
+    run<31>("v_add_u32 4 chains, 1 w/SIMD", 16, 1);
+    run<2>("v_add_u32 16 chains, 4 w/SIMD", 16, 4);
+    run<2>("v_add_u32 16 chains, 1 w/SIMD", 16, 1);
+    run<40>("v_add_u32 d=a[i+1]+s (not in place)", 16, 4);
+    run<41>("alternate add/max in place", 16, 4);
+    run<42>("v_subrev_u32 a, sgpr, a", 16, 4);
+    run<43>("v_max_i32 a, 0, a", 16, 4);
+    run<45>("v_add_u32 d = x + y (3 regs)", 16, 4);
+    run<46>("v_max_i32 d = max(x, y) (3 regs)", 16, 4);
+    run<47>("add;max;subrev triple (3 ops)", 48, 4);
+    run<19>("v_add_u32_sdwa sext byte", 16, 8);
+    run<20>("v_add_f32", 16, 8);
+    run<21>("v_max_f32", 16, 8);
+    run<22>("v_bfe_i32", 16, 8);
+    run<23>("v_cmp_gt_f32+v_addc (2 ops)", 32, 8);
+    run<24>("v_sub_u32", 16, 8);
+    run<25>("v_max_u32", 16, 8);
+    run<26>("v_max_i32_sdwa sext word", 16, 8);
+    run<27>("v_sub_u16", 16, 8);
+    run<28>("v_max_u16", 16, 8);
     run<12>("v_pk_mad_i16 clamp", 16, 8);
     run<13>("v_alignbit_b32", 16, 8);
     run<14>("v_cndmask_b32", 16, 8);
