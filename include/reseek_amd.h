@@ -145,16 +145,20 @@ int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *a, const rsk_db *b, const uint32
 /* Pairs, DP cells (sum LA*LB) and trace bytes written to HBM by the last rsk_align_pairs call. */
 int rsk_align_last_work(rsk_ctx *ctx, uint64_t *pairs, uint64_t *cells, uint64_t *tb_bytes);
 
-/* ---- P10/P11/P12: Mu k-mer prefilter (exact k-mers) -----------------------------------------------
+/* ---- P10/P11/P12: Mu k-mer prefilter ----------------------------------------------------------------
  * Batch form of MuDex::FromSeqDB (mudex.cpp:386; index of the QUERY set, built once and cached in q)
  * + PrefilterMu::Search over every target (prefiltermu.cpp:382): spaced 5-of-7 k-mers, self-score
  * mask 36, two-hit diagonals, FindHSP diagonal score.  Appends (query, target, score) triples, in
  * no particular order, one per (query, target) with a two-hit diagonal scoring > 0; *d_n = count
- * (entries beyond `capacity` are dropped).  This is the `-prefilter_mu` configuration; the k-mer
- * neighbourhoods of `-search -fast -db` (muprefilter.cpp:70-102) are not built yet.
+ * (entries beyond `capacity` are dropped).
+ * neighbourhood: 0 = exact k-mers (`reseek -prefilter_mu`, cmd_prefiltermu.cpp:52);
+ *                1 = "idxq" (query k-mers indexed with their >= 36 neighbourhood, exact matches listed
+ *                    twice as in mudex.cpp:201-219; `-search -fast -db` with <= 100 queries or -idxq);
+ *                2 = "idxt" (neighbourhood of each target k-mer, prefiltermu.cpp:174-199; > 100 queries
+ *                    or -idxt);  -1 = the reference's choice by query count (muprefilter.cpp:78-87).
  * At most 65535 queries (uint16 query index in the reference as well). */
-int rsk_mu_prefilter_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, uint32_t *d_out_q, uint32_t *d_out_t,
-                         uint32_t *d_out_score, size_t capacity, uint32_t *d_n);
+int rsk_mu_prefilter_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int neighbourhood, uint32_t *d_out_q,
+                         uint32_t *d_out_t, uint32_t *d_out_score, size_t capacity, uint32_t *d_n);
 /* RankedScoresBag (rankedscoresbag.cpp:34-51,185-231) on host arrays: per query keep the top
  * rsb_size targets exactly as the reference does with -threads 1 (truncation at 2B, quicksort tie
  * order).  out_* (capacity n) may be NULL; *nout = survivors.  tmp_tsv_path (optional) receives the

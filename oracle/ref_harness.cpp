@@ -29,6 +29,9 @@
 #include "myutils.h"
 #include "dss.h"
 #include "dssaligner.h"
+#include "museqsource.h"
+#include "prefiltermu.h"
+#include "seqdb.h"
 #include "chainreader2.h"
 #include "parasail.h"
 #include "mumx.h"
@@ -568,6 +571,29 @@ static void cmd_benchmu(const string &FaFN, uint64_t NPairs, uint Threads)
 	  Pairs.size(), Cells, Threads, Secs[0], Secs[1], (unsigned long long) Check[0], (unsigned long long) Check[1]);
 	}
 
+// The k-mer neighbourhood prefilter as cmd_search runs it (search.cpp:78-100 -> MuPreFilter
+// muprefilter.cpp:70), on Mu FASTA inputs: writes the (query, target, score) list of the
+// RankedScoresBag and the target-major hand-off TSV.  Mode: idxq | idxt | auto (via -idxq/-idxt after --).
+void MuPreFilter(const DSSParams &Params, SeqDB &QDB, MuSeqSource &FSS, const string &OutputFN);
+static void cmd_prefhood(const string &QFa, const string &TFa, const string &ScoresFN, const string &TmpFN)
+	{
+	DSSParams Params;
+	Params.SetDSSParams(DM_UseCommandLineOption);
+	SeqDB QDB;
+	QDB.FromFasta(QFa);
+	SeqDB TDB;
+	TDB.FromFasta(TFa);
+	MuSeqSource FSS;
+	FSS.OpenFasta(TFa);
+	MuPreFilter(Params, QDB, FSS, TmpFN);
+	vector<string> QLabels, TLabels;
+	for (uint i = 0; i < QDB.GetSeqCount(); ++i) QLabels.push_back(QDB.GetLabel(i));
+	for (uint i = 0; i < TDB.GetSeqCount(); ++i) TLabels.push_back(TDB.GetLabel(i));
+	FILE *f = CreateStdioFile(ScoresFN);
+	PrefilterMu::m_RSB.ToScoreTsv(f, QLabels, TLabels);
+	CloseStdioFile(f);
+	}
+
 int main(int argc, char **argv)
 	{
 	if (argc < 2)
@@ -602,6 +628,8 @@ int main(int argc, char **argv)
 		cmd_mukat(A[0], (uint) atoi(A[1].c_str()), (uint) atoi(A[2].c_str()), A[3]);
 	else if (Cmd == "randkat" && A.size() == 3)
 		cmd_randkat(strtoull(A[0].c_str(), 0, 0), (uint) atoi(A[1].c_str()), A[2]);
+	else if (Cmd == "prefhood" && A.size() == 4)
+		cmd_prefhood(A[0], A[1], A[2], A[3]);
 	else if (Cmd == "benchmu" && A.size() == 3)
 		cmd_benchmu(A[0], strtoull(A[1].c_str(), 0, 0), (uint) atoi(A[2].c_str()));
 	else

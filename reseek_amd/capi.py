@@ -57,7 +57,7 @@ SIGNATURES["rsk_align_last_work"] = (C.c_int, [C.c_void_p, u64p, u64p, u64p])
 SIGNATURES["rsk_search_rskdb"] = (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_double, C.c_int,
                                             C.c_char_p, u64p, u64p])
 
-SIGNATURES["rsk_mu_prefilter_dev"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+SIGNATURES["rsk_mu_prefilter_dev"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                                 C.c_size_t, C.c_void_p])
 SIGNATURES["rsk_rsb_select"] = (C.c_int, [u32p, u32p, u32p, C.c_size_t, C.c_uint32, C.c_uint32, u32p, u32p, u32p,
                                           C.POINTER(C.c_size_t), C.c_char_p])
@@ -183,9 +183,9 @@ class Ctx:
         return n.value, list(st)
 
     # ---- P10-P12 k-mer prefilter ---------------------------------------------------------------------
-    def mu_prefilter_dev(self, q, t, d_q, d_t, d_score, capacity, d_n):
-        _check(lib().rsk_mu_prefilter_dev(self.h, q.h, t.h, C.c_void_p(d_q), C.c_void_p(d_t), C.c_void_p(d_score), capacity,
-                                          C.c_void_p(d_n)))
+    def mu_prefilter_dev(self, q, t, d_q, d_t, d_score, capacity, d_n, neighbourhood=0):
+        _check(lib().rsk_mu_prefilter_dev(self.h, q.h, t.h, neighbourhood, C.c_void_p(d_q), C.c_void_p(d_t), C.c_void_p(d_score),
+                                          capacity, C.c_void_p(d_n)))
 
     def mu_gapless_last_work(self):
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()

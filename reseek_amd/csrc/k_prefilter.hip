@@ -19,6 +19,8 @@
 #include <algorithm>
 #include <vector>
 
+#include <hipcub/hipcub.hpp>
+
 #include "rsk_internal.h"
 #include "rsk_tables_data.h"
 
@@ -38,15 +40,93 @@ static int pf_upload_tables(rsk_ctx *ctx)
     return RSK_OK;
 }
 
-__global__ void k_pf_fill_table(const uint32_t *ukmer, const uint32_t *ustart, uint32_t nu, uint2 *table)
+// ---------------------------------------------------------------------------------------------
+// P10 index build on the device.  mode 0: exact k-mers (MuDex::FromSeqDB without neighbourhood);
+// mode 1 ("idxq", mudex.cpp:158-176,201-219): the posting (q, pos) of k-mer K goes to row K AND to the
+// row of every 5-mer K' with pair score S(K,K') >= 36 -- K itself included, so an exact match is listed
+// twice (and is a "two-hit" diagonal on its own: reference behaviour, kept); mode 2 ("idxt",
+// prefiltermu.cpp:174-199): the reference enumerates the neighbourhood of each TARGET k-mer against the
+// plain index; S is symmetric, so listing (q, pos) in the rows of all neighbours of K (once each, K
+// included) gives the same (TPos, QIdx, QPos) items -- with 288 GB of HBM the expanded index
+// (~660 postings per query position) replaces the per-target enumeration.
+// One workgroup per chain, one thread per k-mer position: branch-and-bound over the per-letter score
+// lists sorted by decreasing score (the reference's MerMx::GetHighScoring5mers mermx.cpp:484 bounds
+// AB|CD|E the same way; only the resulting SET matters).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pf_hood(const uint8_t *mu, const uint32_t *off, const uint32_t *len, int mode, int pass,
+                                                 uint32_t *cnt, const uint2 *table, uint32_t *postings,
+                                                 unsigned long long *total)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nu) table[ukmer[i]] = make_uint2(ustart[i], ustart[i + 1] - ustart[i]);
+    __shared__ signed char ss[36][36];     // scores of letter l's partners, descending
+    __shared__ uint8_t sl[36][36];         // the partner letters in that order
+    const int tid = threadIdx.x;
+    if (tid < 36) {
+        signed char sc[36];
+        uint8_t lt[36];
+        for (int b = 0; b < 36; ++b) { sc[b] = c_mu_s8[tid * 36 + b]; lt[b] = (uint8_t) b; }
+        for (int i = 1; i < 36; ++i) {                     // insertion sort, descending, stable
+            const signed char v = sc[i]; const uint8_t l = lt[i];
+            int j = i - 1;
+            while (j >= 0 && sc[j] < v) { sc[j + 1] = sc[j]; lt[j + 1] = lt[j]; --j; }
+            sc[j + 1] = v; lt[j + 1] = l;
+        }
+        for (int b = 0; b < 36; ++b) { ss[tid][b] = sc[b]; sl[tid][b] = lt[b]; }
+    }
+    __syncthreads();
+    const uint32_t q = blockIdx.x;
+    const uint32_t L = len[q];
+    const uint8_t *s = mu + off[q];
+    unsigned long long mine = 0;
+    auto emit = [&](uint32_t code, uint32_t p) {
+        if (pass == 0) { atomicAdd(&cnt[code], 1u); ++mine; }
+        else { const uint32_t slot = atomicAdd(&cnt[code], 1u); postings[table[code].x + slot] = (q << 16) | p; }
+    };
+    for (uint32_t p = tid; p + 7 <= L; p += blockDim.x) {
+        const uint32_t a0 = s[p], a1 = s[p + 1], a2 = s[p + 2], a3 = s[p + 5], a4 = s[p + 6];
+        const int self = c_mu_s8[a0 * 37] + c_mu_s8[a1 * 37] + c_mu_s8[a2 * 37] + c_mu_s8[a3 * 37] + c_mu_s8[a4 * 37];
+        if (self < PF_MINSELF) continue;
+        if (mode != 2) emit((((a0 * 36 + a1) * 36 + a2) * 36 + a3) * 36 + a4, p);
+        if (mode == 0) continue;
+        const int r4 = ss[a4][0], r3 = r4 + ss[a3][0], r2 = r3 + ss[a2][0], r1 = r2 + ss[a1][0];
+        for (int i0 = 0; i0 < 36; ++i0) {
+            const int s0 = ss[a0][i0];
+            if (s0 + r1 < PF_MINSELF) break;
+            const uint32_t c0 = sl[a0][i0];
+            for (int i1 = 0; i1 < 36; ++i1) {
+                const int s1 = s0 + ss[a1][i1];
+                if (s1 + r2 < PF_MINSELF) break;
+                const uint32_t c1 = c0 * 36 + sl[a1][i1];
+                for (int i2 = 0; i2 < 36; ++i2) {
+                    const int s2 = s1 + ss[a2][i2];
+                    if (s2 + r3 < PF_MINSELF) break;
+                    const uint32_t c2 = c1 * 36 + sl[a2][i2];
+                    for (int i3 = 0; i3 < 36; ++i3) {
+                        const int s3 = s2 + ss[a3][i3];
+                        if (s3 + r4 < PF_MINSELF) break;
+                        const uint32_t c3 = c2 * 36 + sl[a3][i3];
+                        for (int i4 = 0; i4 < 36; ++i4) {
+                            if (s3 + ss[a4][i4] < PF_MINSELF) break;
+                            emit(c3 * 36 + sl[a4][i4], p);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (pass == 0 && mine) atomicAdd(total, mine);
+}
+
+__global__ void k_pf_make_table(const uint32_t *start, uint32_t *cnt, uint2 *table)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= PF_DICT) return;
+    table[k] = make_uint2(start[k], cnt[k]);
+    cnt[k] = 0;                    // becomes the fill cursor
 }
 
 struct pf_args {
     const uint2 *table;            // [36^5] (start, count) into postings
-    const uint32_t *postings;      // q << 16 | pos, sorted by (kmer, q, pos)
+    const uint32_t *postings;      // q << 16 | pos, grouped by k-mer row (unordered within a row)
     const uint8_t *q_mu; const uint32_t *q_off; const uint32_t *q_len;
     const uint8_t *t_mu; const uint32_t *t_off; const uint32_t *t_len;
     uint32_t nt, nq;
@@ -143,12 +223,9 @@ __global__ __launch_bounds__(PF_THREADS) void k_prefilter(pf_args a)
                     const uint32_t k = pf_kmer(tl + p, self);
                     if (self < PF_MINSELF) continue;
                     const uint2 r = a.table[k];
-                    // postings of a row are sorted by (q, pos): binary search the sub-range of this query
-                    uint32_t lo = 0, hi2 = r.y;
-                    while (lo < hi2) { const uint32_t mid = (lo + hi2) >> 1; if ((a.postings[r.x + mid] >> 16) < q) lo = mid + 1; else hi2 = mid; }
-                    for (uint32_t c = lo; c < r.y; ++c) {
+                    for (uint32_t c = 0; c < r.y; ++c) {          // rows are unordered (atomic fill): linear scan
                         const uint32_t post = a.postings[r.x + c];
-                        if ((post >> 16) != q) break;
+                        if ((post >> 16) != q) continue;
                         const uint32_t d = (QL + p - (post & 0xFFFFu) - 1) & 0xFFFFu;
                         if (d > 16383u) continue;
                         atomicAdd(&hist[d], 1u);
@@ -262,63 +339,60 @@ __global__ __launch_bounds__(PF_THREADS) void k_prefilter(pf_args a)
 // ---------------------------------------------------------------------------------------------
 // host: index build (P10) + launch
 // ---------------------------------------------------------------------------------------------
-int rsk_build_mudex(rsk_db *db)
+int rsk_build_mudex(rsk_db *db, int mode)
 {
-    if (db->mudex_built) return RSK_OK;
+    if (db->mudex_built && db->mudex_mode == mode) return RSK_OK;
     if (db->n > 65535) { rsk_set_error("k-mer prefilter: at most 65535 query chains (uint16 query index, prefiltermu.cpp:296)"); return RSK_E_RANGE; }
-    std::vector<uint64_t> ent;
-    static const int o[5] = { 0, 1, 2, 5, 6 };
-    for (uint32_t q = 0; q < db->n; ++q) {
-        const uint8_t *s = &db->h_mu[db->off[q]];
-        const uint32_t L = db->len[q];
-        for (uint32_t p = 0; p + 7 <= L; ++p) {
-            uint32_t k = 0;
-            int self = 0;
-            for (int i = 0; i < 5; ++i) { const uint32_t l = s[p + o[i]]; k = k * 36 + l; self += rsk_mu_s8[l * 36 + l]; }
-            if (self < PF_MINSELF) continue;
-            ent.push_back(((uint64_t) k << 32) | ((uint64_t) q << 16) | p);
-        }
+    for (uint32_t L : db->len)
+        if (L > 65535) { rsk_set_error("k-mer prefilter: query longer than 65535 (uint16 position)"); return RSK_E_RANGE; }
+    if (db->d_pf_postings) { (void) hipFree(db->d_pf_postings); db->d_pf_postings = nullptr; db->hbm_bytes -= db->pf_postings * 4; }
+    uint32_t *d_cnt = nullptr, *d_start = nullptr;
+    unsigned long long *d_total = nullptr, total = 0;
+    void *d_tmp = nullptr;
+    auto cleanup = [&]() { (void) hipFree(d_cnt); (void) hipFree(d_start); (void) hipFree(d_total); (void) hipFree(d_tmp); };
+    if (!db->d_pf_table) {
+        RSK_HIP(hipMalloc((void **) &db->d_pf_table, (size_t) PF_DICT * sizeof(uint2)));
+        db->hbm_bytes += (size_t) PF_DICT * sizeof(uint2);
     }
-    std::sort(ent.begin(), ent.end());
-    std::vector<uint32_t> postings(ent.size()), ukmer, ustart;
-    for (size_t i = 0; i < ent.size(); ++i) {
-        postings[i] = (uint32_t) (ent[i] & 0xFFFFFFFFu);
-        const uint32_t k = (uint32_t) (ent[i] >> 32);
-        if (ukmer.empty() || ukmer.back() != k) { ukmer.push_back(k); ustart.push_back((uint32_t) i); }
-    }
-    ustart.push_back((uint32_t) ent.size());
-    uint32_t *d_uk = nullptr, *d_us = nullptr;
-    RSK_HIP(hipMalloc((void **) &db->d_pf_table, (size_t) PF_DICT * sizeof(uint2)));
-    RSK_HIP(hipMemset(db->d_pf_table, 0, (size_t) PF_DICT * sizeof(uint2)));
-    RSK_HIP(hipMalloc((void **) &db->d_pf_postings, std::max<size_t>(postings.size(), 1) * 4));
-    RSK_HIP(hipMemcpy(db->d_pf_postings, postings.data(), postings.size() * 4, hipMemcpyHostToDevice));
-    if (!ukmer.empty()) {
-        RSK_HIP(hipMalloc((void **) &d_uk, ukmer.size() * 4));
-        RSK_HIP(hipMalloc((void **) &d_us, ustart.size() * 4));
-        RSK_HIP(hipMemcpy(d_uk, ukmer.data(), ukmer.size() * 4, hipMemcpyHostToDevice));
-        RSK_HIP(hipMemcpy(d_us, ustart.data(), ustart.size() * 4, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(k_pf_fill_table, dim3((unsigned) ((ukmer.size() + 255) / 256)), dim3(256), 0, 0, d_uk, d_us,
-                           (uint32_t) ukmer.size(), (uint2 *) db->d_pf_table);
-        RSK_HIP(hipGetLastError());
-        RSK_HIP(hipDeviceSynchronize());
-        (void) hipFree(d_uk);
-        (void) hipFree(d_us);
-    }
-    db->pf_postings = postings.size();
-    db->hbm_bytes += (size_t) PF_DICT * sizeof(uint2) + postings.size() * 4;
+    RSK_HIP(hipMalloc((void **) &d_cnt, (size_t) PF_DICT * 4));
+    RSK_HIP(hipMalloc((void **) &d_start, (size_t) PF_DICT * 4));
+    RSK_HIP(hipMalloc((void **) &d_total, 8));
+    RSK_HIP(hipMemset(d_cnt, 0, (size_t) PF_DICT * 4));
+    RSK_HIP(hipMemset(d_total, 0, 8));
+    if (db->n) hipLaunchKernelGGL(k_pf_hood, dim3(db->n), dim3(256), 0, 0, db->d_mu, db->d_off, db->d_len, mode, 0, d_cnt,
+                                  (const uint2 *) nullptr, (uint32_t *) nullptr, d_total);
+    RSK_HIP(hipGetLastError());
+    RSK_HIP(hipMemcpy(&total, d_total, 8, hipMemcpyDeviceToHost));
+    if (total > 0xFFFFFFF0ull) { cleanup(); rsk_set_error("k-mer prefilter: %llu index postings exceed 2^32; split the query set", total); return RSK_E_RANGE; }
+    size_t tmp_bytes = 0;
+    RSK_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_cnt, d_start, (int) PF_DICT));
+    RSK_HIP(hipMalloc(&d_tmp, std::max<size_t>(tmp_bytes, 16)));
+    RSK_HIP(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_cnt, d_start, (int) PF_DICT));
+    hipLaunchKernelGGL(k_pf_make_table, dim3((PF_DICT + 255) / 256), dim3(256), 0, 0, d_start, d_cnt, (uint2 *) db->d_pf_table);
+    RSK_HIP(hipMalloc((void **) &db->d_pf_postings, std::max<size_t>((size_t) total, 1) * 4));
+    if (db->n) hipLaunchKernelGGL(k_pf_hood, dim3(db->n), dim3(256), 0, 0, db->d_mu, db->d_off, db->d_len, mode, 1, d_cnt,
+                                  (const uint2 *) db->d_pf_table, db->d_pf_postings, d_total);
+    RSK_HIP(hipGetLastError());
+    RSK_HIP(hipDeviceSynchronize());
+    cleanup();
+    db->pf_postings = (size_t) total;
+    db->hbm_bytes += (size_t) total * 4;
     db->mudex_built = true;
+    db->mudex_mode = mode;
     return RSK_OK;
 }
 
-extern "C" int rsk_mu_prefilter_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, uint32_t *d_out_q, uint32_t *d_out_t,
-                                    uint32_t *d_out_score, size_t capacity, uint32_t *d_n)
+extern "C" int rsk_mu_prefilter_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int neighbourhood, uint32_t *d_out_q,
+                                    uint32_t *d_out_t, uint32_t *d_out_score, size_t capacity, uint32_t *d_n)
 {
     if (!ctx || !q || !t || !d_out_q || !d_out_t || !d_out_score || !d_n) { rsk_set_error("rsk_mu_prefilter_dev: NULL argument"); return RSK_E_INVALID; }
     if (!q->d_mu || !t->d_mu) { rsk_set_error("rsk_mu_prefilter_dev: chain set has no Mu letters"); return RSK_E_INVALID; }
     RSK_HIP(hipSetDevice(ctx->device));
     int rc = pf_upload_tables(ctx);
     if (rc != RSK_OK) return rc;
-    if ((rc = rsk_build_mudex(const_cast<rsk_db *>(q))) != RSK_OK) return rc;
+    if (neighbourhood < -1 || neighbourhood > 2) { rsk_set_error("rsk_mu_prefilter_dev: neighbourhood must be -1, 0, 1 or 2"); return RSK_E_INVALID; }
+    if (neighbourhood == -1) neighbourhood = q->n <= 100 ? 1 : 2;      // MAX_QUERY_CHAINS_FOR_QUERY_NEIGHBORHOOD muprefilter.cpp:78-87
+    if ((rc = rsk_build_mudex(const_cast<rsk_db *>(q), neighbourhood)) != RSK_OK) return rc;
     for (uint32_t L : t->len)
         if (L > 65534) { rsk_set_error("rsk_mu_prefilter_dev: target longer than 65534"); return RSK_E_RANGE; }
     uint32_t *d_over = nullptr;

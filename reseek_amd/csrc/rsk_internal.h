@@ -95,6 +95,7 @@ struct rsk_db {
     std::vector<uint32_t> h_len_rank;
     // k-mer prefilter index (built lazily when the chain set is the query side)
     bool mudex_built = false;
+    int mudex_mode = -1;                // 0 exact k-mers, 1 idxq, 2 idxt-equivalent (k_prefilter.hip)
     void *d_pf_table = nullptr;         // uint2 [36^5] (start, count)
     uint32_t *d_pf_postings = nullptr;  // q << 16 | pos
     size_t pf_postings = 0;
@@ -109,5 +110,5 @@ int rsk_launch_gapless_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, con
                              const uint32_t *d_it, size_t npairs, int32_t *d_scores,
                              uint32_t *d_besti, uint32_t *d_bestj);
 int rsk_build_rings(rsk_db *db);
-int rsk_build_mudex(rsk_db *db);
+int rsk_build_mudex(rsk_db *db, int mode);
 int rsk_build_len_perm(rsk_db *db);

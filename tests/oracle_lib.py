@@ -64,6 +64,8 @@ def lib():
         L.rsko_sw_fast.argtypes = [f32p, C.c_int, C.c_int, C.c_float, C.c_float, u32p, u32p, C.c_char_p, u32p, u8p]
         L.rsko_prefilter.restype = C.c_size_t
         L.rsko_prefilter.argtypes = [u8p, u32p, C.c_uint32, u8p, u32p, C.c_uint32, u32p, u32p, u32p, C.c_size_t]
+        L.rsko_prefilter_mode.restype = C.c_size_t
+        L.rsko_prefilter_mode.argtypes = [u8p, u32p, C.c_uint32, u8p, u32p, C.c_uint32, C.c_int, u32p, u32p, u32p, C.c_size_t]
         L.rsko_rsb.restype = C.c_size_t
         L.rsko_rsb.argtypes = [u32p, u32p, u32p, C.c_size_t, C.c_uint32, C.c_uint32, u32p, u32p, u32p]
         _lib = L
@@ -147,16 +149,16 @@ def mu_filter_pairs(seqs, ia, ib, omega_fwd, open_=2, ext=1):
     return f, r, s
 
 
-def prefilter(qseqs, tseqs, cap=None):
-    """Exact-k-mer Mu prefilter (P10/P11): -> (q, t, score) arrays, targets in order."""
+def prefilter(qseqs, tseqs, cap=None, mode=0):
+    """Mu prefilter (P10/P11; mode 0 exact k-mers, 1 idxq, 2 idxt): -> (q, t, score) arrays, targets in order."""
     qmu, qoff = concat_mu(qseqs)
     tmu, toff = concat_mu(tseqs)
     cap = cap or max(1024, len(qseqs) * len(tseqs))
     oq = np.zeros(cap, np.uint32)
     ot = np.zeros(cap, np.uint32)
     os_ = np.zeros(cap, np.uint32)
-    n = lib().rsko_prefilter(_p(qmu, u8p), _p(qoff, u32p), len(qseqs), _p(tmu, u8p), _p(toff, u32p), len(tseqs),
-                             _p(oq, u32p), _p(ot, u32p), _p(os_, u32p), cap)
+    n = lib().rsko_prefilter_mode(_p(qmu, u8p), _p(qoff, u32p), len(qseqs), _p(tmu, u8p), _p(toff, u32p), len(tseqs), mode,
+                                  _p(oq, u32p), _p(ot, u32p), _p(os_, u32p), cap)
     assert n <= cap
     return oq[:n], ot[:n], os_[:n]
 

@@ -24,7 +24,7 @@ def ctx():
     c.close()
 
 
-def run_prefilter(ctx, qseqs, tseqs=None, cap=20_000_000):
+def run_prefilter(ctx, qseqs, tseqs=None, cap=20_000_000, mode=0):
     import torch
     import reseek_amd
     q = reseek_amd.Db.from_mu_seqs(ctx, qseqs)
@@ -33,7 +33,7 @@ def run_prefilter(ctx, qseqs, tseqs=None, cap=20_000_000):
     dt = torch.zeros(cap, dtype=torch.int32, device="cuda")
     ds = torch.zeros(cap, dtype=torch.int32, device="cuda")
     dn = torch.zeros(1, dtype=torch.int32, device="cuda")
-    ctx.mu_prefilter_dev(q, t, dq.data_ptr(), dt.data_ptr(), ds.data_ptr(), cap, dn.data_ptr())
+    ctx.mu_prefilter_dev(q, t, dq.data_ptr(), dt.data_ptr(), ds.data_ptr(), cap, dn.data_ptr(), neighbourhood=mode)
     torch.cuda.synchronize()
     n = int(dn.item())
     assert n <= cap
@@ -106,3 +106,34 @@ def test_many_hits_forces_lds_chunking(ctx):
     q, t, s, _ = run_prefilter(ctx, qs, ts)
     oq, ot, os_ = ol.prefilter(qs, ts)
     assert as_set(q, t, s) == as_set(oq, ot, os_) and len(oq) == 300 * 6
+
+
+def test_neighbourhood_modes_match_muprefilter(ctx):
+    """`-search -fast -db` prefilter (MuPreFilter muprefilter.cpp:70): idxq and idxt neighbourhood modes,
+    80 queries x 1000 targets, against the reference's score list and hand-off TSV."""
+    import reseek_amd
+    labels, seqs = fx.read_mu_fasta("scop40.mu.fa.gz", limit=1000)
+    qs = seqs[:80]
+    for mode, tag in ((1, "h80"), (2, "h80t")):
+        q, t, s, _ = run_prefilter(ctx, qs, seqs, mode=mode)
+        with tempfile.TemporaryDirectory() as td:
+            tmp = os.path.join(td, "tmp.tsv")
+            rq, rt, rs = reseek_amd.capi.rsb_select(q, t, s, len(qs), 1500, tmp_tsv_path=tmp)
+            want = gzip.open(os.path.join(fx.GOLDEN, "prefilter_hood_%s_scores.tsv.gz" % tag)).read().decode()
+            assert scores_text(labels, rq, rt, rs) == want
+            want_tmp = gzip.open(os.path.join(fx.GOLDEN, "prefilter_hood_%s_tmp.tsv.gz" % tag)).read().decode()
+            assert open(tmp).read() == want_tmp
+    # the reference's automatic choice: <= 100 queries -> idxq
+    q2, t2, s2, _ = run_prefilter(ctx, qs, seqs[:200], mode=-1)
+    oq, ot, os_ = ol.prefilter(qs, seqs[:200], mode=1)
+    assert as_set(q2, t2, s2) == as_set(oq, ot, os_)
+
+
+def test_neighbourhood_self_1000(ctx):
+    """1000 x 1000 (> 100 queries -> idxt): device vs the reference's scores."""
+    import reseek_amd
+    labels, seqs = fx.read_mu_fasta("scop40.mu.fa.gz", limit=1000)
+    q, t, s, ms = run_prefilter(ctx, seqs, mode=-1)
+    rq, rt, rs = reseek_amd.capi.rsb_select(q, t, s, len(seqs), 1500)
+    want = gzip.open(os.path.join(fx.GOLDEN, "prefilter_hood_h1000_scores.tsv.gz")).read().decode()
+    assert scores_text(labels, rq, rt, rs) == want

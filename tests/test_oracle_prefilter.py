@@ -39,3 +39,17 @@ def test_scop40_full_checksums():
     assert len(rq) == int(want["lines"])
     assert hashlib.md5(scores_text(labels, labels, rq, rt, rs).encode()).hexdigest() == want["sorted_scores_md5"]
     assert hashlib.md5(fx.prefilter_tmp_tsv(rq, rt).encode()).hexdigest() == want["tmp_tsv_md5"]
+
+
+def test_neighbourhood_modes_match_muprefilter():
+    """k-mer neighbourhoods as `-search -fast -db` runs them (MuPreFilter muprefilter.cpp:70): 80 queries
+    against 1000 targets, query-side ("idxq", exact matches listed twice) and target-side ("idxt")."""
+    labels, seqs = fx.read_mu_fasta("scop40.mu.fa.gz", limit=1000)
+    qs = seqs[:80]
+    for mode, tag in ((1, "h80"), (2, "h80t")):
+        q, t, s = ol.prefilter(qs, seqs, mode=mode)
+        rq, rt, rs = ol.rsb(q, t, s, len(qs), 1500)
+        want = gzip.open(os.path.join(fx.GOLDEN, "prefilter_hood_%s_scores.tsv.gz" % tag)).read().decode()
+        assert scores_text(labels, labels, rq, rt, rs) == want
+        want_tmp = gzip.open(os.path.join(fx.GOLDEN, "prefilter_hood_%s_tmp.tsv.gz" % tag)).read().decode()
+        assert fx.prefilter_tmp_tsv(rq, rt) == want_tmp
