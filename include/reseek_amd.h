@@ -145,6 +145,14 @@ int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *a, const rsk_db *b, const uint32
 /* Pairs, DP cells (sum LA*LB) and trace bytes written to HBM by the last rsk_align_pairs call. */
 int rsk_align_last_work(rsk_ctx *ctx, uint64_t *pairs, uint64_t *cells, uint64_t *tb_bytes);
 
+/* Pair-list form of the Mu filter: DSSAligner::AlignMuParaBags (parasail_mu.cpp:183) as
+ * DSSAligner::AlignBags applies it to each prefilter candidate (chainbag.cpp:68-74).  Host arrays;
+ * pass[p] = 1 iff MuScore >= omega, with MuScore = 0 when fwd' < omega_fwd.  fwd/rev (optional) get
+ * fwd' (777 if saturated) and the raw reverse score (255 if saturated; 0 when not computed). */
+int rsk_mu_filter_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, const uint32_t *iq, const uint32_t *it,
+                        size_t npairs, int gap_open, int gap_ext, float omega, float omega_fwd, uint8_t *pass,
+                        int32_t *fwd, int32_t *rev);
+
 /* ---- P10/P11/P12: Mu k-mer prefilter ----------------------------------------------------------------
  * Batch form of MuDex::FromSeqDB (mudex.cpp:386; index of the QUERY set, built once and cached in q)
  * + PrefilterMu::Search over every target (prefiltermu.cpp:382): spaced 5-of-7 k-mers, self-score
@@ -175,8 +183,13 @@ int rsk_rsb_select(const uint32_t *q, const uint32_t *t, const uint32_t *score, 
  * self-rev score) -- reading .bca and computing the DSS features is row (f) "next".
  * db_rskdb == NULL/"" => self search (all-vs-all, both orientations of every hit are written, as
  * runself.cpp:59-68).  evalue < 0 => the mode's default (10; none for -verysensitive).
+ * mode "fast" WITH a db follows search.cpp:76-111: MuPreFilter (k-mer neighbourhood prefilter over the
+ * Mu letters, top-1500 per query, hand-off TSV) then PostMuFilter (AlignBags of every candidate under
+ * the "sensitive" preset, DM_AlwaysSensitive); the containers must then carry the self-rev scores of
+ * the sensitive preset, as PostMuFilter computes them (postmufilter.cpp:79,171).  The hand-off file
+ * <out_tsv>.prefilter.tmp is kept when RSK_KEEPTMP=1 (-keeptmp).
  * stats8 (optional, 8 values): pairs, m_AlnCount, m_MuFilterInputCount, m_MuFilterDiscardCount,
- * MKF pairs, full alignments, hits, 0. */
+ * MKF pairs, full alignments, hits, 0 (1 for the prefilter path, where "pairs" = prefilter candidates). */
 int rsk_search_rskdb(rsk_ctx *ctx, const char *query_rskdb, const char *db_rskdb, const char *mode,
                      const char *columns, double evalue, int noself, const char *out_tsv, uint64_t *nhits,
                      uint64_t *stats8);

@@ -59,6 +59,8 @@ SIGNATURES["rsk_search_rskdb"] = (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, 
 
 SIGNATURES["rsk_mu_prefilter_dev"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                                 C.c_size_t, C.c_void_p])
+SIGNATURES["rsk_mu_filter_pairs"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, u32p, u32p, C.c_size_t, C.c_int, C.c_int,
+                                               C.c_float, C.c_float, C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(C.c_int32)])
 SIGNATURES["rsk_rsb_select"] = (C.c_int, [u32p, u32p, u32p, C.c_size_t, C.c_uint32, C.c_uint32, u32p, u32p, u32p,
                                           C.POINTER(C.c_size_t), C.c_char_p])
 
@@ -183,6 +185,19 @@ class Ctx:
         return n.value, list(st)
 
     # ---- P10-P12 k-mer prefilter ---------------------------------------------------------------------
+    def mu_filter_pairs(self, q, t, iq, it, omega, omega_fwd, gap_open=2, gap_ext=1):
+        """-> (pass uint8[n], fwd int32[n], rev int32[n]) for host pair lists."""
+        iq = np.ascontiguousarray(iq, np.uint32)
+        it = np.ascontiguousarray(it, np.uint32)
+        n = len(iq)
+        ok = np.zeros(n, np.uint8)
+        fwd = np.zeros(n, np.int32)
+        rev = np.zeros(n, np.int32)
+        _check(lib().rsk_mu_filter_pairs(self.h, q.h, t.h, iq.ctypes.data_as(u32p), it.ctypes.data_as(u32p), n, gap_open, gap_ext,
+                                         omega, omega_fwd, ok.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                         fwd.ctypes.data_as(C.POINTER(C.c_int32)), rev.ctypes.data_as(C.POINTER(C.c_int32))))
+        return ok, fwd, rev
+
     def mu_prefilter_dev(self, q, t, d_q, d_t, d_score, capacity, d_n, neighbourhood=0):
         _check(lib().rsk_mu_prefilter_dev(self.h, q.h, t.h, neighbourhood, C.c_void_p(d_q), C.c_void_p(d_t), C.c_void_p(d_score),
                                           capacity, C.c_void_p(d_n)))

@@ -338,6 +338,8 @@ static bool parse_mode(const char *mode, SearchOptions &o)
 
 void rsk_set_error(const char *fmt, ...);
 
+static bool keep_tmp_env() { const char *e = getenv("RSK_KEEPTMP"); return e && *e && *e != '0'; }    // -keeptmp
+
 extern "C" int rsk_search_rskdb(rsk_ctx *ctx, const char *query_rskdb, const char *db_rskdb, const char *mode, const char *columns,
                                 double evalue, int noself, const char *out_tsv, uint64_t *nhits, uint64_t *stats8)
 {
@@ -358,10 +360,34 @@ extern "C" int rsk_search_rskdb(rsk_ctx *ctx, const char *query_rskdb, const cha
         DBS.Setup();
         for (USERFIELD u : DBS.m_DA.m_UFs)
             if (u == UF_Undefined) { rsk_set_error("rsk_search_rskdb: invalid -columns field"); return RSK_E_INVALID; }
+        const bool have_db = db_rskdb != nullptr && *db_rskdb;
+        if (have_db && o.mode == AM_Fast) {
+            // cmd_search search.cpp:76-111: k-mer prefilter, then the candidates under the "sensitive" preset
+            DBSearcher Src;
+            Src.m_Params = &Params;
+            Src.m_Opts = o;
+            Src.m_Ctx = ctx;
+            Src.LoadDB(db_rskdb);
+            const std::string tmp = std::string(out_tsv) + ".prefilter.tmp";
+            MuPreFilter(Params, DBS, Src, tmp);
+            SearchOptions o2 = o;
+            o2.mode = AM_Sensitive;                  // DM_AlwaysSensitive dssparams.cpp:27-42
+            DSSParams Params2;
+            Params2.SetDSSParams(o2);
+            PostMuFilter(Params2, tmp, DBS, Src, out_tsv);
+            if (!keep_tmp_env()) remove(tmp.c_str());
+            if (nhits) *nhits = DBS.m_HitCount;
+            if (stats8) {
+                stats8[0] = DBS.m_ProcessedPairCount; stats8[1] = DBS.m_ProcessedPairCount - DBS.m_MKFPairCount; stats8[2] = DBS.m_MuFilterInputCount;
+                stats8[3] = DBS.m_MuFilterDiscardCount; stats8[4] = DBS.m_MKFPairCount; stats8[5] = DBS.m_SWCount;
+                stats8[6] = DBS.m_HitCount; stats8[7] = 1;
+            }
+            return RSK_OK;
+        }
         FILE *f = fopen(out_tsv, "w");
         if (!f) { rsk_set_error("rsk_search_rskdb: cannot create %s", out_tsv); return RSK_E_INVALID; }
         DBS.m_fTsv = f;
-        if (db_rskdb == nullptr || !*db_rskdb) DBS.RunSelf();
+        if (!have_db) DBS.RunSelf();
         else {
             DBSearcher Src;
             Src.m_Params = &Params;

@@ -1,0 +1,200 @@
+// postmufilter.cpp -- host mirror of the two stages of `reseek -search Q -db DB -fast`
+// (cmd_search search.cpp:62-111):
+//   MuPreFilter  muprefilter.cpp:70-133   Mu k-mer prefilter of every DB chain against the query index,
+//                                         bounded top-B per query, hand-off TSV (rankedscoresbag.cpp:185)
+//   PostMuFilter postmufilter.cpp:190-290 for each target line of that file: DSSAligner::AlignBags
+//                                         (chainbag.cpp:44) of every listed query against the target,
+//                                         Accept (:106) and ToTsv(up = true).
+// The reference walks one (query, target) candidate at a time; here the candidate list is cut into
+// the same three streams as AlignBags' decision tree and each stream is one GPU batch call:
+//   DoMKF_Bags -> host MKF path;  Omega > 0 -> rsk_mu_filter_pairs;  survivors -> rsk_align_pairs.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstring>
+#include <stdexcept>
+
+#include "reseek_host.h"
+
+namespace reseek_amd {
+
+static void check(int rc, const char *what)
+{
+    if (rc != RSK_OK) throw std::runtime_error(std::string(what) + ": " + rsk_last_error());
+}
+
+void MuPreFilter(const DSSParams &Params, DBSearcher &QDB, DBSearcher &TDB, const std::string &OutputFN)
+{
+    (void) Params;
+    rsk_ctx *ctx = QDB.m_Ctx;
+    if (!ctx) throw std::runtime_error("MuPreFilter: no GPU context");
+    TDB.m_Ctx = ctx;
+    TDB.UploadToGpu();
+    const uint NQ = QDB.GetDBChainCount(), NT = TDB.GetDBChainCount();
+    // Query letters as cmd_search hands them over (search.cpp:91-98): MuSeqSource writes the query chains
+    // as text with 'A' + letter (museqsource.cpp:45-53, pdbchain.cpp:70), SeqDB::ToLetters reads the text
+    // back through g_CharToLetterMu, whose table has L = 10 and K = 11 (alpha.cpp:3291) -- so the QUERY side
+    // of the prefilter sees letters 10 and 11 exchanged, the target side (m_ASCII = false) does not.
+    // Reference behaviour, kept: the hand-off file is compared byte for byte.
+    std::vector<uint32_t> qlen(NQ);
+    size_t qtot = 0;
+    for (uint i = 0; i < NQ; ++i) { qlen[i] = QDB.m_DBChains[i]->GetSeqLength(); qtot += qlen[i]; }
+    std::vector<uint8_t> qmu(qtot);
+    size_t qo = 0;
+    for (uint i = 0; i < NQ; ++i)
+        for (byte l : *QDB.m_DBMuLettersVec[i]) qmu[qo++] = l == 10 ? 11 : (l == 11 ? 10 : l);
+    rsk_db *qdb = nullptr;
+    check(rsk_db_create(ctx, NQ, qlen.data(), qmu.data(), nullptr, nullptr, nullptr, nullptr, nullptr, &qdb), "rsk_db_create");
+    struct db_guard { rsk_db *d; ~db_guard() { rsk_db_destroy(d); } } guard{ qdb };
+    auto hipok = [](hipError_t e, const char *w) { if (e != hipSuccess) throw std::runtime_error(std::string(w) + ": " + hipGetErrorString(e)); };
+    // every (query, target) can appear at most once
+    size_t cap = (size_t) std::min<uint64_t>((uint64_t) NQ * NT, 1ull << 28);
+    uint32_t *d_q = nullptr, *d_t = nullptr, *d_s = nullptr, *d_n = nullptr;
+    std::vector<uint32_t> hq, ht, hs;
+    for (;;) {
+        hipok(hipMalloc((void **) &d_q, std::max<size_t>(cap, 1) * 4), "hipMalloc");
+        hipok(hipMalloc((void **) &d_t, std::max<size_t>(cap, 1) * 4), "hipMalloc");
+        hipok(hipMalloc((void **) &d_s, std::max<size_t>(cap, 1) * 4), "hipMalloc");
+        hipok(hipMalloc((void **) &d_n, 4), "hipMalloc");
+        const int rc = rsk_mu_prefilter_dev(ctx, qdb, TDB.m_Db, QDB.m_Opts.idx_mode, d_q, d_t, d_s, cap, d_n);
+        uint32_t n = 0;
+        if (rc == RSK_OK) hipok(hipMemcpy(&n, d_n, 4, hipMemcpyDeviceToHost), "copy n");
+        if (rc == RSK_OK && n <= cap) {
+            hq.resize(n); ht.resize(n); hs.resize(n);
+            hipok(hipMemcpy(hq.data(), d_q, (size_t) n * 4, hipMemcpyDeviceToHost), "copy");
+            hipok(hipMemcpy(ht.data(), d_t, (size_t) n * 4, hipMemcpyDeviceToHost), "copy");
+            hipok(hipMemcpy(hs.data(), d_s, (size_t) n * 4, hipMemcpyDeviceToHost), "copy");
+        }
+        (void) hipFree(d_q); (void) hipFree(d_t); (void) hipFree(d_s); (void) hipFree(d_n);
+        check(rc, "rsk_mu_prefilter_dev");
+        if (n <= cap) break;
+        cap = n;                               // the count is exact even when the list was truncated
+    }
+    size_t nout = 0;
+    check(rsk_rsb_select(hq.data(), ht.data(), hs.data(), hq.size(), NQ, QDB.m_Opts.rsb_size, nullptr, nullptr, nullptr, &nout,
+                         OutputFN.c_str()),
+          "rsk_rsb_select");
+}
+
+static bool Accept(const DSSAligner &DA, double MaxEvalue, double MaxPvalue, double MinTS)     // postmufilter.cpp:106-115
+{
+    if (DA.m_EvalueA <= MaxEvalue) return true;
+    if (DA.m_PvalueA <= MaxPvalue) return true;
+    if (DA.m_NewTestStatisticA >= MinTS) return true;
+    return false;
+}
+
+void PostMuFilter(const DSSParams &Params, const std::string &MuFilterTsvFN, DBSearcher &Q, DBSearcher &DB, const std::string &HitsFN)
+{
+    const SearchOptions &O = Q.m_Opts;
+    double MaxEvalue = 10, MaxPvalue = -1, MinTS = 9e9;                    // postmufilter.cpp:31-33,196-203
+    if (O.evalue_set) MaxEvalue = O.evalue;
+    else if (O.mode == AM_VerySensitive) MaxEvalue = 9e9;
+    if (O.pvalue_set) MaxPvalue = O.pvalue;
+    if (O.mints_set) MinTS = O.mints;
+
+    FILE *fin = fopen(MuFilterTsvFN.c_str(), "r");
+    if (!fin) throw std::runtime_error("PostMuFilter: cannot open " + MuFilterTsvFN);
+    std::vector<char> buf(1 << 16);
+    std::string line;
+    auto readline = [&]() -> bool {
+        line.clear();
+        for (;;) {
+            if (!fgets(buf.data(), (int) buf.size(), fin)) return !line.empty();
+            line += buf.data();
+            if (!line.empty() && line.back() == '\n') { line.pop_back(); return true; }
+        }
+    };
+    if (!readline()) { fclose(fin); throw std::runtime_error("PostMuFilter: empty hand-off file"); }
+    unsigned LineCount = 0;
+    if (sscanf(line.c_str(), "prefilter\t%u", &LineCount) != 1) { fclose(fin); throw std::runtime_error("PostMuFilter: bad header line"); }
+    if (LineCount == 0) { fclose(fin); fprintf(stderr, "Warning: No hits found by mufilter pass\n"); return; }   // :219-223 (no hits file)
+    const uint NQ = Q.GetDBChainCount(), NT = DB.GetDBChainCount();
+    std::vector<uint32_t> pq, pt;                                          // candidates in file order (A = query, B = target)
+    for (unsigned k = 0; k < LineCount; ++k) {
+        if (!readline()) { fclose(fin); throw std::runtime_error("PostMuFilter: truncated hand-off file"); }
+        const char *s = line.c_str();
+        char *e;
+        const unsigned long T = strtoul(s, &e, 10);
+        const unsigned long K = strtoul(e, &e, 10);
+        if (T >= NT) { fclose(fin); throw std::runtime_error("PostMuFilter: target index out of range"); }
+        for (unsigned long c = 0; c < K; ++c) {
+            if (*e != '\t') { fclose(fin); throw std::runtime_error("PostMuFilter: short target line"); }
+            const unsigned long qi = strtoul(e, &e, 10);
+            if (qi >= NQ) { fclose(fin); throw std::runtime_error("PostMuFilter: query index out of range"); }
+            pq.push_back((uint32_t) qi); pt.push_back((uint32_t) T);
+        }
+    }
+    fclose(fin);
+
+    rsk_ctx *ctx = Q.m_Ctx;
+    if (!ctx) throw std::runtime_error("PostMuFilter: no GPU context");
+    DB.m_Ctx = ctx;
+    Q.UploadToGpu();
+    DB.UploadToGpu();
+    FILE *fTsv = fopen(HitsFN.c_str(), "w");
+    if (!fTsv) throw std::runtime_error("PostMuFilter: cannot create " + HitsFN);
+    DSSAligner &DA = Q.m_DA;
+    DA.SetParams(Params);
+    DA.SetColumns(O.columns);
+    DA.m_Ctx = ctx;
+
+    // DoMKF_Bags chainbag.cpp:6-21
+    std::vector<uint32_t> fq, ft;
+    std::vector<std::pair<uint32_t, uint32_t> > mkf;
+    for (size_t p = 0; p < pq.size(); ++p) {
+        const uint LA = Q.m_DBChains[pq[p]]->GetSeqLength(), LB = DB.m_DBChains[pt[p]]->GetSeqLength();
+        if (LA >= Params.m_MKFL || LB >= Params.m_MKFL) mkf.emplace_back(pq[p], pt[p]);
+        else { fq.push_back(pq[p]); ft.push_back(pt[p]); }
+    }
+    Q.m_MKFPairCount = mkf.size();
+    Q.m_ProcessedPairCount = pq.size();
+    // Mu filter (chainbag.cpp:67-73)
+    std::vector<uint32_t> ia, ib;
+    if (Params.m_Omega > 0 && !fq.empty()) {
+        std::vector<uint8_t> pass(fq.size());
+        check(rsk_mu_filter_pairs(ctx, Q.m_Db, DB.m_Db, fq.data(), ft.data(), fq.size(), Params.m_ParaMuGapOpen, Params.m_ParaMuGapExt,
+                                  Params.m_Omega, Params.m_OmegaFwd, pass.data(), nullptr, nullptr),
+              "rsk_mu_filter_pairs");
+        for (size_t p = 0; p < fq.size(); ++p)
+            if (pass[p]) { ia.push_back(fq[p]); ib.push_back(ft[p]); }
+        Q.m_MuFilterInputCount = fq.size();
+        Q.m_MuFilterDiscardCount = fq.size() - ia.size();
+    } else { ia.swap(fq); ib.swap(ft); }
+    // SetSMx_NoRev + SWFast + CalcEvalue (chainbag.cpp:74-84) in batches
+    const size_t B = std::max<size_t>(1, O.batch_pairs);
+    for (size_t b = 0; b < ia.size(); b += B) {
+        const size_t n = std::min(ia.size(), b + B) - b;
+        std::vector<rsk_aln> out(n);
+        const size_t bytes = rsk_align_paths_bytes(Q.m_Db, DB.m_Db, ia.data() + b, ib.data() + b, n);
+        std::vector<char> paths(bytes + 1);
+        check(rsk_align_pairs(ctx, Q.m_Db, DB.m_Db, ia.data() + b, ib.data() + b, n, Params.m_GapOpen, Params.m_GapExt, Params.m_MinFwdScore,
+                              out.data(), paths.data(), bytes),
+              "rsk_align_pairs");
+        for (size_t p = 0; p < n; ++p) {
+            ++Q.m_SWCount;
+            const uint i = ia[b + p], j = ib[b + p];
+            DA.m_ChainA = Q.m_DBChains[i]; DA.m_ProfileA = Q.m_DBProfiles[i];
+            DA.m_ChainB = DB.m_DBChains[j]; DA.m_ProfileB = DB.m_DBProfiles[j];
+            DA.m_SelfRevScoreA = Q.m_DBSelfRevScores[i]; DA.m_SelfRevScoreB = DB.m_DBSelfRevScores[j];
+            DA.SetFromAln(out[p], paths.data() + out[p].path_off);
+            if (Accept(DA, MaxEvalue, MaxPvalue, MinTS)) { DA.ToTsv(fTsv, true); ++Q.m_HitCount; }
+        }
+    }
+    // long chains: MKF on the host (chainbag.cpp:58-65)
+    uint prev = UINT_MAX;
+    for (auto &pr : mkf) {
+        const uint i = pr.first, j = pr.second;
+        if (i != prev) {
+            DA.SetQuery(*Q.m_DBChains[i], Q.m_DBProfiles[i], Q.m_DBMuLettersVec[i], Q.m_DBMuKmersVec[i], Q.m_DBSelfRevScores[i]);
+            prev = i;
+        }
+        DA.SetTarget(*DB.m_DBChains[j], DB.m_DBProfiles[j], DB.m_DBMuLettersVec[j], DB.m_DBMuKmersVec[j], DB.m_DBSelfRevScores[j]);
+        DA.AlignMKF();
+        if (Accept(DA, MaxEvalue, MaxPvalue, MinTS)) { DA.ToTsv(fTsv, true); ++Q.m_HitCount; }
+    }
+    DA.UnsetQuery();
+    fclose(fTsv);
+}
+
+}   // namespace reseek_amd

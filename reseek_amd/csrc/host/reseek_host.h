@@ -51,6 +51,9 @@ struct SearchOptions {
     float gapext = 0;                                  // applied only when -gapopen is set (dssparams.cpp:96-97, kept)
     bool mkfl_set = false;    uint mkfl = 0;           // -mkfl
     bool selfrev0 = false;                             // -selfrev0
+    bool pvalue_set = false;  double pvalue = -1;      // -pvalue (PostMuFilter Accept, postmufilter.cpp:106-115)
+    int idx_mode = -1;                                 // -idxq (1) / -idxt (2); -1 = by query count (muprefilter.cpp:78-87)
+    uint rsb_size = 1500;                              // -rsb_size (prefiltermuparams.h:15)
     size_t batch_pairs = 1u << 16;                     // pairs per GPU alignment batch (bounds the trace memory)
 };
 
@@ -221,9 +224,18 @@ public:
     virtual void OnSetup() {}
     virtual void OnAln(DSSAligner &DA, bool Up) {}
 
-private:
     void UploadToGpu();
+
+private:
     void AlignPairBatch(const std::vector<uint32_t> &ia, const std::vector<uint32_t> &ib, bool Self);
 };
+
+// `reseek -search Q -db DB -fast` (search.cpp:62-111): k-mer prefilter over the Mu letters, then the
+// candidates of its hand-off file are aligned under the "sensitive" preset.
+//   MuPreFilter  muprefilter.cpp:70   (query index + neighbourhoods, per-target scan, RankedScoresBag, ToTsv)
+//   PostMuFilter postmufilter.cpp:190 (per target line: AlignBags against each listed query, Accept, ToTsv)
+void MuPreFilter(const DSSParams &Params, DBSearcher &QDB, DBSearcher &TDB, const std::string &OutputFN);
+void PostMuFilter(const DSSParams &Params, const std::string &MuFilterTsvFN, DBSearcher &Q, DBSearcher &DB,
+                  const std::string &HitsFN);
 
 }   // namespace reseek_amd

@@ -642,6 +642,91 @@ extern "C" int rsk_mu_filter_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t,
     return RSK_OK;
 }
 
+// Pair-list form of the filter (DSSAligner::AlignMuParaBags parasail_mu.cpp:183 as PostMuFilter calls it per
+// (query, target) candidate, chainbag.cpp:68-74): host arrays in, per-pair verdict out.
+static int musw_run_pairlist(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, const uint32_t *iq, const uint32_t *it,
+                             const std::vector<uint32_t> &sel, int reverse, int gap_open, int gap_ext, std::vector<uint8_t> &raw)
+{
+    // CSR by query; within a query the targets by increasing length (the pairs of a wave then end together)
+    const size_t n = sel.size();
+    raw.assign(n, 0);
+    if (n == 0) return RSK_OK;
+    std::vector<uint32_t> ord(n);
+    for (size_t k = 0; k < n; ++k) ord[k] = (uint32_t) k;
+    std::sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) {
+        const uint32_t px = sel[x], py = sel[y];
+        if (iq[px] != iq[py]) return iq[px] < iq[py];
+        const uint32_t lx = t->len[it[px]], ly = t->len[it[py]];
+        return lx != ly ? lx < ly : px < py;
+    });
+    std::vector<uint32_t> cnt(q->n, 0), rowstart((size_t) q->n + 1, 0), list(n);
+    for (size_t k = 0; k < n; ++k) ++cnt[iq[sel[ord[k]]]];
+    for (uint32_t i = 0; i < q->n; ++i) rowstart[i + 1] = rowstart[i] + cnt[i];
+    for (size_t k = 0; k < n; ++k) list[k] = it[sel[ord[k]]];       // ord is grouped by query already
+    musw_ws ws(ctx);
+    uint32_t *d_cnt = nullptr, *d_rowstart = nullptr, *d_list = nullptr;
+    uint8_t *d_out = nullptr;
+    int rc;
+    if ((rc = ws.alloc(&d_cnt, q->n)) != RSK_OK) return rc;
+    if ((rc = ws.alloc(&d_rowstart, (size_t) q->n + 1)) != RSK_OK) return rc;
+    if ((rc = ws.alloc(&d_list, n)) != RSK_OK) return rc;
+    if ((rc = ws.alloc(&d_out, n)) != RSK_OK) return rc;
+    RSK_HIP(hipMemcpyAsync(d_cnt, cnt.data(), (size_t) q->n * 4, hipMemcpyHostToDevice, ctx->stream));
+    RSK_HIP(hipMemcpyAsync(d_rowstart, rowstart.data(), ((size_t) q->n + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    RSK_HIP(hipMemcpyAsync(d_list, list.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+    musw_args a = {};
+    a.q_mu = q->d_mu; a.q_off = q->d_off; a.q_len = q->d_len;
+    a.t_mu = t->d_mu; a.t_off = t->d_off; a.t_len = t->d_len;
+    a.cnt = d_cnt; a.first = nullptr; a.perm = nullptr; a.tri = 0; a.list = d_list; a.rowstart = d_rowstart;
+    a.reverse = reverse; a.open = gap_open; a.ext = gap_ext;
+    a.out = d_out; a.ldo = 0;
+    if ((rc = run_mu_sw_lists(ctx, q, t, a, item_upper_bound(q, n), ws)) != RSK_OK) return rc;
+    std::vector<uint8_t> sorted_raw(n);
+    RSK_HIP(hipMemcpyAsync(sorted_raw.data(), d_out, n, hipMemcpyDeviceToHost, ctx->stream));
+    RSK_HIP(hipStreamSynchronize(ctx->stream));
+    for (size_t k = 0; k < n; ++k) raw[ord[k]] = sorted_raw[k];
+    return RSK_OK;
+}
+
+extern "C" int rsk_mu_filter_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, const uint32_t *iq, const uint32_t *it, size_t npairs,
+                                   int gap_open, int gap_ext, float omega, float omega_fwd, uint8_t *pass, int32_t *fwd, int32_t *rev)
+{
+    if (!ctx || !q || !t || (npairs && (!iq || !it || !pass))) { rsk_set_error("rsk_mu_filter_pairs: NULL argument"); return RSK_E_INVALID; }
+    if (!q->d_mu || !t->d_mu) { rsk_set_error("rsk_mu_filter_pairs: chain set has no Mu letters"); return RSK_E_INVALID; }
+    if (gap_open < 0 || gap_ext < 0) { rsk_set_error("rsk_mu_filter_pairs: gap costs must be >= 0"); return RSK_E_INVALID; }
+    if (npairs > 0xFFFFFFF0ull) { rsk_set_error("rsk_mu_filter_pairs: too many pairs in one call"); return RSK_E_RANGE; }
+    for (size_t p = 0; p < npairs; ++p)
+        if (iq[p] >= q->n || it[p] >= t->n) { rsk_set_error("rsk_mu_filter_pairs: pair %zu out of range", p); return RSK_E_INVALID; }
+    RSK_HIP(hipSetDevice(ctx->device));
+    int rc = rsk_upload_mu_tables(ctx);
+    if (rc != RSK_OK) return rc;
+    RSK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    std::vector<uint32_t> all(npairs);
+    for (size_t p = 0; p < npairs; ++p) all[p] = (uint32_t) p;
+    std::vector<uint8_t> rawf, rawr;
+    if ((rc = musw_run_pairlist(ctx, q, t, iq, it, all, 0, gap_open, gap_ext, rawf)) != RSK_OK) return rc;
+    std::vector<uint32_t> cand;
+    for (size_t p = 0; p < npairs; ++p) {
+        const float f = rawf[p] == 255 ? 777.0f : (float) rawf[p];          // parasail_mu.cpp:135-139
+        if (!(f < omega_fwd)) cand.push_back((uint32_t) p);                  // :141-146
+    }
+    if ((rc = musw_run_pairlist(ctx, q, t, iq, it, cand, 1, gap_open, gap_ext, rawr)) != RSK_OK) return rc;
+    RSK_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    size_t c = 0;
+    for (size_t p = 0; p < npairs; ++p) {
+        const int f = rawf[p] == 255 ? 777 : rawf[p];
+        int r = 0;
+        float score = 0.0f;                                                  // fwd < OmegaFwd: AlignMuQP_Para returns 0
+        if (c < cand.size() && cand[c] == p) { r = rawr[c]; score = (float) f - (float) r; ++c; }
+        pass[p] = !(score < omega);                                          // chainbag.cpp:71-73
+        if (fwd) fwd[p] = f;
+        if (rev) rev[p] = r;
+    }
+    ctx->mf_pairs = npairs;
+    ctx->mf_candidates = cand.size();
+    return RSK_OK;
+}
+
 extern "C" int rsk_mu_filter_last_work(rsk_ctx *ctx, uint64_t *pairs, uint64_t *candidates)
 {
     if (!ctx) { rsk_set_error("rsk_mu_filter_last_work: ctx is NULL"); return RSK_E_INVALID; }

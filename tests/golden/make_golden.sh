@@ -82,5 +82,19 @@ LC_ALL=C sort $TMP/s1000_b50.tsv | gzip -9n > $G/prefilter_sub1000_b50_scores.ts
 $R -prefilter_mu $T/scop40.mu.fa -db $T/scop40.mu.fa -output $TMP/tfull.tsv -output2 $TMP/sfull.tsv -threads 1 -quiet >/dev/null 2>&1
 echo "lines $(wc -l < $TMP/sfull.tsv) sorted_scores_md5 $(LC_ALL=C sort $TMP/sfull.tsv | md5sum | cut -d' ' -f1) tmp_tsv_md5 $(md5sum < $TMP/tfull.tsv | cut -d' ' -f1)" > $G/prefilter_scop40_full.md5.txt
 cat $G/prefilter_scop40_full.md5.txt
+# 8. `-search -fast -db`: k-mer neighbourhood prefilter (MuPreFilter) + PostMuFilter under the sensitive preset
+mkdir -p $TMP/kt
+TMPDIR=$TMP/kt $R -search $T/q100.bca -db $T/q100.bca -fast -columns $COLS -output $TMP/q100fast.tsv -threads 1 -keeptmp -quiet >/dev/null 2>&1
+sort $TMP/q100fast.tsv | gzip -9n > $G/hits_q100_db_q100_fast.tsv.gz
+gzip -9n < $TMP/kt/rce.*.tmp > $G/prefilter_q100_db_q100_fast_tmp.tsv.gz
+$R -search $T/q100.bca -db $T/q100.bca -fast -output $TMP/q100fast_std.tsv -threads 1 -quiet >/dev/null 2>&1
+sort $TMP/q100fast_std.tsv | gzip -9n > $G/hits_q100_db_q100_fast_std.tsv.gz
+#    neighbourhood prefilter alone on Mu FASTA inputs (ref_harness prefhood = MuPreFilter + RankedScoresBag::ToScoreTsv)
+awk 'BEGIN{n=0} /^>/{n++} n<=80' $T/scop40.mu.fa > $TMP/sub80.mu.fa
+$H prefhood $TMP/sub80.mu.fa $TMP/sub1000.mu.fa $TMP/h80_scores.tsv $TMP/h80_tmp.tsv -- -fast -threads 1
+$H prefhood $TMP/sub80.mu.fa $TMP/sub1000.mu.fa $TMP/h80t_scores.tsv $TMP/h80t_tmp.tsv -- -fast -threads 1 -idxt
+$H prefhood $TMP/sub1000.mu.fa $TMP/sub1000.mu.fa $TMP/h1000_scores.tsv $TMP/h1000_tmp.tsv -- -fast -threads 1
+for n in h80 h80t; do LC_ALL=C sort $TMP/${n}_scores.tsv | gzip -9n > $G/prefilter_hood_${n}_scores.tsv.gz; gzip -9n < $TMP/${n}_tmp.tsv > $G/prefilter_hood_${n}_tmp.tsv.gz; done
+LC_ALL=C sort $TMP/h1000_scores.tsv | gzip -9n > $G/prefilter_hood_h1000_scores.tsv.gz
 rm -rf $TMP
 ls -la $G

@@ -144,3 +144,32 @@ def test_rectangular_and_unsorted_targets(ctx):
     want = {(int(a), int(b)) for a, b, f1, s1 in zip(np.repeat(np.arange(23), 157), np.tile(np.arange(157), 23), ff, ss)
             if f1 >= 10 and s1 >= 3.0}
     assert set(res) == want and len(want) > 5
+
+
+def test_pair_list_filter_matches_oracle(ctx):
+    """rsk_mu_filter_pairs (AlignMuParaBags per prefilter candidate, chainbag.cpp:68-74): arbitrary pair
+    lists with repeats, both presets, vs the per-pair oracle and the reference's q100 filter values."""
+    import reseek_amd
+    chains = fx.read_rskdb("q100_sensitive.rskdb.gz")
+    seqs = [c.mu for c in chains]
+    rng = np.random.default_rng(11)
+    n = 3000
+    iq = rng.integers(0, len(seqs), n).astype(np.uint32)
+    it = rng.integers(0, len(seqs), n).astype(np.uint32)
+    iq[:50] = it[:50]                       # self pairs (saturate)
+    q = reseek_amd.Db.from_mu_seqs(ctx, seqs)
+    for omega, omega_fwd in ((12.0, 20.0), (22.0, 50.0)):
+        ok, fwd, rev = ctx.mu_filter_pairs(q, q, iq, it, omega, omega_fwd)
+        of, orv, osc = ol.mu_filter_pairs(seqs, iq, it, omega_fwd)
+        want_fwd = of                       # the oracle reports 777 for saturated forward scores
+        assert np.array_equal(fwd, want_fwd) and (fwd == 777).sum() >= 50
+        cand = ~(want_fwd.astype(np.float32) < omega_fwd)
+        assert np.array_equal(rev[cand], orv[cand]) and not rev[~cand].any()
+        assert np.array_equal(ok.astype(bool), ~(osc < omega))
+        assert ok.any() and not ok.all()
+    q.close()
+    # empty list
+    q = reseek_amd.Db.from_mu_seqs(ctx, seqs[:3])
+    ok, fwd, rev = ctx.mu_filter_pairs(q, q, np.zeros(0, np.uint32), np.zeros(0, np.uint32), 12.0, 20.0)
+    assert len(ok) == 0
+    q.close()

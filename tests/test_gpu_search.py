@@ -88,3 +88,18 @@ def test_q100_vs_db_q100_sensitive(ctx, tmpdir):
     st = run(ctx, tmpdir, "q100_sensitive.rskdb.gz", "sensitive", COLS, "hits_q100_db_q100_sensitive.tsv.gz",
              db2="q100_sensitive_dbq.rskdb.gz")
     assert st[0] == 10000
+
+
+def test_q100_vs_db_q100_fast_prefilter_path(ctx, tmpdir, monkeypatch):
+    """`reseek -search Q -db DB -fast` (search.cpp:76-111): MuPreFilter (k-mer neighbourhoods, idxq for 100
+    queries) -> hand-off TSV -> PostMuFilter (AlignBags under the sensitive preset).  Both the hand-off
+    file (-keeptmp) and the hit table must equal the reference's."""
+    monkeypatch.setenv("RSK_KEEPTMP", "1")
+    st = run(ctx, tmpdir, "q100_sensitive_dbq.rskdb.gz", "fast", COLS, "hits_q100_db_q100_fast.tsv.gz",
+             db2="q100_sensitive_dbq.rskdb.gz")
+    out = os.path.join(tmpdir, "out_q100_sensitive_dbq.rskdb.gz_fast.tsv")
+    want_tmp = gzip.open(os.path.join(fx.GOLDEN, "prefilter_q100_db_q100_fast_tmp.tsv.gz")).read().decode()
+    assert open(out + ".prefilter.tmp").read() == want_tmp
+    assert st[7] == 1 and st[0] == sum(int(ln.split("\t")[1]) for ln in want_tmp.splitlines()[1:])
+    run(ctx, tmpdir, "q100_sensitive_dbq.rskdb.gz", "fast", None, "hits_q100_db_q100_fast_std.tsv.gz",
+        db2="q100_sensitive_dbq.rskdb.gz")
