@@ -145,6 +145,20 @@ int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *a, const rsk_db *b, const uint32
 /* Pairs, DP cells (sum LA*LB) and trace bytes written to HBM by the last rsk_align_pairs call. */
 int rsk_align_last_work(rsk_ctx *ctx, uint64_t *pairs, uint64_t *cells, uint64_t *tb_bytes);
 
+/* ---- D1: the reference's remaining dead-but-named kernels, pair-list form (host arrays) -------------
+ * rsk_mu_pinop_pairs:         SWFastPinop swfastpinop.cpp:6 (int32 3-state local DP on IntScoreMx_Mu rows;
+ *                             Open/Ext are the reference's negative int8 values, e.g. -2/-1).
+ * rsk_mu_gapless_profb_pairs: SWFastGaplessProfb swgaplessprofb.cpp:6 (float gapless score on ScoreMx_Mu rows
+ *                             minus the same for the reversed query, DSSAligner::AlignMuQP dssaligner.cpp:1064).
+ * rsk_gapless_float_pairs:    SWFastGapless swgapless.cpp:46 on the SetSMx_NoRev matrix of (a[ia], b[ib]);
+ *                             besti/bestj (optional) = first best cell in row-major order, RSK_NO_POS if score 0. */
+int rsk_mu_pinop_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, const uint32_t *iq, const uint32_t *it,
+                       size_t npairs, int open, int ext, int32_t *scores);
+int rsk_mu_gapless_profb_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, const uint32_t *iq,
+                               const uint32_t *it, size_t npairs, float *scores);
+int rsk_gapless_float_pairs(rsk_ctx *ctx, const rsk_db *a, const rsk_db *b, const uint32_t *ia, const uint32_t *ib,
+                            size_t npairs, float *scores, uint32_t *besti, uint32_t *bestj);
+
 /* Pair-list form of the Mu filter: DSSAligner::AlignMuParaBags (parasail_mu.cpp:183) as
  * DSSAligner::AlignBags applies it to each prefilter candidate (chainbag.cpp:68-74).  Host arrays;
  * pass[p] = 1 iff MuScore >= omega, with MuScore = 0 when fwd' < omega_fwd.  fwd/rev (optional) get

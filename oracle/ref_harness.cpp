@@ -571,6 +571,62 @@ static void cmd_benchmu(const string &FaFN, uint64_t NPairs, uint Threads)
 	  Pairs.size(), Cells, Threads, Secs[0], Secs[1], (unsigned long long) Check[0], (unsigned long long) Check[1]);
 	}
 
+// D1 leftovers on real chains: for all ordered pairs (i, j) of the first N chains:
+//   f32 SWFastGaplessProfb(ProfMu(A), B)                     (swgaplessprofb.cpp:6; ProfMu = rows of ScoreMx_Mu, dssaligner.cpp:429)
+//   f32 SWFastGapless(SMx(A,B)); u32 Besti, Bestj           (swgapless.cpp:46 on the 8-feature SetSMx_NoRev matrix)
+// Header "RSKD11\0\0", u32 N.
+float SWFastGaplessProfb(float *DProw_, const float * const *ProfA, uint LA, const byte *B, uint LB);
+float SWFastGapless(XDPMem &Mem, const Mx<float> &SMx, uint LA, uint LB, uint &Besti, uint &Bestj);
+static void cmd_d1pairs(const string &InFN, const string &OutFN, uint MaxChains)
+	{
+	DSSParams Params;
+	Params.SetDSSParams(DM_UseCommandLineOption);
+	vector<ChainData *> CDs;
+	LoadChains(InFN, Params, CDs, MaxChains);
+	const uint N = SIZE(CDs);
+	FILE *f = fopen(OutFN.c_str(), "wb");
+	asserta(f != 0);
+	wbytes(f, "RSKD11\0\0", 8);
+	w32(f, N);
+	DSSParams PNo = Params;
+	PNo.m_OwnScoreMxs = false;
+	PNo.m_Omega = 0;
+	PNo.m_MKFL = 999999;
+	DSSAligner DN;
+	DN.SetParams(PNo);
+	XDPMem Mem;
+	for (uint i = 0; i < N; ++i)
+		{
+		const ChainData &A = *CDs[i];
+		const uint LA = A.Chain->GetSeqLength();
+		vector<const float *> ProfMu(LA);
+		for (uint p = 0; p < LA; ++p)
+			ProfMu[p] = ScoreMx_Mu[A.Mu[p]];
+		for (uint j = 0; j < N; ++j)
+			{
+			const ChainData &B = *CDs[j];
+			const uint LB = B.Chain->GetSeqLength();
+			vector<float> DProw(2*LB + 8);
+			float Pb = SWFastGaplessProfb(DProw.data(), ProfMu.data(), LA, B.Mu.data(), LB);
+			wf32(f, Pb);
+			DN.SetQuery(*A.Chain, &A.Profile, &A.Mu, 0, A.SelfRev);
+			DN.SetTarget(*B.Chain, &B.Profile, &B.Mu, 0, B.SelfRev);
+			DN.Align_NoAccel();          // fills the SetSMx_NoRev matrix for this pair
+			uint Besti, Bestj;
+			Mx<float> SMx;
+			SMx.Alloc(LA, LB, __FILE__, __LINE__);
+			const float * const *SD = DN.GetSMxData();
+			for (uint p = 0; p < LA; ++p)
+				for (uint q = 0; q < LB; ++q)
+					SMx.m_Data[p][q] = SD[p][q];
+			float G = SWFastGapless(Mem, SMx, LA, LB, Besti, Bestj);
+			wf32(f, G); w32(f, Besti); w32(f, Bestj);
+			}
+		}
+	fclose(f);
+	fprintf(stderr, "d1pairs: %u chains -> %s\n", N, OutFN.c_str());
+	}
+
 // The k-mer neighbourhood prefilter as cmd_search runs it (search.cpp:78-100 -> MuPreFilter
 // muprefilter.cpp:70), on Mu FASTA inputs: writes the (query, target, score) list of the
 // RankedScoresBag and the target-major hand-off TSV.  Mode: idxq | idxt | auto (via -idxq/-idxt after --).
@@ -628,6 +684,8 @@ int main(int argc, char **argv)
 		cmd_mukat(A[0], (uint) atoi(A[1].c_str()), (uint) atoi(A[2].c_str()), A[3]);
 	else if (Cmd == "randkat" && A.size() == 3)
 		cmd_randkat(strtoull(A[0].c_str(), 0, 0), (uint) atoi(A[1].c_str()), A[2]);
+	else if (Cmd == "d1pairs" && A.size() == 3)
+		cmd_d1pairs(A[0], A[1], (uint) atoi(A[2].c_str()));
 	else if (Cmd == "prefhood" && A.size() == 4)
 		cmd_prefhood(A[0], A[1], A[2], A[3]);
 	else if (Cmd == "benchmu" && A.size() == 3)

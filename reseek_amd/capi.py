@@ -59,6 +59,11 @@ SIGNATURES["rsk_search_rskdb"] = (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, 
 
 SIGNATURES["rsk_mu_prefilter_dev"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                                 C.c_size_t, C.c_void_p])
+SIGNATURES["rsk_mu_pinop_pairs"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, u32p, u32p, C.c_size_t, C.c_int, C.c_int,
+                                              C.POINTER(C.c_int32)])
+SIGNATURES["rsk_mu_gapless_profb_pairs"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, u32p, u32p, C.c_size_t, C.POINTER(C.c_float)])
+SIGNATURES["rsk_gapless_float_pairs"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, u32p, u32p, C.c_size_t, C.POINTER(C.c_float),
+                                                   u32p, u32p])
 SIGNATURES["rsk_mu_filter_pairs"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, u32p, u32p, C.c_size_t, C.c_int, C.c_int,
                                                C.c_float, C.c_float, C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(C.c_int32)])
 SIGNATURES["rsk_rsb_select"] = (C.c_int, [u32p, u32p, u32p, C.c_size_t, C.c_uint32, C.c_uint32, u32p, u32p, u32p,
@@ -185,6 +190,32 @@ class Ctx:
         return n.value, list(st)
 
     # ---- P10-P12 k-mer prefilter ---------------------------------------------------------------------
+    def mu_pinop_pairs(self, q, t, iq, it, open_=-2, ext=-1):
+        iq = np.ascontiguousarray(iq, np.uint32)
+        it = np.ascontiguousarray(it, np.uint32)
+        out = np.zeros(len(iq), np.int32)
+        _check(lib().rsk_mu_pinop_pairs(self.h, q.h, t.h, iq.ctypes.data_as(u32p), it.ctypes.data_as(u32p), len(iq), open_, ext,
+                                        out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out
+
+    def mu_gapless_profb_pairs(self, q, t, iq, it):
+        iq = np.ascontiguousarray(iq, np.uint32)
+        it = np.ascontiguousarray(it, np.uint32)
+        out = np.zeros(len(iq), np.float32)
+        _check(lib().rsk_mu_gapless_profb_pairs(self.h, q.h, t.h, iq.ctypes.data_as(u32p), it.ctypes.data_as(u32p), len(iq),
+                                                out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def gapless_float_pairs(self, a, b, ia, ib):
+        ia = np.ascontiguousarray(ia, np.uint32)
+        ib = np.ascontiguousarray(ib, np.uint32)
+        sc = np.zeros(len(ia), np.float32)
+        bi = np.zeros(len(ia), np.uint32)
+        bj = np.zeros(len(ia), np.uint32)
+        _check(lib().rsk_gapless_float_pairs(self.h, a.h, b.h, ia.ctypes.data_as(u32p), ib.ctypes.data_as(u32p), len(ia),
+                                             sc.ctypes.data_as(C.POINTER(C.c_float)), bi.ctypes.data_as(u32p), bj.ctypes.data_as(u32p)))
+        return sc, bi, bj
+
     def mu_filter_pairs(self, q, t, iq, it, omega, omega_fwd, gap_open=2, gap_ext=1):
         """-> (pass uint8[n], fwd int32[n], rev int32[n]) for host pair lists."""
         iq = np.ascontiguousarray(iq, np.uint32)

@@ -727,6 +727,155 @@ extern "C" int rsk_mu_filter_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *
     return RSK_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// D1: the reference's dead-but-named Mu kernels, pair-list form (not on the -search path; kept simple)
+// ---------------------------------------------------------------------------------------------
+static __device__ __constant__ float c_mu_f32[36 * 36];        // ScoreMx_Mu (mumx_data.cpp:3)
+
+// SWFastPinop swfastpinop.cpp:6-78: int32 3-state local DP whose D/I states open from the diagonal
+// predecessor (SavedM0), Open/Ext negative.  One thread per pair, row arrays in global scratch.
+__global__ void k_mu_pinop(const uint8_t *q_mu, const uint32_t *q_off, const uint32_t *q_len, const uint8_t *t_mu, const uint32_t *t_off,
+                           const uint32_t *t_len, const uint32_t *iq, const uint32_t *it, uint32_t npairs, int open, int ext,
+                           int *scratch, size_t stride, int32_t *out)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npairs) return;
+    const uint8_t *A = q_mu + q_off[iq[p]], *B = t_mu + t_off[it[p]];
+    const int LA = (int) q_len[iq[p]], LB = (int) t_len[it[p]];
+    int *Mrow = scratch + (size_t) p * stride, *Drow = Mrow + LB;
+    for (int j = 0; j < LB; ++j) { Mrow[j] = 0; Drow[j] = 0; }
+    int best = 0, M0 = 0;
+    for (int i = 0; i < LA; ++i) {
+        const signed char *srow = c_mu_int + 36 * A[i];
+        int I0 = 0;
+        for (int j = 0; j < LB; ++j) {
+            const int saved = M0;
+            int x = M0;
+            if (Drow[j] > x) x = Drow[j];
+            if (I0 > x) x = I0;
+            if (0 >= x) x = 0;
+            M0 = Mrow[j];
+            x += srow[B[j]];
+            if (x > best) best = x;
+            Mrow[j] = x;
+            const int md = saved + open;
+            int d = Drow[j] + ext;
+            if (md >= d) d = md;
+            Drow[j] = d;
+            I0 += ext;
+            if (md >= I0) I0 = md;
+        }
+        M0 = 0;
+    }
+    out[p] = best;
+}
+
+// SWFastGaplessProfb swgaplessprofb.cpp:6-66: fused forward / reversed-A float gapless scores on the
+// rows of ScoreMx_Mu; every diagonal is an independent sequential fp32 chain, so one thread walks one
+// diagonal (same operand order as the reference) and the workgroup reduces the two maxima.
+__global__ __launch_bounds__(256) void k_mu_gapless_profb(const uint8_t *q_mu, const uint32_t *q_off, const uint32_t *q_len,
+                                                          const uint8_t *t_mu, const uint32_t *t_off, const uint32_t *t_len,
+                                                          const uint32_t *iq, const uint32_t *it, float *out)
+{
+    __shared__ int sF, sR;
+    const uint32_t p = blockIdx.x;
+    const uint8_t *A = q_mu + q_off[iq[p]], *B = t_mu + t_off[it[p]];
+    const int LA = (int) q_len[iq[p]], LB = (int) t_len[it[p]];
+    if (threadIdx.x == 0) { sF = 0; sR = 0; }
+    __syncthreads();
+    float bestF = 0.0f, bestR = 0.0f;
+    for (int d = threadIdx.x; d < LA + LB - 1; d += blockDim.x) {
+        int i = LA - 1 - d; if (i < 0) i = 0;
+        int j = d - (LA - 1); if (j < 0) j = 0;
+        float xf = 0.0f, xr = 0.0f;
+        for (; i < LA && j < LB; ++i, ++j) {
+            if (xf < 0.0f) xf = 0.0f;
+            if (xr < 0.0f) xr = 0.0f;
+            const uint32_t b = B[j];
+            xf += c_mu_f32[36 * A[i] + b];
+            xr += c_mu_f32[36 * A[LA - i - 1] + b];
+            if (xf > bestF) bestF = xf;
+            if (xr > bestR) bestR = xr;
+        }
+    }
+    atomicMax(&sF, __builtin_bit_cast(int, bestF));          // non-negative floats order like their bit patterns
+    atomicMax(&sR, __builtin_bit_cast(int, bestR));
+    __syncthreads();
+    if (threadIdx.x == 0) out[p] = __builtin_bit_cast(float, sF) - __builtin_bit_cast(float, sR);
+}
+
+static int d1_stage_pairs(rsk_ctx *ctx, musw_ws &ws, const rsk_db *q, const rsk_db *t, const uint32_t *iq, const uint32_t *it, size_t n,
+                          uint32_t **d_iq, uint32_t **d_it, const char *who)
+{
+    for (size_t p = 0; p < n; ++p)
+        if (iq[p] >= q->n || it[p] >= t->n) { rsk_set_error("%s: pair %zu out of range", who, p); return RSK_E_INVALID; }
+    int rc;
+    if ((rc = ws.alloc(d_iq, n)) != RSK_OK) return rc;
+    if ((rc = ws.alloc(d_it, n)) != RSK_OK) return rc;
+    RSK_HIP(hipMemcpyAsync(*d_iq, iq, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    RSK_HIP(hipMemcpyAsync(*d_it, it, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    return RSK_OK;
+}
+
+extern "C" int rsk_mu_pinop_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, const uint32_t *iq, const uint32_t *it, size_t npairs,
+                                  int open, int ext, int32_t *scores)
+{
+    if (!ctx || !q || !t || (npairs && (!iq || !it || !scores))) { rsk_set_error("rsk_mu_pinop_pairs: NULL argument"); return RSK_E_INVALID; }
+    if (!q->d_mu || !t->d_mu) { rsk_set_error("rsk_mu_pinop_pairs: chain set has no Mu letters"); return RSK_E_INVALID; }
+    if (open > 0 || ext > 0 || open < -128 || ext < -128) { rsk_set_error("rsk_mu_pinop_pairs: Open/Ext are int8 <= 0 (swfastpinop.cpp:9)"); return RSK_E_INVALID; }
+    if (npairs == 0) return RSK_OK;
+    RSK_HIP(hipSetDevice(ctx->device));
+    int rc = rsk_upload_mu_tables(ctx);
+    if (rc != RSK_OK) return rc;
+    musw_ws ws(ctx);
+    uint32_t *d_iq, *d_it;
+    if ((rc = d1_stage_pairs(ctx, ws, q, t, iq, it, npairs, &d_iq, &d_it, "rsk_mu_pinop_pairs")) != RSK_OK) return rc;
+    uint32_t maxLB = 1;
+    for (size_t p = 0; p < npairs; ++p) maxLB = std::max(maxLB, t->len[it[p]]);
+    const size_t stride = 2 * (size_t) maxLB;
+    int *d_scratch;
+    int32_t *d_out;
+    if ((rc = ws.alloc(&d_scratch, stride * npairs)) != RSK_OK) return rc;
+    if ((rc = ws.alloc(&d_out, npairs)) != RSK_OK) return rc;
+    RSK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    hipLaunchKernelGGL(k_mu_pinop, dim3((unsigned) ((npairs + 63) / 64)), dim3(64), 0, ctx->stream, q->d_mu, q->d_off, q->d_len, t->d_mu,
+                       t->d_off, t->d_len, d_iq, d_it, (uint32_t) npairs, open, ext, d_scratch, stride, d_out);
+    RSK_HIP(hipGetLastError());
+    RSK_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    RSK_HIP(hipMemcpyAsync(scores, d_out, npairs * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RSK_HIP(hipStreamSynchronize(ctx->stream));
+    return RSK_OK;
+}
+
+extern "C" int rsk_mu_gapless_profb_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, const uint32_t *iq, const uint32_t *it,
+                                          size_t npairs, float *scores)
+{
+    if (!ctx || !q || !t || (npairs && (!iq || !it || !scores))) { rsk_set_error("rsk_mu_gapless_profb_pairs: NULL argument"); return RSK_E_INVALID; }
+    if (!q->d_mu || !t->d_mu) { rsk_set_error("rsk_mu_gapless_profb_pairs: chain set has no Mu letters"); return RSK_E_INVALID; }
+    if (npairs == 0) return RSK_OK;
+    if (npairs > 0x7FFFFFFFull) { rsk_set_error("rsk_mu_gapless_profb_pairs: too many pairs"); return RSK_E_RANGE; }
+    RSK_HIP(hipSetDevice(ctx->device));
+    static bool up[64] = { false };
+    if (!(ctx->device < 64 && up[ctx->device])) {
+        RSK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_mu_f32), rsk_mu_f32, sizeof(rsk_mu_f32)));
+        if (ctx->device < 64) up[ctx->device] = true;
+    }
+    musw_ws ws(ctx);
+    uint32_t *d_iq, *d_it;
+    int rc;
+    if ((rc = d1_stage_pairs(ctx, ws, q, t, iq, it, npairs, &d_iq, &d_it, "rsk_mu_gapless_profb_pairs")) != RSK_OK) return rc;
+    float *d_out;
+    if ((rc = ws.alloc(&d_out, npairs)) != RSK_OK) return rc;
+    RSK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    hipLaunchKernelGGL(k_mu_gapless_profb, dim3((unsigned) npairs), dim3(256), 0, ctx->stream, q->d_mu, q->d_off, q->d_len, t->d_mu, t->d_off,
+                       t->d_len, d_iq, d_it, d_out);
+    RSK_HIP(hipGetLastError());
+    RSK_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    RSK_HIP(hipMemcpyAsync(scores, d_out, npairs * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RSK_HIP(hipStreamSynchronize(ctx->stream));
+    return RSK_OK;
+}
+
 extern "C" int rsk_mu_filter_last_work(rsk_ctx *ctx, uint64_t *pairs, uint64_t *candidates)
 {
     if (!ctx) { rsk_set_error("rsk_mu_filter_last_work: ctx is NULL"); return RSK_E_INVALID; }

@@ -962,6 +962,101 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
     return RSK_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// D1: SWFastGapless swgapless.cpp:46-97 on the SetSMx_NoRev matrix (dead code in the reference; pair-list
+// form).  One workgroup per pair, one thread per diagonal: S(i,j) is summed in feature order from the
+// tables, H = max(H, 0) + S runs along the diagonal in the reference's operand order; the best cell is
+// the first maximum in row-major order (strict > per diagonal, then value desc / i asc / j asc).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gapless_float(swf_args a, float *score, uint32_t *besti, uint32_t *bestj)
+{
+    __shared__ float sb[256];
+    __shared__ uint32_t si[256], sj[256];
+    const uint32_t p = blockIdx.x;
+    const uint32_t A = a.ia[p], B = a.ib[p];
+    const int LA = (int) a.a_len[A], LB = (int) a.b_len[B];
+    const uint8_t *pa = a.a_prof + a.a_off[A], *pb = a.b_prof + a.b_off[B];
+    const int toff[8] = { 0, 400, 656, 912, 1168, 1424, 1680, 1936 };
+    const int asz[8] = { 20, 16, 16, 16, 16, 16, 16, 16 };
+    float best = 0.0f;
+    uint32_t bi = 0xFFFFFFFFu, bj = 0xFFFFFFFFu;
+    for (int d = threadIdx.x; d < LA + LB - 1; d += blockDim.x) {
+        int i = LA - 1 - d; if (i < 0) i = 0;
+        int j = d - (LA - 1); if (j < 0) j = 0;
+        float x = 0.0f;
+        for (; i < LA && j < LB; ++i, ++j) {
+            float S = c_swf_tables.t[toff[0] + pa[i] * asz[0] + pb[j]];
+#pragma unroll
+            for (int f = 1; f < 8; ++f) S += c_swf_tables.t[toff[f] + pa[(size_t) f * a.a_npad + i] * asz[f] + pb[(size_t) f * a.b_npad + j]];
+            if (x < 0.0f) x = 0.0f;
+            x += S;
+            if (x > best || (x == best && x > 0.0f && ((uint32_t) i < bi || ((uint32_t) i == bi && (uint32_t) j < bj)))) {
+                best = x; bi = (uint32_t) i; bj = (uint32_t) j;
+            }
+        }
+    }
+    sb[threadIdx.x] = best; si[threadIdx.x] = bi; sj[threadIdx.x] = bj;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if ((int) threadIdx.x < s) {
+            const float ob = sb[threadIdx.x + s];
+            const uint32_t oi = si[threadIdx.x + s], oj = sj[threadIdx.x + s];
+            const float mb = sb[threadIdx.x];
+            const uint32_t mi = si[threadIdx.x], mj = sj[threadIdx.x];
+            if (ob > mb || (ob == mb && ob > 0.0f && (oi < mi || (oi == mi && oj < mj)))) { sb[threadIdx.x] = ob; si[threadIdx.x] = oi; sj[threadIdx.x] = oj; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { score[p] = sb[0]; besti[p] = si[0]; bestj[p] = sj[0]; }
+}
+
+extern "C" int rsk_gapless_float_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *dbb, const uint32_t *ia, const uint32_t *ib,
+                                       size_t npairs, float *scores, uint32_t *besti, uint32_t *bestj)
+{
+    if (!ctx || !dba || !dbb || (npairs && (!ia || !ib || !scores))) { rsk_set_error("rsk_gapless_float_pairs: NULL argument"); return RSK_E_INVALID; }
+    if (!dba->d_prof || !dbb->d_prof) { rsk_set_error("rsk_gapless_float_pairs: chain set has no profiles"); return RSK_E_INVALID; }
+    if (npairs == 0) return RSK_OK;
+    if (npairs > 0x7FFFFFFFull) { rsk_set_error("rsk_gapless_float_pairs: too many pairs"); return RSK_E_RANGE; }
+    for (size_t p = 0; p < npairs; ++p)
+        if (ia[p] >= dba->n || ib[p] >= dbb->n) { rsk_set_error("rsk_gapless_float_pairs: pair %zu out of range", p); return RSK_E_INVALID; }
+    RSK_HIP(hipSetDevice(ctx->device));
+    int rc = swf_upload_tables(ctx);
+    if (rc != RSK_OK) return rc;
+    struct ws_t {
+        rsk_ctx *ctx;
+        std::vector<void *> all;
+        ~ws_t() { for (void *p : all) rsk_pool_free(ctx, p); }
+    } ws{ ctx, {} };
+    auto dalloc = [&](void **p, size_t bytes) -> int {
+        int r = rsk_pool_alloc(ctx, p, std::max<size_t>(bytes, 16));
+        if (r != RSK_OK) return r;
+        ws.all.push_back(*p);
+        return RSK_OK;
+    };
+    uint32_t *d_ia, *d_ib, *d_bi, *d_bj;
+    float *d_sc;
+    if ((rc = dalloc((void **) &d_ia, npairs * 4)) != RSK_OK) return rc;
+    if ((rc = dalloc((void **) &d_ib, npairs * 4)) != RSK_OK) return rc;
+    if ((rc = dalloc((void **) &d_bi, npairs * 4)) != RSK_OK) return rc;
+    if ((rc = dalloc((void **) &d_bj, npairs * 4)) != RSK_OK) return rc;
+    if ((rc = dalloc((void **) &d_sc, npairs * 4)) != RSK_OK) return rc;
+    RSK_HIP(hipMemcpyAsync(d_ia, ia, npairs * 4, hipMemcpyHostToDevice, ctx->stream));
+    RSK_HIP(hipMemcpyAsync(d_ib, ib, npairs * 4, hipMemcpyHostToDevice, ctx->stream));
+    swf_args a = {};
+    a.a_prof = dba->d_prof; a.a_off = dba->d_off; a.a_len = dba->d_len; a.a_npad = dba->npad;
+    a.b_prof = dbb->d_prof; a.b_off = dbb->d_off; a.b_len = dbb->d_len; a.b_npad = dbb->npad;
+    a.ia = d_ia; a.ib = d_ib;
+    RSK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    hipLaunchKernelGGL(k_gapless_float, dim3((unsigned) npairs), dim3(256), 0, ctx->stream, a, d_sc, d_bi, d_bj);
+    RSK_HIP(hipGetLastError());
+    RSK_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    RSK_HIP(hipMemcpyAsync(scores, d_sc, npairs * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (besti) RSK_HIP(hipMemcpyAsync(besti, d_bi, npairs * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (bestj) RSK_HIP(hipMemcpyAsync(bestj, d_bj, npairs * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RSK_HIP(hipStreamSynchronize(ctx->stream));
+    return RSK_OK;
+}
+
 extern "C" int rsk_align_last_work(rsk_ctx *ctx, uint64_t *pairs, uint64_t *cells, uint64_t *tb_bytes)
 {
     if (!ctx) { rsk_set_error("rsk_align_last_work: ctx is NULL"); return RSK_E_INVALID; }

@@ -125,6 +125,16 @@ def read_randkat(name):
     return out
 
 
+def read_d1pairs(name):
+    """-> (n, float32 [n, n] profb, float32 [n, n] gapless score, uint32 [n, n, 2] best i/j); rows = A, columns = B."""
+    with _open(name) as f:
+        buf = f.read()
+    assert buf[:8] == b"RSKD11\0\0"
+    (n,) = struct.unpack_from("<I", buf, 8)
+    rec = np.frombuffer(buf, np.dtype([("pb", "<f4"), ("g", "<f4"), ("bi", "<u4"), ("bj", "<u4")]), n * n, 12).reshape(n, n)
+    return n, rec["pb"].copy(), rec["g"].copy(), np.stack([rec["bi"], rec["bj"]], axis=-1)
+
+
 def read_tsv(name):
     with _open(name) as f:
         txt = f.read().decode()

@@ -62,6 +62,10 @@ def lib():
         L.rsko_set_smx.argtypes = [u8p, C.c_int, u8p, C.c_int, f32p]
         L.rsko_sw_fast.restype = C.c_float
         L.rsko_sw_fast.argtypes = [f32p, C.c_int, C.c_int, C.c_float, C.c_float, u32p, u32p, C.c_char_p, u32p, u8p]
+        L.rsko_gapless_profb.restype = C.c_float
+        L.rsko_gapless_profb.argtypes = [u8p, C.c_int, u8p, C.c_int]
+        L.rsko_gapless_float_pair.restype = C.c_float
+        L.rsko_gapless_float_pair.argtypes = [u8p, C.c_int, u8p, C.c_int, u32p, u32p]
         L.rsko_prefilter.restype = C.c_size_t
         L.rsko_prefilter.argtypes = [u8p, u32p, C.c_uint32, u8p, u32p, C.c_uint32, u32p, u32p, u32p, C.c_size_t]
         L.rsko_prefilter_mode.restype = C.c_size_t
@@ -96,6 +100,18 @@ def mu_filter(A, B, omega_fwd, open_=2, ext=1):
     f, r = C.c_int32(), C.c_int32()
     s = lib().rsko_mu_filter(_p(A, u8p), len(A), _p(B, u8p), len(B), open_, ext, omega_fwd, C.byref(f), C.byref(r))
     return s, f.value, r.value
+
+
+def gapless_profb(A, B):
+    return lib().rsko_gapless_profb(_p(A, u8p), len(A), _p(B, u8p), len(B))
+
+
+def gapless_float_pair(profA, profB):
+    pa = np.ascontiguousarray(profA)
+    pb = np.ascontiguousarray(profB)
+    bi, bj = C.c_uint32(), C.c_uint32()
+    s = lib().rsko_gapless_float_pair(_p(pa, u8p), pa.shape[1], _p(pb, u8p), pb.shape[1], C.byref(bi), C.byref(bj))
+    return s, bi.value, bj.value
 
 
 def align_pair(profA, profB):
