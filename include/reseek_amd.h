@@ -189,12 +189,25 @@ int rsk_rsb_select(const uint32_t *q, const uint32_t *t, const uint32_t *score, 
                    uint32_t rsb_size, uint32_t *out_q, uint32_t *out_t, uint32_t *out_score, size_t *nout,
                    const char *tmp_tsv_path);
 
+/* ---- (f) rows 1-2: per-chain featurisation and the .bca container (host code, no GPU needed) --------
+ * rsk_dss_featurize: DSS::GetProfile (dss.cpp:716: AA, NENDist, Conf, NENConf, RENDist, DstNxtHlx, StrandDens,
+ *   NormDens -> prof[8][L] feature-major) and DSS::GetMuLetters (dss.cpp:700 -> mu[L]) of one chain given its
+ *   amino-acid characters and CA coordinates.  prof or mu may be NULL.
+ * rsk_bca_info / rsk_bca_read_chain: BCAData::Open / ReadChain (bcadata.cpp:60,191): coordinates are the
+ *   quantised floats IC/10.0f - 1000 (pdbchain.h:90).  *L receives the chain length (also on RSK_E_RANGE). */
+int rsk_dss_featurize(const char *seq, const float *x, const float *y, const float *z, uint32_t L, uint8_t *prof,
+                      uint8_t *mu);
+int rsk_bca_info(const char *path, uint64_t *nchains, uint64_t *nresidues, uint32_t *max_len, uint32_t *max_label);
+int rsk_bca_read_chain(const char *path, uint64_t idx, char *label, size_t label_cap, char *seq, float *x, float *y,
+                       float *z, uint32_t cap, uint32_t *L);
+
 /* ---- P1/P2/P13: the search drivers ---------------------------------------------------------------
  * `reseek -search Q [-db DB] -fast|-sensitive|-verysensitive -output F [-columns C] [-evalue E] [-noself]`
  * (cmd_search search.cpp:62 -> SelfSearch :20 / Search_NoMuFilter :39), driven by the C++ mirror
  * classes in reseek_amd/csrc/host/ (DBSearcher::LoadDB/Setup/RunSelf/RunQuery/BaseOnAln, DSSAligner).
- * Chain sets are read from ".rskdb" containers (per-chain DSS profile, Mu letters, CA coordinates,
- * self-rev score) -- reading .bca and computing the DSS features is row (f) "next".
+ * Chain sets are read from .bca files (BCAData + DSS featurisation on the host cores + self-rev scores
+ * in one GPU batch, P8) or from ".rskdb" containers (precomputed per-chain DSS profile, Mu letters, CA
+ * coordinates, self-rev score), chosen by the file extension.
  * db_rskdb == NULL/"" => self search (all-vs-all, both orientations of every hit are written, as
  * runself.cpp:59-68).  evalue < 0 => the mode's default (10; none for -verysensitive).
  * mode "fast" WITH a db follows search.cpp:76-111: MuPreFilter (k-mer neighbourhood prefilter over the

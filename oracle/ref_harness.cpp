@@ -141,6 +141,7 @@ static void cmd_tables(const string &OutFN)
 	fprintf(f, "//   rsk_mu_int        = IntScoreMx_Mu == parasail_mu_ (mumx_data.cpp:42, parasail_mu.cpp:23-60)\n");
 	fprintf(f, "//   rsk_mu_s8         = Mu_S_ij_i8 (mumx_data.cpp:81)\n");
 	fprintf(f, "//   rsk_mu_f32        = ScoreMx_Mu (mumx_data.cpp:3)\n");
+	fprintf(f, "//   rsk_aa_letter     = g_CharToLetterAmino (alpha.cpp:271);  rsk_bins_* = thresholds of DSS::ValueToInt_* (valuetoint.cpp)\n");
 	fprintf(f, "// Floats are written as exact hex-float literals.\n");
 	const uint FC = Params.GetFeatureCount();
 	fprintf(f, "#define RSK_NFEATURES %u\n", FC);
@@ -209,6 +210,46 @@ static void cmd_tables(const string &OutFN)
 		fprintf(f, "\n");
 		}
 	fprintf(f, "};\n");
+	// amino-acid character -> letter (alpha.cpp:271 g_CharToLetterAmino; 255 = not a letter)
+	fprintf(f, "static const unsigned char rsk_aa_letter[256] = {\n");
+	for (uint a = 0; a < 256; ++a)
+		fprintf(f, "%u,%s", (unsigned) g_CharToLetterAmino[a], a%32 == 31 ? "\n" : "");
+	fprintf(f, "};\n");
+	// bin thresholds of the float features of the profile (valuetoint.cpp; probed through
+	// DSS::ValueToInt_*: t_k = smallest double with ValueToInt(t_k) == k+1, found by bisection)
+	{
+	DSS D;
+	const char *Names[5] = { "NENDist", "RENDist", "DstNxtHlx", "StrandDens", "NormDens" };
+	for (int w = 0; w < 5; ++w)
+		{
+		fprintf(f, "static const double rsk_bins_%s[15] = {", Names[w]);
+		for (uint k = 0; k < 15; ++k)
+			{
+			auto V2I = [&](double v) -> uint
+				{
+				switch (w)
+					{
+				case 0: return D.ValueToInt_NENDist(v);
+				case 1: return D.ValueToInt_RENDist(v);
+				case 2: return D.ValueToInt_DstNxtHlx(v);
+				case 3: return D.ValueToInt_StrandDens(v);
+				default: return D.ValueToInt_NormDens(v);
+					}
+				};
+			double lo = 0, hi = 1000;      // V2I(lo) <= k < V2I(hi)
+			asserta(V2I(lo) <= k && V2I(hi) > k);
+			for (int it = 0; it < 200; ++it)
+				{
+				double mid = lo + (hi - lo)/2;
+				if (mid == lo || mid == hi)
+					break;
+				if (V2I(mid) > k) hi = mid; else lo = mid;
+				}
+			fprintf(f, "%s%a", k ? ", " : "", hi);
+			}
+		fprintf(f, "};\n");
+		}
+	}
 	fclose(f);
 	}
 

@@ -59,6 +59,9 @@ SIGNATURES["rsk_search_rskdb"] = (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, 
 
 SIGNATURES["rsk_mu_prefilter_dev"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                                 C.c_size_t, C.c_void_p])
+SIGNATURES["rsk_dss_featurize"] = (C.c_int, [C.c_char_p, f32p, f32p, f32p, C.c_uint32, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8)])
+SIGNATURES["rsk_bca_info"] = (C.c_int, [C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), u32p, u32p])
+SIGNATURES["rsk_bca_read_chain"] = (C.c_int, [C.c_char_p, C.c_uint64, C.c_char_p, C.c_size_t, C.c_char_p, f32p, f32p, f32p, C.c_uint32, u32p])
 SIGNATURES["rsk_mu_pinop_pairs"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, u32p, u32p, C.c_size_t, C.c_int, C.c_int,
                                               C.POINTER(C.c_int32)])
 SIGNATURES["rsk_mu_gapless_profb_pairs"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, u32p, u32p, C.c_size_t, C.POINTER(C.c_float)])
@@ -296,3 +299,36 @@ def rsb_select(q, t, score, nqueries, rsb_size=1500, tmp_tsv_path=None):
                                 _p(os_, u32p), C.byref(nout), tmp_tsv_path.encode() if tmp_tsv_path else None))
     m = nout.value
     return oq[:m], ot[:m], os_[:m]
+
+
+def dss_featurize(seq, x, y, z):
+    """DSS::GetProfile + GetMuLetters of one chain -> (prof uint8 [8, L], mu uint8 [L]).  Host code."""
+    L = len(seq)
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.ascontiguousarray(y, np.float32)
+    z = np.ascontiguousarray(z, np.float32)
+    prof = np.zeros((8, L), np.uint8)
+    mu = np.zeros(L, np.uint8)
+    s = seq.encode() if isinstance(seq, str) else bytes(seq)
+    _check(lib().rsk_dss_featurize(s, _p(x, f32p), _p(y, f32p), _p(z, f32p), L, _p(prof, u8p), _p(mu, u8p)))
+    return prof, mu
+
+
+def bca_info(path):
+    n, r = C.c_uint64(), C.c_uint64()
+    ml, mlab = C.c_uint32(), C.c_uint32()
+    _check(lib().rsk_bca_info(path.encode(), C.byref(n), C.byref(r), C.byref(ml), C.byref(mlab)))
+    return n.value, r.value, ml.value, mlab.value
+
+
+def bca_read_chain(path, idx, cap=70000):
+    """-> (label, seq, x, y, z) of chain idx of a .bca file."""
+    lab = C.create_string_buffer(1024)
+    seq = C.create_string_buffer(cap + 1)
+    x = np.zeros(cap, np.float32)
+    y = np.zeros(cap, np.float32)
+    z = np.zeros(cap, np.float32)
+    L = C.c_uint32()
+    _check(lib().rsk_bca_read_chain(path.encode(), idx, lab, 1024, seq, _p(x, f32p), _p(y, f32p), _p(z, f32p), cap, C.byref(L)))
+    n = L.value
+    return lab.value.decode(), seq.raw[:n].split(b"\0")[0].decode(), x[:n].copy(), y[:n].copy(), z[:n].copy()

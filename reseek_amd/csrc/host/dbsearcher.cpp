@@ -10,8 +10,10 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <stdexcept>
+#include <thread>
 
 #include "reseek_host.h"
 
@@ -47,8 +49,145 @@ static void GetMuKmers(const std::vector<byte> &Mu, std::vector<uint> &Kmers)
     for (size_t i = 0; i + 3 <= L; ++i) Kmers.push_back(((uint) Mu[i] * 36 + Mu[i + 1]) * 36 + Mu[i + 2]);
 }
 
+static bool EndsWith(const std::string &s, const std::string &suf)
+{
+    return s.size() >= suf.size() && s.compare(s.size() - suf.size(), suf.size(), suf) == 0;
+}
+
+// ProfileLoader::Load profileloader.cpp:72 for a .bca file: read, featurise (host threads), self-rev (GPU batch)
+void DBSearcher::LoadBCA(const std::string &FN)
+{
+    BCAData B;
+    B.Open(FN);
+    const uint64_t n = B.GetChainCount();
+    for (uint64_t k = 0; k < n; ++k) {
+        PDBChain *C = new PDBChain;
+        B.ReadChain(k, *C);
+        if (C->GetSeqLength() < 1) { delete C; continue; }              // m_MinChainLength = 1 (profileloader.cpp:82)
+        AddChain(C, new std::vector<std::vector<byte> >, new std::vector<byte>);
+        m_DBMuKmersVec.push_back(new std::vector<uint>);
+    }
+    const uint N = GetDBChainCount();
+    const unsigned T = std::max(1u, std::min<unsigned>(std::thread::hardware_concurrency(), 64u));
+    std::atomic<uint> next{0};
+    auto body = [&]() {
+        DSS D;
+        D.SetParams(*m_Params);
+        for (;;) {
+            const uint i = next.fetch_add(1);
+            if (i >= N) return;
+            D.Init(*m_DBChains[i]);
+            D.GetProfile(*m_DBProfiles[i]);
+            D.GetMuLetters(*m_DBMuLettersVec[i]);
+            DSS::GetMuKmers(*m_DBMuLettersVec[i], *m_DBMuKmersVec[i], m_Params->m_MKFPatternStr);
+        }
+    };
+    std::vector<std::thread> ts;
+    for (unsigned t = 0; t < T; ++t) ts.emplace_back(body);
+    for (auto &t : ts) t.join();
+    ComputeSelfRevScores();
+}
+
+// GetSelfRevScore alignpair.cpp:7-24 for every chain: AlignQueryTarget of the chain against its reversed copy
+// (profile of the reversed chain; the Mu letters / k-mers passed for BOTH sides are the un-reversed ones -- the
+// reference's behaviour), m_AlnFwdScore is the result.  Chains that take the MKF path run on the host.
+void DBSearcher::ComputeSelfRevScores()
+{
+    const uint N = GetDBChainCount();
+    m_DBSelfRevScores.assign(N, 0.0f);
+    if (m_Opts.selfrev0 || N == 0) return;
+    if (!m_Ctx) throw std::runtime_error("DBSearcher: self-rev scores need a GPU context");
+    DSSParams DAP = *m_Params;
+    bool HaveMu = true;
+    if (!m_SelfRevQueryFlavour) {
+        DAP.m_UsePara = false;
+        DAP.m_Omega = 0;
+        HaveMu = m_Params->m_Omega > 0;                                 // LoadDB dbsearcher.cpp:249-251
+    }
+    // reversed chains and their profiles
+    std::vector<PDBChain> Rev(N);
+    std::vector<std::vector<std::vector<byte> > > RevProf(N);
+    {
+        const unsigned T = std::max(1u, std::min<unsigned>(std::thread::hardware_concurrency(), 64u));
+        std::atomic<uint> next{0};
+        auto body = [&]() {
+            DSS D;
+            D.SetParams(*m_Params);
+            for (;;) {
+                const uint i = next.fetch_add(1);
+                if (i >= N) return;
+                m_DBChains[i]->GetReverse(Rev[i]);
+                D.Init(Rev[i]);
+                D.GetProfile(RevProf[i]);
+            }
+        };
+        std::vector<std::thread> ts;
+        for (unsigned t = 0; t < T; ++t) ts.emplace_back(body);
+        for (auto &t : ts) t.join();
+    }
+    std::vector<uint32_t> gpu, mkf;
+    for (uint i = 0; i < N; ++i) {
+        const uint L = m_DBChains[i]->GetSeqLength();
+        const bool DoMKF = HaveMu && !m_DBMuKmersVec[i]->empty() && L >= DAP.m_MKFL;      // DoMKF dssaligner.cpp:715
+        (DoMKF ? mkf : gpu).push_back(i);
+    }
+    if (!gpu.empty()) {
+        std::vector<uint32_t> len(N);
+        size_t tot = 0;
+        for (uint i = 0; i < N; ++i) { len[i] = m_DBChains[i]->GetSeqLength(); tot += len[i]; }
+        std::vector<uint8_t> mu(tot), pf(tot * RSK_NFEAT), pr(tot * RSK_NFEAT);
+        size_t o = 0;
+        for (uint i = 0; i < N; ++i) {
+            const uint L = len[i];
+            memcpy(&mu[o], m_DBMuLettersVec[i]->data(), L);
+            for (int f = 0; f < RSK_NFEAT; ++f) {
+                memcpy(&pf[o * RSK_NFEAT + (size_t) f * L], (*m_DBProfiles[i])[f].data(), L);
+                memcpy(&pr[o * RSK_NFEAT + (size_t) f * L], RevProf[i][f].data(), L);
+            }
+            o += L;
+        }
+        rsk_db *fdb = nullptr, *rdb = nullptr;
+        check(rsk_db_create(m_Ctx, N, len.data(), mu.data(), pf.data(), nullptr, nullptr, nullptr, nullptr, &fdb), "rsk_db_create");
+        struct guard { rsk_db *d; ~guard() { if (d) rsk_db_destroy(d); } } g1{ fdb }, g2{ nullptr };
+        check(rsk_db_create(m_Ctx, N, len.data(), mu.data(), pr.data(), nullptr, nullptr, nullptr, nullptr, &rdb), "rsk_db_create");
+        g2.d = rdb;
+        std::vector<uint32_t> idx = gpu;
+        if (DAP.m_Omega > 0) {                                           // MuFilter dssaligner.cpp:817-826 (self vs self letters)
+            std::vector<uint8_t> pass(idx.size());
+            check(rsk_mu_filter_pairs(m_Ctx, fdb, fdb, idx.data(), idx.data(), idx.size(), DAP.m_ParaMuGapOpen, DAP.m_ParaMuGapExt, DAP.m_Omega,
+                                      DAP.m_OmegaFwd, pass.data(), nullptr, nullptr),
+                  "rsk_mu_filter_pairs");
+            std::vector<uint32_t> keep;
+            for (size_t k = 0; k < idx.size(); ++k)
+                if (pass[k]) keep.push_back(idx[k]);
+            idx.swap(keep);
+        }
+        const size_t B = std::max<size_t>(1, m_Opts.batch_pairs);
+        for (size_t b = 0; b < idx.size(); b += B) {
+            const size_t m = std::min(idx.size(), b + B) - b;
+            std::vector<rsk_aln> out(m);
+            check(rsk_align_pairs(m_Ctx, fdb, rdb, idx.data() + b, idx.data() + b, m, DAP.m_GapOpen, DAP.m_GapExt, DAP.m_MinFwdScore, out.data(),
+                                  nullptr, 0),
+                  "rsk_align_pairs");
+            for (size_t k = 0; k < m; ++k) m_DBSelfRevScores[idx[b + k]] = out[k].score;
+        }
+    }
+    if (!mkf.empty()) {
+        DSSAligner DA;
+        DA.SetParams(DAP);
+        for (uint32_t i : mkf) {
+            DA.SetQuery(*m_DBChains[i], m_DBProfiles[i], m_DBMuLettersVec[i], m_DBMuKmersVec[i], FLT_MAX);
+            DA.SetTarget(Rev[i], &RevProf[i], m_DBMuLettersVec[i], m_DBMuKmersVec[i], FLT_MAX);
+            DA.AlignMKF();
+            m_DBSelfRevScores[i] = DA.m_AlnFwdScore;
+        }
+        DA.UnsetQuery();
+    }
+}
+
 void DBSearcher::LoadDB(const std::string &DBFN)
 {
+    if (EndsWith(DBFN, ".bca")) { LoadBCA(DBFN); return; }
     FILE *f = fopen(DBFN.c_str(), "rb");
     if (!f) throw std::runtime_error("LoadDB: cannot open " + DBFN);
     auto rd = [&](void *p, size_t n) { if (n && fread(p, 1, n, f) != n) { fclose(f); throw std::runtime_error("LoadDB: truncated " + DBFN); } };
@@ -352,28 +491,31 @@ extern "C" int rsk_search_rskdb(rsk_ctx *ctx, const char *query_rskdb, const cha
     try {
         DSSParams Params;
         Params.SetDSSParams(o);
+        const bool have_db = db_rskdb != nullptr && *db_rskdb;
+        const bool prefilter_path = have_db && o.mode == AM_Fast;        // search.cpp:76-111
+        SearchOptions o2 = o;
+        o2.mode = AM_Sensitive;                  // DM_AlwaysSensitive dssparams.cpp:27-42
+        DSSParams Params2;
+        Params2.SetDSSParams(o2);
         DBSearcher DBS;                       // SelfSearch search.cpp:20-37 / Search_NoMuFilter :39-60
-        DBS.m_Params = &Params;
+        DBS.m_Params = prefilter_path ? &Params2 : &Params;
+        DBS.m_SelfRevQueryFlavour = prefilter_path;      // PostMuFilter computes query self-rev scores itself (postmufilter.cpp:79)
         DBS.m_Opts = o;
         DBS.m_Ctx = ctx;
         DBS.LoadDB(query_rskdb);
         DBS.Setup();
         for (USERFIELD u : DBS.m_DA.m_UFs)
             if (u == UF_Undefined) { rsk_set_error("rsk_search_rskdb: invalid -columns field"); return RSK_E_INVALID; }
-        const bool have_db = db_rskdb != nullptr && *db_rskdb;
-        if (have_db && o.mode == AM_Fast) {
+        if (prefilter_path) {
             // cmd_search search.cpp:76-111: k-mer prefilter, then the candidates under the "sensitive" preset
             DBSearcher Src;
-            Src.m_Params = &Params;
+            Src.m_Params = &Params2;
+            Src.m_SelfRevQueryFlavour = true;            // postmufilter.cpp:171
             Src.m_Opts = o;
             Src.m_Ctx = ctx;
             Src.LoadDB(db_rskdb);
             const std::string tmp = std::string(out_tsv) + ".prefilter.tmp";
             MuPreFilter(Params, DBS, Src, tmp);
-            SearchOptions o2 = o;
-            o2.mode = AM_Sensitive;                  // DM_AlwaysSensitive dssparams.cpp:27-42
-            DSSParams Params2;
-            Params2.SetDSSParams(o2);
             PostMuFilter(Params2, tmp, DBS, Src, out_tsv);
             if (!keep_tmp_env()) remove(tmp.c_str());
             if (nhits) *nhits = DBS.m_HitCount;
@@ -391,6 +533,7 @@ extern "C" int rsk_search_rskdb(rsk_ctx *ctx, const char *query_rskdb, const cha
         else {
             DBSearcher Src;
             Src.m_Params = &Params;
+            Src.m_SelfRevQueryFlavour = true;            // runquery.cpp:43-44
             Src.m_Opts = o;
             Src.m_Ctx = ctx;
             Src.LoadDB(db_rskdb);

@@ -78,6 +78,59 @@ public:
     std::vector<float> m_Xs, m_Ys, m_Zs;
     uint m_Idx = UINT_MAX;
     uint GetSeqLength() const { return (uint) m_Seq.size(); }
+    float GetDist(uint Pos1, uint Pos2) const;          // pdbchain.cpp:310
+    void GetReverse(PDBChain &Rev) const;               // pdbchain.cpp:478
+    void GetSS(std::string &SS) const;                  // getss.cpp:33
+};
+
+class DSS {                                             // dss.h:15 (Discrete Structure States: per-chain featurisation)
+public:
+    const PDBChain *m_Chain = nullptr;
+    std::vector<double> m_Density_ScaledValues;
+    std::vector<uint> m_NENs, m_RENs;
+    std::string m_SS;
+    int m_Density_W = 50, m_Density_w = 3, m_SSDensity_W = 50, m_SSDensity_w = 8;     // dss.h:24-37
+    double m_Density_Radius = 20.0;
+    int m_NEN_W = 100, m_NEN_w = 12;
+    double m_DefaultNENDist = 10.0, m_SSDensity_epsilon = 1;
+    uint m_SSE_MinLength = 8, m_SSE_Margin = 8;
+    std::vector<uint> m_SSE_Mids;
+    std::vector<char> m_SSE_cs;
+    bool m_SSEsDone = false;
+    const DSSParams *m_Params = nullptr;
+
+    void Init(const PDBChain &Chain);
+    void SetParams(const DSSParams &Params) { m_Params = &Params; }
+    uint GetSeqLength() const { return m_Chain->GetSeqLength(); }
+    uint GetFeature(uint FeatureIndex, uint Pos);       // index into the 8 profile features (rsk_feature_name)
+    void GetProfile(std::vector<std::vector<byte> > &Profile);                          // dss.cpp:716
+    void GetMuLetters(std::vector<byte> &Letters);                                      // dss.cpp:700
+    static void GetMuKmers(const std::vector<byte> &MuLetters, std::vector<uint> &Kmers, const std::string &PatternStr);   // dss.cpp:659
+    void SetSS();
+    void SetNENs();
+    void SetSSEs();
+    void SetDensity_ScaledValues();
+    double GetDensity(uint Pos) const;
+    double GetSSDensity(uint Pos, char c);
+    double GetFloat_DstNxtHlx(uint Pos);
+    uint CalcNEN(uint Pos) const;
+    uint CalcREN(uint Pos, uint NEN) const;
+    uint ConfLetter(uint Pos) const;
+};
+
+const uint32_t BCA_MAGIC = 0xBCABCA;                    // bcadata.h:36
+class BCAData {                                         // bcadata.h:8 (reader side)
+public:
+    FILE *m_f = nullptr;
+    std::vector<std::string> m_Labels;
+    std::vector<uint64_t> m_Offsets;
+    std::vector<uint32_t> m_SeqLengths;
+    std::mutex m_ReadLock;
+    ~BCAData() { Close(); }
+    void Open(const std::string &FN);
+    void Close();
+    uint64_t GetChainCount() const { return m_SeqLengths.size(); }
+    void ReadChain(uint64_t ChainIdx, PDBChain &Chain);
 };
 
 class DSSAligner;
@@ -215,6 +268,13 @@ public:
     // DSS profile / Mu letters / 3-mers / CA coordinates / self-rev score per chain, format in
     // tests/fixtures.py and DESIGN.md); .bca + on-the-fly DSS featurisation is row (f) "next".
     void LoadDB(const std::string &DBFN);
+    // .bca input: chains are featurised on the host cores (DSS) and the self-rev scores (P8, GetSelfRevScore
+    // alignpair.cpp:7) are computed in one GPU batch.  m_SelfRevQueryFlavour selects the aligner settings the
+    // reference uses for them: false = ProfileLoader (profileloader.cpp:23-26: Omega 0, no Mu filter),
+    // true = the search/PostMuFilter params themselves (runquery.cpp:43, postmufilter.cpp:79,171).
+    bool m_SelfRevQueryFlavour = false;
+    void LoadBCA(const std::string &FN);
+    void ComputeSelfRevScores();
     void AddChain(PDBChain *ptrChain, std::vector<std::vector<byte> > *ptrProfile, std::vector<byte> *ptrMuLetters);
     void Setup();                                       // dbsearcher.cpp:73
     void RunSelf();                                     // runself.cpp:101

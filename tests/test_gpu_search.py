@@ -103,3 +103,40 @@ def test_q100_vs_db_q100_fast_prefilter_path(ctx, tmpdir, monkeypatch):
     assert st[7] == 1 and st[0] == sum(int(ln.split("\t")[1]) for ln in want_tmp.splitlines()[1:])
     run(ctx, tmpdir, "q100_sensitive_dbq.rskdb.gz", "fast", None, "hits_q100_db_q100_fast_std.tsv.gz",
         db2="q100_sensitive_dbq.rskdb.gz")
+
+
+def unpack_bca(name, tmpdir):
+    dst = os.path.join(tmpdir, name)
+    if not os.path.exists(dst):
+        with gzip.open(os.path.join(fx.GOLDEN, name + ".gz"), "rb") as f, open(dst, "wb") as g:
+            g.write(f.read())
+    return dst
+
+
+def run_bca(ctx, tmpdir, q, mode, columns, golden, db=None):
+    out = os.path.join(tmpdir, "outbca_%s_%s_%s.tsv" % (q, db, mode))
+    nhits, stats = ctx.search_rskdb(unpack_bca(q, tmpdir), out, mode, db=unpack_bca(db, tmpdir) if db else None, columns=columns)
+    got = sorted(open(out).read().splitlines())
+    want = ["\t".join(r) for r in fx.read_tsv(golden)]
+    if got != want:
+        gs, ws = set(got), set(want)
+        raise AssertionError("hit tables differ: %d vs %d rows\nmissing: %s\nextra: %s" % (len(got), len(want), sorted(ws - gs)[:5], sorted(gs - ws)[:5]))
+    return stats
+
+
+def test_bca_input_all_modes(ctx, tmpdir):
+    """The whole path from the reference's own .bca test files: BCAData reader, DSS featurisation on the host,
+    self-rev scores (P8) on the GPU, then the searches above -- against the same golden hit tables."""
+    run_bca(ctx, tmpdir, "q10.bca", "sensitive", COLS, "hits_q10_sensitive.tsv")
+    run_bca(ctx, tmpdir, "q100.bca", "sensitive", COLS, "hits_q100_sensitive.tsv.gz")
+    run_bca(ctx, tmpdir, "q100.bca", "fast", COLS, "hits_q100_fast.tsv.gz")
+    run_bca(ctx, tmpdir, "q100.bca", "verysensitive", None, "hits_q100_verysensitive_std.tsv.gz")
+
+
+def test_bca_input_long_chains(ctx, tmpdir):
+    run_bca(ctx, tmpdir, "palms.bca", "sensitive", COLS, "hits_palms_sensitive.tsv.gz")
+
+
+def test_bca_input_db_modes(ctx, tmpdir):
+    run_bca(ctx, tmpdir, "q100.bca", "sensitive", COLS, "hits_q100_db_q100_sensitive.tsv.gz", db="q100.bca")
+    run_bca(ctx, tmpdir, "q100.bca", "fast", COLS, "hits_q100_db_q100_fast.tsv.gz", db="q100.bca")

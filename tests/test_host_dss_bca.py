@@ -1,0 +1,53 @@
+"""Host featurisation: the DSS mirror and the .bca reader against the per-chain bytes the
+reference computed (tests/golden/*.rskdb.gz, dumped by oracle/ref_harness from the reference's own DSS).
+The .bca files are the reference's own test data (test_data/q10.bca, q100.bca, palms.bca).  No GPU needed."""
+import gzip
+import os
+import shutil
+import tempfile
+
+import numpy as np
+import pytest
+
+import fixtures as fx
+
+
+@pytest.fixture(scope="module")
+def bca_dir():
+    d = tempfile.mkdtemp(prefix="rsk_bca_")
+    for name in ("q10", "q100", "palms"):
+        with gzip.open(os.path.join(fx.GOLDEN, name + ".bca.gz"), "rb") as f, open(os.path.join(d, name + ".bca"), "wb") as g:
+            g.write(f.read())
+    yield d
+    shutil.rmtree(d, ignore_errors=True)
+
+
+@pytest.mark.parametrize("name,fixture", [("q10", "q10_sensitive.rskdb.gz"), ("q100", "q100_sensitive.rskdb.gz"),
+                                          ("palms", "palms_sensitive.rskdb.gz")])
+def test_bca_reader_and_dss_bytes(bca_dir, name, fixture):
+    from reseek_amd import capi
+    chains = fx.read_rskdb(fixture)
+    path = os.path.join(bca_dir, name + ".bca")
+    n, nres, maxlen, _ = capi.bca_info(path)
+    assert n == len(chains) and nres == sum(c.L for c in chains) and maxlen == max(c.L for c in chains)
+    bad = []
+    for i, c in enumerate(chains):
+        label, seq, x, y, z = capi.bca_read_chain(path, i)
+        assert label == c.label and seq == c.seq
+        assert x.tobytes() == c.x.tobytes() and y.tobytes() == c.y.tobytes() and z.tobytes() == c.z.tobytes()
+        prof, mu = capi.dss_featurize(seq, x, y, z)
+        if not (np.array_equal(prof, c.prof) and np.array_equal(mu, c.mu)):
+            bad.append((i, [int((prof[f] != c.prof[f]).sum()) for f in range(8)], int((mu != c.mu).sum())))
+    assert not bad, bad[:10]
+
+
+def test_bca_errors(bca_dir):
+    from reseek_amd import capi
+    with pytest.raises(capi.RskError):
+        capi.bca_info(os.path.join(bca_dir, "missing.bca"))
+    junk = os.path.join(bca_dir, "junk.bca")
+    open(junk, "wb").write(b"not a bca file at all........................")
+    with pytest.raises(capi.RskError):
+        capi.bca_info(junk)
+    with pytest.raises(capi.RskError):
+        capi.bca_read_chain(os.path.join(bca_dir, "q10.bca"), 10)
