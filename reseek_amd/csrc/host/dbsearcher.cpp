@@ -382,25 +382,46 @@ static void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self)
         const size_t e = std::min(ia.size(), b + B);
         AlignAndReplay(S, ctx, SrcA, S, std::vector<uint32_t>(ia.begin() + b, ia.begin() + e), std::vector<uint32_t>(ib.begin() + b, ib.begin() + e), Self);
     }
-    // long-chain pairs: host MKF path (dssaligner.cpp:809-813)
-    DSSAligner &DA = S.m_DA;
-    uint prev = UINT_MAX;
-    for (auto &pr : mkf) {
-        const uint i = pr.first, j = pr.second;
-        if (i != prev) {
-            DA.SetQuery(*SrcA.m_DBChains[i], SrcA.m_DBProfiles[i], SrcA.m_DBMuLettersVec[i], SrcA.m_DBMuKmersVec[i], SrcA.m_DBSelfRevScores[i]);
-            prev = i;
+    // long-chain pairs: host MKF path (dssaligner.cpp:809-813), one aligner per host thread as in the
+    // reference (dbsearcher.cpp:98-106); BaseOnAln serialises the output under m_Lock.
+    if (!mkf.empty()) {
+        const unsigned T = (unsigned) std::max<size_t>(1, std::min<size_t>({ (size_t) std::thread::hardware_concurrency(), (size_t) 64, mkf.size() / 64 + 1 }));
+        std::atomic<size_t> next{0};
+        const size_t CH = 64;
+        auto body = [&]() {
+            DSSAligner DA;
+            DA.SetParams(P);
+            DA.SetColumns(S.m_Opts.columns);
+            uint prev = UINT_MAX;
+            for (;;) {
+                const size_t b = next.fetch_add(CH);
+                if (b >= mkf.size()) break;
+                const size_t e = std::min(mkf.size(), b + CH);
+                for (size_t k = b; k < e; ++k) {
+                    const uint i = mkf[k].first, j = mkf[k].second;
+                    if (i != prev) {
+                        DA.SetQuery(*SrcA.m_DBChains[i], SrcA.m_DBProfiles[i], SrcA.m_DBMuLettersVec[i], SrcA.m_DBMuKmersVec[i], SrcA.m_DBSelfRevScores[i]);
+                        prev = i;
+                    }
+                    DA.SetTarget(*S.m_DBChains[j], S.m_DBProfiles[j], S.m_DBMuLettersVec[j], S.m_DBMuKmersVec[j], S.m_DBSelfRevScores[j]);
+                    DA.AlignMKF();
+                    if (DA.m_Path.empty()) continue;
+                    if (Self) {
+                        S.BaseOnAln(DA, true);
+                        if (i != j) S.BaseOnAln(DA, false);
+                    } else
+                        S.BaseOnAln(DA, false);
+                }
+            }
+            DA.UnsetQuery();
+        };
+        if (T == 1) body();
+        else {
+            std::vector<std::thread> ts;
+            for (unsigned t = 0; t < T; ++t) ts.emplace_back(body);
+            for (auto &t : ts) t.join();
         }
-        DA.SetTarget(*S.m_DBChains[j], S.m_DBProfiles[j], S.m_DBMuLettersVec[j], S.m_DBMuKmersVec[j], S.m_DBSelfRevScores[j]);
-        DA.AlignMKF();
-        if (DA.m_Path.empty()) continue;
-        if (Self) {
-            S.BaseOnAln(DA, true);
-            if (i != j) S.BaseOnAln(DA, false);
-        } else
-            S.BaseOnAln(DA, false);
     }
-    DA.UnsetQuery();
 }
 
 void DBSearcher::RunSelf()

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""End-to-end `-search` timing (SURVEY 8d metric ii: chain-pairs/s incl. filtered pairs) on a synthetic
+SCOP40-shaped structure set: Mu letters as bench.py, profile bytes iid, CA random walk, self-rev 0.
+Writes an .rskdb container, then runs rsk_search_rskdb (load + upload + Mu filter + SW/traceback/LDDT +
+MKF on the host threads + hit replay + TSV).  Not the driver's bench line."""
+import json
+import os
+import struct
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+import reseek_amd  # noqa: E402
+
+
+def write_rskdb(path, seqs, rng):
+    with open(path, "wb") as f:
+        f.write(b"RSKDB1\0\0" + struct.pack("<II", len(seqs), 8))
+        for k, mu in enumerate(seqs):
+            L = len(mu)
+            label = ("syn%05d" % k).encode()
+            f.write(struct.pack("<II", L, len(label)) + label)
+            aa = rng.integers(0, 20, L)
+            f.write(bytes(b"ACDEFGHIKLMNPQRSTVWY"[int(a)] for a in aa))
+            f.write(mu.astype(np.uint8).tobytes())
+            prof = np.concatenate([aa[None, :], rng.integers(0, 16, (7, L))]).astype(np.uint8)
+            f.write(prof.tobytes())
+            xyz = np.cumsum(rng.normal(0, 2.2, (3, L)), axis=1).astype(np.float32)
+            f.write(xyz.tobytes())
+            f.write(struct.pack("<f", 0.0))
+            km = (mu[:-2].astype(np.uint32) * 36 + mu[1:-1]) * 36 + mu[2:] if L >= 3 else np.zeros(0, np.uint32)
+            f.write(struct.pack("<I", len(km)) + km.astype(np.uint32).tobytes())
+
+
+def main():
+    nch = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    mode = sys.argv[2] if len(sys.argv) > 2 else "sensitive"
+    seqs = bench.synth_mu_chains(0x5EED5EEC, nch or None)
+    rng = np.random.default_rng(5)
+    ctx = reseek_amd.Ctx(0, stream=torch.cuda.current_stream().cuda_stream)
+    with tempfile.TemporaryDirectory() as td:
+        db = os.path.join(td, "syn.rskdb")
+        write_rskdb(db, seqs, rng)
+        out = os.path.join(td, "hits.tsv")
+        res = {}
+        for rep in range(2):
+            t0 = time.perf_counter()
+            nhits, st = ctx.search_rskdb(db, out, mode)
+            dt = time.perf_counter() - t0
+            res["run%d" % rep] = {"seconds": dt, "pairs": int(st[0]), "pairs_per_s": st[0] / dt, "mufilter_in": int(st[2]),
+                                  "mufilter_discard": int(st[3]), "mkf_pairs": int(st[4]), "sw_pairs": int(st[5]), "hits": int(nhits)}
+        print(json.dumps({"chains": len(seqs), "mode": mode, **res}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
