@@ -33,9 +33,11 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 
 
 #define MUSW_R 32
-#define MUSW_WAVES 4
-#define MUSW_PADSCORE (-128)       // pad rows / pad letters: never part of an alignment (H stays below the H it came from)
-#define MUSW_CLASS0_LQPAD 1024     // profile 37*32*32 B = 37.9 KB: four workgroups per CU
+#define MUSW_PADSCORE (-1000)      // pad rows / pad letters: never part of an alignment
+// query classes by padded length: LDS profile 37 * LQpad * 2 B; waves per workgroup chosen so a CU holds ~16-20 waves
+#define MUSW_NCLASS 3
+static const uint32_t musw_class_lqpad[MUSW_NCLASS] = { 416, 1024, 2048 };      // 30.8 KB, 75.8 KB, 151.6 KB
+static const uint32_t musw_class_waves[MUSW_NCLASS] = { 4, 8, 16 };
 #define MUSW_MAX_LQ 2048           // 64 strips of 32 rows (one pair per wave)
 
 __device__ __forceinline__ int dpp_wave_shr1(int x)
@@ -62,29 +64,41 @@ struct musw_args {
     uint32_t *counter;          // work counter (persistent workgroups)
 };
 
-// sign-extended byte K of w added to x in one VALU op (SDWA operand select)
-template <int K> __device__ __forceinline__ int musw_add_sbyte(int x, int w)
+typedef short v2s __attribute__((ext_vector_type(2)));
+typedef unsigned short v2us __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int pk_add(int a, int b) { return __builtin_bit_cast(int, __builtin_bit_cast(v2s, a) + __builtin_bit_cast(v2s, b)); }
+__device__ __forceinline__ int pk_max(int a, int b) { return __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(v2s, a), __builtin_bit_cast(v2s, b))); }
+// unsigned saturating subtract: floors at 0
+__device__ __forceinline__ int pk_subs(int a, int b) { return __builtin_bit_cast(int, __builtin_elementwise_sub_sat(__builtin_bit_cast(v2us, a), __builtin_bit_cast(v2us, b))); }
+// (lo half of a, hi half of b)
+__device__ __forceinline__ int pk_lo_hi(int a, int b)
 {
     int r;
-    if (K == 0) asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(x), "v"(w));
-    if (K == 1) asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(x), "v"(w));
-    if (K == 2) asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(x), "v"(w));
-    if (K == 3) asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(x), "v"(w));
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(0xFFFF), "v"(a), "v"(b));
     return r;
 }
 
-__global__ __launch_bounds__(64 * MUSW_WAVES) void k_mu_sw(musw_args a, uint32_t gmax)
+// Two cells per VALU op: the 32 rows of a strip are 16 registers of packed int16, row r in the low
+// half and row r + 16 in the high half.  The high half runs ONE COLUMN BEHIND the low half (the same
+// systolic skew that separates neighbouring lanes, applied inside the lane), so the vertical F chain
+// row 15 -> row 16 crosses from the low half of one step to the high half of the next; the next lane
+// is two columns behind.  E and F are kept floored at 0 with unsigned saturating subtracts (a negative
+// E or F is equivalent to 0 in H = max(0, ...)), which also removes the explicit max(., 0).
+// Per 2 cells: bfi (merge the two profile rows), add, max E, max F, max best, sub, sub, max, sub, max.
+__global__ __launch_bounds__(1024) void k_mu_sw(musw_args a, uint32_t gmax)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // int8 query profile: prof[c][h][st][16] = s(c, a_i) for rows i = 32*st + 16*h + (0..15); 37 letter rows
-    signed char *prof = (signed char *) smem;
-    signed char *mat = prof + (size_t) 37 * gmax * 32;
+    // int16 query profile, dword (c, k, st, w) = rows 32*st + 4*k + w (low half) and + 16 (high half) against letter c:
+    // P[((c*4 + k)*g + st)*4 + w]; a lane's four b128 reads per letter row are conflict-free across the strips of a pair
+    int *prof = (int *) smem;
+    signed char *mat = (signed char *) (prof + (size_t) 37 * gmax * 16);
     uint32_t *wg_item = (uint32_t *) (mat + 1312);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     for (int i = tid; i < 1296; i += blockDim.x) mat[i] = (signed char) c_mu_int[i];
     uint32_t cur_q = 0xFFFFFFFFu;
-    uint32_t LQ = 0, g = 1, RS = 32;
+    uint32_t LQ = 0, g = 1;
     const uint32_t nitems = *a.nitems;
 
     for (;;) {
@@ -99,27 +113,17 @@ __global__ __launch_bounds__(64 * MUSW_WAVES) void k_mu_sw(musw_args a, uint32_t
             cur_q = q;
             LQ = a.q_len[q];
             g = (LQ + MUSW_R - 1) / MUSW_R;
-            RS = g * 32;                                   // bytes per letter row
             const uint8_t *Q = a.q_mu + a.q_off[q];
-            // one dword (4 rows) per thread and step; pad rows (i >= LQ) and the pad-letter row 36 = PADSCORE
-            const uint32_t dw_per_row = g * 8;
-            for (uint32_t idx = tid; idx < 37 * dw_per_row; idx += blockDim.x) {
-                const uint32_t c = idx / dw_per_row, w = idx - c * dw_per_row;
-                const uint32_t h = w / (g * 4), rem = w - h * (g * 4);
-                const uint32_t sst = rem >> 2, k = rem & 3;
-                const uint32_t i0 = sst * MUSW_R + h * 16 + k * 4;
-                uint32_t packed = 0;
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const uint32_t i = i0 + b;
-                    int v = MUSW_PADSCORE;
-                    if (c < 36 && i < LQ) {
-                        const uint32_t qi = a.reverse ? (LQ - 1 - i) : i;
-                        v = mat[c * 36 + Q[qi]];
-                    }
-                    packed |= (uint32_t) (v & 0xFF) << (8 * b);
-                }
-                ((uint32_t *) prof)[idx] = packed;
+            const uint32_t per_c = g * 16;
+            for (uint32_t idx = tid; idx < 37 * per_c; idx += blockDim.x) {
+                const uint32_t c = idx / per_c, rem = idx - c * per_c;
+                const uint32_t k = rem / (g * 4), rem2 = rem - k * (g * 4);
+                const uint32_t sst = rem2 >> 2, w = rem2 & 3;
+                const uint32_t ilo = sst * MUSW_R + 4 * k + w, ihi = ilo + 16;
+                int vlo = MUSW_PADSCORE, vhi = MUSW_PADSCORE;
+                if (c < 36 && ilo < LQ) vlo = mat[c * 36 + Q[a.reverse ? (LQ - 1 - ilo) : ilo]];
+                if (c < 36 && ihi < LQ) vhi = mat[c * 36 + Q[a.reverse ? (LQ - 1 - ihi) : ihi]];
+                prof[idx] = (vlo & 0xFFFF) | (vhi << 16);
             }
             __syncthreads();
         }
@@ -136,30 +140,32 @@ __global__ __launch_bounds__(64 * MUSW_WAVES) void k_mu_sw(musw_args a, uint32_t
             LB = a.t_len[t];
             B = a.t_mu + a.t_off[t];
         }
-        // columns this wave must run: max over lanes of LB + strip delay
-        uint32_t ncol = active ? (LB + st) : 0;
+        // steps this wave must run: low half of strip st is at column step - 2*st, the high half one behind
+        uint32_t ncol = active ? (LB + 2 * st + 1) : 0;
 #pragma unroll
         for (int s = 32; s >= 1; s >>= 1) ncol = max(ncol, (uint32_t) __shfl_xor((int) ncol, s, 64));
         if (ncol == 0) continue;
 
-        int H[MUSW_R], E[MUSW_R];
+        int H[16], E[16];
 #pragma unroll
-        for (int r = 0; r < MUSW_R; ++r) { H[r] = 0; E[r] = 0; }
+        for (int r = 0; r < 16; ++r) { H[r] = 0; E[r] = 0; }
         int best = 0;
-        int hand = 0;          // (F << 16) | H of the bottom row of this strip at its previous column
-        int diag_in = 0;       // H(i0-1, j-1) for the top row
-        const int open = a.open, ext = a.ext;
-        const signed char *lane_prof = prof + st * 16;
-        const uint32_t half = g * 16;
+        int bot_h = 0, bot_f = 0;      // (row 15 | row 31) H and outgoing F of the previous step
+        int diag_in = 0;               // H above the top rows at the previous column
+        const int open2 = (a.open & 0xFFFF) * 0x10001, ext2 = (a.ext & 0xFFFF) * 0x10001;
+        const char *lane_prof = (const char *) prof + st * 16;
+        const uint32_t kstride = g * 16, RS = g * 64;         // bytes between k blocks / letter rows
+        const int top_mask = st == 0 ? (int) 0xFFFF0000 : -1; // the very first rows have no strip above: H = F = 0
         unsigned lw = active ? *(const unsigned *) B : 0u;    // letters j..j+3 (chains are padded to 16 in HBM)
         unsigned lw_next = 0;
+        unsigned c_prev = 36;
 
         for (uint32_t col = 0; col < ncol; ++col) {
-            const int j = (int) col - (int) st;     // this lane's target column at this step
-            // bottom row of the strip above at the same column j (it computed it one step earlier)
-            const int inc = dpp_wave_shr1(hand);
-            int up_h = 0, up_f = 0;
-            if (st != 0) { up_h = inc & 0xFFFF; up_f = (int) ((unsigned) inc >> 16); }
+            const int j = (int) col - 2 * (int) st;            // column of the low half; the high half is at j - 1
+            // rows above: low half <- high half of the previous lane (its previous step), high half <- own low half
+            const int xh = dpp_wave_shr1(bot_h), xf = dpp_wave_shr1(bot_f);
+            const int up_h = (int) __builtin_amdgcn_alignbit((unsigned) bot_h, (unsigned) xh, 16) & top_mask;
+            const int up_f = (int) __builtin_amdgcn_alignbit((unsigned) bot_f, (unsigned) xf, 16) & top_mask;
             unsigned c = 36;
             if (j >= 0 && (uint32_t) j < LB) {
                 const int jm = j & 3;
@@ -169,31 +175,32 @@ __global__ __launch_bounds__(64 * MUSW_WAVES) void k_mu_sw(musw_args a, uint32_t
                 }
                 c = (lw >> (8 * jm)) & 0xFF;
             }
-            const signed char *row = lane_prof + c * RS;
-            const v4i S0 = *(const v4i *) row, S1 = *(const v4i *) (row + half);
+            const char *rowl = lane_prof + c * RS, *rowh = lane_prof + c_prev * RS;
+            c_prev = c;
+            v4i Pl[4], Ph[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { Pl[k] = *(const v4i *) (rowl + k * kstride); Ph[k] = *(const v4i *) (rowh + k * kstride); }
             int diag = diag_in;
             int F = up_f;
             diag_in = up_h;
 #pragma unroll
-            for (int r = 0; r < MUSW_R; ++r) {
-                const int w = r < 16 ? S0[r >> 2] : S1[(r - 16) >> 2];
-                int h = (r & 3) == 0 ? musw_add_sbyte<0>(diag, w) : (r & 3) == 1 ? musw_add_sbyte<1>(diag, w)
-                      : (r & 3) == 2 ? musw_add_sbyte<2>(diag, w) : musw_add_sbyte<3>(diag, w);
-                h = max(h, 0);
-                h = max(h, E[r]);
-                h = max(h, F);
+            for (int r = 0; r < 16; ++r) {
+                const int S = pk_lo_hi(Pl[r >> 2][r & 3], Ph[r >> 2][r & 3]);
+                int h = pk_add(diag, S);
+                h = pk_max(h, E[r]);
+                h = pk_max(h, F);
                 diag = H[r];
                 H[r] = h;
-                best = max(best, h);
-                const int ho = h - open;
-                E[r] = max(E[r] - ext, ho);
-                F = max(F - ext, ho);
+                best = pk_max(best, h);
+                const int ho = pk_subs(h, open2);
+                E[r] = pk_max(pk_subs(E[r], ext2), ho);
+                F = pk_max(pk_subs(F, ext2), ho);
             }
-            // bottom row of this strip -> next lane (16 bits each: anything above 250 saturates anyway)
-            hand = (min(max(F, 0), 0x7FFF) << 16) | min(H[MUSW_R - 1], 0xFFFF);
+            bot_h = H[15];
+            bot_f = F;
         }
-        // best over the g strips of each pair (lanes pr*g .. pr*g+g-1); the first lane of a group collects
-        int red = best;
+        int red = max(best & 0xFFFF, (int) ((unsigned) best >> 16));
+        best = red;
         for (uint32_t d = 1; d < g; ++d) {
             const int o = __shfl(best, (int) ((lane + d) & 63), 64);
             if (st + d < g) red = max(red, o);
@@ -245,14 +252,16 @@ __global__ void k_mu_sw_slow(musw_args a, const uint2 *pairs, const uint32_t *pa
 // ---------------------------------------------------------------------------------------------
 // device-side queue construction
 // ---------------------------------------------------------------------------------------------
-// class of a query by its padded length: 0: <= 1024, 1: <= 2048 (LDS int8 profile), 4: slow path
+// class of a query by its padded length: 0: <= 416, 1: <= 1024, 2: <= 2048 (LDS int16 profile), 4: slow path
 __device__ __forceinline__ int musw_class(uint32_t LQ)
 {
     const uint32_t lp = (LQ + MUSW_R - 1) / MUSW_R * MUSW_R;
-    if (lp <= MUSW_CLASS0_LQPAD) return 0;
-    if (LQ <= MUSW_MAX_LQ) return 1;
+    if (lp <= 416) return 0;
+    if (lp <= 1024) return 1;
+    if (LQ <= MUSW_MAX_LQ) return 2;
     return 4;
 }
+__device__ __forceinline__ uint32_t musw_waves(int cls) { return cls == 0 ? 4u : cls == 1 ? 8u : 16u; }
 
 // implicit lists: first[q], cnt[q]
 // Self triangle: the Mu matrix and the gap costs are symmetric, so score(q,t) == score(t,q) (forward
@@ -284,7 +293,7 @@ __global__ __launch_bounds__(1024) void k_musw_scan_items(const uint32_t *q_len,
             if (cls == 4) v = cnt[q];                          // slow path: one item per pair
             else {
                 const uint32_t g = (LQ + MUSW_R - 1) / MUSW_R;
-                const uint32_t per_wg = (64 / g) * MUSW_WAVES;
+                const uint32_t per_wg = (64 / g) * musw_waves(cls);
                 v = (cnt[q] + per_wg - 1) / per_wg;
             }
         }
@@ -325,7 +334,7 @@ __global__ void k_musw_fill_items(const uint32_t *q_len, const uint32_t *cnt, co
         return;
     }
     const uint32_t g = (LQ + MUSW_R - 1) / MUSW_R;
-    const uint32_t per_wg = (64 / g) * MUSW_WAVES;
+    const uint32_t per_wg = (64 / g) * musw_waves(cls);
     for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) items[item_start[q] + k] = make_uint2(q, k * per_wg);
 }
 
@@ -462,11 +471,10 @@ static int run_mu_sw_lists(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, musw_
     if ((rc = ws.alloc(&ws.items, (size_t) max_items_hint)) != RSK_OK) return rc;
     uint32_t maxLQ = 0;
     bool has_class[5] = { false, false, false, false, false };
-    const uint32_t class_lqpad[2] = { MUSW_CLASS0_LQPAD, MUSW_MAX_LQ };
     for (uint32_t i = 0; i < nq; ++i) {
         const uint32_t L = q->len[i], lp = (L + MUSW_R - 1) / MUSW_R * MUSW_R;
         maxLQ = std::max(maxLQ, L);
-        const int c = lp <= MUSW_CLASS0_LQPAD ? 0 : L <= MUSW_MAX_LQ ? 1 : 4;
+        const int c = lp <= 416 ? 0 : lp <= 1024 ? 1 : L <= MUSW_MAX_LQ ? 2 : 4;
         has_class[c] = true;
     }
     for (int cls = 0; cls < 5; ++cls) {
@@ -481,16 +489,17 @@ static int run_mu_sw_lists(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, musw_
         a.items = ws.items;
         a.nitems = ws.nitems;
         a.counter = ws.counter;
-        if (cls <= 1) {
-            const uint32_t gmax = class_lqpad[cls] / MUSW_R;
-            const size_t lds = (size_t) 37 * gmax * 32 + 1312 + 16;
+        if (cls < MUSW_NCLASS) {
+            const uint32_t gmax = musw_class_lqpad[cls] / MUSW_R;
+            const uint32_t waves = musw_class_waves[cls];
+            const size_t lds = (size_t) 37 * gmax * 64 + 1312 + 16;
             static bool attr_set = false;
             if (!attr_set) {
                 RSK_HIP(hipFuncSetAttribute((const void *) k_mu_sw, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
                 attr_set = true;
             }
-            const int wg_per_cu = std::max(1, std::min(4, (int) (163840 / lds)));
-            hipLaunchKernelGGL(k_mu_sw, dim3(ctx->num_cus * wg_per_cu), dim3(64 * MUSW_WAVES), lds, ctx->stream, a, gmax);
+            const int wg_per_cu = std::max(1, std::min<int>(20 / (int) waves, (int) (163840 / lds)));
+            hipLaunchKernelGGL(k_mu_sw, dim3(ctx->num_cus * wg_per_cu), dim3(64 * waves), lds, ctx->stream, a, gmax);
         } else {
             // slow path: needs the item count on the host to size the launch
             uint32_t n = 0;
@@ -515,7 +524,8 @@ static uint32_t item_exact_implicit(const rsk_db *q, uint32_t nt, int self_trian
         const uint32_t L = q->len[i];
         const uint64_t cnt = self_triangle ? nt - q->h_len_rank[i] : nt;
         if (L > MUSW_MAX_LQ) { n += cnt; continue; }
-        const uint32_t g = (L + MUSW_R - 1) / MUSW_R, per_wg = (64 / g) * MUSW_WAVES;
+        const uint32_t g = (L + MUSW_R - 1) / MUSW_R, lp = g * MUSW_R;
+        const uint32_t per_wg = (64 / g) * (lp <= 416 ? 4u : lp <= 1024 ? 8u : 16u);
         n += (cnt + per_wg - 1) / per_wg;
     }
     return (uint32_t) std::min<uint64_t>(n, 0xFFFFFFF0ull);
