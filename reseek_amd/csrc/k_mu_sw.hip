@@ -146,9 +146,10 @@ __global__ __launch_bounds__(1024) void k_mu_sw(musw_args a, uint32_t gmax)
         for (int s = 32; s >= 1; s >>= 1) ncol = max(ncol, (uint32_t) __shfl_xor((int) ncol, s, 64));
         if (ncol == 0) continue;
 
-        int H[16], E[16];
+        // H lives in two register sets that swap roles every step (no copies for the diagonal hand-down)
+        int HA[16], HB[16], E[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { H[r] = 0; E[r] = 0; }
+        for (int r = 0; r < 16; ++r) { HA[r] = 0; HB[r] = 0; E[r] = 0; }
         int best = 0;
         int bot_h = 0, bot_f = 0;      // (row 15 | row 31) H and outgoing F of the previous step
         int diag_in = 0;               // H above the top rows at the previous column
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(1024) void k_mu_sw(musw_args a, uint32_t gmax)
         unsigned lw_next = 0;
         unsigned c_prev = 36;
 
-        for (uint32_t col = 0; col < ncol; ++col) {
+        auto step = [&](const int (&Hin)[16], int (&Hout)[16], uint32_t col) {
             const int j = (int) col - 2 * (int) st;            // column of the low half; the high half is at j - 1
             // rows above: low half <- high half of the previous lane (its previous step), high half <- own low half
             const int xh = dpp_wave_shr1(bot_h), xf = dpp_wave_shr1(bot_f);
@@ -189,15 +190,20 @@ __global__ __launch_bounds__(1024) void k_mu_sw(musw_args a, uint32_t gmax)
                 int h = pk_add(diag, S);
                 h = pk_max(h, E[r]);
                 h = pk_max(h, F);
-                diag = H[r];
-                H[r] = h;
+                diag = Hin[r];
+                Hout[r] = h;
                 best = pk_max(best, h);
                 const int ho = pk_subs(h, open2);
                 E[r] = pk_max(pk_subs(E[r], ext2), ho);
                 F = pk_max(pk_subs(F, ext2), ho);
             }
-            bot_h = H[15];
+            bot_h = Hout[15];
             bot_f = F;
+        };
+        // an odd step count is rounded up: the extra step only sees pad letters / finished columns
+        for (uint32_t col = 0; col < ncol; col += 2) {
+            step(HA, HB, col);
+            step(HB, HA, col + 1);
         }
         int red = max(best & 0xFFFF, (int) ((unsigned) best >> 16));
         best = red;
