@@ -188,6 +188,16 @@ def main():
         # algorithmic HBM bytes per launch: (LA + LB + 8) per pair, score-only
         alg_bytes = sum(len(s) * (n - i) for i, s in enumerate(seqs)) + \
             float(np.cumsum([len(s) for s in seqs][::-1])[::-1].sum()) + 8.0 * pairs
+        # HBM traffic per launch: rocprofv3 PMC counters of this same command, committed under profiles/
+        # (FETCH_SIZE doubled on gfx950 as MI355X_MICROARCH.md prescribes; separate --pmc passes)
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01e_traffic.json")) as f:
+                tj = json.load(f)
+            if n == 11211 and not args.chains:
+                traffic = float(tj["traffic_bytes_per_launch"])
+        except (OSError, ValueError, KeyError):
+            traffic = None
         res = {
             "metric": "aligned cells/sec (SCOP40-shaped all-vs-all, gapless int Mu kernel)",
             "value": cells_per_s, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -207,8 +217,8 @@ def main():
                 "kernel_ms": kernel_ms, "cell_slots_issued": slots, "slot_efficiency": cells / max(1, slots),
                 "hbm": {"bound": "hbm", "achieved": alg_bytes / (kernel_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
                         "unit": "GB/s", "frac": alg_bytes / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                        "algorithmic_bytes": alg_bytes, "traffic": None},
-                "traffic": None},
+                        "algorithmic_bytes": alg_bytes, "traffic": traffic},
+                "traffic": traffic, "traffic_source": "profiles/r01e_traffic.json (rocprofv3 PMC, same workload)" if traffic else None},
         }
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(seqs)
