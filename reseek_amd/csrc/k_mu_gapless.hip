@@ -145,18 +145,20 @@ __device__ __forceinline__ int dpp_wave_ror1(int x)
     return __builtin_amdgcn_update_dpp(x, x, 0x13C /* wave_ror:1 */, 0xF, 0xF, false);
 }
 
-// One pair of target letters (c0, c1) with compile-time rotation state R (0..3).
-// Logical dword i of group m lives in physical register G[m][(i - R) & 3].
+// One pair of target letters (c0, c1) with compile-time rotation state R (0..D-1).
+// A lane owns D CONSECUTIVE ring dwords (ring dword D*lane + k, k = 0..D-1); logical dword k lives in
+// physical register G[(k - R) mod D], so "every value moves up one ring dword" is a change of R plus
+// ONE v_mov_b32_dpp wave_ror:1 for the dword that crosses to the next lane (lane 63 -> lane 0 closes
+// the ring by itself).  The LDS profile keeps the b128 blocks of all lanes contiguous (block m of lane l
+// at m*1024 + 16*l: conflict-free), only the builder knows the slot permutation.
 template <int D, int R>
-__device__ __forceinline__ void ring_pairstep(int (&G)[D / 4][4], int (&E)[D / 4][4], int (&O)[D / 4][4],
-                                              const char *lane_p1, const char *lane_p2, unsigned c0, unsigned c1,
-                                              bool lane0)
+__device__ __forceinline__ void ring_pairstep(int (&G)[D], int (&E)[D], int (&O)[D], const char *lane_p1, const char *lane_p2,
+                                              unsigned c0, unsigned c1)
 {
     constexpr int M = D / 4;
     constexpr int RSB = RingGeom<D>::RSB;
     v4i S[M], T[M];
-    // row offsets are wave-uniform: shift on the scalar unit, then ONE 32-bit VOP2 add per address
-    // (v_lshl_add_u32 is a VOP3 op and issues at half rate on gfx950)
+    // row offsets are wave-uniform: multiply on the scalar unit, then ONE VOP2 add per address
     const unsigned o0 = (unsigned) __builtin_amdgcn_readfirstlane((int) (c0 * (unsigned) RSB));
     const unsigned o1 = (unsigned) __builtin_amdgcn_readfirstlane((int) (c1 * (unsigned) RSB));
     const char *a0 = lane_p1 + o0;
@@ -167,35 +169,28 @@ __device__ __forceinline__ void ring_pairstep(int (&G)[D / 4][4], int (&E)[D / 4
         T[m] = *(const v4i *) (a1 + m * 1024);
     }
 #pragma unroll
-    for (int m = 0; m < M; ++m) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int p = (i - R) & 3;
-            G[m][p] = pk_addsat(G[m][p], S[m][i]);
-            E[m][i] = pk_max(E[m][i], G[m][p]);
-        }
+    for (int k = 0; k < D; ++k) {
+        const int p = (k - R + D) % D;
+        G[p] = pk_addsat(G[p], S[k >> 2][k & 3]);
+        E[k] = pk_max(E[k], G[p]);
     }
 #pragma unroll
-    for (int m = 0; m < M; ++m) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int p = (i - R) & 3;
-            G[m][p] = pk_addsat(G[m][p], T[m][i]);
-            O[m][i] = pk_max(O[m][i], G[m][p]);
-        }
+    for (int k = 0; k < D; ++k) {
+        const int p = (k - R + D) % D;
+        G[p] = pk_addsat(G[p], T[k >> 2][k & 3]);
+        O[k] = pk_max(O[k], G[p]);
     }
-    // every value moves up one ring dword: logical 3 of each group crosses to the next lane
-    constexpr int p3 = (3 - R) & 3;
-    int r[M];
-#pragma unroll
-    for (int m = 0; m < M; ++m) r[m] = dpp_wave_ror1(G[m][p3]);
-    if (M == 1) {
-        G[0][p3] = r[0];
-    } else {
-        // lane 0 receives lane 63's value of the PREVIOUS group (ring dword 256*m - 1)
-#pragma unroll
-        for (int m = 0; m < M; ++m) G[m][p3] = lane0 ? r[(m + M - 1) % M] : r[m];
-    }
+    constexpr int pl = (D - 1 - R + D) % D;
+    G[pl] = dpp_wave_ror1(G[pl]);
+}
+
+template <int D, int R0>
+__device__ __forceinline__ void ring_8letters(int (&G)[D], int (&E)[D], int (&O)[D], const char *lane_p1, const char *lane_p2, uint2 Lc)
+{
+    ring_pairstep<D, (R0 + 0) % D>(G, E, O, lane_p1, lane_p2, Lc.x & 0xFF, (Lc.x >> 8) & 0xFF);
+    ring_pairstep<D, (R0 + 1) % D>(G, E, O, lane_p1, lane_p2, (Lc.x >> 16) & 0xFF, Lc.x >> 24);
+    ring_pairstep<D, (R0 + 2) % D>(G, E, O, lane_p1, lane_p2, Lc.y & 0xFF, (Lc.y >> 8) & 0xFF);
+    ring_pairstep<D, (R0 + 3) % D>(G, E, O, lane_p1, lane_p2, (Lc.y >> 16) & 0xFF, Lc.y >> 24);
 }
 
 template <int D, int NW>
@@ -235,10 +230,12 @@ __global__ __launch_bounds__(64 * NW) void k_gapless_ring(const rsk_ring *__rest
     // build both profile copies, 8 slots (16 bytes) per store
     for (int idx = tid; idx < Gm::NROWS * (P / 8); idx += nthreads) {
         const int c = idx / (P / 8), g = idx - c * (P / 8);
+        // LDS block g = (b128 block m = g / 64 of lane g % 64) holds ring granule M * lane + m
+        const int rg = M * (g & 63) + (g >> 6);
         short v1[8], v2[8];
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-            const int s = (8 * g + k) & (P - 1);
+            const int s = (8 * rg + k) & (P - 1);
             const unsigned l = rl[s];
             const short v = (c == 36 || l == 0xFF) ? (short) -32768 : (short) mat[c * 36 + l];
             if (k < 8) v1[k] = v;
@@ -250,13 +247,12 @@ __global__ __launch_bounds__(64 * NW) void k_gapless_ring(const rsk_ring *__rest
     __syncthreads();
 
     const int wave = tid >> 6, lane = tid & 63;
-    const bool lane0 = (lane == 0);
     const char *lane_p1 = (const char *) prof1 + lane * 16;
     const char *lane_p2 = (const char *) prof2 + lane * 16;
     int *wres = res + wave * NQMAX;
     int lq[M];
 #pragma unroll
-    for (int m = 0; m < M; ++m) lq[m] = ring_laneq[rg.laneq_off + m * 64 + lane];
+    for (int m = 0; m < M; ++m) lq[m] = ring_laneq[rg.laneq_off + M * lane + m];
 
     for (;;) {
         uint32_t t = 0;
@@ -267,25 +263,33 @@ __global__ __launch_bounds__(64 * NW) void k_gapless_ring(const rsk_ring *__rest
         const uint32_t tlen = __builtin_amdgcn_readfirstlane(t_len[t]);
         const uint2 *lp = (const uint2 *) (t_mu + toff);
         const uint32_t nch = (tlen + 7) >> 3;
-        int G[M][4], E[M][4], O[M][4];
+        int G[D], E[D], O[D];
 #pragma unroll
-        for (int m = 0; m < M; ++m)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { G[m][i] = FLOOR2; E[m][i] = FLOOR2; O[m][i] = FLOOR2; }
-        uint2 L = lp[0];
-        for (uint32_t ch = 0; ch < nch; ++ch) {
-            const uint2 Lc = L;
-            L = lp[ch + 1];   // prefetch (the chain set has >= 64 bytes of tail padding)
-            ring_pairstep<D, 0>(G, E, O, lane_p1, lane_p2, Lc.x & 0xFF, (Lc.x >> 8) & 0xFF, lane0);
-            ring_pairstep<D, 1>(G, E, O, lane_p1, lane_p2, (Lc.x >> 16) & 0xFF, Lc.x >> 24, lane0);
-            ring_pairstep<D, 2>(G, E, O, lane_p1, lane_p2, Lc.y & 0xFF, (Lc.y >> 8) & 0xFF, lane0);
-            ring_pairstep<D, 3>(G, E, O, lane_p1, lane_p2, (Lc.y >> 16) & 0xFF, Lc.y >> 24, lane0);
+        for (int k = 0; k < D; ++k) { G[k] = FLOOR2; E[k] = FLOOR2; O[k] = FLOOR2; }
+        // a full rotation of the register names takes D pair-steps = 2*D letters
+        if (D == 4) {
+            uint2 L = lp[0];
+            for (uint32_t ch = 0; ch < nch; ++ch) {
+                const uint2 Lc = L;
+                L = lp[ch + 1];   // prefetch (the chain set has >= 64 bytes of tail padding)
+                ring_8letters<D, 0>(G, E, O, lane_p1, lane_p2, Lc);
+            }
+        } else {
+            uint2 L0 = lp[0], L1 = lp[1];
+            uint32_t ch = 0;
+            for (; ch + 2 <= nch; ch += 2) {
+                const uint2 Lc0 = L0, Lc1 = L1;
+                L0 = lp[ch + 2]; L1 = lp[ch + 3];
+                ring_8letters<D, 0>(G, E, O, lane_p1, lane_p2, Lc0);
+                ring_8letters<D, 4>(G, E, O, lane_p1, lane_p2, Lc1);
+            }
+            if (ch < nch) ring_8letters<D, 0>(G, E, O, lane_p1, lane_p2, L0);   // odd tail: the target ends here, names need not close
         }
         // per-query reduction
 #pragma unroll
         for (int m = 0; m < M; ++m) {
-            int b = pk_max(pk_max(E[m][0], E[m][1]), pk_max(E[m][2], E[m][3]));
-            b = pk_max(b, pk_max(pk_max(O[m][0], O[m][1]), pk_max(O[m][2], O[m][3])));
+            int b = pk_max(pk_max(E[4 * m], E[4 * m + 1]), pk_max(E[4 * m + 2], E[4 * m + 3]));
+            b = pk_max(b, pk_max(pk_max(O[4 * m], O[4 * m + 1]), pk_max(O[4 * m + 2], O[4 * m + 3])));
             const int lo = (int) (short) (b & 0xFFFF), hi = b >> 16;
             const int v = max(lo, hi);
             if (lq[m] != 0xFF) atomicMax(&wres[lq[m]], v);
