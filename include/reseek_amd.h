@@ -221,6 +221,34 @@ int rsk_search_rskdb(rsk_ctx *ctx, const char *query_rskdb, const char *db_rskdb
                      const char *columns, double evalue, int noself, const char *out_tsv, uint64_t *nhits,
                      uint64_t *stats8);
 
+/* The same driver with the remaining command-line options of `reseek -search` that touch the path
+ * (myutils options of search.cpp / dssparams.cpp / dbsearcher.cpp / muprefilter.cpp / postmufilter.cpp).
+ * Zero-initialise, set `mode`; fields left 0/NULL mean "option not given". */
+typedef struct rsk_search_opts {
+    const char *mode;          /* "fast" | "sensitive" | "verysensitive" */
+    const char *columns;       /* -columns */
+    double evalue;             /* -evalue; used when evalue_set != 0 */
+    int evalue_set;
+    double mints;              /* -mints; used when mints_set != 0 */
+    int mints_set;
+    double pvalue;             /* -pvalue (PostMuFilter accept rule); used when pvalue_set != 0 */
+    int pvalue_set;
+    int noself;                /* -noself */
+    int selfrev0;              /* -selfrev0 */
+    int idx_mode;              /* 0 = by query count, 1 = -idxq, 2 = -idxt */
+    uint32_t rsb_size;         /* -rsb_size (0 = 1500) */
+    const char *dbmu;          /* -dbmu: Mu FASTA of the DB chains for the prefilter stage (search.cpp:93-96) */
+    int keeptmp;               /* -keeptmp: keep <out_tsv>.prefilter.tmp */
+} rsk_search_opts;
+int rsk_search(rsk_ctx *ctx, const char *query_path, const char *db_path, const rsk_search_opts *opts,
+               const char *out_tsv, uint64_t *nhits, uint64_t *stats8);
+
+/* `reseek -convert in.bca -bca out.bca` / `-feature_fasta out.fa` (convert.cpp:262, Mu alphabet): BCAData
+ * writer (bcadata.cpp:15-58,140-168: a file it wrote is reproduced byte for byte) and the Mu FASTA of a
+ * .bca file ('A' + letter, 80 columns, chains in file order). */
+int rsk_bca_copy(const char *in_bca, const char *out_bca);
+int rsk_bca_to_mu_fasta(const char *in_bca, const char *out_fasta);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,6 +76,19 @@ GAP_OPEN = -0.685533     # namedparams.cpp:45
 GAP_EXT = -0.051881      # namedparams.cpp:46
 
 
+class SearchOpts(C.Structure):
+    _fields_ = [("mode", C.c_char_p), ("columns", C.c_char_p), ("evalue", C.c_double), ("evalue_set", C.c_int),
+                ("mints", C.c_double), ("mints_set", C.c_int), ("pvalue", C.c_double), ("pvalue_set", C.c_int),
+                ("noself", C.c_int), ("selfrev0", C.c_int), ("idx_mode", C.c_int), ("rsb_size", C.c_uint32),
+                ("dbmu", C.c_char_p), ("keeptmp", C.c_int)]
+
+
+SIGNATURES["rsk_search"] = (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(SearchOpts), C.c_char_p, C.POINTER(C.c_uint64),
+                                      C.POINTER(C.c_uint64)])
+SIGNATURES["rsk_bca_copy"] = (C.c_int, [C.c_char_p, C.c_char_p])
+SIGNATURES["rsk_bca_to_mu_fasta"] = (C.c_int, [C.c_char_p, C.c_char_p])
+
+
 class RskError(RuntimeError):
     pass
 
@@ -190,6 +203,22 @@ class Ctx:
         _check(lib().rsk_search_rskdb(self.h, query.encode(), db.encode() if db else None, mode.encode(),
                                       columns.encode() if columns else None, evalue, int(noself), out_tsv.encode(),
                                       C.byref(n), st))
+        return n.value, list(st)
+
+    def search(self, query, out_tsv, mode, db=None, **kw):
+        """rsk_search with the options struct: columns, evalue, mints, pvalue, noself, selfrev0, idx_mode, rsb_size, dbmu, keeptmp."""
+        o = SearchOpts()
+        o.mode = mode.encode()
+        for k, v in kw.items():
+            if k in ("columns", "dbmu"):
+                setattr(o, k, v.encode() if v else None)
+            elif k in ("evalue", "mints", "pvalue"):
+                setattr(o, k, float(v)); setattr(o, k + "_set", 1)
+            else:
+                setattr(o, k, int(v))
+        n = C.c_uint64()
+        st = (C.c_uint64 * 8)()
+        _check(lib().rsk_search(self.h, query.encode(), db.encode() if db else None, C.byref(o), out_tsv.encode(), C.byref(n), st))
         return n.value, list(st)
 
     # ---- P10-P12 k-mer prefilter ---------------------------------------------------------------------
@@ -332,3 +361,11 @@ def bca_read_chain(path, idx, cap=70000):
     _check(lib().rsk_bca_read_chain(path.encode(), idx, lab, 1024, seq, _p(x, f32p), _p(y, f32p), _p(z, f32p), cap, C.byref(L)))
     n = L.value
     return lab.value.decode(), seq.raw[:n].split(b"\0")[0].decode(), x[:n].copy(), y[:n].copy(), z[:n].copy()
+
+
+def bca_copy(src, dst):
+    _check(lib().rsk_bca_copy(src.encode(), dst.encode()))
+
+
+def bca_to_mu_fasta(src, dst):
+    _check(lib().rsk_bca_to_mu_fasta(src.encode(), dst.encode()))

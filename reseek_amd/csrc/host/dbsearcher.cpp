@@ -500,15 +500,9 @@ void rsk_set_error(const char *fmt, ...);
 
 static bool keep_tmp_env() { const char *e = getenv("RSK_KEEPTMP"); return e && *e && *e != '0'; }    // -keeptmp
 
-extern "C" int rsk_search_rskdb(rsk_ctx *ctx, const char *query_rskdb, const char *db_rskdb, const char *mode, const char *columns,
-                                double evalue, int noself, const char *out_tsv, uint64_t *nhits, uint64_t *stats8)
+static int search_impl(rsk_ctx *ctx, const char *query_rskdb, const char *db_rskdb, const SearchOptions &o, const char *out_tsv,
+                       uint64_t *nhits, uint64_t *stats8)
 {
-    if (!ctx || !query_rskdb || !out_tsv) { rsk_set_error("rsk_search_rskdb: NULL argument"); return RSK_E_INVALID; }
-    SearchOptions o;
-    if (!parse_mode(mode, o)) { rsk_set_error("rsk_search_rskdb: mode must be fast, sensitive or verysensitive"); return RSK_E_INVALID; }
-    if (columns) o.columns = columns;
-    if (evalue >= 0) { o.evalue_set = true; o.evalue = evalue; }
-    o.noself = noself != 0;
     try {
         DSSParams Params;
         Params.SetDSSParams(o);
@@ -538,7 +532,7 @@ extern "C" int rsk_search_rskdb(rsk_ctx *ctx, const char *query_rskdb, const cha
             const std::string tmp = std::string(out_tsv) + ".prefilter.tmp";
             MuPreFilter(Params, DBS, Src, tmp);
             PostMuFilter(Params2, tmp, DBS, Src, out_tsv);
-            if (!keep_tmp_env()) remove(tmp.c_str());
+            if (!o.keeptmp && !keep_tmp_env()) remove(tmp.c_str());
             if (nhits) *nhits = DBS.m_HitCount;
             if (stats8) {
                 stats8[0] = DBS.m_ProcessedPairCount; stats8[1] = DBS.m_ProcessedPairCount - DBS.m_MKFPairCount; stats8[2] = DBS.m_MuFilterInputCount;
@@ -572,4 +566,36 @@ extern "C" int rsk_search_rskdb(rsk_ctx *ctx, const char *query_rskdb, const cha
         return RSK_E_INVALID;
     }
     return RSK_OK;
+}
+
+extern "C" int rsk_search_rskdb(rsk_ctx *ctx, const char *query_rskdb, const char *db_rskdb, const char *mode, const char *columns,
+                                double evalue, int noself, const char *out_tsv, uint64_t *nhits, uint64_t *stats8)
+{
+    if (!ctx || !query_rskdb || !out_tsv) { rsk_set_error("rsk_search_rskdb: NULL argument"); return RSK_E_INVALID; }
+    SearchOptions o;
+    if (!parse_mode(mode, o)) { rsk_set_error("rsk_search_rskdb: mode must be fast, sensitive or verysensitive"); return RSK_E_INVALID; }
+    if (columns) o.columns = columns;
+    if (evalue >= 0) { o.evalue_set = true; o.evalue = evalue; }
+    o.noself = noself != 0;
+    return search_impl(ctx, query_rskdb, db_rskdb, o, out_tsv, nhits, stats8);
+}
+
+extern "C" int rsk_search(rsk_ctx *ctx, const char *query_path, const char *db_path, const rsk_search_opts *opts, const char *out_tsv,
+                          uint64_t *nhits, uint64_t *stats8)
+{
+    if (!ctx || !query_path || !out_tsv || !opts) { rsk_set_error("rsk_search: NULL argument"); return RSK_E_INVALID; }
+    SearchOptions o;
+    if (!parse_mode(opts->mode, o)) { rsk_set_error("rsk_search: mode must be fast, sensitive or verysensitive"); return RSK_E_INVALID; }
+    if (opts->columns) o.columns = opts->columns;
+    if (opts->evalue_set) { o.evalue_set = true; o.evalue = opts->evalue; }
+    if (opts->mints_set) { o.mints_set = true; o.mints = opts->mints; }
+    if (opts->pvalue_set) { o.pvalue_set = true; o.pvalue = opts->pvalue; }
+    o.noself = opts->noself != 0;
+    o.selfrev0 = opts->selfrev0 != 0;
+    if (opts->idx_mode < 0 || opts->idx_mode > 2) { rsk_set_error("rsk_search: idx_mode must be 0, 1 or 2"); return RSK_E_INVALID; }
+    o.idx_mode = opts->idx_mode == 0 ? -1 : opts->idx_mode;
+    if (opts->rsb_size) o.rsb_size = opts->rsb_size;
+    if (opts->dbmu) o.dbmu = opts->dbmu;
+    o.keeptmp = opts->keeptmp != 0;
+    return search_impl(ctx, query_path, db_path, o, out_tsv, nhits, stats8);
 }

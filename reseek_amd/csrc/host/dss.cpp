@@ -377,9 +377,78 @@ void BCAData::Open(const std::string &FN)
 
 void BCAData::Close()
 {
+    if (m_f && m_Writing) {
+        // bcadata.cpp:140-168: length array, labels, then the three header fields
+        const uint64_t ChainCount = m_SeqLengths.size();
+        const uint64_t SeqLengthsPos = (uint64_t) ftello(m_f);
+        fwrite(m_SeqLengths.data(), 4, (size_t) ChainCount, m_f);
+        uint64_t LabelDataSize = 0;
+        for (const std::string &Label : m_Labels) { fwrite(Label.c_str(), 1, Label.size() + 1, m_f); LabelDataSize += Label.size() + 1; }
+        fseeko(m_f, 4, SEEK_SET);
+        fwrite(&ChainCount, 8, 1, m_f);
+        fwrite(&SeqLengthsPos, 8, 1, m_f);
+        fwrite(&LabelDataSize, 8, 1, m_f);
+    }
     if (m_f) fclose(m_f);
     m_f = nullptr;
+    m_Writing = false;
     m_Labels.clear(); m_Offsets.clear(); m_SeqLengths.clear();
+}
+
+void BCAData::Create(const std::string &FN)
+{
+    Close();
+    m_f = fopen(FN.c_str(), "wb");
+    if (!m_f) throw std::runtime_error("BCAData::Create: cannot create " + FN);
+    const uint32_t Magic = BCA_MAGIC;
+    const uint64_t Placeholder = 0;
+    fwrite(&Magic, 4, 1, m_f);
+    for (int k = 0; k < 3; ++k) fwrite(&Placeholder, 8, 1, m_f);
+    m_Writing = true;
+}
+
+void BCAData::WriteChain(const PDBChain &Chain)
+{
+    if (!m_f || !m_Writing) throw std::runtime_error("BCAData::WriteChain: not open for writing");
+    const uint L = Chain.GetSeqLength();
+    m_Labels.push_back(Chain.m_Label);
+    m_SeqLengths.push_back(L);
+    std::vector<uint16_t> ICs(3 * (size_t) L);
+    for (uint i = 0; i < L; ++i) {                                   // PDBChain::CoordToIC pdbchain.h:89: uint16((X + 1000)*10 + 0.5)
+        ICs[3 * i] = uint16_t((Chain.m_Xs[i] + 1000) * 10 + 0.5);
+        ICs[3 * i + 1] = uint16_t((Chain.m_Ys[i] + 1000) * 10 + 0.5);
+        ICs[3 * i + 2] = uint16_t((Chain.m_Zs[i] + 1000) * 10 + 0.5);
+    }
+    fwrite(Chain.m_Seq.data(), 1, L, m_f);
+    fwrite(ICs.data(), 2, 3 * (size_t) L, m_f);
+}
+
+void ReadMuFasta(const std::string &FN, std::vector<std::string> &Labels, std::vector<std::vector<byte> > &Seqs)
+{
+    FILE *f = fopen(FN.c_str(), "r");
+    if (!f) throw std::runtime_error("ReadMuFasta: cannot open " + FN);
+    byte lut[256];
+    memset(lut, 0xFF, sizeof(lut));
+    static const char MuChars[] = "ABCDEFGHIJLKMNOPQRSTUVWXYZabcdefghij";   // g_LetterToCharMu alpha.cpp:3550 (L before K)
+    for (int i = 0; i < 36; ++i) lut[(unsigned char) MuChars[i]] = (byte) i;
+    Labels.clear();
+    Seqs.clear();
+    std::vector<char> buf(1 << 16);
+    std::string line;
+    for (;;) {
+        if (!fgets(buf.data(), (int) buf.size(), f)) break;
+        line = buf.data();
+        while (!line.empty() && (line.back() == '\n' || line.back() == '\r')) line.pop_back();
+        if (line.empty()) continue;
+        if (line[0] == '>') { Labels.push_back(line.substr(1)); Seqs.emplace_back(); continue; }
+        if (Seqs.empty()) { fclose(f); throw std::runtime_error("ReadMuFasta: sequence data before the first label"); }
+        for (char c : line) {
+            const byte l = lut[(unsigned char) c];
+            if (l == 0xFF) { fclose(f); throw std::runtime_error("ReadMuFasta: invalid Mu character"); }
+            Seqs.back().push_back(l);
+        }
+    }
+    fclose(f);
 }
 
 void BCAData::ReadChain(uint64_t ChainIdx, PDBChain &Chain)
@@ -480,6 +549,54 @@ extern "C" int rsk_bca_read_chain(const char *path, uint64_t idx, char *label, s
         if (z) memcpy(z, C.m_Zs.data(), 4 * (size_t) n);
     } catch (const std::exception &e) {
         rsk_set_error("rsk_bca_read_chain: %s", e.what());
+        return RSK_E_INVALID;
+    }
+    return RSK_OK;
+}
+
+extern "C" int rsk_bca_copy(const char *in_bca, const char *out_bca)
+{
+    if (!in_bca || !out_bca) { rsk_set_error("rsk_bca_copy: NULL argument"); return RSK_E_INVALID; }
+    try {
+        BCAData In, Out;
+        In.Open(in_bca);
+        Out.Create(out_bca);
+        PDBChain C;
+        for (uint64_t k = 0; k < In.GetChainCount(); ++k) { In.ReadChain(k, C); Out.WriteChain(C); }
+        Out.Close();
+    } catch (const std::exception &e) {
+        rsk_set_error("rsk_bca_copy: %s", e.what());
+        return RSK_E_INVALID;
+    }
+    return RSK_OK;
+}
+
+extern "C" int rsk_bca_to_mu_fasta(const char *in_bca, const char *out_fasta)
+{
+    if (!in_bca || !out_fasta) { rsk_set_error("rsk_bca_to_mu_fasta: NULL argument"); return RSK_E_INVALID; }
+    try {
+        BCAData In;
+        In.Open(in_bca);
+        FILE *f = fopen(out_fasta, "w");
+        if (!f) throw std::runtime_error(std::string("cannot create ") + out_fasta);
+        PDBChain C;
+        DSS D;
+        std::vector<byte> Mu;
+        for (uint64_t k = 0; k < In.GetChainCount(); ++k) {
+            In.ReadChain(k, C);
+            const uint L = C.GetSeqLength();
+            if (L == 0) continue;                                    // SeqToFasta sfasta.cpp:10-11
+            D.Init(C);
+            D.GetMuLetters(Mu);
+            fprintf(f, ">%s\n", C.m_Label.c_str());
+            for (uint From = 0; From < L; From += 80) {              // ROWLEN 80 (myutils.h:380)
+                for (uint Pos = From; Pos < std::min(L, From + 80); ++Pos) fputc(Mu[Pos] < 26 ? 'A' + Mu[Pos] : 'a' + (Mu[Pos] - 26), f);
+                fputc('\n', f);
+            }
+        }
+        fclose(f);
+    } catch (const std::exception &e) {
+        rsk_set_error("rsk_bca_to_mu_fasta: %s", e.what());
         return RSK_E_INVALID;
     }
     return RSK_OK;

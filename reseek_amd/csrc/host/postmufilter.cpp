@@ -32,8 +32,27 @@ void MuPreFilter(const DSSParams &Params, DBSearcher &QDB, DBSearcher &TDB, cons
     rsk_ctx *ctx = QDB.m_Ctx;
     if (!ctx) throw std::runtime_error("MuPreFilter: no GPU context");
     TDB.m_Ctx = ctx;
-    TDB.UploadToGpu();
-    const uint NQ = QDB.GetDBChainCount(), NT = TDB.GetDBChainCount();
+    const uint NQ = QDB.GetDBChainCount();
+    // target letters: the DB chains' own Mu letters (MuSeqSource::OpenChains, m_ASCII = false) or, with -dbmu,
+    // a Mu FASTA read through g_CharToLetterMu (MuSeqSource::OpenFasta museqsource.cpp:21-30, search.cpp:93-96)
+    rsk_db *tdb = nullptr;
+    struct tdb_guard { rsk_db *d = nullptr; ~tdb_guard() { if (d) rsk_db_destroy(d); } } tguard;
+    uint NT;
+    if (!QDB.m_Opts.dbmu.empty()) {
+        std::vector<std::string> TLabels;
+        std::vector<std::vector<byte> > TSeqs;
+        ReadMuFasta(QDB.m_Opts.dbmu, TLabels, TSeqs);
+        NT = (uint) TSeqs.size();
+        std::vector<uint32_t> tlen(NT);
+        std::vector<uint8_t> tmu;
+        for (uint i = 0; i < NT; ++i) { tlen[i] = (uint32_t) TSeqs[i].size(); tmu.insert(tmu.end(), TSeqs[i].begin(), TSeqs[i].end()); }
+        check(rsk_db_create(ctx, NT, tlen.data(), tmu.data(), nullptr, nullptr, nullptr, nullptr, nullptr, &tdb), "rsk_db_create");
+        tguard.d = tdb;
+    } else {
+        TDB.UploadToGpu();
+        tdb = TDB.m_Db;
+        NT = TDB.GetDBChainCount();
+    }
     // Query letters as cmd_search hands them over (search.cpp:91-98): MuSeqSource writes the query chains
     // as text with 'A' + letter (museqsource.cpp:45-53, pdbchain.cpp:70), SeqDB::ToLetters reads the text
     // back through g_CharToLetterMu, whose table has L = 10 and K = 11 (alpha.cpp:3291) -- so the QUERY side
@@ -59,7 +78,7 @@ void MuPreFilter(const DSSParams &Params, DBSearcher &QDB, DBSearcher &TDB, cons
         hipok(hipMalloc((void **) &d_t, std::max<size_t>(cap, 1) * 4), "hipMalloc");
         hipok(hipMalloc((void **) &d_s, std::max<size_t>(cap, 1) * 4), "hipMalloc");
         hipok(hipMalloc((void **) &d_n, 4), "hipMalloc");
-        const int rc = rsk_mu_prefilter_dev(ctx, qdb, TDB.m_Db, QDB.m_Opts.idx_mode, d_q, d_t, d_s, cap, d_n);
+        const int rc = rsk_mu_prefilter_dev(ctx, qdb, tdb, QDB.m_Opts.idx_mode, d_q, d_t, d_s, cap, d_n);
         uint32_t n = 0;
         if (rc == RSK_OK) hipok(hipMemcpy(&n, d_n, 4, hipMemcpyDeviceToHost), "copy n");
         if (rc == RSK_OK && n <= cap) {

@@ -54,6 +54,8 @@ struct SearchOptions {
     bool pvalue_set = false;  double pvalue = -1;      // -pvalue (PostMuFilter Accept, postmufilter.cpp:106-115)
     int idx_mode = -1;                                 // -idxq (1) / -idxt (2); -1 = by query count (muprefilter.cpp:78-87)
     uint rsb_size = 1500;                              // -rsb_size (prefiltermuparams.h:15)
+    std::string dbmu;                                  // -dbmu: Mu FASTA of the DB for the prefilter stage (search.cpp:93-96)
+    bool keeptmp = false;                              // -keeptmp
     size_t batch_pairs = 1u << 16;                     // pairs per GPU alignment batch (bounds the trace memory)
 };
 
@@ -127,11 +129,17 @@ public:
     std::vector<uint32_t> m_SeqLengths;
     std::mutex m_ReadLock;
     ~BCAData() { Close(); }
+    bool m_Writing = false;
     void Open(const std::string &FN);
     void Close();
     uint64_t GetChainCount() const { return m_SeqLengths.size(); }
     void ReadChain(uint64_t ChainIdx, PDBChain &Chain);
+    void Create(const std::string &FN);                 // bcadata.cpp:15
+    void WriteChain(const PDBChain &Chain);             // bcadata.cpp:34
 };
+// Mu FASTA: letters are written as 'A' + letter (pdbchain.cpp:70) and read back through g_CharToLetterMu
+// (alpha.cpp:3291: 'L' -> 10, 'K' -> 11), exactly as the reference does.
+void ReadMuFasta(const std::string &FN, std::vector<std::string> &Labels, std::vector<std::vector<byte> > &Seqs);
 
 class DSSAligner;
 

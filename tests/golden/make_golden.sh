@@ -96,5 +96,18 @@ $H prefhood $TMP/sub80.mu.fa $TMP/sub1000.mu.fa $TMP/h80t_scores.tsv $TMP/h80t_t
 $H prefhood $TMP/sub1000.mu.fa $TMP/sub1000.mu.fa $TMP/h1000_scores.tsv $TMP/h1000_tmp.tsv -- -fast -threads 1
 for n in h80 h80t; do LC_ALL=C sort $TMP/${n}_scores.tsv | gzip -9n > $G/prefilter_hood_${n}_scores.tsv.gz; gzip -9n < $TMP/${n}_tmp.tsv > $G/prefilter_hood_${n}_tmp.tsv.gz; done
 LC_ALL=C sort $TMP/h1000_scores.tsv | gzip -9n > $G/prefilter_hood_h1000_scores.tsv.gz
+# 9. -convert (Mu FASTA, .bca round trip) and -dbmu
+$R -convert $T/q100.bca -feature_fasta $TMP/q100.mu.fa -threads 1 -quiet >/dev/null 2>&1
+gzip -9n < $TMP/q100.mu.fa > $G/q100_convert.mu.fa.gz
+$R -convert $T/q10.bca -bca $TMP/q10_rt.bca -threads 1 -quiet >/dev/null 2>&1
+cmp $TMP/q10_rt.bca $T/q10.bca          # the reference's own writer reproduces its test file
+mkdir -p $TMP/kt2
+TMPDIR=$TMP/kt2 $R -search $T/q100.bca -db $T/q100.bca -fast -dbmu $TMP/q100.mu.fa -columns $COLS -output $TMP/q100fast_dbmu.tsv -threads 1 -keeptmp -quiet >/dev/null 2>&1
+sort $TMP/q100fast_dbmu.tsv | gzip -9n > $G/hits_q100_db_q100_fast_dbmu.tsv.gz
+gzip -9n < $TMP/kt2/rce.*.tmp > $G/prefilter_q100_db_q100_fast_dbmu_tmp.tsv.gz
+for f in q10 q100 palms; do gzip -9n < $T/$f.bca > $G/$f.bca.gz; done
+# 10. D1 leftovers on real chains
+$H d1pairs $T/q100.bca $TMP/d1pairs_q40.bin 40 -- -sensitive
+gzip -9n < $TMP/d1pairs_q40.bin > $G/d1pairs_q40_sensitive.bin.gz
 rm -rf $TMP
 ls -la $G

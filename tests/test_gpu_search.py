@@ -140,3 +140,29 @@ def test_bca_input_long_chains(ctx, tmpdir):
 def test_bca_input_db_modes(ctx, tmpdir):
     run_bca(ctx, tmpdir, "q100.bca", "sensitive", COLS, "hits_q100_db_q100_sensitive.tsv.gz", db="q100.bca")
     run_bca(ctx, tmpdir, "q100.bca", "fast", COLS, "hits_q100_db_q100_fast.tsv.gz", db="q100.bca")
+
+
+def test_bca_fast_db_with_dbmu_and_options(ctx, tmpdir):
+    """-dbmu (prefilter targets from the Mu FASTA that `-convert -feature_fasta` wrote; both sides then see the
+    exchanged letters 10/11, so candidates and hits differ from the run without -dbmu -- as in the reference),
+    plus -keeptmp and -rsb_size through the options struct."""
+    from reseek_amd import capi
+    q = unpack_bca("q100.bca", tmpdir)
+    fa = os.path.join(tmpdir, "q100_dbmu.mu.fa")
+    capi.bca_to_mu_fasta(q, fa)
+    out = os.path.join(tmpdir, "out_dbmu.tsv")
+    nhits, st = ctx.search(q, out, "fast", db=q, columns=COLS, dbmu=fa, keeptmp=1)
+    want = ["\t".join(r) for r in fx.read_tsv("hits_q100_db_q100_fast_dbmu.tsv.gz")]
+    assert sorted(open(out).read().splitlines()) == want and nhits == len(want)
+    want_tmp = gzip.open(os.path.join(fx.GOLDEN, "prefilter_q100_db_q100_fast_dbmu_tmp.tsv.gz")).read().decode()
+    assert open(out + ".prefilter.tmp").read() == want_tmp
+    # a tiny bag keeps fewer candidates
+    out2 = os.path.join(tmpdir, "out_rsb5.tsv")
+    n2, st2 = ctx.search(q, out2, "fast", db=q, rsb_size=5)
+    assert st2[0] <= 5 * 100 and 0 < n2 <= nhits
+    # -evalue through the struct == through the positional API
+    out3 = os.path.join(tmpdir, "out_e.tsv")
+    n3, _ = ctx.search(q, out3, "sensitive", evalue=1e-3, columns=COLS)
+    out4 = os.path.join(tmpdir, "out_e2.tsv")
+    n4, _ = ctx.search_rskdb(q, out4, "sensitive", columns=COLS, evalue=1e-3)
+    assert n3 == n4 and sorted(open(out3).read().splitlines()) == sorted(open(out4).read().splitlines())

@@ -51,3 +51,18 @@ def test_bca_errors(bca_dir):
         capi.bca_info(junk)
     with pytest.raises(capi.RskError):
         capi.bca_read_chain(os.path.join(bca_dir, "q10.bca"), 10)
+
+
+def test_bca_writer_and_mu_fasta_match_convert(bca_dir):
+    """`reseek -convert`: the BCAData writer reproduces the reference's own files byte for byte, and the Mu FASTA
+    equals `-convert q100.bca -feature_fasta` of the reference binary."""
+    from reseek_amd import capi
+    for name in ("q10", "q100", "palms"):
+        src = os.path.join(bca_dir, name + ".bca")
+        dst = os.path.join(bca_dir, name + "_copy.bca")
+        capi.bca_copy(src, dst)
+        assert open(dst, "rb").read() == open(src, "rb").read()
+    fa = os.path.join(bca_dir, "q100.mu.fa")
+    capi.bca_to_mu_fasta(os.path.join(bca_dir, "q100.bca"), fa)
+    want = gzip.open(os.path.join(fx.GOLDEN, "q100_convert.mu.fa.gz")).read()
+    assert open(fa, "rb").read() == want
