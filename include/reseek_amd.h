@@ -167,6 +167,19 @@ int rsk_mu_filter_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, const ui
                         size_t npairs, int gap_open, int gap_ext, float omega, float omega_fwd, uint8_t *pass,
                         int32_t *fwd, int32_t *rev);
 
+/* ---- P9 (first half): seeding stage of the long-chain MKF path -----------------------------------------
+ * MuKmerFilter::SetHashTable (mukmerfilter.cpp:208) + the seed loop of MuKmerFilter::Align (:316-389) with
+ * MuXDrop (:105).  found[p] = 1 iff some seed HSP of pair p scores >= min_hsp_score (m_MKF_MinHSPScore, 50);
+ * for those pairs a record is appended (any order): rec_pair = p, rec_nkept = number of HSPs the reference
+ * keeps (strictly improving score, new Loi, in (PosT, slot) order), rec_kept[r*cap*4 ...] = their
+ * (Loi, Loj, Len, Score), at most cap (<= 32) stored; a count > cap is an upper bound (redo that pair
+ * with the host path).  *nrecords may exceed max_records (then enlarge and
+ * call again).  x1 = m_MKF_X1 (8).  Chaining and the gapped float X-drop of the found pairs stay in
+ * host/dssaligner.cpp. */
+int rsk_mkf_seed_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, const uint32_t *iq, const uint32_t *it,
+                       size_t npairs, int x1, int min_hsp_score, uint32_t cap, uint8_t *found, size_t max_records,
+                       size_t *nrecords, uint32_t *rec_pair, uint32_t *rec_nkept, int32_t *rec_kept);
+
 /* ---- P10/P11/P12: Mu k-mer prefilter ----------------------------------------------------------------
  * Batch form of MuDex::FromSeqDB (mudex.cpp:386; index of the QUERY set, built once and cached in q)
  * + PrefilterMu::Search over every target (prefiltermu.cpp:382): spaced 5-of-7 k-mers, self-score

@@ -668,6 +668,52 @@ static void cmd_d1pairs(const string &InFN, const string &OutFN, uint MaxChains)
 	fprintf(stderr, "d1pairs: %u chains -> %s\n", N, OutFN.c_str());
 	}
 
+// MKF seeding known answers: MuKmerFilter::SetQ(A) + Align(B) (mukmerfilter.cpp:234,316) for all ordered pairs of
+// the first N chains: kept seed HSPs and the chain.  "RSKMF1\0\0", u32 N; per pair: u32 nkept, nkept x (i32 Loi,
+// Loj, Len, Score), i32 BestChainScore, u32 nchain, nchain x (i32 Loi, Loj, Len).
+#include "mukmerfilter.h"
+static void cmd_mkfkat(const string &InFN, const string &OutFN, uint MaxChains)
+	{
+	DSSParams Params;
+	Params.SetDSSParams(DM_UseCommandLineOption);
+	vector<ChainData *> CDs;
+	LoadChains(InFN, Params, CDs, MaxChains);
+	const uint N = SIZE(CDs);
+	FILE *f = fopen(OutFN.c_str(), "wb");
+	asserta(f != 0);
+	wbytes(f, "RSKMF1\0\0", 8);
+	w32(f, N);
+	MuKmerFilter MKF;
+	MKF.SetParams(Params);
+	for (uint i = 0; i < N; ++i)
+		{
+		const ChainData &A = *CDs[i];
+		MKF.SetQ(A.Chain->m_Label, &A.Mu, &A.Kmers);
+		for (uint j = 0; j < N; ++j)
+			{
+			const ChainData &B = *CDs[j];
+			MKF.Align(B.Mu, B.Kmers);
+			const uint nk = SIZE(MKF.m_MuKmerHSPLois);
+			w32(f, nk);
+			for (uint k = 0; k < nk; ++k)
+				{
+				wi32(f, MKF.m_MuKmerHSPLois[k]); wi32(f, MKF.m_MuKmerHSPLojs[k]);
+				wi32(f, MKF.m_MuKmerHSPLens[k]); wi32(f, MKF.m_MuKmerHSPScores[k]);
+				}
+			wi32(f, MKF.m_BestChainScore);
+			const uint nc = SIZE(MKF.m_ChainHSPLois);
+			w32(f, nc);
+			for (uint k = 0; k < nc; ++k)
+				{
+				wi32(f, MKF.m_ChainHSPLois[k]); wi32(f, MKF.m_ChainHSPLojs[k]); wi32(f, MKF.m_ChainHSPLens[k]);
+				}
+			}
+		MKF.ResetQ();
+		}
+	fclose(f);
+	fprintf(stderr, "mkfkat: %u chains -> %s\n", N, OutFN.c_str());
+	}
+
 // The k-mer neighbourhood prefilter as cmd_search runs it (search.cpp:78-100 -> MuPreFilter
 // muprefilter.cpp:70), on Mu FASTA inputs: writes the (query, target, score) list of the
 // RankedScoresBag and the target-major hand-off TSV.  Mode: idxq | idxt | auto (via -idxq/-idxt after --).
@@ -725,6 +771,8 @@ int main(int argc, char **argv)
 		cmd_mukat(A[0], (uint) atoi(A[1].c_str()), (uint) atoi(A[2].c_str()), A[3]);
 	else if (Cmd == "randkat" && A.size() == 3)
 		cmd_randkat(strtoull(A[0].c_str(), 0, 0), (uint) atoi(A[1].c_str()), A[2]);
+	else if (Cmd == "mkfkat" && A.size() == 3)
+		cmd_mkfkat(A[0], A[1], (uint) atoi(A[2].c_str()));
 	else if (Cmd == "d1pairs" && A.size() == 3)
 		cmd_d1pairs(A[0], A[1], (uint) atoi(A[2].c_str()));
 	else if (Cmd == "prefhood" && A.size() == 4)

@@ -62,6 +62,8 @@ SIGNATURES["rsk_mu_prefilter_dev"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void
 SIGNATURES["rsk_dss_featurize"] = (C.c_int, [C.c_char_p, f32p, f32p, f32p, C.c_uint32, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8)])
 SIGNATURES["rsk_bca_info"] = (C.c_int, [C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), u32p, u32p])
 SIGNATURES["rsk_bca_read_chain"] = (C.c_int, [C.c_char_p, C.c_uint64, C.c_char_p, C.c_size_t, C.c_char_p, f32p, f32p, f32p, C.c_uint32, u32p])
+SIGNATURES["rsk_mkf_seed_pairs"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, u32p, u32p, C.c_size_t, C.c_int, C.c_int, C.c_uint32,
+                                              C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_size_t), u32p, u32p, C.POINTER(C.c_int32)])
 SIGNATURES["rsk_mu_pinop_pairs"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, u32p, u32p, C.c_size_t, C.c_int, C.c_int,
                                               C.POINTER(C.c_int32)])
 SIGNATURES["rsk_mu_gapless_profb_pairs"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, u32p, u32p, C.c_size_t, C.POINTER(C.c_float)])
@@ -222,6 +224,24 @@ class Ctx:
         return n.value, list(st)
 
     # ---- P10-P12 k-mer prefilter ---------------------------------------------------------------------
+    def mkf_seed_pairs(self, q, t, iq, it, x1=8, min_hsp_score=50, cap=16, max_records=None):
+        """-> (found uint8[n], {pair index: (nkept, kept int32 [min(nkept, cap), 4])})"""
+        iq = np.ascontiguousarray(iq, np.uint32)
+        it = np.ascontiguousarray(it, np.uint32)
+        n = len(iq)
+        mr = max_records if max_records is not None else max(n, 1)
+        found = np.zeros(n, np.uint8)
+        rp = np.zeros(mr, np.uint32)
+        rn = np.zeros(mr, np.uint32)
+        rk = np.zeros((mr, cap, 4), np.int32)
+        nrec = C.c_size_t()
+        _check(lib().rsk_mkf_seed_pairs(self.h, q.h, t.h, iq.ctypes.data_as(u32p), it.ctypes.data_as(u32p), n, x1, min_hsp_score, cap,
+                                        found.ctypes.data_as(C.POINTER(C.c_uint8)), mr, C.byref(nrec), rp.ctypes.data_as(u32p),
+                                        rn.ctypes.data_as(u32p), rk.ctypes.data_as(C.POINTER(C.c_int32))))
+        assert nrec.value <= mr
+        recs = {int(rp[r]): (int(rn[r]), rk[r, :min(int(rn[r]), cap)].copy()) for r in range(nrec.value)}
+        return found, recs
+
     def mu_pinop_pairs(self, q, t, iq, it, open_=-2, ext=-1):
         iq = np.ascontiguousarray(iq, np.uint32)
         it = np.ascontiguousarray(it, np.uint32)

@@ -11,9 +11,12 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <thread>
+#include <unordered_map>
 
 #include "reseek_host.h"
 
@@ -308,8 +311,87 @@ static void AlignAndReplay(DBSearcher &S, rsk_ctx *ctx, DBSearcher &SrcA, DBSear
 }
 
 // Shared body of RunSelf / RunQuery: A-side chains come from SrcA, B-side from *this.
+void RunMKFPairs(rsk_ctx *Ctx, const DSSParams &P, const std::string &Columns, DBSearcher &SrcA, DBSearcher &SrcB,
+                 const std::vector<std::pair<uint32_t, uint32_t> > &Pairs, const std::function<void(DSSAligner &, uint, uint)> &OnHit)
+{
+    const size_t n = Pairs.size();
+    if (n == 0) return;
+    const uint32_t CAP = 32;
+    // records of the pairs that have a seed HSP (everything else has no alignment: mukmerfilter.cpp:387, dssaligner.cpp:1397)
+    struct Rec { uint32_t pair, nkept; std::vector<int32_t> kept; };
+    std::vector<Rec> recs;
+    const size_t BATCH = 1u << 22;
+    for (size_t b = 0; b < n; b += BATCH) {
+        const size_t m = std::min(n, b + BATCH) - b;
+        std::vector<uint32_t> iq(m), it(m);
+        for (size_t k = 0; k < m; ++k) { iq[k] = Pairs[b + k].first; it[k] = Pairs[b + k].second; }
+        std::vector<uint8_t> found(m);
+        size_t maxrec = std::max<size_t>(1024, m / 16), nrec = 0;
+        std::vector<uint32_t> rp, rn;
+        std::vector<int32_t> rk;
+        for (;;) {
+            rp.resize(maxrec); rn.resize(maxrec); rk.resize(maxrec * CAP * 4);
+            check(rsk_mkf_seed_pairs(Ctx, SrcA.m_Db, SrcB.m_Db, iq.data(), it.data(), m, P.m_MKF_X1, P.m_MKF_MinHSPScore, CAP, found.data(), maxrec,
+                                     &nrec, rp.data(), rn.data(), rk.data()),
+                  "rsk_mkf_seed_pairs");
+            if (nrec <= maxrec) break;
+            maxrec = nrec;
+        }
+        for (size_t r = 0; r < nrec; ++r) {
+            Rec R;
+            R.pair = (uint32_t) (b + rp[r]);
+            R.nkept = rn[r];
+            R.kept.assign(rk.begin() + r * CAP * 4, rk.begin() + r * CAP * 4 + 4 * (size_t) std::min(rn[r], CAP));
+            recs.push_back(std::move(R));
+        }
+    }
+    std::sort(recs.begin(), recs.end(), [](const Rec &x, const Rec &y) { return x.pair < y.pair; });
+    const unsigned T = (unsigned) std::max<size_t>(1, std::min<size_t>({ (size_t) std::thread::hardware_concurrency(), (size_t) 64, recs.size() / 16 + 1 }));
+    std::atomic<size_t> next{0};
+    std::mutex lock;
+    auto body = [&]() {
+        DSSAligner DA;
+        DA.SetParams(P);
+        DA.SetColumns(Columns);
+        for (;;) {
+            const size_t r = next.fetch_add(1);
+            if (r >= recs.size()) break;
+            const Rec &R = recs[r];
+            const uint i = Pairs[R.pair].first, j = Pairs[R.pair].second;
+            DA.SetQuery(*SrcA.m_DBChains[i], SrcA.m_DBProfiles[i], SrcA.m_DBMuLettersVec[i], SrcA.m_DBMuKmersVec[i], SrcA.m_DBSelfRevScores[i]);
+            DA.SetTarget(*SrcB.m_DBChains[j], SrcB.m_DBProfiles[j], SrcB.m_DBMuLettersVec[j], SrcB.m_DBMuKmersVec[j], SrcB.m_DBSelfRevScores[j]);
+            if (R.nkept > CAP) DA.AlignMKF();                             // list truncated on the device: full host path
+            else DA.AlignMKF_FromSeeds(R.kept.data(), R.nkept);
+            std::lock_guard<std::mutex> g(lock);
+            OnHit(DA, i, j);
+        }
+        DA.UnsetQuery();
+    };
+    if (T == 1) body();
+    else {
+        std::vector<std::thread> ts;
+        for (unsigned t = 0; t < T; ++t) ts.emplace_back(body);
+        for (auto &t : ts) t.join();
+    }
+}
+
+namespace {
+struct PhaseTimer {                              // RSK_TRACE=1: wall time of the driver's phases on stderr
+    bool on = getenv("RSK_TRACE") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void lap(const char *what)
+    {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[RunPairs] %-22s %9.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+}   // namespace
+
 static void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self)
 {
+    PhaseTimer tm;
     const DSSParams &P = *S.m_Params;
     rsk_ctx *ctx = S.m_Ctx;
     const uint NA = SrcA.GetDBChainCount(), NB = S.GetDBChainCount();
@@ -358,11 +440,37 @@ static void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self)
             if (Skip(i, j) || IsMKF(i, j)) continue;
             ia.push_back(i); ib.push_back(j);
         }
-        for (uint i = 0; i < NA; ++i)
-            for (uint j = Self ? i : 0; j < NB; ++j) {
-                if (Skip(i, j)) { ++nskip; continue; }
-                if (IsMKF(i, j)) { mkf.emplace_back(i, j); ++nmkf; }
+        // MKF pairs = either chain >= m_MKFL (both with k-mers): enumerated from the list of long chains,
+        // not by walking the whole pair space
+        std::vector<uint32_t> longB;
+        for (uint j = 0; j < NB; ++j)
+            if (!S.m_DBMuKmersVec[j]->empty() && S.m_DBChains[j]->GetSeqLength() >= P.m_MKFL) longB.push_back(j);
+        for (uint i = 0; i < NA; ++i) {
+            if (SrcA.m_DBMuKmersVec[i]->empty()) continue;
+            const uint j0 = Self ? i : 0;
+            if (SrcA.m_DBChains[i]->GetSeqLength() >= P.m_MKFL) {
+                for (uint j = j0; j < NB; ++j) {
+                    if (S.m_DBMuKmersVec[j]->empty() || Skip(i, j)) continue;
+                    mkf.emplace_back(i, j); ++nmkf;
+                }
+            } else {
+                for (auto it = std::lower_bound(longB.begin(), longB.end(), j0); it != longB.end(); ++it) {
+                    if (Skip(i, *it)) continue;
+                    mkf.emplace_back(i, *it); ++nmkf;
+                }
             }
+        }
+        if (S.m_Opts.noself) {
+            if (Self) nskip = NA;
+            else {
+                std::unordered_map<std::string, uint32_t> cntB;
+                for (uint j = 0; j < NB; ++j) ++cntB[S.m_DBChains[j]->m_Label];
+                for (uint i = 0; i < NA; ++i) {
+                    auto it = cntB.find(SrcA.m_DBChains[i]->m_Label);
+                    if (it != cntB.end()) nskip += it->second;
+                }
+            }
+        }
         npairs = total - nskip;
         S.m_MKFPairCount = nmkf;
         S.m_MuFilterInputCount = npairs - nmkf;
@@ -377,51 +485,24 @@ static void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self)
     }
     S.m_ProcessedPairCount = npairs;
     S.m_AlnCount = npairs - mkf.size();
+    tm.lap("filter + pair lists");
     const size_t B = std::max<size_t>(1, S.m_Opts.batch_pairs);
     for (size_t b = 0; b < ia.size(); b += B) {
         const size_t e = std::min(ia.size(), b + B);
         AlignAndReplay(S, ctx, SrcA, S, std::vector<uint32_t>(ia.begin() + b, ia.begin() + e), std::vector<uint32_t>(ib.begin() + b, ib.begin() + e), Self);
     }
+    tm.lap("align + replay");
     // long-chain pairs: host MKF path (dssaligner.cpp:809-813), one aligner per host thread as in the
     // reference (dbsearcher.cpp:98-106); BaseOnAln serialises the output under m_Lock.
-    if (!mkf.empty()) {
-        const unsigned T = (unsigned) std::max<size_t>(1, std::min<size_t>({ (size_t) std::thread::hardware_concurrency(), (size_t) 64, mkf.size() / 64 + 1 }));
-        std::atomic<size_t> next{0};
-        const size_t CH = 64;
-        auto body = [&]() {
-            DSSAligner DA;
-            DA.SetParams(P);
-            DA.SetColumns(S.m_Opts.columns);
-            uint prev = UINT_MAX;
-            for (;;) {
-                const size_t b = next.fetch_add(CH);
-                if (b >= mkf.size()) break;
-                const size_t e = std::min(mkf.size(), b + CH);
-                for (size_t k = b; k < e; ++k) {
-                    const uint i = mkf[k].first, j = mkf[k].second;
-                    if (i != prev) {
-                        DA.SetQuery(*SrcA.m_DBChains[i], SrcA.m_DBProfiles[i], SrcA.m_DBMuLettersVec[i], SrcA.m_DBMuKmersVec[i], SrcA.m_DBSelfRevScores[i]);
-                        prev = i;
-                    }
-                    DA.SetTarget(*S.m_DBChains[j], S.m_DBProfiles[j], S.m_DBMuLettersVec[j], S.m_DBMuKmersVec[j], S.m_DBSelfRevScores[j]);
-                    DA.AlignMKF();
-                    if (DA.m_Path.empty()) continue;
-                    if (Self) {
-                        S.BaseOnAln(DA, true);
-                        if (i != j) S.BaseOnAln(DA, false);
-                    } else
-                        S.BaseOnAln(DA, false);
-                }
-            }
-            DA.UnsetQuery();
-        };
-        if (T == 1) body();
-        else {
-            std::vector<std::thread> ts;
-            for (unsigned t = 0; t < T; ++t) ts.emplace_back(body);
-            for (auto &t : ts) t.join();
-        }
-    }
+    RunMKFPairs(ctx, P, S.m_Opts.columns, SrcA, S, mkf, [&](DSSAligner &DA, uint i, uint j) {
+        if (DA.m_Path.empty()) return;
+        if (Self) {
+            S.BaseOnAln(DA, true);
+            if (i != j) S.BaseOnAln(DA, false);
+        } else
+            S.BaseOnAln(DA, false);
+    });
+    tm.lap("MKF (GPU seeds + host)");
 }
 
 void DBSearcher::RunSelf()

@@ -666,6 +666,27 @@ void DSSAligner::AlignMKF()
     PostAlignMKF();
 }
 
+void MuKmerFilter::SetSeedHSPs(const int32_t *Kept4, uint Count)
+{
+    m_MuKmerHSPLois.clear(); m_MuKmerHSPLojs.clear(); m_MuKmerHSPLens.clear(); m_MuKmerHSPScores.clear();
+    m_ChainHSPLois.clear(); m_ChainHSPLojs.clear(); m_ChainHSPLens.clear();
+    m_BestChainScore = 0;
+    m_BestHSPScore = 0;
+    for (uint k = 0; k < Count; ++k) {
+        m_MuKmerHSPLois.push_back(Kept4[4 * k]); m_MuKmerHSPLojs.push_back(Kept4[4 * k + 1]);
+        m_MuKmerHSPLens.push_back(Kept4[4 * k + 2]); m_MuKmerHSPScores.push_back(Kept4[4 * k + 3]);
+        m_BestHSPScore = std::max(m_BestHSPScore, (int) Kept4[4 * k + 3]);
+    }
+    if (Count) ChainHSPs();                               // FoundHSP (mukmerfilter.cpp:387-388)
+}
+
+void DSSAligner::AlignMKF_FromSeeds(const int32_t *Kept4, uint Count)
+{
+    ClearAlign();
+    m_MKF.SetSeedHSPs(Kept4, Count);
+    PostAlignMKF();
+}
+
 void DSSAligner::PostAlignMKF()
 {
     if (m_MKF.m_BestChainScore <= 0) return;

@@ -203,46 +203,11 @@ void PostMuFilter(const DSSParams &Params, const std::string &MuFilterTsvFN, DBS
             if (Accept(DA, MaxEvalue, MaxPvalue, MinTS)) { DA.ToTsv(fTsv, true); ++Q.m_HitCount; }
         }
     }
-    // long chains: MKF on the host (chainbag.cpp:58-65), one aligner per host thread (postmufilter.cpp:116)
-    if (!mkf.empty()) {
-        std::sort(mkf.begin(), mkf.end());
-        const unsigned T = (unsigned) std::max<size_t>(1, std::min<size_t>({ (size_t) std::thread::hardware_concurrency(), (size_t) 64, mkf.size() / 64 + 1 }));
-        std::atomic<size_t> next{0};
-        std::mutex out_lock;
-        const size_t CH = 64;
-        auto body = [&]() {
-            DSSAligner TA;
-            TA.SetParams(Params);
-            TA.SetColumns(O.columns);
-            uint prev = UINT_MAX;
-            for (;;) {
-                const size_t b = next.fetch_add(CH);
-                if (b >= mkf.size()) break;
-                const size_t e = std::min(mkf.size(), b + CH);
-                for (size_t k = b; k < e; ++k) {
-                    const uint i = mkf[k].first, j = mkf[k].second;
-                    if (i != prev) {
-                        TA.SetQuery(*Q.m_DBChains[i], Q.m_DBProfiles[i], Q.m_DBMuLettersVec[i], Q.m_DBMuKmersVec[i], Q.m_DBSelfRevScores[i]);
-                        prev = i;
-                    }
-                    TA.SetTarget(*DB.m_DBChains[j], DB.m_DBProfiles[j], DB.m_DBMuLettersVec[j], DB.m_DBMuKmersVec[j], DB.m_DBSelfRevScores[j]);
-                    TA.AlignMKF();
-                    if (Accept(TA, MaxEvalue, MaxPvalue, MinTS)) {
-                        std::lock_guard<std::mutex> g(out_lock);
-                        TA.ToTsv(fTsv, true);
-                        ++Q.m_HitCount;
-                    }
-                }
-            }
-            TA.UnsetQuery();
-        };
-        if (T == 1) body();
-        else {
-            std::vector<std::thread> ts;
-            for (unsigned t = 0; t < T; ++t) ts.emplace_back(body);
-            for (auto &t : ts) t.join();
-        }
-    }
+    // long chains: MKF (chainbag.cpp:58-65): seeding on the GPU, the rest on host threads
+    std::sort(mkf.begin(), mkf.end());
+    RunMKFPairs(ctx, Params, O.columns, Q, DB, mkf, [&](DSSAligner &TA, uint, uint) {
+        if (Accept(TA, MaxEvalue, MaxPvalue, MinTS)) { TA.ToTsv(fTsv, true); ++Q.m_HitCount; }
+    });
     fclose(fTsv);
 }
 

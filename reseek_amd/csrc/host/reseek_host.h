@@ -15,6 +15,7 @@
 #include <climits>
 #include <cstdint>
 #include <cstdio>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -160,6 +161,8 @@ public:
     void ResetQ();
     void SetQ(const std::string &LabelQ, const std::vector<byte> *ptrMuLettersQ, const std::vector<uint> *ptrMuKmersQ);
     void Align(const std::vector<byte> &MuLettersT, const std::vector<uint> &MuKmersT);
+    // the state Align() leaves when its seed loop kept these HSPs (computed by rsk_mkf_seed_pairs), then ChainHSPs()
+    void SetSeedHSPs(const int32_t *Kept4, uint Count);
     int MuXDrop(int PosQ, int LQ, int PosT, int LT, int X, int &Loi, int &Loj, int &Len) const;
     void ChainHSPs();
 };
@@ -204,6 +207,7 @@ public:
     void ClearAlign();                                  // dssaligner.cpp:906
     void AlignQueryTarget();                            // dssaligner.cpp:793 (one pair; batch of 1 on the GPU)
     void AlignMKF();                                    // dssaligner.cpp:1387
+    void AlignMKF_FromSeeds(const int32_t *Kept4, uint Count);   // same, seeding stage already done on the GPU
     void PostAlignMKF();                                // dssaligner.cpp:1395
     float GetMegaHSPScore(uint Lo_i, uint Lo_j, uint Len);   // dssaligner.cpp:488
     float SubstScore(uint PosA, uint PosB);             // xdrophsp.cpp:8
@@ -302,6 +306,12 @@ private:
 // candidates of its hand-off file are aligned under the "sensitive" preset.
 //   MuPreFilter  muprefilter.cpp:70   (query index + neighbourhoods, per-target scan, RankedScoresBag, ToTsv)
 //   PostMuFilter postmufilter.cpp:190 (per target line: AlignBags against each listed query, Accept, ToTsv)
+// The MKF path for a list of (A, B) pairs: seeding of every pair on the GPU (rsk_mkf_seed_pairs), chaining +
+// gapped X-drop + statistics of the pairs with a seed HSP on host threads; OnHit is called under a lock
+// for every pair that ends with an alignment (DA.m_Path non-empty is NOT required: the caller decides).
+void RunMKFPairs(rsk_ctx *Ctx, const DSSParams &Params, const std::string &Columns, DBSearcher &SrcA, DBSearcher &SrcB,
+                 const std::vector<std::pair<uint32_t, uint32_t> > &Pairs, const std::function<void(DSSAligner &, uint, uint)> &OnHit);
+
 void MuPreFilter(const DSSParams &Params, DBSearcher &QDB, DBSearcher &TDB, const std::string &OutputFN);
 void PostMuFilter(const DSSParams &Params, const std::string &MuFilterTsvFN, DBSearcher &Q, DBSearcher &DB,
                   const std::string &HitsFN);

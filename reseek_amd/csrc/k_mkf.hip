@@ -1,0 +1,230 @@
+// k_mkf.hip -- seeding stage of the long-chain path on gfx950 (first half):
+//   MuKmerFilter::SetHashTable mukmerfilter.cpp:208-225  query 3-mer table, first HASHW = 4 positions per k-mer
+//   MuKmerFilter::Align        mukmerfilter.cpp:316-389  for each target 3-mer, each stored query position:
+//                              MuXDrop :105-175 (ungapped X-drop on IntScoreMx_Mu, both directions);
+//                              HSPs with score >= MinHSPScore that STRICTLY improve on the best so far and
+//                              start at a new query position are kept, in (PosT, slot) order.
+// Every pair of the MKF path runs this stage; only the few pairs with a kept HSP go on to chaining and the
+// gapped float X-drop (host/dssaligner.cpp).  MI355X layout: one table per query chain that occurs in
+// the batch (373 KB each: a SCOP40-sized set is 4 GB of 288), one wave per pair: the lanes take 64
+// consecutive target positions, look up their four candidate query positions with one 8-byte load
+// and extend them; the order-dependent keep rule is resolved by walking the (rare) lanes that beat
+// the running best in lane order.  Integer work, L2-resident letters; bound: table-probe latency.
+#include <algorithm>
+#include <vector>
+
+#include "rsk_dev_tables.h"
+
+#define MKF_DICT 46656u            // 36^3
+#define MKF_HASHW 4
+#define MKF_WAVES 4
+
+// one workgroup per listed query: clear its table, then insert positions in order (first come, <= 4 per k-mer)
+__global__ __launch_bounds__(256) void k_mkf_build(const uint8_t *q_mu, const uint32_t *q_off, const uint32_t *q_len, const uint32_t *qlist,
+                                                   uint16_t *tables)
+{
+    const uint32_t q = qlist[blockIdx.x];
+    uint16_t *T = tables + (size_t) blockIdx.x * MKF_DICT * MKF_HASHW;
+    uint4 *T4 = (uint4 *) T;
+    const uint4 ff = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    for (uint32_t i = threadIdx.x; i < MKF_DICT * MKF_HASHW * 2 / 16; i += blockDim.x) T4[i] = ff;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint8_t *Q = q_mu + q_off[q];
+        const uint32_t L = q_len[q];
+        for (uint32_t p = 0; p + 3 <= L; ++p) {
+            const uint32_t k = ((uint32_t) Q[p] * 36 + Q[p + 1]) * 36 + Q[p + 2];
+            uint16_t *s = T + (size_t) k * MKF_HASHW;
+            for (int w = 0; w < MKF_HASHW; ++w)
+                if (s[w] == 0xFFFF) { s[w] = (uint16_t) p; break; }
+        }
+    }
+}
+
+__device__ __forceinline__ int mkf_xdrop(const uint8_t *Q, int LQ, const uint8_t *T, int LT, int PosQ, int PosT, int X, int &Loi, int &Loj,
+                                         int &Len)
+{
+    Loi = PosQ; Loj = PosT;
+    int i = PosQ, j = PosT, fs = 0, bf = 0, flen = 0;
+    while (i < LQ && j < LT) {
+        fs += c_mu_int[36 * Q[i++] + T[j++]];
+        if (fs > bf) { flen = i - PosQ; bf = fs; }
+        else if (fs + X < bf) break;
+    }
+    int rs = 0, br = 0, rlen = 0;
+    i = PosQ - 1; j = PosT - 1;
+    while (i >= 0 && j >= 0) {
+        rs += c_mu_int[36 * Q[i] + T[j]];
+        if (rs > br) { br = rs; Loi = i; Loj = j; rlen = PosQ - i; }
+        else if (rs + X < br) break;
+        --i; --j;
+    }
+    Len = flen + rlen;
+    return bf + br;
+}
+
+struct mkf_args {
+    const uint8_t *q_mu; const uint32_t *q_off; const uint32_t *q_len;
+    const uint8_t *t_mu; const uint32_t *t_off; const uint32_t *t_len;
+    const uint32_t *iq, *it;           // pairs
+    const uint32_t *qslot;             // table index of each pair's query
+    const uint16_t *tables;
+    uint32_t npairs;
+    int X, min_score;
+    uint32_t cap;                      // kept HSPs stored per record (<= MKF_CAP_MAX)
+    uint8_t *found;                    // per pair: any seed with score >= min_score
+    // compact records of the found pairs (appended with one atomic each)
+    uint32_t *nrec; uint32_t max_rec;
+    uint32_t *rec_pair, *rec_nkept;    // nkept may exceed cap: the list is then truncated and the host redoes the pair
+    int4 *rec_kept;                    // [max_rec][cap] (Loi, Loj, Len, Score)
+};
+#define MKF_CAP_MAX 32
+
+__global__ __launch_bounds__(64 * MKF_WAVES) void k_mkf_seed(mkf_args a)
+{
+    const uint32_t p = blockIdx.x * MKF_WAVES + (threadIdx.x >> 6);
+    if (p >= a.npairs) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t q = a.iq[p], t = a.it[p];
+    const uint8_t *Q = a.q_mu + a.q_off[q], *T = a.t_mu + a.t_off[t];
+    const int LQ = (int) a.q_len[q], LT = (int) a.t_len[t];
+    const uint16_t *tab = a.tables + (size_t) a.qslot[p] * MKF_DICT * MKF_HASHW;
+    __shared__ int4 skept[MKF_WAVES][MKF_CAP_MAX];
+    int4 *kept = skept[threadIdx.x >> 6];
+    int best = 0;
+    uint32_t nk = 0;
+    bool found = false;
+    for (int base = 0; base + 3 <= LT; base += 64) {
+        const int PosT = base + lane;
+        int sc[MKF_HASHW], loi[MKF_HASHW], loj[MKF_HASHW], len[MKF_HASHW];
+        int mx = 0;
+#pragma unroll
+        for (int w = 0; w < MKF_HASHW; ++w) sc[w] = 0;
+        if (PosT + 3 <= LT) {
+            const uint32_t k = ((uint32_t) T[PosT] * 36 + T[PosT + 1]) * 36 + T[PosT + 2];
+            const uint2 s = *(const uint2 *) (tab + (size_t) k * MKF_HASHW);
+            const uint32_t pos[4] = { s.x & 0xFFFFu, s.x >> 16, s.y & 0xFFFFu, s.y >> 16 };
+#pragma unroll
+            for (int w = 0; w < MKF_HASHW; ++w) {
+                if (pos[w] == 0xFFFFu) continue;
+                const int v = mkf_xdrop(Q, LQ, T, LT, (int) pos[w], PosT, a.X, loi[w], loj[w], len[w]);
+                if (v >= a.min_score) { sc[w] = v; mx = max(mx, v); }
+            }
+        }
+        if (__ballot(mx > 0)) found = true;
+        // lanes whose best candidate beats the running best, in lane (= PosT) order
+        unsigned long long m = __ballot(mx > best);
+        while (m) {
+            const int l = __builtin_ctzll(m);
+#pragma unroll
+            for (int w = 0; w < MKF_HASHW; ++w) {
+                const int v = __shfl(sc[w], l, 64);
+                if (v > best) {                                   // strictly improving (mukmerfilter.cpp:362)
+                    best = v;
+                    const int Li = __shfl(loi[w], l, 64), Lj = __shfl(loj[w], l, 64), Ln = __shfl(len[w], l, 64);
+                    // "Old" test: an HSP with this Loi was kept before (:364-371); the list is short
+                    bool old = false;
+                    for (uint32_t k = lane; k < min(nk, a.cap); k += 64) old |= kept[k].x == Li;
+                    if (!__ballot(old)) {
+                        if (lane == 0 && nk < a.cap) kept[nk] = make_int4(Li, Lj, Ln, v);
+                        ++nk;
+                        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                    }
+                }
+            }
+            m &= m - 1;
+            m &= __ballot(mx > best);                            // later lanes must still beat the new best
+        }
+    }
+    if (lane == 0) a.found[p] = found ? 1 : 0;
+    if (found) {
+        uint32_t r = 0;
+        if (lane == 0) r = atomicAdd(a.nrec, 1u);
+        r = (uint32_t) __shfl((int) r, 0, 64);
+        if (r < a.max_rec) {
+            if (lane == 0) { a.rec_pair[r] = p; a.rec_nkept[r] = nk; }
+            for (uint32_t k = lane; k < min(nk, a.cap); k += 64) a.rec_kept[(size_t) r * a.cap + k] = kept[k];
+        }
+    }
+}
+
+extern "C" int rsk_mkf_seed_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, const uint32_t *iq, const uint32_t *it, size_t npairs,
+                                  int x1, int min_hsp_score, uint32_t cap, uint8_t *found, size_t max_records, size_t *nrecords,
+                                  uint32_t *rec_pair, uint32_t *rec_nkept, int32_t *rec_kept)
+{
+    if (!ctx || !q || !t || (npairs && (!iq || !it || !found)) || !nrecords || cap == 0 || cap > MKF_CAP_MAX ||
+        (max_records && (!rec_pair || !rec_nkept || !rec_kept))) {
+        rsk_set_error("rsk_mkf_seed_pairs: bad argument (cap must be 1..%d)", MKF_CAP_MAX);
+        return RSK_E_INVALID;
+    }
+    if (!q->d_mu || !t->d_mu) { rsk_set_error("rsk_mkf_seed_pairs: chain set has no Mu letters"); return RSK_E_INVALID; }
+    *nrecords = 0;
+    if (npairs == 0) return RSK_OK;
+    if (npairs > 0x7FFFFFFFull || max_records > 0x7FFFFFFFull) { rsk_set_error("rsk_mkf_seed_pairs: too many pairs in one call"); return RSK_E_RANGE; }
+    for (size_t p = 0; p < npairs; ++p)
+        if (iq[p] >= q->n || it[p] >= t->n) { rsk_set_error("rsk_mkf_seed_pairs: pair %zu out of range", p); return RSK_E_INVALID; }
+    RSK_HIP(hipSetDevice(ctx->device));
+    int rc = rsk_upload_mu_tables(ctx);
+    if (rc != RSK_OK) return rc;
+    // distinct queries -> table slots
+    std::vector<uint32_t> slot_of(q->n, 0xFFFFFFFFu), qlist, qslot(npairs);
+    for (size_t p = 0; p < npairs; ++p) {
+        if (slot_of[iq[p]] == 0xFFFFFFFFu) { slot_of[iq[p]] = (uint32_t) qlist.size(); qlist.push_back(iq[p]); }
+        qslot[p] = slot_of[iq[p]];
+    }
+    struct ws_t {
+        rsk_ctx *ctx;
+        std::vector<void *> all;
+        ~ws_t() { for (void *p : all) rsk_pool_free(ctx, p); }
+    } ws{ ctx, {} };
+    auto dalloc = [&](void **p, size_t bytes) -> int {
+        int r = rsk_pool_alloc(ctx, p, std::max<size_t>(bytes, 16));
+        if (r != RSK_OK) return r;
+        ws.all.push_back(*p);
+        return RSK_OK;
+    };
+    uint32_t *d_iq, *d_it, *d_qslot, *d_qlist, *d_nrec, *d_rpair, *d_rnk;
+    uint16_t *d_tab;
+    uint8_t *d_found;
+    int4 *d_rkept;
+    if ((rc = dalloc((void **) &d_iq, npairs * 4)) != RSK_OK) return rc;
+    if ((rc = dalloc((void **) &d_it, npairs * 4)) != RSK_OK) return rc;
+    if ((rc = dalloc((void **) &d_qslot, npairs * 4)) != RSK_OK) return rc;
+    if ((rc = dalloc((void **) &d_qlist, qlist.size() * 4)) != RSK_OK) return rc;
+    if ((rc = dalloc((void **) &d_tab, qlist.size() * (size_t) MKF_DICT * MKF_HASHW * 2)) != RSK_OK) return rc;
+    if ((rc = dalloc((void **) &d_found, npairs)) != RSK_OK) return rc;
+    if ((rc = dalloc((void **) &d_nrec, 4)) != RSK_OK) return rc;
+    if ((rc = dalloc((void **) &d_rpair, max_records * 4)) != RSK_OK) return rc;
+    if ((rc = dalloc((void **) &d_rnk, max_records * 4)) != RSK_OK) return rc;
+    if ((rc = dalloc((void **) &d_rkept, max_records * (size_t) cap * sizeof(int4))) != RSK_OK) return rc;
+    RSK_HIP(hipMemcpyAsync(d_iq, iq, npairs * 4, hipMemcpyHostToDevice, ctx->stream));
+    RSK_HIP(hipMemcpyAsync(d_it, it, npairs * 4, hipMemcpyHostToDevice, ctx->stream));
+    RSK_HIP(hipMemcpyAsync(d_qslot, qslot.data(), npairs * 4, hipMemcpyHostToDevice, ctx->stream));
+    RSK_HIP(hipMemcpyAsync(d_qlist, qlist.data(), qlist.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    RSK_HIP(hipMemsetAsync(d_nrec, 0, 4, ctx->stream));
+    RSK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    hipLaunchKernelGGL(k_mkf_build, dim3((unsigned) qlist.size()), dim3(256), 0, ctx->stream, q->d_mu, q->d_off, q->d_len, d_qlist, d_tab);
+    mkf_args a = {};
+    a.q_mu = q->d_mu; a.q_off = q->d_off; a.q_len = q->d_len;
+    a.t_mu = t->d_mu; a.t_off = t->d_off; a.t_len = t->d_len;
+    a.iq = d_iq; a.it = d_it; a.qslot = d_qslot; a.tables = d_tab;
+    a.npairs = (uint32_t) npairs; a.X = x1; a.min_score = min_hsp_score; a.cap = cap;
+    a.found = d_found; a.nrec = d_nrec; a.max_rec = (uint32_t) max_records;
+    a.rec_pair = d_rpair; a.rec_nkept = d_rnk; a.rec_kept = d_rkept;
+    hipLaunchKernelGGL(k_mkf_seed, dim3((unsigned) ((npairs + MKF_WAVES - 1) / MKF_WAVES)), dim3(64 * MKF_WAVES), 0, ctx->stream, a);
+    RSK_HIP(hipGetLastError());
+    RSK_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    uint32_t nrec = 0;
+    RSK_HIP(hipMemcpyAsync(found, d_found, npairs, hipMemcpyDeviceToHost, ctx->stream));
+    RSK_HIP(hipMemcpyAsync(&nrec, d_nrec, 4, hipMemcpyDeviceToHost, ctx->stream));
+    RSK_HIP(hipStreamSynchronize(ctx->stream));
+    *nrecords = nrec;
+    const size_t m = std::min<size_t>(nrec, max_records);
+    if (m) {
+        RSK_HIP(hipMemcpyAsync(rec_pair, d_rpair, m * 4, hipMemcpyDeviceToHost, ctx->stream));
+        RSK_HIP(hipMemcpyAsync(rec_nkept, d_rnk, m * 4, hipMemcpyDeviceToHost, ctx->stream));
+        RSK_HIP(hipMemcpyAsync(rec_kept, d_rkept, m * (size_t) cap * sizeof(int4), hipMemcpyDeviceToHost, ctx->stream));
+        RSK_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return RSK_OK;
+}

@@ -135,6 +135,25 @@ def read_d1pairs(name):
     return n, rec["pb"].copy(), rec["g"].copy(), np.stack([rec["bi"], rec["bj"]], axis=-1)
 
 
+def read_mkfkat(name):
+    """-> (n, dict (i, j) -> (kept int32 [k, 4], best_chain_score, chain int32 [c, 3])); i = query, j = target."""
+    with _open(name) as f:
+        buf = f.read()
+    assert buf[:8] == b"RSKMF1\0\0"
+    (n,) = struct.unpack_from("<I", buf, 8)
+    p = 12
+    out = {}
+    for i in range(n):
+        for j in range(n):
+            (nk,) = struct.unpack_from("<I", buf, p); p += 4
+            kept = np.frombuffer(buf, np.int32, 4 * nk, p).reshape(nk, 4).copy(); p += 16 * nk
+            (bcs, nc) = struct.unpack_from("<iI", buf, p); p += 8
+            chain = np.frombuffer(buf, np.int32, 3 * nc, p).reshape(nc, 3).copy(); p += 12 * nc
+            out[(i, j)] = (kept, bcs, chain)
+    assert p == len(buf)
+    return n, out
+
+
 def read_tsv(name):
     with _open(name) as f:
         txt = f.read().decode()

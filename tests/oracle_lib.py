@@ -66,6 +66,8 @@ def lib():
         L.rsko_gapless_profb.argtypes = [u8p, C.c_int, u8p, C.c_int]
         L.rsko_gapless_float_pair.restype = C.c_float
         L.rsko_gapless_float_pair.argtypes = [u8p, C.c_int, u8p, C.c_int, u32p, u32p]
+        L.rsko_mkf_seed.restype = C.c_int
+        L.rsko_mkf_seed.argtypes = [u8p, C.c_int, u8p, C.c_int, C.c_int, C.c_int, C.c_int, i32p, C.POINTER(C.c_int)]
         L.rsko_prefilter.restype = C.c_size_t
         L.rsko_prefilter.argtypes = [u8p, u32p, C.c_uint32, u8p, u32p, C.c_uint32, u32p, u32p, u32p, C.c_size_t]
         L.rsko_prefilter_mode.restype = C.c_size_t
@@ -100,6 +102,14 @@ def mu_filter(A, B, omega_fwd, open_=2, ext=1):
     f, r = C.c_int32(), C.c_int32()
     s = lib().rsko_mu_filter(_p(A, u8p), len(A), _p(B, u8p), len(B), open_, ext, omega_fwd, C.byref(f), C.byref(r))
     return s, f.value, r.value
+
+
+def mkf_seed(Q, T, x1=8, min_score=50, cap=64):
+    """-> (found, nkept, kept int32 [min(nkept, cap), 4])"""
+    kept = np.zeros((cap, 4), np.int32)
+    found = C.c_int()
+    nk = lib().rsko_mkf_seed(_p(Q, u8p), len(Q), _p(T, u8p), len(T), x1, min_score, cap, _p(kept, i32p), C.byref(found))
+    return bool(found.value), nk, kept[:min(nk, cap)].copy()
 
 
 def gapless_profb(A, B):
