@@ -129,12 +129,21 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (librsk has no CPU fallback)")
+    # RSK_BENCH_ONE_DEVICE=1 (debug only): all ranks share cuda:0 and talk over gloo, to exercise the N > 1
+    # code path on a single-GPU box; the numbers of such a run mean nothing.
+    one_device = os.environ.get("RSK_BENCH_ONE_DEVICE", "") == "1"
+    if one_device:
+        local = 0
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if one_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    coll_dev = torch.device("cpu") if one_device else torch.device("cuda", local)
 
     seqs = synth_mu_chains(0x5EED5EEC + rank, args.chains or None)
     n = len(seqs)
@@ -163,9 +172,11 @@ def main():
     if dist is not None:
         # the path's only collective: gather of the per-rank hit buffers (query, target, score) onto rank 0
         from reseek_amd import dist as rdist
-        hit = torch.nonzero(torch.triu((out.to(torch.int32) & 0xFFFF) >= 120))
+        # scores are uint16 stored in an int16 tensor: >= 120 unsigned  <=>  >= 120 or negative as int16
+        hit = torch.nonzero((out >= 120) | (out < 0))
+        hit = hit[hit[:, 1] >= hit[:, 0]]                      # i <= j (entries below the diagonal are by-products)
         rows = torch.cat([hit.to(torch.int32), (out[hit[:, 0], hit[:, 1]].to(torch.int32) & 0xFFFF)[:, None]], dim=1)
-        gathered = rdist.gather_rows(rows.cpu().numpy(), dst=0, device=torch.device("cuda", local))
+        gathered = rdist.gather_rows(rows.cpu().numpy(), dst=0, device=coll_dev)
         summary[0] = 0 if gathered is None else gathered.shape[0]
     barrier()
     dt = time.perf_counter() - t0
@@ -173,8 +184,8 @@ def main():
     kernel_ms = ctx.last_kernel_ms()
     pairs, cells, slots = ctx.mu_gapless_last_work()
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    tot = torch.tensor([float(cells), float(pairs)], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+    tot = torch.tensor([float(cells), float(pairs)], dtype=torch.float64, device=coll_dev)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
