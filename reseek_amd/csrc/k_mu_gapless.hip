@@ -26,6 +26,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <map>
 
 #include "rsk_dev_tables.h"
 
@@ -48,32 +49,39 @@ int rsk_build_rings(rsk_db *db)
     std::vector<uint32_t> qids;
     std::vector<rsk_ring> rings;
     db->long_q.clear();
-    // Consecutive queries per ring (keeps a ring's smallest query index close to its members: the
-    // self-triangle skips all targets below it); ring size 512 or 1024 slots, whichever fills better.
-    // (First-fit-decreasing over windows was measured and is not better: chain sets sorted by length
-    // have near-equal blocks inside a window, the loss is the capacity quantum, not the packing order.)
-    uint32_t i = 0;
-    static const uint32_t Ds[2] = { 4, 8 };
-    while (i < n) {
-        if (qblock(db->len[i]) > RING_MAX_BLOCK) { db->long_q.push_back(i); ++i; continue; }
-        uint32_t bestD = 0, bestCnt = 0;
-        double bestFill = -1;
-        for (uint32_t D : Ds) {
-            uint32_t cap = 128 * D, used = 0, cnt = 0;
-            uint64_t real = 0;
-            for (uint32_t j = i; j < n; ++j) {
-                uint32_t b = qblock(db->len[j]);
-                if (b > RING_MAX_BLOCK || used + b > cap) break;
-                used += b; real += db->len[j]; ++cnt;
-            }
-            if (cnt == 0) continue;
-            double fill = (double) real / cap;
-            if (fill >= bestFill) { bestFill = fill; bestD = D; bestCnt = cnt; }
-        }
+    // Best-fit-decreasing bin packing of the query blocks into 1024-slot rings (capacity quantum, not order, is
+    // what a ring loses: consecutive chains of a length-sorted set leave 1024 mod block unused).  Any grouping
+    // is valid because the chain set is then PROCESSED in ring order: position p of the permuted order
+    // `ring_perm` is the p-th ring member; in self-triangle mode a ring takes the targets at positions >= its
+    // first member, so every unordered pair is scored at least once (the score is symmetric) and stored at
+    // out[min][max].  Chains too long for a ring come last in the order (per-pair kernel).
+    std::vector<uint32_t> items;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (qblock(db->len[i]) > RING_MAX_BLOCK) db->long_q.push_back(i);
+        else items.push_back(i);
+    }
+    std::stable_sort(items.begin(), items.end(), [&](uint32_t x, uint32_t y) { return qblock(db->len[x]) > qblock(db->len[y]); });
+    struct bin { uint32_t used = 0; std::vector<uint32_t> members; };
+    std::vector<bin> bins;
+    std::multimap<uint32_t, uint32_t> by_free;          // free slots -> bin index
+    const uint32_t CAP = 1024, NQCAP = 128;
+    for (uint32_t q : items) {
+        const uint32_t b = qblock(db->len[q]);
+        auto it = by_free.lower_bound(b);               // tightest bin that still takes the block
+        while (it != by_free.end() && bins[it->second].members.size() >= NQCAP) ++it;
+        uint32_t bi;
+        if (it == by_free.end()) { bi = (uint32_t) bins.size(); bins.emplace_back(); }
+        else { bi = it->second; by_free.erase(it); }
+        bins[bi].used += b;
+        bins[bi].members.push_back(q);
+        if (bins[bi].used < CAP) by_free.insert({ CAP - bins[bi].used, bi });
+    }
+    for (const bin &B : bins) {
+        const uint32_t bestD = B.used <= 512 ? 4 : 8;
         rsk_ring r;
         r.D = bestD;
-        r.nq = bestCnt;
-        r.min_q = i;
+        r.nq = (uint32_t) B.members.size();
+        r.min_q = 0;                                    // position in the permuted order, set below
         r.letters_off = (uint32_t) letters.size();
         r.laneq_off = (uint32_t) laneq.size();
         r.qid_off = (uint32_t) qids.size();
@@ -83,18 +91,26 @@ int rsk_build_rings(rsk_db *db)
         uint8_t *rl = &letters[r.letters_off];
         uint8_t *lq = &laneq[r.laneq_off];
         uint32_t s = 0;
-        for (uint32_t k = 0; k < bestCnt; ++k) {
-            const uint32_t q = i + k, L = db->len[q], b = qblock(L);
+        for (uint32_t k = 0; k < r.nq; ++k) {
+            const uint32_t q = B.members[k], L = db->len[q], b = qblock(L);
             memcpy(rl + s + 1, &db->h_mu[db->off[q]], L);     // slot s = separator, then the L rows
             for (uint32_t g = s / 8; g < (s + b) / 8; ++g) lq[g] = (uint8_t) k;   // granule g = slots [8g, 8g+8)
             qids.push_back(q);
             s += b;
         }
         rings.push_back(r);
-        i += bestCnt;
     }
     // sort by D so each class is one launch
     std::stable_sort(rings.begin(), rings.end(), [](const rsk_ring &a, const rsk_ring &b) { return a.D < b.D; });
+    // processing order: ring members in launch order, then the long chains
+    std::vector<uint32_t> perm;
+    perm.reserve(n);
+    for (rsk_ring &r : rings) {
+        r.min_q = (uint32_t) perm.size();
+        for (uint32_t k = 0; k < r.nq; ++k) perm.push_back(qids[r.qid_off + k]);
+    }
+    for (uint32_t q : db->long_q) perm.push_back(q);
+    db->h_ring_perm = perm;
     db->rings = rings;
     db->ring_slots_total = 0;
     for (auto &r : rings) db->ring_slots_total += 128ull * r.D;
@@ -111,6 +127,7 @@ int rsk_build_rings(rsk_db *db)
     if ((rc = up((void **) &db->d_ring_letters, letters.data(), letters.size())) != RSK_OK) return rc;
     if ((rc = up((void **) &db->d_ring_laneq, laneq.data(), laneq.size())) != RSK_OK) return rc;
     if ((rc = up((void **) &db->d_ring_qid, qids.data(), qids.size() * 4)) != RSK_OK) return rc;
+    if ((rc = up((void **) &db->d_ring_perm, perm.data(), perm.size() * 4)) != RSK_OK) return rc;
     db->rings_built = true;
     return RSK_OK;
 }
@@ -202,6 +219,7 @@ __global__ __launch_bounds__(64 * NW) void k_gapless_ring(const rsk_ring *__rest
                                                           const uint8_t *__restrict__ t_mu,
                                                           const uint32_t *__restrict__ t_off,
                                                           const uint32_t *__restrict__ t_len, uint32_t nt,
+                                                          const uint32_t *__restrict__ t_perm,   // self triangle: processing order
                                                           uint32_t tb_size, int self_triangle,
                                                           uint16_t *__restrict__ out, size_t ldo)
 {
@@ -259,6 +277,7 @@ __global__ __launch_bounds__(64 * NW) void k_gapless_ring(const rsk_ring *__rest
         if (lane == 0) t = atomicAdd(&next_t, 1u);
         t = __builtin_amdgcn_readfirstlane(t);
         if (t >= t1) break;
+        if (self_triangle) t = __builtin_amdgcn_readfirstlane(t_perm[t]);     // position -> chain
         const uint32_t toff = __builtin_amdgcn_readfirstlane(t_off[t]);
         const uint32_t tlen = __builtin_amdgcn_readfirstlane(t_len[t]);
         const uint2 *lp = (const uint2 *) (t_mu + toff);
@@ -298,7 +317,9 @@ __global__ __launch_bounds__(64 * NW) void k_gapless_ring(const rsk_ring *__rest
         for (uint32_t k = lane; k < rg.nq; k += 64) {
             const int v = wres[k];
             wres[k] = FLOOR32;
-            out[(size_t) ring_qid[rg.qid_off + k] * ldo + t] = (uint16_t) (v + 32768);
+            const uint32_t qid = ring_qid[rg.qid_off + k];
+            const size_t o = self_triangle ? (size_t) min(qid, t) * ldo + max(qid, t) : (size_t) qid * ldo + t;
+            out[o] = (uint16_t) (v + 32768);
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     }
@@ -376,7 +397,7 @@ static int launch_ring_class(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, con
         attr_set = true;
     }
     hipLaunchKernelGGL((k_gapless_ring<D, NW>), dim3(nwork), dim3(64 * NW), lds, ctx->stream, q->d_ring_tab, d_work,
-                       q->d_ring_letters, q->d_ring_laneq, q->d_ring_qid, t->d_mu, t->d_off, t->d_len, t->n, tb_size,
+                       q->d_ring_letters, q->d_ring_laneq, q->d_ring_qid, t->d_mu, t->d_off, t->d_len, t->n, q->d_ring_perm, tb_size,
                        self_triangle, d_scores, ldo);
     RSK_HIP(hipGetLastError());
     return RSK_OK;
@@ -388,16 +409,21 @@ int rsk_launch_gapless_rings(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int
     int rc = rsk_upload_mu_tables(ctx);
     if (rc != RSK_OK) return rc;
     // work accounting (host side, O(rings))
+    // targets in processing order: the ring permutation of the (same) chain set in self-triangle mode
     std::vector<uint64_t> pre_len(t->n + 1, 0), pre_slots(t->n + 1, 0);
     for (uint32_t i = 0; i < t->n; ++i) {
-        pre_len[i + 1] = pre_len[i] + t->len[i];
-        pre_slots[i + 1] = pre_slots[i] + (uint64_t) ((t->len[i] + 7) / 8 * 8);
+        const uint32_t L = t->len[self_triangle ? q->h_ring_perm[i] : i];
+        pre_len[i + 1] = pre_len[i] + L;
+        pre_slots[i + 1] = pre_slots[i] + (uint64_t) ((L + 7) / 8 * 8);
     }
     uint64_t pairs = 0, cells = 0, slots = 0;
-    for (uint32_t i = 0; i < q->n; ++i) {
-        const uint32_t ts = self_triangle ? i : 0;
-        pairs += t->n - ts;
-        cells += (uint64_t) q->len[i] * (pre_len[t->n] - pre_len[ts]);
+    if (self_triangle) {                                  // the pair space of the contract: every unordered pair once
+        pairs = (uint64_t) q->n * (q->n + 1) / 2;
+        uint64_t suffix = 0;
+        for (uint32_t i = q->n; i-- > 0;) { suffix += q->len[i]; cells += (uint64_t) q->len[i] * suffix; }
+    } else {
+        pairs = (uint64_t) q->n * t->n;
+        cells = pre_len[t->n] * [&]() { uint64_t z = 0; for (uint32_t L : q->len) z += L; return z; }();
     }
     uint32_t nD4 = 0, nD8 = 0;
     for (auto &r : q->rings) {
@@ -405,9 +431,13 @@ int rsk_launch_gapless_rings(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int
         const uint32_t ts = self_triangle ? r.min_q : 0;
         slots += 128ull * r.D * (pre_slots[t->n] - pre_slots[ts]);
     }
-    for (uint32_t lqi : q->long_q) {
-        const uint32_t ts = self_triangle ? lqi : 0;
-        slots += (uint64_t) q->len[lqi] * (pre_len[t->n] - pre_len[ts]);
+    {
+        uint32_t pos = (uint32_t) (q->n - q->long_q.size());
+        for (uint32_t lqi : q->long_q) {
+            const uint32_t ts = self_triangle ? pos : 0;
+            slots += (uint64_t) q->len[lqi] * (pre_len[t->n] - pre_len[ts]);
+            ++pos;
+        }
     }
     ctx->gl_pairs = pairs; ctx->gl_cells = cells; ctx->gl_slots = slots;
 
@@ -456,8 +486,17 @@ int rsk_launch_gapless_rings(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int
     // queries too long for a ring: per-pair kernel over (long q) x targets
     if (!q->long_q.empty()) {
         std::vector<uint32_t> iq, it;
-        for (uint32_t lqi : q->long_q)
-            for (uint32_t j = self_triangle ? lqi : 0; j < t->n; ++j) { iq.push_back(lqi); it.push_back(j); }
+        uint32_t pos = (uint32_t) (q->n - q->long_q.size());      // long chains close the processing order
+        for (uint32_t lqi : q->long_q) {
+            if (self_triangle) {
+                for (uint32_t p = pos; p < t->n; ++p) {           // symmetric score: stored at [min][max]
+                    const uint32_t tj = q->h_ring_perm[p];
+                    iq.push_back(std::min(lqi, tj)); it.push_back(std::max(lqi, tj));
+                }
+            } else
+                for (uint32_t j = 0; j < t->n; ++j) { iq.push_back(lqi); it.push_back(j); }
+            ++pos;
+        }
         uint32_t *d_iq = nullptr, *d_it = nullptr;
         RSK_HIP(hipMalloc((void **) &d_iq, iq.size() * 4));
         RSK_HIP(hipMalloc((void **) &d_it, it.size() * 4));

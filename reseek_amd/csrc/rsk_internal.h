@@ -84,6 +84,8 @@ struct rsk_db {
     uint8_t *d_ring_letters = nullptr;
     uint8_t *d_ring_laneq = nullptr;
     uint32_t *d_ring_qid = nullptr;
+    uint32_t *d_ring_perm = nullptr;    // processing order of the chains in self-triangle mode (ring members, then long chains)
+    std::vector<uint32_t> h_ring_perm;
     // gapless work list cache (valid for one target set + triangle flag)
     uint64_t work_for = 0;              // uid of the target set the list was built for
     int work_tri = -1;
