@@ -35,6 +35,7 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 
 #define FLOOR2 ((int) 0x80008000)
 #define FLOOR32 (-32768)
+#define RING_TB 256          // targets per work item
 #define RING_MAX_BLOCK 1024   // largest query block (1 + L rounded up to 8) that fits a D = 8 ring
 
 // ---------------------------------------------------------------------------------------------
@@ -220,6 +221,7 @@ __global__ __launch_bounds__(64 * NW) void k_gapless_ring(const rsk_ring *__rest
                                                           const uint32_t *__restrict__ t_off,
                                                           const uint32_t *__restrict__ t_len, uint32_t nt,
                                                           const uint32_t *__restrict__ t_perm,   // self triangle: processing order
+                                                          const uint32_t *__restrict__ t_claim,  // positions of each aligned block, longest first
                                                           uint32_t tb_size, int self_triangle,
                                                           uint16_t *__restrict__ out, size_t ldo)
 {
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(64 * NW) void k_gapless_ring(const rsk_ring *__rest
     const int nthreads = 64 * NW;
     const uint2 wk = work[blockIdx.x];
     const rsk_ring rg = rings[wk.x];
-    const uint32_t t0 = (self_triangle && wk.y < rg.min_q) ? rg.min_q : wk.y;
+    const uint32_t t0 = wk.y;
     const uint32_t t1 = min(nt, wk.y + tb_size);
     if (tid == 0) next_t = t0;
 
@@ -277,7 +279,11 @@ __global__ __launch_bounds__(64 * NW) void k_gapless_ring(const rsk_ring *__rest
         if (lane == 0) t = atomicAdd(&next_t, 1u);
         t = __builtin_amdgcn_readfirstlane(t);
         if (t >= t1) break;
-        if (self_triangle) t = __builtin_amdgcn_readfirstlane(t_perm[t]);     // position -> chain
+        t = __builtin_amdgcn_readfirstlane(t_claim[t]);                       // longest targets of the block first (LPT)
+        if (self_triangle) {
+            if (t < rg.min_q) continue;                                       // positions before the ring's first member
+            t = __builtin_amdgcn_readfirstlane(t_perm[t]);                    // position -> chain
+        }
         const uint32_t toff = __builtin_amdgcn_readfirstlane(t_off[t]);
         const uint32_t tlen = __builtin_amdgcn_readfirstlane(t_len[t]);
         const uint2 *lp = (const uint2 *) (t_mu + toff);
@@ -397,9 +403,27 @@ static int launch_ring_class(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, con
         attr_set = true;
     }
     hipLaunchKernelGGL((k_gapless_ring<D, NW>), dim3(nwork), dim3(64 * NW), lds, ctx->stream, q->d_ring_tab, d_work,
-                       q->d_ring_letters, q->d_ring_laneq, q->d_ring_qid, t->d_mu, t->d_off, t->d_len, t->n, q->d_ring_perm, tb_size,
-                       self_triangle, d_scores, ldo);
+                       q->d_ring_letters, q->d_ring_laneq, q->d_ring_qid, t->d_mu, t->d_off, t->d_len, t->n, q->d_ring_perm,
+                       self_triangle ? q->d_tri_claim : t->d_nat_claim, tb_size, self_triangle, d_scores, ldo);
     RSK_HIP(hipGetLastError());
+    return RSK_OK;
+}
+
+// positions of every aligned RING_TB block ordered by decreasing target length: the waves of a workgroup claim the
+// long targets first, so the block ends without one wave still walking a long chain (LPT scheduling)
+static int build_claim_order(const rsk_db *db, const uint32_t *perm, uint32_t **d_out)
+{
+    if (*d_out) return RSK_OK;
+    std::vector<uint32_t> claim(db->n);
+    for (uint32_t i = 0; i < db->n; ++i) claim[i] = i;
+    for (uint32_t b = 0; b < db->n; b += RING_TB) {
+        const uint32_t e = std::min(db->n, b + RING_TB);
+        std::stable_sort(claim.begin() + b, claim.begin() + e, [&](uint32_t x, uint32_t y) {
+            return db->len[perm ? perm[x] : x] > db->len[perm ? perm[y] : y];
+        });
+    }
+    RSK_HIP(hipMalloc((void **) d_out, std::max<size_t>(db->n, 1) * 4));
+    RSK_HIP(hipMemcpy(*d_out, claim.data(), (size_t) db->n * 4, hipMemcpyHostToDevice));
     return RSK_OK;
 }
 
@@ -407,6 +431,9 @@ int rsk_launch_gapless_rings(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int
                              uint16_t *d_scores, size_t ldo)
 {
     int rc = rsk_upload_mu_tables(ctx);
+    if (rc != RSK_OK) return rc;
+    if (self_triangle) rc = build_claim_order(q, q->h_ring_perm.data(), &const_cast<rsk_db *>(q)->d_tri_claim);
+    else rc = build_claim_order(t, nullptr, &const_cast<rsk_db *>(t)->d_nat_claim);
     if (rc != RSK_OK) return rc;
     // work accounting (host side, O(rings))
     // targets in processing order: the ring permutation of the (same) chain set in self-triangle mode
@@ -445,7 +472,7 @@ int rsk_launch_gapless_rings(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int
     // expensive ones first.  Cached per (target set, triangle flag) in the query chain set.
     rsk_db *qm = const_cast<rsk_db *>(q);
     if (qm->work_for != t->uid || qm->work_tri != self_triangle) {
-        const uint32_t TB[2] = { 128, 256 };   // targets per workgroup for D = 4 / 8
+        const uint32_t TB[2] = { RING_TB, RING_TB };   // targets per workgroup (the claim order is built for this block size)
         std::vector<uint2> w[2];
         std::vector<uint64_t> cost[2];
         for (uint32_t ri = 0; ri < q->rings.size(); ++ri) {
@@ -479,9 +506,9 @@ int rsk_launch_gapless_rings(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int
 
     RSK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     rc = launch_ring_class<8, 16>(ctx, q, t, (const uint2 *) q->d_work + q->work_count[0], q->work_count[1], self_triangle,
-                                  d_scores, ldo, 256);
+                                  d_scores, ldo, RING_TB);
     if (rc != RSK_OK) return rc;
-    rc = launch_ring_class<4, 8>(ctx, q, t, (const uint2 *) q->d_work, q->work_count[0], self_triangle, d_scores, ldo, 128);
+    rc = launch_ring_class<4, 8>(ctx, q, t, (const uint2 *) q->d_work, q->work_count[0], self_triangle, d_scores, ldo, RING_TB);
     if (rc != RSK_OK) return rc;
     // queries too long for a ring: per-pair kernel over (long q) x targets
     if (!q->long_q.empty()) {

@@ -86,6 +86,8 @@ struct rsk_db {
     uint32_t *d_ring_qid = nullptr;
     uint32_t *d_ring_perm = nullptr;    // processing order of the chains in self-triangle mode (ring members, then long chains)
     std::vector<uint32_t> h_ring_perm;
+    uint32_t *d_tri_claim = nullptr;    // per 256-position block of ring_perm: positions by decreasing chain length
+    uint32_t *d_nat_claim = nullptr;    // same for the natural chain order (rectangular mode, this set as targets)
     // gapless work list cache (valid for one target set + triangle flag)
     uint64_t work_for = 0;              // uid of the target set the list was built for
     int work_tri = -1;
