@@ -252,6 +252,10 @@ typedef struct rsk_search_opts {
     uint32_t rsb_size;         /* -rsb_size (0 = 1500) */
     const char *dbmu;          /* -dbmu: Mu FASTA of the DB chains for the prefilter stage (search.cpp:93-96) */
     int keeptmp;               /* -keeptmp: keep <out_tsv>.prefilter.tmp */
+    uint32_t shard_index;      /* multi-GPU (one process per GPU): this process handles shard shard_index of       */
+    uint32_t shard_count;      /* shard_count: -db mode = a contiguous range of DB chains balanced by residues;     */
+                               /* self search = the pairs (i <= j) whose j lies in a range balanced by DP cells.    */
+                               /* The union of the shards' hit tables is the unsharded table.  0 or 1 = no shards. */
 } rsk_search_opts;
 int rsk_search(rsk_ctx *ctx, const char *query_path, const char *db_path, const rsk_search_opts *opts,
                const char *out_tsv, uint64_t *nhits, uint64_t *stats8);

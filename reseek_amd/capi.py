@@ -82,7 +82,7 @@ class SearchOpts(C.Structure):
     _fields_ = [("mode", C.c_char_p), ("columns", C.c_char_p), ("evalue", C.c_double), ("evalue_set", C.c_int),
                 ("mints", C.c_double), ("mints_set", C.c_int), ("pvalue", C.c_double), ("pvalue_set", C.c_int),
                 ("noself", C.c_int), ("selfrev0", C.c_int), ("idx_mode", C.c_int), ("rsb_size", C.c_uint32),
-                ("dbmu", C.c_char_p), ("keeptmp", C.c_int)]
+                ("dbmu", C.c_char_p), ("keeptmp", C.c_int), ("shard_index", C.c_uint32), ("shard_count", C.c_uint32)]
 
 
 SIGNATURES["rsk_search"] = (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(SearchOpts), C.c_char_p, C.POINTER(C.c_uint64),

@@ -29,10 +29,12 @@ static void check(int rc, const char *what)
 
 DBSearcher::~DBSearcher()
 {
-    for (auto p : m_DBChains) delete p;
-    for (auto p : m_DBProfiles) delete p;
-    for (auto p : m_DBMuLettersVec) delete p;
-    for (auto p : m_DBMuKmersVec) delete p;
+    if (m_OwnsChains) {
+        for (auto p : m_DBChains) delete p;
+        for (auto p : m_DBProfiles) delete p;
+        for (auto p : m_DBMuLettersVec) delete p;
+        for (auto p : m_DBMuKmersVec) delete p;
+    }
     if (m_Db) rsk_db_destroy(m_Db);
 }
 
@@ -282,7 +284,7 @@ void DBSearcher::UploadToGpu()
 
 // Align a batch of (ia, ib) pairs of one chain set on the GPU and replay the hits.
 static void AlignAndReplay(DBSearcher &S, rsk_ctx *ctx, DBSearcher &SrcA, DBSearcher &SrcB, const std::vector<uint32_t> &ia,
-                           const std::vector<uint32_t> &ib, bool Self)
+                           const std::vector<uint32_t> &ib, bool Self, uint joff = 0)
 {
     const DSSParams &P = *S.m_Params;
     const size_t n = ia.size();
@@ -304,7 +306,7 @@ static void AlignAndReplay(DBSearcher &S, rsk_ctx *ctx, DBSearcher &SrcA, DBSear
         DA.SetFromAln(out[p], paths.data() + out[p].path_off);
         if (Self) {
             S.BaseOnAln(DA, true);
-            if (i != j) S.BaseOnAln(DA, false);
+            if (i != joff + j) S.BaseOnAln(DA, false);
         } else
             S.BaseOnAln(DA, false);                                          // runquery.cpp:73: A = DB chain, B = query
     }
@@ -389,13 +391,18 @@ struct PhaseTimer {                              // RSK_TRACE=1: wall time of th
 };
 }   // namespace
 
-static void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self)
+// Self with SelfOffset >= 0 is one SHARD of a self search: B = the chains [SelfOffset, SelfOffset + NB) of
+// the set, A = its chains [0, SelfOffset + NB); the pairs i <= SelfOffset + j are this shard's part of the triangle.
+static void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOffset = -1)
 {
     PhaseTimer tm;
     const DSSParams &P = *S.m_Params;
     rsk_ctx *ctx = S.m_Ctx;
     const uint NA = SrcA.GetDBChainCount(), NB = S.GetDBChainCount();
     const bool UseMu = P.m_Omega > 0;            // LoadDB keeps Mu letters only when Omega > 0 (dbsearcher.cpp:249-251)
+    const bool Tri = Self && SelfOffset < 0;     // the whole triangle in one call
+    const uint joff = SelfOffset > 0 ? (uint) SelfOffset : 0;
+    auto InShard = [&](uint i, uint j) { return !Self || i <= joff + j; };
     auto IsMKF = [&](uint i, uint j) {           // DSSAligner::DoMKF dssaligner.cpp:715-732
         if (!UseMu) return false;
         if (SrcA.m_DBMuKmersVec[i]->empty() || S.m_DBMuKmersVec[j]->empty()) return false;
@@ -403,8 +410,10 @@ static void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self)
     };
     auto Skip = [&](uint i, uint j) {
         if (!S.m_Opts.noself) return false;
-        return Self ? (i == j) : (SrcA.m_DBChains[i]->m_Label == S.m_DBChains[j]->m_Label);
+        return Self ? (i == joff + j) : (SrcA.m_DBChains[i]->m_Label == S.m_DBChains[j]->m_Label);
     };
+    uint64_t SelfTotal = 0;                      // pairs of this (shard of the) triangle
+    if (Self) for (uint j = 0; j < NB; ++j) SelfTotal += std::min<uint64_t>(NA, (uint64_t) joff + j + 1);
     std::vector<uint32_t> ia, ib;                // pairs for the full alignment
     std::vector<std::pair<uint32_t, uint32_t> > mkf;
     uint64_t npairs = 0;
@@ -413,14 +422,14 @@ static void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self)
         const size_t ldo = NB;
         uint8_t *d_fwd = nullptr;
         uint32_t *d_pq = nullptr, *d_pt = nullptr, *d_n = nullptr;
-        const uint64_t total = Self ? (uint64_t) NA * (NA + 1) / 2 : (uint64_t) NA * NB;
-        size_t cap = (size_t) std::min<uint64_t>(total, 1ull << 31);
+        const uint64_t total = Self ? SelfTotal : (uint64_t) NA * NB;
+        size_t cap = (size_t) std::min<uint64_t>(Tri ? total : (uint64_t) NA * NB, 1ull << 31);
         auto hipok = [](hipError_t e, const char *w) { if (e != hipSuccess) throw std::runtime_error(std::string(w) + ": " + hipGetErrorString(e)); };
         hipok(hipMalloc((void **) &d_fwd, (size_t) NA * ldo), "hipMalloc fwd");
         hipok(hipMalloc((void **) &d_pq, cap * 4), "hipMalloc pairs");
         hipok(hipMalloc((void **) &d_pt, cap * 4), "hipMalloc pairs");
         hipok(hipMalloc((void **) &d_n, 4), "hipMalloc n");
-        check(rsk_mu_filter_dev(ctx, SrcA.m_Db, S.m_Db, Self ? 1 : 0, P.m_ParaMuGapOpen, P.m_ParaMuGapExt, P.m_Omega, P.m_OmegaFwd, d_fwd, ldo,
+        check(rsk_mu_filter_dev(ctx, SrcA.m_Db, S.m_Db, Tri ? 1 : 0, P.m_ParaMuGapOpen, P.m_ParaMuGapExt, P.m_Omega, P.m_OmegaFwd, d_fwd, ldo,
                                 d_pq, d_pt, nullptr, nullptr, cap, d_n),
               "rsk_mu_filter_dev");
         uint32_t ns = 0;
@@ -437,7 +446,7 @@ static void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self)
         uint64_t nmkf = 0, nskip = 0;
         for (uint32_t k : ord) {
             const uint i = pq[k], j = pt[k];
-            if (Skip(i, j) || IsMKF(i, j)) continue;
+            if (!InShard(i, j) || Skip(i, j) || IsMKF(i, j)) continue;
             ia.push_back(i); ib.push_back(j);
         }
         // MKF pairs = either chain >= m_MKFL (both with k-mers): enumerated from the list of long chains,
@@ -447,7 +456,7 @@ static void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self)
             if (!S.m_DBMuKmersVec[j]->empty() && S.m_DBChains[j]->GetSeqLength() >= P.m_MKFL) longB.push_back(j);
         for (uint i = 0; i < NA; ++i) {
             if (SrcA.m_DBMuKmersVec[i]->empty()) continue;
-            const uint j0 = Self ? i : 0;
+            const uint j0 = Self ? (i > joff ? i - joff : 0) : 0;
             if (SrcA.m_DBChains[i]->GetSeqLength() >= P.m_MKFL) {
                 for (uint j = j0; j < NB; ++j) {
                     if (S.m_DBMuKmersVec[j]->empty() || Skip(i, j)) continue;
@@ -461,7 +470,7 @@ static void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self)
             }
         }
         if (S.m_Opts.noself) {
-            if (Self) nskip = NA;
+            if (Self) nskip = NB;               // the diagonal pairs of this shard
             else {
                 std::unordered_map<std::string, uint32_t> cntB;
                 for (uint j = 0; j < NB; ++j) ++cntB[S.m_DBChains[j]->m_Label];
@@ -477,7 +486,7 @@ static void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self)
         S.m_MuFilterDiscardCount = S.m_MuFilterInputCount - ia.size();
     } else {
         for (uint i = 0; i < NA; ++i)
-            for (uint j = Self ? i : 0; j < NB; ++j) {
+            for (uint j = Self ? (i > joff ? i - joff : 0) : 0; j < NB; ++j) {
                 if (Skip(i, j)) continue;
                 ia.push_back(i); ib.push_back(j);
                 ++npairs;
@@ -489,7 +498,7 @@ static void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self)
     const size_t B = std::max<size_t>(1, S.m_Opts.batch_pairs);
     for (size_t b = 0; b < ia.size(); b += B) {
         const size_t e = std::min(ia.size(), b + B);
-        AlignAndReplay(S, ctx, SrcA, S, std::vector<uint32_t>(ia.begin() + b, ia.begin() + e), std::vector<uint32_t>(ib.begin() + b, ib.begin() + e), Self);
+        AlignAndReplay(S, ctx, SrcA, S, std::vector<uint32_t>(ia.begin() + b, ia.begin() + e), std::vector<uint32_t>(ib.begin() + b, ib.begin() + e), Self, joff);
     }
     tm.lap("align + replay");
     // long-chain pairs: host MKF path (dssaligner.cpp:809-813), one aligner per host thread as in the
@@ -498,7 +507,7 @@ static void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self)
         if (DA.m_Path.empty()) return;
         if (Self) {
             S.BaseOnAln(DA, true);
-            if (i != j) S.BaseOnAln(DA, false);
+            if (i != joff + j) S.BaseOnAln(DA, false);
         } else
             S.BaseOnAln(DA, false);
     });
@@ -509,6 +518,42 @@ void DBSearcher::RunSelf()
 {
     UploadToGpu();
     RunPairs(*this, *this, true);
+}
+
+// chains [Lo, Hi) of Src as a searcher of their own (borrowed pointers)
+void DBSearcher::MakeView(const DBSearcher &Src, uint Lo, uint Hi)
+{
+    m_OwnsChains = false;
+    m_Params = Src.m_Params; m_Opts = Src.m_Opts; m_Ctx = Src.m_Ctx;
+    m_DBChains.assign(Src.m_DBChains.begin() + Lo, Src.m_DBChains.begin() + Hi);
+    m_DBProfiles.assign(Src.m_DBProfiles.begin() + Lo, Src.m_DBProfiles.begin() + Hi);
+    m_DBMuLettersVec.assign(Src.m_DBMuLettersVec.begin() + Lo, Src.m_DBMuLettersVec.begin() + Hi);
+    m_DBMuKmersVec.assign(Src.m_DBMuKmersVec.begin() + Lo, Src.m_DBMuKmersVec.begin() + Hi);
+    m_DBSelfRevScores.assign(Src.m_DBSelfRevScores.begin() + Lo, Src.m_DBSelfRevScores.begin() + Hi);
+}
+
+// shard `Index` of `Count` of the self search: targets [Lo, Hi) chosen so that the cells of the triangle are balanced
+void DBSearcher::RunSelfShard(uint Index, uint Count)
+{
+    const uint N = GetDBChainCount();
+    std::vector<double> cum(N + 1, 0.0);         // cells of the pairs (i <= j) up to target j
+    double pre = 0;
+    for (uint j = 0; j < N; ++j) { pre += m_DBChains[j]->GetSeqLength(); cum[j + 1] = cum[j] + pre * m_DBChains[j]->GetSeqLength(); }
+    auto bound = [&](uint r) { return r >= Count ? N : (uint) (std::lower_bound(cum.begin(), cum.end(), cum[N] * r / Count) - cum.begin()); };
+    const uint Lo = std::min(N, bound(Index)), Hi = std::max(Lo, std::min(N, bound(Index + 1)));
+    DBSearcher A, B;
+    A.MakeView(*this, 0, Hi);
+    B.MakeView(*this, Lo, Hi);
+    B.Setup();
+    B.m_fTsv = m_fTsv;
+    if (Hi > Lo) {
+        A.UploadToGpu();
+        B.UploadToGpu();
+        RunPairs(B, A, true, (int64_t) Lo);
+    }
+    m_HitCount = B.m_HitCount; m_ProcessedPairCount = B.m_ProcessedPairCount; m_AlnCount = B.m_AlnCount;
+    m_MuFilterInputCount = B.m_MuFilterInputCount; m_MuFilterDiscardCount = B.m_MuFilterDiscardCount;
+    m_MKFPairCount = B.m_MKFPairCount; m_SWCount = B.m_SWCount;
 }
 
 void DBSearcher::RunQuery(DBSearcher &DBChainsSource)
@@ -602,6 +647,10 @@ static int search_impl(rsk_ctx *ctx, const char *query_rskdb, const char *db_rsk
         DBS.Setup();
         for (USERFIELD u : DBS.m_DA.m_UFs)
             if (u == UF_Undefined) { rsk_set_error("rsk_search_rskdb: invalid -columns field"); return RSK_E_INVALID; }
+        if (prefilter_path && o.shard_count > 1) {
+            rsk_set_error("rsk_search: shards are not supported on the -fast -db path (the per-query top-B of the prefilter is a reduction over all targets)");
+            return RSK_E_INVALID;
+        }
         if (prefilter_path) {
             // cmd_search search.cpp:76-111: k-mer prefilter, then the candidates under the "sensitive" preset
             DBSearcher Src;
@@ -625,15 +674,29 @@ static int search_impl(rsk_ctx *ctx, const char *query_rskdb, const char *db_rsk
         FILE *f = fopen(out_tsv, "w");
         if (!f) { rsk_set_error("rsk_search_rskdb: cannot create %s", out_tsv); return RSK_E_INVALID; }
         DBS.m_fTsv = f;
-        if (!have_db) DBS.RunSelf();
-        else {
+        if (o.shard_count > 1 && o.shard_index >= o.shard_count) { fclose(f); rsk_set_error("rsk_search: shard_index >= shard_count"); return RSK_E_INVALID; }
+        if (!have_db) {
+            if (o.shard_count > 1) DBS.RunSelfShard(o.shard_index, o.shard_count);
+            else DBS.RunSelf();
+        } else {
             DBSearcher Src;
             Src.m_Params = &Params;
             Src.m_SelfRevQueryFlavour = true;            // runquery.cpp:43-44
             Src.m_Opts = o;
             Src.m_Ctx = ctx;
             Src.LoadDB(db_rskdb);
-            DBS.RunQuery(Src);
+            if (o.shard_count > 1) {
+                // -db mode: contiguous target shards balanced by residues, the query set is replicated
+                const uint NS = Src.GetDBChainCount();
+                std::vector<uint64_t> cum(NS + 1, 0);
+                for (uint i = 0; i < NS; ++i) cum[i + 1] = cum[i] + Src.m_DBChains[i]->GetSeqLength();
+                auto bound = [&](uint r) { return r >= o.shard_count ? NS : (uint) (std::lower_bound(cum.begin(), cum.end(), cum[NS] * r / o.shard_count) - cum.begin()); };
+                const uint Lo = std::min(NS, bound(o.shard_index)), Hi = std::max(Lo, std::min(NS, bound(o.shard_index + 1)));
+                DBSearcher View;
+                View.MakeView(Src, Lo, Hi);
+                if (Hi > Lo) DBS.RunQuery(View);
+            } else
+                DBS.RunQuery(Src);
         }
         fclose(f);
         if (nhits) *nhits = DBS.m_HitCount;
@@ -678,5 +741,7 @@ extern "C" int rsk_search(rsk_ctx *ctx, const char *query_path, const char *db_p
     if (opts->rsb_size) o.rsb_size = opts->rsb_size;
     if (opts->dbmu) o.dbmu = opts->dbmu;
     o.keeptmp = opts->keeptmp != 0;
+    o.shard_index = opts->shard_index;
+    o.shard_count = opts->shard_count;
     return search_impl(ctx, query_path, db_path, o, out_tsv, nhits, stats8);
 }

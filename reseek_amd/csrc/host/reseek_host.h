@@ -57,6 +57,7 @@ struct SearchOptions {
     uint rsb_size = 1500;                              // -rsb_size (prefiltermuparams.h:15)
     std::string dbmu;                                  // -dbmu: Mu FASTA of the DB for the prefilter stage (search.cpp:93-96)
     bool keeptmp = false;                              // -keeptmp
+    uint shard_index = 0, shard_count = 0;             // multi-GPU: this rank's shard of the targets (0/0 or x/1 = everything)
     size_t batch_pairs = 1u << 16;                     // pairs per GPU alignment batch (bounds the trace memory)
 };
 
@@ -291,6 +292,9 @@ public:
     void Setup();                                       // dbsearcher.cpp:73
     void RunSelf();                                     // runself.cpp:101
     void RunQuery(DBSearcher &DBChainsSource);          // runquery.cpp:82 (A = each chain of the source, B = our chains)
+    bool m_OwnsChains = true;
+    void MakeView(const DBSearcher &Src, uint Lo, uint Hi);
+    void RunSelfShard(uint Index, uint Count);          // one rank's part of the self-search triangle
     bool Reject(DSSAligner &DA, bool Up) const;         // dbsearcher.cpp:258
     void BaseOnAln(DSSAligner &DA, bool Up);            // dbsearcher.cpp:267
     virtual void OnSetup() {}

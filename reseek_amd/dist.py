@@ -47,3 +47,41 @@ def gather_rows(rows, dst=0, group=None, device=None):
     if rank != dst:
         return None
     return np.concatenate([b[:c].cpu().numpy() for b, c in zip(bufs, counts)], axis=0)
+
+
+def gather_text(text, dst=0, group=None):
+    """Concatenation (rank order) of every rank's text on rank `dst`, None elsewhere: the hit tables of the
+    target shards (one exchange at the end of a search, tens of MB at most)."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    parts = [None] * world if rank == dst else None
+    dist.gather_object(text, parts, dst=dst, group=group)
+    return "".join(parts) if rank == dst else None
+
+
+def search_sharded(ctx, query, out_tsv, mode, db=None, group=None, **kw):
+    """One process per GPU: every rank runs its shard of the search (rsk_search with shard_index = rank,
+    shard_count = world size; -db mode: a contiguous target range balanced by residues with the queries
+    replicated; self search: a target range of the triangle balanced by DP cells), then the hit tables are
+    gathered on rank 0, which writes `out_tsv`.  Returns (hits of all ranks, per-rank stats) on rank 0,
+    (local hits, stats) elsewhere.  No collective on the data path."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    part = "%s.rank%d" % (out_tsv, rank)
+    nhits, stats = ctx.search(query, part, mode, db=db, shard_index=rank, shard_count=world, **kw)
+    with open(part) as f:
+        text = f.read()
+    import os
+    os.remove(part)
+    if world == 1:
+        with open(out_tsv, "w") as f:
+            f.write(text)
+        return nhits, stats
+    merged = gather_text(text, dst=0, group=group)
+    if rank == 0:
+        with open(out_tsv, "w") as f:
+            f.write(merged)
+        return merged.count("\n"), stats
+    return nhits, stats

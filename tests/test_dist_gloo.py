@@ -68,3 +68,33 @@ def test_gather_rows_world2_gloo():
         want.append(np.stack([rng.integers(0, 256, n), rng.integers(lo, hi, n), rng.integers(0, 5000, n)], axis=1).astype(np.int32))
     assert np.array_equal(got, np.concatenate(want))
     assert np.array_equal(got2, want[0])
+
+
+def _text_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    text = "".join("q%d\tt%d\t%d\n" % (rank, k, k * k) for k in range(5 + 3 * rank)) if rank != 1 else ""
+    got = rdist.gather_text(text, dst=0)
+    dist.barrier()
+    if rank == 0:
+        q.put(got)
+    dist.destroy_process_group()
+
+
+def test_gather_text_world3_gloo():
+    """the end-of-search exchange of search_sharded: per-rank hit tables (one may be empty) -> rank 0, rank order"""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_text_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    got = q.get(timeout=120)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = "".join("q0\tt%d\t%d\n" % (k, k * k) for k in range(5)) + "".join("q2\tt%d\t%d\n" % (k, k * k) for k in range(11))
+    assert got == want

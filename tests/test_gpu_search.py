@@ -166,3 +166,33 @@ def test_bca_fast_db_with_dbmu_and_options(ctx, tmpdir):
     out4 = os.path.join(tmpdir, "out_e2.tsv")
     n4, _ = ctx.search_rskdb(q, out4, "sensitive", columns=COLS, evalue=1e-3)
     assert n3 == n4 and sorted(open(out3).read().splitlines()) == sorted(open(out4).read().splitlines())
+
+
+def test_sharded_search_equals_unsharded(ctx, tmpdir):
+    """the union of the shards' hit tables is the unsharded table (self search: triangle cut by target
+    range; -db mode: DB chains cut by residues).  The shards run one after another on this single GPU."""
+    q = unpack_bca("q100.bca", tmpdir)
+    for db, golden in ((None, "hits_q100_sensitive.tsv.gz"), (q, "hits_q100_db_q100_sensitive.tsv.gz")):
+        for count in (2, 3, 7):
+            lines, pairs = [], 0
+            for idx in range(count):
+                out = os.path.join(tmpdir, "shard_%s_%d_%d.tsv" % ("db" if db else "self", count, idx))
+                n, st = ctx.search(q, out, "sensitive", db=db, columns=COLS, shard_index=idx, shard_count=count)
+                got = open(out).read().splitlines()
+                assert n == len(got)
+                lines += got
+                pairs += st[0]
+            want = ["\t".join(r) for r in fx.read_tsv(golden)]
+            assert sorted(lines) == want
+            assert pairs == (10000 if db else 5050)
+    # palms: shards with MKF pairs
+    p = unpack_bca("palms.bca", tmpdir)
+    lines = []
+    for idx in range(4):
+        out = os.path.join(tmpdir, "shard_palms_%d.tsv" % idx)
+        ctx.search(p, out, "sensitive", columns=COLS, shard_index=idx, shard_count=4)
+        lines += open(out).read().splitlines()
+    assert sorted(lines) == ["\t".join(r) for r in fx.read_tsv("hits_palms_sensitive.tsv.gz")]
+    from reseek_amd import capi
+    with pytest.raises(capi.RskError):
+        ctx.search(q, os.path.join(tmpdir, "x.tsv"), "fast", db=q, shard_index=0, shard_count=2)

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Multi-GPU search smoke test: `python -m torch.distributed.run --nproc-per-node N tools/search_dist_demo.py`
+runs reseek_amd.dist.search_sharded on the q100 fixture (self search and -db mode) with one process per GPU
+and checks the gathered hit table against the reference's golden table on rank 0.
+RSK_BENCH_ONE_DEVICE=1: all ranks share cuda:0 and use gloo (single-GPU boxes)."""
+import gzip
+import os
+import sys
+import tempfile
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import reseek_amd  # noqa: E402
+from reseek_amd import dist as rdist  # noqa: E402
+
+COLS = "query+target+qlo+qhi+ql+tlo+thi+tl+pctid+pvalue+evalue+cigar+dpscore+lddt+newts+ids+gaps+aq"
+
+
+def main():
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    one = os.environ.get("RSK_BENCH_ONE_DEVICE", "") == "1"
+    if one:
+        local = 0
+    torch.cuda.set_device(local)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        if one:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    ctx = reseek_amd.Ctx(local, stream=torch.cuda.current_stream().cuda_stream)
+    golden = os.path.join(ROOT, "tests", "golden")
+    with tempfile.TemporaryDirectory() as td:
+        bca = os.path.join(td, "q100_rank%d.bca" % rank)
+        with gzip.open(os.path.join(golden, "q100.bca.gz"), "rb") as f, open(bca, "wb") as g:
+            g.write(f.read())
+        ok = True
+        for db, gold in ((None, "hits_q100_sensitive.tsv.gz"), (bca, "hits_q100_db_q100_sensitive.tsv.gz")):
+            out = os.path.join(td, "hits_rank%d.tsv" % rank)
+            n, st = rdist.search_sharded(ctx, bca, out, "sensitive", db=db, columns=COLS)
+            if rank == 0:
+                got = sorted(open(out).read().splitlines())
+                want = sorted(gzip.open(os.path.join(golden, gold)).read().decode().splitlines())
+                ok = ok and got == want
+                print("world %d %s: %d hits, %s" % (world, "db" if db else "self", len(got), "identical to the reference" if got == want else "MISMATCH"))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()
