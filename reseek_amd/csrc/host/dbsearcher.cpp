@@ -14,6 +14,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <stdexcept>
 #include <thread>
 #include <unordered_map>
@@ -167,9 +168,8 @@ void DBSearcher::ComputeSelfRevScores()
                 if (pass[k]) keep.push_back(idx[k]);
             idx.swap(keep);
         }
-        const size_t B = std::max<size_t>(1, m_Opts.batch_pairs);
-        for (size_t b = 0; b < idx.size(); b += B) {
-            const size_t m = std::min(idx.size(), b + B) - b;
+        for (auto &be : AlignBatches(m_Opts, *this, *this, idx, idx)) {
+            const size_t b = be.first, m = be.second - be.first;
             std::vector<rsk_aln> out(m);
             check(rsk_align_pairs(m_Ctx, fdb, rdb, idx.data() + b, idx.data() + b, m, DAP.m_GapOpen, DAP.m_GapExt, DAP.m_MinFwdScore, out.data(),
                                   nullptr, 0),
@@ -291,19 +291,27 @@ static void AlignAndReplay(DBSearcher &S, rsk_ctx *ctx, DBSearcher &SrcA, DBSear
     if (n == 0) return;
     std::vector<rsk_aln> out(n);
     const size_t bytes = rsk_align_paths_bytes(SrcA.m_Db, SrcB.m_Db, ia.data(), ib.data(), n);
-    std::vector<char> paths(bytes + 1);
+    std::unique_ptr<char[]> paths_buf(new char[bytes + 1]);                 // not value-initialised: hundreds of MB per batch
+    char *paths = paths_buf.get();
     check(rsk_align_pairs(ctx, SrcA.m_Db, SrcB.m_Db, ia.data(), ib.data(), n, P.m_GapOpen, P.m_GapExt, P.m_MinFwdScore, out.data(),
-                          paths.data(), bytes),
+                          paths, bytes),
           "rsk_align_pairs");
     DSSAligner &DA = S.m_DA;
     for (size_t p = 0; p < n; ++p) {
         ++S.m_SWCount;
         if (out[p].path_len == 0) continue;                                  // runself.cpp:61 / runquery.cpp:72
+        // Reject (dbsearcher.cpp:258) on the batch record itself: both orientations carry the same E-value / TS, and a
+        // plain DBSearcher does nothing with a rejected hit -- skip the string work for the (many) rejected pairs
+        if (!S.m_HasOnAlnOverride) {
+            const float ev = out[p].evalue, ts = out[p].evalue != FLT_MAX ? out[p].ts : -FLT_MAX;
+            if (!S.m_Opts.scores_are_not_evalues && ev > S.m_MaxEvalue) continue;
+            if (S.m_Opts.mints_set && ts < S.m_Opts.mints) continue;
+        }
         const uint i = ia[p], j = ib[p];
         DA.m_ChainA = SrcA.m_DBChains[i]; DA.m_ProfileA = SrcA.m_DBProfiles[i];
         DA.m_ChainB = SrcB.m_DBChains[j]; DA.m_ProfileB = SrcB.m_DBProfiles[j];
         DA.m_SelfRevScoreA = SrcA.m_DBSelfRevScores[i]; DA.m_SelfRevScoreB = SrcB.m_DBSelfRevScores[j];
-        DA.SetFromAln(out[p], paths.data() + out[p].path_off);
+        DA.SetFromAln(out[p], paths + out[p].path_off);
         if (Self) {
             S.BaseOnAln(DA, true);
             if (i != joff + j) S.BaseOnAln(DA, false);
@@ -313,6 +321,22 @@ static void AlignAndReplay(DBSearcher &S, rsk_ctx *ctx, DBSearcher &SrcA, DBSear
 }
 
 // Shared body of RunSelf / RunQuery: A-side chains come from SrcA, B-side from *this.
+std::vector<std::pair<size_t, size_t> > AlignBatches(const SearchOptions &O, const DBSearcher &A, const DBSearcher &B,
+                                                     const std::vector<uint32_t> &ia, const std::vector<uint32_t> &ib)
+{
+    std::vector<std::pair<size_t, size_t> > out;
+    const size_t maxp = std::max<size_t>(1, O.batch_pairs);
+    size_t b = 0;
+    uint64_t cells = 0;
+    for (size_t k = 0; k < ia.size(); ++k) {
+        const uint64_t c = (uint64_t) A.m_DBChains[ia[k]]->GetSeqLength() * B.m_DBChains[ib[k]]->GetSeqLength();
+        if (k > b && (k - b >= maxp || cells + c > O.batch_cells)) { out.emplace_back(b, k); b = k; cells = 0; }
+        cells += c;
+    }
+    if (b < ia.size()) out.emplace_back(b, ia.size());
+    return out;
+}
+
 void RunMKFPairs(rsk_ctx *Ctx, const DSSParams &P, const std::string &Columns, DBSearcher &SrcA, DBSearcher &SrcB,
                  const std::vector<std::pair<uint32_t, uint32_t> > &Pairs, const std::function<void(DSSAligner &, uint, uint)> &OnHit)
 {
@@ -348,7 +372,9 @@ void RunMKFPairs(rsk_ctx *Ctx, const DSSParams &P, const std::string &Columns, D
         }
     }
     std::sort(recs.begin(), recs.end(), [](const Rec &x, const Rec &y) { return x.pair < y.pair; });
-    const unsigned T = (unsigned) std::max<size_t>(1, std::min<size_t>({ (size_t) std::thread::hardware_concurrency(), (size_t) 64, recs.size() / 16 + 1 }));
+    if (getenv("RSK_TRACE")) fprintf(stderr, "[RunMKFPairs] %zu pairs, %zu with a seed HSP\n", n, recs.size());
+    const auto t_host0 = std::chrono::steady_clock::now();
+    const unsigned T = (unsigned) std::max<size_t>(1, std::min<size_t>({ (size_t) std::thread::hardware_concurrency(), (size_t) 128, recs.size() / 8 + 1 }));
     std::atomic<size_t> next{0};
     std::mutex lock;
     auto body = [&]() {
@@ -375,6 +401,9 @@ void RunMKFPairs(rsk_ctx *Ctx, const DSSParams &P, const std::string &Columns, D
         for (unsigned t = 0; t < T; ++t) ts.emplace_back(body);
         for (auto &t : ts) t.join();
     }
+    if (getenv("RSK_TRACE"))
+        fprintf(stderr, "[RunMKFPairs] host stage %.3f ms on %u threads\n",
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count(), T);
 }
 
 namespace {
@@ -495,11 +524,9 @@ static void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOff
     S.m_ProcessedPairCount = npairs;
     S.m_AlnCount = npairs - mkf.size();
     tm.lap("filter + pair lists");
-    const size_t B = std::max<size_t>(1, S.m_Opts.batch_pairs);
-    for (size_t b = 0; b < ia.size(); b += B) {
-        const size_t e = std::min(ia.size(), b + B);
-        AlignAndReplay(S, ctx, SrcA, S, std::vector<uint32_t>(ia.begin() + b, ia.begin() + e), std::vector<uint32_t>(ib.begin() + b, ib.begin() + e), Self, joff);
-    }
+    for (auto &be : AlignBatches(S.m_Opts, SrcA, S, ia, ib))
+        AlignAndReplay(S, ctx, SrcA, S, std::vector<uint32_t>(ia.begin() + be.first, ia.begin() + be.second),
+                       std::vector<uint32_t>(ib.begin() + be.first, ib.begin() + be.second), Self, joff);
     tm.lap("align + replay");
     // long-chain pairs: host MKF path (dssaligner.cpp:809-813), one aligner per host thread as in the
     // reference (dbsearcher.cpp:98-106); BaseOnAln serialises the output under m_Lock.

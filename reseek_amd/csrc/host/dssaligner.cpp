@@ -439,17 +439,28 @@ void MuKmerFilter::ChainHSPs()
 // ---------------------------------------------------------------------------------------------
 namespace {
 struct XDropMem {
+    // Trace cells are generation-stamped (stamp << 8 | bits): a cell not written during the current call reads as 0,
+    // exactly as with a freshly zeroed matrix, without clearing (la+8)*(lb+8) bytes per call (that memset was the
+    // whole cost of the long-chain path when many pairs reach the gapped X-drop).
     uint LA = 0, LB = 0, Cols = 0;
-    std::vector<byte> TB;
+    std::vector<uint16_t> TB;
+    uint16_t Gen = 0;
     std::vector<float> M, D;
     void Alloc(uint la, uint lb)
     {
         LA = la; LB = lb; Cols = lb + 8;
-        TB.assign((size_t) (la + 8) * Cols, 0);
+        const size_t need = (size_t) (la + 8) * Cols;
+        if (need > TB.size()) { TB.assign(need + need / 4, 0); Gen = 0; }
+        if (++Gen == 256) { std::fill(TB.begin(), TB.end(), (uint16_t) 0); Gen = 1; }
         M.assign(lb + 9, 0.0f);
         D.assign(lb + 9, 0.0f);
     }
-    byte &tb(uint i, uint j) { return TB[(size_t) i * Cols + j]; }
+    void set_tb(uint i, uint j, byte v) { TB[(size_t) i * Cols + j] = (uint16_t) ((Gen << 8) | v); }
+    byte tb(uint i, uint j) const
+    {
+        const uint16_t c = TB[(size_t) i * Cols + j];
+        return (c >> 8) == Gen ? (byte) (c & 0xFF) : (byte) 0;
+    }
     float *Mrow() { return M.data() + 1; }     // Mrow[-1] is valid
     float *Drow() { return D.data() + 1; }
 };
@@ -530,14 +541,14 @@ float XDropFwd(XDropMem &Mem, float X, float Open, float Ext, SubFn Sub, uint Lo
                     endj = new_endj;
                 }
             }
-            Mem.tb(i, j) = TraceBits;
+            Mem.set_tb(i, j, TraceBits);
         }
         if (jhi < LB) {                                             // end of Drow[]
             const uint jhi1 = jhi + 1;
-            Mem.tb(i, jhi1) = 0;
+            Mem.set_tb(i, jhi1, 0);
             const float md = M0 + Open;
             Drow[jhi1] += Ext;
-            if (md >= Drow[jhi1]) { Drow[jhi1] = md; Mem.tb(i, jhi1) = TRACEBITS_MD; }
+            if (md >= Drow[jhi1]) { Drow[jhi1] = md; Mem.set_tb(i, jhi1, TRACEBITS_MD); }
         }
         if (next_jlo == UINT_MAX) break;
         prev_jlo = jlo; prev_jhi = jhi;

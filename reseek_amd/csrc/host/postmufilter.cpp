@@ -184,9 +184,8 @@ void PostMuFilter(const DSSParams &Params, const std::string &MuFilterTsvFN, DBS
         Q.m_MuFilterDiscardCount = fq.size() - ia.size();
     } else { ia.swap(fq); ib.swap(ft); }
     // SetSMx_NoRev + SWFast + CalcEvalue (chainbag.cpp:74-84) in batches
-    const size_t B = std::max<size_t>(1, O.batch_pairs);
-    for (size_t b = 0; b < ia.size(); b += B) {
-        const size_t n = std::min(ia.size(), b + B) - b;
+    for (auto &be : AlignBatches(O, Q, DB, ia, ib)) {
+        const size_t b = be.first, n = be.second - be.first;
         std::vector<rsk_aln> out(n);
         const size_t bytes = rsk_align_paths_bytes(Q.m_Db, DB.m_Db, ia.data() + b, ib.data() + b, n);
         std::vector<char> paths(bytes + 1);

@@ -58,7 +58,8 @@ struct SearchOptions {
     std::string dbmu;                                  // -dbmu: Mu FASTA of the DB for the prefilter stage (search.cpp:93-96)
     bool keeptmp = false;                              // -keeptmp
     uint shard_index = 0, shard_count = 0;             // multi-GPU: this rank's shard of the targets (0/0 or x/1 = everything)
-    size_t batch_pairs = 1u << 16;                     // pairs per GPU alignment batch (bounds the trace memory)
+    size_t batch_pairs = 1u << 20;                     // upper bound of pairs per GPU alignment batch
+    uint64_t batch_cells = 24ull << 30;                // ... and of DP cells per batch (~1 trace byte per cell in HBM)
 };
 
 class DSSParams {
@@ -299,6 +300,7 @@ public:
     void BaseOnAln(DSSAligner &DA, bool Up);            // dbsearcher.cpp:267
     virtual void OnSetup() {}
     virtual void OnAln(DSSAligner &DA, bool Up) {}
+    bool m_HasOnAlnOverride = false;                    // subclasses that override Reject/BaseOnAln semantics set this: every aligned pair is then replayed
 
     void UploadToGpu();
 
@@ -315,6 +317,10 @@ private:
 // for every pair that ends with an alignment (DA.m_Path non-empty is NOT required: the caller decides).
 void RunMKFPairs(rsk_ctx *Ctx, const DSSParams &Params, const std::string &Columns, DBSearcher &SrcA, DBSearcher &SrcB,
                  const std::vector<std::pair<uint32_t, uint32_t> > &Pairs, const std::function<void(DSSAligner &, uint, uint)> &OnHit);
+
+// [b, e) ranges of a pair list such that each batch has <= batch_pairs pairs and <= batch_cells DP cells
+std::vector<std::pair<size_t, size_t> > AlignBatches(const SearchOptions &O, const DBSearcher &A, const DBSearcher &B,
+                                                     const std::vector<uint32_t> &ia, const std::vector<uint32_t> &ib);
 
 void MuPreFilter(const DSSParams &Params, DBSearcher &QDB, DBSearcher &TDB, const std::string &OutputFN);
 void PostMuFilter(const DSSParams &Params, const std::string &MuFilterTsvFN, DBSearcher &Q, DBSearcher &DB,

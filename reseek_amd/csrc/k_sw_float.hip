@@ -526,51 +526,77 @@ __global__ void k_traceback(const uint8_t *tb, const uint64_t *tb_off, const uin
 // GetLDDT_mu_fast lddt.cpp:63-124 over the M columns of a path (GetPosABs dssaligner.cpp:1282).
 // One wave per pair.  The reference's symmetric accumulation over column pairs c < c' equals, per
 // column, the sum over all other columns (integer counts), so each lane owns whole columns.
+#define LDDT_LDS_COLS 256
 __global__ __launch_bounds__(256) void k_lddt(const char *paths, const uint64_t *path_start, const uint32_t *path_len,
                                               const uint32_t *lo_a, const uint32_t *lo_b, const uint32_t *ia, const uint32_t *ib,
                                               const uint32_t *a_off, const uint32_t *b_off,
                                               const float *ax, const float *ay, const float *az,
                                               const float *bx, const float *by, const float *bz,
                                               uint32_t npairs, uint32_t *scratch_pos, const uint64_t *scratch_off,
-                                              float *frac_scratch, float *lddt_out, uint32_t *counts_out)
+                                              float *frac_scratch, float *lddt_out, uint32_t *counts_out,
+                                              const float *score, float min_fwd_score)
 {
+    __shared__ float sc[4][7][LDDT_LDS_COLS];      // per wave: x,y,z of A and of B at the aligned columns, per-column fraction
     const uint32_t p = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (p >= npairs) return;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // CalcEvalue leaves everything unset below m_MinFwdScore (dssaligner.cpp:861): no LDDT needed for those pairs
+    if (score[p] < min_fwd_score || score[p] == 0.0f) {
+        if (lane == 0) { lddt_out[p] = 0.0f; counts_out[3 * p] = 0; counts_out[3 * p + 1] = 0; counts_out[3 * p + 2] = 0; }
+        return;
+    }
     const uint32_t len = path_len[p];
     uint32_t *posA = scratch_pos + 2 * scratch_off[p];
     uint32_t *posB = posA + (scratch_off[p + 1] - scratch_off[p]);
     float *frac = frac_scratch + scratch_off[p];
-    // lane 0 expands the path (sequential, short)
-    uint32_t ncols = 0, nM = 0, nD = 0, nI = 0;
-    if (lane == 0) {
-        const char *P = paths + path_start[p];
-        uint32_t pa = lo_a[p], pb = lo_b[p];
-        for (uint32_t c = 0; c < len; ++c) {
-            const char ch = P[c];
-            if (ch == 'M') { posA[nM] = pa++; posB[nM] = pb++; ++nM; }
-            else if (ch == 'D') { ++pa; ++nD; }
-            else { ++pb; ++nI; }
+    // expand the path with wave-wide prefix counts (GetPosABs dssaligner.cpp:1282): 64 path characters per step
+    const char *P = paths + path_start[p];
+    const uint32_t la0 = lo_a[p], lb0 = lo_b[p];
+    uint32_t nM = 0, nD = 0, nI = 0;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (uint32_t base = 0; base < len; base += 64) {
+        const uint32_t c = base + lane;
+        const char ch = c < len ? P[c] : 0;
+        const unsigned long long mM = __ballot(ch == 'M'), mD = __ballot(ch == 'D'), mI = __ballot(ch == 'I');
+        if (ch == 'M') {
+            const uint32_t kM = nM + (uint32_t) __popcll(mM & lt), kD = nD + (uint32_t) __popcll(mD & lt), kI = nI + (uint32_t) __popcll(mI & lt);
+            posA[kM] = la0 + kM + kD;
+            posB[kM] = lb0 + kM + kI;
         }
-        ncols = nM;
-        if (counts_out) { counts_out[3 * p] = nM; counts_out[3 * p + 1] = nD; counts_out[3 * p + 2] = nI; }
+        nM += (uint32_t) __popcll(mM); nD += (uint32_t) __popcll(mD); nI += (uint32_t) __popcll(mI);
     }
-    ncols = (uint32_t) __shfl((int) ncols, 0, 64);
+    const uint32_t ncols = nM;
+    if (lane == 0) { counts_out[3 * p] = nM; counts_out[3 * p + 1] = nD; counts_out[3 * p + 2] = nI; }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     if (ncols == 0) { if (lane == 0) lddt_out[p] = 0.0f; return; }
     const float *AX = ax + a_off[ia[p]], *AY = ay + a_off[ia[p]], *AZ = az + a_off[ia[p]];
     const float *BX = bx + b_off[ib[p]], *BY = by + b_off[ib[p]], *BZ = bz + b_off[ib[p]];
     const float R0sq = 15.0f * 15.0f;
+    const bool in_lds = ncols <= LDDT_LDS_COLS;
+    if (in_lds) {
+        for (uint32_t c = lane; c < ncols; c += 64) {
+            const uint32_t a1 = posA[c], b1 = posB[c];
+            sc[wv][0][c] = AX[a1]; sc[wv][1][c] = AY[a1]; sc[wv][2][c] = AZ[a1];
+            sc[wv][3][c] = BX[b1]; sc[wv][4][c] = BY[b1]; sc[wv][5][c] = BZ[b1];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
     for (uint32_t ci = lane; ci < ncols; ci += 64) {
         const uint32_t a1 = posA[ci], b1 = posB[ci];
         const float x1 = AX[a1], y1 = AY[a1], z1 = AZ[a1], u1 = BX[b1], v1 = BY[b1], w1 = BZ[b1];
         uint32_t cons = 0, pres = 0;
         for (uint32_t cj = 0; cj < ncols; ++cj) {
             if (cj == ci) continue;
-            const uint32_t a2 = posA[cj], b2 = posB[cj];
+            float x2, y2, z2, u2, v2, w2;
+            if (in_lds) {
+                x2 = sc[wv][0][cj]; y2 = sc[wv][1][cj]; z2 = sc[wv][2][cj]; u2 = sc[wv][3][cj]; v2 = sc[wv][4][cj]; w2 = sc[wv][5][cj];
+            } else {
+                const uint32_t a2 = posA[cj], b2 = posB[cj];
+                x2 = AX[a2]; y2 = AY[a2]; z2 = AZ[a2]; u2 = BX[b2]; v2 = BY[b2]; w2 = BZ[b2];
+            }
             // (x1-x2)^2 == (x2-x1)^2 exactly, so the reference's (lower column) - (higher column) order is immaterial
-            const float dx = x1 - AX[a2], dy = y1 - AY[a2], dz = z1 - AZ[a2];
-            const float ex = u1 - BX[b2], ey = v1 - BY[b2], ez = w1 - BZ[b2];
+            const float dx = x1 - x2, dy = y1 - y2, dz = z1 - z2;
+            const float ex = u1 - u2, ey = v1 - v2, ez = w1 - w2;
             float d1s = dx * dx; d1s += dy * dy; d1s += dz * dz;       // pdbchain.cpp:320-335: dx*dx + dy*dy + dz*dz
             float d2s = ex * ex; d2s += ey * ey; d2s += ez * ez;
             if (d1s > R0sq && d2s > R0sq) continue;
@@ -579,12 +605,14 @@ __global__ __launch_bounds__(256) void k_lddt(const char *paths, const uint64_t 
             pres += (diff <= 0.5f) + (diff <= 1.0f) + (diff <= 2.0f) + (diff <= 4.0f);
             cons += 4;
         }
-        frac[ci] = cons > 0 ? (float) pres / (float) cons : 0.0f;
+        const float fr = cons > 0 ? (float) pres / (float) cons : 0.0f;
+        if (in_lds) sc[wv][6][ci] = fr;
+        else frac[ci] = fr;
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     if (lane == 0) {
         float total = 0.0f;
-        for (uint32_t c = 0; c < ncols; ++c) total += frac[c];      // sequential, column order (lddt.cpp:111-121)
+        for (uint32_t c = 0; c < ncols; ++c) total += in_lds ? sc[wv][6][c] : frac[c];      // sequential, column order (lddt.cpp:111-121)
         lddt_out[p] = total / (float) ncols;
     }
 }
@@ -892,7 +920,7 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
         if ((rc = dalloc((void **) &d_frac, so * 4)) != RSK_OK) return rc;
         hipLaunchKernelGGL(k_lddt, dim3((unsigned) ((npairs + 3) / 4)), dim3(256), 0, ctx->stream, d_paths, d_pstart, d_plen, d_loa, d_lob,
                            d_ia, d_ib, dba->d_off, dbb->d_off, dba->d_x, dba->d_y, dba->d_z, dbb->d_x, dbb->d_y, dbb->d_z,
-                           (uint32_t) npairs, d_pos, d_scoff, d_frac, d_lddt, d_counts);
+                           (uint32_t) npairs, d_pos, d_scoff, d_frac, d_lddt, d_counts, d_score, min_fwd_score);
         RSK_HIP(hipGetLastError());
     }
     if (paths) {

@@ -38,9 +38,55 @@ def write_rskdb(path, seqs, rng):
             f.write(struct.pack("<I", len(km)) + km.astype(np.uint32).tobytes())
 
 
+def write_bca(path, lens, rng):
+    """Synthetic .bca (bcadata.cpp layout): CA traces = random walks with 3.8 A steps whose direction persists
+    (helix-like / strand-like stretches), amino acids iid.  Featurisation (DSS) and self-rev then run in LoadDB."""
+    n = len(lens)
+    with open(path, "wb") as f:
+        f.write(struct.pack("<IQQQ", 0xBCABCA, n, 0, 0))
+        for L in lens:
+            L = int(L)
+            aa = rng.integers(0, 20, L)
+            f.write(bytes(b"ACDEFGHIKLMNPQRSTVWY"[int(a)] for a in aa))
+            d = rng.normal(0, 1, (L, 3))
+            for k in range(1, L):                      # persistent direction
+                d[k] = 0.8 * d[k - 1] + 0.6 * d[k]
+            d /= np.linalg.norm(d, axis=1, keepdims=True)
+            xyz = np.cumsum(3.8 * d, axis=0)
+            xyz -= xyz.mean(axis=0)
+            ic = np.clip(((xyz.astype(np.float32) + 1000) * 10 + 0.5), 0, 65535).astype(np.uint16)
+            f.write(ic.tobytes())
+        pos = f.tell()
+        f.write(np.asarray(lens, np.uint32).tobytes())
+        labels = b"".join(("syn%05d" % k).encode() + b"\0" for k in range(n))
+        f.write(labels)
+        f.seek(4)
+        f.write(struct.pack("<QQQ", n, pos, len(labels)))
+
+
 def main():
     nch = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     mode = sys.argv[2] if len(sys.argv) > 2 else "sensitive"
+    if len(sys.argv) > 3 and sys.argv[3] == "bca":
+        lens = bench.scop40_lengths()
+        rng = np.random.default_rng(7)
+        if nch:
+            lens = lens[rng.choice(len(lens), nch, replace=nch > len(lens))]
+        ctx = reseek_amd.Ctx(0, stream=torch.cuda.current_stream().cuda_stream)
+        with tempfile.TemporaryDirectory() as td:
+            db = os.path.join(td, "syn.bca")
+            write_bca(db, lens, rng)
+            out = os.path.join(td, "hits.tsv")
+            res = {}
+            for rep in range(2):
+                t0 = time.perf_counter()
+                nhits, st = ctx.search_rskdb(db, out, mode)
+                dt = time.perf_counter() - t0
+                res["run%d" % rep] = {"seconds": dt, "pairs": int(st[0]), "pairs_per_s": st[0] / dt, "mufilter_in": int(st[2]),
+                                      "mufilter_discard": int(st[3]), "mkf_pairs": int(st[4]), "sw_pairs": int(st[5]), "hits": int(nhits)}
+            print(json.dumps({"input": ".bca (host DSS featurisation + GPU self-rev inside the timed call)", "chains": len(lens),
+                              "mode": mode, **res}, indent=1))
+        return
     seqs = bench.synth_mu_chains(0x5EED5EEC, nch or None)
     rng = np.random.default_rng(5)
     ctx = reseek_amd.Ctx(0, stream=torch.cuda.current_stream().cuda_stream)
