@@ -109,5 +109,20 @@ for f in q10 q100 palms; do gzip -9n < $T/$f.bca > $G/$f.bca.gz; done
 # 10. D1 leftovers on real chains
 $H d1pairs $T/q100.bca $TMP/d1pairs_q40.bin 40 -- -sensitive
 gzip -9n < $TMP/d1pairs_q40.bin > $G/d1pairs_q40_sensitive.bin.gz
+# 11. edge cases: chains of 1..65 residues, a 2099-residue chain, a duplicate chain and a duplicated label
+python3 $G/make_edge_bca.py $TMP/edge.bca
+gzip -9n < $TMP/edge.bca > $G/edge.bca.gz
+for m in sensitive fast verysensitive; do
+  $R -search $TMP/edge.bca -$m -columns $COLS -output $TMP/edge_$m.tsv -threads 1 -quiet >/dev/null 2>&1
+  sort $TMP/edge_$m.tsv | gzip -9n > $G/hits_edge_$m.tsv.gz
+done
+$R -search $TMP/edge.bca -db $TMP/edge.bca -sensitive -columns $COLS -output $TMP/edge_db.tsv -threads 1 -quiet >/dev/null 2>&1
+sort $TMP/edge_db.tsv | gzip -9n > $G/hits_edge_db.tsv.gz
+$R -search $TMP/edge.bca -db $TMP/edge.bca -sensitive -noself -columns $COLS -output $TMP/edge_db_noself.tsv -threads 1 -quiet >/dev/null 2>&1
+sort $TMP/edge_db_noself.tsv | gzip -9n > $G/hits_edge_db_noself.tsv.gz
+mkdir -p $TMP/kt3
+TMPDIR=$TMP/kt3 $R -search $TMP/edge.bca -db $TMP/edge.bca -fast -columns $COLS -output $TMP/edge_fastdb.tsv -threads 1 -keeptmp -quiet >/dev/null 2>&1
+sort $TMP/edge_fastdb.tsv | gzip -9n > $G/hits_edge_fastdb.tsv.gz
+gzip -9n < $TMP/kt3/rce.*.tmp > $G/prefilter_edge_fastdb_tmp.tsv.gz
 rm -rf $TMP
 ls -la $G

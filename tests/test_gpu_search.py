@@ -196,3 +196,21 @@ def test_sharded_search_equals_unsharded(ctx, tmpdir):
     from reseek_amd import capi
     with pytest.raises(capi.RskError):
         ctx.search(q, os.path.join(tmpdir, "x.tsv"), "fast", db=q, shard_index=0, shard_count=2)
+
+
+def test_edge_case_chains(ctx, tmpdir):
+    """Ragged input (tests/golden/make_edge_bca.py): chains of 1, 2, 3, 5, 7, 8, 12, 31..33, 63..65 residues (below the
+    k-mer / DSS window sizes), a 2099-residue chain (MKF + row groups), an identical chain under another label and
+    a repeated label -- every mode, -db with and without -noself, and the two-stage -fast -db path."""
+    e = unpack_bca("edge.bca", tmpdir)
+    run_bca(ctx, tmpdir, "edge.bca", "sensitive", COLS, "hits_edge_sensitive.tsv.gz")
+    run_bca(ctx, tmpdir, "edge.bca", "fast", COLS, "hits_edge_fast.tsv.gz")
+    run_bca(ctx, tmpdir, "edge.bca", "verysensitive", COLS, "hits_edge_verysensitive.tsv.gz")
+    run_bca(ctx, tmpdir, "edge.bca", "sensitive", COLS, "hits_edge_db.tsv.gz", db="edge.bca")
+    out = os.path.join(tmpdir, "edge_noself.tsv")
+    ctx.search(e, out, "sensitive", db=e, columns=COLS, noself=1)
+    assert sorted(open(out).read().splitlines()) == ["\t".join(r) for r in fx.read_tsv("hits_edge_db_noself.tsv.gz")]
+    out = os.path.join(tmpdir, "edge_fastdb.tsv")
+    ctx.search(e, out, "fast", db=e, columns=COLS, keeptmp=1)
+    assert sorted(open(out).read().splitlines()) == ["\t".join(r) for r in fx.read_tsv("hits_edge_fastdb.tsv.gz")]
+    assert open(out + ".prefilter.tmp").read() == gzip.open(os.path.join(fx.GOLDEN, "prefilter_edge_fastdb_tmp.tsv.gz")).read().decode()
