@@ -5,9 +5,11 @@
 // per-query top-B selection depends on arrival order under score ties, so it is replayed here in the
 // order the reference produces with -threads 1 (targets ascending).  It is O(#triples) host work.
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <map>
 #include <numeric>
+#include <thread>
 #include <vector>
 
 #include "reseek_host.h"
@@ -94,17 +96,41 @@ extern "C" int rsk_rsb_select(const uint32_t *q, const uint32_t *t, const uint32
                               uint32_t *out_q, uint32_t *out_t, uint32_t *out_score, size_t *nout, const char *tmp_tsv_path)
 {
     if ((n && (!q || !t || !score)) || !nout || rsb_size == 0) { rsk_set_error("rsk_rsb_select: bad argument"); return RSK_E_INVALID; }
-    std::vector<uint32_t> ord(n);
-    std::iota(ord.begin(), ord.end(), 0u);
-    std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return t[a] != t[b] ? t[a] < t[b] : q[a] < q[b]; });
+    // A query's bag only depends on ITS triples in target order, so the queries are replayed independently on the
+    // host threads: counting sort by query, then per query a sort by target and the AddScore sequence.
+    for (size_t k = 0; k < n; ++k)
+        if (q[k] >= nqueries) { rsk_set_error("rsk_rsb_select: query index out of range"); return RSK_E_INVALID; }
+    std::vector<size_t> qstart((size_t) nqueries + 1, 0);
+    for (size_t k = 0; k < n; ++k) ++qstart[q[k] + 1];
+    for (uint32_t i = 0; i < nqueries; ++i) qstart[i + 1] += qstart[i];
+    std::vector<uint64_t> byq(n);                       // target << 16 | score, grouped by query
+    {
+        std::vector<size_t> cur(qstart.begin(), qstart.end() - 1);
+        for (size_t k = 0; k < n; ++k) byq[cur[q[k]]++] = ((uint64_t) t[k] << 16) | (uint16_t) score[k];
+    }
     RankedScoresBag RSB;
     RSB.m_B = rsb_size;
     RSB.Init(nqueries);
-    for (uint32_t k : ord) {
-        if (q[k] >= nqueries) { rsk_set_error("rsk_rsb_select: query index out of range"); return RSK_E_INVALID; }
-        RSB.AddScore(q[k], t[k], (uint16_t) score[k]);
+    {
+        const unsigned T = (unsigned) std::max<size_t>(1, std::min<size_t>({ (size_t) std::thread::hardware_concurrency(), (size_t) 64, n / 65536 + 1 }));
+        std::atomic<uint32_t> next{0};
+        auto body = [&]() {
+            for (;;) {
+                const uint32_t qi = next.fetch_add(1);
+                if (qi >= nqueries) return;
+                uint64_t *b = byq.data() + qstart[qi], *e = byq.data() + qstart[qi + 1];
+                std::sort(b, e);                                   // a (query, target) pair occurs once: order = target order
+                for (uint64_t *x = b; x != e; ++x) RSB.AddScore(qi, (uint) (*x >> 16), (uint16_t) (*x & 0xFFFF));
+                RSB.TruncateVecs(qi);
+            }
+        };
+        if (T == 1) body();
+        else {
+            std::vector<std::thread> ts;
+            for (unsigned k = 0; k < T; ++k) ts.emplace_back(body);
+            for (auto &th : ts) th.join();
+        }
     }
-    RSB.Finish();
     size_t m = 0;
     for (uint32_t qi = 0; qi < nqueries; ++qi) {
         const auto &S = RSB.m_QueryIdxToScoreVec[qi];

@@ -17,6 +17,8 @@
 //     equal q are max-reduced and (q, t, score) is appended to the output with one atomic per run.
 //   * targets with more hits than fit in LDS are processed in query-range chunks.
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include <hipcub/hipcub.hpp>
@@ -134,6 +136,10 @@ struct pf_args {
     uint32_t capacity;
     uint32_t *out_n;
     uint32_t *overflow;            // set if a single 64-query bucket exceeds PF_CAP hits for one target
+    unsigned long long *hits;      // statistics: (TPos, posting) items seen over all targets
+    uint32_t t_base;               // first target of this launch (targets are batched by scratch size)
+    const uint64_t *koff;          // per target of the launch: offset of its key region in kscratch
+    uint32_t *kscratch;            // keys (q << 14 | diag) of a target, grouped by 64-query bucket (written once, read once)
 };
 
 __device__ __forceinline__ uint32_t pf_kmer(const uint8_t *s, int &self)
@@ -150,20 +156,46 @@ __device__ __forceinline__ uint32_t pf_kmer(const uint8_t *s, int &self)
     return k;
 }
 
+// upper bound of the keys of each target (sum of the index row sizes of its unmasked k-mers) -> sizes the scratch
+__global__ __launch_bounds__(256) void k_pf_rowsum(const uint2 *table, const uint8_t *t_mu, const uint32_t *t_off, const uint32_t *t_len,
+                                                   uint32_t nt, uint64_t *sums)
+{
+    const uint32_t t = blockIdx.x;
+    if (t >= nt) return;
+    __shared__ unsigned long long acc;
+    if (threadIdx.x == 0) acc = 0;
+    __syncthreads();
+    const uint32_t TL = t_len[t];
+    const uint8_t *T = t_mu + t_off[t];
+    unsigned long long mine = 0;
+    for (uint32_t p = threadIdx.x; p + 7 <= TL; p += blockDim.x) {
+        int self;
+        const uint32_t k = pf_kmer(T + p, self);
+        if (self < PF_MINSELF) continue;
+        mine += table[k].y;
+    }
+    if (mine) atomicAdd(&acc, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) sums[t] = acc;
+}
+
 __global__ __launch_bounds__(PF_THREADS) void k_prefilter(pf_args a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t *keys = (uint32_t *) smem;                                  // PF_CAP
     uint32_t *score = keys + PF_CAP;                                     // PF_CAP (score of the run head candidates)
     uint32_t *bucket = score + PF_CAP;                                   // 1025: hits per 64-query bucket
-    uint32_t *sv = bucket + 1032;                                        // 8 scalars shared by the workgroup
+    uint32_t *boff = bucket + 1032;                                      // 1025: start of each bucket in this target's key region
+    uint32_t *cursor = boff + 1032;                                      // 1024: scatter cursors
+    uint32_t *sv = cursor + 1024;                                        // 8 scalars shared by the workgroup
     signed char *mat = (signed char *) (sv + 8);                         // 1296
     uint8_t *tl = (uint8_t *) (mat + 1312);                              // target letters, up to 65536 + 16
     uint32_t &s_n = sv[0], &s_total = sv[1], &s_chunk_lo = sv[2], &s_chunk_hi = sv[3], &s_more = sv[4];
 
     const int tid = threadIdx.x;
     for (int i = tid; i < 1296; i += PF_THREADS) mat[i] = c_mu_s8[i];
-    const uint32_t t = blockIdx.x;
+    const uint32_t t = a.t_base + blockIdx.x;
+    uint32_t *kscr = a.kscratch + a.koff[blockIdx.x];
     const uint32_t TL = a.t_len[t];
     const uint8_t *T = a.t_mu + a.t_off[t];
     for (uint32_t i = tid; i < TL; i += PF_THREADS) tl[i] = T[i];
@@ -193,7 +225,35 @@ __global__ __launch_bounds__(PF_THREADS) void k_prefilter(pf_args a)
     __syncthreads();
     if (my_total) atomicAdd(&s_total, my_total);
     __syncthreads();
+    if (tid == 0 && a.hits) atomicAdd(a.hits, (unsigned long long) s_total);
     if (s_total < 2) return;
+    // ---- every key goes ONCE to this target's region of the HBM scratch, grouped by bucket (counting sort);
+    // the chunks below are then contiguous ranges of it (re-walking the index rows per chunk was quadratic
+    // in the hits of a target -- neighbourhood indexes have ~100x the hits of exact k-mers)
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int b = 0; b < 1024; ++b) { boff[b] = run; run += bucket[b]; }
+        boff[1024] = run;
+    }
+    __syncthreads();
+    for (int i = tid; i < 1024; i += PF_THREADS) cursor[i] = boff[i];
+    __syncthreads();
+    for (uint32_t p = tid; p < NK; p += PF_THREADS) {
+        int self;
+        const uint32_t k = pf_kmer(tl + p, self);
+        if (self < PF_MINSELF) continue;
+        const uint2 r = a.table[k];
+        for (uint32_t c = 0; c < r.y; ++c) {
+            const uint32_t post = a.postings[r.x + c];
+            const uint32_t q = post >> 16, qp = post & 0xFFFFu;
+            const uint32_t d = (a.q_len[q] + p - qp - 1) & 0xFFFFu;
+            if (d > 16383u) continue;
+            const uint32_t pos = atomicAdd(&cursor[q >> 6], 1u);
+            __hip_atomic_store(kscr + pos, (q << 14) | d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __threadfence();
+    __syncthreads();
 
     uint32_t chunk_lo = 0;                    // first bucket of the current chunk
     for (;;) {
@@ -218,18 +278,9 @@ __global__ __launch_bounds__(PF_THREADS) void k_prefilter(pf_args a)
                 if (tid == 0) s_n = 0;
                 __syncthreads();
                 const uint32_t QL = a.q_len[q];
-                for (uint32_t p = tid; p < NK; p += PF_THREADS) {
-                    int self;
-                    const uint32_t k = pf_kmer(tl + p, self);
-                    if (self < PF_MINSELF) continue;
-                    const uint2 r = a.table[k];
-                    for (uint32_t c = 0; c < r.y; ++c) {          // rows are unordered (atomic fill): linear scan
-                        const uint32_t post = a.postings[r.x + c];
-                        if ((post >> 16) != q) continue;
-                        const uint32_t d = (QL + p - (post & 0xFFFFu) - 1) & 0xFFFFu;
-                        if (d > 16383u) continue;
-                        atomicAdd(&hist[d], 1u);
-                    }
+                for (uint32_t idx = boff[s_chunk_lo] + tid; idx < boff[s_chunk_hi]; idx += PF_THREADS) {
+                    const uint32_t key = __hip_atomic_load(kscr + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((key >> 14) == q) atomicAdd(&hist[key & 16383u], 1u);
                 }
                 __syncthreads();
                 uint32_t best = 0;
@@ -257,22 +308,11 @@ __global__ __launch_bounds__(PF_THREADS) void k_prefilter(pf_args a)
                 __syncthreads();
             }
         } else if (expect >= 2) {
-            // ---- expand the hits of this chunk into LDS keys
-            for (uint32_t p = tid; p < NK; p += PF_THREADS) {
-                int self;
-                const uint32_t k = pf_kmer(tl + p, self);
-                if (self < PF_MINSELF) continue;
-                const uint2 r = a.table[k];
-                for (uint32_t c = 0; c < r.y; ++c) {
-                    const uint32_t post = a.postings[r.x + c];
-                    const uint32_t q = post >> 16, qp = post & 0xFFFFu;
-                    if (q < qlo || q >= qhi) continue;
-                    const uint32_t d = (a.q_len[q] + p - qp - 1) & 0xFFFFu;
-                    if (d > 16383u) continue;
-                    const uint32_t pos = atomicAdd(&s_n, 1u);
-                    if (pos < PF_CAP) keys[pos] = (q << 14) | d;
-                }
-            }
+            // ---- the keys of this chunk are one contiguous range of the scratch
+            const uint32_t k0 = boff[s_chunk_lo], k1 = boff[s_chunk_hi];
+            for (uint32_t idx = k0 + tid; idx < k1; idx += PF_THREADS)
+                keys[idx - k0] = __hip_atomic_load(kscr + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) s_n = k1 - k0;
             __syncthreads();
             const uint32_t n = min(s_n, (uint32_t) PF_CAP);
             uint32_t np2 = 2;
@@ -396,8 +436,8 @@ extern "C" int rsk_mu_prefilter_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db 
     for (uint32_t L : t->len)
         if (L > 65534) { rsk_set_error("rsk_mu_prefilter_dev: target longer than 65534"); return RSK_E_RANGE; }
     uint32_t *d_over = nullptr;
-    RSK_HIP(hipMalloc((void **) &d_over, 4));
-    RSK_HIP(hipMemsetAsync(d_over, 0, 4, ctx->stream));
+    RSK_HIP(hipMalloc((void **) &d_over, 16));
+    RSK_HIP(hipMemsetAsync(d_over, 0, 16, ctx->stream));
     RSK_HIP(hipMemsetAsync(d_n, 0, 4, ctx->stream));
     pf_args a = {};
     a.table = (const uint2 *) q->d_pf_table; a.postings = q->d_pf_postings;
@@ -405,19 +445,62 @@ extern "C" int rsk_mu_prefilter_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db 
     a.t_mu = t->d_mu; a.t_off = t->d_off; a.t_len = t->d_len; a.nt = t->n; a.nq = q->n;
     a.out_q = d_out_q; a.out_t = d_out_t; a.out_score = d_out_score;
     a.capacity = (uint32_t) std::min<size_t>(capacity, 0xFFFFFFFFu);
-    a.out_n = d_n; a.overflow = d_over;
+    a.out_n = d_n; a.overflow = d_over; a.hits = (unsigned long long *) (d_over + 2);
     uint32_t maxTL = 0;
     for (uint32_t L : t->len) maxTL = std::max(maxTL, L);
-    const size_t lds = (size_t) PF_CAP * 8 + 1040 * 4 + 1312 + (((size_t) maxTL + 31) & ~15u);
+    const size_t lds = (size_t) PF_CAP * 8 + (1032 + 1032 + 1024 + 8) * 4 + 1312 + (((size_t) maxTL + 31) & ~15u);
     if (lds > 163000) { rsk_set_error("rsk_mu_prefilter_dev: target of %u residues does not fit the LDS staging", maxTL); (void) hipFree(d_over); return RSK_E_RANGE; }
     RSK_HIP(hipFuncSetAttribute((const void *) k_prefilter, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
     RSK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-    if (t->n) hipLaunchKernelGGL(k_prefilter, dim3(t->n), dim3(PF_THREADS), lds, ctx->stream, a);
-    RSK_HIP(hipGetLastError());
+    if (t->n) {
+        // key scratch: per target an upper bound of its keys; targets go in batches whose scratch fits the budget
+        uint64_t *d_sums = nullptr;
+        RSK_HIP(hipMalloc((void **) &d_sums, (size_t) t->n * 8));
+        hipLaunchKernelGGL(k_pf_rowsum, dim3(t->n), dim3(256), 0, ctx->stream, (const uint2 *) q->d_pf_table, t->d_mu, t->d_off, t->d_len, t->n, d_sums);
+        std::vector<uint64_t> sums(t->n);
+        RSK_HIP(hipMemcpyAsync(sums.data(), d_sums, (size_t) t->n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        RSK_HIP(hipStreamSynchronize(ctx->stream));
+        (void) hipFree(d_sums);
+        const uint64_t budget_keys = 12ull << 30;                       // 48 GB of 4-byte keys per batch
+        uint32_t *d_scr = nullptr;
+        uint64_t *d_koff = nullptr;
+        uint64_t scr_cap = 0;
+        std::vector<uint64_t> koff;
+        for (uint32_t t0 = 0; t0 < t->n;) {
+            uint32_t t1 = t0;
+            uint64_t keys = 0;
+            koff.clear();
+            while (t1 < t->n && (t1 == t0 || keys + sums[t1] <= budget_keys)) { koff.push_back(keys); keys += sums[t1]; ++t1; }
+            if (keys + 16 > scr_cap) {
+                if (d_scr) (void) hipFree(d_scr);
+                scr_cap = keys + 16;
+                if (hipMalloc((void **) &d_scr, scr_cap * 4) != hipSuccess) {
+                    (void) hipFree(d_over); if (d_koff) (void) hipFree(d_koff);
+                    rsk_set_error("rsk_mu_prefilter_dev: out of device memory for %llu seed keys", (unsigned long long) keys);
+                    return RSK_E_NOMEM;
+                }
+            }
+            if (d_koff) (void) hipFree(d_koff);
+            RSK_HIP(hipMalloc((void **) &d_koff, koff.size() * 8));
+            RSK_HIP(hipMemcpyAsync(d_koff, koff.data(), koff.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+            a.t_base = t0; a.koff = d_koff; a.kscratch = d_scr;
+            hipLaunchKernelGGL(k_prefilter, dim3(t1 - t0), dim3(PF_THREADS), lds, ctx->stream, a);
+            RSK_HIP(hipGetLastError());
+            RSK_HIP(hipStreamSynchronize(ctx->stream));                 // koff (host vector) and the scratch are reused by the next batch
+            t0 = t1;
+        }
+        if (d_scr) (void) hipFree(d_scr);
+        if (d_koff) (void) hipFree(d_koff);
+    }
     RSK_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     uint32_t over = 0;
+    unsigned long long hits = 0;
     RSK_HIP(hipMemcpyAsync(&over, d_over, 4, hipMemcpyDeviceToHost, ctx->stream));
+    RSK_HIP(hipMemcpyAsync(&hits, d_over + 2, 8, hipMemcpyDeviceToHost, ctx->stream));
     RSK_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->pf_hits = hits;
+    ctx->pf_postings = q->pf_postings;
+    if (getenv("RSK_TRACE")) fprintf(stderr, "[prefilter] index postings %zu, seed items %llu\n", q->pf_postings, hits);
     (void) hipFree(d_over);
     if (over) { rsk_set_error("rsk_mu_prefilter_dev: more than %d k-mer hits between one target and 64 consecutive queries", PF_CAP); return RSK_E_RANGE; }
     return RSK_OK;

@@ -137,3 +137,19 @@ def test_neighbourhood_self_1000(ctx):
     rq, rt, rs = reseek_amd.capi.rsb_select(q, t, s, len(seqs), 1500)
     want = gzip.open(os.path.join(fx.GOLDEN, "prefilter_hood_h1000_scores.tsv.gz")).read().decode()
     assert scores_text(labels, rq, rt, rs) == want
+
+
+def test_scop40_full_neighbourhood_checksums(ctx):
+    """All 11,211 SCOP40 Mu sequences against themselves WITH k-mer neighbourhoods (> 100 queries -> idxt), as
+    MuPreFilter runs inside `-search -fast -db`: 2.9e9 seed items, 65 M (query, target) two-hit pairs, top-1500 per
+    query -> md5 of the reference's score list and hand-off file (ref_harness prefhood, ~15 min on one CPU thread)."""
+    import reseek_amd
+    labels, seqs = fx.read_mu_fasta("scop40.mu.fa.gz")
+    q, t, s, ms = run_prefilter(ctx, seqs, cap=80_000_000, mode=-1)
+    with tempfile.TemporaryDirectory() as td:
+        tmp = os.path.join(td, "tmp.tsv")
+        rq, rt, rs = reseek_amd.capi.rsb_select(q, t, s, len(seqs), 1500, tmp_tsv_path=tmp)
+        want = dict(zip(*[iter(open(os.path.join(fx.GOLDEN, "prefilter_hood_scop40_full.md5.txt")).read().split())] * 2))
+        assert len(rq) == int(want["lines"])
+        assert hashlib.md5(scores_text(labels, rq, rt, rs).encode()).hexdigest() == want["sorted_scores_md5"]
+        assert hashlib.md5(open(tmp, "rb").read()).hexdigest() == want["tmp_tsv_md5"]
