@@ -78,13 +78,14 @@ def main():
             write_bca(db, lens, rng)
             out = os.path.join(td, "hits.tsv")
             res = {}
+            use_db = len(sys.argv) > 4 and sys.argv[4] == "db"      # Q vs the same set as -db (mode fast -> prefilter path)
             for rep in range(2):
                 t0 = time.perf_counter()
-                nhits, st = ctx.search_rskdb(db, out, mode)
+                nhits, st = ctx.search_rskdb(db, out, mode, db=db if use_db else None)
                 dt = time.perf_counter() - t0
                 res["run%d" % rep] = {"seconds": dt, "pairs": int(st[0]), "pairs_per_s": st[0] / dt, "mufilter_in": int(st[2]),
                                       "mufilter_discard": int(st[3]), "mkf_pairs": int(st[4]), "sw_pairs": int(st[5]), "hits": int(nhits)}
-            print(json.dumps({"input": ".bca (host DSS featurisation + GPU self-rev inside the timed call)", "chains": len(lens),
+            print(json.dumps({"input": ".bca (host DSS featurisation + GPU self-rev inside the timed call)", "db": use_db, "chains": len(lens),
                               "mode": mode, **res}, indent=1))
         return
     seqs = bench.synth_mu_chains(0x5EED5EEC, nch or None)
