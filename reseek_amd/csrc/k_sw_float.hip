@@ -303,23 +303,41 @@ struct swq_item { uint32_t first, count; };
 #define SWQ_BIT_GE(w, x, y) asm("v_cmp_ge_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(w) : "v"(x), "v"(y) : "vcc")
 #define SWQ_BIT_0GE(w, y) asm("v_cmp_ge_f32_e32 vcc, 0, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(w) : "v"(y) : "vcc")
 
+typedef float swq_v2f __attribute__((ext_vector_type(2)));
+typedef float swq_v4f __attribute__((ext_vector_type(4)));
+typedef const volatile __attribute__((address_space(3))) swq_v4f *swq_ldsp;   // volatile: see the fetch in k_sw_qp
+// v_max_f32 without the canonicalising v_max x, x, x that fmaxf() costs per fresh operand (no NaNs occur here)
+__device__ __forceinline__ float swq_max(float x, float y)
+{
+    float r;
+    asm("v_max_f32_e32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+
 template <bool T>
 __global__ __launch_bounds__(64 * SWQ_NW) void k_sw_qp(swf_args a, const swq_item *items)
 {
-    extern __shared__ __attribute__((aligned(16))) float qp[];
+    extern __shared__ float4 qp4[];
+    float *qp = (float *) qp4;
     constexpr int R = SWQ_R;
     const swq_item it = items[blockIdx.x];
     const uint32_t strip_chain = T ? a.ib[it.first] : a.ia[it.first];
     const uint32_t LA = T ? a.b_len[strip_chain] : a.a_len[strip_chain];     // strip chain length
     const uint32_t g = (LA + R - 1) / R;
-    const uint32_t gs = g * R;                     // floats per (f,c) row of the profile
-    uint32_t *next_batch = (uint32_t *) (qp + (size_t) SWQ_NFC * gs);
+    constexpr uint32_t G = SWQ_MAX_G;              // fixed row geometry: quad blocks G float4 apart, rows (R/4) * G float4 apart
+    uint32_t *next_batch = (uint32_t *) (qp + (size_t) SWQ_NFC * (R / 4) * G * 4);
     {
         const uint8_t *sp = T ? (a.b_prof + a.b_off[strip_chain]) : (a.a_prof + a.a_off[strip_chain]);
         const size_t snpad = T ? a.b_npad : a.a_npad;
-        const uint32_t tot = SWQ_NFC * gs;
+        const uint32_t gs = g * R, tot = SWQ_NFC * gs;
         for (uint32_t idx = threadIdx.x; idx < tot; idx += blockDim.x) {
-            const uint32_t fc = idx / gs, i = idx - fc * gs;
+            // float4 ((fc * (R/4) + quad) * G + strip) holds residues strip * R + quad * 4 + 0..3 of row fc: the
+            // ds_read_b128 of the g lanes of a pair are 16 B apart, and the R/4 quads of a lane sit at
+            // immediate offsets (quad * G * 16 B) from one address
+            const uint32_t fc = idx / gs, rem = idx - fc * gs;
+            const uint32_t quad = rem / (g * 4), rem2 = rem - quad * (g * 4);
+            const uint32_t strip = rem2 >> 2, w = rem2 & 3;
+            const uint32_t i = strip * R + quad * 4 + w;
             const uint32_t f = fc < 20 ? 0 : ((fc - 20) >> 4) + 1;
             const uint32_t c = fc < 20 ? fc : ((fc - 20) & 15);
             const uint32_t as = f == 0 ? 20 : 16, tof = f == 0 ? 0 : 400 + (f - 1) * 256;
@@ -328,7 +346,7 @@ __global__ __launch_bounds__(64 * SWQ_NW) void k_sw_qp(swf_args a, const swq_ite
                 const uint32_t letter = sp[(size_t) f * snpad + i];
                 v = c_swf_tables.t[tof + (T ? c * as + letter : letter * as + c)];
             }
-            qp[idx] = v;
+            qp[((fc * (R / 4) + quad) * G + strip) * 4 + w] = v;
         }
         if (threadIdx.x == 0) *next_batch = 0;
     }
@@ -339,8 +357,7 @@ __global__ __launch_bounds__(64 * SWQ_NW) void k_sw_qp(swf_args a, const swq_ite
     const uint32_t pr = lane / g, st = lane - pr * g;
     const float Open = a.open, Ext = a.ext;
     const uint32_t i0 = st * R;
-    const uint32_t gsb = gs * 4;                   // bytes per (f,c) row
-    const char *qpl = (const char *) qp + i0 * 4;  // this lane's record within a row
+    const swq_ldsp qpl = (swq_ldsp) qp4 + st;  // this lane's float4 slot within a quad block
     for (;;) {
         uint32_t b = 0;
         if (lane == 0) b = atomicAdd(next_batch, 1u);
@@ -374,12 +391,12 @@ __global__ __launch_bounds__(64 * SWQ_NW) void k_sw_qp(swf_args a, const swq_ite
                 const uint4 cb = cbn;
                 cbn = *(const uint4 *) (bcb + (size_t) (j + 1) * 8);
                 const uint32_t cbw[4] = { cb.x, cb.y, cb.z, cb.w };
-                const char *rec[8];
+                swq_ldsp rec[8];
 #pragma unroll
                 for (int f = 0; f < 8; ++f) {
                     const uint32_t c4 = (f & 1) ? (cbw[f >> 1] >> 16) : (cbw[f >> 1] & 0xFFFFu);      // letter * 4
                     const uint32_t fcb = f == 0 ? 0 : 20 + (f - 1) * 16;
-                    rec[f] = qpl + (fcb * gsb + (c4 >> 2) * gsb);
+                    rec[f] = qpl + (fcb + (c4 >> 2)) * ((R / 4) * G);
                 }
                 float ch = st == 0 ? SWF_MINUS_INF : in_d;
                 if (st != 0) Md[0] = carry_in;
@@ -388,13 +405,14 @@ __global__ __launch_bounds__(64 * SWQ_NW) void k_sw_qp(swf_args a, const swq_ite
                 uint32_t w = 0;
 #pragma unroll
                 for (int q = 0; q < R / 4; ++q) {
-                    float4 v[8];
+                    // volatile keeps each fetch one ds_read_b128 (the SLP vectoriser would split it into b64 halves)
+                    swq_v4f v[8];
 #pragma unroll
-                    for (int f = 0; f < 8; ++f) v[f] = *(const float4 *) (rec[f] + q * 16);
-                    float S4[4];
-                    S4[0] = v[0].x; S4[1] = v[0].y; S4[2] = v[0].z; S4[3] = v[0].w;
+                    for (int f = 0; f < 8; ++f) v[f] = rec[f][q * G];
+                    swq_v2f Slo = v[0].lo, Shi = v[0].hi;              // v_pk_add_f32: two residues per add
 #pragma unroll
-                    for (int f = 1; f < 8; ++f) { S4[0] += v[f].x; S4[1] += v[f].y; S4[2] += v[f].z; S4[3] += v[f].w; }
+                    for (int f = 1; f < 8; ++f) { Slo += v[f].lo; Shi += v[f].hi; }
+                    const float S4[4] = { Slo.x, Slo.y, Shi.x, Shi.y };
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr) {
                         const int r = q * 4 + rr;
@@ -403,20 +421,20 @@ __global__ __launch_bounds__(64 * SWQ_NW) void k_sw_qp(swf_args a, const swq_ite
                         const float n = T ? ch : In[r];
                         Md[r] = carry;
                         SWQ_BIT_GT(w, d, m);                 // TB_DM candidate (sw.cpp:127)
-                        const float x1 = fmaxf(m, d);
+                        const float x1 = swq_max(m, d);
                         SWQ_BIT_GT(w, n, x1);                // TB_IM (sw.cpp:135)
-                        const float x2 = fmaxf(x1, n);
+                        const float x2 = swq_max(x1, n);
                         SWQ_BIT_0GE(w, x2);                  // TB_SM (sw.cpp:143)
-                        const float xM = fmaxf(x2, 0.0f) + S4[rr];
+                        const float xM = swq_max(x2, 0.0f) + S4[rr];
                         if (xM > rb[r]) { rb[r] = xM; rj[r] = (uint32_t) j; }
                         carry = xM;
                         const float md = m + Open;
                         const float de = d + Ext;
                         SWQ_BIT_GE(w, md, de);               // TB_MD (sw.cpp:166)
-                        const float dd = fmaxf(md, de);
+                        const float dd = swq_max(md, de);
                         const float ne = n + Ext;
                         SWQ_BIT_GE(w, md, ne);               // TB_MI (sw.cpp:181)
-                        const float ni = fmaxf(md, ne);
+                        const float ni = swq_max(md, ne);
                         if (T) { ch = ni; In[r] = dd; }
                         else { ch = dd; In[r] = ni; }
                         if (r % 6 == 5 || r == R - 1) tbp[(size_t) j * g * SWQ_W + r / 6] = w;
@@ -896,7 +914,8 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
             const uint32_t chain = c == 0 ? sia[q.first] : sib[q.first];
             gmax = std::max(gmax, (sdb->len[chain] + SWQ_R - 1) / SWQ_R);
         }
-        const size_t lds = (size_t) SWQ_NFC * gmax * SWQ_R * 4 + 16;
+        (void) gmax;
+        const size_t lds = (size_t) SWQ_NFC * (SWQ_R / 4) * SWQ_MAX_G * 16 + 16;   // fixed row geometry
         const swq_item *d_q = (const swq_item *) (D + (c == 0 ? o_q0 : o_q1));
         if (c == 0) hipLaunchKernelGGL(k_sw_qp<false>, dim3((unsigned) qitems[c].size()), dim3(64 * SWQ_NW), lds, ctx->stream, a, d_q);
         else hipLaunchKernelGGL(k_sw_qp<true>, dim3((unsigned) qitems[c].size()), dim3(64 * SWQ_NW), lds, ctx->stream, a, d_q);
