@@ -282,7 +282,8 @@ __global__ __launch_bounds__(64 * SWF_WAVES) void k_sw_float(swf_args a, uint32_
 // its filter survivors).  One workgroup = one group: it first expands the strip chain into a
 // "query profile" in LDS,
 //     QP[f][c][i] = feature table f, strip-chain letter of residue i, against step-chain letter c
-//     (132 (f,c) combinations x LApad floats = 528 B per residue: chains up to SWQ_MAX_L residues),
+//     (132 (f,c) combinations x 528 B per residue: SWQ_MAX_L residues per profile; a longer strip chain is
+//     processed in segments of SWQ_MAX_G strips, one profile after the other, rows meeting through `bnd`),
 // stored as records of R consecutive residues, so that a lane fetches the S-contributions of its
 // whole strip for one feature with R/4 ds_read_b128 and no per-cell address arithmetic
 // (the legacy kernel above spends 8 ds_read_b32 + 16 address ops per cell).  Waves claim batches
@@ -320,24 +321,31 @@ __global__ __launch_bounds__(64 * SWQ_NW) void k_sw_qp(swf_args a, const swq_ite
     extern __shared__ float4 qp4[];
     float *qp = (float *) qp4;
     constexpr int R = SWQ_R;
+    constexpr uint32_t G = SWQ_MAX_G;              // fixed row geometry: quad blocks G float4 apart, rows (R/4) * G float4 apart
     const swq_item it = items[blockIdx.x];
     const uint32_t strip_chain = T ? a.ib[it.first] : a.ia[it.first];
     const uint32_t LA = T ? a.b_len[strip_chain] : a.a_len[strip_chain];     // strip chain length
-    const uint32_t g = (LA + R - 1) / R;
-    constexpr uint32_t G = SWQ_MAX_G;              // fixed row geometry: quad blocks G float4 apart, rows (R/4) * G float4 apart
+    const uint32_t gtot = (LA + R - 1) / R;        // strips of the whole chain
+    const uint32_t nseg = (gtot + G - 1) / G;      // segments of up to G strips: one LDS profile each
     uint32_t *next_batch = (uint32_t *) (qp + (size_t) SWQ_NFC * (R / 4) * G * 4);
+    const int lane = threadIdx.x & 63;
+    const float Open = a.open, Ext = a.ext;
+    for (uint32_t seg = 0; seg < nseg; ++seg) {
+    const uint32_t sbase = seg * G;                // first strip of this segment
+    const uint32_t g = min(G, gtot - sbase);
+    if (seg) { __threadfence(); __syncthreads(); } // every wave is done with the previous profile; its boundary rows are in L2
     {
         const uint8_t *sp = T ? (a.b_prof + a.b_off[strip_chain]) : (a.a_prof + a.a_off[strip_chain]);
         const size_t snpad = T ? a.b_npad : a.a_npad;
         const uint32_t gs = g * R, tot = SWQ_NFC * gs;
         for (uint32_t idx = threadIdx.x; idx < tot; idx += blockDim.x) {
-            // float4 ((fc * (R/4) + quad) * G + strip) holds residues strip * R + quad * 4 + 0..3 of row fc: the
-            // ds_read_b128 of the g lanes of a pair are 16 B apart, and the R/4 quads of a lane sit at
+            // float4 ((fc * (R/4) + quad) * G + strip) holds residues (sbase + strip) * R + quad * 4 + 0..3 of row
+            // fc: the ds_read_b128 of the g lanes of a pair are 16 B apart, and the R/4 quads of a lane sit at
             // immediate offsets (quad * G * 16 B) from one address
             const uint32_t fc = idx / gs, rem = idx - fc * gs;
             const uint32_t quad = rem / (g * 4), rem2 = rem - quad * (g * 4);
             const uint32_t strip = rem2 >> 2, w = rem2 & 3;
-            const uint32_t i = strip * R + quad * 4 + w;
+            const uint32_t i = (sbase + strip) * R + quad * 4 + w;
             const uint32_t f = fc < 20 ? 0 : ((fc - 20) >> 4) + 1;
             const uint32_t c = fc < 20 ? fc : ((fc - 20) & 15);
             const uint32_t as = f == 0 ? 20 : 16, tof = f == 0 ? 0 : 400 + (f - 1) * 256;
@@ -351,13 +359,15 @@ __global__ __launch_bounds__(64 * SWQ_NW) void k_sw_qp(swf_args a, const swq_ite
         if (threadIdx.x == 0) *next_batch = 0;
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63;
     const uint32_t npw = 64 / g;                   // pairs per wave pass
     const uint32_t nbatch = (it.count + npw - 1) / npw;
     const uint32_t pr = lane / g, st = lane - pr * g;
-    const float Open = a.open, Ext = a.ext;
-    const uint32_t i0 = st * R;
-    const swq_ldsp qpl = (swq_ldsp) qp4 + st;  // this lane's float4 slot within a quad block
+    const uint32_t i0 = (sbase + st) * R;
+    const swq_ldsp qpl = (swq_ldsp) qp4 + st;      // this lane's float4 slot within a quad block
+    // rows of different segments meet through `bnd` (HBM, agent-scope accesses): the last strip of segment s
+    // leaves {M, D/I} of its bottom row per step, strip 0 of segment s + 1 takes them as the row above
+    const bool reads_bnd = seg > 0 && st == 0;
+    const bool writes_bnd = seg + 1 < nseg && st == g - 1;
     for (;;) {
         uint32_t b = 0;
         if (lane == 0) b = atomicAdd(next_batch, 1u);
@@ -369,27 +379,37 @@ __global__ __launch_bounds__(64 * SWQ_NW) void k_sw_qp(swf_args a, const swq_ite
         const uint32_t step_chain = T ? a.ia[p] : a.ib[p];
         const uint32_t LB = T ? a.a_len[step_chain] : a.b_len[step_chain];
         const uint16_t *bcb = T ? (a.a_cb + (size_t) a.a_off[step_chain] * 8) : (a.b_cb + (size_t) a.b_off[step_chain] * 8);
-        uint32_t *tbp = (uint32_t *) (a.tb + a.tb_off[p]) + st * SWQ_W;
+        uint32_t *tbp = (uint32_t *) (a.tb + a.tb_off[p]) + (sbase + st) * SWQ_W;
+        long long *bnd = nseg > 1 ? (long long *) (a.bnd + a.bnd_off[p]) : nullptr;
 
         float Md[R], In[R], rb[R];
         uint32_t rj[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) { Md[r] = SWF_MINUS_INF; In[r] = SWF_MINUS_INF; rb[r] = 0.0f; rj[r] = 0; }
-        if (st == 0) Md[0] = 0.0f;
+        if (st == 0 && seg == 0) Md[0] = 0.0f;
         float hand_m = SWF_MINUS_INF, hand_d = SWF_MINUS_INF, carry_in = SWF_MINUS_INF;
         uint32_t ncol = active ? (LB + st) : 0;
 #pragma unroll
         for (int s = 32; s >= 1; s >>= 1) ncol = max(ncol, (uint32_t) __shfl_xor((int) ncol, s, 64));
         uint4 cbn = make_uint4(0, 0, 0, 0);
         if (active) cbn = *(const uint4 *) bcb;
+        long long bnn = 0;                         // boundary words of the next step (strip 0 of a later segment)
+        if (seg && reads_bnd && active) bnn = __hip_atomic_load(bnd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
         for (uint32_t col = 0; col < ncol; ++col) {
             const int j = (int) col - (int) st;
-            const float in_m = dpp_shr1_f(hand_m);
-            const float in_d = dpp_shr1_f(hand_d);
+            float in_m = dpp_shr1_f(hand_m);
+            float in_d = dpp_shr1_f(hand_d);
             if (active && j >= 0 && (uint32_t) j < LB) {
                 const uint4 cb = cbn;
                 cbn = *(const uint4 *) (bcb + (size_t) (j + 1) * 8);
+                if (seg) {                         // wave-uniform
+                    if (reads_bnd) {
+                        in_m = __builtin_bit_cast(float, (int) (uint32_t) (unsigned long long) bnn);
+                        in_d = __builtin_bit_cast(float, (int) ((unsigned long long) bnn >> 32));
+                        if ((uint32_t) j + 1 < LB) bnn = __hip_atomic_load(bnd + j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
                 const uint32_t cbw[4] = { cb.x, cb.y, cb.z, cb.w };
                 swq_ldsp rec[8];
 #pragma unroll
@@ -398,8 +418,8 @@ __global__ __launch_bounds__(64 * SWQ_NW) void k_sw_qp(swf_args a, const swq_ite
                     const uint32_t fcb = f == 0 ? 0 : 20 + (f - 1) * 16;
                     rec[f] = qpl + (fcb + (c4 >> 2)) * ((R / 4) * G);
                 }
-                float ch = st == 0 ? SWF_MINUS_INF : in_d;
-                if (st != 0) Md[0] = carry_in;
+                float ch = (st == 0 && seg == 0) ? SWF_MINUS_INF : in_d;
+                if (st != 0 || seg != 0) Md[0] = carry_in;
                 else if (j > 0) Md[0] = SWF_MINUS_INF;
                 float carry = SWF_MINUS_INF;
                 uint32_t w = 0;
@@ -437,11 +457,18 @@ __global__ __launch_bounds__(64 * SWQ_NW) void k_sw_qp(swf_args a, const swq_ite
                         const float ni = swq_max(md, ne);
                         if (T) { ch = ni; In[r] = dd; }
                         else { ch = dd; In[r] = ni; }
-                        if (r % 6 == 5 || r == R - 1) tbp[(size_t) j * g * SWQ_W + r / 6] = w;
+                        if (r % 6 == 5 || r == R - 1) tbp[(size_t) j * gtot * SWQ_W + r / 6] = w;
                     }
                 }
                 hand_m = carry;
                 hand_d = ch;
+                if (nseg > 1) {                    // wave-uniform
+                    if (writes_bnd) {
+                        const unsigned long long bw = (unsigned long long) (uint32_t) __builtin_bit_cast(int, carry) |
+                                                      ((unsigned long long) (uint32_t) __builtin_bit_cast(int, ch) << 32);
+                        __hip_atomic_store(bnd + j, (long long) bw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
             }
             carry_in = in_m;
         }
@@ -462,10 +489,17 @@ __global__ __launch_bounds__(64 * SWQ_NW) void k_sw_qp(swf_args a, const swq_ite
             }
         }
         if (active && st == 0) {
+            if (seg) {                             // merge with the best of the earlier segments (same rule)
+                const float ob = __builtin_bit_cast(float, __hip_atomic_load((int *) a.score + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                const uint32_t oi = (uint32_t) __hip_atomic_load((int *) a.besti + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t oj = (uint32_t) __hip_atomic_load((int *) a.bestj + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (ob > best || (ob == best && ob > 0.0f && (oi < bi || (oi == bi && oj < bj)))) { best = ob; bi = oi; bj = oj; }
+            }
             a.score[p] = best;
             a.besti[p] = bi;
             a.bestj[p] = bj;
         }
+    }
     }
 }
 
@@ -734,20 +768,20 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
     std::vector<uint32_t> cntA(dba->n, 0), cntB;
     for (size_t p = 0; p < npairs; ++p) ++cntA[ia[p]];
     bool anyB = false;
-    for (size_t p = 0; p < npairs && !anyB; ++p) anyB = dba->len[ia[p]] > SWQ_MAX_L || cntA[ia[p]] < min_group;
+    for (size_t p = 0; p < npairs && !anyB; ++p) anyB = cntA[ia[p]] < min_group;
     if (anyB) {
         cntB.assign(dbb->n, 0);
         for (size_t p = 0; p < npairs; ++p)
-            if (dba->len[ia[p]] > SWQ_MAX_L || cntA[ia[p]] < min_group) ++cntB[ib[p]];
+            if (cntA[ia[p]] < min_group) ++cntB[ib[p]];
     }
     struct keyed { uint64_t key; uint32_t idx; };
     std::vector<keyed> ord(npairs);
     for (size_t p = 0; p < npairs; ++p) {
         const uint32_t LA = dba->len[ia[p]], LB = dbb->len[ib[p]];
         uint64_t key;
-        if (LA > 0 && LA <= SWQ_MAX_L && cntA[ia[p]] >= min_group)
+        if (LA > 0 && cntA[ia[p]] >= min_group)
             key = ((uint64_t) 0 << 62) | ((uint64_t) ia[p] << 24) | (0xFFFFFFu - std::min(LB, 0xFFFFFFu));
-        else if (LB > 0 && LB <= SWQ_MAX_L && cntB[ib[p]] >= min_group)
+        else if (LB > 0 && cntB[ib[p]] >= min_group)
             key = ((uint64_t) 1 << 62) | ((uint64_t) ib[p] << 24) | (0xFFFFFFu - std::min(LA, 0xFFFFFFu));
         else if (!(LA > 64 * SWF_R && LB <= 64 * SWF_R))
             key = ((uint64_t) 2 << 62) | ((uint64_t) (0xFFFFFFu - std::min(LA, 0xFFFFFFu)) << 32);
@@ -782,7 +816,7 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
             const uint32_t chain = (uint32_t) ((ord[k].key >> 24) & 0xFFFFFFFFu);
             size_t e = k;
             while (e < end && (uint32_t) ((ord[e].key >> 24) & 0xFFFFFFFFu) == chain) ++e;
-            const uint32_t g = (sdb->len[chain] + SWQ_R - 1) / SWQ_R;
+            const uint32_t g = std::min<uint32_t>((sdb->len[chain] + SWQ_R - 1) / SWQ_R, SWQ_MAX_G);
             const uint32_t npw = 64 / g;
             const size_t chunk = (size_t) npw * SWQ_NW * 2;
             for (size_t s = k; s < e; s += chunk) qitems[c].push_back(swq_item{ (uint32_t) s, (uint32_t) std::min(chunk, e - s) });
@@ -825,8 +859,13 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
         const uint32_t LA = dba->len[ia[p]], LB = dbb->len[ib[p]];
         bnd_off[k] = bno;
         tb_off[k] = tbo;
-        if (c == 0) tbo += (uint64_t) LB * ((LA + SWQ_R - 1) / SWQ_R) * (SWQ_W * 4);
-        else if (c == 1) tbo += (uint64_t) LA * ((LB + SWQ_R - 1) / SWQ_R) * (SWQ_W * 4);
+        if (c == 0) {
+            tbo += (uint64_t) LB * ((LA + SWQ_R - 1) / SWQ_R) * (SWQ_W * 4);
+            if (LA > SWQ_MAX_L) bno += 2 * (uint64_t) LB;       // multi-segment strip chain: 2 words per step
+        } else if (c == 1) {
+            tbo += (uint64_t) LA * ((LB + SWQ_R - 1) / SWQ_R) * (SWQ_W * 4);
+            if (LB > SWQ_MAX_L) bno += 2 * (uint64_t) LA;
+        }
         else if (c == 2) {
             if (LA > 64 * SWF_R) bno += 2 * (uint64_t) LB;      // multi-group pair: 2 words per step
             tbo += (uint64_t) ((LA + 15) & ~15u) * LB;
@@ -907,14 +946,6 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
     }
     for (int c = 0; c < 2; ++c) {
         if (qitems[c].empty()) continue;
-        // LDS of a launch = the longest strip chain among its groups
-        uint32_t gmax = 1;
-        const rsk_db *sdb = c == 0 ? dba : dbb;
-        for (const swq_item &q : qitems[c]) {
-            const uint32_t chain = c == 0 ? sia[q.first] : sib[q.first];
-            gmax = std::max(gmax, (sdb->len[chain] + SWQ_R - 1) / SWQ_R);
-        }
-        (void) gmax;
         const size_t lds = (size_t) SWQ_NFC * (SWQ_R / 4) * SWQ_MAX_G * 16 + 16;   // fixed row geometry
         const swq_item *d_q = (const swq_item *) (D + (c == 0 ? o_q0 : o_q1));
         if (c == 0) hipLaunchKernelGGL(k_sw_qp<false>, dim3((unsigned) qitems[c].size()), dim3(64 * SWQ_NW), lds, ctx->stream, a, d_q);

@@ -129,3 +129,43 @@ def test_tiny_and_ragged_chains(ctx):
         if opath:
             assert bits(al.evalue) == bits(st.evalue) and bits(al.lddt) == bits(st.lddt)
     db.close()
+
+
+def test_long_strip_chains_in_groups(ctx):
+    """Chains longer than one LDS query profile (300 residues) that have many partners: k_sw_qp runs them in
+    segments whose rows meet through HBM.  Both orientations (long chain first / second), lengths around the
+    segment boundaries, a repeat for ties."""
+    import copy
+    import reseek_amd
+    chains = fx.read_rskdb("q100_sensitive.rskdb.gz")
+    rng = np.random.default_rng(7)
+    longs = []
+    for L in (300, 301, 312, 599, 601, 913):
+        c = copy.copy(chains[0])
+        c.mu = rng.integers(0, 36, L).astype(np.uint8)
+        c.prof = np.concatenate([rng.integers(0, 20, (1, L)), rng.integers(0, 16, (7, L))]).astype(np.uint8)
+        src = chains[len(longs) + 1].prof
+        reps = (L + src.shape[1] - 1) // src.shape[1]
+        c.prof[:, :] = np.tile(src, (1, reps))[:, :L]      # real profile, repeated: long alignments across segments
+        c.x = np.cumsum(rng.normal(0, 2.2, L)).astype(np.float32)
+        c.y = np.cumsum(rng.normal(0, 2.2, L)).astype(np.float32)
+        c.z = np.cumsum(rng.normal(0, 2.2, L)).astype(np.float32)
+        c.seq = (c.seq * (L // max(1, len(c.seq)) + 1))[:L]
+        longs.append(c)
+    others = chains[1:13]
+    allc = longs + others
+    db = reseek_amd.Db.from_chains(ctx, allc)
+    nl, n = len(longs), len(allc)
+    pairs = [(a, b) for a in range(nl) for b in range(n)] + [(b, a) for a in range(nl) for b in range(nl, n)]
+    res = ctx.align_pairs(db, db, [p[0] for p in pairs], [p[1] for p in pairs], min_fwd_score=0.0)
+    nlong = 0
+    for (a, b), (al, path) in zip(pairs, res):
+        s, lo_i, lo_j, opath = ol.align_pair(allc[a].prof, allc[b].prof)
+        assert bits(al.score) == bits(s) and path == opath, (a, b)
+        if opath:
+            assert (al.lo_a, al.lo_b) == (lo_i, lo_j), (a, b)
+            ok, st = ol.calc_evalue(s, 0.0, opath, lo_i, lo_j, allc[a], allc[b])
+            assert bits(al.lddt) == bits(st.lddt) and bits(al.evalue) == bits(st.evalue), (a, b)
+            nlong += len(opath) > 300
+    assert nlong >= 4
+    db.close()

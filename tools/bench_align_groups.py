@@ -22,6 +22,10 @@ def main():
     rng = np.random.default_rng(3)
     order = rng.permutation(len(seqs))
     seqs = [seqs[i] for i in order]
+    maxq = int(sys.argv[3]) if len(sys.argv) > 3 else 0      # >0: only queries up to this length (the k_sw_qp LDS limit is 300)
+    if maxq:
+        head = [s for s in seqs if len(s) <= maxq][:nq]
+        seqs = head + [s for s in seqs if not any(s is h for h in head)]
     lens = np.array([len(s) for s in seqs], np.uint32)
     tot = int(lens.sum())
     prof = np.concatenate([np.concatenate([rng.integers(0, 20, (1, int(L))), rng.integers(0, 16, (7, int(L)))]).astype(np.uint8).reshape(-1)
