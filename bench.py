@@ -70,12 +70,31 @@ def synth_mu_chains(seed, nchains=None):
     return [seqs[i] for i in order]
 
 
+def usable_cpus():
+    """CPUs this process may actually use: min(affinity mask, cgroup CPU quota).  (The GPU boxes expose 256 hardware
+    threads but cap the container at a 16-CPU quota; threads beyond the quota only get throttled.)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(per))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                n = min(n, max(1, -(-q // per)))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(seqs, seconds_target=15.0):
     """Reference CPU kernels timed on this box's host cores on a bounded sample of the same pairs.
     kind "reference": oracle/_ref/ref_harness (the unmodified reference objects, built from
     /root/reference by oracle/Makefile.ref) runs SWFastPinopGapless on a strided sample of the
     triangle; falls back to the C restatement ("port", 1 core) if that binary did not travel."""
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()
     harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
     if os.path.exists(harness):
         with tempfile.TemporaryDirectory() as td:
@@ -92,8 +111,8 @@ def cpu_baseline(seqs, seconds_target=15.0):
                 r = json.loads(out)
                 return {"value": r["cells"] / r["gapless_secs"], "unit": "cells/s", "cores": cores, "kind": "reference",
                         "sample": "%d pairs strided over the all-vs-all triangle (%.3g cells), SWFastPinopGapless "
-                                  "(swfastpinopgapless.cpp:6) via oracle/_ref/ref_harness, %d std::threads; same binary's "
-                                  "AVX2 parasail fwd filter: %.3g cells/s" % (r["pairs"], r["cells"], cores,
+                                  "(swfastpinopgapless.cpp:6) via oracle/_ref/ref_harness, %d std::threads = the container's CPU quota (%d hardware threads visible); same binary's "
+                                  "AVX2 parasail fwd filter: %.3g cells/s" % (r["pairs"], r["cells"], cores, os.cpu_count() or 1,
                                                                               r["cells"] / r["parasail_fwd_secs"])}
             except Exception as e:  # noqa: BLE001
                 sys.stderr.write("cpu_baseline: reference harness failed (%s); using the C port\n" % e)

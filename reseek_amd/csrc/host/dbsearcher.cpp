@@ -60,9 +60,47 @@ static bool EndsWith(const std::string &s, const std::string &suf)
     return s.size() >= suf.size() && s.compare(s.size() - suf.size(), suf.size(), suf) == 0;
 }
 
+unsigned HostThreads(unsigned cap)
+{
+    if (const char *e = getenv("RSK_HOST_THREADS")) { const int v = atoi(e); if (v > 0) return (unsigned) v; }
+    static const unsigned avail = [] {
+        unsigned n = std::max(1u, std::thread::hardware_concurrency());
+        long long quota = -1, period = 0;
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                         // cgroup v2: "<quota|max> <period>"
+            char q[64];
+            if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+            fclose(f);
+        } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {      // cgroup v1
+            if (fscanf(g, "%lld", &quota) != 1) quota = -1;
+            fclose(g);
+            if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%lld", &period) != 1) period = 0; fclose(h); }
+        }
+        if (quota > 0 && period > 0) n = std::min<unsigned>(n, (unsigned) std::max<long long>(1, (quota + period - 1) / period));
+        return n;
+    }();
+    return std::max(1u, std::min(avail, cap));
+}
+
+namespace {
+struct PhaseTimer {                              // RSK_TRACE=1: wall time of the driver's phases on stderr
+    const char *who;
+    bool on = getenv("RSK_TRACE") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit PhaseTimer(const char *w = "RunPairs") : who(w) {}
+    void lap(const char *what)
+    {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[%s] %-22s %9.3f ms\n", who, what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+}   // namespace
+
 // ProfileLoader::Load profileloader.cpp:72 for a .bca file: read, featurise (host threads), self-rev (GPU batch)
 void DBSearcher::LoadBCA(const std::string &FN)
 {
+    PhaseTimer tm("LoadBCA");
     BCAData B;
     B.Open(FN);
     const uint64_t n = B.GetChainCount();
@@ -73,8 +111,9 @@ void DBSearcher::LoadBCA(const std::string &FN)
         AddChain(C, new std::vector<std::vector<byte> >, new std::vector<byte>);
         m_DBMuKmersVec.push_back(new std::vector<uint>);
     }
+    tm.lap("read chains");
     const uint N = GetDBChainCount();
-    const unsigned T = std::max(1u, std::min<unsigned>(std::thread::hardware_concurrency(), 64u));
+    const unsigned T = HostThreads(128);
     std::atomic<uint> next{0};
     auto body = [&]() {
         DSS D;
@@ -82,16 +121,26 @@ void DBSearcher::LoadBCA(const std::string &FN)
         for (;;) {
             const uint i = next.fetch_add(1);
             if (i >= N) return;
+            // featurise into this thread's own vectors, then hand them over: the destination vector headers of
+            // neighbouring chains share cache lines, per-residue push_back on them would ping-pong between cores
+            std::vector<std::vector<byte> > Prof;
+            std::vector<byte> Mu;
+            std::vector<uint> Kmers;
             D.Init(*m_DBChains[i]);
-            D.GetProfile(*m_DBProfiles[i]);
-            D.GetMuLetters(*m_DBMuLettersVec[i]);
-            DSS::GetMuKmers(*m_DBMuLettersVec[i], *m_DBMuKmersVec[i], m_Params->m_MKFPatternStr);
+            D.GetProfile(Prof);
+            D.GetMuLetters(Mu);
+            DSS::GetMuKmers(Mu, Kmers, m_Params->m_MKFPatternStr);
+            m_DBProfiles[i]->swap(Prof);
+            m_DBMuLettersVec[i]->swap(Mu);
+            m_DBMuKmersVec[i]->swap(Kmers);
         }
     };
     std::vector<std::thread> ts;
     for (unsigned t = 0; t < T; ++t) ts.emplace_back(body);
     for (auto &t : ts) t.join();
+    tm.lap("featurise (host)");
     ComputeSelfRevScores();
+    tm.lap("self-rev scores");
 }
 
 // GetSelfRevScore alignpair.cpp:7-24 for every chain: AlignQueryTarget of the chain against its reversed copy
@@ -110,11 +159,12 @@ void DBSearcher::ComputeSelfRevScores()
         DAP.m_Omega = 0;
         HaveMu = m_Params->m_Omega > 0;                                 // LoadDB dbsearcher.cpp:249-251
     }
+    PhaseTimer tm("SelfRev");
     // reversed chains and their profiles
     std::vector<PDBChain> Rev(N);
     std::vector<std::vector<std::vector<byte> > > RevProf(N);
     {
-        const unsigned T = std::max(1u, std::min<unsigned>(std::thread::hardware_concurrency(), 64u));
+        const unsigned T = HostThreads(128);
         std::atomic<uint> next{0};
         auto body = [&]() {
             DSS D;
@@ -122,15 +172,20 @@ void DBSearcher::ComputeSelfRevScores()
             for (;;) {
                 const uint i = next.fetch_add(1);
                 if (i >= N) return;
-                m_DBChains[i]->GetReverse(Rev[i]);
-                D.Init(Rev[i]);
-                D.GetProfile(RevProf[i]);
+                PDBChain R;
+                std::vector<std::vector<byte> > Prof;
+                m_DBChains[i]->GetReverse(R);
+                D.Init(R);
+                D.GetProfile(Prof);
+                std::swap(Rev[i], R);
+                RevProf[i].swap(Prof);
             }
         };
         std::vector<std::thread> ts;
         for (unsigned t = 0; t < T; ++t) ts.emplace_back(body);
         for (auto &t : ts) t.join();
     }
+    tm.lap("reverse + featurise");
     std::vector<uint32_t> gpu, mkf;
     for (uint i = 0; i < N; ++i) {
         const uint L = m_DBChains[i]->GetSeqLength();
@@ -152,11 +207,13 @@ void DBSearcher::ComputeSelfRevScores()
             }
             o += L;
         }
+        tm.lap("pack");
         rsk_db *fdb = nullptr, *rdb = nullptr;
         check(rsk_db_create(m_Ctx, N, len.data(), mu.data(), pf.data(), nullptr, nullptr, nullptr, nullptr, &fdb), "rsk_db_create");
         struct guard { rsk_db *d; ~guard() { if (d) rsk_db_destroy(d); } } g1{ fdb }, g2{ nullptr };
         check(rsk_db_create(m_Ctx, N, len.data(), mu.data(), pr.data(), nullptr, nullptr, nullptr, nullptr, &rdb), "rsk_db_create");
         g2.d = rdb;
+        tm.lap("upload");
         std::vector<uint32_t> idx = gpu;
         if (DAP.m_Omega > 0) {                                           // MuFilter dssaligner.cpp:817-826 (self vs self letters)
             std::vector<uint8_t> pass(idx.size());
@@ -176,17 +233,29 @@ void DBSearcher::ComputeSelfRevScores()
                   "rsk_align_pairs");
             for (size_t k = 0; k < m; ++k) m_DBSelfRevScores[idx[b + k]] = out[k].score;
         }
+        tm.lap("GPU filter + SW");
     }
     if (!mkf.empty()) {
-        DSSAligner DA;
-        DA.SetParams(DAP);
-        for (uint32_t i : mkf) {
-            DA.SetQuery(*m_DBChains[i], m_DBProfiles[i], m_DBMuLettersVec[i], m_DBMuKmersVec[i], FLT_MAX);
-            DA.SetTarget(Rev[i], &RevProf[i], m_DBMuLettersVec[i], m_DBMuKmersVec[i], FLT_MAX);
-            DA.AlignMKF();
-            m_DBSelfRevScores[i] = DA.m_AlnFwdScore;
-        }
-        DA.UnsetQuery();
+        const unsigned T = (unsigned) std::max<size_t>(1, std::min<size_t>((size_t) HostThreads(128), mkf.size()));
+        std::atomic<size_t> next{0};
+        auto body = [&]() {
+            DSSAligner DA;
+            DA.SetParams(DAP);
+            for (;;) {
+                const size_t k = next.fetch_add(1);
+                if (k >= mkf.size()) break;
+                const uint32_t i = mkf[k];
+                DA.SetQuery(*m_DBChains[i], m_DBProfiles[i], m_DBMuLettersVec[i], m_DBMuKmersVec[i], FLT_MAX);
+                DA.SetTarget(Rev[i], &RevProf[i], m_DBMuLettersVec[i], m_DBMuKmersVec[i], FLT_MAX);
+                DA.AlignMKF();
+                m_DBSelfRevScores[i] = DA.m_AlnFwdScore;
+            }
+            DA.UnsetQuery();
+        };
+        std::vector<std::thread> ts;
+        for (unsigned t = 0; t < T; ++t) ts.emplace_back(body);
+        for (auto &t : ts) t.join();
+        tm.lap("MKF chains (host)");
     }
 }
 
@@ -374,7 +443,7 @@ void RunMKFPairs(rsk_ctx *Ctx, const DSSParams &P, const std::string &Columns, D
     std::sort(recs.begin(), recs.end(), [](const Rec &x, const Rec &y) { return x.pair < y.pair; });
     if (getenv("RSK_TRACE")) fprintf(stderr, "[RunMKFPairs] %zu pairs, %zu with a seed HSP\n", n, recs.size());
     const auto t_host0 = std::chrono::steady_clock::now();
-    const unsigned T = (unsigned) std::max<size_t>(1, std::min<size_t>({ (size_t) std::thread::hardware_concurrency(), (size_t) 128, recs.size() / 8 + 1 }));
+    const unsigned T = (unsigned) std::max<size_t>(1, std::min<size_t>((size_t) HostThreads(128), recs.size() / 8 + 1));
     std::atomic<size_t> next{0};
     std::mutex lock;
     auto body = [&]() {
@@ -405,20 +474,6 @@ void RunMKFPairs(rsk_ctx *Ctx, const DSSParams &P, const std::string &Columns, D
         fprintf(stderr, "[RunMKFPairs] host stage %.3f ms on %u threads\n",
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count(), T);
 }
-
-namespace {
-struct PhaseTimer {                              // RSK_TRACE=1: wall time of the driver's phases on stderr
-    bool on = getenv("RSK_TRACE") != nullptr;
-    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-    void lap(const char *what)
-    {
-        if (!on) return;
-        const auto t1 = std::chrono::steady_clock::now();
-        fprintf(stderr, "[RunPairs] %-22s %9.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
-        t0 = t1;
-    }
-};
-}   // namespace
 
 // Self with SelfOffset >= 0 is one SHARD of a self search: B = the chains [SelfOffset, SelfOffset + NB) of
 // the set, A = its chains [0, SelfOffset + NB); the pairs i <= SelfOffset + j are this shard's part of the triangle.
@@ -585,10 +640,13 @@ void DBSearcher::RunSelfShard(uint Index, uint Count)
 
 void DBSearcher::RunQuery(DBSearcher &DBChainsSource)
 {
+    PhaseTimer tm("RunQuery");
     UploadToGpu();
     DBChainsSource.m_Ctx = m_Ctx;
     DBChainsSource.UploadToGpu();
+    tm.lap("upload both sets");
     RunPairs(*this, DBChainsSource, false);
+    tm.lap("RunPairs");
 }
 
 // One pair through the same GPU kernels (the reference's per-pair entry point, dssaligner.cpp:793).

@@ -74,6 +74,7 @@ void DSS::Init(const PDBChain &Chain)
     m_NENs.clear();
     m_RENs.clear();
     m_Density_ScaledValues.clear();
+    m_DistFactors.clear();
     m_SSE_Mids.clear();
     m_SSE_cs.clear();
     m_SSEsDone = false;
@@ -144,8 +145,24 @@ void DSS::SetNENs()
     }
 }
 
-double DSS::GetDensity(uint Pos) const                                // dss.cpp:217-244
+// exp(-dist(i, i + k) / radius) for k = 1..W, computed once per chain: the two density features (dss.cpp:217-244,
+// 339-372) use the same radius and window and dist is symmetric, so each unordered residue pair needs one exp()
+// instead of four.  The features still add the factors in the reference's order (ascending Pos2).
+void DSS::SetDistFactors()
 {
+    if (!m_DistFactors.empty()) return;
+    const uint L = GetSeqLength();
+    const int W = std::max(m_Density_W, m_SSDensity_W), w = std::min(m_Density_w, m_SSDensity_w);
+    m_DistFactorW = W;
+    m_DistFactors.assign((size_t) L * W + 1, 0.0);
+    for (uint Pos = 0; Pos < L; ++Pos)
+        for (int k = w + 1; k <= W && Pos + k < L; ++k)
+            m_DistFactors[(size_t) Pos * W + (k - 1)] = exp(-(double) m_Chain->GetDist(Pos, Pos + k) / m_Density_Radius);
+}
+
+double DSS::GetDensity(uint Pos)                                      // dss.cpp:217-244
+{
+    SetDistFactors();
     const uint L = GetSeqLength();
     if (Pos == 0 || Pos + 1 >= L) return DBL_MAX;
     int iLo = (int) Pos - m_Density_W;
@@ -155,8 +172,7 @@ double DSS::GetDensity(uint Pos) const                                // dss.cpp
     double D = 0;
     for (uint Pos2 = (uint) iLo; Pos2 <= (uint) iHi; ++Pos2) {
         if (Pos2 + m_Density_w >= Pos && Pos2 <= Pos + m_Density_w) continue;
-        const double Dist = m_Chain->GetDist(Pos, Pos2);
-        D += exp(-Dist / m_Density_Radius);
+        D += DistFactor(Pos, Pos2);
     }
     return D;
 }
@@ -183,6 +199,7 @@ void DSS::SetDensity_ScaledValues()                                   // dss.cpp
 double DSS::GetSSDensity(uint Pos, char c)                            // dss.cpp:339-372
 {
     SetSS();
+    SetDistFactors();
     const uint L = GetSeqLength();
     if (Pos == 0 || Pos + 1 >= L) return DBL_MAX;
     int iLo = (int) Pos - m_SSDensity_W;
@@ -192,10 +209,9 @@ double DSS::GetSSDensity(uint Pos, char c)                            // dss.cpp
     double D = 0, Dc = 0;
     for (uint Pos2 = (uint) iLo; Pos2 <= (uint) iHi; ++Pos2) {
         if (Pos2 + m_SSDensity_w >= Pos && Pos2 <= Pos + m_SSDensity_w) continue;
-        const double Dist = m_Chain->GetDist(Pos, Pos2);
-        const double DistFactor = exp(-Dist / m_Density_Radius);
-        D += DistFactor;
-        if (m_SS[Pos2] == c) Dc += DistFactor;
+        const double Factor = DistFactor(Pos, Pos2);
+        D += Factor;
+        if (m_SS[Pos2] == c) Dc += Factor;
     }
     return Dc / (D + m_SSDensity_epsilon);
 }

@@ -112,7 +112,7 @@ extern "C" int rsk_rsb_select(const uint32_t *q, const uint32_t *t, const uint32
     RSB.m_B = rsb_size;
     RSB.Init(nqueries);
     {
-        const unsigned T = (unsigned) std::max<size_t>(1, std::min<size_t>({ (size_t) std::thread::hardware_concurrency(), (size_t) 64, n / 65536 + 1 }));
+        const unsigned T = (unsigned) std::max<size_t>(1, std::min<size_t>((size_t) HostThreads(64), n / 65536 + 1));
         std::atomic<uint32_t> next{0};
         auto body = [&]() {
             for (;;) {

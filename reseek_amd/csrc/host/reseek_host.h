@@ -24,6 +24,11 @@
 
 namespace reseek_amd {
 
+// Worker threads for per-chain / per-pair host work: min(hardware threads, this process's cgroup CPU quota, cap);
+// RSK_HOST_THREADS overrides.  (Threads beyond the quota only get the whole process throttled.)
+unsigned HostThreads(unsigned cap);
+
+
 typedef unsigned char byte;
 typedef unsigned int uint;
 
@@ -92,6 +97,8 @@ class DSS {                                             // dss.h:15 (Discrete St
 public:
     const PDBChain *m_Chain = nullptr;
     std::vector<double> m_Density_ScaledValues;
+    std::vector<double> m_DistFactors;                 // [L][W]: exp(-dist(i, i + k + 1) / radius)
+    int m_DistFactorW = 0;
     std::vector<uint> m_NENs, m_RENs;
     std::string m_SS;
     int m_Density_W = 50, m_Density_w = 3, m_SSDensity_W = 50, m_SSDensity_w = 8;     // dss.h:24-37
@@ -115,7 +122,12 @@ public:
     void SetNENs();
     void SetSSEs();
     void SetDensity_ScaledValues();
-    double GetDensity(uint Pos) const;
+    double GetDensity(uint Pos);
+    void SetDistFactors();
+    double DistFactor(uint Pos, uint Pos2) const      // Pos != Pos2, |Pos - Pos2| <= window
+    {
+        return Pos2 > Pos ? m_DistFactors[(size_t) Pos * m_DistFactorW + (Pos2 - Pos - 1)] : m_DistFactors[(size_t) Pos2 * m_DistFactorW + (Pos - Pos2 - 1)];
+    }
     double GetSSDensity(uint Pos, char c);
     double GetFloat_DstNxtHlx(uint Pos);
     uint CalcNEN(uint Pos) const;

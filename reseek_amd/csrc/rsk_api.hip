@@ -144,6 +144,25 @@ extern "C" float rsk_ctx_last_kernel_ms(rsk_ctx *ctx)
     return ms;
 }
 
+// cb[r][f] = letter * 4, ra[r][f] = letter * alphabet(f) * 4 from the feature-major profile bytes (padding letters are 0)
+__global__ void k_db_derive(const uint8_t *prof, size_t npad, uint16_t *cb, uint16_t *ra)
+{
+    const size_t r = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= npad) return;
+    uint16_t c[8], a[8];
+#pragma unroll
+    for (int f = 0; f < 8; ++f) {
+        const uint32_t l = prof[(size_t) f * npad + r];
+        c[f] = (uint16_t) (l * 4);
+        a[f] = (uint16_t) (l * (f == 0 ? 20 : 16) * 4);
+    }
+    uint4 vc, va;
+    vc.x = c[0] | ((uint32_t) c[1] << 16); vc.y = c[2] | ((uint32_t) c[3] << 16); vc.z = c[4] | ((uint32_t) c[5] << 16); vc.w = c[6] | ((uint32_t) c[7] << 16);
+    va.x = a[0] | ((uint32_t) a[1] << 16); va.y = a[2] | ((uint32_t) a[3] << 16); va.z = a[4] | ((uint32_t) a[5] << 16); va.w = a[6] | ((uint32_t) a[7] << 16);
+    ((uint4 *) cb)[r] = vc;
+    ((uint4 *) ra)[r] = va;
+}
+
 template <class T>
 static int dev_upload(T **d, const T *h, size_t count, uint64_t &bytes)
 {
@@ -205,22 +224,28 @@ extern "C" int rsk_db_create(rsk_ctx *ctx, uint32_t n, const uint32_t *lengths, 
         std::vector<uint8_t> hp((size_t) RSK_NFEAT * o, 0);
         uint64_t src = 0;
         for (uint32_t i = 0; i < n; ++i) {
-            for (int f = 0; f < RSK_NFEAT; ++f)
-                memcpy(&hp[(size_t) f * o + db->off[i]], prof + src + (size_t) f * lengths[i], lengths[i]);
+            for (int f = 0; f < RSK_NFEAT; ++f) {
+                const uint8_t *row = prof + src + (size_t) f * lengths[i];
+                uint8_t mx = 0;
+                for (uint32_t k = 0; k < lengths[i]; ++k) mx = row[k] > mx ? row[k] : mx;
+                if (mx >= (f == 0 ? 20 : 16)) { rsk_set_error("rsk_db_create: profile letter %u out of range (chain %u feature %d)", mx, i, f); delete db; return RSK_E_INVALID; }
+                memcpy(&hp[(size_t) f * o + db->off[i]], row, lengths[i]);
+            }
             src += (uint64_t) RSK_NFEAT * lengths[i];
         }
         if ((rc = dev_upload(&db->d_prof, hp.data(), hp.size(), db->hbm_bytes)) != RSK_OK) return rc;
-        std::vector<uint16_t> cb(((size_t) o + 64) * 8, 0), ra(((size_t) o + 64) * 8, 0);
-        for (uint32_t i = 0; i < n; ++i)
-            for (uint32_t k = 0; k < lengths[i]; ++k)
-                for (int f = 0; f < RSK_NFEAT; ++f) {
-                    const uint8_t c = hp[(size_t) f * o + db->off[i] + k];
-                    if (c >= (f == 0 ? 20 : 16)) { rsk_set_error("rsk_db_create: profile letter %u out of range (chain %u feature %d)", c, i, f); delete db; return RSK_E_INVALID; }
-                    cb[((size_t) db->off[i] + k) * 8 + f] = (uint16_t) (c * 4);
-                    ra[((size_t) db->off[i] + k) * 8 + f] = (uint16_t) (c * (f == 0 ? 20 : 16) * 4);
-                }
-        if ((rc = dev_upload(&db->d_prof_cb, cb.data(), cb.size(), db->hbm_bytes)) != RSK_OK) return rc;
-        if ((rc = dev_upload(&db->d_prof_ra, ra.data(), ra.size(), db->hbm_bytes)) != RSK_OK) return rc;
+        // the float-SW kernels read letter * 4 (column offsets) and letter * alphabet * 4 (row offsets) per feature,
+        // residue-major: derived on the device from the bytes just uploaded
+        const size_t nrec = ((size_t) o + 64) * 8;
+        RSK_HIP(hipMalloc((void **) &db->d_prof_cb, nrec * 2));
+        RSK_HIP(hipMalloc((void **) &db->d_prof_ra, nrec * 2));
+        db->hbm_bytes += nrec * 4;
+        RSK_HIP(hipMemsetAsync(db->d_prof_cb + (size_t) o * 8, 0, 64 * 8 * 2, ctx->stream));
+        RSK_HIP(hipMemsetAsync(db->d_prof_ra + (size_t) o * 8, 0, 64 * 8 * 2, ctx->stream));
+        if (o) hipLaunchKernelGGL(k_db_derive, dim3((unsigned) ((o + 255) / 256)), dim3(256), 0, ctx->stream, db->d_prof, (size_t) o,
+                                  db->d_prof_cb, db->d_prof_ra);
+        RSK_HIP(hipGetLastError());
+        RSK_HIP(hipStreamSynchronize(ctx->stream));
     }
     if (x) {
         std::vector<float> hx((size_t) o, 0.f), hy((size_t) o, 0.f), hz((size_t) o, 0.f);

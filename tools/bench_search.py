@@ -12,6 +12,7 @@ import time
 
 import numpy as np
 import torch
+from scipy.signal import lfilter
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -48,9 +49,7 @@ def write_bca(path, lens, rng):
             L = int(L)
             aa = rng.integers(0, 20, L)
             f.write(bytes(b"ACDEFGHIKLMNPQRSTVWY"[int(a)] for a in aa))
-            d = rng.normal(0, 1, (L, 3))
-            for k in range(1, L):                      # persistent direction
-                d[k] = 0.8 * d[k - 1] + 0.6 * d[k]
+            d = lfilter([0.6], [1.0, -0.8], rng.normal(0, 1, (L, 3)) / 0.6, axis=0)      # persistent direction: d[k] = 0.8 d[k-1] + n[k]
             d /= np.linalg.norm(d, axis=1, keepdims=True)
             xyz = np.cumsum(3.8 * d, axis=0)
             xyz -= xyz.mean(axis=0)
@@ -64,7 +63,34 @@ def write_bca(path, lens, rng):
         f.write(struct.pack("<QQQ", n, pos, len(labels)))
 
 
+def main_qdb():
+    """bench_search.py qdb NQ ND MODE: NQ query chains against an ND-chain .bca database (one GPU's shard of
+    BASELINE configs 4 / 5: 256 x 1M -sensitive -> 256 x 125000; 1k x 700k -verysensitive -> 1000 x 87500)."""
+    nq, nd, mode = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    lens = bench.scop40_lengths()
+    rng = np.random.default_rng(11)
+    ctx = reseek_amd.Ctx(0, stream=torch.cuda.current_stream().cuda_stream)
+    with tempfile.TemporaryDirectory() as td:
+        q, db, out = os.path.join(td, "q.bca"), os.path.join(td, "db.bca"), os.path.join(td, "hits.tsv")
+        write_bca(q, lens[rng.choice(len(lens), nq)], rng)
+        t0 = time.perf_counter()
+        write_bca(db, lens[rng.choice(len(lens), nd)], rng)
+        tgen = time.perf_counter() - t0
+        res = {}
+        for rep in range(2):
+            t0 = time.perf_counter()
+            nhits, st = ctx.search_rskdb(q, out, mode, db=db)
+            dt = time.perf_counter() - t0
+            res["run%d" % rep] = {"seconds": dt, "pairs": int(st[0]), "pairs_per_s": st[0] / dt, "mufilter_in": int(st[2]),
+                                  "mufilter_discard": int(st[3]), "mkf_pairs": int(st[4]), "sw_pairs": int(st[5]), "hits": int(nhits),
+                                  "tsv_bytes": os.path.getsize(out)}
+        print(json.dumps({"input": ".bca query + .bca db (DSS featurisation + self-rev inside the timed call)", "queries": nq,
+                          "db_chains": nd, "mode": mode, "db_generation_s": tgen, **res}, indent=1))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "qdb":
+        return main_qdb()
     nch = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     mode = sys.argv[2] if len(sys.argv) > 2 else "sensitive"
     if len(sys.argv) > 3 and sys.argv[3] == "bca":
