@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <future>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -352,29 +353,49 @@ void DBSearcher::UploadToGpu()
 }
 
 // Align a batch of (ia, ib) pairs of one chain set on the GPU and replay the hits.
-static void AlignAndReplay(DBSearcher &S, rsk_ctx *ctx, DBSearcher &SrcA, DBSearcher &SrcB, const std::vector<uint32_t> &ia,
-                           const std::vector<uint32_t> &ib, bool Self, uint joff = 0)
+// One batch of (ia, ib) pairs: the GPU stage (AlignBatch: rsk_align_pairs) and the host stage (ReplayBatch: hit
+// records -> Reject -> TSV lines).  RunPairs runs the GPU stage of batch k + 1 while batch k is replayed.
+struct AlignedBatch {
+    std::vector<uint32_t> ia, ib;
+    std::vector<rsk_aln> out;
+    std::unique_ptr<char[]> paths;
+};
+
+static std::unique_ptr<AlignedBatch> AlignBatch(const DSSParams &P, rsk_ctx *ctx, DBSearcher &SrcA, DBSearcher &SrcB, std::vector<uint32_t> ia,
+                                                std::vector<uint32_t> ib)
+{
+    std::unique_ptr<AlignedBatch> B(new AlignedBatch);
+    B->ia = std::move(ia);
+    B->ib = std::move(ib);
+    const size_t n = B->ia.size();
+    if (n == 0) return B;
+    B->out.resize(n);
+    const size_t bytes = rsk_align_paths_bytes(SrcA.m_Db, SrcB.m_Db, B->ia.data(), B->ib.data(), n);
+    B->paths.reset(new char[bytes + 1]);                                     // not value-initialised: hundreds of MB per batch
+    check(rsk_align_pairs(ctx, SrcA.m_Db, SrcB.m_Db, B->ia.data(), B->ib.data(), n, P.m_GapOpen, P.m_GapExt, P.m_MinFwdScore, B->out.data(),
+                          B->paths.get(), bytes),
+          "rsk_align_pairs");
+    return B;
+}
+
+static void ReplayBatch(DBSearcher &S, DBSearcher &SrcA, DBSearcher &SrcB, const AlignedBatch &B, bool Self, uint joff = 0)
 {
     const DSSParams &P = *S.m_Params;
+    const std::vector<uint32_t> &ia = B.ia, &ib = B.ib;
+    const std::vector<rsk_aln> &out = B.out;
+    const char *paths = B.paths.get();
     const size_t n = ia.size();
     if (n == 0) return;
-    std::vector<rsk_aln> out(n);
-    const size_t bytes = rsk_align_paths_bytes(SrcA.m_Db, SrcB.m_Db, ia.data(), ib.data(), n);
-    std::unique_ptr<char[]> paths_buf(new char[bytes + 1]);                 // not value-initialised: hundreds of MB per batch
-    char *paths = paths_buf.get();
-    check(rsk_align_pairs(ctx, SrcA.m_Db, SrcB.m_Db, ia.data(), ib.data(), n, P.m_GapOpen, P.m_GapExt, P.m_MinFwdScore, out.data(),
-                          paths, bytes),
-          "rsk_align_pairs");
-    DSSAligner &DA = S.m_DA;
-    for (size_t p = 0; p < n; ++p) {
-        ++S.m_SWCount;
-        if (out[p].path_len == 0) continue;                                  // runself.cpp:61 / runquery.cpp:72
+    S.m_SWCount += n;
+    // one pair's hit record -> DSSAligner result fields -> Reject / hit line(s), as runself.cpp:61-66 / runquery.cpp:72-73
+    auto replay = [&](DSSAligner &DA, size_t p, auto &&OnHit) {
+        if (out[p].path_len == 0) return;                                    // runself.cpp:61 / runquery.cpp:72
         // Reject (dbsearcher.cpp:258) on the batch record itself: both orientations carry the same E-value / TS, and a
         // plain DBSearcher does nothing with a rejected hit -- skip the string work for the (many) rejected pairs
         if (!S.m_HasOnAlnOverride) {
             const float ev = out[p].evalue, ts = out[p].evalue != FLT_MAX ? out[p].ts : -FLT_MAX;
-            if (!S.m_Opts.scores_are_not_evalues && ev > S.m_MaxEvalue) continue;
-            if (S.m_Opts.mints_set && ts < S.m_Opts.mints) continue;
+            if (!S.m_Opts.scores_are_not_evalues && ev > S.m_MaxEvalue) return;
+            if (S.m_Opts.mints_set && ts < S.m_Opts.mints) return;
         }
         const uint i = ia[p], j = ib[p];
         DA.m_ChainA = SrcA.m_DBChains[i]; DA.m_ProfileA = SrcA.m_DBProfiles[i];
@@ -382,11 +403,50 @@ static void AlignAndReplay(DBSearcher &S, rsk_ctx *ctx, DBSearcher &SrcA, DBSear
         DA.m_SelfRevScoreA = SrcA.m_DBSelfRevScores[i]; DA.m_SelfRevScoreB = SrcB.m_DBSelfRevScores[j];
         DA.SetFromAln(out[p], paths + out[p].path_off);
         if (Self) {
-            S.BaseOnAln(DA, true);
-            if (i != joff + j) S.BaseOnAln(DA, false);
+            OnHit(DA, true);
+            if (i != joff + j) OnHit(DA, false);
         } else
-            S.BaseOnAln(DA, false);                                          // runquery.cpp:73: A = DB chain, B = query
+            OnHit(DA, false);                                                // runquery.cpp:73: A = DB chain, B = query
+    };
+    const unsigned T = (unsigned) std::min<size_t>(HostThreads(64), n / 2048 + 1);
+    if (S.m_HasOnAlnOverride || T < 2) {
+        // subclasses see every hit through OnAln in pair order, one at a time (the reference's m_Lock semantics)
+        for (size_t p = 0; p < n; ++p) replay(S.m_DA, p, [&](DSSAligner &DA, bool Up) { S.BaseOnAln(DA, Up); });
+        return;
     }
+    // plain DBSearcher: BaseOnAln = Reject + hit count + one TSV line.  Threads format contiguous slices of the batch
+    // into memory streams, which are then appended to the output in slice order (= the sequential row order).
+    struct slice { char *buf = nullptr; size_t size = 0; uint64_t hits = 0; std::string err; };
+    std::vector<slice> sl(T);
+    std::vector<std::thread> ts;
+    for (unsigned t = 0; t < T; ++t)
+        ts.emplace_back([&, t]() {
+            slice &me = sl[t];
+            try {
+                FILE *mf = S.m_fTsv ? open_memstream(&me.buf, &me.size) : nullptr;
+                if (S.m_fTsv && !mf) throw std::runtime_error("open_memstream failed");
+                DSSAligner DA;
+                DA.SetParams(P);
+                DA.m_UFs = S.m_DA.m_UFs;
+                const size_t lo = n * t / T, hi = n * (t + 1) / T;
+                for (size_t p = lo; p < hi; ++p)
+                    replay(DA, p, [&](DSSAligner &D, bool Up) {
+                        if (S.Reject(D, Up)) return;
+                        ++me.hits;
+                        if (mf && !(S.m_Opts.noself && D.m_ChainA->m_Label == D.m_ChainB->m_Label)) D.ToTsvUnlocked(mf, Up);
+                    });
+                DA.UnsetQuery();
+                if (mf) fclose(mf);
+            } catch (const std::exception &e) { me.err = e.what(); }
+        });
+    for (auto &t : ts) t.join();
+    for (slice &me : sl) {
+        if (me.err.empty() && me.size && fwrite(me.buf, 1, me.size, S.m_fTsv) != me.size) me.err = "short write to the hits file";
+        free(me.buf);
+        S.m_HitCount += me.hits;
+    }
+    for (slice &me : sl)
+        if (!me.err.empty()) throw std::runtime_error("hit replay: " + me.err);
 }
 
 // Shared body of RunSelf / RunQuery: A-side chains come from SrcA, B-side from *this.
@@ -579,9 +639,28 @@ static void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOff
     S.m_ProcessedPairCount = npairs;
     S.m_AlnCount = npairs - mkf.size();
     tm.lap("filter + pair lists");
-    for (auto &be : AlignBatches(S.m_Opts, SrcA, S, ia, ib))
-        AlignAndReplay(S, ctx, SrcA, S, std::vector<uint32_t>(ia.begin() + be.first, ia.begin() + be.second),
-                       std::vector<uint32_t>(ib.begin() + be.first, ib.begin() + be.second), Self, joff);
+    {
+        const auto batches = AlignBatches(S.m_Opts, SrcA, S, ia, ib);
+        auto launch = [&](size_t k) {
+            const auto be = batches[k];
+            return std::async(std::launch::async, [&, be]() {
+                return AlignBatch(P, ctx, SrcA, S, std::vector<uint32_t>(ia.begin() + be.first, ia.begin() + be.second),
+                                  std::vector<uint32_t>(ib.begin() + be.first, ib.begin() + be.second));
+            });
+        };
+        std::future<std::unique_ptr<AlignedBatch> > next;
+        if (!batches.empty()) next = launch(0);
+        for (size_t k = 0; k < batches.size(); ++k) {
+            std::unique_ptr<AlignedBatch> cur = next.get();                  // rethrows a failed GPU stage
+            if (k + 1 < batches.size()) next = launch(k + 1);
+            try {
+                ReplayBatch(S, SrcA, S, *cur, Self, joff);
+            } catch (...) {
+                if (next.valid()) next.wait();                               // the GPU stage in flight references this frame
+                throw;
+            }
+        }
+    }
     tm.lap("align + replay");
     // long-chain pairs: host MKF path (dssaligner.cpp:809-813), one aligner per host thread as in the
     // reference (dbsearcher.cpp:98-106); BaseOnAln serialises the output under m_Lock.

@@ -853,6 +853,12 @@ void DSSAligner::ToTsv(FILE *f, bool Up, bool NoSelf)
     if (f == nullptr) return;
     if (NoSelf && m_ChainA->m_Label == m_ChainB->m_Label) return;
     std::lock_guard<std::mutex> g(m_OutputLock);
+    ToTsvUnlocked(f, Up);
+}
+
+// one hit line into a stream that only this thread writes (the batch replay formats into per-thread buffers)
+void DSSAligner::ToTsvUnlocked(FILE *f, bool Up)
+{
     for (size_t i = 0; i < m_UFs.size(); ++i) {
         if (i > 0) fputc('\t', f);
         WriteUserField(f, m_UFs[i], Up);

@@ -776,7 +776,8 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
     }
     struct keyed { uint64_t key; uint32_t idx; };
     std::vector<keyed> ord(npairs);
-    for (size_t p = 0; p < npairs; ++p) {
+    rsk_parallel_for(npairs, 65536, [&](size_t p_lo, size_t p_hi) {
+    for (size_t p = p_lo; p < p_hi; ++p) {
         const uint32_t LA = dba->len[ia[p]], LB = dbb->len[ib[p]];
         uint64_t key;
         if (LA > 0 && cntA[ia[p]] >= min_group)
@@ -789,7 +790,24 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
             key = ((uint64_t) 3 << 62) | ((uint64_t) (0xFFFFFFu - std::min(LB, 0xFFFFFFu)) << 32);
         ord[p] = keyed{ key, (uint32_t) p };
     }
-    std::sort(ord.begin(), ord.end(), [](const keyed &x, const keyed &y) { return x.key != y.key ? x.key < y.key : x.idx < y.idx; });
+    });
+    {
+        // slices sorted on the host worker threads, then merged pairwise (keys are unique: (key, idx) is a total order)
+        const auto less = [](const keyed &x, const keyed &y) { return x.key != y.key ? x.key < y.key : x.idx < y.idx; };
+        const unsigned T = (unsigned) std::min<size_t>(reseek_amd::HostThreads(64), npairs / 65536 + 1);
+        std::vector<size_t> cut(T + 1);
+        for (unsigned t = 0; t <= T; ++t) cut[t] = npairs * t / T;
+        rsk_parallel_for(T, 1, [&](size_t lo, size_t hi) { for (size_t t = lo; t < hi; ++t) std::sort(ord.begin() + cut[t], ord.begin() + cut[t + 1], less); });
+        for (unsigned w = 1; w < T; w *= 2) {
+            const unsigned nm = (T + 2 * w - 1) / (2 * w);
+            rsk_parallel_for(nm, 1, [&](size_t lo, size_t hi) {
+                for (size_t m = lo; m < hi; ++m) {
+                    const unsigned a = (unsigned) m * 2 * w, b = std::min(T, a + w), c = std::min(T, a + 2 * w);
+                    if (b < c) std::inplace_merge(ord.begin() + cut[a], ord.begin() + cut[b], ord.begin() + cut[c], less);
+                }
+            });
+        }
+    }
     swf_classes cl;
     {
         uint32_t cnt[4] = { 0, 0, 0, 0 };
@@ -1002,7 +1020,8 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
         tm.lap("paths d2h");
     }
 
-    for (size_t p = 0; p < npairs; ++p) {
+    rsk_parallel_for(npairs, 16384, [&](size_t p_lo, size_t p_hi) {
+    for (size_t p = p_lo; p < p_hi; ++p) {
         const size_t k = slot[p];
         rsk_aln &o = out[p];
         const uint32_t LA = dba->len[ia[p]], LB = dbb->len[ib[p]];
@@ -1035,6 +1054,7 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
             o.evalue = (float) (pv * 8340.0);      // SCOP40c_DBSIZE statsig.h:3
         }
     }
+    });
     tm.lap("host stats");
     ctx->al_pairs = npairs; ctx->al_cells = cells; ctx->al_tb_bytes = tbo;
     return RSK_OK;

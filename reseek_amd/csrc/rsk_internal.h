@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <map>
 #include <string>
+#include <thread>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/reseek_amd.h"
@@ -117,3 +119,17 @@ int rsk_launch_gapless_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, con
 int rsk_build_rings(rsk_db *db);
 int rsk_build_mudex(rsk_db *db, int mode);
 int rsk_build_len_perm(rsk_db *db);
+
+// host worker threads: min(hardware threads, cgroup CPU quota, cap) -- defined in host/dbsearcher.cpp
+namespace reseek_amd { unsigned HostThreads(unsigned cap); }
+
+// run body(lo, hi) over [0, n) on the host worker threads (contiguous slices)
+template <class F>
+static inline void rsk_parallel_for(size_t n, size_t min_per_thread, F body)
+{
+    const unsigned T = (unsigned) std::min<size_t>(reseek_amd::HostThreads(64), n / (min_per_thread ? min_per_thread : 1) + 1);
+    if (T < 2) { body((size_t) 0, n); return; }
+    std::vector<std::thread> ts;
+    for (unsigned t = 0; t < T; ++t) ts.emplace_back([&, t]() { body(n * t / T, n * (t + 1) / T); });
+    for (auto &t : ts) t.join();
+}
