@@ -180,6 +180,21 @@ int rsk_mkf_seed_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, const uin
                        size_t npairs, int x1, int min_hsp_score, uint32_t cap, uint8_t *found, size_t max_records,
                        size_t *nrecords, uint32_t *rec_pair, uint32_t *rec_nkept, int32_t *rec_kept);
 
+/* ---- P9 (second half, host): the gapped float X-drop building blocks on an explicit LA x LB score matrix
+ * (row-major S[a * LB + b]) -- XDropFwd (xdropfwd.cpp:71), XDropBwd (xdropbwd.cpp:28), MergeFwdBwd
+ * (mergefwdback.cpp:6), in the form the reference's own self-test drives them (test_xdrop.cpp:81-175).
+ * XDropFwd extends from (lo_a, lo_b) towards the chain ends, XDropBwd from (hi_a, hi_b) towards the starts;
+ * open / ext are added (pass them negative).  path: caller buffer, NUL-terminated, *path_len = its length.
+ * Inside -search these run per long-chain pair with DSSAligner::SubstScore as the matrix
+ * (host/dssaligner.cpp, XDropHSP xdrophsp.cpp:42).  Host code: ctx-free, no GPU involved. */
+int rsk_xdrop_fwd(const float *S, uint32_t LA, uint32_t LB, float X, float open, float ext, uint32_t lo_a, uint32_t lo_b,
+                  float *score, char *path, size_t path_cap, uint32_t *path_len);
+int rsk_xdrop_bwd(const float *S, uint32_t LA, uint32_t LB, float X, float open, float ext, uint32_t hi_a, uint32_t hi_b,
+                  float *score, char *path, size_t path_cap, uint32_t *path_len);
+int rsk_merge_fwd_bwd(uint32_t LA, uint32_t LB, uint32_t fwd_lo_a, uint32_t fwd_lo_b, const char *fwd_path, uint32_t bwd_hi_a,
+                      uint32_t bwd_hi_b, const char *bwd_path, uint32_t *lo_a, uint32_t *lo_b, uint32_t *hi_a, uint32_t *hi_b,
+                      char *path, size_t path_cap, uint32_t *path_len);
+
 /* ---- P10/P11/P12: Mu k-mer prefilter ----------------------------------------------------------------
  * Batch form of MuDex::FromSeqDB (mudex.cpp:386; index of the QUERY set, built once and cached in q)
  * + PrefilterMu::Search over every target (prefiltermu.cpp:382): spaced 5-of-7 k-mers, self-score

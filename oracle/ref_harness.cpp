@@ -24,6 +24,7 @@
 //   pairs    <in.bca> <out.bin> <maxchains>  [-- mode]
 //   mukat    <in.mu.fa> <first> <count> <out.bin>
 //   randkat  <seed> <npairs> <out.bin>
+//   xdropkat <seed> <nrandom> <out.bin>      (the reference's -test_xdrop / testsw peptide pairs + random ones)
 //   benchmu  <in.mu.fa> <npairs> <threads>    (times the reference kernels; bench.py cpu_baseline)
 
 #include "myutils.h"
@@ -737,6 +738,114 @@ static void cmd_prefhood(const string &QFa, const string &TFa, const string &Sco
 	CloseStdioFile(f);
 	}
 
+
+// xdropkat: the reference's own X-drop / SW self-test vectors (test_xdrop.cpp:177-187: three peptide pairs through
+// SWFast, XDropFwd, XDropBwd, MergeFwdBwd with BLOSUM62, Open -3, Ext -1, X 8; swgaplessprof.cpp:158-166: six
+// peptide pairs through SWGapless) plus <nrandom> random peptide pairs run the same way.  The fixture holds the
+// inputs as data (the explicit score matrix of each pair) and every output of the reference functions.
+void SetBLOSUM62();
+float GetBlosum62Score(char a, char b);
+float SWGapless(Mx<float> &DPMx, const Mx<float> &SMx, uint LA, uint LB, uint &Loi, uint &Loj, uint &ColCount);
+void MergeFwdBwd(uint LA, uint LB, uint FwdLoA, uint FwdLoB, const string &FwdPath, uint BwdHiA, uint BwdHiB, const string &BwdPath,
+  uint &LoA, uint &LoB, uint &HiA, uint &HiB, string &Path);
+static const float * const *s_KatS;
+static float KatSubFn(void *, uint PosA, uint PosB) { return s_KatS[PosA][PosB]; }
+static void wstr(FILE *f, const string &s) { w32(f, (uint32_t) s.size()); wbytes(f, s.data(), s.size()); }
+
+static void xdropkat_case(FILE *f, const string &A, const string &B, float Open, float Ext, float X)
+	{
+	const uint LA = SIZE(A), LB = SIZE(B);
+	Mx<float> SMx;
+	SMx.Alloc(LA, LB, __FILE__, __LINE__);
+	float **S = SMx.GetData();
+	for (uint i = 0; i < LA; ++i)
+		for (uint j = 0; j < LB; ++j)
+			S[i][j] = GetBlosum62Score(A[i], B[j]);
+	s_KatS = S;
+	wstr(f, A); wstr(f, B);
+	wf32(f, Open); wf32(f, Ext); wf32(f, X);
+	for (uint i = 0; i < LA; ++i) wbytes(f, S[i], 4 * (size_t) LB);
+	XDPMem Mem;
+	string SWPath;
+	uint Loi, Loj, Leni, Lenj;
+	float SWScore = SWFast(Mem, S, LA, LB, Open, Ext, Loi, Loj, Leni, Lenj, SWPath);
+	wf32(f, SWScore); w32(f, Loi); w32(f, Loj); w32(f, Leni); w32(f, Lenj); wstr(f, SWPath);
+	Mx<float> DPMx;
+	uint gLoi = 0, gLoj = 0, gCols = 0;
+	float GScore = SWGapless(DPMx, SMx, LA, LB, gLoi, gLoj, gCols);
+	wf32(f, GScore); w32(f, gLoi); w32(f, gLoj); w32(f, gCols);
+	const uint ColCount = SIZE(SWPath);
+	if (ColCount < 8) { w32(f, 0); return; }           // test_xdrop.cpp:113-114
+	w32(f, 1);
+	uint MidPosA = Loi, MidPosB = Loj;
+	for (uint Col = 0; Col < ColCount / 2; ++Col)
+		{
+		char c = SWPath[Col];
+		if (c == 'M' || c == 'D') ++MidPosA;
+		if (c == 'M' || c == 'I') ++MidPosB;
+		}
+	w32(f, MidPosA); w32(f, MidPosB);
+	string FwdPath, BwdPath, MergedPath;
+	uint FwdSegLoA = 0, FwdSegLoB = 0, BwdSegLoA = 0, BwdSegLoB = 0;
+	float FwdScore = XDropFwd(Mem, X, Open, Ext, KatSubFn, 0, MidPosA + 1, LA, MidPosB + 1, LB, &FwdSegLoA, &FwdSegLoB, FwdPath);
+	wf32(f, FwdScore); w32(f, FwdSegLoA); w32(f, FwdSegLoB); wstr(f, FwdPath);
+	float BwdScore = XDropBwd(Mem, X, Open, Ext, KatSubFn, 0, MidPosA, LA, MidPosB, LB, &BwdSegLoA, &BwdSegLoB, BwdPath);
+	wf32(f, BwdScore); w32(f, BwdSegLoA); w32(f, BwdSegLoB); wstr(f, BwdPath);
+	if (FwdPath.empty() && BwdPath.empty()) { w32(f, 0); return; }     // MergeFwdBwd asserts on this input (mergefwdback.cpp:11)
+	w32(f, 1);
+	uint MLoA, MLoB, MHiA, MHiB;
+	MergeFwdBwd(LA, LB, MidPosA + 1, MidPosB + 1, FwdPath, MidPosA, MidPosB, BwdPath, MLoA, MLoB, MHiA, MHiB, MergedPath);
+	w32(f, MLoA); w32(f, MLoB); w32(f, MHiA); w32(f, MHiB); wstr(f, MergedPath);
+	}
+
+static void cmd_xdropkat(uint64_t Seed, uint NRandom, const string &OutFN)
+	{
+	SetBLOSUM62();
+	FILE *f = fopen(OutFN.c_str(), "wb");
+	if (!f) Die("cannot create %s", OutFN.c_str());
+	static const char *Fixed[][2] = {
+		{ "DVLGYLRFLTKGERQANLNF", "WVLGLRFLTKGERQANLNF" },           // test_xdrop.cpp:179-186
+		{ "DVLGYLRFLTERQANLNF", "WVLGLRFLTKGERQANLNF" },
+		{ "DVLGYLRFLTKGERQANLNF", "WVLGLINSRFLTKGERQANLNF" },
+		{ "LQNGSEQVENCE", "LQNGSEQVENCE" },                          // swgaplessprof.cpp:160-165
+		{ "QNGSEQVENCE", "LQNGSEQVENCE" },
+		{ "LQNGSEQVENCE", "QNGSEQVENCE" },
+		{ "LQNGSEQVENC", "QNGSEQVENCE" },
+		{ "SEQVENCE", "QVE" },
+		{ "QVE", "SEQVENCE" },
+	};
+	const uint NFixed = sizeof(Fixed) / sizeof(Fixed[0]);
+	wbytes(f, "XDKAT1\0\0", 8);
+	w32(f, NFixed + NRandom);
+	for (uint k = 0; k < NFixed; ++k)
+		xdropkat_case(f, Fixed[k][0], Fixed[k][1], -3, -1, 8);
+	s_rng = Seed;
+	static const char AA[] = "ACDEFGHIKLMNPQRSTVWY";
+	for (uint k = 0; k < NRandom; ++k)
+		{
+		const uint LA = 8 + splitmix64() % 150;
+		string A, B;
+		for (uint p = 0; p < LA; ++p) A += AA[splitmix64() % 20];
+		// mutated copy (sub 0.2 / ins 0.08 / del 0.08), random flanks, sometimes a second copy of a segment
+		for (uint p = splitmix64() % 6; p > 0; --p) B += AA[splitmix64() % 20];
+		for (uint p = 0; p < LA; ++p)
+			{
+			uint r = splitmix64() % 100;
+			if (r < 8) continue;
+			if (r < 16) B += AA[splitmix64() % 20];
+			B += r < 36 ? AA[splitmix64() % 20] : A[p];
+			}
+		if (k % 5 == 0 && LA > 30) B += A.substr(LA / 3, LA / 3);
+		for (uint p = splitmix64() % 6; p > 0; --p) B += AA[splitmix64() % 20];
+		const float Open = k % 3 == 0 ? -3.0f : (k % 3 == 1 ? -1.5f : -0.685533f * 8);
+		const float Ext = k % 3 == 0 ? -1.0f : (k % 3 == 1 ? -0.25f : -0.051881f * 8);
+		const float X = k % 4 == 0 ? 8.0f : (k % 4 == 1 ? 4.0f : (k % 4 == 2 ? 16.0f : 2.5f));
+		xdropkat_case(f, A, B, Open, Ext, X);
+		}
+	fclose(f);
+	fprintf(stderr, "xdropkat: %u cases -> %s\n", NFixed + NRandom, OutFN.c_str());
+	}
+
 int main(int argc, char **argv)
 	{
 	if (argc < 2)
@@ -777,6 +886,8 @@ int main(int argc, char **argv)
 		cmd_d1pairs(A[0], A[1], (uint) atoi(A[2].c_str()));
 	else if (Cmd == "prefhood" && A.size() == 4)
 		cmd_prefhood(A[0], A[1], A[2], A[3]);
+	else if (Cmd == "xdropkat" && A.size() == 3)
+		cmd_xdropkat(strtoull(A[0].c_str(), 0, 0), (uint) atoi(A[1].c_str()), A[2]);
 	else if (Cmd == "benchmu" && A.size() == 3)
 		cmd_benchmu(A[0], strtoull(A[1].c_str(), 0, 0), (uint) atoi(A[2].c_str()));
 	else

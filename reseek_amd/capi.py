@@ -64,6 +64,11 @@ SIGNATURES["rsk_bca_info"] = (C.c_int, [C.c_char_p, C.POINTER(C.c_uint64), C.POI
 SIGNATURES["rsk_bca_read_chain"] = (C.c_int, [C.c_char_p, C.c_uint64, C.c_char_p, C.c_size_t, C.c_char_p, f32p, f32p, f32p, C.c_uint32, u32p])
 SIGNATURES["rsk_mkf_seed_pairs"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, u32p, u32p, C.c_size_t, C.c_int, C.c_int, C.c_uint32,
                                               C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_size_t), u32p, u32p, C.POINTER(C.c_int32)])
+SIGNATURES["rsk_xdrop_fwd"] = (C.c_int, [f32p, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32,
+                                         f32p, C.c_char_p, C.c_size_t, u32p])
+SIGNATURES["rsk_xdrop_bwd"] = SIGNATURES["rsk_xdrop_fwd"]
+SIGNATURES["rsk_merge_fwd_bwd"] = (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint32, C.c_uint32, C.c_char_p,
+                                             u32p, u32p, u32p, u32p, C.c_char_p, C.c_size_t, u32p])
 SIGNATURES["rsk_mu_pinop_pairs"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, u32p, u32p, C.c_size_t, C.c_int, C.c_int,
                                               C.POINTER(C.c_int32)])
 SIGNATURES["rsk_mu_gapless_profb_pairs"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, u32p, u32p, C.c_size_t, C.POINTER(C.c_float)])
@@ -348,6 +353,35 @@ def rsb_select(q, t, score, nqueries, rsb_size=1500, tmp_tsv_path=None):
                                 _p(os_, u32p), C.byref(nout), tmp_tsv_path.encode() if tmp_tsv_path else None))
     m = nout.value
     return oq[:m], ot[:m], os_[:m]
+
+
+def _xdrop(fn, S, X, gap_open, gap_ext, a, b):
+    S = np.ascontiguousarray(S, np.float32)
+    LA, LB = S.shape
+    buf = C.create_string_buffer(LA + LB + 2)
+    score, n = C.c_float(), C.c_uint32()
+    _check(fn(_p(S, f32p), LA, LB, X, gap_open, gap_ext, a, b, C.byref(score), buf, len(buf), C.byref(n)))
+    return score.value, buf.value.decode()
+
+
+def xdrop_fwd(S, X, gap_open, gap_ext, lo_a, lo_b):
+    """XDropFwd (xdropfwd.cpp:71) on an explicit score matrix S[LA, LB] -> (score, path).  Host code."""
+    return _xdrop(lib().rsk_xdrop_fwd, S, X, gap_open, gap_ext, lo_a, lo_b)
+
+
+def xdrop_bwd(S, X, gap_open, gap_ext, hi_a, hi_b):
+    """XDropBwd (xdropbwd.cpp:28) -> (score, path)."""
+    return _xdrop(lib().rsk_xdrop_bwd, S, X, gap_open, gap_ext, hi_a, hi_b)
+
+
+def merge_fwd_bwd(LA, LB, fwd_lo_a, fwd_lo_b, fwd_path, bwd_hi_a, bwd_hi_b, bwd_path):
+    """MergeFwdBwd (mergefwdback.cpp:6) -> (lo_a, lo_b, hi_a, hi_b, path)."""
+    v = [C.c_uint32() for _ in range(4)]
+    buf = C.create_string_buffer(len(fwd_path) + len(bwd_path) + 2)
+    n = C.c_uint32()
+    _check(lib().rsk_merge_fwd_bwd(LA, LB, fwd_lo_a, fwd_lo_b, fwd_path.encode(), bwd_hi_a, bwd_hi_b, bwd_path.encode(),
+                                   C.byref(v[0]), C.byref(v[1]), C.byref(v[2]), C.byref(v[3]), buf, len(buf), C.byref(n)))
+    return v[0].value, v[1].value, v[2].value, v[3].value, buf.value.decode()
 
 
 def dss_featurize(seq, x, y, z):

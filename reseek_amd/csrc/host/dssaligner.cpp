@@ -867,3 +867,54 @@ void DSSAligner::ToTsvUnlocked(FILE *f, bool Up)
 }
 
 }   // namespace reseek_amd
+
+// ---------------------------------------------------------------------------------------------
+// C-ABI of the gapped X-drop building blocks on an explicit score matrix (the form the reference's own
+// self-test drives them in, test_xdrop.cpp:81-175).  Host code; no GPU involved.
+// ---------------------------------------------------------------------------------------------
+void rsk_set_error(const char *fmt, ...);
+
+namespace {
+int put_path(const std::string &Path, char *path, size_t cap, uint32_t *len, const char *who)
+{
+    if (len) *len = (uint32_t) Path.size();
+    if (Path.size() + 1 > cap || !path) { rsk_set_error("%s: path buffer too small (%zu needed)", who, Path.size() + 1); return RSK_E_INVALID; }
+    memcpy(path, Path.c_str(), Path.size() + 1);
+    return RSK_OK;
+}
+}   // namespace
+
+extern "C" int rsk_xdrop_fwd(const float *S, uint32_t LA, uint32_t LB, float X, float open, float ext, uint32_t lo_a, uint32_t lo_b,
+                             float *score, char *path, size_t path_cap, uint32_t *path_len)
+{
+    if (!S || !score || lo_a > LA || lo_b > LB) { rsk_set_error("rsk_xdrop_fwd: invalid argument"); return RSK_E_INVALID; }
+    reseek_amd::XDropMem Mem;
+    std::string Path;
+    unsigned s1, s2;
+    *score = reseek_amd::XDropFwd(Mem, X, open, ext, [&](unsigned a, unsigned b) { return S[(size_t) a * LB + b]; }, lo_a, LA, lo_b, LB, &s1, &s2, Path);
+    return put_path(Path, path, path_cap, path_len, "rsk_xdrop_fwd");
+}
+
+extern "C" int rsk_xdrop_bwd(const float *S, uint32_t LA, uint32_t LB, float X, float open, float ext, uint32_t hi_a, uint32_t hi_b,
+                             float *score, char *path, size_t path_cap, uint32_t *path_len)
+{
+    if (!S || !score || hi_a >= LA || hi_b >= LB) { rsk_set_error("rsk_xdrop_bwd: invalid argument"); return RSK_E_INVALID; }
+    reseek_amd::XDropMem Mem;
+    std::string Path;
+    unsigned s1, s2;
+    *score = reseek_amd::XDropBwd(Mem, X, open, ext, [&](unsigned a, unsigned b) { return S[(size_t) a * LB + b]; }, hi_a, LA, hi_b, LB, &s1, &s2, Path);
+    return put_path(Path, path, path_cap, path_len, "rsk_xdrop_bwd");
+}
+
+extern "C" int rsk_merge_fwd_bwd(uint32_t LA, uint32_t LB, uint32_t fwd_lo_a, uint32_t fwd_lo_b, const char *fwd_path, uint32_t bwd_hi_a,
+                                 uint32_t bwd_hi_b, const char *bwd_path, uint32_t *lo_a, uint32_t *lo_b, uint32_t *hi_a, uint32_t *hi_b,
+                                 char *path, size_t path_cap, uint32_t *path_len)
+{
+    if (!fwd_path || !bwd_path || !lo_a || !lo_b || !hi_a || !hi_b) { rsk_set_error("rsk_merge_fwd_bwd: NULL argument"); return RSK_E_INVALID; }
+    if (!*fwd_path && !*bwd_path) { rsk_set_error("rsk_merge_fwd_bwd: both paths are empty (mergefwdback.cpp:11 asserts)"); return RSK_E_INVALID; }
+    std::string Path;
+    unsigned la, lb, ha, hb;
+    reseek_amd::MergeFwdBwd(LA, LB, fwd_lo_a, fwd_lo_b, fwd_path, bwd_hi_a, bwd_hi_b, bwd_path, la, lb, ha, hb, Path);
+    *lo_a = la; *lo_b = lb; *hi_a = ha; *hi_b = hb;
+    return put_path(Path, path, path_cap, path_len, "rsk_merge_fwd_bwd");
+}

@@ -55,6 +55,9 @@ $H mukat $T/scop40.mu.fa 0 160 $TMP/mukat_scop40_160.bin
 gzip -9n < $TMP/mukat_scop40_160.bin > $G/mukat_scop40_160.bin.gz
 $H randkat 0x5EED5EEC 3000 $TMP/randkat_3000.bin
 gzip -9n < $TMP/randkat_3000.bin > $G/randkat_3000.bin.gz
+# the reference's own -test_xdrop / testsw peptide pairs (+300 random ones) through SWFast, SWGapless, XDropFwd/Bwd, MergeFwdBwd
+$H xdropkat 0x5EED 300 $TMP/xdropkat_309.bin
+gzip -9n < $TMP/xdropkat_309.bin > $G/xdropkat_309.bin.gz
 
 # 6. the empirical SCOP40 chain-length list (used by the synthetic generator)
 python3 - <<EOF

@@ -62,6 +62,8 @@ def lib():
         L.rsko_set_smx.argtypes = [u8p, C.c_int, u8p, C.c_int, f32p]
         L.rsko_sw_fast.restype = C.c_float
         L.rsko_sw_fast.argtypes = [f32p, C.c_int, C.c_int, C.c_float, C.c_float, u32p, u32p, C.c_char_p, u32p, u8p]
+        L.rsko_sw_gapless_float.restype = C.c_float
+        L.rsko_sw_gapless_float.argtypes = [f32p, C.c_int, C.c_int, u32p, u32p]
         L.rsko_gapless_profb.restype = C.c_float
         L.rsko_gapless_profb.argtypes = [u8p, C.c_int, u8p, C.c_int]
         L.rsko_gapless_float_pair.restype = C.c_float
@@ -121,6 +123,24 @@ def gapless_float_pair(profA, profB):
     pb = np.ascontiguousarray(profB)
     bi, bj = C.c_uint32(), C.c_uint32()
     s = lib().rsko_gapless_float_pair(_p(pa, u8p), pa.shape[1], _p(pb, u8p), pb.shape[1], C.byref(bi), C.byref(bj))
+    return s, bi.value, bj.value
+
+
+def sw_fast_matrix(S, open_, ext):
+    """SWFast (sw.cpp:79) on an explicit score matrix float32 [LA, LB] -> (score, lo_i, lo_j, path)"""
+    S = np.ascontiguousarray(S, np.float32)
+    LA, LB = S.shape
+    buf = C.create_string_buffer(LA + LB + 2)
+    lo_i, lo_j, n = C.c_uint32(0xFFFFFFFF), C.c_uint32(0xFFFFFFFF), C.c_uint32()
+    s = lib().rsko_sw_fast(_p(S, f32p), LA, LB, open_, ext, C.byref(lo_i), C.byref(lo_j), buf, C.byref(n), None)
+    return s, lo_i.value, lo_j.value, buf.value.decode()
+
+
+def sw_gapless_matrix(S):
+    """SWFastGapless (swgapless.cpp:46) on an explicit score matrix -> (score, besti, bestj)"""
+    S = np.ascontiguousarray(S, np.float32)
+    bi, bj = C.c_uint32(), C.c_uint32()
+    s = lib().rsko_sw_gapless_float(_p(S, f32p), S.shape[0], S.shape[1], C.byref(bi), C.byref(bj))
     return s, bi.value, bj.value
 
 
