@@ -764,15 +764,22 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
     // ---- classes: 0/1 = query-profile kernel (strips along A / along B), 2/3 = per-pair kernel --------
     // A pair goes to the query-profile kernel when one of its chains fits the LDS profile and enough
     // pairs of this call share that chain to fill a wave; everything else takes the per-pair kernel.
-    static const uint32_t min_group = getenv("RSK_SWQ_MIN_GROUP") ? (uint32_t) atoi(getenv("RSK_SWQ_MIN_GROUP")) : 4;
+    // A workgroup of k_sw_qp holds ONE profile (its LDS), so its parallelism is (pairs of the group) x (strips of the
+    // chain) lanes; below ~10 waves' worth the per-pair kernel, which fills the CU with unrelated pairs, is faster
+    // (measured on the SCOP40 -sensitive survivors: crossover at 30-50 pairs per 175-residue query).
+    const uint32_t min_lanes = getenv("RSK_SWQ_MIN_LANES") ? (uint32_t) atoi(getenv("RSK_SWQ_MIN_LANES")) : 640;
+    auto qp_ok = [&](uint32_t count, uint32_t L) {
+        const uint32_t g = std::min<uint32_t>((L + SWQ_R - 1) / SWQ_R, SWQ_MAX_G);
+        return L > 0 && (uint64_t) count * g >= min_lanes;
+    };
     std::vector<uint32_t> cntA(dba->n, 0), cntB;
     for (size_t p = 0; p < npairs; ++p) ++cntA[ia[p]];
     bool anyB = false;
-    for (size_t p = 0; p < npairs && !anyB; ++p) anyB = cntA[ia[p]] < min_group;
+    for (size_t p = 0; p < npairs && !anyB; ++p) anyB = !qp_ok(cntA[ia[p]], dba->len[ia[p]]);
     if (anyB) {
         cntB.assign(dbb->n, 0);
         for (size_t p = 0; p < npairs; ++p)
-            if (cntA[ia[p]] < min_group) ++cntB[ib[p]];
+            if (!qp_ok(cntA[ia[p]], dba->len[ia[p]])) ++cntB[ib[p]];
     }
     struct keyed { uint64_t key; uint32_t idx; };
     std::vector<keyed> ord(npairs);
@@ -780,9 +787,9 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
     for (size_t p = p_lo; p < p_hi; ++p) {
         const uint32_t LA = dba->len[ia[p]], LB = dbb->len[ib[p]];
         uint64_t key;
-        if (LA > 0 && cntA[ia[p]] >= min_group)
+        if (qp_ok(cntA[ia[p]], LA))
             key = ((uint64_t) 0 << 62) | ((uint64_t) ia[p] << 24) | (0xFFFFFFu - std::min(LB, 0xFFFFFFu));
-        else if (LB > 0 && cntB[ib[p]] >= min_group)
+        else if (!cntB.empty() && qp_ok(cntB[ib[p]], LB))
             key = ((uint64_t) 1 << 62) | ((uint64_t) ib[p] << 24) | (0xFFFFFFu - std::min(LA, 0xFFFFFFu));
         else if (!(LA > 64 * SWF_R && LB <= 64 * SWF_R))
             key = ((uint64_t) 2 << 62) | ((uint64_t) (0xFFFFFFu - std::min(LA, 0xFFFFFFu)) << 32);

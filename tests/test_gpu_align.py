@@ -26,6 +26,17 @@ def ctx():
     c.close()
 
 
+@pytest.fixture(autouse=True, params=["per-pair kernel for small groups (default)", "query-profile kernel for every group"])
+def kernel_choice(request, monkeypatch):
+    """rsk_align_pairs sends a group of pairs that share a chain to k_sw_qp only when the group fills ~10 waves
+    (RSK_SWQ_MIN_LANES, default 640); every test here runs under the default and with the threshold at 1, so both
+    float-SW kernels see all the cases."""
+    if request.param.startswith("query-profile"):
+        monkeypatch.setenv("RSK_SWQ_MIN_LANES", "1")
+    else:
+        monkeypatch.delenv("RSK_SWQ_MIN_LANES", raising=False)
+
+
 def check_against_records(ctx, chains, recs, min_fwd):
     import reseek_amd
     db = reseek_amd.Db.from_chains(ctx, chains)
