@@ -104,6 +104,20 @@ __device__ __forceinline__ float dpp_shr1_f(float x)
                                                                   0x138 /* wave_shr:1 */, 0xF, 0xF, false));
 }
 
+// w = 2 * w + (x > y) / (x >= y): the comparison bit enters through the carry
+#define SWQ_BIT_GT(w, x, y) asm("v_cmp_gt_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(w) : "v"(x), "v"(y) : "vcc")
+#define SWQ_BIT_GE(w, x, y) asm("v_cmp_ge_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(w) : "v"(x), "v"(y) : "vcc")
+#define SWQ_BIT_0GE(w, y) asm("v_cmp_ge_f32_e32 vcc, 0, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(w) : "v"(y) : "vcc")
+
+
+// v_max_f32 without the canonicalising v_max x, x, x that fmaxf() costs per fresh operand (no NaNs occur here)
+__device__ __forceinline__ float swq_max(float x, float y)
+{
+    float r;
+    asm("v_max_f32_e32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+
 // T = false: strips along A (rows), the wave steps over the columns of B; trace block TB[j][LApad].
 // T = true : strips along B (columns), the wave steps over the rows of A;  trace block TB[i][LBpad].
 template <bool T>
@@ -133,6 +147,9 @@ __global__ __launch_bounds__(64 * SWF_WAVES) void k_sw_float(swf_args a, uint32_
     float best = 0.0f;
     uint32_t bi = 0xFFFFFFFFu, bj = 0xFFFFFFFFu;
     int *bnd = a.bnd ? a.bnd + a.bnd_off[p] : nullptr;     // only multi-group pairs (one pair per wave) use it
+    // best cell of each register row: first step at which the row reached its maximum (strict >)
+    float rb[SWF_R];
+    uint32_t rj[SWF_R];
 
     // Chains with more than 64 strips are processed in row groups of 64 strips; the bottom row of a
     // group goes through `bnd` (HBM, agent-scope accesses: written by lane 63, read by lane 0 later).
@@ -169,7 +186,7 @@ __global__ __launch_bounds__(64 * SWF_WAVES) void k_sw_float(swf_args a, uint32_
 
     float Md[SWF_R], In[SWF_R];      // DPM[i][j] (diagonal input of row r at the next column), DPI[i][j]
 #pragma unroll
-    for (int r = 0; r < SWF_R; ++r) { Md[r] = SWF_MINUS_INF; In[r] = SWF_MINUS_INF; }
+    for (int r = 0; r < SWF_R; ++r) { Md[r] = SWF_MINUS_INF; In[r] = SWF_MINUS_INF; rb[r] = 0.0f; rj[r] = 0; }
     if (st == 0 && rg == 0) Md[0] = 0.0f;   // DPM[0][0] = 0 (sw.cpp:117)
     float hand_m = SWF_MINUS_INF, hand_d = SWF_MINUS_INF;   // bottom row of this strip at its previous column
     float carry_in = SWF_MINUS_INF;                         // DPM[i0][j] from the lane above (arrives one step early)
@@ -206,7 +223,11 @@ __global__ __launch_bounds__(64 * SWF_WAVES) void k_sw_float(swf_args a, uint32_
             if (st != 0 || rg != 0) Md[0] = carry_in;                   // DPM[i0][j] = bottom DPM of the strip above at column j-1
             else if (j > 0) Md[0] = SWF_MINUS_INF;                      // DPM[0][j>0] = -inf (sw.cpp:102-111)
             float carry = SWF_MINUS_INF;                                // DPM[i0+r][j+1] produced by row r-1
-            uint32_t tbw[4] = { 0, 0, 0, 0 };
+            // branch-free cell: the five comparisons of the recurrence enter a trace byte through the carry
+            // (same bit order as k_sw_qp: DM candidate, IM candidate, SM, MD, MI; decoded in swf_trace_flags);
+            // the byte of row r sits at bits 8 * (3 - r % 4) of its dword
+            uint32_t tbw[4];
+            uint32_t w = 0;
 #pragma unroll
             for (int r = 0; r < SWF_R; ++r) {
                 // S(i,j): features summed 0 -> 7 (dssaligner.cpp:553-597)
@@ -222,28 +243,27 @@ __global__ __launch_bounds__(64 * SWF_WAVES) void k_sw_float(swf_args a, uint32_
                 const float d = T ? In[r] : ch;     // DPD of this grid point
                 const float n = T ? ch : In[r];     // DPI of this grid point
                 Md[r] = carry;                      // becomes this register's diagonal input at the next step
+                if (r & 3) w <<= 3;
                 // MATCH (sw.cpp:123-155)
-                float xM = m;
-                uint32_t t = 0;
-                if (d > xM) { xM = d; t = TB_DM; }
-                if (n > xM) { xM = n; t = TB_IM; }
-                if (0.0f >= xM) { xM = 0.0f; t = TB_SM; }
-                xM += S;
-                if (xM >= best) {
-                    const uint32_t ii = T ? (uint32_t) j : i0 + r, jj = T ? i0 + r : (uint32_t) j;
-                    if (xM > best || (best > 0.0f && (ii < bi || (ii == bi && jj < bj)))) { best = xM; bi = ii; bj = jj; }
-                }
+                SWQ_BIT_GT(w, d, m);                 // TB_DM candidate (sw.cpp:127)
+                const float x1 = swq_max(m, d);
+                SWQ_BIT_GT(w, n, x1);                // TB_IM (sw.cpp:135)
+                const float x2 = swq_max(x1, n);
+                SWQ_BIT_0GE(w, x2);                  // TB_SM (sw.cpp:143)
+                const float xM = swq_max(x2, 0.0f) + S;
+                if (xM > rb[r]) { rb[r] = xM; rj[r] = (uint32_t) j; }
                 carry = xM;
-                // DELETE (sw.cpp:163-176): DPD[i+1][j]
+                // DELETE (sw.cpp:163-176): DPD[i+1][j];  INSERT (sw.cpp:178-191): DPI[i][j+1]
                 const float md = m + Open;
-                float dd = d + Ext;
-                if (md >= dd) { dd = md; t |= TB_MD; }
-                // INSERT (sw.cpp:178-191): DPI[i][j+1]
-                float ni = n + Ext;
-                if (md >= ni) { ni = md; t |= TB_MI; }
+                const float de = d + Ext;
+                SWQ_BIT_GE(w, md, de);               // TB_MD (sw.cpp:166)
+                const float dd = swq_max(md, de);
+                const float ne = n + Ext;
+                SWQ_BIT_GE(w, md, ne);               // TB_MI (sw.cpp:181)
+                const float ni = swq_max(md, ne);
                 if (T) { ch = ni; In[r] = dd; }
                 else { ch = dd; In[r] = ni; }
-                tbw[r >> 2] |= t << (8 * (r & 3));
+                if ((r & 3) == 3) { tbw[r >> 2] = w; w = 0; }
             }
             hand_m = carry;      // DPM[i0+16][j+1]
             hand_d = ch;         // DPD[i0+16][j] (normal) / DPI[i][j0+16] (transposed)
@@ -254,6 +274,12 @@ __global__ __launch_bounds__(64 * SWF_WAVES) void k_sw_float(swf_args a, uint32_
             }
         }
         if (!reads_bnd) carry_in = in_m;   // value sent by the lane above at this step is for its column j+1 == our next column
+    }
+    // fold the rows of this group into the lane's best: highest score, then smallest i, then smallest j
+#pragma unroll
+    for (int r = 0; r < SWF_R; ++r) {
+        const uint32_t ii = T ? rj[r] : i0 + r, jj = T ? i0 + r : rj[r];
+        if (rb[r] > best || (rb[r] == best && best > 0.0f && (ii < bi || (ii == bi && jj < bj)))) { best = rb[r]; bi = ii; bj = jj; }
     }
     if (it.ngroups > 1) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // boundary stores of this group have left the wave
@@ -299,22 +325,9 @@ __global__ __launch_bounds__(64 * SWF_WAVES) void k_sw_float(swf_args a, uint32_
 
 struct swq_item { uint32_t first, count; };
 
-// w = 2 * w + (x > y) / (x >= y): the comparison bit enters through the carry
-#define SWQ_BIT_GT(w, x, y) asm("v_cmp_gt_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(w) : "v"(x), "v"(y) : "vcc")
-#define SWQ_BIT_GE(w, x, y) asm("v_cmp_ge_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(w) : "v"(x), "v"(y) : "vcc")
-#define SWQ_BIT_0GE(w, y) asm("v_cmp_ge_f32_e32 vcc, 0, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(w) : "v"(y) : "vcc")
-
 typedef float swq_v2f __attribute__((ext_vector_type(2)));
 typedef float swq_v4f __attribute__((ext_vector_type(4)));
 typedef const volatile __attribute__((address_space(3))) swq_v4f *swq_ldsp;   // volatile: see the fetch in k_sw_qp
-// v_max_f32 without the canonicalising v_max x, x, x that fmaxf() costs per fresh operand (no NaNs occur here)
-__device__ __forceinline__ float swq_max(float x, float y)
-{
-    float r;
-    asm("v_max_f32_e32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
-    return r;
-}
-
 template <bool T>
 __global__ __launch_bounds__(64 * SWQ_NW) void k_sw_qp(swf_args a, const swq_item *items)
 {
@@ -510,13 +523,18 @@ struct swf_classes { uint32_t first[5]; };
 
 __device__ __forceinline__ uint32_t swf_trace_flags(const uint8_t *T, uint32_t cls, uint32_t ld, uint32_t i, uint32_t j)
 {
-    if (cls >= 2) return cls == 2 ? T[(size_t) j * ld + i] : T[(size_t) i * ld + j];
-    const uint32_t srow = cls == 0 ? i : j, step = cls == 0 ? j : i;     // ld = g (strips of the pair)
-    const uint32_t st = srow / SWQ_R, r = srow - st * SWQ_R;
-    const uint32_t wd = r / 6, q = r - wd * 6;
-    const uint32_t k = (wd == SWQ_W - 1) ? (SWQ_R - 6 * (SWQ_W - 1)) : 6;
-    const uint32_t w = ((const uint32_t *) T)[((size_t) step * ld + st) * SWQ_W + wd];
-    const uint32_t bits = (w >> (5 * (k - 1 - q))) & 31u;
+    uint32_t bits;
+    if (cls >= 2) {
+        // k_sw_float: one byte per cell, the four rows of a dword in big-endian order
+        bits = (cls == 2 ? T[(size_t) j * ld + (i ^ 3u)] : T[(size_t) i * ld + (j ^ 3u)]) & 31u;
+    } else {
+        const uint32_t srow = cls == 0 ? i : j, step = cls == 0 ? j : i;     // ld = g (strips of the pair)
+        const uint32_t st = srow / SWQ_R, r = srow - st * SWQ_R;
+        const uint32_t wd = r / 6, q = r - wd * 6;
+        const uint32_t k = (wd == SWQ_W - 1) ? (SWQ_R - 6 * (SWQ_W - 1)) : 6;
+        const uint32_t w = ((const uint32_t *) T)[((size_t) step * ld + st) * SWQ_W + wd];
+        bits = (w >> (5 * (k - 1 - q))) & 31u;
+    }
     uint32_t t = 0;
     if (bits & 4) t = TB_SM;
     else if (bits & 8) t = TB_IM;
