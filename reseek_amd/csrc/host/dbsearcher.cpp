@@ -21,6 +21,7 @@
 #include <unordered_map>
 
 #include "reseek_host.h"
+#include "../rsk_internal.h"
 
 namespace reseek_amd {
 
@@ -584,15 +585,25 @@ static void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOff
         hipok(hipMemcpy(pt.data(), d_pt, (size_t) ns * 4, hipMemcpyDeviceToHost), "copy pairs");
         (void) hipFree(d_fwd); (void) hipFree(d_pq); (void) hipFree(d_pt); (void) hipFree(d_n);
         // deterministic order (the device list is unordered)
-        std::vector<uint32_t> ord(ns);
-        for (uint32_t k = 0; k < ns; ++k) ord[k] = k;
-        std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return pq[a] != pq[b] ? pq[a] < pq[b] : pt[a] < pt[b]; });
-        uint64_t nmkf = 0, nskip = 0;
-        for (uint32_t k : ord) {
-            const uint i = pq[k], j = pt[k];
-            if (!InShard(i, j) || Skip(i, j) || IsMKF(i, j)) continue;
-            ia.push_back(i); ib.push_back(j);
+        // counting sort by the A-side chain, then each chain's partners ascending (on the host worker threads)
+        std::vector<uint32_t> first((size_t) NA + 1, 0), partners(ns);
+        for (uint32_t k = 0; k < ns; ++k) ++first[pq[k] + 1];
+        for (uint i = 0; i < NA; ++i) first[i + 1] += first[i];
+        {
+            std::vector<uint32_t> cursor(first.begin(), first.end() - 1);
+            for (uint32_t k = 0; k < ns; ++k) partners[cursor[pq[k]]++] = pt[k];
         }
+        rsk_parallel_for(NA, 4096, [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; ++i) std::sort(partners.begin() + first[i], partners.begin() + first[i + 1]);
+        });
+        uint64_t nmkf = 0, nskip = 0;
+        ia.reserve(ns); ib.reserve(ns);
+        for (uint i = 0; i < NA; ++i)
+            for (uint32_t k = first[i]; k < first[i + 1]; ++k) {
+                const uint j = partners[k];
+                if (!InShard(i, j) || Skip(i, j) || IsMKF(i, j)) continue;
+                ia.push_back(i); ib.push_back(j);
+            }
         // MKF pairs = either chain >= m_MKFL (both with k-mers): enumerated from the list of long chains,
         // not by walking the whole pair space
         std::vector<uint32_t> longB;
