@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <thread>
 #include <unordered_map>
@@ -356,14 +357,48 @@ void DBSearcher::UploadToGpu()
 // Align a batch of (ia, ib) pairs of one chain set on the GPU and replay the hits.
 // One batch of (ia, ib) pairs: the GPU stage (AlignBatch: rsk_align_pairs) and the host stage (ReplayBatch: hit
 // records -> Reject -> TSV lines).  RunPairs runs the GPU stage of batch k + 1 while batch k is replayed.
+// Page-locked host buffers for the packed paths of a batch (hundreds of MB; the device-to-host copy into pageable
+// memory was ~25 % of the GPU stage): two or three buffers are recycled between the batches of a run.
+struct PinnedPool {
+    std::mutex lock;
+    std::vector<std::pair<char *, size_t> > idle;
+    char *Get(size_t bytes, size_t &cap)
+    {
+        {
+            std::lock_guard<std::mutex> g(lock);
+            for (size_t k = 0; k < idle.size(); ++k)
+                if (idle[k].second >= bytes) {
+                    char *p = idle[k].first;
+                    cap = idle[k].second;
+                    idle.erase(idle.begin() + k);
+                    return p;
+                }
+            if (!idle.empty()) { (void) hipHostFree(idle.back().first); idle.pop_back(); }      // too small: replace it
+        }
+        void *p = nullptr;
+        cap = bytes + bytes / 8 + 4096;
+        if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) throw std::runtime_error("hipHostMalloc failed for the path buffer");
+        return (char *) p;
+    }
+    void Put(char *p, size_t cap)
+    {
+        std::lock_guard<std::mutex> g(lock);
+        idle.emplace_back(p, cap);
+    }
+    ~PinnedPool() { for (auto &b : idle) (void) hipHostFree(b.first); }
+};
+
 struct AlignedBatch {
     std::vector<uint32_t> ia, ib;
     std::vector<rsk_aln> out;
-    std::unique_ptr<char[]> paths;
+    PinnedPool *pool = nullptr;
+    char *paths = nullptr;
+    size_t paths_cap = 0;
+    ~AlignedBatch() { if (paths) pool->Put(paths, paths_cap); }
 };
 
-static std::unique_ptr<AlignedBatch> AlignBatch(const DSSParams &P, rsk_ctx *ctx, DBSearcher &SrcA, DBSearcher &SrcB, std::vector<uint32_t> ia,
-                                                std::vector<uint32_t> ib)
+static std::unique_ptr<AlignedBatch> AlignBatch(const DSSParams &P, rsk_ctx *ctx, PinnedPool &Pool, DBSearcher &SrcA, DBSearcher &SrcB,
+                                                std::vector<uint32_t> ia, std::vector<uint32_t> ib)
 {
     std::unique_ptr<AlignedBatch> B(new AlignedBatch);
     B->ia = std::move(ia);
@@ -372,9 +407,10 @@ static std::unique_ptr<AlignedBatch> AlignBatch(const DSSParams &P, rsk_ctx *ctx
     if (n == 0) return B;
     B->out.resize(n);
     const size_t bytes = rsk_align_paths_bytes(SrcA.m_Db, SrcB.m_Db, B->ia.data(), B->ib.data(), n);
-    B->paths.reset(new char[bytes + 1]);                                     // not value-initialised: hundreds of MB per batch
+    B->pool = &Pool;
+    B->paths = Pool.Get(bytes + 1, B->paths_cap);
     check(rsk_align_pairs(ctx, SrcA.m_Db, SrcB.m_Db, B->ia.data(), B->ib.data(), n, P.m_GapOpen, P.m_GapExt, P.m_MinFwdScore, B->out.data(),
-                          B->paths.get(), bytes),
+                          B->paths, bytes),
           "rsk_align_pairs");
     return B;
 }
@@ -384,7 +420,7 @@ static void ReplayBatch(DBSearcher &S, DBSearcher &SrcA, DBSearcher &SrcB, const
     const DSSParams &P = *S.m_Params;
     const std::vector<uint32_t> &ia = B.ia, &ib = B.ib;
     const std::vector<rsk_aln> &out = B.out;
-    const char *paths = B.paths.get();
+    const char *paths = B.paths;
     const size_t n = ia.size();
     if (n == 0) return;
     S.m_SWCount += n;
@@ -416,16 +452,16 @@ static void ReplayBatch(DBSearcher &S, DBSearcher &SrcA, DBSearcher &SrcB, const
         return;
     }
     // plain DBSearcher: BaseOnAln = Reject + hit count + one TSV line.  Threads format contiguous slices of the batch
-    // into memory streams, which are then appended to the output in slice order (= the sequential row order).
-    struct slice { char *buf = nullptr; size_t size = 0; uint64_t hits = 0; std::string err; };
+    // into strings, which are then appended to the output in slice order (= the sequential row order).
+    struct slice { std::string buf; uint64_t hits = 0; std::string err; };
     std::vector<slice> sl(T);
+    PhaseTimer rt("ReplayBatch");
     std::vector<std::thread> ts;
     for (unsigned t = 0; t < T; ++t)
         ts.emplace_back([&, t]() {
             slice &me = sl[t];
             try {
-                FILE *mf = S.m_fTsv ? open_memstream(&me.buf, &me.size) : nullptr;
-                if (S.m_fTsv && !mf) throw std::runtime_error("open_memstream failed");
+                const bool want = S.m_fTsv != nullptr;
                 DSSAligner DA;
                 DA.SetParams(P);
                 DA.m_UFs = S.m_DA.m_UFs;
@@ -434,18 +470,19 @@ static void ReplayBatch(DBSearcher &S, DBSearcher &SrcA, DBSearcher &SrcB, const
                     replay(DA, p, [&](DSSAligner &D, bool Up) {
                         if (S.Reject(D, Up)) return;
                         ++me.hits;
-                        if (mf && !(S.m_Opts.noself && D.m_ChainA->m_Label == D.m_ChainB->m_Label)) D.ToTsvUnlocked(mf, Up);
+                        if (want && !(S.m_Opts.noself && D.m_ChainA->m_Label == D.m_ChainB->m_Label)) D.AppendTsv(me.buf, Up);
                     });
                 DA.UnsetQuery();
-                if (mf) fclose(mf);
             } catch (const std::exception &e) { me.err = e.what(); }
         });
     for (auto &t : ts) t.join();
+    rt.lap("format (threads)");
     for (slice &me : sl) {
-        if (me.err.empty() && me.size && fwrite(me.buf, 1, me.size, S.m_fTsv) != me.size) me.err = "short write to the hits file";
-        free(me.buf);
+        if (me.err.empty() && !me.buf.empty() && fwrite(me.buf.data(), 1, me.buf.size(), S.m_fTsv) != me.buf.size())
+            me.err = "short write to the hits file";
         S.m_HitCount += me.hits;
     }
+    rt.lap("append to the hits file");
     for (slice &me : sl)
         if (!me.err.empty()) throw std::runtime_error("hit replay: " + me.err);
 }
@@ -652,10 +689,11 @@ static void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOff
     tm.lap("filter + pair lists");
     {
         const auto batches = AlignBatches(S.m_Opts, SrcA, S, ia, ib);
+        PinnedPool Pool;                                                     // outlives every batch of the loop below
         auto launch = [&](size_t k) {
             const auto be = batches[k];
             return std::async(std::launch::async, [&, be]() {
-                return AlignBatch(P, ctx, SrcA, S, std::vector<uint32_t>(ia.begin() + be.first, ia.begin() + be.second),
+                return AlignBatch(P, ctx, Pool, SrcA, S, std::vector<uint32_t>(ia.begin() + be.first, ia.begin() + be.second),
                                   std::vector<uint32_t>(ib.begin() + be.first, ib.begin() + be.second));
             });
         };

@@ -741,14 +741,25 @@ double DSSAligner::GetTCovPct(bool Top) const
     return Pct;
 }
 
-float DSSAligner::GetPctId() const
+float DSSAligner::GetPctId() const                    // dssaligner.cpp:1325: identical residues / aligned columns
 {
     uint PosA = m_LoA, PosB = m_LoB, N = 0, n = 0;
-    const std::string &SeqA = m_ChainA->m_Seq, &SeqB = m_ChainB->m_Seq;
-    for (char c : m_Path) {
-        if (c == 'M') { if (SeqA[PosA] == SeqB[PosB]) ++n; ++PosA; ++PosB; ++N; }
-        else if (c == 'D') ++PosA;
-        else if (c == 'I') ++PosB;
+    const char *SeqA = m_ChainA->m_Seq.data(), *SeqB = m_ChainB->m_Seq.data();
+    const char *P = m_Path.data();
+    const size_t L = m_Path.size();
+    // run by run (paths are mostly long M runs): the comparison loop of a run has no data-dependent branch
+    for (size_t k = 0; k < L;) {
+        const char c = P[k];
+        size_t e = k + 1;
+        while (e < L && P[e] == c) ++e;
+        const uint r = (uint) (e - k);
+        if (c == 'M') {
+            uint eq = 0;
+            for (uint t = 0; t < r; ++t) eq += SeqA[PosA + t] == SeqB[PosB + t];
+            n += eq; PosA += r; PosB += r; N += r;
+        } else if (c == 'D') PosA += r;
+        else if (c == 'I') PosB += r;
+        k = e;
     }
     return N == 0 ? 0 : (n * 100.0f) / N;
 }
@@ -810,60 +821,77 @@ static const char *EvalueToStr(double E, char *buf, size_t n)
     return buf;
 }
 
+// WriteUserField userfields.cpp:45: one field of a hit line, appended to `out` (printf formats as the reference)
+void DSSAligner::AppendUserField(std::string &out, USERFIELD UF, bool Up)
+{
+    char tmp[64];
+    std::string s;
+    auto u = [&](uint v) {                       // "%u"
+        char b[12];
+        int k = 12;
+        do { b[--k] = (char) ('0' + v % 10); v /= 10; } while (v);
+        out.append(b + k, (size_t) (12 - k));
+    };
+    auto f = [&](const char *fmt, double v) { const int k = snprintf(tmp, sizeof(tmp), fmt, v); out.append(tmp, (size_t) k); };
+    switch (UF) {
+    case UF_query: out += GetLabel(Up); break;
+    case UF_target: out += GetLabel(!Up); break;
+    case UF_evalue: out += EvalueToStr(GetEvalue(Up), tmp, sizeof(tmp)); break;
+    case UF_pvalue: f("%.3g", GetPvalue(Up)); break;
+    case UF_ql: u(GetQL(Up)); break;
+    case UF_tl: u(GetTL(Up)); break;
+    case UF_qlo: u(GetLo(Up) + 1); break;
+    case UF_qhi: u(GetHi(Up) + 1); break;
+    case UF_tlo: u(GetLo(!Up) + 1); break;
+    case UF_thi: u(GetHi(!Up) + 1); break;
+    case UF_qcovpct: f("%.1f", GetQCovPct(Up)); break;
+    case UF_tcovpct: f("%.1f", GetTCovPct(Up)); break;
+    case UF_pctid: f("%.1f", GetPctId()); break;
+    case UF_ts: f("%.3g", GetTestStatistic(Up)); break;
+    case UF_newts: f("%.3g", GetNewTestStatistic(Up)); break;
+    case UF_raw: f("%.3g", m_AlnFwdScore); break;
+    case UF_ids: u(m_Ids); break;
+    case UF_gaps: u(m_Gaps); break;
+    case UF_cigar: PathToCIGAR(m_Path.c_str(), s, Up); out += s; break;
+    case UF_qrow: GetRow(Up, true, false, s); out += s; break;
+    case UF_trow: GetRow(Up, false, false, s); out += s; break;
+    case UF_qrowg: GetRow(Up, true, true, s); out += s; break;
+    case UF_trowg: GetRow(Up, false, true, s); out += s; break;
+    case UF_dpscore: f("%.4g", m_AlnFwdScore); break;
+    case UF_lddt: f("%.4g", m_LDDT != FLT_MAX ? m_LDDT : GetLDDT()); break;
+    case UF_aq: f("%.4f", GetAQ(Up)); break;
+    case UF_muhsp: { const int k = snprintf(tmp, sizeof(tmp), "%d", m_MKF.m_BestHSPScore); out.append(tmp, (size_t) k); break; }
+    case UF_muchain: { const int k = snprintf(tmp, sizeof(tmp), "%d", m_MKF.m_BestChainScore); out.append(tmp, (size_t) k); break; }
+    default: out += '?'; break;        // gscore / muscore belong to commands outside -search
+    }
+}
+
 void DSSAligner::WriteUserField(FILE *f, USERFIELD UF, bool Up)
 {
     if (f == nullptr) return;
-    char tmp[64];
     std::string s;
-    switch (UF) {
-    case UF_query: fputs(GetLabel(Up), f); break;
-    case UF_target: fputs(GetLabel(!Up), f); break;
-    case UF_evalue: fputs(EvalueToStr(GetEvalue(Up), tmp, sizeof(tmp)), f); break;
-    case UF_pvalue: fprintf(f, "%.3g", GetPvalue(Up)); break;
-    case UF_ql: fprintf(f, "%u", GetQL(Up)); break;
-    case UF_tl: fprintf(f, "%u", GetTL(Up)); break;
-    case UF_qlo: fprintf(f, "%u", GetLo(Up) + 1); break;
-    case UF_qhi: fprintf(f, "%u", GetHi(Up) + 1); break;
-    case UF_tlo: fprintf(f, "%u", GetLo(!Up) + 1); break;
-    case UF_thi: fprintf(f, "%u", GetHi(!Up) + 1); break;
-    case UF_qcovpct: fprintf(f, "%.1f", GetQCovPct(Up)); break;
-    case UF_tcovpct: fprintf(f, "%.1f", GetTCovPct(Up)); break;
-    case UF_pctid: fprintf(f, "%.1f", GetPctId()); break;
-    case UF_ts: fprintf(f, "%.3g", GetTestStatistic(Up)); break;
-    case UF_newts: fprintf(f, "%.3g", GetNewTestStatistic(Up)); break;
-    case UF_raw: fprintf(f, "%.3g", m_AlnFwdScore); break;
-    case UF_ids: fprintf(f, "%u", m_Ids); break;
-    case UF_gaps: fprintf(f, "%u", m_Gaps); break;
-    case UF_cigar: PathToCIGAR(m_Path.c_str(), s, Up); fputs(s.c_str(), f); break;
-    case UF_qrow: GetRow(Up, true, false, s); fputs(s.c_str(), f); break;
-    case UF_trow: GetRow(Up, false, false, s); fputs(s.c_str(), f); break;
-    case UF_qrowg: GetRow(Up, true, true, s); fputs(s.c_str(), f); break;
-    case UF_trowg: GetRow(Up, false, true, s); fputs(s.c_str(), f); break;
-    case UF_dpscore: fprintf(f, "%.4g", m_AlnFwdScore); break;
-    case UF_lddt: fprintf(f, "%.4g", m_LDDT != FLT_MAX ? m_LDDT : GetLDDT()); break;
-    case UF_aq: fprintf(f, "%.4f", GetAQ(Up)); break;
-    case UF_muhsp: fprintf(f, "%d", m_MKF.m_BestHSPScore); break;
-    case UF_muchain: fprintf(f, "%d", m_MKF.m_BestChainScore); break;
-    default: fputs("?", f); break;        // gscore / muscore belong to commands outside -search
+    AppendUserField(s, UF, Up);
+    fputs(s.c_str(), f);
+}
+
+// ToTsv dssaligner.cpp:1016: one hit line appended to `out`
+void DSSAligner::AppendTsv(std::string &out, bool Up)
+{
+    for (size_t i = 0; i < m_UFs.size(); ++i) {
+        if (i > 0) out += '\t';
+        AppendUserField(out, m_UFs[i], Up);
     }
+    out += '\n';
 }
 
 void DSSAligner::ToTsv(FILE *f, bool Up, bool NoSelf)
 {
     if (f == nullptr) return;
     if (NoSelf && m_ChainA->m_Label == m_ChainB->m_Label) return;
+    std::string line;
+    AppendTsv(line, Up);
     std::lock_guard<std::mutex> g(m_OutputLock);
-    ToTsvUnlocked(f, Up);
-}
-
-// one hit line into a stream that only this thread writes (the batch replay formats into per-thread buffers)
-void DSSAligner::ToTsvUnlocked(FILE *f, bool Up)
-{
-    for (size_t i = 0; i < m_UFs.size(); ++i) {
-        if (i > 0) fputc('\t', f);
-        WriteUserField(f, m_UFs[i], Up);
-    }
-    fputc('\n', f);
+    fwrite(line.data(), 1, line.size(), f);
 }
 
 }   // namespace reseek_amd

@@ -228,7 +228,8 @@ public:
     float XDropHSP(uint Loi_in, uint Loj_in, uint Len, uint &Loi_out, uint &Loj_out, uint &Hii_out, uint &Hij_out);
     void CalcEvalue();                                  // dssaligner.cpp:852 (host form, used by the MKF path)
     float GetLDDT() const;                              // dssaligner.cpp:1313
-    void ToTsvUnlocked(FILE *f, bool Up);                    // ToTsv without m_OutputLock / -noself test
+    void AppendTsv(std::string &out, bool Up);               // the hit line of ToTsv, appended to a caller buffer
+    void AppendUserField(std::string &out, USERFIELD UF, bool Up);
     void SetFromAln(const rsk_aln &Aln, const char *Path);   // fill the result fields from a GPU batch record
 
     void ToTsv(FILE *f, bool Up, bool NoSelf = false);  // dssaligner.cpp:1016

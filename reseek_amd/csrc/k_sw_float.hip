@@ -392,7 +392,7 @@ __global__ __launch_bounds__(64 * SWQ_NW) void k_sw_qp(swf_args a, const swq_ite
         const uint32_t step_chain = T ? a.ia[p] : a.ib[p];
         const uint32_t LB = T ? a.a_len[step_chain] : a.b_len[step_chain];
         const uint16_t *bcb = T ? (a.a_cb + (size_t) a.a_off[step_chain] * 8) : (a.b_cb + (size_t) a.b_off[step_chain] * 8);
-        uint32_t *tbp = (uint32_t *) (a.tb + a.tb_off[p]) + (sbase + st) * SWQ_W;
+        uint32_t *tbp = (uint32_t *) (a.tb + a.tb_off[p]) + (size_t) (sbase + st) * LB * SWQ_W;    // strip-major: [strip][step][W]
         long long *bnd = nseg > 1 ? (long long *) (a.bnd + a.bnd_off[p]) : nullptr;
 
         float Md[R], In[R], rb[R];
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(64 * SWQ_NW) void k_sw_qp(swf_args a, const swq_ite
                         const float ni = swq_max(md, ne);
                         if (T) { ch = ni; In[r] = dd; }
                         else { ch = dd; In[r] = ni; }
-                        if (r % 6 == 5 || r == R - 1) tbp[(size_t) j * gtot * SWQ_W + r / 6] = w;
+                        if (r % 6 == 5 || r == R - 1) tbp[(size_t) j * SWQ_W + r / 6] = w;
                     }
                 }
                 hand_m = carry;
@@ -528,11 +528,11 @@ __device__ __forceinline__ uint32_t swf_trace_flags(const uint8_t *T, uint32_t c
         // k_sw_float: one byte per cell, the four rows of a dword in big-endian order
         bits = (cls == 2 ? T[(size_t) j * ld + (i ^ 3u)] : T[(size_t) i * ld + (j ^ 3u)]) & 31u;
     } else {
-        const uint32_t srow = cls == 0 ? i : j, step = cls == 0 ? j : i;     // ld = g (strips of the pair)
+        const uint32_t srow = cls == 0 ? i : j, step = cls == 0 ? j : i;
         const uint32_t st = srow / SWQ_R, r = srow - st * SWQ_R;
         const uint32_t wd = r / 6, q = r - wd * 6;
         const uint32_t k = (wd == SWQ_W - 1) ? (SWQ_R - 6 * (SWQ_W - 1)) : 6;
-        const uint32_t w = ((const uint32_t *) T)[((size_t) step * ld + st) * SWQ_W + wd];
+        const uint32_t w = ((const uint32_t *) T)[((size_t) st * ld + step) * SWQ_W + wd];      // ld = steps of the pair
         bits = (w >> (5 * (k - 1 - q))) & 31u;
     }
     uint32_t t = 0;
@@ -559,17 +559,25 @@ __global__ void k_traceback(const uint8_t *tb, const uint64_t *tb_off, const uin
     if (score[p] == 0.0f) return;                     // sw.cpp:200-201
     const uint32_t cls = (p >= cl.first[1]) + (p >= cl.first[2]) + (p >= cl.first[3]);
     const uint32_t LA = a_len[ia[p]], LB = b_len[ib[p]];
-    const uint32_t ld = cls == 0 ? (LA + SWQ_R - 1) / SWQ_R : cls == 1 ? (LB + SWQ_R - 1) / SWQ_R
+    const uint32_t ld = cls == 0 ? LB : cls == 1 ? LA
                       : cls == 2 ? ((LA + 15) & ~15u) : ((LB + 15) & ~15u);
     const uint8_t *T = tb + tb_off[p];
     uint32_t i = besti[p] + 1, j = bestj[p] + 1;      // 1-based
     const uint32_t Besti = i, Bestj = j;
-    uint64_t w = path_end[p];
+    uint64_t w = path_end[p];                          // the path is written backwards from here
     int state = 0;                                    // 0 M, 1 D, 2 I
     uint32_t n = 0;
+    // characters are collected four at a time and stored as one aligned dword (a byte store per step made
+    // this kernel store-request bound); `acc` holds the `nacc` characters below address w - nacc
+    uint32_t acc = 0, nacc = 0;
     for (;;) {
-        paths[--w] = state == 0 ? 'M' : (state == 1 ? 'D' : 'I');
+        const uint32_t ch = state == 0 ? 'M' : (state == 1 ? 'D' : 'I');
         ++n;
+        if (nacc == 0 && (w & 3) != 0) paths[--w] = (char) ch;            // head: up to 3 bytes down to a dword boundary
+        else {
+            acc = (acc << 8) | ch;
+            if (++nacc == 4) { w -= 4; *(uint32_t *) (paths + w) = acc; nacc = 0; }
+        }
         if (state == 0) {
             const uint32_t t = swf_trace_flags(T, cls, ld, i - 1, j - 1);
             if (t & TB_DM) state = 1;
@@ -586,6 +594,7 @@ __global__ void k_traceback(const uint8_t *tb, const uint64_t *tb_off, const uin
             --j;
         }
     }
+    for (uint32_t k = nacc; k > 0; --k) paths[--w] = (char) ((acc >> (8 * (k - 1))) & 0xFFu);      // tail: oldest character first (highest address)
     path_start[p] = w;
     path_len[p] = n;
     const uint32_t leni = Besti - i + 1, lenj = Bestj - j + 1;
@@ -594,8 +603,8 @@ __global__ void k_traceback(const uint8_t *tb, const uint64_t *tb_off, const uin
 }
 
 // GetLDDT_mu_fast lddt.cpp:63-124 over the M columns of a path (GetPosABs dssaligner.cpp:1282).
-// One wave per pair.  The reference's symmetric accumulation over column pairs c < c' equals, per
-// column, the sum over all other columns (integer counts), so each lane owns whole columns.
+// One wave per pair.  The reference accumulates, over the column pairs c < c' within R0, (4, thresholds met)
+// into both columns: integer counts, so any order of the additions gives the same per-column fractions.
 #define LDDT_LDS_COLS 256
 __global__ __launch_bounds__(256) void k_lddt(const char *paths, const uint64_t *path_start, const uint32_t *path_len,
                                               const uint32_t *lo_a, const uint32_t *lo_b, const uint32_t *ia, const uint32_t *ib,
@@ -606,7 +615,11 @@ __global__ __launch_bounds__(256) void k_lddt(const char *paths, const uint64_t 
                                               float *frac_scratch, float *lddt_out, uint32_t *counts_out,
                                               const float *score, float min_fwd_score)
 {
-    __shared__ float sc[4][7][LDDT_LDS_COLS];      // per wave: x,y,z of A and of B at the aligned columns, per-column fraction
+    // per wave: coordinates of A and B at the aligned columns ({ax, ay, az, bx} / {by, bz}) and per-column counters
+    // (considered | preserved << 16; at most 4 * 255 each)
+    __shared__ float4 sc4[4][LDDT_LDS_COLS];
+    __shared__ float2 sc2[4][LDDT_LDS_COLS];
+    __shared__ uint32_t scnt[4][LDDT_LDS_COLS];
     const uint32_t p = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (p >= npairs) return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -644,30 +657,86 @@ __global__ __launch_bounds__(256) void k_lddt(const char *paths, const uint64_t 
     const float R0sq = 15.0f * 15.0f;
     const bool in_lds = ncols <= LDDT_LDS_COLS;
     if (in_lds) {
+        // Every unordered column pair once: the ncols (ncols - 1) / 2 pairs, row-major (ci < cj), are cut into 64 equal
+        // runs, one per lane; a pair within R0 adds (4, thresholds met) to the counters of BOTH columns (integers, so
+        // the order of the additions is immaterial).  All lanes busy whatever ncols is, half the distance work.
         for (uint32_t c = lane; c < ncols; c += 64) {
             const uint32_t a1 = posA[c], b1 = posB[c];
-            sc[wv][0][c] = AX[a1]; sc[wv][1][c] = AY[a1]; sc[wv][2][c] = AZ[a1];
-            sc[wv][3][c] = BX[b1]; sc[wv][4][c] = BY[b1]; sc[wv][5][c] = BZ[b1];
+            sc4[wv][c] = make_float4(AX[a1], AY[a1], AZ[a1], BX[b1]);
+            sc2[wv][c] = make_float2(BY[b1], BZ[b1]);
+            scnt[wv][c] = 0;
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    }
+        const uint32_t C = ncols, npair = C * (C - 1) / 2, per = (npair + 63) / 64;
+        const uint32_t t0 = (uint32_t) lane * per, t1 = min(npair, t0 + per);
+        if (t0 < t1) {
+            // row of the first pair: largest ci with ci (2C - ci - 1) / 2 <= t0
+            const float twoc = (float) (2 * C - 1);
+            uint32_t ci = (uint32_t) ((twoc - sqrtf(fmaxf(twoc * twoc - 8.0f * (float) t0, 0.0f))) * 0.5f);
+            ci = min(ci, C - 2);
+            while (ci > 0 && ci * (2 * C - ci - 1) / 2 > t0) --ci;
+            while ((ci + 1) * (2 * C - ci - 2) / 2 <= t0) ++ci;
+            uint32_t cj = ci + 1 + (t0 - ci * (2 * C - ci - 1) / 2);
+            float4 p4 = sc4[wv][ci];
+            float2 p2 = sc2[wv][ci];
+            uint32_t own = 0;
+            for (uint32_t t = t0; t < t1; ++t) {
+                const float4 q4 = sc4[wv][cj];
+                const float2 q2 = sc2[wv][cj];
+                // (x1-x2)^2 == (x2-x1)^2 exactly, so the reference's (lower column) - (higher column) order is immaterial
+                const float dx = p4.x - q4.x, dy = p4.y - q4.y, dz = p4.z - q4.z;
+                const float ex = p4.w - q4.w, ey = p2.x - q2.x, ez = p2.y - q2.y;
+                float d1s = dx * dx; d1s += dy * dy; d1s += dz * dz;       // pdbchain.cpp:320-335: dx*dx + dy*dy + dz*dz
+                float d2s = ex * ex; d2s += ey * ey; d2s += ez * ez;
+                if (!(d1s > R0sq && d2s > R0sq)) {
+                    const float d1 = sqrtf(d1s), d2 = sqrtf(d2s);
+                    const float diff = fabsf(d1 - d2);
+                    const uint32_t inc = 4u | (((diff <= 0.5f) + (diff <= 1.0f) + (diff <= 2.0f) + (diff <= 4.0f)) << 16);
+                    own += inc;
+                    atomicAdd(&scnt[wv][cj], inc);
+                }
+                if (++cj == C) {
+                    if (own) atomicAdd(&scnt[wv][ci], own);
+                    own = 0;
+                    ++ci;
+                    cj = ci + 1;
+                    if (ci < C - 1) { p4 = sc4[wv][ci]; p2 = sc2[wv][ci]; }
+                }
+            }
+            if (own) atomicAdd(&scnt[wv][ci], own);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        // per-column fractions in registers (column c in lane c % 64, slot c / 64), then the reference's sequential
+        // sum in column order (lddt.cpp:111-121): one v_readlane + v_add per column instead of a dependent LDS read
+        float fr[LDDT_LDS_COLS / 64];
+#pragma unroll
+        for (int k = 0; k < LDDT_LDS_COLS / 64; ++k) {
+            const uint32_t c = (uint32_t) k * 64 + lane;
+            const uint32_t v = c < ncols ? scnt[wv][c] : 0u, cons = v & 0xFFFFu, pres = v >> 16;
+            fr[k] = cons > 0 ? (float) pres / (float) cons : 0.0f;
+        }
+        float total = 0.0f;
+#pragma unroll
+        for (int k = 0; k < LDDT_LDS_COLS / 64; ++k) {
+            const uint32_t n = ncols > (uint32_t) k * 64 ? min(64u, ncols - (uint32_t) k * 64) : 0u;
+            for (uint32_t c = 0; c < n; ++c)
+                total += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fr[k]), (int) c));
+        }
+        if (lane == 0) lddt_out[p] = total / (float) ncols;
+        return;
+    } else
     for (uint32_t ci = lane; ci < ncols; ci += 64) {
+        // alignments longer than the LDS staging: a lane owns whole columns, coordinates from HBM
         const uint32_t a1 = posA[ci], b1 = posB[ci];
         const float x1 = AX[a1], y1 = AY[a1], z1 = AZ[a1], u1 = BX[b1], v1 = BY[b1], w1 = BZ[b1];
         uint32_t cons = 0, pres = 0;
         for (uint32_t cj = 0; cj < ncols; ++cj) {
             if (cj == ci) continue;
-            float x2, y2, z2, u2, v2, w2;
-            if (in_lds) {
-                x2 = sc[wv][0][cj]; y2 = sc[wv][1][cj]; z2 = sc[wv][2][cj]; u2 = sc[wv][3][cj]; v2 = sc[wv][4][cj]; w2 = sc[wv][5][cj];
-            } else {
-                const uint32_t a2 = posA[cj], b2 = posB[cj];
-                x2 = AX[a2]; y2 = AY[a2]; z2 = AZ[a2]; u2 = BX[b2]; v2 = BY[b2]; w2 = BZ[b2];
-            }
-            // (x1-x2)^2 == (x2-x1)^2 exactly, so the reference's (lower column) - (higher column) order is immaterial
+            const uint32_t a2 = posA[cj], b2 = posB[cj];
+            const float x2 = AX[a2], y2 = AY[a2], z2 = AZ[a2], u2 = BX[b2], v2 = BY[b2], w2 = BZ[b2];
             const float dx = x1 - x2, dy = y1 - y2, dz = z1 - z2;
             const float ex = u1 - u2, ey = v1 - v2, ez = w1 - w2;
-            float d1s = dx * dx; d1s += dy * dy; d1s += dz * dz;       // pdbchain.cpp:320-335: dx*dx + dy*dy + dz*dz
+            float d1s = dx * dx; d1s += dy * dy; d1s += dz * dz;
             float d2s = ex * ex; d2s += ey * ey; d2s += ez * ez;
             if (d1s > R0sq && d2s > R0sq) continue;
             const float d1 = sqrtf(d1s), d2 = sqrtf(d2s);
@@ -675,14 +744,12 @@ __global__ __launch_bounds__(256) void k_lddt(const char *paths, const uint64_t 
             pres += (diff <= 0.5f) + (diff <= 1.0f) + (diff <= 2.0f) + (diff <= 4.0f);
             cons += 4;
         }
-        const float fr = cons > 0 ? (float) pres / (float) cons : 0.0f;
-        if (in_lds) sc[wv][6][ci] = fr;
-        else frac[ci] = fr;
+        frac[ci] = cons > 0 ? (float) pres / (float) cons : 0.0f;
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     if (lane == 0) {
         float total = 0.0f;
-        for (uint32_t c = 0; c < ncols; ++c) total += in_lds ? sc[wv][6][c] : frac[c];      // sequential, column order (lddt.cpp:111-121)
+        for (uint32_t c = 0; c < ncols; ++c) total += frac[c];      // sequential, column order (lddt.cpp:111-121)
         lddt_out[p] = total / (float) ncols;
     }
 }
