@@ -195,6 +195,17 @@ int rsk_merge_fwd_bwd(uint32_t LA, uint32_t LB, uint32_t fwd_lo_a, uint32_t fwd_
                       uint32_t bwd_hi_b, const char *bwd_path, uint32_t *lo_a, uint32_t *lo_b, uint32_t *hi_a, uint32_t *hi_b,
                       char *path, size_t path_cap, uint32_t *path_len);
 
+/* P9 (second half, device): the two gapped X-drop extensions of XDropHSP (xdrophsp.cpp:97-108) for a list of seeded
+ * pairs -- XDropFwd from (lo_a, lo_b) to the chain ends and XDropBwd from (lo_a - 1, lo_b - 1) to the chain starts,
+ * with DSSAligner::SubstScore (xdrophsp.cpp:8) as the substitution function; X = m_MKF_X2, gap_open / gap_ext =
+ * m_GapOpen / m_GapExt (negative).  1 <= lo < L on both chains.  One GPU thread per extension.  Host arrays:
+ * score_fwd / score_bwd [n]; the path of extension k is paths[*_off[k] .. + *_len[k]) (not NUL-terminated);
+ * paths_bytes >= sum(LA + LB + 4). */
+int rsk_xdrop_pairs(rsk_ctx *ctx, const rsk_db *a, const rsk_db *b, const uint32_t *ia, const uint32_t *ib,
+                    const uint32_t *lo_a, const uint32_t *lo_b, size_t n, float X, float gap_open, float gap_ext,
+                    float *score_fwd, float *score_bwd, char *paths, size_t paths_bytes, uint64_t *fwd_off,
+                    uint32_t *fwd_len, uint64_t *bwd_off, uint32_t *bwd_len);
+
 /* ---- P10/P11/P12: Mu k-mer prefilter ----------------------------------------------------------------
  * Batch form of MuDex::FromSeqDB (mudex.cpp:386; index of the QUERY set, built once and cached in q)
  * + PrefilterMu::Search over every target (prefiltermu.cpp:382): spaced 5-of-7 k-mers, self-score

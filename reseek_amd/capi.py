@@ -64,6 +64,9 @@ SIGNATURES["rsk_bca_info"] = (C.c_int, [C.c_char_p, C.POINTER(C.c_uint64), C.POI
 SIGNATURES["rsk_bca_read_chain"] = (C.c_int, [C.c_char_p, C.c_uint64, C.c_char_p, C.c_size_t, C.c_char_p, f32p, f32p, f32p, C.c_uint32, u32p])
 SIGNATURES["rsk_mkf_seed_pairs"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, u32p, u32p, C.c_size_t, C.c_int, C.c_int, C.c_uint32,
                                               C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_size_t), u32p, u32p, C.POINTER(C.c_int32)])
+SIGNATURES["rsk_xdrop_pairs"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, u32p, u32p, u32p, u32p, C.c_size_t, C.c_float, C.c_float,
+                                           C.c_float, f32p, f32p, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64), u32p,
+                                           C.POINTER(C.c_uint64), u32p])
 SIGNATURES["rsk_xdrop_fwd"] = (C.c_int, [f32p, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32,
                                          f32p, C.c_char_p, C.c_size_t, u32p])
 SIGNATURES["rsk_xdrop_bwd"] = SIGNATURES["rsk_xdrop_fwd"]
@@ -229,6 +232,26 @@ class Ctx:
         return n.value, list(st)
 
     # ---- P10-P12 k-mer prefilter ---------------------------------------------------------------------
+    def xdrop_pairs(self, a, b, ia, ib, lo_a, lo_b, X, gap_open, gap_ext):
+        """rsk_xdrop_pairs -> list of (score_fwd, fwd_path, score_bwd, bwd_path)"""
+        ia = np.ascontiguousarray(ia, np.uint32)
+        ib = np.ascontiguousarray(ib, np.uint32)
+        lo_a = np.ascontiguousarray(lo_a, np.uint32)
+        lo_b = np.ascontiguousarray(lo_b, np.uint32)
+        n = len(ia)
+        la, lb = np.asarray(a.lengths), np.asarray(b.lengths)
+        nbytes = int((la[ia].astype(np.int64) + lb[ib] + 4).sum()) + 16
+        buf = C.create_string_buffer(nbytes)
+        sf, sb = np.zeros(n, np.float32), np.zeros(n, np.float32)
+        fo, bo = np.zeros(n, np.uint64), np.zeros(n, np.uint64)
+        fl, bl = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        u64p = C.POINTER(C.c_uint64)
+        _check(lib().rsk_xdrop_pairs(self.h, a.h, b.h, _p(ia, u32p), _p(ib, u32p), _p(lo_a, u32p), _p(lo_b, u32p), n, X, gap_open, gap_ext,
+                                     _p(sf, f32p), _p(sb, f32p), buf, nbytes, _p(fo, u64p), _p(fl, u32p), _p(bo, u64p), _p(bl, u32p)))
+        raw = buf.raw
+        return [(float(sf[k]), raw[int(fo[k]):int(fo[k]) + int(fl[k])].decode(), float(sb[k]), raw[int(bo[k]):int(bo[k]) + int(bl[k])].decode())
+                for k in range(n)]
+
     def mkf_seed_pairs(self, q, t, iq, it, x1=8, min_hsp_score=50, cap=16, max_records=None):
         """-> (found uint8[n], {pair index: (nkept, kept int32 [min(nkept, cap), 4])})"""
         iq = np.ascontiguousarray(iq, np.uint32)

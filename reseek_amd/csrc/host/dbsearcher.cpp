@@ -25,6 +25,7 @@
 #include "../rsk_internal.h"
 
 namespace reseek_amd {
+extern std::atomic<uint64_t> g_MKFNsMega, g_MKFNsXDrop, g_MKFNsStats;      // host/dssaligner.cpp (RSK_TRACE)
 
 static void check(int rc, const char *what)
 {
@@ -569,8 +570,9 @@ void RunMKFPairs(rsk_ctx *Ctx, const DSSParams &P, const std::string &Columns, D
         for (auto &t : ts) t.join();
     }
     if (getenv("RSK_TRACE"))
-        fprintf(stderr, "[RunMKFPairs] host stage %.3f ms on %u threads\n",
-                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count(), T);
+        fprintf(stderr, "[RunMKFPairs] host stage %.3f ms on %u threads (thread-ms so far: mega score %.1f, gapped X-drop %.1f, statistics %.1f)\n",
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count(), T, g_MKFNsMega.load() / 1e6,
+                g_MKFNsXDrop.load() / 1e6, g_MKFNsStats.load() / 1e6);
 }
 
 // Self with SelfOffset >= 0 is one SHARD of a self search: B = the chains [SelfOffset, SelfOffset + NB) of

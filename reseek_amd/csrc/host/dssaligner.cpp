@@ -8,6 +8,8 @@
 //      xdropfwd.cpp:71, xdropbwd.cpp:28, mergefwdback.cpp:6)
 // Compiled with -ffp-contract=off: float results must match the reference's strict-IEEE build.
 #include <algorithm>
+#include <chrono>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -698,9 +700,14 @@ void DSSAligner::AlignMKF_FromSeeds(const int32_t *Kept4, uint Count)
     PostAlignMKF();
 }
 
+// RSK_TRACE: nanoseconds spent in the parts of the host MKF stage, summed over threads (reported by RunMKFPairs)
+std::atomic<uint64_t> g_MKFNsMega{0}, g_MKFNsXDrop{0}, g_MKFNsStats{0};
+static inline uint64_t NowNs() { return (uint64_t) std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 void DSSAligner::PostAlignMKF()
 {
     if (m_MKF.m_BestChainScore <= 0) return;
+    const uint64_t t0 = NowNs();
     float MegaHSPTotal = 0, BestMegaScore = 0;
     uint BestMegaIdx = 0;
     const uint M = (uint) m_MKF.m_ChainHSPLois.size();
@@ -709,9 +716,13 @@ void DSSAligner::PostAlignMKF()
         if (MegaScore > BestMegaScore) { BestMegaScore = MegaScore; BestMegaIdx = Idx; }
         MegaHSPTotal += MegaScore;
     }
+    const uint64_t t1 = NowNs();
+    g_MKFNsMega += t1 - t0;
     if (MegaHSPTotal < m_Params->m_MKF_MinMegaHSPScore) return;
     m_XDropScore = XDropHSP((uint) m_MKF.m_ChainHSPLois[BestMegaIdx], (uint) m_MKF.m_ChainHSPLojs[BestMegaIdx],
                             (uint) m_MKF.m_ChainHSPLens[BestMegaIdx], m_LoA, m_LoB, m_HiA, m_HiB);
+    const uint64_t t2 = NowNs();
+    g_MKFNsXDrop += t2 - t1;
     m_AlnFwdScore = m_XDropScore;
     m_Path = m_XDropPath;
     uint nM, nD, nI;
@@ -719,6 +730,7 @@ void DSSAligner::PostAlignMKF()
     m_HiA = m_LoA + nM + nD - 1;
     m_HiB = m_LoB + nM + nI - 1;
     CalcEvalue();
+    g_MKFNsStats += NowNs() - t2;
 }
 
 // ---------------------------------------------------------------------------------------------

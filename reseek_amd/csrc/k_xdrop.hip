@@ -1,0 +1,351 @@
+// k_xdrop.hip -- P9, second half: the banded ("X-drop") float DP of the long-chain MKF path on the device.
+//
+//   XDropFwd  xdropfwd.cpp:71-390 (+ its traceback :10-67)
+//   XDropBwd  xdropbwd.cpp:28-52  (= XDropFwd on the reversed prefixes, path reversed)
+//   SubstScore xdrophsp.cpp:8     (sum of the 8 weighted feature tables, feature order 0 -> 7)
+// as XDropHSP (xdrophsp.cpp:42) calls them for one seeded pair: forward from (LoA, LoB) to the chain ends,
+// backward from (LoA - 1, LoB - 1) to the chain starts.
+//
+// The DP is sequential along a row (the insert state I0 and the running row bounds depend on the cell to
+// the left) and its row range depends on the previous row, so one extension has no regular parallelism.
+// There are as many independent extensions as seeded pairs x 2 though: ONE THREAD PER EXTENSION, rows and
+// trace cells in HBM scratch (the trace of a pair can reach LA x LB bytes; 288 GB of HBM take tens of
+// thousands of them at once).  Every float operation is the reference's, in its order (-ffp-contract=off),
+// so scores and paths are bit-identical; tests/test_gpu_xdrop.py compares with the host mirror of the same
+// functions, which the reference's own -test_xdrop vectors pin (tests/test_xdrop_kat.py).
+//
+// Algorithmic bytes per extension: 16 B of table offsets per row + 16 B per cell (column offsets), 16 B of
+// row state and 1 B of trace per cell.  Latency-bound scalar-style code by nature; what makes it fast is
+// the number of extensions in flight, not the kernel (roofline: none that is meaningful).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "rsk_internal.h"
+#include "rsk_tables_data.h"
+
+#define XD_MINUS_INF (-9e9f)         // xdpmem.h:6
+#define XD_DM 0x01                   // tracebit.h:4-8
+#define XD_IM 0x02
+#define XD_MD 0x04
+#define XD_MI 0x08
+#define XD_TABLE_FLOATS (400 + 7 * 256)
+
+struct xd_tables { float t[XD_TABLE_FLOATS]; };
+static __device__ __constant__ xd_tables c_xd_tables;
+static const int h_xd_toff[8] = { 0, 400, 656, 912, 1168, 1424, 1680, 1936 };
+
+static int xd_upload_tables(rsk_ctx *ctx)
+{
+    static bool done[64] = { false };
+    if (ctx->device < 64 && done[ctx->device]) return RSK_OK;
+    xd_tables h;
+    for (int i = 0; i < XD_TABLE_FLOATS; ++i) h.t[i] = 0.0f;
+    for (int f = 0; f < RSK_NFEATURES; ++f) {
+        const int as = (int) rsk_feature_alpha[f];
+        for (int a = 0; a < as; ++a)
+            for (int b = 0; b < as; ++b) h.t[h_xd_toff[f] + a * as + b] = rsk_feature_mx[f][a * RSK_FEATURE_DIM + b];
+    }
+    RSK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_xd_tables), &h, sizeof(h)));
+    if (ctx->device < 64) done[ctx->device] = true;
+    return RSK_OK;
+}
+
+struct xd_args {
+    const uint16_t *a_ra;            // A: [npadA][8] table row offsets in bytes (letter * alphabet * 4)
+    const uint16_t *b_cb;            // B: [npadB][8] column offsets in bytes (letter * 4)
+    const uint32_t *a_off, *b_off, *a_len, *b_len;
+    const uint32_t *ia, *ib, *lo_a, *lo_b;     // requests
+    uint32_t nreq;
+    float X, open, ext;
+    float *rows;                     // per extension: Mrow (LB' + 9 floats) then Drow (LB' + 9), at rows + row_off[e]
+    const uint64_t *row_off;
+    uint8_t *tb;                     // per extension: (LA' + 9) x (LB' + 9) trace bytes (zeroed), at tb + tb_off[e]
+    const uint64_t *tb_off;
+    float *score;                    // [2 * nreq]: fwd, bwd
+    char *paths;                     // per extension a slot of LA' + LB' + 2 chars at paths + path_off[e]
+    const uint64_t *path_off;
+    uint32_t *path_start;            // offset of the first path character inside the slot
+    uint32_t *path_len;
+};
+
+// One extension = XDropFwd(Mem, X, Open, Ext, Sub, LoA, aLA, LoB, aLB): thread e = 2 * request + direction.
+// direction 0 (forward):  local (i, j) >= 1 is the residue pair (LoA + i - 1, LoB + j - 1), extents LA - LoA, LB - LoB;
+// direction 1 (backward): XDropBwd = the same DP on the reversed prefixes of lengths RLA = LoA, RLB = LoB
+//                         (HiA = LoA - 1): local (i, j) is the residue pair (RLA - i, RLB - j); its path is reversed.
+__global__ __launch_bounds__(256) void k_xdrop(xd_args a)
+{
+    __shared__ float tab[XD_TABLE_FLOATS];
+    for (int i = threadIdx.x; i < XD_TABLE_FLOATS; i += blockDim.x) tab[i] = c_xd_tables.t[i];
+    __syncthreads();
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 2 * a.nreq) return;
+    const uint32_t req = e >> 1, dir = e & 1;
+    const uint32_t A = a.ia[req], B = a.ib[req];
+    const uint32_t LoA = a.lo_a[req], LoB = a.lo_b[req];
+    const uint32_t LA = dir ? LoA : a.a_len[A] - LoA, LB = dir ? LoB : a.b_len[B] - LoB;      // extents of this extension
+    const uint16_t *RA = a.a_ra + (size_t) a.a_off[A] * 8, *CB = a.b_cb + (size_t) a.b_off[B] * 8;
+    const char *tabb = (const char *) tab;
+    const uint32_t toffb[8] = { 0 * 4, 400 * 4, 656 * 4, 912 * 4, 1168 * 4, 1424 * 4, 1680 * 4, 1936 * 4 };
+    char *slot = a.paths + a.path_off[e];
+    const uint32_t cap = LA + LB + 2;
+    a.path_start[e] = 0;
+    a.path_len[e] = 0;
+    // residue of local row i / column j
+    auto posA = [&](uint32_t i) { return dir ? LoA - i : LoA + i - 1; };
+    auto posB = [&](uint32_t j) { return dir ? LoB - j : LoB + j - 1; };
+    uint32_t rowo[8];                 // table row offsets of the current row (bytes, table base included)
+    auto set_row = [&](uint32_t i) {
+        const uint4 w = *(const uint4 *) (RA + (size_t) posA(i) * 8);
+        const uint32_t ww[4] = { w.x, w.y, w.z, w.w };
+#pragma unroll
+        for (int f = 0; f < 8; ++f) rowo[f] = toffb[f] + ((f & 1) ? (ww[f >> 1] >> 16) : (ww[f >> 1] & 0xFFFFu));
+    };
+    auto sub = [&](uint32_t j) {      // SubstScore: Total = 0; Total += feature f, f = 0..7
+        const uint4 w = *(const uint4 *) (CB + (size_t) posB(j) * 8);
+        const uint32_t ww[4] = { w.x, w.y, w.z, w.w };
+        float Total = 0.0f;
+#pragma unroll
+        for (int f = 0; f < 8; ++f) Total += *(const float *) (tabb + rowo[f] + ((f & 1) ? (ww[f >> 1] >> 16) : (ww[f >> 1] & 0xFFFFu)));
+        return Total;
+    };
+    if (LA == 1 || LB == 1) {         // xdropfwd.cpp:84-92
+        set_row(1);
+        const float Score = sub(1);
+        if (Score > 0) { slot[0] = 'M'; a.path_len[e] = 1; }
+        a.score[e] = Score;
+        return;
+    }
+    const float Open = a.open, Ext = a.ext, X = a.X;
+    const float AbsOpen = -Open, AbsExt = -Ext;
+    float *Mrow = a.rows + a.row_off[e] + 1;          // Mrow[-1] is valid
+    float *Drow = Mrow + (LB + 9);
+    uint8_t *TB = a.tb + a.tb_off[e];
+    const uint32_t Cols = LB + 1 + 8;                  // XDPMem::Alloc(LA + 1, LB + 1)
+    Mrow[-1] = XD_MINUS_INF;
+    Drow[0] = XD_MINUS_INF;
+    Drow[1] = XD_MINUS_INF;
+    float BestScore = 0;
+    uint32_t Besti = 0, Bestj = 0;
+    uint32_t prev_jlo = 0, prev_jhi = 0, jlo = 1, jhi = 1;
+    float M0 = BestScore;
+    for (uint32_t i = 1; i <= LA; ++i) {
+        if (jlo == prev_jlo) { Mrow[jlo - 1] = XD_MINUS_INF; Drow[jlo] = XD_MINUS_INF; }
+        uint32_t endj = min(prev_jhi + 1, LB);
+        for (uint32_t j = endj + 1; j <= min(jhi + 1, LB); ++j) { Mrow[j - 1] = XD_MINUS_INF; Drow[j] = XD_MINUS_INF; }
+        uint32_t next_jlo = 0xFFFFFFFFu, next_jhi = 0xFFFFFFFFu;
+        float I0 = XD_MINUS_INF;
+        set_row(i);
+        for (uint32_t j = jlo; j <= jhi; ++j) {
+            uint8_t TraceBits = 0;
+            const float SavedM0 = M0;
+            // MATCH
+            float xM = M0;
+            const float dj = Drow[j];
+            if (dj > xM) { xM = dj; TraceBits = XD_DM; }
+            if (I0 > xM) { xM = I0; TraceBits = XD_IM; }
+            M0 = Mrow[j];
+            float s = sub(j);
+            s += xM;
+            Mrow[j] = s;
+            const float h = s - BestScore + X;
+            if (h > 0) { next_jlo = min(next_jlo, j + 1); next_jhi = j + 1; }
+            if (h > AbsOpen) next_jlo = min(next_jlo, j);
+            if (h > AbsExt && j == jhi && jhi + 1 < LB) {        // match-insert may extend the current row
+                ++jhi;
+                const uint32_t new_endj = max(min(jhi + 1, LB), endj);
+                for (uint32_t j2 = endj + 1; j2 <= new_endj; ++j2) {
+                    if (j2 - 1 > j) Mrow[j2 - 1] = XD_MINUS_INF;
+                    Drow[j2] = XD_MINUS_INF;
+                }
+                endj = new_endj;
+            }
+            if (s >= BestScore) { BestScore = s; Besti = i; Bestj = j; }
+            // DELETE
+            if (j != jlo) {
+                const float md = SavedM0 + Open;
+                float d = Drow[j];
+                d += Ext;
+                if (md >= d) { d = md; TraceBits |= XD_MD; }
+                Drow[j] = d;
+                const float hd = d - BestScore + X;
+                if (hd > 0) { next_jlo = min(next_jlo, j - 1); next_jhi = max(next_jhi, j - 1); }
+            }
+            // INSERT
+            {
+                const float mi = SavedM0 + Open;
+                I0 += Ext;
+                if (mi >= I0) { I0 = mi; TraceBits |= XD_MI; }
+                const float hi = I0 - BestScore + X;
+                if (hi > 0) { next_jlo = min(next_jlo, j + 1); next_jhi = max(next_jhi, j + 1); }
+                if (hi > AbsExt && j == jhi && jhi + 1 < LB) {
+                    ++jhi;
+                    const uint32_t new_endj = max(min(jhi + 1, LB), endj);
+                    for (uint32_t j2 = endj + 1; j2 <= new_endj; ++j2) { Mrow[j2 - 1] = XD_MINUS_INF; Drow[j2] = XD_MINUS_INF; }
+                    endj = new_endj;
+                }
+            }
+            TB[(size_t) i * Cols + j] = TraceBits;
+        }
+        if (jhi < LB) {                                             // end of Drow[]
+            const uint32_t jhi1 = jhi + 1;
+            uint8_t t = 0;
+            const float md = M0 + Open;
+            float d = Drow[jhi1];
+            d += Ext;
+            if (md >= d) { d = md; t = XD_MD; }
+            Drow[jhi1] = d;
+            TB[(size_t) i * Cols + jhi1] = t;
+        }
+        if (next_jlo == 0xFFFFFFFFu) break;
+        prev_jlo = jlo; prev_jhi = jhi;
+        jlo = next_jlo; jhi = next_jhi;
+        if (jlo > LB) jlo = LB;
+        if (jhi > LB) jhi = LB;
+        if (jlo == prev_jlo) { M0 = XD_MINUS_INF; Drow[jlo] = XD_MINUS_INF; }
+        else M0 = Mrow[jlo - 1];
+    }
+    if (BestScore <= 0.0f) { a.score[e] = 0.0f; return; }
+    // traceback (xdropfwd.cpp:10-67): stops when the first row or column is reached.  XDropFwd returns the
+    // walk reversed, XDropBwd reverses it once more: the forward extension writes from the end of its slot
+    // downwards (so that the slot reads in path order), the backward extension writes the walk as it goes.
+    uint32_t i = Besti, j = Bestj, n = 0;
+    char State = 'M';
+    for (;;) {
+        if (dir) slot[n] = State;
+        else slot[cap - 1 - n] = State;
+        ++n;
+        if (i == 1 || j == 1) break;
+        char Next;
+        if (State == 'M') {
+            const uint8_t c = TB[(size_t) i * Cols + j];
+            Next = (c & XD_DM) ? 'D' : (c & XD_IM) ? 'I' : 'M';
+            --i; --j;
+        } else if (State == 'D') {
+            Next = (TB[(size_t) i * Cols + j + 1] & XD_MD) ? 'M' : 'D';
+            --i;
+        } else {
+            Next = (TB[(size_t) (i + 1) * Cols + j] & XD_MI) ? 'M' : 'I';
+            --j;
+        }
+        State = Next;
+    }
+    a.path_start[e] = dir ? 0 : cap - n;
+    a.path_len[e] = n;
+    a.score[e] = BestScore;
+}
+
+// XDropHSP's two extensions (xdrophsp.cpp:97-108) for a list of seeded pairs.  Host arrays in, host arrays out.
+extern "C" int rsk_xdrop_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *dbb, const uint32_t *ia, const uint32_t *ib,
+                               const uint32_t *lo_a, const uint32_t *lo_b, size_t n, float X, float gap_open, float gap_ext,
+                               float *score_fwd, float *score_bwd, char *paths, size_t paths_bytes, uint64_t *fwd_off,
+                               uint32_t *fwd_len, uint64_t *bwd_off, uint32_t *bwd_len)
+{
+    if (!ctx || !dba || !dbb || (n && (!ia || !ib || !lo_a || !lo_b || !score_fwd || !score_bwd || !paths || !fwd_off || !fwd_len || !bwd_off || !bwd_len))) {
+        rsk_set_error("rsk_xdrop_pairs: NULL argument");
+        return RSK_E_INVALID;
+    }
+    if (!dba->d_prof_ra || !dbb->d_prof_cb) { rsk_set_error("rsk_xdrop_pairs: chain set has no profiles"); return RSK_E_INVALID; }
+    if (gap_open > 0 || gap_ext > 0) { rsk_set_error("rsk_xdrop_pairs: gap penalties must be <= 0"); return RSK_E_INVALID; }
+    if (n == 0) return RSK_OK;
+    if (n > 0x3FFFFFFFull) { rsk_set_error("rsk_xdrop_pairs: too many pairs in one call"); return RSK_E_RANGE; }
+    RSK_HIP(hipSetDevice(ctx->device));
+    int rc = xd_upload_tables(ctx);
+    if (rc != RSK_OK) return rc;
+    // per-extension slots; the forward extension needs lo < L on both chains, the backward one lo >= 1 (xdropbwd.cpp:37-38)
+    size_t need = 0;
+    for (size_t r = 0; r < n; ++r) {
+        if (ia[r] >= dba->n || ib[r] >= dbb->n) { rsk_set_error("rsk_xdrop_pairs: pair %zu out of range", r); return RSK_E_INVALID; }
+        const uint32_t LA = dba->len[ia[r]], LB = dbb->len[ib[r]];
+        if (lo_a[r] == 0 || lo_b[r] == 0 || lo_a[r] >= LA || lo_b[r] >= LB) {
+            rsk_set_error("rsk_xdrop_pairs: start (%u, %u) of pair %zu outside 1..L-1", lo_a[r], lo_b[r], r);
+            return RSK_E_INVALID;
+        }
+        need += (size_t) LA + LB + 4;
+    }
+    if (paths_bytes < need) { rsk_set_error("rsk_xdrop_pairs: paths buffer too small (%zu < %zu)", paths_bytes, need); return RSK_E_INVALID; }
+
+    struct ws_t {
+        std::vector<void *> all;
+        ~ws_t() { for (void *p : all) (void) hipFree(p); }
+        int alloc(void **p, size_t bytes)
+        {
+            hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+            if (e != hipSuccess) return rsk_hip_fail(e, "hipMalloc", __FILE__, __LINE__);
+            all.push_back(*p);
+            return RSK_OK;
+        }
+    };
+    // sub-batches bounded by the trace scratch (the rest is small)
+    const uint64_t TB_BUDGET = 24ull << 30;
+    size_t r0 = 0;
+    uint64_t poff = 0;                // running offset into the caller's paths buffer
+    while (r0 < n) {
+        std::vector<uint64_t> row_off, tb_off, path_off;
+        uint64_t ro = 0, to = 0, po = 0;
+        size_t r1 = r0;
+        while (r1 < n) {
+            const uint32_t LA = dba->len[ia[r1]], LB = dbb->len[ib[r1]];
+            const uint32_t ext[2][2] = { { LA - lo_a[r1], LB - lo_b[r1] }, { lo_a[r1], lo_b[r1] } };
+            const uint64_t t_need = (uint64_t) (ext[0][0] + 9) * (ext[0][1] + 9) + (uint64_t) (ext[1][0] + 9) * (ext[1][1] + 9) + 64;
+            if (r1 > r0 && to + t_need > TB_BUDGET) break;
+            for (int d = 0; d < 2; ++d) {
+                row_off.push_back(ro); ro += 2ull * (ext[d][1] + 9);
+                tb_off.push_back(to); to += ((uint64_t) (ext[d][0] + 9) * (ext[d][1] + 9) + 15) & ~15ull;
+                path_off.push_back(po); po += ext[d][0] + ext[d][1] + 2;
+            }
+            ++r1;
+        }
+        const size_t m = r1 - r0;
+        ws_t ws;
+        uint32_t *d_ia, *d_ib, *d_la, *d_lb, *d_pstart, *d_plen;
+        uint64_t *d_rowoff, *d_tboff, *d_pathoff;
+        float *d_rows, *d_score;
+        uint8_t *d_tb;
+        char *d_paths;
+        if ((rc = ws.alloc((void **) &d_ia, m * 4)) || (rc = ws.alloc((void **) &d_ib, m * 4)) || (rc = ws.alloc((void **) &d_la, m * 4)) ||
+            (rc = ws.alloc((void **) &d_lb, m * 4)) || (rc = ws.alloc((void **) &d_pstart, 2 * m * 4)) || (rc = ws.alloc((void **) &d_plen, 2 * m * 4)) ||
+            (rc = ws.alloc((void **) &d_rowoff, 2 * m * 8)) || (rc = ws.alloc((void **) &d_tboff, 2 * m * 8)) ||
+            (rc = ws.alloc((void **) &d_pathoff, 2 * m * 8)) || (rc = ws.alloc((void **) &d_rows, ro * 4)) || (rc = ws.alloc((void **) &d_score, 2 * m * 4)) ||
+            (rc = ws.alloc((void **) &d_tb, to)) || (rc = ws.alloc((void **) &d_paths, po)))
+            return rc;
+        RSK_HIP(hipMemcpyAsync(d_ia, ia + r0, m * 4, hipMemcpyHostToDevice, ctx->stream));
+        RSK_HIP(hipMemcpyAsync(d_ib, ib + r0, m * 4, hipMemcpyHostToDevice, ctx->stream));
+        RSK_HIP(hipMemcpyAsync(d_la, lo_a + r0, m * 4, hipMemcpyHostToDevice, ctx->stream));
+        RSK_HIP(hipMemcpyAsync(d_lb, lo_b + r0, m * 4, hipMemcpyHostToDevice, ctx->stream));
+        RSK_HIP(hipMemcpyAsync(d_rowoff, row_off.data(), 2 * m * 8, hipMemcpyHostToDevice, ctx->stream));
+        RSK_HIP(hipMemcpyAsync(d_tboff, tb_off.data(), 2 * m * 8, hipMemcpyHostToDevice, ctx->stream));
+        RSK_HIP(hipMemcpyAsync(d_pathoff, path_off.data(), 2 * m * 8, hipMemcpyHostToDevice, ctx->stream));
+        RSK_HIP(hipMemsetAsync(d_tb, 0, to, ctx->stream));          // unwritten trace cells read as 0 (XDPMem zeroes its matrix)
+        RSK_HIP(hipMemsetAsync(d_rows, 0, ro * 4, ctx->stream));    // as XDPMem::Alloc leaves its rows
+        xd_args a;
+        a.a_ra = dba->d_prof_ra; a.b_cb = dbb->d_prof_cb;
+        a.a_off = dba->d_off; a.b_off = dbb->d_off; a.a_len = dba->d_len; a.b_len = dbb->d_len;
+        a.ia = d_ia; a.ib = d_ib; a.lo_a = d_la; a.lo_b = d_lb;
+        a.nreq = (uint32_t) m;
+        a.X = X; a.open = gap_open; a.ext = gap_ext;
+        a.rows = d_rows; a.row_off = d_rowoff; a.tb = d_tb; a.tb_off = d_tboff;
+        a.score = d_score; a.paths = d_paths; a.path_off = d_pathoff; a.path_start = d_pstart; a.path_len = d_plen;
+        hipLaunchKernelGGL(k_xdrop, dim3((unsigned) ((2 * m + 255) / 256)), dim3(256), 0, ctx->stream, a);
+        RSK_HIP(hipGetLastError());
+        std::vector<float> h_score(2 * m);
+        std::vector<uint32_t> h_pstart(2 * m), h_plen(2 * m);
+        RSK_HIP(hipMemcpyAsync(h_score.data(), d_score, 2 * m * 4, hipMemcpyDeviceToHost, ctx->stream));
+        RSK_HIP(hipMemcpyAsync(h_pstart.data(), d_pstart, 2 * m * 4, hipMemcpyDeviceToHost, ctx->stream));
+        RSK_HIP(hipMemcpyAsync(h_plen.data(), d_plen, 2 * m * 4, hipMemcpyDeviceToHost, ctx->stream));
+        RSK_HIP(hipMemcpyAsync(paths + poff, d_paths, po, hipMemcpyDeviceToHost, ctx->stream));
+        RSK_HIP(hipStreamSynchronize(ctx->stream));
+        for (size_t k = 0; k < m; ++k) {
+            score_fwd[r0 + k] = h_score[2 * k];
+            score_bwd[r0 + k] = h_score[2 * k + 1];
+            fwd_off[r0 + k] = poff + path_off[2 * k] + h_pstart[2 * k];
+            fwd_len[r0 + k] = h_plen[2 * k];
+            bwd_off[r0 + k] = poff + path_off[2 * k + 1] + h_pstart[2 * k + 1];
+            bwd_len[r0 + k] = h_plen[2 * k + 1];
+        }
+        poff += po;
+        r0 = r1;
+    }
+    return RSK_OK;
+}

@@ -1,0 +1,84 @@
+"""GPU parity of the gapped float X-drop extensions of the long-chain path (second half):
+rsk_xdrop_pairs (one GPU thread per extension) against the host mirror of XDropFwd / XDropBwd (rsk_xdrop_fwd/bwd on
+the explicit SetSMx_NoRev matrix from the oracle), which tests/test_xdrop_kat.py pins to the reference's own
+-test_xdrop vectors.  Score bits and paths must be identical."""
+import ctypes as C
+import struct
+
+import numpy as np
+import pytest
+
+import fixtures as fx
+import oracle_lib as ol
+from reseek_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(x):
+    return struct.unpack("<I", struct.pack("<f", x))[0]
+
+
+def smx(pa, pb):
+    pa, pb = np.ascontiguousarray(pa), np.ascontiguousarray(pb)
+    S = np.zeros((pa.shape[1], pb.shape[1]), np.float32)
+    ol.lib().rsko_set_smx(pa.ctypes.data_as(C.POINTER(C.c_uint8)), pa.shape[1], pb.ctypes.data_as(C.POINTER(C.c_uint8)), pb.shape[1],
+                          S.ctypes.data_as(C.POINTER(C.c_float)))
+    return S
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+    import reseek_amd
+    assert torch.cuda.is_available()
+    c = reseek_amd.Ctx(0, stream=torch.cuda.current_stream().cuda_stream)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("fixture,X,go,ge", [("palms_sensitive.rskdb.gz", 8.0, -0.685533, -0.051881),
+                                             ("q100_sensitive.rskdb.gz", 8.0, -0.685533, -0.051881),
+                                             ("q100_sensitive.rskdb.gz", 2.5, -3.0, -1.0)])
+def test_xdrop_pairs_match_the_host_mirror(ctx, fixture, X, go, ge):
+    import reseek_amd
+    chains = fx.read_rskdb(fixture)[:14]
+    db = reseek_amd.Db.from_chains(ctx, chains)
+    rng = np.random.default_rng(5)
+    ia, ib, la, lb = [], [], [], []
+    n = len(chains)
+    for a in range(n):
+        for b in rng.choice(n, 4, replace=False):
+            LA, LB = chains[a].prof.shape[1], chains[b].prof.shape[1]
+            if LA < 3 or LB < 3:
+                continue
+            # a start on a self-like diagonal (long extensions), a random one, and the edges 1 / L - 1
+            for (x, y) in ((min(LA, LB) // 2, min(LA, LB) // 2), (int(rng.integers(1, LA)), int(rng.integers(1, LB))), (1, 1), (LA - 1, LB - 1),
+                           (1, LB - 1)):
+                ia.append(a); ib.append(int(b)); la.append(x); lb.append(y)
+    res = ctx.xdrop_pairs(db, db, ia, ib, la, lb, X, go, ge)
+    nlong = 0
+    cache = {}
+    for k, (sf, pf, sb, pb) in enumerate(res):
+        key = (ia[k], ib[k])
+        if key not in cache:
+            cache[key] = smx(chains[ia[k]].prof, chains[ib[k]].prof)
+        S = cache[key]
+        hf, hpf = capi.xdrop_fwd(S, X, go, ge, la[k], lb[k])
+        hb, hpb = capi.xdrop_bwd(S, X, go, ge, la[k] - 1, lb[k] - 1)
+        assert bits(sf) == bits(hf) and pf == hpf, (k, "fwd", ia[k], ib[k], la[k], lb[k])
+        assert bits(sb) == bits(hb) and pb == hpb, (k, "bwd", ia[k], ib[k], la[k], lb[k])
+        nlong += len(pf) > 40 or len(pb) > 40
+    assert len(res) > 200 and nlong > 10
+    db.close()
+
+
+def test_xdrop_pairs_rejects_bad_starts(ctx):
+    import reseek_amd
+    chains = fx.read_rskdb("q100_sensitive.rskdb.gz")[:2]
+    db = reseek_amd.Db.from_chains(ctx, chains)
+    with pytest.raises(RuntimeError):
+        ctx.xdrop_pairs(db, db, [0], [1], [0], [1], 8.0, -0.685533, -0.051881)
+    with pytest.raises(RuntimeError):
+        ctx.xdrop_pairs(db, db, [0], [1], [1], [chains[1].prof.shape[1]], 8.0, -0.685533, -0.051881)
+    db.close()
