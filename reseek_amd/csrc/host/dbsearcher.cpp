@@ -543,32 +543,101 @@ void RunMKFPairs(rsk_ctx *Ctx, const DSSParams &P, const std::string &Columns, D
     if (getenv("RSK_TRACE")) fprintf(stderr, "[RunMKFPairs] %zu pairs, %zu with a seed HSP\n", n, recs.size());
     const auto t_host0 = std::chrono::steady_clock::now();
     const unsigned T = (unsigned) std::max<size_t>(1, std::min<size_t>((size_t) HostThreads(128), recs.size() / 8 + 1));
-    std::atomic<size_t> next{0};
+    auto parallel = [&](const std::function<void(DSSAligner &, size_t)> &fn) {
+        std::atomic<size_t> next{0};
+        auto body = [&]() {
+            DSSAligner DA;
+            DA.SetParams(P);
+            DA.SetColumns(Columns);
+            for (;;) {
+                const size_t r = next.fetch_add(1);
+                if (r >= recs.size()) break;
+                fn(DA, r);
+            }
+            DA.UnsetQuery();
+        };
+        if (T == 1) body();
+        else {
+            std::vector<std::thread> ts;
+            std::vector<std::string> errs(T);
+            for (unsigned t = 0; t < T; ++t)
+                ts.emplace_back([&, t]() { try { body(); } catch (const std::exception &e) { errs[t] = e.what(); } });
+            for (auto &t : ts) t.join();
+            for (auto &e : errs)
+                if (!e.empty()) throw std::runtime_error(e);
+        }
+    };
+    auto set_pair = [&](DSSAligner &DA, size_t r) {
+        const uint i = Pairs[recs[r].pair].first, j = Pairs[recs[r].pair].second;
+        DA.SetQuery(*SrcA.m_DBChains[i], SrcA.m_DBProfiles[i], SrcA.m_DBMuLettersVec[i], SrcA.m_DBMuKmersVec[i], SrcA.m_DBSelfRevScores[i]);
+        DA.SetTarget(*SrcB.m_DBChains[j], SrcB.m_DBProfiles[j], SrcB.m_DBMuLettersVec[j], SrcB.m_DBMuKmersVec[j], SrcB.m_DBSelfRevScores[j]);
+    };
+    // stage 1 (host threads): chain the seed HSPs, score the chained HSPs, pick the start of the gapped extension
+    // (PostAlignMKF up to XDropHSP's start, dssaligner.cpp:1395-1418, xdrophsp.cpp:42-95).  req: 0 = no alignment,
+    // 1 = extension requested, 2 = whole pair on the host (seed list truncated on the device, or a start at a chain end)
+    std::vector<uint8_t> req(recs.size(), 0);
+    std::vector<uint32_t> rqa(recs.size(), 0), rqb(recs.size(), 0);
+    parallel([&](DSSAligner &DA, size_t r) {
+        const Rec &R = recs[r];
+        if (R.nkept > CAP) { req[r] = 2; return; }
+        set_pair(DA, r);
+        DA.m_XDropMode = 1;
+        DA.AlignMKF_FromSeeds(R.kept.data(), R.nkept);
+        DA.m_XDropMode = 0;
+        if (!DA.m_XDropReqValid) return;
+        const uint LA = DA.m_ChainA->GetSeqLength(), LB = DA.m_ChainB->GetSeqLength();
+        const bool ok = DA.m_XDropReqLoA >= 1 && DA.m_XDropReqLoA < LA && DA.m_XDropReqLoB >= 1 && DA.m_XDropReqLoB < LB;
+        req[r] = ok ? 1 : 2;
+        rqa[r] = DA.m_XDropReqLoA; rqb[r] = DA.m_XDropReqLoB;
+    });
+    // stage 2 (GPU): both extensions of every requested pair, one thread each
+    std::vector<size_t> slot(recs.size(), (size_t) -1);
+    std::vector<uint32_t> xa, xb, xla, xlb;
+    size_t xbytes = 0;
+    for (size_t r = 0; r < recs.size(); ++r)
+        if (req[r] == 1) {
+            slot[r] = xa.size();
+            const uint i = Pairs[recs[r].pair].first, j = Pairs[recs[r].pair].second;
+            xa.push_back(i); xb.push_back(j); xla.push_back(rqa[r]); xlb.push_back(rqb[r]);
+            xbytes += (size_t) SrcA.m_DBChains[i]->GetSeqLength() + SrcB.m_DBChains[j]->GetSeqLength() + 4;
+        }
+    const size_t nx = xa.size();
+    std::vector<float> xsf(nx), xsb(nx);
+    std::vector<uint64_t> xfo(nx), xbo(nx);
+    std::vector<uint32_t> xfl(nx), xbl(nx);
+    std::vector<char> xpaths(xbytes + 16);
+    if (nx)
+        check(rsk_xdrop_pairs(Ctx, SrcA.m_Db, SrcB.m_Db, xa.data(), xb.data(), xla.data(), xlb.data(), nx, float(P.m_MKF_X2), P.m_GapOpen, P.m_GapExt,
+                              xsf.data(), xsb.data(), xpaths.data(), xpaths.size(), xfo.data(), xfl.data(), xbo.data(), xbl.data()),
+              "rsk_xdrop_pairs");
+    const auto t_host1 = std::chrono::steady_clock::now();
+    // stage 3 (host threads): merge the extensions, statistics, hit
     std::mutex lock;
-    auto body = [&]() {
-        DSSAligner DA;
-        DA.SetParams(P);
-        DA.SetColumns(Columns);
-        for (;;) {
-            const size_t r = next.fetch_add(1);
-            if (r >= recs.size()) break;
-            const Rec &R = recs[r];
-            const uint i = Pairs[R.pair].first, j = Pairs[R.pair].second;
-            DA.SetQuery(*SrcA.m_DBChains[i], SrcA.m_DBProfiles[i], SrcA.m_DBMuLettersVec[i], SrcA.m_DBMuKmersVec[i], SrcA.m_DBSelfRevScores[i]);
-            DA.SetTarget(*SrcB.m_DBChains[j], SrcB.m_DBProfiles[j], SrcB.m_DBMuLettersVec[j], SrcB.m_DBMuKmersVec[j], SrcB.m_DBSelfRevScores[j]);
+    parallel([&](DSSAligner &DA, size_t r) {
+        if (req[r] == 0) return;                                         // no alignment: nothing to report (m_Path empty)
+        const Rec &R = recs[r];
+        const uint i = Pairs[R.pair].first, j = Pairs[R.pair].second;
+        set_pair(DA, r);
+        if (req[r] == 2) {
             if (R.nkept > CAP) DA.AlignMKF();                             // list truncated on the device: full host path
             else DA.AlignMKF_FromSeeds(R.kept.data(), R.nkept);
-            std::lock_guard<std::mutex> g(lock);
-            OnHit(DA, i, j);
+        } else {
+            const size_t k = slot[r];
+            DA.m_XDropMode = 2;
+            DA.m_XDropReqValid = true;
+            DA.m_XDropReqLoA = rqa[r]; DA.m_XDropReqLoB = rqb[r];
+            DA.m_XDropExtScoreFwd = xsf[k]; DA.m_XDropExtScoreBwd = xsb[k];
+            DA.m_XDropExtFwdPath.assign(xpaths.data() + xfo[k], xfl[k]);
+            DA.m_XDropExtBwdPath.assign(xpaths.data() + xbo[k], xbl[k]);
+            DA.AlignMKF_FromSeeds(R.kept.data(), R.nkept);
+            DA.m_XDropMode = 0;
         }
-        DA.UnsetQuery();
-    };
-    if (T == 1) body();
-    else {
-        std::vector<std::thread> ts;
-        for (unsigned t = 0; t < T; ++t) ts.emplace_back(body);
-        for (auto &t : ts) t.join();
-    }
+        std::lock_guard<std::mutex> g(lock);
+        OnHit(DA, i, j);
+    });
+    if (getenv("RSK_TRACE"))
+        fprintf(stderr, "[RunMKFPairs] %zu gapped extensions on the GPU, stages 1+2 %.3f ms\n", nx,
+                std::chrono::duration<double, std::milli>(t_host1 - t_host0).count());
     if (getenv("RSK_TRACE"))
         fprintf(stderr, "[RunMKFPairs] host stage %.3f ms on %u threads (thread-ms so far: mega score %.1f, gapped X-drop %.1f, statistics %.1f)\n",
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count(), T, g_MKFNsMega.load() / 1e6,

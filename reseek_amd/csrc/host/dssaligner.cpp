@@ -660,12 +660,25 @@ float DSSAligner::XDropHSP(uint Loi_in, uint Loj_in, uint Len, uint &Loi_out, ui
         if (MerScore > BestMerScore) { BestMerScore = MerScore; LoA = Loi_in + MerStart; LoB = Loj_in + MerStart; }
     }
     if (std::min(LoA, LoB) < K / 2) { LoA += K / 2; LoB += K / 2; }
-    static thread_local XDropMem Mem;
-    auto Sub = [this](uint a, uint b) { return SubstScore(a, b); };
     std::string FwdPath, BwdPath;
-    uint s1, s2;
-    const float ScoreFwd = XDropFwd(Mem, X, Open, Ext, Sub, LoA, LA, LoB, LB, &s1, &s2, FwdPath);
-    const float ScoreBwd = XDropBwd(Mem, X, Open, Ext, Sub, LoA - 1, LA, LoB - 1, LB, &s1, &s2, BwdPath);
+    float ScoreFwd, ScoreBwd;
+    if (m_XDropMode == 1) {                                      // request only: the extensions run in a GPU batch
+        m_XDropReqValid = true;
+        m_XDropReqLoA = LoA; m_XDropReqLoB = LoB;
+        m_XDropPath.clear();
+        return 0;
+    }
+    if (m_XDropMode == 2) {
+        if (LoA != m_XDropReqLoA || LoB != m_XDropReqLoB) throw std::runtime_error("XDropHSP: GPU extensions belong to another start");
+        ScoreFwd = m_XDropExtScoreFwd; ScoreBwd = m_XDropExtScoreBwd;
+        FwdPath = m_XDropExtFwdPath; BwdPath = m_XDropExtBwdPath;
+    } else {
+        static thread_local XDropMem Mem;
+        auto Sub = [this](uint a, uint b) { return SubstScore(a, b); };
+        uint s1, s2;
+        ScoreFwd = XDropFwd(Mem, X, Open, Ext, Sub, LoA, LA, LoB, LB, &s1, &s2, FwdPath);
+        ScoreBwd = XDropBwd(Mem, X, Open, Ext, Sub, LoA - 1, LA, LoB - 1, LB, &s1, &s2, BwdPath);
+    }
     const float TotalScore = ScoreFwd + ScoreBwd;
     if (TotalScore < 10) { m_XDropPath.clear(); return 0; }
     MergeFwdBwd(LA, LB, LoA, LoB, FwdPath, LoA - 1, LoB - 1, BwdPath, Loi_out, Loj_out, Hii_out, Hij_out, m_XDropPath);
@@ -706,6 +719,7 @@ static inline uint64_t NowNs() { return (uint64_t) std::chrono::duration_cast<st
 
 void DSSAligner::PostAlignMKF()
 {
+    m_XDropReqValid = m_XDropMode == 2 ? m_XDropReqValid : false;
     if (m_MKF.m_BestChainScore <= 0) return;
     const uint64_t t0 = NowNs();
     float MegaHSPTotal = 0, BestMegaScore = 0;
@@ -723,6 +737,7 @@ void DSSAligner::PostAlignMKF()
                             (uint) m_MKF.m_ChainHSPLens[BestMegaIdx], m_LoA, m_LoB, m_HiA, m_HiB);
     const uint64_t t2 = NowNs();
     g_MKFNsXDrop += t2 - t1;
+    if (m_XDropMode == 1) return;                                // start recorded, nothing aligned yet
     m_AlnFwdScore = m_XDropScore;
     m_Path = m_XDropPath;
     uint nM, nD, nI;

@@ -192,6 +192,14 @@ public:
     MuKmerFilter m_MKF;
     float m_XDropScore = 0;
     std::string m_XDropPath;
+    // Where the two gapped extensions of XDropHSP run: 0 = here (host DP); 1 = nowhere, only record their start
+    // (m_XDropReq*) and stop -- RunMKFPairs collects the requests of a batch for rsk_xdrop_pairs; 2 = take the
+    // extensions computed on the GPU (m_XDropExt*) for the recorded start.
+    int m_XDropMode = 0;
+    bool m_XDropReqValid = false;
+    uint m_XDropReqLoA = 0, m_XDropReqLoB = 0;
+    float m_XDropExtScoreFwd = 0, m_XDropExtScoreBwd = 0;
+    std::string m_XDropExtFwdPath, m_XDropExtBwdPath;
 
     std::string m_Path;
     uint m_LoA = UINT_MAX, m_LoB = UINT_MAX, m_HiA = UINT_MAX, m_HiB = UINT_MAX;
