@@ -174,8 +174,8 @@ int rsk_mu_filter_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, const ui
  * keeps (strictly improving score, new Loi, in (PosT, slot) order), rec_kept[r*cap*4 ...] = their
  * (Loi, Loj, Len, Score), at most cap (<= 32) stored; a count > cap is an upper bound (redo that pair
  * with the host path).  *nrecords may exceed max_records (then enlarge and
- * call again).  x1 = m_MKF_X1 (8).  Chaining and the gapped float X-drop of the found pairs stay in
- * host/dssaligner.cpp. */
+ * call again).  x1 = m_MKF_X1 (8).  Chaining of the kept HSPs stays in host/dssaligner.cpp; the gapped
+ * extensions of the found pairs are rsk_xdrop_pairs below. */
 int rsk_mkf_seed_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, const uint32_t *iq, const uint32_t *it,
                        size_t npairs, int x1, int min_hsp_score, uint32_t cap, uint8_t *found, size_t max_records,
                        size_t *nrecords, uint32_t *rec_pair, uint32_t *rec_nkept, int32_t *rec_kept);

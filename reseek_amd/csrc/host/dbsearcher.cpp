@@ -6,7 +6,8 @@
 //   Mu filter (rsk_mu_filter_dev)  ->  survivors  ->  rsk_align_pairs  ->  hit records,
 // then every hit is replayed through DSSAligner + BaseOnAln so Reject/-evalue/-mints, OnAln
 // subclasses and -columns behave as in the reference.  Pairs that take the long-chain MKF path
-// (DoMKF, dssaligner.cpp:715) are aligned on the host (row P9, not yet on the GPU).
+// (DoMKF, dssaligner.cpp:715) go through RunMKFPairs: seeding and the gapped X-drop extensions in GPU batches
+// (rsk_mkf_seed_pairs, rsk_xdrop_pairs), chaining / start selection / merge / statistics on host threads.
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
