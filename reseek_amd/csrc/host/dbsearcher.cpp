@@ -511,7 +511,8 @@ void RunMKFPairs(rsk_ctx *Ctx, const DSSParams &P, const std::string &Columns, D
 {
     const size_t n = Pairs.size();
     if (n == 0) return;
-    const uint32_t CAP = 32;
+    // seed HSPs per pair returned by the device (RSK_MKF_CAP lowers it so that tests reach the truncated-list path)
+    const uint32_t CAP = getenv("RSK_MKF_CAP") ? (uint32_t) std::max(1, std::min(32, atoi(getenv("RSK_MKF_CAP")))) : 32;
     // records of the pairs that have a seed HSP (everything else has no alignment: mukmerfilter.cpp:387, dssaligner.cpp:1397)
     struct Rec { uint32_t pair, nkept; std::vector<int32_t> kept; };
     std::vector<Rec> recs;
@@ -575,20 +576,18 @@ void RunMKFPairs(rsk_ctx *Ctx, const DSSParams &P, const std::string &Columns, D
     };
     // stage 1 (host threads): chain the seed HSPs, score the chained HSPs, pick the start of the gapped extension
     // (PostAlignMKF up to XDropHSP's start, dssaligner.cpp:1395-1418, xdrophsp.cpp:42-95).  req: 0 = no alignment,
-    // 1 = extension requested, 2 = whole pair on the host (seed list truncated on the device, or a start at a chain end)
+    // 1 = extensions requested (rsk_xdrop_pairs rejects a start outside 1..L-1; XDropHSP cannot produce one)
     std::vector<uint8_t> req(recs.size(), 0);
     std::vector<uint32_t> rqa(recs.size(), 0), rqb(recs.size(), 0);
     parallel([&](DSSAligner &DA, size_t r) {
         const Rec &R = recs[r];
-        if (R.nkept > CAP) { req[r] = 2; return; }
         set_pair(DA, r);
         DA.m_XDropMode = 1;
-        DA.AlignMKF_FromSeeds(R.kept.data(), R.nkept);
+        if (R.nkept > CAP) DA.AlignMKF();                                 // seed list truncated on the device: seeds from MuKmerFilter::Align
+        else DA.AlignMKF_FromSeeds(R.kept.data(), R.nkept);
         DA.m_XDropMode = 0;
         if (!DA.m_XDropReqValid) return;
-        const uint LA = DA.m_ChainA->GetSeqLength(), LB = DA.m_ChainB->GetSeqLength();
-        const bool ok = DA.m_XDropReqLoA >= 1 && DA.m_XDropReqLoA < LA && DA.m_XDropReqLoB >= 1 && DA.m_XDropReqLoB < LB;
-        req[r] = ok ? 1 : 2;
+        req[r] = 1;
         rqa[r] = DA.m_XDropReqLoA; rqb[r] = DA.m_XDropReqLoB;
     });
     // stage 2 (GPU): both extensions of every requested pair, one thread each
@@ -619,20 +618,16 @@ void RunMKFPairs(rsk_ctx *Ctx, const DSSParams &P, const std::string &Columns, D
         const Rec &R = recs[r];
         const uint i = Pairs[R.pair].first, j = Pairs[R.pair].second;
         set_pair(DA, r);
-        if (req[r] == 2) {
-            if (R.nkept > CAP) DA.AlignMKF();                             // list truncated on the device: full host path
-            else DA.AlignMKF_FromSeeds(R.kept.data(), R.nkept);
-        } else {
-            const size_t k = slot[r];
-            DA.m_XDropMode = 2;
-            DA.m_XDropReqValid = true;
-            DA.m_XDropReqLoA = rqa[r]; DA.m_XDropReqLoB = rqb[r];
-            DA.m_XDropExtScoreFwd = xsf[k]; DA.m_XDropExtScoreBwd = xsb[k];
-            DA.m_XDropExtFwdPath.assign(xpaths.data() + xfo[k], xfl[k]);
-            DA.m_XDropExtBwdPath.assign(xpaths.data() + xbo[k], xbl[k]);
-            DA.AlignMKF_FromSeeds(R.kept.data(), R.nkept);
-            DA.m_XDropMode = 0;
-        }
+        const size_t k = slot[r];
+        DA.m_XDropMode = 2;
+        DA.m_XDropReqValid = true;
+        DA.m_XDropReqLoA = rqa[r]; DA.m_XDropReqLoB = rqb[r];
+        DA.m_XDropExtScoreFwd = xsf[k]; DA.m_XDropExtScoreBwd = xsb[k];
+        DA.m_XDropExtFwdPath.assign(xpaths.data() + xfo[k], xfl[k]);
+        DA.m_XDropExtBwdPath.assign(xpaths.data() + xbo[k], xbl[k]);
+        if (R.nkept > CAP) DA.AlignMKF();
+        else DA.AlignMKF_FromSeeds(R.kept.data(), R.nkept);
+        DA.m_XDropMode = 0;
         std::lock_guard<std::mutex> g(lock);
         OnHit(DA, i, j);
     });

@@ -82,6 +82,13 @@ def test_palms_sensitive_long_chains_mkf(ctx, tmpdir):
     assert st[4] > 300      # lengths 418..2,099: most pairs take the MKF path
 
 
+def test_palms_with_truncated_seed_lists(ctx, tmpdir, monkeypatch):
+    """RSK_MKF_CAP=1: the device returns one seed HSP per pair, every pair with more takes the path that re-seeds
+    with MuKmerFilter::Align on the host before its extensions go to the GPU -- same hit table."""
+    monkeypatch.setenv("RSK_MKF_CAP", "1")
+    run(ctx, tmpdir, "palms_sensitive.rskdb.gz", "sensitive", COLS, "hits_palms_sensitive.tsv.gz")
+
+
 def test_q100_vs_db_q100_sensitive(ctx, tmpdir):
     """`reseek -search Q -db DB -sensitive` (Search_NoMuFilter search.cpp:39): A = streamed DB chain whose
     self-rev score is computed under the search params (runquery.cpp:43-44), B = query chain."""
