@@ -220,22 +220,34 @@ float DSSAligner::GetLDDT() const
     const uint n = (uint) PosAs.size();
     if (n == 0) return 0;
     const PDBChain &Q = *m_ChainA, &T = *m_ChainB;
+    // coordinates of the aligned columns, contiguous: the squared distances of a column to all later columns are a
+    // branch-free (vectorisable) loop; the few pairs within R0 are finished in a second pass
+    static thread_local std::vector<float> buf;
+    buf.resize((size_t) 8 * n);
+    float *ax = buf.data(), *ay = ax + n, *az = ay + n, *bx = az + n, *by = bx + n, *bz = by + n, *d1 = bz + n, *d2 = d1 + n;
+    for (uint c = 0; c < n; ++c) {
+        ax[c] = Q.m_Xs[PosAs[c]]; ay[c] = Q.m_Ys[PosAs[c]]; az[c] = Q.m_Zs[PosAs[c]];
+        bx[c] = T.m_Xs[PosBs[c]]; by[c] = T.m_Ys[PosBs[c]]; bz[c] = T.m_Zs[PosBs[c]];
+    }
     std::vector<uint> cons(n, 0), pres(n, 0);
     const float R0sq = 15.0f * 15.0f;
     for (uint ci = 0; ci < n; ++ci) {
+        const float x1 = ax[ci], y1 = ay[ci], z1 = az[ci], u1 = bx[ci], v1 = by[ci], w1 = bz[ci];
         for (uint cj = ci + 1; cj < n; ++cj) {
-            const float dx = Q.m_Xs[PosAs[ci]] - Q.m_Xs[PosAs[cj]], dy = Q.m_Ys[PosAs[ci]] - Q.m_Ys[PosAs[cj]],
-                        dz = Q.m_Zs[PosAs[ci]] - Q.m_Zs[PosAs[cj]];
-            const float d1s = dx * dx + dy * dy + dz * dz;
-            const float ex = T.m_Xs[PosBs[ci]] - T.m_Xs[PosBs[cj]], ey = T.m_Ys[PosBs[ci]] - T.m_Ys[PosBs[cj]],
-                        ez = T.m_Zs[PosBs[ci]] - T.m_Zs[PosBs[cj]];
-            const float d2s = ex * ex + ey * ey + ez * ez;
-            if (d1s > R0sq && d2s > R0sq) continue;
-            const float diff = fabsf(sqrtf(d1s) - sqrtf(d2s));
-            const uint k = (diff <= 0.5f) + (diff <= 1.0f) + (diff <= 2.0f) + (diff <= 4.0f);
-            pres[ci] += k; pres[cj] += k;
-            cons[ci] += 4; cons[cj] += 4;
+            const float dx = x1 - ax[cj], dy = y1 - ay[cj], dz = z1 - az[cj];
+            const float ex = u1 - bx[cj], ey = v1 - by[cj], ez = w1 - bz[cj];
+            d1[cj] = dx * dx + dy * dy + dz * dz;
+            d2[cj] = ex * ex + ey * ey + ez * ez;
         }
+        uint consi = 0, presi = 0;
+        for (uint cj = ci + 1; cj < n; ++cj) {
+            if (d1[cj] > R0sq && d2[cj] > R0sq) continue;
+            const float diff = fabsf(sqrtf(d1[cj]) - sqrtf(d2[cj]));
+            const uint k = (diff <= 0.5f) + (diff <= 1.0f) + (diff <= 2.0f) + (diff <= 4.0f);
+            presi += k; pres[cj] += k;
+            consi += 4; cons[cj] += 4;
+        }
+        cons[ci] += consi; pres[ci] += presi;
     }
     float total = 0;
     for (uint c = 0; c < n; ++c) {
