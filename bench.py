@@ -131,6 +131,30 @@ def cpu_baseline(seqs, seconds_target=15.0):
             "sample": "%d random pairs (%.3g cells), oracle/rsk_oracle.c rsko_mu_gapless, 1 thread" % (npairs, cells)}
 
 
+def search_end_to_end(seqs):
+    """SURVEY 8d metric (ii): chain-pairs/s of the whole `-search -sensitive` call (container load + upload + Mu filter +
+    SW/traceback/LDDT + long-chain path + hit replay + TSV) on the same SCOP40-shaped set, with synthetic profile bytes
+    and CA traces added (tools/bench_search.py); second of two runs.  Reported beside the kernel metric, not as `value`."""
+    import torch
+    import reseek_amd
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_search
+    ctx = reseek_amd.Ctx(0, stream=torch.cuda.current_stream().cuda_stream)
+    with tempfile.TemporaryDirectory() as td:
+        db, out = os.path.join(td, "syn.rskdb"), os.path.join(td, "hits.tsv")
+        bench_search.write_rskdb(db, seqs, np.random.default_rng(5))
+        best = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            nhits, st = ctx.search_rskdb(db, out, "sensitive")
+            dt = time.perf_counter() - t0
+            best = {"mode": "-search -sensitive, all-vs-all, whole call", "seconds": dt, "chain_pairs": int(st[0]),
+                    "chain_pairs_per_sec": st[0] / dt, "mu_filter_survivors": int(st[5]), "long_chain_pairs": int(st[4]),
+                    "hits": int(nhits)}
+    ctx.close()
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -138,6 +162,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--chains", type=int, default=0, help="0 = the full SCOP40-shaped set (11,211)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-search", action="store_true", help="skip the end-to-end -search leg (rank 0, 1 GPU only)")
     args = ap.parse_args()
 
     import torch
@@ -252,6 +277,11 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(seqs)
+        if not args.no_search and world == 1 and not args.chains:
+            try:
+                res["search"] = search_end_to_end(seqs)
+            except Exception as e:  # noqa: BLE001 -- the kernel metric above stands on its own
+                sys.stderr.write("bench: end-to-end search leg failed: %s\n" % e)
         print(json.dumps(res))
     if dist is not None:
         dist.barrier()
