@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""End-to-end check against the reference BINARY on a synthetic structure set (GPU box; needs oracle/_ref/reseek, which
+travels with the snapshot): writes an N-chain .bca (tools/bench_search.py generator), runs
+    oracle/_ref/reseek -search syn.bca -<mode> -output ref.tsv -threads T
+and rsk_search on the same file, compares the sorted hit tables line by line and prints both wall times.
+usage: compare_with_reference.py [nchains=1000] [mode=sensitive] [db_chains=0] [threads=1]   (db_chains > 0: -search Q -db DB)
+
+threads = 1 is the default on purpose: with several threads the reference binary is not reproducible on sets with
+long-chain (MKF) pairs -- two 16-thread runs of the same command gave 44,193 and 44,195 rows on a 3000-chain set, the
+1-thread run 44,189 rows, identical to ours.  (Its banded X-drop traceback reads trace cells next to the path that
+the DP never wrote; XDPMem's matrix comes from malloc without clearing, xdpmem.h:96-108 / mx.h:38-54, so the outcome
+depends on what the allocator hands back, i.e. on the thread's history.  Here such cells read as 0, which is what a
+fresh process sees.)  `threads = 0` uses all usable CPUs (timing comparisons)."""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import bench  # noqa: E402
+import bench_search  # noqa: E402
+import reseek_amd  # noqa: E402
+
+
+def compare(n, mode, ndb=0, threads=1, seed=21, keep=None, long_chains=0):
+    """-> dict (see main); ["identical"] tells whether the sorted hit tables are equal."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "reseek")
+    if not os.path.exists(ref):
+        raise FileNotFoundError("oracle/_ref/reseek is missing (make -f oracle/Makefile.ref where /root/reference exists)")
+    lens = bench.scop40_lengths()
+    rng = np.random.default_rng(seed)
+    if threads <= 0:
+        threads = bench.usable_cpus()
+    ctx = reseek_amd.Ctx(0, stream=torch.cuda.current_stream().cuda_stream)
+    try:
+        with tempfile.TemporaryDirectory() as td:
+            q = os.path.join(td, "q.bca")
+            ql = lens[rng.choice(len(lens), n)].copy()
+            ql[:long_chains] = [620 + 140 * k for k in range(long_chains)]      # chains that take the MKF / X-drop path for sure
+            bench_search.write_bca(q, ql, rng)
+            db = None
+            if ndb:
+                db = os.path.join(td, "db.bca")
+                bench_search.write_bca(db, lens[rng.choice(len(lens), ndb)], rng)
+            ref_tsv, our_tsv = os.path.join(td, "ref.tsv"), os.path.join(td, "our.tsv")
+            cmd = [ref, "-search", q, "-" + mode, "-output", ref_tsv, "-threads", str(threads)] + (["-db", db] if db else [])
+            t0 = time.perf_counter()
+            subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=td)
+            t_ref = time.perf_counter() - t0
+            ctx.search_rskdb(q, our_tsv, mode, db=db)            # warm-up (HIP module load, allocator)
+            t0 = time.perf_counter()
+            nhits, st = ctx.search_rskdb(q, our_tsv, mode, db=db)
+            t_our = time.perf_counter() - t0
+            a = sorted(open(ref_tsv).read().splitlines())
+            b = sorted(open(our_tsv).read().splitlines())
+            res = {"chains": n, "db_chains": ndb, "mode": mode, "pairs": int(st[0]), "long_chain_pairs": int(st[4]), "reference_threads": threads,
+                   "reference_seconds": t_ref, "our_seconds": t_our, "speedup": t_ref / t_our, "reference_rows": len(a), "our_rows": len(b),
+                   "identical": a == b}
+            if a != b:
+                sa, sb = set(a), set(b)
+                res["only_reference"] = sorted(sa - sb)[:12]
+                res["only_ours"] = sorted(sb - sa)[:12]
+                res["n_only_reference"], res["n_only_ours"] = len(sa - sb), len(sb - sa)
+                if keep:
+                    import shutil
+                    os.makedirs(keep, exist_ok=True)
+                    for f in (q, ref_tsv, our_tsv) + ((db,) if db else ()):
+                        shutil.copy(f, keep)
+            return res
+    finally:
+        ctx.close()
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+    mode = sys.argv[2] if len(sys.argv) > 2 else "sensitive"
+    ndb = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    threads = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+    res = compare(n, mode, ndb, threads, keep=os.environ.get("RSK_COMPARE_KEEP"))
+    print(json.dumps(res, indent=1))
+    if not res["identical"]:
+        sys.exit(1)
+
+
+if __name__ == "__main__":
+    main()
