@@ -20,6 +20,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "rsk_internal.h"
@@ -279,6 +282,9 @@ extern "C" int rsk_xdrop_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
     };
     // sub-batches bounded by the trace scratch (the rest is small)
     const uint64_t TB_BUDGET = 24ull << 30;
+    const bool trace = getenv("RSK_TRACE") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     size_t r0 = 0;
     uint64_t poff = 0;                // running offset into the caller's paths buffer
     while (r0 < n) {
@@ -298,6 +304,7 @@ extern "C" int rsk_xdrop_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
             ++r1;
         }
         const size_t m = r1 - r0;
+        const auto t_a = now();
         ws_t ws;
         uint32_t *d_ia, *d_ib, *d_la, *d_lb, *d_pstart, *d_plen;
         uint64_t *d_rowoff, *d_tboff, *d_pathoff;
@@ -310,6 +317,7 @@ extern "C" int rsk_xdrop_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
             (rc = ws.alloc((void **) &d_pathoff, 2 * m * 8)) || (rc = ws.alloc((void **) &d_rows, ro * 4)) || (rc = ws.alloc((void **) &d_score, 2 * m * 4)) ||
             (rc = ws.alloc((void **) &d_tb, to)) || (rc = ws.alloc((void **) &d_paths, po)))
             return rc;
+        const auto t_b = now();
         RSK_HIP(hipMemcpyAsync(d_ia, ia + r0, m * 4, hipMemcpyHostToDevice, ctx->stream));
         RSK_HIP(hipMemcpyAsync(d_ib, ib + r0, m * 4, hipMemcpyHostToDevice, ctx->stream));
         RSK_HIP(hipMemcpyAsync(d_la, lo_a + r0, m * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -327,8 +335,12 @@ extern "C" int rsk_xdrop_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
         a.X = X; a.open = gap_open; a.ext = gap_ext;
         a.rows = d_rows; a.row_off = d_rowoff; a.tb = d_tb; a.tb_off = d_tboff;
         a.score = d_score; a.paths = d_paths; a.path_off = d_pathoff; a.path_start = d_pstart; a.path_len = d_plen;
+        if (trace) RSK_HIP(hipStreamSynchronize(ctx->stream));
+        const auto t_c = now();
         hipLaunchKernelGGL(k_xdrop, dim3((unsigned) ((2 * m + 255) / 256)), dim3(256), 0, ctx->stream, a);
         RSK_HIP(hipGetLastError());
+        if (trace) RSK_HIP(hipStreamSynchronize(ctx->stream));
+        const auto t_d = now();
         std::vector<float> h_score(2 * m);
         std::vector<uint32_t> h_pstart(2 * m), h_plen(2 * m);
         RSK_HIP(hipMemcpyAsync(h_score.data(), d_score, 2 * m * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -344,6 +356,9 @@ extern "C" int rsk_xdrop_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
             bwd_off[r0 + k] = poff + path_off[2 * k + 1] + h_pstart[2 * k + 1];
             bwd_len[r0 + k] = h_plen[2 * k + 1];
         }
+        if (trace)
+            fprintf(stderr, "[rsk_xdrop_pairs] %zu pairs: trace scratch %.2f GB, alloc %.1f ms, h2d + clear %.1f ms, kernel %.1f ms, d2h %.1f ms\n", m,
+                    to / 1073741824.0, ms(t_a, t_b), ms(t_b, t_c), ms(t_c, t_d), ms(t_d, now()));
         poff += po;
         r0 = r1;
     }
