@@ -83,7 +83,8 @@ def main():
     mode = sys.argv[2] if len(sys.argv) > 2 else "sensitive"
     ndb = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     threads = int(sys.argv[4]) if len(sys.argv) > 4 else 1
-    res = compare(n, mode, ndb, threads, keep=os.environ.get("RSK_COMPARE_KEEP"))
+    res = compare(n, mode, ndb, threads, seed=int(os.environ.get("RSK_COMPARE_SEED", "21")), keep=os.environ.get("RSK_COMPARE_KEEP"),
+                  long_chains=int(os.environ.get("RSK_COMPARE_LONG", "0")))
     print(json.dumps(res, indent=1))
     if not res["identical"]:
         sys.exit(1)
