@@ -87,19 +87,6 @@ unsigned HostThreads(unsigned cap)
 }
 
 namespace {
-struct PhaseTimer {                              // RSK_TRACE=1: wall time of the driver's phases on stderr
-    const char *who;
-    bool on = getenv("RSK_TRACE") != nullptr;
-    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-    explicit PhaseTimer(const char *w = "RunPairs") : who(w) {}
-    void lap(const char *what)
-    {
-        if (!on) return;
-        const auto t1 = std::chrono::steady_clock::now();
-        fprintf(stderr, "[%s] %-22s %9.3f ms\n", who, what, std::chrono::duration<double, std::milli>(t1 - t0).count());
-        t0 = t1;
-    }
-};
 }   // namespace
 
 // ProfileLoader::Load profileloader.cpp:72 for a .bca file: read, featurise (host threads), self-rev (GPU batch)

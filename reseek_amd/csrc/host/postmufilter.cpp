@@ -11,6 +11,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <memory>
 #include <atomic>
 #include <cstring>
 #include <mutex>
@@ -65,6 +66,7 @@ void MuPreFilter(const DSSParams &Params, DBSearcher &QDB, DBSearcher &TDB, cons
     size_t qo = 0;
     for (uint i = 0; i < NQ; ++i)
         for (byte l : *QDB.m_DBMuLettersVec[i]) qmu[qo++] = l == 10 ? 11 : (l == 11 ? 10 : l);
+    PhaseTimer tm("MuPreFilter");
     rsk_db *qdb = nullptr;
     check(rsk_db_create(ctx, NQ, qlen.data(), qmu.data(), nullptr, nullptr, nullptr, nullptr, nullptr, &qdb), "rsk_db_create");
     struct db_guard { rsk_db *d; ~db_guard() { rsk_db_destroy(d); } } guard{ qdb };
@@ -92,10 +94,12 @@ void MuPreFilter(const DSSParams &Params, DBSearcher &QDB, DBSearcher &TDB, cons
         if (n <= cap) break;
         cap = n;                               // the count is exact even when the list was truncated
     }
+    tm.lap("index + scan (GPU)");
     size_t nout = 0;
     check(rsk_rsb_select(hq.data(), ht.data(), hs.data(), hq.size(), NQ, QDB.m_Opts.rsb_size, nullptr, nullptr, nullptr, &nout,
                          OutputFN.c_str()),
           "rsk_rsb_select");
+    tm.lap("top-B bags + hand-off");
 }
 
 static bool Accept(const DSSAligner &DA, double MaxEvalue, double MaxPvalue, double MinTS)     // postmufilter.cpp:106-115
@@ -108,6 +112,7 @@ static bool Accept(const DSSAligner &DA, double MaxEvalue, double MaxPvalue, dou
 
 void PostMuFilter(const DSSParams &Params, const std::string &MuFilterTsvFN, DBSearcher &Q, DBSearcher &DB, const std::string &HitsFN)
 {
+    PhaseTimer tm("PostMuFilter");
     const SearchOptions &O = Q.m_Opts;
     double MaxEvalue = 10, MaxPvalue = -1, MinTS = 9e9;                    // postmufilter.cpp:31-33,196-203
     if (O.evalue_set) MaxEvalue = O.evalue;
@@ -148,12 +153,14 @@ void PostMuFilter(const DSSParams &Params, const std::string &MuFilterTsvFN, DBS
         }
     }
     fclose(fin);
+    tm.lap("read hand-off file");
 
     rsk_ctx *ctx = Q.m_Ctx;
     if (!ctx) throw std::runtime_error("PostMuFilter: no GPU context");
     DB.m_Ctx = ctx;
     Q.UploadToGpu();
     DB.UploadToGpu();
+    tm.lap("upload both sets");
     FILE *fTsv = fopen(HitsFN.c_str(), "w");
     if (!fTsv) throw std::runtime_error("PostMuFilter: cannot create " + HitsFN);
     DSSAligner &DA = Q.m_DA;
@@ -183,30 +190,36 @@ void PostMuFilter(const DSSParams &Params, const std::string &MuFilterTsvFN, DBS
         Q.m_MuFilterInputCount = fq.size();
         Q.m_MuFilterDiscardCount = fq.size() - ia.size();
     } else { ia.swap(fq); ib.swap(ft); }
+    tm.lap("Mu filter (pair list)");
     // SetSMx_NoRev + SWFast + CalcEvalue (chainbag.cpp:74-84) in batches
     for (auto &be : AlignBatches(O, Q, DB, ia, ib)) {
         const size_t b = be.first, n = be.second - be.first;
         std::vector<rsk_aln> out(n);
         const size_t bytes = rsk_align_paths_bytes(Q.m_Db, DB.m_Db, ia.data() + b, ib.data() + b, n);
-        std::vector<char> paths(bytes + 1);
+        std::unique_ptr<char[]> paths_buf(new char[bytes + 1]);              // not value-initialised: hundreds of MB per batch
+        char *paths = paths_buf.get();
         check(rsk_align_pairs(ctx, Q.m_Db, DB.m_Db, ia.data() + b, ib.data() + b, n, Params.m_GapOpen, Params.m_GapExt, Params.m_MinFwdScore,
-                              out.data(), paths.data(), bytes),
+                              out.data(), paths, bytes),
               "rsk_align_pairs");
+        Q.m_SWCount += n;
         for (size_t p = 0; p < n; ++p) {
-            ++Q.m_SWCount;
+            // Accept (postmufilter.cpp:106-115) on the batch record: rejected pairs need no string work
+            if (!(out[p].evalue <= MaxEvalue || out[p].pvalue <= MaxPvalue || (out[p].evalue != FLT_MAX && out[p].ts >= MinTS))) continue;
             const uint i = ia[b + p], j = ib[b + p];
             DA.m_ChainA = Q.m_DBChains[i]; DA.m_ProfileA = Q.m_DBProfiles[i];
             DA.m_ChainB = DB.m_DBChains[j]; DA.m_ProfileB = DB.m_DBProfiles[j];
             DA.m_SelfRevScoreA = Q.m_DBSelfRevScores[i]; DA.m_SelfRevScoreB = DB.m_DBSelfRevScores[j];
-            DA.SetFromAln(out[p], paths.data() + out[p].path_off);
+            DA.SetFromAln(out[p], paths + out[p].path_off);
             if (Accept(DA, MaxEvalue, MaxPvalue, MinTS)) { DA.ToTsv(fTsv, true); ++Q.m_HitCount; }
         }
     }
+    tm.lap("align + replay");
     // long chains: MKF (chainbag.cpp:58-65): seeding on the GPU, the rest on host threads
     std::sort(mkf.begin(), mkf.end());
     RunMKFPairs(ctx, Params, O.columns, Q, DB, mkf, [&](DSSAligner &TA, uint, uint) {
         if (Accept(TA, MaxEvalue, MaxPvalue, MinTS)) { TA.ToTsv(fTsv, true); ++Q.m_HitCount; }
     });
+    tm.lap("MKF");
     fclose(fTsv);
 }
 

@@ -15,6 +15,9 @@
 #include <climits>
 #include <cstdint>
 #include <cstdio>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <functional>
 #include <mutex>
 #include <string>
@@ -27,6 +30,20 @@ namespace reseek_amd {
 // Worker threads for per-chain / per-pair host work: min(hardware threads, this process's cgroup CPU quota, cap);
 // RSK_HOST_THREADS overrides.  (Threads beyond the quota only get the whole process throttled.)
 unsigned HostThreads(unsigned cap);
+
+struct PhaseTimer {                              // RSK_TRACE=1: wall time of the driver's phases on stderr
+    const char *who;
+    bool on = getenv("RSK_TRACE") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit PhaseTimer(const char *w = "RunPairs") : who(w) {}
+    void lap(const char *what)
+    {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[%s] %-22s %9.3f ms\n", who, what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
 
 
 typedef unsigned char byte;

@@ -667,18 +667,24 @@ static int musw_run_pairlist(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, con
     const size_t n = sel.size();
     raw.assign(n, 0);
     if (n == 0) return RSK_OK;
-    std::vector<uint32_t> ord(n);
-    for (size_t k = 0; k < n; ++k) ord[k] = (uint32_t) k;
-    std::sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) {
-        const uint32_t px = sel[x], py = sel[y];
-        if (iq[px] != iq[py]) return iq[px] < iq[py];
-        const uint32_t lx = t->len[it[px]], ly = t->len[it[py]];
-        return lx != ly ? lx < ly : px < py;
-    });
-    std::vector<uint32_t> cnt(q->n, 0), rowstart((size_t) q->n + 1, 0), list(n);
-    for (size_t k = 0; k < n; ++k) ++cnt[iq[sel[ord[k]]]];
+    // counting sort by query, then each query's partners by (length, position in the caller's list) on the host worker
+    // threads (one comparison sort over tens of millions of candidates was the whole cost of this call)
+    std::vector<uint32_t> cnt(q->n, 0), rowstart((size_t) q->n + 1, 0), ord(n), list(n);
+    for (size_t k = 0; k < n; ++k) ++cnt[iq[sel[k]]];
     for (uint32_t i = 0; i < q->n; ++i) rowstart[i + 1] = rowstart[i] + cnt[i];
-    for (size_t k = 0; k < n; ++k) list[k] = it[sel[ord[k]]];       // ord is grouped by query already
+    {
+        std::vector<uint32_t> cursor(rowstart.begin(), rowstart.end() - 1);
+        for (size_t k = 0; k < n; ++k) ord[cursor[iq[sel[k]]]++] = (uint32_t) k;
+    }
+    rsk_parallel_for(q->n, 64, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i)
+            std::sort(ord.begin() + rowstart[i], ord.begin() + rowstart[i + 1], [&](uint32_t x, uint32_t y) {
+                const uint32_t px = sel[x], py = sel[y];
+                const uint32_t lx = t->len[it[px]], ly = t->len[it[py]];
+                return lx != ly ? lx < ly : px < py;
+            });
+    });
+    rsk_parallel_for(n, 1 << 16, [&](size_t lo, size_t hi) { for (size_t k = lo; k < hi; ++k) list[k] = it[sel[ord[k]]]; });
     musw_ws ws(ctx);
     uint32_t *d_cnt = nullptr, *d_rowstart = nullptr, *d_list = nullptr;
     uint8_t *d_out = nullptr;
