@@ -27,7 +27,8 @@
 #include "rsk_tables_data.h"
 
 #define PF_THREADS 512
-#define PF_CAP 8192               // keys per chunk held in LDS
+#define PF_CAP 4096               // keys per chunk (hash set of 2 * PF_CAP slots in LDS)
+#define PF_QSPAN 4096             // queries per chunk (64 buckets of 64)
 #define PF_DICT 60466176u         // 36^5
 #define PF_MINSELF 36             // MIN_KMER_PAIR_SCORE prefiltermuparams.h:22
 
@@ -139,6 +140,9 @@ struct pf_args {
     unsigned long long *hits;      // statistics: (TPos, posting) items seen over all targets
     uint32_t t_base;               // first target of this launch (targets are batched by scratch size)
     const uint64_t *koff;          // per target of the launch: offset of its key region in kscratch
+    uint32_t tl_cap;               // target letters staged in LDS up to this length
+    unsigned long long *stat;      // RSK_TRACE: chunks, overflowing buckets, query runs, dense queries, two-hit diagonals, clock cycles of the chunk phase
+    uint32_t dbg;                  // RSK_PF_DEBUG: 1 = stop after the counting pass, 2 = after the scatter pass (timing experiments)
     uint32_t *kscratch;            // keys (q << 14 | diag) of a target, grouped by 64-query bucket (written once, read once)
 };
 
@@ -182,14 +186,15 @@ __global__ __launch_bounds__(256) void k_pf_rowsum(const uint2 *table, const uin
 __global__ __launch_bounds__(PF_THREADS) void k_prefilter(pf_args a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint32_t *keys = (uint32_t *) smem;                                  // PF_CAP
-    uint32_t *score = keys + PF_CAP;                                     // PF_CAP (score of the run head candidates)
-    uint32_t *bucket = score + PF_CAP;                                   // 1025: hits per 64-query bucket
+    uint32_t *keys = (uint32_t *) smem;                                  // 2 * PF_CAP: hash set of a chunk's keys / dense histogram
+    uint32_t *list2 = keys + 2 * PF_CAP;                                 // PF_CAP / 2: the chunk's two-hit (query, diagonal) keys
+    uint32_t *qmax = list2 + PF_CAP / 2;                                 // PF_QSPAN: best diagonal score per query of the chunk
+    uint32_t *bucket = qmax + PF_QSPAN;                                  // 1025: hits per 64-query bucket
     uint32_t *boff = bucket + 1032;                                      // 1025: start of each bucket in this target's key region
     uint32_t *cursor = boff + 1032;                                      // 1024: scatter cursors
     uint32_t *sv = cursor + 1024;                                        // 8 scalars shared by the workgroup
     signed char *mat = (signed char *) (sv + 8);                         // 1296
-    uint8_t *tl = (uint8_t *) (mat + 1312);                              // target letters, up to 65536 + 16
+    uint8_t *tl_lds = (uint8_t *) (mat + 1312);                          // target letters (when they fit: a.tl_cap)
     uint32_t &s_n = sv[0], &s_total = sv[1], &s_chunk_lo = sv[2], &s_chunk_hi = sv[3], &s_more = sv[4];
 
     const int tid = threadIdx.x;
@@ -198,7 +203,11 @@ __global__ __launch_bounds__(PF_THREADS) void k_prefilter(pf_args a)
     uint32_t *kscr = a.kscratch + a.koff[blockIdx.x];
     const uint32_t TL = a.t_len[t];
     const uint8_t *T = a.t_mu + a.t_off[t];
-    for (uint32_t i = tid; i < TL; i += PF_THREADS) tl[i] = T[i];
+    const uint8_t *tl = T;                                               // chains longer than the LDS staging are read in place
+    if (TL <= a.tl_cap) {
+        for (uint32_t i = tid; i < TL; i += PF_THREADS) tl_lds[i] = T[i];
+        tl = tl_lds;
+    }
     __syncthreads();
     if (TL < 7) return;
     const uint32_t NK = TL - 6;
@@ -227,6 +236,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_prefilter(pf_args a)
     __syncthreads();
     if (tid == 0 && a.hits) atomicAdd(a.hits, (unsigned long long) s_total);
     if (s_total < 2) return;
+    if (a.dbg == 1) return;
     // ---- every key goes ONCE to this target's region of the HBM scratch, grouped by bucket (counting sort);
     // the chunks below are then contiguous ranges of it (re-walking the index rows per chunk was quadratic
     // in the hits of a target -- neighbourhood indexes have ~100x the hits of exact k-mers)
@@ -249,124 +259,143 @@ __global__ __launch_bounds__(PF_THREADS) void k_prefilter(pf_args a)
             const uint32_t d = (a.q_len[q] + p - qp - 1) & 0xFFFFu;
             if (d > 16383u) continue;
             const uint32_t pos = atomicAdd(&cursor[q >> 6], 1u);
-            __hip_atomic_store(kscr + pos, (q << 14) | d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            kscr[pos] = (q << 14) | d;        // read back by this workgroup only, after __threadfence + barrier; never read before
         }
     }
     __threadfence();
     __syncthreads();
+    if (a.dbg == 2) return;
 
+    // Kadane over the whole diagonal d of query q (FindHSP prefiltermu.cpp:12, diag.h:51-92), score clamped to u16
+    auto diag_score = [&](uint32_t q, int d) -> uint32_t {
+        const int QL = (int) a.q_len[q];
+        const uint8_t *Q = a.q_mu + a.q_off[q];
+        int i0 = QL - d - 1; if (i0 < 0) i0 = 0;
+        int j0 = d + 1 - QL; if (j0 < 0) j0 = 0;
+        int hi = QL - 1; if (QL + (int) TL - d - 2 < hi) hi = QL + (int) TL - d - 2;
+        const int len = hi - i0 + 1;
+        int F = 0, Bst = 0;
+        for (int k = 0; k < len; ++k) {
+            F += mat[Q[i0 + k] * 36 + tl[j0 + k]];
+            if (F > Bst) Bst = F;
+            else if (F < 0) F = 0;
+        }
+        return (uint32_t) (Bst > 0 ? (Bst >= 65535 ? 65534 : Bst) : 0);
+    };
+    auto emit = [&](uint32_t q, uint32_t best) {
+        const uint32_t pos = atomicAdd(a.out_n, 1u);
+        if (pos < a.capacity) { a.out_q[pos] = q; a.out_t[pos] = t; a.out_score[pos] = best; }
+    };
+    // The keys [k0, k1) of the scratch whose query lies in [qa, qb) (at most PF_CAP of them, qb - qa <= PF_QSPAN):
+    // two-hit diagonals = keys that occur at least twice (twohitdiag.cpp:368-389).  Every key goes into an LDS hash set
+    // (linear probing, load <= 0.5); the FIRST repeat of a key marks its slot and appends the key to list2; then one
+    // thread per two-hit diagonal (dense lanes) scores it, and each query emits its best.  (A bitonic sort of the chunk
+    // did this before: 91 barrier-separated passes over 8192 keys.)  Called by the whole workgroup.
+    auto process_range = [&](uint32_t k0, uint32_t k1, uint32_t qa, uint32_t qb, bool filter) {
+        const uint32_t nqc = qb - qa;
+        for (uint32_t i = tid; i < 2 * PF_CAP; i += PF_THREADS) keys[i] = 0xFFFFFFFFu;
+        for (uint32_t i = tid; i < nqc; i += PF_THREADS) qmax[i] = 0;
+        if (tid == 0) s_n = 0;
+        __syncthreads();
+        for (uint32_t idx = k0 + tid; idx < k1; idx += PF_THREADS) {
+            const uint32_t key = kscr[idx];
+            if (filter && ((key >> 14) < qa || (key >> 14) >= qb)) continue;
+            uint32_t h = (key * 2654435761u) >> 19;                              // 13 bits: 2 * PF_CAP slots
+            for (;;) {
+                const uint32_t old = atomicCAS(&keys[h], 0xFFFFFFFFu, key);
+                if (old == 0xFFFFFFFFu) break;                                   // first occurrence
+                if ((old & 0x7FFFFFFFu) == key) {
+                    if (!(old & 0x80000000u) && !(atomicOr(&keys[h], 0x80000000u) & 0x80000000u)) list2[atomicAdd(&s_n, 1u)] = key;
+                    break;
+                }
+                h = (h + 1) & (2 * PF_CAP - 1);
+            }
+        }
+        __syncthreads();
+        const uint32_t n2 = s_n;
+        if (a.stat && tid == 0) atomicAdd(a.stat + 4, (unsigned long long) n2);
+        for (uint32_t i = tid; i < n2; i += PF_THREADS) {
+            const uint32_t key = list2[i];
+            const uint32_t sc = diag_score(key >> 14, (int) (key & 16383u));
+            if (sc > 0) atomicMax(&qmax[(key >> 14) - qa], sc);
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < nqc; i += PF_THREADS)
+            if (qmax[i] > 0) emit(qa + i, qmax[i]);
+        __syncthreads();
+    };
+    // One query whose keys alone exceed PF_CAP for this target (low-complexity chains): two 16384-bit LDS bitmaps
+    // (diagonal seen once / seen twice) instead of the hash set.
+    auto process_dense_query = [&](uint32_t k0, uint32_t k1, uint32_t q) {
+        uint32_t *seen1 = keys, *seen2 = keys + 512;
+        for (uint32_t i = tid; i < 1024; i += PF_THREADS) seen1[i] = 0;
+        if (tid == 0) s_n = 0;
+        __syncthreads();
+        for (uint32_t idx = k0 + tid; idx < k1; idx += PF_THREADS) {
+            const uint32_t key = kscr[idx];
+            if ((key >> 14) != q) continue;
+            const uint32_t d = key & 16383u, bit = 1u << (d & 31);
+            if (atomicOr(&seen1[d >> 5], bit) & bit) atomicOr(&seen2[d >> 5], bit);
+        }
+        __syncthreads();
+        uint32_t best = 0;
+        for (uint32_t d = tid; d < 16384u; d += PF_THREADS)
+            if ((seen2[d >> 5] >> (d & 31)) & 1u) best = max(best, diag_score(q, (int) d));
+        if (best) atomicMax(&s_n, best);
+        __syncthreads();
+        if (tid == 0 && s_n > 0) emit(q, s_n);
+        __syncthreads();
+    };
+
+    const long long t_chunk0 = a.stat ? (long long) clock64() : 0;
     uint32_t chunk_lo = 0;                    // first bucket of the current chunk
     for (;;) {
-        // thread 0 picks the chunk [chunk_lo, chunk_hi) of buckets with <= PF_CAP hits
+        // thread 0 picks the chunk [chunk_lo, chunk_hi) of buckets with <= PF_CAP keys
         if (tid == 0) {
             uint32_t sum = 0, hi = chunk_lo;
-            while (hi < 1024 && sum + bucket[hi] <= PF_CAP) { sum += bucket[hi]; ++hi; }
+            while (hi < 1024 && hi - chunk_lo < PF_QSPAN / 64 && sum + bucket[hi] <= PF_CAP) { sum += bucket[hi]; ++hi; }
             sv[5] = 0;
-            if (hi == chunk_lo) { sv[5] = 1; hi = chunk_lo + 1; sum = 0; }    // one bucket alone overflows the key array: dense path
-            s_chunk_lo = chunk_lo; s_chunk_hi = hi; s_more = hi < 1024 ? 1u : 0u; s_n = 0;
+            if (hi == chunk_lo) { sv[5] = 1; hi = chunk_lo + 1; sum = bucket[chunk_lo]; }   // one bucket alone exceeds the hash set
+            s_chunk_lo = chunk_lo; s_chunk_hi = hi; s_more = hi < 1024 ? 1u : 0u;
             s_total = sum;
         }
         __syncthreads();
-        const uint32_t qlo = s_chunk_lo << 6, qhi = s_chunk_hi << 6;
-        const uint32_t expect = s_total;
-        if (sv[5]) {
-            // ---- dense path (low-complexity chains): one query at a time, hits counted per diagonal in a
-            // 16384-entry LDS histogram (keys[] and score[] together), no sort.
-            uint32_t *hist = keys;                         // 2 * PF_CAP = 16384 counters
-            for (uint32_t q = qlo; q < min(qhi, a.nq); ++q) {
-                for (uint32_t i = tid; i < 2 * PF_CAP; i += PF_THREADS) hist[i] = 0;
-                if (tid == 0) s_n = 0;
-                __syncthreads();
-                const uint32_t QL = a.q_len[q];
-                for (uint32_t idx = boff[s_chunk_lo] + tid; idx < boff[s_chunk_hi]; idx += PF_THREADS) {
-                    const uint32_t key = __hip_atomic_load(kscr + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((key >> 14) == q) atomicAdd(&hist[key & 16383u], 1u);
-                }
-                __syncthreads();
-                uint32_t best = 0;
-                const uint8_t *Q = a.q_mu + a.q_off[q];
-                for (uint32_t d = tid; d < 2 * PF_CAP; d += PF_THREADS) {
-                    if (hist[d] < 2) continue;
-                    int i0 = (int) QL - (int) d - 1; if (i0 < 0) i0 = 0;
-                    int j0 = (int) d + 1 - (int) QL; if (j0 < 0) j0 = 0;
-                    int hi3 = (int) QL - 1; if ((int) QL + (int) TL - (int) d - 2 < hi3) hi3 = (int) QL + (int) TL - (int) d - 2;
-                    const int len = hi3 - i0 + 1;
-                    int F = 0, Bst = 0;
-                    for (int k = 0; k < len; ++k) {
-                        F += mat[Q[i0 + k] * 36 + tl[j0 + k]];
-                        if (F > Bst) Bst = F;
-                        else if (F < 0) F = 0;
-                    }
-                    if (Bst > 0) best = max(best, (uint32_t) (Bst >= 65535 ? 65534 : Bst));
-                }
-                if (best) atomicMax(&s_n, best);
-                __syncthreads();
-                if (tid == 0 && s_n > 0) {
-                    const uint32_t pos = atomicAdd(a.out_n, 1u);
-                    if (pos < a.capacity) { a.out_q[pos] = q; a.out_t[pos] = t; a.out_score[pos] = s_n; }
-                }
-                __syncthreads();
-            }
-        } else if (expect >= 2) {
-            // ---- the keys of this chunk are one contiguous range of the scratch
-            const uint32_t k0 = boff[s_chunk_lo], k1 = boff[s_chunk_hi];
-            for (uint32_t idx = k0 + tid; idx < k1; idx += PF_THREADS)
-                keys[idx - k0] = __hip_atomic_load(kscr + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (tid == 0) s_n = k1 - k0;
+        const uint32_t qlo = s_chunk_lo << 6, qhi = min(s_chunk_hi << 6, a.nq);
+        const uint32_t expect = s_total, over = sv[5];
+        const uint32_t k0 = boff[s_chunk_lo], k1 = boff[s_chunk_hi];
+        __syncthreads();
+        if (a.stat && tid == 0) { atomicAdd(a.stat + 0, 1ull); if (over) atomicAdd(a.stat + 1, 1ull); }
+        if (!over) {
+            if (expect >= 2) process_range(k0, k1, qlo, qhi, false);
+        } else {
+            // ---- the bucket is cut into runs of queries with <= PF_CAP keys each (its keys are scanned once per run);
+            // a query that exceeds PF_CAP on its own takes the bitmap path
+            uint32_t *qcnt = qmax;                                               // 64 counters (qmax is cleared by process_range)
+            for (uint32_t i = tid; i < 64; i += PF_THREADS) qcnt[i] = 0;
             __syncthreads();
-            const uint32_t n = min(s_n, (uint32_t) PF_CAP);
-            uint32_t np2 = 2;
-            while (np2 < n) np2 <<= 1;
-            for (uint32_t i = n + tid; i < np2; i += PF_THREADS) keys[i] = 0xFFFFFFFFu;
+            for (uint32_t idx = k0 + tid; idx < k1; idx += PF_THREADS) atomicAdd(&qcnt[(kscr[idx] >> 14) - qlo], 1u);
             __syncthreads();
-            // ---- bitonic sort of keys[0..np2)
-            for (uint32_t k2 = 2; k2 <= np2; k2 <<= 1) {
-                for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
-                    for (uint32_t i = tid; i < np2; i += PF_THREADS) {
-                        const uint32_t ixj = i ^ j;
-                        if (ixj > i) {
-                            const uint32_t x = keys[i], y = keys[ixj];
-                            const bool up = (i & k2) == 0;
-                            if ((x > y) == up) { keys[i] = y; keys[ixj] = x; }
-                        }
-                    }
-                    __syncthreads();
+            uint32_t *run_lo = cursor, *run_hi = cursor + 64, *run_dense = cursor + 128;   // the scatter cursors are free now
+            if (tid == 0) {
+                uint32_t nr = 0, q = 0;
+                const uint32_t nqb = qhi - qlo;
+                while (q < nqb) {
+                    if (qcnt[q] > PF_CAP) { run_lo[nr] = q; run_hi[nr] = q + 1; run_dense[nr] = 1; ++nr; ++q; continue; }
+                    uint32_t sum = 0, e = q;
+                    while (e < nqb && qcnt[e] <= PF_CAP && sum + qcnt[e] <= PF_CAP) { sum += qcnt[e]; ++e; }
+                    run_lo[nr] = q; run_hi[nr] = e; run_dense[nr] = sum < 2 ? 2 : 0; ++nr;       // 2 = nothing to do
+                    q = e;
                 }
-            }
-            // ---- two-hit diagonals: first element of every run of >= 2 equal keys; Kadane on the diagonal
-            for (uint32_t i = tid; i < n; i += PF_THREADS) {
-                uint32_t sc = 0;
-                const uint32_t key = keys[i];
-                if (i + 1 < n && keys[i + 1] == key && (i == 0 || keys[i - 1] != key)) {
-                    const uint32_t q = key >> 14;
-                    const int d = (int) (key & 16383u);
-                    const int QL = (int) a.q_len[q];
-                    const uint8_t *Q = a.q_mu + a.q_off[q];
-                    int i0 = QL - d - 1; if (i0 < 0) i0 = 0;                    // diag.h:51-92
-                    int j0 = d + 1 - QL; if (j0 < 0) j0 = 0;
-                    int hi = QL - 1; if (QL + (int) TL - d - 2 < hi) hi = QL + (int) TL - d - 2;
-                    const int len = hi - i0 + 1;
-                    int F = 0, Bst = 0;
-                    for (int k = 0; k < len; ++k) {
-                        F += mat[Q[i0 + k] * 36 + tl[j0 + k]];
-                        if (F > Bst) Bst = F;
-                        else if (F < 0) F = 0;
-                    }
-                    sc = (uint32_t) (Bst > 0 ? (Bst >= 65535 ? 65534 : Bst) : 0);
-                }
-                score[i] = sc;
+                sv[6] = nr;
             }
             __syncthreads();
-            // ---- per query: the head of each run of equal q takes the maximum and emits
-            for (uint32_t i = tid; i < n; i += PF_THREADS) {
-                const uint32_t q = keys[i] >> 14;
-                if (i > 0 && (keys[i - 1] >> 14) == q) continue;
-                uint32_t best = 0;
-                for (uint32_t k = i; k < n && (keys[k] >> 14) == q; ++k) best = max(best, score[k]);
-                if (best > 0) {
-                    const uint32_t pos = atomicAdd(a.out_n, 1u);
-                    if (pos < a.capacity) { a.out_q[pos] = q; a.out_t[pos] = t; a.out_score[pos] = best; }
-                }
+            const uint32_t nr = sv[6];
+            for (uint32_t r = 0; r < nr; ++r) {
+                const uint32_t qa = qlo + run_lo[r], qb = qlo + run_hi[r], kind = run_dense[r];
+                __syncthreads();
+                if (a.stat && tid == 0) atomicAdd(a.stat + (kind == 1 ? 3 : 2), 1ull);
+                if (kind == 1) process_dense_query(k0, k1, qa);
+                else if (kind == 0) process_range(k0, k1, qa, qb, true);
             }
         }
         __syncthreads();
@@ -374,6 +403,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_prefilter(pf_args a)
         chunk_lo = s_chunk_hi;
         __syncthreads();
     }
+    if (a.stat && tid == 0) atomicAdd(a.stat + 5, (unsigned long long) ((long long) clock64() - t_chunk0));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -436,8 +466,8 @@ extern "C" int rsk_mu_prefilter_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db 
     for (uint32_t L : t->len)
         if (L > 65534) { rsk_set_error("rsk_mu_prefilter_dev: target longer than 65534"); return RSK_E_RANGE; }
     uint32_t *d_over = nullptr;
-    RSK_HIP(hipMalloc((void **) &d_over, 16));
-    RSK_HIP(hipMemsetAsync(d_over, 0, 16, ctx->stream));
+    RSK_HIP(hipMalloc((void **) &d_over, 16 + 64));
+    RSK_HIP(hipMemsetAsync(d_over, 0, 16 + 64, ctx->stream));
     RSK_HIP(hipMemsetAsync(d_n, 0, 4, ctx->stream));
     pf_args a = {};
     a.table = (const uint2 *) q->d_pf_table; a.postings = q->d_pf_postings;
@@ -446,10 +476,17 @@ extern "C" int rsk_mu_prefilter_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db 
     a.out_q = d_out_q; a.out_t = d_out_t; a.out_score = d_out_score;
     a.capacity = (uint32_t) std::min<size_t>(capacity, 0xFFFFFFFFu);
     a.out_n = d_n; a.overflow = d_over; a.hits = (unsigned long long *) (d_over + 2);
+    a.stat = getenv("RSK_TRACE") ? (unsigned long long *) (d_over + 4) : nullptr;
     uint32_t maxTL = 0;
     for (uint32_t L : t->len) maxTL = std::max(maxTL, L);
-    const size_t lds = (size_t) PF_CAP * 8 + (1032 + 1032 + 1024 + 8) * 4 + 1312 + (((size_t) maxTL + 31) & ~15u);
-    if (lds > 163000) { rsk_set_error("rsk_mu_prefilter_dev: target of %u residues does not fit the LDS staging", maxTL); (void) hipFree(d_over); return RSK_E_RANGE; }
+    // hash set + two-hit list + per-query maxima + bucket bookkeeping + matrix + target letters (as many as fit; longer
+    // targets are read from HBM in place)
+    const size_t lds_fixed = (size_t) PF_CAP * 8 + (size_t) PF_CAP / 2 * 4 + (size_t) PF_QSPAN * 4 + (1032 + 1032 + 1024 + 8) * 4 + 1312;
+    // two workgroups per CU (their chunk loops are latency-bound): each may use half of the 160 KB
+    const uint32_t tl_cap = (uint32_t) std::min<size_t>(maxTL, (81000 - lds_fixed - 32) & ~(size_t) 15);
+    a.tl_cap = tl_cap;
+    a.dbg = getenv("RSK_PF_DEBUG") ? (uint32_t) atoi(getenv("RSK_PF_DEBUG")) : 0;
+    const size_t lds = lds_fixed + (((size_t) tl_cap + 31) & ~(size_t) 15);
     RSK_HIP(hipFuncSetAttribute((const void *) k_prefilter, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
     RSK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     if (t->n) {
@@ -497,10 +534,15 @@ extern "C" int rsk_mu_prefilter_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db 
     unsigned long long hits = 0;
     RSK_HIP(hipMemcpyAsync(&over, d_over, 4, hipMemcpyDeviceToHost, ctx->stream));
     RSK_HIP(hipMemcpyAsync(&hits, d_over + 2, 8, hipMemcpyDeviceToHost, ctx->stream));
+    unsigned long long stat[8] = { 0 };
+    RSK_HIP(hipMemcpyAsync(stat, d_over + 4, 64, hipMemcpyDeviceToHost, ctx->stream));
     RSK_HIP(hipStreamSynchronize(ctx->stream));
     ctx->pf_hits = hits;
     ctx->pf_postings = q->pf_postings;
-    if (getenv("RSK_TRACE")) fprintf(stderr, "[prefilter] index postings %zu, seed items %llu\n", q->pf_postings, hits);
+    if (getenv("RSK_TRACE"))
+        fprintf(stderr, "[prefilter] index postings %zu, seed items %llu; chunks %llu, overflowing buckets %llu (query runs %llu, dense queries %llu), "
+                        "two-hit diagonals %llu, chunk-phase cycles (100 MHz clock, summed over targets) %llu\n",
+                q->pf_postings, hits, stat[0], stat[1], stat[2], stat[3], stat[4], stat[5]);
     (void) hipFree(d_over);
     if (over) { rsk_set_error("rsk_mu_prefilter_dev: more than %d k-mer hits between one target and 64 consecutive queries", PF_CAP); return RSK_E_RANGE; }
     return RSK_OK;
