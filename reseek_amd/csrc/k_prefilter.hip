@@ -30,6 +30,7 @@
 #define PF_CAP 4096               // keys per chunk (hash set of 2 * PF_CAP slots in LDS)
 #define PF_QSPAN 4096             // queries per chunk (64 buckets of 64)
 #define PF_DICT 60466176u         // 36^5
+#define PF_LONGROW 64             // index rows from this length on are walked by a whole wave
 #define PF_MINSELF 36             // MIN_KMER_PAIR_SCORE prefiltermuparams.h:22
 
 static __device__ __constant__ signed char c_mu_s8[36 * 36];   // Mu_S_ij_i8 (mumx_data.cpp:81)
@@ -212,24 +213,49 @@ __global__ __launch_bounds__(PF_THREADS) void k_prefilter(pf_args a)
     if (TL < 7) return;
     const uint32_t NK = TL - 6;
 
+    // ---- walk of the index rows of this target's k-mers, used twice (count, then scatter).  Row lengths span four
+    // orders of magnitude with neighbourhood indexes; a thread that walked a 10^4-posting row alone kept its wave
+    // busy for milliseconds of dependent latency.  Short rows stay with the thread that owns the position, rows of
+    // >= PF_LONGROW postings are queued in LDS and split over the lanes of a wave (coalesced posting loads).
+    uint32_t *rowq = keys;                                               // (position, start, count) of the queued rows; keys[] is free here
+    const int lane = tid & 63, wid = tid >> 6;
+    auto walk = [&](auto &&item) {
+        for (uint32_t base = 0; base < NK; base += PF_THREADS) {
+            const uint32_t p = base + tid;
+            if (tid == 0) sv[7] = 0;
+            __syncthreads();
+            if (p < NK) {
+                int self;
+                const uint32_t k = pf_kmer(tl + p, self);
+                if (self >= PF_MINSELF) {
+                    const uint2 r = a.table[k];
+                    if (r.y >= PF_LONGROW) {
+                        const uint32_t e = atomicAdd(&sv[7], 1u);
+                        rowq[3 * e] = p; rowq[3 * e + 1] = r.x; rowq[3 * e + 2] = r.y;
+                    } else
+                        for (uint32_t c = 0; c < r.y; ++c) item(p, a.postings[r.x + c]);
+                }
+            }
+            __syncthreads();
+            const uint32_t nrow = sv[7];
+            for (uint32_t e = wid; e < nrow; e += PF_THREADS / 64) {
+                const uint32_t rp = rowq[3 * e], rx = rowq[3 * e + 1], ry = rowq[3 * e + 2];
+                for (uint32_t c = lane; c < ry; c += 64) item(rp, a.postings[rx + c]);
+            }
+            __syncthreads();
+        }
+    };
     // ---- hits per 64-query bucket over the whole target -> chunks of <= PF_CAP keys
     for (int i = tid; i < 1025; i += PF_THREADS) bucket[i] = 0;
     __syncthreads();
     uint32_t my_total = 0;
-    for (uint32_t p = tid; p < NK; p += PF_THREADS) {
-        int self;
-        const uint32_t k = pf_kmer(tl + p, self);
-        if (self < PF_MINSELF) continue;
-        const uint2 r = a.table[k];
-        for (uint32_t c = 0; c < r.y; ++c) {
-            const uint32_t post = a.postings[r.x + c];
-            const uint32_t q = post >> 16, qp = post & 0xFFFFu;
-            const uint32_t d = (a.q_len[q] + p - qp - 1) & 0xFFFFu;
-            if (d > 16383u) continue;
-            atomicAdd(&bucket[q >> 6], 1u);
-            ++my_total;
-        }
-    }
+    walk([&](uint32_t p, uint32_t post) {
+        const uint32_t q = post >> 16, qp = post & 0xFFFFu;
+        const uint32_t d = (a.q_len[q] + p - qp - 1) & 0xFFFFu;
+        if (d > 16383u) return;
+        atomicAdd(&bucket[q >> 6], 1u);
+        ++my_total;
+    });
     if (tid == 0) s_total = 0;
     __syncthreads();
     if (my_total) atomicAdd(&s_total, my_total);
@@ -248,20 +274,13 @@ __global__ __launch_bounds__(PF_THREADS) void k_prefilter(pf_args a)
     __syncthreads();
     for (int i = tid; i < 1024; i += PF_THREADS) cursor[i] = boff[i];
     __syncthreads();
-    for (uint32_t p = tid; p < NK; p += PF_THREADS) {
-        int self;
-        const uint32_t k = pf_kmer(tl + p, self);
-        if (self < PF_MINSELF) continue;
-        const uint2 r = a.table[k];
-        for (uint32_t c = 0; c < r.y; ++c) {
-            const uint32_t post = a.postings[r.x + c];
-            const uint32_t q = post >> 16, qp = post & 0xFFFFu;
-            const uint32_t d = (a.q_len[q] + p - qp - 1) & 0xFFFFu;
-            if (d > 16383u) continue;
-            const uint32_t pos = atomicAdd(&cursor[q >> 6], 1u);
-            kscr[pos] = (q << 14) | d;        // read back by this workgroup only, after __threadfence + barrier; never read before
-        }
-    }
+    walk([&](uint32_t p, uint32_t post) {
+        const uint32_t q = post >> 16, qp = post & 0xFFFFu;
+        const uint32_t d = (a.q_len[q] + p - qp - 1) & 0xFFFFu;
+        if (d > 16383u) return;
+        const uint32_t pos = atomicAdd(&cursor[q >> 6], 1u);
+        kscr[pos] = (q << 14) | d;        // read back by this workgroup only, after __threadfence + barrier; never read before
+    });
     __threadfence();
     __syncthreads();
     if (a.dbg == 2) return;
