@@ -108,6 +108,25 @@ def test_many_hits_forces_lds_chunking(ctx):
     assert as_set(q, t, s) == as_set(oq, ot, os_) and len(oq) == 300 * 6
 
 
+def test_long_targets_and_overflowing_buckets_vs_oracle(ctx):
+    """Paths of k_prefilter that ordinary chains do not reach: targets longer than the LDS letter staging (read in place),
+    a 64-query bucket whose keys exceed the hash set (cut into query runs), and a single query that exceeds it alone
+    (bitmap path); exact and neighbourhood indexes."""
+    rng = np.random.default_rng(8)
+    labels, seqs = fx.read_mu_fasta("scop40.mu.fa.gz")
+    long_t = np.concatenate([seqs[i] for i in range(0, 120)])[:16000]                   # 16,000 letters > staging
+    motif = rng.integers(0, 36, 30).astype(np.uint8)
+    lowc_t = np.tile(motif, 400)[:9000]                                                  # low complexity, long
+    qs = [seqs[i] for i in range(0, 40)]                                                 # real chains (parts of long_t)
+    qs += [np.tile(motif, 12)[: int(L)] for L in rng.integers(200, 360, 70)]             # same bucket as each other: overflow
+    qs += [np.tile(motif, 60)[:1700]]                                                    # one query with > 4096 keys vs lowc_t
+    ts = [long_t, lowc_t, seqs[500], np.tile(motif, 10)[:250]]
+    for mode in (0, 2):
+        q, t, s, _ = run_prefilter(ctx, qs, ts, mode=mode)
+        oq, ot, os_ = ol.prefilter(qs, ts, mode=mode)
+        assert as_set(q, t, s) == as_set(oq, ot, os_) and len(oq) > 100, mode
+
+
 def test_neighbourhood_modes_match_muprefilter(ctx):
     """`-search -fast -db` prefilter (MuPreFilter muprefilter.cpp:70): idxq and idxt neighbourhood modes,
     80 queries x 1000 targets, against the reference's score list and hand-off TSV."""
