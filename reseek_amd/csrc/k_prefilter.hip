@@ -292,13 +292,33 @@ __global__ __launch_bounds__(PF_THREADS) void k_prefilter(pf_args a)
         int i0 = QL - d - 1; if (i0 < 0) i0 = 0;
         int j0 = d + 1 - QL; if (j0 < 0) j0 = 0;
         int hi = QL - 1; if (QL + (int) TL - d - 2 < hi) hi = QL + (int) TL - d - 2;
-        const int len = hi - i0 + 1;
+        int len = hi - i0 + 1;
         int F = 0, Bst = 0;
-        for (int k = 0; k < len; ++k) {
-            F += mat[Q[i0 + k] * 36 + tl[j0 + k]];
+        auto step = [&](uint32_t ql, uint32_t tlet) {
+            F += mat[ql * 36 + tlet];
             if (F > Bst) Bst = F;
             else if (F < 0) F = 0;
+        };
+        const uint8_t *qp = Q + i0, *tp = tl + j0;
+        while (len > 0 && ((uintptr_t) qp & 3)) { step(*qp++, *tp++); --len; }
+        if (len >= 4) {
+            // four residues per iteration: one aligned dword of query letters, the target letters through a sliding pair
+            // of aligned dwords (chains and the LDS staging are padded, reading up to 3 bytes past the end is safe)
+            const uint32_t tsh = (uint32_t) ((uintptr_t) tp & 3);
+            const uint32_t *tw = (const uint32_t *) (tp - tsh);
+            uint32_t ta = *tw++;
+            for (; len >= 4; len -= 4, qp += 4, tp += 4) {
+                const uint32_t qw = *(const uint32_t *) qp;
+                const uint32_t tb = *tw++;
+                const uint32_t t4 = __builtin_amdgcn_alignbyte(tb, ta, tsh);
+                ta = tb;
+                step(qw & 0xFFu, t4 & 0xFFu);
+                step((qw >> 8) & 0xFFu, (t4 >> 8) & 0xFFu);
+                step((qw >> 16) & 0xFFu, (t4 >> 16) & 0xFFu);
+                step(qw >> 24, t4 >> 24);
+            }
         }
+        while (len > 0) { step(*qp++, *tp++); --len; }
         return (uint32_t) (Bst > 0 ? (Bst >= 65535 ? 65534 : Bst) : 0);
     };
     auto emit = [&](uint32_t q, uint32_t best) {
