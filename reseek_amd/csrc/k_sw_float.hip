@@ -606,6 +606,7 @@ __global__ void k_traceback(const uint8_t *tb, const uint64_t *tb_off, const uin
 // One wave per pair.  The reference accumulates, over the column pairs c < c' within R0, (4, thresholds met)
 // into both columns: integer counts, so any order of the additions gives the same per-column fractions.
 #define LDDT_LDS_COLS 256
+#define LDDT_LONG_COLS 4096
 __global__ __launch_bounds__(256) void k_lddt(const char *paths, const uint64_t *path_start, const uint32_t *path_len,
                                               const uint32_t *lo_a, const uint32_t *lo_b, const uint32_t *ia, const uint32_t *ib,
                                               const uint32_t *a_off, const uint32_t *b_off,
@@ -655,6 +656,7 @@ __global__ __launch_bounds__(256) void k_lddt(const char *paths, const uint64_t 
     const float *AX = ax + a_off[ia[p]], *AY = ay + a_off[ia[p]], *AZ = az + a_off[ia[p]];
     const float *BX = bx + b_off[ib[p]], *BY = by + b_off[ib[p]], *BZ = bz + b_off[ib[p]];
     const float R0sq = 15.0f * 15.0f;
+    if (ncols > LDDT_LDS_COLS && ncols <= LDDT_LONG_COLS) return;       // k_lddt_long: a whole workgroup per pair
     const bool in_lds = ncols <= LDDT_LDS_COLS;
     if (in_lds) {
         // Every unordered column pair once: the ncols (ncols - 1) / 2 pairs, row-major (ci < cj), are cut into 64 equal
@@ -754,6 +756,88 @@ __global__ __launch_bounds__(256) void k_lddt(const char *paths, const uint64_t 
     }
 }
 
+
+// Alignments of LDDT_LDS_COLS < columns <= LDDT_LONG_COLS (long homologous chains): the same unordered-pair scheme with a
+// whole workgroup per pair (k_lddt has expanded the path into scratch_pos and left the column count in counts_out).
+// Launched twice over host-built candidate lists: up to 1024 columns (32 KB of LDS) and up to 4096 (128 KB).
+__global__ __launch_bounds__(256) void k_lddt_long(const uint32_t *list, uint32_t nlist, uint32_t cap, const uint32_t *ia, const uint32_t *ib,
+                                                   const uint32_t *a_off, const uint32_t *b_off,
+                                                   const float *ax, const float *ay, const float *az,
+                                                   const float *bx, const float *by, const float *bz,
+                                                   const uint32_t *scratch_pos, const uint64_t *scratch_off,
+                                                   float *lddt_out, const uint32_t *counts_out, const float *score, float min_fwd_score)
+{
+    extern __shared__ float4 lddt_smem[];                               // cap columns: float4, float2, counter, fraction
+    float4 *c4 = lddt_smem;
+    float2 *c2 = (float2 *) (c4 + cap);
+    uint32_t *cnt = (uint32_t *) (c2 + cap);
+    float *frs = (float *) (cnt + cap);
+    if (blockIdx.x >= nlist) return;
+    const uint32_t p = list[blockIdx.x];                                // candidates: min(LA, LB) allows that many columns
+    if (score[p] < min_fwd_score || score[p] == 0.0f) return;
+    const uint32_t C = counts_out[3 * p];
+    if (C <= LDDT_LDS_COLS || C > cap) return;                          // k_lddt did it / the other launch does it
+    const int tid = threadIdx.x;
+    const uint32_t *posA = scratch_pos + 2 * scratch_off[p];
+    const uint32_t *posB = posA + (scratch_off[p + 1] - scratch_off[p]);
+    const float *AX = ax + a_off[ia[p]], *AY = ay + a_off[ia[p]], *AZ = az + a_off[ia[p]];
+    const float *BX = bx + b_off[ib[p]], *BY = by + b_off[ib[p]], *BZ = bz + b_off[ib[p]];
+    for (uint32_t c = tid; c < C; c += 256) {
+        const uint32_t a1 = posA[c], b1 = posB[c];
+        c4[c] = make_float4(AX[a1], AY[a1], AZ[a1], BX[b1]);
+        c2[c] = make_float2(BY[b1], BZ[b1]);
+        cnt[c] = 0;
+    }
+    __syncthreads();
+    const float R0sq = 15.0f * 15.0f;
+    const uint32_t npair = C * (C - 1) / 2, per = (npair + 255) / 256;
+    const uint32_t t0 = (uint32_t) tid * per, t1 = min(npair, t0 + per);
+    if (t0 < t1) {
+        const float twoc = (float) (2 * C - 1);
+        uint32_t ci = (uint32_t) ((twoc - sqrtf(fmaxf(twoc * twoc - 8.0f * (float) t0, 0.0f))) * 0.5f);
+        ci = min(ci, C - 2);
+        while (ci > 0 && ci * (2 * C - ci - 1) / 2 > t0) --ci;
+        while ((ci + 1) * (2 * C - ci - 2) / 2 <= t0) ++ci;
+        uint32_t cj = ci + 1 + (t0 - ci * (2 * C - ci - 1) / 2);
+        float4 p4 = c4[ci];
+        float2 p2 = c2[ci];
+        uint32_t own = 0;
+        for (uint32_t t = t0; t < t1; ++t) {
+            const float4 q4 = c4[cj];
+            const float2 q2 = c2[cj];
+            const float dx = p4.x - q4.x, dy = p4.y - q4.y, dz = p4.z - q4.z;
+            const float ex = p4.w - q4.w, ey = p2.x - q2.x, ez = p2.y - q2.y;
+            float d1s = dx * dx; d1s += dy * dy; d1s += dz * dz;
+            float d2s = ex * ex; d2s += ey * ey; d2s += ez * ez;
+            if (!(d1s > R0sq && d2s > R0sq)) {
+                const float d1 = sqrtf(d1s), d2 = sqrtf(d2s);
+                const float diff = fabsf(d1 - d2);
+                const uint32_t inc = 4u | (((diff <= 0.5f) + (diff <= 1.0f) + (diff <= 2.0f) + (diff <= 4.0f)) << 16);
+                own += inc;
+                atomicAdd(&cnt[cj], inc);
+            }
+            if (++cj == C) {
+                if (own) atomicAdd(&cnt[ci], own);
+                own = 0;
+                ++ci;
+                cj = ci + 1;
+                if (ci < C - 1) { p4 = c4[ci]; p2 = c2[ci]; }
+            }
+        }
+        if (own) atomicAdd(&cnt[ci], own);
+    }
+    __syncthreads();
+    for (uint32_t c = tid; c < C; c += 256) {
+        const uint32_t v = cnt[c], cons = v & 0xFFFFu, pres = v >> 16;
+        frs[c] = cons > 0 ? (float) pres / (float) cons : 0.0f;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float total = 0.0f;
+        for (uint32_t c = 0; c < C; ++c) total += frs[c];      // sequential, column order (lddt.cpp:111-121)
+        lddt_out[p] = total / (float) C;
+    }
+}
 
 // caller-order path packing: out_len[p] = path_len[slot[p]] + 1 is scanned on the device, then one
 // wave per pair copies its path (NUL-terminated) to its final offset.
@@ -954,6 +1038,14 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
     }
     const size_t o_items = hb.add(items.size() * sizeof(swf_item) + 16);
     const size_t o_q0 = hb.add(qitems[0].size() * sizeof(swq_item) + 16), o_q1 = hb.add(qitems[1].size() * sizeof(swq_item) + 16);
+    // pairs (sorted order) whose alignment can exceed the per-wave LDDT staging: min(LA, LB) bounds the aligned columns
+    std::vector<uint32_t> lddt_list[2];
+    if (want_stats && paths)
+        for (size_t k = 0; k < npairs; ++k) {
+            const uint32_t m = std::min(dba->len[ia[ord[k].idx]], dbb->len[ib[ord[k].idx]]);
+            if (m > LDDT_LDS_COLS) lddt_list[m <= 1024 ? 0 : 1].push_back((uint32_t) k);
+        }
+    const size_t o_lddt[2] = { hb.add(lddt_list[0].size() * 4 + 16), hb.add(lddt_list[1].size() * 4 + 16) };
     void *hpin = nullptr;
     if ((rc = rsk_pinned(ctx, 0, hb.bytes, &hpin)) != RSK_OK) return rc;
     char *H = (char *) hpin;
@@ -993,6 +1085,7 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
     memcpy(H + o_items, items.data(), items.size() * sizeof(swf_item));
     memcpy(H + o_q0, qitems[0].data(), qitems[0].size() * sizeof(swq_item));
     memcpy(H + o_q1, qitems[1].data(), qitems[1].size() * sizeof(swq_item));
+    for (int c = 0; c < 2; ++c) memcpy(H + o_lddt[c], lddt_list[c].data(), lddt_list[c].size() * 4);
     tm.lap("offsets+items");
 
     struct ws_t {
@@ -1081,6 +1174,18 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
         hipLaunchKernelGGL(k_lddt, dim3((unsigned) ((npairs + 3) / 4)), dim3(256), 0, ctx->stream, d_paths, d_pstart, d_plen, d_loa, d_lob,
                            d_ia, d_ib, dba->d_off, dbb->d_off, dba->d_x, dba->d_y, dba->d_z, dbb->d_x, dbb->d_y, dbb->d_z,
                            (uint32_t) npairs, d_pos, d_scoff, d_frac, d_lddt, d_counts, d_score, min_fwd_score);
+        for (int c = 0; c < 2; ++c) {
+            const uint32_t nl = (uint32_t) lddt_list[c].size(), cap = c == 0 ? 1024u : (uint32_t) LDDT_LONG_COLS;
+            if (nl == 0) continue;
+            static bool lddt_attr = false;
+            if (!lddt_attr) {
+                RSK_HIP(hipFuncSetAttribute((const void *) k_lddt_long, hipFuncAttributeMaxDynamicSharedMemorySize, LDDT_LONG_COLS * 32));
+                lddt_attr = true;
+            }
+            hipLaunchKernelGGL(k_lddt_long, dim3(nl), dim3(256), (size_t) cap * 32, ctx->stream, (const uint32_t *) (D + o_lddt[c]), nl, cap, d_ia,
+                               d_ib, dba->d_off, dbb->d_off, dba->d_x, dba->d_y, dba->d_z, dbb->d_x, dbb->d_y, dbb->d_z, d_pos, d_scoff, d_lddt,
+                               d_counts, d_score, min_fwd_score);
+        }
         RSK_HIP(hipGetLastError());
     }
     if (paths) {
