@@ -1086,6 +1086,13 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
     memcpy(H + o_q0, qitems[0].data(), qitems[0].size() * sizeof(swq_item));
     memcpy(H + o_q1, qitems[1].data(), qitems[1].size() * sizeof(swq_item));
     for (int c = 0; c < 2; ++c) memcpy(H + o_lddt[c], lddt_list[c].data(), lddt_list[c].size() * 4);
+    if (tm.on) {
+        uint64_t cc[4] = { 0, 0, 0, 0 };
+        for (size_t k = 0; k < npairs; ++k) cc[ord[k].key >> 62] += (uint64_t) dba->len[ia[ord[k].idx]] * dbb->len[ib[ord[k].idx]];
+        fprintf(stderr, "[rsk_align_pairs] classes (pairs / Gcells): qp %u / %.2f, qp-transposed %u / %.2f, per-pair %u / %.2f, per-pair-transposed %u / %.2f\n",
+                cl.first[1] - cl.first[0], cc[0] / 1e9, cl.first[2] - cl.first[1], cc[1] / 1e9, cl.first[3] - cl.first[2], cc[2] / 1e9,
+                cl.first[4] - cl.first[3], cc[3] / 1e9);
+    }
     tm.lap("offsets+items");
 
     struct ws_t {
