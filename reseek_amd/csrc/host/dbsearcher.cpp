@@ -404,12 +404,10 @@ static std::unique_ptr<AlignedBatch> AlignBatch(const DSSParams &P, rsk_ctx *ctx
     return B;
 }
 
-static void ReplayBatch(DBSearcher &S, DBSearcher &SrcA, DBSearcher &SrcB, const AlignedBatch &B, bool Self, uint joff = 0)
+static void ReplayBatch(DBSearcher &S, DBSearcher &SrcA, DBSearcher &SrcB, const std::vector<uint32_t> &ia, const std::vector<uint32_t> &ib,
+                        const std::vector<rsk_aln> &out, const char *paths, bool Self, uint joff = 0)
 {
     const DSSParams &P = *S.m_Params;
-    const std::vector<uint32_t> &ia = B.ia, &ib = B.ib;
-    const std::vector<rsk_aln> &out = B.out;
-    const char *paths = B.paths;
     const size_t n = ia.size();
     if (n == 0) return;
     S.m_SWCount += n;
@@ -491,6 +489,36 @@ std::vector<std::pair<size_t, size_t> > AlignBatches(const SearchOptions &O, con
     }
     if (b < ia.size()) out.emplace_back(b, ia.size());
     return out;
+}
+
+// rsk_align_pairs over the batches of a pair list with the GPU stage of batch k + 1 running while `OnBatch` consumes
+// batch k on the calling thread (RunPairs: hit replay; PostMuFilter: Accept + hit lines).
+void ForEachAlignedBatch(const DSSParams &P, rsk_ctx *ctx, const SearchOptions &O, DBSearcher &SrcA, DBSearcher &SrcB,
+                         const std::vector<uint32_t> &ia, const std::vector<uint32_t> &ib,
+                         const std::function<void(const std::vector<uint32_t> &, const std::vector<uint32_t> &, const std::vector<rsk_aln> &,
+                                                  const char *)> &OnBatch)
+{
+    const auto batches = AlignBatches(O, SrcA, SrcB, ia, ib);
+    PinnedPool Pool;                                                     // outlives every batch of the loop below
+    auto launch = [&](size_t k) {
+        const auto be = batches[k];
+        return std::async(std::launch::async, [&, be]() {
+            return AlignBatch(P, ctx, Pool, SrcA, SrcB, std::vector<uint32_t>(ia.begin() + be.first, ia.begin() + be.second),
+                              std::vector<uint32_t>(ib.begin() + be.first, ib.begin() + be.second));
+        });
+    };
+    std::future<std::unique_ptr<AlignedBatch> > next;
+    if (!batches.empty()) next = launch(0);
+    for (size_t k = 0; k < batches.size(); ++k) {
+        std::unique_ptr<AlignedBatch> cur = next.get();                  // rethrows a failed GPU stage
+        if (k + 1 < batches.size()) next = launch(k + 1);
+        try {
+            OnBatch(cur->ia, cur->ib, cur->out, cur->paths);
+        } catch (...) {
+            if (next.valid()) next.wait();                               // the GPU stage in flight references this frame
+            throw;
+        }
+    }
 }
 
 void RunMKFPairs(rsk_ctx *Ctx, const DSSParams &P, const std::string &Columns, DBSearcher &SrcA, DBSearcher &SrcB,
@@ -741,29 +769,10 @@ static void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOff
     S.m_ProcessedPairCount = npairs;
     S.m_AlnCount = npairs - mkf.size();
     tm.lap("filter + pair lists");
-    {
-        const auto batches = AlignBatches(S.m_Opts, SrcA, S, ia, ib);
-        PinnedPool Pool;                                                     // outlives every batch of the loop below
-        auto launch = [&](size_t k) {
-            const auto be = batches[k];
-            return std::async(std::launch::async, [&, be]() {
-                return AlignBatch(P, ctx, Pool, SrcA, S, std::vector<uint32_t>(ia.begin() + be.first, ia.begin() + be.second),
-                                  std::vector<uint32_t>(ib.begin() + be.first, ib.begin() + be.second));
-            });
-        };
-        std::future<std::unique_ptr<AlignedBatch> > next;
-        if (!batches.empty()) next = launch(0);
-        for (size_t k = 0; k < batches.size(); ++k) {
-            std::unique_ptr<AlignedBatch> cur = next.get();                  // rethrows a failed GPU stage
-            if (k + 1 < batches.size()) next = launch(k + 1);
-            try {
-                ReplayBatch(S, SrcA, S, *cur, Self, joff);
-            } catch (...) {
-                if (next.valid()) next.wait();                               // the GPU stage in flight references this frame
-                throw;
-            }
-        }
-    }
+    ForEachAlignedBatch(P, ctx, S.m_Opts, SrcA, S, ia, ib,
+                        [&](const std::vector<uint32_t> &bia, const std::vector<uint32_t> &bib, const std::vector<rsk_aln> &out, const char *paths) {
+                            ReplayBatch(S, SrcA, S, bia, bib, out, paths, Self, joff);
+                        });
     tm.lap("align + replay");
     // long-chain pairs: host MKF path (dssaligner.cpp:809-813), one aligner per host thread as in the
     // reference (dbsearcher.cpp:98-106); BaseOnAln serialises the output under m_Lock.

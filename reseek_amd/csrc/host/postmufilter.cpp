@@ -192,27 +192,21 @@ void PostMuFilter(const DSSParams &Params, const std::string &MuFilterTsvFN, DBS
     } else { ia.swap(fq); ib.swap(ft); }
     tm.lap("Mu filter (pair list)");
     // SetSMx_NoRev + SWFast + CalcEvalue (chainbag.cpp:74-84) in batches
-    for (auto &be : AlignBatches(O, Q, DB, ia, ib)) {
-        const size_t b = be.first, n = be.second - be.first;
-        std::vector<rsk_aln> out(n);
-        const size_t bytes = rsk_align_paths_bytes(Q.m_Db, DB.m_Db, ia.data() + b, ib.data() + b, n);
-        std::unique_ptr<char[]> paths_buf(new char[bytes + 1]);              // not value-initialised: hundreds of MB per batch
-        char *paths = paths_buf.get();
-        check(rsk_align_pairs(ctx, Q.m_Db, DB.m_Db, ia.data() + b, ib.data() + b, n, Params.m_GapOpen, Params.m_GapExt, Params.m_MinFwdScore,
-                              out.data(), paths, bytes),
-              "rsk_align_pairs");
+    ForEachAlignedBatch(Params, ctx, O, Q, DB, ia, ib,
+                        [&](const std::vector<uint32_t> &bia, const std::vector<uint32_t> &bib, const std::vector<rsk_aln> &out, const char *paths) {
+        const size_t n = bia.size();
         Q.m_SWCount += n;
         for (size_t p = 0; p < n; ++p) {
             // Accept (postmufilter.cpp:106-115) on the batch record: rejected pairs need no string work
             if (!(out[p].evalue <= MaxEvalue || out[p].pvalue <= MaxPvalue || (out[p].evalue != FLT_MAX && out[p].ts >= MinTS))) continue;
-            const uint i = ia[b + p], j = ib[b + p];
+            const uint i = bia[p], j = bib[p];
             DA.m_ChainA = Q.m_DBChains[i]; DA.m_ProfileA = Q.m_DBProfiles[i];
             DA.m_ChainB = DB.m_DBChains[j]; DA.m_ProfileB = DB.m_DBProfiles[j];
             DA.m_SelfRevScoreA = Q.m_DBSelfRevScores[i]; DA.m_SelfRevScoreB = DB.m_DBSelfRevScores[j];
             DA.SetFromAln(out[p], paths + out[p].path_off);
             if (Accept(DA, MaxEvalue, MaxPvalue, MinTS)) { DA.ToTsv(fTsv, true); ++Q.m_HitCount; }
         }
-    }
+    });
     tm.lap("align + replay");
     // long chains: MKF (chainbag.cpp:58-65): seeding on the GPU, the rest on host threads
     std::sort(mkf.begin(), mkf.end());

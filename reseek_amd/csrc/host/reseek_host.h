@@ -354,6 +354,10 @@ private:
 // The MKF path for a list of (A, B) pairs: seeding of every pair on the GPU (rsk_mkf_seed_pairs), chaining +
 // gapped X-drop + statistics of the pairs with a seed HSP on host threads; OnHit is called under a lock
 // for every pair that ends with an alignment (DA.m_Path non-empty is NOT required: the caller decides).
+void ForEachAlignedBatch(const DSSParams &P, rsk_ctx *ctx, const SearchOptions &O, DBSearcher &SrcA, DBSearcher &SrcB,
+                         const std::vector<uint32_t> &ia, const std::vector<uint32_t> &ib,
+                         const std::function<void(const std::vector<uint32_t> &, const std::vector<uint32_t> &, const std::vector<rsk_aln> &,
+                                                  const char *)> &OnBatch);
 void RunMKFPairs(rsk_ctx *Ctx, const DSSParams &Params, const std::string &Columns, DBSearcher &SrcA, DBSearcher &SrcB,
                  const std::vector<std::pair<uint32_t, uint32_t> > &Pairs, const std::function<void(DSSAligner &, uint, uint)> &OnHit);
 
