@@ -683,17 +683,23 @@ static void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOff
     uint64_t npairs = 0;
     if (UseMu) {
         // Mu filter over the whole enumerated pair space on the GPU
-        const size_t ldo = NB;
+        // The kernel keeps one chain's profile in LDS and streams the other set past it.  The Mu matrix is symmetric and
+        // SW(rev(A), B) = SW(A, rev(B)) = SW(rev(B), A), so fwd, rev and the saturation flags do not depend on which chain
+        // plays which role: with a small query set against a large database the queries take the profile side
+        // (125,000 profiles x 256 partners each would rebuild a profile per 26 wave passes).
+        const bool Swap = !Self && NA > NB;
+        rsk_db *FilterQ = Swap ? S.m_Db : SrcA.m_Db, *FilterT = Swap ? SrcA.m_Db : S.m_Db;
+        const size_t ldo = Swap ? NA : NB;
         uint8_t *d_fwd = nullptr;
         uint32_t *d_pq = nullptr, *d_pt = nullptr, *d_n = nullptr;
         const uint64_t total = Self ? SelfTotal : (uint64_t) NA * NB;
         size_t cap = (size_t) std::min<uint64_t>(Tri ? total : (uint64_t) NA * NB, 1ull << 31);
         auto hipok = [](hipError_t e, const char *w) { if (e != hipSuccess) throw std::runtime_error(std::string(w) + ": " + hipGetErrorString(e)); };
-        hipok(hipMalloc((void **) &d_fwd, (size_t) NA * ldo), "hipMalloc fwd");
+        hipok(hipMalloc((void **) &d_fwd, (size_t) (Swap ? NB : NA) * ldo), "hipMalloc fwd");
         hipok(hipMalloc((void **) &d_pq, cap * 4), "hipMalloc pairs");
         hipok(hipMalloc((void **) &d_pt, cap * 4), "hipMalloc pairs");
         hipok(hipMalloc((void **) &d_n, 4), "hipMalloc n");
-        check(rsk_mu_filter_dev(ctx, SrcA.m_Db, S.m_Db, Tri ? 1 : 0, P.m_ParaMuGapOpen, P.m_ParaMuGapExt, P.m_Omega, P.m_OmegaFwd, d_fwd, ldo,
+        check(rsk_mu_filter_dev(ctx, FilterQ, FilterT, Tri ? 1 : 0, P.m_ParaMuGapOpen, P.m_ParaMuGapExt, P.m_Omega, P.m_OmegaFwd, d_fwd, ldo,
                                 d_pq, d_pt, nullptr, nullptr, cap, d_n),
               "rsk_mu_filter_dev");
         uint32_t ns = 0;
@@ -703,6 +709,7 @@ static void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOff
         hipok(hipMemcpy(pq.data(), d_pq, (size_t) ns * 4, hipMemcpyDeviceToHost), "copy pairs");
         hipok(hipMemcpy(pt.data(), d_pt, (size_t) ns * 4, hipMemcpyDeviceToHost), "copy pairs");
         (void) hipFree(d_fwd); (void) hipFree(d_pq); (void) hipFree(d_pt); (void) hipFree(d_n);
+        if (Swap) pq.swap(pt);                                               // back to (A-side, B-side)
         // deterministic order (the device list is unordered)
         // counting sort by the A-side chain, then each chain's partners ascending (on the host worker threads)
         std::vector<uint32_t> first((size_t) NA + 1, 0), partners(ns);
