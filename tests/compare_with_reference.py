@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""End-to-end check against the reference BINARY on a synthetic structure set (GPU box; needs oracle/_ref/reseek, which
+"""TEST INFRASTRUCTURE (lives under tests/ because it executes oracle/_ref/reseek).
+End-to-end check against the reference BINARY on a synthetic structure set (GPU box; needs oracle/_ref/reseek, which
 travels with the snapshot): writes an N-chain .bca (tools/bench_search.py generator), runs
     oracle/_ref/reseek -search syn.bca -<mode> -output ref.tsv -threads T
 and rsk_search on the same file, compares the sorted hit tables line by line and prints both wall times.
-usage: compare_with_reference.py [nchains=1000] [mode=sensitive] [db_chains=0] [threads=1]   (db_chains > 0: -search Q -db DB)
+usage: python tests/compare_with_reference.py [nchains=1000] [mode=sensitive] [db_chains=0] [threads=1]   (db_chains > 0: -search Q -db DB)
 
 threads = 1 is the default on purpose: with several threads the reference binary is not reproducible on sets with
 long-chain (MKF) pairs -- two 16-thread runs of the same command gave 44,193 and 44,195 rows on a 3000-chain set, the
@@ -23,7 +24,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))       # bench_search.py: the synthetic .bca writer
 import bench  # noqa: E402
 import bench_search  # noqa: E402
 import reseek_amd  # noqa: E402

@@ -1,6 +1,6 @@
 """End to end against the reference BINARY itself (oracle/_ref/reseek, built from /root/reference by oracle/Makefile.ref;
 it travels with the snapshot like the built .so): fresh synthetic structure sets that no fixture has seen go through
-`reseek -search` (-threads 1, see tools/compare_with_reference.py for why) and through rsk_search; the sorted hit
+`reseek -search` (-threads 1, see tests/compare_with_reference.py for why) and through rsk_search; the sorted hit
 tables must be identical -- every mode, self and -db, prefilter path and long-chain (MKF / X-drop) pairs included.
 Skipped when the binary did not travel."""
 import os
@@ -19,7 +19,6 @@ REF = os.path.join(ROOT, "oracle", "_ref", "reseek")
 @pytest.mark.parametrize("n,mode,ndb,seed", [(260, "sensitive", 0, 3), (110, "verysensitive", 0, 4), (400, "fast", 0, 5),
                                             (60, "sensitive", 500, 6), (60, "fast", 500, 7)])
 def test_hit_table_equals_the_reference_binary(n, mode, ndb, seed):
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
     import compare_with_reference as cwr
     res = cwr.compare(n, mode, ndb, threads=1, seed=seed, long_chains=4 if mode != "verysensitive" else 0)
     assert res["identical"], res
