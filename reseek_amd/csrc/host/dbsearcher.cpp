@@ -865,15 +865,19 @@ void DSSAligner::AlignQueryTarget()
     rsk_db *a = mk(*m_ChainA, *m_ProfileA, m_MuLettersA, m_SelfRevScoreA), *b = mk(*m_ChainB, *m_ProfileB, m_MuLettersB, m_SelfRevScoreB);
     bool pass = true;
     if (m_Params->m_Omega > 0 && m_MuLettersA && m_MuLettersB) {
-        uint8_t *d_fwd; uint32_t *d_p;
-        hipMalloc((void **) &d_fwd, 16); hipMalloc((void **) &d_p, 16);
-        check(rsk_mu_filter_dev(m_Ctx, a, b, 0, m_Params->m_ParaMuGapOpen, m_Params->m_ParaMuGapExt, m_Params->m_Omega, m_Params->m_OmegaFwd, d_fwd, 1,
-                                d_p, d_p + 1, nullptr, nullptr, 1, d_p + 2),
-              "rsk_mu_filter_dev");
+        auto hipok = [](hipError_t e, const char *w) { if (e != hipSuccess) throw std::runtime_error(std::string(w) + ": " + hipGetErrorString(e)); };
+        uint8_t *d_fwd = nullptr;
+        uint32_t *d_p = nullptr;
+        hipok(hipMalloc((void **) &d_fwd, 16), "hipMalloc");
+        hipok(hipMalloc((void **) &d_p, 16), "hipMalloc");
+        const int rc = rsk_mu_filter_dev(m_Ctx, a, b, 0, m_Params->m_ParaMuGapOpen, m_Params->m_ParaMuGapExt, m_Params->m_Omega, m_Params->m_OmegaFwd,
+                                         d_fwd, 1, d_p, d_p + 1, nullptr, nullptr, 1, d_p + 2);
         uint32_t n = 0;
-        hipMemcpy(&n, d_p + 2, 4, hipMemcpyDeviceToHost);
+        const hipError_t ce = rc == RSK_OK ? hipMemcpy(&n, d_p + 2, 4, hipMemcpyDeviceToHost) : hipSuccess;
+        (void) hipFree(d_fwd); (void) hipFree(d_p);
+        check(rc, "rsk_mu_filter_dev");
+        hipok(ce, "hipMemcpy");
         pass = n > 0;
-        hipFree(d_fwd); hipFree(d_p);
     }
     if (pass) {
         const uint32_t z = 0;
