@@ -62,7 +62,7 @@ struct xd_args {
     const uint32_t *ia, *ib, *lo_a, *lo_b;     // requests
     uint32_t nreq;
     float X, open, ext;
-    float *rows;                     // per extension: Mrow (LB' + 9 floats) then Drow (LB' + 9), at rows + row_off[e]
+    float *rows;                     // per extension: LB' + 9 {Mrow, Drow} float2 records, at rows + row_off[e]
     const uint64_t *row_off;
     uint8_t *tb;                     // per extension: (LA' + 9) x (LB' + 9) trace bytes (zeroed), at tb + tb_off[e]
     const uint64_t *tb_off;
@@ -122,36 +122,46 @@ __global__ __launch_bounds__(256) void k_xdrop(xd_args a)
     }
     const float Open = a.open, Ext = a.ext, X = a.X;
     const float AbsOpen = -Open, AbsExt = -Ext;
-    float *Mrow = a.rows + a.row_off[e] + 1;          // Mrow[-1] is valid
-    float *Drow = Mrow + (LB + 9);
+    // Row state: the reference's Mrow[] / Drow[] interleaved as MD[j] = {Mrow[j], Drow[j]}, so a cell is ONE 8-byte load
+    // and ONE 8-byte store (the kernel is bound by the rate of its scattered memory transactions).  The row extensions
+    // below write single components of other columns; when they hit the current column j they act on the pending values.
+    float2 *MD = (float2 *) (a.rows + a.row_off[e]) + 1;        // MD[-1] is valid
     uint8_t *TB = a.tb + a.tb_off[e];
-    const uint32_t Cols = LB + 1 + 8;                  // XDPMem::Alloc(LA + 1, LB + 1)
-    Mrow[-1] = XD_MINUS_INF;
-    Drow[0] = XD_MINUS_INF;
-    Drow[1] = XD_MINUS_INF;
+    const uint32_t Cols = LB + 1 + 8;                            // XDPMem::Alloc(LA + 1, LB + 1)
+    MD[-1].x = XD_MINUS_INF;
+    MD[0].y = XD_MINUS_INF;
+    MD[1].y = XD_MINUS_INF;
     float BestScore = 0;
     uint32_t Besti = 0, Bestj = 0;
     uint32_t prev_jlo = 0, prev_jhi = 0, jlo = 1, jhi = 1;
     float M0 = BestScore;
     for (uint32_t i = 1; i <= LA; ++i) {
-        if (jlo == prev_jlo) { Mrow[jlo - 1] = XD_MINUS_INF; Drow[jlo] = XD_MINUS_INF; }
+        if (jlo == prev_jlo) { MD[jlo - 1].x = XD_MINUS_INF; MD[jlo].y = XD_MINUS_INF; }
         uint32_t endj = min(prev_jhi + 1, LB);
-        for (uint32_t j = endj + 1; j <= min(jhi + 1, LB); ++j) { Mrow[j - 1] = XD_MINUS_INF; Drow[j] = XD_MINUS_INF; }
+        for (uint32_t j = endj + 1; j <= min(jhi + 1, LB); ++j) { MD[j - 1].x = XD_MINUS_INF; MD[j].y = XD_MINUS_INF; }
         uint32_t next_jlo = 0xFFFFFFFFu, next_jhi = 0xFFFFFFFFu;
         float I0 = XD_MINUS_INF;
         set_row(i);
+        // trace bytes of the row: four consecutive cells that start on a dword boundary go out as one store
+        uint32_t tb_acc = 0, tb_cnt = 0;
+        const size_t tb_row = (size_t) i * Cols;
+        auto tb_flush = [&](size_t next_addr) {                  // bytes [next_addr - tb_cnt, next_addr) are pending
+            for (uint32_t k = 0; k < tb_cnt; ++k) TB[next_addr - tb_cnt + k] = (uint8_t) (tb_acc >> (8 * k));
+            tb_cnt = 0; tb_acc = 0;
+        };
         for (uint32_t j = jlo; j <= jhi; ++j) {
             uint8_t TraceBits = 0;
             const float SavedM0 = M0;
+            const float2 md0 = MD[j];
+            float m_new, d_cur = md0.y;
             // MATCH
             float xM = M0;
-            const float dj = Drow[j];
-            if (dj > xM) { xM = dj; TraceBits = XD_DM; }
+            if (d_cur > xM) { xM = d_cur; TraceBits = XD_DM; }
             if (I0 > xM) { xM = I0; TraceBits = XD_IM; }
-            M0 = Mrow[j];
+            M0 = md0.x;
             float s = sub(j);
             s += xM;
-            Mrow[j] = s;
+            m_new = s;                                           // Mrow[j] = s
             const float h = s - BestScore + X;
             if (h > 0) { next_jlo = min(next_jlo, j + 1); next_jhi = j + 1; }
             if (h > AbsOpen) next_jlo = min(next_jlo, j);
@@ -159,19 +169,21 @@ __global__ __launch_bounds__(256) void k_xdrop(xd_args a)
                 ++jhi;
                 const uint32_t new_endj = max(min(jhi + 1, LB), endj);
                 for (uint32_t j2 = endj + 1; j2 <= new_endj; ++j2) {
-                    if (j2 - 1 > j) Mrow[j2 - 1] = XD_MINUS_INF;
-                    Drow[j2] = XD_MINUS_INF;
+                    if (j2 - 1 > j) MD[j2 - 1].x = XD_MINUS_INF;
+                    if (j2 == j) d_cur = XD_MINUS_INF;           // Drow[j] of the current column: read again below
+                    else MD[j2].y = XD_MINUS_INF;
                 }
                 endj = new_endj;
             }
             if (s >= BestScore) { BestScore = s; Besti = i; Bestj = j; }
             // DELETE
+            float d_new = d_cur;
             if (j != jlo) {
                 const float md = SavedM0 + Open;
-                float d = Drow[j];
+                float d = d_cur;
                 d += Ext;
                 if (md >= d) { d = md; TraceBits |= XD_MD; }
-                Drow[j] = d;
+                d_new = d;                                       // Drow[j] = d
                 const float hd = d - BestScore + X;
                 if (hd > 0) { next_jlo = min(next_jlo, j - 1); next_jhi = max(next_jhi, j - 1); }
             }
@@ -185,29 +197,44 @@ __global__ __launch_bounds__(256) void k_xdrop(xd_args a)
                 if (hi > AbsExt && j == jhi && jhi + 1 < LB) {
                     ++jhi;
                     const uint32_t new_endj = max(min(jhi + 1, LB), endj);
-                    for (uint32_t j2 = endj + 1; j2 <= new_endj; ++j2) { Mrow[j2 - 1] = XD_MINUS_INF; Drow[j2] = XD_MINUS_INF; }
+                    for (uint32_t j2 = endj + 1; j2 <= new_endj; ++j2) {
+                        if (j2 - 1 == j) m_new = XD_MINUS_INF;   // Mrow[j] of the current column, after its store
+                        else MD[j2 - 1].x = XD_MINUS_INF;
+                        if (j2 == j) d_new = XD_MINUS_INF;
+                        else MD[j2].y = XD_MINUS_INF;
+                    }
                     endj = new_endj;
                 }
             }
-            TB[(size_t) i * Cols + j] = TraceBits;
+            MD[j] = make_float2(m_new, d_new);
+            const size_t addr = tb_row + j;
+            const uint32_t off = (uint32_t) ((uintptr_t) (TB + addr) & 3);
+            if (off == tb_cnt) {                                  // continues (or starts, off == 0) an aligned run
+                tb_acc |= (uint32_t) TraceBits << (8 * off);
+                if (++tb_cnt == 4) { *(uint32_t *) (TB + addr - 3) = tb_acc; tb_cnt = 0; tb_acc = 0; }
+            } else {
+                tb_flush(addr);
+                TB[addr] = TraceBits;
+            }
         }
+        tb_flush(tb_row + jhi + 1);
         if (jhi < LB) {                                             // end of Drow[]
             const uint32_t jhi1 = jhi + 1;
             uint8_t t = 0;
             const float md = M0 + Open;
-            float d = Drow[jhi1];
+            float d = MD[jhi1].y;
             d += Ext;
             if (md >= d) { d = md; t = XD_MD; }
-            Drow[jhi1] = d;
-            TB[(size_t) i * Cols + jhi1] = t;
+            MD[jhi1].y = d;
+            TB[tb_row + jhi1] = t;
         }
         if (next_jlo == 0xFFFFFFFFu) break;
         prev_jlo = jlo; prev_jhi = jhi;
         jlo = next_jlo; jhi = next_jhi;
         if (jlo > LB) jlo = LB;
         if (jhi > LB) jhi = LB;
-        if (jlo == prev_jlo) { M0 = XD_MINUS_INF; Drow[jlo] = XD_MINUS_INF; }
-        else M0 = Mrow[jlo - 1];
+        if (jlo == prev_jlo) { M0 = XD_MINUS_INF; MD[jlo].y = XD_MINUS_INF; }
+        else M0 = MD[jlo - 1].x;
     }
     if (BestScore <= 0.0f) { a.score[e] = 0.0f; return; }
     // traceback (xdropfwd.cpp:10-67): stops when the first row or column is reached.  XDropFwd returns the
