@@ -14,7 +14,7 @@ for f in sorted(glob.glob(os.path.join(root, "**", "*.db"), recursive=True)):
     except sqlite3.Error:
         rows = []
     if rows and "trace" in f:
-        print("  kernel stats (ns): name, calls, total, average, pct")
+        print("  kernel stats (us): name, calls, total, average, pct")
         for r in rows[:8]:
             print("   %-60s %5d %14.0f %14.0f %6.2f" % (r[0][:60], r[1], r[2], r[3], r[4]))
     try:
