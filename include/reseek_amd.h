@@ -232,10 +232,14 @@ int rsk_rsb_select(const uint32_t *q, const uint32_t *t, const uint32_t *score, 
  * rsk_dss_featurize: DSS::GetProfile (dss.cpp:716: AA, NENDist, Conf, NENConf, RENDist, DstNxtHlx, StrandDens,
  *   NormDens -> prof[8][L] feature-major) and DSS::GetMuLetters (dss.cpp:700 -> mu[L]) of one chain given its
  *   amino-acid characters and CA coordinates.  prof or mu may be NULL.
+ * rsk_dss_featurize_reversed: the profile of the REVERSED chain (PDBChain::GetReverse pdbchain.cpp:470 + DSS::GetProfile),
+ *   i.e. the target side of GetSelfRevScore (alignpair.cpp:7-24), given the un-reversed chain; position p of the result is
+ *   residue L-1-p.  Same bytes as rsk_dss_featurize on the reversed arrays, without a second round of exp() calls.
  * rsk_bca_info / rsk_bca_read_chain: BCAData::Open / ReadChain (bcadata.cpp:60,191): coordinates are the
  *   quantised floats IC/10.0f - 1000 (pdbchain.h:90).  *L receives the chain length (also on RSK_E_RANGE). */
 int rsk_dss_featurize(const char *seq, const float *x, const float *y, const float *z, uint32_t L, uint8_t *prof,
                       uint8_t *mu);
+int rsk_dss_featurize_reversed(const char *seq, const float *x, const float *y, const float *z, uint32_t L, uint8_t *prof);
 int rsk_bca_info(const char *path, uint64_t *nchains, uint64_t *nresidues, uint32_t *max_len, uint32_t *max_label);
 int rsk_bca_read_chain(const char *path, uint64_t idx, char *label, size_t label_cap, char *seq, float *x, float *y,
                        float *z, uint32_t cap, uint32_t *L);

@@ -59,6 +59,7 @@ SIGNATURES["rsk_search_rskdb"] = (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, 
 
 SIGNATURES["rsk_mu_prefilter_dev"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                                 C.c_size_t, C.c_void_p])
+SIGNATURES["rsk_dss_featurize_reversed"] = (C.c_int, [C.c_char_p, f32p, f32p, f32p, C.c_uint32, C.POINTER(C.c_uint8)])
 SIGNATURES["rsk_dss_featurize"] = (C.c_int, [C.c_char_p, f32p, f32p, f32p, C.c_uint32, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8)])
 SIGNATURES["rsk_bca_info"] = (C.c_int, [C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), u32p, u32p])
 SIGNATURES["rsk_bca_read_chain"] = (C.c_int, [C.c_char_p, C.c_uint64, C.c_char_p, C.c_size_t, C.c_char_p, f32p, f32p, f32p, C.c_uint32, u32p])
@@ -418,6 +419,18 @@ def dss_featurize(seq, x, y, z):
     s = seq.encode() if isinstance(seq, str) else bytes(seq)
     _check(lib().rsk_dss_featurize(s, _p(x, f32p), _p(y, f32p), _p(z, f32p), L, _p(prof, u8p), _p(mu, u8p)))
     return prof, mu
+
+
+def dss_featurize_reversed(seq, x, y, z):
+    """Profile of the reversed chain (target side of GetSelfRevScore) given the un-reversed chain -> uint8 [8, L]."""
+    L = len(seq)
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.ascontiguousarray(y, np.float32)
+    z = np.ascontiguousarray(z, np.float32)
+    prof = np.zeros((8, L), np.uint8)
+    s = seq.encode() if isinstance(seq, str) else bytes(seq)
+    _check(lib().rsk_dss_featurize_reversed(s, _p(x, f32p), _p(y, f32p), _p(z, f32p), L, _p(prof, u8p)))
+    return prof
 
 
 def bca_info(path):

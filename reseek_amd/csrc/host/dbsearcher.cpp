@@ -107,9 +107,13 @@ void DBSearcher::LoadBCA(const std::string &FN)
     const uint N = GetDBChainCount();
     const unsigned T = HostThreads(128);
     std::atomic<uint> next{0};
+    const bool WantRev = !m_Opts.selfrev0 && m_Ctx;
+    m_RevProfiles.clear();
+    if (WantRev) m_RevProfiles.resize(N);
     auto body = [&]() {
-        DSS D;
+        DSS D, DR;
         D.SetParams(*m_Params);
+        DR.SetParams(*m_Params);
         for (;;) {
             const uint i = next.fetch_add(1);
             if (i >= N) return;
@@ -125,6 +129,15 @@ void DBSearcher::LoadBCA(const std::string &FN)
             m_DBProfiles[i]->swap(Prof);
             m_DBMuLettersVec[i]->swap(Mu);
             m_DBMuKmersVec[i]->swap(Kmers);
+            if (WantRev) {
+                // profile of the reversed chain for ComputeSelfRevScores, while D still holds this chain's exp() table
+                PDBChain R;
+                std::vector<std::vector<byte> > RevProf;
+                m_DBChains[i]->GetReverse(R);
+                DR.InitReversed(R, D);
+                DR.GetProfile(RevProf);
+                m_RevProfiles[i].swap(RevProf);
+            }
         }
     };
     std::vector<std::thread> ts;
@@ -155,7 +168,10 @@ void DBSearcher::ComputeSelfRevScores()
     // reversed chains and their profiles
     std::vector<PDBChain> Rev(N);
     std::vector<std::vector<std::vector<byte> > > RevProf(N);
-    {
+    if (m_RevProfiles.size() == N) {
+        // LoadBCA featurised the reversed chains together with the chains (shared exp() tables)
+        RevProf.swap(m_RevProfiles);                                    // (the long chains below reverse themselves)
+    } else {
         const unsigned T = HostThreads(128);
         std::atomic<uint> next{0};
         auto body = [&]() {
@@ -177,6 +193,7 @@ void DBSearcher::ComputeSelfRevScores()
         for (unsigned t = 0; t < T; ++t) ts.emplace_back(body);
         for (auto &t : ts) t.join();
     }
+    m_RevProfiles.clear();
     tm.lap("reverse + featurise");
     std::vector<uint32_t> gpu, mkf;
     for (uint i = 0; i < N; ++i) {
@@ -238,6 +255,7 @@ void DBSearcher::ComputeSelfRevScores()
                 if (k >= mkf.size()) break;
                 const uint32_t i = mkf[k];
                 DA.SetQuery(*m_DBChains[i], m_DBProfiles[i], m_DBMuLettersVec[i], m_DBMuKmersVec[i], FLT_MAX);
+                if (Rev[i].GetSeqLength() == 0) m_DBChains[i]->GetReverse(Rev[i]);
                 DA.SetTarget(Rev[i], &RevProf[i], m_DBMuLettersVec[i], m_DBMuKmersVec[i], FLT_MAX);
                 DA.AlignMKF();
                 m_DBSelfRevScores[i] = DA.m_AlnFwdScore;

@@ -141,6 +141,7 @@ public:
     void SetDensity_ScaledValues();
     double GetDensity(uint Pos);
     void SetDistFactors();
+    void InitReversed(const PDBChain &Rev, DSS &Fwd);   // Init(Rev) + the exp() table mirrored from Fwd (Fwd is on the un-reversed chain)
     double DistFactor(uint Pos, uint Pos2) const      // Pos != Pos2, |Pos - Pos2| <= window
     {
         return Pos2 > Pos ? m_DistFactors[(size_t) Pos * m_DistFactorW + (Pos2 - Pos - 1)] : m_DistFactors[(size_t) Pos2 * m_DistFactorW + (Pos - Pos2 - 1)];
@@ -306,6 +307,7 @@ public:
     std::vector<std::vector<byte> *> m_DBMuLettersVec;
     std::vector<std::vector<uint> *> m_DBMuKmersVec;
     std::vector<float> m_DBSelfRevScores;
+    std::vector<std::vector<std::vector<byte> > > m_RevProfiles;   // LoadBCA -> ComputeSelfRevScores: profiles of the reversed chains
     double m_MaxEvalue = 10;
     uint m_HitCount = 0;
     uint64_t m_ProcessedPairCount = 0;

@@ -41,6 +41,26 @@ def test_bca_reader_and_dss_bytes(bca_dir, name, fixture):
     assert not bad, bad[:10]
 
 
+def test_reversed_chain_profile_shortcut(bca_dir):
+    """rsk_dss_featurize_reversed (exp() table mirrored from the un-reversed chain, used for the self-rev scores) gives
+    the bytes of a full featurisation of the reversed arrays; fixtures + random walks incl. very short and > 2*window chains."""
+    from reseek_amd import capi
+    cases = []
+    for name in ("q10", "q100", "palms"):
+        path = os.path.join(bca_dir, name + ".bca")
+        for i in range(capi.bca_info(path)[0]):
+            cases.append(capi.bca_read_chain(path, i)[1:])
+    rng = np.random.default_rng(17)
+    for L in (1, 2, 3, 7, 13, 14, 27, 51, 52, 101, 102, 203, 640, 1500):
+        seq = "".join("ACDEFGHIKLMNPQRSTVWY"[k] for k in rng.integers(0, 20, L))
+        xyz = np.cumsum(rng.normal(0, 2.2, (3, L)), axis=1).astype(np.float32)
+        cases.append((seq, xyz[0], xyz[1], xyz[2]))
+    for seq, x, y, z in cases:
+        want = capi.dss_featurize(seq[::-1], x[::-1], y[::-1], z[::-1])[0]
+        got = capi.dss_featurize_reversed(seq, x, y, z)
+        assert np.array_equal(got, want), (len(seq), [int((got[f] != want[f]).sum()) for f in range(8)])
+
+
 def test_bca_errors(bca_dir):
     from reseek_amd import capi
     with pytest.raises(capi.RskError):
