@@ -79,6 +79,9 @@ void DSS::Init(const PDBChain &Chain)
     m_RENs.clear();
     m_Density_ScaledValues.clear();
     m_DistFactors.clear();
+    m_ConfLetters.clear();
+    m_DensityValues.clear();
+    m_StrandDensValues.clear();
     m_SSE_Mids.clear();
     m_SSE_cs.clear();
     m_SSEsDone = false;
@@ -157,14 +160,66 @@ uint DSS::CalcREN(uint Pos, uint NEN) const                           // dss.cpp
     return MinPos;
 }
 
+// First index k in [0, n) whose sqrtf(d2[k]) is the smallest (what the running "Dist < MinDist" loops of CalcNEN /
+// CalcREN keep), or -1 when the range is empty or nothing is below the initial MinDist of 999.  sqrtf is monotone, so
+// the smallest distance is sqrtf(min d2); several different d2 can round to that same float, they all lie within a
+// few ulp of the minimum: candidates are d2 <= min * (1 + 1e-6), each confirmed with its own sqrtf.
+static int FirstNearest(const float *d2, int n)
+{
+    if (n <= 0) return -1;
+    float m8[8];
+    for (int l = 0; l < 8; ++l) m8[l] = FLT_MAX;
+    int k = 0;
+    for (; k + 8 <= n; k += 8)
+        for (int l = 0; l < 8; ++l) m8[l] = d2[k + l] < m8[l] ? d2[k + l] : m8[l];
+    float m2 = FLT_MAX;
+    for (; k < n; ++k) m2 = d2[k] < m2 ? d2[k] : m2;
+    for (int l = 0; l < 8; ++l) m2 = m8[l] < m2 ? m8[l] : m2;
+    if (m2 == FLT_MAX) return -1;                                    // every position excluded
+    const float s = sqrtf(m2);
+    if (!((double) s < 999)) return -1;
+    const float thr = m2 + m2 * 1e-6f;
+    for (k = 0; k + 8 <= n; k += 8) {
+        int any = 0;
+        for (int l = 0; l < 8; ++l) any |= d2[k + l] <= thr;
+        if (any) break;
+    }
+    for (; k < n; ++k)
+        if (d2[k] <= thr && sqrtf(d2[k]) == s) return k;
+    return -1;                                                        // not reached: the minimum itself qualifies
+}
+
+// dss.cpp:374-440 for every position (CalcNEN / CalcREN above are the per-position statement of the same): the
+// squared distances of the +-100 window are computed once per position as a vectorisable loop (same float
+// operations per element as GetDist, minus the square root), NEN is the nearest of the whole window, REN the
+// nearest of the part of it on the other side of Pos.
 void DSS::SetNENs()
 {
     if (!m_NENs.empty()) return;
     const uint L = GetSeqLength();
+    const float *X = m_Chain->m_Xs.data(), *Y = m_Chain->m_Ys.data(), *Z = m_Chain->m_Zs.data();
+    std::vector<float> buf((size_t) 2 * m_NEN_W + 16);
+    float *d2 = buf.data();
+    m_NENs.reserve(L);
+    m_RENs.reserve(L);
     for (uint Pos = 0; Pos < L; ++Pos) {
-        const uint NEN = CalcNEN(Pos);
+        const int lo = std::max(0, (int) Pos - m_NEN_W), hi = std::min((int) L - 1, (int) Pos + m_NEN_W), n = hi - lo + 1;
+        const float x = X[Pos], y = Y[Pos], z = Z[Pos];
+        for (int k = 0; k < n; ++k) {
+            const float dx = x - X[lo + k], dy = y - Y[lo + k], dz = z - Z[lo + k];
+            d2[k] = dx * dx + dy * dy + dz * dz;
+        }
+        // |offset| <= m_NEN_w is skipped by both searches
+        const int xlo = std::max(lo, (int) Pos - m_NEN_w), xhi = std::min(hi, (int) Pos + m_NEN_w);
+        for (int q = xlo; q <= xhi; ++q) d2[q - lo] = FLT_MAX;
+        const int kn = FirstNearest(d2, n);
+        if (kn < 0) { m_NENs.push_back(UINT_MAX); m_RENs.push_back(UINT_MAX); continue; }
+        const uint NEN = (uint) (lo + kn);
         m_NENs.push_back(NEN);
-        m_RENs.push_back(CalcREN(Pos, NEN));
+        int kr;
+        if (NEN > Pos) kr = FirstNearest(d2, (int) Pos - lo);                                   // [lo, Pos - 1]
+        else { kr = FirstNearest(d2 + (Pos + 1 - lo), hi - (int) Pos); if (kr >= 0) kr += Pos + 1 - lo; }   // [Pos + 1, hi]
+        m_RENs.push_back(kr < 0 ? UINT_MAX : (uint) (lo + kr));
     }
 }
 
@@ -185,19 +240,46 @@ void DSS::SetDistFactors()
 
 double DSS::GetDensity(uint Pos)                                      // dss.cpp:217-244
 {
+    SetDensities();
+    return m_DensityValues[Pos];
+}
+
+// GetDensity (dss.cpp:217-244) and GetSSDensity(Pos, 's') (dss.cpp:339-372) of every position in one pass over the
+// factor table.  Each of the three sums (density; SS density total and its strand part) adds its terms in ascending
+// Pos2 exactly as the reference's loops do -- the sums are separate dependency chains, so running them side by side
+// hides the latency of the double adds that a single chain is bound by.
+void DSS::SetDensities()
+{
+    if (!m_DensityValues.empty()) return;
+    SetSS();
     SetDistFactors();
     const uint L = GetSeqLength();
-    if (Pos == 0 || Pos + 1 >= L) return DBL_MAX;
-    int iLo = (int) Pos - m_Density_W;
-    if (iLo < 0) iLo = 0;
-    int iHi = (int) Pos + m_Density_W;
-    if (iHi >= (int) L) iHi = (int) L - 1;
-    double D = 0;
-    for (uint Pos2 = (uint) iLo; Pos2 <= (uint) iHi; ++Pos2) {
-        if (Pos2 + m_Density_w >= Pos && Pos2 <= Pos + m_Density_w) continue;
-        D += DistFactor(Pos, Pos2);
+    m_DensityValues.assign(L, DBL_MAX);
+    m_StrandDensValues.assign(L, DBL_MAX);
+    if (m_Density_W != m_SSDensity_W || m_Density_w > m_SSDensity_w) throw std::runtime_error("DSS::SetDensities: unexpected windows");
+    const int W = m_Density_W, w1 = m_Density_w, w2 = m_SSDensity_w, TW = m_DistFactorW;
+    const double *T = m_DistFactors.data();
+    const char *SS = m_SS.data();
+    for (int Pos = 1; Pos + 1 < (int) L; ++Pos) {
+        const int lo = std::max(0, Pos - W), hi = std::min((int) L - 1, Pos + W);
+        double D1 = 0, D2 = 0, Dc = 0;
+        int q = lo;
+        for (; q < Pos - w2; ++q) {                                   // left of both exclusion zones
+            const double F = T[(size_t) q * TW + (Pos - q - 1)];
+            D1 += F; D2 += F;
+            if (SS[q] == 's') Dc += F;
+        }
+        for (; q < Pos - w1; ++q) D1 += T[(size_t) q * TW + (Pos - q - 1)];
+        const double *R = T + (size_t) Pos * TW - Pos - 1;            // R[q] = factor(Pos, q) for q > Pos
+        for (q = Pos + w1 + 1; q <= std::min(hi, Pos + w2); ++q) D1 += R[q];
+        for (; q <= hi; ++q) {
+            const double F = R[q];
+            D1 += F; D2 += F;
+            if (SS[q] == 's') Dc += F;
+        }
+        m_DensityValues[Pos] = D1;
+        m_StrandDensValues[Pos] = Dc / (D2 + m_SSDensity_epsilon);
     }
-    return D;
 }
 
 void DSS::SetDensity_ScaledValues()                                   // dss.cpp:179-215
@@ -221,6 +303,7 @@ void DSS::SetDensity_ScaledValues()                                   // dss.cpp
 
 double DSS::GetSSDensity(uint Pos, char c)                            // dss.cpp:339-372
 {
+    if (c == 's') { SetDensities(); return m_StrandDensValues[Pos]; }
     SetSS();
     SetDistFactors();
     const uint L = GetSeqLength();
@@ -294,6 +377,14 @@ uint DSS::ConfLetter(uint Pos) const
     return Best;
 }
 
+void DSS::SetConfLetters()                                            // Conf of Pos and NENConf of its neighbours read the same letter
+{
+    if (!m_ConfLetters.empty()) return;
+    const uint L = GetSeqLength();
+    m_ConfLetters.resize(L);
+    for (uint Pos = 0; Pos < L; ++Pos) m_ConfLetters[Pos] = ConfLetter(Pos);
+}
+
 static uint SS3(char c)                                              // dss.cpp:64-76: h 0, s 1, t 2, ~ 2, else WILDCARD (0)
 {
     switch (c) {
@@ -319,14 +410,16 @@ uint DSS::GetFeature(uint FeatureIndex, uint Pos)                     // dss.cpp
         return Bin(rsk_bins_NENDist, d);
     }
     case 2: {                                                         // Conf myss.cpp:162-170
-        const uint c = ConfLetter(Pos);
+        SetConfLetters();
+        const uint c = m_ConfLetters[Pos];
         return c == UINT_MAX ? 0 : c;
     }
     case 3: {                                                         // NENConf myss.cpp:172-188
         SetNENs();
         const uint NEN = m_NENs[Pos];
         if (NEN == UINT_MAX) return 0;
-        const uint c = ConfLetter(NEN);
+        SetConfLetters();
+        const uint c = m_ConfLetters[NEN];
         return c == UINT_MAX ? 0 : c;
     }
     case 4: {                                                         // RENDist dss.cpp:521-528

@@ -116,7 +116,8 @@ public:
     std::vector<double> m_Density_ScaledValues;
     std::vector<double> m_DistFactors;                 // [L][W]: exp(-dist(i, i + k + 1) / radius)
     int m_DistFactorW = 0;
-    std::vector<uint> m_NENs, m_RENs;
+    std::vector<uint> m_NENs, m_RENs, m_ConfLetters;
+    std::vector<double> m_DensityValues, m_StrandDensValues;
     std::string m_SS;
     int m_Density_W = 50, m_Density_w = 3, m_SSDensity_W = 50, m_SSDensity_w = 8;     // dss.h:24-37
     double m_Density_Radius = 20.0;
@@ -141,6 +142,8 @@ public:
     void SetDensity_ScaledValues();
     double GetDensity(uint Pos);
     void SetDistFactors();
+    void SetConfLetters();
+    void SetDensities();
     void InitReversed(const PDBChain &Rev, DSS &Fwd);   // Init(Rev) + the exp() table mirrored from Fwd (Fwd is on the un-reversed chain)
     double DistFactor(uint Pos, uint Pos2) const      // Pos != Pos2, |Pos - Pos2| <= window
     {
