@@ -203,19 +203,21 @@ void DBSearcher::ComputeSelfRevScores()
     }
     if (!gpu.empty()) {
         std::vector<uint32_t> len(N);
-        size_t tot = 0;
-        for (uint i = 0; i < N; ++i) { len[i] = m_DBChains[i]->GetSeqLength(); tot += len[i]; }
+        std::vector<size_t> start((size_t) N + 1, 0);
+        for (uint i = 0; i < N; ++i) { len[i] = m_DBChains[i]->GetSeqLength(); start[i + 1] = start[i] + len[i]; }
+        const size_t tot = start[N];
         std::vector<uint8_t> mu(tot), pf(tot * RSK_NFEAT), pr(tot * RSK_NFEAT);
-        size_t o = 0;
-        for (uint i = 0; i < N; ++i) {
-            const uint L = len[i];
-            memcpy(&mu[o], m_DBMuLettersVec[i]->data(), L);
-            for (int f = 0; f < RSK_NFEAT; ++f) {
-                memcpy(&pf[o * RSK_NFEAT + (size_t) f * L], (*m_DBProfiles[i])[f].data(), L);
-                memcpy(&pr[o * RSK_NFEAT + (size_t) f * L], RevProf[i][f].data(), L);
+        rsk_parallel_for(N, 512, [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; ++i) {
+                const uint L = len[i];
+                const size_t o = start[i];
+                memcpy(&mu[o], m_DBMuLettersVec[i]->data(), L);
+                for (int f = 0; f < RSK_NFEAT; ++f) {
+                    memcpy(&pf[o * RSK_NFEAT + (size_t) f * L], (*m_DBProfiles[i])[f].data(), L);
+                    memcpy(&pr[o * RSK_NFEAT + (size_t) f * L], RevProf[i][f].data(), L);
+                }
             }
-            o += L;
-        }
+        });
         tm.lap("pack");
         rsk_db *fdb = nullptr, *rdb = nullptr;
         check(rsk_db_create(m_Ctx, N, len.data(), mu.data(), pf.data(), nullptr, nullptr, nullptr, nullptr, &fdb), "rsk_db_create");
@@ -343,20 +345,22 @@ void DBSearcher::UploadToGpu()
     if (!m_Ctx) throw std::runtime_error("DBSearcher: no GPU context");
     const uint n = GetDBChainCount();
     std::vector<uint32_t> len(n);
-    size_t tot = 0;
-    for (uint i = 0; i < n; ++i) { len[i] = m_DBChains[i]->GetSeqLength(); tot += len[i]; }
+    std::vector<size_t> start((size_t) n + 1, 0);
+    for (uint i = 0; i < n; ++i) { len[i] = m_DBChains[i]->GetSeqLength(); start[i + 1] = start[i] + len[i]; }
+    const size_t tot = start[n];
     std::vector<uint8_t> mu(tot), prof(tot * RSK_NFEAT);
     std::vector<float> x(tot), y(tot), z(tot);
-    size_t o = 0;
-    for (uint i = 0; i < n; ++i) {
-        const uint L = len[i];
-        memcpy(&mu[o], m_DBMuLettersVec[i]->data(), L);
-        for (int f = 0; f < RSK_NFEAT; ++f) memcpy(&prof[o * RSK_NFEAT + (size_t) f * L], (*m_DBProfiles[i])[f].data(), L);
-        memcpy(&x[o], m_DBChains[i]->m_Xs.data(), 4 * (size_t) L);
-        memcpy(&y[o], m_DBChains[i]->m_Ys.data(), 4 * (size_t) L);
-        memcpy(&z[o], m_DBChains[i]->m_Zs.data(), 4 * (size_t) L);
-        o += L;
-    }
+    rsk_parallel_for(n, 512, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) {
+            const uint L = len[i];
+            const size_t o = start[i];
+            memcpy(&mu[o], m_DBMuLettersVec[i]->data(), L);
+            for (int f = 0; f < RSK_NFEAT; ++f) memcpy(&prof[o * RSK_NFEAT + (size_t) f * L], (*m_DBProfiles[i])[f].data(), L);
+            memcpy(&x[o], m_DBChains[i]->m_Xs.data(), 4 * (size_t) L);
+            memcpy(&y[o], m_DBChains[i]->m_Ys.data(), 4 * (size_t) L);
+            memcpy(&z[o], m_DBChains[i]->m_Zs.data(), 4 * (size_t) L);
+        }
+    });
     check(rsk_db_create(m_Ctx, n, len.data(), mu.data(), prof.data(), x.data(), y.data(), z.data(), m_DBSelfRevScores.data(), &m_Db),
           "rsk_db_create");
 }

@@ -207,31 +207,62 @@ extern "C" int rsk_db_create(rsk_ctx *ctx, uint32_t n, const uint32_t *lengths, 
     int rc;
     if ((rc = dev_upload(&db->d_len, db->len.data(), n, db->hbm_bytes)) != RSK_OK) return rc;
     if ((rc = dev_upload(&db->d_off, db->off.data(), (size_t) n + 1, db->hbm_bytes)) != RSK_OK) return rc;
+    // packing into the padded device layout runs on the host threads, chains are independent (src[i] = residues before chain i)
+    std::vector<uint64_t> src((size_t) n + 1, 0);
+    for (uint32_t i = 0; i < n; ++i) src[i + 1] = src[i] + lengths[i];
     if (mu) {
         db->h_mu.assign((size_t) o + 64, (uint8_t) RSK_MU_NULL);
-        uint64_t src = 0;
-        for (uint32_t i = 0; i < n; ++i) {
-            for (uint32_t k = 0; k < lengths[i]; ++k) {
-                uint8_t c = mu[src + k];
-                if (c >= RSK_MU_ALPHA) { rsk_set_error("rsk_db_create: Mu letter %u out of range in chain %u", c, i); delete db; return RSK_E_INVALID; }
-                db->h_mu[db->off[i] + k] = c;
+        std::atomic<uint32_t> bad{UINT32_MAX};
+        rsk_parallel_for(n, 512, [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; ++i) {
+                const uint8_t *row = mu + src[i];
+                uint8_t mx = 0;
+                for (uint32_t k = 0; k < lengths[i]; ++k) mx = row[k] > mx ? row[k] : mx;
+                if (mx >= RSK_MU_ALPHA) {
+                    uint32_t cur = bad.load();
+                    while ((uint32_t) i < cur && !bad.compare_exchange_weak(cur, (uint32_t) i)) {}
+                    continue;
+                }
+                memcpy(&db->h_mu[db->off[i]], row, lengths[i]);
             }
-            src += lengths[i];
+        });
+        if (bad.load() != UINT32_MAX) {
+            const uint32_t i = bad.load();
+            uint8_t c = 0;
+            for (uint32_t k = 0; k < lengths[i] && c < RSK_MU_ALPHA; ++k) c = mu[src[i] + k];
+            rsk_set_error("rsk_db_create: Mu letter %u out of range in chain %u", c, i);
+            delete db;
+            return RSK_E_INVALID;
         }
         if ((rc = dev_upload(&db->d_mu, db->h_mu.data(), db->h_mu.size(), db->hbm_bytes)) != RSK_OK) return rc;
     }
     if (prof) {
         std::vector<uint8_t> hp((size_t) RSK_NFEAT * o, 0);
-        uint64_t src = 0;
-        for (uint32_t i = 0; i < n; ++i) {
-            for (int f = 0; f < RSK_NFEAT; ++f) {
-                const uint8_t *row = prof + src + (size_t) f * lengths[i];
-                uint8_t mx = 0;
-                for (uint32_t k = 0; k < lengths[i]; ++k) mx = row[k] > mx ? row[k] : mx;
-                if (mx >= (f == 0 ? 20 : 16)) { rsk_set_error("rsk_db_create: profile letter %u out of range (chain %u feature %d)", mx, i, f); delete db; return RSK_E_INVALID; }
-                memcpy(&hp[(size_t) f * o + db->off[i]], row, lengths[i]);
-            }
-            src += (uint64_t) RSK_NFEAT * lengths[i];
+        std::atomic<uint64_t> bad{UINT64_MAX};                        // (chain << 8) | feature of the first offender
+        rsk_parallel_for(n, 512, [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; ++i)
+                for (int f = 0; f < RSK_NFEAT; ++f) {
+                    const uint8_t *row = prof + (uint64_t) RSK_NFEAT * src[i] + (size_t) f * lengths[i];
+                    uint8_t mx = 0;
+                    for (uint32_t k = 0; k < lengths[i]; ++k) mx = row[k] > mx ? row[k] : mx;
+                    if (mx >= (f == 0 ? 20 : 16)) {
+                        const uint64_t key = ((uint64_t) i << 8) | (uint64_t) f;
+                        uint64_t cur = bad.load();
+                        while (key < cur && !bad.compare_exchange_weak(cur, key)) {}
+                        continue;
+                    }
+                    memcpy(&hp[(size_t) f * o + db->off[i]], row, lengths[i]);
+                }
+        });
+        if (bad.load() != UINT64_MAX) {
+            const uint32_t i = (uint32_t) (bad.load() >> 8);
+            const int f = (int) (bad.load() & 255);
+            const uint8_t *row = prof + (uint64_t) RSK_NFEAT * src[i] + (size_t) f * lengths[i];
+            uint8_t mx = 0;
+            for (uint32_t k = 0; k < lengths[i]; ++k) mx = row[k] > mx ? row[k] : mx;
+            rsk_set_error("rsk_db_create: profile letter %u out of range (chain %u feature %d)", mx, i, f);
+            delete db;
+            return RSK_E_INVALID;
         }
         if ((rc = dev_upload(&db->d_prof, hp.data(), hp.size(), db->hbm_bytes)) != RSK_OK) return rc;
         // the float-SW kernels read letter * 4 (column offsets) and letter * alphabet * 4 (row offsets) per feature,
@@ -249,13 +280,13 @@ extern "C" int rsk_db_create(rsk_ctx *ctx, uint32_t n, const uint32_t *lengths, 
     }
     if (x) {
         std::vector<float> hx((size_t) o, 0.f), hy((size_t) o, 0.f), hz((size_t) o, 0.f);
-        uint64_t src = 0;
-        for (uint32_t i = 0; i < n; ++i) {
-            memcpy(&hx[db->off[i]], x + src, 4 * (size_t) lengths[i]);
-            memcpy(&hy[db->off[i]], y + src, 4 * (size_t) lengths[i]);
-            memcpy(&hz[db->off[i]], z + src, 4 * (size_t) lengths[i]);
-            src += lengths[i];
-        }
+        rsk_parallel_for(n, 512, [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; ++i) {
+                memcpy(&hx[db->off[i]], x + src[i], 4 * (size_t) lengths[i]);
+                memcpy(&hy[db->off[i]], y + src[i], 4 * (size_t) lengths[i]);
+                memcpy(&hz[db->off[i]], z + src[i], 4 * (size_t) lengths[i]);
+            }
+        });
         if ((rc = dev_upload(&db->d_x, hx.data(), hx.size(), db->hbm_bytes)) != RSK_OK) return rc;
         if ((rc = dev_upload(&db->d_y, hy.data(), hy.size(), db->hbm_bytes)) != RSK_OK) return rc;
         if ((rc = dev_upload(&db->d_z, hz.data(), hz.size(), db->hbm_bytes)) != RSK_OK) return rc;
