@@ -239,6 +239,9 @@ int rsk_rsb_select(const uint32_t *q, const uint32_t *t, const uint32_t *score, 
  *   quantised floats IC/10.0f - 1000 (pdbchain.h:90).  *L receives the chain length (also on RSK_E_RANGE). */
 int rsk_dss_featurize(const char *seq, const float *x, const float *y, const float *z, uint32_t L, uint8_t *prof,
                       uint8_t *mu);
+/* Self-test of the hit-line number formatting ("%.1f", "%.3g" fast paths of DSSAligner::WriteUserField userfields.cpp:45)
+ * against snprintf on n pseudo-random values: returns the number of differing strings (0 expected). Host code. */
+uint64_t rsk_selftest_format(uint64_t seed, uint64_t n);
 int rsk_dss_featurize_reversed(const char *seq, const float *x, const float *y, const float *z, uint32_t L, uint8_t *prof);
 int rsk_bca_info(const char *path, uint64_t *nchains, uint64_t *nresidues, uint32_t *max_len, uint32_t *max_label);
 int rsk_bca_read_chain(const char *path, uint64_t idx, char *label, size_t label_cap, char *seq, float *x, float *y,

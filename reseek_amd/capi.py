@@ -59,6 +59,7 @@ SIGNATURES["rsk_search_rskdb"] = (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, 
 
 SIGNATURES["rsk_mu_prefilter_dev"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                                 C.c_size_t, C.c_void_p])
+SIGNATURES["rsk_selftest_format"] = (C.c_uint64, [C.c_uint64, C.c_uint64])
 SIGNATURES["rsk_dss_featurize_reversed"] = (C.c_int, [C.c_char_p, f32p, f32p, f32p, C.c_uint32, C.POINTER(C.c_uint8)])
 SIGNATURES["rsk_dss_featurize"] = (C.c_int, [C.c_char_p, f32p, f32p, f32p, C.c_uint32, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8)])
 SIGNATURES["rsk_bca_info"] = (C.c_int, [C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), u32p, u32p])

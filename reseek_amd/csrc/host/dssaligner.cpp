@@ -17,6 +17,8 @@
 #include "reseek_host.h"
 #include "../rsk_tables_data.h"
 
+void rsk_set_error(const char *fmt, ...);
+
 namespace reseek_amd {
 
 static const float MINUS_INFINITY = -9e9f;   // xdpmem.h:6
@@ -851,6 +853,106 @@ void DSSAligner::GetRow_B(std::string &Row, bool Global) const
     }
 }
 
+// printf("%.1f") and printf("%.3g") of the values hit lines carry (percent identity, coverage, P-value, scores): two
+// snprintf calls were a third of the per-row cost of a 90-million-row -verysensitive output.  The fast paths scale the
+// value by an exactly representable power of ten (one rounding, relative error 2^-53), so the scaled value is off by
+// < 1e-12; whenever it lies within 1e-6 of a rounding boundary -- or the value is outside the range handled --
+// snprintf decides.  The text is therefore printf's in every case (rsk_selftest_format compares them at random).
+static const double kP10[23] = { 1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20,
+                                 1e21, 1e22 };
+
+static void AppendFixed1(std::string &out, double x)                  // "%.1f"
+{
+    if (x >= 0 && x < 1e5 && !std::signbit(x)) {
+        const double s = x * 10.0, fl = floor(s), fr = s - fl;
+        if (fabs(fr - 0.5) >= 1e-6) {
+            uint32_t n = (uint32_t) fl + (fr > 0.5 ? 1u : 0u);
+            char b[16];
+            int k = 16;
+            b[--k] = (char) ('0' + n % 10); n /= 10;
+            b[--k] = '.';
+            do { b[--k] = (char) ('0' + n % 10); n /= 10; } while (n);
+            out.append(b + k, (size_t) (16 - k));
+            return;
+        }
+    }
+    char tmp[64];
+    const int k = snprintf(tmp, sizeof(tmp), "%.1f", x);
+    out.append(tmp, (size_t) k);
+}
+
+static void AppendG3(std::string &out, double x)                      // "%.3g"
+{
+    if (x >= 1e-20 && x < 1000) {
+        int E = (int) floor(log10(x));
+        if (E >= -20 && E <= 2) {
+            double s = x * kP10[2 - E];
+            if (s < 100 && E > -20) { --E; s = x * kP10[2 - E]; }
+            else if (s >= 1000 && E < 2) { ++E; s = x * kP10[2 - E]; }
+            if (s >= 100 && s < 999.4) {
+                const double fl = floor(s), fr = s - fl;
+                if (fabs(fr - 0.5) >= 1e-6) {
+                    const uint32_t d = (uint32_t) fl + (fr > 0.5 ? 1u : 0u);          // 100..999
+                    char dg[3] = { (char) ('0' + d / 100), (char) ('0' + d / 10 % 10), (char) ('0' + d % 10) };
+                    int nd = 3;
+                    while (nd > 1 && dg[nd - 1] == '0') --nd;                         // %g drops trailing zeros
+                    char b[32];
+                    int k = 0;
+                    if (E < -4) {                                                     // d.dde-XX
+                        b[k++] = dg[0];
+                        if (nd > 1) { b[k++] = '.'; for (int q = 1; q < nd; ++q) b[k++] = dg[q]; }
+                        b[k++] = 'e'; b[k++] = '-';
+                        const int a = -E;
+                        b[k++] = (char) ('0' + a / 10); b[k++] = (char) ('0' + a % 10);
+                    } else if (E < 0) {                                               // 0.000ddd
+                        b[k++] = '0'; b[k++] = '.';
+                        for (int q = 0; q < -E - 1; ++q) b[k++] = '0';
+                        for (int q = 0; q < nd; ++q) b[k++] = dg[q];
+                    } else {                                                          // E + 1 digits before the point
+                        for (int q = 0; q <= E; ++q) b[k++] = dg[q];
+                        if (nd > E + 1) { b[k++] = '.'; for (int q = E + 1; q < nd; ++q) b[k++] = dg[q]; }
+                    }
+                    out.append(b, (size_t) k);
+                    return;
+                }
+            }
+        }
+    }
+    char tmp[64];
+    const int k = snprintf(tmp, sizeof(tmp), "%.3g", x);
+    out.append(tmp, (size_t) k);
+}
+
+// Self-test of the two formatters against snprintf: n values from the distributions hit lines see (ratios of small
+// integers times 100, floats of every decade from 1e-25 to 1e4, decimal ties and their neighbours).  Returns the number
+// of differing strings (0 expected); the first difference goes to rsk_last_error.
+extern "C" uint64_t rsk_selftest_format(uint64_t seed, uint64_t n)
+{
+    uint64_t st = seed * 0x9E3779B97F4A7C15ull + 1, bad = 0;
+    auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
+    char t1[64], t2[64];
+    std::string a;
+    for (uint64_t it = 0; it < n; ++it) {
+        double x;
+        const uint64_t r = rnd();
+        switch (r & 7) {
+        case 0: { const uint64_t den = 1 + (rnd() % 2000); x = 100.0 * (double) (rnd() % (den + 1)) / (double) den; break; }        // percent identity
+        case 1: x = (double) (float) pow(10.0, -25.0 + 29.0 * (double) (rnd() >> 11) * (1.0 / 9007199254740992.0)); break;        // floats, every decade
+        case 2: x = pow(10.0, -25.0 + 29.0 * (double) (rnd() >> 11) * (1.0 / 9007199254740992.0)); break;
+        case 3: x = ((double) (rnd() % 20000) + 0.5) / 10.0; break;                                                                // "%.1f" ties
+        case 4: x = (double) (float) (((double) (rnd() % 20000) + 0.5) / 10.0); break;
+        case 5: { const int e = (int) (rnd() % 24) - 21; x = ((double) (100 + rnd() % 900) + 0.5) * pow(10.0, e - 2); break; }       // "%.3g" ties
+        case 6: { const int e = (int) (rnd() % 24) - 21; x = (double) (float) ((double) (100 + rnd() % 900) * pow(10.0, e - 2)); break; }   // powers of ten, 9995...
+        default: x = (double) (rnd() % 100001) / 1000.0; if (rnd() & 1) x = nextafter(x, (rnd() & 2) ? 1e9 : -1e9); break;
+        }
+        a.clear(); AppendFixed1(a, x); snprintf(t1, sizeof(t1), "%.1f", x);
+        if (a != t1) { if (!bad) rsk_set_error("rsk_selftest_format: %%.1f of %.17g: \"%s\" vs printf \"%s\"", x, a.c_str(), t1); ++bad; }
+        a.clear(); AppendG3(a, x); snprintf(t2, sizeof(t2), "%.3g", x);
+        if (a != t2) { if (!bad) rsk_set_error("rsk_selftest_format: %%.3g of %.17g: \"%s\" vs printf \"%s\"", x, a.c_str(), t2); ++bad; }
+    }
+    return bad;
+}
+
 static const char *EvalueToStr(double E, char *buf, size_t n)
 {
     if (E > 10) E = 99;
@@ -871,7 +973,12 @@ void DSSAligner::AppendUserField(std::string &out, USERFIELD UF, bool Up)
         do { b[--k] = (char) ('0' + v % 10); v /= 10; } while (v);
         out.append(b + k, (size_t) (12 - k));
     };
-    auto f = [&](const char *fmt, double v) { const int k = snprintf(tmp, sizeof(tmp), fmt, v); out.append(tmp, (size_t) k); };
+    auto f = [&](const char *fmt, double v) {
+        if (fmt[2] == '1') return AppendFixed1(out, v);                   // "%.1f"
+        if (fmt[2] == '3') return AppendG3(out, v);                       // "%.3g"
+        const int k = snprintf(tmp, sizeof(tmp), fmt, v);
+        out.append(tmp, (size_t) k);
+    };
     switch (UF) {
     case UF_query: out += GetLabel(Up); break;
     case UF_target: out += GetLabel(!Up); break;
