@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <deque>
 #include <chrono>
 #include <future>
 #include <cstdlib>
@@ -522,22 +523,39 @@ void ForEachAlignedBatch(const DSSParams &P, rsk_ctx *ctx, const SearchOptions &
 {
     const auto batches = AlignBatches(O, SrcA, SrcB, ia, ib);
     PinnedPool Pool;                                                     // outlives every batch of the loop below
+    // Two GPU stages in flight (batches k + 1 and k + 2 while k is replayed), each on a context of its own (stream,
+    // device pool, staging buffers): the host part of rsk_align_pairs (grouping the pairs, work items, statistics) is
+    // a quarter of a stage, with a single stage in flight the GPU idles through it.  The chain sets are read-only here.
+    struct ctx_guard { rsk_ctx *c = nullptr; ~ctx_guard() { if (c) rsk_ctx_destroy(c); } } second;
+    const int inflight = getenv("RSK_ALIGN_INFLIGHT") ? std::max(1, std::min(2, atoi(getenv("RSK_ALIGN_INFLIGHT")))) : 2;
+    if (inflight > 1 && batches.size() >= 3) check(rsk_ctx_create(ctx->device, &second.c), "rsk_ctx_create");
     auto launch = [&](size_t k) {
         const auto be = batches[k];
-        return std::async(std::launch::async, [&, be]() {
-            return AlignBatch(P, ctx, Pool, SrcA, SrcB, std::vector<uint32_t>(ia.begin() + be.first, ia.begin() + be.second),
+        rsk_ctx *c = (second.c && (k & 1)) ? second.c : ctx;
+        return std::async(std::launch::async, [&, be, c]() {
+            return AlignBatch(P, c, Pool, SrcA, SrcB, std::vector<uint32_t>(ia.begin() + be.first, ia.begin() + be.second),
                               std::vector<uint32_t>(ib.begin() + be.first, ib.begin() + be.second));
         });
     };
-    std::future<std::unique_ptr<AlignedBatch> > next;
-    if (!batches.empty()) next = launch(0);
+    std::deque<std::future<std::unique_ptr<AlignedBatch> > > q;
+    size_t launched = 0;
+    auto drain = [&]() { for (auto &f : q) if (f.valid()) f.wait(); };   // stages in flight reference this frame
+    if (!batches.empty()) q.push_back(launch(launched++));               // the first stage runs alone (one-time table uploads)
     for (size_t k = 0; k < batches.size(); ++k) {
-        std::unique_ptr<AlignedBatch> cur = next.get();                  // rethrows a failed GPU stage
-        if (k + 1 < batches.size()) next = launch(k + 1);
+        std::unique_ptr<AlignedBatch> cur;
+        try {
+            cur = q.front().get();                                       // rethrows a failed GPU stage
+        } catch (...) {
+            q.pop_front();
+            drain();
+            throw;
+        }
+        q.pop_front();
+        while (launched < batches.size() && q.size() < (second.c ? 2u : 1u)) q.push_back(launch(launched++));
         try {
             OnBatch(cur->ia, cur->ib, cur->out, cur->paths);
         } catch (...) {
-            if (next.valid()) next.wait();                               // the GPU stage in flight references this frame
+            drain();
             throw;
         }
     }
