@@ -816,20 +816,57 @@ static void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOff
     S.m_ProcessedPairCount = npairs;
     S.m_AlnCount = npairs - mkf.size();
     tm.lap("filter + pair lists");
-    ForEachAlignedBatch(P, ctx, S.m_Opts, SrcA, S, ia, ib,
-                        [&](const std::vector<uint32_t> &bia, const std::vector<uint32_t> &bib, const std::vector<rsk_aln> &out, const char *paths) {
-                            ReplayBatch(S, SrcA, S, bia, bib, out, paths, Self, joff);
-                        });
-    tm.lap("align + replay");
-    // long-chain pairs: host MKF path (dssaligner.cpp:809-813), one aligner per host thread as in the
-    // reference (dbsearcher.cpp:98-106); BaseOnAln serialises the output under m_Lock.
-    RunMKFPairs(ctx, P, S.m_Opts.columns, SrcA, S, mkf, [&](DSSAligner &DA, uint i, uint j) {
+    auto align = [&]() {
+        ForEachAlignedBatch(P, ctx, S.m_Opts, SrcA, S, ia, ib,
+                            [&](const std::vector<uint32_t> &bia, const std::vector<uint32_t> &bib, const std::vector<rsk_aln> &out, const char *paths) {
+                                ReplayBatch(S, SrcA, S, bia, bib, out, paths, Self, joff);
+                            });
+    };
+    // long-chain pairs: MKF path (dssaligner.cpp:809-813), one aligner per host thread as in the reference
+    // (dbsearcher.cpp:98-106); BaseOnAln serialises the output under m_Lock.
+    auto each_orientation = [&](DSSAligner &DA, uint i, uint j, auto &&fn) {
         if (DA.m_Path.empty()) return;
         if (Self) {
-            S.BaseOnAln(DA, true);
-            if (i != joff + j) S.BaseOnAln(DA, false);
+            fn(DA, true);
+            if (i != joff + j) fn(DA, false);
         } else
-            S.BaseOnAln(DA, false);
+            fn(DA, false);
+    };
+    // A plain DBSearcher with both jobs to do runs them side by side: the long-chain job on a context of its own, its
+    // hit lines collected in memory and appended after the alignment job's (the order of the output file stays: Smith-
+    // Waterman hits, then long-chain hits).  Its kernels (one thread per extension, a few waves per SIMD) and its host
+    // stages leave most of the GPU and, between their bursts, of the host threads to the alignment job.
+    const bool overlap = !S.m_HasOnAlnOverride && !mkf.empty() && !ia.empty() && !(getenv("RSK_MKF_OVERLAP") && atoi(getenv("RSK_MKF_OVERLAP")) == 0);
+    if (overlap) {
+        struct ctx_guard { rsk_ctx *c = nullptr; ~ctx_guard() { if (c) rsk_ctx_destroy(c); } } own;
+        check(rsk_ctx_create(ctx->device, &own.c), "rsk_ctx_create");
+        std::string lines;
+        uint64_t hits = 0;
+        std::future<void> job = std::async(std::launch::async, [&]() {
+            RunMKFPairs(own.c, P, S.m_Opts.columns, SrcA, S, mkf, [&](DSSAligner &DA, uint i, uint j) {   // called under RunMKFPairs' lock
+                each_orientation(DA, i, j, [&](DSSAligner &D, bool Up) {
+                    if (S.Reject(D, Up)) return;
+                    ++hits;
+                    if (S.m_fTsv && !(S.m_Opts.noself && D.m_ChainA->m_Label == D.m_ChainB->m_Label)) D.AppendTsv(lines, Up);
+                });
+            });
+        });
+        try {
+            align();
+        } catch (...) {
+            job.wait();
+            throw;
+        }
+        job.get();
+        tm.lap("align + replay | MKF side by side");
+        S.m_HitCount += hits;
+        if (!lines.empty() && fwrite(lines.data(), 1, lines.size(), S.m_fTsv) != lines.size()) throw std::runtime_error("short write to the hits file");
+        return;
+    }
+    align();
+    tm.lap("align + replay");
+    RunMKFPairs(ctx, P, S.m_Opts.columns, SrcA, S, mkf, [&](DSSAligner &DA, uint i, uint j) {
+        each_orientation(DA, i, j, [&](DSSAligner &D, bool Up) { S.BaseOnAln(D, Up); });
     });
     tm.lap("MKF (GPU seeds + host)");
 }
