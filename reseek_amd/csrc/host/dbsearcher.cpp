@@ -349,8 +349,8 @@ void DBSearcher::UploadToGpu()
     std::vector<size_t> start((size_t) n + 1, 0);
     for (uint i = 0; i < n; ++i) { len[i] = m_DBChains[i]->GetSeqLength(); start[i + 1] = start[i] + len[i]; }
     const size_t tot = start[n];
-    std::vector<uint8_t> mu(tot), prof(tot * RSK_NFEAT);
-    std::vector<float> x(tot), y(tot), z(tot);
+    std::unique_ptr<uint8_t[]> mu(new uint8_t[tot + 1]), prof(new uint8_t[tot * RSK_NFEAT + 1]);      // filled below, not value-initialised
+    std::unique_ptr<float[]> x(new float[tot + 1]), y(new float[tot + 1]), z(new float[tot + 1]);
     rsk_parallel_for(n, 512, [&](size_t lo, size_t hi) {
         for (size_t i = lo; i < hi; ++i) {
             const uint L = len[i];
@@ -362,7 +362,7 @@ void DBSearcher::UploadToGpu()
             memcpy(&z[o], m_DBChains[i]->m_Zs.data(), 4 * (size_t) L);
         }
     });
-    check(rsk_db_create(m_Ctx, n, len.data(), mu.data(), prof.data(), x.data(), y.data(), z.data(), m_DBSelfRevScores.data(), &m_Db),
+    check(rsk_db_create(m_Ctx, n, len.data(), mu.get(), prof.get(), x.get(), y.get(), z.get(), m_DBSelfRevScores.data(), &m_Db),
           "rsk_db_create");
 }
 
@@ -660,10 +660,11 @@ void RunMKFPairs(rsk_ctx *Ctx, const DSSParams &P, const std::string &Columns, D
     std::vector<float> xsf(nx), xsb(nx);
     std::vector<uint64_t> xfo(nx), xbo(nx);
     std::vector<uint32_t> xfl(nx), xbl(nx);
-    std::vector<char> xpaths(xbytes + 16);
+    std::unique_ptr<char[]> xpaths_mem(new char[xbytes + 16]);         // hundreds of MB: not value-initialised
+    char *const xpaths = xpaths_mem.get();
     if (nx)
         check(rsk_xdrop_pairs(Ctx, SrcA.m_Db, SrcB.m_Db, xa.data(), xb.data(), xla.data(), xlb.data(), nx, float(P.m_MKF_X2), P.m_GapOpen, P.m_GapExt,
-                              xsf.data(), xsb.data(), xpaths.data(), xpaths.size(), xfo.data(), xfl.data(), xbo.data(), xbl.data()),
+                              xsf.data(), xsb.data(), xpaths, xbytes + 16, xfo.data(), xfl.data(), xbo.data(), xbl.data()),
               "rsk_xdrop_pairs");
     const auto t_host1 = std::chrono::steady_clock::now();
     // stage 3 (host threads): merge the extensions, statistics, hit
@@ -678,8 +679,8 @@ void RunMKFPairs(rsk_ctx *Ctx, const DSSParams &P, const std::string &Columns, D
         DA.m_XDropReqValid = true;
         DA.m_XDropReqLoA = rqa[r]; DA.m_XDropReqLoB = rqb[r];
         DA.m_XDropExtScoreFwd = xsf[k]; DA.m_XDropExtScoreBwd = xsb[k];
-        DA.m_XDropExtFwdPath.assign(xpaths.data() + xfo[k], xfl[k]);
-        DA.m_XDropExtBwdPath.assign(xpaths.data() + xbo[k], xbl[k]);
+        DA.m_XDropExtFwdPath.assign(xpaths + xfo[k], xfl[k]);
+        DA.m_XDropExtBwdPath.assign(xpaths + xbo[k], xbl[k]);
         if (R.nkept > CAP) DA.AlignMKF();
         else DA.AlignMKF_FromSeeds(R.kept.data(), R.nkept);
         DA.m_XDropMode = 0;

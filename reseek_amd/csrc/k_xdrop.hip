@@ -312,6 +312,46 @@ extern "C" int rsk_xdrop_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
     const bool trace = getenv("RSK_TRACE") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    // One workspace for the whole call, sized by the largest sub-batch: hipFree + hipMalloc of tens of GB between
+    // sub-batches cost up to 0.8 s on some boxes.
+    uint64_t max_ro = 0, max_to = 0, max_po = 0;
+    size_t max_m = 0;
+    for (size_t q0 = 0; q0 < n;) {
+        uint64_t ro = 0, to = 0, po = 0;
+        size_t q1 = q0;
+        while (q1 < n) {
+            const uint32_t LA = dba->len[ia[q1]], LB = dbb->len[ib[q1]];
+            const uint32_t ext[2][2] = { { LA - lo_a[q1], LB - lo_b[q1] }, { lo_a[q1], lo_b[q1] } };
+            const uint64_t t_need = (uint64_t) (ext[0][0] + 9) * (ext[0][1] + 9) + (uint64_t) (ext[1][0] + 9) * (ext[1][1] + 9) + 64;
+            if (q1 > q0 && to + t_need > TB_BUDGET) break;
+            for (int d = 0; d < 2; ++d) {
+                ro += 2ull * (ext[d][1] + 9);
+                to += ((uint64_t) (ext[d][0] + 9) * (ext[d][1] + 9) + 15) & ~15ull;
+                po += ext[d][0] + ext[d][1] + 2;
+            }
+            ++q1;
+        }
+        max_ro = std::max(max_ro, ro); max_to = std::max(max_to, to); max_po = std::max(max_po, po);
+        max_m = std::max(max_m, q1 - q0);
+        q0 = q1;
+    }
+    const auto t_alloc0 = now();
+    ws_t ws;
+    uint32_t *d_ia, *d_ib, *d_la, *d_lb, *d_pstart, *d_plen;
+    uint64_t *d_rowoff, *d_tboff, *d_pathoff;
+    float *d_rows, *d_score;
+    uint8_t *d_tb;
+    char *d_paths;
+    {
+        const size_t m = max_m;
+        if ((rc = ws.alloc((void **) &d_ia, m * 4)) || (rc = ws.alloc((void **) &d_ib, m * 4)) || (rc = ws.alloc((void **) &d_la, m * 4)) ||
+            (rc = ws.alloc((void **) &d_lb, m * 4)) || (rc = ws.alloc((void **) &d_pstart, 2 * m * 4)) || (rc = ws.alloc((void **) &d_plen, 2 * m * 4)) ||
+            (rc = ws.alloc((void **) &d_rowoff, 2 * m * 8)) || (rc = ws.alloc((void **) &d_tboff, 2 * m * 8)) ||
+            (rc = ws.alloc((void **) &d_pathoff, 2 * m * 8)) || (rc = ws.alloc((void **) &d_rows, max_ro * 4)) || (rc = ws.alloc((void **) &d_score, 2 * m * 4)) ||
+            (rc = ws.alloc((void **) &d_tb, max_to)) || (rc = ws.alloc((void **) &d_paths, max_po)))
+            return rc;
+    }
+    if (trace) fprintf(stderr, "[rsk_xdrop_pairs] workspace %.2f GB allocated in %.1f ms\n", (max_to + max_ro * 4 + max_po) / 1073741824.0, ms(t_alloc0, now()));
     size_t r0 = 0;
     uint64_t poff = 0;                // running offset into the caller's paths buffer
     while (r0 < n) {
@@ -332,19 +372,7 @@ extern "C" int rsk_xdrop_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
         }
         const size_t m = r1 - r0;
         const auto t_a = now();
-        ws_t ws;
-        uint32_t *d_ia, *d_ib, *d_la, *d_lb, *d_pstart, *d_plen;
-        uint64_t *d_rowoff, *d_tboff, *d_pathoff;
-        float *d_rows, *d_score;
-        uint8_t *d_tb;
-        char *d_paths;
-        if ((rc = ws.alloc((void **) &d_ia, m * 4)) || (rc = ws.alloc((void **) &d_ib, m * 4)) || (rc = ws.alloc((void **) &d_la, m * 4)) ||
-            (rc = ws.alloc((void **) &d_lb, m * 4)) || (rc = ws.alloc((void **) &d_pstart, 2 * m * 4)) || (rc = ws.alloc((void **) &d_plen, 2 * m * 4)) ||
-            (rc = ws.alloc((void **) &d_rowoff, 2 * m * 8)) || (rc = ws.alloc((void **) &d_tboff, 2 * m * 8)) ||
-            (rc = ws.alloc((void **) &d_pathoff, 2 * m * 8)) || (rc = ws.alloc((void **) &d_rows, ro * 4)) || (rc = ws.alloc((void **) &d_score, 2 * m * 4)) ||
-            (rc = ws.alloc((void **) &d_tb, to)) || (rc = ws.alloc((void **) &d_paths, po)))
-            return rc;
-        const auto t_b = now();
+        const auto t_b = t_a;
         RSK_HIP(hipMemcpyAsync(d_ia, ia + r0, m * 4, hipMemcpyHostToDevice, ctx->stream));
         RSK_HIP(hipMemcpyAsync(d_ib, ib + r0, m * 4, hipMemcpyHostToDevice, ctx->stream));
         RSK_HIP(hipMemcpyAsync(d_la, lo_a + r0, m * 4, hipMemcpyHostToDevice, ctx->stream));

@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <memory>
 #include <cfloat>
 
 #include "rsk_internal.h"
@@ -237,7 +238,8 @@ extern "C" int rsk_db_create(rsk_ctx *ctx, uint32_t n, const uint32_t *lengths, 
         if ((rc = dev_upload(&db->d_mu, db->h_mu.data(), db->h_mu.size(), db->hbm_bytes)) != RSK_OK) return rc;
     }
     if (prof) {
-        std::vector<uint8_t> hp((size_t) RSK_NFEAT * o, 0);
+        std::unique_ptr<uint8_t[]> hp_mem(new uint8_t[(size_t) RSK_NFEAT * o + 1]);   // not value-initialised: chains are copied, pads zeroed below
+        uint8_t *const hp = hp_mem.get();
         std::atomic<uint64_t> bad{UINT64_MAX};                        // (chain << 8) | feature of the first offender
         rsk_parallel_for(n, 512, [&](size_t lo, size_t hi) {
             for (size_t i = lo; i < hi; ++i)
@@ -252,6 +254,7 @@ extern "C" int rsk_db_create(rsk_ctx *ctx, uint32_t n, const uint32_t *lengths, 
                         continue;
                     }
                     memcpy(&hp[(size_t) f * o + db->off[i]], row, lengths[i]);
+                    memset(&hp[(size_t) f * o + db->off[i] + lengths[i]], 0, db->off[i + 1] - db->off[i] - lengths[i]);
                 }
         });
         if (bad.load() != UINT64_MAX) {
@@ -264,7 +267,7 @@ extern "C" int rsk_db_create(rsk_ctx *ctx, uint32_t n, const uint32_t *lengths, 
             delete db;
             return RSK_E_INVALID;
         }
-        if ((rc = dev_upload(&db->d_prof, hp.data(), hp.size(), db->hbm_bytes)) != RSK_OK) return rc;
+        if ((rc = dev_upload(&db->d_prof, hp, (size_t) RSK_NFEAT * o, db->hbm_bytes)) != RSK_OK) return rc;
         // the float-SW kernels read letter * 4 (column offsets) and letter * alphabet * 4 (row offsets) per feature,
         // residue-major: derived on the device from the bytes just uploaded
         const size_t nrec = ((size_t) o + 64) * 8;
@@ -279,17 +282,18 @@ extern "C" int rsk_db_create(rsk_ctx *ctx, uint32_t n, const uint32_t *lengths, 
         RSK_HIP(hipStreamSynchronize(ctx->stream));
     }
     if (x) {
-        std::vector<float> hx((size_t) o, 0.f), hy((size_t) o, 0.f), hz((size_t) o, 0.f);
+        std::unique_ptr<float[]> hx(new float[(size_t) o + 1]), hy(new float[(size_t) o + 1]), hz(new float[(size_t) o + 1]);
         rsk_parallel_for(n, 512, [&](size_t lo, size_t hi) {
             for (size_t i = lo; i < hi; ++i) {
                 memcpy(&hx[db->off[i]], x + src[i], 4 * (size_t) lengths[i]);
                 memcpy(&hy[db->off[i]], y + src[i], 4 * (size_t) lengths[i]);
                 memcpy(&hz[db->off[i]], z + src[i], 4 * (size_t) lengths[i]);
+                for (uint32_t k = db->off[i] + lengths[i]; k < db->off[i + 1]; ++k) hx[k] = hy[k] = hz[k] = 0.f;
             }
         });
-        if ((rc = dev_upload(&db->d_x, hx.data(), hx.size(), db->hbm_bytes)) != RSK_OK) return rc;
-        if ((rc = dev_upload(&db->d_y, hy.data(), hy.size(), db->hbm_bytes)) != RSK_OK) return rc;
-        if ((rc = dev_upload(&db->d_z, hz.data(), hz.size(), db->hbm_bytes)) != RSK_OK) return rc;
+        if ((rc = dev_upload(&db->d_x, hx.get(), (size_t) o, db->hbm_bytes)) != RSK_OK) return rc;
+        if ((rc = dev_upload(&db->d_y, hy.get(), (size_t) o, db->hbm_bytes)) != RSK_OK) return rc;
+        if ((rc = dev_upload(&db->d_z, hz.get(), (size_t) o, db->hbm_bytes)) != RSK_OK) return rc;
     }
     {
         std::vector<float> sr(n, FLT_MAX);
