@@ -523,9 +523,11 @@ void ForEachAlignedBatch(const DSSParams &P, rsk_ctx *ctx, const SearchOptions &
 {
     const auto batches = AlignBatches(O, SrcA, SrcB, ia, ib);
     PinnedPool Pool;                                                     // outlives every batch of the loop below
-    // Two GPU stages in flight (batches k + 1 and k + 2 while k is replayed), each on a context of its own (stream,
-    // device pool, staging buffers): the host part of rsk_align_pairs (grouping the pairs, work items, statistics) is
-    // a quarter of a stage, with a single stage in flight the GPU idles through it.  The chain sets are read-only here.
+    // Two GPU stages in flight (batches k + 1 and k + 2 while k is replayed), each on a context of its own (device
+    // pool, staging buffers): the host part of rsk_align_pairs (grouping the pairs, work items, statistics) is a
+    // quarter of a stage, with a single stage in flight the GPU idles through it.  The chain sets are read-only here.
+    // The second context launches on the default stream, like the caller's unless rsk_ctx_set_stream gave it another
+    // one: kernels of the two stages run one after the other, what overlaps is host work with kernels.
     struct ctx_guard { rsk_ctx *c = nullptr; ~ctx_guard() { if (c) rsk_ctx_destroy(c); } } second;
     const int inflight = getenv("RSK_ALIGN_INFLIGHT") ? std::max(1, std::min(2, atoi(getenv("RSK_ALIGN_INFLIGHT")))) : 2;
     if (inflight > 1 && batches.size() >= 3) check(rsk_ctx_create(ctx->device, &second.c), "rsk_ctx_create");
@@ -835,8 +837,8 @@ static void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOff
     };
     // A plain DBSearcher with both jobs to do runs them side by side: the long-chain job on a context of its own, its
     // hit lines collected in memory and appended after the alignment job's (the order of the output file stays: Smith-
-    // Waterman hits, then long-chain hits).  Its kernels (one thread per extension, a few waves per SIMD) and its host
-    // stages leave most of the GPU and, between their bursts, of the host threads to the alignment job.
+    // Waterman hits, then long-chain hits).  The host stages of one job run while the other job's kernels do (the
+    // contexts share the default stream, so the kernels themselves are not concurrent).
     const bool overlap = !S.m_HasOnAlnOverride && !mkf.empty() && !ia.empty() && !(getenv("RSK_MKF_OVERLAP") && atoi(getenv("RSK_MKF_OVERLAP")) == 0);
     if (overlap) {
         struct ctx_guard { rsk_ctx *c = nullptr; ~ctx_guard() { if (c) rsk_ctx_destroy(c); } } own;

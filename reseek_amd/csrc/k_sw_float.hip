@@ -1222,7 +1222,8 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
     const uint64_t *h_outoff = (const uint64_t *) (RH + r_outoff);
     if (paths) {
         const uint64_t total = h_outoff[npairs];
-        RSK_HIP(hipMemcpy(paths, d_packed, total, hipMemcpyDeviceToHost));
+        RSK_HIP(hipMemcpyAsync(paths, d_packed, total, hipMemcpyDeviceToHost, ctx->stream));
+        RSK_HIP(hipStreamSynchronize(ctx->stream));
         tm.lap("paths d2h");
     }
 

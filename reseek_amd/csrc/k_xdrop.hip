@@ -19,6 +19,7 @@
 // the number of extensions in flight, not the kernel (roofline: none that is meaningful).
 #include <hip/hip_runtime.h>
 
+#include <hipcub/hipcub.hpp>
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -267,6 +268,24 @@ __global__ __launch_bounds__(256) void k_xdrop(xd_args a)
 }
 
 // XDropHSP's two extensions (xdrophsp.cpp:97-108) for a list of seeded pairs.  Host arrays in, host arrays out.
+// The path of an extension fills a small part of its worst-case slot: the paths are packed back to back on the device
+// (sizes scanned, one wave copies one path) and only the packed bytes cross PCIe.
+__global__ void k_xd_sizes(const uint32_t *path_len, uint32_t n2, uint64_t *sizes)
+{
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e <= n2) sizes[e] = e < n2 ? path_len[e] : 0;
+}
+__global__ void k_xd_pack(const char *paths, const uint64_t *path_off, const uint32_t *path_start, const uint32_t *path_len, const uint64_t *out_off,
+                          uint32_t n2, char *out)
+{
+    const uint32_t e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (e >= n2) return;
+    const uint32_t len = path_len[e];
+    const char *src = paths + path_off[e] + path_start[e];
+    char *dst = out + out_off[e];
+    for (uint32_t c = threadIdx.x & 63; c < len; c += 64) dst[c] = src[c];
+}
+
 extern "C" int rsk_xdrop_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *dbb, const uint32_t *ia, const uint32_t *ib,
                                const uint32_t *lo_a, const uint32_t *lo_b, size_t n, float X, float gap_open, float gap_ext,
                                float *score_fwd, float *score_bwd, char *paths, size_t paths_bytes, uint64_t *fwd_off,
@@ -341,9 +360,16 @@ extern "C" int rsk_xdrop_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
     uint64_t *d_rowoff, *d_tboff, *d_pathoff;
     float *d_rows, *d_score;
     uint8_t *d_tb;
-    char *d_paths;
+    char *d_paths, *d_packed;
+    uint64_t *d_sizes, *d_outoff;
+    void *d_scan = nullptr;
+    size_t scan_bytes = 0;
+    RSK_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (uint64_t *) nullptr, (uint64_t *) nullptr, (int) (2 * max_m + 1), ctx->stream));
     {
         const size_t m = max_m;
+        if ((rc = ws.alloc((void **) &d_packed, max_po + 16)) || (rc = ws.alloc((void **) &d_sizes, (2 * m + 1) * 8)) ||
+            (rc = ws.alloc((void **) &d_outoff, (2 * m + 1) * 8)) || (rc = ws.alloc(&d_scan, scan_bytes)))
+            return rc;
         if ((rc = ws.alloc((void **) &d_ia, m * 4)) || (rc = ws.alloc((void **) &d_ib, m * 4)) || (rc = ws.alloc((void **) &d_la, m * 4)) ||
             (rc = ws.alloc((void **) &d_lb, m * 4)) || (rc = ws.alloc((void **) &d_pstart, 2 * m * 4)) || (rc = ws.alloc((void **) &d_plen, 2 * m * 4)) ||
             (rc = ws.alloc((void **) &d_rowoff, 2 * m * 8)) || (rc = ws.alloc((void **) &d_tboff, 2 * m * 8)) ||
@@ -396,21 +422,33 @@ extern "C" int rsk_xdrop_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
         RSK_HIP(hipGetLastError());
         if (trace) RSK_HIP(hipStreamSynchronize(ctx->stream));
         const auto t_d = now();
+        const uint32_t n2 = (uint32_t) (2 * m);
+        hipLaunchKernelGGL(k_xd_sizes, dim3((n2 + 256) / 256), dim3(256), 0, ctx->stream, d_plen, n2, d_sizes);
+        RSK_HIP(hipcub::DeviceScan::ExclusiveSum(d_scan, scan_bytes, d_sizes, d_outoff, (int) (n2 + 1), ctx->stream));
+        hipLaunchKernelGGL(k_xd_pack, dim3((n2 + 3) / 4), dim3(256), 0, ctx->stream, d_paths, d_pathoff, d_pstart, d_plen, d_outoff, n2, d_packed);
+        RSK_HIP(hipGetLastError());
         std::vector<float> h_score(2 * m);
-        std::vector<uint32_t> h_pstart(2 * m), h_plen(2 * m);
+        std::vector<uint32_t> h_plen(2 * m);
+        std::vector<uint64_t> h_outoff(2 * m + 1);
         RSK_HIP(hipMemcpyAsync(h_score.data(), d_score, 2 * m * 4, hipMemcpyDeviceToHost, ctx->stream));
-        RSK_HIP(hipMemcpyAsync(h_pstart.data(), d_pstart, 2 * m * 4, hipMemcpyDeviceToHost, ctx->stream));
         RSK_HIP(hipMemcpyAsync(h_plen.data(), d_plen, 2 * m * 4, hipMemcpyDeviceToHost, ctx->stream));
-        RSK_HIP(hipMemcpyAsync(paths + poff, d_paths, po, hipMemcpyDeviceToHost, ctx->stream));
+        RSK_HIP(hipMemcpyAsync(h_outoff.data(), d_outoff, (2 * m + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
         RSK_HIP(hipStreamSynchronize(ctx->stream));
+        const uint64_t packed = h_outoff[2 * m];
+        if (poff + packed > paths_bytes) { rsk_set_error("rsk_xdrop_pairs: paths buffer too small"); return RSK_E_INVALID; }
+        if (packed) {
+            RSK_HIP(hipMemcpyAsync(paths + poff, d_packed, packed, hipMemcpyDeviceToHost, ctx->stream));   // (a null-stream copy would wait for every other stream)
+            RSK_HIP(hipStreamSynchronize(ctx->stream));
+        }
         for (size_t k = 0; k < m; ++k) {
             score_fwd[r0 + k] = h_score[2 * k];
             score_bwd[r0 + k] = h_score[2 * k + 1];
-            fwd_off[r0 + k] = poff + path_off[2 * k] + h_pstart[2 * k];
+            fwd_off[r0 + k] = poff + h_outoff[2 * k];
             fwd_len[r0 + k] = h_plen[2 * k];
-            bwd_off[r0 + k] = poff + path_off[2 * k + 1] + h_pstart[2 * k + 1];
+            bwd_off[r0 + k] = poff + h_outoff[2 * k + 1];
             bwd_len[r0 + k] = h_plen[2 * k + 1];
         }
+        po = packed;
         if (trace)
             fprintf(stderr, "[rsk_xdrop_pairs] %zu pairs: trace scratch %.2f GB, alloc %.1f ms, h2d + clear %.1f ms, kernel %.1f ms, d2h %.1f ms\n", m,
                     to / 1073741824.0, ms(t_a, t_b), ms(t_b, t_c), ms(t_c, t_d), ms(t_d, now()));
