@@ -371,6 +371,26 @@ void DBSearcher::UploadToGpu()
 // records -> Reject -> TSV lines).  RunPairs runs the GPU stage of batch k + 1 while batch k is replayed.
 // Page-locked host buffers for the packed paths of a batch (hundreds of MB; the device-to-host copy into pageable
 // memory was ~25 % of the GPU stage): two or three buffers are recycled between the batches of a run.
+// A secondary context of this device.  RSK_OWN_STREAMS=1 (experimental, off by default) gives it a non-blocking
+// stream of its own so that its kernels can run next to the primary context's; otherwise it launches on the default stream.
+struct SecondaryCtx {
+    rsk_ctx *c = nullptr;
+    hipStream_t st = nullptr;
+    void Create(int device)
+    {
+        check(rsk_ctx_create(device, &c), "rsk_ctx_create");
+        if (getenv("RSK_OWN_STREAMS") && atoi(getenv("RSK_OWN_STREAMS")) != 0) {
+            if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { st = nullptr; return; }
+            rsk_ctx_set_stream(c, (void *) st);
+        }
+    }
+    ~SecondaryCtx()
+    {
+        if (c) rsk_ctx_destroy(c);
+        if (st) (void) hipStreamDestroy(st);
+    }
+};
+
 struct PinnedPool {
     std::mutex lock;
     std::vector<std::pair<char *, size_t> > idle;
@@ -528,9 +548,9 @@ void ForEachAlignedBatch(const DSSParams &P, rsk_ctx *ctx, const SearchOptions &
     // quarter of a stage, with a single stage in flight the GPU idles through it.  The chain sets are read-only here.
     // The second context launches on the default stream, like the caller's unless rsk_ctx_set_stream gave it another
     // one: kernels of the two stages run one after the other, what overlaps is host work with kernels.
-    struct ctx_guard { rsk_ctx *c = nullptr; ~ctx_guard() { if (c) rsk_ctx_destroy(c); } } second;
+    SecondaryCtx second;
     const int inflight = getenv("RSK_ALIGN_INFLIGHT") ? std::max(1, std::min(2, atoi(getenv("RSK_ALIGN_INFLIGHT")))) : 2;
-    if (inflight > 1 && batches.size() >= 3) check(rsk_ctx_create(ctx->device, &second.c), "rsk_ctx_create");
+    if (inflight > 1 && batches.size() >= 3) second.Create(ctx->device);
     auto launch = [&](size_t k) {
         const auto be = batches[k];
         rsk_ctx *c = (second.c && (k & 1)) ? second.c : ctx;
@@ -841,8 +861,8 @@ static void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOff
     // contexts share the default stream, so the kernels themselves are not concurrent).
     const bool overlap = !S.m_HasOnAlnOverride && !mkf.empty() && !ia.empty() && !(getenv("RSK_MKF_OVERLAP") && atoi(getenv("RSK_MKF_OVERLAP")) == 0);
     if (overlap) {
-        struct ctx_guard { rsk_ctx *c = nullptr; ~ctx_guard() { if (c) rsk_ctx_destroy(c); } } own;
-        check(rsk_ctx_create(ctx->device, &own.c), "rsk_ctx_create");
+        SecondaryCtx own;
+        own.Create(ctx->device);
         std::string lines;
         uint64_t hits = 0;
         std::future<void> job = std::async(std::launch::async, [&]() {
