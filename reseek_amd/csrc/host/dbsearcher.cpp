@@ -522,7 +522,8 @@ std::vector<std::pair<size_t, size_t> > AlignBatches(const SearchOptions &O, con
                                                      const std::vector<uint32_t> &ia, const std::vector<uint32_t> &ib)
 {
     std::vector<std::pair<size_t, size_t> > out;
-    const size_t maxp = std::max<size_t>(1, O.batch_pairs);
+    // RSK_BATCH_PAIRS lowers the batch size so that tests reach the multi-batch pipeline with small inputs
+    const size_t maxp = std::max<size_t>(1, getenv("RSK_BATCH_PAIRS") ? (size_t) atoll(getenv("RSK_BATCH_PAIRS")) : O.batch_pairs);
     size_t b = 0;
     uint64_t cells = 0;
     for (size_t k = 0; k < ia.size(); ++k) {

@@ -89,6 +89,20 @@ def test_palms_with_truncated_seed_lists(ctx, tmpdir, monkeypatch):
     run(ctx, tmpdir, "palms_sensitive.rskdb.gz", "sensitive", COLS, "hits_palms_sensitive.tsv.gz")
 
 
+@pytest.mark.parametrize("own_streams", ["0", "1"])
+def test_many_small_batches_pipeline(ctx, tmpdir, monkeypatch, own_streams):
+    """RSK_BATCH_PAIRS=300: the alignment job becomes a pipeline of many batches (two GPU stages in flight on two
+    contexts, hit replay of the batch before them on the host threads) with the long-chain job beside it; with
+    RSK_OWN_STREAMS=1 the secondary contexts launch on non-blocking streams of their own.  Same hit tables."""
+    monkeypatch.setenv("RSK_BATCH_PAIRS", "300")
+    monkeypatch.setenv("RSK_OWN_STREAMS", own_streams)
+    st = run(ctx, tmpdir, "q100_verysensitive.rskdb.gz", "verysensitive", COLS, "hits_q100_verysensitive.tsv.gz")
+    assert st[0] == 5050
+    run(ctx, tmpdir, "q100_sensitive.rskdb.gz", "sensitive", COLS, "hits_q100_sensitive.tsv.gz")
+    run(ctx, tmpdir, "palms_sensitive.rskdb.gz", "sensitive", COLS, "hits_palms_sensitive.tsv.gz")
+    run(ctx, tmpdir, "q100_sensitive.rskdb.gz", "sensitive", COLS, "hits_q100_db_q100_sensitive.tsv.gz", db2="q100_sensitive_dbq.rskdb.gz")
+
+
 def test_q100_vs_db_q100_sensitive(ctx, tmpdir):
     """`reseek -search Q -db DB -sensitive` (Search_NoMuFilter search.cpp:39): A = streamed DB chain whose
     self-rev score is computed under the search params (runquery.cpp:43-44), B = query chain."""
