@@ -101,6 +101,9 @@ def test_many_small_batches_pipeline(ctx, tmpdir, monkeypatch, own_streams):
     run(ctx, tmpdir, "q100_sensitive.rskdb.gz", "sensitive", COLS, "hits_q100_sensitive.tsv.gz")
     run(ctx, tmpdir, "palms_sensitive.rskdb.gz", "sensitive", COLS, "hits_palms_sensitive.tsv.gz")
     run(ctx, tmpdir, "q100_sensitive.rskdb.gz", "sensitive", COLS, "hits_q100_db_q100_sensitive.tsv.gz", db2="q100_sensitive_dbq.rskdb.gz")
+    # PostMuFilter (the -fast -db path) consumes its candidates through the same pipeline
+    run(ctx, tmpdir, "q100_sensitive_dbq.rskdb.gz", "fast", COLS, "hits_q100_db_q100_fast.tsv.gz", db2="q100_sensitive_dbq.rskdb.gz")
+    run_bca(ctx, tmpdir, "q100.bca", "sensitive", COLS, "hits_q100_sensitive.tsv.gz")
 
 
 def test_q100_vs_db_q100_sensitive(ctx, tmpdir):
