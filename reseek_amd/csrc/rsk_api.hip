@@ -185,6 +185,7 @@ extern "C" int rsk_db_create(rsk_ctx *ctx, uint32_t n, const uint32_t *lengths, 
     RSK_HIP(hipSetDevice(ctx->device));
     static std::atomic<uint64_t> next_uid{1};
     rsk_db *db = new rsk_db;
+    std::unique_ptr<rsk_db, void (*)(rsk_db *)> owner(db, rsk_db_destroy);   // every error return below releases the device arrays too
     db->ctx = ctx;
     db->uid = next_uid.fetch_add(1);
     db->n = n;
@@ -194,13 +195,12 @@ extern "C" int rsk_db_create(rsk_ctx *ctx, uint32_t n, const uint32_t *lengths, 
     for (uint32_t i = 0; i < n; ++i) {
         if (lengths[i] == 0 || lengths[i] >= 65535) {   // uint16 positions, mukmerfilter.cpp:211
             rsk_set_error("rsk_db_create: chain %u has length %u (must be 1..65534)", i, lengths[i]);
-            delete db;
             return RSK_E_RANGE;
         }
         db->off[i] = (uint32_t) o;
         o += (lengths[i] + RSK_CHAIN_PAD - 1) / RSK_CHAIN_PAD * RSK_CHAIN_PAD;
         nres += lengths[i];
-        if (o >= 0xFFFF0000ull) { rsk_set_error("rsk_db_create: chain set too large for 32-bit offsets"); delete db; return RSK_E_RANGE; }
+        if (o >= 0xFFFF0000ull) { rsk_set_error("rsk_db_create: chain set too large for 32-bit offsets"); return RSK_E_RANGE; }
     }
     db->off[n] = (uint32_t) o;
     db->nres = nres;
@@ -232,7 +232,6 @@ extern "C" int rsk_db_create(rsk_ctx *ctx, uint32_t n, const uint32_t *lengths, 
             uint8_t c = 0;
             for (uint32_t k = 0; k < lengths[i] && c < RSK_MU_ALPHA; ++k) c = mu[src[i] + k];
             rsk_set_error("rsk_db_create: Mu letter %u out of range in chain %u", c, i);
-            delete db;
             return RSK_E_INVALID;
         }
         if ((rc = dev_upload(&db->d_mu, db->h_mu.data(), db->h_mu.size(), db->hbm_bytes)) != RSK_OK) return rc;
@@ -264,7 +263,6 @@ extern "C" int rsk_db_create(rsk_ctx *ctx, uint32_t n, const uint32_t *lengths, 
             uint8_t mx = 0;
             for (uint32_t k = 0; k < lengths[i]; ++k) mx = row[k] > mx ? row[k] : mx;
             rsk_set_error("rsk_db_create: profile letter %u out of range (chain %u feature %d)", mx, i, f);
-            delete db;
             return RSK_E_INVALID;
         }
         if ((rc = dev_upload(&db->d_prof, hp, (size_t) RSK_NFEAT * o, db->hbm_bytes)) != RSK_OK) return rc;
@@ -301,7 +299,7 @@ extern "C" int rsk_db_create(rsk_ctx *ctx, uint32_t n, const uint32_t *lengths, 
         db->h_selfrev = sr;
         if ((rc = dev_upload(&db->d_selfrev, sr.data(), n, db->hbm_bytes)) != RSK_OK) return rc;
     }
-    *out = db;
+    *out = owner.release();
     return RSK_OK;
 }
 

@@ -67,3 +67,31 @@ def test_pinop_matches_reference_kats(ctx):
     want = [ol.mu_pinop(seqs2[a], seqs2[b], -5, -2) for a, b in zip(ia[:100], ib[:100])]
     assert got.tolist() == want
     db.close()
+
+
+@pytest.mark.gpu
+def test_db_create_rejects_bad_chain_sets(ctx):
+    """rsk_db_create error behaviour: zero-length / over-long chains, Mu or profile letters outside their alphabets
+    (reported for the first offending chain, the packing runs on several threads); nothing leaks into the next call."""
+    import reseek_amd
+    from reseek_amd import capi
+    rng = np.random.default_rng(3)
+    lengths = np.array([50, 70, 30, 90], np.uint32)
+    tot = int(lengths.sum())
+    mu = rng.integers(0, 36, tot).astype(np.uint8)
+    prof = np.concatenate([np.concatenate([rng.integers(0, 20, (1, L)), rng.integers(0, 16, (7, L))]).astype(np.uint8).ravel() for L in lengths])
+    with pytest.raises(capi.RskError, match="length"):
+        reseek_amd.Db(ctx, np.array([50, 0, 30], np.uint32), mu=mu[:80])
+    with pytest.raises(capi.RskError, match="length"):
+        reseek_amd.Db(ctx, np.array([65535], np.uint32), mu=np.zeros(65535, np.uint8))
+    bad = mu.copy(); bad[50 + 10] = 36; bad[50 + 70 + 5] = 99          # chains 1 and 2: chain 1 is reported
+    with pytest.raises(capi.RskError, match="Mu letter 36 out of range in chain 1"):
+        reseek_amd.Db(ctx, lengths, mu=bad)
+    badp = prof.copy(); badp[8 * (50 + 70) + 3 * 30 + 7] = 16          # chain 2, feature 3
+    with pytest.raises(capi.RskError, match="chain 2 feature 3"):
+        reseek_amd.Db(ctx, lengths, mu=mu, prof=badp)
+    badp = prof.copy(); badp[8 * 50 + 4] = 20                          # chain 1, feature 0 (amino acids: 20 letters)
+    with pytest.raises(capi.RskError, match="chain 1 feature 0"):
+        reseek_amd.Db(ctx, lengths, mu=mu, prof=badp)
+    db = reseek_amd.Db(ctx, lengths, mu=mu, prof=prof)
+    assert capi.lib().rsk_db_nchains(db.h) == 4
