@@ -5,7 +5,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "librsk.so")
+# RSK_LIB: another build of the same library (kernel-variant experiments: tools/exp/)
+LIB_PATH = os.environ.get("RSK_LIB") or os.path.join(HERE, "librsk.so")
 
 _lib = None
 

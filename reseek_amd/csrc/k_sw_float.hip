@@ -23,6 +23,7 @@
 //   * a second kernel walks the trace (one thread per pair), a third computes LDDT over the aligned
 //     columns (one wave per pair).
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <chrono>
 #include <cstdio>
@@ -37,7 +38,13 @@
 #include "rsk_internal.h"
 #include "rsk_tables_data.h"
 
-#define SWF_R 16
+#ifndef SWF_R
+#define SWF_R 16                     // rows per lane (multiple of 4)
+#endif
+#ifndef SWF_WPE
+#define SWF_WPE 2                    // waves per SIMD the kernel is built for (see k_sw_float)
+#endif
+#define SWF_PADR(L) ((((L) + SWF_R - 1) / SWF_R) * SWF_R)
 #define SWF_WAVES 4
 #define SWF_MINUS_INF (-9e9f)        // xdpmem.h:6
 #define TB_DM 0x01                   // tracebit.h:4-8
@@ -120,10 +127,13 @@ __device__ __forceinline__ float swq_max(float x, float y)
 
 // T = false: strips along A (rows), the wave steps over the columns of B; trace block TB[j][LApad].
 // T = true : strips along B (columns), the wave steps over the rows of A;  trace block TB[i][LBpad].
-// 3 waves per SIMD (168 VGPRs, the row offsets of two strips' worth spill outside the column loop): 18 % faster than the
-// 230-VGPR / 2-wave build; 4 waves (128 VGPRs) spills inside the loop and is 2x slower.
+// Built for 2 waves per SIMD (<= 256 VGPRs, no spills).  The kernel is bound by the LDS: 8 random ds_read_b32 per cell,
+// ~3.2 distinct addresses on the busiest bank of a 32-lane group = ~6 LDS cycles per wave-instruction (PMC, r02d: LDS
+// busy 75 % of the kernel's cycles, two thirds of it bank conflicts; VALU issue 58 %).  Variants measured on the 199 k
+// SCOP40-shaped -sensitive survivors (profiles/r02c_sw_float_notes.txt): R = 16 / 2 waves 20.2 ms, R = 12 / 3 waves 20.8,
+// R = 16 / 3 waves (54 spilled VGPRs) 22.6, R = 20 and 24 / 2 waves 21.6, R = 12 / 4 waves (60 spills) 28.1.
 template <bool T>
-__global__ __launch_bounds__(64 * SWF_WAVES) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_sw_float(swf_args a, uint32_t item_base)
+__global__ __launch_bounds__(64 * SWF_WAVES) __attribute__((amdgpu_waves_per_eu(SWF_WPE, SWF_WPE))) void k_sw_float(swf_args a, uint32_t item_base)
 {
     __shared__ __attribute__((aligned(16))) float tab[SWF_TABLE_FLOATS];
     for (int i = threadIdx.x; i < SWF_TABLE_FLOATS; i += blockDim.x) tab[i] = c_swf_tables.t[i];
@@ -140,7 +150,7 @@ __global__ __launch_bounds__(64 * SWF_WAVES) __attribute__((amdgpu_waves_per_eu(
     const uint32_t LA0 = a.a_len[A], LB0 = a.b_len[B];
     // from here on "LA"/rows/i refer to the strip chain and "LB"/columns/j to the step chain
     const uint32_t LA = T ? LB0 : LA0, LB = T ? LA0 : LB0;
-    const uint32_t LApad = (LA + 15) & ~15u;
+    const uint32_t LApad = SWF_PADR(LA);
     const float Open = a.open, Ext = a.ext;
     const uint16_t *bcb = T ? (a.a_ra + (size_t) a.a_off[A] * 8) : (a.b_cb + (size_t) a.b_off[B] * 8);
     const char *tabb = (const char *) tab;
@@ -172,8 +182,9 @@ __global__ __launch_bounds__(64 * SWF_WAVES) __attribute__((amdgpu_waves_per_eu(
         for (int f = 0; f < 8; ++f) {
             const uint8_t *src = T ? (a.b_prof + (size_t) f * a.b_npad + a.b_off[B] + i0)
                                    : (a.a_prof + (size_t) f * a.a_npad + a.a_off[A] + i0);   // 16-byte aligned (chains padded to 16)
-            const uint4 w = *(const uint4 *) src;
-            const uint32_t ww[4] = { w.x, w.y, w.z, w.w };
+            uint32_t ww[SWF_R / 4];                 // i0 is a multiple of 4 and the chain set has tail padding
+#pragma unroll
+            for (int k = 0; k < SWF_R / 4; ++k) ww[k] = ((const uint32_t *) src)[k];
 #pragma unroll
             for (int r = 0; r < SWF_R; ++r) {
                 const uint32_t letter = (ww[r >> 2] >> (8 * (r & 3))) & 0xFF;
@@ -228,7 +239,7 @@ __global__ __launch_bounds__(64 * SWF_WAVES) __attribute__((amdgpu_waves_per_eu(
             // branch-free cell: the five comparisons of the recurrence enter a trace byte through the carry
             // (same bit order as k_sw_qp: DM candidate, IM candidate, SM, MD, MI; decoded in swf_trace_flags);
             // the byte of row r sits at bits 8 * (3 - r % 4) of its dword
-            uint32_t tbw[4];
+            uint32_t tbw[SWF_R / 4];
             uint32_t w = 0;
 #pragma unroll
             for (int r = 0; r < SWF_R; ++r) {
@@ -269,7 +280,11 @@ __global__ __launch_bounds__(64 * SWF_WAVES) __attribute__((amdgpu_waves_per_eu(
             }
             hand_m = carry;      // DPM[i0+16][j+1]
             hand_d = ch;         // DPD[i0+16][j] (normal) / DPI[i][j0+16] (transposed)
-            *(uint4 *) (tbp + (size_t) j * LApad) = make_uint4(tbw[0], tbw[1], tbw[2], tbw[3]);
+            {
+                uint32_t *tq = (uint32_t *) (tbp + (size_t) j * LApad);
+#pragma unroll
+                for (int k = 0; k < SWF_R / 4; ++k) tq[k] = tbw[k];
+            }
             if (writes_bnd) {
                 __hip_atomic_store(bnd + 2 * j, __builtin_bit_cast(int, hand_m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(bnd + 2 * j + 1, __builtin_bit_cast(int, hand_d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -324,19 +339,22 @@ __global__ __launch_bounds__(64 * SWF_WAVES) __attribute__((amdgpu_waves_per_eu(
 #define SWQ_NFC 132                               // 20 + 7 * 16 (feature, step letter) combinations
 #define SWQ_MAX_G ((163840 - 256) / (SWQ_NFC * SWQ_R * 4))
 #define SWQ_MAX_L (SWQ_MAX_G * SWQ_R)
+#define SWQ_LDS_BYTES(G) ((size_t) SWQ_NFC * (SWQ_R / 4) * (G) * 16 + 16)
 
 struct swq_item { uint32_t first, count; };
 
 typedef float swq_v2f __attribute__((ext_vector_type(2)));
 typedef float swq_v4f __attribute__((ext_vector_type(4)));
 typedef const volatile __attribute__((address_space(3))) swq_v4f *swq_ldsp;   // volatile: see the fetch in k_sw_qp
-template <bool T>
+// G = strips per LDS profile (SWQ_MAX_G: the whole LDS of a CU).  Smaller profiles with several workgroups per CU were
+// measured on the SCOP40-shaped -sensitive survivors (groups of tens of pairs) and lost to the per-pair kernel at every
+// group-size threshold (profiles/r02c_sw_float_notes.txt), so one geometry is instantiated.
+template <bool T, int G>
 __global__ __launch_bounds__(64 * SWQ_NW) void k_sw_qp(swf_args a, const swq_item *items)
 {
     extern __shared__ float4 qp4[];
     float *qp = (float *) qp4;
     constexpr int R = SWQ_R;
-    constexpr uint32_t G = SWQ_MAX_G;              // fixed row geometry: quad blocks G float4 apart, rows (R/4) * G float4 apart
     const swq_item it = items[blockIdx.x];
     const uint32_t strip_chain = T ? a.ib[it.first] : a.ia[it.first];
     const uint32_t LA = T ? a.b_len[strip_chain] : a.a_len[strip_chain];     // strip chain length
@@ -352,24 +370,28 @@ __global__ __launch_bounds__(64 * SWQ_NW) void k_sw_qp(swf_args a, const swq_ite
     {
         const uint8_t *sp = T ? (a.b_prof + a.b_off[strip_chain]) : (a.a_prof + a.a_off[strip_chain]);
         const size_t snpad = T ? a.b_npad : a.a_npad;
-        const uint32_t gs = g * R, tot = SWQ_NFC * gs;
+        // float4 ((fc * (R/4) + quad) * G + strip) holds residues (sbase + strip) * R + quad * 4 + 0..3 of row
+        // fc: the ds_read_b128 of the g lanes of a pair are 16 B apart, and the R/4 quads of a lane sit at
+        // immediate offsets (quad * G * 16 B) from one address.  One record per thread and iteration.
+        const uint32_t per_fc = (R / 4) * g, tot = SWQ_NFC * per_fc;
         for (uint32_t idx = threadIdx.x; idx < tot; idx += blockDim.x) {
-            // float4 ((fc * (R/4) + quad) * G + strip) holds residues (sbase + strip) * R + quad * 4 + 0..3 of row
-            // fc: the ds_read_b128 of the g lanes of a pair are 16 B apart, and the R/4 quads of a lane sit at
-            // immediate offsets (quad * G * 16 B) from one address
-            const uint32_t fc = idx / gs, rem = idx - fc * gs;
-            const uint32_t quad = rem / (g * 4), rem2 = rem - quad * (g * 4);
-            const uint32_t strip = rem2 >> 2, w = rem2 & 3;
-            const uint32_t i = (sbase + strip) * R + quad * 4 + w;
+            const uint32_t fc = idx / per_fc, rem = idx - fc * per_fc;
+            const uint32_t quad = rem / g, strip = rem - quad * g;
+            const uint32_t i = (sbase + strip) * R + quad * 4;
             const uint32_t f = fc < 20 ? 0 : ((fc - 20) >> 4) + 1;
             const uint32_t c = fc < 20 ? fc : ((fc - 20) & 15);
             const uint32_t as = f == 0 ? 20 : 16, tof = f == 0 ? 0 : 400 + (f - 1) * 256;
-            float v = f == 0 ? -1e30f : 0.0f;      // rows below the chain end: S = -1e30, never a maximum
+            const float padv = f == 0 ? -1e30f : 0.0f;      // rows below the chain end: S = -1e30, never a maximum
+            float v[4] = { padv, padv, padv, padv };
             if (i < LA) {
-                const uint32_t letter = sp[(size_t) f * snpad + i];
-                v = c_swf_tables.t[tof + (T ? c * as + letter : letter * as + c)];
+                const uint32_t l4 = *(const uint32_t *) (sp + (size_t) f * snpad + i);      // i % 4 == 0, chains padded to 16
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const uint32_t letter = (l4 >> (8 * w)) & 0xFFu;
+                    if (i + w < LA) v[w] = c_swf_tables.t[tof + (T ? c * as + letter : letter * as + c)];
+                }
             }
-            qp[((fc * (R / 4) + quad) * G + strip) * 4 + w] = v;
+            qp4[(fc * (R / 4) + quad) * G + strip] = make_float4(v[0], v[1], v[2], v[3]);
         }
         if (threadIdx.x == 0) *next_batch = 0;
     }
@@ -562,7 +584,7 @@ __global__ void k_traceback(const uint8_t *tb, const uint64_t *tb_off, const uin
     const uint32_t cls = (p >= cl.first[1]) + (p >= cl.first[2]) + (p >= cl.first[3]);
     const uint32_t LA = a_len[ia[p]], LB = b_len[ib[p]];
     const uint32_t ld = cls == 0 ? LB : cls == 1 ? LA
-                      : cls == 2 ? ((LA + 15) & ~15u) : ((LB + 15) & ~15u);
+                      : cls == 2 ? SWF_PADR(LA) : SWF_PADR(LB);
     const uint8_t *T = tb + tb_off[p];
     uint32_t i = besti[p] + 1, j = bestj[p] + 1;      // 1-based
     const uint32_t Besti = i, Bestj = j;
@@ -938,11 +960,17 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
     // A workgroup of k_sw_qp holds ONE profile (its LDS), so its parallelism is (pairs of the group) x (strips of the
     // chain) lanes; below ~10 waves' worth the per-pair kernel, which fills the CU with unrelated pairs, is faster
     // (measured on the SCOP40 -sensitive survivors: crossover at 30-50 pairs per 175-residue query).
-    const uint32_t min_lanes = getenv("RSK_SWQ_MIN_LANES") ? (uint32_t) atoi(getenv("RSK_SWQ_MIN_LANES")) : 640;
-    auto qp_ok = [&](uint32_t count, uint32_t L) {
+    // A group takes the query-profile kernel when its pairs x strips amount to >= min_lanes lanes.  Measured (r02c): after the
+    // per-pair kernel's (strips, steps) ordering the profile kernel only wins for groups of hundreds of pairs (one
+    // workgroup per CU idles while its longest pair finishes), e.g. a query against a database; all-vs-all survivor
+    // groups (tens of pairs) stay with the per-pair kernel.
+    const uint32_t min_lanes = getenv("RSK_SWQ_MIN_LANES") ? (uint32_t) atoi(getenv("RSK_SWQ_MIN_LANES")) : 8192;
+    auto qp_bucket = [&](uint32_t count, uint32_t L) -> int {
+        if (L == 0) return -1;
         const uint32_t g = std::min<uint32_t>((L + SWQ_R - 1) / SWQ_R, SWQ_MAX_G);
-        return L > 0 && (uint64_t) count * g >= min_lanes;
+        return (uint64_t) count * g >= min_lanes ? 0 : -1;
     };
+    auto qp_ok = [&](uint32_t count, uint32_t L) { return qp_bucket(count, L) >= 0; };
     std::vector<uint32_t> cntA(dba->n, 0), cntB;
     for (size_t p = 0; p < npairs; ++p) ++cntA[ia[p]];
     bool anyB = false;
@@ -962,10 +990,15 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
             key = ((uint64_t) 0 << 62) | ((uint64_t) ia[p] << 24) | (0xFFFFFFu - std::min(LB, 0xFFFFFFu));
         else if (!cntB.empty() && qp_ok(cntB[ib[p]], LB))
             key = ((uint64_t) 1 << 62) | ((uint64_t) ib[p] << 24) | (0xFFFFFFu - std::min(LA, 0xFFFFFFu));
+        // per-pair kernel: the pairs of a wave share the strip count g and run until the longest step chain among them is
+        // done, so the order is (strips desc, steps desc): lane-slot efficiency 0.53 -> 0.84 on SCOP40 lengths compared
+        // with ordering by the strip chain's length alone
         else if (!(LA > 64 * SWF_R && LB <= 64 * SWF_R))
-            key = ((uint64_t) 2 << 62) | ((uint64_t) (0xFFFFFFu - std::min(LA, 0xFFFFFFu)) << 32);
+            key = ((uint64_t) 2 << 62) | ((uint64_t) (0xFFFFFu - std::min((LA + SWF_R - 1) / SWF_R, 0xFFFFFu)) << 40) |
+                  ((uint64_t) (0xFFFFFFu - std::min(LB, 0xFFFFFFu)) << 16);
         else
-            key = ((uint64_t) 3 << 62) | ((uint64_t) (0xFFFFFFu - std::min(LB, 0xFFFFFFu)) << 32);
+            key = ((uint64_t) 3 << 62) | ((uint64_t) (0xFFFFFu - std::min((LB + SWF_R - 1) / SWF_R, 0xFFFFFu)) << 40) |
+                  ((uint64_t) (0xFFFFFFu - std::min(LA, 0xFFFFFFu)) << 16);
         ord[p] = keyed{ key, (uint32_t) p };
     }
     });
@@ -1039,7 +1072,7 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
         }
     }
     const size_t o_items = hb.add(items.size() * sizeof(swf_item) + 16);
-    const size_t o_q0 = hb.add(qitems[0].size() * sizeof(swq_item) + 16), o_q1 = hb.add(qitems[1].size() * sizeof(swq_item) + 16);
+    const size_t o_q[2] = { hb.add(qitems[0].size() * sizeof(swq_item) + 16), hb.add(qitems[1].size() * sizeof(swq_item) + 16) };
     // pairs (sorted order) whose alignment can exceed the per-wave LDDT staging: min(LA, LB) bounds the aligned columns
     std::vector<uint32_t> lddt_list[2];
     if (want_stats && paths)
@@ -1072,8 +1105,8 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
         }
         else if (c == 2) {
             if (LA > 64 * SWF_R) bno += 2 * (uint64_t) LB;      // multi-group pair: 2 words per step
-            tbo += (uint64_t) ((LA + 15) & ~15u) * LB;
-        } else tbo += (uint64_t) ((LB + 15) & ~15u) * LA;
+            tbo += (uint64_t) SWF_PADR(LA) * LB;
+        } else tbo += (uint64_t) SWF_PADR(LB) * LA;
         tbo = (tbo + 15) & ~(uint64_t) 15;
         pe += (uint64_t) LA + LB + 1;
         path_end[k] = pe;
@@ -1085,8 +1118,7 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
     sc_off[npairs] = so;
     bnd_off[npairs] = bno;
     memcpy(H + o_items, items.data(), items.size() * sizeof(swf_item));
-    memcpy(H + o_q0, qitems[0].data(), qitems[0].size() * sizeof(swq_item));
-    memcpy(H + o_q1, qitems[1].data(), qitems[1].size() * sizeof(swq_item));
+    for (int c = 0; c < 2; ++c) memcpy(H + o_q[c], qitems[c].data(), qitems[c].size() * sizeof(swq_item));
     for (int c = 0; c < 2; ++c) memcpy(H + o_lddt[c], lddt_list[c].data(), lddt_list[c].size() * 4);
     if (tm.on) {
         uint64_t cc[4] = { 0, 0, 0, 0 };
@@ -1150,18 +1182,21 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
     a.score = d_score; a.besti = d_bi; a.bestj = d_bj;
     a.bnd = d_bnd; a.bnd_off = d_bndoff;
     RSK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-    static bool attr_done = false;
-    if (!attr_done) {
-        RSK_HIP(hipFuncSetAttribute((const void *) k_sw_qp<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
-        RSK_HIP(hipFuncSetAttribute((const void *) k_sw_qp<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
-        attr_done = true;
+    {
+        static std::atomic<bool> attr_done[64];     // per device: the attribute belongs to the device's code object
+        const int dv = ctx->device & 63;
+        if (!attr_done[dv].load(std::memory_order_acquire)) {
+            RSK_HIP(hipFuncSetAttribute((const void *) k_sw_qp<false, SWQ_MAX_G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) SWQ_LDS_BYTES(SWQ_MAX_G)));
+            RSK_HIP(hipFuncSetAttribute((const void *) k_sw_qp<true, SWQ_MAX_G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) SWQ_LDS_BYTES(SWQ_MAX_G)));
+            attr_done[dv].store(true, std::memory_order_release);
+        }
     }
     for (int c = 0; c < 2; ++c) {
         if (qitems[c].empty()) continue;
-        const size_t lds = (size_t) SWQ_NFC * (SWQ_R / 4) * SWQ_MAX_G * 16 + 16;   // fixed row geometry
-        const swq_item *d_q = (const swq_item *) (D + (c == 0 ? o_q0 : o_q1));
-        if (c == 0) hipLaunchKernelGGL(k_sw_qp<false>, dim3((unsigned) qitems[c].size()), dim3(64 * SWQ_NW), lds, ctx->stream, a, d_q);
-        else hipLaunchKernelGGL(k_sw_qp<true>, dim3((unsigned) qitems[c].size()), dim3(64 * SWQ_NW), lds, ctx->stream, a, d_q);
+        const swq_item *d_q = (const swq_item *) (D + o_q[c]);
+        const dim3 grid((unsigned) qitems[c].size()), block(64 * SWQ_NW);
+        if (c == 0) hipLaunchKernelGGL((k_sw_qp<false, SWQ_MAX_G>), grid, block, SWQ_LDS_BYTES(SWQ_MAX_G), ctx->stream, a, d_q);
+        else hipLaunchKernelGGL((k_sw_qp<true, SWQ_MAX_G>), grid, block, SWQ_LDS_BYTES(SWQ_MAX_G), ctx->stream, a, d_q);
     }
     if (nitems_normal) {
         a.nitems = nitems_normal;

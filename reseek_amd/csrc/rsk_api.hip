@@ -169,7 +169,7 @@ static int dev_upload(T **d, const T *h, size_t count, uint64_t &bytes)
 {
     *d = nullptr;
     if (count == 0) return RSK_OK;
-    RSK_HIP(hipMalloc((void **) d, count * sizeof(T)));
+    RSK_HIP(hipMalloc((void **) d, count * sizeof(T) + 64));      // slack: kernels read whole dwords / strips past the last padded chain
     RSK_HIP(hipMemcpy(*d, h, count * sizeof(T), hipMemcpyHostToDevice));
     bytes += count * sizeof(T);
     return RSK_OK;
