@@ -155,6 +155,175 @@ def search_end_to_end(seqs):
     return best
 
 
+def _load_json(name):
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
+def live_kernels(ctx, seqs, db, reps=3):
+    """`roofline_live`: the kernels reseek -search actually runs (the gapless kernel of `value` has no caller in the
+    reference), timed with the library's HIP events on the launch stream, on the same SCOP40-shaped set:
+      k_mu_sw     Mu SW filter forward pass over the whole triangle (parasail_mu.cpp:120), packed int16
+      k_sw_float  float SW + trace of the -sensitive filter survivors (sw.cpp:79; per-pair kernel)
+      k_sw_qp     float SW + trace, 64 queries x all chains (query-profile kernel; the -db / -verysensitive regime)
+    Bounds: VALU issue (one wave64 instruction per 4 cycles per SIMD for mixed VOP2/VOP3/DPP streams, profiles/r02_ubench_valu.txt)
+    and, for k_sw_float, the LDS (8 random ds_read_b32 per cell).  `pmc` = issue / LDS-busy fractions from the rocprofv3
+    counter passes of `bench.py --live-only` committed as profiles/r02_live_pmc.json (tools/prof_live.sh)."""
+    import torch
+    import reseek_amd
+    n = len(seqs)
+    lens = np.array([len(s) for s in seqs], np.float64)
+    tri_cells = float((lens * np.cumsum(lens[::-1])[::-1]).sum())
+    out8 = torch.zeros((n, n), dtype=torch.uint8, device="cuda")
+    pmc = _load_json("r02_live_pmc.json") or {}
+    res = []
+
+    def med(f):
+        v = []
+        for _ in range(reps):
+            f()
+            torch.cuda.synchronize()
+            v.append(ctx.last_kernel_ms())
+        return float(np.median(v))
+
+    # --- k_mu_sw
+    ctx.mu_sw_matrix_dev(db, db, True, False, out8.data_ptr(), n)
+    ms = med(lambda: ctx.mu_sw_matrix_dev(db, db, True, False, out8.data_ptr(), n))
+    alg = float((lens * (n - np.arange(n))).sum() + np.cumsum(lens[::-1])[::-1].sum() + n * (n + 1) / 2)      # LA + LB + 1 per pair
+    res.append({"kernel": "k_mu_sw", "what": "Mu SW filter, forward pass, all pairs i<=j", "kernel_ms": ms, "cells": tri_cells,
+                "cells_per_s": tri_cells / ms * 1e3, "bound": "valu", "valu_ops_per_cell": 5.0, "unit": "T lane-ops/s",
+                "achieved": tri_cells * 5.0 / ms * 1e3 / 1e12, "peak": PEAK_VALU_LANEOPS / 1e12,
+                "frac": tri_cells * 5.0 / ms * 1e3 / PEAK_VALU_LANEOPS,
+                "hbm": {"algorithmic_bytes": alg, "achieved_GBs": alg / ms * 1e3 / 1e9, "frac": alg / ms * 1e3 / 1e9 / PEAK_HBM_GBS},
+                "pmc": pmc.get("k_mu_sw")})
+    # --- survivors of the -sensitive filter -> float SW (per-pair kernel)
+    cap = 4_000_000
+    pq = torch.zeros(cap, dtype=torch.int32, device="cuda")
+    pt = torch.zeros(cap, dtype=torch.int32, device="cuda")
+    nn = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ctx.mu_filter_dev(db, db, True, 12.0, 20.0, out8.data_ptr(), n, pq.data_ptr(), pt.data_ptr(), 0, 0, cap, nn.data_ptr())
+    torch.cuda.synchronize()
+    ns = int(nn.item())
+    ia = pq[:ns].cpu().numpy().astype(np.uint32)
+    ib = pt[:ns].cpu().numpy().astype(np.uint32)
+    o = np.lexsort((ib, ia))
+    ia, ib = ia[o], ib[o]
+    rng = np.random.default_rng(3)
+    li = np.array([len(s) for s in seqs], np.uint32)
+    tot = int(li.sum())
+    prof = np.concatenate([np.concatenate([rng.integers(0, 20, (1, int(L))), rng.integers(0, 16, (7, int(L)))]).astype(np.uint8).reshape(-1)
+                           for L in li])
+    xyz = tuple(np.cumsum(rng.normal(0, 2.2, tot)).astype(np.float32) for _ in range(3))
+    dbs = reseek_amd.Db(ctx, li, mu=np.concatenate(seqs), prof=prof, xyz=xyz, selfrev=np.zeros(n, np.float32))
+
+    def sw_entry(name, what, a, b, minfwd, valu_per_cell, lds):
+        ctx.align_pairs(dbs, dbs, a, b, min_fwd_score=minfwd, collect=False)      # warm the allocator pool
+        v = []
+        for _ in range(reps):
+            ctx.align_pairs(dbs, dbs, a, b, min_fwd_score=minfwd, collect=False)
+            v.append(ctx.last_kernel_ms())
+        ms_ = float(np.median(v))
+        p_, cells, tb = ctx.align_last_work()
+        la, lb = li[a].astype(np.float64), li[b].astype(np.float64)
+        alg_ = float((8 * (la + lb)).sum() + tb + (la + lb).sum())                # SURVEY 8d: 8(LA+LB) + trace + path
+        e = {"kernel": name, "what": what, "kernel_ms": ms_, "pairs": int(p_), "cells": float(cells), "cells_per_s": cells / ms_ * 1e3,
+             "bound": "valu", "valu_ops_per_cell": valu_per_cell, "unit": "T lane-ops/s",
+             "achieved": cells * valu_per_cell / ms_ * 1e3 / 1e12, "peak": PEAK_VALU_LANEOPS / 1e12,
+             "frac": cells * valu_per_cell / ms_ * 1e3 / PEAK_VALU_LANEOPS,
+             "hbm": {"algorithmic_bytes": alg_, "trace_bytes": float(tb), "achieved_GBs": alg_ / ms_ * 1e3 / 1e9,
+                     "frac": alg_ / ms_ * 1e3 / 1e9 / PEAK_HBM_GBS},
+             "pmc": pmc.get(name)}
+        if lds:
+            # 8 ds_read_b32 gathers per cell; conflict-free LDS rate = 32 lanes/clk/CU
+            peak_g = 256 * 32 * 2.4e9
+            e["lds"] = {"gathers_per_cell": 8, "achieved_Tgathers_per_s": 8 * cells / ms_ * 1e3 / 1e12, "peak_conflict_free": peak_g / 1e12,
+                        "frac_conflict_free": 8 * cells / ms_ * 1e3 / peak_g,
+                        "note": "random 4-byte gathers: ~3 distinct addresses on the busiest bank of a 32-lane group, i.e. the "
+                                "attainable rate is about a third of the conflict-free one"}
+        return e
+
+    res.append(sw_entry("k_sw_float", "float SW + trace of the %d -sensitive Mu-filter survivors (per-pair kernel)" % ns, ia, ib, 7.0, 41.0, True))
+    nq = 64
+    order = np.random.default_rng(4).permutation(n)[:nq].astype(np.uint32)
+    qa = np.repeat(order, n)
+    qb = np.tile(np.arange(n, dtype=np.uint32), nq)
+    res.append(sw_entry("k_sw_qp", "float SW + trace, %d queries x %d chains (query-profile kernel)" % (nq, n), qa, qb, 0.0, 29.0, False))
+    return res
+
+
+def search_vs_reference(nsample=1500, reps=3):
+    """The whole `-search -sensitive` call from a .bca file next to the REFERENCE BINARY on this box's host cores.
+    Ours: the full SCOP40-shaped synthetic .bca (11,211 chains: DSS featurisation + self-rev + filter + SW + long-chain
+    path + hit table), second of two runs.  Reference: oracle/_ref/reseek -search on an every-k-th-chain sample of the
+    same file (all usable cores, median of `reps`), reported as chain-pairs/s; rule for the full set: seconds =
+    pairs_full / that rate (the sample is unbiased in length, the cost of the search is per pair).  The sorted hit table of
+    the sample is compared with ours on the same sample."""
+    import torch
+    import reseek_amd
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_search
+    ref = os.path.join(ROOT, "oracle", "_ref", "reseek")
+    lens = scop40_lengths()
+    recs = bench_search.gen_bca_chains(lens, np.random.default_rng(7))
+    ctx = reseek_amd.Ctx(0, stream=torch.cuda.current_stream().cuda_stream)
+    out = {}
+    try:
+        with tempfile.TemporaryDirectory() as td:
+            full, samp = os.path.join(td, "syn.bca"), os.path.join(td, "sample.bca")
+            bench_search.write_bca_records(full, recs)
+            idx = np.linspace(0, len(recs) - 1, nsample).astype(np.int64)
+            bench_search.write_bca_records(samp, [recs[i] for i in idx], labels=["syn%05d" % i for i in idx])
+            hits = os.path.join(td, "hits.tsv")
+            for _ in range(2):
+                t0 = time.perf_counter()
+                nh, st = ctx.search_rskdb(full, hits, "sensitive")
+                dt = time.perf_counter() - t0
+            out = {"mode": "-search -sensitive all-vs-all from a synthetic .bca (featurisation + self-rev inside the call)",
+                   "chains": len(recs), "seconds": dt, "chain_pairs": int(st[0]), "chain_pairs_per_sec": st[0] / dt,
+                   "sw_pairs": int(st[5]), "long_chain_pairs": int(st[4]), "hits": int(nh)}
+            ours_s = os.path.join(td, "ours_sample.tsv")
+            t0 = time.perf_counter()
+            nh_s, st_s = ctx.search_rskdb(samp, ours_s, "sensitive")
+            t_ours_s = time.perf_counter() - t0
+            if os.path.exists(ref):
+                cores = usable_cpus()
+                ref_tsv = os.path.join(td, "ref.tsv")
+                ts = []
+                for _ in range(reps):
+                    t0 = time.perf_counter()
+                    subprocess.run([ref, "-search", samp, "-sensitive", "-output", ref_tsv, "-threads", str(cores)], check=True,
+                                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=td, timeout=900)
+                    ts.append(time.perf_counter() - t0)
+                tm = float(np.median(ts))
+                a = sorted(open(ref_tsv).read().splitlines())
+                b = sorted(open(ours_s).read().splitlines())
+                pairs_s = float(st_s[0])
+                sa, sb = set(a), set(b)
+                diff = sorted((sa - sb) | (sb - sa))
+                long_labels = {"syn%05d" % i for i in idx if recs[i][2] >= 600}      # m_MKFL of -sensitive
+                diff_long = [r for r in diff if r.split("\t")[0] in long_labels or r.split("\t")[1] in long_labels]
+                out["cpu_baseline"] = {
+                    "value": pairs_s / tm, "unit": "chain-pairs/s", "cores": cores, "kind": "reference",
+                    "sample": "oracle/_ref/reseek -search sample.bca -sensitive -threads %d: every %.2f-th chain of the same .bca "
+                              "(%d chains, %d pairs); median of %d runs" % (cores, len(recs) / nsample, nsample, int(pairs_s), reps),
+                    "seconds_runs": ts, "seconds_median": tm,
+                    "rule": "full-set seconds = chain_pairs / value",
+                    "extrapolated_full_set_seconds": out["chain_pairs"] / (pairs_s / tm),
+                    "speedup_whole_call": (out["chain_pairs"] / (pairs_s / tm)) / out["seconds"],
+                    "ours_on_the_same_sample_seconds": t_ours_s}
+                out["hit_table_on_sample"] = {
+                    "identical": a == b, "reference_rows": len(a), "our_rows": len(b), "rows_differing": len(diff),
+                    "rows_differing_without_a_chain_of_600_or_more": len(diff) - len(diff_long),
+                    "note": "with several threads the reference is not reproducible on pairs with a chain >= 600 residues (its "
+                            "banded X-drop traceback reads uninitialised trace cells, DESIGN.md section 5); its 1-thread table equals ours"}
+    finally:
+        ctx.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -162,7 +331,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--chains", type=int, default=0, help="0 = the full SCOP40-shaped set (11,211)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-search", action="store_true", help="skip the end-to-end -search leg (rank 0, 1 GPU only)")
+    ap.add_argument("--no-search", action="store_true", help="skip the end-to-end -search legs (rank 0, 1 GPU only)")
+    ap.add_argument("--no-live", action="store_true", help="skip the live-path kernel rooflines (rank 0, 1 GPU only)")
+    ap.add_argument("--live-only", action="store_true", help="only the live-path kernels (the command tools/prof_live.sh profiles)")
     args = ap.parse_args()
 
     import torch
@@ -194,6 +365,9 @@ def main():
     stream = torch.cuda.current_stream()
     ctx = reseek_amd.Ctx(local, stream=stream.cuda_stream)
     db = reseek_amd.Db.from_mu_seqs(ctx, seqs)          # inputs resident in HBM before the timed region
+    if args.live_only:
+        print(json.dumps({"roofline_live": live_kernels(ctx, seqs, db, reps=1)}))
+        return
     out = torch.zeros((n, n), dtype=torch.int16, device="cuda")
     summary = torch.zeros(2, dtype=torch.int64, device="cuda")
 
@@ -277,9 +451,17 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(seqs)
+        if not args.no_live and world == 1 and not args.chains:
+            try:
+                del out
+                torch.cuda.empty_cache()
+                res["roofline_live"] = live_kernels(ctx, seqs, db)
+            except Exception as e:  # noqa: BLE001 -- the kernel metric above stands on its own
+                sys.stderr.write("bench: live-kernel leg failed: %s\n" % e)
         if not args.no_search and world == 1 and not args.chains:
             try:
                 res["search"] = search_end_to_end(seqs)
+                res["search_bca"] = search_vs_reference()
             except Exception as e:  # noqa: BLE001 -- the kernel metric above stands on its own
                 sys.stderr.write("bench: end-to-end search leg failed: %s\n" % e)
         print(json.dumps(res))

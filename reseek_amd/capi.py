@@ -191,8 +191,8 @@ class Ctx:
         return a.value, b.value
 
     # ---- P5/P6/P7 main alignment ---------------------------------------------------------------
-    def align_pairs(self, a, b, ia, ib, min_fwd_score=7.0, gap_open=GAP_OPEN, gap_ext=GAP_EXT):
-        """-> list of (Aln, path str)"""
+    def align_pairs(self, a, b, ia, ib, min_fwd_score=7.0, gap_open=GAP_OPEN, gap_ext=GAP_EXT, collect=True):
+        """-> list of (Aln, path str); collect=False: run the call, return None (timing)"""
         ia = np.ascontiguousarray(ia, np.uint32)
         ib = np.ascontiguousarray(ib, np.uint32)
         n = len(ia)
@@ -201,6 +201,8 @@ class Ctx:
         out = (Aln * max(1, n))()
         _check(lib().rsk_align_pairs(self.h, a.h, b.h, _p(ia, u32p), _p(ib, u32p), n, gap_open, gap_ext, min_fwd_score,
                                      out, buf, nbytes))
+        if not collect:
+            return None
         raw = buf.raw
         return [(out[k], raw[out[k].path_off:out[k].path_off + out[k].path_len].decode()) for k in range(n)]
 

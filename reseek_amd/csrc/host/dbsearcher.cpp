@@ -97,14 +97,30 @@ void DBSearcher::LoadBCA(const std::string &FN)
     BCAData B;
     B.Open(FN);
     const uint64_t n = B.GetChainCount();
+    std::vector<PDBChain *> Chains;
+    Chains.reserve(n);
     for (uint64_t k = 0; k < n; ++k) {
         PDBChain *C = new PDBChain;
         B.ReadChain(k, *C);
+        Chains.push_back(C);
+    }
+    tm.lap("read chains");
+    LoadChains(Chains);
+}
+
+// The chains become this searcher's set (ownership taken; Chains is left empty): DSS profile, Mu letters and Mu 3-mers
+// of every chain on the host threads, then the self-rev scores in one GPU batch.
+void DBSearcher::LoadChains(std::vector<PDBChain *> &Chains)
+{
+    PhaseTimer tm("LoadChains");
+    if (!m_Ctx) m_Ctx = DefaultCtx();
+    if (m_Opts.mode == AM_Invalid) m_Opts = g_Opts;
+    for (PDBChain *C : Chains) {
         if (C->GetSeqLength() < 1) { delete C; continue; }              // m_MinChainLength = 1 (profileloader.cpp:82)
         AddChain(C, new std::vector<std::vector<byte> >, new std::vector<byte>);
         m_DBMuKmersVec.push_back(new std::vector<uint>);
     }
-    tm.lap("read chains");
+    Chains.clear();
     const uint N = GetDBChainCount();
     const unsigned T = HostThreads(128);
     std::atomic<uint> next{0};
@@ -274,6 +290,8 @@ void DBSearcher::ComputeSelfRevScores()
 
 void DBSearcher::LoadDB(const std::string &DBFN)
 {
+    if (!m_Ctx) m_Ctx = DefaultCtx();
+    if (m_Opts.mode == AM_Invalid) m_Opts = g_Opts;
     if (EndsWith(DBFN, ".bca")) { LoadBCA(DBFN); return; }
     FILE *f = fopen(DBFN.c_str(), "rb");
     if (!f) throw std::runtime_error("LoadDB: cannot open " + DBFN);
@@ -314,6 +332,8 @@ void DBSearcher::LoadDB(const std::string &DBFN)
 
 void DBSearcher::Setup()
 {
+    if (!m_Ctx) m_Ctx = DefaultCtx();
+    if (m_Opts.mode == AM_Invalid) m_Opts = g_Opts;
     if (m_Opts.evalue_set) m_MaxEvalue = m_Opts.evalue;
     else m_MaxEvalue = (m_Opts.mode == AM_VerySensitive) ? DBL_MAX : 10;
     m_HitCount = 0;
@@ -897,6 +917,7 @@ static void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOff
 
 void DBSearcher::RunSelf()
 {
+    if (!m_fTsv) m_fTsv = g_fTsv;
     UploadToGpu();
     RunPairs(*this, *this, true);
 }
@@ -940,6 +961,7 @@ void DBSearcher::RunSelfShard(uint Index, uint Count)
 void DBSearcher::RunQuery(DBSearcher &DBChainsSource)
 {
     PhaseTimer tm("RunQuery");
+    if (!m_fTsv) m_fTsv = g_fTsv;
     UploadToGpu();
     DBChainsSource.m_Ctx = m_Ctx;
     DBChainsSource.UploadToGpu();
@@ -948,12 +970,69 @@ void DBSearcher::RunQuery(DBSearcher &DBChainsSource)
     tm.lap("RunPairs");
 }
 
+// runquery.cpp:18-125.  The reference's threads pull one chain at a time from the reader, featurise it, compute its
+// self-rev score and walk it past every loaded chain.  Here the reader's chains are taken in batches (bounded by chains and
+// residues, so a -db file of any size needs a fixed amount of host RAM and HBM): a loader thread reads + featurises +
+// self-rev-scores batch k + 1 (on a context of its own) while batch k goes through the filter / alignment kernels.
+void DBSearcher::RunQuery(ChainReader2 &QCR)
+{
+    if (!m_Ctx) m_Ctx = DefaultCtx();
+    if (!m_fTsv) m_fTsv = g_fTsv;
+    UploadToGpu();
+    SecondaryCtx loader;
+    loader.Create(m_Ctx->device);
+    auto load = [&]() -> std::unique_ptr<DBSearcher> {
+        std::vector<PDBChain *> Chains;
+        uint64_t nres = 0;
+        while (Chains.size() < m_StreamBatchChains && nres < m_StreamBatchResidues) {
+            PDBChain *C = QCR.GetNext();
+            if (!C) break;
+            nres += C->GetSeqLength();
+            Chains.push_back(C);
+        }
+        std::unique_ptr<DBSearcher> Src;
+        if (Chains.empty()) return Src;
+        Src.reset(new DBSearcher);
+        Src->m_Params = m_Params;
+        Src->m_SelfRevQueryFlavour = true;               // runquery.cpp:43-44: the search params themselves
+        Src->m_Opts = m_Opts;
+        Src->m_Ctx = loader.c;
+        try {
+            Src->LoadChains(Chains);
+        } catch (...) {
+            for (PDBChain *C : Chains) delete C;
+            throw;
+        }
+        return Src;
+    };
+    uint64_t pairs = 0, alns = 0, mkf = 0, fin = 0, fdis = 0;
+    std::future<std::unique_ptr<DBSearcher> > next = std::async(std::launch::async, load);
+    for (;;) {
+        std::unique_ptr<DBSearcher> Src = next.get();
+        if (!Src) break;
+        next = std::async(std::launch::async, load);
+        try {
+            RunQuery(*Src);
+        } catch (...) {
+            next.wait();
+            throw;
+        }
+        pairs += m_ProcessedPairCount; alns += m_AlnCount; mkf += m_MKFPairCount; fin += m_MuFilterInputCount; fdis += m_MuFilterDiscardCount;
+    }
+    m_ProcessedPairCount = pairs; m_AlnCount = alns; m_MKFPairCount = mkf; m_MuFilterInputCount = fin; m_MuFilterDiscardCount = fdis;
+}
+
 // One pair through the same GPU kernels (the reference's per-pair entry point, dssaligner.cpp:793).
 void DSSAligner::AlignQueryTarget()
 {
     ClearAlign();
     if (DoMKF()) { AlignMKF(); return; }
-    if (!m_Ctx) throw std::runtime_error("DSSAligner::AlignQueryTarget: no GPU context (set m_Ctx)");
+    AlignPairOnGpu();
+}
+
+void DSSAligner::AlignPairOnGpu()
+{
+    if (!m_Ctx) m_Ctx = DefaultCtx();
     auto mk = [&](const PDBChain &C, const std::vector<std::vector<byte> > &Prof, const std::vector<byte> *Mu, float SelfRev) {
         const uint32_t L = C.GetSeqLength();
         std::vector<uint8_t> prof((size_t) L * RSK_NFEAT);
@@ -1067,6 +1146,25 @@ static int search_impl(rsk_ctx *ctx, const char *query_rskdb, const char *db_rsk
             if (o.shard_count > 1) DBS.RunSelfShard(o.shard_index, o.shard_count);
             else DBS.RunSelf();
         } else {
+            const std::string dbfn = db_rskdb;
+            if (dbfn.size() >= 4 && dbfn.compare(dbfn.size() - 4, 4, ".bca") == 0) {
+                // Search_NoMuFilter search.cpp:39-60: the -db file streams through a ChainReader2
+                ChainReader2 CR;
+                if (o.shard_count > 1) {
+                    // -db mode: contiguous target shards balanced by residues, the query set is replicated
+                    BCAData B;
+                    B.Open(dbfn);
+                    const uint64_t NS = B.GetChainCount();
+                    std::vector<uint64_t> cum(NS + 1, 0);
+                    for (uint64_t i = 0; i < NS; ++i) cum[i + 1] = cum[i] + B.m_SeqLengths[i];
+                    auto bound = [&](uint r) { return r >= o.shard_count ? NS : (uint64_t) (std::lower_bound(cum.begin(), cum.end(), cum[NS] * r / o.shard_count) - cum.begin()); };
+                    const uint64_t Lo = std::min(NS, bound(o.shard_index)), Hi = std::max(Lo, std::min(NS, bound(o.shard_index + 1)));
+                    CR.OpenRange(dbfn, Lo, Hi);
+                } else
+                    CR.Open(dbfn);
+                if (const char *e = getenv("RSK_STREAM_CHAINS")) { const long v = atol(e); if (v > 0) DBS.m_StreamBatchChains = (uint) v; }
+                DBS.RunQuery(CR);
+            } else {
             DBSearcher Src;
             Src.m_Params = &Params;
             Src.m_SelfRevQueryFlavour = true;            // runquery.cpp:43-44
@@ -1085,6 +1183,7 @@ static int search_impl(rsk_ctx *ctx, const char *query_rskdb, const char *db_rsk
                 if (Hi > Lo) DBS.RunQuery(View);
             } else
                 DBS.RunQuery(Src);
+            }
         }
         fclose(f);
         if (nhits) *nhits = DBS.m_HitCount;

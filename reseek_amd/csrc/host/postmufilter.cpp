@@ -27,6 +27,9 @@ static void check(int rc, const char *what)
     if (rc != RSK_OK) throw std::runtime_error(std::string(what) + ": " + rsk_last_error());
 }
 
+void MuPreFilterLetters(rsk_ctx *ctx, const std::vector<uint32_t> &qlen, const std::vector<uint8_t> &qmu, rsk_db *tdb, uint NT, int idx_mode,
+                        uint rsb_size, const std::string &OutputFN);
+
 void MuPreFilter(const DSSParams &Params, DBSearcher &QDB, DBSearcher &TDB, const std::string &OutputFN)
 {
     (void) Params;
@@ -66,6 +69,14 @@ void MuPreFilter(const DSSParams &Params, DBSearcher &QDB, DBSearcher &TDB, cons
     size_t qo = 0;
     for (uint i = 0; i < NQ; ++i)
         for (byte l : *QDB.m_DBMuLettersVec[i]) qmu[qo++] = l == 10 ? 11 : (l == 11 ? 10 : l);
+    MuPreFilterLetters(ctx, qlen, qmu, tdb, NT, QDB.m_Opts.idx_mode, QDB.m_Opts.rsb_size, OutputFN);
+}
+
+// index of the query letters + scan of every target + per-query top-B + hand-off file (muprefilter.cpp:90-133)
+void MuPreFilterLetters(rsk_ctx *ctx, const std::vector<uint32_t> &qlen, const std::vector<uint8_t> &qmu, rsk_db *tdb, uint NT, int idx_mode,
+                        uint rsb_size, const std::string &OutputFN)
+{
+    const uint NQ = (uint) qlen.size();
     PhaseTimer tm("MuPreFilter");
     rsk_db *qdb = nullptr;
     check(rsk_db_create(ctx, NQ, qlen.data(), qmu.data(), nullptr, nullptr, nullptr, nullptr, nullptr, &qdb), "rsk_db_create");
@@ -80,7 +91,7 @@ void MuPreFilter(const DSSParams &Params, DBSearcher &QDB, DBSearcher &TDB, cons
         hipok(hipMalloc((void **) &d_t, std::max<size_t>(cap, 1) * 4), "hipMalloc");
         hipok(hipMalloc((void **) &d_s, std::max<size_t>(cap, 1) * 4), "hipMalloc");
         hipok(hipMalloc((void **) &d_n, 4), "hipMalloc");
-        const int rc = rsk_mu_prefilter_dev(ctx, qdb, tdb, QDB.m_Opts.idx_mode, d_q, d_t, d_s, cap, d_n);
+        const int rc = rsk_mu_prefilter_dev(ctx, qdb, tdb, idx_mode, d_q, d_t, d_s, cap, d_n);
         uint32_t n = 0;
         if (rc == RSK_OK) hipok(hipMemcpy(&n, d_n, 4, hipMemcpyDeviceToHost), "copy n");
         if (rc == RSK_OK && n <= cap) {
@@ -96,8 +107,7 @@ void MuPreFilter(const DSSParams &Params, DBSearcher &QDB, DBSearcher &TDB, cons
     }
     tm.lap("index + scan (GPU)");
     size_t nout = 0;
-    check(rsk_rsb_select(hq.data(), ht.data(), hs.data(), hq.size(), NQ, QDB.m_Opts.rsb_size, nullptr, nullptr, nullptr, &nout,
-                         OutputFN.c_str()),
+    check(rsk_rsb_select(hq.data(), ht.data(), hs.data(), hq.size(), NQ, rsb_size, nullptr, nullptr, nullptr, &nout, OutputFN.c_str()),
           "rsk_rsb_select");
     tm.lap("top-B bags + hand-off");
 }
@@ -110,16 +120,12 @@ static bool Accept(const DSSAligner &DA, double MaxEvalue, double MaxPvalue, dou
     return false;
 }
 
-void PostMuFilter(const DSSParams &Params, const std::string &MuFilterTsvFN, DBSearcher &Q, DBSearcher &DB, const std::string &HitsFN)
+// The hand-off file of the prefilter (rankedscoresbag.cpp:185-231): "prefilter\t<#targets>", then "TIdx\tK\tQIdx..." lines ->
+// candidate pairs in file order (A = query, B = target).  NoHits = the header announces no target line (postmufilter.cpp:219-223).
+void ReadHandOff(const std::string &MuFilterTsvFN, uint NQ, uint64_t NT, std::vector<uint32_t> &pq, std::vector<uint32_t> &pt, bool &NoHits)
 {
-    PhaseTimer tm("PostMuFilter");
-    const SearchOptions &O = Q.m_Opts;
-    double MaxEvalue = 10, MaxPvalue = -1, MinTS = 9e9;                    // postmufilter.cpp:31-33,196-203
-    if (O.evalue_set) MaxEvalue = O.evalue;
-    else if (O.mode == AM_VerySensitive) MaxEvalue = 9e9;
-    if (O.pvalue_set) MaxPvalue = O.pvalue;
-    if (O.mints_set) MinTS = O.mints;
-
+    NoHits = false;
+    pq.clear(); pt.clear();
     FILE *fin = fopen(MuFilterTsvFN.c_str(), "r");
     if (!fin) throw std::runtime_error("PostMuFilter: cannot open " + MuFilterTsvFN);
     std::vector<char> buf(1 << 16);
@@ -135,9 +141,7 @@ void PostMuFilter(const DSSParams &Params, const std::string &MuFilterTsvFN, DBS
     if (!readline()) { fclose(fin); throw std::runtime_error("PostMuFilter: empty hand-off file"); }
     unsigned LineCount = 0;
     if (sscanf(line.c_str(), "prefilter\t%u", &LineCount) != 1) { fclose(fin); throw std::runtime_error("PostMuFilter: bad header line"); }
-    if (LineCount == 0) { fclose(fin); fprintf(stderr, "Warning: No hits found by mufilter pass\n"); return; }   // :219-223 (no hits file)
-    const uint NQ = Q.GetDBChainCount(), NT = DB.GetDBChainCount();
-    std::vector<uint32_t> pq, pt;                                          // candidates in file order (A = query, B = target)
+    if (LineCount == 0) { fclose(fin); fprintf(stderr, "Warning: No hits found by mufilter pass\n"); NoHits = true; return; }   // :219-223 (no hits file)
     for (unsigned k = 0; k < LineCount; ++k) {
         if (!readline()) { fclose(fin); throw std::runtime_error("PostMuFilter: truncated hand-off file"); }
         const char *s = line.c_str();
@@ -153,7 +157,33 @@ void PostMuFilter(const DSSParams &Params, const std::string &MuFilterTsvFN, DBS
         }
     }
     fclose(fin);
+}
+
+void PostMuFilterPairs(const DSSParams &Params, DBSearcher &Q, DBSearcher &DB, const std::vector<uint32_t> &pq, const std::vector<uint32_t> &pt,
+                       const std::string &HitsFN);
+
+void PostMuFilter(const DSSParams &Params, const std::string &MuFilterTsvFN, DBSearcher &Q, DBSearcher &DB, const std::string &HitsFN)
+{
+    PhaseTimer tm("PostMuFilter");
+    std::vector<uint32_t> pq, pt;
+    bool NoHits = false;
+    ReadHandOff(MuFilterTsvFN, Q.GetDBChainCount(), DB.GetDBChainCount(), pq, pt, NoHits);
     tm.lap("read hand-off file");
+    if (NoHits) return;
+    PostMuFilterPairs(Params, Q, DB, pq, pt, HitsFN);
+}
+
+// AlignBags (chainbag.cpp:44) of every candidate, Accept (postmufilter.cpp:106) and ToTsv(up = true)
+void PostMuFilterPairs(const DSSParams &Params, DBSearcher &Q, DBSearcher &DB, const std::vector<uint32_t> &pq, const std::vector<uint32_t> &pt,
+                       const std::string &HitsFN)
+{
+    PhaseTimer tm("PostMuFilter");
+    const SearchOptions &O = Q.m_Opts;
+    double MaxEvalue = 10, MaxPvalue = -1, MinTS = 9e9;                    // postmufilter.cpp:31-33,196-203
+    if (O.evalue_set) MaxEvalue = O.evalue;
+    else if (O.mode == AM_VerySensitive) MaxEvalue = 9e9;
+    if (O.pvalue_set) MaxPvalue = O.pvalue;
+    if (O.mints_set) MinTS = O.mints;
 
     rsk_ctx *ctx = Q.m_Ctx;
     if (!ctx) throw std::runtime_error("PostMuFilter: no GPU context");

@@ -78,11 +78,28 @@ struct SearchOptions {
     int idx_mode = -1;                                 // -idxq (1) / -idxt (2); -1 = by query count (muprefilter.cpp:78-87)
     uint rsb_size = 1500;                              // -rsb_size (prefiltermuparams.h:15)
     std::string dbmu;                                  // -dbmu: Mu FASTA of the DB for the prefilter stage (search.cpp:93-96)
+    std::string db, output;                            // -db, -output (read by the reference-shaped callers: g_Opts below)
+    bool fast_set() const { return mode == AM_Fast; }  // optset_fast
     bool keeptmp = false;                              // -keeptmp
     uint shard_index = 0, shard_count = 0;             // multi-GPU: this rank's shard of the targets (0/0 or x/1 = everything)
     size_t batch_pairs = 1u << 20;                     // upper bound of pairs per GPU alignment batch
     uint64_t batch_cells = 24ull << 30;                // ... and of DP cells per batch (~1 trace byte per cell in HBM)
 };
+
+enum DECIDE_MODE {                                      // dssparams.h:16-25
+    DM_Invalid, DM_AlwaysFast, DM_AlwaysSensitive, DM_AlwaysVerysensitive, DM_DefaultFast, DM_DefaultSensitive, DM_UseCommandLineOption
+};
+
+// The reference's process-wide state, for callers written like search.cpp: the parsed command line behind its opt(x) /
+// optset_x macros (myutils.h:365-372), the first positional argument, and the hits file of output.cpp:8-20.
+extern SearchOptions g_Opts;
+extern std::string g_Arg1;
+extern FILE *g_fTsv;
+void OpenOutputFiles();                                 // output.cpp:8  (creates g_Opts.output; "" = no file)
+void CloseOutputFiles();                                // output.cpp:15
+// A library needs a device context where the reference has none: DBSearcher / DSSAligner objects whose m_Ctx was never
+// set use this one (created on first use on device RSK_DEVICE, default 0; destroyed at exit).
+rsk_ctx *DefaultCtx();
 
 class DSSParams {
 public:
@@ -96,7 +113,9 @@ public:
     float m_MKF_MinMegaHSPScore = FLT_MAX;
     std::string m_MKFPatternStr = "111";
     void SetDefaults();                                 // namedparams.cpp:32
-    void SetDSSParams(const SearchOptions &Opts);       // dssparams.cpp:44 (DM_UseCommandLineOption)
+    void SetDSSParams(const SearchOptions &Opts);       // dssparams.cpp:44 with an explicit command line
+    void SetDSSParams(DECIDE_MODE DM);                  // dssparams.cpp:44: the mode from DM / g_Opts, the other options from g_Opts
+    std::string m_MuPrefPatternStr = "1110011";         // prefiltermuparams.h (asserted by cmd_search search.cpp:82-83)
 };
 
 class PDBChain {                                        // pdbchain.h:10 (the members the path uses)
@@ -177,6 +196,32 @@ public:
 // (alpha.cpp:3291: 'L' -> 10, 'K' -> 11), exactly as the reference does.
 void ReadMuFasta(const std::string &FN, std::vector<std::string> &Labels, std::vector<std::vector<byte> > &Seqs);
 
+// chainreader2.h:10 -- streams the chains of a structure file.  Only the .bca container is on this path (PDB / mmCIF /
+// .cal parsing is out of scope: SURVEY section 2); Open() throws for anything else.  GetNext() returns a new PDBChain
+// the caller deletes, 0 at the end (runquery.cpp:33-35); thread-safe like the reference's (m_CRGlobalLock).
+class ChainReader2 {
+public:
+    BCAData m_BCA;
+    uint64_t m_ChainIdx_BCA = 0, m_EndIdx_BCA = 0;
+    std::string m_CurrentFN;
+    std::mutex m_CRGlobalLock;
+    void Open(const std::string &FileName);
+    void OpenRange(const std::string &FileName, uint64_t Lo, uint64_t Hi);   // chains [Lo, Hi) only (multi-GPU target shards)
+    PDBChain *GetNext();
+    uint64_t GetChainCount() const { return m_EndIdx_BCA; }
+};
+
+class ChainBag {                                        // chainbag.h:5 -- borrowed pointers to one chain's search inputs
+public:
+    const PDBChain *m_ptrChain = nullptr;
+    const std::vector<std::vector<byte> > *m_ptrProfile = nullptr;
+    const std::vector<byte> *m_ptrMuLetters = nullptr;
+    const std::vector<uint> *m_ptrMuKmers = nullptr;
+    const void *m_ptrProfPara = nullptr, *m_ptrProfParaRev = nullptr;   // parasail profiles: unused here (the Mu kernel builds its own in LDS)
+    const uint16_t *m_ptrKmerHashTableQ = nullptr;
+    float m_SelfRevScore = FLT_MAX;
+};
+
 class DSSAligner;
 
 class MuKmerFilter {                                    // mukmerfilter.h:10
@@ -196,6 +241,8 @@ public:
     void ResetQ();
     void SetQ(const std::string &LabelQ, const std::vector<byte> *ptrMuLettersQ, const std::vector<uint> *ptrMuKmersQ);
     void Align(const std::vector<byte> &MuLettersT, const std::vector<uint> &MuKmersT);
+    void SetBagQ(const ChainBag &BagQ);                 // mukmerfilter.h:82 (mukmerfilter2.cpp): SetQ from a bag
+    void AlignBag(const ChainBag &BagT);                // mukmerfilter.h:87: Align against a bag's letters / k-mers
     // the state Align() leaves when its seed loop kept these HSPs (computed by rsk_mkf_seed_pairs), then ChainHSPs()
     void SetSeedHSPs(const int32_t *Kept4, uint Count);
     int MuXDrop(int PosQ, int LQ, int PosT, int LT, int X, int &Loi, int &Loj, int &Len) const;
@@ -249,6 +296,10 @@ public:
     bool DoMKF() const;                                 // dssaligner.cpp:715
     void ClearAlign();                                  // dssaligner.cpp:906
     void AlignQueryTarget();                            // dssaligner.cpp:793 (one pair; batch of 1 on the GPU)
+    bool DoMKF_Bags(const ChainBag &BagA, const ChainBag &BagB) const;   // chainbag.cpp:6
+    void AlignBags(const ChainBag &BagA, const ChainBag &BagB);          // chainbag.cpp:44 (one pair; batch of 1 on the GPU)
+    void AlignBagsMKF(const ChainBag &BagA, const ChainBag &BagB);       // chainbag.cpp:24
+    void AlignPairOnGpu();                              // MuFilter (:619) + Align_NoAccel (:929) + CalcEvalue of the current pair, batch of one
     void AlignMKF();                                    // dssaligner.cpp:1387
     void AlignMKF_FromSeeds(const int32_t *Kept4, uint Count);   // same, seeding stage already done on the GPU
     void PostAlignMKF();                                // dssaligner.cpp:1395
@@ -336,7 +387,12 @@ public:
     void AddChain(PDBChain *ptrChain, std::vector<std::vector<byte> > *ptrProfile, std::vector<byte> *ptrMuLetters);
     void Setup();                                       // dbsearcher.cpp:73
     void RunSelf();                                     // runself.cpp:101
-    void RunQuery(DBSearcher &DBChainsSource);          // runquery.cpp:82 (A = each chain of the source, B = our chains)
+    void RunQuery(ChainReader2 &QCR);                   // runquery.cpp:82: the reader's chains are streamed past our chains in batches
+    void RunQuery(DBSearcher &DBChainsSource);          // the same for a chain set that is already loaded (A = its chains, B = ours)
+    // chains per streamed batch of RunQuery(ChainReader2 &): bounds the host RAM / HBM a -db file needs, whatever its size
+    uint m_StreamBatchChains = 1u << 17;
+    uint64_t m_StreamBatchResidues = 48ull << 20;
+    void LoadChains(std::vector<PDBChain *> &Chains);   // take ownership, featurise on the host threads, self-rev scores on the GPU
     bool m_OwnsChains = true;
     void MakeView(const DBSearcher &Src, uint Lo, uint Hi);
     void RunSelfShard(uint Index, uint Count);          // one rank's part of the self-search triangle
@@ -370,6 +426,42 @@ void RunMKFPairs(rsk_ctx *Ctx, const DSSParams &Params, const std::string &Colum
 std::vector<std::pair<size_t, size_t> > AlignBatches(const SearchOptions &O, const DBSearcher &A, const DBSearcher &B,
                                                      const std::vector<uint32_t> &ia, const std::vector<uint32_t> &ib);
 
+// museqsource.h:8 -- the Mu-letter view of a chain file (OpenChains: chains are featurised on the fly) or of a Mu FASTA
+// (OpenFasta, -dbmu).  m_ASCII = true yields 'A' + letter characters (what SeqDB::FromSS stores), false raw letters.
+class MuSeqSource {
+public:
+    bool m_IsFasta = false, m_ASCII = true;
+    ChainReader2 m_CR;
+    const DSSParams *m_Params = nullptr;
+    std::vector<std::string> m_FaLabels;                // OpenFasta: read up front
+    std::vector<std::vector<byte> > m_FaSeqs;
+    size_t m_FaNext = 0;
+    void OpenFasta(const std::string &FileName);
+    void OpenChains(const std::string &FileName, const DSSParams &Params);
+    bool GetNext(std::string &Label, std::vector<byte> &Seq);   // SeqSource::GetNext (seqsource.h), value form
+    // everything that is left, featurised on the host threads (what MuPreFilter / SeqDB::FromSS consume)
+    void GetAll(std::vector<std::string> &Labels, std::vector<std::vector<byte> > &Seqs);
+    void Close() {}
+};
+
+class SeqDB {                                           // seqdb.h:9 (the members the path uses)
+public:
+    std::vector<std::string> m_Labels, m_Seqs;
+    uint GetSeqCount() const { return (uint) m_Seqs.size(); }
+    unsigned AddSeq(const std::string &Label, const std::string &Seq) { m_Labels.push_back(Label); m_Seqs.push_back(Seq); return GetSeqCount() - 1; }
+    const std::string &GetSeq(unsigned i) const { return m_Seqs[i]; }
+    const std::string &GetLabel(unsigned i) const { return m_Labels[i]; }
+    unsigned GetSeqLength(unsigned i) const { return (unsigned) m_Seqs[i].size(); }
+    void FromSS(MuSeqSource &SS);                       // seqdb.cpp FromSS
+    void ToLetters(const byte *CharToLetter);           // seqdb.cpp ToLetters (in place)
+};
+extern const byte *const g_CharToLetterMu;              // alpha.cpp:3291, 256 entries (sic: 'K' -> 10, 'L' -> 11; 0xFF = invalid)
+
+// search.cpp:9-18: the two stages of `-search -fast -db` with the reference's argument lists ...
+void MuPreFilter(const DSSParams &Params, SeqDB &QueryDB, MuSeqSource &FSS, const std::string &OutputFN);
+void PostMuFilter(const DSSParams &Params, const std::string &MuFilterTsvFN, const std::string &QueryCAFN, const std::string &DBBCAFN,
+                  const std::string &HitsFN);
+// ... and on chain sets that are already loaded (what rsk_search uses)
 void MuPreFilter(const DSSParams &Params, DBSearcher &QDB, DBSearcher &TDB, const std::string &OutputFN);
 void PostMuFilter(const DSSParams &Params, const std::string &MuFilterTsvFN, DBSearcher &Q, DBSearcher &DB,
                   const std::string &HitsFN);

@@ -39,28 +39,43 @@ def write_rskdb(path, seqs, rng):
             f.write(struct.pack("<I", len(km)) + km.astype(np.uint32).tobytes())
 
 
-def write_bca(path, lens, rng):
-    """Synthetic .bca (bcadata.cpp layout): CA traces = random walks with 3.8 A steps whose direction persists
-    (helix-like / strand-like stretches), amino acids iid.  Featurisation (DSS) and self-rev then run in LoadDB."""
-    n = len(lens)
+def gen_bca_chains(lens, rng):
+    """Synthetic chains for a .bca file: CA traces = random walks with 3.8 A steps whose direction persists (helix-like /
+    strand-like stretches), amino acids iid.  -> list of (amino-acid bytes, interleaved uint16 x,y,z bytes, L)."""
+    recs = []
+    for L in lens:
+        L = int(L)
+        aa = rng.integers(0, 20, L)
+        seq = bytes(b"ACDEFGHIKLMNPQRSTVWY"[int(a)] for a in aa)
+        d = lfilter([0.6], [1.0, -0.8], rng.normal(0, 1, (L, 3)) / 0.6, axis=0)      # persistent direction: d[k] = 0.8 d[k-1] + n[k]
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        xyz = np.cumsum(3.8 * d, axis=0)
+        xyz -= xyz.mean(axis=0)
+        ic = np.clip(((xyz.astype(np.float32) + 1000) * 10 + 0.5), 0, 65535).astype(np.uint16)
+        recs.append((seq, ic.tobytes(), L))
+    return recs
+
+
+def write_bca_records(path, recs, labels=None):
+    """bcadata.cpp layout: magic, #chains, offset of the length table, label bytes; per chain sequence + 3L uint16
+    coordinates; uint32 lengths; NUL-terminated labels."""
+    n = len(recs)
     with open(path, "wb") as f:
         f.write(struct.pack("<IQQQ", 0xBCABCA, n, 0, 0))
-        for L in lens:
-            L = int(L)
-            aa = rng.integers(0, 20, L)
-            f.write(bytes(b"ACDEFGHIKLMNPQRSTVWY"[int(a)] for a in aa))
-            d = lfilter([0.6], [1.0, -0.8], rng.normal(0, 1, (L, 3)) / 0.6, axis=0)      # persistent direction: d[k] = 0.8 d[k-1] + n[k]
-            d /= np.linalg.norm(d, axis=1, keepdims=True)
-            xyz = np.cumsum(3.8 * d, axis=0)
-            xyz -= xyz.mean(axis=0)
-            ic = np.clip(((xyz.astype(np.float32) + 1000) * 10 + 0.5), 0, 65535).astype(np.uint16)
-            f.write(ic.tobytes())
+        for seq, ic, _ in recs:
+            f.write(seq)
+            f.write(ic)
         pos = f.tell()
-        f.write(np.asarray(lens, np.uint32).tobytes())
-        labels = b"".join(("syn%05d" % k).encode() + b"\0" for k in range(n))
-        f.write(labels)
+        f.write(np.asarray([r[2] for r in recs], np.uint32).tobytes())
+        lab = b"".join((labels[k] if labels else "syn%05d" % k).encode() + b"\0" for k in range(n))
+        f.write(lab)
         f.seek(4)
-        f.write(struct.pack("<QQQ", n, pos, len(labels)))
+        f.write(struct.pack("<QQQ", n, pos, len(lab)))
+
+
+def write_bca(path, lens, rng):
+    """Synthetic .bca; featurisation (DSS) and self-rev then run in LoadDB."""
+    write_bca_records(path, gen_bca_chains(lens, rng))
 
 
 def main_qdb():
