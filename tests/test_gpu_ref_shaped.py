@@ -1,0 +1,95 @@
+"""SURVEY 8b "signatures to keep": tests/ref_shaped/search_main.cpp is written in the call sequence of the reference's
+search.cpp:20-111 (DBSearcher::LoadDB/Setup/RunSelf, ChainReader2 + RunQuery, MuSeqSource / SeqDB / MuPreFilter /
+PostMuFilter with the reference's argument lists).  It is compiled here against reseek_host.h + librsk.so and its hit
+tables must equal the reference binary's goldens; a second program drives the per-pair entry points
+(SetQuery/SetTarget/AlignQueryTarget, ChainBag + AlignBags, MuKmerFilter::SetBagQ/AlignBag)."""
+import gzip
+import os
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+import fixtures as fx
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COLS = "query+target+qlo+qhi+ql+tlo+thi+tl+pctid+pvalue+evalue+cigar+dpscore+lddt+newts+ids+gaps+aq"
+
+
+def _compile(src, exe):
+    cxx = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else "g++"
+    cmd = [cxx] + (["-x", "c++"] if cxx.endswith("hipcc") else []) + [
+        "-std=c++17", "-O1", "-I", os.path.join(ROOT, "reseek_amd", "csrc", "host"), src, "-L", os.path.join(ROOT, "reseek_amd"), "-lrsk",
+        "-Wl,-rpath," + os.path.join(ROOT, "reseek_amd"), "-pthread", "-o", exe]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+
+
+@pytest.fixture(scope="module")
+def work():
+    d = tempfile.mkdtemp(prefix="rsk_refshaped_")
+    for name in ("q100.bca", "palms.bca"):
+        with gzip.open(os.path.join(fx.GOLDEN, name + ".gz"), "rb") as f, open(os.path.join(d, name), "wb") as g:
+            g.write(f.read())
+    _compile(os.path.join(ROOT, "tests", "ref_shaped", "search_main.cpp"), os.path.join(d, "search_main"))
+    _compile(os.path.join(ROOT, "tests", "ref_shaped", "pair_main.cpp"), os.path.join(d, "pair_main"))
+    yield d
+    shutil.rmtree(d, ignore_errors=True)
+
+
+def _run(work, args, golden):
+    out = os.path.join(work, "hits.tsv")
+    if os.path.exists(out):
+        os.remove(out)
+    r = subprocess.run([os.path.join(work, "search_main")] + args + ["-output", out, "-columns", COLS], capture_output=True, text=True, cwd=work)
+    assert r.returncode == 0, r.stderr
+    got = sorted(open(out).read().splitlines())
+    want = sorted("\t".join(x) for x in fx.read_tsv(golden))
+    assert got == want, "hit tables differ: %d vs %d rows" % (len(got), len(want))
+
+
+def test_selfsearch_sequence(work):
+    _run(work, ["q100.bca", "-sensitive"], "hits_q100_sensitive.tsv.gz")
+
+
+def test_selfsearch_long_chains(work):
+    _run(work, ["palms.bca", "-sensitive"], "hits_palms_sensitive.tsv.gz")
+
+
+def test_search_nomufilter_streams_a_chainreader2(work):
+    _run(work, ["q100.bca", "-db", "q100.bca", "-sensitive"], "hits_q100_db_q100_sensitive.tsv.gz")
+
+
+def test_cmd_search_fast_db_two_stage(work):
+    """MuSeqSource / SeqDB / MuPreFilter / PostMuFilter with the argument lists of search.cpp:9-18; the hand-off file
+    must be the reference's byte for byte (-keeptmp)."""
+    _run(work, ["q100.bca", "-db", "q100.bca", "-fast", "-keeptmp"], "hits_q100_db_q100_fast.tsv.gz")
+    tmp = open(os.path.join(work, "hits.tsv.prefilter.tmp")).read()
+    with gzip.open(os.path.join(fx.GOLDEN, "prefilter_q100_db_q100_fast_tmp.tsv.gz"), "rt") as f:
+        assert tmp == f.read()
+
+
+def test_per_pair_entry_points(work):
+    """pair_main: every pair (i <= j) of the first 24 chains of q100 plus the long-chain set through
+    DSSAligner::AlignQueryTarget and again through ChainBag + AlignBags; both must reproduce the golden rows."""
+    r = subprocess.run([os.path.join(work, "pair_main"), "q100.bca", "24", "palms.bca", "6"], capture_output=True, text=True, cwd=work)
+    assert r.returncode == 0, r.stderr
+    rows = [ln.split("\t") for ln in r.stdout.splitlines() if ln and not ln.startswith("#")]
+    gold = {}
+    for name in ("hits_q100_sensitive.tsv.gz", "hits_palms_sensitive.tsv.gz"):
+        for x in fx.read_tsv(name):
+            gold[(x[0], x[1])] = x
+    assert rows, "pair_main printed nothing"
+    n_hit = 0
+    for x in rows:
+        how, line = x[0], x[1:]
+        key = (line[0], line[1])
+        if key in gold:            # E <= 10 rows of the golden table must match to the last column
+            assert line == gold[key], (how, line, gold[key])
+            n_hit += 1
+    assert n_hit >= 40
+    # the two forms print the same rows
+    aq = sorted(tuple(x[1:]) for x in rows if x[0] == "AlignQueryTarget")
+    ab = sorted(tuple(x[1:]) for x in rows if x[0] == "AlignBags")
+    assert aq == ab and aq

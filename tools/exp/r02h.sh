@@ -1,0 +1,2 @@
+O=gpurun_out/r02h; mkdir -p $O
+timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -15
