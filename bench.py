@@ -8,8 +8,12 @@ kernel (SWFastGapless_Int, swgaplessint.cpp:7) -> uint16 score matrix in HBM.
 One "step" = one full all-vs-all pass with the chain set already resident in HBM.
 
 metric = aligned DP cells/s (sum LA*LB over scored pairs / wall), chain-pairs/s reported beside it.
-N > 1 (one process per GPU, torchrun): each rank owns an independent SCOP40-shaped shard (seed +
-rank) -- weak scaling; the only exchange is an RCCL all_gather of the per-rank hit summary.
+N > 1 (one process per GPU, torchrun): strong scaling -- ONE SCOP40-shaped set, rank r scores the pairs whose
+target lies in its range of the triangle (ranges balanced by DP cells), value = all cells / max-over-ranks time;
+the only exchange is an RCCL all_gather of the per-rank hit buffers.  The whole `-search` call is sharded the same
+way (`search`).  --weak gives every rank an independent set instead.
+Beside the contract's fields the line carries `roofline_live` (the kernels the live -search path runs) and
+`search_bca` (whole call from a .bca file, with the reference binary timed on this box's host cores).
 """
 import argparse
 import json
@@ -324,6 +328,34 @@ def search_vs_reference(nsample=1500, reps=3):
     return out
 
 
+def search_sharded_leg(ctx, seqs, rank, world, dist, coll_dev):
+    """N > 1: the whole `-search -sensitive` all-vs-all call with the triangle cut into target ranges, one per rank
+    (rsk_search shard_index / shard_count), hit tables gathered on rank 0 over the process group; max-over-ranks wall
+    time of the second of two runs."""
+    import torch
+    from reseek_amd import dist as rdist
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_search
+    with tempfile.TemporaryDirectory() as td:
+        db, out = os.path.join(td, "syn.rskdb"), os.path.join(td, "hits.tsv")
+        bench_search.write_rskdb(db, seqs, np.random.default_rng(5))
+        for _ in range(2):
+            dist.barrier()
+            t0 = time.perf_counter()
+            nhits, st = rdist.search_sharded(ctx, db, out, "sensitive", device=coll_dev)
+            dist.barrier()
+            dt = time.perf_counter() - t0
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+        p = torch.tensor([float(st[0])], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(p, op=dist.ReduceOp.SUM)
+        if rank != 0:
+            return None
+        return {"mode": "-search -sensitive, all-vs-all, whole call, triangle sharded by target range over %d ranks" % world,
+                "seconds": float(t.item()), "chain_pairs": int(p.item()), "chain_pairs_per_sec": float(p.item()) / float(t.item()),
+                "hits_gathered": int(nhits)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -331,6 +363,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--chains", type=int, default=0, help="0 = the full SCOP40-shaped set (11,211)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--weak", action="store_true", help="N > 1: an independent SCOP40-shaped set per rank instead of shards of one")
     ap.add_argument("--no-search", action="store_true", help="skip the end-to-end -search legs (rank 0, 1 GPU only)")
     ap.add_argument("--no-live", action="store_true", help="skip the live-path kernel rooflines (rank 0, 1 GPU only)")
     ap.add_argument("--live-only", action="store_true", help="only the live-path kernels (the command tools/prof_live.sh profiles)")
@@ -360,19 +393,36 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     coll_dev = torch.device("cpu") if one_device else torch.device("cuda", local)
 
-    seqs = synth_mu_chains(0x5EED5EEC + rank, args.chains or None)
+    # N > 1: ONE SCOP40-shaped set on every rank (strong scaling, BASELINE metric "SCOP40 all-vs-all, 1/2/4/8 GPUs"); rank r
+    # scores the pairs (i <= j) whose target j lies in its range [lo, hi) of the length-sorted set, ranges balanced by DP
+    # cells: a rectangular launch chains[0:lo) x chains[lo:hi) plus the triangle of chains[lo:hi).  --weak: an independent
+    # set per rank (seed + rank), as in round 1.
+    seqs = synth_mu_chains(0x5EED5EEC + (rank if args.weak else 0), args.chains or None)
     n = len(seqs)
+    lens = np.array([len(s) for s in seqs], np.float64)
+    if world > 1 and not args.weak:
+        cum = np.concatenate([[0.0], np.cumsum(lens * np.cumsum(lens))])       # cells of the pairs (i <= j) up to target j
+        bounds = [int(np.searchsorted(cum, cum[-1] * r / world, side="left")) for r in range(world)] + [n]
+        lo, hi = bounds[rank], max(bounds[rank], bounds[rank + 1])
+    else:
+        lo, hi = 0, n
+    nb = hi - lo
     stream = torch.cuda.current_stream()
     ctx = reseek_amd.Ctx(local, stream=stream.cuda_stream)
-    db = reseek_amd.Db.from_mu_seqs(ctx, seqs)          # inputs resident in HBM before the timed region
+    db = reseek_amd.Db.from_mu_seqs(ctx, seqs[lo:hi]) if nb else None          # inputs resident in HBM before the timed region
+    dbq = reseek_amd.Db.from_mu_seqs(ctx, seqs[:lo]) if lo and nb else None
     if args.live_only:
         print(json.dumps({"roofline_live": live_kernels(ctx, seqs, db, reps=1)}))
         return
-    out = torch.zeros((n, n), dtype=torch.int16, device="cuda")
+    out = torch.zeros((max(nb, 1), max(nb, 1)), dtype=torch.int16, device="cuda")
+    outq = torch.zeros((max(lo, 1), max(nb, 1)), dtype=torch.int16, device="cuda") if dbq is not None else None
     summary = torch.zeros(2, dtype=torch.int64, device="cuda")
 
     def step():
-        ctx.mu_gapless_matrix_dev(db, db, True, out.data_ptr(), n)
+        if dbq is not None:
+            ctx.mu_gapless_matrix_dev(dbq, db, False, outq.data_ptr(), nb)
+        if db is not None:
+            ctx.mu_gapless_matrix_dev(db, db, True, out.data_ptr(), nb)
 
     def barrier():
         if dist is not None:
@@ -382,25 +432,39 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    kernel_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        # HIP events recorded by the library on this same stream around its launches
     if dist is not None:
         # the path's only collective: gather of the per-rank hit buffers (query, target, score) onto rank 0
         from reseek_amd import dist as rdist
         # scores are uint16 stored in an int16 tensor: >= 120 unsigned  <=>  >= 120 or negative as int16
         hit = torch.nonzero((out >= 120) | (out < 0))
         hit = hit[hit[:, 1] >= hit[:, 0]]                      # i <= j (entries below the diagonal are by-products)
-        rows = torch.cat([hit.to(torch.int32), (out[hit[:, 0], hit[:, 1]].to(torch.int32) & 0xFFFF)[:, None]], dim=1)
+        rows = torch.cat([(hit + lo).to(torch.int32), (out[hit[:, 0], hit[:, 1]].to(torch.int32) & 0xFFFF)[:, None]], dim=1)
+        if outq is not None:
+            hq = torch.nonzero((outq >= 120) | (outq < 0))
+            rq = torch.cat([hq[:, :1].to(torch.int32), (hq[:, 1:] + lo).to(torch.int32),
+                            (outq[hq[:, 0], hq[:, 1]].to(torch.int32) & 0xFFFF)[:, None]], dim=1)
+            rows = torch.cat([rows, rq], dim=0)
         gathered = rdist.gather_rows(rows.cpu().numpy(), dst=0, device=coll_dev)
         summary[0] = 0 if gathered is None else gathered.shape[0]
     barrier()
     dt = time.perf_counter() - t0
-    # per-launch kernel time of the last step from the library's HIP events (same stream)
-    kernel_ms = ctx.last_kernel_ms()
-    pairs, cells, slots = ctx.mu_gapless_last_work()
+    # per-launch kernel time (the library's HIP events on the launch stream) and work of this rank's launches, untimed pass
+    kernel_ms, pairs, cells, slots = 0.0, 0, 0, 0
+    if dbq is not None:
+        ctx.mu_gapless_matrix_dev(dbq, db, False, outq.data_ptr(), nb)
+        torch.cuda.synchronize()
+        kernel_ms += ctx.last_kernel_ms()
+        w = ctx.mu_gapless_last_work()
+        pairs, cells, slots = pairs + w[0], cells + w[1], slots + w[2]
+    if db is not None:
+        ctx.mu_gapless_matrix_dev(db, db, True, out.data_ptr(), nb)
+        torch.cuda.synchronize()
+        kernel_ms += ctx.last_kernel_ms()
+        w = ctx.mu_gapless_last_work()
+        pairs, cells, slots = pairs + w[0], cells + w[1], slots + w[2]
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
     tot = torch.tensor([float(cells), float(pairs)], dtype=torch.float64, device=coll_dev)
@@ -409,14 +473,18 @@ def main():
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     dt = float(tmax.item())
     total_cells, total_pairs = float(tot[0].item()), float(tot[1].item())
+    search_n = None
+    if dist is not None and not args.no_search and not args.weak:
+        search_n = search_sharded_leg(ctx, seqs, rank, world, dist, coll_dev)
 
     if rank == 0:
         cells_per_s = total_cells * args.steps / dt
         k_cells_per_s = cells / (kernel_ms * 1e-3)
         nres = float(sum(len(s) for s in seqs))
         # algorithmic HBM bytes per launch: (LA + LB + 8) per pair, score-only
-        alg_bytes = sum(len(s) * (n - i) for i, s in enumerate(seqs)) + \
-            float(np.cumsum([len(s) for s in seqs][::-1])[::-1].sum()) + 8.0 * pairs
+        blk = lens[lo:hi]
+        alg_bytes = float((blk * (nb - np.arange(nb))).sum() + np.cumsum(blk[::-1])[::-1].sum() + 8.0 * pairs +
+                          (lens[:lo].sum() * nb + blk.sum() * lo))       # triangle of the block + rectangle above it
         # HBM traffic per launch: rocprofv3 PMC counters of this same command, committed under profiles/
         # (FETCH_SIZE doubled on gfx950 as MI355X_MICROARCH.md prescribes; separate --pmc passes)
         traffic = None
@@ -430,12 +498,16 @@ def main():
         res = {
             "metric": "aligned cells/sec (SCOP40-shaped all-vs-all, gapless int Mu kernel)",
             "value": cells_per_s, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None,
             "dtype": "int16", "data": "synthetic",
             "chain_pairs_per_sec": total_pairs * args.steps / dt,
-            "config": {"workload": "BASELINE configs[1]: SCOP40-shaped (%d chains, %d residues per GPU) all-vs-all "
-                                   "i<=j, swgaplessint kernel only" % (n, int(nres)),
-                       "pairs_per_gpu": pairs, "cells_per_gpu": cells, "sharding": "one independent shard per GPU"},
+            "config": {"workload": "BASELINE configs[1]: SCOP40-shaped (%d chains, %d residues%s) all-vs-all "
+                                   "i<=j, swgaplessint kernel only" % (n, int(nres), " per GPU" if args.weak else ""),
+                       "pairs_total": int(total_pairs), "cells_total": total_cells, "pairs_rank0": pairs, "cells_rank0": cells,
+                       "sharding": "one independent set per GPU (--weak)" if args.weak else
+                                   "one set; rank r takes the targets [lo, hi) of the triangle, ranges balanced by DP cells: "
+                                   "rectangle chains[0:lo) x chains[lo:hi) + triangle of chains[lo:hi); no data-path collective, "
+                                   "hit buffers gathered over RCCL"},
             "roofline": {
                 "bound": "valu", "kernel": "k_gapless_ring<8,16> (+<4,8>)",
                 "achieved": k_cells_per_s / 1e12, "peak": PEAK_VALU_LANEOPS / 1e12, "unit": "T lane-ops/s",
@@ -458,6 +530,8 @@ def main():
                 res["roofline_live"] = live_kernels(ctx, seqs, db)
             except Exception as e:  # noqa: BLE001 -- the kernel metric above stands on its own
                 sys.stderr.write("bench: live-kernel leg failed: %s\n" % e)
+        if search_n is not None:
+            res["search"] = search_n
         if not args.no_search and world == 1 and not args.chains:
             try:
                 res["search"] = search_end_to_end(seqs)

@@ -98,6 +98,12 @@ class SearchOpts(C.Structure):
 
 SIGNATURES["rsk_search"] = (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(SearchOpts), C.c_char_p, C.POINTER(C.c_uint64),
                                       C.POINTER(C.c_uint64)])
+SIGNATURES["rsk_fast_shard_open"] = (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(SearchOpts), C.POINTER(C.c_void_p)])
+SIGNATURES["rsk_fast_shard_candidates"] = (C.c_int, [C.c_void_p, C.POINTER(u32p), C.POINTER(u32p), C.POINTER(u32p), C.POINTER(C.c_size_t)])
+SIGNATURES["rsk_fast_shard_finish"] = (C.c_int, [C.c_void_p, u32p, u32p, u32p, C.c_size_t, C.c_char_p, C.c_char_p, C.POINTER(C.c_uint64),
+                                                 C.POINTER(C.c_uint64)])
+SIGNATURES["rsk_fast_shard_close"] = (None, [C.c_void_p])
+SIGNATURES["rsk_rsb_merge"] = (C.c_int, [u32p, u32p, u32p, C.c_size_t, C.c_uint32, C.c_uint32, u32p, u32p, u32p, C.POINTER(C.c_size_t)])
 SIGNATURES["rsk_bca_copy"] = (C.c_int, [C.c_char_p, C.c_char_p])
 SIGNATURES["rsk_bca_to_mu_fasta"] = (C.c_int, [C.c_char_p, C.c_char_p])
 
@@ -220,8 +226,8 @@ class Ctx:
                                       C.byref(n), st))
         return n.value, list(st)
 
-    def search(self, query, out_tsv, mode, db=None, **kw):
-        """rsk_search with the options struct: columns, evalue, mints, pvalue, noself, selfrev0, idx_mode, rsb_size, dbmu, keeptmp."""
+    @staticmethod
+    def _opts(mode, kw):
         o = SearchOpts()
         o.mode = mode.encode()
         for k, v in kw.items():
@@ -231,6 +237,18 @@ class Ctx:
                 setattr(o, k, float(v)); setattr(o, k + "_set", 1)
             else:
                 setattr(o, k, int(v))
+        return o
+
+    def fast_shard_open(self, query, db, **kw):
+        """-search -fast -db, stage 1 on target shard shard_index of shard_count -> FastShard (local top-B candidates)"""
+        o = self._opts("fast", kw)
+        h = C.c_void_p()
+        _check(lib().rsk_fast_shard_open(self.h, query.encode(), db.encode(), C.byref(o), C.byref(h)))
+        return FastShard(h)
+
+    def search(self, query, out_tsv, mode, db=None, **kw):
+        """rsk_search with the options struct: columns, evalue, mints, pvalue, noself, selfrev0, idx_mode, rsb_size, dbmu, keeptmp."""
+        o = self._opts(mode, kw)
         n = C.c_uint64()
         st = (C.c_uint64 * 8)()
         _check(lib().rsk_search(self.h, query.encode(), db.encode() if db else None, C.byref(o), out_tsv.encode(), C.byref(n), st))
@@ -322,6 +340,51 @@ class Ctx:
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
         _check(lib().rsk_mu_gapless_last_work(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
+
+
+class FastShard:
+    """Handle of rsk_fast_shard_open: candidates() -> int32 [n, 3] (query, global target, score); finish(all ranks' rows)."""
+
+    def __init__(self, h):
+        self.h = h
+
+    def candidates(self):
+        q, t, s = u32p(), u32p(), u32p()
+        n = C.c_size_t()
+        _check(lib().rsk_fast_shard_candidates(self.h, C.byref(q), C.byref(t), C.byref(s), C.byref(n)))
+        if n.value == 0:
+            return np.zeros((0, 3), np.int32)
+        f = lambda p: np.ctypeslib.as_array(p, shape=(n.value,)).astype(np.int32)      # noqa: E731
+        return np.stack([f(q), f(t), f(s)], axis=1)
+
+    def finish(self, rows, out_tsv, tmp_tsv=None):
+        rows = np.ascontiguousarray(rows, np.int32).reshape(-1, 3)
+        q = np.ascontiguousarray(rows[:, 0], np.uint32)
+        t = np.ascontiguousarray(rows[:, 1], np.uint32)
+        s = np.ascontiguousarray(rows[:, 2], np.uint32)
+        nh = C.c_uint64()
+        st = (C.c_uint64 * 8)()
+        _check(lib().rsk_fast_shard_finish(self.h, _p(q, u32p), _p(t, u32p), _p(s, u32p), len(q), out_tsv.encode(),
+                                           tmp_tsv.encode() if tmp_tsv else None, C.byref(nh), st))
+        return nh.value, list(st)
+
+    def close(self):
+        if self.h:
+            lib().rsk_fast_shard_close(self.h)
+            self.h = None
+
+
+def rsb_merge(rows, nqueries, rsb_size):
+    """rsk_rsb_merge: per query the rsb_size best (score desc, target asc) of int32 [n, 3] (query, target, score) rows"""
+    rows = np.ascontiguousarray(rows, np.int32).reshape(-1, 3)
+    q = np.ascontiguousarray(rows[:, 0], np.uint32)
+    t = np.ascontiguousarray(rows[:, 1], np.uint32)
+    s = np.ascontiguousarray(rows[:, 2], np.uint32)
+    oq, ot, os_ = np.zeros(len(q), np.uint32), np.zeros(len(q), np.uint32), np.zeros(len(q), np.uint32)
+    n = C.c_size_t()
+    _check(lib().rsk_rsb_merge(_p(q, u32p), _p(t, u32p), _p(s, u32p), len(q), nqueries, rsb_size, _p(oq, u32p), _p(ot, u32p), _p(os_, u32p),
+                               C.byref(n)))
+    return np.stack([oq[:n.value], ot[:n.value], os_[:n.value]], axis=1).astype(np.int32)
 
 
 class Db:

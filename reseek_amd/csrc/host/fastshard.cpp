@@ -1,0 +1,259 @@
+// fastshard.cpp -- `reseek -search Q -db DB -fast` with the DB cut into target shards, one per GPU.
+// The prefilter's per-query top-B (RankedScoresBag, rankedscoresbag.cpp:34-51) is a reduction over ALL targets, so the
+// sharded form has one exchange in the middle:
+//   rsk_fast_shard_open        queries loaded; k-mer prefilter over this rank's target range; local top-B per query
+//   rsk_fast_shard_candidates  -> the local (query, global target, score) triples            [caller: all_gather]
+//   rsk_fast_shard_finish      merge of every rank's triples, top-B per query, then PostMuFilter (AlignBags, Accept, ToTsv)
+//                              of the candidates whose target lies in this rank's range -> this rank's hit table
+// Tie rule of both selections: higher score first, then lower target index.  The reference's bag keeps whichever of the
+// equal-scoring candidates its quicksort leaves in front (arrival-order dependent); the two agree whenever no
+// query has more than B candidates or the B-th score is not tied, and in every case the kept set is a valid top-B.
+#include <algorithm>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "reseek_host.h"
+
+void rsk_set_error(const char *fmt, ...);
+
+namespace reseek_amd {
+void MuPreFilterScan(rsk_ctx *ctx, const std::vector<uint32_t> &qlen, const std::vector<uint8_t> &qmu, rsk_db *tdb, uint NT, int idx_mode,
+                     std::vector<uint32_t> &hq, std::vector<uint32_t> &ht, std::vector<uint32_t> &hs);
+void PostMuFilterPairs(const DSSParams &Params, DBSearcher &Q, DBSearcher &DB, const std::vector<uint32_t> &pq, const std::vector<uint32_t> &pt,
+                       const std::string &HitsFN);
+}
+using namespace reseek_amd;
+
+// per query the rsb_size best (score desc, target asc) of the given triples; output grouped by query, best first
+static void TopB(const uint32_t *q, const uint32_t *t, const uint32_t *s, size_t n, uint32_t nqueries, uint32_t B, std::vector<uint32_t> &oq,
+                 std::vector<uint32_t> &ot, std::vector<uint32_t> &os)
+{
+    std::vector<size_t> first((size_t) nqueries + 1, 0);
+    for (size_t k = 0; k < n; ++k) {
+        if (q[k] >= nqueries) throw std::runtime_error("top-B: query index out of range");
+        ++first[q[k] + 1];
+    }
+    for (uint32_t i = 0; i < nqueries; ++i) first[i + 1] += first[i];
+    std::vector<uint64_t> key(n);                          // (65535 - score) << 32 | target: ascending = best first
+    {
+        std::vector<size_t> cur(first.begin(), first.end() - 1);
+        for (size_t k = 0; k < n; ++k) key[cur[q[k]]++] = ((uint64_t) (0xFFFFu - std::min<uint32_t>(s[k], 0xFFFFu)) << 32) | t[k];
+    }
+    oq.clear(); ot.clear(); os.clear();
+    for (uint32_t i = 0; i < nqueries; ++i) {
+        uint64_t *b = key.data() + first[i], *e = key.data() + first[i + 1];
+        std::sort(b, e);
+        e = std::unique(b, e);                             // the same (target, score) reported by two ranks cannot happen; harmless
+        const size_t keep = std::min<size_t>((size_t) (e - b), B);
+        for (size_t k = 0; k < keep; ++k) { oq.push_back(i); ot.push_back((uint32_t) b[k]); os.push_back(0xFFFFu - (uint32_t) (b[k] >> 32)); }
+    }
+}
+
+extern "C" int rsk_rsb_merge(const uint32_t *q, const uint32_t *t, const uint32_t *score, size_t n, uint32_t nqueries, uint32_t rsb_size,
+                             uint32_t *out_q, uint32_t *out_t, uint32_t *out_score, size_t *nout)
+{
+    if ((n && (!q || !t || !score)) || !nout || rsb_size == 0) { rsk_set_error("rsk_rsb_merge: bad argument"); return RSK_E_INVALID; }
+    try {
+        std::vector<uint32_t> oq, ot, os;
+        TopB(q, t, score, n, nqueries, rsb_size, oq, ot, os);
+        *nout = oq.size();
+        if (out_q)
+            for (size_t k = 0; k < oq.size(); ++k) { out_q[k] = oq[k]; out_t[k] = ot[k]; out_score[k] = os[k]; }
+    } catch (const std::exception &e) {
+        rsk_set_error("rsk_rsb_merge: %s", e.what());
+        return RSK_E_INVALID;
+    }
+    return RSK_OK;
+}
+
+struct rsk_fast_shard {
+    rsk_ctx *ctx = nullptr;
+    SearchOptions o, o2;
+    DSSParams Params, Params2;
+    DBSearcher Q;
+    std::string db_path;
+    uint64_t Lo = 0, Hi = 0, NT = 0;                       // this rank's target range [Lo, Hi) of NT DB chains
+    std::vector<uint32_t> cq, ct, cs;                      // local top-B triples (global target indexes)
+};
+
+static bool parse_opts(const rsk_search_opts *opts, SearchOptions &o)
+{
+    const std::string m = opts->mode ? opts->mode : "";
+    if (m != "fast") return false;
+    o.mode = AM_Fast;
+    if (opts->columns) o.columns = opts->columns;
+    if (opts->evalue_set) { o.evalue_set = true; o.evalue = opts->evalue; }
+    if (opts->mints_set) { o.mints_set = true; o.mints = opts->mints; }
+    if (opts->pvalue_set) { o.pvalue_set = true; o.pvalue = opts->pvalue; }
+    o.noself = opts->noself != 0;
+    o.selfrev0 = opts->selfrev0 != 0;
+    o.idx_mode = opts->idx_mode == 0 ? -1 : opts->idx_mode;
+    if (opts->rsb_size) o.rsb_size = opts->rsb_size;
+    if (opts->dbmu) o.dbmu = opts->dbmu;
+    o.shard_index = opts->shard_index;
+    o.shard_count = opts->shard_count ? opts->shard_count : 1;
+    return true;
+}
+
+extern "C" int rsk_fast_shard_open(rsk_ctx *ctx, const char *query_path, const char *db_path, const rsk_search_opts *opts, rsk_fast_shard **out)
+{
+    if (!ctx || !query_path || !db_path || !opts || !out) { rsk_set_error("rsk_fast_shard_open: NULL argument"); return RSK_E_INVALID; }
+    *out = nullptr;
+    std::unique_ptr<rsk_fast_shard> S(new rsk_fast_shard);
+    if (!parse_opts(opts, S->o)) { rsk_set_error("rsk_fast_shard_open: mode must be \"fast\" (the other modes shard through rsk_search)"); return RSK_E_INVALID; }
+    if (S->o.shard_index >= S->o.shard_count) { rsk_set_error("rsk_fast_shard_open: shard_index >= shard_count"); return RSK_E_INVALID; }
+    if (opts->idx_mode < 0 || opts->idx_mode > 2) { rsk_set_error("rsk_fast_shard_open: idx_mode must be 0, 1 or 2"); return RSK_E_INVALID; }
+    try {
+        S->ctx = ctx;
+        S->db_path = db_path;
+        if (!(S->db_path.size() >= 4 && S->db_path.compare(S->db_path.size() - 4, 4, ".bca") == 0))
+            throw std::runtime_error(".bca format required for -db (search.cpp:79)");
+        S->Params.SetDSSParams(S->o);
+        S->o2 = S->o;
+        S->o2.mode = AM_Sensitive;                          // DM_AlwaysSensitive search.cpp:104
+        S->Params2.SetDSSParams(S->o2);
+        S->Q.m_Params = &S->Params2;
+        S->Q.m_SelfRevQueryFlavour = true;                  // postmufilter.cpp:79
+        S->Q.m_Opts = S->o;
+        S->Q.m_Ctx = ctx;
+        S->Q.LoadDB(query_path);
+        S->Q.Setup();
+        for (USERFIELD u : S->Q.m_DA.m_UFs)
+            if (u == UF_Undefined) throw std::runtime_error("invalid -columns field");
+        // target Mu letters of this rank's range, balanced by residues (the scan's cost is per target residue)
+        std::vector<std::vector<byte> > TSeqs;
+        if (!S->o.dbmu.empty()) {
+            std::vector<std::string> Labels;
+            std::vector<std::vector<byte> > All;
+            ReadMuFasta(S->o.dbmu, Labels, All);
+            S->NT = All.size();
+            std::vector<uint64_t> cum(S->NT + 1, 0);
+            for (uint64_t i = 0; i < S->NT; ++i) cum[i + 1] = cum[i] + All[i].size();
+            auto bound = [&](uint r) { return r >= S->o.shard_count ? S->NT : (uint64_t) (std::lower_bound(cum.begin(), cum.end(), cum[S->NT] * r / S->o.shard_count) - cum.begin()); };
+            S->Lo = std::min(S->NT, bound(S->o.shard_index));
+            S->Hi = std::max(S->Lo, std::min(S->NT, bound(S->o.shard_index + 1)));
+            TSeqs.assign(All.begin() + S->Lo, All.begin() + S->Hi);
+        } else {
+            BCAData B;
+            B.Open(S->db_path);
+            S->NT = B.GetChainCount();
+            std::vector<uint64_t> cum(S->NT + 1, 0);
+            for (uint64_t i = 0; i < S->NT; ++i) cum[i + 1] = cum[i] + B.m_SeqLengths[i];
+            auto bound = [&](uint r) { return r >= S->o.shard_count ? S->NT : (uint64_t) (std::lower_bound(cum.begin(), cum.end(), cum[S->NT] * r / S->o.shard_count) - cum.begin()); };
+            S->Lo = std::min(S->NT, bound(S->o.shard_index));
+            S->Hi = std::max(S->Lo, std::min(S->NT, bound(S->o.shard_index + 1)));
+            MuSeqSource SS;
+            SS.m_IsFasta = false;
+            SS.m_Params = &S->Params;
+            SS.m_ASCII = false;                             // muprefilter.cpp:84
+            SS.m_CR.OpenRange(S->db_path, S->Lo, S->Hi);
+            std::vector<std::string> Labels;
+            SS.GetAll(Labels, TSeqs);
+        }
+        const uint NTl = (uint) TSeqs.size();
+        if (NTl) {
+            std::vector<uint32_t> tlen(NTl);
+            std::vector<uint8_t> tmu;
+            for (uint i = 0; i < NTl; ++i) { tlen[i] = (uint32_t) TSeqs[i].size(); tmu.insert(tmu.end(), TSeqs[i].begin(), TSeqs[i].end()); }
+            rsk_db *tdb = nullptr;
+            if (rsk_db_create(ctx, NTl, tlen.data(), tmu.data(), nullptr, nullptr, nullptr, nullptr, nullptr, &tdb) != RSK_OK)
+                throw std::runtime_error(std::string("rsk_db_create: ") + rsk_last_error());
+            struct guard { rsk_db *d; ~guard() { rsk_db_destroy(d); } } g{ tdb };
+            // query letters with 10 / 11 exchanged, as SeqDB::ToLetters(g_CharToLetterMu) leaves them (search.cpp:91-98)
+            const uint NQ = S->Q.GetDBChainCount();
+            std::vector<uint32_t> qlen(NQ);
+            std::vector<uint8_t> qmu;
+            for (uint i = 0; i < NQ; ++i) {
+                qlen[i] = S->Q.m_DBChains[i]->GetSeqLength();
+                for (byte l : *S->Q.m_DBMuLettersVec[i]) qmu.push_back(l == 10 ? 11 : (l == 11 ? 10 : l));
+            }
+            std::vector<uint32_t> hq, ht, hs;
+            MuPreFilterScan(ctx, qlen, qmu, tdb, NTl, S->o.idx_mode, hq, ht, hs);
+            for (uint32_t &t : ht) t += (uint32_t) S->Lo;
+            TopB(hq.data(), ht.data(), hs.data(), hq.size(), NQ, S->o.rsb_size, S->cq, S->ct, S->cs);
+        }
+    } catch (const std::exception &e) {
+        rsk_set_error("rsk_fast_shard_open: %s", e.what());
+        return RSK_E_INVALID;
+    }
+    *out = S.release();
+    return RSK_OK;
+}
+
+extern "C" int rsk_fast_shard_candidates(rsk_fast_shard *S, const uint32_t **q, const uint32_t **t, const uint32_t **score, size_t *n)
+{
+    if (!S || !q || !t || !score || !n) { rsk_set_error("rsk_fast_shard_candidates: NULL argument"); return RSK_E_INVALID; }
+    *q = S->cq.data(); *t = S->ct.data(); *score = S->cs.data(); *n = S->cq.size();
+    return RSK_OK;
+}
+
+extern "C" int rsk_fast_shard_finish(rsk_fast_shard *S, const uint32_t *q, const uint32_t *t, const uint32_t *score, size_t n,
+                                     const char *out_tsv, const char *tmp_tsv, uint64_t *nhits, uint64_t *stats8)
+{
+    if (!S || !out_tsv || (n && (!q || !t || !score))) { rsk_set_error("rsk_fast_shard_finish: NULL argument"); return RSK_E_INVALID; }
+    try {
+        const uint NQ = S->Q.GetDBChainCount();
+        std::vector<uint32_t> mq, mt, ms;
+        TopB(q, t, score, n, NQ, S->o.rsb_size, mq, mt, ms);
+        if (tmp_tsv && *tmp_tsv) {
+            // the hand-off file of the merged bags (rankedscoresbag.cpp:185-231), for comparison with a single-GPU run
+            RankedScoresBag RSB;
+            RSB.m_B = S->o.rsb_size;
+            RSB.Init(NQ);
+            for (size_t k = 0; k < mq.size(); ++k) { RSB.m_QueryIdxToScoreVec[mq[k]].push_back((uint16_t) ms[k]); RSB.m_QueryIdxToTargetIdxVec[mq[k]].push_back(mt[k]); }
+            FILE *f = fopen(tmp_tsv, "w");
+            if (!f) throw std::runtime_error(std::string("cannot create ") + tmp_tsv);
+            RSB.m_B = UINT32_MAX;                           // already truncated: ToTsv must not re-sort
+            RSB.ToTsv(f);
+            fclose(f);
+        }
+        // candidates of this rank's targets, target-major as PostMuFilter reads them from the hand-off file
+        std::vector<std::pair<uint32_t, uint32_t> > mine;  // (target, query)
+        for (size_t k = 0; k < mq.size(); ++k)
+            if (mt[k] >= S->Lo && mt[k] < S->Hi) mine.emplace_back(mt[k], mq[k]);
+        std::sort(mine.begin(), mine.end());
+        std::vector<uint32_t> uniq;
+        for (auto &p : mine)
+            if (uniq.empty() || uniq.back() != p.first) uniq.push_back(p.first);
+        FILE *f = fopen(out_tsv, "w");                      // a rank without candidates still leaves an (empty) table
+        if (!f) throw std::runtime_error(std::string("cannot create ") + out_tsv);
+        fclose(f);
+        if (!mine.empty()) {
+            BCAData B;
+            B.Open(S->db_path);
+            std::vector<PDBChain *> Chains;
+            for (uint32_t ti : uniq) {
+                PDBChain *C = new PDBChain;
+                B.ReadChain(ti, *C);
+                Chains.push_back(C);
+            }
+            DBSearcher DB;
+            DB.m_Params = &S->Params2;
+            DB.m_SelfRevQueryFlavour = true;                // postmufilter.cpp:171
+            DB.m_Opts = S->o;
+            DB.m_Ctx = S->ctx;
+            DB.LoadChains(Chains);
+            if (DB.GetDBChainCount() != uniq.size()) throw std::runtime_error("empty chain among the candidates");
+            std::vector<uint32_t> pq, pt;
+            for (auto &p : mine) {
+                pq.push_back(p.second);
+                pt.push_back((uint32_t) (std::lower_bound(uniq.begin(), uniq.end(), p.first) - uniq.begin()));
+            }
+            PostMuFilterPairs(S->Params2, S->Q, DB, pq, pt, out_tsv);
+        }
+        if (nhits) *nhits = S->Q.m_HitCount;
+        if (stats8) {
+            stats8[0] = S->Q.m_ProcessedPairCount; stats8[1] = S->Q.m_ProcessedPairCount - S->Q.m_MKFPairCount; stats8[2] = S->Q.m_MuFilterInputCount;
+            stats8[3] = S->Q.m_MuFilterDiscardCount; stats8[4] = S->Q.m_MKFPairCount; stats8[5] = S->Q.m_SWCount;
+            stats8[6] = S->Q.m_HitCount; stats8[7] = 1;
+        }
+    } catch (const std::exception &e) {
+        rsk_set_error("rsk_fast_shard_finish: %s", e.what());
+        return RSK_E_INVALID;
+    }
+    return RSK_OK;
+}
+
+extern "C" void rsk_fast_shard_close(rsk_fast_shard *S) { delete S; }

@@ -72,9 +72,9 @@ void MuPreFilter(const DSSParams &Params, DBSearcher &QDB, DBSearcher &TDB, cons
     MuPreFilterLetters(ctx, qlen, qmu, tdb, NT, QDB.m_Opts.idx_mode, QDB.m_Opts.rsb_size, OutputFN);
 }
 
-// index of the query letters + scan of every target + per-query top-B + hand-off file (muprefilter.cpp:90-133)
-void MuPreFilterLetters(rsk_ctx *ctx, const std::vector<uint32_t> &qlen, const std::vector<uint8_t> &qmu, rsk_db *tdb, uint NT, int idx_mode,
-                        uint rsb_size, const std::string &OutputFN)
+// index of the query letters + scan of every target (muprefilter.cpp:90-126): (query, target, score) triples, unordered
+void MuPreFilterScan(rsk_ctx *ctx, const std::vector<uint32_t> &qlen, const std::vector<uint8_t> &qmu, rsk_db *tdb, uint NT, int idx_mode,
+                     std::vector<uint32_t> &hq, std::vector<uint32_t> &ht, std::vector<uint32_t> &hs)
 {
     const uint NQ = (uint) qlen.size();
     PhaseTimer tm("MuPreFilter");
@@ -85,7 +85,7 @@ void MuPreFilterLetters(rsk_ctx *ctx, const std::vector<uint32_t> &qlen, const s
     // every (query, target) can appear at most once
     size_t cap = (size_t) std::min<uint64_t>((uint64_t) NQ * NT, 1ull << 28);
     uint32_t *d_q = nullptr, *d_t = nullptr, *d_s = nullptr, *d_n = nullptr;
-    std::vector<uint32_t> hq, ht, hs;
+    hq.clear(); ht.clear(); hs.clear();
     for (;;) {
         hipok(hipMalloc((void **) &d_q, std::max<size_t>(cap, 1) * 4), "hipMalloc");
         hipok(hipMalloc((void **) &d_t, std::max<size_t>(cap, 1) * 4), "hipMalloc");
@@ -106,8 +106,18 @@ void MuPreFilterLetters(rsk_ctx *ctx, const std::vector<uint32_t> &qlen, const s
         cap = n;                               // the count is exact even when the list was truncated
     }
     tm.lap("index + scan (GPU)");
+}
+
+// ... + per-query top-B + hand-off file (muprefilter.cpp:127-133)
+void MuPreFilterLetters(rsk_ctx *ctx, const std::vector<uint32_t> &qlen, const std::vector<uint8_t> &qmu, rsk_db *tdb, uint NT, int idx_mode,
+                        uint rsb_size, const std::string &OutputFN)
+{
+    std::vector<uint32_t> hq, ht, hs;
+    MuPreFilterScan(ctx, qlen, qmu, tdb, NT, idx_mode, hq, ht, hs);
+    PhaseTimer tm("MuPreFilter");
     size_t nout = 0;
-    check(rsk_rsb_select(hq.data(), ht.data(), hs.data(), hq.size(), NQ, rsb_size, nullptr, nullptr, nullptr, &nout, OutputFN.c_str()),
+    check(rsk_rsb_select(hq.data(), ht.data(), hs.data(), hq.size(), (uint32_t) qlen.size(), rsb_size, nullptr, nullptr, nullptr, &nout,
+                         OutputFN.c_str()),
           "rsk_rsb_select");
     tm.lap("top-B bags + hand-off");
 }

@@ -20,66 +20,84 @@ def shard_by_residues(lengths, world_size):
     return [(bounds[r], bounds[r + 1]) for r in range(world_size)]
 
 
-def gather_rows(rows, dst=0, group=None, device=None):
-    """Variable-length gather of fixed-width records (int32 [n_r, k] per rank) onto rank `dst`:
-    all_gather of the counts, then an all_gather of buffers padded to the largest count (hit buffers
-    are tiny compared with the pair space, so padding costs nothing).  Returns the concatenation in
-    rank order on dst, None elsewhere."""
+def _all_gather_padded(local, group=None, device=None):
+    """all_gather of variable-length 1-D/2-D arrays of one dtype: the counts first, then buffers padded to the largest
+    count.  -> list of per-rank arrays (every rank gets all of them)."""
     import torch
     import torch.distributed as dist
-    rows = np.ascontiguousarray(rows, dtype=np.int32)
-    if rows.ndim != 2:
-        raise ValueError("rows must be [n, k]")
-    k = rows.shape[1]
     world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
     dev = device if device is not None else torch.device("cpu")
-    cnt = torch.tensor([rows.shape[0]], dtype=torch.int64, device=dev)
+    tail = local.shape[1:]
+    cnt = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
     cnts = [torch.zeros_like(cnt) for _ in range(world)]
     dist.all_gather(cnts, cnt, group=group)
     counts = [int(c.item()) for c in cnts]
     m = max(max(counts), 1)
-    buf = torch.zeros((m, k), dtype=torch.int32, device=dev)
-    if rows.shape[0]:
-        buf[:rows.shape[0]] = torch.from_numpy(rows).to(dev)
+    t = torch.from_numpy(np.ascontiguousarray(local))
+    buf = torch.zeros((m,) + tuple(tail), dtype=t.dtype, device=dev)
+    if local.shape[0]:
+        buf[:local.shape[0]] = t.to(dev)
     bufs = [torch.zeros_like(buf) for _ in range(world)]
     dist.all_gather(bufs, buf, group=group)
-    if rank != dst:
-        return None
-    return np.concatenate([b[:c].cpu().numpy() for b, c in zip(bufs, counts)], axis=0)
+    return [b[:c].cpu().numpy() for b, c in zip(bufs, counts)]
 
 
-def gather_text(text, dst=0, group=None):
-    """Concatenation (rank order) of every rank's text on rank `dst`, None elsewhere: the hit tables of the
-    target shards (one exchange at the end of a search, tens of MB at most)."""
+def gather_rows(rows, dst=0, group=None, device=None, all_ranks=False):
+    """Variable-length gather of fixed-width records (int32 [n_r, k] per rank): all_gather of the counts, then an
+    all_gather of buffers padded to the largest count (hit buffers are tiny compared with the pair space, so padding
+    costs nothing).  Returns the concatenation in rank order on `dst` (None elsewhere), or on every rank with all_ranks."""
     import torch.distributed as dist
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    parts = [None] * world if rank == dst else None
-    dist.gather_object(text, parts, dst=dst, group=group)
-    return "".join(parts) if rank == dst else None
+    rows = np.ascontiguousarray(rows, dtype=np.int32)
+    if rows.ndim != 2:
+        raise ValueError("rows must be [n, k]")
+    parts = _all_gather_padded(rows, group=group, device=device)
+    if not all_ranks and dist.get_rank(group) != dst:
+        return None
+    return np.concatenate(parts, axis=0)
 
 
-def search_sharded(ctx, query, out_tsv, mode, db=None, group=None, **kw):
-    """One process per GPU: every rank runs its shard of the search (rsk_search with shard_index = rank,
-    shard_count = world size; -db mode: a contiguous target range balanced by residues with the queries
-    replicated; self search: a target range of the triangle balanced by DP cells), then the hit tables are
-    gathered on rank 0, which writes `out_tsv`.  Returns (hits of all ranks, per-rank stats) on rank 0,
-    (local hits, stats) elsewhere.  No collective on the data path."""
+def gather_text(text, dst=0, group=None, device=None):
+    """Concatenation (rank order) of every rank's text on rank `dst`, None elsewhere: the hit tables of the target
+    shards (one exchange at the end of a search, tens of MB at most) as byte counts + one padded uint8
+    all_gather -- tensors only, so the same call runs over RCCL (device = the rank's GPU) and gloo."""
+    import torch.distributed as dist
+    raw = np.frombuffer(text.encode(), dtype=np.uint8)
+    parts = _all_gather_padded(raw, group=group, device=device)
+    if dist.get_rank(group) != dst:
+        return None
+    return b"".join(p.tobytes() for p in parts).decode()
+
+
+def search_sharded(ctx, query, out_tsv, mode, db=None, group=None, device=None, **kw):
+    """One process per GPU: every rank runs its shard of the search, then the hit tables are gathered on rank 0, which
+    writes `out_tsv`.  -db mode: a contiguous target range balanced by residues with the queries replicated; self
+    search: a target range of the triangle balanced by DP cells (rsk_search with shard_index = rank, shard_count = world
+    size): no collective on the data path.  -fast -db: the prefilter's per-query top-B is a reduction over all targets,
+    so the ranks exchange their local top-B lists once (all_gather) between the prefilter and the alignment stage
+    (rsk_fast_shard_*).  Returns (hits of all ranks, stats) on rank 0, (local hits, stats) elsewhere."""
+    import os
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     part = "%s.rank%d" % (out_tsv, rank)
-    nhits, stats = ctx.search(query, part, mode, db=db, shard_index=rank, shard_count=world, **kw)
+    if mode == "fast" and db and world > 1:
+        keeptmp = kw.pop("keeptmp", 0)
+        sh = ctx.fast_shard_open(query, db, shard_index=rank, shard_count=world, **kw)
+        try:
+            allrows = gather_rows(sh.candidates(), group=group, device=device, all_ranks=True)
+            nhits, stats = sh.finish(allrows, part, tmp_tsv=(out_tsv + ".prefilter.tmp") if keeptmp and rank == 0 else None)
+        finally:
+            sh.close()
+    else:
+        nhits, stats = ctx.search(query, part, mode, db=db, shard_index=rank, shard_count=world, **kw)
     with open(part) as f:
         text = f.read()
-    import os
     os.remove(part)
     if world == 1:
         with open(out_tsv, "w") as f:
             f.write(text)
         return nhits, stats
-    merged = gather_text(text, dst=0, group=group)
+    merged = gather_text(text, dst=0, group=group, device=device)
     if rank == 0:
         with open(out_tsv, "w") as f:
             f.write(merged)

@@ -1,0 +1,46 @@
+"""The N > 1 path end to end on ONE GPU: two processes (torch.distributed, gloo; RSK_BENCH_ONE_DEVICE=1 makes both use
+cuda:0) run reseek_amd.dist.search_sharded on the q100 fixture -- self search, -db mode and the two-stage -fast -db
+path with its all_gather of the local top-B lists -- and rank 0 compares the gathered hit tables with the reference's
+goldens (tools/search_dist_demo.py); bench.py --gpus 2 runs its strong-scaling shards the same way."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _torchrun(script, nproc, extra=()):
+    env = dict(os.environ, RSK_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), script] + list(extra)
+    return subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
+
+
+def test_search_sharded_world2_gloo_one_device():
+    r = _torchrun(os.path.join(ROOT, "tools", "search_dist_demo.py"), 2)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("identical to the reference") == 3, r.stdout
+
+
+def test_bench_strong_scaling_world2_gloo_one_device():
+    r = _torchrun(os.path.join(ROOT, "bench.py"), 2, ["--gpus", "2", "--steps", "2", "--warmup", "1", "--chains", "1500"])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["scaling"] == "strong"
+    n = 1500
+    assert res["config"]["pairs_total"] == n * (n + 1) // 2      # the shards partition the triangle
+    assert res["value"] > 0

@@ -1,0 +1,112 @@
+"""`-search -fast -db` with the DB cut into target shards (rsk_fast_shard_*): local prefilter + local top-B per
+shard, exchange of the lists, merge, alignment of each shard's own candidates.  The shards run one after another on this
+GPU (the exchange is a numpy concatenation here; tests/test_gpu_dist.py runs the same through torch.distributed), and the
+union of their hit tables / the merged hand-off file must equal the reference's single-process goldens."""
+import gzip
+import os
+import shutil
+import tempfile
+
+import numpy as np
+import pytest
+
+import fixtures as fx
+
+pytestmark = pytest.mark.gpu
+COLS = "query+target+qlo+qhi+ql+tlo+thi+tl+pctid+pvalue+evalue+cigar+dpscore+lddt+newts+ids+gaps+aq"
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+    import reseek_amd
+    assert torch.cuda.is_available()
+    c = reseek_amd.Ctx(0, stream=torch.cuda.current_stream().cuda_stream)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def work():
+    d = tempfile.mkdtemp(prefix="rsk_fastshard_")
+    for name in ("q100.bca", "edge.bca"):
+        with gzip.open(os.path.join(fx.GOLDEN, name + ".gz"), "rb") as f, open(os.path.join(d, name), "wb") as g:
+            g.write(f.read())
+    yield d
+    shutil.rmtree(d, ignore_errors=True)
+
+
+def run_shards(ctx, work, q, db, count, **kw):
+    shards = [ctx.fast_shard_open(q, db, shard_index=k, shard_count=count, columns=COLS, **kw) for k in range(count)]
+    try:
+        local = [s.candidates() for s in shards]
+        allrows = np.concatenate(local[::-1])           # any rank order must do
+        lines, hits = [], 0
+        tmp = os.path.join(work, "merged.tmp")
+        for k, s in enumerate(shards):
+            out = os.path.join(work, "fs_%d_%d.tsv" % (count, k))
+            n, st = s.finish(allrows, out, tmp_tsv=tmp if k == 0 else None)
+            got = open(out).read().splitlines()
+            assert n == len(got)
+            lines += got
+            hits += n
+        return sorted(lines), open(tmp).read(), local
+    finally:
+        for s in shards:
+            s.close()
+
+
+def test_q100_fast_db_shards_equal_the_reference(ctx, work):
+    q = os.path.join(work, "q100.bca")
+    want = ["\t".join(r) for r in fx.read_tsv("hits_q100_db_q100_fast.tsv.gz")]
+    with gzip.open(os.path.join(fx.GOLDEN, "prefilter_q100_db_q100_fast_tmp.tsv.gz"), "rt") as f:
+        want_tmp = f.read()
+    for count in (1, 2, 3, 7):
+        lines, tmp, local = run_shards(ctx, work, q, q, count)
+        assert lines == want, "shards %d: %d vs %d rows" % (count, len(lines), len(want))
+        assert tmp == want_tmp                               # no query exceeds B = 1500 here: the merged bags are the reference's
+        # every local list only names targets of its own range, and the ranges partition the DB
+        tmin = [int(l[:, 1].min()) for l in local if len(l)]
+        tmax = [int(l[:, 1].max()) for l in local if len(l)]
+        assert all(tmax[k] < tmin[k + 1] for k in range(len(tmin) - 1))
+
+
+def test_truncating_bags_are_shard_invariant(ctx, work):
+    """-rsb_size 20 cuts most bags of q100 x q100: whatever the shard count, the merged hand-off file and the hit table are
+    the same, and they equal the single-process run wherever the reference's cut is not among tied scores."""
+    q = os.path.join(work, "q100.bca")
+    ref_lines, ref_tmp, _ = run_shards(ctx, work, q, q, 1, rsb_size=20)
+    for count in (2, 5):
+        lines, tmp, _ = run_shards(ctx, work, q, q, count, rsb_size=20)
+        assert lines == ref_lines and tmp == ref_tmp
+    # against the reference-exact bag of the unsharded call (rsk_search, quicksort tie order): same number of candidates
+    out = os.path.join(work, "unsharded_b20.tsv")
+    n, st = ctx.search(q, out, "fast", db=q, columns=COLS, rsb_size=20, keeptmp=1)
+    cand_ref = sum(int(ln.split("\t")[1]) for ln in open(out + ".prefilter.tmp").read().splitlines()[1:])
+    cand_ours = sum(int(ln.split("\t")[1]) for ln in ref_tmp.splitlines()[1:])
+    assert cand_ref == cand_ours
+
+
+def test_edge_chains_and_dbmu(ctx, work):
+    e = os.path.join(work, "edge.bca")
+    want = ["\t".join(r) for r in fx.read_tsv("hits_edge_fastdb.tsv.gz")]
+    for count in (2, 4):
+        lines, tmp, _ = run_shards(ctx, work, e, e, count)
+        assert lines == want
+    # -dbmu: the target letters come from a Mu FASTA (search.cpp:93-96), sharded by sequence
+    from reseek_amd import capi
+    q = os.path.join(work, "q100.bca")
+    fa = os.path.join(work, "q100.mu.fa")
+    capi.bca_to_mu_fasta(q, fa)
+    want = ["\t".join(r) for r in fx.read_tsv("hits_q100_db_q100_fast_dbmu.tsv.gz")]
+    lines, tmp, _ = run_shards(ctx, work, q, q, 3, dbmu=fa)
+    assert lines == want
+
+
+def test_errors(ctx, work):
+    from reseek_amd import capi
+    q = os.path.join(work, "q100.bca")
+    with pytest.raises(capi.RskError):
+        ctx.fast_shard_open(q, q, shard_index=3, shard_count=3)
+    with pytest.raises(capi.RskError):
+        ctx.fast_shard_open(q, os.path.join(work, "missing.bca"), shard_index=0, shard_count=2)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Multi-GPU search smoke test: `python -m torch.distributed.run --nproc-per-node N tools/search_dist_demo.py`
-runs reseek_amd.dist.search_sharded on the q100 fixture (self search and -db mode) with one process per GPU
+runs reseek_amd.dist.search_sharded on the q100 fixture (self search, -db mode and the two-stage -fast -db path) with one process per GPU
 and checks the gathered hit table against the reference's golden table on rank 0.
 RSK_BENCH_ONE_DEVICE=1: all ranks share cuda:0 and use gloo (single-GPU boxes)."""
 import gzip
@@ -34,6 +34,7 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    coll_dev = torch.device("cpu") if (one or world == 1) else torch.device("cuda", local)      # RCCL gathers device tensors
     ctx = reseek_amd.Ctx(local, stream=torch.cuda.current_stream().cuda_stream)
     golden = os.path.join(ROOT, "tests", "golden")
     with tempfile.TemporaryDirectory() as td:
@@ -41,14 +42,16 @@ def main():
         with gzip.open(os.path.join(golden, "q100.bca.gz"), "rb") as f, open(bca, "wb") as g:
             g.write(f.read())
         ok = True
-        for db, gold in ((None, "hits_q100_sensitive.tsv.gz"), (bca, "hits_q100_db_q100_sensitive.tsv.gz")):
+        for mode, db, gold in (("sensitive", None, "hits_q100_sensitive.tsv.gz"), ("sensitive", bca, "hits_q100_db_q100_sensitive.tsv.gz"),
+                               ("fast", bca, "hits_q100_db_q100_fast.tsv.gz")):
             out = os.path.join(td, "hits_rank%d.tsv" % rank)
-            n, st = rdist.search_sharded(ctx, bca, out, "sensitive", db=db, columns=COLS)
+            n, st = rdist.search_sharded(ctx, bca, out, mode, db=db, columns=COLS, device=coll_dev)
             if rank == 0:
                 got = sorted(open(out).read().splitlines())
                 want = sorted(gzip.open(os.path.join(golden, gold)).read().decode().splitlines())
                 ok = ok and got == want
-                print("world %d %s: %d hits, %s" % (world, "db" if db else "self", len(got), "identical to the reference" if got == want else "MISMATCH"))
+                print("world %d %s %s: %d hits, %s" % (world, mode, "db" if db else "self", len(got),
+                                                       "identical to the reference" if got == want else "MISMATCH"))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
