@@ -739,8 +739,9 @@ void RunMKFPairs(rsk_ctx *Ctx, const DSSParams &P, const std::string &Columns, D
                 g_MKFNsXDrop.load() / 1e6, g_MKFNsStats.load() / 1e6);
 }
 
-// Self with SelfOffset >= 0 is one SHARD of a self search: B = the chains [SelfOffset, SelfOffset + NB) of
-// the set, A = its chains [0, SelfOffset + NB); the pairs i <= SelfOffset + j are this shard's part of the triangle.
+// Self with SelfOffset >= 0 is (part of) one SHARD of a self search: B = the chains [SelfOffset, SelfOffset + NB)
+// of the set, A = its chains [0, NA) with NA = SelfOffset (the rectangle above the shard's triangle) or up to
+// SelfOffset + NB; the pairs i <= SelfOffset + j are scored.
 static void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOffset = -1)
 {
     PhaseTimer tm;
@@ -777,22 +778,36 @@ static void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOff
         uint8_t *d_fwd = nullptr;
         uint32_t *d_pq = nullptr, *d_pt = nullptr, *d_n = nullptr;
         const uint64_t total = Self ? SelfTotal : (uint64_t) NA * NB;
-        size_t cap = (size_t) std::min<uint64_t>(Tri ? total : (uint64_t) NA * NB, 1ull << 31);
+        // survivor lists: sized for 1/16 of the pairs (the presets pass 0.3 % - 15 %), re-run with the exact count on overflow
+        // (the kernel counts every survivor; it only stops storing at `cap`)
+        const uint64_t dense = Tri ? total : (uint64_t) NA * NB;
+        size_t cap = (size_t) std::min<uint64_t>(dense, std::max<uint64_t>(1u << 22, dense / 16));
         auto hipok = [](hipError_t e, const char *w) { if (e != hipSuccess) throw std::runtime_error(std::string(w) + ": " + hipGetErrorString(e)); };
-        hipok(hipMalloc((void **) &d_fwd, (size_t) (Swap ? NB : NA) * ldo), "hipMalloc fwd");
-        hipok(hipMalloc((void **) &d_pq, cap * 4), "hipMalloc pairs");
-        hipok(hipMalloc((void **) &d_pt, cap * 4), "hipMalloc pairs");
-        hipok(hipMalloc((void **) &d_n, 4), "hipMalloc n");
-        check(rsk_mu_filter_dev(ctx, FilterQ, FilterT, Tri ? 1 : 0, P.m_ParaMuGapOpen, P.m_ParaMuGapExt, P.m_Omega, P.m_OmegaFwd, d_fwd, ldo,
-                                d_pq, d_pt, nullptr, nullptr, cap, d_n),
-              "rsk_mu_filter_dev");
+        struct dev_bufs {
+            uint8_t *fwd = nullptr; uint32_t *pq = nullptr, *pt = nullptr, *n = nullptr;
+            ~dev_bufs() { (void) hipFree(fwd); (void) hipFree(pq); (void) hipFree(pt); (void) hipFree(n); }
+        } D;
+        hipok(hipMalloc((void **) &D.fwd, (size_t) (Swap ? NB : NA) * ldo), "hipMalloc fwd");
+        hipok(hipMalloc((void **) &D.n, 4), "hipMalloc n");
         uint32_t ns = 0;
-        hipok(hipMemcpy(&ns, d_n, 4, hipMemcpyDeviceToHost), "copy n");
-        if (ns > cap) throw std::runtime_error("Mu filter survivor list overflow");
+        for (;;) {
+            hipok(hipMalloc((void **) &D.pq, std::max<size_t>(cap, 1) * 4), "hipMalloc pairs");
+            hipok(hipMalloc((void **) &D.pt, std::max<size_t>(cap, 1) * 4), "hipMalloc pairs");
+            check(rsk_mu_filter_dev(ctx, FilterQ, FilterT, Tri ? 1 : 0, P.m_ParaMuGapOpen, P.m_ParaMuGapExt, P.m_Omega, P.m_OmegaFwd, D.fwd, ldo,
+                                    D.pq, D.pt, nullptr, nullptr, cap, D.n),
+                  "rsk_mu_filter_dev");
+            hipok(hipMemcpy(&ns, D.n, 4, hipMemcpyDeviceToHost), "copy n");
+            if (ns <= cap) break;
+            (void) hipFree(D.pq); (void) hipFree(D.pt);
+            D.pq = D.pt = nullptr;
+            cap = ns;
+        }
+        d_fwd = D.fwd; d_pq = D.pq; d_pt = D.pt; d_n = D.n;
         std::vector<uint32_t> pq(ns), pt(ns);
         hipok(hipMemcpy(pq.data(), d_pq, (size_t) ns * 4, hipMemcpyDeviceToHost), "copy pairs");
         hipok(hipMemcpy(pt.data(), d_pt, (size_t) ns * 4, hipMemcpyDeviceToHost), "copy pairs");
-        (void) hipFree(d_fwd); (void) hipFree(d_pq); (void) hipFree(d_pt); (void) hipFree(d_n);
+        (void) hipFree(D.fwd); (void) hipFree(D.pq); (void) hipFree(D.pt); (void) hipFree(D.n);
+        D.fwd = nullptr; D.pq = D.pt = D.n = nullptr;
         if (Swap) pq.swap(pt);                                               // back to (A-side, B-side)
         // deterministic order (the device list is unordered)
         // counting sort by the A-side chain, then each chain's partners ascending (on the host worker threads)
@@ -835,7 +850,7 @@ static void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOff
             }
         }
         if (S.m_Opts.noself) {
-            if (Self) nskip = NB;               // the diagonal pairs of this shard
+            if (Self) nskip = NA > joff ? std::min<uint64_t>(NB, NA - joff) : 0;      // the diagonal pairs this pass holds
             else {
                 std::unordered_map<std::string, uint32_t> cntB;
                 for (uint j = 0; j < NB; ++j) ++cntB[S.m_DBChains[j]->m_Label];
@@ -915,11 +930,74 @@ static void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOff
     tm.lap("MKF (GPU seeds + host)");
 }
 
+// Largest dense pair block one Mu-filter pass may cover: the forward-score matrix is one byte per pair in HBM and the
+// survivor counter is 32 bits.  RSK_FILTER_TILE_PAIRS lowers it (tests).
+static uint64_t FilterTilePairs()
+{
+    uint64_t v = 4ull << 30;
+    if (const char *e = getenv("RSK_FILTER_TILE_PAIRS")) { const long long x = atoll(e); if (x > 0) v = (uint64_t) x; }
+    return std::min<uint64_t>(v, 0xFFFFFFFFull);
+}
+
+struct PairCounters {
+    uint64_t pairs = 0, alns = 0, fin = 0, fdis = 0, mkf = 0;
+    void add(const DBSearcher &S) { pairs += S.m_ProcessedPairCount; alns += S.m_AlnCount; fin += S.m_MuFilterInputCount; fdis += S.m_MuFilterDiscardCount; mkf += S.m_MKFPairCount; }
+    void store(DBSearcher &S) const { S.m_ProcessedPairCount = pairs; S.m_AlnCount = alns; S.m_MuFilterInputCount = fin; S.m_MuFilterDiscardCount = fdis; S.m_MKFPairCount = mkf; }
+};
+
+// The triangle of the chains [Lo, Hi) of `Set` plus the rectangle chains[0, Lo) x chains[Lo, Hi) above it, in target
+// blocks whose filter passes stay below the tile size.  (0, N) = the whole self search; a shard passes its own range.
+static void RunSelfRange(DBSearcher &Set, uint Lo, uint Hi, FILE *fTsv, PairCounters &C, uint64_t &Hits, uint64_t &SW)
+{
+    const uint64_t tile = FilterTilePairs();
+    uint b0 = Lo;
+    while (b0 < Hi) {
+        // widest block [b0, b1) with b1 * (b1 - b0) <= tile pairs (at least one target)
+        uint b1 = b0 + 1;
+        {
+            uint lo = b0 + 1, hi = Hi;
+            while (lo < hi) {
+                const uint mid = lo + (hi - lo + 1) / 2;
+                if ((uint64_t) mid * (mid - b0) <= tile) lo = mid; else hi = mid - 1;
+            }
+            b1 = std::max(b0 + 1, lo);
+        }
+        DBSearcher B;
+        B.MakeView(Set, b0, b1);
+        B.Setup();
+        B.m_fTsv = fTsv;
+        B.UploadToGpu();
+        if (b0 > 0) {
+            DBSearcher A;
+            A.MakeView(Set, 0, b0);
+            A.UploadToGpu();
+            RunPairs(B, A, true, (int64_t) b0);
+            C.add(B);
+        }
+        RunPairs(B, B, true);
+        C.add(B);
+        Hits += B.m_HitCount;
+        SW += B.m_SWCount;
+        b0 = b1;
+    }
+}
+
 void DBSearcher::RunSelf()
 {
     if (!m_fTsv) m_fTsv = g_fTsv;
-    UploadToGpu();
-    RunPairs(*this, *this, true);
+    const uint N = GetDBChainCount();
+    if (m_HasOnAlnOverride || (uint64_t) N * N <= FilterTilePairs()) {
+        UploadToGpu();
+        RunPairs(*this, *this, true);
+        return;
+    }
+    // a set whose dense pair matrix exceeds one filter pass (~65 k chains): target blocks, as the shards of a multi-GPU run
+    PairCounters C;
+    uint64_t Hits = 0, SW = 0;
+    RunSelfRange(*this, 0, N, m_fTsv, C, Hits, SW);
+    C.store(*this);
+    m_HitCount += (uint) Hits;
+    m_SWCount += SW;
 }
 
 // chains [Lo, Hi) of Src as a searcher of their own (borrowed pointers)
@@ -943,19 +1021,15 @@ void DBSearcher::RunSelfShard(uint Index, uint Count)
     for (uint j = 0; j < N; ++j) { pre += m_DBChains[j]->GetSeqLength(); cum[j + 1] = cum[j] + pre * m_DBChains[j]->GetSeqLength(); }
     auto bound = [&](uint r) { return r >= Count ? N : (uint) (std::lower_bound(cum.begin(), cum.end(), cum[N] * r / Count) - cum.begin()); };
     const uint Lo = std::min(N, bound(Index)), Hi = std::max(Lo, std::min(N, bound(Index + 1)));
-    DBSearcher A, B;
-    A.MakeView(*this, 0, Hi);
-    B.MakeView(*this, Lo, Hi);
-    B.Setup();
-    B.m_fTsv = m_fTsv;
-    if (Hi > Lo) {
-        A.UploadToGpu();
-        B.UploadToGpu();
-        RunPairs(B, A, true, (int64_t) Lo);
-    }
-    m_HitCount = B.m_HitCount; m_ProcessedPairCount = B.m_ProcessedPairCount; m_AlnCount = B.m_AlnCount;
-    m_MuFilterInputCount = B.m_MuFilterInputCount; m_MuFilterDiscardCount = B.m_MuFilterDiscardCount;
-    m_MKFPairCount = B.m_MKFPairCount; m_SWCount = B.m_SWCount;
+    // this shard = the rectangle chains[0, Lo) x chains[Lo, Hi) plus the triangle of chains[Lo, Hi): no pair of the square
+    // [Lo, Hi)^2 below its diagonal is ever scored (a single rectangular pass [0, Hi) x [Lo, Hi) made the first shard do
+    // twice its share of the filter)
+    PairCounters C;
+    uint64_t Hits = 0, SW = 0;
+    if (Hi > Lo) RunSelfRange(*this, Lo, Hi, m_fTsv, C, Hits, SW);
+    C.store(*this);
+    m_HitCount = (uint) Hits;
+    m_SWCount = SW;
 }
 
 void DBSearcher::RunQuery(DBSearcher &DBChainsSource)
@@ -964,10 +1038,28 @@ void DBSearcher::RunQuery(DBSearcher &DBChainsSource)
     if (!m_fTsv) m_fTsv = g_fTsv;
     UploadToGpu();
     DBChainsSource.m_Ctx = m_Ctx;
-    DBChainsSource.UploadToGpu();
-    tm.lap("upload both sets");
-    RunPairs(*this, DBChainsSource, false);
-    tm.lap("RunPairs");
+    const uint NA = DBChainsSource.GetDBChainCount(), NB = GetDBChainCount();
+    const uint64_t tile = FilterTilePairs();
+    if (m_HasOnAlnOverride || (uint64_t) NA * NB <= tile || NA <= 1) {
+        DBChainsSource.UploadToGpu();
+        tm.lap("upload both sets");
+        RunPairs(*this, DBChainsSource, false);
+        tm.lap("RunPairs");
+        return;
+    }
+    // row blocks of the source so that one filter pass stays below the tile size
+    const uint rows = (uint) std::max<uint64_t>(1, tile / std::max<uint>(NB, 1));
+    PairCounters C;
+    for (uint lo = 0; lo < NA; lo += rows) {
+        DBSearcher View;
+        View.MakeView(DBChainsSource, lo, std::min(NA, lo + rows));
+        View.m_Ctx = m_Ctx;
+        View.UploadToGpu();
+        RunPairs(*this, View, false);
+        C.add(*this);
+    }
+    C.store(*this);
+    tm.lap("RunPairs (row blocks)");
 }
 
 // runquery.cpp:18-125.  The reference's threads pull one chain at a time from the reader, featurise it, compute its

@@ -69,7 +69,7 @@ struct mkf_args {
     const uint32_t *iq, *it;           // pairs
     const uint32_t *qslot;             // table index of each pair's query
     const uint16_t *tables;
-    uint32_t npairs;
+    uint32_t pair_lo, pair_hi;         // this launch handles the pairs [pair_lo, pair_hi) of the call
     int X, min_score;
     uint32_t cap;                      // kept HSPs stored per record (<= MKF_CAP_MAX)
     uint8_t *found;                    // per pair: any seed with score >= min_score
@@ -82,8 +82,8 @@ struct mkf_args {
 
 __global__ __launch_bounds__(64 * MKF_WAVES) void k_mkf_seed(mkf_args a)
 {
-    const uint32_t p = blockIdx.x * MKF_WAVES + (threadIdx.x >> 6);
-    if (p >= a.npairs) return;
+    const uint32_t p = a.pair_lo + blockIdx.x * MKF_WAVES + (threadIdx.x >> 6);
+    if (p >= a.pair_hi) return;
     const int lane = threadIdx.x & 63;
     const uint32_t q = a.iq[p], t = a.it[p];
     const uint8_t *Q = a.q_mu + a.q_off[q], *T = a.t_mu + a.t_off[t];
@@ -166,12 +166,31 @@ extern "C" int rsk_mkf_seed_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t
     RSK_HIP(hipSetDevice(ctx->device));
     int rc = rsk_upload_mu_tables(ctx);
     if (rc != RSK_OK) return rc;
-    // distinct queries -> table slots
+    // distinct queries -> table slots.  One 373 KB table per distinct query; the pairs are cut into consecutive chunks of
+    // at most `budget` distinct queries (3 GB of tables) that reuse one table block, so a call whose query side is a whole
+    // database (-db mode with a long query: every DB chain is a distinct iq) needs no more memory than a small one.
+    const size_t budget = getenv("RSK_MKF_MAX_TABLES") ? (size_t) std::max(1, atoi(getenv("RSK_MKF_MAX_TABLES"))) : 8192;
+    struct chunk_t { size_t p0, p1, q0, q1; };
+    std::vector<chunk_t> chunks;
     std::vector<uint32_t> slot_of(q->n, 0xFFFFFFFFu), qlist, qslot(npairs);
-    for (size_t p = 0; p < npairs; ++p) {
-        if (slot_of[iq[p]] == 0xFFFFFFFFu) { slot_of[iq[p]] = (uint32_t) qlist.size(); qlist.push_back(iq[p]); }
-        qslot[p] = slot_of[iq[p]];
+    {
+        size_t p0 = 0, q0 = 0;
+        for (size_t p = 0; p < npairs; ++p) {
+            if (slot_of[iq[p]] == 0xFFFFFFFFu) {
+                if (qlist.size() - q0 == budget) {          // close the chunk before this pair
+                    chunks.push_back({ p0, p, q0, qlist.size() });
+                    for (size_t k = q0; k < qlist.size(); ++k) slot_of[qlist[k]] = 0xFFFFFFFFu;
+                    p0 = p; q0 = qlist.size();
+                }
+                slot_of[iq[p]] = (uint32_t) (qlist.size() - q0);
+                qlist.push_back(iq[p]);
+            }
+            qslot[p] = slot_of[iq[p]];
+        }
+        chunks.push_back({ p0, npairs, q0, qlist.size() });
     }
+    size_t max_tables = 0;
+    for (const chunk_t &c : chunks) max_tables = std::max(max_tables, c.q1 - c.q0);
     struct ws_t {
         rsk_ctx *ctx;
         std::vector<void *> all;
@@ -191,7 +210,7 @@ extern "C" int rsk_mkf_seed_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t
     if ((rc = dalloc((void **) &d_it, npairs * 4)) != RSK_OK) return rc;
     if ((rc = dalloc((void **) &d_qslot, npairs * 4)) != RSK_OK) return rc;
     if ((rc = dalloc((void **) &d_qlist, qlist.size() * 4)) != RSK_OK) return rc;
-    if ((rc = dalloc((void **) &d_tab, qlist.size() * (size_t) MKF_DICT * MKF_HASHW * 2)) != RSK_OK) return rc;
+    if ((rc = dalloc((void **) &d_tab, max_tables * (size_t) MKF_DICT * MKF_HASHW * 2)) != RSK_OK) return rc;
     if ((rc = dalloc((void **) &d_found, npairs)) != RSK_OK) return rc;
     if ((rc = dalloc((void **) &d_nrec, 4)) != RSK_OK) return rc;
     if ((rc = dalloc((void **) &d_rpair, max_records * 4)) != RSK_OK) return rc;
@@ -203,15 +222,18 @@ extern "C" int rsk_mkf_seed_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t
     RSK_HIP(hipMemcpyAsync(d_qlist, qlist.data(), qlist.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     RSK_HIP(hipMemsetAsync(d_nrec, 0, 4, ctx->stream));
     RSK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-    hipLaunchKernelGGL(k_mkf_build, dim3((unsigned) qlist.size()), dim3(256), 0, ctx->stream, q->d_mu, q->d_off, q->d_len, d_qlist, d_tab);
     mkf_args a = {};
     a.q_mu = q->d_mu; a.q_off = q->d_off; a.q_len = q->d_len;
     a.t_mu = t->d_mu; a.t_off = t->d_off; a.t_len = t->d_len;
     a.iq = d_iq; a.it = d_it; a.qslot = d_qslot; a.tables = d_tab;
-    a.npairs = (uint32_t) npairs; a.X = x1; a.min_score = min_hsp_score; a.cap = cap;
+    a.X = x1; a.min_score = min_hsp_score; a.cap = cap;
     a.found = d_found; a.nrec = d_nrec; a.max_rec = (uint32_t) max_records;
     a.rec_pair = d_rpair; a.rec_nkept = d_rnk; a.rec_kept = d_rkept;
-    hipLaunchKernelGGL(k_mkf_seed, dim3((unsigned) ((npairs + MKF_WAVES - 1) / MKF_WAVES)), dim3(64 * MKF_WAVES), 0, ctx->stream, a);
+    for (const chunk_t &c : chunks) {                       // same stream: a chunk's tables are rebuilt after its seeding kernel is done
+        hipLaunchKernelGGL(k_mkf_build, dim3((unsigned) (c.q1 - c.q0)), dim3(256), 0, ctx->stream, q->d_mu, q->d_off, q->d_len, d_qlist + c.q0, d_tab);
+        a.pair_lo = (uint32_t) c.p0; a.pair_hi = (uint32_t) c.p1;
+        hipLaunchKernelGGL(k_mkf_seed, dim3((unsigned) ((c.p1 - c.p0 + MKF_WAVES - 1) / MKF_WAVES)), dim3(64 * MKF_WAVES), 0, ctx->stream, a);
+    }
     RSK_HIP(hipGetLastError());
     RSK_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     uint32_t nrec = 0;

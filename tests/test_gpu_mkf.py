@@ -37,6 +37,19 @@ def test_palms_all_pairs_match_reference(ctx):
         else:
             assert p not in recs
     assert nfound > 100
+    # a table budget smaller than the number of distinct queries (one 373 KB 3-mer table each): the call runs in chunks
+    # that reuse one table block -- interleaved query order so that queries recur across chunks
+    import os
+    perm = np.random.default_rng(5).permutation(n * n)
+    os.environ["RSK_MKF_MAX_TABLES"] = "3"
+    try:
+        found3, recs3 = ctx.mkf_seed_pairs(db, db, iq[perm], it[perm], cap=32)
+    finally:
+        del os.environ["RSK_MKF_MAX_TABLES"]
+    assert np.array_equal(found3, found[perm])
+    for k, p in enumerate(perm):
+        if found[p]:
+            assert recs3[k][0] == recs[p][0] and np.array_equal(recs3[k][1], recs[p][1])
     # truncation: cap 1 keeps the first HSP; the count is exact when it fits and an upper bound (> cap) otherwise
     found1, recs1 = ctx.mkf_seed_pairs(db, db, iq, it, cap=1)
     assert np.array_equal(found1, found)

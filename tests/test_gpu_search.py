@@ -238,3 +238,40 @@ def test_edge_case_chains(ctx, tmpdir):
     ctx.search(e, out, "fast", db=e, columns=COLS, keeptmp=1)
     assert sorted(open(out).read().splitlines()) == ["\t".join(r) for r in fx.read_tsv("hits_edge_fastdb.tsv.gz")]
     assert open(out + ".prefilter.tmp").read() == gzip.open(os.path.join(fx.GOLDEN, "prefilter_edge_fastdb_tmp.tsv.gz")).read().decode()
+
+
+def test_tiled_pair_space_equals_one_pass(ctx, tmpdir, monkeypatch):
+    """Pair spaces larger than one Mu-filter pass run in target blocks (self search: triangle + rectangle per block, as the
+    multi-GPU shards) or row blocks of the streamed set (-db); the survivor lists start small and are re-run on overflow.
+    With the tile forced down to 1500 pairs every fixture takes that path and must reproduce the same tables."""
+    monkeypatch.setenv("RSK_FILTER_TILE_PAIRS", "1500")
+    run_bca(ctx, tmpdir, "q100.bca", "sensitive", COLS, "hits_q100_sensitive.tsv.gz")
+    run_bca(ctx, tmpdir, "q100.bca", "fast", COLS, "hits_q100_fast.tsv.gz")
+    run_bca(ctx, tmpdir, "palms.bca", "sensitive", COLS, "hits_palms_sensitive.tsv.gz")
+    run_bca(ctx, tmpdir, "q100.bca", "sensitive", COLS, "hits_q100_db_q100_sensitive.tsv.gz", db="q100.bca")
+    st = run(ctx, tmpdir, "q100_sensitive.rskdb.gz", "sensitive", COLS, "hits_q100_sensitive.tsv.gz")
+    assert st[0] == 5050 and st[4] == 490 and st[2] == 4560          # the counters add up over the blocks
+    q = unpack_bca("q100.bca", tmpdir)
+    lines = []
+    for idx in range(3):
+        out = os.path.join(tmpdir, "tiled_shard_%d.tsv" % idx)
+        ctx.search(q, out, "sensitive", columns=COLS, shard_index=idx, shard_count=3)
+        lines += open(out).read().splitlines()
+    assert sorted(lines) == ["\t".join(r) for r in fx.read_tsv("hits_q100_sensitive.tsv.gz")]
+
+
+def test_streamed_db_batches(ctx, tmpdir, monkeypatch):
+    """RunQuery(ChainReader2 &): the -db file streams in batches of RSK_STREAM_CHAINS chains (loader thread featurises
+    batch k + 1 while batch k is searched); 7 chains per batch = 15 batches of q100."""
+    monkeypatch.setenv("RSK_STREAM_CHAINS", "7")
+    q = unpack_bca("q100.bca", tmpdir)
+    out = os.path.join(tmpdir, "streamed.tsv")
+    n, st = ctx.search(q, out, "sensitive", db=q, columns=COLS)
+    assert sorted(open(out).read().splitlines()) == ["\t".join(r) for r in fx.read_tsv("hits_q100_db_q100_sensitive.tsv.gz")]
+    assert st[0] == 10000
+    p = unpack_bca("palms.bca", tmpdir)
+    out1, out2 = os.path.join(tmpdir, "palms_db_stream.tsv"), os.path.join(tmpdir, "palms_db_whole.tsv")
+    ctx.search(p, out1, "sensitive", db=p, columns=COLS)
+    monkeypatch.delenv("RSK_STREAM_CHAINS")
+    ctx.search(p, out2, "sensitive", db=p, columns=COLS)
+    assert sorted(open(out1).read().splitlines()) == sorted(open(out2).read().splitlines())
