@@ -30,7 +30,7 @@ import bench_search  # noqa: E402
 import reseek_amd  # noqa: E402
 
 
-def compare(n, mode, ndb=0, threads=1, seed=21, keep=None, long_chains=0):
+def compare(n, mode, ndb=0, threads=1, seed=21, keep=None, long_chains=0, tail=False):
     """-> dict (see main); ["identical"] tells whether the sorted hit tables are equal."""
     ref = os.path.join(ROOT, "oracle", "_ref", "reseek")
     if not os.path.exists(ref):
@@ -45,11 +45,18 @@ def compare(n, mode, ndb=0, threads=1, seed=21, keep=None, long_chains=0):
             q = os.path.join(td, "q.bca")
             ql = lens[rng.choice(len(lens), n)].copy()
             ql[:long_chains] = [620 + 140 * k for k in range(long_chains)]      # chains that take the MKF / X-drop path for sure
+            dbl = lens[rng.choice(len(lens), ndb)].copy() if ndb else None
+            if tail:
+                # PDB-like lengths: lognormal, median ~250, tail to 5,000 (BASELINE configs[3] / configs[4])
+                ql = np.clip(rng.lognormal(np.log(250), 0.6, n), 30, 1500).astype(np.int64)
+                if ndb:
+                    dbl = np.clip(rng.lognormal(np.log(250), 0.75, ndb), 20, 5000).astype(np.int64)
+                    dbl[:3] = [5000, 2600, 1100]
             bench_search.write_bca(q, ql, rng)
             db = None
             if ndb:
                 db = os.path.join(td, "db.bca")
-                bench_search.write_bca(db, lens[rng.choice(len(lens), ndb)], rng)
+                bench_search.write_bca(db, dbl, rng)
             ref_tsv, our_tsv = os.path.join(td, "ref.tsv"), os.path.join(td, "our.tsv")
             cmd = [ref, "-search", q, "-" + mode, "-output", ref_tsv, "-threads", str(threads)] + (["-db", db] if db else [])
             t0 = time.perf_counter()

@@ -129,3 +129,17 @@ sort $TMP/edge_fastdb.tsv | gzip -9n > $G/hits_edge_fastdb.tsv.gz
 gzip -9n < $TMP/kt3/rce.*.tmp > $G/prefilter_edge_fastdb_tmp.tsv.gz
 rm -rf $TMP
 ls -la $G
+# 12. BASELINE configs[3] / configs[4] shapes at fixture size: -db searches in -sensitive and -verysensitive, with a
+#     PDB-like length tail up to 5,000 residues (Mu fallback > 2048, row groups > 1024, long-chain path >= 600)
+python3 $G/make_tail_bca.py subset $T/q100.bca $TMP/q32.bca 32
+$R -search $TMP/q32.bca -db $T/q100.bca -verysensitive -columns $COLS -output $TMP/q32v.tsv -threads 1 -quiet >/dev/null 2>&1
+sort $TMP/q32v.tsv | gzip -9n > $G/hits_q32_db_q100_verysensitive.tsv.gz
+python3 $G/make_tail_bca.py tail $TMP/tailq.bca $TMP/taildb.bca
+gzip -9n < $TMP/tailq.bca > $G/tailq.bca.gz
+gzip -9n < $TMP/taildb.bca > $G/taildb.bca.gz
+for m in sensitive verysensitive; do
+  $R -search $TMP/tailq.bca -db $TMP/taildb.bca -$m -columns $COLS -output $TMP/tail_$m.tsv -threads 1 -quiet >/dev/null 2>&1
+  sort $TMP/tail_$m.tsv | gzip -9n > $G/hits_tail_db_$m.tsv.gz
+done
+$R -search $TMP/taildb.bca -verysensitive -columns $COLS -output $TMP/tail_self_v.tsv -threads 1 -quiet >/dev/null 2>&1
+sort $TMP/tail_self_v.tsv | gzip -9n > $G/hits_taildb_self_verysensitive.tsv.gz

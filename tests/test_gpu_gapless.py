@@ -128,3 +128,34 @@ def test_scop40_scale_properties(ctx):
     pairs, cells, slots = ctx.mu_gapless_last_work()
     assert pairs == n * n and cells == int(lens.sum()) ** 2 and slots >= cells
     db.close()
+
+
+def test_scop40_scale_triangle_mode_vs_oracle(ctx):
+    """The configuration bench.py times (BASELINE configs[1]): 11,211 chains sorted by length, self_triangle = True.  A seeded
+    sample of 3,000 pairs i <= j of the triangle bit-exact vs the oracle, the work counters of the triangle, and equality
+    with the rectangular pass on the upper triangle (the score is symmetric)."""
+    import torch
+    import reseek_amd
+    lens = fx.scop40_lengths()
+    rng = np.random.default_rng(2025)
+    order = np.argsort(lens, kind="stable")
+    seqs = [rng.integers(0, 36, int(L)).astype(np.uint8) for L in lens[order]]
+    n = len(seqs)
+    db = reseek_amd.Db.from_mu_seqs(ctx, seqs)
+    out = torch.zeros((n, n), dtype=torch.int16, device="cuda")
+    ctx.mu_gapless_matrix_dev(db, db, True, out.data_ptr(), n)
+    torch.cuda.synchronize()
+    pairs, cells, slots = ctx.mu_gapless_last_work()
+    L = lens[order].astype(np.int64)
+    assert pairs == n * (n + 1) // 2 and cells == int((L * np.cumsum(L[::-1])[::-1]).sum()) and slots >= cells
+    a = rng.integers(0, n, 3000)
+    b = rng.integers(0, n, 3000)
+    ia, ib = np.minimum(a, b), np.maximum(a, b)
+    got = out[torch.from_numpy(ia).cuda(), torch.from_numpy(ib).cuda()].cpu().numpy().view(np.uint16).astype(np.int32)
+    assert np.array_equal(got, ol.mu_gapless_pairs(seqs, ia, ib))
+    rect = torch.zeros((n, n), dtype=torch.int16, device="cuda")
+    ctx.mu_gapless_matrix_dev(db, db, False, rect.data_ptr(), n)
+    torch.cuda.synchronize()
+    iu = torch.triu_indices(n, n, device="cuda")
+    assert bool((out[iu[0], iu[1]] == rect[iu[0], iu[1]]).all())
+    db.close()

@@ -25,3 +25,17 @@ def test_hit_table_equals_the_reference_binary(n, mode, ndb, seed):
     assert res["reference_rows"] > 0
     if mode != "verysensitive":
         assert res["long_chain_pairs"] > 0        # chains >= 600: MKF seeding + GPU X-drop extensions took part
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref/reseek was not built (no /root/reference at build time)")
+@pytest.mark.parametrize("n,mode,ndb,seed", [(24, "verysensitive", 160, 11), (48, "sensitive", 400, 12)])
+def test_db_search_with_a_pdb_like_length_tail(n, mode, ndb, seed):
+    """BASELINE configs[3] / configs[4] at test size: query batch vs a DB whose lengths are lognormal with a tail to 5,000
+    (-verysensitive: every pair through SW + traceback, chains > 1024 in row groups / transposed; -sensitive: Mu filter
+    fallback > 2048 and the long-chain path), reference binary vs rsk_search on data no fixture has seen."""
+    import compare_with_reference as cwr
+    res = cwr.compare(n, mode, ndb, threads=1, seed=seed, tail=True)
+    assert res["identical"], res
+    assert res["reference_rows"] > 0
+    if mode == "sensitive":
+        assert res["long_chain_pairs"] > 0
