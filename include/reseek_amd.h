@@ -206,6 +206,19 @@ int rsk_xdrop_pairs(rsk_ctx *ctx, const rsk_db *a, const rsk_db *b, const uint32
                     float *score_fwd, float *score_bwd, char *paths, size_t paths_bytes, uint64_t *fwd_off,
                     uint32_t *fwd_len, uint64_t *bwd_off, uint32_t *bwd_len);
 
+/* P9 after the chaining, in ONE device batch (what DBSearcher's long-chain stage uses): per pair the chained seed HSPs
+ * (MuKmerFilter::ChainHSPs mukmerfilter.cpp:391, kept on the host: Chainer::Chain sorts with libc qsort on a comparator that
+ * is no total order) as a CSR list hsp_first[npairs + 1] / hsp_lo_a / hsp_lo_b / hsp_len ->
+ *   PostAlignMKF (dssaligner.cpp:1395: GetMegaHSPScore :488 of every HSP, sum < min_mega_score => no alignment, best HSP),
+ *   XDropHSP (xdrophsp.cpp:42: best 8-mer of that HSP = start, XDropFwd + XDropBwd with X = x2, total < 10 => no alignment),
+ *   MergeFwdBwd (mergefwdback.cpp:6) and CalcEvalue (dssaligner.cpp:852).
+ * out / paths as rsk_align_pairs (path_len == 0 = no alignment).  status[p]: 0 = gated out, 1 = extended on the device,
+ * 2 = the start fell outside 1..L-1 of a chain (cannot happen for chains >= 8; the caller's per-pair path decides). */
+int rsk_mkf_align_pairs(rsk_ctx *ctx, const rsk_db *a, const rsk_db *b, const uint32_t *ia, const uint32_t *ib, size_t npairs,
+                        const uint32_t *hsp_first, const int32_t *hsp_lo_a, const int32_t *hsp_lo_b, const int32_t *hsp_len, float x2,
+                        float gap_open, float gap_ext, float min_mega_score, float min_fwd_score, rsk_aln *out, uint8_t *status, char *paths,
+                        size_t paths_bytes);
+
 /* ---- P10/P11/P12: Mu k-mer prefilter ----------------------------------------------------------------
  * Batch form of MuDex::FromSeqDB (mudex.cpp:386; index of the QUERY set, built once and cached in q)
  * + PrefilterMu::Search over every target (prefiltermu.cpp:382): spaced 5-of-7 k-mers, self-score

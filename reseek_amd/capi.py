@@ -70,6 +70,8 @@ SIGNATURES["rsk_mkf_seed_pairs"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p
 SIGNATURES["rsk_xdrop_pairs"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, u32p, u32p, u32p, u32p, C.c_size_t, C.c_float, C.c_float,
                                            C.c_float, f32p, f32p, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64), u32p,
                                            C.POINTER(C.c_uint64), u32p])
+SIGNATURES["rsk_mkf_align_pairs"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, u32p, u32p, C.c_size_t, u32p, i32p, i32p, i32p, C.c_float,
+                                               C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(Aln), u8p, C.c_char_p, C.c_size_t])
 SIGNATURES["rsk_xdrop_fwd"] = (C.c_int, [f32p, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32,
                                          f32p, C.c_char_p, C.c_size_t, u32p])
 SIGNATURES["rsk_xdrop_bwd"] = SIGNATURES["rsk_xdrop_fwd"]

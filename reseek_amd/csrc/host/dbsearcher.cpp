@@ -672,71 +672,79 @@ void RunMKFPairs(rsk_ctx *Ctx, const DSSParams &P, const std::string &Columns, D
         DA.SetQuery(*SrcA.m_DBChains[i], SrcA.m_DBProfiles[i], SrcA.m_DBMuLettersVec[i], SrcA.m_DBMuKmersVec[i], SrcA.m_DBSelfRevScores[i]);
         DA.SetTarget(*SrcB.m_DBChains[j], SrcB.m_DBProfiles[j], SrcB.m_DBMuLettersVec[j], SrcB.m_DBMuKmersVec[j], SrcB.m_DBSelfRevScores[j]);
     };
-    // stage 1 (host threads): chain the seed HSPs, score the chained HSPs, pick the start of the gapped extension
-    // (PostAlignMKF up to XDropHSP's start, dssaligner.cpp:1395-1418, xdrophsp.cpp:42-95).  req: 0 = no alignment,
-    // 1 = extensions requested (rsk_xdrop_pairs rejects a start outside 1..L-1; XDropHSP cannot produce one)
-    std::vector<uint8_t> req(recs.size(), 0);
-    std::vector<uint32_t> rqa(recs.size(), 0), rqb(recs.size(), 0);
-    parallel([&](DSSAligner &DA, size_t r) {
-        const Rec &R = recs[r];
-        set_pair(DA, r);
-        DA.m_XDropMode = 1;
-        if (R.nkept > CAP) DA.AlignMKF();                                 // seed list truncated on the device: seeds from MuKmerFilter::Align
-        else DA.AlignMKF_FromSeeds(R.kept.data(), R.nkept);
-        DA.m_XDropMode = 0;
-        if (!DA.m_XDropReqValid) return;
-        req[r] = 1;
-        rqa[r] = DA.m_XDropReqLoA; rqb[r] = DA.m_XDropReqLoB;
-    });
-    // stage 2 (GPU): both extensions of every requested pair, one thread each
+    // stage 1 (host threads): chain the seed HSPs of every record (MuKmerFilter::ChainHSPs mukmerfilter.cpp:391 ->
+    // Chainer::Chain, libc qsort on a comparator that is no total order: the one step that stays on the host).
+    // RSK_MKF_HOST=1 keeps the whole per-pair path on the host threads (the parity reference of the device batch).
+    const bool host_only = getenv("RSK_MKF_HOST") && atoi(getenv("RSK_MKF_HOST")) != 0;
+    struct Chained { std::vector<int32_t> lo_a, lo_b, len; };
+    std::vector<Chained> chains(recs.size());
+    if (!host_only)
+        parallel([&](DSSAligner &DA, size_t r) {
+            const Rec &R = recs[r];
+            if (R.nkept > CAP) {                                          // seed list truncated on the device: seeds from MuKmerFilter::Align
+                set_pair(DA, r);
+                DA.m_MKF.Align(*DA.m_MuLettersB, *DA.m_MuKmersB);
+            } else
+                DA.m_MKF.SetSeedHSPs(R.kept.data(), R.nkept);
+            if (DA.m_MKF.m_BestChainScore <= 0) return;                   // PostAlignMKF dssaligner.cpp:1397
+            Chained &C = chains[r];
+            C.lo_a.assign(DA.m_MKF.m_ChainHSPLois.begin(), DA.m_MKF.m_ChainHSPLois.end());
+            C.lo_b.assign(DA.m_MKF.m_ChainHSPLojs.begin(), DA.m_MKF.m_ChainHSPLojs.end());
+            C.len.assign(DA.m_MKF.m_ChainHSPLens.begin(), DA.m_MKF.m_ChainHSPLens.end());
+        });
+    // stage 2 (GPU, one batch): mega-HSP scores + gates, start of the gapped extensions, both extensions, merge, statistics
     std::vector<size_t> slot(recs.size(), (size_t) -1);
-    std::vector<uint32_t> xa, xb, xla, xlb;
+    std::vector<uint32_t> xa, xb, first(1, 0);
+    std::vector<int32_t> hla, hlb, hlen;
     size_t xbytes = 0;
-    for (size_t r = 0; r < recs.size(); ++r)
-        if (req[r] == 1) {
-            slot[r] = xa.size();
-            const uint i = Pairs[recs[r].pair].first, j = Pairs[recs[r].pair].second;
-            xa.push_back(i); xb.push_back(j); xla.push_back(rqa[r]); xlb.push_back(rqb[r]);
-            xbytes += (size_t) SrcA.m_DBChains[i]->GetSeqLength() + SrcB.m_DBChains[j]->GetSeqLength() + 4;
-        }
+    for (size_t r = 0; r < recs.size(); ++r) {
+        if (chains[r].len.empty()) continue;
+        slot[r] = xa.size();
+        const uint i = Pairs[recs[r].pair].first, j = Pairs[recs[r].pair].second;
+        xa.push_back(i); xb.push_back(j);
+        hla.insert(hla.end(), chains[r].lo_a.begin(), chains[r].lo_a.end());
+        hlb.insert(hlb.end(), chains[r].lo_b.begin(), chains[r].lo_b.end());
+        hlen.insert(hlen.end(), chains[r].len.begin(), chains[r].len.end());
+        first.push_back((uint32_t) hla.size());
+        xbytes += (size_t) SrcA.m_DBChains[i]->GetSeqLength() + SrcB.m_DBChains[j]->GetSeqLength() + 1;
+    }
     const size_t nx = xa.size();
-    std::vector<float> xsf(nx), xsb(nx);
-    std::vector<uint64_t> xfo(nx), xbo(nx);
-    std::vector<uint32_t> xfl(nx), xbl(nx);
+    std::vector<rsk_aln> xout(nx);
+    std::vector<uint8_t> xstatus(nx);
     std::unique_ptr<char[]> xpaths_mem(new char[xbytes + 16]);         // hundreds of MB: not value-initialised
     char *const xpaths = xpaths_mem.get();
     if (nx)
-        check(rsk_xdrop_pairs(Ctx, SrcA.m_Db, SrcB.m_Db, xa.data(), xb.data(), xla.data(), xlb.data(), nx, float(P.m_MKF_X2), P.m_GapOpen, P.m_GapExt,
-                              xsf.data(), xsb.data(), xpaths, xbytes + 16, xfo.data(), xfl.data(), xbo.data(), xbl.data()),
-              "rsk_xdrop_pairs");
+        check(rsk_mkf_align_pairs(Ctx, SrcA.m_Db, SrcB.m_Db, xa.data(), xb.data(), nx, first.data(), hla.data(), hlb.data(), hlen.data(),
+                                  float(P.m_MKF_X2), P.m_GapOpen, P.m_GapExt, P.m_MKF_MinMegaHSPScore, P.m_MinFwdScore, xout.data(), xstatus.data(),
+                                  xpaths, xbytes + 16),
+              "rsk_mkf_align_pairs");
     const auto t_host1 = std::chrono::steady_clock::now();
-    // stage 3 (host threads): merge the extensions, statistics, hit
+    // stage 3 (host threads): the aligned pairs become DSSAligner results and go to the caller
     std::mutex lock;
     parallel([&](DSSAligner &DA, size_t r) {
-        if (req[r] == 0) return;                                         // no alignment: nothing to report (m_Path empty)
         const Rec &R = recs[r];
         const uint i = Pairs[R.pair].first, j = Pairs[R.pair].second;
-        set_pair(DA, r);
         const size_t k = slot[r];
-        DA.m_XDropMode = 2;
-        DA.m_XDropReqValid = true;
-        DA.m_XDropReqLoA = rqa[r]; DA.m_XDropReqLoB = rqb[r];
-        DA.m_XDropExtScoreFwd = xsf[k]; DA.m_XDropExtScoreBwd = xsb[k];
-        DA.m_XDropExtFwdPath.assign(xpaths + xfo[k], xfl[k]);
-        DA.m_XDropExtBwdPath.assign(xpaths + xbo[k], xbl[k]);
-        if (R.nkept > CAP) DA.AlignMKF();
-        else DA.AlignMKF_FromSeeds(R.kept.data(), R.nkept);
-        DA.m_XDropMode = 0;
+        if (host_only || (k != (size_t) -1 && xstatus[k] == 2)) {
+            // the whole pair on this thread: seeds known (or MuKmerFilter::Align), host X-drop, host statistics
+            set_pair(DA, r);
+            if (R.nkept > CAP) DA.AlignMKF();
+            else DA.AlignMKF_FromSeeds(R.kept.data(), R.nkept);
+        } else {
+            if (k == (size_t) -1 || xout[k].path_len == 0) return;       // no alignment: nothing to report (m_Path empty)
+            DA.ClearAlign();
+            DA.m_ChainA = SrcA.m_DBChains[i]; DA.m_ProfileA = SrcA.m_DBProfiles[i];
+            DA.m_ChainB = SrcB.m_DBChains[j]; DA.m_ProfileB = SrcB.m_DBProfiles[j];
+            DA.m_SelfRevScoreA = SrcA.m_DBSelfRevScores[i]; DA.m_SelfRevScoreB = SrcB.m_DBSelfRevScores[j];
+            DA.SetFromAln(xout[k], xpaths + xout[k].path_off);
+        }
         std::lock_guard<std::mutex> g(lock);
         OnHit(DA, i, j);
     });
     if (getenv("RSK_TRACE"))
-        fprintf(stderr, "[RunMKFPairs] %zu gapped extensions on the GPU, stages 1+2 %.3f ms\n", nx,
-                std::chrono::duration<double, std::milli>(t_host1 - t_host0).count());
-    if (getenv("RSK_TRACE"))
-        fprintf(stderr, "[RunMKFPairs] host stage %.3f ms on %u threads (thread-ms so far: mega score %.1f, gapped X-drop %.1f, statistics %.1f)\n",
-                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count(), T, g_MKFNsMega.load() / 1e6,
-                g_MKFNsXDrop.load() / 1e6, g_MKFNsStats.load() / 1e6);
+        fprintf(stderr, "[RunMKFPairs] %zu pairs with chained HSPs through the device batch: chaining + batch %.3f ms, replay %.3f ms (%u threads)\n", nx,
+                std::chrono::duration<double, std::milli>(t_host1 - t_host0).count(),
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host1).count(), T);
 }
 
 // Self with SelfOffset >= 0 is (part of) one SHARD of a self search: B = the chains [SelfOffset, SelfOffset + NB)

@@ -197,6 +197,7 @@ void DSSAligner::SetFromAln(const rsk_aln &a, const char *Path)
     m_AlnFwdScore = a.score;
     m_Path.assign(Path, a.path_len);
     m_LoA = a.lo_a; m_LoB = a.lo_b;
+    if (a.hi_a != RSK_NO_POS) { m_HiA = a.hi_a; m_HiB = a.hi_b; }      // the long-chain batch sets Hi also below MinFwdScore (PostAlignMKF)
     if (a.evalue != FLT_MAX) {
         m_HiA = a.hi_a; m_HiB = a.hi_b; m_Ids = a.ids; m_Gaps = a.gaps;
         m_LDDT = a.lddt;

@@ -1302,6 +1302,135 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
     return RSK_OK;
 }
 
+// CalcEvalue (dssaligner.cpp:852-904) for alignments that already sit on the device as paths -- the long-chain (MKF) pairs
+// of rsk_mkf_align_pairs (k_xdrop.hip): LDDT over the aligned columns (k_lddt / k_lddt_long), path packing in pair order,
+// the statistics with libm pow on the host.  d_* arrays are in pair order; d_pstart = absolute offset of a pair's path in
+// d_paths, d_plen its length (0 = no alignment), d_score the alignment score (0 = no alignment).
+int rsk_paths_stats_pack(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *dbb, size_t npairs, const uint32_t *ia, const uint32_t *ib,
+                         const uint32_t *d_ia, const uint32_t *d_ib, const char *d_paths, const uint64_t *d_pstart, const uint32_t *d_plen,
+                         const uint32_t *d_loa, const uint32_t *d_lob, const float *d_score, float min_fwd_score, rsk_aln *out, char *paths,
+                         size_t paths_bytes)
+{
+    if (npairs == 0) return RSK_OK;
+    if (!dba->d_x || !dbb->d_x) { rsk_set_error("rsk_paths_stats_pack: chain sets have no coordinates"); return RSK_E_INVALID; }
+    struct ws_t {
+        rsk_ctx *ctx;
+        std::vector<void *> all;
+        ~ws_t() { for (void *p : all) rsk_pool_free(ctx, p); }
+    } ws{ ctx, {} };
+    auto dalloc = [&](void **p, size_t bytes) -> int {
+        int r = rsk_pool_alloc(ctx, p, std::max<size_t>(bytes, 16));
+        if (r != RSK_OK) return r;
+        ws.all.push_back(*p);
+        return RSK_OK;
+    };
+    int rc;
+    // scratch offsets (aligned columns <= min(LA, LB)), candidate lists of the long-alignment LDDT kernel, identity slot
+    std::vector<uint64_t> sc_off(npairs + 1);
+    std::vector<uint32_t> lddt_list[2], ident(npairs);
+    uint64_t so = 0;
+    size_t need = 0;
+    for (size_t p = 0; p < npairs; ++p) {
+        const uint32_t LA = dba->len[ia[p]], LB = dbb->len[ib[p]], m = std::min(LA, LB);
+        sc_off[p] = so;
+        so += m;
+        if (m > LDDT_LDS_COLS) lddt_list[m <= 1024 ? 0 : 1].push_back((uint32_t) p);
+        ident[p] = (uint32_t) p;
+        need += (size_t) LA + LB + 1;
+    }
+    sc_off[npairs] = so;
+    if (paths_bytes < need) { rsk_set_error("rsk_paths_stats_pack: paths buffer too small (%zu < %zu)", paths_bytes, need); return RSK_E_INVALID; }
+    uint64_t *d_scoff, *d_sizes, *d_outoff;
+    uint32_t *d_pos, *d_counts, *d_ident, *d_list[2] = { nullptr, nullptr };
+    float *d_frac, *d_lddt;
+    char *d_packed;
+    if ((rc = dalloc((void **) &d_scoff, (npairs + 1) * 8)) || (rc = dalloc((void **) &d_sizes, (npairs + 1) * 8)) ||
+        (rc = dalloc((void **) &d_outoff, (npairs + 1) * 8)) || (rc = dalloc((void **) &d_pos, 2 * so * 4)) || (rc = dalloc((void **) &d_frac, so * 4)) ||
+        (rc = dalloc((void **) &d_counts, npairs * 12)) || (rc = dalloc((void **) &d_lddt, npairs * 4)) || (rc = dalloc((void **) &d_ident, npairs * 4)) ||
+        (rc = dalloc((void **) &d_packed, need + 16)))
+        return rc;
+    RSK_HIP(hipMemcpyAsync(d_scoff, sc_off.data(), (npairs + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    RSK_HIP(hipMemcpyAsync(d_ident, ident.data(), npairs * 4, hipMemcpyHostToDevice, ctx->stream));
+    for (int c = 0; c < 2; ++c)
+        if (!lddt_list[c].empty()) {
+            if ((rc = dalloc((void **) &d_list[c], lddt_list[c].size() * 4)) != RSK_OK) return rc;
+            RSK_HIP(hipMemcpyAsync(d_list[c], lddt_list[c].data(), lddt_list[c].size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        }
+    hipLaunchKernelGGL(k_lddt, dim3((unsigned) ((npairs + 3) / 4)), dim3(256), 0, ctx->stream, d_paths, d_pstart, d_plen, d_loa, d_lob, d_ia, d_ib,
+                       dba->d_off, dbb->d_off, dba->d_x, dba->d_y, dba->d_z, dbb->d_x, dbb->d_y, dbb->d_z, (uint32_t) npairs, d_pos, d_scoff, d_frac,
+                       d_lddt, d_counts, d_score, min_fwd_score);
+    for (int c = 0; c < 2; ++c) {
+        const uint32_t nl = (uint32_t) lddt_list[c].size(), cap = c == 0 ? 1024u : (uint32_t) LDDT_LONG_COLS;
+        if (nl == 0) continue;
+        RSK_HIP(hipFuncSetAttribute((const void *) k_lddt_long, hipFuncAttributeMaxDynamicSharedMemorySize, LDDT_LONG_COLS * 32));
+        hipLaunchKernelGGL(k_lddt_long, dim3(nl), dim3(256), (size_t) cap * 32, ctx->stream, d_list[c], nl, cap, d_ia, d_ib, dba->d_off, dbb->d_off,
+                           dba->d_x, dba->d_y, dba->d_z, dbb->d_x, dbb->d_y, dbb->d_z, d_pos, d_scoff, d_lddt, d_counts, d_score, min_fwd_score);
+    }
+    RSK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_path_sizes, dim3((unsigned) ((npairs + 255) / 256)), dim3(256), 0, ctx->stream, d_ident, d_plen, (uint32_t) npairs, d_sizes);
+    size_t tmp_bytes = 0;
+    RSK_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_sizes, d_outoff, (int) npairs + 1, ctx->stream));
+    void *d_tmp = nullptr;
+    if ((rc = dalloc(&d_tmp, tmp_bytes)) != RSK_OK) return rc;
+    RSK_HIP(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_sizes, d_outoff, (int) npairs + 1, ctx->stream));
+    hipLaunchKernelGGL(k_path_pack, dim3((unsigned) ((npairs + 3) / 4)), dim3(256), 0, ctx->stream, d_ident, d_plen, d_pstart, d_paths, d_outoff,
+                       (uint32_t) npairs, d_packed);
+    RSK_HIP(hipGetLastError());
+    std::vector<float> h_score(npairs), h_lddt(npairs);
+    std::vector<uint32_t> h_loa(npairs), h_lob(npairs), h_plen(npairs), h_counts(3 * npairs);
+    std::vector<uint64_t> h_outoff(npairs + 1);
+    RSK_HIP(hipMemcpyAsync(h_score.data(), d_score, npairs * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RSK_HIP(hipMemcpyAsync(h_lddt.data(), d_lddt, npairs * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RSK_HIP(hipMemcpyAsync(h_loa.data(), d_loa, npairs * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RSK_HIP(hipMemcpyAsync(h_lob.data(), d_lob, npairs * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RSK_HIP(hipMemcpyAsync(h_plen.data(), d_plen, npairs * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RSK_HIP(hipMemcpyAsync(h_counts.data(), d_counts, npairs * 12, hipMemcpyDeviceToHost, ctx->stream));
+    RSK_HIP(hipMemcpyAsync(h_outoff.data(), d_outoff, (npairs + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    RSK_HIP(hipStreamSynchronize(ctx->stream));
+    if (h_outoff[npairs]) {
+        RSK_HIP(hipMemcpyAsync(paths, d_packed, h_outoff[npairs], hipMemcpyDeviceToHost, ctx->stream));
+        RSK_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    rsk_parallel_for(npairs, 16384, [&](size_t p_lo, size_t p_hi) {
+        for (size_t p = p_lo; p < p_hi; ++p) {
+            rsk_aln &o = out[p];
+            const uint32_t LA = dba->len[ia[p]], LB = dbb->len[ib[p]];
+            o.score = h_score[p];
+            o.lo_a = h_loa[p]; o.lo_b = h_lob[p];
+            o.path_len = h_plen[p];
+            o.hi_a = o.hi_b = o.ids = o.gaps = RSK_NO_POS;
+            o.lddt = o.pvalue = o.evalue = o.qual = FLT_MAX;
+            o.ts = -FLT_MAX;
+            o.path_off = h_outoff[p];
+            if (o.path_len == 0) continue;
+            // PostAlignMKF sets Hi from the path counts before CalcEvalue (dssaligner.cpp:1425-1428): also below MinFwdScore
+            uint32_t nM = 0, nD = 0, nI = 0;
+            if (!(o.score < min_fwd_score)) { nM = h_counts[3 * p]; nD = h_counts[3 * p + 1]; nI = h_counts[3 * p + 2]; }
+            else
+                for (const char *c = paths + o.path_off; *c; ++c) { nM += *c == 'M'; nD += *c == 'D'; nI += *c == 'I'; }
+            o.hi_a = o.lo_a + nM + nD - 1;
+            o.hi_b = o.lo_b + nM + nI - 1;
+            if (o.score < min_fwd_score) continue;                         // CalcEvalue dssaligner.cpp:861
+            o.ids = nM;
+            o.gaps = nD + nI;
+            const float sra = dba->h_selfrev[ia[p]], srb = dbb->h_selfrev[ib[p]];
+            float rev = 0;
+            if (sra != FLT_MAX && srb != FLT_MAX) rev = (sra + srb) / 2;
+            const float L = float(LA + LB) / 2;
+            const float dpw = 1.7f, lddtw = 0.13f, ladd = 250.0f, revtsw = 2.0f;
+            float ts = lddtw * h_lddt[p];
+            ts += (dpw * o.score - revtsw * rev) / (L + ladd);
+            o.lddt = h_lddt[p];
+            o.ts = ts;
+            const double pv = swf_pvalue(ts);
+            o.pvalue = (float) pv;
+            o.qual = (float) swf_qual(ts);
+            o.evalue = (float) (pv * 8340.0);
+        }
+    });
+    return RSK_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // D1: SWFastGapless swgapless.cpp:46-97 on the SetSMx_NoRev matrix (dead code in the reference; pair-list
 // form).  One workgroup per pair, one thread per diagonal: S(i,j) is summed in feature order from the

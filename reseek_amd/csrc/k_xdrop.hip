@@ -72,6 +72,10 @@ struct xd_args {
     const uint64_t *path_off;
     uint32_t *path_start;            // offset of the first path character inside the slot
     uint32_t *path_len;
+    // rsk_mkf_align_pairs: the starts come from k_mkf_start on the device, so the scratch is laid out per PAIR (sized for
+    // the worst split) and the two extensions of a pair divide it by the start they find there
+    int per_pair;                    // row_off / tb_off / path_off are indexed by request; the backward extension follows the forward one
+    const uint8_t *valid;            // per request (optional): 0 = no extension wanted
 };
 
 // One extension = XDropFwd(Mem, X, Open, Ext, Sub, LoA, aLA, LoB, aLB): thread e = 2 * request + direction.
@@ -86,13 +90,24 @@ __global__ __launch_bounds__(256) void k_xdrop(xd_args a)
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= 2 * a.nreq) return;
     const uint32_t req = e >> 1, dir = e & 1;
+    if (a.valid && !a.valid[req]) { a.path_start[e] = 0; a.path_len[e] = 0; a.score[e] = 0.0f; return; }
     const uint32_t A = a.ia[req], B = a.ib[req];
     const uint32_t LoA = a.lo_a[req], LoB = a.lo_b[req];
     const uint32_t LA = dir ? LoA : a.a_len[A] - LoA, LB = dir ? LoB : a.b_len[B] - LoB;      // extents of this extension
+    uint64_t row_o, tb_o, path_o;
+    if (a.per_pair) {
+        row_o = a.row_off[req]; tb_o = a.tb_off[req]; path_o = a.path_off[req];
+        if (dir) {                                                                              // behind the forward extension's share
+            const uint64_t FA = a.a_len[A] - LoA, FB = a.b_len[B] - LoB;
+            row_o += 2 * (FB + 9);
+            tb_o += ((FA + 9) * (FB + 9) + 15) & ~15ull;
+            path_o += FA + FB + 2;
+        }
+    } else { row_o = a.row_off[e]; tb_o = a.tb_off[e]; path_o = a.path_off[e]; }
     const uint16_t *RA = a.a_ra + (size_t) a.a_off[A] * 8, *CB = a.b_cb + (size_t) a.b_off[B] * 8;
     const char *tabb = (const char *) tab;
     const uint32_t toffb[8] = { 0 * 4, 400 * 4, 656 * 4, 912 * 4, 1168 * 4, 1424 * 4, 1680 * 4, 1936 * 4 };
-    char *slot = a.paths + a.path_off[e];
+    char *slot = a.paths + path_o;
     const uint32_t cap = LA + LB + 2;
     a.path_start[e] = 0;
     a.path_len[e] = 0;
@@ -126,8 +141,8 @@ __global__ __launch_bounds__(256) void k_xdrop(xd_args a)
     // Row state: the reference's Mrow[] / Drow[] interleaved as MD[j] = {Mrow[j], Drow[j]}, so a cell is ONE 8-byte load
     // and ONE 8-byte store (the kernel is bound by the rate of its scattered memory transactions).  The row extensions
     // below write single components of other columns; when they hit the current column j they act on the pending values.
-    float2 *MD = (float2 *) (a.rows + a.row_off[e]) + 1;        // MD[-1] is valid
-    uint8_t *TB = a.tb + a.tb_off[e];
+    float2 *MD = (float2 *) (a.rows + row_o) + 1;               // MD[-1] is valid
+    uint8_t *TB = a.tb + tb_o;
     const uint32_t Cols = LB + 1 + 8;                            // XDPMem::Alloc(LA + 1, LB + 1)
     MD[-1].x = XD_MINUS_INF;
     MD[0].y = XD_MINUS_INF;
@@ -408,7 +423,7 @@ extern "C" int rsk_xdrop_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
         RSK_HIP(hipMemcpyAsync(d_pathoff, path_off.data(), 2 * m * 8, hipMemcpyHostToDevice, ctx->stream));
         RSK_HIP(hipMemsetAsync(d_tb, 0, to, ctx->stream));          // unwritten trace cells read as 0 (XDPMem zeroes its matrix)
         RSK_HIP(hipMemsetAsync(d_rows, 0, ro * 4, ctx->stream));    // as XDPMem::Alloc leaves its rows
-        xd_args a;
+        xd_args a = {};
         a.a_ra = dba->d_prof_ra; a.b_cb = dbb->d_prof_cb;
         a.a_off = dba->d_off; a.b_off = dbb->d_off; a.a_len = dba->d_len; a.b_len = dbb->d_len;
         a.ia = d_ia; a.ib = d_ib; a.lo_a = d_la; a.lo_b = d_lb;
@@ -454,6 +469,269 @@ extern "C" int rsk_xdrop_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
                     to / 1073741824.0, ms(t_a, t_b), ms(t_b, t_c), ms(t_c, t_d), ms(t_d, now()));
         poff += po;
         r0 = r1;
+    }
+    return RSK_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// rsk_mkf_align_pairs: everything of the long-chain path after the chaining of the seed HSPs in ONE device batch
+//   PostAlignMKF dssaligner.cpp:1395-1430 (GetMegaHSPScore :488 of every chained HSP, the MinMegaHSPScore gate, best HSP),
+//   XDropHSP xdrophsp.cpp:42-117 (best 8-mer of that HSP = start, XDropFwd + XDropBwd, TotalScore < 10 => no alignment),
+//   MergeFwdBwd mergefwdback.cpp:6, CalcEvalue dssaligner.cpp:852 (LDDT, test statistic, E-value).
+// Only the chaining (Chainer::Chain: libc qsort on a comparator that is no total order) stays on the host.
+// ---------------------------------------------------------------------------------------------
+struct mkfa_args {
+    const uint16_t *a_ra, *b_cb;
+    const uint32_t *a_off, *b_off, *a_len, *b_len;
+    const uint32_t *ia, *ib;
+    const uint32_t *hsp_first;       // [npairs + 1]
+    const int32_t *hsp_lo_a, *hsp_lo_b, *hsp_len;
+    uint32_t npairs;
+    float min_mega;
+    uint8_t *valid;                  // 1 = extensions wanted, 0 = no alignment, 2 = start outside 1..L-1 (host decides)
+    uint32_t *lo_a, *lo_b;           // start of the gapped extensions
+};
+
+// one thread per pair; every sum in the reference's order
+__global__ __launch_bounds__(256) void k_mkf_start(mkfa_args a)
+{
+    __shared__ float tab[XD_TABLE_FLOATS];
+    for (int i = threadIdx.x; i < XD_TABLE_FLOATS; i += blockDim.x) tab[i] = c_xd_tables.t[i];
+    __syncthreads();
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= a.npairs) return;
+    const uint32_t A = a.ia[p], B = a.ib[p];
+    const uint16_t *RA = a.a_ra + (size_t) a.a_off[A] * 8, *CB = a.b_cb + (size_t) a.b_off[B] * 8;
+    const char *tabb = (const char *) tab;
+    const uint32_t toffb[8] = { 0 * 4, 400 * 4, 656 * 4, 912 * 4, 1168 * 4, 1424 * 4, 1680 * 4, 1936 * 4 };
+    const uint32_t h0 = a.hsp_first[p], h1 = a.hsp_first[p + 1];
+    a.valid[p] = 0; a.lo_a[p] = 0; a.lo_b[p] = 0;
+    if (h1 == h0) return;
+    float MegaTotal = 0, BestMega = 0;
+    uint32_t BestIdx = h0;
+    for (uint32_t h = h0; h < h1; ++h) {
+        // GetMegaHSPScore dssaligner.cpp:488: Total += M_f[a][b] for f = 0..7 (outer), k = 0..Len-1 (inner)
+        const uint32_t Li = (uint32_t) a.hsp_lo_a[h], Lj = (uint32_t) a.hsp_lo_b[h], Len = (uint32_t) a.hsp_len[h];
+        float Total = 0;
+        for (int f = 0; f < 8; ++f)
+            for (uint32_t k = 0; k < Len; ++k)
+                Total += *(const float *) (tabb + toffb[f] + RA[(size_t) (Li + k) * 8 + f] + CB[(size_t) (Lj + k) * 8 + f]);
+        if (Total > BestMega) { BestMega = Total; BestIdx = h; }
+        MegaTotal += Total;
+    }
+    if (MegaTotal < a.min_mega) return;
+    // XDropHSP xdrophsp.cpp:42-95: start = the highest-scoring 8-mer of the best HSP (first one on ties), else its middle
+    const uint32_t Li = (uint32_t) a.hsp_lo_a[BestIdx], Lj = (uint32_t) a.hsp_lo_b[BestIdx], Len = (uint32_t) a.hsp_len[BestIdx];
+    uint32_t LoA = Li + Len / 2, LoB = Lj + Len / 2;
+    auto sub = [&](uint32_t c) {
+        float Total = 0.0f;
+#pragma unroll
+        for (int f = 0; f < 8; ++f) Total += *(const float *) (tabb + toffb[f] + RA[(size_t) (Li + c) * 8 + f] + CB[(size_t) (Lj + c) * 8 + f]);
+        return Total;
+    };
+    if (Len >= 8) {
+        float w0 = sub(0), w1 = sub(1), w2 = sub(2), w3 = sub(3), w4 = sub(4), w5 = sub(5), w6 = sub(6), w7;
+        float BestMer = 0;
+        for (uint32_t ms = 0; ms + 8 <= Len; ++ms) {
+            w7 = sub(ms + 7);
+            float Mer = 0;
+            Mer += w0; Mer += w1; Mer += w2; Mer += w3; Mer += w4; Mer += w5; Mer += w6; Mer += w7;
+            if (Mer > BestMer) { BestMer = Mer; LoA = Li + ms; LoB = Lj + ms; }
+            w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = w5; w5 = w6; w6 = w7;
+        }
+    }
+    if (min(LoA, LoB) < 4) { LoA += 4; LoB += 4; }
+    a.lo_a[p] = LoA; a.lo_b[p] = LoB;
+    a.valid[p] = (LoA >= 1 && LoB >= 1 && LoA < a.a_len[A] && LoB < a.b_len[B]) ? 1 : 2;
+}
+
+struct mkfm_args {
+    const uint32_t *a_len, *b_len, *ia, *ib;
+    const uint8_t *valid;
+    const uint32_t *req_lo_a, *req_lo_b;
+    const float *xscore;             // [2 * npairs]
+    const char *xpaths; const uint64_t *xpath_off; const uint32_t *xpath_start, *xpath_len;
+    uint32_t npairs;
+    char *mpaths; const uint64_t *mpath_off;     // merged paths: slot of LA + LB + 5 per pair
+    float *score; uint32_t *lo_a, *lo_b; uint64_t *pstart; uint32_t *plen;
+};
+
+// MergeFwdBwd mergefwdback.cpp:6-26 + the TotalScore gate of XDropHSP (xdrophsp.cpp:111-115); one wave per pair
+__global__ __launch_bounds__(256) void k_mkf_merge(mkfm_args a)
+{
+    const uint32_t p = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (p >= a.npairs) return;
+    const int lane = threadIdx.x & 63;
+    const uint64_t mo = a.mpath_off[p];
+    bool ok = a.valid[p] == 1;
+    float total = 0;
+    if (ok) {
+        total = a.xscore[2 * p] + a.xscore[2 * p + 1];       // ScoreFwd + ScoreBwd
+        ok = !(total < 10.0f);
+    }
+    if (!ok) {
+        if (lane == 0) { a.score[p] = 0.0f; a.lo_a[p] = RSK_NO_POS; a.lo_b[p] = RSK_NO_POS; a.pstart[p] = mo; a.plen[p] = 0; a.mpaths[mo] = 0; }
+        return;
+    }
+    const uint32_t A = a.ia[p], B = a.ib[p];
+    const uint32_t LoA = a.req_lo_a[p], LoB = a.req_lo_b[p];
+    const uint64_t FA = a.a_len[A] - LoA, FB = a.b_len[B] - LoB;
+    const uint64_t fo = a.xpath_off[p], bo = fo + FA + FB + 2;                  // per-pair slot: forward share, then backward share
+    const char *fp = a.xpaths + fo + a.xpath_start[2 * p], *bp = a.xpaths + bo + a.xpath_start[2 * p + 1];
+    const uint32_t fl = a.xpath_len[2 * p], bl = a.xpath_len[2 * p + 1];
+    uint32_t nMD = 0, nMI = 0;                                                   // columns of the backward path that consume A / B
+    for (uint32_t c0 = 0; c0 < bl; c0 += 64) {
+        const uint32_t c = c0 + lane;
+        const char ch = c < bl ? bp[c] : 0;
+        nMD += (uint32_t) __popcll(__ballot(ch == 'M' || ch == 'D'));
+        nMI += (uint32_t) __popcll(__ballot(ch == 'M' || ch == 'I'));
+        if (c < bl) a.mpaths[mo + c] = ch;
+    }
+    for (uint32_t c = lane; c < fl; c += 64) a.mpaths[mo + bl + c] = fp[c];
+    if (lane == 0) {
+        a.mpaths[mo + bl + fl] = 0;
+        a.score[p] = total;
+        a.lo_a[p] = LoA - nMD;                                                   // BwdHiA + 1 - (M + D), BwdHiA = LoA - 1 (= FwdLoA if the backward path is empty)
+        a.lo_b[p] = LoB - nMI;
+        a.pstart[p] = mo;
+        a.plen[p] = bl + fl;
+    }
+}
+
+extern "C" int rsk_mkf_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *dbb, const uint32_t *ia, const uint32_t *ib, size_t npairs,
+                                   const uint32_t *hsp_first, const int32_t *hsp_lo_a, const int32_t *hsp_lo_b, const int32_t *hsp_len, float x2,
+                                   float gap_open, float gap_ext, float min_mega_score, float min_fwd_score, rsk_aln *out, uint8_t *status,
+                                   char *paths, size_t paths_bytes)
+{
+    if (!ctx || !dba || !dbb || (npairs && (!ia || !ib || !hsp_first || !out || !status || !paths))) { rsk_set_error("rsk_mkf_align_pairs: NULL argument"); return RSK_E_INVALID; }
+    if (!dba->d_prof_ra || !dbb->d_prof_cb || !dba->d_x || !dbb->d_x) { rsk_set_error("rsk_mkf_align_pairs: chain sets need profiles and coordinates"); return RSK_E_INVALID; }
+    if (gap_open > 0 || gap_ext > 0) { rsk_set_error("rsk_mkf_align_pairs: gap penalties must be <= 0"); return RSK_E_INVALID; }
+    if (npairs == 0) return RSK_OK;
+    if (npairs > 0x3FFFFFFFull) { rsk_set_error("rsk_mkf_align_pairs: too many pairs in one call"); return RSK_E_RANGE; }
+    const size_t nh = hsp_first[npairs];
+    if (nh && (!hsp_lo_a || !hsp_lo_b || !hsp_len)) { rsk_set_error("rsk_mkf_align_pairs: NULL HSP arrays"); return RSK_E_INVALID; }
+    size_t need = 0;
+    for (size_t p = 0; p < npairs; ++p) {
+        if (ia[p] >= dba->n || ib[p] >= dbb->n || hsp_first[p + 1] < hsp_first[p]) { rsk_set_error("rsk_mkf_align_pairs: pair %zu out of range", p); return RSK_E_INVALID; }
+        const uint32_t LA = dba->len[ia[p]], LB = dbb->len[ib[p]];
+        for (uint32_t h = hsp_first[p]; h < hsp_first[p + 1]; ++h)
+            if (hsp_lo_a[h] < 0 || hsp_lo_b[h] < 0 || hsp_len[h] < 1 || (uint64_t) hsp_lo_a[h] + hsp_len[h] > LA || (uint64_t) hsp_lo_b[h] + hsp_len[h] > LB) {
+                rsk_set_error("rsk_mkf_align_pairs: HSP %u of pair %zu outside its chains", h, p);
+                return RSK_E_INVALID;
+            }
+        need += (size_t) LA + LB + 1;
+    }
+    if (paths_bytes < need) { rsk_set_error("rsk_mkf_align_pairs: paths buffer too small (%zu < %zu)", paths_bytes, need); return RSK_E_INVALID; }
+    RSK_HIP(hipSetDevice(ctx->device));
+    int rc = xd_upload_tables(ctx);
+    if (rc != RSK_OK) return rc;
+    const bool trace = getenv("RSK_TRACE") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    struct ws_t {
+        rsk_ctx *ctx;
+        std::vector<void *> all;
+        ~ws_t() { for (void *p : all) rsk_pool_free(ctx, p); }
+    } ws{ ctx, {} };
+    auto dalloc = [&](void **p, size_t bytes) -> int {
+        int r = rsk_pool_alloc(ctx, p, std::max<size_t>(bytes, 16));
+        if (r != RSK_OK) return r;
+        ws.all.push_back(*p);
+        return RSK_OK;
+    };
+    // sub-batches bounded by the trace scratch: per pair (LA + 18)(LB + 18) bytes cover any split into the two extensions
+    const uint64_t TB_BUDGET = 24ull << 30;
+    size_t done = 0, poff = 0;
+    while (done < npairs) {
+        const auto t0 = now();
+        std::vector<uint64_t> row_off, tb_off, path_off, mp_off;
+        uint64_t ro = 0, to = 0, po = 0, mo = 0;
+        size_t p1 = done;
+        while (p1 < npairs) {
+            const uint64_t LA = dba->len[ia[p1]], LB = dbb->len[ib[p1]];
+            const uint64_t t_need = (LA + 18) * (LB + 18) + 32;
+            if (p1 > done && to + t_need > TB_BUDGET) break;
+            row_off.push_back(ro); ro += 2 * (LB + 18);
+            tb_off.push_back(to); to += (t_need + 15) & ~15ull;
+            path_off.push_back(po); po += LA + LB + 4;
+            mp_off.push_back(mo); mo += LA + LB + 5;
+            ++p1;
+        }
+        const size_t m = p1 - done;
+        const uint32_t h_lo = hsp_first[done], h_hi = hsp_first[p1];
+        std::vector<uint32_t> first(m + 1);
+        for (size_t k = 0; k <= m; ++k) first[k] = hsp_first[done + k] - h_lo;
+        uint32_t *d_ia, *d_ib, *d_first, *d_loa, *d_lob, *d_pstart, *d_plen, *d_mloa, *d_mlob, *d_mplen;
+        int32_t *d_hla, *d_hlb, *d_hlen;
+        uint8_t *d_valid, *d_tb;
+        uint64_t *d_rowoff, *d_tboff, *d_pathoff, *d_mpoff, *d_mpstart;
+        float *d_rows, *d_xscore, *d_mscore;
+        char *d_paths, *d_mpaths;
+        const size_t nhb = std::max<size_t>(h_hi - h_lo, 1);
+        if ((rc = dalloc((void **) &d_ia, m * 4)) || (rc = dalloc((void **) &d_ib, m * 4)) || (rc = dalloc((void **) &d_first, (m + 1) * 4)) ||
+            (rc = dalloc((void **) &d_hla, nhb * 4)) || (rc = dalloc((void **) &d_hlb, nhb * 4)) || (rc = dalloc((void **) &d_hlen, nhb * 4)) ||
+            (rc = dalloc((void **) &d_valid, m)) || (rc = dalloc((void **) &d_loa, m * 4)) || (rc = dalloc((void **) &d_lob, m * 4)) ||
+            (rc = dalloc((void **) &d_pstart, 2 * m * 4)) || (rc = dalloc((void **) &d_plen, 2 * m * 4)) || (rc = dalloc((void **) &d_xscore, 2 * m * 4)) ||
+            (rc = dalloc((void **) &d_rowoff, m * 8)) || (rc = dalloc((void **) &d_tboff, m * 8)) || (rc = dalloc((void **) &d_pathoff, m * 8)) ||
+            (rc = dalloc((void **) &d_mpoff, m * 8)) || (rc = dalloc((void **) &d_rows, ro * 4)) || (rc = dalloc((void **) &d_tb, to)) ||
+            (rc = dalloc((void **) &d_paths, po)) || (rc = dalloc((void **) &d_mpaths, mo)) || (rc = dalloc((void **) &d_mscore, m * 4)) ||
+            (rc = dalloc((void **) &d_mloa, m * 4)) || (rc = dalloc((void **) &d_mlob, m * 4)) || (rc = dalloc((void **) &d_mpstart, m * 8)) ||
+            (rc = dalloc((void **) &d_mplen, m * 4)))
+            return rc;
+        RSK_HIP(hipMemcpyAsync(d_ia, ia + done, m * 4, hipMemcpyHostToDevice, ctx->stream));
+        RSK_HIP(hipMemcpyAsync(d_ib, ib + done, m * 4, hipMemcpyHostToDevice, ctx->stream));
+        RSK_HIP(hipMemcpyAsync(d_first, first.data(), (m + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+        if (h_hi > h_lo) {
+            RSK_HIP(hipMemcpyAsync(d_hla, hsp_lo_a + h_lo, (size_t) (h_hi - h_lo) * 4, hipMemcpyHostToDevice, ctx->stream));
+            RSK_HIP(hipMemcpyAsync(d_hlb, hsp_lo_b + h_lo, (size_t) (h_hi - h_lo) * 4, hipMemcpyHostToDevice, ctx->stream));
+            RSK_HIP(hipMemcpyAsync(d_hlen, hsp_len + h_lo, (size_t) (h_hi - h_lo) * 4, hipMemcpyHostToDevice, ctx->stream));
+        }
+        RSK_HIP(hipMemcpyAsync(d_rowoff, row_off.data(), m * 8, hipMemcpyHostToDevice, ctx->stream));
+        RSK_HIP(hipMemcpyAsync(d_tboff, tb_off.data(), m * 8, hipMemcpyHostToDevice, ctx->stream));
+        RSK_HIP(hipMemcpyAsync(d_pathoff, path_off.data(), m * 8, hipMemcpyHostToDevice, ctx->stream));
+        RSK_HIP(hipMemcpyAsync(d_mpoff, mp_off.data(), m * 8, hipMemcpyHostToDevice, ctx->stream));
+        RSK_HIP(hipMemsetAsync(d_tb, 0, to, ctx->stream));          // unwritten trace cells read as 0 (XDPMem zeroes its matrix)
+        RSK_HIP(hipMemsetAsync(d_rows, 0, ro * 4, ctx->stream));    // as XDPMem::Alloc leaves its rows
+        mkfa_args sa = {};
+        sa.a_ra = dba->d_prof_ra; sa.b_cb = dbb->d_prof_cb; sa.a_off = dba->d_off; sa.b_off = dbb->d_off; sa.a_len = dba->d_len; sa.b_len = dbb->d_len;
+        sa.ia = d_ia; sa.ib = d_ib; sa.hsp_first = d_first; sa.hsp_lo_a = d_hla; sa.hsp_lo_b = d_hlb; sa.hsp_len = d_hlen;
+        sa.npairs = (uint32_t) m; sa.min_mega = min_mega_score; sa.valid = d_valid; sa.lo_a = d_loa; sa.lo_b = d_lob;
+        hipLaunchKernelGGL(k_mkf_start, dim3((unsigned) ((m + 255) / 256)), dim3(256), 0, ctx->stream, sa);
+        xd_args xa = {};
+        xa.a_ra = dba->d_prof_ra; xa.b_cb = dbb->d_prof_cb; xa.a_off = dba->d_off; xa.b_off = dbb->d_off; xa.a_len = dba->d_len; xa.b_len = dbb->d_len;
+        xa.ia = d_ia; xa.ib = d_ib; xa.lo_a = d_loa; xa.lo_b = d_lob; xa.nreq = (uint32_t) m;
+        xa.X = x2; xa.open = gap_open; xa.ext = gap_ext;
+        xa.rows = d_rows; xa.row_off = d_rowoff; xa.tb = d_tb; xa.tb_off = d_tboff;
+        xa.score = d_xscore; xa.paths = d_paths; xa.path_off = d_pathoff; xa.path_start = d_pstart; xa.path_len = d_plen;
+        xa.per_pair = 1; xa.valid = d_valid;
+        RSK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+        hipLaunchKernelGGL(k_xdrop, dim3((unsigned) ((2 * m + 255) / 256)), dim3(256), 0, ctx->stream, xa);
+        RSK_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+        mkfm_args ma = {};
+        ma.a_len = dba->d_len; ma.b_len = dbb->d_len; ma.ia = d_ia; ma.ib = d_ib; ma.valid = d_valid; ma.req_lo_a = d_loa; ma.req_lo_b = d_lob;
+        ma.xscore = d_xscore; ma.xpaths = d_paths; ma.xpath_off = d_pathoff; ma.xpath_start = d_pstart; ma.xpath_len = d_plen;
+        ma.npairs = (uint32_t) m; ma.mpaths = d_mpaths; ma.mpath_off = d_mpoff;
+        ma.score = d_mscore; ma.lo_a = d_mloa; ma.lo_b = d_mlob; ma.pstart = d_mpstart; ma.plen = d_mplen;
+        hipLaunchKernelGGL(k_mkf_merge, dim3((unsigned) ((m + 3) / 4)), dim3(256), 0, ctx->stream, ma);
+        RSK_HIP(hipGetLastError());
+        RSK_HIP(hipMemcpyAsync(status + done, d_valid, m, hipMemcpyDeviceToHost, ctx->stream));
+        const auto t1 = now();
+        if (trace) RSK_HIP(hipStreamSynchronize(ctx->stream));
+        const auto t2 = now();
+        if ((rc = rsk_paths_stats_pack(ctx, dba, dbb, m, ia + done, ib + done, d_ia, d_ib, d_mpaths, d_mpstart, d_mplen, d_mloa, d_mlob, d_mscore,
+                                       min_fwd_score, out + done, paths + poff, paths_bytes - poff)) != RSK_OK)
+            return rc;
+        // path offsets of this sub-batch are relative to its part of the caller's buffer
+        size_t used = 0;
+        for (size_t k = 0; k < m; ++k) { used = std::max<size_t>(used, (size_t) out[done + k].path_off + out[done + k].path_len + 1); out[done + k].path_off += poff; }
+        poff += used;
+        if (trace)
+            fprintf(stderr, "[rsk_mkf_align_pairs] %zu pairs, %u HSPs: trace scratch %.2f GB; setup %.1f ms, start + X-drop + merge %.1f ms, statistics + d2h %.1f ms\n",
+                    m, h_hi - h_lo, to / 1073741824.0, ms(t0, t1), ms(t1, t2), ms(t2, now()));
+        for (void *q : ws.all) rsk_pool_free(ctx, q);                // the next sub-batch reuses the blocks
+        ws.all.clear();
+        done = p1;
     }
     return RSK_OK;
 }

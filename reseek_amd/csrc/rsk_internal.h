@@ -120,6 +120,12 @@ int rsk_build_rings(rsk_db *db);
 int rsk_build_mudex(rsk_db *db, int mode);
 int rsk_build_len_perm(rsk_db *db);
 
+// k_sw_float.hip: CalcEvalue + path packing for alignments whose paths already sit on the device (see the definition)
+int rsk_paths_stats_pack(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *dbb, size_t npairs, const uint32_t *ia, const uint32_t *ib,
+                         const uint32_t *d_ia, const uint32_t *d_ib, const char *d_paths, const uint64_t *d_pstart, const uint32_t *d_plen,
+                         const uint32_t *d_loa, const uint32_t *d_lob, const float *d_score, float min_fwd_score, rsk_aln *out, char *paths,
+                         size_t paths_bytes);
+
 // host worker threads: min(hardware threads, cgroup CPU quota, cap) -- defined in host/dbsearcher.cpp
 namespace reseek_amd { unsigned HostThreads(unsigned cap); }
 

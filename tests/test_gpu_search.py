@@ -275,3 +275,17 @@ def test_streamed_db_batches(ctx, tmpdir, monkeypatch):
     monkeypatch.delenv("RSK_STREAM_CHAINS")
     ctx.search(p, out2, "sensitive", db=p, columns=COLS)
     assert sorted(open(out1).read().splitlines()) == sorted(open(out2).read().splitlines())
+
+
+def test_long_chain_device_batch_equals_host_path(ctx, tmpdir, monkeypatch):
+    """The long-chain pairs go through ONE device batch after the chaining (rsk_mkf_align_pairs: mega-HSP scores, 8-mer
+    start, both X-drop extensions, MergeFwdBwd, LDDT / E-value); RSK_MKF_HOST=1 runs the same pairs one at a time on the
+    host threads (host X-drop mirror, pinned to the reference's -test_xdrop vectors).  Both must give the golden tables;
+    RSK_MKF_CAP=2 truncates the device seed lists so that MuKmerFilter::Align re-seeds on the host."""
+    for host in ("0", "1"):
+        monkeypatch.setenv("RSK_MKF_HOST", host)
+        run_bca(ctx, tmpdir, "palms.bca", "sensitive", COLS, "hits_palms_sensitive.tsv.gz")
+        run_bca(ctx, tmpdir, "edge.bca", "sensitive", COLS, "hits_edge_sensitive.tsv.gz")
+    monkeypatch.setenv("RSK_MKF_HOST", "0")
+    monkeypatch.setenv("RSK_MKF_CAP", "2")
+    run_bca(ctx, tmpdir, "palms.bca", "sensitive", COLS, "hits_palms_sensitive.tsv.gz")
