@@ -78,7 +78,8 @@ uint64_t rsk_db_hbm_bytes(const rsk_db *db);
  * device memory, ldo >= nt).  With self_triangle != 0 (q == t, all-vs-all) only pairs the
  * reference's RunSelf enumerates (it >= iq, runself.cpp:72-99) are guaranteed to be written;
  * other cells may or may not be.  Asynchronous on the context stream.
- * Chains longer than 16383 residues return RSK_E_RANGE. */
+ * Scores are exact up to 65535 = 4 * 16383: if BOTH sets hold a chain longer than 16383 residues the call returns RSK_E_RANGE
+ * (a pair of such chains could saturate); queries longer than 1022 take a per-pair kernel inside the same call. */
 int rsk_mu_gapless_matrix_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int self_triangle,
                               uint16_t *d_scores, size_t ldo);
 /* Pair-list form with the position of the first strict maximum in row-major order (Besti/Bestj of

@@ -391,15 +391,18 @@ void DBSearcher::UploadToGpu()
 // records -> Reject -> TSV lines).  RunPairs runs the GPU stage of batch k + 1 while batch k is replayed.
 // Page-locked host buffers for the packed paths of a batch (hundreds of MB; the device-to-host copy into pageable
 // memory was ~25 % of the GPU stage): two or three buffers are recycled between the batches of a run.
-// A secondary context of this device.  RSK_OWN_STREAMS=1 (experimental, off by default) gives it a non-blocking
-// stream of its own so that its kernels can run next to the primary context's; otherwise it launches on the default stream.
+// A secondary context of this device, with a non-blocking stream of its own: its kernels run next to the primary
+// context's (the long-chain job's X-drop tail under the alignment job's kernels, batch k + 1's uploads under batch k).
+// Audited for this (r02): every entry point queues its copies / memsets / kernels on the context's stream and the host
+// callers call rsk_ctx_sync before their own synchronous copies; chain sets are uploaded with synchronous copies before
+// any context uses them.  RSK_OWN_STREAMS=0 puts every context back on the default stream.
 struct SecondaryCtx {
     rsk_ctx *c = nullptr;
     hipStream_t st = nullptr;
     void Create(int device)
     {
         check(rsk_ctx_create(device, &c), "rsk_ctx_create");
-        if (getenv("RSK_OWN_STREAMS") && atoi(getenv("RSK_OWN_STREAMS")) != 0) {
+        if (!(getenv("RSK_OWN_STREAMS") && atoi(getenv("RSK_OWN_STREAMS")) == 0)) {
             if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { st = nullptr; return; }
             rsk_ctx_set_stream(c, (void *) st);
         }
@@ -804,6 +807,7 @@ static void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOff
             check(rsk_mu_filter_dev(ctx, FilterQ, FilterT, Tri ? 1 : 0, P.m_ParaMuGapOpen, P.m_ParaMuGapExt, P.m_Omega, P.m_OmegaFwd, D.fwd, ldo,
                                     D.pq, D.pt, nullptr, nullptr, cap, D.n),
                   "rsk_mu_filter_dev");
+            check(rsk_ctx_sync(ctx), "rsk_ctx_sync");                  // the filter is queued on the context's stream; the copies below are not
             hipok(hipMemcpy(&ns, D.n, 4, hipMemcpyDeviceToHost), "copy n");
             if (ns <= cap) break;
             (void) hipFree(D.pq); (void) hipFree(D.pt);
@@ -1153,6 +1157,7 @@ void DSSAligner::AlignPairOnGpu()
         const int rc = rsk_mu_filter_dev(m_Ctx, a, b, 0, m_Params->m_ParaMuGapOpen, m_Params->m_ParaMuGapExt, m_Params->m_Omega, m_Params->m_OmegaFwd,
                                          d_fwd, 1, d_p, d_p + 1, nullptr, nullptr, 1, d_p + 2);
         uint32_t n = 0;
+        if (rc == RSK_OK) (void) rsk_ctx_sync(m_Ctx);
         const hipError_t ce = rc == RSK_OK ? hipMemcpy(&n, d_p + 2, 4, hipMemcpyDeviceToHost) : hipSuccess;
         (void) hipFree(d_fwd); (void) hipFree(d_p);
         check(rc, "rsk_mu_filter_dev");

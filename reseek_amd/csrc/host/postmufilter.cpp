@@ -93,6 +93,7 @@ void MuPreFilterScan(rsk_ctx *ctx, const std::vector<uint32_t> &qlen, const std:
         hipok(hipMalloc((void **) &d_n, 4), "hipMalloc");
         const int rc = rsk_mu_prefilter_dev(ctx, qdb, tdb, idx_mode, d_q, d_t, d_s, cap, d_n);
         uint32_t n = 0;
+        if (rc == RSK_OK) check(rsk_ctx_sync(ctx), "rsk_ctx_sync");
         if (rc == RSK_OK) hipok(hipMemcpy(&n, d_n, 4, hipMemcpyDeviceToHost), "copy n");
         if (rc == RSK_OK && n <= cap) {
             hq.resize(n); ht.resize(n); hs.resize(n);

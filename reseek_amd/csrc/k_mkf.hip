@@ -167,9 +167,9 @@ extern "C" int rsk_mkf_seed_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t
     int rc = rsk_upload_mu_tables(ctx);
     if (rc != RSK_OK) return rc;
     // distinct queries -> table slots.  One 373 KB table per distinct query; the pairs are cut into consecutive chunks of
-    // at most `budget` distinct queries (3 GB of tables) that reuse one table block, so a call whose query side is a whole
-    // database (-db mode with a long query: every DB chain is a distinct iq) needs no more memory than a small one.
-    const size_t budget = getenv("RSK_MKF_MAX_TABLES") ? (size_t) std::max(1, atoi(getenv("RSK_MKF_MAX_TABLES"))) : 8192;
+    // at most `budget` distinct queries (24 GB of tables) that reuse one table block, so a call whose query side is a whole
+    // database (-db mode with a long query: every DB chain is a distinct iq) is bounded whatever the database size.
+    const size_t budget = getenv("RSK_MKF_MAX_TABLES") ? (size_t) std::max(1, atoi(getenv("RSK_MKF_MAX_TABLES"))) : 65536;
     struct chunk_t { size_t p0, p1, q0, q1; };
     std::vector<chunk_t> chunks;
     std::vector<uint32_t> slot_of(q->n, 0xFFFFFFFFu), qlist, qslot(npairs);

@@ -397,11 +397,12 @@ static int launch_ring_class(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, con
 {
     if (nwork == 0) return RSK_OK;
     constexpr size_t lds = ring_lds_bytes<D, NW>();
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<int> attr_set[64];      // one per template instance and device
+    const int arc = rsk_once_per_device(attr_set, ctx->device, [&]() -> int {
         RSK_HIP(hipFuncSetAttribute((const void *) k_gapless_ring<D, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-        attr_set = true;
-    }
+        return RSK_OK;
+    });
+    if (arc != RSK_OK) return arc;
     hipLaunchKernelGGL((k_gapless_ring<D, NW>), dim3(nwork), dim3(64 * NW), lds, ctx->stream, q->d_ring_tab, d_work,
                        q->d_ring_letters, q->d_ring_laneq, q->d_ring_qid, t->d_mu, t->d_off, t->d_len, t->n, q->d_ring_perm,
                        self_triangle ? q->d_tri_claim : t->d_nat_claim, tb_size, self_triangle, d_scores, ldo);
@@ -499,6 +500,30 @@ int rsk_launch_gapless_rings(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int
             RSK_HIP(hipMalloc((void **) &qm->d_work, all.size() * sizeof(uint2)));
             RSK_HIP(hipMemcpy(qm->d_work, all.data(), all.size() * sizeof(uint2), hipMemcpyHostToDevice));
         }
+        // queries too long for a ring: (long query, target) pairs of the per-pair kernel, part of the same cache
+        if (qm->d_long_iq) { (void) hipFree(qm->d_long_iq); (void) hipFree(qm->d_long_it); qm->d_long_iq = qm->d_long_it = nullptr; }
+        qm->long_pairs = 0;
+        if (!q->long_q.empty()) {
+            std::vector<uint32_t> iq, it;
+            uint32_t pos = (uint32_t) (q->n - q->long_q.size());      // long chains close the processing order
+            for (uint32_t lqi : q->long_q) {
+                if (self_triangle) {
+                    for (uint32_t p = pos; p < t->n; ++p) {           // symmetric score: stored at [min][max]
+                        const uint32_t tj = q->h_ring_perm[p];
+                        iq.push_back(std::min(lqi, tj)); it.push_back(std::max(lqi, tj));
+                    }
+                } else
+                    for (uint32_t j = 0; j < t->n; ++j) { iq.push_back(lqi); it.push_back(j); }
+                ++pos;
+            }
+            if (!iq.empty()) {
+                RSK_HIP(hipMalloc((void **) &qm->d_long_iq, iq.size() * 4));
+                RSK_HIP(hipMalloc((void **) &qm->d_long_it, it.size() * 4));
+                RSK_HIP(hipMemcpy(qm->d_long_iq, iq.data(), iq.size() * 4, hipMemcpyHostToDevice));
+                RSK_HIP(hipMemcpy(qm->d_long_it, it.data(), it.size() * 4, hipMemcpyHostToDevice));
+                qm->long_pairs = (uint32_t) iq.size();
+            }
+        }
         qm->work_for = t->uid;
         qm->work_tri = self_triangle;
     }
@@ -511,32 +536,11 @@ int rsk_launch_gapless_rings(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int
     rc = launch_ring_class<4, 8>(ctx, q, t, (const uint2 *) q->d_work, q->work_count[0], self_triangle, d_scores, ldo, RING_TB);
     if (rc != RSK_OK) return rc;
     // queries too long for a ring: per-pair kernel over (long q) x targets
-    if (!q->long_q.empty()) {
-        std::vector<uint32_t> iq, it;
-        uint32_t pos = (uint32_t) (q->n - q->long_q.size());      // long chains close the processing order
-        for (uint32_t lqi : q->long_q) {
-            if (self_triangle) {
-                for (uint32_t p = pos; p < t->n; ++p) {           // symmetric score: stored at [min][max]
-                    const uint32_t tj = q->h_ring_perm[p];
-                    iq.push_back(std::min(lqi, tj)); it.push_back(std::max(lqi, tj));
-                }
-            } else
-                for (uint32_t j = 0; j < t->n; ++j) { iq.push_back(lqi); it.push_back(j); }
-            ++pos;
-        }
-        uint32_t *d_iq = nullptr, *d_it = nullptr;
-        RSK_HIP(hipMalloc((void **) &d_iq, iq.size() * 4));
-        RSK_HIP(hipMalloc((void **) &d_it, it.size() * 4));
-        RSK_HIP(hipMemcpyAsync(d_iq, iq.data(), iq.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-        RSK_HIP(hipMemcpyAsync(d_it, it.data(), it.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-        const uint32_t np = (uint32_t) iq.size();
-        hipLaunchKernelGGL(k_gapless_pairs, dim3(np), dim3(1024), 0, ctx->stream, q->d_mu, q->d_off, q->d_len,
-                           t->d_mu, t->d_off, t->d_len, d_iq, d_it, np, (int32_t *) nullptr, (uint32_t *) nullptr,
+    if (q->long_pairs) {                               // list built with the work list (cached per target set + triangle flag)
+        hipLaunchKernelGGL(k_gapless_pairs, dim3(q->long_pairs), dim3(1024), 0, ctx->stream, q->d_mu, q->d_off, q->d_len,
+                           t->d_mu, t->d_off, t->d_len, q->d_long_iq, q->d_long_it, q->long_pairs, (int32_t *) nullptr, (uint32_t *) nullptr,
                            (uint32_t *) nullptr, d_scores, ldo);
         RSK_HIP(hipGetLastError());
-        RSK_HIP(hipStreamSynchronize(ctx->stream));   // host vectors / temp buffers must outlive the copies
-        (void) hipFree(d_iq);
-        (void) hipFree(d_it);
     }
     RSK_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     return RSK_OK;

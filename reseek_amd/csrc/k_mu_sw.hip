@@ -499,11 +499,12 @@ static int run_mu_sw_lists(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, musw_
             const uint32_t gmax = musw_class_lqpad[cls] / MUSW_R;
             const uint32_t waves = musw_class_waves[cls];
             const size_t lds = (size_t) 37 * gmax * 64 + 1312 + 16;
-            static bool attr_set = false;
-            if (!attr_set) {
+            static std::atomic<int> attr_set[64];
+            const int arc = rsk_once_per_device(attr_set, ctx->device, [&]() -> int {
                 RSK_HIP(hipFuncSetAttribute((const void *) k_mu_sw, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
-                attr_set = true;
-            }
+                return RSK_OK;
+            });
+            if (arc != RSK_OK) return arc;
             const int wg_per_cu = std::max(1, std::min<int>(20 / (int) waves, (int) (163840 / lds)));
             hipLaunchKernelGGL(k_mu_sw, dim3(ctx->num_cus * wg_per_cu), dim3(64 * waves), lds, ctx->stream, a, gmax);
         } else {
@@ -877,10 +878,13 @@ extern "C" int rsk_mu_gapless_profb_pairs(rsk_ctx *ctx, const rsk_db *q, const r
     if (npairs == 0) return RSK_OK;
     if (npairs > 0x7FFFFFFFull) { rsk_set_error("rsk_mu_gapless_profb_pairs: too many pairs"); return RSK_E_RANGE; }
     RSK_HIP(hipSetDevice(ctx->device));
-    static bool up[64] = { false };
-    if (!(ctx->device < 64 && up[ctx->device])) {
-        RSK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_mu_f32), rsk_mu_f32, sizeof(rsk_mu_f32)));
-        if (ctx->device < 64) up[ctx->device] = true;
+    {
+        static std::atomic<int> up[64];
+        const int urc = rsk_once_per_device(up, ctx->device, [&]() -> int {
+            RSK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_mu_f32), rsk_mu_f32, sizeof(rsk_mu_f32)));
+            return RSK_OK;
+        });
+        if (urc != RSK_OK) return urc;
     }
     musw_ws ws(ctx);
     uint32_t *d_iq, *d_it;

@@ -37,11 +37,11 @@ static __device__ __constant__ signed char c_mu_s8[36 * 36];   // Mu_S_ij_i8 (mu
 
 static int pf_upload_tables(rsk_ctx *ctx)
 {
-    static bool done[64] = { false };
-    if (ctx->device < 64 && done[ctx->device]) return RSK_OK;
-    RSK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_mu_s8), rsk_mu_s8, sizeof(rsk_mu_s8)));
-    if (ctx->device < 64) done[ctx->device] = true;
-    return RSK_OK;
+    static std::atomic<int> done[64];
+    return rsk_once_per_device(done, ctx->device, [&]() -> int {
+        RSK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_mu_s8), rsk_mu_s8, sizeof(rsk_mu_s8)));
+        return RSK_OK;
+    });
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -455,35 +455,36 @@ int rsk_build_mudex(rsk_db *db, int mode)
     for (uint32_t L : db->len)
         if (L > 65535) { rsk_set_error("k-mer prefilter: query longer than 65535 (uint16 position)"); return RSK_E_RANGE; }
     if (db->d_pf_postings) { (void) hipFree(db->d_pf_postings); db->d_pf_postings = nullptr; db->hbm_bytes -= db->pf_postings * 4; }
-    uint32_t *d_cnt = nullptr, *d_start = nullptr;
-    unsigned long long *d_total = nullptr, total = 0;
-    void *d_tmp = nullptr;
-    auto cleanup = [&]() { (void) hipFree(d_cnt); (void) hipFree(d_start); (void) hipFree(d_total); (void) hipFree(d_tmp); };
+    // temporaries through the context's pool (returned on every exit path); everything on the context's stream
+    rsk_ctx *ctx = db->ctx;
+    rsk_scratch ws(ctx);
+    uint32_t *d_cnt, *d_start;
+    unsigned long long *d_total, total = 0;
+    void *d_tmp;
+    int rc;
     if (!db->d_pf_table) {
         RSK_HIP(hipMalloc((void **) &db->d_pf_table, (size_t) PF_DICT * sizeof(uint2)));
         db->hbm_bytes += (size_t) PF_DICT * sizeof(uint2);
     }
-    RSK_HIP(hipMalloc((void **) &d_cnt, (size_t) PF_DICT * 4));
-    RSK_HIP(hipMalloc((void **) &d_start, (size_t) PF_DICT * 4));
-    RSK_HIP(hipMalloc((void **) &d_total, 8));
-    RSK_HIP(hipMemset(d_cnt, 0, (size_t) PF_DICT * 4));
-    RSK_HIP(hipMemset(d_total, 0, 8));
-    if (db->n) hipLaunchKernelGGL(k_pf_hood, dim3(db->n), dim3(256), 0, 0, db->d_mu, db->d_off, db->d_len, mode, 0, d_cnt,
+    if ((rc = ws.alloc(&d_cnt, (size_t) PF_DICT)) || (rc = ws.alloc(&d_start, (size_t) PF_DICT)) || (rc = ws.alloc(&d_total, 1))) return rc;
+    RSK_HIP(hipMemsetAsync(d_cnt, 0, (size_t) PF_DICT * 4, ctx->stream));
+    RSK_HIP(hipMemsetAsync(d_total, 0, 8, ctx->stream));
+    if (db->n) hipLaunchKernelGGL(k_pf_hood, dim3(db->n), dim3(256), 0, ctx->stream, db->d_mu, db->d_off, db->d_len, mode, 0, d_cnt,
                                   (const uint2 *) nullptr, (uint32_t *) nullptr, d_total);
     RSK_HIP(hipGetLastError());
-    RSK_HIP(hipMemcpy(&total, d_total, 8, hipMemcpyDeviceToHost));
-    if (total > 0xFFFFFFF0ull) { cleanup(); rsk_set_error("k-mer prefilter: %llu index postings exceed 2^32; split the query set", total); return RSK_E_RANGE; }
+    RSK_HIP(hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
+    RSK_HIP(hipStreamSynchronize(ctx->stream));
+    if (total > 0xFFFFFFF0ull) { rsk_set_error("k-mer prefilter: %llu index postings exceed 2^32; split the query set", total); return RSK_E_RANGE; }
     size_t tmp_bytes = 0;
-    RSK_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_cnt, d_start, (int) PF_DICT));
-    RSK_HIP(hipMalloc(&d_tmp, std::max<size_t>(tmp_bytes, 16)));
-    RSK_HIP(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_cnt, d_start, (int) PF_DICT));
-    hipLaunchKernelGGL(k_pf_make_table, dim3((PF_DICT + 255) / 256), dim3(256), 0, 0, d_start, d_cnt, (uint2 *) db->d_pf_table);
+    RSK_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_cnt, d_start, (int) PF_DICT, ctx->stream));
+    if ((rc = ws.alloc(&d_tmp, std::max<size_t>(tmp_bytes, 16))) != RSK_OK) return rc;
+    RSK_HIP(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_cnt, d_start, (int) PF_DICT, ctx->stream));
+    hipLaunchKernelGGL(k_pf_make_table, dim3((PF_DICT + 255) / 256), dim3(256), 0, ctx->stream, d_start, d_cnt, (uint2 *) db->d_pf_table);
     RSK_HIP(hipMalloc((void **) &db->d_pf_postings, std::max<size_t>((size_t) total, 1) * 4));
-    if (db->n) hipLaunchKernelGGL(k_pf_hood, dim3(db->n), dim3(256), 0, 0, db->d_mu, db->d_off, db->d_len, mode, 1, d_cnt,
+    if (db->n) hipLaunchKernelGGL(k_pf_hood, dim3(db->n), dim3(256), 0, ctx->stream, db->d_mu, db->d_off, db->d_len, mode, 1, d_cnt,
                                   (const uint2 *) db->d_pf_table, db->d_pf_postings, d_total);
     RSK_HIP(hipGetLastError());
-    RSK_HIP(hipDeviceSynchronize());
-    cleanup();
+    RSK_HIP(hipStreamSynchronize(ctx->stream));
     db->pf_postings = (size_t) total;
     db->hbm_bytes += (size_t) total * 4;
     db->mudex_built = true;
@@ -504,8 +505,9 @@ extern "C" int rsk_mu_prefilter_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db 
     if ((rc = rsk_build_mudex(const_cast<rsk_db *>(q), neighbourhood)) != RSK_OK) return rc;
     for (uint32_t L : t->len)
         if (L > 65534) { rsk_set_error("rsk_mu_prefilter_dev: target longer than 65534"); return RSK_E_RANGE; }
-    uint32_t *d_over = nullptr;
-    RSK_HIP(hipMalloc((void **) &d_over, 16 + 64));
+    rsk_scratch ws(ctx);                       // every temporary goes back to the pool on every exit path
+    uint32_t *d_over;
+    if ((rc = ws.alloc((void **) &d_over, 16 + 64)) != RSK_OK) return rc;
     RSK_HIP(hipMemsetAsync(d_over, 0, 16 + 64, ctx->stream));
     RSK_HIP(hipMemsetAsync(d_n, 0, 4, ctx->stream));
     pf_args a = {};
@@ -526,38 +528,37 @@ extern "C" int rsk_mu_prefilter_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db 
     a.tl_cap = tl_cap;
     a.dbg = getenv("RSK_PF_DEBUG") ? (uint32_t) atoi(getenv("RSK_PF_DEBUG")) : 0;
     const size_t lds = lds_fixed + (((size_t) tl_cap + 31) & ~(size_t) 15);
-    RSK_HIP(hipFuncSetAttribute((const void *) k_prefilter, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    RSK_HIP(hipFuncSetAttribute((const void *) k_prefilter, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));   // depends on the call's targets
     RSK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     if (t->n) {
         // key scratch: per target an upper bound of its keys; targets go in batches whose scratch fits the budget
-        uint64_t *d_sums = nullptr;
-        RSK_HIP(hipMalloc((void **) &d_sums, (size_t) t->n * 8));
+        uint64_t *d_sums;
+        if ((rc = ws.alloc(&d_sums, (size_t) t->n)) != RSK_OK) return rc;
         hipLaunchKernelGGL(k_pf_rowsum, dim3(t->n), dim3(256), 0, ctx->stream, (const uint2 *) q->d_pf_table, t->d_mu, t->d_off, t->d_len, t->n, d_sums);
         std::vector<uint64_t> sums(t->n);
         RSK_HIP(hipMemcpyAsync(sums.data(), d_sums, (size_t) t->n * 8, hipMemcpyDeviceToHost, ctx->stream));
         RSK_HIP(hipStreamSynchronize(ctx->stream));
-        (void) hipFree(d_sums);
         const uint64_t budget_keys = 12ull << 30;                       // 48 GB of 4-byte keys per batch
-        uint32_t *d_scr = nullptr;
-        uint64_t *d_koff = nullptr;
-        uint64_t scr_cap = 0;
+        // batches: the largest key count and target count size the two scratch blocks once
+        uint64_t max_keys = 0;
+        uint32_t max_nt = 0;
+        for (uint32_t t0 = 0; t0 < t->n;) {
+            uint32_t t1 = t0;
+            uint64_t keys = 0;
+            while (t1 < t->n && (t1 == t0 || keys + sums[t1] <= budget_keys)) { keys += sums[t1]; ++t1; }
+            max_keys = std::max(max_keys, keys); max_nt = std::max(max_nt, t1 - t0);
+            t0 = t1;
+        }
+        uint32_t *d_scr;
+        uint64_t *d_koff;
+        if ((rc = ws.alloc(&d_scr, (size_t) max_keys + 16)) != RSK_OK) { rsk_set_error("rsk_mu_prefilter_dev: out of device memory for %llu seed keys", (unsigned long long) max_keys); return rc; }
+        if ((rc = ws.alloc(&d_koff, (size_t) max_nt)) != RSK_OK) return rc;
         std::vector<uint64_t> koff;
         for (uint32_t t0 = 0; t0 < t->n;) {
             uint32_t t1 = t0;
             uint64_t keys = 0;
             koff.clear();
             while (t1 < t->n && (t1 == t0 || keys + sums[t1] <= budget_keys)) { koff.push_back(keys); keys += sums[t1]; ++t1; }
-            if (keys + 16 > scr_cap) {
-                if (d_scr) (void) hipFree(d_scr);
-                scr_cap = keys + 16;
-                if (hipMalloc((void **) &d_scr, scr_cap * 4) != hipSuccess) {
-                    (void) hipFree(d_over); if (d_koff) (void) hipFree(d_koff);
-                    rsk_set_error("rsk_mu_prefilter_dev: out of device memory for %llu seed keys", (unsigned long long) keys);
-                    return RSK_E_NOMEM;
-                }
-            }
-            if (d_koff) (void) hipFree(d_koff);
-            RSK_HIP(hipMalloc((void **) &d_koff, koff.size() * 8));
             RSK_HIP(hipMemcpyAsync(d_koff, koff.data(), koff.size() * 8, hipMemcpyHostToDevice, ctx->stream));
             a.t_base = t0; a.koff = d_koff; a.kscratch = d_scr;
             hipLaunchKernelGGL(k_prefilter, dim3(t1 - t0), dim3(PF_THREADS), lds, ctx->stream, a);
@@ -565,8 +566,6 @@ extern "C" int rsk_mu_prefilter_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db 
             RSK_HIP(hipStreamSynchronize(ctx->stream));                 // koff (host vector) and the scratch are reused by the next batch
             t0 = t1;
         }
-        if (d_scr) (void) hipFree(d_scr);
-        if (d_koff) (void) hipFree(d_koff);
     }
     RSK_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     uint32_t over = 0;
@@ -582,7 +581,6 @@ extern "C" int rsk_mu_prefilter_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db 
         fprintf(stderr, "[prefilter] index postings %zu, seed items %llu; chunks %llu, overflowing buckets %llu (query runs %llu, dense queries %llu), "
                         "two-hit diagonals %llu, chunk-phase cycles (100 MHz clock, summed over targets) %llu\n",
                 q->pf_postings, hits, stat[0], stat[1], stat[2], stat[3], stat[4], stat[5]);
-    (void) hipFree(d_over);
     if (over) { rsk_set_error("rsk_mu_prefilter_dev: more than %d k-mer hits between one target and 64 consecutive queries", PF_CAP); return RSK_E_RANGE; }
     return RSK_OK;
 }

@@ -64,8 +64,8 @@ static const int h_swf_toff[8] = { 0, 400, 656, 912, 1168, 1424, 1680, 1936 };
 
 static int swf_upload_tables(rsk_ctx *ctx)
 {
-    static bool done[64] = { false };
-    if (ctx->device < 64 && done[ctx->device]) return RSK_OK;
+    static std::atomic<int> done[64];
+    return rsk_once_per_device(done, ctx->device, [&]() -> int {
     swf_tables h;
     for (int i = 0; i < SWF_TABLE_FLOATS; ++i) h.t[i] = -1e30f;
     for (int f = 0; f < RSK_NFEATURES; ++f) {
@@ -74,8 +74,8 @@ static int swf_upload_tables(rsk_ctx *ctx)
             for (int b = 0; b < as; ++b) h.t[h_swf_toff[f] + a * as + b] = rsk_feature_mx[f][a * RSK_FEATURE_DIM + b];
     }
     RSK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_swf_tables), &h, sizeof(h)));
-    if (ctx->device < 64) done[ctx->device] = true;
     return RSK_OK;
+    });
 }
 
 struct swf_item {            // one wave's work: pairs [first, first+count), g lanes per pair, row groups of g strips
@@ -1183,13 +1183,14 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
     a.bnd = d_bnd; a.bnd_off = d_bndoff;
     RSK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     {
-        static std::atomic<bool> attr_done[64];     // per device: the attribute belongs to the device's code object
-        const int dv = ctx->device & 63;
-        if (!attr_done[dv].load(std::memory_order_acquire)) {
+        static std::atomic<int> attr_done[64];      // per device: the attribute belongs to the device's code object
+        const int arc = rsk_once_per_device(attr_done, ctx->device, [&]() -> int {
             RSK_HIP(hipFuncSetAttribute((const void *) k_sw_qp<false, SWQ_MAX_G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) SWQ_LDS_BYTES(SWQ_MAX_G)));
             RSK_HIP(hipFuncSetAttribute((const void *) k_sw_qp<true, SWQ_MAX_G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) SWQ_LDS_BYTES(SWQ_MAX_G)));
-            attr_done[dv].store(true, std::memory_order_release);
-        }
+            RSK_HIP(hipFuncSetAttribute((const void *) k_lddt_long, hipFuncAttributeMaxDynamicSharedMemorySize, LDDT_LONG_COLS * 32));
+            return RSK_OK;
+        });
+        if (arc != RSK_OK) return arc;
     }
     for (int c = 0; c < 2; ++c) {
         if (qitems[c].empty()) continue;
@@ -1221,11 +1222,6 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
         for (int c = 0; c < 2; ++c) {
             const uint32_t nl = (uint32_t) lddt_list[c].size(), cap = c == 0 ? 1024u : (uint32_t) LDDT_LONG_COLS;
             if (nl == 0) continue;
-            static bool lddt_attr = false;
-            if (!lddt_attr) {
-                RSK_HIP(hipFuncSetAttribute((const void *) k_lddt_long, hipFuncAttributeMaxDynamicSharedMemorySize, LDDT_LONG_COLS * 32));
-                lddt_attr = true;
-            }
             hipLaunchKernelGGL(k_lddt_long, dim3(nl), dim3(256), (size_t) cap * 32, ctx->stream, (const uint32_t *) (D + o_lddt[c]), nl, cap, d_ia,
                                d_ib, dba->d_off, dbb->d_off, dba->d_x, dba->d_y, dba->d_z, dbb->d_x, dbb->d_y, dbb->d_z, d_pos, d_scoff, d_lddt,
                                d_counts, d_score, min_fwd_score);
@@ -1362,7 +1358,12 @@ int rsk_paths_stats_pack(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *dbb, siz
     for (int c = 0; c < 2; ++c) {
         const uint32_t nl = (uint32_t) lddt_list[c].size(), cap = c == 0 ? 1024u : (uint32_t) LDDT_LONG_COLS;
         if (nl == 0) continue;
-        RSK_HIP(hipFuncSetAttribute((const void *) k_lddt_long, hipFuncAttributeMaxDynamicSharedMemorySize, LDDT_LONG_COLS * 32));
+        static std::atomic<int> lddt_attr[64];
+        const int arc = rsk_once_per_device(lddt_attr, ctx->device, [&]() -> int {
+            RSK_HIP(hipFuncSetAttribute((const void *) k_lddt_long, hipFuncAttributeMaxDynamicSharedMemorySize, LDDT_LONG_COLS * 32));
+            return RSK_OK;
+        });
+        if (arc != RSK_OK) return arc;
         hipLaunchKernelGGL(k_lddt_long, dim3(nl), dim3(256), (size_t) cap * 32, ctx->stream, d_list[c], nl, cap, d_ia, d_ib, dba->d_off, dbb->d_off,
                            dba->d_x, dba->d_y, dba->d_z, dbb->d_x, dbb->d_y, dbb->d_z, d_pos, d_scoff, d_lddt, d_counts, d_score, min_fwd_score);
     }

@@ -42,8 +42,8 @@ static const int h_xd_toff[8] = { 0, 400, 656, 912, 1168, 1424, 1680, 1936 };
 
 static int xd_upload_tables(rsk_ctx *ctx)
 {
-    static bool done[64] = { false };
-    if (ctx->device < 64 && done[ctx->device]) return RSK_OK;
+    static std::atomic<int> done[64];
+    return rsk_once_per_device(done, ctx->device, [&]() -> int {
     xd_tables h;
     for (int i = 0; i < XD_TABLE_FLOATS; ++i) h.t[i] = 0.0f;
     for (int f = 0; f < RSK_NFEATURES; ++f) {
@@ -52,8 +52,8 @@ static int xd_upload_tables(rsk_ctx *ctx)
             for (int b = 0; b < as; ++b) h.t[h_xd_toff[f] + a * as + b] = rsk_feature_mx[f][a * RSK_FEATURE_DIM + b];
     }
     RSK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_xd_tables), &h, sizeof(h)));
-    if (ctx->device < 64) done[ctx->device] = true;
     return RSK_OK;
+    });
 }
 
 struct xd_args {

@@ -46,13 +46,21 @@ extern "C" int rsk_ctx_create(int device, rsk_ctx **out)
         rsk_set_error("rsk_ctx_create: device %d is %s; librsk is built for gfx950 only", device, prop.gcnArchName);
         return RSK_E_DEVICE;
     }
-    rsk_ctx *c = new rsk_ctx;
+    std::unique_ptr<rsk_ctx> c(new rsk_ctx);
     c->device = device;
     c->num_cus = prop.multiProcessorCount;
     RSK_HIP(hipEventCreate(&c->ev0));
-    RSK_HIP(hipEventCreate(&c->ev1));
-    *out = c;
+    if (hipError_t ee = hipEventCreate(&c->ev1)) { (void) hipEventDestroy(c->ev0); return rsk_hip_fail(ee, "hipEventCreate", __FILE__, __LINE__); }
+    *out = c.release();
     return RSK_OK;
+}
+
+rsk_scratch::~rsk_scratch() { for (void *p : all) rsk_pool_free(ctx, p); }
+int rsk_scratch::alloc(void **p, size_t bytes)
+{
+    const int r = rsk_pool_alloc(ctx, p, std::max<size_t>(bytes, 16));
+    if (r == RSK_OK) all.push_back(*p);
+    return r;
 }
 
 int rsk_pool_alloc(rsk_ctx *ctx, void **p, size_t bytes)
@@ -307,7 +315,7 @@ extern "C" void rsk_db_destroy(rsk_db *db)
 {
     if (!db) return;
     void *ptrs[] = { db->d_len, db->d_off, db->d_mu, db->d_prof, db->d_x, db->d_y, db->d_z, db->d_selfrev,
-                     db->d_ring_tab, db->d_ring_letters, db->d_ring_laneq, db->d_ring_qid, db->d_ring_perm, db->d_tri_claim, db->d_nat_claim, db->d_work, db->d_prof_cb, db->d_prof_ra, db->d_pf_table, db->d_pf_postings, db->d_len_perm, db->d_len_rank };
+                     db->d_ring_tab, db->d_ring_letters, db->d_ring_laneq, db->d_ring_qid, db->d_ring_perm, db->d_tri_claim, db->d_nat_claim, db->d_work, db->d_prof_cb, db->d_prof_ra, db->d_pf_table, db->d_pf_postings, db->d_len_perm, db->d_len_rank, db->d_long_iq, db->d_long_it };
     for (void *p : ptrs)
         if (p) (void) hipFree(p);
     delete db;
@@ -326,6 +334,17 @@ extern "C" int rsk_mu_gapless_matrix_dev(rsk_ctx *ctx, const rsk_db *q, const rs
     if (!q->d_mu || !t->d_mu) { rsk_set_error("rsk_mu_gapless_matrix_dev: chain set has no Mu letters"); return RSK_E_INVALID; }
     if (ldo < t->n) { rsk_set_error("rsk_mu_gapless_matrix_dev: ldo < number of targets"); return RSK_E_INVALID; }
     if (self_triangle && q != t) { rsk_set_error("rsk_mu_gapless_matrix_dev: self_triangle needs q == t"); return RSK_E_INVALID; }
+    // uint16 output: the largest score is 4 * min(LA, LB), so a pair of chains > 16383 could saturate; the pair-list form
+    // (int32 scores) has no such limit
+    {
+        uint32_t mq = 0, mt = 0;
+        for (uint32_t L : q->len) mq = std::max(mq, L);
+        for (uint32_t L : t->len) mt = std::max(mt, L);
+        if (std::min(mq, mt) > 16383) {
+            rsk_set_error("rsk_mu_gapless_matrix_dev: chains of %u and %u residues could exceed the uint16 score range (use rsk_mu_gapless_pairs)", mq, mt);
+            return RSK_E_RANGE;
+        }
+    }
     RSK_HIP(hipSetDevice(ctx->device));
     if (!q->rings_built) {
         int rc = rsk_build_rings(const_cast<rsk_db *>(q));
@@ -344,24 +363,21 @@ extern "C" int rsk_mu_gapless_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db 
         if (iq[p] >= q->n || it[p] >= t->n) { rsk_set_error("rsk_mu_gapless_pairs: pair %zu out of range", p); return RSK_E_INVALID; }
     if (npairs == 0) return RSK_OK;
     RSK_HIP(hipSetDevice(ctx->device));
-    uint32_t *d_iq = nullptr, *d_it = nullptr, *d_bi = nullptr, *d_bj = nullptr;
-    int32_t *d_sc = nullptr;
-    RSK_HIP(hipMalloc((void **) &d_iq, npairs * 4));
-    RSK_HIP(hipMalloc((void **) &d_it, npairs * 4));
-    RSK_HIP(hipMalloc((void **) &d_sc, npairs * 4));
-    RSK_HIP(hipMalloc((void **) &d_bi, npairs * 4));
-    RSK_HIP(hipMalloc((void **) &d_bj, npairs * 4));
+    rsk_scratch ws(ctx);
+    uint32_t *d_iq, *d_it, *d_bi, *d_bj;
+    int32_t *d_sc;
+    int rc;
+    if ((rc = ws.alloc(&d_iq, npairs)) || (rc = ws.alloc(&d_it, npairs)) || (rc = ws.alloc(&d_sc, npairs)) || (rc = ws.alloc(&d_bi, npairs)) ||
+        (rc = ws.alloc(&d_bj, npairs)))
+        return rc;
     RSK_HIP(hipMemcpyAsync(d_iq, iq, npairs * 4, hipMemcpyHostToDevice, ctx->stream));
     RSK_HIP(hipMemcpyAsync(d_it, it, npairs * 4, hipMemcpyHostToDevice, ctx->stream));
-    int rc = rsk_launch_gapless_pairs(ctx, q, t, d_iq, d_it, npairs, d_sc, d_bi, d_bj);
-    if (rc == RSK_OK) {
-        RSK_HIP(hipMemcpyAsync(scores, d_sc, npairs * 4, hipMemcpyDeviceToHost, ctx->stream));
-        if (besti) RSK_HIP(hipMemcpyAsync(besti, d_bi, npairs * 4, hipMemcpyDeviceToHost, ctx->stream));
-        if (bestj) RSK_HIP(hipMemcpyAsync(bestj, d_bj, npairs * 4, hipMemcpyDeviceToHost, ctx->stream));
-        RSK_HIP(hipStreamSynchronize(ctx->stream));
-    }
-    (void) hipFree(d_iq); (void) hipFree(d_it); (void) hipFree(d_sc); (void) hipFree(d_bi); (void) hipFree(d_bj);
-    return rc;
+    if ((rc = rsk_launch_gapless_pairs(ctx, q, t, d_iq, d_it, npairs, d_sc, d_bi, d_bj)) != RSK_OK) return rc;
+    RSK_HIP(hipMemcpyAsync(scores, d_sc, npairs * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (besti) RSK_HIP(hipMemcpyAsync(besti, d_bi, npairs * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (bestj) RSK_HIP(hipMemcpyAsync(bestj, d_bj, npairs * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RSK_HIP(hipStreamSynchronize(ctx->stream));
+    return RSK_OK;
 }
 
 extern "C" int rsk_mu_gapless_last_work(rsk_ctx *ctx, uint64_t *pairs, uint64_t *cells, uint64_t *cell_slots)

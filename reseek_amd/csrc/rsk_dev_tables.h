@@ -8,9 +8,9 @@ static __device__ __constant__ signed char c_mu_int[36 * 36];   // IntScoreMx_Mu
 
 static int rsk_upload_mu_tables(rsk_ctx *ctx)
 {
-    static bool done[64] = { false };
-    if (ctx->device < 64 && done[ctx->device]) return RSK_OK;
-    RSK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_mu_int), rsk_mu_int, sizeof(rsk_mu_int)));
-    if (ctx->device < 64) done[ctx->device] = true;
-    return RSK_OK;
+    static std::atomic<int> done[64];          // one per translation unit that includes this header (each has its own c_mu_int)
+    return rsk_once_per_device(done, ctx->device, [&]() -> int {
+        RSK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_mu_int), rsk_mu_int, sizeof(rsk_mu_int)));
+        return RSK_OK;
+    });
 }

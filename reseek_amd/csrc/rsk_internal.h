@@ -44,6 +44,36 @@ struct rsk_ctx {
     size_t pin_bytes[4] = { 0, 0, 0, 0 };
 };
 
+// One-time per-DEVICE initialisation (constant-table uploads, hipFuncSetAttribute: both belong to the device's copy of the
+// code object), safe against the host threads that drive several contexts at once: `flags` is a zero-initialised static
+// array of 64 atomics; returns f()'s code.
+#include <atomic>
+#include <mutex>
+template <class F>
+static inline int rsk_once_per_device(std::atomic<int> *flags, int device, F f)
+{
+    std::atomic<int> &fl = flags[device & 63];
+    if (fl.load(std::memory_order_acquire)) return RSK_OK;
+    static std::mutex m;
+    std::lock_guard<std::mutex> g(m);
+    if (fl.load(std::memory_order_relaxed)) return RSK_OK;
+    const int rc = f();
+    if (rc == RSK_OK) fl.store(1, std::memory_order_release);
+    return rc;
+}
+
+// device temporaries of one call, returned to the context's pool on every exit path
+struct rsk_scratch {
+    rsk_ctx *ctx;
+    std::vector<void *> all;
+    explicit rsk_scratch(rsk_ctx *c) : ctx(c) {}
+    rsk_scratch(const rsk_scratch &) = delete;
+    rsk_scratch &operator=(const rsk_scratch &) = delete;
+    ~rsk_scratch();
+    int alloc(void **p, size_t bytes);
+    template <class T> int alloc(T **p, size_t count) { return alloc((void **) p, count * sizeof(T)); }
+};
+
 int rsk_pool_alloc(rsk_ctx *ctx, void **p, size_t bytes);
 void rsk_pool_free(rsk_ctx *ctx, void *p);
 void rsk_pool_release(rsk_ctx *ctx);
@@ -96,6 +126,8 @@ struct rsk_db {
     int work_tri = -1;
     void *d_work = nullptr;             // uint2 (ring, first target) entries, D = 4 class first
     uint32_t work_count[2] = { 0, 0 };
+    uint32_t *d_long_iq = nullptr, *d_long_it = nullptr;   // (long query, target) pairs of the per-pair kernel, same cache key
+    uint32_t long_pairs = 0;
     // chains by increasing length (Mu SW filter: the targets a wave works on at once have similar lengths)
     uint32_t *d_len_perm = nullptr;     // perm[k] = chain index of rank k
     uint32_t *d_len_rank = nullptr;     // rank[chain]

@@ -159,3 +159,23 @@ def test_scop40_scale_triangle_mode_vs_oracle(ctx):
     iu = torch.triu_indices(n, n, device="cuda")
     assert bool((out[iu[0], iu[1]] == rect[iu[0], iu[1]]).all())
     db.close()
+
+
+def test_uint16_range_contract(ctx):
+    """rsk_mu_gapless_matrix_dev writes uint16: a pair of chains longer than 16383 could exceed 65535 -> RSK_E_RANGE (the header's
+    contract); one such chain against short ones is fine (score <= 4 * min(LA, LB))."""
+    import torch
+    import reseek_amd
+    from reseek_amd import capi
+    rng = np.random.default_rng(3)
+    big = [rng.integers(0, 36, 16400).astype(np.uint8), rng.integers(0, 36, 50).astype(np.uint8)]
+    small = [rng.integers(0, 36, int(L)).astype(np.uint8) for L in (30, 200, 999)]
+    dbig, dsmall = reseek_amd.Db.from_mu_seqs(ctx, big), reseek_amd.Db.from_mu_seqs(ctx, small)
+    out = torch.zeros((2, 2), dtype=torch.int16, device="cuda")
+    with pytest.raises(capi.RskError):
+        ctx.mu_gapless_matrix_dev(dbig, dbig, True, out.data_ptr(), 2)
+    got = run_matrix(ctx, big, small)
+    ia, ib = np.meshgrid(np.arange(2), np.arange(3), indexing="ij")
+    want = ol.mu_gapless_pairs(big + small, ia.ravel(), ib.ravel() + 2).reshape(2, 3)
+    assert np.array_equal(got, want)
+    dbig.close(); dsmall.close()
