@@ -52,6 +52,9 @@ void rsk_ctx_destroy(rsk_ctx *ctx);
  * so torch events/timers see the kernels. */
 int rsk_ctx_set_stream(rsk_ctx *ctx, void *hip_stream);
 int rsk_ctx_sync(rsk_ctx *ctx);
+/* Device scratch is cached: per context in an allocator pool, and the search drivers keep their helper contexts (own
+ * streams, own pools) idle per device between calls.  rsk_ctx_trim returns all of that to the device (hipFree). */
+void rsk_ctx_trim(rsk_ctx *ctx);
 /* Average duration (ms) of the device work enqueued by the last compute call, measured with HIP
  * events on the context stream; < 0 if none. */
 float rsk_ctx_last_kernel_ms(rsk_ctx *ctx);

@@ -25,6 +25,7 @@ SIGNATURES = {
     "rsk_ctx_destroy": (None, [C.c_void_p]),
     "rsk_ctx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rsk_ctx_sync": (C.c_int, [C.c_void_p]),
+    "rsk_ctx_trim": (None, [C.c_void_p]),
     "rsk_ctx_last_kernel_ms": (C.c_float, [C.c_void_p]),
     "rsk_db_create": (C.c_int, [C.c_void_p, C.c_uint32, u32p, u8p, u8p, f32p, f32p, f32p, f32p, C.POINTER(C.c_void_p)]),
     "rsk_db_destroy": (None, [C.c_void_p]),

@@ -399,9 +399,23 @@ void DBSearcher::UploadToGpu()
 struct SecondaryCtx {
     rsk_ctx *c = nullptr;
     hipStream_t st = nullptr;
-    void Create(int device)
+    int device = -1;
+    // Idle secondary contexts are kept per device and handed out again: a context's allocator pool holds the scratch of
+    // its last job (tens of GB of X-drop trace, the SW trace blocks), and hipMalloc / hipFree of blocks that size cost
+    // hundreds of ms -- per search and, with a streamed -db file, per batch.  rsk_ctx_trim() releases them.
+    struct Idle { int device; rsk_ctx *c; hipStream_t st; };
+    static std::mutex &Lock() { static std::mutex m; return m; }
+    static std::vector<Idle> &IdleList() { static std::vector<Idle> v; return v; }
+    void Create(int dev)
     {
-        check(rsk_ctx_create(device, &c), "rsk_ctx_create");
+        device = dev;
+        {
+            std::lock_guard<std::mutex> g(Lock());
+            auto &v = IdleList();
+            for (size_t k = 0; k < v.size(); ++k)
+                if (v[k].device == dev) { c = v[k].c; st = v[k].st; v.erase(v.begin() + k); return; }
+        }
+        check(rsk_ctx_create(dev, &c), "rsk_ctx_create");
         if (!(getenv("RSK_OWN_STREAMS") && atoi(getenv("RSK_OWN_STREAMS")) == 0)) {
             if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { st = nullptr; return; }
             rsk_ctx_set_stream(c, (void *) st);
@@ -409,8 +423,24 @@ struct SecondaryCtx {
     }
     ~SecondaryCtx()
     {
-        if (c) rsk_ctx_destroy(c);
+        if (!c) return;
+        (void) rsk_ctx_sync(c);
+        std::lock_guard<std::mutex> g(Lock());
+        auto &v = IdleList();
+        if (v.size() < 6) { v.push_back(Idle{ device, c, st }); return; }
+        rsk_ctx_destroy(c);
         if (st) (void) hipStreamDestroy(st);
+    }
+    static void Trim(int dev)
+    {
+        std::lock_guard<std::mutex> g(Lock());
+        auto &v = IdleList();
+        for (size_t k = 0; k < v.size();)
+            if (dev < 0 || v[k].device == dev) {
+                rsk_ctx_destroy(v[k].c);
+                if (v[k].st) (void) hipStreamDestroy(v[k].st);
+                v.erase(v.begin() + k);
+            } else ++k;
     }
 };
 
@@ -1178,6 +1208,13 @@ void DSSAligner::AlignPairOnGpu()
 }
 
 }   // namespace reseek_amd
+
+extern "C" void rsk_ctx_trim(rsk_ctx *ctx)
+{
+    if (!ctx) return;
+    reseek_amd::SecondaryCtx::Trim(ctx->device);
+    rsk_pool_release(ctx);
+}
 
 // ---------------------------------------------------------------------------------------------
 // C-ABI: `reseek -search Q [-db DB] -fast|-sensitive|-verysensitive -output F [-columns C] [-evalue E]`

@@ -390,8 +390,10 @@ public:
     void RunQuery(ChainReader2 &QCR);                   // runquery.cpp:82: the reader's chains are streamed past our chains in batches
     void RunQuery(DBSearcher &DBChainsSource);          // the same for a chain set that is already loaded (A = its chains, B = ours)
     // chains per streamed batch of RunQuery(ChainReader2 &): bounds the host RAM / HBM a -db file needs, whatever its size
-    uint m_StreamBatchChains = 1u << 17;
-    uint64_t m_StreamBatchResidues = 48ull << 20;
+    // (measured, 256 queries x 125,000 chains -sensitive: 131072 per batch 4.9 s, 32768 3.5 s, 16384 3.4 s -- the loader
+    // thread featurises batch k + 1 under batch k's kernels)
+    uint m_StreamBatchChains = 1u << 15;
+    uint64_t m_StreamBatchResidues = 8ull << 20;
     void LoadChains(std::vector<PDBChain *> &Chains);   // take ownership, featurise on the host threads, self-rev scores on the GPU
     bool m_OwnsChains = true;
     void MakeView(const DBSearcher &Src, uint Lo, uint Hi);

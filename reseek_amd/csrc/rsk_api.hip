@@ -68,11 +68,13 @@ int rsk_pool_alloc(rsk_ctx *ctx, void **p, size_t bytes)
     size_t cls = 256;
     while (cls < bytes) cls <<= 1;
     if (cls > (1ull << 30)) cls = (bytes + (1ull << 28) - 1) / (1ull << 28) * (1ull << 28);   // >1 GiB: 256 MiB steps
-    auto it = ctx->pool_free.find(cls);
-    if (it != ctx->pool_free.end()) {
+    // smallest cached block that holds the request without wasting more than its size again
+    auto it = ctx->pool_free.lower_bound(cls);
+    if (it != ctx->pool_free.end() && it->first <= 2 * cls) {
         *p = it->second;
+        const size_t actual = it->first;             // the block keeps its real size
         ctx->pool_free.erase(it);
-        ctx->pool_live[*p] = cls;
+        ctx->pool_live[*p] = actual;
         return RSK_OK;
     }
     hipError_t e = hipMalloc(p, cls);
