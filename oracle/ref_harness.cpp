@@ -25,6 +25,7 @@
 //   mukat    <in.mu.fa> <first> <count> <out.bin>
 //   randkat  <seed> <npairs> <out.bin>
 //   xdropkat <seed> <nrandom> <out.bin>      (the reference's -test_xdrop / testsw peptide pairs + random ones)
+//   xdrophsp <in.bca> <out.bin> <maxchains>  [-- mode]   (long-chain pairs: chained HSPs, mega scores, XDropHSP start, XDropFwd / XDropBwd, merge)
 //   benchmu  <in.mu.fa> <npairs> <threads>    (times the reference kernels; bench.py cpu_baseline)
 
 #include "myutils.h"
@@ -62,6 +63,7 @@ static void w32(FILE *f, uint32_t v) { fwrite(&v, 4, 1, f); }
 static void wi32(FILE *f, int32_t v) { fwrite(&v, 4, 1, f); }
 static void wf32(FILE *f, float v) { fwrite(&v, 4, 1, f); }
 static void wbytes(FILE *f, const void *p, size_t n) { if (n) fwrite(p, 1, n, f); }
+static void wstr(FILE *f, const string &s);
 
 static void InitOpts(int argc, char **argv, int first_opt)
 	{
@@ -715,6 +717,107 @@ static void cmd_mkfkat(const string &InFN, const string &OutFN, uint MaxChains)
 	fprintf(stderr, "mkfkat: %u chains -> %s\n", N, OutFN.c_str());
 	}
 
+// xdrophsp: the long-chain path of every ordered pair of the first N chains, step by step through the reference's own
+// functions (PostAlignMKF dssaligner.cpp:1395 / XDropHSP xdrophsp.cpp:42 restated as calls, not copied): chained HSPs of
+// MuKmerFilter::Align, DSSAligner::GetMegaHSPScore of each, the start XDropHSP derives from StaticSubstScore, XDropFwd and
+// XDropBwd from that start, MergeFwdBwd.  The result is checked against DSSAligner::AlignMKF of the same pair before it is
+// written, so the fixture is the reference's own answer split into its stages.
+static void cmd_xdrophsp(const string &InFN, const string &OutFN, uint MaxChains)
+	{
+	DSSParams Params;
+	Params.SetDSSParams(DM_UseCommandLineOption);
+	vector<ChainData *> CDs;
+	LoadChains(InFN, Params, CDs, MaxChains);
+	const uint N = SIZE(CDs);
+	FILE *f = fopen(OutFN.c_str(), "wb");
+	asserta(f != 0);
+	wbytes(f, "RSKXH1\0\0", 8);
+	w32(f, N);
+	DSSAligner DA;
+	DA.SetParams(Params);
+	XDPMem Mem;
+	uint NRec = 0, NAln = 0;
+	for (uint i = 0; i < N; ++i)
+		{
+		const ChainData &A = *CDs[i];
+		for (uint j = 0; j < N; ++j)
+			{
+			const ChainData &B = *CDs[j];
+			DA.SetQuery(*A.Chain, &A.Profile, &A.Mu, &A.Kmers, A.SelfRev);
+			DA.SetTarget(*B.Chain, &B.Profile, &B.Mu, &B.Kmers, B.SelfRev);
+			if (!DA.DoMKF())
+				continue;
+			DA.AlignMKF();                          // the reference's answer for the pair
+			const string RefPath = DA.m_Path;
+			const float RefScore = DA.m_AlnFwdScore;
+			const uint RefLoA = DA.m_LoA, RefLoB = DA.m_LoB;
+			// ... and its stages
+			const MuKmerFilter &MKF = DA.m_MKF;
+			const uint M = SIZE(MKF.m_ChainHSPLois);
+			w32(f, i); w32(f, j);
+			wi32(f, MKF.m_BestChainScore);
+			w32(f, M);
+			float MegaTotal = 0, BestMega = 0;
+			uint BestIdx = 0;
+			for (uint k = 0; k < M; ++k)
+				{
+				const float Mega = DA.GetMegaHSPScore((uint) MKF.m_ChainHSPLois[k], (uint) MKF.m_ChainHSPLojs[k], (uint) MKF.m_ChainHSPLens[k]);
+				wi32(f, MKF.m_ChainHSPLois[k]); wi32(f, MKF.m_ChainHSPLojs[k]); wi32(f, MKF.m_ChainHSPLens[k]); wf32(f, Mega);
+				if (Mega > BestMega) { BestMega = Mega; BestIdx = k; }
+				MegaTotal += Mega;
+				}
+			wf32(f, MegaTotal);
+			const bool Gate = MKF.m_BestChainScore > 0 && M > 0 && !(MegaTotal < Params.m_MKF_MinMegaHSPScore);
+			w32(f, Gate ? 1 : 0);
+			++NRec;
+			if (!Gate)
+				{
+				asserta(RefPath.empty());
+				continue;
+				}
+			// start of the gapped extensions: best 8-mer of the best HSP under StaticSubstScore
+			const uint Li = (uint) MKF.m_ChainHSPLois[BestIdx], Lj = (uint) MKF.m_ChainHSPLojs[BestIdx], Len = (uint) MKF.m_ChainHSPLens[BestIdx];
+			uint LoA = Li + Len/2, LoB = Lj + Len/2;
+			float BestMer = 0;
+			for (uint s0 = 0; s0 + 8 <= Len; ++s0)
+				{
+				float Mer = 0;
+				for (uint k = 0; k < 8; ++k)
+					Mer += DSSAligner::StaticSubstScore((void *) &DA, Li + s0 + k, Lj + s0 + k);
+				if (Mer > BestMer) { BestMer = Mer; LoA = Li + s0; LoB = Lj + s0; }
+				}
+			if (min(LoA, LoB) < 4) { LoA += 4; LoB += 4; }
+			const uint LA = A.Chain->GetSeqLength(), LB = B.Chain->GetSeqLength();
+			string FwdPath, BwdPath, Path;
+			uint s1, s2;
+			const float ScoreFwd = XDropFwd(Mem, float(Params.m_MKF_X2), Params.m_GapOpen, Params.m_GapExt, DSSAligner::StaticSubstScore,
+			  (void *) &DA, LoA, LA, LoB, LB, &s1, &s2, FwdPath);
+			const float ScoreBwd = XDropBwd(Mem, float(Params.m_MKF_X2), Params.m_GapOpen, Params.m_GapExt, DSSAligner::StaticSubstScore,
+			  (void *) &DA, LoA - 1, LA, LoB - 1, LB, &s1, &s2, BwdPath);
+			const float Total = ScoreFwd + ScoreBwd;
+			uint MLoA = UINT_MAX, MLoB = UINT_MAX, MHiA = UINT_MAX, MHiB = UINT_MAX;
+			if (!(Total < 10))
+				MergeFwdBwd(LA, LB, LoA, LoB, FwdPath, LoA - 1, LoB - 1, BwdPath, MLoA, MLoB, MHiA, MHiB, Path);
+			// the stages reproduce the reference's own result
+			if (Total < 10)
+				asserta(RefPath.empty() && RefScore == 0);
+			else
+				asserta(RefPath == Path && RefScore == Total && RefLoA == MLoA && RefLoB == MLoB);
+			w32(f, BestIdx); w32(f, LoA); w32(f, LoB);
+			wf32(f, ScoreFwd); wstr(f, FwdPath);
+			wf32(f, ScoreBwd); wstr(f, BwdPath);
+			wf32(f, Total < 10 ? 0.0f : Total);
+			w32(f, MLoA); w32(f, MLoB);
+			wstr(f, Path);
+			wf32(f, DA.m_EvalueA); wf32(f, DA.GetLDDT());
+			if (!Path.empty()) ++NAln;
+			}
+		}
+	w32(f, UINT_MAX);
+	fclose(f);
+	fprintf(stderr, "xdrophsp: %u chains, %u long-chain pairs, %u aligned -> %s\n", N, NRec, NAln, OutFN.c_str());
+	}
+
 // The k-mer neighbourhood prefilter as cmd_search runs it (search.cpp:78-100 -> MuPreFilter
 // muprefilter.cpp:70), on Mu FASTA inputs: writes the (query, target, score) list of the
 // RankedScoresBag and the target-major hand-off TSV.  Mode: idxq | idxt | auto (via -idxq/-idxt after --).
@@ -886,6 +989,8 @@ int main(int argc, char **argv)
 		cmd_d1pairs(A[0], A[1], (uint) atoi(A[2].c_str()));
 	else if (Cmd == "prefhood" && A.size() == 4)
 		cmd_prefhood(A[0], A[1], A[2], A[3]);
+	else if (Cmd == "xdrophsp" && A.size() == 3)
+		cmd_xdrophsp(A[0], A[1], (uint) atoi(A[2].c_str()));
 	else if (Cmd == "xdropkat" && A.size() == 3)
 		cmd_xdropkat(strtoull(A[0].c_str(), 0, 0), (uint) atoi(A[1].c_str()), A[2]);
 	else if (Cmd == "benchmu" && A.size() == 3)

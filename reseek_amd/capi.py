@@ -278,6 +278,24 @@ class Ctx:
         return [(float(sf[k]), raw[int(fo[k]):int(fo[k]) + int(fl[k])].decode(), float(sb[k]), raw[int(bo[k]):int(bo[k]) + int(bl[k])].decode())
                 for k in range(n)]
 
+    def mkf_align_pairs(self, a, b, ia, ib, hsp_first, hsp_lo_a, hsp_lo_b, hsp_len, x2=8.0, gap_open=GAP_OPEN, gap_ext=GAP_EXT,
+                        min_mega_score=-4.0, min_fwd_score=7.0):
+        """rsk_mkf_align_pairs -> (list of (Aln, path str), status uint8[n])"""
+        ia = np.ascontiguousarray(ia, np.uint32)
+        ib = np.ascontiguousarray(ib, np.uint32)
+        hf = np.ascontiguousarray(hsp_first, np.uint32)
+        hla, hlb, hl = (np.ascontiguousarray(x, np.int32) for x in (hsp_lo_a, hsp_lo_b, hsp_len))
+        n = len(ia)
+        la, lb = np.asarray(a.lengths), np.asarray(b.lengths)
+        nbytes = int((la[ia].astype(np.int64) + lb[ib] + 1).sum()) + 16
+        buf = C.create_string_buffer(nbytes)
+        out = (Aln * max(1, n))()
+        status = np.zeros(max(1, n), np.uint8)
+        _check(lib().rsk_mkf_align_pairs(self.h, a.h, b.h, _p(ia, u32p), _p(ib, u32p), n, _p(hf, u32p), _p(hla, i32p), _p(hlb, i32p), _p(hl, i32p),
+                                         x2, gap_open, gap_ext, min_mega_score, min_fwd_score, out, _p(status, u8p), buf, nbytes))
+        raw = buf.raw
+        return [(out[k], raw[out[k].path_off:out[k].path_off + out[k].path_len].decode()) for k in range(n)], status[:n]
+
     def mkf_seed_pairs(self, q, t, iq, it, x1=8, min_hsp_score=50, cap=16, max_records=None):
         """-> (found uint8[n], {pair index: (nkept, kept int32 [min(nkept, cap), 4])})"""
         iq = np.ascontiguousarray(iq, np.uint32)

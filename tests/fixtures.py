@@ -154,6 +154,45 @@ def read_mkfkat(name):
     return n, out
 
 
+def read_xdrophsp(name):
+    """oracle/ref_harness xdrophsp: the long-chain path of every long-chain pair (i = A, j = B), stage by stage, from the
+    reference's own functions.  -> (n, list of dicts): chain (int32 [c, 3]), mega (float32 bits [c]), mega_total bits, gate;
+    for gated-in pairs also best_idx, lo_a, lo_b, fwd / bwd (score bits, path), total bits (0 = no alignment), mlo_a, mlo_b,
+    path, evalue bits, lddt bits."""
+    with _open(name) as f:
+        buf = f.read()
+    assert buf[:8] == b"RSKXH1\0\0"
+    (n,) = struct.unpack_from("<I", buf, 8)
+    p = 12
+    recs = []
+
+    def rstr():
+        nonlocal p
+        (m,) = struct.unpack_from("<I", buf, p); p += 4
+        v = buf[p:p + m].decode(); p += m
+        return v
+
+    while True:
+        (i,) = struct.unpack_from("<I", buf, p); p += 4
+        if i == 0xFFFFFFFF:
+            break
+        (j, bcs, m) = struct.unpack_from("<IiI", buf, p); p += 12
+        rows = np.frombuffer(buf, np.int32, 4 * m, p).reshape(m, 4).copy(); p += 16 * m
+        (mt, gate) = struct.unpack_from("<II", buf, p); p += 8
+        r = {"i": i, "j": j, "best_chain_score": bcs, "chain": rows[:, :3].copy(), "mega": rows[:, 3].view(np.uint32).copy(), "mega_total": mt, "gate": gate}
+        if gate:
+            (r["best_idx"], r["lo_a"], r["lo_b"], sf) = struct.unpack_from("<IIII", buf, p); p += 16
+            r["fwd"] = (sf, rstr())
+            (sb,) = struct.unpack_from("<I", buf, p); p += 4
+            r["bwd"] = (sb, rstr())
+            (r["total"], r["mlo_a"], r["mlo_b"]) = struct.unpack_from("<III", buf, p); p += 12
+            r["path"] = rstr()
+            (r["evalue"], r["lddt"]) = struct.unpack_from("<II", buf, p); p += 8
+        recs.append(r)
+    assert p == len(buf)
+    return n, recs
+
+
 def read_tsv(name):
     with _open(name) as f:
         txt = f.read().decode()

@@ -143,3 +143,7 @@ for m in sensitive verysensitive; do
 done
 $R -search $TMP/taildb.bca -verysensitive -columns $COLS -output $TMP/tail_self_v.tsv -threads 1 -quiet >/dev/null 2>&1
 sort $TMP/tail_self_v.tsv | gzip -9n > $G/hits_taildb_self_verysensitive.tsv.gz
+# 13. the long-chain path stage by stage (chained HSPs, mega scores, XDropHSP start, XDropFwd / XDropBwd, MergeFwdBwd) for every
+#     long-chain pair of palms.bca, from the reference's own functions (checked against DSSAligner::AlignMKF inside the harness)
+$H xdrophsp $T/palms.bca $TMP/xdrophsp_palms.bin 39 -- -sensitive
+gzip -9n < $TMP/xdrophsp_palms.bin > $G/xdrophsp_palms_sensitive.bin.gz

@@ -82,3 +82,47 @@ def test_xdrop_pairs_rejects_bad_starts(ctx):
     with pytest.raises(RuntimeError):
         ctx.xdrop_pairs(db, db, [0], [1], [1], [chains[1].prof.shape[1]], 8.0, -0.685533, -0.051881)
     db.close()
+
+
+def test_long_chain_stages_match_the_reference(ctx):
+    """Direct fixture of the reference's long-chain path (oracle/ref_harness xdrophsp on palms.bca, every long-chain pair,
+    each stage from the reference's own GetMegaHSPScore / StaticSubstScore / XDropFwd / XDropBwd / MergeFwdBwd and checked
+    against DSSAligner::AlignMKF inside the harness):
+      * rsk_xdrop_pairs from the reference's start -> forward / backward score bits and paths;
+      * rsk_mkf_align_pairs from the reference's chained HSPs -> the start it derives (through the merged Lo), total score
+        bits, merged path, E-value and LDDT bits, and the MinMegaHSPScore / TotalScore gates."""
+    import reseek_amd
+    chains = fx.read_rskdb("palms_sensitive.rskdb.gz")
+    n, recs = fx.read_xdrophsp("xdrophsp_palms_sensitive.bin.gz")
+    assert n == len(chains)
+    db = reseek_amd.Db.from_chains(ctx, chains)
+    gated = [r for r in recs if r["gate"]]
+    assert len(gated) > 500
+    # 1. the two extensions from the reference's start
+    res = ctx.xdrop_pairs(db, db, [r["i"] for r in gated], [r["j"] for r in gated], [r["lo_a"] for r in gated], [r["lo_b"] for r in gated],
+                          8.0, -0.685533, -0.051881)
+    for r, (sf, pf, sb, pb) in zip(gated, res):
+        assert (bits(sf), pf) == r["fwd"], (r["i"], r["j"], "fwd")
+        assert (bits(sb), pb) == r["bwd"], (r["i"], r["j"], "bwd")
+    # 2. the whole device batch from the chained HSPs
+    have = [r for r in recs if len(r["chain"])]
+    first = np.concatenate([[0], np.cumsum([len(r["chain"]) for r in have])]).astype(np.uint32)
+    hsp = np.concatenate([r["chain"] for r in have]).astype(np.int32)
+    out, status = ctx.mkf_align_pairs(db, db, [r["i"] for r in have], [r["j"] for r in have], first, hsp[:, 0], hsp[:, 1], hsp[:, 2],
+                                      x2=8.0, min_mega_score=-4.0, min_fwd_score=7.0)
+    naln = 0
+    for r, (a, path), st in zip(have, out, status):
+        key = (r["i"], r["j"])
+        if not r["gate"] or r["best_chain_score"] <= 0:
+            assert st == 0 or r["best_chain_score"] <= 0, key          # the host drops BestChainScore <= 0 before the batch
+            if r["gate"] == 0:
+                assert a.path_len == 0, key
+            continue
+        assert st == 1, key
+        assert bits(a.score) == r["total"] and path == r["path"], key
+        if r["path"]:
+            assert (a.lo_a, a.lo_b) == (r["mlo_a"], r["mlo_b"]), key
+            assert bits(a.evalue) == r["evalue"] and bits(a.lddt) == r["lddt"], key
+            naln += 1
+    assert naln > 500
+    db.close()
