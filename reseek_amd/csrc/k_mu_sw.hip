@@ -39,6 +39,10 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 static const uint32_t musw_class_lqpad[MUSW_NCLASS] = { 416, 1024, 2048 };      // 30.8 KB, 75.8 KB, 151.6 KB
 static const uint32_t musw_class_waves[MUSW_NCLASS] = { 4, 8, 16 };
 #define MUSW_MAX_LQ 2048           // 64 strips of 32 rows (one pair per wave)
+// A workgroup item = MUSW_CHUNK wave-batches per wave of consecutive list positions of one query; the waves claim the
+// batches from an LDS counter, so a wave that is done early (reverse pass: early exit below) takes the next batch instead
+// of waiting at the item barrier for the slowest wave.
+#define MUSW_CHUNK 4
 
 __device__ __forceinline__ int dpp_wave_shr1(int x)
 {
@@ -62,6 +66,11 @@ struct musw_args {
     uint8_t *out;               // raw score min(best,255) with 255 = saturated
     size_t ldo;                 // dense: out[q*ldo + t];  CSR: out[rowstart[q] + k]
     uint32_t *counter;          // work counter (persistent workgroups)
+    // Reverse pass of the filter only (optional, aligned with `out`): the pair fails as soon as its running best exceeds
+    // thr = floor(fwd' - Omega) (fwd' - rev >= Omega <=> rev <= thr, parasail_mu.cpp:147-160, dssaligner.cpp:626), and the
+    // best only grows: a wave whose pairs have all failed stops.  The score it leaves (> thr, <= the true one) still fails
+    // in k_musw_survivors; pairs that pass are never cut short, so the reverse scores reported for survivors are exact.
+    const int16_t *thr;
 };
 
 typedef short v2s __attribute__((ext_vector_type(2)));
@@ -93,8 +102,10 @@ __global__ __launch_bounds__(1024) void k_mu_sw(musw_args a, uint32_t gmax)
     // P[((c*4 + k)*g + st)*4 + w]; a lane's four b128 reads per letter row are conflict-free across the strips of a pair
     int *prof = (int *) smem;
     signed char *mat = (signed char *) (prof + (size_t) 37 * gmax * 16);
-    uint32_t *wg_item = (uint32_t *) (mat + 1312);
+    uint32_t *wg_item = (uint32_t *) (mat + 1312);           // [0] item, [1] batch counter of the item
+    int *pbest = (int *) (wg_item + 4);                      // per wave 64 running pair maxima (early exit of the reverse pass)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t nwaves = blockDim.x >> 6;
 
     for (int i = tid; i < 1296; i += blockDim.x) mat[i] = (signed char) c_mu_int[i];
     uint32_t cur_q = 0xFFFFFFFFu;
@@ -103,7 +114,7 @@ __global__ __launch_bounds__(1024) void k_mu_sw(musw_args a, uint32_t gmax)
 
     for (;;) {
         __syncthreads();
-        if (tid == 0) wg_item[0] = atomicAdd(a.counter, 1u);
+        if (tid == 0) { wg_item[0] = atomicAdd(a.counter, 1u); wg_item[1] = 0; }
         __syncthreads();
         const uint32_t item = wg_item[0];
         if (item >= nitems) break;
@@ -128,10 +139,16 @@ __global__ __launch_bounds__(1024) void k_mu_sw(musw_args a, uint32_t gmax)
             __syncthreads();
         }
         const uint32_t ppw = 64 / g;                 // pairs per wave (g <= 64 guaranteed by the host)
-        const uint32_t k0 = it.y + wave * ppw;       // first list position of this wave
         const uint32_t cnt = a.cnt[q];
+        const uint32_t chunk_end = min(cnt, it.y + ppw * nwaves * MUSW_CHUNK);
         const uint32_t pr = lane / g, st = lane - pr * g;     // pair slot and strip of this lane
-        const bool active = (pr < ppw) && (k0 + pr < cnt);
+        for (;;) {                                   // batches of ppw consecutive list positions, claimed by the waves
+        uint32_t bq = 0;
+        if (lane == 0) bq = atomicAdd(&wg_item[1], 1u);
+        bq = (uint32_t) __builtin_amdgcn_readfirstlane((int) bq);
+        const uint32_t k0 = it.y + bq * ppw;         // first list position of this batch
+        if (k0 >= chunk_end) break;
+        const bool active = (pr < ppw) && (k0 + pr < chunk_end);
         uint32_t t = 0, LB = 0;
         const uint8_t *B = a.t_mu;
         if (active) {
@@ -200,10 +217,22 @@ __global__ __launch_bounds__(1024) void k_mu_sw(musw_args a, uint32_t gmax)
             bot_h = Hout[15];
             bot_f = F;
         };
+        int thr_l = -1;                               // inactive lanes count as decided
+        if (a.thr) {
+            if (active) thr_l = a.thr[a.rowstart[q] + k0 + pr];
+            pbest[wave * 64 + lane] = 0;
+        }
         // an odd step count is rounded up: the extra step only sees pad letters / finished columns
         for (uint32_t col = 0; col < ncol; col += 2) {
             step(HA, HB, col);
             step(HB, HA, col + 1);
+            if (a.thr && (col & 6) == 6) {           // every 8 columns: has every pair of this wave failed already?
+                const int mine = max(best & 0xFFFF, (int) ((unsigned) best >> 16));
+                __hip_atomic_fetch_max(&pbest[wave * 64 + pr], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                const int pb = pbest[wave * 64 + pr];
+                if (__ballot(pb <= thr_l) == 0ull) break;
+            }
         }
         int red = max(best & 0xFFFF, (int) ((unsigned) best >> 16));
         best = red;
@@ -217,6 +246,7 @@ __global__ __launch_bounds__(1024) void k_mu_sw(musw_args a, uint32_t gmax)
             else if (a.tri) a.out[(size_t) min(q, t) * a.ldo + max(q, t)] = v;
             else a.out[(size_t) q * a.ldo + t] = v;
         }
+        }   // batches
     }
 }
 
@@ -299,7 +329,7 @@ __global__ __launch_bounds__(1024) void k_musw_scan_items(const uint32_t *q_len,
             if (cls == 4) v = cnt[q];                          // slow path: one item per pair
             else {
                 const uint32_t g = (LQ + MUSW_R - 1) / MUSW_R;
-                const uint32_t per_wg = (64 / g) * musw_waves(cls);
+                const uint32_t per_wg = (64 / g) * musw_waves(cls) * MUSW_CHUNK;
                 v = (cnt[q] + per_wg - 1) / per_wg;
             }
         }
@@ -340,7 +370,7 @@ __global__ void k_musw_fill_items(const uint32_t *q_len, const uint32_t *cnt, co
         return;
     }
     const uint32_t g = (LQ + MUSW_R - 1) / MUSW_R;
-    const uint32_t per_wg = (64 / g) * musw_waves(cls);
+    const uint32_t per_wg = (64 / g) * musw_waves(cls) * MUSW_CHUNK;
     for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) items[item_start[q] + k] = make_uint2(q, k * per_wg);
 }
 
@@ -351,7 +381,7 @@ __global__ void k_musw_fill_items(const uint32_t *q_len, const uint32_t *cnt, co
 __global__ __launch_bounds__(256) void k_musw_candidates(const uint8_t *fwd, size_t ldo, const uint32_t *first, const uint32_t *cnt,
                                                          const uint32_t *perm, int tri,
                                                          uint32_t nq, float omega_fwd, int pass, uint32_t *ccnt,
-                                                         const uint32_t *rowstart, uint32_t *list)
+                                                         const uint32_t *rowstart, uint32_t *list, int16_t *thr, float omega)
 {
     const uint32_t q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (q >= nq) return;
@@ -362,14 +392,19 @@ __global__ __launch_bounds__(256) void k_musw_candidates(const uint8_t *fwd, siz
         const uint32_t kk = k + lane;
         bool c = false;
         uint32_t t = 0;
+        float f = 0.0f;
         if (kk < n) {
             t = perm[f0 + kk];
             const int raw = tri ? fwd[(size_t) min(q, t) * ldo + max(q, t)] : fwd[(size_t) q * ldo + t];
-            const float f = raw == 255 ? 777.0f : (float) raw;     // parasail_mu.cpp:135-139
+            f = raw == 255 ? 777.0f : (float) raw;                 // parasail_mu.cpp:135-139
             c = !(f < omega_fwd);                                    // :141-146
         }
         const unsigned long long m = __ballot(c);
-        if (pass == 1 && c) list[rowstart[q] + run + __popcll(m & ((1ull << lane) - 1ull))] = t;
+        if (pass == 1 && c) {
+            const uint32_t pos = rowstart[q] + run + __popcll(m & ((1ull << lane) - 1ull));
+            list[pos] = t;
+            if (thr) thr[pos] = (int16_t) fminf(fmaxf(floorf(f - omega), -1.0f), 32767.0f);   // rev <= thr <=> fwd' - rev >= Omega
+        }
         run += (uint32_t) __popcll(m);
     }
     if (pass == 0 && lane == 0) ccnt[q] = run;
@@ -498,7 +533,7 @@ static int run_mu_sw_lists(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, musw_
         if (cls < MUSW_NCLASS) {
             const uint32_t gmax = musw_class_lqpad[cls] / MUSW_R;
             const uint32_t waves = musw_class_waves[cls];
-            const size_t lds = (size_t) 37 * gmax * 64 + 1312 + 16;
+            const size_t lds = (size_t) 37 * gmax * 64 + 1312 + 16 + (size_t) waves * 256;
             static std::atomic<int> attr_set[64];
             const int arc = rsk_once_per_device(attr_set, ctx->device, [&]() -> int {
                 RSK_HIP(hipFuncSetAttribute((const void *) k_mu_sw, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
@@ -532,7 +567,7 @@ static uint32_t item_exact_implicit(const rsk_db *q, uint32_t nt, int self_trian
         const uint64_t cnt = self_triangle ? nt - q->h_len_rank[i] : nt;
         if (L > MUSW_MAX_LQ) { n += cnt; continue; }
         const uint32_t g = (L + MUSW_R - 1) / MUSW_R, lp = g * MUSW_R;
-        const uint32_t per_wg = (64 / g) * (lp <= 416 ? 4u : lp <= 1024 ? 8u : 16u);
+        const uint32_t per_wg = (64 / g) * (lp <= 416 ? 4u : lp <= 1024 ? 8u : 16u) * MUSW_CHUNK;
         n += (cnt + per_wg - 1) / per_wg;
     }
     return (uint32_t) std::min<uint64_t>(n, 0xFFFFFFF0ull);
@@ -634,7 +669,7 @@ extern "C" int rsk_mu_filter_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t,
     if ((rc = ws.alloc(&ccnt, nq)) != RSK_OK) return rc;
     if ((rc = ws.alloc(&rowstart, (size_t) nq + 1)) != RSK_OK) return rc;
     hipLaunchKernelGGL(k_musw_candidates, dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, d_fwd, ldo, ws.first, ws.cnt, a.perm, a.tri, nq, omega_fwd,
-                       0, ccnt, (const uint32_t *) nullptr, (uint32_t *) nullptr);
+                       0, ccnt, (const uint32_t *) nullptr, (uint32_t *) nullptr, (int16_t *) nullptr, omega);
     hipLaunchKernelGGL(k_exclusive_scan_u32, dim3(1), dim3(1024), 0, ctx->stream, ccnt, nq, rowstart);
     uint32_t ncand = 0;
     RSK_HIP(hipMemcpyAsync(&ncand, rowstart + nq, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -642,13 +677,16 @@ extern "C" int rsk_mu_filter_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t,
     ctx->mf_pairs = total;
     ctx->mf_candidates = ncand;
     if (ncand) {
+        int16_t *thr = nullptr;
+        const bool early = !(getenv("RSK_MUSW_EARLY_EXIT") && atoi(getenv("RSK_MUSW_EARLY_EXIT")) == 0);
         if ((rc = ws.alloc(&list, ncand)) != RSK_OK) return rc;
         if ((rc = ws.alloc(&rev, ncand)) != RSK_OK) return rc;
+        if (early && (rc = ws.alloc(&thr, ncand)) != RSK_OK) return rc;
         hipLaunchKernelGGL(k_musw_candidates, dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, d_fwd, ldo, ws.first, ws.cnt, a.perm, a.tri, nq,
-                           omega_fwd, 1, ccnt, rowstart, list);
+                           omega_fwd, 1, ccnt, rowstart, list, thr, omega);
         musw_args b = a;
         b.cnt = ccnt; b.first = nullptr; b.list = list; b.rowstart = rowstart;
-        b.reverse = 1; b.out = rev;
+        b.reverse = 1; b.out = rev; b.thr = thr;
         if ((rc = run_mu_sw_lists(ctx, q, t, b, item_upper_bound(q, ncand), ws2)) != RSK_OK) return rc;
         hipLaunchKernelGGL(k_musw_survivors, dim3((nq + 3) / 4), dim3(256), 0, ctx->stream, d_fwd, ldo, a.tri, ccnt, rowstart, list, rev, nq,
                            omega, d_pairs_q, d_pairs_t, d_pairs_fwd, d_pairs_rev, (uint32_t) capacity, d_npairs);
@@ -662,7 +700,8 @@ extern "C" int rsk_mu_filter_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t,
 // Pair-list form of the filter (DSSAligner::AlignMuParaBags parasail_mu.cpp:183 as PostMuFilter calls it per
 // (query, target) candidate, chainbag.cpp:68-74): host arrays in, per-pair verdict out.
 static int musw_run_pairlist(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, const uint32_t *iq, const uint32_t *it,
-                             const std::vector<uint32_t> &sel, int reverse, int gap_open, int gap_ext, std::vector<uint8_t> &raw)
+                             const std::vector<uint32_t> &sel, int reverse, int gap_open, int gap_ext, std::vector<uint8_t> &raw,
+                             const std::vector<int16_t> *thr_sel = nullptr)      // early-exit thresholds of the reverse pass, aligned with sel
 {
     // CSR by query; within a query the targets by increasing length (the pairs of a wave then end together)
     const size_t n = sel.size();
@@ -703,6 +742,15 @@ static int musw_run_pairlist(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, con
     a.cnt = d_cnt; a.first = nullptr; a.perm = nullptr; a.tri = 0; a.list = d_list; a.rowstart = d_rowstart;
     a.reverse = reverse; a.open = gap_open; a.ext = gap_ext;
     a.out = d_out; a.ldo = 0;
+    std::vector<int16_t> thr_sorted;
+    if (thr_sel) {
+        int16_t *d_thr = nullptr;
+        thr_sorted.resize(n);
+        for (size_t k = 0; k < n; ++k) thr_sorted[k] = (*thr_sel)[ord[k]];
+        if ((rc = ws.alloc(&d_thr, n)) != RSK_OK) return rc;
+        RSK_HIP(hipMemcpyAsync(d_thr, thr_sorted.data(), n * 2, hipMemcpyHostToDevice, ctx->stream));
+        a.thr = d_thr;
+    }
     if ((rc = run_mu_sw_lists(ctx, q, t, a, item_upper_bound(q, n), ws)) != RSK_OK) return rc;
     std::vector<uint8_t> sorted_raw(n);
     RSK_HIP(hipMemcpyAsync(sorted_raw.data(), d_out, n, hipMemcpyDeviceToHost, ctx->stream));
@@ -733,7 +781,17 @@ extern "C" int rsk_mu_filter_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *
         const float f = rawf[p] == 255 ? 777.0f : (float) rawf[p];          // parasail_mu.cpp:135-139
         if (!(f < omega_fwd)) cand.push_back((uint32_t) p);                  // :141-146
     }
-    if ((rc = musw_run_pairlist(ctx, q, t, iq, it, cand, 1, gap_open, gap_ext, rawr)) != RSK_OK) return rc;
+    // the caller does not ask for the reverse scores: pairs that have failed may stop early (see musw_args::thr)
+    std::vector<int16_t> thr;
+    const bool early = !rev && !(getenv("RSK_MUSW_EARLY_EXIT") && atoi(getenv("RSK_MUSW_EARLY_EXIT")) == 0);
+    if (early) {
+        thr.resize(cand.size());
+        for (size_t c2 = 0; c2 < cand.size(); ++c2) {
+            const float f = rawf[cand[c2]] == 255 ? 777.0f : (float) rawf[cand[c2]];
+            thr[c2] = (int16_t) std::min(std::max(floorf(f - omega), -1.0f), 32767.0f);
+        }
+    }
+    if ((rc = musw_run_pairlist(ctx, q, t, iq, it, cand, 1, gap_open, gap_ext, rawr, early ? &thr : nullptr)) != RSK_OK) return rc;
     RSK_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     size_t c = 0;
     for (size_t p = 0; p < npairs; ++p) {

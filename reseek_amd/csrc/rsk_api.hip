@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <chrono>
 #include <memory>
 #include <cfloat>
 
@@ -77,7 +78,12 @@ int rsk_pool_alloc(rsk_ctx *ctx, void **p, size_t bytes)
         ctx->pool_live[*p] = actual;
         return RSK_OK;
     }
+    static const bool trace = getenv("RSK_TRACE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(p, cls);
+    if (trace && cls >= (64u << 20))
+        fprintf(stderr, "[pool] hipMalloc %.2f GB (pool of this context %.2f GB) took %.2f ms\n", cls / 1073741824.0, ctx->pool_bytes / 1073741824.0,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     if (e != hipSuccess) {
         rsk_pool_release(ctx);                       // drop cached blocks and retry once
         e = hipMalloc(p, cls);
