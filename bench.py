@@ -489,7 +489,7 @@ def main():
         # (FETCH_SIZE doubled on gfx950 as MI355X_MICROARCH.md prescribes; separate --pmc passes)
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01f_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r02u_traffic.json")) as f:
                 tj = json.load(f)
             if n == 11211 and not args.chains:
                 traffic = float(tj["traffic_bytes_per_launch"])
@@ -519,7 +519,7 @@ def main():
                 "hbm": {"bound": "hbm", "achieved": alg_bytes / (kernel_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
                         "unit": "GB/s", "frac": alg_bytes / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                         "algorithmic_bytes": alg_bytes, "traffic": traffic},
-                "traffic": traffic, "traffic_source": "profiles/r01f_traffic.json (rocprofv3 PMC, same workload)" if traffic else None},
+                "traffic": traffic, "traffic_source": "profiles/r02u_traffic.json (rocprofv3 PMC, same workload)" if traffic else None},
         }
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(seqs)
