@@ -5,39 +5,74 @@
 //                              HSPs with score >= MinHSPScore that STRICTLY improve on the best so far and
 //                              start at a new query position are kept, in (PosT, slot) order.
 // Every pair of the MKF path runs this stage; only the few pairs with a kept HSP go on to chaining and the
-// gapped float X-drop (host/dssaligner.cpp).  MI355X layout: one table per query chain that occurs in
-// the batch (373 KB each: a SCOP40-sized set is 4 GB of 288), one wave per pair: the lanes take 64
-// consecutive target positions, look up their four candidate query positions with one 8-byte load
-// and extend them; the order-dependent keep rule is resolved by walking the (rare) lanes that beat
+// gapped float X-drop (host/dssaligner.cpp).  MI355X layout: one compact hash table per query chain
+// that occurs in the batch (same content as the reference's 46656 x 4 table, 32-64 bytes per residue),
+// one wave per pair: the lanes take 64 consecutive target positions, look up their four candidate
+// query positions with one 16-byte probe (load factor <= 0.5) and extend them; the order-dependent keep rule is resolved by walking the (rare) lanes that beat
 // the running best in lane order.  Integer work, L2-resident letters; bound: table-probe latency.
 #include <algorithm>
 #include <vector>
 
 #include "rsk_dev_tables.h"
 
-#define MKF_DICT 46656u            // 36^3
 #define MKF_HASHW 4
 #define MKF_WAVES 4
 
+// Table of one query chain: open addressing, 2^bits >= 2 * (L - 2) slots of 16 bytes
+//   { k-mer, pos0 | pos1 << 16, pos2 | pos3 << 16, unused },   empty slot: k-mer = MKF_EMPTY, unused positions 0xFFFF.
+// The content equals the reference's 46656 x 4 table (first four positions of each k-mer, in chain order) but takes 32-64
+// bytes per residue instead of 373 KB per chain, so the tables of a whole database batch stay in L2.
+#define MKF_EMPTY 0xFFFFFFFFu
+#define MKF_MIN_BITS 6
+#define MKF_LDS_BITS 11            // tables up to 2^11 slots (32 KB) are assembled in LDS and copied out
+
+__device__ __forceinline__ uint32_t mkf_hash(uint32_t k, uint32_t bits) { return (k * 2654435761u) >> (32 - bits); }
+
+template <typename TAB>
+__device__ __forceinline__ void mkf_insert_all(TAB *T, uint32_t bits, const uint8_t *Q, uint32_t L)
+{
+    const uint32_t mask = (1u << bits) - 1;
+    for (uint32_t p = 0; p + 3 <= L; ++p) {
+        const uint32_t k = ((uint32_t) Q[p] * 36 + Q[p + 1]) * 36 + Q[p + 2];
+        uint32_t h = mkf_hash(k, bits);
+        for (;;) {
+            uint4 e = T[h];
+            if (e.x == MKF_EMPTY) { e.x = k; e.y = 0xFFFF0000u | p; T[h] = e; break; }
+            if (e.x == k) {
+                if ((e.y >> 16) == 0xFFFFu) e.y = (e.y & 0xFFFFu) | (p << 16);
+                else if ((e.z & 0xFFFFu) == 0xFFFFu) e.z = 0xFFFF0000u | p;
+                else if ((e.z >> 16) == 0xFFFFu) e.z = (e.z & 0xFFFFu) | (p << 16);
+                else break;                                       // already four positions: first come, first kept
+                T[h] = e;
+                break;
+            }
+            h = (h + 1) & mask;
+        }
+    }
+}
+
 // one workgroup per listed query: clear its table, then insert positions in order (first come, <= 4 per k-mer)
 __global__ __launch_bounds__(256) void k_mkf_build(const uint8_t *q_mu, const uint32_t *q_off, const uint32_t *q_len, const uint32_t *qlist,
-                                                   uint16_t *tables)
+                                                   const uint32_t *tab_off, const uint8_t *tab_bits, uint4 *tables)
 {
     const uint32_t q = qlist[blockIdx.x];
-    uint16_t *T = tables + (size_t) blockIdx.x * MKF_DICT * MKF_HASHW;
-    uint4 *T4 = (uint4 *) T;
-    const uint4 ff = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-    for (uint32_t i = threadIdx.x; i < MKF_DICT * MKF_HASHW * 2 / 16; i += blockDim.x) T4[i] = ff;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint8_t *Q = q_mu + q_off[q];
-        const uint32_t L = q_len[q];
-        for (uint32_t p = 0; p + 3 <= L; ++p) {
-            const uint32_t k = ((uint32_t) Q[p] * 36 + Q[p + 1]) * 36 + Q[p + 2];
-            uint16_t *s = T + (size_t) k * MKF_HASHW;
-            for (int w = 0; w < MKF_HASHW; ++w)
-                if (s[w] == 0xFFFF) { s[w] = (uint16_t) p; break; }
-        }
+    const uint32_t bits = tab_bits[blockIdx.x];
+    uint4 *T = tables + tab_off[blockIdx.x];
+    const uint32_t H = 1u << bits;
+    const uint4 ff = make_uint4(MKF_EMPTY, 0xFFFFFFFFu, 0xFFFFFFFFu, 0);
+    const uint8_t *Q = q_mu + q_off[q];
+    const uint32_t L = q_len[q];
+    __shared__ uint4 S[1u << MKF_LDS_BITS];
+    if (bits <= MKF_LDS_BITS) {
+        for (uint32_t i = threadIdx.x; i < H; i += blockDim.x) S[i] = ff;
+        __syncthreads();
+        if (threadIdx.x == 0) mkf_insert_all(S, bits, Q, L);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < H; i += blockDim.x) T[i] = S[i];
+    } else {
+        for (uint32_t i = threadIdx.x; i < H; i += blockDim.x) T[i] = ff;
+        __syncthreads();
+        if (threadIdx.x == 0) mkf_insert_all(T, bits, Q, L);
     }
 }
 
@@ -68,7 +103,9 @@ struct mkf_args {
     const uint8_t *t_mu; const uint32_t *t_off; const uint32_t *t_len;
     const uint32_t *iq, *it;           // pairs
     const uint32_t *qslot;             // table index of each pair's query
-    const uint16_t *tables;
+    const uint32_t *tab_off;           // per table: first slot in `tables`
+    const uint8_t *tab_bits;           // per table: log2 of its slot count
+    const uint4 *tables;
     uint32_t pair_lo, pair_hi;         // this launch handles the pairs [pair_lo, pair_hi) of the call
     int X, min_score;
     uint32_t cap;                      // kept HSPs stored per record (<= MKF_CAP_MAX)
@@ -88,7 +125,8 @@ __global__ __launch_bounds__(64 * MKF_WAVES) void k_mkf_seed(mkf_args a)
     const uint32_t q = a.iq[p], t = a.it[p];
     const uint8_t *Q = a.q_mu + a.q_off[q], *T = a.t_mu + a.t_off[t];
     const int LQ = (int) a.q_len[q], LT = (int) a.t_len[t];
-    const uint16_t *tab = a.tables + (size_t) a.qslot[p] * MKF_DICT * MKF_HASHW;
+    const uint32_t slot = a.qslot[p], bits = a.tab_bits[slot], hmask = (1u << bits) - 1;
+    const uint4 *tab = a.tables + a.tab_off[slot];
     __shared__ int4 skept[MKF_WAVES][MKF_CAP_MAX];
     int4 *kept = skept[threadIdx.x >> 6];
     int best = 0;
@@ -102,8 +140,11 @@ __global__ __launch_bounds__(64 * MKF_WAVES) void k_mkf_seed(mkf_args a)
         for (int w = 0; w < MKF_HASHW; ++w) sc[w] = 0;
         if (PosT + 3 <= LT) {
             const uint32_t k = ((uint32_t) T[PosT] * 36 + T[PosT + 1]) * 36 + T[PosT + 2];
-            const uint2 s = *(const uint2 *) (tab + (size_t) k * MKF_HASHW);
-            const uint32_t pos[4] = { s.x & 0xFFFFu, s.x >> 16, s.y & 0xFFFFu, s.y >> 16 };
+            uint32_t h = mkf_hash(k, bits);
+            uint4 s = tab[h];
+            while (s.x != k && s.x != MKF_EMPTY) { h = (h + 1) & hmask; s = tab[h]; }
+            if (s.x != k) s.y = s.z = 0xFFFFFFFFu;
+            const uint32_t pos[4] = { s.y & 0xFFFFu, s.y >> 16, s.z & 0xFFFFu, s.z >> 16 };
 #pragma unroll
             for (int w = 0; w < MKF_HASHW; ++w) {
                 if (pos[w] == 0xFFFFu) continue;
@@ -166,31 +207,40 @@ extern "C" int rsk_mkf_seed_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t
     RSK_HIP(hipSetDevice(ctx->device));
     int rc = rsk_upload_mu_tables(ctx);
     if (rc != RSK_OK) return rc;
-    // distinct queries -> table slots.  One 373 KB table per distinct query; the pairs are cut into consecutive chunks of
-    // at most `budget` distinct queries (24 GB of tables) that reuse one table block, so a call whose query side is a whole
-    // database (-db mode with a long query: every DB chain is a distinct iq) is bounded whatever the database size.
-    const size_t budget = getenv("RSK_MKF_MAX_TABLES") ? (size_t) std::max(1, atoi(getenv("RSK_MKF_MAX_TABLES"))) : 65536;
+    // distinct queries -> tables.  A table takes 16 bytes x 2^bits slots (2^bits >= 2 (L - 2)); the pairs are cut into
+    // consecutive chunks whose tables fit a byte budget (and a table-count budget, RSK_MKF_MAX_TABLES) and reuse one block,
+    // so a call whose query side is a whole database (-db mode with a long query: every DB chain is a distinct iq) is
+    // bounded whatever the database size.
+    const size_t budget = getenv("RSK_MKF_MAX_TABLES") ? (size_t) std::max(1, atoi(getenv("RSK_MKF_MAX_TABLES"))) : (size_t) 1 << 22;
+    const size_t slot_budget = (size_t) 1 << 29;                 // 8 GB of 16-byte slots
     struct chunk_t { size_t p0, p1, q0, q1; };
     std::vector<chunk_t> chunks;
-    std::vector<uint32_t> slot_of(q->n, 0xFFFFFFFFu), qlist, qslot(npairs);
+    std::vector<uint32_t> slot_of(q->n, 0xFFFFFFFFu), qlist, qslot(npairs), tab_off;
+    std::vector<uint8_t> tab_bits;
+    size_t max_slots = 0;
     {
-        size_t p0 = 0, q0 = 0;
+        size_t p0 = 0, q0 = 0, slots = 0;
         for (size_t p = 0; p < npairs; ++p) {
             if (slot_of[iq[p]] == 0xFFFFFFFFu) {
-                if (qlist.size() - q0 == budget) {          // close the chunk before this pair
+                const uint32_t L = q->len[iq[p]], nk = L >= 3 ? L - 2 : 0;
+                uint32_t bits = MKF_MIN_BITS;
+                while ((1u << bits) < 2 * nk) ++bits;
+                if (qlist.size() - q0 == budget || (slots && slots + ((size_t) 1 << bits) > slot_budget)) {   // close the chunk before this pair
                     chunks.push_back({ p0, p, q0, qlist.size() });
                     for (size_t k = q0; k < qlist.size(); ++k) slot_of[qlist[k]] = 0xFFFFFFFFu;
-                    p0 = p; q0 = qlist.size();
+                    p0 = p; q0 = qlist.size(); slots = 0;
                 }
-                slot_of[iq[p]] = (uint32_t) (qlist.size() - q0);
+                slot_of[iq[p]] = (uint32_t) qlist.size();
                 qlist.push_back(iq[p]);
+                tab_off.push_back((uint32_t) slots);
+                tab_bits.push_back((uint8_t) bits);
+                slots += (size_t) 1 << bits;
+                max_slots = std::max(max_slots, slots);
             }
             qslot[p] = slot_of[iq[p]];
         }
         chunks.push_back({ p0, npairs, q0, qlist.size() });
     }
-    size_t max_tables = 0;
-    for (const chunk_t &c : chunks) max_tables = std::max(max_tables, c.q1 - c.q0);
     struct ws_t {
         rsk_ctx *ctx;
         std::vector<void *> all;
@@ -202,15 +252,17 @@ extern "C" int rsk_mkf_seed_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t
         ws.all.push_back(*p);
         return RSK_OK;
     };
-    uint32_t *d_iq, *d_it, *d_qslot, *d_qlist, *d_nrec, *d_rpair, *d_rnk;
-    uint16_t *d_tab;
-    uint8_t *d_found;
+    uint32_t *d_iq, *d_it, *d_qslot, *d_qlist, *d_toff, *d_nrec, *d_rpair, *d_rnk;
+    uint4 *d_tab;
+    uint8_t *d_found, *d_tbits;
     int4 *d_rkept;
     if ((rc = dalloc((void **) &d_iq, npairs * 4)) != RSK_OK) return rc;
     if ((rc = dalloc((void **) &d_it, npairs * 4)) != RSK_OK) return rc;
     if ((rc = dalloc((void **) &d_qslot, npairs * 4)) != RSK_OK) return rc;
     if ((rc = dalloc((void **) &d_qlist, qlist.size() * 4)) != RSK_OK) return rc;
-    if ((rc = dalloc((void **) &d_tab, max_tables * (size_t) MKF_DICT * MKF_HASHW * 2)) != RSK_OK) return rc;
+    if ((rc = dalloc((void **) &d_toff, qlist.size() * 4)) != RSK_OK) return rc;
+    if ((rc = dalloc((void **) &d_tbits, qlist.size())) != RSK_OK) return rc;
+    if ((rc = dalloc((void **) &d_tab, max_slots * sizeof(uint4))) != RSK_OK) return rc;
     if ((rc = dalloc((void **) &d_found, npairs)) != RSK_OK) return rc;
     if ((rc = dalloc((void **) &d_nrec, 4)) != RSK_OK) return rc;
     if ((rc = dalloc((void **) &d_rpair, max_records * 4)) != RSK_OK) return rc;
@@ -220,17 +272,20 @@ extern "C" int rsk_mkf_seed_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t
     RSK_HIP(hipMemcpyAsync(d_it, it, npairs * 4, hipMemcpyHostToDevice, ctx->stream));
     RSK_HIP(hipMemcpyAsync(d_qslot, qslot.data(), npairs * 4, hipMemcpyHostToDevice, ctx->stream));
     RSK_HIP(hipMemcpyAsync(d_qlist, qlist.data(), qlist.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    RSK_HIP(hipMemcpyAsync(d_toff, tab_off.data(), qlist.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    RSK_HIP(hipMemcpyAsync(d_tbits, tab_bits.data(), qlist.size(), hipMemcpyHostToDevice, ctx->stream));
     RSK_HIP(hipMemsetAsync(d_nrec, 0, 4, ctx->stream));
     RSK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     mkf_args a = {};
     a.q_mu = q->d_mu; a.q_off = q->d_off; a.q_len = q->d_len;
     a.t_mu = t->d_mu; a.t_off = t->d_off; a.t_len = t->d_len;
-    a.iq = d_iq; a.it = d_it; a.qslot = d_qslot; a.tables = d_tab;
+    a.iq = d_iq; a.it = d_it; a.qslot = d_qslot; a.tab_off = d_toff; a.tab_bits = d_tbits; a.tables = d_tab;
     a.X = x1; a.min_score = min_hsp_score; a.cap = cap;
     a.found = d_found; a.nrec = d_nrec; a.max_rec = (uint32_t) max_records;
     a.rec_pair = d_rpair; a.rec_nkept = d_rnk; a.rec_kept = d_rkept;
     for (const chunk_t &c : chunks) {                       // same stream: a chunk's tables are rebuilt after its seeding kernel is done
-        hipLaunchKernelGGL(k_mkf_build, dim3((unsigned) (c.q1 - c.q0)), dim3(256), 0, ctx->stream, q->d_mu, q->d_off, q->d_len, d_qlist + c.q0, d_tab);
+        hipLaunchKernelGGL(k_mkf_build, dim3((unsigned) (c.q1 - c.q0)), dim3(256), 0, ctx->stream, q->d_mu, q->d_off, q->d_len, d_qlist + c.q0,
+                           d_toff + c.q0, d_tbits + c.q0, d_tab);
         a.pair_lo = (uint32_t) c.p0; a.pair_hi = (uint32_t) c.p1;
         hipLaunchKernelGGL(k_mkf_seed, dim3((unsigned) ((c.p1 - c.p0 + MKF_WAVES - 1) / MKF_WAVES)), dim3(64 * MKF_WAVES), 0, ctx->stream, a);
     }
@@ -241,6 +296,12 @@ extern "C" int rsk_mkf_seed_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t
     RSK_HIP(hipMemcpyAsync(&nrec, d_nrec, 4, hipMemcpyDeviceToHost, ctx->stream));
     RSK_HIP(hipStreamSynchronize(ctx->stream));
     *nrecords = nrec;
+    if (getenv("RSK_TRACE")) {
+        float ms = 0;
+        (void) hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+        fprintf(stderr, "[rsk_mkf_seed_pairs] %zu pairs, %zu tables in %zu chunk(s), %.1f MB of tables, kernels %.2f ms\n", npairs, qlist.size(),
+                chunks.size(), max_slots * 16 / 1048576.0, ms);
+    }
     const size_t m = std::min<size_t>(nrec, max_records);
     if (m) {
         RSK_HIP(hipMemcpyAsync(rec_pair, d_rpair, m * 4, hipMemcpyDeviceToHost, ctx->stream));
