@@ -11,17 +11,18 @@
 //   fwd - rev >= Omega.
 //
 // MI355X design (integer VALU bound; no GEMM, almost no HBM traffic):
-//   * one workgroup = one query chain x a batch of target chains.  The query profile
-//     prof[c][i] = s(c, a_i) (int32, 37 letter rows, padded stride) lives in LDS (replaces the
-//     striped int8 AVX2 profile of SetMuQP_Para parasail_mu.cpp:163).
-//   * the query is cut into strips of R = 32 rows; a strip's H/E values stay in VGPRs.  The
-//     g = ceil(LQ/32) strips of ONE pair sit on g CONSECUTIVE LANES that run one column behind
-//     each other (systolic array): lane k hands the bottom-row (H, F) of its strip to lane k+1 with
+//   * one workgroup = one query chain x a batch of target chains.  The query profile (packed int16, 37 letter
+//     rows, two query rows per dword) lives in LDS (replaces the striped int8 AVX2 profile of SetMuQP_Para
+//     parasail_mu.cpp:163).
+//   * the query is cut into strips of R = 32 rows; a strip's H/E values stay in 16 VGPRs of packed int16 (row r low,
+//     row r + 16 high, see the kernel).  The g = ceil(LQ/32) strips of ONE pair sit on g CONSECUTIVE LANES that run
+//     behind each other (systolic array): lane k hands the bottom-row (H, F) of its strip to lane k+1 with
 //     a single v_mov_b32_dpp wave_shr:1 per column -- no scratch memory, no LDS hand-off.
 //     A wave therefore works on floor(64/g) targets at once.
-//   * per column a lane fetches its 32 profile scores with eight ds_read_b128 (row = its target
-//     letter; every strip record is padded to 36 ints = 9 sixteen-byte slots so the strips of a pair hit distinct LDS banks).
-//   * all per-cell ops are 32-bit VOP2 (full issue rate on gfx950; VOP3/VOP3P issue at half rate).
+//   * per column a lane fetches the 32 profile scores of its strip with four ds_read_b128 (row = its target letter;
+//     the strips of a pair are 16 B apart, conflict-free).
+//   * two cells per VALU op (v_pk_add_i16 / v_pk_max_i16 / v_pk_sub_u16 clamp): 10 ops per cell pair.
+//   * reverse pass of the filter: exact early exit once every pair of the wave has failed (musw_args.thr).
 //   * persistent workgroups pull (query, target batch) items from a device-side queue that is
 //     also built on the device (the reverse pass runs on data-dependent survivor lists).
 #include <algorithm>

@@ -330,18 +330,33 @@ __global__ __launch_bounds__(64 * SWF_WAVES) __attribute__((amdgpu_waves_per_eu(
 // stored as records of R consecutive residues, so that a lane fetches the S-contributions of its
 // whole strip for one feature with R/4 ds_read_b128 and no per-cell address arithmetic
 // (the legacy kernel above spends 8 ds_read_b32 + 16 address ops per cell).  Waves claim batches
-// of floor(64/g) pairs from an LDS counter.  Trace: 5 comparison bits per cell, shifted into a
-// dword by v_cmp + v_addc_co (6 cells per dword), W = ceil(R/6) dwords per lane and column.
+// of floor(64/g) pairs from an LDS counter.
+// Trace: the 5 comparisons of a cell are v_cmp's that write their 64-lane masks to SGPR pairs, and the masks leave
+// the wave through SCALAR stores (s_store_dwordx4, two masks each): no VALU op folds bits into a word and no
+// vector store carries them (round 1 shifted them into a dword with v_addc_co, 5 extra VALU ops per cell, and
+// wrote 8 B per lane and column at a lane stride).  The trace of a wave batch is a block of [column][row][bit]
+// qwords (SWQ_COL_BYTES per column), bit `lane` of a qword = that lane's cell; k_traceback picks its lane's bit.
 // ---------------------------------------------------------------------------------------------
 #define SWQ_R 12
-#define SWQ_W ((SWQ_R + 5) / 6)
+#define SWQ_COL_BYTES (SWQ_R * 5 * 8)             // trace of one column of a wave batch: R rows x 5 masks of 64 lanes
 #define SWQ_NW 16
 #define SWQ_NFC 132                               // 20 + 7 * 16 (feature, step letter) combinations
 #define SWQ_MAX_G ((163840 - 256) / (SWQ_NFC * SWQ_R * 4))
 #define SWQ_MAX_L (SWQ_MAX_G * SWQ_R)
 #define SWQ_LDS_BYTES(G) ((size_t) SWQ_NFC * (SWQ_R / 4) * (G) * 16 + 16)
 
-struct swq_item { uint32_t first, count; };
+// one workgroup item: `count` consecutive pairs (sorted order) of one group.  Its trace blocks, one per (segment, wave
+// batch), are ncol columns each and start at tb + tb_base: block (seg, b) is number seg * nb_full + b, nb_full = the
+// batches of a full segment (every segment before the last has SWQ_MAX_G strips).
+struct swq_item { uint32_t first, count, ncol, pad; uint64_t tb_base; };
+
+// comparison -> 64-lane mask in an SGPR pair (lanes outside EXEC read 0)
+#define SWQ_MASK_GT(m, x, y) asm volatile("v_cmp_gt_f32_e64 %0, %1, %2" : "=s"(m) : "v"(x), "v"(y))
+#define SWQ_MASK_GE(m, x, y) asm volatile("v_cmp_ge_f32_e64 %0, %1, %2" : "=s"(m) : "v"(x), "v"(y))
+#define SWQ_MASK_0GE(m, y) asm volatile("v_cmp_ge_f32_e64 %0, 0, %1" : "=s"(m) : "v"(y))
+// two masks to trace memory (wave-uniform address, 16-byte aligned)
+#define SWQ_STORE2(m0, m1, ptr, off) \
+    asm volatile("s_store_dwordx4 %0, %1, %2" :: "s"(__uint128_t(m0) | (__uint128_t(m1) << 64)), "s"(ptr), "n"(off) : "memory")
 
 typedef float swq_v2f __attribute__((ext_vector_type(2)));
 typedef float swq_v4f __attribute__((ext_vector_type(4)));
@@ -416,7 +431,15 @@ __global__ __launch_bounds__(64 * SWQ_NW) void k_sw_qp(swf_args a, const swq_ite
         const uint32_t step_chain = T ? a.ia[p] : a.ib[p];
         const uint32_t LB = T ? a.a_len[step_chain] : a.b_len[step_chain];
         const uint16_t *bcb = T ? (a.a_cb + (size_t) a.a_off[step_chain] * 8) : (a.b_cb + (size_t) a.b_off[step_chain] * 8);
-        uint32_t *tbp = (uint32_t *) (a.tb + a.tb_off[p]) + (size_t) (sbase + st) * LB * SWQ_W;    // strip-major: [strip][step][W]
+        // trace block of this (segment, batch): wave-uniform address in SGPRs
+        const unsigned long long *tblk;
+        {
+            const uint32_t nb_full = (it.count + (64 / G) - 1) / (64 / G);
+            const unsigned long long t0 = (unsigned long long) (a.tb + it.tb_base) + (unsigned long long) (seg * nb_full + b) * it.ncol * SWQ_COL_BYTES;
+            const unsigned lo = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) t0);
+            const unsigned hi = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) (t0 >> 32));
+            tblk = (const unsigned long long *) (((unsigned long long) hi << 32) | lo);
+        }
         long long *bnd = nseg > 1 ? (long long *) (a.bnd + a.bnd_off[p]) : nullptr;
 
         float Md[R], In[R], rb[R];
@@ -459,7 +482,7 @@ __global__ __launch_bounds__(64 * SWQ_NW) void k_sw_qp(swf_args a, const swq_ite
                 if (st != 0 || seg != 0) Md[0] = carry_in;
                 else if (j > 0) Md[0] = SWF_MINUS_INF;
                 float carry = SWF_MINUS_INF;
-                uint32_t w = 0;
+                const unsigned long long *tcol = tblk + (size_t) col * (SWQ_COL_BYTES / 8);
 #pragma unroll
                 for (int q = 0; q < R / 4; ++q) {
                     // volatile keeps each fetch one ds_read_b128 (the SLP vectoriser would split it into b64 halves)
@@ -470,31 +493,36 @@ __global__ __launch_bounds__(64 * SWQ_NW) void k_sw_qp(swf_args a, const swq_ite
 #pragma unroll
                     for (int f = 1; f < 8; ++f) { Slo += v[f].lo; Shi += v[f].hi; }
                     const float S4[4] = { Slo.x, Slo.y, Shi.x, Shi.y };
+                    unsigned long long tm[10];                           // masks of two cells
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr) {
                         const int r = q * 4 + rr;
+                        unsigned long long *tc = tm + 5 * (rr & 1);
                         const float m = Md[r];
                         const float d = T ? In[r] : ch;
                         const float n = T ? ch : In[r];
                         Md[r] = carry;
-                        SWQ_BIT_GT(w, d, m);                 // TB_DM candidate (sw.cpp:127)
+                        SWQ_MASK_GT(tc[0], d, m);            // TB_DM candidate (sw.cpp:127)
                         const float x1 = swq_max(m, d);
-                        SWQ_BIT_GT(w, n, x1);                // TB_IM (sw.cpp:135)
+                        SWQ_MASK_GT(tc[1], n, x1);           // TB_IM (sw.cpp:135)
                         const float x2 = swq_max(x1, n);
-                        SWQ_BIT_0GE(w, x2);                  // TB_SM (sw.cpp:143)
+                        SWQ_MASK_0GE(tc[2], x2);             // TB_SM (sw.cpp:143)
                         const float xM = swq_max(x2, 0.0f) + S4[rr];
                         if (xM > rb[r]) { rb[r] = xM; rj[r] = (uint32_t) j; }
                         carry = xM;
                         const float md = m + Open;
                         const float de = d + Ext;
-                        SWQ_BIT_GE(w, md, de);               // TB_MD (sw.cpp:166)
+                        SWQ_MASK_GE(tc[3], md, de);          // TB_MD (sw.cpp:166)
                         const float dd = swq_max(md, de);
                         const float ne = n + Ext;
-                        SWQ_BIT_GE(w, md, ne);               // TB_MI (sw.cpp:181)
+                        SWQ_MASK_GE(tc[4], md, ne);          // TB_MI (sw.cpp:181)
                         const float ni = swq_max(md, ne);
                         if (T) { ch = ni; In[r] = dd; }
                         else { ch = dd; In[r] = ni; }
-                        if (r % 6 == 5 || r == R - 1) tbp[(size_t) j * SWQ_W + r / 6] = w;
+                        if (rr & 1) {                        // rows r - 1 and r: 80 bytes
+#pragma unroll
+                            for (int k = 0; k < 10; k += 2) SWQ_STORE2(tm[k], tm[k + 1], tcol, (r >> 1) * 80 + k * 8);
+                        }
                     }
                 }
                 hand_m = carry;
@@ -538,6 +566,7 @@ __global__ __launch_bounds__(64 * SWQ_NW) void k_sw_qp(swf_args a, const swq_ite
         }
     }
     }
+    asm volatile("s_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory");     // the trace masks sit in the scalar data cache
 }
 
 // TraceBackBitSW sw.cpp:8-77.  One thread per pair; path chars are written backwards into
@@ -545,19 +574,26 @@ __global__ __launch_bounds__(64 * SWQ_NW) void k_sw_qp(swf_args a, const swq_ite
 // 0 = k_sw_qp strips along A, 1 = k_sw_qp strips along B, 2 = k_sw_float<false>, 3 = k_sw_float<true>.
 struct swf_classes { uint32_t first[5]; };
 
-__device__ __forceinline__ uint32_t swf_trace_flags(const uint8_t *T, uint32_t cls, uint32_t ld, uint32_t i, uint32_t j)
+// which: 0 = the three "into M" bits (DM, IM, SM), 1 = MD, 2 = MI -- a traceback step needs only those of its state
+__device__ __forceinline__ uint32_t swf_trace_flags(const uint8_t *T, uint32_t cls, uint32_t ld, uint32_t i, uint32_t j, const swq_item &it,
+                                                    uint32_t pidx, uint32_t gtot, int which)
 {
     uint32_t bits;
     if (cls >= 2) {
         // k_sw_float: one byte per cell, the four rows of a dword in big-endian order
         bits = (cls == 2 ? T[(size_t) j * ld + (i ^ 3u)] : T[(size_t) i * ld + (j ^ 3u)]) & 31u;
     } else {
+        // k_sw_qp: block (segment, wave batch) -> column -> row -> mask; this pair's cell is bit `lane` of the mask
         const uint32_t srow = cls == 0 ? i : j, step = cls == 0 ? j : i;
-        const uint32_t st = srow / SWQ_R, r = srow - st * SWQ_R;
-        const uint32_t wd = r / 6, q = r - wd * 6;
-        const uint32_t k = (wd == SWQ_W - 1) ? (SWQ_R - 6 * (SWQ_W - 1)) : 6;
-        const uint32_t w = ((const uint32_t *) T)[((size_t) st * ld + step) * SWQ_W + wd];      // ld = steps of the pair
-        bits = (w >> (5 * (k - 1 - q))) & 31u;
+        const uint32_t strip = srow / SWQ_R, r = srow - strip * SWQ_R;
+        const uint32_t seg = strip / SWQ_MAX_G, st = strip - seg * SWQ_MAX_G;
+        const uint32_t g = min((uint32_t) SWQ_MAX_G, gtot - seg * SWQ_MAX_G), npw = 64 / g;
+        const uint32_t nb_full = (it.count + (64 / SWQ_MAX_G) - 1) / (64 / SWQ_MAX_G);
+        const uint32_t b = pidx / npw, lane = (pidx - b * npw) * g + st;
+        const unsigned long long *M = (const unsigned long long *) (T + ((size_t) (seg * nb_full + b) * it.ncol + step + st) * SWQ_COL_BYTES) + r * 5;
+        if (which == 0) bits = ((uint32_t) (M[0] >> lane) & 1u) << 4 | ((uint32_t) (M[1] >> lane) & 1u) << 3 | ((uint32_t) (M[2] >> lane) & 1u) << 2;
+        else if (which == 1) bits = ((uint32_t) (M[3] >> lane) & 1u) << 1;
+        else bits = (uint32_t) (M[4] >> lane) & 1u;
     }
     uint32_t t = 0;
     if (bits & 4) t = TB_SM;
@@ -572,7 +608,7 @@ __global__ void k_traceback(const uint8_t *tb, const uint64_t *tb_off, const uin
                             const uint32_t *ib, const uint32_t *b_len, swf_classes cl,
                             const float *score, const uint32_t *besti, const uint32_t *bestj, uint32_t npairs,
                             char *paths, const uint64_t *path_end, uint64_t *path_start, uint32_t *path_len,
-                            uint32_t *lo_a, uint32_t *lo_b)
+                            uint32_t *lo_a, uint32_t *lo_b, const swq_item *qitems0, const swq_item *qitems1, const uint32_t *qp_item)
 {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= npairs) return;
@@ -585,7 +621,14 @@ __global__ void k_traceback(const uint8_t *tb, const uint64_t *tb_off, const uin
     const uint32_t LA = a_len[ia[p]], LB = b_len[ib[p]];
     const uint32_t ld = cls == 0 ? LB : cls == 1 ? LA
                       : cls == 2 ? SWF_PADR(LA) : SWF_PADR(LB);
-    const uint8_t *T = tb + tb_off[p];
+    swq_item it = {};
+    uint32_t pidx = 0, gtot = 1;
+    if (cls < 2) {                                    // k_sw_qp pairs: the trace lives in the blocks of the pair's workgroup item
+        it = (cls == 0 ? qitems0 : qitems1)[qp_item[p]];
+        pidx = p - it.first;
+        gtot = ((cls == 0 ? LA : LB) + SWQ_R - 1) / SWQ_R;
+    }
+    const uint8_t *T = tb + (cls < 2 ? it.tb_base : tb_off[p]);
     uint32_t i = besti[p] + 1, j = bestj[p] + 1;      // 1-based
     const uint32_t Besti = i, Bestj = j;
     uint64_t w = path_end[p];                          // the path is written backwards from here
@@ -603,17 +646,17 @@ __global__ void k_traceback(const uint8_t *tb, const uint64_t *tb_off, const uin
             if (++nacc == 4) { w -= 4; *(uint32_t *) (paths + w) = acc; nacc = 0; }
         }
         if (state == 0) {
-            const uint32_t t = swf_trace_flags(T, cls, ld, i - 1, j - 1);
+            const uint32_t t = swf_trace_flags(T, cls, ld, i - 1, j - 1, it, pidx, gtot, 0);
             if (t & TB_DM) state = 1;
             else if (t & TB_IM) state = 2;
             else if (t & TB_SM) break;
             --i; --j;
         } else if (state == 1) {
-            const uint32_t t = swf_trace_flags(T, cls, ld, i - 1, j);
+            const uint32_t t = swf_trace_flags(T, cls, ld, i - 1, j, it, pidx, gtot, 1);
             state = (t & TB_MD) ? 0 : 1;
             --i;
         } else {
-            const uint32_t t = swf_trace_flags(T, cls, ld, i, j - 1);
+            const uint32_t t = swf_trace_flags(T, cls, ld, i, j - 1, it, pidx, gtot, 2);
             state = (t & TB_MI) ? 0 : 2;
             --j;
         }
@@ -1032,7 +1075,7 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
     swf_blob hb;
     const size_t o_ia = hb.add(npairs * 4), o_ib = hb.add(npairs * 4), o_slot = hb.add(npairs * 4);
     const size_t o_tboff = hb.add((npairs + 1) * 8), o_pend = hb.add(npairs * 8), o_scoff = hb.add((npairs + 1) * 8);
-    const size_t o_bndoff = hb.add((npairs + 1) * 8);
+    const size_t o_bndoff = hb.add((npairs + 1) * 8), o_qpitem = hb.add(npairs * 4);
     std::vector<swq_item> qitems[2];
     std::vector<swf_item> items;
     uint32_t nitems_normal = 0;
@@ -1048,7 +1091,7 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
             const uint32_t g = std::min<uint32_t>((sdb->len[chain] + SWQ_R - 1) / SWQ_R, SWQ_MAX_G);
             const uint32_t npw = 64 / g;
             const size_t chunk = (size_t) npw * SWQ_NW * 2;
-            for (size_t s = k; s < e; s += chunk) qitems[c].push_back(swq_item{ (uint32_t) s, (uint32_t) std::min(chunk, e - s) });
+            for (size_t s = k; s < e; s += chunk) qitems[c].push_back(swq_item{ (uint32_t) s, (uint32_t) std::min(chunk, e - s), 0, 0, 0 });
             k = e;
         }
         // longest-running workgroups first
@@ -1087,7 +1130,31 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
     uint32_t *sia = (uint32_t *) (H + o_ia), *sib = (uint32_t *) (H + o_ib), *slot = (uint32_t *) (H + o_slot);
     uint64_t *tb_off = (uint64_t *) (H + o_tboff), *path_end = (uint64_t *) (H + o_pend), *sc_off = (uint64_t *) (H + o_scoff);
     uint64_t *bnd_off = (uint64_t *) (H + o_bndoff);
+    uint32_t *qp_item = (uint32_t *) (H + o_qpitem);
     uint64_t tbo = 0, pe = 0, so = 0, bno = 0, cells = 0;
+    // trace blocks of the query-profile items: one block of ncol columns per (segment, wave batch), see swq_item
+    for (int c = 0; c < 2; ++c)
+        for (size_t q = 0; q < qitems[c].size(); ++q) {
+            swq_item &it = qitems[c][q];
+            const uint32_t p0 = ord[it.first].idx;
+            const uint32_t Ls = c == 0 ? dba->len[ia[p0]] : dbb->len[ib[p0]];               // strip chain of the group
+            uint32_t lmax = 0;
+            for (uint32_t k = 0; k < it.count; ++k) {
+                const uint32_t p = ord[it.first + k].idx;
+                lmax = std::max(lmax, c == 0 ? dbb->len[ib[p]] : dba->len[ia[p]]);          // step chains
+                qp_item[it.first + k] = (uint32_t) q;
+            }
+            const uint32_t gtot = (Ls + SWQ_R - 1) / SWQ_R;
+            uint64_t nblocks = 0;
+            for (uint32_t s0 = 0; s0 < gtot; s0 += SWQ_MAX_G) {
+                const uint32_t npw = 64 / std::min<uint32_t>(SWQ_MAX_G, gtot - s0);
+                nblocks += (it.count + npw - 1) / npw;
+            }
+            it.ncol = lmax + SWQ_MAX_G;                                                     // column index = step + strip-in-segment
+            it.tb_base = tbo;
+            tbo += nblocks * it.ncol * SWQ_COL_BYTES;
+        }
+    for (size_t k = cl.first[2]; k < npairs; ++k) qp_item[k] = 0;
     for (size_t k = 0; k < npairs; ++k) {
         const uint32_t p = ord[k].idx;
         const uint32_t c = (uint32_t) (ord[k].key >> 62);
@@ -1096,11 +1163,9 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
         const uint32_t LA = dba->len[ia[p]], LB = dbb->len[ib[p]];
         bnd_off[k] = bno;
         tb_off[k] = tbo;
-        if (c == 0) {
-            tbo += (uint64_t) LB * ((LA + SWQ_R - 1) / SWQ_R) * (SWQ_W * 4);
+        if (c == 0) {                                           // trace: the item's blocks (above)
             if (LA > SWQ_MAX_L) bno += 2 * (uint64_t) LB;       // multi-segment strip chain: 2 words per step
         } else if (c == 1) {
-            tbo += (uint64_t) LA * ((LB + SWQ_R - 1) / SWQ_R) * (SWQ_W * 4);
             if (LB > SWQ_MAX_L) bno += 2 * (uint64_t) LA;
         }
         else if (c == 2) {
@@ -1211,7 +1276,8 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
     RSK_HIP(hipGetLastError());
     RSK_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     hipLaunchKernelGGL(k_traceback, dim3((unsigned) ((npairs + 63) / 64)), dim3(64), 0, ctx->stream, d_tb, d_tboff, d_ia, dba->d_len,
-                       d_ib, dbb->d_len, cl, d_score, d_bi, d_bj, (uint32_t) npairs, d_paths, d_pend, d_pstart, d_plen, d_loa, d_lob);
+                       d_ib, dbb->d_len, cl, d_score, d_bi, d_bj, (uint32_t) npairs, d_paths, d_pend, d_pstart, d_plen, d_loa, d_lob,
+                       (const swq_item *) (D + o_q[0]), (const swq_item *) (D + o_q[1]), (const uint32_t *) (D + o_qpitem));
     RSK_HIP(hipGetLastError());
     if (want_stats) {
         if ((rc = dalloc((void **) &d_pos, 2 * so * 4)) != RSK_OK) return rc;
