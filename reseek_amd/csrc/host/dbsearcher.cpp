@@ -403,17 +403,22 @@ struct SecondaryCtx {
     // Idle secondary contexts are kept per device and handed out again: a context's allocator pool holds the scratch of
     // its last job (tens of GB of X-drop trace, the SW trace blocks), and hipMalloc / hipFree of blocks that size cost
     // hundreds of ms -- per search and, with a streamed -db file, per batch.  rsk_ctx_trim() releases them.
-    struct Idle { int device; rsk_ctx *c; hipStream_t st; };
+    // A context is handed back to the ROLE it served (second alignment stage / long-chain job / -db loader): the roles'
+    // scratch differs by orders of magnitude, and a 26 GB trace block that has to be allocated again costs 0.7 s on
+    // some hosts.
+    struct Idle { int device; rsk_ctx *c; hipStream_t st; const char *role; };
+    const char *role = "";
     static std::mutex &Lock() { static std::mutex m; return m; }
     static std::vector<Idle> &IdleList() { static std::vector<Idle> v; return v; }
-    void Create(int dev)
+    void Create(int dev, const char *Role)
     {
         device = dev;
+        role = Role;
         {
             std::lock_guard<std::mutex> g(Lock());
             auto &v = IdleList();
             for (size_t k = 0; k < v.size(); ++k)
-                if (v[k].device == dev) { c = v[k].c; st = v[k].st; v.erase(v.begin() + k); return; }
+                if (v[k].device == dev && strcmp(v[k].role, Role) == 0) { c = v[k].c; st = v[k].st; v.erase(v.begin() + k); return; }
         }
         check(rsk_ctx_create(dev, &c), "rsk_ctx_create");
         if (!(getenv("RSK_OWN_STREAMS") && atoi(getenv("RSK_OWN_STREAMS")) == 0)) {
@@ -427,7 +432,7 @@ struct SecondaryCtx {
         (void) rsk_ctx_sync(c);
         std::lock_guard<std::mutex> g(Lock());
         auto &v = IdleList();
-        if (v.size() < 6) { v.push_back(Idle{ device, c, st }); return; }
+        if (v.size() < 6) { v.push_back(Idle{ device, c, st, role }); return; }
         rsk_ctx_destroy(c);
         if (st) (void) hipStreamDestroy(st);
     }
@@ -549,12 +554,27 @@ static void ReplayBatch(DBSearcher &S, DBSearcher &SrcA, DBSearcher &SrcB, const
                 DA.SetParams(P);
                 DA.m_UFs = S.m_DA.m_UFs;
                 const size_t lo = n * t / T, hi = n * (t + 1) / T;
-                for (size_t p = lo; p < hi; ++p)
+                if (want) me.buf.reserve((hi - lo) * 56);
+                // A hit line touches two chain objects, their labels and sequences (percent identity) and the path: five
+                // or six cache misses that cost more than the formatting itself.  They are requested a few pairs ahead.
+                auto touch = [&](size_t q, bool deep) {
+                    const PDBChain *a = SrcA.m_DBChains[ia[q]], *b = SrcB.m_DBChains[ib[q]];
+                    if (!deep) { __builtin_prefetch(a); __builtin_prefetch(b); return; }
+                    if (out[q].path_len == 0) return;
+                    __builtin_prefetch(a->m_Label.data()); __builtin_prefetch(b->m_Label.data());
+                    if (out[q].lo_a != RSK_NO_POS) { __builtin_prefetch(a->m_Seq.data() + out[q].lo_a); __builtin_prefetch(a->m_Seq.data() + out[q].lo_a + 64); }
+                    if (out[q].lo_b != RSK_NO_POS) { __builtin_prefetch(b->m_Seq.data() + out[q].lo_b); __builtin_prefetch(b->m_Seq.data() + out[q].lo_b + 64); }
+                    __builtin_prefetch(paths + out[q].path_off);
+                };
+                for (size_t p = lo; p < hi; ++p) {
+                    if (p + 24 < hi) touch(p + 24, false);
+                    if (p + 12 < hi) touch(p + 12, true);
                     replay(DA, p, [&](DSSAligner &D, bool Up) {
                         if (S.Reject(D, Up)) return;
                         ++me.hits;
                         if (want && !(S.m_Opts.noself && D.m_ChainA->m_Label == D.m_ChainB->m_Label)) D.AppendTsv(me.buf, Up);
                     });
+                }
                 DA.UnsetQuery();
             } catch (const std::exception &e) { me.err = e.what(); }
         });
@@ -604,7 +624,7 @@ void ForEachAlignedBatch(const DSSParams &P, rsk_ctx *ctx, const SearchOptions &
     // one: kernels of the two stages run one after the other, what overlaps is host work with kernels.
     SecondaryCtx second;
     const int inflight = getenv("RSK_ALIGN_INFLIGHT") ? std::max(1, std::min(2, atoi(getenv("RSK_ALIGN_INFLIGHT")))) : 2;
-    if (inflight > 1 && batches.size() >= 3) second.Create(ctx->device);
+    if (inflight > 1 && batches.size() >= 3) second.Create(ctx->device, "align");
     auto launch = [&](size_t k) {
         const auto be = batches[k];
         rsk_ctx *c = (second.c && (k & 1)) ? second.c : ctx;
@@ -940,7 +960,7 @@ static void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOff
     const bool overlap = !S.m_HasOnAlnOverride && !mkf.empty() && !ia.empty() && !(getenv("RSK_MKF_OVERLAP") && atoi(getenv("RSK_MKF_OVERLAP")) == 0);
     if (overlap) {
         SecondaryCtx own;
-        own.Create(ctx->device);
+        own.Create(ctx->device, "mkf");
         std::string lines;
         uint64_t hits = 0;
         std::future<void> job = std::async(std::launch::async, [&]() {
@@ -1114,7 +1134,7 @@ void DBSearcher::RunQuery(ChainReader2 &QCR)
     if (!m_fTsv) m_fTsv = g_fTsv;
     UploadToGpu();
     SecondaryCtx loader;
-    loader.Create(m_Ctx->device);
+    loader.Create(m_Ctx->device, "loader");
     auto load = [&]() -> std::unique_ptr<DBSearcher> {
         std::vector<PDBChain *> Chains;
         uint64_t nres = 0;

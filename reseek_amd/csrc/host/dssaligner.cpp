@@ -789,15 +789,26 @@ float DSSAligner::GetPctId() const                    // dssaligner.cpp:1325: id
     const char *SeqA = m_ChainA->m_Seq.data(), *SeqB = m_ChainB->m_Seq.data();
     const char *P = m_Path.data();
     const size_t L = m_Path.size();
-    // run by run (paths are mostly long M runs): the comparison loop of a run has no data-dependent branch
+    // run by run (paths are mostly long M runs): the end of a run is found eight path characters at a time, the
+    // comparison loop of a run has no data-dependent branch (it vectorises)
     for (size_t k = 0; k < L;) {
         const char c = P[k];
         size_t e = k + 1;
+        const uint64_t cc = 0x0101010101010101ull * (uint8_t) c;
+        while (e + 8 <= L) {
+            uint64_t w;
+            memcpy(&w, P + e, 8);
+            w ^= cc;
+            if (w) { e += (size_t) (__builtin_ctzll(w) >> 3); goto run_end; }
+            e += 8;
+        }
         while (e < L && P[e] == c) ++e;
+    run_end:
         const uint r = (uint) (e - k);
         if (c == 'M') {
+            const char *a = SeqA + PosA, *b = SeqB + PosB;
             uint eq = 0;
-            for (uint t = 0; t < r; ++t) eq += SeqA[PosA + t] == SeqB[PosB + t];
+            for (uint t = 0; t < r; ++t) eq += a[t] == b[t];
             n += eq; PosA += r; PosB += r; N += r;
         } else if (c == 'D') PosA += r;
         else if (c == 'I') PosB += r;
@@ -885,7 +896,9 @@ static void AppendFixed1(std::string &out, double x)                  // "%.1f"
 static void AppendG3(std::string &out, double x)                      // "%.3g"
 {
     if (x >= 1e-20 && x < 1000) {
-        int E = (int) floor(log10(x));
+        // decimal exponent from the binary one: floor(log10 x) is this estimate or one more, which the scaled value
+        // below tells apart (no log10 call: it was a quarter of the cost of a default hit line)
+        int E = (int) floor(ilogb(x) * 0.30102999566398120);
         if (E >= -20 && E <= 2) {
             double s = x * kP10[2 - E];
             if (s < 100 && E > -20) { --E; s = x * kP10[2 - E]; }

@@ -40,7 +40,9 @@ struct PhaseTimer {                              // RSK_TRACE=1: wall time of th
     {
         if (!on) return;
         const auto t1 = std::chrono::steady_clock::now();
-        fprintf(stderr, "[%s] %-22s %9.3f ms\n", who, what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        // @: wall clock in ms modulo 100 s, to line up the stages of concurrent threads
+        fprintf(stderr, "[%s] %-22s %9.3f ms   @%.1f\n", who, what, std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                std::chrono::duration<double, std::milli>(t1.time_since_epoch()).count() - 1e5 * floor(std::chrono::duration<double>(t1.time_since_epoch()).count() / 100));
         t0 = t1;
     }
 };

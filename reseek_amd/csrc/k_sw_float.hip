@@ -956,6 +956,7 @@ extern "C" size_t rsk_align_paths_bytes(const rsk_db *a, const rsk_db *b, const 
 
 namespace {
 struct swf_timer {
+    const void *who = nullptr;
     bool on;
     std::chrono::steady_clock::time_point t0;
     swf_timer() : on(getenv("RSK_TRACE") != nullptr), t0(std::chrono::steady_clock::now()) {}
@@ -963,7 +964,8 @@ struct swf_timer {
     {
         if (!on) return;
         const auto t1 = std::chrono::steady_clock::now();
-        fprintf(stderr, "[rsk_align_pairs] %-18s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        fprintf(stderr, "[rsk_align_pairs] %-18s %8.3f ms   @%.1f ctx %p\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                std::chrono::duration<double, std::milli>(t1.time_since_epoch()).count() - 1e5 * floor(std::chrono::duration<double>(t1.time_since_epoch()).count() / 100), who);
         t0 = t1;
     }
 };
@@ -987,6 +989,7 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
     if (npairs > 0x7FFFFFFFull) { rsk_set_error("rsk_align_pairs: too many pairs in one call"); return RSK_E_RANGE; }
     const bool want_stats = dba->d_x && dbb->d_x;
     swf_timer tm;
+    tm.who = ctx;
     size_t need = 0;
     for (size_t p = 0; p < npairs; ++p) {
         if (ia[p] >= dba->n || ib[p] >= dbb->n) { rsk_set_error("rsk_align_pairs: pair %zu out of range", p); return RSK_E_INVALID; }
@@ -1150,7 +1153,7 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
                 const uint32_t npw = 64 / std::min<uint32_t>(SWQ_MAX_G, gtot - s0);
                 nblocks += (it.count + npw - 1) / npw;
             }
-            it.ncol = lmax + SWQ_MAX_G;                                                     // column index = step + strip-in-segment
+            it.ncol = lmax + std::min<uint32_t>(SWQ_MAX_G, gtot);                           // column index = step + strip-in-segment
             it.tb_base = tbo;
             tbo += nblocks * it.ncol * SWQ_COL_BYTES;
         }
@@ -1310,7 +1313,7 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
     void *rpin = nullptr;
     if ((rc = rsk_pinned(ctx, 1, rb.bytes, &rpin)) != RSK_OK) return rc;
     RSK_HIP(hipMemcpyAsync(rpin, RD, rb.bytes, hipMemcpyDeviceToHost, ctx->stream));
-    RSK_HIP(hipStreamSynchronize(ctx->stream));
+    if ((rc = rsk_stream_wait(ctx)) != RSK_OK) return rc;
     tm.lap("kernels+d2h");
     const char *RH = (const char *) rpin;
     const float *h_score = (const float *) (RH + r_score), *h_lddt = (const float *) (RH + r_lddt);

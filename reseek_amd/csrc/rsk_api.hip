@@ -68,7 +68,12 @@ int rsk_pool_alloc(rsk_ctx *ctx, void **p, size_t bytes)
 {
     size_t cls = 256;
     while (cls < bytes) cls <<= 1;
-    if (cls > (1ull << 30)) cls = (bytes + (1ull << 28) - 1) / (1ull << 28) * (1ull << 28);   // >1 GiB: 256 MiB steps
+    if (cls > (1ull << 30)) {
+        // > 1 GiB: steps of 1/8 of the power of two below (256 MiB at least), so that the slightly different scratch sizes
+        // of consecutive batches land in one class and reuse one block (a fresh hipMalloc of tens of GB can cost 0.7 s)
+        const size_t step = std::max<size_t>(1ull << 28, (cls >> 1) >> 3);
+        cls = (bytes + step - 1) / step * step;
+    }
     // smallest cached block that holds the request without wasting more than its size again
     auto it = ctx->pool_free.lower_bound(cls);
     if (it != ctx->pool_free.end() && it->first <= 2 * cls) {
@@ -91,6 +96,14 @@ int rsk_pool_alloc(rsk_ctx *ctx, void **p, size_t bytes)
     }
     ctx->pool_live[*p] = cls;
     ctx->pool_bytes += cls;
+    return RSK_OK;
+}
+
+int rsk_stream_wait(rsk_ctx *ctx)
+{
+    if (!ctx->ev_wait) RSK_HIP(hipEventCreateWithFlags(&ctx->ev_wait, hipEventBlockingSync | hipEventDisableTiming));
+    RSK_HIP(hipEventRecord(ctx->ev_wait, ctx->stream));
+    RSK_HIP(hipEventSynchronize(ctx->ev_wait));
     return RSK_OK;
 }
 
@@ -135,6 +148,7 @@ extern "C" void rsk_ctx_destroy(rsk_ctx *ctx)
     for (auto &kv : ctx->pool_live) (void) hipFree(kv.first);
     if (ctx->ev0) (void) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void) hipEventDestroy(ctx->ev1);
+    if (ctx->ev_wait) (void) hipEventDestroy(ctx->ev_wait);
     delete ctx;
 }
 

@@ -26,6 +26,7 @@ struct rsk_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_wait = nullptr;   // blocking-sync event of rsk_stream_wait (created on first use)
     float last_ms = -1.0f;
     // accounting of the last gapless matrix call
     uint64_t gl_pairs = 0, gl_cells = 0, gl_slots = 0;
@@ -75,6 +76,9 @@ struct rsk_scratch {
 };
 
 int rsk_pool_alloc(rsk_ctx *ctx, void **p, size_t bytes);
+// Waits for the context's stream without spinning: the long waits (tens of ms of kernels) of several host threads would
+// otherwise each burn a core of a CPU-quota'd container.
+int rsk_stream_wait(rsk_ctx *ctx);
 void rsk_pool_free(rsk_ctx *ctx, void *p);
 void rsk_pool_release(rsk_ctx *ctx);
 int rsk_pinned(rsk_ctx *ctx, int slot, size_t bytes, void **p);
