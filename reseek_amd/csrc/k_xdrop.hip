@@ -282,6 +282,308 @@ __global__ __launch_bounds__(256) void k_xdrop(xd_args a)
     a.score[e] = BestScore;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_xdrop_wave: the same extension with ONE WAVE per extension.  What the sequential formulation hides: every value of
+// row i depends on row i - 1 only -- Mrow[j] = Sub + max(M'[j-1], D'[j], I0), Drow[j] = max(M'[j-1] + Open, D'[j] + Ext),
+// and even the insert state I0 is a running max over the PREVIOUS row's M (I0 <- max(I0 + Ext, M'[j-1] + Open)).  So the
+// columns jlo .. jhi-1 of a row are computed 64 at a time, one per lane:
+//   * I0: a max-plus scan whose float additions must happen in the reference's order; f(x) = x + Ext is monotone, so
+//     max(f(a), f(b)) = f(max(a, b)) holds exactly and the chain is evaluated lane to lane with v_add + v_max on
+//     DPP wave_shr:1 operands (n steps for n columns; only this 2-instruction chain is serial);
+//   * BestScore as seen by column j = max(BestScore, prefix max of the row's earlier cells) -- max is associative, the
+//     6-step shuffle scan is exact; the best cell is the LAST one that reaches the row maximum (the reference updates on >=);
+//   * the band of the next row: next_jlo is a min over per-cell candidates; next_jhi is the fold of "assign j+1" (h > 0)
+//     and "max" (hd, hi) events in cell order, including the reference's UINT_MAX start value that max() cannot leave:
+//     the last assigning cell and the events after it decide.
+// The last column of the band (whose tests may extend the row, cell by cell) and everything after it run as the
+// sequential code, executed uniformly by the wave.  Row state and trace bytes are the same HBM arrays, accessed
+// coalesced.  Same results as k_xdrop bit for bit (tests/test_gpu_xdrop.py runs both).
+#define XDW_WAVES 4
+__device__ __forceinline__ float xdw_shr1(float v, float lane0)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, lane0), __builtin_bit_cast(int, v), 0x138 /* wave_shr:1 */, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float xdw_bcast(float v, uint32_t l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), (int) l)); }
+
+__global__ __launch_bounds__(64 * XDW_WAVES) void k_xdrop_wave(xd_args a)
+{
+    __shared__ float tab[XD_TABLE_FLOATS];
+    for (int i = threadIdx.x; i < XD_TABLE_FLOATS; i += blockDim.x) tab[i] = c_xd_tables.t[i];
+    __syncthreads();
+    const uint32_t e = blockIdx.x * XDW_WAVES + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    if (e >= 2 * a.nreq) return;
+    const uint32_t req = e >> 1, dir = e & 1;
+    if (a.valid && !a.valid[req]) { a.path_start[e] = 0; a.path_len[e] = 0; a.score[e] = 0.0f; return; }
+    const uint32_t A = a.ia[req], B = a.ib[req];
+    const uint32_t LoA = a.lo_a[req], LoB = a.lo_b[req];
+    const uint32_t LA = dir ? LoA : a.a_len[A] - LoA, LB = dir ? LoB : a.b_len[B] - LoB;      // extents of this extension
+    uint64_t row_o, tb_o, path_o;
+    if (a.per_pair) {
+        row_o = a.row_off[req]; tb_o = a.tb_off[req]; path_o = a.path_off[req];
+        if (dir) {                                                                              // behind the forward extension's share
+            const uint64_t FA = a.a_len[A] - LoA, FB = a.b_len[B] - LoB;
+            row_o += 2 * (FB + 9);
+            tb_o += ((FA + 9) * (FB + 9) + 15) & ~15ull;
+            path_o += FA + FB + 2;
+        }
+    } else { row_o = a.row_off[e]; tb_o = a.tb_off[e]; path_o = a.path_off[e]; }
+    const uint16_t *RA = a.a_ra + (size_t) a.a_off[A] * 8, *CB = a.b_cb + (size_t) a.b_off[B] * 8;
+    const char *tabb = (const char *) tab;
+    const uint32_t toffb[8] = { 0 * 4, 400 * 4, 656 * 4, 912 * 4, 1168 * 4, 1424 * 4, 1680 * 4, 1936 * 4 };
+    char *slot = a.paths + path_o;
+    const uint32_t cap = LA + LB + 2;
+    a.path_start[e] = 0;
+    a.path_len[e] = 0;
+    auto posA = [&](uint32_t i) { return dir ? LoA - i : LoA + i - 1; };
+    auto posB = [&](uint32_t j) { return dir ? LoB - j : LoB + j - 1; };
+    uint32_t rowo[8];
+    auto set_row = [&](uint32_t i) {
+        const uint4 w = *(const uint4 *) (RA + (size_t) posA(i) * 8);
+        const uint32_t ww[4] = { w.x, w.y, w.z, w.w };
+#pragma unroll
+        for (int f = 0; f < 8; ++f) rowo[f] = toffb[f] + ((f & 1) ? (ww[f >> 1] >> 16) : (ww[f >> 1] & 0xFFFFu));
+    };
+    auto sub = [&](uint32_t j) {      // SubstScore: Total = 0; Total += feature f, f = 0..7
+        const uint4 w = *(const uint4 *) (CB + (size_t) posB(j) * 8);
+        const uint32_t ww[4] = { w.x, w.y, w.z, w.w };
+        float Total = 0.0f;
+#pragma unroll
+        for (int f = 0; f < 8; ++f) Total += *(const float *) (tabb + rowo[f] + ((f & 1) ? (ww[f >> 1] >> 16) : (ww[f >> 1] & 0xFFFFu)));
+        return Total;
+    };
+    if (LA == 1 || LB == 1) {         // xdropfwd.cpp:84-92
+        set_row(1);
+        const float Score = sub(1);
+        if (Score > 0) { slot[0] = 'M'; a.path_len[e] = 1; }
+        a.score[e] = Score;
+        return;
+    }
+    const float Open = a.open, Ext = a.ext, X = a.X;
+    const float AbsOpen = -Open, AbsExt = -Ext;
+    float2 *MD = (float2 *) (a.rows + row_o) + 1;               // MD[-1] is valid
+    uint8_t *TB = a.tb + tb_o;
+    const uint32_t Cols = LB + 1 + 8;                            // XDPMem::Alloc(LA + 1, LB + 1)
+    const uint32_t U = 0xFFFFFFFFu;
+    MD[-1].x = XD_MINUS_INF;
+    MD[0].y = XD_MINUS_INF;
+    MD[1].y = XD_MINUS_INF;
+    float BestScore = 0;
+    uint32_t Besti = 0, Bestj = 0;
+    uint32_t prev_jlo = 0, prev_jhi = 0, jlo = 1, jhi = 1;
+    float M0 = BestScore;
+    for (uint32_t i = 1; i <= LA; ++i) {
+        if (jlo == prev_jlo) { MD[jlo - 1].x = XD_MINUS_INF; MD[jlo].y = XD_MINUS_INF; }
+        uint32_t endj = min(prev_jhi + 1, LB);
+        for (uint32_t j = endj + 1 + lane; j <= min(jhi + 1, LB); j += 64) { MD[j - 1].x = XD_MINUS_INF; MD[j].y = XD_MINUS_INF; }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        uint32_t next_jlo = U, next_jhi = U;
+        float I0 = XD_MINUS_INF;
+        set_row(i);
+        const size_t tb_row = (size_t) i * Cols;
+        // ---- columns jlo .. jhi - 1, 64 per step ----
+        const uint32_t jb_end = jhi;
+        for (uint32_t jc = jlo; jc < jb_end; jc += 64) {
+            const uint32_t n = min(64u, jb_end - jc);
+            const uint32_t j = jc + lane;
+            const bool act = lane < n;
+            float2 md0 = make_float2(XD_MINUS_INF, XD_MINUS_INF);
+            float sj = 0.0f;
+            if (act) { md0 = MD[j]; sj = sub(j); }
+            const float Mjm1 = xdw_shr1(md0.x, M0);              // M'[j-1] (SavedM0 of the cell)
+            const float d_cur = md0.y;
+            const float mi = Mjm1 + Open;                        // = md of the delete state, = mi of the insert state
+            float v = mi;
+            for (uint32_t t = 0; t < n; ++t) {                   // v[l] = I0 after column l: final for lanes <= t after step t
+                const float x = xdw_shr1(v, I0) + Ext;
+                v = x > mi ? x : mi;
+            }
+            const float I0in = xdw_shr1(v, I0);                  // insert state entering the cell
+            uint32_t bits = 0;
+            float xM = Mjm1;
+            if (d_cur > xM) { xM = d_cur; bits = XD_DM; }
+            if (I0in > xM) { xM = I0in; bits = XD_IM; }
+            float s = sj;
+            s += xM;
+            // BestScore as the cell sees it: before / after its own match update
+            const float sv = act ? s : -3.0e38f;
+            float incl = sv;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const float t = __shfl_up(incl, d, 64);
+                if ((int) lane >= d) incl = t > incl ? t : incl;
+            }
+            float excl = __shfl_up(incl, 1, 64);
+            if (lane == 0) excl = -3.0e38f;
+            const float pm = excl > BestScore ? excl : BestScore;
+            const float pmi = incl > BestScore ? incl : BestScore;
+            const float h = s - pm + X;
+            // DELETE
+            float d_new = d_cur;
+            bool E2 = false;
+            const bool notfirst = j != jlo;
+            if (notfirst) {
+                float d = d_cur;
+                d += Ext;
+                if (mi >= d) { d = mi; bits |= XD_MD; }
+                d_new = d;
+                const float hd = d - pmi + X;
+                E2 = hd > 0;
+            }
+            // INSERT
+            {
+                const float fI = I0in + Ext;
+                if (mi >= fI) bits |= XD_MI;
+            }
+            const float hi = v - pmi + X;
+            const bool E1 = act && h > 0, E3 = act && hi > 0;
+            E2 = E2 && act;
+            // next row's band
+            uint32_t lo_c = U;
+            if (E1) lo_c = j + 1;
+            if (act && h > AbsOpen) lo_c = min(lo_c, j);
+            if (E2) lo_c = min(lo_c, j - 1);
+            if (E3) lo_c = min(lo_c, j + 1);
+            uint32_t e23 = 0;
+            if (E2) e23 = j - 1;
+            if (E3) e23 = max(e23, j + 1);
+            const unsigned long long m1 = __ballot(E1);
+            uint32_t l1 = 0;
+            if (m1) { l1 = 63u - (uint32_t) __builtin_clzll(m1); if (lane < l1) e23 = 0; }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                lo_c = min(lo_c, (uint32_t) __shfl_xor((int) lo_c, d, 64));
+                e23 = max(e23, (uint32_t) __shfl_xor((int) e23, d, 64));
+            }
+            next_jlo = min(next_jlo, lo_c);
+            if (m1) next_jhi = max(jc + l1 + 1, e23);
+            else if (next_jhi != U) next_jhi = max(next_jhi, e23);
+            // best cell: the last one that reaches the maximum (s >= BestScore updates, xdropfwd.cpp)
+            const float mx = xdw_bcast(incl, 63);
+            if (mx >= BestScore) {
+                BestScore = mx;
+                Besti = i;
+                Bestj = jc + 63u - (uint32_t) __builtin_clzll(__ballot(act && s == mx));
+            }
+            if (act) { MD[j] = make_float2(s, d_new); TB[tb_row + j] = (uint8_t) bits; }
+            M0 = xdw_bcast(md0.x, n - 1);
+            I0 = xdw_bcast(v, n - 1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        // ---- the last column and the cells the row may grow by: the reference's loop, run uniformly ----
+        for (uint32_t j = jb_end; j <= jhi; ++j) {
+            uint8_t TraceBits = 0;
+            const float SavedM0 = M0;
+            const float2 md0 = MD[j];
+            float m_new, d_cur = md0.y;
+            float xM = M0;
+            if (d_cur > xM) { xM = d_cur; TraceBits = XD_DM; }
+            if (I0 > xM) { xM = I0; TraceBits = XD_IM; }
+            M0 = md0.x;
+            float s = sub(j);
+            s += xM;
+            m_new = s;
+            const float h = s - BestScore + X;
+            if (h > 0) { next_jlo = min(next_jlo, j + 1); next_jhi = j + 1; }
+            if (h > AbsOpen) next_jlo = min(next_jlo, j);
+            if (h > AbsExt && j == jhi && jhi + 1 < LB) {        // match-insert may extend the current row
+                ++jhi;
+                const uint32_t new_endj = max(min(jhi + 1, LB), endj);
+                for (uint32_t j2 = endj + 1; j2 <= new_endj; ++j2) {
+                    if (j2 - 1 > j) MD[j2 - 1].x = XD_MINUS_INF;
+                    if (j2 == j) d_cur = XD_MINUS_INF;
+                    else MD[j2].y = XD_MINUS_INF;
+                }
+                endj = new_endj;
+            }
+            if (s >= BestScore) { BestScore = s; Besti = i; Bestj = j; }
+            float d_new = d_cur;
+            if (j != jlo) {
+                const float md = SavedM0 + Open;
+                float d = d_cur;
+                d += Ext;
+                if (md >= d) { d = md; TraceBits |= XD_MD; }
+                d_new = d;
+                const float hd = d - BestScore + X;
+                if (hd > 0) { next_jlo = min(next_jlo, j - 1); next_jhi = max(next_jhi, j - 1); }
+            }
+            {
+                const float mi = SavedM0 + Open;
+                I0 += Ext;
+                if (mi >= I0) { I0 = mi; TraceBits |= XD_MI; }
+                const float hi = I0 - BestScore + X;
+                if (hi > 0) { next_jlo = min(next_jlo, j + 1); next_jhi = max(next_jhi, j + 1); }
+                if (hi > AbsExt && j == jhi && jhi + 1 < LB) {
+                    ++jhi;
+                    const uint32_t new_endj = max(min(jhi + 1, LB), endj);
+                    for (uint32_t j2 = endj + 1; j2 <= new_endj; ++j2) {
+                        if (j2 - 1 == j) m_new = XD_MINUS_INF;
+                        else MD[j2 - 1].x = XD_MINUS_INF;
+                        if (j2 == j) d_new = XD_MINUS_INF;
+                        else MD[j2].y = XD_MINUS_INF;
+                    }
+                    endj = new_endj;
+                }
+            }
+            MD[j] = make_float2(m_new, d_new);
+            TB[tb_row + j] = TraceBits;
+        }
+        if (jhi < LB) {                                             // end of Drow[]
+            const uint32_t jhi1 = jhi + 1;
+            uint8_t t = 0;
+            const float md = M0 + Open;
+            float d = MD[jhi1].y;
+            d += Ext;
+            if (md >= d) { d = md; t = XD_MD; }
+            MD[jhi1].y = d;
+            TB[tb_row + jhi1] = t;
+        }
+        if (next_jlo == U) break;
+        prev_jlo = jlo; prev_jhi = jhi;
+        jlo = next_jlo; jhi = next_jhi;
+        if (jlo > LB) jlo = LB;
+        if (jhi > LB) jhi = LB;
+        if (jlo == prev_jlo) { M0 = XD_MINUS_INF; MD[jlo].y = XD_MINUS_INF; }
+        else M0 = MD[jlo - 1].x;
+    }
+    if (BestScore <= 0.0f) { a.score[e] = 0.0f; return; }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    uint32_t i = Besti, j = Bestj, n = 0;
+    char State = 'M';
+    for (;;) {
+        if (dir) slot[n] = State;
+        else slot[cap - 1 - n] = State;
+        ++n;
+        if (i == 1 || j == 1) break;
+        char Next;
+        if (State == 'M') {
+            const uint8_t c = TB[(size_t) i * Cols + j];
+            Next = (c & XD_DM) ? 'D' : (c & XD_IM) ? 'I' : 'M';
+            --i; --j;
+        } else if (State == 'D') {
+            Next = (TB[(size_t) i * Cols + j + 1] & XD_MD) ? 'M' : 'D';
+            --i;
+        } else {
+            Next = (TB[(size_t) (i + 1) * Cols + j] & XD_MI) ? 'M' : 'I';
+            --j;
+        }
+        State = Next;
+    }
+    a.path_start[e] = dir ? 0 : cap - n;
+    a.path_len[e] = n;
+    a.score[e] = BestScore;
+}
+
+// launch of either form: RSK_XDROP_WAVE=0 selects the thread-per-extension kernel (tests run both)
+static void xd_launch(rsk_ctx *ctx, const xd_args &xa, size_t nreq)
+{
+    const char *ev = getenv("RSK_XDROP_WAVE");
+    if (!(ev && atoi(ev) == 0))
+        hipLaunchKernelGGL(k_xdrop_wave, dim3((unsigned) ((2 * nreq + XDW_WAVES - 1) / XDW_WAVES)), dim3(64 * XDW_WAVES), 0, ctx->stream, xa);
+    else
+        hipLaunchKernelGGL(k_xdrop, dim3((unsigned) ((2 * nreq + 255) / 256)), dim3(256), 0, ctx->stream, xa);
+}
+
 // XDropHSP's two extensions (xdrophsp.cpp:97-108) for a list of seeded pairs.  Host arrays in, host arrays out.
 // The path of an extension fills a small part of its worst-case slot: the paths are packed back to back on the device
 // (sizes scanned, one wave copies one path) and only the packed bytes cross PCIe.
@@ -433,7 +735,7 @@ extern "C" int rsk_xdrop_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
         a.score = d_score; a.paths = d_paths; a.path_off = d_pathoff; a.path_start = d_pstart; a.path_len = d_plen;
         if (trace) RSK_HIP(hipStreamSynchronize(ctx->stream));
         const auto t_c = now();
-        hipLaunchKernelGGL(k_xdrop, dim3((unsigned) ((2 * m + 255) / 256)), dim3(256), 0, ctx->stream, a);
+        xd_launch(ctx, a, m);
         RSK_HIP(hipGetLastError());
         if (trace) RSK_HIP(hipStreamSynchronize(ctx->stream));
         const auto t_d = now();
@@ -706,7 +1008,7 @@ extern "C" int rsk_mkf_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db
         xa.score = d_xscore; xa.paths = d_paths; xa.path_off = d_pathoff; xa.path_start = d_pstart; xa.path_len = d_plen;
         xa.per_pair = 1; xa.valid = d_valid;
         RSK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-        hipLaunchKernelGGL(k_xdrop, dim3((unsigned) ((2 * m + 255) / 256)), dim3(256), 0, ctx->stream, xa);
+        xd_launch(ctx, xa, m);
         RSK_HIP(hipEventRecord(ctx->ev1, ctx->stream));
         mkfm_args ma = {};
         ma.a_len = dba->d_len; ma.b_len = dbb->d_len; ma.ia = d_ia; ma.ib = d_ib; ma.valid = d_valid; ma.req_lo_a = d_loa; ma.req_lo_b = d_lob;

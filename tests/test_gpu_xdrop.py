@@ -37,11 +37,15 @@ def ctx():
     c.close()
 
 
+@pytest.mark.parametrize("kernel", ["wave", "thread"])
 @pytest.mark.parametrize("fixture,X,go,ge", [("palms_sensitive.rskdb.gz", 8.0, -0.685533, -0.051881),
                                              ("q100_sensitive.rskdb.gz", 8.0, -0.685533, -0.051881),
                                              ("q100_sensitive.rskdb.gz", 2.5, -3.0, -1.0)])
-def test_xdrop_pairs_match_the_host_mirror(ctx, fixture, X, go, ge):
+def test_xdrop_pairs_match_the_host_mirror(ctx, fixture, X, go, ge, kernel, monkeypatch):
+    """Both device forms of the extension (k_xdrop_wave: a wave per extension, the default; k_xdrop: a thread per extension)
+    against the host mirror of XDropFwd / XDropBwd, scores and paths bit for bit."""
     import reseek_amd
+    monkeypatch.setenv("RSK_XDROP_WAVE", "1" if kernel == "wave" else "0")
     chains = fx.read_rskdb(fixture)[:14]
     db = reseek_amd.Db.from_chains(ctx, chains)
     rng = np.random.default_rng(5)
