@@ -299,22 +299,42 @@ __global__ __launch_bounds__(256) void k_xdrop(xd_args a)
 // sequential code, executed uniformly by the wave.  Row state and trace bytes are the same HBM arrays, accessed
 // coalesced.  Same results as k_xdrop bit for bit (tests/test_gpu_xdrop.py runs both).
 #define XDW_WAVES 4
+#ifdef XDW_PROF
+// debug build only (tools/exp): wave-cycles per phase, rows, chunks, sequential cells, traceback steps
+__device__ unsigned long long g_xdw_prof[12];
+#define XDW_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#define XDW_ADD(k, v) do { if (lane == 0) atomicAdd(&g_xdw_prof[k], (unsigned long long) (v)); } while (0)
+extern "C" int rsk_debug_xdw_prof(unsigned long long *out)
+{
+    unsigned long long z[12] = { 0 };
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_xdw_prof), sizeof(z)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_xdw_prof), z, sizeof(z)) != hipSuccess) return -1;
+    return 0;
+}
+#else
+#define XDW_T(var)
+#define XDW_ADD(k, v)
+#endif
 __device__ __forceinline__ float xdw_shr1(float v, float lane0)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, lane0), __builtin_bit_cast(int, v), 0x138 /* wave_shr:1 */, 0xF, 0xF, false));
 }
 __device__ __forceinline__ float xdw_bcast(float v, uint32_t l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), (int) l)); }
 
-__global__ __launch_bounds__(64 * XDW_WAVES) void k_xdrop_wave(xd_args a)
+// Row state {Mrow[j], Drow[j]}: a ring of XDW_RING columns in LDS (the band of a row spans a few hundred columns), or the
+// HBM array when the band of some row does not fit -- the extension is then simply run again in that mode.
+#define XDW_RING 512
+template <bool RING> struct xdw_rows {
+    float2 *p;
+    __device__ __forceinline__ float2 &operator()(uint32_t j) const { return RING ? p[j & (XDW_RING - 1)] : p[(int32_t) j]; }
+};
+
+// returns false iff RING and the band outgrew the ring (nothing final has been written then)
+template <bool RING>
+__device__ __forceinline__ bool xdw_extend(const xd_args &a, const float *tab, float2 *ring, uint32_t e, uint32_t lane)
 {
-    __shared__ float tab[XD_TABLE_FLOATS];
-    for (int i = threadIdx.x; i < XD_TABLE_FLOATS; i += blockDim.x) tab[i] = c_xd_tables.t[i];
-    __syncthreads();
-    const uint32_t e = blockIdx.x * XDW_WAVES + (threadIdx.x >> 6);
-    const uint32_t lane = threadIdx.x & 63;
-    if (e >= 2 * a.nreq) return;
     const uint32_t req = e >> 1, dir = e & 1;
-    if (a.valid && !a.valid[req]) { a.path_start[e] = 0; a.path_len[e] = 0; a.score[e] = 0.0f; return; }
+    if (a.valid && !a.valid[req]) { a.path_start[e] = 0; a.path_len[e] = 0; a.score[e] = 0.0f; return true; }
     const uint32_t A = a.ia[req], B = a.ib[req];
     const uint32_t LoA = a.lo_a[req], LoB = a.lo_b[req];
     const uint32_t LA = dir ? LoA : a.a_len[A] - LoA, LB = dir ? LoB : a.b_len[B] - LoB;      // extents of this extension
@@ -338,14 +358,16 @@ __global__ __launch_bounds__(64 * XDW_WAVES) void k_xdrop_wave(xd_args a)
     auto posA = [&](uint32_t i) { return dir ? LoA - i : LoA + i - 1; };
     auto posB = [&](uint32_t j) { return dir ? LoB - j : LoB + j - 1; };
     uint32_t rowo[8];
-    auto set_row = [&](uint32_t i) {
-        const uint4 w = *(const uint4 *) (RA + (size_t) posA(i) * 8);
+    // The 16-byte profile records of the row (A side) and of the columns (B side) are requested one step ahead of their
+    // use: an extension is a chain of dependent steps, what it waits for is memory latency.
+    auto load_ra = [&](uint32_t i) { return *(const uint4 *) (RA + (size_t) posA(i) * 8); };
+    auto load_cb = [&](uint32_t j) { return *(const uint4 *) (CB + (size_t) posB(j) * 8); };
+    auto set_row_w = [&](const uint4 w) {
         const uint32_t ww[4] = { w.x, w.y, w.z, w.w };
 #pragma unroll
         for (int f = 0; f < 8; ++f) rowo[f] = toffb[f] + ((f & 1) ? (ww[f >> 1] >> 16) : (ww[f >> 1] & 0xFFFFu));
     };
-    auto sub = [&](uint32_t j) {      // SubstScore: Total = 0; Total += feature f, f = 0..7
-        const uint4 w = *(const uint4 *) (CB + (size_t) posB(j) * 8);
+    auto sub_w = [&](const uint4 w) { // SubstScore: Total = 0; Total += feature f, f = 0..7
         const uint32_t ww[4] = { w.x, w.y, w.z, w.w };
         float Total = 0.0f;
 #pragma unroll
@@ -353,50 +375,73 @@ __global__ __launch_bounds__(64 * XDW_WAVES) void k_xdrop_wave(xd_args a)
         return Total;
     };
     if (LA == 1 || LB == 1) {         // xdropfwd.cpp:84-92
-        set_row(1);
-        const float Score = sub(1);
+        set_row_w(load_ra(1));
+        const float Score = sub_w(load_cb(1));
         if (Score > 0) { slot[0] = 'M'; a.path_len[e] = 1; }
         a.score[e] = Score;
-        return;
+        return true;
     }
     const float Open = a.open, Ext = a.ext, X = a.X;
     const float AbsOpen = -Open, AbsExt = -Ext;
-    float2 *MD = (float2 *) (a.rows + row_o) + 1;               // MD[-1] is valid
+    const xdw_rows<RING> MDr{ RING ? ring : (float2 *) (a.rows + row_o) + 1 };     // index -1 is valid in either form
+#define MD(j) MDr((uint32_t) (j))
+    if (RING) {                                                   // as XDPMem::Alloc leaves its rows
+        for (uint32_t k = lane; k < XDW_RING; k += 64) ring[k] = make_float2(0.0f, 0.0f);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
     uint8_t *TB = a.tb + tb_o;
     const uint32_t Cols = LB + 1 + 8;                            // XDPMem::Alloc(LA + 1, LB + 1)
     const uint32_t U = 0xFFFFFFFFu;
-    MD[-1].x = XD_MINUS_INF;
-    MD[0].y = XD_MINUS_INF;
-    MD[1].y = XD_MINUS_INF;
+    MD(-1).x = XD_MINUS_INF;
+    MD(0).y = XD_MINUS_INF;
+    MD(1).y = XD_MINUS_INF;
     float BestScore = 0;
     uint32_t Besti = 0, Bestj = 0;
     uint32_t prev_jlo = 0, prev_jhi = 0, jlo = 1, jhi = 1;
     float M0 = BestScore;
+    uint4 ra_next = load_ra(1);
     for (uint32_t i = 1; i <= LA; ++i) {
-        if (jlo == prev_jlo) { MD[jlo - 1].x = XD_MINUS_INF; MD[jlo].y = XD_MINUS_INF; }
+        if (RING && jhi - jlo + 5 > XDW_RING) return false;       // columns jlo - 1 .. jhi + 2 are touched
+        if (jlo == prev_jlo) { MD(jlo - 1).x = XD_MINUS_INF; MD(jlo).y = XD_MINUS_INF; }
         uint32_t endj = min(prev_jhi + 1, LB);
-        for (uint32_t j = endj + 1 + lane; j <= min(jhi + 1, LB); j += 64) { MD[j - 1].x = XD_MINUS_INF; MD[j].y = XD_MINUS_INF; }
+        for (uint32_t j = endj + 1 + lane; j <= min(jhi + 1, LB); j += 64) { MD(j - 1).x = XD_MINUS_INF; MD(j).y = XD_MINUS_INF; }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         uint32_t next_jlo = U, next_jhi = U;
         float I0 = XD_MINUS_INF;
-        set_row(i);
+        XDW_T(t_row);
+        set_row_w(ra_next);
+        if (i < LA) ra_next = load_ra(i + 1);
         const size_t tb_row = (size_t) i * Cols;
-        // ---- columns jlo .. jhi - 1, 64 per step ----
-        const uint32_t jb_end = jhi;
+        // ---- columns jlo .. jhi (the band the previous row asked for), 64 per step ----
+        const uint32_t jlast = jhi;                              // its cell may grow the row: handled after the step that holds it
+        const uint32_t jb_end = jhi + 1;
+        // the sequential part (cells the row grows by) starts behind the band: two columns in flight
+        uint4 cb_t0 = load_cb(min(jb_end, LB)), cb_t1 = load_cb(min(jb_end + 1, LB));
+        uint4 cb_next = make_uint4(0, 0, 0, 0);
+        if (jlo + lane < jb_end) cb_next = load_cb(jlo + lane);
+        float hL = 0.0f, hiL = 0.0f;
         for (uint32_t jc = jlo; jc < jb_end; jc += 64) {
             const uint32_t n = min(64u, jb_end - jc);
             const uint32_t j = jc + lane;
             const bool act = lane < n;
+            const uint4 cbw = cb_next;
+            if (j + 64 < jb_end) cb_next = load_cb(j + 64);
             float2 md0 = make_float2(XD_MINUS_INF, XD_MINUS_INF);
             float sj = 0.0f;
-            if (act) { md0 = MD[j]; sj = sub(j); }
+            if (act) { md0 = MD(j); sj = sub_w(cbw); }
             const float Mjm1 = xdw_shr1(md0.x, M0);              // M'[j-1] (SavedM0 of the cell)
             const float d_cur = md0.y;
             const float mi = Mjm1 + Open;                        // = md of the delete state, = mi of the insert state
+            // insert state after each column: v[l] = max over k <= l of f^(l-k)(mi[k]) and of f^(l+1)(I0), f(x) = x + Ext applied
+            // add by add (the reference's roundings); doubling steps, a lane without a source keeps its value (f^d(v) <= v)
             float v = mi;
-            for (uint32_t t = 0; t < n; ++t) {                   // v[l] = I0 after column l: final for lanes <= t after step t
-                const float x = xdw_shr1(v, I0) + Ext;
-                v = x > mi ? x : mi;
+            { const float x = I0 + Ext; if (lane == 0) v = x > mi ? x : mi; }
+#pragma unroll
+            for (int sft = 0; sft < 6; ++sft) {
+                float t = __shfl_up(v, 1u << sft, 64);
+#pragma unroll
+                for (int q = 0; q < (1 << sft); ++q) t += Ext;
+                v = t > v ? t : v;
             }
             const float I0in = xdw_shr1(v, I0);                  // insert state entering the cell
             uint32_t bits = 0;
@@ -408,13 +453,13 @@ __global__ __launch_bounds__(64 * XDW_WAVES) void k_xdrop_wave(xd_args a)
             // BestScore as the cell sees it: before / after its own match update
             const float sv = act ? s : -3.0e38f;
             float incl = sv;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const float t = __shfl_up(incl, d, 64);
-                if ((int) lane >= d) incl = t > incl ? t : incl;
-            }
-            float excl = __shfl_up(incl, 1, 64);
-            if (lane == 0) excl = -3.0e38f;
+            // inclusive max scan on DPP operands: within rows of 16 lanes, then across the rows (no LDS round trips)
+#define XDW_SCAN_STEP(ctrl, rows) { const float t = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, -3.0e38f), \
+                                        __builtin_bit_cast(int, incl), ctrl, rows, 0xF, false)); incl = t > incl ? t : incl; }
+            XDW_SCAN_STEP(0x111, 0xF) XDW_SCAN_STEP(0x112, 0xF) XDW_SCAN_STEP(0x114, 0xF) XDW_SCAN_STEP(0x118, 0xF)      // row_shr:1,2,4,8
+            XDW_SCAN_STEP(0x142, 0xA) XDW_SCAN_STEP(0x143, 0xC)                                                          // row_bcast:15, row_bcast:31
+#undef XDW_SCAN_STEP
+            const float excl = xdw_shr1(incl, -3.0e38f);
             const float pm = excl > BestScore ? excl : BestScore;
             const float pmi = incl > BestScore ? incl : BestScore;
             const float h = s - pm + X;
@@ -438,26 +483,25 @@ __global__ __launch_bounds__(64 * XDW_WAVES) void k_xdrop_wave(xd_args a)
             const float hi = v - pmi + X;
             const bool E1 = act && h > 0, E3 = act && hi > 0;
             E2 = E2 && act;
-            // next row's band
+            // next row's band: the candidates are j - 1, j, j + 1 of the cells with an event, so the min / max over the lanes
+            // are the first / last lanes of the event masks
+            const bool E0 = act && h > AbsOpen;
+            const unsigned long long m1 = __ballot(E1), m0 = __ballot(E0), m2 = __ballot(E2), m3 = __ballot(E3);
             uint32_t lo_c = U;
-            if (E1) lo_c = j + 1;
-            if (act && h > AbsOpen) lo_c = min(lo_c, j);
-            if (E2) lo_c = min(lo_c, j - 1);
-            if (E3) lo_c = min(lo_c, j + 1);
-            uint32_t e23 = 0;
-            if (E2) e23 = j - 1;
-            if (E3) e23 = max(e23, j + 1);
-            const unsigned long long m1 = __ballot(E1);
-            uint32_t l1 = 0;
-            if (m1) { l1 = 63u - (uint32_t) __builtin_clzll(m1); if (lane < l1) e23 = 0; }
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) {
-                lo_c = min(lo_c, (uint32_t) __shfl_xor((int) lo_c, d, 64));
-                e23 = max(e23, (uint32_t) __shfl_xor((int) e23, d, 64));
-            }
+            if (m1 | m3) lo_c = jc + (uint32_t) __builtin_ctzll(m1 | m3) + 1;
+            if (m0) lo_c = min(lo_c, jc + (uint32_t) __builtin_ctzll(m0));
+            if (m2) lo_c = min(lo_c, jc + (uint32_t) __builtin_ctzll(m2) - 1);
             next_jlo = min(next_jlo, lo_c);
-            if (m1) next_jhi = max(jc + l1 + 1, e23);
-            else if (next_jhi != U) next_jhi = max(next_jhi, e23);
+            {
+                uint32_t l1 = 0;
+                unsigned long long keep = ~0ull;                 // events that count: those of the last assigning cell and after it
+                if (m1) { l1 = 63u - (uint32_t) __builtin_clzll(m1); keep = ~0ull << l1; }
+                uint32_t e23 = 0;
+                if (m2 & keep) e23 = jc + 63u - (uint32_t) __builtin_clzll(m2 & keep) - 1;
+                if (m3 & keep) e23 = max(e23, jc + 63u - (uint32_t) __builtin_clzll(m3 & keep) + 1);
+                if (m1) next_jhi = max(jc + l1 + 1, e23);
+                else if (next_jhi != U) next_jhi = max(next_jhi, e23);
+            }
             // best cell: the last one that reaches the maximum (s >= BestScore updates, xdropfwd.cpp)
             const float mx = xdw_bcast(incl, 63);
             if (mx >= BestScore) {
@@ -465,22 +509,50 @@ __global__ __launch_bounds__(64 * XDW_WAVES) void k_xdrop_wave(xd_args a)
                 Besti = i;
                 Bestj = jc + 63u - (uint32_t) __builtin_clzll(__ballot(act && s == mx));
             }
-            if (act) { MD[j] = make_float2(s, d_new); TB[tb_row + j] = (uint8_t) bits; }
+            if (act) { MD(j) = make_float2(s, d_new); TB[tb_row + j] = (uint8_t) bits; }
             M0 = xdw_bcast(md0.x, n - 1);
             I0 = xdw_bcast(v, n - 1);
+            hL = xdw_bcast(h, n - 1);                            // of column jlast after the last step
+            hiL = xdw_bcast(hi, n - 1);
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        // ---- the last column and the cells the row may grow by: the reference's loop, run uniformly ----
+        // the cell of column jlast may extend the row (xdropfwd.cpp: the two "j == jhi" tests of a cell): the columns that
+        // enter the band are cleared as the reference clears them, including its overwrite of the cell's own fresh Mrow[j]
+        if (hL > AbsExt && jhi + 1 < LB) {
+            ++jhi;
+            if (RING && jhi - jlo + 5 > XDW_RING) return false;
+            const uint32_t new_endj = max(min(jhi + 1, LB), endj);
+            for (uint32_t j2 = endj + 1; j2 <= new_endj; ++j2) {
+                if (j2 - 1 > jlast) MD(j2 - 1).x = XD_MINUS_INF;
+                MD(j2).y = XD_MINUS_INF;
+            }
+            endj = new_endj;
+        } else if (hiL > AbsExt && jhi + 1 < LB) {
+            ++jhi;
+            if (RING && jhi - jlo + 5 > XDW_RING) return false;
+            const uint32_t new_endj = max(min(jhi + 1, LB), endj);
+            for (uint32_t j2 = endj + 1; j2 <= new_endj; ++j2) {
+                MD(j2 - 1).x = XD_MINUS_INF;                     // j2 - 1 == jlast: Mrow[jlast] just stored is lost, as in the reference
+                MD(j2).y = XD_MINUS_INF;
+            }
+            endj = new_endj;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        XDW_T(t_body);
+        XDW_ADD(0, t_body - t_row); XDW_ADD(4, 1); XDW_ADD(5, (jb_end - jlo + 63) / 64);
+        // ---- the cells the row grows by: the reference's loop, run uniformly ----
         for (uint32_t j = jb_end; j <= jhi; ++j) {
             uint8_t TraceBits = 0;
             const float SavedM0 = M0;
-            const float2 md0 = MD[j];
+            const float2 md0 = MD(j);
             float m_new, d_cur = md0.y;
             float xM = M0;
             if (d_cur > xM) { xM = d_cur; TraceBits = XD_DM; }
             if (I0 > xM) { xM = I0; TraceBits = XD_IM; }
             M0 = md0.x;
-            float s = sub(j);
+            float s = sub_w(cb_t0);
+            cb_t0 = cb_t1;
+            cb_t1 = load_cb(min(j + 2, LB));
             s += xM;
             m_new = s;
             const float h = s - BestScore + X;
@@ -488,11 +560,12 @@ __global__ __launch_bounds__(64 * XDW_WAVES) void k_xdrop_wave(xd_args a)
             if (h > AbsOpen) next_jlo = min(next_jlo, j);
             if (h > AbsExt && j == jhi && jhi + 1 < LB) {        // match-insert may extend the current row
                 ++jhi;
+                if (RING && jhi - jlo + 5 > XDW_RING) return false;
                 const uint32_t new_endj = max(min(jhi + 1, LB), endj);
                 for (uint32_t j2 = endj + 1; j2 <= new_endj; ++j2) {
-                    if (j2 - 1 > j) MD[j2 - 1].x = XD_MINUS_INF;
+                    if (j2 - 1 > j) MD(j2 - 1).x = XD_MINUS_INF;
                     if (j2 == j) d_cur = XD_MINUS_INF;
-                    else MD[j2].y = XD_MINUS_INF;
+                    else MD(j2).y = XD_MINUS_INF;
                 }
                 endj = new_endj;
             }
@@ -515,27 +588,30 @@ __global__ __launch_bounds__(64 * XDW_WAVES) void k_xdrop_wave(xd_args a)
                 if (hi > 0) { next_jlo = min(next_jlo, j + 1); next_jhi = max(next_jhi, j + 1); }
                 if (hi > AbsExt && j == jhi && jhi + 1 < LB) {
                     ++jhi;
+                    if (RING && jhi - jlo + 5 > XDW_RING) return false;
                     const uint32_t new_endj = max(min(jhi + 1, LB), endj);
                     for (uint32_t j2 = endj + 1; j2 <= new_endj; ++j2) {
                         if (j2 - 1 == j) m_new = XD_MINUS_INF;
-                        else MD[j2 - 1].x = XD_MINUS_INF;
+                        else MD(j2 - 1).x = XD_MINUS_INF;
                         if (j2 == j) d_new = XD_MINUS_INF;
-                        else MD[j2].y = XD_MINUS_INF;
+                        else MD(j2).y = XD_MINUS_INF;
                     }
                     endj = new_endj;
                 }
             }
-            MD[j] = make_float2(m_new, d_new);
+            MD(j) = make_float2(m_new, d_new);
             TB[tb_row + j] = TraceBits;
         }
+        XDW_T(t_tail);
+        XDW_ADD(1, t_tail - t_body); XDW_ADD(6, jhi - jb_end + 1);
         if (jhi < LB) {                                             // end of Drow[]
             const uint32_t jhi1 = jhi + 1;
             uint8_t t = 0;
             const float md = M0 + Open;
-            float d = MD[jhi1].y;
+            float d = MD(jhi1).y;
             d += Ext;
             if (md >= d) { d = md; t = XD_MD; }
-            MD[jhi1].y = d;
+            MD(jhi1).y = d;
             TB[tb_row + jhi1] = t;
         }
         if (next_jlo == U) break;
@@ -543,11 +619,12 @@ __global__ __launch_bounds__(64 * XDW_WAVES) void k_xdrop_wave(xd_args a)
         jlo = next_jlo; jhi = next_jhi;
         if (jlo > LB) jlo = LB;
         if (jhi > LB) jhi = LB;
-        if (jlo == prev_jlo) { M0 = XD_MINUS_INF; MD[jlo].y = XD_MINUS_INF; }
-        else M0 = MD[jlo - 1].x;
+        if (jlo == prev_jlo) { M0 = XD_MINUS_INF; MD(jlo).y = XD_MINUS_INF; }
+        else M0 = MD(jlo - 1).x;
     }
-    if (BestScore <= 0.0f) { a.score[e] = 0.0f; return; }
+    if (BestScore <= 0.0f) { a.score[e] = 0.0f; return true; }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    XDW_T(t_tb0);
     uint32_t i = Besti, j = Bestj, n = 0;
     char State = 'M';
     for (;;) {
@@ -569,9 +646,25 @@ __global__ __launch_bounds__(64 * XDW_WAVES) void k_xdrop_wave(xd_args a)
         }
         State = Next;
     }
+    XDW_T(t_tb1);
+    XDW_ADD(2, t_tb1 - t_tb0); XDW_ADD(7, n); XDW_ADD(8, 1);
     a.path_start[e] = dir ? 0 : cap - n;
     a.path_len[e] = n;
     a.score[e] = BestScore;
+    return true;
+#undef MD
+}
+
+__global__ __launch_bounds__(64 * XDW_WAVES) void k_xdrop_wave(xd_args a)
+{
+    __shared__ float tab[XD_TABLE_FLOATS];
+    __shared__ float2 ring[XDW_WAVES][XDW_RING];
+    for (int i = threadIdx.x; i < XD_TABLE_FLOATS; i += blockDim.x) tab[i] = c_xd_tables.t[i];
+    __syncthreads();
+    const uint32_t e = blockIdx.x * XDW_WAVES + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    if (e >= 2 * a.nreq) return;
+    if (!xdw_extend<true>(a, tab, ring[threadIdx.x >> 6], e, lane)) xdw_extend<false>(a, tab, nullptr, e, lane);
 }
 
 // launch of either form: RSK_XDROP_WAVE=0 selects the thread-per-extension kernel (tests run both)
