@@ -673,13 +673,16 @@ void RunMKFPairs(rsk_ctx *Ctx, const DSSParams &P, const std::string &Columns, D
         std::vector<uint32_t> iq(m), it(m);
         for (size_t k = 0; k < m; ++k) { iq[k] = Pairs[b + k].first; it[k] = Pairs[b + k].second; }
         std::vector<uint8_t> found(m);
-        size_t maxrec = std::max<size_t>(1024, m / 16), nrec = 0;
-        std::vector<uint32_t> rp, rn;
-        std::vector<int32_t> rk;
+        // Room for a record of every pair up to 2 M pairs: a self search seeds a few per cent of its long-chain pairs, a -db
+        // search with long queries 95 %, and a record list that overflows costs a second run of the whole seeding kernel.
+        // The arrays are not value-initialised (512 B per record; only the records returned are ever touched).
+        size_t maxrec = m <= ((size_t) 2 << 20) ? m : std::max<size_t>((size_t) 2 << 20, m / 4), nrec = 0;
+        std::unique_ptr<uint32_t[]> rp, rn;
+        std::unique_ptr<int32_t[]> rk;
         for (;;) {
-            rp.resize(maxrec); rn.resize(maxrec); rk.resize(maxrec * CAP * 4);
+            rp.reset(new uint32_t[maxrec]); rn.reset(new uint32_t[maxrec]); rk.reset(new int32_t[maxrec * CAP * 4]);
             check(rsk_mkf_seed_pairs(Ctx, SrcA.m_Db, SrcB.m_Db, iq.data(), it.data(), m, P.m_MKF_X1, P.m_MKF_MinHSPScore, CAP, found.data(), maxrec,
-                                     &nrec, rp.data(), rn.data(), rk.data()),
+                                     &nrec, rp.get(), rn.get(), rk.get()),
                   "rsk_mkf_seed_pairs");
             if (nrec <= maxrec) break;
             maxrec = nrec;
@@ -688,7 +691,7 @@ void RunMKFPairs(rsk_ctx *Ctx, const DSSParams &P, const std::string &Columns, D
             Rec R;
             R.pair = (uint32_t) (b + rp[r]);
             R.nkept = rn[r];
-            R.kept.assign(rk.begin() + r * CAP * 4, rk.begin() + r * CAP * 4 + 4 * (size_t) std::min(rn[r], CAP));
+            R.kept.assign(rk.get() + r * CAP * 4, rk.get() + r * CAP * 4 + 4 * (size_t) std::min(rn[r], CAP));
             recs.push_back(std::move(R));
         }
     }

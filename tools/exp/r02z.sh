@@ -1,2 +1,3 @@
-timeout 600 python -m pytest tests/test_gpu_xdrop.py tests/test_gpu_mkf.py -x -q 2>&1 | tail -3
-RSK_MKF_OVERLAP=0 bash tools/prof_search.sh r02z_c3s qdb 256 30000 sensitive | head -8
+timeout 900 python -m pytest tests/test_gpu_xdrop.py tests/test_gpu_mkf.py tests/test_gpu_search.py -x -q 2>&1 | tail -3
+timeout 300 python tools/bench_search.py qdb 256 30000 sensitive 2>/dev/null | grep '"seconds"'
+timeout 600 python tools/bench_search.py qdb 256 125000 sensitive 2>/dev/null | grep '"seconds"'
