@@ -688,6 +688,8 @@ __global__ __launch_bounds__(256) void k_lddt(const char *paths, const uint64_t 
     __shared__ float4 sc4[4][LDDT_LDS_COLS];
     __shared__ float2 sc2[4][LDDT_LDS_COLS];
     __shared__ uint32_t scnt[4][LDDT_LDS_COLS];
+    __shared__ uint32_t sq_cols[4][128];            // queue of column pairs within R0: (ci | cj << 16), squared distances
+    __shared__ float2 sq_d[4][128];
     const uint32_t p = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (p >= npairs) return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -731,49 +733,94 @@ __global__ __launch_bounds__(256) void k_lddt(const char *paths, const uint64_t 
         // the order of the additions is immaterial).  All lanes busy whatever ncols is, half the distance work.
         for (uint32_t c = lane; c < ncols; c += 64) {
             const uint32_t a1 = posA[c], b1 = posB[c];
-            sc4[wv][c] = make_float4(AX[a1], AY[a1], AZ[a1], BX[b1]);
-            sc2[wv][c] = make_float2(BY[b1], BZ[b1]);
+            sc4[wv][c] = make_float4(AX[a1], BX[b1], AY[a1], BY[b1]);        // (A, B) pairs per axis: the two distances run as packed fp32 ops
+            sc2[wv][c] = make_float2(AZ[a1], BZ[b1]);
             scnt[wv][c] = 0;
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         const uint32_t C = ncols, npair = C * (C - 1) / 2, per = (npair + 63) / 64;
         const uint32_t t0 = (uint32_t) lane * per, t1 = min(npair, t0 + per);
+        // Two phases per step so that the expensive part runs on full waves: every lane tests one column pair (two squared
+        // distances); the ~10 % that lie within R0 are compacted into a per-wave LDS queue (ballot + prefix count), and
+        // whenever 64 are waiting each lane finishes one of them (two correctly rounded square roots, the four
+        // thresholds, the counters of both columns).  Before, the wave ran the square-root block on almost every step
+        // for the few lanes that needed it.
+        uint32_t ci = 0, cj = 1;
+        float4 p4 = make_float4(0, 0, 0, 0);
+        float2 p2 = make_float2(0, 0);
         if (t0 < t1) {
             // row of the first pair: largest ci with ci (2C - ci - 1) / 2 <= t0
             const float twoc = (float) (2 * C - 1);
-            uint32_t ci = (uint32_t) ((twoc - sqrtf(fmaxf(twoc * twoc - 8.0f * (float) t0, 0.0f))) * 0.5f);
+            ci = (uint32_t) ((twoc - sqrtf(fmaxf(twoc * twoc - 8.0f * (float) t0, 0.0f))) * 0.5f);
             ci = min(ci, C - 2);
             while (ci > 0 && ci * (2 * C - ci - 1) / 2 > t0) --ci;
             while ((ci + 1) * (2 * C - ci - 2) / 2 <= t0) ++ci;
-            uint32_t cj = ci + 1 + (t0 - ci * (2 * C - ci - 1) / 2);
-            float4 p4 = sc4[wv][ci];
-            float2 p2 = sc2[wv][ci];
-            uint32_t own = 0;
-            for (uint32_t t = t0; t < t1; ++t) {
+            cj = ci + 1 + (t0 - ci * (2 * C - ci - 1) / 2);
+            p4 = sc4[wv][ci];
+            p2 = sc2[wv][ci];
+        }
+        uint32_t qn = 0;                                          // entries waiting in the queue (wave-uniform)
+        auto drain = [&](uint32_t n) {                            // the first n entries, one per lane
+            if ((uint32_t) lane < n) {
+                const uint32_t cc = sq_cols[wv][lane];
+                const float2 dd = sq_d[wv][lane];
+                const float d1 = sqrtf(dd.x), d2 = sqrtf(dd.y);
+                const float diff = fabsf(d1 - d2);
+                const uint32_t inc = 4u | (((diff <= 0.5f) + (diff <= 1.0f) + (diff <= 2.0f) + (diff <= 4.0f)) << 16);
+                atomicAdd(&scnt[wv][cc & 0xFFFFu], inc);
+                atomicAdd(&scnt[wv][cc >> 16], inc);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            // the entries behind the first 64 move to the front
+            if (n == 64 && qn > 64) {
+                const uint32_t rest = qn - 64;
+                uint32_t cc = 0;
+                float2 dd = make_float2(0, 0);
+                if ((uint32_t) lane < rest) { cc = sq_cols[wv][64 + lane]; dd = sq_d[wv][64 + lane]; }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                if ((uint32_t) lane < rest) { sq_cols[wv][lane] = cc; sq_d[wv][lane] = dd; }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            }
+            qn -= n;
+        };
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        for (uint32_t k = 0; k < per; ++k) {
+            const bool live = t0 + k < t1;
+            bool hit = false;
+            float d1s = 0.0f, d2s = 0.0f;
+            if (live) {
                 const float4 q4 = sc4[wv][cj];
                 const float2 q2 = sc2[wv][cj];
-                // (x1-x2)^2 == (x2-x1)^2 exactly, so the reference's (lower column) - (higher column) order is immaterial
-                const float dx = p4.x - q4.x, dy = p4.y - q4.y, dz = p4.z - q4.z;
-                const float ex = p4.w - q4.w, ey = p2.x - q2.x, ez = p2.y - q2.y;
-                float d1s = dx * dx; d1s += dy * dy; d1s += dz * dz;       // pdbchain.cpp:320-335: dx*dx + dy*dy + dz*dz
-                float d2s = ex * ex; d2s += ey * ey; d2s += ez * ez;
-                if (!(d1s > R0sq && d2s > R0sq)) {
-                    const float d1 = sqrtf(d1s), d2 = sqrtf(d2s);
-                    const float diff = fabsf(d1 - d2);
-                    const uint32_t inc = 4u | (((diff <= 0.5f) + (diff <= 1.0f) + (diff <= 2.0f) + (diff <= 4.0f)) << 16);
-                    own += inc;
-                    atomicAdd(&scnt[wv][cj], inc);
-                }
-                if (++cj == C) {
-                    if (own) atomicAdd(&scnt[wv][ci], own);
-                    own = 0;
-                    ++ci;
-                    cj = ci + 1;
-                    if (ci < C - 1) { p4 = sc4[wv][ci]; p2 = sc2[wv][ci]; }
-                }
+                // (x1-x2)^2 == (x2-x1)^2 exactly, so the reference's (lower column) - (higher column) order is immaterial.
+                // pdbchain.cpp:320-335: dx*dx + dy*dy + dz*dz, every product and sum rounded separately (-ffp-contract=off);
+                // lane-wise packed ops (v_pk_add_f32 / v_pk_mul_f32) do the A-side and the B-side distance at once
+                swq_v2f X = swq_v2f{ p4.x, p4.y } - swq_v2f{ q4.x, q4.y };
+                swq_v2f Y = swq_v2f{ p4.z, p4.w } - swq_v2f{ q4.z, q4.w };
+                swq_v2f Z = swq_v2f{ p2.x, p2.y } - swq_v2f{ q2.x, q2.y };
+                swq_v2f D = X * X;
+                D += Y * Y;
+                D += Z * Z;
+                d1s = D.x; d2s = D.y;
+                hit = !(d1s > R0sq && d2s > R0sq);
             }
-            if (own) atomicAdd(&scnt[wv][ci], own);
+            const unsigned long long m = __ballot(hit);
+            if (m) {
+                if (hit) {
+                    const uint32_t slot = qn + (uint32_t) __popcll(m & lt);
+                    sq_cols[wv][slot] = ci | (cj << 16);
+                    sq_d[wv][slot] = make_float2(d1s, d2s);
+                }
+                qn += (uint32_t) __popcll(m);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                if (qn >= 64) drain(64);
+            }
+            if (live && ++cj == C) {
+                ++ci;
+                cj = ci + 1;
+                if (ci < C - 1) { p4 = sc4[wv][ci]; p2 = sc2[wv][ci]; }
+            }
         }
+        if (qn) drain(qn);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         // per-column fractions in registers (column c in lane c % 64, slot c / 64), then the reference's sequential
         // sum in column order (lddt.cpp:111-121): one v_readlane + v_add per column instead of a dependent LDS read
