@@ -16,6 +16,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <functional>
@@ -42,7 +43,7 @@ struct PhaseTimer {                              // RSK_TRACE=1: wall time of th
         const auto t1 = std::chrono::steady_clock::now();
         // @: wall clock in ms modulo 100 s, to line up the stages of concurrent threads
         fprintf(stderr, "[%s] %-22s %9.3f ms   @%.1f\n", who, what, std::chrono::duration<double, std::milli>(t1 - t0).count(),
-                std::chrono::duration<double, std::milli>(t1.time_since_epoch()).count() - 1e5 * floor(std::chrono::duration<double>(t1.time_since_epoch()).count() / 100));
+                std::chrono::duration<double, std::milli>(t1.time_since_epoch()).count() - 1e5 * std::floor(std::chrono::duration<double>(t1.time_since_epoch()).count() / 100));
         t0 = t1;
     }
 };
