@@ -636,7 +636,11 @@ void ForEachAlignedBatch(const DSSParams &P, rsk_ctx *ctx, const SearchOptions &
     std::deque<std::future<std::unique_ptr<AlignedBatch> > > q;
     size_t launched = 0;
     auto drain = [&]() { for (auto &f : q) if (f.valid()) f.wait(); };   // stages in flight reference this frame
-    if (!batches.empty()) q.push_back(launch(launched++));               // the first stage runs alone (one-time table uploads)
+    // the first stage of a process runs alone (one-time table uploads); later calls (the next batch of a streamed
+    // database) start with both stages
+    static std::atomic<bool> tables_up{false};
+    if (!batches.empty()) q.push_back(launch(launched++));
+    if (tables_up.load() && second.c && launched < batches.size()) q.push_back(launch(launched++));
     for (size_t k = 0; k < batches.size(); ++k) {
         std::unique_ptr<AlignedBatch> cur;
         try {
@@ -646,6 +650,7 @@ void ForEachAlignedBatch(const DSSParams &P, rsk_ctx *ctx, const SearchOptions &
             drain();
             throw;
         }
+        tables_up.store(true);
         q.pop_front();
         while (launched < batches.size() && q.size() < (second.c ? 2u : 1u)) q.push_back(launch(launched++));
         try {
@@ -1160,10 +1165,12 @@ void DBSearcher::RunQuery(ChainReader2 &QCR)
             for (PDBChain *C : Chains) delete C;
             throw;
         }
+        Src->UploadToGpu();                              // here, beside the search of the previous batch (synchronous copies)
         return Src;
     };
     uint64_t pairs = 0, alns = 0, mkf = 0, fin = 0, fdis = 0;
     std::future<std::unique_ptr<DBSearcher> > next = std::async(std::launch::async, load);
+    std::future<void> teardown;                          // the previous batch (32,768 chains, its device arrays) is freed off this thread
     for (;;) {
         std::unique_ptr<DBSearcher> Src = next.get();
         if (!Src) break;
@@ -1174,8 +1181,11 @@ void DBSearcher::RunQuery(ChainReader2 &QCR)
             next.wait();
             throw;
         }
+        if (teardown.valid()) teardown.wait();
+        teardown = std::async(std::launch::async, [dead = std::shared_ptr<DBSearcher>(Src.release())]() mutable { dead.reset(); });
         pairs += m_ProcessedPairCount; alns += m_AlnCount; mkf += m_MKFPairCount; fin += m_MuFilterInputCount; fdis += m_MuFilterDiscardCount;
     }
+    if (teardown.valid()) teardown.wait();
     m_ProcessedPairCount = pairs; m_AlnCount = alns; m_MKFPairCount = mkf; m_MuFilterInputCount = fin; m_MuFilterDiscardCount = fdis;
 }
 
