@@ -1057,7 +1057,7 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
     // per-pair kernel's (strips, steps) ordering the profile kernel only wins for groups of hundreds of pairs (one
     // workgroup per CU idles while its longest pair finishes), e.g. a query against a database; all-vs-all survivor
     // groups (tens of pairs) stay with the per-pair kernel.
-    const uint32_t min_lanes = getenv("RSK_SWQ_MIN_LANES") ? (uint32_t) atoi(getenv("RSK_SWQ_MIN_LANES")) : 8192;
+    const uint32_t min_lanes = getenv("RSK_SWQ_MIN_LANES") ? (uint32_t) atoi(getenv("RSK_SWQ_MIN_LANES")) : 4096;
     auto qp_bucket = [&](uint32_t count, uint32_t L) -> int {
         if (L == 0) return -1;
         const uint32_t g = std::min<uint32_t>((L + SWQ_R - 1) / SWQ_R, SWQ_MAX_G);
