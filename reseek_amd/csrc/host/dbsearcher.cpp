@@ -935,12 +935,31 @@ static void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOff
         S.m_MuFilterInputCount = npairs - nmkf;
         S.m_MuFilterDiscardCount = S.m_MuFilterInputCount - ia.size();
     } else {
-        for (uint i = 0; i < NA; ++i)
-            for (uint j = Self ? (i > joff ? i - joff : 0) : 0; j < NB; ++j) {
-                if (Skip(i, j)) continue;
-                ia.push_back(i); ib.push_back(j);
-                ++npairs;
+        // every pair of the enumerated space (tens of millions for a query batch against a DB batch): row starts by a
+        // prefix sum, rows filled on the host threads
+        std::vector<uint64_t> first((size_t) NA + 1, 0);
+        rsk_parallel_for(NA, 4096, [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; ++i) {
+                const uint j0 = Self ? ((uint) i > joff ? (uint) i - joff : 0) : 0;
+                uint64_t c = NB > j0 ? NB - j0 : 0;
+                if (S.m_Opts.noself)
+                    for (uint j = j0; j < NB; ++j) c -= Skip((uint) i, j) ? 1 : 0;
+                first[i + 1] = c;
             }
+        });
+        for (uint i = 0; i < NA; ++i) first[i + 1] += first[i];
+        npairs = first[NA];
+        ia.resize(npairs); ib.resize(npairs);
+        rsk_parallel_for(NA, 256, [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; ++i) {
+                uint64_t k = first[i];
+                for (uint j = Self ? ((uint) i > joff ? (uint) i - joff : 0) : 0; j < NB; ++j) {
+                    if (Skip((uint) i, j)) continue;
+                    ia[k] = (uint32_t) i; ib[k] = j;
+                    ++k;
+                }
+            }
+        });
     }
     S.m_ProcessedPairCount = npairs;
     S.m_AlnCount = npairs - mkf.size();

@@ -1200,7 +1200,11 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
                 const uint32_t npw = 64 / std::min<uint32_t>(SWQ_MAX_G, gtot - s0);
                 nblocks += (it.count + npw - 1) / npw;
             }
-            it.ncol = lmax + std::min<uint32_t>(SWQ_MAX_G, gtot);                           // column index = step + strip-in-segment
+            // column index = step + strip-in-segment.  A block is written by ONE wave through its CU's scalar cache: blocks
+            // start on 128-byte lines and span whole lines (ncol a multiple of 4: 4 x 480 B = 15 lines), so no cache line is
+            // ever shared between the scalar caches of two CUs
+            it.ncol = (lmax + std::min<uint32_t>(SWQ_MAX_G, gtot) + 3) & ~3u;
+            tbo = (tbo + 127) & ~(uint64_t) 127;
             it.tb_base = tbo;
             tbo += nblocks * it.ncol * SWQ_COL_BYTES;
         }
