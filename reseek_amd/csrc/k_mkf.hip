@@ -17,6 +17,7 @@
 
 #define MKF_HASHW 4
 #define MKF_WAVES 4
+#define MKF_QUEUE 320               // seeds waiting for a full wave: < 64 + 64 target positions x 4 slots
 
 // Table of one query chain: open addressing, 2^bits >= 2 * (L - 2) slots of 16 bytes
 //   { k-mer, pos0 | pos1 << 16, pos2 | pos3 << 16, unused },   empty slot: k-mer = MKF_EMPTY, unused positions 0xFFFF.
@@ -128,55 +129,80 @@ __global__ __launch_bounds__(64 * MKF_WAVES) void k_mkf_seed(mkf_args a)
     const uint32_t slot = a.qslot[p], bits = a.tab_bits[slot], hmask = (1u << bits) - 1;
     const uint4 *tab = a.tables + a.tab_off[slot];
     __shared__ int4 skept[MKF_WAVES][MKF_CAP_MAX];
+    __shared__ uint32_t sseeds[MKF_WAVES][MKF_QUEUE];
     int4 *kept = skept[threadIdx.x >> 6];
+    uint32_t *queue = sseeds[threadIdx.x >> 6];
     int best = 0;
-    uint32_t nk = 0;
+    uint32_t nk = 0, qn = 0;
     bool found = false;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    // Two phases so that the extensions run on full waves: the lanes look up the (<= 4) query positions of 64 target
+    // positions and append them as seeds (PosQ | PosT << 16) to an LDS queue in (PosT, slot) order -- only a few per cent
+    // of the 3-mers occur in the query, so seed by seed the wave would sit in the extension loop with one or two lanes
+    // active; whenever 64 seeds wait each lane extends one.  The order-dependent keep rule then walks, in queue order,
+    // the lanes that beat the running best.
+    auto process = [&](uint32_t n) {                              // the first n <= 64 seeds of the queue
+        int sc = 0, loi = 0, loj = 0, len = 0;
+        if ((uint32_t) lane < n) {
+            const uint32_t sd = queue[lane];
+            const int v = mkf_xdrop(Q, LQ, T, LT, (int) (sd & 0xFFFFu), (int) (sd >> 16), a.X, loi, loj, len);
+            if (v >= a.min_score) sc = v;
+        }
+        if (__ballot(sc > 0)) found = true;
+        unsigned long long m = __ballot(sc > best);
+        while (m) {
+            const int l = __builtin_ctzll(m);
+            const int v = __shfl(sc, l, 64);
+            if (v > best) {                                       // strictly improving (mukmerfilter.cpp:362)
+                best = v;
+                const int Li = __shfl(loi, l, 64), Lj = __shfl(loj, l, 64), Ln = __shfl(len, l, 64);
+                // "Old" test: an HSP with this Loi was kept before (:364-371); the list is short
+                bool old = false;
+                for (uint32_t k = lane; k < min(nk, a.cap); k += 64) old |= kept[k].x == Li;
+                if (!__ballot(old)) {
+                    if (lane == 0 && nk < a.cap) kept[nk] = make_int4(Li, Lj, Ln, v);
+                    ++nk;
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                }
+            }
+            m &= m - 1;
+            m &= __ballot(sc > best);                            // later seeds must still beat the new best
+        }
+        // the seeds behind the first n move to the front
+        const uint32_t rest = qn - n;
+        for (uint32_t k0 = 0; k0 < rest; k0 += 64) {
+            uint32_t v = 0;
+            if (k0 + lane < rest) v = queue[n + k0 + lane];
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            if (k0 + lane < rest) queue[k0 + lane] = v;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        }
+        qn = rest;
+    };
     for (int base = 0; base + 3 <= LT; base += 64) {
         const int PosT = base + lane;
-        int sc[MKF_HASHW], loi[MKF_HASHW], loj[MKF_HASHW], len[MKF_HASHW];
-        int mx = 0;
-#pragma unroll
-        for (int w = 0; w < MKF_HASHW; ++w) sc[w] = 0;
+        uint32_t pos[4] = { 0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu };
         if (PosT + 3 <= LT) {
             const uint32_t k = ((uint32_t) T[PosT] * 36 + T[PosT + 1]) * 36 + T[PosT + 2];
             uint32_t h = mkf_hash(k, bits);
             uint4 s = tab[h];
             while (s.x != k && s.x != MKF_EMPTY) { h = (h + 1) & hmask; s = tab[h]; }
-            if (s.x != k) s.y = s.z = 0xFFFFFFFFu;
-            const uint32_t pos[4] = { s.y & 0xFFFFu, s.y >> 16, s.z & 0xFFFFu, s.z >> 16 };
-#pragma unroll
-            for (int w = 0; w < MKF_HASHW; ++w) {
-                if (pos[w] == 0xFFFFu) continue;
-                const int v = mkf_xdrop(Q, LQ, T, LT, (int) pos[w], PosT, a.X, loi[w], loj[w], len[w]);
-                if (v >= a.min_score) { sc[w] = v; mx = max(mx, v); }
-            }
+            if (s.x == k) { pos[0] = s.y & 0xFFFFu; pos[1] = s.y >> 16; pos[2] = s.z & 0xFFFFu; pos[3] = s.z >> 16; }
         }
-        if (__ballot(mx > 0)) found = true;
-        // lanes whose best candidate beats the running best, in lane (= PosT) order
-        unsigned long long m = __ballot(mx > best);
-        while (m) {
-            const int l = __builtin_ctzll(m);
+        // positions fill the slots from the front (first come), so the count says which are valid
+        const uint32_t c = (pos[0] != 0xFFFFu) + (pos[1] != 0xFFFFu) + (pos[2] != 0xFFFFu) + (pos[3] != 0xFFFFu);
+        const unsigned long long b0 = __ballot(c & 1u), b1 = __ballot(c & 2u), b2 = __ballot(c & 4u);
+        if (b0 | b1 | b2) {
+            const uint32_t offs = (uint32_t) __popcll(b0 & lt) + 2u * (uint32_t) __popcll(b1 & lt) + 4u * (uint32_t) __popcll(b2 & lt);
 #pragma unroll
-            for (int w = 0; w < MKF_HASHW; ++w) {
-                const int v = __shfl(sc[w], l, 64);
-                if (v > best) {                                   // strictly improving (mukmerfilter.cpp:362)
-                    best = v;
-                    const int Li = __shfl(loi[w], l, 64), Lj = __shfl(loj[w], l, 64), Ln = __shfl(len[w], l, 64);
-                    // "Old" test: an HSP with this Loi was kept before (:364-371); the list is short
-                    bool old = false;
-                    for (uint32_t k = lane; k < min(nk, a.cap); k += 64) old |= kept[k].x == Li;
-                    if (!__ballot(old)) {
-                        if (lane == 0 && nk < a.cap) kept[nk] = make_int4(Li, Lj, Ln, v);
-                        ++nk;
-                        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                    }
-                }
-            }
-            m &= m - 1;
-            m &= __ballot(mx > best);                            // later lanes must still beat the new best
+            for (int w = 0; w < MKF_HASHW; ++w)
+                if ((uint32_t) w < c) queue[qn + offs + w] = pos[w] | ((uint32_t) PosT << 16);
+            qn += (uint32_t) __popcll(b0) + 2u * (uint32_t) __popcll(b1) + 4u * (uint32_t) __popcll(b2);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            while (qn >= 64) process(64);
         }
     }
+    if (qn) process(qn);
     if (lane == 0) a.found[p] = found ? 1 : 0;
     if (found) {
         uint32_t r = 0;
