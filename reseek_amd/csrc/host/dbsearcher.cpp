@@ -1162,10 +1162,14 @@ void DBSearcher::RunQuery(ChainReader2 &QCR)
     UploadToGpu();
     SecondaryCtx loader;
     loader.Create(m_Ctx->device, "loader");
+    // The first batch is a quarter of the others: nothing can run on the GPU before it is featurised, and the loader has
+    // the second (full) batch ready by the time the first has gone through the kernels.
+    size_t nloaded = 0;
     auto load = [&]() -> std::unique_ptr<DBSearcher> {
         std::vector<PDBChain *> Chains;
         uint64_t nres = 0;
-        while (Chains.size() < m_StreamBatchChains && nres < m_StreamBatchResidues) {
+        const size_t maxc = nloaded++ == 0 ? std::max<size_t>(std::min<size_t>(m_StreamBatchChains, 1024), m_StreamBatchChains / 4) : m_StreamBatchChains;
+        while (Chains.size() < maxc && nres < m_StreamBatchResidues) {
             PDBChain *C = QCR.GetNext();
             if (!C) break;
             nres += C->GetSeqLength();
