@@ -873,11 +873,13 @@ static void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOff
             cap = ns;
         }
         d_fwd = D.fwd; d_pq = D.pq; d_pt = D.pt; d_n = D.n;
+        tm.lap("  Mu filter kernels");
         std::vector<uint32_t> pq(ns), pt(ns);
         hipok(hipMemcpy(pq.data(), d_pq, (size_t) ns * 4, hipMemcpyDeviceToHost), "copy pairs");
         hipok(hipMemcpy(pt.data(), d_pt, (size_t) ns * 4, hipMemcpyDeviceToHost), "copy pairs");
         (void) hipFree(D.fwd); (void) hipFree(D.pq); (void) hipFree(D.pt); (void) hipFree(D.n);
         D.fwd = nullptr; D.pq = D.pt = D.n = nullptr;
+        tm.lap("  survivors d2h + free");
         if (Swap) pq.swap(pt);                                               // back to (A-side, B-side)
         // deterministic order (the device list is unordered)
         // counting sort by the A-side chain, then each chain's partners ascending (on the host worker threads)
@@ -891,6 +893,7 @@ static void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOff
         rsk_parallel_for(NA, 4096, [&](size_t lo, size_t hi) {
             for (size_t i = lo; i < hi; ++i) std::sort(partners.begin() + first[i], partners.begin() + first[i + 1]);
         });
+        tm.lap("  survivor order");
         uint64_t nmkf = 0, nskip = 0;
         ia.reserve(ns); ib.reserve(ns);
         for (uint i = 0; i < NA; ++i)
@@ -899,6 +902,7 @@ static void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOff
                 if (!InShard(i, j) || Skip(i, j) || IsMKF(i, j)) continue;
                 ia.push_back(i); ib.push_back(j);
             }
+        tm.lap("  alignment pair list");
         // MKF pairs = either chain >= m_MKFL (both with k-mers): enumerated from the list of long chains,
         // not by walking the whole pair space
         std::vector<uint32_t> longB;
