@@ -127,6 +127,46 @@ void DBSearcher::LoadChains(std::vector<PDBChain *> &Chains)
     const bool WantRev = !m_Opts.selfrev0 && m_Ctx;
     m_RevProfiles.clear();
     if (WantRev) m_RevProfiles.resize(N);
+    // The two density features (two thirds of the host featurisation: libm exp) come from the device for the whole batch,
+    // chains and reversed chains (rsk_dss_densities, k_dss.hip); DSS::UseDeviceDensities accepts them chain by chain
+    // only where no binned value is near a bin boundary, so the letters stay the host's.  RSK_GPU_DENSITY=0: host only.
+    std::vector<uint64_t> roff;
+    std::vector<std::string> ssf, ssr;
+    std::unique_ptr<double[]> dens;                          // [4][total]: density / strand density of the chains, of the reversed chains
+    uint64_t rtotal = 0;
+    std::atomic<uint64_t> dens_fallbacks{0};
+    if (m_Ctx && N && !(getenv("RSK_GPU_DENSITY") && atoi(getenv("RSK_GPU_DENSITY")) == 0)) {
+        roff.assign((size_t) N + 1, 0);
+        for (uint i = 0; i < N; ++i) roff[i + 1] = roff[i] + m_DBChains[i]->GetSeqLength();
+        rtotal = roff[N];
+        ssf.resize(N); ssr.resize(N);
+        std::unique_ptr<float[]> px(new float[rtotal + 1]), py(new float[rtotal + 1]), pz(new float[rtotal + 1]);
+        std::unique_ptr<char[]> pf(new char[rtotal + 1]), pr(new char[rtotal + 1]);
+        std::vector<uint32_t> len(N);
+        rsk_parallel_for(N, 256, [&](size_t lo, size_t hi) {
+            PDBChain R;
+            for (size_t i = lo; i < hi; ++i) {
+                const PDBChain &C = *m_DBChains[i];
+                const uint L = C.GetSeqLength();
+                len[i] = L;
+                C.GetSS(ssf[i]);
+                C.GetReverse(R);
+                R.GetSS(ssr[i]);
+                memcpy(&px[roff[i]], C.m_Xs.data(), 4 * (size_t) L);
+                memcpy(&py[roff[i]], C.m_Ys.data(), 4 * (size_t) L);
+                memcpy(&pz[roff[i]], C.m_Zs.data(), 4 * (size_t) L);
+                memcpy(&pf[roff[i]], ssf[i].data(), L);
+                memcpy(&pr[roff[i]], ssr[i].data(), L);
+            }
+        });
+        dens.reset(new double[4 * rtotal + 4]);
+        DSS D0;
+        check(rsk_dss_densities(m_Ctx, N, len.data(), px.get(), py.get(), pz.get(), pf.get(), pr.get(), D0.m_Density_W, D0.m_Density_w,
+                                D0.m_SSDensity_w, D0.m_Density_Radius, D0.m_SSDensity_epsilon, dens.get(), dens.get() + rtotal,
+                                dens.get() + 2 * rtotal, dens.get() + 3 * rtotal),
+              "rsk_dss_densities");
+        tm.lap("densities (device)");
+    }
     auto body = [&]() {
         DSS D, DR;
         D.SetParams(*m_Params);
@@ -140,6 +180,7 @@ void DBSearcher::LoadChains(std::vector<PDBChain *> &Chains)
             std::vector<byte> Mu;
             std::vector<uint> Kmers;
             D.Init(*m_DBChains[i]);
+            if (dens && !D.UseDeviceDensities(dens.get() + roff[i], dens.get() + rtotal + roff[i], &ssf[i])) ++dens_fallbacks;
             D.GetProfile(Prof);
             D.GetMuLetters(Mu);
             DSS::GetMuKmers(Mu, Kmers, m_Params->m_MKFPatternStr);
@@ -151,7 +192,11 @@ void DBSearcher::LoadChains(std::vector<PDBChain *> &Chains)
                 PDBChain R;
                 std::vector<std::vector<byte> > RevProf;
                 m_DBChains[i]->GetReverse(R);
-                DR.InitReversed(R, D);
+                DR.Init(R);
+                if (!(dens && DR.UseDeviceDensities(dens.get() + 2 * rtotal + roff[i], dens.get() + 3 * rtotal + roff[i], &ssr[i]))) {
+                    if (dens) ++dens_fallbacks;
+                    DR.InitReversed(R, D);
+                }
                 DR.GetProfile(RevProf);
                 m_RevProfiles[i].swap(RevProf);
             }
@@ -161,6 +206,8 @@ void DBSearcher::LoadChains(std::vector<PDBChain *> &Chains)
     for (unsigned t = 0; t < T; ++t) ts.emplace_back(body);
     for (auto &t : ts) t.join();
     tm.lap("featurise (host)");
+    if (dens && getenv("RSK_TRACE")) fprintf(stderr, "[LoadChains] %u chains: %llu chain featurisations redone on the host (density near a bin boundary)\n", N,
+                                             (unsigned long long) dens_fallbacks.load());
     ComputeSelfRevScores();
     tm.lap("self-rev scores");
 }

@@ -282,6 +282,33 @@ void DSS::SetDensities()
     }
 }
 
+bool DSS::UseDeviceDensities(const double *Dens, const double *StrandDens, const std::string *SS)
+{
+    const uint L = GetSeqLength();
+    const double Margin = 1e-9;                                       // device-vs-libm exp: the values differ by ~1e-14
+    auto near_a_boundary = [&](const double *T, double v) {
+        for (uint k = 0; k < 15; ++k)
+            if (fabs(v - T[k]) <= Margin) return true;
+        return false;
+    };
+    // feature 6 (dss.cpp:339-372) bins the strand density itself
+    for (uint Pos = 0; Pos < L; ++Pos)
+        if (StrandDens[Pos] != DBL_MAX && near_a_boundary(rsk_bins_StrandDens, StrandDens[Pos])) return false;
+    // feature 7 bins (D - min) / max(range, 1) (SetDensity_ScaledValues, dss.cpp:179-215)
+    double MinValue = 999, MaxValue = 0;
+    for (uint Pos = 0; Pos < L; ++Pos)
+        if (Dens[Pos] != DBL_MAX) { MinValue = std::min(MinValue, Dens[Pos]); MaxValue = std::max(MaxValue, Dens[Pos]); }
+    double Range = MaxValue - MinValue;
+    if (fabs(Range - 1) <= Margin) return false;                      // which side of "Range < 1" is not certain
+    if (Range < 1) Range = 1;
+    for (uint Pos = 0; Pos < L; ++Pos)
+        if (Dens[Pos] != DBL_MAX && near_a_boundary(rsk_bins_NormDens, (Dens[Pos] - MinValue) / Range)) return false;
+    m_DensityValues.assign(Dens, Dens + L);
+    m_StrandDensValues.assign(StrandDens, StrandDens + L);
+    if (SS) m_SS = *SS;
+    return true;
+}
+
 void DSS::SetDensity_ScaledValues()                                   // dss.cpp:179-215
 {
     if (!m_Density_ScaledValues.empty()) return;

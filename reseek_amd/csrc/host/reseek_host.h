@@ -167,6 +167,10 @@ public:
     void SetConfLetters();
     void SetDensities();
     void InitReversed(const PDBChain &Rev, DSS &Fwd);   // Init(Rev) + the exp() table mirrored from Fwd (Fwd is on the un-reversed chain)
+    // Densities of this chain as rsk_dss_densities (k_dss.hip) computed them: device exp() differs from libm's in the last
+    // bit, so they are accepted only if every quantity that gets binned lies further than 1e-9 from all bin boundaries
+    // (then the letters are the host's, bit for bit); false = nothing kept, featurise on the host as usual.
+    bool UseDeviceDensities(const double *Dens, const double *StrandDens, const std::string *SS = nullptr);
     double DistFactor(uint Pos, uint Pos2) const      // Pos != Pos2, |Pos - Pos2| <= window
     {
         return Pos2 > Pos ? m_DistFactors[(size_t) Pos * m_DistFactorW + (Pos2 - Pos - 1)] : m_DistFactors[(size_t) Pos2 * m_DistFactorW + (Pos - Pos2 - 1)];

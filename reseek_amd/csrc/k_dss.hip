@@ -1,0 +1,139 @@
+// k_dss.hip -- the exp()-heavy part of the DSS featurisation on the device (the per-chain
+// inputs of the path): the two density features of dss.cpp,
+//   GetDensity      dss.cpp:217-244   D1(Pos)  = sum over |q - Pos| in (w1, W] of exp(-dist(Pos, q) / R)
+//   GetSSDensity    dss.cpp:339-372   Dc / (D2 + eps), D2 the same sum over |q - Pos| in (w2, W], Dc its strand ('s') part
+// for every position of a batch of chains AND of their reversed copies (GetSelfRevScore alignpair.cpp:7-24 featurises
+// the reversed chain).  On the host they are two thirds of the featurisation time (libm exp), which is what a 16-CPU
+// container spends most of its cycles on while a .bca database streams past a query batch.
+//
+// Exactness: distances are the reference's float expression (pdbchain.cpp:310) and the sums run in its order
+// (ascending q), in double; the only operation that differs from the host is exp() (device libm, <= 1 ulp, against
+// glibc's), so a density differs from the host's by a few 1e-16 relative.  The host (DSS::UseDeviceDensities,
+// host/dss.cpp) bins the values and recomputes, with libm, every chain in which a binned quantity lies within 1e-9 of a
+// bin boundary -- the letters it emits are therefore the host's, bit for bit.
+//
+// One thread per residue: the forward-chain position and the reversed-chain position of the same index (independent
+// loops over <= 2 W neighbours).  Inputs are L2 resident; bound: double-precision exp throughput (1.1e9 per 32 k chains).
+#include <algorithm>
+#include <vector>
+
+#include "rsk_internal.h"
+
+struct dss_args {
+    const float *x, *y, *z;            // concatenated chains
+    const uint8_t *ss_fwd, *ss_rev;    // SS characters of the chains / of the reversed chains (index = reversed position)
+    const uint32_t *res_chain;         // chain of each residue
+    const uint64_t *off;               // first residue of each chain
+    const uint32_t *len;
+    uint64_t total;
+    int W, w1, w2;
+    double radius, eps;
+    double *dens_fwd, *sdens_fwd, *dens_rev, *sdens_rev;
+};
+
+__device__ __forceinline__ double dss_factor(const float *X, const float *Y, const float *Z, uint32_t a, uint32_t b, double radius)
+{
+    // (double) PDBChain::GetDist: float dx*dx + dy*dy + dz*dz, float sqrt; then exp(-d / radius) in double
+    const float dx = X[a] - X[b], dy = Y[a] - Y[b], dz = Z[a] - Z[b];
+    float d2 = dx * dx;
+    d2 += dy * dy;
+    d2 += dz * dz;
+    const float d = sqrtf(d2);
+    return exp(-(double) d / radius);
+}
+
+// DSS::SetDensities (host/dss.cpp) for position Pos of a chain whose residue i is residue `map(i)` of the stored chain:
+// REV = false: map(i) = i; REV = true: map(i) = L - 1 - i (the reversed chain; dist is bitwise symmetric)
+template <bool REV>
+__device__ __forceinline__ void dss_position(const float *X, const float *Y, const float *Z, const uint8_t *SS, int L, int Pos, int W, int w1, int w2,
+                                             double radius, double eps, double &dens, double &sdens)
+{
+    if (Pos < 1 || Pos + 1 >= L) { dens = 1.7976931348623157e308; sdens = 1.7976931348623157e308; return; }      // DBL_MAX: no value
+    auto fac = [&](int q) { return REV ? dss_factor(X, Y, Z, (uint32_t) (L - 1 - Pos), (uint32_t) (L - 1 - q), radius) : dss_factor(X, Y, Z, (uint32_t) Pos, (uint32_t) q, radius); };
+    const int lo = max(0, Pos - W), hi = min(L - 1, Pos + W);
+    double D1 = 0, D2 = 0, Dc = 0;
+    int q = lo;
+    for (; q < Pos - w2; ++q) {
+        const double F = fac(q);
+        D1 += F; D2 += F;
+        if (SS[q] == 's') Dc += F;
+    }
+    for (; q < Pos - w1; ++q) D1 += fac(q);
+    for (q = Pos + w1 + 1; q <= min(hi, Pos + w2); ++q) D1 += fac(q);
+    for (; q <= hi; ++q) {
+        const double F = fac(q);
+        D1 += F; D2 += F;
+        if (SS[q] == 's') Dc += F;
+    }
+    dens = D1;
+    sdens = Dc / (D2 + eps);
+}
+
+__global__ __launch_bounds__(256) void k_dss_density(dss_args a)
+{
+    const uint64_t r = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.total) return;
+    const uint32_t c = a.res_chain[r];
+    const uint64_t o = a.off[c];
+    const int L = (int) a.len[c], Pos = (int) (r - o);
+    const float *X = a.x + o, *Y = a.y + o, *Z = a.z + o;
+    double d, s;
+    dss_position<false>(X, Y, Z, a.ss_fwd + o, L, Pos, a.W, a.w1, a.w2, a.radius, a.eps, d, s);
+    a.dens_fwd[r] = d; a.sdens_fwd[r] = s;
+    dss_position<true>(X, Y, Z, a.ss_rev + o, L, Pos, a.W, a.w1, a.w2, a.radius, a.eps, d, s);
+    a.dens_rev[r] = d; a.sdens_rev[r] = s;
+}
+
+// Densities of n chains (concatenated coordinates and SS strings; ss_rev[off + i] = SS of position i of the REVERSED
+// chain) -> four double arrays of `total` values (DBL_MAX where the reference leaves no value).  Host arrays in and out.
+extern "C" int rsk_dss_densities(rsk_ctx *ctx, uint32_t n, const uint32_t *len, const float *x, const float *y, const float *z, const char *ss_fwd,
+                                 const char *ss_rev, int W, int w1, int w2, double radius, double eps, double *dens_fwd, double *sdens_fwd,
+                                 double *dens_rev, double *sdens_rev)
+{
+    if (!ctx || (n && (!len || !x || !y || !z || !ss_fwd || !ss_rev || !dens_fwd || !sdens_fwd || !dens_rev || !sdens_rev))) {
+        rsk_set_error("rsk_dss_densities: NULL argument");
+        return RSK_E_INVALID;
+    }
+    if (W < 1 || w1 < 0 || w2 < w1 || w2 > W || !(radius > 0)) { rsk_set_error("rsk_dss_densities: windows must satisfy 0 <= w1 <= w2 <= W, radius > 0"); return RSK_E_INVALID; }
+    if (n == 0) return RSK_OK;
+    std::vector<uint64_t> off((size_t) n + 1, 0);
+    for (uint32_t i = 0; i < n; ++i) off[i + 1] = off[i] + len[i];
+    const uint64_t total = off[n];
+    if (total == 0) return RSK_OK;
+    std::vector<uint32_t> res_chain(total);
+    rsk_parallel_for(n, 1024, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) std::fill(res_chain.begin() + off[i], res_chain.begin() + off[i + 1], (uint32_t) i);
+    });
+    RSK_HIP(hipSetDevice(ctx->device));
+    rsk_scratch ws(ctx);
+    float *d_x, *d_y, *d_z;
+    uint8_t *d_ssf, *d_ssr;
+    uint32_t *d_rc, *d_len;
+    uint64_t *d_off;
+    double *d_out;
+    int rc;
+    if ((rc = ws.alloc(&d_x, total)) || (rc = ws.alloc(&d_y, total)) || (rc = ws.alloc(&d_z, total)) || (rc = ws.alloc(&d_ssf, total)) ||
+        (rc = ws.alloc(&d_ssr, total)) || (rc = ws.alloc(&d_rc, total)) || (rc = ws.alloc(&d_len, (size_t) n)) || (rc = ws.alloc(&d_off, (size_t) n + 1)) ||
+        (rc = ws.alloc(&d_out, 4 * total)))
+        return rc;
+    RSK_HIP(hipMemcpyAsync(d_x, x, total * 4, hipMemcpyHostToDevice, ctx->stream));
+    RSK_HIP(hipMemcpyAsync(d_y, y, total * 4, hipMemcpyHostToDevice, ctx->stream));
+    RSK_HIP(hipMemcpyAsync(d_z, z, total * 4, hipMemcpyHostToDevice, ctx->stream));
+    RSK_HIP(hipMemcpyAsync(d_ssf, ss_fwd, total, hipMemcpyHostToDevice, ctx->stream));
+    RSK_HIP(hipMemcpyAsync(d_ssr, ss_rev, total, hipMemcpyHostToDevice, ctx->stream));
+    RSK_HIP(hipMemcpyAsync(d_rc, res_chain.data(), total * 4, hipMemcpyHostToDevice, ctx->stream));
+    RSK_HIP(hipMemcpyAsync(d_len, len, (size_t) n * 4, hipMemcpyHostToDevice, ctx->stream));
+    RSK_HIP(hipMemcpyAsync(d_off, off.data(), ((size_t) n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    dss_args a = {};
+    a.x = d_x; a.y = d_y; a.z = d_z; a.ss_fwd = d_ssf; a.ss_rev = d_ssr; a.res_chain = d_rc; a.off = d_off; a.len = d_len; a.total = total;
+    a.W = W; a.w1 = w1; a.w2 = w2; a.radius = radius; a.eps = eps;
+    a.dens_fwd = d_out; a.sdens_fwd = d_out + total; a.dens_rev = d_out + 2 * total; a.sdens_rev = d_out + 3 * total;
+    hipLaunchKernelGGL(k_dss_density, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, ctx->stream, a);
+    RSK_HIP(hipGetLastError());
+    RSK_HIP(hipMemcpyAsync(dens_fwd, a.dens_fwd, total * 8, hipMemcpyDeviceToHost, ctx->stream));
+    RSK_HIP(hipMemcpyAsync(sdens_fwd, a.sdens_fwd, total * 8, hipMemcpyDeviceToHost, ctx->stream));
+    RSK_HIP(hipMemcpyAsync(dens_rev, a.dens_rev, total * 8, hipMemcpyDeviceToHost, ctx->stream));
+    RSK_HIP(hipMemcpyAsync(sdens_rev, a.sdens_rev, total * 8, hipMemcpyDeviceToHost, ctx->stream));
+    RSK_HIP(hipStreamSynchronize(ctx->stream));
+    return RSK_OK;
+}

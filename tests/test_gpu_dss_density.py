@@ -1,0 +1,88 @@
+"""rsk_dss_densities (k_dss.hip): the two density features of DSS (dss.cpp:217-244, 339-372) for chains and their reversed
+copies on the device.  The device exp() is not libm's, so the values are compared with a numpy restatement to a relative
+1e-12 here; the LETTERS the host bins from them are the host's by construction (DSS::UseDeviceDensities keeps a chain's
+device values only if nothing binned is within 1e-9 of a bin boundary) -- the search tests against the goldens and the
+reference binary run with the device densities, and the last test compares a search with and without them."""
+import os
+
+import numpy as np
+import pytest
+
+import fixtures as fx
+
+pytestmark = pytest.mark.gpu
+DBL_MAX = np.finfo(np.float64).max
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+    import reseek_amd
+    assert torch.cuda.is_available()
+    c = reseek_amd.Ctx(0, stream=torch.cuda.current_stream().cuda_stream)
+    yield c
+    c.close()
+
+
+def ref_densities(x, y, z, ss, W=50, w1=3, w2=8, radius=20.0, eps=1.0):
+    """SetDensities of one chain: float distances (pdbchain.cpp:310), double exp, sums in ascending position."""
+    L = len(x)
+    dens = np.full(L, DBL_MAX)
+    sd = np.full(L, DBL_MAX)
+    x, y, z = (np.asarray(v, np.float32) for v in (x, y, z))
+    for pos in range(1, L - 1):
+        q = np.arange(max(0, pos - W), min(L - 1, pos + W) + 1)
+        dx, dy, dz = x[pos] - x[q], y[pos] - y[q], z[pos] - z[q]
+        d2 = (dx * dx + dy * dy).astype(np.float32) + (dz * dz).astype(np.float32)
+        f = np.exp(-np.sqrt(d2.astype(np.float32)).astype(np.float64) / radius)
+        k = np.abs(q - pos)
+        dens[pos] = f[k > w1].sum()
+        far = k > w2
+        d2sum = f[far].sum()
+        dc = f[far & (ss[q] == ord("s"))].sum()
+        sd[pos] = dc / (d2sum + eps)
+    return dens, sd
+
+
+def test_device_densities_match_a_numpy_restatement(ctx):
+    rng = np.random.default_rng(11)
+    lens = np.array([1, 2, 3, 4, 9, 17, 60, 61, 130, 411, 1203], np.uint32)
+    tot = int(lens.sum())
+    xyz = [np.cumsum(rng.normal(0, 2.2, tot)).astype(np.float32) for _ in range(3)]
+    ssf = rng.choice(np.frombuffer(b"sh~t", np.uint8), tot)
+    ssr = rng.choice(np.frombuffer(b"sh~t", np.uint8), tot)
+    df, sf, dr, sr = ctx.dss_densities(lens, *xyz, ssf.tobytes(), ssr.tobytes())
+    o = 0
+    for L in lens:
+        L = int(L)
+        sl = slice(o, o + L)
+        x, y, z = (v[sl] for v in xyz)
+        for got_d, got_s, want in ((df[sl], sf[sl], ref_densities(x, y, z, ssf[sl])),
+                                   (dr[sl], sr[sl], ref_densities(x[::-1], y[::-1], z[::-1], ssr[sl]))):
+            wd, ws = want
+            assert np.array_equal(got_d == DBL_MAX, wd == DBL_MAX) and np.array_equal(got_s == DBL_MAX, ws == DBL_MAX)
+            m = wd != DBL_MAX
+            assert np.allclose(got_d[m], wd[m], rtol=1e-12, atol=1e-13) and np.allclose(got_s[m], ws[m], rtol=1e-12, atol=1e-13)
+        o += L
+
+
+def test_rejects_bad_windows(ctx):
+    import reseek_amd
+    one = np.zeros(4, np.float32)
+    with pytest.raises(reseek_amd.RskError):
+        ctx.dss_densities([4], one, one, one, b"ssss", b"ssss", W=50, w1=9, w2=8)
+
+
+@pytest.mark.parametrize("mode", ["sensitive", "verysensitive"])
+def test_search_is_the_same_with_and_without_device_densities(ctx, tmpdir, monkeypatch, mode):
+    import gzip
+    q = os.path.join(str(tmpdir), "q100.bca")
+    with gzip.open(os.path.join(fx.GOLDEN, "q100.bca.gz"), "rb") as f, open(q, "wb") as g:
+        g.write(f.read())
+    outs = []
+    for dev in ("1", "0"):
+        monkeypatch.setenv("RSK_GPU_DENSITY", dev)
+        out = os.path.join(str(tmpdir), "hits_%s.tsv" % dev)
+        ctx.search(q, out, mode=mode, db=q)
+        outs.append(sorted(open(out).read().splitlines()))
+    assert outs[0] == outs[1] and len(outs[0]) > 100
