@@ -264,10 +264,14 @@ uint64_t rsk_selftest_format(uint64_t seed, uint64_t n);
  * Dc / (D2 + eps)); ss_fwd / ss_rev = the SS strings (getss.cpp:33) of the chains / of the reversed chains, concatenated like
  * the coordinates.  Outputs: sum(len) doubles each, DBL_MAX where the reference has no value (chain ends).  The device
  * exp() differs from libm's in the last bit: the host mirror bins these values only where they are further than 1e-9
- * from every bin boundary (DSS::UseDeviceDensities) and recomputes the other chains itself.  Host arrays in and out. */
+ * from every bin boundary (DSS::UseDeviceDensities) and recomputes the other chains itself.  nen_W > 0: also
+ * DSS::CalcNEN / CalcREN dss.cpp:374-440 (nearest residue within +-nen_W outside +-nen_w, and the nearest on the other
+ * side) of every residue, UINT32_MAX = none -- float distances and comparisons only, identical to the host's.
+ * Host arrays in and out. */
 int rsk_dss_densities(rsk_ctx *ctx, uint32_t n, const uint32_t *len, const float *x, const float *y, const float *z,
                       const char *ss_fwd, const char *ss_rev, int W, int w1, int w2, double radius, double eps,
-                      double *dens_fwd, double *sdens_fwd, double *dens_rev, double *sdens_rev);
+                      double *dens_fwd, double *sdens_fwd, double *dens_rev, double *sdens_rev,
+                      int nen_W, int nen_w, uint32_t *nen_fwd, uint32_t *ren_fwd, uint32_t *nen_rev, uint32_t *ren_rev);
 int rsk_dss_featurize_reversed(const char *seq, const float *x, const float *y, const float *z, uint32_t L, uint8_t *prof);
 int rsk_bca_info(const char *path, uint64_t *nchains, uint64_t *nresidues, uint32_t *max_len, uint32_t *max_label);
 int rsk_bca_read_chain(const char *path, uint64_t idx, char *label, size_t label_cap, char *seq, float *x, float *y,

@@ -133,6 +133,7 @@ void DBSearcher::LoadChains(std::vector<PDBChain *> &Chains)
     std::vector<uint64_t> roff;
     std::vector<std::string> ssf, ssr;
     std::unique_ptr<double[]> dens;                          // [4][total]: density / strand density of the chains, of the reversed chains
+    std::unique_ptr<uint32_t[]> nens;                        // [4][total]: NEN / REN of the chains, of the reversed chains
     uint64_t rtotal = 0;
     std::atomic<uint64_t> dens_fallbacks{0};
     if (m_Ctx && N && !(getenv("RSK_GPU_DENSITY") && atoi(getenv("RSK_GPU_DENSITY")) == 0)) {
@@ -160,10 +161,12 @@ void DBSearcher::LoadChains(std::vector<PDBChain *> &Chains)
             }
         });
         dens.reset(new double[4 * rtotal + 4]);
+        nens.reset(new uint32_t[4 * rtotal + 4]);
         DSS D0;
         check(rsk_dss_densities(m_Ctx, N, len.data(), px.get(), py.get(), pz.get(), pf.get(), pr.get(), D0.m_Density_W, D0.m_Density_w,
                                 D0.m_SSDensity_w, D0.m_Density_Radius, D0.m_SSDensity_epsilon, dens.get(), dens.get() + rtotal,
-                                dens.get() + 2 * rtotal, dens.get() + 3 * rtotal),
+                                dens.get() + 2 * rtotal, dens.get() + 3 * rtotal, D0.m_NEN_W, D0.m_NEN_w, nens.get(), nens.get() + rtotal,
+                                nens.get() + 2 * rtotal, nens.get() + 3 * rtotal),
               "rsk_dss_densities");
         tm.lap("densities (device)");
     }
@@ -180,7 +183,10 @@ void DBSearcher::LoadChains(std::vector<PDBChain *> &Chains)
             std::vector<byte> Mu;
             std::vector<uint> Kmers;
             D.Init(*m_DBChains[i]);
-            if (dens && !D.UseDeviceDensities(dens.get() + roff[i], dens.get() + rtotal + roff[i], &ssf[i])) ++dens_fallbacks;
+            if (dens) {
+                if (!D.UseDeviceDensities(dens.get() + roff[i], dens.get() + rtotal + roff[i], &ssf[i])) ++dens_fallbacks;
+                D.UseDeviceNENs(nens.get() + roff[i], nens.get() + rtotal + roff[i]);
+            }
             D.GetProfile(Prof);
             D.GetMuLetters(Mu);
             DSS::GetMuKmers(Mu, Kmers, m_Params->m_MKFPatternStr);
@@ -197,6 +203,7 @@ void DBSearcher::LoadChains(std::vector<PDBChain *> &Chains)
                     if (dens) ++dens_fallbacks;
                     DR.InitReversed(R, D);
                 }
+                if (dens) DR.UseDeviceNENs(nens.get() + 2 * rtotal + roff[i], nens.get() + 3 * rtotal + roff[i]);
                 DR.GetProfile(RevProf);
                 m_RevProfiles[i].swap(RevProf);
             }

@@ -171,6 +171,8 @@ public:
     // bit, so they are accepted only if every quantity that gets binned lies further than 1e-9 from all bin boundaries
     // (then the letters are the host's, bit for bit); false = nothing kept, featurise on the host as usual.
     bool UseDeviceDensities(const double *Dens, const double *StrandDens, const std::string *SS = nullptr);
+    // NEN / REN of every position as rsk_dss_densities computed them (float comparisons only: identical to SetNENs)
+    void UseDeviceNENs(const uint32_t *NEN, const uint32_t *REN) { const uint L = GetSeqLength(); m_NENs.assign(NEN, NEN + L); m_RENs.assign(REN, REN + L); }
     double DistFactor(uint Pos, uint Pos2) const      // Pos != Pos2, |Pos - Pos2| <= window
     {
         return Pos2 > Pos ? m_DistFactors[(size_t) Pos * m_DistFactorW + (Pos2 - Pos - 1)] : m_DistFactors[(size_t) Pos2 * m_DistFactorW + (Pos - Pos2 - 1)];

@@ -29,6 +29,8 @@ struct dss_args {
     int W, w1, w2;
     double radius, eps;
     double *dens_fwd, *sdens_fwd, *dens_rev, *sdens_rev;
+    int NW, Nw;                        // nearest-neighbour window / exclusion (dss.h: m_NEN_W, m_NEN_w); NW = 0: not wanted
+    uint32_t *nen_fwd, *ren_fwd, *nen_rev, *ren_rev;
 };
 
 __device__ __forceinline__ double dss_factor(const float *X, const float *Y, const float *Z, uint32_t a, uint32_t b, double radius)
@@ -69,6 +71,36 @@ __device__ __forceinline__ void dss_position(const float *X, const float *Y, con
     sdens = Dc / (D2 + eps);
 }
 
+// DSS::CalcNEN / CalcREN (dss.cpp:374-440): the nearest residue within +-NW positions outside +-Nw (first one in
+// ascending position among equals: the reference's running "Dist < MinDist" from 999), and the nearest one on the other
+// side of Pos.  Float distances and comparisons only: the device result IS the host's.
+template <bool REV>
+__device__ __forceinline__ void dss_neighbours(const float *X, const float *Y, const float *Z, int L, int Pos, int NW, int Nw, uint32_t &nen, uint32_t &ren)
+{
+    auto dist = [&](int q) {
+        const uint32_t s0 = (uint32_t) (REV ? L - 1 - Pos : Pos), s1 = (uint32_t) (REV ? L - 1 - q : q);
+        const float dx = X[s0] - X[s1], dy = Y[s0] - Y[s1], dz = Z[s0] - Z[s1];
+        float d2 = dx * dx;
+        d2 += dy * dy;
+        d2 += dz * dz;
+        return (double) sqrtf(d2);
+    };
+    auto nearest = [&](int lo, int hi) {
+        double MinDist = 999;
+        uint32_t MinPos = 0xFFFFFFFFu;
+        for (int q = lo; q <= hi; ++q) {
+            if (q + Nw >= Pos && q <= Pos + Nw) continue;
+            const double d = dist(q);
+            if (d < MinDist) { MinDist = d; MinPos = (uint32_t) q; }
+        }
+        return MinPos;
+    };
+    const int lo = max(0, Pos - NW), hi = min(L - 1, Pos + NW);
+    nen = nearest(lo, hi);
+    if (nen == 0xFFFFFFFFu) { ren = 0xFFFFFFFFu; return; }
+    ren = (int) nen > Pos ? nearest(lo, Pos - 1) : nearest(Pos + 1, hi);
+}
+
 __global__ __launch_bounds__(256) void k_dss_density(dss_args a)
 {
     const uint64_t r = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
@@ -82,14 +114,24 @@ __global__ __launch_bounds__(256) void k_dss_density(dss_args a)
     a.dens_fwd[r] = d; a.sdens_fwd[r] = s;
     dss_position<true>(X, Y, Z, a.ss_rev + o, L, Pos, a.W, a.w1, a.w2, a.radius, a.eps, d, s);
     a.dens_rev[r] = d; a.sdens_rev[r] = s;
+    if (a.NW > 0) {
+        uint32_t ne, re;
+        dss_neighbours<false>(X, Y, Z, L, Pos, a.NW, a.Nw, ne, re);
+        a.nen_fwd[r] = ne; a.ren_fwd[r] = re;
+        dss_neighbours<true>(X, Y, Z, L, Pos, a.NW, a.Nw, ne, re);
+        a.nen_rev[r] = ne; a.ren_rev[r] = re;
+    }
 }
 
 // Densities of n chains (concatenated coordinates and SS strings; ss_rev[off + i] = SS of position i of the REVERSED
-// chain) -> four double arrays of `total` values (DBL_MAX where the reference leaves no value).  Host arrays in and out.
+// chain) -> four double arrays of `total` values (DBL_MAX where the reference leaves no value); with nen_W > 0 also the
+// nearest-neighbour positions NEN / REN of every residue (UINT_MAX = none), chains and reversed chains.  Host arrays.
 extern "C" int rsk_dss_densities(rsk_ctx *ctx, uint32_t n, const uint32_t *len, const float *x, const float *y, const float *z, const char *ss_fwd,
                                  const char *ss_rev, int W, int w1, int w2, double radius, double eps, double *dens_fwd, double *sdens_fwd,
-                                 double *dens_rev, double *sdens_rev)
+                                 double *dens_rev, double *sdens_rev, int nen_W, int nen_w, uint32_t *nen_fwd, uint32_t *ren_fwd,
+                                 uint32_t *nen_rev, uint32_t *ren_rev)
 {
+    if (nen_W > 0 && (nen_w < 0 || !nen_fwd || !ren_fwd || !nen_rev || !ren_rev)) { rsk_set_error("rsk_dss_densities: neighbour outputs missing"); return RSK_E_INVALID; }
     if (!ctx || (n && (!len || !x || !y || !z || !ss_fwd || !ss_rev || !dens_fwd || !sdens_fwd || !dens_rev || !sdens_rev))) {
         rsk_set_error("rsk_dss_densities: NULL argument");
         return RSK_E_INVALID;
@@ -111,7 +153,9 @@ extern "C" int rsk_dss_densities(rsk_ctx *ctx, uint32_t n, const uint32_t *len, 
     uint32_t *d_rc, *d_len;
     uint64_t *d_off;
     double *d_out;
+    uint32_t *d_nn = nullptr;
     int rc;
+    if (nen_W > 0 && (rc = ws.alloc(&d_nn, 4 * total)) != RSK_OK) return rc;
     if ((rc = ws.alloc(&d_x, total)) || (rc = ws.alloc(&d_y, total)) || (rc = ws.alloc(&d_z, total)) || (rc = ws.alloc(&d_ssf, total)) ||
         (rc = ws.alloc(&d_ssr, total)) || (rc = ws.alloc(&d_rc, total)) || (rc = ws.alloc(&d_len, (size_t) n)) || (rc = ws.alloc(&d_off, (size_t) n + 1)) ||
         (rc = ws.alloc(&d_out, 4 * total)))
@@ -128,12 +172,20 @@ extern "C" int rsk_dss_densities(rsk_ctx *ctx, uint32_t n, const uint32_t *len, 
     a.x = d_x; a.y = d_y; a.z = d_z; a.ss_fwd = d_ssf; a.ss_rev = d_ssr; a.res_chain = d_rc; a.off = d_off; a.len = d_len; a.total = total;
     a.W = W; a.w1 = w1; a.w2 = w2; a.radius = radius; a.eps = eps;
     a.dens_fwd = d_out; a.sdens_fwd = d_out + total; a.dens_rev = d_out + 2 * total; a.sdens_rev = d_out + 3 * total;
+    a.NW = nen_W > 0 ? nen_W : 0; a.Nw = nen_w;
+    if (d_nn) { a.nen_fwd = d_nn; a.ren_fwd = d_nn + total; a.nen_rev = d_nn + 2 * total; a.ren_rev = d_nn + 3 * total; }
     hipLaunchKernelGGL(k_dss_density, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, ctx->stream, a);
     RSK_HIP(hipGetLastError());
     RSK_HIP(hipMemcpyAsync(dens_fwd, a.dens_fwd, total * 8, hipMemcpyDeviceToHost, ctx->stream));
     RSK_HIP(hipMemcpyAsync(sdens_fwd, a.sdens_fwd, total * 8, hipMemcpyDeviceToHost, ctx->stream));
     RSK_HIP(hipMemcpyAsync(dens_rev, a.dens_rev, total * 8, hipMemcpyDeviceToHost, ctx->stream));
     RSK_HIP(hipMemcpyAsync(sdens_rev, a.sdens_rev, total * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (d_nn) {
+        RSK_HIP(hipMemcpyAsync(nen_fwd, a.nen_fwd, total * 4, hipMemcpyDeviceToHost, ctx->stream));
+        RSK_HIP(hipMemcpyAsync(ren_fwd, a.ren_fwd, total * 4, hipMemcpyDeviceToHost, ctx->stream));
+        RSK_HIP(hipMemcpyAsync(nen_rev, a.nen_rev, total * 4, hipMemcpyDeviceToHost, ctx->stream));
+        RSK_HIP(hipMemcpyAsync(ren_rev, a.ren_rev, total * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
     RSK_HIP(hipStreamSynchronize(ctx->stream));
     return RSK_OK;
 }

@@ -44,6 +44,34 @@ def ref_densities(x, y, z, ss, W=50, w1=3, w2=8, radius=20.0, eps=1.0):
     return dens, sd
 
 
+def ref_neighbours(x, y, z, NW=100, Nw=12):
+    """CalcNEN / CalcREN (dss.cpp:374-440): first nearest in ascending position, running minimum from 999."""
+    L = len(x)
+    x, y, z = (np.asarray(v, np.float32) for v in (x, y, z))
+    NONE = 0xFFFFFFFF
+    nen = np.full(L, NONE, np.uint32)
+    ren = np.full(L, NONE, np.uint32)
+
+    def nearest(pos, lo, hi):
+        q = np.arange(lo, hi + 1)
+        q = q[np.abs(q - pos) > Nw]
+        if len(q) == 0:
+            return NONE
+        dx, dy, dz = x[pos] - x[q], y[pos] - y[q], z[pos] - z[q]
+        d2 = (dx * dx + dy * dy).astype(np.float32) + (dz * dz).astype(np.float32)
+        d = np.sqrt(d2.astype(np.float32)).astype(np.float64)
+        k = int(np.argmin(d))                      # first minimum
+        return int(q[k]) if d[k] < 999 else NONE
+
+    for pos in range(L):
+        lo, hi = max(0, pos - NW), min(L - 1, pos + NW)
+        n = nearest(pos, lo, hi)
+        nen[pos] = n
+        if n != NONE:
+            ren[pos] = nearest(pos, lo, pos - 1) if n > pos else nearest(pos, pos + 1, hi)
+    return nen, ren
+
+
 def test_device_densities_match_a_numpy_restatement(ctx):
     rng = np.random.default_rng(11)
     lens = np.array([1, 2, 3, 4, 9, 17, 60, 61, 130, 411, 1203], np.uint32)
@@ -51,7 +79,7 @@ def test_device_densities_match_a_numpy_restatement(ctx):
     xyz = [np.cumsum(rng.normal(0, 2.2, tot)).astype(np.float32) for _ in range(3)]
     ssf = rng.choice(np.frombuffer(b"sh~t", np.uint8), tot)
     ssr = rng.choice(np.frombuffer(b"sh~t", np.uint8), tot)
-    df, sf, dr, sr = ctx.dss_densities(lens, *xyz, ssf.tobytes(), ssr.tobytes())
+    (df, sf, dr, sr), (nf, rf, nr, rr) = ctx.dss_densities(lens, *xyz, ssf.tobytes(), ssr.tobytes())
     o = 0
     for L in lens:
         L = int(L)
@@ -63,6 +91,9 @@ def test_device_densities_match_a_numpy_restatement(ctx):
             assert np.array_equal(got_d == DBL_MAX, wd == DBL_MAX) and np.array_equal(got_s == DBL_MAX, ws == DBL_MAX)
             m = wd != DBL_MAX
             assert np.allclose(got_d[m], wd[m], rtol=1e-12, atol=1e-13) and np.allclose(got_s[m], ws[m], rtol=1e-12, atol=1e-13)
+        # nearest neighbours: float arithmetic only, so the positions are the host's exactly
+        for got_n, got_r, want in ((nf[sl], rf[sl], ref_neighbours(x, y, z)), (nr[sl], rr[sl], ref_neighbours(x[::-1], y[::-1], z[::-1]))):
+            assert np.array_equal(got_n, want[0]) and np.array_equal(got_r, want[1])
         o += L
 
 
