@@ -277,22 +277,21 @@ void DBSearcher::ComputeSelfRevScores()
         std::vector<size_t> start((size_t) N + 1, 0);
         for (uint i = 0; i < N; ++i) { len[i] = m_DBChains[i]->GetSeqLength(); start[i + 1] = start[i] + len[i]; }
         const size_t tot = start[N];
-        std::vector<uint8_t> mu(tot), pf(tot * RSK_NFEAT), pr(tot * RSK_NFEAT);
+        // The chains themselves go up once, as the set the search will use (UploadToGpu, its self-rev scores completed at the
+        // end of this function): it is the query side here.  Only the reversed profiles need a set of their own.
+        std::vector<uint8_t> mu(tot), pr(tot * RSK_NFEAT);
         rsk_parallel_for(N, 512, [&](size_t lo, size_t hi) {
             for (size_t i = lo; i < hi; ++i) {
                 const uint L = len[i];
                 const size_t o = start[i];
                 memcpy(&mu[o], m_DBMuLettersVec[i]->data(), L);
-                for (int f = 0; f < RSK_NFEAT; ++f) {
-                    memcpy(&pf[o * RSK_NFEAT + (size_t) f * L], (*m_DBProfiles[i])[f].data(), L);
-                    memcpy(&pr[o * RSK_NFEAT + (size_t) f * L], RevProf[i][f].data(), L);
-                }
+                for (int f = 0; f < RSK_NFEAT; ++f) memcpy(&pr[o * RSK_NFEAT + (size_t) f * L], RevProf[i][f].data(), L);
             }
         });
         tm.lap("pack");
-        rsk_db *fdb = nullptr, *rdb = nullptr;
-        check(rsk_db_create(m_Ctx, N, len.data(), mu.data(), pf.data(), nullptr, nullptr, nullptr, nullptr, &fdb), "rsk_db_create");
-        struct guard { rsk_db *d; ~guard() { if (d) rsk_db_destroy(d); } } g1{ fdb }, g2{ nullptr };
+        UploadToGpu();
+        rsk_db *fdb = m_Db, *rdb = nullptr;
+        struct guard { rsk_db *d; ~guard() { if (d) rsk_db_destroy(d); } } g2{ nullptr };
         check(rsk_db_create(m_Ctx, N, len.data(), mu.data(), pr.data(), nullptr, nullptr, nullptr, nullptr, &rdb), "rsk_db_create");
         g2.d = rdb;
         tm.lap("upload");
@@ -340,6 +339,7 @@ void DBSearcher::ComputeSelfRevScores()
         for (auto &t : ts) t.join();
         tm.lap("MKF chains (host)");
     }
+    if (m_Db) check(rsk_db_update_selfrev(m_Db, m_DBSelfRevScores.data()), "rsk_db_update_selfrev");
 }
 
 void DBSearcher::LoadDB(const std::string &DBFN)

@@ -333,6 +333,16 @@ extern "C" int rsk_db_create(rsk_ctx *ctx, uint32_t n, const uint32_t *lengths, 
     return RSK_OK;
 }
 
+// The self-rev scores of a chain set that was uploaded before they were known (DBSearcher::ComputeSelfRevScores aligns
+// the uploaded set against its reversed copy and then completes it): synchronous copy.
+int rsk_db_update_selfrev(rsk_db *db, const float *selfrev)
+{
+    if (!db || !selfrev || !db->d_selfrev) { rsk_set_error("rsk_db_update_selfrev: NULL argument"); return RSK_E_INVALID; }
+    db->h_selfrev.assign(selfrev, selfrev + db->n);
+    RSK_HIP(hipMemcpy(db->d_selfrev, selfrev, (size_t) db->n * 4, hipMemcpyHostToDevice));
+    return RSK_OK;
+}
+
 extern "C" void rsk_db_destroy(rsk_db *db)
 {
     if (!db) return;

@@ -79,6 +79,7 @@ int rsk_pool_alloc(rsk_ctx *ctx, void **p, size_t bytes);
 // Waits for the context's stream without spinning: the long waits (tens of ms of kernels) of several host threads would
 // otherwise each burn a core of a CPU-quota'd container.
 int rsk_stream_wait(rsk_ctx *ctx);
+int rsk_db_update_selfrev(rsk_db *db, const float *selfrev);   // completes a set uploaded before its self-rev scores were known
 void rsk_pool_free(rsk_ctx *ctx, void *p);
 void rsk_pool_release(rsk_ctx *ctx);
 int rsk_pinned(rsk_ctx *ctx, int slot, size_t bytes, void **p);
