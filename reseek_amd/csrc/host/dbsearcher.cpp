@@ -163,11 +163,20 @@ void DBSearcher::LoadChains(std::vector<PDBChain *> &Chains)
         dens.reset(new double[4 * rtotal + 4]);
         nens.reset(new uint32_t[4 * rtotal + 4]);
         DSS D0;
-        check(rsk_dss_densities(m_Ctx, N, len.data(), px.get(), py.get(), pz.get(), pf.get(), pr.get(), D0.m_Density_W, D0.m_Density_w,
-                                D0.m_SSDensity_w, D0.m_Density_Radius, D0.m_SSDensity_epsilon, dens.get(), dens.get() + rtotal,
-                                dens.get() + 2 * rtotal, dens.get() + 3 * rtotal, D0.m_NEN_W, D0.m_NEN_w, nens.get(), nens.get() + rtotal,
-                                nens.get() + 2 * rtotal, nens.get() + 3 * rtotal),
-              "rsk_dss_densities");
+        // device calls of at most 16 M residues (a self search loads its whole set here); RSK_DSS_CHUNK_RESIDUES: tests
+        const uint64_t chunk = getenv("RSK_DSS_CHUNK_RESIDUES") ? (uint64_t) std::max(1ll, atoll(getenv("RSK_DSS_CHUNK_RESIDUES"))) : (uint64_t) 16 << 20;
+        for (uint c0 = 0; c0 < N;) {
+            uint c1 = c0 + 1;
+            while (c1 < N && roff[c1 + 1] - roff[c0] <= chunk) ++c1;
+            const uint64_t o = roff[c0];
+            check(rsk_dss_densities(m_Ctx, c1 - c0, len.data() + c0, px.get() + o, py.get() + o, pz.get() + o, pf.get() + o, pr.get() + o,
+                                    D0.m_Density_W, D0.m_Density_w, D0.m_SSDensity_w, D0.m_Density_Radius, D0.m_SSDensity_epsilon,
+                                    dens.get() + o, dens.get() + rtotal + o, dens.get() + 2 * rtotal + o, dens.get() + 3 * rtotal + o,
+                                    D0.m_NEN_W, D0.m_NEN_w, nens.get() + o, nens.get() + rtotal + o, nens.get() + 2 * rtotal + o,
+                                    nens.get() + 3 * rtotal + o),
+                  "rsk_dss_densities");
+            c0 = c1;
+        }
         tm.lap("densities (device)");
     }
     auto body = [&]() {
@@ -653,8 +662,12 @@ std::vector<std::pair<size_t, size_t> > AlignBatches(const SearchOptions &O, con
     const size_t maxp = std::max<size_t>(1, getenv("RSK_BATCH_PAIRS") ? (size_t) atoll(getenv("RSK_BATCH_PAIRS")) : O.batch_pairs);
     size_t b = 0;
     uint64_t cells = 0;
+    // flat length tables: the loop below runs over tens of millions of pairs (two pointer chases per pair took 0.1 s)
+    std::vector<uint32_t> la(A.m_DBChains.size()), lb(B.m_DBChains.size());
+    for (size_t i = 0; i < la.size(); ++i) la[i] = A.m_DBChains[i]->GetSeqLength();
+    for (size_t j = 0; j < lb.size(); ++j) lb[j] = B.m_DBChains[j]->GetSeqLength();
     for (size_t k = 0; k < ia.size(); ++k) {
-        const uint64_t c = (uint64_t) A.m_DBChains[ia[k]]->GetSeqLength() * B.m_DBChains[ib[k]]->GetSeqLength();
+        const uint64_t c = (uint64_t) la[ia[k]] * lb[ib[k]];
         if (k > b && (k - b >= maxp || cells + c > O.batch_cells)) { out.emplace_back(b, k); b = k; cells = 0; }
         cells += c;
     }

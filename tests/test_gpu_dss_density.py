@@ -111,9 +111,11 @@ def test_search_is_the_same_with_and_without_device_densities(ctx, tmpdir, monke
     with gzip.open(os.path.join(fx.GOLDEN, "q100.bca.gz"), "rb") as f, open(q, "wb") as g:
         g.write(f.read())
     outs = []
-    for dev in ("1", "0"):
+    for dev, chunk in (("1", None), ("0", None), ("1", "700")):      # device, host only, device in calls of <= 700 residues
         monkeypatch.setenv("RSK_GPU_DENSITY", dev)
-        out = os.path.join(str(tmpdir), "hits_%s.tsv" % dev)
+        if chunk:
+            monkeypatch.setenv("RSK_DSS_CHUNK_RESIDUES", chunk)
+        out = os.path.join(str(tmpdir), "hits_%s_%s.tsv" % (dev, chunk))
         ctx.search(q, out, mode=mode, db=q)
         outs.append(sorted(open(out).read().splitlines()))
-    assert outs[0] == outs[1] and len(outs[0]) > 100
+    assert outs[0] == outs[1] == outs[2] and len(outs[0]) > 100
