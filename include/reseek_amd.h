@@ -261,15 +261,18 @@ int rsk_dss_featurize(const char *seq, const float *x, const float *y, const flo
 uint64_t rsk_selftest_format(uint64_t seed, uint64_t n);
 /* The two density features of a batch of chains and of their reversed copies on the device: DSS::GetDensity dss.cpp:217-244
  * and DSS::GetSSDensity(Pos, 's') dss.cpp:339-372 (window W, exclusion zones w1 <= w2, exp(-dist / radius), strand density
- * Dc / (D2 + eps)); ss_fwd / ss_rev = the SS strings (getss.cpp:33) of the chains / of the reversed chains, concatenated like
- * the coordinates.  Outputs: sum(len) doubles each, DBL_MAX where the reference has no value (chain ends).  The device
+ * Dc / (D2 + eps)).  Also returned, computed first on the device: the SS strings (PDBChain::GetSS getss.cpp:6-60) and the
+ * Conf letters (DSS::ConfLetter myss.cpp:125-160, 0xFF = none) of the chains / of the reversed chains, concatenated like
+ * the coordinates -- float / double comparison chains, identical to the host's.  Densities: sum(len) doubles each,
+ * DBL_MAX where the reference has no value (chain ends).  The device
  * exp() differs from libm's in the last bit: the host mirror bins these values only where they are further than 1e-9
  * from every bin boundary (DSS::UseDeviceDensities) and recomputes the other chains itself.  nen_W > 0: also
  * DSS::CalcNEN / CalcREN dss.cpp:374-440 (nearest residue within +-nen_W outside +-nen_w, and the nearest on the other
  * side) of every residue, UINT32_MAX = none -- float distances and comparisons only, identical to the host's.
  * Host arrays in and out. */
 int rsk_dss_densities(rsk_ctx *ctx, uint32_t n, const uint32_t *len, const float *x, const float *y, const float *z,
-                      const char *ss_fwd, const char *ss_rev, int W, int w1, int w2, double radius, double eps,
+                      char *ss_fwd, char *ss_rev, uint8_t *conf_fwd, uint8_t *conf_rev,
+                      int W, int w1, int w2, double radius, double eps,
                       double *dens_fwd, double *sdens_fwd, double *dens_rev, double *sdens_rev,
                       int nen_W, int nen_w, uint32_t *nen_fwd, uint32_t *ren_fwd, uint32_t *nen_rev, uint32_t *ren_rev);
 int rsk_dss_featurize_reversed(const char *seq, const float *x, const float *y, const float *z, uint32_t L, uint8_t *prof);

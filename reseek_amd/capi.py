@@ -62,7 +62,8 @@ SIGNATURES["rsk_search_rskdb"] = (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, 
 SIGNATURES["rsk_mu_prefilter_dev"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                                 C.c_size_t, C.c_void_p])
 SIGNATURES["rsk_selftest_format"] = (C.c_uint64, [C.c_uint64, C.c_uint64])
-SIGNATURES["rsk_dss_densities"] = (C.c_int, [C.c_void_p, C.c_uint32, u32p, f32p, f32p, f32p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int,
+SIGNATURES["rsk_dss_densities"] = (C.c_int, [C.c_void_p, C.c_uint32, u32p, f32p, f32p, f32p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_int, C.c_int, C.c_int,
                                              C.c_double, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                              C.POINTER(C.c_double), C.c_int, C.c_int, u32p, u32p, u32p, u32p])
 SIGNATURES["rsk_dss_featurize_reversed"] = (C.c_int, [C.c_char_p, f32p, f32p, f32p, C.c_uint32, C.POINTER(C.c_uint8)])
@@ -299,18 +300,20 @@ class Ctx:
         raw = buf.raw
         return [(out[k], raw[out[k].path_off:out[k].path_off + out[k].path_len].decode()) for k in range(n)], status[:n]
 
-    def dss_densities(self, lens, x, y, z, ss_fwd, ss_rev, W=50, w1=3, w2=8, radius=20.0, eps=1.0, nen_W=100, nen_w=12):
-        """rsk_dss_densities -> (dens_fwd, sdens_fwd, dens_rev, sdens_rev) float64 and (nen_fwd, ren_fwd, nen_rev, ren_rev) uint32
-        arrays over the concatenated residues"""
+    def dss_densities(self, lens, x, y, z, W=50, w1=3, w2=8, radius=20.0, eps=1.0, nen_W=100, nen_w=12):
+        """rsk_dss_densities -> dict of arrays over the concatenated residues: ss_fwd/ss_rev (uint8 chars), conf_fwd/conf_rev (uint8,
+        255 = none), dens_fwd/sdens_fwd/dens_rev/sdens_rev (float64), nen_fwd/ren_fwd/nen_rev/ren_rev (uint32)"""
         lens = np.ascontiguousarray(lens, np.uint32)
         x, y, z = (np.ascontiguousarray(v, np.float32) for v in (x, y, z))
         tot = int(lens.sum())
-        out = [np.zeros(max(tot, 1), np.float64) for _ in range(4)]
+        b8 = {k: np.zeros(max(tot, 1), np.uint8) for k in ("ss_fwd", "ss_rev", "conf_fwd", "conf_rev")}
+        f64 = {k: np.zeros(max(tot, 1), np.float64) for k in ("dens_fwd", "sdens_fwd", "dens_rev", "sdens_rev")}
+        u32 = {k: np.zeros(max(tot, 1), np.uint32) for k in ("nen_fwd", "ren_fwd", "nen_rev", "ren_rev")}
         f64p = C.POINTER(C.c_double)
-        nn = [np.zeros(max(tot, 1), np.uint32) for _ in range(4)]
-        _check(lib().rsk_dss_densities(self.h, len(lens), _p(lens, u32p), _p(x, f32p), _p(y, f32p), _p(z, f32p), bytes(ss_fwd), bytes(ss_rev),
-                                       W, w1, w2, radius, eps, *[_p(o, f64p) for o in out], nen_W, nen_w, *[_p(o, u32p) for o in nn]))
-        return tuple(o[:tot] for o in out), tuple(o[:tot] for o in nn)
+        _check(lib().rsk_dss_densities(self.h, len(lens), _p(lens, u32p), _p(x, f32p), _p(y, f32p), _p(z, f32p),
+                                       *[v.ctypes.data for v in b8.values()], W, w1, w2, radius, eps, *[_p(v, f64p) for v in f64.values()],
+                                       nen_W, nen_w, *[_p(v, u32p) for v in u32.values()]))
+        return {k: v[:tot] for d in (b8, f64, u32) for k, v in d.items()}
 
     def mkf_seed_pairs(self, q, t, iq, it, x1=8, min_hsp_score=50, cap=16, max_records=None):
         """-> (found uint8[n], {pair index: (nkept, kept int32 [min(nkept, cap), 4])})"""

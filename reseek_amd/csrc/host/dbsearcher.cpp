@@ -127,11 +127,14 @@ void DBSearcher::LoadChains(std::vector<PDBChain *> &Chains)
     const bool WantRev = !m_Opts.selfrev0 && m_Ctx;
     m_RevProfiles.clear();
     if (WantRev) m_RevProfiles.resize(N);
-    // The two density features (two thirds of the host featurisation: libm exp) come from the device for the whole batch,
-    // chains and reversed chains (rsk_dss_densities, k_dss.hip); DSS::UseDeviceDensities accepts them chain by chain
-    // only where no binned value is near a bin boundary, so the letters stay the host's.  RSK_GPU_DENSITY=0: host only.
+    // The per-residue quantities of the featurisation come from the device for the whole batch, chains and reversed
+    // chains (rsk_dss_densities, k_dss.hip): SS characters, Conf letters and nearest neighbours (float comparison chains:
+    // identical to the host's) and the two density features (two thirds of the host cost: libm exp), which
+    // DSS::UseDeviceDensities accepts chain by chain only where no binned value is near a bin boundary, so the letters
+    // stay the host's.  RSK_GPU_DENSITY=0: host only.
     std::vector<uint64_t> roff;
-    std::vector<std::string> ssf, ssr;
+    std::unique_ptr<char[]> ssb;                             // [2][total]: SS of the chains, of the reversed chains
+    std::unique_ptr<uint8_t[]> confb;                        // [2][total]: Conf letters
     std::unique_ptr<double[]> dens;                          // [4][total]: density / strand density of the chains, of the reversed chains
     std::unique_ptr<uint32_t[]> nens;                        // [4][total]: NEN / REN of the chains, of the reversed chains
     uint64_t rtotal = 0;
@@ -140,26 +143,20 @@ void DBSearcher::LoadChains(std::vector<PDBChain *> &Chains)
         roff.assign((size_t) N + 1, 0);
         for (uint i = 0; i < N; ++i) roff[i + 1] = roff[i] + m_DBChains[i]->GetSeqLength();
         rtotal = roff[N];
-        ssf.resize(N); ssr.resize(N);
         std::unique_ptr<float[]> px(new float[rtotal + 1]), py(new float[rtotal + 1]), pz(new float[rtotal + 1]);
-        std::unique_ptr<char[]> pf(new char[rtotal + 1]), pr(new char[rtotal + 1]);
         std::vector<uint32_t> len(N);
         rsk_parallel_for(N, 256, [&](size_t lo, size_t hi) {
-            PDBChain R;
             for (size_t i = lo; i < hi; ++i) {
                 const PDBChain &C = *m_DBChains[i];
                 const uint L = C.GetSeqLength();
                 len[i] = L;
-                C.GetSS(ssf[i]);
-                C.GetReverse(R);
-                R.GetSS(ssr[i]);
                 memcpy(&px[roff[i]], C.m_Xs.data(), 4 * (size_t) L);
                 memcpy(&py[roff[i]], C.m_Ys.data(), 4 * (size_t) L);
                 memcpy(&pz[roff[i]], C.m_Zs.data(), 4 * (size_t) L);
-                memcpy(&pf[roff[i]], ssf[i].data(), L);
-                memcpy(&pr[roff[i]], ssr[i].data(), L);
             }
         });
+        ssb.reset(new char[2 * rtotal + 2]);
+        confb.reset(new uint8_t[2 * rtotal + 2]);
         dens.reset(new double[4 * rtotal + 4]);
         nens.reset(new uint32_t[4 * rtotal + 4]);
         DSS D0;
@@ -169,11 +166,11 @@ void DBSearcher::LoadChains(std::vector<PDBChain *> &Chains)
             uint c1 = c0 + 1;
             while (c1 < N && roff[c1 + 1] - roff[c0] <= chunk) ++c1;
             const uint64_t o = roff[c0];
-            check(rsk_dss_densities(m_Ctx, c1 - c0, len.data() + c0, px.get() + o, py.get() + o, pz.get() + o, pf.get() + o, pr.get() + o,
-                                    D0.m_Density_W, D0.m_Density_w, D0.m_SSDensity_w, D0.m_Density_Radius, D0.m_SSDensity_epsilon,
-                                    dens.get() + o, dens.get() + rtotal + o, dens.get() + 2 * rtotal + o, dens.get() + 3 * rtotal + o,
-                                    D0.m_NEN_W, D0.m_NEN_w, nens.get() + o, nens.get() + rtotal + o, nens.get() + 2 * rtotal + o,
-                                    nens.get() + 3 * rtotal + o),
+            check(rsk_dss_densities(m_Ctx, c1 - c0, len.data() + c0, px.get() + o, py.get() + o, pz.get() + o, ssb.get() + o, ssb.get() + rtotal + o,
+                                    confb.get() + o, confb.get() + rtotal + o, D0.m_Density_W, D0.m_Density_w, D0.m_SSDensity_w, D0.m_Density_Radius,
+                                    D0.m_SSDensity_epsilon, dens.get() + o, dens.get() + rtotal + o, dens.get() + 2 * rtotal + o,
+                                    dens.get() + 3 * rtotal + o, D0.m_NEN_W, D0.m_NEN_w, nens.get() + o, nens.get() + rtotal + o,
+                                    nens.get() + 2 * rtotal + o, nens.get() + 3 * rtotal + o),
                   "rsk_dss_densities");
             c0 = c1;
         }
@@ -193,8 +190,9 @@ void DBSearcher::LoadChains(std::vector<PDBChain *> &Chains)
             std::vector<uint> Kmers;
             D.Init(*m_DBChains[i]);
             if (dens) {
-                if (!D.UseDeviceDensities(dens.get() + roff[i], dens.get() + rtotal + roff[i], &ssf[i])) ++dens_fallbacks;
+                D.UseDeviceLocal(ssb.get() + roff[i], confb.get() + roff[i]);
                 D.UseDeviceNENs(nens.get() + roff[i], nens.get() + rtotal + roff[i]);
+                if (!D.UseDeviceDensities(dens.get() + roff[i], dens.get() + rtotal + roff[i])) ++dens_fallbacks;
             }
             D.GetProfile(Prof);
             D.GetMuLetters(Mu);
@@ -208,11 +206,14 @@ void DBSearcher::LoadChains(std::vector<PDBChain *> &Chains)
                 std::vector<std::vector<byte> > RevProf;
                 m_DBChains[i]->GetReverse(R);
                 DR.Init(R);
-                if (!(dens && DR.UseDeviceDensities(dens.get() + 2 * rtotal + roff[i], dens.get() + 3 * rtotal + roff[i], &ssr[i]))) {
+                if (!(dens && DR.UseDeviceDensities(dens.get() + 2 * rtotal + roff[i], dens.get() + 3 * rtotal + roff[i]))) {
                     if (dens) ++dens_fallbacks;
                     DR.InitReversed(R, D);
                 }
-                if (dens) DR.UseDeviceNENs(nens.get() + 2 * rtotal + roff[i], nens.get() + 3 * rtotal + roff[i]);
+                if (dens) {
+                    DR.UseDeviceLocal(ssb.get() + rtotal + roff[i], confb.get() + rtotal + roff[i]);
+                    DR.UseDeviceNENs(nens.get() + 2 * rtotal + roff[i], nens.get() + 3 * rtotal + roff[i]);
+                }
                 DR.GetProfile(RevProf);
                 m_RevProfiles[i].swap(RevProf);
             }

@@ -282,7 +282,7 @@ void DSS::SetDensities()
     }
 }
 
-bool DSS::UseDeviceDensities(const double *Dens, const double *StrandDens, const std::string *SS)
+bool DSS::UseDeviceDensities(const double *Dens, const double *StrandDens)
 {
     const uint L = GetSeqLength();
     const double Margin = 1e-9;                                       // device-vs-libm exp: the values differ by ~1e-14
@@ -305,7 +305,6 @@ bool DSS::UseDeviceDensities(const double *Dens, const double *StrandDens, const
         if (Dens[Pos] != DBL_MAX && near_a_boundary(rsk_bins_NormDens, (Dens[Pos] - MinValue) / Range)) return false;
     m_DensityValues.assign(Dens, Dens + L);
     m_StrandDensValues.assign(StrandDens, StrandDens + L);
-    if (SS) m_SS = *SS;
     return true;
 }
 

@@ -170,7 +170,15 @@ public:
     // Densities of this chain as rsk_dss_densities (k_dss.hip) computed them: device exp() differs from libm's in the last
     // bit, so they are accepted only if every quantity that gets binned lies further than 1e-9 from all bin boundaries
     // (then the letters are the host's, bit for bit); false = nothing kept, featurise on the host as usual.
-    bool UseDeviceDensities(const double *Dens, const double *StrandDens, const std::string *SS = nullptr);
+    bool UseDeviceDensities(const double *Dens, const double *StrandDens);
+    // SS characters and Conf letters (0xFF = none) of every position from the same call: exact on the device
+    void UseDeviceLocal(const char *SS, const uint8_t *Conf)
+    {
+        const uint L = GetSeqLength();
+        m_SS.assign(SS, SS + L);
+        m_ConfLetters.resize(L);
+        for (uint Pos = 0; Pos < L; ++Pos) m_ConfLetters[Pos] = Conf[Pos] == 0xFF ? UINT_MAX : Conf[Pos];
+    }
     // NEN / REN of every position as rsk_dss_densities computed them (float comparisons only: identical to SetNENs)
     void UseDeviceNENs(const uint32_t *NEN, const uint32_t *REN) { const uint L = GetSeqLength(); m_NENs.assign(NEN, NEN + L); m_RENs.assign(REN, REN + L); }
     double DistFactor(uint Pos, uint Pos2) const      // Pos != Pos2, |Pos - Pos2| <= window

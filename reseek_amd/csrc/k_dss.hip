@@ -18,10 +18,14 @@
 #include <vector>
 
 #include "rsk_internal.h"
+#include "host/dss_data.h"
+
+static __device__ __constant__ double c_conf_means[16][9];
 
 struct dss_args {
     const float *x, *y, *z;            // concatenated chains
-    const uint8_t *ss_fwd, *ss_rev;    // SS characters of the chains / of the reversed chains (index = reversed position)
+    uint8_t *ss_fwd, *ss_rev;          // SS characters of the chains / of the reversed chains (index = reversed position): k_dss_local
+    uint8_t *conf_fwd, *conf_rev;      // Conf letters (0xFF = none)
     const uint32_t *res_chain;         // chain of each residue
     const uint64_t *off;               // first residue of each chain
     const uint32_t *len;
@@ -69,6 +73,66 @@ __device__ __forceinline__ void dss_position(const float *X, const float *Y, con
     }
     dens = D1;
     sdens = Dc / (D2 + eps);
+}
+
+// PDBChain::GetSS (getss.cpp:6-60, after TM-align's sec_str) and DSS::ConfLetter (myss.cpp:125-160: nine CA-CA distances
+// around Pos, nearest of 16 cluster centres, first wins ties) of position Pos of the chain / the reversed chain.  Float
+// distances, double differences, products, sums and square root rounded one by one as on the host: identical letters.
+template <bool REV>
+__device__ __forceinline__ void dss_local(const float *X, const float *Y, const float *Z, int L, int Pos, uint8_t &ss, uint8_t &conf)
+{
+    auto dist = [&](int a, int b) {
+        const uint32_t s0 = (uint32_t) (REV ? L - 1 - a : a), s1 = (uint32_t) (REV ? L - 1 - b : b);
+        const float dx = X[s0] - X[s1], dy = Y[s0] - Y[s1], dz = Z[s0] - Z[s1];
+        float d2 = dx * dx;
+        d2 += dy * dy;
+        d2 += dz * dz;
+        return (double) sqrtf(d2);
+    };
+    if (Pos < 2 || Pos + 2 >= L) ss = '~';
+    else {
+        const double d13 = dist(Pos - 2, Pos), d14 = dist(Pos - 2, Pos + 1), d15 = dist(Pos - 2, Pos + 2);
+        const double d24 = dist(Pos - 1, Pos + 1), d25 = dist(Pos - 1, Pos + 2), d35 = dist(Pos, Pos + 2);
+        const double DH = 2.1, DS = 1.42;
+        if (fabs(d15 - 6.37) < DH && fabs(d14 - 5.18) < DH && fabs(d25 - 5.18) < DH && fabs(d13 - 5.45) < DH && fabs(d24 - 5.45) < DH &&
+            fabs(d35 - 5.45) < DH)
+            ss = 'h';
+        else if (fabs(d15 - 13) < DS && fabs(d14 - 10.4) < DS && fabs(d25 - 10.4) < DS && fabs(d13 - 6.1) < DS && fabs(d24 - 6.1) < DS &&
+                 fabs(d35 - 6.1) < DS)
+            ss = 's';
+        else if (d15 < 8.2) ss = 't';
+        else ss = '~';
+    }
+    if (Pos < 3 || Pos + 3 >= L) { conf = 0xFF; return; }
+    const int iv[9] = { -2, -2, -2, -1, -1, 0, -3, 0, -3 }, jv[9] = { 0, 1, 2, 1, 2, 2, 3, 3, 0 };
+    double v[9];
+#pragma unroll
+    for (int m = 0; m < 9; ++m) v[m] = dist(Pos + iv[m], Pos + jv[m]);
+    double MinDist = 1.7976931348623157e308;
+    uint32_t Best = 0;
+    for (uint32_t k = 0; k < 16; ++k) {
+        double Sum2 = 0;
+#pragma unroll
+        for (int m = 0; m < 9; ++m) { const double diff = v[m] - c_conf_means[k][m]; Sum2 += diff * diff; }
+        const double d = sqrt(Sum2);
+        if (k == 0 || d < MinDist) { Best = k; MinDist = d; }
+    }
+    conf = (uint8_t) Best;
+}
+
+__global__ __launch_bounds__(256) void k_dss_local(dss_args a)
+{
+    const uint64_t r = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.total) return;
+    const uint32_t c = a.res_chain[r];
+    const uint64_t o = a.off[c];
+    const int L = (int) a.len[c], Pos = (int) (r - o);
+    const float *X = a.x + o, *Y = a.y + o, *Z = a.z + o;
+    uint8_t ss, cf;
+    dss_local<false>(X, Y, Z, L, Pos, ss, cf);
+    a.ss_fwd[r] = ss; a.conf_fwd[r] = cf;
+    dss_local<true>(X, Y, Z, L, Pos, ss, cf);
+    a.ss_rev[r] = ss; a.conf_rev[r] = cf;
 }
 
 // DSS::CalcNEN / CalcREN (dss.cpp:374-440): the nearest residue within +-NW positions outside +-Nw (first one in
@@ -123,16 +187,16 @@ __global__ __launch_bounds__(256) void k_dss_density(dss_args a)
     }
 }
 
-// Densities of n chains (concatenated coordinates and SS strings; ss_rev[off + i] = SS of position i of the REVERSED
-// chain) -> four double arrays of `total` values (DBL_MAX where the reference leaves no value); with nen_W > 0 also the
-// nearest-neighbour positions NEN / REN of every residue (UINT_MAX = none), chains and reversed chains.  Host arrays.
-extern "C" int rsk_dss_densities(rsk_ctx *ctx, uint32_t n, const uint32_t *len, const float *x, const float *y, const float *z, const char *ss_fwd,
-                                 const char *ss_rev, int W, int w1, int w2, double radius, double eps, double *dens_fwd, double *sdens_fwd,
-                                 double *dens_rev, double *sdens_rev, int nen_W, int nen_w, uint32_t *nen_fwd, uint32_t *ren_fwd,
-                                 uint32_t *nen_rev, uint32_t *ren_rev)
+// Per-residue DSS quantities of n chains (concatenated coordinates) and of their reversed copies (index = position in the
+// reversed chain): SS characters and Conf letters (0xFF = none), the two densities (DBL_MAX where the reference leaves no
+// value) and, with nen_W > 0, the nearest-neighbour positions NEN / REN (UINT_MAX = none).  Host arrays in and out.
+extern "C" int rsk_dss_densities(rsk_ctx *ctx, uint32_t n, const uint32_t *len, const float *x, const float *y, const float *z, char *ss_fwd,
+                                 char *ss_rev, uint8_t *conf_fwd, uint8_t *conf_rev, int W, int w1, int w2, double radius, double eps,
+                                 double *dens_fwd, double *sdens_fwd, double *dens_rev, double *sdens_rev, int nen_W, int nen_w,
+                                 uint32_t *nen_fwd, uint32_t *ren_fwd, uint32_t *nen_rev, uint32_t *ren_rev)
 {
     if (nen_W > 0 && (nen_w < 0 || !nen_fwd || !ren_fwd || !nen_rev || !ren_rev)) { rsk_set_error("rsk_dss_densities: neighbour outputs missing"); return RSK_E_INVALID; }
-    if (!ctx || (n && (!len || !x || !y || !z || !ss_fwd || !ss_rev || !dens_fwd || !sdens_fwd || !dens_rev || !sdens_rev))) {
+    if (!ctx || (n && (!len || !x || !y || !z || !ss_fwd || !ss_rev || !conf_fwd || !conf_rev || !dens_fwd || !sdens_fwd || !dens_rev || !sdens_rev))) {
         rsk_set_error("rsk_dss_densities: NULL argument");
         return RSK_E_INVALID;
     }
@@ -147,35 +211,48 @@ extern "C" int rsk_dss_densities(rsk_ctx *ctx, uint32_t n, const uint32_t *len, 
         for (size_t i = lo; i < hi; ++i) std::fill(res_chain.begin() + off[i], res_chain.begin() + off[i + 1], (uint32_t) i);
     });
     RSK_HIP(hipSetDevice(ctx->device));
+    {
+        static std::atomic<int> done[64];
+        const int trc = rsk_once_per_device(done, ctx->device, [&]() -> int {
+            RSK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_conf_means), rsk_conf_means, sizeof(rsk_conf_means)));
+            return RSK_OK;
+        });
+        if (trc != RSK_OK) return trc;
+    }
     rsk_scratch ws(ctx);
     float *d_x, *d_y, *d_z;
-    uint8_t *d_ssf, *d_ssr;
+    uint8_t *d_b;                      // ss_fwd, ss_rev, conf_fwd, conf_rev
     uint32_t *d_rc, *d_len;
     uint64_t *d_off;
     double *d_out;
     uint32_t *d_nn = nullptr;
     int rc;
     if (nen_W > 0 && (rc = ws.alloc(&d_nn, 4 * total)) != RSK_OK) return rc;
-    if ((rc = ws.alloc(&d_x, total)) || (rc = ws.alloc(&d_y, total)) || (rc = ws.alloc(&d_z, total)) || (rc = ws.alloc(&d_ssf, total)) ||
-        (rc = ws.alloc(&d_ssr, total)) || (rc = ws.alloc(&d_rc, total)) || (rc = ws.alloc(&d_len, (size_t) n)) || (rc = ws.alloc(&d_off, (size_t) n + 1)) ||
+    if ((rc = ws.alloc(&d_x, total)) || (rc = ws.alloc(&d_y, total)) || (rc = ws.alloc(&d_z, total)) || (rc = ws.alloc(&d_b, 4 * total)) ||
+        (rc = ws.alloc(&d_rc, total)) || (rc = ws.alloc(&d_len, (size_t) n)) || (rc = ws.alloc(&d_off, (size_t) n + 1)) ||
         (rc = ws.alloc(&d_out, 4 * total)))
         return rc;
     RSK_HIP(hipMemcpyAsync(d_x, x, total * 4, hipMemcpyHostToDevice, ctx->stream));
     RSK_HIP(hipMemcpyAsync(d_y, y, total * 4, hipMemcpyHostToDevice, ctx->stream));
     RSK_HIP(hipMemcpyAsync(d_z, z, total * 4, hipMemcpyHostToDevice, ctx->stream));
-    RSK_HIP(hipMemcpyAsync(d_ssf, ss_fwd, total, hipMemcpyHostToDevice, ctx->stream));
-    RSK_HIP(hipMemcpyAsync(d_ssr, ss_rev, total, hipMemcpyHostToDevice, ctx->stream));
     RSK_HIP(hipMemcpyAsync(d_rc, res_chain.data(), total * 4, hipMemcpyHostToDevice, ctx->stream));
     RSK_HIP(hipMemcpyAsync(d_len, len, (size_t) n * 4, hipMemcpyHostToDevice, ctx->stream));
     RSK_HIP(hipMemcpyAsync(d_off, off.data(), ((size_t) n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     dss_args a = {};
-    a.x = d_x; a.y = d_y; a.z = d_z; a.ss_fwd = d_ssf; a.ss_rev = d_ssr; a.res_chain = d_rc; a.off = d_off; a.len = d_len; a.total = total;
+    a.x = d_x; a.y = d_y; a.z = d_z; a.res_chain = d_rc; a.off = d_off; a.len = d_len; a.total = total;
+    a.ss_fwd = d_b; a.ss_rev = d_b + total; a.conf_fwd = d_b + 2 * total; a.conf_rev = d_b + 3 * total;
     a.W = W; a.w1 = w1; a.w2 = w2; a.radius = radius; a.eps = eps;
     a.dens_fwd = d_out; a.sdens_fwd = d_out + total; a.dens_rev = d_out + 2 * total; a.sdens_rev = d_out + 3 * total;
     a.NW = nen_W > 0 ? nen_W : 0; a.Nw = nen_w;
     if (d_nn) { a.nen_fwd = d_nn; a.ren_fwd = d_nn + total; a.nen_rev = d_nn + 2 * total; a.ren_rev = d_nn + 3 * total; }
-    hipLaunchKernelGGL(k_dss_density, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, ctx->stream, a);
+    const dim3 grid((unsigned) ((total + 255) / 256));
+    hipLaunchKernelGGL(k_dss_local, grid, dim3(256), 0, ctx->stream, a);            // SS of every residue before the densities read their neighbours'
+    hipLaunchKernelGGL(k_dss_density, grid, dim3(256), 0, ctx->stream, a);
     RSK_HIP(hipGetLastError());
+    RSK_HIP(hipMemcpyAsync(ss_fwd, a.ss_fwd, total, hipMemcpyDeviceToHost, ctx->stream));
+    RSK_HIP(hipMemcpyAsync(ss_rev, a.ss_rev, total, hipMemcpyDeviceToHost, ctx->stream));
+    RSK_HIP(hipMemcpyAsync(conf_fwd, a.conf_fwd, total, hipMemcpyDeviceToHost, ctx->stream));
+    RSK_HIP(hipMemcpyAsync(conf_rev, a.conf_rev, total, hipMemcpyDeviceToHost, ctx->stream));
     RSK_HIP(hipMemcpyAsync(dens_fwd, a.dens_fwd, total * 8, hipMemcpyDeviceToHost, ctx->stream));
     RSK_HIP(hipMemcpyAsync(sdens_fwd, a.sdens_fwd, total * 8, hipMemcpyDeviceToHost, ctx->stream));
     RSK_HIP(hipMemcpyAsync(dens_rev, a.dens_rev, total * 8, hipMemcpyDeviceToHost, ctx->stream));

@@ -72,14 +72,76 @@ def ref_neighbours(x, y, z, NW=100, Nw=12):
     return nen, ren
 
 
+def dist64(x, y, z, a, b):
+    """(double) PDBChain::GetDist: float expression, float sqrt"""
+    dx, dy, dz = np.float32(x[a] - x[b]), np.float32(y[a] - y[b]), np.float32(z[a] - z[b])
+    d2 = np.float32(np.float32(np.float32(dx * dx) + np.float32(dy * dy)) + np.float32(dz * dz))
+    return np.float64(np.sqrt(d2, dtype=np.float32))
+
+
+CONF_MEANS = None
+
+
+def conf_means():
+    """the 16 x 9 cluster centres of reseek_amd/csrc/host/dss_data.h"""
+    global CONF_MEANS
+    if CONF_MEANS is None:
+        import re
+        txt = open(os.path.join(os.path.dirname(fx.GOLDEN), "..", "reseek_amd", "csrc", "host", "dss_data.h")).read()
+        rows = re.findall(r"\{\s*([0-9.,\s]+)\}", txt[txt.index("rsk_conf_means"):])
+        CONF_MEANS = np.array([[float(v) for v in r.split(",") if v.strip()] for r in rows[:16]], np.float64)
+        assert CONF_MEANS.shape == (16, 9)
+    return CONF_MEANS
+
+
+def ref_local(x, y, z):
+    """PDBChain::GetSS (getss.cpp:6-60) and DSS::ConfLetter (myss.cpp:125-160)"""
+    L = len(x)
+    x, y, z = (np.asarray(v, np.float32) for v in (x, y, z))
+    ss = np.full(L, ord("~"), np.uint8)
+    conf = np.full(L, 255, np.uint8)
+    M = conf_means()
+    iv, jv = (-2, -2, -2, -1, -1, 0, -3, 0, -3), (0, 1, 2, 1, 2, 2, 3, 3, 0)
+    for p in range(L):
+        if 2 <= p < L - 2:
+            d13, d14, d15 = dist64(x, y, z, p - 2, p), dist64(x, y, z, p - 2, p + 1), dist64(x, y, z, p - 2, p + 2)
+            d24, d25, d35 = dist64(x, y, z, p - 1, p + 1), dist64(x, y, z, p - 1, p + 2), dist64(x, y, z, p, p + 2)
+            if all(abs(d - c) < 2.1 for d, c in ((d15, 6.37), (d14, 5.18), (d25, 5.18), (d13, 5.45), (d24, 5.45), (d35, 5.45))):
+                ss[p] = ord("h")
+            elif all(abs(d - c) < 1.42 for d, c in ((d15, 13), (d14, 10.4), (d25, 10.4), (d13, 6.1), (d24, 6.1), (d35, 6.1))):
+                ss[p] = ord("s")
+            elif d15 < 8.2:
+                ss[p] = ord("t")
+        if 3 <= p < L - 3:
+            v = np.array([dist64(x, y, z, p + i, p + j) for i, j in zip(iv, jv)], np.float64)
+            best, mind = 0, None
+            for k in range(16):
+                s2 = np.float64(0)
+                for m in range(9):
+                    d = v[m] - M[k][m]
+                    s2 = s2 + d * d
+                dk = np.sqrt(s2)
+                if k == 0 or dk < mind:
+                    best, mind = k, dk
+            conf[p] = best
+    return ss, conf
+
+
 def test_device_densities_match_a_numpy_restatement(ctx):
     rng = np.random.default_rng(11)
-    lens = np.array([1, 2, 3, 4, 9, 17, 60, 61, 130, 411, 1203], np.uint32)
+    lens = np.array([1, 2, 3, 4, 5, 6, 7, 9, 17, 60, 61, 130, 411, 1203], np.uint32)
     tot = int(lens.sum())
-    xyz = [np.cumsum(rng.normal(0, 2.2, tot)).astype(np.float32) for _ in range(3)]
-    ssf = rng.choice(np.frombuffer(b"sh~t", np.uint8), tot)
-    ssr = rng.choice(np.frombuffer(b"sh~t", np.uint8), tot)
-    (df, sf, dr, sr), (nf, rf, nr, rr) = ctx.dss_densities(lens, *xyz, ssf.tobytes(), ssr.tobytes())
+    # persistent random walks with 3.8 A steps: helix- and strand-like stretches occur (SS letters h / s / t / ~ all appear)
+    from scipy.signal import lfilter
+    d = lfilter([0.6], [1.0, -0.8], rng.normal(0, 1, (tot, 3)) / 0.6, axis=0)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    walk = np.cumsum(3.8 * d, axis=0)
+    xyz = [np.ascontiguousarray(walk[:, k], np.float32) for k in range(3)]
+    r = ctx.dss_densities(lens, *xyz)
+    df, sf, dr, sr = r["dens_fwd"], r["sdens_fwd"], r["dens_rev"], r["sdens_rev"]
+    nf, rf, nr, rr = r["nen_fwd"], r["ren_fwd"], r["nen_rev"], r["ren_rev"]
+    ssf, ssr = r["ss_fwd"], r["ss_rev"]
+    assert len(set(ssf.tolist())) >= 3
     o = 0
     for L in lens:
         L = int(L)
@@ -91,6 +153,9 @@ def test_device_densities_match_a_numpy_restatement(ctx):
             assert np.array_equal(got_d == DBL_MAX, wd == DBL_MAX) and np.array_equal(got_s == DBL_MAX, ws == DBL_MAX)
             m = wd != DBL_MAX
             assert np.allclose(got_d[m], wd[m], rtol=1e-12, atol=1e-13) and np.allclose(got_s[m], ws[m], rtol=1e-12, atol=1e-13)
+        # SS characters and Conf letters: comparison chains on float / double values, exact
+        for got_s, got_c, want in ((ssf[sl], r["conf_fwd"][sl], ref_local(x, y, z)), (ssr[sl], r["conf_rev"][sl], ref_local(x[::-1], y[::-1], z[::-1]))):
+            assert np.array_equal(got_s, want[0]) and np.array_equal(got_c, want[1])
         # nearest neighbours: float arithmetic only, so the positions are the host's exactly
         for got_n, got_r, want in ((nf[sl], rf[sl], ref_neighbours(x, y, z)), (nr[sl], rr[sl], ref_neighbours(x[::-1], y[::-1], z[::-1]))):
             assert np.array_equal(got_n, want[0]) and np.array_equal(got_r, want[1])
@@ -101,7 +166,7 @@ def test_rejects_bad_windows(ctx):
     import reseek_amd
     one = np.zeros(4, np.float32)
     with pytest.raises(reseek_amd.RskError):
-        ctx.dss_densities([4], one, one, one, b"ssss", b"ssss", W=50, w1=9, w2=8)
+        ctx.dss_densities([4], one, one, one, W=50, w1=9, w2=8)
 
 
 @pytest.mark.parametrize("mode", ["sensitive", "verysensitive"])
