@@ -77,7 +77,8 @@ __global__ __launch_bounds__(256) void k_mkf_build(const uint8_t *q_mu, const ui
     }
 }
 
-__device__ __forceinline__ int mkf_xdrop(const uint8_t *Q, int LQ, const uint8_t *T, int LT, int PosQ, int PosT, int X, int &Loi, int &Loj,
+template <typename MAT>
+__device__ __forceinline__ int mkf_xdrop(const MAT c_mu_int, const uint8_t *Q, int LQ, const uint8_t *T, int LT, int PosQ, int PosT, int X, int &Loi, int &Loj,
                                          int &Len)
 {
     Loi = PosQ; Loj = PosT;
@@ -120,6 +121,11 @@ struct mkf_args {
 
 __global__ __launch_bounds__(64 * MKF_WAVES) void k_mkf_seed(mkf_args a)
 {
+    __shared__ int4 skept[MKF_WAVES][MKF_CAP_MAX];
+    __shared__ uint32_t sseeds[MKF_WAVES][MKF_QUEUE];
+    __shared__ signed char smat[1296];                            // the integer Mu matrix: one LDS read per extension step
+    for (int i = threadIdx.x; i < 1296; i += blockDim.x) smat[i] = (signed char) c_mu_int[i];
+    __syncthreads();
     const uint32_t p = a.pair_lo + blockIdx.x * MKF_WAVES + (threadIdx.x >> 6);
     if (p >= a.pair_hi) return;
     const int lane = threadIdx.x & 63;
@@ -128,8 +134,6 @@ __global__ __launch_bounds__(64 * MKF_WAVES) void k_mkf_seed(mkf_args a)
     const int LQ = (int) a.q_len[q], LT = (int) a.t_len[t];
     const uint32_t slot = a.qslot[p], bits = a.tab_bits[slot], hmask = (1u << bits) - 1;
     const uint4 *tab = a.tables + a.tab_off[slot];
-    __shared__ int4 skept[MKF_WAVES][MKF_CAP_MAX];
-    __shared__ uint32_t sseeds[MKF_WAVES][MKF_QUEUE];
     int4 *kept = skept[threadIdx.x >> 6];
     uint32_t *queue = sseeds[threadIdx.x >> 6];
     int best = 0;
@@ -145,7 +149,7 @@ __global__ __launch_bounds__(64 * MKF_WAVES) void k_mkf_seed(mkf_args a)
         int sc = 0, loi = 0, loj = 0, len = 0;
         if ((uint32_t) lane < n) {
             const uint32_t sd = queue[lane];
-            const int v = mkf_xdrop(Q, LQ, T, LT, (int) (sd & 0xFFFFu), (int) (sd >> 16), a.X, loi, loj, len);
+            const int v = mkf_xdrop(smat, Q, LQ, T, LT, (int) (sd & 0xFFFFu), (int) (sd >> 16), a.X, loi, loj, len);
             if (v >= a.min_score) sc = v;
         }
         if (__ballot(sc > 0)) found = true;
