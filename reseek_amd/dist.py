@@ -33,7 +33,7 @@ def _all_gather_padded(local, group=None, device=None):
     dist.all_gather(cnts, cnt, group=group)
     counts = [int(c.item()) for c in cnts]
     m = max(max(counts), 1)
-    t = torch.from_numpy(np.ascontiguousarray(local))
+    t = torch.from_numpy(np.array(local, order="C", copy=True))      # a writable copy: frombuffer views are read-only
     buf = torch.zeros((m,) + tuple(tail), dtype=t.dtype, device=dev)
     if local.shape[0]:
         buf[:local.shape[0]] = t.to(dev)
