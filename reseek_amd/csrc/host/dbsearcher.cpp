@@ -731,7 +731,8 @@ void ForEachAlignedBatch(const DSSParams &P, rsk_ctx *ctx, const SearchOptions &
 }
 
 void RunMKFPairs(rsk_ctx *Ctx, const DSSParams &P, const std::string &Columns, DBSearcher &SrcA, DBSearcher &SrcB,
-                 const std::vector<std::pair<uint32_t, uint32_t> > &Pairs, const std::function<void(DSSAligner &, uint, uint)> &OnHit)
+                 const std::vector<std::pair<uint32_t, uint32_t> > &Pairs, const std::function<void(DSSAligner &, uint, uint)> &OnHit,
+                 const std::function<void(DSSAligner &, uint, uint, unsigned)> *OnHitOfWorker)
 {
     const size_t n = Pairs.size();
     if (n == 0) return;
@@ -772,25 +773,25 @@ void RunMKFPairs(rsk_ctx *Ctx, const DSSParams &P, const std::string &Columns, D
     if (getenv("RSK_TRACE")) fprintf(stderr, "[RunMKFPairs] %zu pairs, %zu with a seed HSP\n", n, recs.size());
     const auto t_host0 = std::chrono::steady_clock::now();
     const unsigned T = (unsigned) std::max<size_t>(1, std::min<size_t>((size_t) HostThreads(128), recs.size() / 8 + 1));
-    auto parallel = [&](const std::function<void(DSSAligner &, size_t)> &fn) {
+    auto parallel = [&](const std::function<void(DSSAligner &, size_t, unsigned)> &fn) {
         std::atomic<size_t> next{0};
-        auto body = [&]() {
+        auto body = [&](unsigned worker) {
             DSSAligner DA;
             DA.SetParams(P);
             DA.SetColumns(Columns);
             for (;;) {
                 const size_t r = next.fetch_add(1);
                 if (r >= recs.size()) break;
-                fn(DA, r);
+                fn(DA, r, worker);
             }
             DA.UnsetQuery();
         };
-        if (T == 1) body();
+        if (T == 1) body(0);
         else {
             std::vector<std::thread> ts;
             std::vector<std::string> errs(T);
             for (unsigned t = 0; t < T; ++t)
-                ts.emplace_back([&, t]() { try { body(); } catch (const std::exception &e) { errs[t] = e.what(); } });
+                ts.emplace_back([&, t]() { try { body(t); } catch (const std::exception &e) { errs[t] = e.what(); } });
             for (auto &t : ts) t.join();
             for (auto &e : errs)
                 if (!e.empty()) throw std::runtime_error(e);
@@ -808,7 +809,7 @@ void RunMKFPairs(rsk_ctx *Ctx, const DSSParams &P, const std::string &Columns, D
     struct Chained { std::vector<int32_t> lo_a, lo_b, len; };
     std::vector<Chained> chains(recs.size());
     if (!host_only)
-        parallel([&](DSSAligner &DA, size_t r) {
+        parallel([&](DSSAligner &DA, size_t r, unsigned) {
             const Rec &R = recs[r];
             if (R.nkept > CAP) {                                          // seed list truncated on the device: seeds from MuKmerFilter::Align
                 set_pair(DA, r);
@@ -850,7 +851,7 @@ void RunMKFPairs(rsk_ctx *Ctx, const DSSParams &P, const std::string &Columns, D
     const auto t_host1 = std::chrono::steady_clock::now();
     // stage 3 (host threads): the aligned pairs become DSSAligner results and go to the caller
     std::mutex lock;
-    parallel([&](DSSAligner &DA, size_t r) {
+    parallel([&](DSSAligner &DA, size_t r, unsigned worker) {
         const Rec &R = recs[r];
         const uint i = Pairs[R.pair].first, j = Pairs[R.pair].second;
         const size_t k = slot[r];
@@ -867,6 +868,7 @@ void RunMKFPairs(rsk_ctx *Ctx, const DSSParams &P, const std::string &Columns, D
             DA.m_SelfRevScoreA = SrcA.m_DBSelfRevScores[i]; DA.m_SelfRevScoreB = SrcB.m_DBSelfRevScores[j];
             DA.SetFromAln(xout[k], xpaths + xout[k].path_off);
         }
+        if (OnHitOfWorker) { (*OnHitOfWorker)(DA, i, j, worker); return; }
         std::lock_guard<std::mutex> g(lock);
         OnHit(DA, i, j);
     });
@@ -1060,16 +1062,19 @@ static void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOff
     if (overlap) {
         SecondaryCtx own;
         own.Create(ctx->device, "mkf");
-        std::string lines;
-        uint64_t hits = 0;
-        std::future<void> job = std::async(std::launch::async, [&]() {
-            RunMKFPairs(own.c, P, S.m_Opts.columns, SrcA, S, mkf, [&](DSSAligner &DA, uint i, uint j) {   // called under RunMKFPairs' lock
-                each_orientation(DA, i, j, [&](DSSAligner &D, bool Up) {
-                    if (S.Reject(D, Up)) return;
-                    ++hits;
-                    if (S.m_fTsv && !(S.m_Opts.noself && D.m_ChainA->m_Label == D.m_ChainB->m_Label)) D.AppendTsv(lines, Up);
-                });
+        // hit lines of the long-chain job: one buffer per worker thread (formatting under one lock was a tenth of the job)
+        struct sink { std::string lines; uint64_t hits = 0; char pad[64]; };
+        std::vector<sink> sinks(HostThreads(128));
+        const std::function<void(DSSAligner &, uint, uint, unsigned)> on_hit = [&](DSSAligner &DA, uint i, uint j, unsigned worker) {
+            sink &me = sinks[worker];
+            each_orientation(DA, i, j, [&](DSSAligner &D, bool Up) {
+                if (S.Reject(D, Up)) return;
+                ++me.hits;
+                if (S.m_fTsv && !(S.m_Opts.noself && D.m_ChainA->m_Label == D.m_ChainB->m_Label)) D.AppendTsv(me.lines, Up);
             });
+        };
+        std::future<void> job = std::async(std::launch::async, [&]() {
+            RunMKFPairs(own.c, P, S.m_Opts.columns, SrcA, S, mkf, [](DSSAligner &, uint, uint) {}, &on_hit);
         });
         try {
             align();
@@ -1079,8 +1084,10 @@ static void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOff
         }
         job.get();
         tm.lap("align + replay | MKF side by side");
-        S.m_HitCount += hits;
-        if (!lines.empty() && fwrite(lines.data(), 1, lines.size(), S.m_fTsv) != lines.size()) throw std::runtime_error("short write to the hits file");
+        for (sink &me : sinks) {
+            S.m_HitCount += me.hits;
+            if (!me.lines.empty() && fwrite(me.lines.data(), 1, me.lines.size(), S.m_fTsv) != me.lines.size()) throw std::runtime_error("short write to the hits file");
+        }
         return;
     }
     align();

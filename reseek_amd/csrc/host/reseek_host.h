@@ -438,8 +438,11 @@ void ForEachAlignedBatch(const DSSParams &P, rsk_ctx *ctx, const SearchOptions &
                          const std::vector<uint32_t> &ia, const std::vector<uint32_t> &ib,
                          const std::function<void(const std::vector<uint32_t> &, const std::vector<uint32_t> &, const std::vector<rsk_aln> &,
                                                   const char *)> &OnBatch);
+// OnHit is called under a lock (one hit at a time, the reference's m_Lock semantics).  OnHitOfWorker, if given, replaces it:
+// called without the lock with the index of the calling worker thread (< HostThreads(128)); calls of one worker are serial.
 void RunMKFPairs(rsk_ctx *Ctx, const DSSParams &Params, const std::string &Columns, DBSearcher &SrcA, DBSearcher &SrcB,
-                 const std::vector<std::pair<uint32_t, uint32_t> > &Pairs, const std::function<void(DSSAligner &, uint, uint)> &OnHit);
+                 const std::vector<std::pair<uint32_t, uint32_t> > &Pairs, const std::function<void(DSSAligner &, uint, uint)> &OnHit,
+                 const std::function<void(DSSAligner &, uint, uint, unsigned)> *OnHitOfWorker = nullptr);
 
 // [b, e) ranges of a pair list such that each batch has <= batch_pairs pairs and <= batch_cells DP cells
 std::vector<std::pair<size_t, size_t> > AlignBatches(const SearchOptions &O, const DBSearcher &A, const DBSearcher &B,
