@@ -11,6 +11,8 @@
 // query positions with one 16-byte probe (load factor <= 0.5) and extend them; the order-dependent keep rule is resolved by walking the (rare) lanes that beat
 // the running best in lane order.  Integer work, L2-resident letters; bound: table-probe latency.
 #include <algorithm>
+#include <cstring>
+#include <memory>
 #include <vector>
 
 #include "rsk_dev_tables.h"
@@ -115,7 +117,9 @@ struct mkf_args {
     // compact records of the found pairs (appended with one atomic each)
     uint32_t *nrec; uint32_t max_rec;
     uint32_t *rec_pair, *rec_nkept;    // nkept may exceed cap: the list is then truncated and the host redoes the pair
-    int4 *rec_kept;                    // [max_rec][cap] (Loi, Loj, Len, Score)
+    int4 *rec_kept;                    // kept HSPs (Loi, Loj, Len, Score) of the records, back to back: record r owns
+                                       // min(nkept, cap) entries from rec_first[r] (only the entries written cross PCIe)
+    uint32_t *rec_first, *nent;
 };
 #define MKF_CAP_MAX 32
 
@@ -213,8 +217,11 @@ __global__ __launch_bounds__(64 * MKF_WAVES) void k_mkf_seed(mkf_args a)
         if (lane == 0) r = atomicAdd(a.nrec, 1u);
         r = (uint32_t) __shfl((int) r, 0, 64);
         if (r < a.max_rec) {
-            if (lane == 0) { a.rec_pair[r] = p; a.rec_nkept[r] = nk; }
-            for (uint32_t k = lane; k < min(nk, a.cap); k += 64) a.rec_kept[(size_t) r * a.cap + k] = kept[k];
+            const uint32_t ne = min(nk, a.cap);
+            uint32_t base = 0;
+            if (lane == 0) { base = atomicAdd(a.nent, ne); a.rec_pair[r] = p; a.rec_nkept[r] = nk; a.rec_first[r] = base; }
+            base = (uint32_t) __shfl((int) base, 0, 64);
+            for (uint32_t k = lane; k < ne; k += 64) a.rec_kept[(size_t) base + k] = kept[k];
         }
     }
 }
@@ -286,6 +293,7 @@ extern "C" int rsk_mkf_seed_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t
     uint4 *d_tab;
     uint8_t *d_found, *d_tbits;
     int4 *d_rkept;
+    uint32_t *d_rfirst, *d_nent;
     if ((rc = dalloc((void **) &d_iq, npairs * 4)) != RSK_OK) return rc;
     if ((rc = dalloc((void **) &d_it, npairs * 4)) != RSK_OK) return rc;
     if ((rc = dalloc((void **) &d_qslot, npairs * 4)) != RSK_OK) return rc;
@@ -298,6 +306,8 @@ extern "C" int rsk_mkf_seed_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t
     if ((rc = dalloc((void **) &d_rpair, max_records * 4)) != RSK_OK) return rc;
     if ((rc = dalloc((void **) &d_rnk, max_records * 4)) != RSK_OK) return rc;
     if ((rc = dalloc((void **) &d_rkept, max_records * (size_t) cap * sizeof(int4))) != RSK_OK) return rc;
+    if ((rc = dalloc((void **) &d_rfirst, max_records * 4)) != RSK_OK) return rc;
+    if ((rc = dalloc((void **) &d_nent, 4)) != RSK_OK) return rc;
     RSK_HIP(hipMemcpyAsync(d_iq, iq, npairs * 4, hipMemcpyHostToDevice, ctx->stream));
     RSK_HIP(hipMemcpyAsync(d_it, it, npairs * 4, hipMemcpyHostToDevice, ctx->stream));
     RSK_HIP(hipMemcpyAsync(d_qslot, qslot.data(), npairs * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -305,6 +315,7 @@ extern "C" int rsk_mkf_seed_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t
     RSK_HIP(hipMemcpyAsync(d_toff, tab_off.data(), qlist.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     RSK_HIP(hipMemcpyAsync(d_tbits, tab_bits.data(), qlist.size(), hipMemcpyHostToDevice, ctx->stream));
     RSK_HIP(hipMemsetAsync(d_nrec, 0, 4, ctx->stream));
+    RSK_HIP(hipMemsetAsync(d_nent, 0, 4, ctx->stream));
     RSK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     mkf_args a = {};
     a.q_mu = q->d_mu; a.q_off = q->d_off; a.q_len = q->d_len;
@@ -312,7 +323,7 @@ extern "C" int rsk_mkf_seed_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t
     a.iq = d_iq; a.it = d_it; a.qslot = d_qslot; a.tab_off = d_toff; a.tab_bits = d_tbits; a.tables = d_tab;
     a.X = x1; a.min_score = min_hsp_score; a.cap = cap;
     a.found = d_found; a.nrec = d_nrec; a.max_rec = (uint32_t) max_records;
-    a.rec_pair = d_rpair; a.rec_nkept = d_rnk; a.rec_kept = d_rkept;
+    a.rec_pair = d_rpair; a.rec_nkept = d_rnk; a.rec_kept = d_rkept; a.rec_first = d_rfirst; a.nent = d_nent;
     for (const chunk_t &c : chunks) {                       // same stream: a chunk's tables are rebuilt after its seeding kernel is done
         hipLaunchKernelGGL(k_mkf_build, dim3((unsigned) (c.q1 - c.q0)), dim3(256), 0, ctx->stream, q->d_mu, q->d_off, q->d_len, d_qlist + c.q0,
                            d_toff + c.q0, d_tbits + c.q0, d_tab);
@@ -334,10 +345,23 @@ extern "C" int rsk_mkf_seed_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t
     }
     const size_t m = std::min<size_t>(nrec, max_records);
     if (m) {
+        // the records' HSP lists sit back to back on the device (a few entries per record, not cap): they are copied
+        // compact and spread into the caller's [record][cap] layout here
+        uint32_t nent = 0;
+        RSK_HIP(hipMemcpyAsync(&nent, d_nent, 4, hipMemcpyDeviceToHost, ctx->stream));
         RSK_HIP(hipMemcpyAsync(rec_pair, d_rpair, m * 4, hipMemcpyDeviceToHost, ctx->stream));
         RSK_HIP(hipMemcpyAsync(rec_nkept, d_rnk, m * 4, hipMemcpyDeviceToHost, ctx->stream));
-        RSK_HIP(hipMemcpyAsync(rec_kept, d_rkept, m * (size_t) cap * sizeof(int4), hipMemcpyDeviceToHost, ctx->stream));
+        std::unique_ptr<uint32_t[]> first(new uint32_t[m]);
+        RSK_HIP(hipMemcpyAsync(first.get(), d_rfirst, m * 4, hipMemcpyDeviceToHost, ctx->stream));
         RSK_HIP(hipStreamSynchronize(ctx->stream));
+        std::unique_ptr<int4[]> ent(new int4[(size_t) nent + 1]);
+        if (nent) RSK_HIP(hipMemcpy(ent.get(), d_rkept, (size_t) nent * sizeof(int4), hipMemcpyDeviceToHost));
+        rsk_parallel_for(m, 4096, [&](size_t lo, size_t hi) {
+            for (size_t r = lo; r < hi; ++r) {
+                const uint32_t ne = std::min(rec_nkept[r], cap);
+                memcpy(rec_kept + r * (size_t) cap * 4, ent.get() + first[r], (size_t) ne * sizeof(int4));
+            }
+        });
     }
     return RSK_OK;
 }
