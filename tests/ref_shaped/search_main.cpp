@@ -1,114 +1,105 @@
-// TEST INFRASTRUCTURE: a caller written in the call sequence of the reference's `reseek -search` command
-// (SelfSearch search.cpp:20-37, Search_NoMuFilter :39-60, cmd_search :62-111) against reseek_host.h + librsk.so.
-// tests/test_gpu_ref_shaped.py compiles it on the GPU box and diffs its hit tables with the golden ones: the boundary test of
-// SURVEY 8b ("signatures to keep").  Where the reference reads opt(x) / optset_x globals this file reads g_Opts.
+// TEST INFRASTRUCTURE: a stand-alone `-search` driver over reseek_host.h + librsk.so, used by tests/test_gpu_ref_shaped.py
+// (compiled on the GPU box, its hit tables are diffed with the reference binary's goldens) and by tools/tsan_host.sh.
+// It exercises the boundary classes of SURVEY 8b -- DBSearcher, ChainReader2, MuSeqSource, SeqDB, MuPreFilter,
+// PostMuFilter, Open/CloseOutputFiles -- in the three shapes `reseek -search` has (all-vs-all, query set against a
+// streamed -db file, two-stage -fast -db).  That the REFERENCE's own caller compiles against the same header is proved
+// separately: oracle/Makefile.ref builds /root/reference/src/search.cpp against tests/ref_shaped/shim/ into
+// oracle/_ref/search_refsrc (nothing of it is stored here).
 //   usage: search_main QUERY [-db DB] -fast|-sensitive|-verysensitive -output HITS [-columns C] [-dbmu FA] [-keeptmp]
+//                      [-noself] [-evalue E] [-devices 0,0,...]
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <memory>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
+#include "cli_flags.h"
 #include "reseek_host.h"
 
-using namespace reseek_amd;
-using std::string;
+namespace ra = reseek_amd;
 
-static void Die(const char *Msg) { throw std::runtime_error(Msg); }
-static bool EndsWith(const string &s, const string &t) { return s.size() >= t.size() && s.compare(s.size() - t.size(), t.size(), t) == 0; }
+namespace {
 
-static void SelfSearch()
+// What the three shapes have in common: a loaded + set-up searcher over the positional chain file, hits file open
+// while `body` runs.
+struct LoadedSearch {
+    ra::DSSParams params;
+    ra::DBSearcher searcher;
+    LoadedSearch()
+    {
+        params.SetDSSParams(ra::DM_UseCommandLineOption);
+        searcher.m_Params = &params;
+        searcher.LoadDB(ra::g_Arg1);
+        searcher.Setup();
+    }
+    template <class F> void with_hits_file(F body)
+    {
+        ra::OpenOutputFiles();
+        body(searcher);
+        ra::CloseOutputFiles();
+    }
+};
+
+void all_vs_all()
 {
-    const string &QFN = g_Arg1;
-    if (!g_Opts.db.empty()) Die("-db not used for -selfsearch");
-
-    DBSearcher DBS;
-    DSSParams Params;
-    Params.SetDSSParams(DM_UseCommandLineOption);
-    DBS.m_Params = &Params;
-
-    DBS.LoadDB(QFN);
-    DBS.Setup();
-
-    OpenOutputFiles();
-    DBS.RunSelf();
-    CloseOutputFiles();
+    LoadedSearch s;
+    s.with_hits_file([](ra::DBSearcher &d) { d.RunSelf(); });
 }
 
-static void Search_NoMuFilter()
+void against_streamed_db()
 {
-    if (g_Opts.db.empty()) Die("-db required");
-
-    const string &QFN = g_Arg1;
-    const string &DBFN = g_Opts.db;
-
-    DBSearcher DBS;
-    DSSParams Params;
-    Params.SetDSSParams(DM_UseCommandLineOption);
-    DBS.m_Params = &Params;
-
-    DBS.LoadDB(QFN);
-    DBS.Setup();
-
-    OpenOutputFiles();
-    ChainReader2 CR;
-    CR.Open(DBFN);
-    DBS.RunQuery(CR);
-    CloseOutputFiles();
+    LoadedSearch s;
+    s.with_hits_file([](ra::DBSearcher &d) {
+        ra::ChainReader2 targets;
+        targets.Open(ra::g_Opts.db);
+        d.RunQuery(targets);
+    });
 }
 
-static void cmd_search()
+bool has_suffix(const std::string &s, const char *suf)
 {
-    if (g_Opts.db.empty()) { SelfSearch(); return; }
-    if (!g_Opts.fast_set()) { Search_NoMuFilter(); return; }
-
-    const string &QueryFN = g_Arg1;
-    const string DBFN = g_Opts.db;
-    if (!EndsWith(DBFN, ".bca")) Die(".bca format required for -db");
-
-    DSSParams Params;
-    Params.SetDSSParams(DM_UseCommandLineOption);
-    if (Params.m_MuPrefPatternStr != "1110011") Die("PatternStr");
-
-    const string MuFilterTsvFN = g_Opts.output + ".prefilter.tmp";       // GetTmpFileName
-
-    MuSeqSource QSS;
-    MuSeqSource DBSS;
-    QSS.OpenChains(QueryFN, Params);
-    if (!g_Opts.dbmu.empty()) DBSS.OpenFasta(g_Opts.dbmu);
-    else DBSS.OpenChains(DBFN, Params);
-
-    SeqDB MuQueryDB;
-    MuQueryDB.FromSS(QSS);
-
-    MuPreFilter(Params, MuQueryDB, DBSS, MuFilterTsvFN);
-
-    DSSParams Params2;
-    Params2.SetDSSParams(DM_AlwaysSensitive);
-    PostMuFilter(Params2, MuFilterTsvFN, QueryFN, DBFN, g_Opts.output);
-
-    if (!g_Opts.keeptmp) remove(MuFilterTsvFN.c_str());
+    const size_t n = strlen(suf);
+    return s.size() >= n && !s.compare(s.size() - n, n, suf);
 }
+
+void two_stage_fast_db()
+{
+    const std::string db_file = ra::g_Opts.db, hits_file = ra::g_Opts.output;
+    if (!has_suffix(db_file, ".bca")) throw std::runtime_error("-fast -db needs a .bca database");
+    const std::string handoff = hits_file + ".prefilter.tmp";
+
+    {   // stage 1: Mu letters of both sides, k-mer prefilter, candidate lists into the hand-off file
+        ra::DSSParams prefilter_params;
+        prefilter_params.SetDSSParams(ra::DM_UseCommandLineOption);
+        if (prefilter_params.m_MuPrefPatternStr != "1110011") throw std::runtime_error("unexpected prefilter pattern");
+        ra::MuSeqSource query_letters, db_letters;
+        query_letters.OpenChains(ra::g_Arg1, prefilter_params);
+        if (ra::g_Opts.dbmu.empty()) db_letters.OpenChains(db_file, prefilter_params);
+        else db_letters.OpenFasta(ra::g_Opts.dbmu);
+        ra::SeqDB query_index_input;
+        query_index_input.FromSS(query_letters);
+        ra::MuPreFilter(prefilter_params, query_index_input, db_letters, handoff);
+    }
+    {   // stage 2: the candidates aligned under the sensitive preset
+        ra::DSSParams align_params;
+        align_params.SetDSSParams(ra::DM_AlwaysSensitive);
+        ra::PostMuFilter(align_params, handoff, ra::g_Arg1, db_file, hits_file);
+    }
+    if (!ra::g_Opts.keeptmp) remove(handoff.c_str());
+}
+
+}   // namespace
 
 int main(int argc, char **argv)
 {
     try {
-        if (argc < 2) Die("usage: search_main QUERY [-db DB] -fast|-sensitive|-verysensitive -output HITS");
-        g_Arg1 = argv[1];
-        for (int i = 2; i < argc; ++i) {
-            const string a = argv[i];
-            auto val = [&]() -> string { if (i + 1 >= argc) Die("missing option value"); return argv[++i]; };
-            if (a == "-db") g_Opts.db = val();
-            else if (a == "-output") g_Opts.output = val();
-            else if (a == "-columns") g_Opts.columns = val();
-            else if (a == "-dbmu") g_Opts.dbmu = val();
-            else if (a == "-fast") g_Opts.mode = AM_Fast;
-            else if (a == "-sensitive") g_Opts.mode = AM_Sensitive;
-            else if (a == "-verysensitive") g_Opts.mode = AM_VerySensitive;
-            else if (a == "-keeptmp") g_Opts.keeptmp = true;
-            else if (a == "-noself") g_Opts.noself = true;
-            else if (a == "-evalue") { g_Opts.evalue_set = true; g_Opts.evalue = atof(val().c_str()); }
-            else Die(("unknown option " + a).c_str());
-        }
-        cmd_search();
+        ref_shaped::parse_command_line(argc, argv);
+        const bool db = !ra::g_Opts.db.empty();
+        void (*const shape)() = !db ? all_vs_all : ra::g_Opts.fast_set() ? two_stage_fast_db : against_streamed_db;
+        shape();
     } catch (const std::exception &e) {
         fprintf(stderr, "search_main: %s\n", e.what());
         return 1;

@@ -1,8 +1,13 @@
-"""SURVEY 8b "signatures to keep": tests/ref_shaped/search_main.cpp is written in the call sequence of the reference's
-search.cpp:20-111 (DBSearcher::LoadDB/Setup/RunSelf, ChainReader2 + RunQuery, MuSeqSource / SeqDB / MuPreFilter /
-PostMuFilter with the reference's argument lists).  It is compiled here against reseek_host.h + librsk.so and its hit
-tables must equal the reference binary's goldens; a second program drives the per-pair entry points
-(SetQuery/SetTarget/AlignQueryTarget, ChainBag + AlignBags, MuKmerFilter::SetBagQ/AlignBag)."""
+"""SURVEY 8b "signatures to keep".  Three C++ callers over reseek_host.h + librsk.so must reproduce the reference binary's
+goldens:
+* oracle/_ref/search_refsrc -- the REFERENCE'S OWN search.cpp (SelfSearch / Search_NoMuFilter / cmd_search,
+  search.cpp:20-111), compiled unmodified in the build container against the name shim tests/ref_shaped/shim/
+  (oracle/Makefile.ref; nothing of it is stored in the repo); the binary travels to the GPU box like oracle/_ref/reseek.
+  If DBSearcher / ChainReader2 / MuSeqSource / SeqDB / MuPreFilter / PostMuFilter drift from the reference's names or
+  argument lists, that build fails; here its output is checked.
+* tests/ref_shaped/search_main.cpp -- our own driver over the same classes (compiled here), also with two device contexts.
+* tests/ref_shaped/pair_main.cpp -- the per-pair entry points (SetQuery/SetTarget/AlignQueryTarget, ChainBag + AlignBags,
+  MuKmerFilter::SetBagQ/AlignBag)."""
 import gzip
 import os
 import shutil
@@ -38,33 +43,47 @@ def work():
     shutil.rmtree(d, ignore_errors=True)
 
 
-def _run(work, args, golden):
+REFSRC = os.path.join(ROOT, "oracle", "_ref", "search_refsrc")
+DRIVERS = ["search_main", "search_refsrc"]
+
+
+@pytest.fixture(params=DRIVERS)
+def driver(request, work):
+    if request.param == "search_refsrc":
+        if not os.path.exists(REFSRC):
+            pytest.skip("oracle/_ref/search_refsrc not built (make -f oracle/Makefile.ref where /root/reference exists)")
+        return REFSRC
+    return os.path.join(work, request.param)
+
+
+def _run(work, args, golden, exe=None, env=None):
     out = os.path.join(work, "hits.tsv")
     if os.path.exists(out):
         os.remove(out)
-    r = subprocess.run([os.path.join(work, "search_main")] + args + ["-output", out, "-columns", COLS], capture_output=True, text=True, cwd=work)
+    r = subprocess.run([exe or os.path.join(work, "search_main")] + args + ["-output", out, "-columns", COLS], capture_output=True, text=True, cwd=work,
+                       env=dict(os.environ, **(env or {})))
     assert r.returncode == 0, r.stderr
     got = sorted(open(out).read().splitlines())
     want = sorted("\t".join(x) for x in fx.read_tsv(golden))
     assert got == want, "hit tables differ: %d vs %d rows" % (len(got), len(want))
 
 
-def test_selfsearch_sequence(work):
-    _run(work, ["q100.bca", "-sensitive"], "hits_q100_sensitive.tsv.gz")
+def test_selfsearch_sequence(work, driver):
+    _run(work, ["q100.bca", "-sensitive"], "hits_q100_sensitive.tsv.gz", driver)
 
 
-def test_selfsearch_long_chains(work):
-    _run(work, ["palms.bca", "-sensitive"], "hits_palms_sensitive.tsv.gz")
+def test_selfsearch_long_chains(work, driver):
+    _run(work, ["palms.bca", "-sensitive"], "hits_palms_sensitive.tsv.gz", driver)
 
 
-def test_search_nomufilter_streams_a_chainreader2(work):
-    _run(work, ["q100.bca", "-db", "q100.bca", "-sensitive"], "hits_q100_db_q100_sensitive.tsv.gz")
+def test_search_nomufilter_streams_a_chainreader2(work, driver):
+    _run(work, ["q100.bca", "-db", "q100.bca", "-sensitive"], "hits_q100_db_q100_sensitive.tsv.gz", driver)
 
 
-def test_cmd_search_fast_db_two_stage(work):
+def test_cmd_search_fast_db_two_stage(work, driver):
     """MuSeqSource / SeqDB / MuPreFilter / PostMuFilter with the argument lists of search.cpp:9-18; the hand-off file
     must be the reference's byte for byte (-keeptmp)."""
-    _run(work, ["q100.bca", "-db", "q100.bca", "-fast", "-keeptmp"], "hits_q100_db_q100_fast.tsv.gz")
+    _run(work, ["q100.bca", "-db", "q100.bca", "-fast", "-keeptmp"], "hits_q100_db_q100_fast.tsv.gz", driver)
     tmp = open(os.path.join(work, "hits.tsv.prefilter.tmp")).read()
     with gzip.open(os.path.join(fx.GOLDEN, "prefilter_q100_db_q100_fast_tmp.tsv.gz"), "rt") as f:
         assert tmp == f.read()
