@@ -179,21 +179,22 @@ int rsk_mu_filter_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, const ui
  * (Loi, Loj, Len, Score), at most cap (<= 32) stored; a count > cap is an upper bound (redo that pair
  * with the host path).  *nrecords may exceed max_records (then enlarge and
  * call again).  x1 = m_MKF_X1 (8).  Chaining of the kept HSPs stays in host/dssaligner.cpp; the gapped
- * extensions of the found pairs are rsk_xdrop_pairs below. */
+ * extensions of the found pairs are rsk_mkf_align_pairs / rsk_xdrop_pairs below. */
 int rsk_mkf_seed_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, const uint32_t *iq, const uint32_t *it,
                        size_t npairs, int x1, int min_hsp_score, uint32_t cap, uint8_t *found, size_t max_records,
                        size_t *nrecords, uint32_t *rec_pair, uint32_t *rec_nkept, int32_t *rec_kept);
 
-/* ---- P9 (second half, host): the gapped float X-drop building blocks on an explicit LA x LB score matrix
- * (row-major S[a * LB + b]) -- XDropFwd (xdropfwd.cpp:71), XDropBwd (xdropbwd.cpp:28), MergeFwdBwd
- * (mergefwdback.cpp:6), in the form the reference's own self-test drives them (test_xdrop.cpp:81-175).
- * XDropFwd extends from (lo_a, lo_b) towards the chain ends, XDropBwd from (hi_a, hi_b) towards the starts;
- * open / ext are added (pass them negative).  path: caller buffer, NUL-terminated, *path_len = its length.
- * Inside -search these run per long-chain pair with DSSAligner::SubstScore as the matrix
- * (host/dssaligner.cpp, XDropHSP xdrophsp.cpp:42).  Host code: ctx-free, no GPU involved. */
-int rsk_xdrop_fwd(const float *S, uint32_t LA, uint32_t LB, float X, float open, float ext, uint32_t lo_a, uint32_t lo_b,
+/* ---- P9 (second half): the gapped float X-drop building blocks on an explicit LA x LB score matrix (row-major
+ * S[a * LB + b], host memory) -- XDropFwd (xdropfwd.cpp:71), XDropBwd (xdropbwd.cpp:28), MergeFwdBwd (mergefwdback.cpp:6),
+ * in the form the reference's own self-test drives them (test_xdrop.cpp:81-175).  rsk_xdrop_fwd / rsk_xdrop_bwd run ONE
+ * extension on the device, through the same kernel as the search's long-chain batch (k_xdrop_wave with the matrix in
+ * place of the profile tables): there is no host implementation of the X-drop DP in this library.
+ * XDropFwd extends from (lo_a, lo_b) towards the chain ends (lo < L on both sides), XDropBwd from (hi_a, hi_b) towards the
+ * starts; open / ext are added (pass them negative).  path: caller buffer, NUL-terminated, *path_len = its length.
+ * rsk_merge_fwd_bwd is plain host code (path concatenation and the Lo / Hi arithmetic). */
+int rsk_xdrop_fwd(rsk_ctx *ctx, const float *S, uint32_t LA, uint32_t LB, float X, float open, float ext, uint32_t lo_a, uint32_t lo_b,
                   float *score, char *path, size_t path_cap, uint32_t *path_len);
-int rsk_xdrop_bwd(const float *S, uint32_t LA, uint32_t LB, float X, float open, float ext, uint32_t hi_a, uint32_t hi_b,
+int rsk_xdrop_bwd(rsk_ctx *ctx, const float *S, uint32_t LA, uint32_t LB, float X, float open, float ext, uint32_t hi_a, uint32_t hi_b,
                   float *score, char *path, size_t path_cap, uint32_t *path_len);
 int rsk_merge_fwd_bwd(uint32_t LA, uint32_t LB, uint32_t fwd_lo_a, uint32_t fwd_lo_b, const char *fwd_path, uint32_t bwd_hi_a,
                       uint32_t bwd_hi_b, const char *bwd_path, uint32_t *lo_a, uint32_t *lo_b, uint32_t *hi_a, uint32_t *hi_b,
@@ -202,7 +203,7 @@ int rsk_merge_fwd_bwd(uint32_t LA, uint32_t LB, uint32_t fwd_lo_a, uint32_t fwd_
 /* P9 (second half, device): the two gapped X-drop extensions of XDropHSP (xdrophsp.cpp:97-108) for a list of seeded
  * pairs -- XDropFwd from (lo_a, lo_b) to the chain ends and XDropBwd from (lo_a - 1, lo_b - 1) to the chain starts,
  * with DSSAligner::SubstScore (xdrophsp.cpp:8) as the substitution function; X = m_MKF_X2, gap_open / gap_ext =
- * m_GapOpen / m_GapExt (negative).  1 <= lo < L on both chains.  One GPU thread per extension.  Host arrays:
+ * m_GapOpen / m_GapExt (negative).  1 <= lo < L on both chains.  One wave per extension (k_xdrop_wave).  Host arrays:
  * score_fwd / score_bwd [n]; the path of extension k is paths[*_off[k] .. + *_len[k]) (not NUL-terminated);
  * paths_bytes >= sum(LA + LB + 4). */
 int rsk_xdrop_pairs(rsk_ctx *ctx, const rsk_db *a, const rsk_db *b, const uint32_t *ia, const uint32_t *ib,
@@ -217,7 +218,8 @@ int rsk_xdrop_pairs(rsk_ctx *ctx, const rsk_db *a, const rsk_db *b, const uint32
  *   XDropHSP (xdrophsp.cpp:42: best 8-mer of that HSP = start, XDropFwd + XDropBwd with X = x2, total < 10 => no alignment),
  *   MergeFwdBwd (mergefwdback.cpp:6) and CalcEvalue (dssaligner.cpp:852).
  * out / paths as rsk_align_pairs (path_len == 0 = no alignment).  status[p]: 0 = gated out, 1 = extended on the device,
- * 2 = the start fell outside 1..L-1 of a chain (cannot happen for chains >= 8; the caller's per-pair path decides). */
+ * 2 = the start fell outside 1..L-1 of a chain (only possible for chains shorter than 8, where the reference's own extents
+ * wrap around): no extension is run, path_len == 0. */
 int rsk_mkf_align_pairs(rsk_ctx *ctx, const rsk_db *a, const rsk_db *b, const uint32_t *ia, const uint32_t *ib, size_t npairs,
                         const uint32_t *hsp_first, const int32_t *hsp_lo_a, const int32_t *hsp_lo_b, const int32_t *hsp_len, float x2,
                         float gap_open, float gap_ext, float min_mega_score, float min_fwd_score, rsk_aln *out, uint8_t *status, char *paths,

@@ -77,7 +77,7 @@ SIGNATURES["rsk_xdrop_pairs"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, u
                                            C.POINTER(C.c_uint64), u32p])
 SIGNATURES["rsk_mkf_align_pairs"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, u32p, u32p, C.c_size_t, u32p, i32p, i32p, i32p, C.c_float,
                                                C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(Aln), u8p, C.c_char_p, C.c_size_t])
-SIGNATURES["rsk_xdrop_fwd"] = (C.c_int, [f32p, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32,
+SIGNATURES["rsk_xdrop_fwd"] = (C.c_int, [C.c_void_p, f32p, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32,
                                          f32p, C.c_char_p, C.c_size_t, u32p])
 SIGNATURES["rsk_xdrop_bwd"] = SIGNATURES["rsk_xdrop_fwd"]
 SIGNATURES["rsk_merge_fwd_bwd"] = (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint32, C.c_uint32, C.c_char_p,
@@ -486,23 +486,24 @@ def rsb_select(q, t, score, nqueries, rsb_size=1500, tmp_tsv_path=None):
     return oq[:m], ot[:m], os_[:m]
 
 
-def _xdrop(fn, S, X, gap_open, gap_ext, a, b):
+def _xdrop(fn, ctx, S, X, gap_open, gap_ext, a, b):
     S = np.ascontiguousarray(S, np.float32)
     LA, LB = S.shape
     buf = C.create_string_buffer(LA + LB + 2)
     score, n = C.c_float(), C.c_uint32()
-    _check(fn(_p(S, f32p), LA, LB, X, gap_open, gap_ext, a, b, C.byref(score), buf, len(buf), C.byref(n)))
+    _check(fn(ctx.h, _p(S, f32p), LA, LB, X, gap_open, gap_ext, a, b, C.byref(score), buf, len(buf), C.byref(n)))
     return score.value, buf.value.decode()
 
 
-def xdrop_fwd(S, X, gap_open, gap_ext, lo_a, lo_b):
-    """XDropFwd (xdropfwd.cpp:71) on an explicit score matrix S[LA, LB] -> (score, path).  Host code."""
-    return _xdrop(lib().rsk_xdrop_fwd, S, X, gap_open, gap_ext, lo_a, lo_b)
+def xdrop_fwd(ctx, S, X, gap_open, gap_ext, lo_a, lo_b):
+    """XDropFwd (xdropfwd.cpp:71) on an explicit score matrix S[LA, LB] -> (score, path): one extension on the device
+    (k_xdrop_wave with the matrix in place of the profile tables)."""
+    return _xdrop(lib().rsk_xdrop_fwd, ctx, S, X, gap_open, gap_ext, lo_a, lo_b)
 
 
-def xdrop_bwd(S, X, gap_open, gap_ext, hi_a, hi_b):
-    """XDropBwd (xdropbwd.cpp:28) -> (score, path)."""
-    return _xdrop(lib().rsk_xdrop_bwd, S, X, gap_open, gap_ext, hi_a, hi_b)
+def xdrop_bwd(ctx, S, X, gap_open, gap_ext, hi_a, hi_b):
+    """XDropBwd (xdropbwd.cpp:28) -> (score, path), on the device."""
+    return _xdrop(lib().rsk_xdrop_bwd, ctx, S, X, gap_open, gap_ext, hi_a, hi_b)
 
 
 def merge_fwd_bwd(LA, LB, fwd_lo_a, fwd_lo_b, fwd_path, bwd_hi_a, bwd_hi_b, bwd_path):

@@ -27,8 +27,6 @@
 #include "../rsk_internal.h"
 
 namespace reseek_amd {
-extern std::atomic<uint64_t> g_MKFNsMega, g_MKFNsXDrop, g_MKFNsStats;      // host/dssaligner.cpp (RSK_TRACE)
-
 static void check(int rc, const char *what)
 {
     if (rc != RSK_OK) throw std::runtime_error(std::string(what) + ": " + rsk_last_error());
@@ -231,7 +229,8 @@ void DBSearcher::LoadChains(std::vector<PDBChain *> &Chains)
 
 // GetSelfRevScore alignpair.cpp:7-24 for every chain: AlignQueryTarget of the chain against its reversed copy
 // (profile of the reversed chain; the Mu letters / k-mers passed for BOTH sides are the un-reversed ones -- the
-// reference's behaviour), m_AlnFwdScore is the result.  Chains that take the MKF path run on the host.
+// reference's behaviour), m_AlnFwdScore is the result.  Chains that take the MKF path (DoMKF: length >= m_MKFL) go through
+// the same device batch as the search's long-chain pairs (RunMKFPairs), against a view of the reversed chains.
 void DBSearcher::ComputeSelfRevScores()
 {
     const uint N = GetDBChainCount();
@@ -282,29 +281,39 @@ void DBSearcher::ComputeSelfRevScores()
         const bool DoMKF = HaveMu && !m_DBMuKmersVec[i]->empty() && L >= DAP.m_MKFL;      // DoMKF dssaligner.cpp:715
         (DoMKF ? mkf : gpu).push_back(i);
     }
-    if (!gpu.empty()) {
-        std::vector<uint32_t> len(N);
-        std::vector<size_t> start((size_t) N + 1, 0);
-        for (uint i = 0; i < N; ++i) { len[i] = m_DBChains[i]->GetSeqLength(); start[i + 1] = start[i] + len[i]; }
-        const size_t tot = start[N];
-        // The chains themselves go up once, as the set the search will use (UploadToGpu, its self-rev scores completed at the
-        // end of this function): it is the query side here.  Only the reversed profiles need a set of their own.
-        std::vector<uint8_t> mu(tot), pr(tot * RSK_NFEAT);
-        rsk_parallel_for(N, 512, [&](size_t lo, size_t hi) {
-            for (size_t i = lo; i < hi; ++i) {
-                const uint L = len[i];
-                const size_t o = start[i];
-                memcpy(&mu[o], m_DBMuLettersVec[i]->data(), L);
-                for (int f = 0; f < RSK_NFEAT; ++f) memcpy(&pr[o * RSK_NFEAT + (size_t) f * L], RevProf[i][f].data(), L);
+    // The chains themselves go up once, as the set the search will use (UploadToGpu, its self-rev scores completed at the
+    // end of this function): it is the query side here.  Only the reversed profiles need a set of their own -- with the
+    // un-reversed Mu letters (what the reference passes for both sides) and, when long chains are present, the reversed
+    // coordinates (the long-chain batch computes the alignment statistics of every pair; only the score is used here).
+    std::vector<uint32_t> len(N);
+    std::vector<size_t> start((size_t) N + 1, 0);
+    for (uint i = 0; i < N; ++i) { len[i] = m_DBChains[i]->GetSeqLength(); start[i + 1] = start[i] + len[i]; }
+    const size_t tot = start[N];
+    std::vector<uint8_t> mu(tot), pr(tot * RSK_NFEAT);
+    std::vector<float> rx, ry, rz;
+    if (!mkf.empty()) { rx.resize(tot); ry.resize(tot); rz.resize(tot); }
+    rsk_parallel_for(N, 512, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) {
+            const uint L = len[i];
+            const size_t o = start[i];
+            memcpy(&mu[o], m_DBMuLettersVec[i]->data(), L);
+            for (int f = 0; f < RSK_NFEAT; ++f) memcpy(&pr[o * RSK_NFEAT + (size_t) f * L], RevProf[i][f].data(), L);
+            if (!rx.empty()) {
+                const PDBChain &C = *m_DBChains[i];
+                for (uint k = 0; k < L; ++k) { rx[o + k] = C.m_Xs[L - 1 - k]; ry[o + k] = C.m_Ys[L - 1 - k]; rz[o + k] = C.m_Zs[L - 1 - k]; }
             }
-        });
-        tm.lap("pack");
-        UploadToGpu();
-        rsk_db *fdb = m_Db, *rdb = nullptr;
-        struct guard { rsk_db *d; ~guard() { if (d) rsk_db_destroy(d); } } g2{ nullptr };
-        check(rsk_db_create(m_Ctx, N, len.data(), mu.data(), pr.data(), nullptr, nullptr, nullptr, nullptr, &rdb), "rsk_db_create");
-        g2.d = rdb;
-        tm.lap("upload");
+        }
+    });
+    tm.lap("pack");
+    UploadToGpu();
+    rsk_db *fdb = m_Db, *rdb = nullptr;
+    struct guard { rsk_db *d; ~guard() { if (d) rsk_db_destroy(d); } } g2{ nullptr };
+    check(rsk_db_create(m_Ctx, N, len.data(), mu.data(), pr.data(), rx.empty() ? nullptr : rx.data(), rx.empty() ? nullptr : ry.data(),
+                        rx.empty() ? nullptr : rz.data(), nullptr, &rdb),
+          "rsk_db_create");
+    g2.d = rdb;
+    tm.lap("upload");
+    if (!gpu.empty()) {
         std::vector<uint32_t> idx = gpu;
         if (DAP.m_Omega > 0) {                                           // MuFilter dssaligner.cpp:817-826 (self vs self letters)
             std::vector<uint8_t> pass(idx.size());
@@ -327,27 +336,37 @@ void DBSearcher::ComputeSelfRevScores()
         tm.lap("GPU filter + SW");
     }
     if (!mkf.empty()) {
-        const unsigned T = (unsigned) std::max<size_t>(1, std::min<size_t>((size_t) HostThreads(128), mkf.size()));
-        std::atomic<size_t> next{0};
-        auto body = [&]() {
-            DSSAligner DA;
-            DA.SetParams(DAP);
-            for (;;) {
-                const size_t k = next.fetch_add(1);
-                if (k >= mkf.size()) break;
-                const uint32_t i = mkf[k];
-                DA.SetQuery(*m_DBChains[i], m_DBProfiles[i], m_DBMuLettersVec[i], m_DBMuKmersVec[i], FLT_MAX);
-                if (Rev[i].GetSeqLength() == 0) m_DBChains[i]->GetReverse(Rev[i]);
-                DA.SetTarget(Rev[i], &RevProf[i], m_DBMuLettersVec[i], m_DBMuKmersVec[i], FLT_MAX);
-                DA.AlignMKF();
-                m_DBSelfRevScores[i] = DA.m_AlnFwdScore;
-            }
-            DA.UnsetQuery();
-        };
-        std::vector<std::thread> ts;
-        for (unsigned t = 0; t < T; ++t) ts.emplace_back(body);
-        for (auto &t : ts) t.join();
-        tm.lap("MKF chains (host)");
+        // B side of the long-chain batch: the reversed chains as a borrowed view (chain objects only for the long ones)
+        DBSearcher RevView;
+        RevView.m_OwnsChains = false;
+        RevView.m_Params = &DAP; RevView.m_Opts = m_Opts; RevView.m_Ctx = m_Ctx;
+        RevView.m_DBChains.assign(N, nullptr);
+        RevView.m_DBProfiles.resize(N);
+        for (uint i = 0; i < N; ++i) RevView.m_DBProfiles[i] = &RevProf[i];
+        RevView.m_DBMuLettersVec = m_DBMuLettersVec;
+        RevView.m_DBMuKmersVec = m_DBMuKmersVec;
+        RevView.m_DBSelfRevScores.assign(N, FLT_MAX);
+        std::vector<float> SelfRevA(N, FLT_MAX);
+        SelfRevA.swap(m_DBSelfRevScores);                                 // SetQuery(..., FLT_MAX) alignpair.cpp:14-17
+        std::vector<std::pair<uint32_t, uint32_t> > Pairs;
+        for (uint32_t i : mkf) {
+            if (Rev[i].GetSeqLength() == 0) m_DBChains[i]->GetReverse(Rev[i]);
+            RevView.m_DBChains[i] = &Rev[i];
+            Pairs.emplace_back(i, i);
+        }
+        RevView.m_Db = rdb;
+        std::vector<float> Score(N, 0.0f);
+        try {
+            RunMKFPairs(m_Ctx, DAP, "", *this, RevView, Pairs, [&](DSSAligner &DA, uint i, uint) { Score[i] = DA.m_AlnFwdScore; });
+        } catch (...) {
+            RevView.m_Db = nullptr;
+            SelfRevA.swap(m_DBSelfRevScores);
+            throw;
+        }
+        RevView.m_Db = nullptr;                                           // rdb belongs to the guard above
+        SelfRevA.swap(m_DBSelfRevScores);
+        for (uint32_t i : mkf) m_DBSelfRevScores[i] = Score[i];
+        tm.lap("long chains (device batch)");
     }
     if (m_Db) check(rsk_db_update_selfrev(m_Db, m_DBSelfRevScores.data()), "rsk_db_update_selfrev");
 }
@@ -804,24 +823,21 @@ void RunMKFPairs(rsk_ctx *Ctx, const DSSParams &P, const std::string &Columns, D
     };
     // stage 1 (host threads): chain the seed HSPs of every record (MuKmerFilter::ChainHSPs mukmerfilter.cpp:391 ->
     // Chainer::Chain, libc qsort on a comparator that is no total order: the one step that stays on the host).
-    // RSK_MKF_HOST=1 keeps the whole per-pair path on the host threads (the parity reference of the device batch).
-    const bool host_only = getenv("RSK_MKF_HOST") && atoi(getenv("RSK_MKF_HOST")) != 0;
     struct Chained { std::vector<int32_t> lo_a, lo_b, len; };
     std::vector<Chained> chains(recs.size());
-    if (!host_only)
-        parallel([&](DSSAligner &DA, size_t r, unsigned) {
-            const Rec &R = recs[r];
-            if (R.nkept > CAP) {                                          // seed list truncated on the device: seeds from MuKmerFilter::Align
-                set_pair(DA, r);
-                DA.m_MKF.Align(*DA.m_MuLettersB, *DA.m_MuKmersB);
-            } else
-                DA.m_MKF.SetSeedHSPs(R.kept.data(), R.nkept);
-            if (DA.m_MKF.m_BestChainScore <= 0) return;                   // PostAlignMKF dssaligner.cpp:1397
-            Chained &C = chains[r];
-            C.lo_a.assign(DA.m_MKF.m_ChainHSPLois.begin(), DA.m_MKF.m_ChainHSPLois.end());
-            C.lo_b.assign(DA.m_MKF.m_ChainHSPLojs.begin(), DA.m_MKF.m_ChainHSPLojs.end());
-            C.len.assign(DA.m_MKF.m_ChainHSPLens.begin(), DA.m_MKF.m_ChainHSPLens.end());
-        });
+    parallel([&](DSSAligner &DA, size_t r, unsigned) {
+        const Rec &R = recs[r];
+        if (R.nkept > CAP) {                                          // seed list truncated on the device: seeds from MuKmerFilter::Align
+            set_pair(DA, r);
+            DA.m_MKF.Align(*DA.m_MuLettersB, *DA.m_MuKmersB);
+        } else
+            DA.m_MKF.SetSeedHSPs(R.kept.data(), R.nkept);
+        if (DA.m_MKF.m_BestChainScore <= 0) return;                   // PostAlignMKF dssaligner.cpp:1397
+        Chained &C = chains[r];
+        C.lo_a.assign(DA.m_MKF.m_ChainHSPLois.begin(), DA.m_MKF.m_ChainHSPLois.end());
+        C.lo_b.assign(DA.m_MKF.m_ChainHSPLojs.begin(), DA.m_MKF.m_ChainHSPLojs.end());
+        C.len.assign(DA.m_MKF.m_ChainHSPLens.begin(), DA.m_MKF.m_ChainHSPLens.end());
+    });
     // stage 2 (GPU, one batch): mega-HSP scores + gates, start of the gapped extensions, both extensions, merge, statistics
     std::vector<size_t> slot(recs.size(), (size_t) -1);
     std::vector<uint32_t> xa, xb, first(1, 0);
@@ -855,19 +871,14 @@ void RunMKFPairs(rsk_ctx *Ctx, const DSSParams &P, const std::string &Columns, D
         const Rec &R = recs[r];
         const uint i = Pairs[R.pair].first, j = Pairs[R.pair].second;
         const size_t k = slot[r];
-        if (host_only || (k != (size_t) -1 && xstatus[k] == 2)) {
-            // the whole pair on this thread: seeds known (or MuKmerFilter::Align), host X-drop, host statistics
-            set_pair(DA, r);
-            if (R.nkept > CAP) DA.AlignMKF();
-            else DA.AlignMKF_FromSeeds(R.kept.data(), R.nkept);
-        } else {
-            if (k == (size_t) -1 || xout[k].path_len == 0) return;       // no alignment: nothing to report (m_Path empty)
-            DA.ClearAlign();
-            DA.m_ChainA = SrcA.m_DBChains[i]; DA.m_ProfileA = SrcA.m_DBProfiles[i];
-            DA.m_ChainB = SrcB.m_DBChains[j]; DA.m_ProfileB = SrcB.m_DBProfiles[j];
-            DA.m_SelfRevScoreA = SrcA.m_DBSelfRevScores[i]; DA.m_SelfRevScoreB = SrcB.m_DBSelfRevScores[j];
-            DA.SetFromAln(xout[k], xpaths + xout[k].path_off);
-        }
+        // status 2 (the start XDropHSP derives lies outside a chain: only possible for chains shorter than 8, where the
+        // reference's own extents wrap around) counts as "no alignment"
+        if (k == (size_t) -1 || xstatus[k] != 1 || xout[k].path_len == 0) return;       // nothing to report (m_Path empty)
+        DA.ClearAlign();
+        DA.m_ChainA = SrcA.m_DBChains[i]; DA.m_ProfileA = SrcA.m_DBProfiles[i];
+        DA.m_ChainB = SrcB.m_DBChains[j]; DA.m_ProfileB = SrcB.m_DBProfiles[j];
+        DA.m_SelfRevScoreA = SrcA.m_DBSelfRevScores[i]; DA.m_SelfRevScoreB = SrcB.m_DBSelfRevScores[j];
+        DA.SetFromAln(xout[k], xpaths + xout[k].path_off);
         if (OnHitOfWorker) { (*OnHitOfWorker)(DA, i, j, worker); return; }
         std::lock_guard<std::mutex> g(lock);
         OnHit(DA, i, j);

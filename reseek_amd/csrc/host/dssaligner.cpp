@@ -452,192 +452,52 @@ void MuKmerFilter::ChainHSPs()
 }
 
 // ---------------------------------------------------------------------------------------------
-// gapped float X-drop (xdropfwd.cpp:71-390, xdropbwd.cpp:28, mergefwdback.cpp:6, xdrophsp.cpp:42)
+// Long-chain pair, per-pair form (AlignMKF dssaligner.cpp:1387, XDropHSP xdrophsp.cpp:42).  The gapped X-drop
+// extensions exist on the device only (k_xdrop.hip): a single pair is a batch of one through the same entry points the
+// search uses (rsk_mkf_align_pairs / rsk_xdrop_pairs); the host keeps the seeding + chaining of MuKmerFilter.
 // ---------------------------------------------------------------------------------------------
 namespace {
-struct XDropMem {
-    // Trace cells are generation-stamped (stamp << 8 | bits): a cell not written during the current call reads as 0,
-    // exactly as with a freshly zeroed matrix, without clearing (la+8)*(lb+8) bytes per call (that memset was the
-    // whole cost of the long-chain path when many pairs reach the gapped X-drop).
-    uint LA = 0, LB = 0, Cols = 0;
-    std::vector<uint16_t> TB;
-    uint16_t Gen = 0;
-    std::vector<float> M, D;
-    void Alloc(uint la, uint lb)
+void rsk_ok(int rc, const char *what)
+{
+    if (rc != RSK_OK) throw std::runtime_error(std::string(what) + ": " + rsk_last_error());
+}
+
+// the two chains of the aligner's current pair as one-chain device sets
+struct PairSets {
+    rsk_db *a = nullptr, *b = nullptr;
+    PairSets(rsk_ctx *ctx, const DSSAligner &DA)
     {
-        LA = la; LB = lb; Cols = lb + 8;
-        const size_t need = (size_t) (la + 8) * Cols;
-        if (need > TB.size()) { TB.assign(need + need / 4, 0); Gen = 0; }
-        if (++Gen == 256) { std::fill(TB.begin(), TB.end(), (uint16_t) 0); Gen = 1; }
-        M.assign(lb + 9, 0.0f);
-        D.assign(lb + 9, 0.0f);
+        a = make(ctx, *DA.m_ChainA, *DA.m_ProfileA, DA.m_MuLettersA, DA.m_SelfRevScoreA);
+        try { b = make(ctx, *DA.m_ChainB, *DA.m_ProfileB, DA.m_MuLettersB, DA.m_SelfRevScoreB); }
+        catch (...) { rsk_db_destroy(a); throw; }
     }
-    void set_tb(uint i, uint j, byte v) { TB[(size_t) i * Cols + j] = (uint16_t) ((Gen << 8) | v); }
-    byte tb(uint i, uint j) const
+    ~PairSets() { rsk_db_destroy(a); rsk_db_destroy(b); }
+    PairSets(const PairSets &) = delete;
+    PairSets &operator=(const PairSets &) = delete;
+    static rsk_db *make(rsk_ctx *ctx, const PDBChain &C, const std::vector<std::vector<byte> > &Prof, const std::vector<byte> *Mu, float SelfRev)
     {
-        const uint16_t c = TB[(size_t) i * Cols + j];
-        return (c >> 8) == Gen ? (byte) (c & 0xFF) : (byte) 0;
+        const uint32_t L = C.GetSeqLength();
+        std::vector<uint8_t> flat((size_t) L * RSK_NFEATURES);
+        for (uint f = 0; f < RSK_NFEATURES; ++f) memcpy(&flat[(size_t) f * L], Prof[f].data(), L);
+        rsk_db *db = nullptr;
+        rsk_ok(rsk_db_create(ctx, 1, &L, Mu ? Mu->data() : nullptr, flat.data(), C.m_Xs.data(), C.m_Ys.data(), C.m_Zs.data(), &SelfRev, &db), "rsk_db_create");
+        return db;
     }
-    float *Mrow() { return M.data() + 1; }     // Mrow[-1] is valid
-    float *Drow() { return D.data() + 1; }
 };
 
-// Sub(PosA, PosB): substitution score of absolute positions
-template <class SubFn>
-float XDropFwd(XDropMem &Mem, float X, float Open, float Ext, SubFn Sub, uint LoA, uint aLA, uint LoB, uint aLB, uint *ptrSegLoA,
-               uint *ptrSegLoB, std::string &Path)
+// mergefwdback.cpp:6: the backward path ends at (BwdHiA, BwdHiB) = start - 1, the forward path begins at the start
+void JoinExtensions(uint FwdLoA, uint FwdLoB, const std::string &FwdPath, uint BwdHiA, uint BwdHiB, const std::string &BwdPath, uint &LoA, uint &LoB,
+                    uint &HiA, uint &HiB, std::string &Path)
 {
-    *ptrSegLoA = UINT_MAX;
-    *ptrSegLoB = UINT_MAX;
-    const uint LA = aLA - LoA, LB = aLB - LoB;
-    Path.clear();
-    if (LA == 1 || LB == 1) {
-        const float Score = Sub(LoA, LoB);
-        if (Score > 0) Path.push_back('M');
-        return Score;
-    }
-    const float AbsOpen = -Open, AbsExt = -Ext;
-    Mem.Alloc(LA + 1, LB + 1);
-    float *Mrow = Mem.Mrow(), *Drow = Mem.Drow();
-    Mrow[-1] = MINUS_INFINITY;
-    Drow[0] = MINUS_INFINITY;
-    Drow[1] = MINUS_INFINITY;
-    float BestScore = 0;
-    uint Besti = 0, Bestj = 0;
-    uint prev_jlo = 0, prev_jhi = 0, jlo = 1, jhi = 1;
-    float M0 = BestScore;
-    for (uint i = 1; i <= LA; ++i) {
-        if (jlo == prev_jlo) { Mrow[jlo - 1] = MINUS_INFINITY; Drow[jlo] = MINUS_INFINITY; }
-        uint endj = std::min(prev_jhi + 1, LB);
-        for (uint j = endj + 1; j <= std::min(jhi + 1, LB); ++j) { Mrow[j - 1] = MINUS_INFINITY; Drow[j] = MINUS_INFINITY; }
-        uint next_jlo = UINT_MAX, next_jhi = UINT_MAX;
-        float I0 = MINUS_INFINITY;
-        for (uint j = jlo; j <= jhi; ++j) {
-            byte TraceBits = 0;
-            const float SavedM0 = M0;
-            // MATCH
-            float xM = M0;
-            if (Drow[j] > xM) { xM = Drow[j]; TraceBits = TRACEBITS_DM; }
-            if (I0 > xM) { xM = I0; TraceBits = TRACEBITS_IM; }
-            M0 = Mrow[j];
-            float s = Sub(LoA + i - 1, LoB + j - 1);
-            s += xM;
-            Mrow[j] = s;
-            float h = s - BestScore + X;
-            if (h > 0) { next_jlo = std::min(next_jlo, j + 1); next_jhi = j + 1; }
-            if (h > AbsOpen) next_jlo = std::min(next_jlo, j);
-            if (h > AbsExt && j == jhi && jhi + 1 < LB) {        // match-insert may extend the current row
-                ++jhi;
-                uint new_endj = std::max(std::min(jhi + 1, LB), endj);
-                for (uint j2 = endj + 1; j2 <= new_endj; ++j2) {
-                    if (j2 - 1 > j) Mrow[j2 - 1] = MINUS_INFINITY;
-                    Drow[j2] = MINUS_INFINITY;
-                }
-                endj = new_endj;
-            }
-            if (s >= BestScore) { BestScore = s; Besti = i; Bestj = j; }
-            // DELETE
-            if (j != jlo) {
-                const float md = SavedM0 + Open;
-                Drow[j] += Ext;
-                if (md >= Drow[j]) { Drow[j] = md; TraceBits |= TRACEBITS_MD; }
-                const float hd = Drow[j] - BestScore + X;
-                if (hd > 0) { next_jlo = std::min(next_jlo, j - 1); next_jhi = std::max(next_jhi, j - 1); }
-            }
-            // INSERT
-            {
-                const float mi = SavedM0 + Open;
-                I0 += Ext;
-                if (mi >= I0) { I0 = mi; TraceBits |= TRACEBITS_MI; }
-                const float hi = I0 - BestScore + X;
-                if (hi > 0) { next_jlo = std::min(next_jlo, j + 1); next_jhi = std::max(next_jhi, j + 1); }
-                if (hi > AbsExt && j == jhi && jhi + 1 < LB) {
-                    ++jhi;
-                    uint new_endj = std::max(std::min(jhi + 1, LB), endj);
-                    for (uint j2 = endj + 1; j2 <= new_endj; ++j2) { Mrow[j2 - 1] = MINUS_INFINITY; Drow[j2] = MINUS_INFINITY; }
-                    endj = new_endj;
-                }
-            }
-            Mem.set_tb(i, j, TraceBits);
-        }
-        if (jhi < LB) {                                             // end of Drow[]
-            const uint jhi1 = jhi + 1;
-            Mem.set_tb(i, jhi1, 0);
-            const float md = M0 + Open;
-            Drow[jhi1] += Ext;
-            if (md >= Drow[jhi1]) { Drow[jhi1] = md; Mem.set_tb(i, jhi1, TRACEBITS_MD); }
-        }
-        if (next_jlo == UINT_MAX) break;
-        prev_jlo = jlo; prev_jhi = jhi;
-        jlo = next_jlo; jhi = next_jhi;
-        if (jlo > LB) jlo = LB;
-        if (jhi > LB) jhi = LB;
-        if (jlo == prev_jlo) { M0 = MINUS_INFINITY; Drow[jlo] = MINUS_INFINITY; }
-        else M0 = Mrow[jlo - 1];
-    }
-    if (BestScore <= 0.0f) return 0.0f;
-    // traceback (xdropfwd.cpp:10-67): stops when the first row or column is reached
-    {
-        uint i = Besti, j = Bestj;
-        char State = 'M';
-        for (;;) {
-            Path += State;
-            if (i == 1 || j == 1) break;
-            char Next;
-            if (State == 'M') {
-                const byte c = Mem.tb(i, j);
-                Next = (c & TRACEBITS_DM) ? 'D' : (c & TRACEBITS_IM) ? 'I' : 'M';
-                --i; --j;
-            } else if (State == 'D') {
-                Next = (Mem.tb(i, j + 1) & TRACEBITS_MD) ? 'M' : 'D';
-                --i;
-            } else {
-                Next = (Mem.tb(i + 1, j) & TRACEBITS_MI) ? 'M' : 'I';
-                --j;
-            }
-            State = Next;
-        }
-        std::reverse(Path.begin(), Path.end());
-    }
-    uint nM, nD, nI;
-    GetPathCounts(Path, nM, nD, nI);
-    *ptrSegLoA = LoA + Besti - nM - nD;
-    *ptrSegLoB = LoB + Bestj - nM - nI;
-    return BestScore;
-}
-
-template <class SubFn>
-float XDropBwd(XDropMem &Mem, float X, float Open, float Ext, SubFn Sub, uint HiA, uint, uint HiB, uint, uint *ptrSegLoA, uint *ptrSegLoB,
-               std::string &Path)
-{
-    *ptrSegLoA = UINT_MAX;
-    *ptrSegLoB = UINT_MAX;
-    const uint RLA = HiA + 1, RLB = HiB + 1;
-    auto RevSub = [&](uint RevPosA, uint RevPosB) { return Sub(RLA - RevPosA - 1, RLB - RevPosB - 1); };
-    uint SegLoA, SegLoB;
-    const float Score = XDropFwd(Mem, X, Open, Ext, RevSub, 0, HiA + 1, 0, HiB + 1, &SegLoA, &SegLoB, Path);
-    std::reverse(Path.begin(), Path.end());
-    return Score;
-}
-
-void MergeFwdBwd(uint, uint, uint FwdLoA, uint FwdLoB, const std::string &FwdPath, uint BwdHiA, uint BwdHiB, const std::string &BwdPath,
-                 uint &LoA, uint &LoB, uint &HiA, uint &HiB, std::string &Path)
-{
-    if (FwdPath.empty()) { HiA = BwdHiA; HiB = BwdHiB; }
-    else {
-        uint M, D, I;
-        GetPathCounts(FwdPath, M, D, I);
-        HiA = FwdLoA + (M + D) - 1;
-        HiB = FwdLoB + (M + I) - 1;
-    }
-    if (BwdPath.empty()) { LoA = FwdLoA; LoB = FwdLoB; }
-    else {
-        uint M, D, I;
-        GetPathCounts(BwdPath, M, D, I);
-        LoA = BwdHiA + 1 - (M + D);
-        LoB = BwdHiB + 1 - (M + I);
-    }
-    Path = BwdPath + FwdPath;
+    uint m, d, i;
+    GetPathCounts(BwdPath, m, d, i);
+    LoA = BwdPath.empty() ? FwdLoA : BwdHiA + 1 - (m + d);
+    LoB = BwdPath.empty() ? FwdLoB : BwdHiB + 1 - (m + i);
+    GetPathCounts(FwdPath, m, d, i);
+    HiA = FwdPath.empty() ? BwdHiA : FwdLoA + (m + d) - 1;
+    HiB = FwdPath.empty() ? BwdHiB : FwdLoB + (m + i) - 1;
+    Path = BwdPath;
+    Path += FwdPath;
 }
 }   // namespace
 
@@ -659,44 +519,39 @@ float DSSAligner::GetMegaHSPScore(uint Lo_i, uint Lo_j, uint Len)
     return Total;
 }
 
+// xdrophsp.cpp:42: start = the best 8-mer of the HSP (its middle if it has none), both gapped extensions from there
+// (one-pair batch on the device), total < 10 => no alignment, else the joined path
 float DSSAligner::XDropHSP(uint Loi_in, uint Loj_in, uint Len, uint &Loi_out, uint &Loj_out, uint &Hii_out, uint &Hij_out)
 {
     Loi_out = Loj_out = Hii_out = Hij_out = UINT_MAX;
-    const float Open = m_Params->m_GapOpen, Ext = m_Params->m_GapExt, X = float(m_Params->m_MKF_X2);
+    m_XDropPath.clear();
     const uint LA = m_ChainA->GetSeqLength(), LB = m_ChainB->GetSeqLength();
-    uint LoA = Loi_in + Len / 2, LoB = Loj_in + Len / 2;
-    const uint K = 8;                                            // highest-scoring 8-mer of the HSP
-    std::vector<float> v(Len);
-    for (uint Col = 0; Col < Len; ++Col) v[Col] = SubstScore(Loi_in + Col, Loj_in + Col);
-    float BestMerScore = 0;
-    for (uint MerStart = 0; MerStart + K <= Len; ++MerStart) {
-        float MerScore = 0;
-        for (uint k = 0; k < K; ++k) MerScore += v[MerStart + k];
-        if (MerScore > BestMerScore) { BestMerScore = MerScore; LoA = Loi_in + MerStart; LoB = Loj_in + MerStart; }
+    const uint K = 8;
+    uint StartA = Loi_in + Len / 2, StartB = Loj_in + Len / 2;
+    std::vector<float> Col(Len);
+    for (uint c = 0; c < Len; ++c) Col[c] = SubstScore(Loi_in + c, Loj_in + c);
+    float BestWindow = 0;
+    for (uint w = 0; w + K <= Len; ++w) {
+        float Window = 0;
+        for (uint k = 0; k < K; ++k) Window += Col[w + k];       // every window summed afresh, in column order
+        if (Window > BestWindow) { BestWindow = Window; StartA = Loi_in + w; StartB = Loj_in + w; }
     }
-    if (std::min(LoA, LoB) < K / 2) { LoA += K / 2; LoB += K / 2; }
-    std::string FwdPath, BwdPath;
-    float ScoreFwd, ScoreBwd;
-    if (m_XDropMode == 1) {                                      // request only: the extensions run in a GPU batch
-        m_XDropReqValid = true;
-        m_XDropReqLoA = LoA; m_XDropReqLoB = LoB;
-        m_XDropPath.clear();
-        return 0;
-    }
-    if (m_XDropMode == 2) {
-        if (LoA != m_XDropReqLoA || LoB != m_XDropReqLoB) throw std::runtime_error("XDropHSP: GPU extensions belong to another start");
-        ScoreFwd = m_XDropExtScoreFwd; ScoreBwd = m_XDropExtScoreBwd;
-        FwdPath = m_XDropExtFwdPath; BwdPath = m_XDropExtBwdPath;
-    } else {
-        static thread_local XDropMem Mem;
-        auto Sub = [this](uint a, uint b) { return SubstScore(a, b); };
-        uint s1, s2;
-        ScoreFwd = XDropFwd(Mem, X, Open, Ext, Sub, LoA, LA, LoB, LB, &s1, &s2, FwdPath);
-        ScoreBwd = XDropBwd(Mem, X, Open, Ext, Sub, LoA - 1, LA, LoB - 1, LB, &s1, &s2, BwdPath);
-    }
+    if (std::min(StartA, StartB) < K / 2) { StartA += K / 2; StartB += K / 2; }
+    if (StartA >= LA || StartB >= LB) return 0;                  // (the reference's extents would wrap around)
+    if (!m_Ctx) m_Ctx = DefaultCtx();
+    PairSets Sets(m_Ctx, *this);
+    const uint32_t zero = 0, lo_a = StartA, lo_b = StartB;
+    float ScoreFwd = 0, ScoreBwd = 0;
+    std::vector<char> buf((size_t) LA + LB + 8);
+    uint64_t fo = 0, bo = 0;
+    uint32_t fl = 0, bl = 0;
+    rsk_ok(rsk_xdrop_pairs(m_Ctx, Sets.a, Sets.b, &zero, &zero, &lo_a, &lo_b, 1, float(m_Params->m_MKF_X2), m_Params->m_GapOpen, m_Params->m_GapExt,
+                           &ScoreFwd, &ScoreBwd, buf.data(), buf.size(), &fo, &fl, &bo, &bl),
+           "rsk_xdrop_pairs");
     const float TotalScore = ScoreFwd + ScoreBwd;
-    if (TotalScore < 10) { m_XDropPath.clear(); return 0; }
-    MergeFwdBwd(LA, LB, LoA, LoB, FwdPath, LoA - 1, LoB - 1, BwdPath, Loi_out, Loj_out, Hii_out, Hij_out, m_XDropPath);
+    if (TotalScore < 10) return 0;
+    JoinExtensions(StartA, StartB, std::string(buf.data() + fo, fl), StartA - 1, StartB - 1, std::string(buf.data() + bo, bl), Loi_out, Loj_out, Hii_out,
+                   Hij_out, m_XDropPath);
     return TotalScore;
 }
 
@@ -728,39 +583,29 @@ void DSSAligner::AlignMKF_FromSeeds(const int32_t *Kept4, uint Count)
     PostAlignMKF();
 }
 
-// RSK_TRACE: nanoseconds spent in the parts of the host MKF stage, summed over threads (reported by RunMKFPairs)
-std::atomic<uint64_t> g_MKFNsMega{0}, g_MKFNsXDrop{0}, g_MKFNsStats{0};
-static inline uint64_t NowNs() { return (uint64_t) std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-
+// dssaligner.cpp:1395: the chained HSPs of the current pair -> mega-HSP gate, XDropHSP, statistics: a batch of one
+// through rsk_mkf_align_pairs (k_mkf_start / k_xdrop_wave / k_mkf_merge / k_lddt)
 void DSSAligner::PostAlignMKF()
 {
-    m_XDropReqValid = m_XDropMode == 2 ? m_XDropReqValid : false;
     if (m_MKF.m_BestChainScore <= 0) return;
-    const uint64_t t0 = NowNs();
-    float MegaHSPTotal = 0, BestMegaScore = 0;
-    uint BestMegaIdx = 0;
-    const uint M = (uint) m_MKF.m_ChainHSPLois.size();
-    for (uint Idx = 0; Idx < M; ++Idx) {
-        const float MegaScore = GetMegaHSPScore((uint) m_MKF.m_ChainHSPLois[Idx], (uint) m_MKF.m_ChainHSPLojs[Idx], (uint) m_MKF.m_ChainHSPLens[Idx]);
-        if (MegaScore > BestMegaScore) { BestMegaScore = MegaScore; BestMegaIdx = Idx; }
-        MegaHSPTotal += MegaScore;
-    }
-    const uint64_t t1 = NowNs();
-    g_MKFNsMega += t1 - t0;
-    if (MegaHSPTotal < m_Params->m_MKF_MinMegaHSPScore) return;
-    m_XDropScore = XDropHSP((uint) m_MKF.m_ChainHSPLois[BestMegaIdx], (uint) m_MKF.m_ChainHSPLojs[BestMegaIdx],
-                            (uint) m_MKF.m_ChainHSPLens[BestMegaIdx], m_LoA, m_LoB, m_HiA, m_HiB);
-    const uint64_t t2 = NowNs();
-    g_MKFNsXDrop += t2 - t1;
-    if (m_XDropMode == 1) return;                                // start recorded, nothing aligned yet
-    m_AlnFwdScore = m_XDropScore;
-    m_Path = m_XDropPath;
-    uint nM, nD, nI;
-    GetPathCounts(m_Path, nM, nD, nI);
-    m_HiA = m_LoA + nM + nD - 1;
-    m_HiB = m_LoB + nM + nI - 1;
-    CalcEvalue();
-    g_MKFNsStats += NowNs() - t2;
+    const size_t M = m_MKF.m_ChainHSPLois.size();
+    if (M == 0) return;
+    if (!m_Ctx) m_Ctx = DefaultCtx();
+    PairSets Sets(m_Ctx, *this);
+    std::vector<int32_t> lo_a(m_MKF.m_ChainHSPLois.begin(), m_MKF.m_ChainHSPLois.end()), lo_b(m_MKF.m_ChainHSPLojs.begin(), m_MKF.m_ChainHSPLojs.end()),
+        len(m_MKF.m_ChainHSPLens.begin(), m_MKF.m_ChainHSPLens.end());
+    const uint32_t zero = 0, first[2] = { 0, (uint32_t) M };
+    rsk_aln out;
+    uint8_t status = 0;
+    std::vector<char> paths((size_t) m_ChainA->GetSeqLength() + m_ChainB->GetSeqLength() + 24);
+    rsk_ok(rsk_mkf_align_pairs(m_Ctx, Sets.a, Sets.b, &zero, &zero, 1, first, lo_a.data(), lo_b.data(), len.data(), float(m_Params->m_MKF_X2),
+                               m_Params->m_GapOpen, m_Params->m_GapExt, m_Params->m_MKF_MinMegaHSPScore, m_Params->m_MinFwdScore, &out, &status,
+                               paths.data(), paths.size()),
+           "rsk_mkf_align_pairs");
+    if (out.path_len == 0) return;
+    SetFromAln(out, paths.data() + out.path_off);
+    m_XDropScore = m_AlnFwdScore;
+    m_XDropPath = m_Path;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1057,52 +902,23 @@ void DSSAligner::ToTsv(FILE *f, bool Up, bool NoSelf)
 }   // namespace reseek_amd
 
 // ---------------------------------------------------------------------------------------------
-// C-ABI of the gapped X-drop building blocks on an explicit score matrix (the form the reference's own
-// self-test drives them in, test_xdrop.cpp:81-175).  Host code; no GPU involved.
+// C-ABI: MergeFwdBwd (mergefwdback.cpp:6) on explicit paths, the companion of rsk_xdrop_fwd / rsk_xdrop_bwd (k_xdrop.hip)
 // ---------------------------------------------------------------------------------------------
 void rsk_set_error(const char *fmt, ...);
-
-namespace {
-int put_path(const std::string &Path, char *path, size_t cap, uint32_t *len, const char *who)
-{
-    if (len) *len = (uint32_t) Path.size();
-    if (Path.size() + 1 > cap || !path) { rsk_set_error("%s: path buffer too small (%zu needed)", who, Path.size() + 1); return RSK_E_INVALID; }
-    memcpy(path, Path.c_str(), Path.size() + 1);
-    return RSK_OK;
-}
-}   // namespace
-
-extern "C" int rsk_xdrop_fwd(const float *S, uint32_t LA, uint32_t LB, float X, float open, float ext, uint32_t lo_a, uint32_t lo_b,
-                             float *score, char *path, size_t path_cap, uint32_t *path_len)
-{
-    if (!S || !score || lo_a > LA || lo_b > LB) { rsk_set_error("rsk_xdrop_fwd: invalid argument"); return RSK_E_INVALID; }
-    reseek_amd::XDropMem Mem;
-    std::string Path;
-    unsigned s1, s2;
-    *score = reseek_amd::XDropFwd(Mem, X, open, ext, [&](unsigned a, unsigned b) { return S[(size_t) a * LB + b]; }, lo_a, LA, lo_b, LB, &s1, &s2, Path);
-    return put_path(Path, path, path_cap, path_len, "rsk_xdrop_fwd");
-}
-
-extern "C" int rsk_xdrop_bwd(const float *S, uint32_t LA, uint32_t LB, float X, float open, float ext, uint32_t hi_a, uint32_t hi_b,
-                             float *score, char *path, size_t path_cap, uint32_t *path_len)
-{
-    if (!S || !score || hi_a >= LA || hi_b >= LB) { rsk_set_error("rsk_xdrop_bwd: invalid argument"); return RSK_E_INVALID; }
-    reseek_amd::XDropMem Mem;
-    std::string Path;
-    unsigned s1, s2;
-    *score = reseek_amd::XDropBwd(Mem, X, open, ext, [&](unsigned a, unsigned b) { return S[(size_t) a * LB + b]; }, hi_a, LA, hi_b, LB, &s1, &s2, Path);
-    return put_path(Path, path, path_cap, path_len, "rsk_xdrop_bwd");
-}
 
 extern "C" int rsk_merge_fwd_bwd(uint32_t LA, uint32_t LB, uint32_t fwd_lo_a, uint32_t fwd_lo_b, const char *fwd_path, uint32_t bwd_hi_a,
                                  uint32_t bwd_hi_b, const char *bwd_path, uint32_t *lo_a, uint32_t *lo_b, uint32_t *hi_a, uint32_t *hi_b,
                                  char *path, size_t path_cap, uint32_t *path_len)
 {
+    (void) LA; (void) LB;
     if (!fwd_path || !bwd_path || !lo_a || !lo_b || !hi_a || !hi_b) { rsk_set_error("rsk_merge_fwd_bwd: NULL argument"); return RSK_E_INVALID; }
     if (!*fwd_path && !*bwd_path) { rsk_set_error("rsk_merge_fwd_bwd: both paths are empty (mergefwdback.cpp:11 asserts)"); return RSK_E_INVALID; }
-    std::string Path;
+    std::string Joined;
     unsigned la, lb, ha, hb;
-    reseek_amd::MergeFwdBwd(LA, LB, fwd_lo_a, fwd_lo_b, fwd_path, bwd_hi_a, bwd_hi_b, bwd_path, la, lb, ha, hb, Path);
+    reseek_amd::JoinExtensions(fwd_lo_a, fwd_lo_b, fwd_path, bwd_hi_a, bwd_hi_b, bwd_path, la, lb, ha, hb, Joined);
     *lo_a = la; *lo_b = lb; *hi_a = ha; *hi_b = hb;
-    return put_path(Path, path, path_cap, path_len, "rsk_merge_fwd_bwd");
+    if (path_len) *path_len = (uint32_t) Joined.size();
+    if (Joined.size() + 1 > path_cap || !path) { rsk_set_error("rsk_merge_fwd_bwd: path buffer too small (%zu needed)", Joined.size() + 1); return RSK_E_INVALID; }
+    memcpy(path, Joined.c_str(), Joined.size() + 1);
+    return RSK_OK;
 }

@@ -5,7 +5,7 @@
 // Mirrors (file:line relative to /root/reference/src):
 //   DSSParams   dssparams.h:27, presets dssparams.cpp:44-104, defaults namedparams.cpp:32-53
 //   DSSAligner  dssaligner.h:18   (SetQuery/SetTarget/AlignQueryTarget, result fields, ToTsv)
-//   MuKmerFilter mukmerfilter.h:10 (long-chain seed-and-extend path, host resident for now)
+//   MuKmerFilter mukmerfilter.h:10 (seeding + chaining of one long-chain pair; the search seeds in batches on the device)
 //   DBSearcher  dbsearcher.h:14   (LoadDB/Setup/RunSelf/RunQuery/BaseOnAln/OnAln)
 // The reference reads command-line options through global opt(x) macros (myutils.h:365-372); here
 // they are one explicit SearchOptions object.
@@ -277,14 +277,6 @@ public:
     MuKmerFilter m_MKF;
     float m_XDropScore = 0;
     std::string m_XDropPath;
-    // Where the two gapped extensions of XDropHSP run: 0 = here (host DP); 1 = nowhere, only record their start
-    // (m_XDropReq*) and stop -- RunMKFPairs collects the requests of a batch for rsk_xdrop_pairs; 2 = take the
-    // extensions computed on the GPU (m_XDropExt*) for the recorded start.
-    int m_XDropMode = 0;
-    bool m_XDropReqValid = false;
-    uint m_XDropReqLoA = 0, m_XDropReqLoB = 0;
-    float m_XDropExtScoreFwd = 0, m_XDropExtScoreBwd = 0;
-    std::string m_XDropExtFwdPath, m_XDropExtBwdPath;
 
     std::string m_Path;
     uint m_LoA = UINT_MAX, m_LoB = UINT_MAX, m_HiA = UINT_MAX, m_HiB = UINT_MAX;
@@ -317,13 +309,13 @@ public:
     void AlignBags(const ChainBag &BagA, const ChainBag &BagB);          // chainbag.cpp:44 (one pair; batch of 1 on the GPU)
     void AlignBagsMKF(const ChainBag &BagA, const ChainBag &BagB);       // chainbag.cpp:24
     void AlignPairOnGpu();                              // MuFilter (:619) + Align_NoAccel (:929) + CalcEvalue of the current pair, batch of one
-    void AlignMKF();                                    // dssaligner.cpp:1387
+    void AlignMKF();                                    // dssaligner.cpp:1387 (seeds + chain here, the rest a device batch of one)
     void AlignMKF_FromSeeds(const int32_t *Kept4, uint Count);   // same, seeding stage already done on the GPU
-    void PostAlignMKF();                                // dssaligner.cpp:1395
+    void PostAlignMKF();                                // dssaligner.cpp:1395 (rsk_mkf_align_pairs, one pair)
     float GetMegaHSPScore(uint Lo_i, uint Lo_j, uint Len);   // dssaligner.cpp:488
     float SubstScore(uint PosA, uint PosB);             // xdrophsp.cpp:8
     float XDropHSP(uint Loi_in, uint Loj_in, uint Len, uint &Loi_out, uint &Loj_out, uint &Hii_out, uint &Hij_out);
-    void CalcEvalue();                                  // dssaligner.cpp:852 (host form, used by the MKF path)
+    void CalcEvalue();                                  // dssaligner.cpp:852 (host form of the statistics the batches compute on the device)
     float GetLDDT() const;                              // dssaligner.cpp:1313
     void AppendTsv(std::string &out, bool Up);               // the hit line of ToTsv, appended to a caller buffer
     void AppendUserField(std::string &out, USERFIELD UF, bool Up);

@@ -6,19 +6,17 @@
 // as XDropHSP (xdrophsp.cpp:42) calls them for one seeded pair: forward from (LoA, LoB) to the chain ends,
 // backward from (LoA - 1, LoB - 1) to the chain starts.
 //
-// The DP is sequential along a row (the insert state I0 and the running row bounds depend on the cell to
-// the left) and its row range depends on the previous row, so one extension has no regular parallelism.
-// There are as many independent extensions as seeded pairs x 2 though: ONE THREAD PER EXTENSION, rows and
-// trace cells in HBM scratch (the trace of a pair can reach LA x LB bytes; 288 GB of HBM take tens of
-// thousands of them at once).  Every float operation is the reference's, in its order (-ffp-contract=off),
-// so scores and paths are bit-identical; tests/test_gpu_xdrop.py compares with the host mirror of the same
-// functions, which the reference's own -test_xdrop vectors pin (tests/test_xdrop_kat.py).
+// ONE WAVE PER EXTENSION (k_xdrop_wave).  The reference's code reads as sequential along a row (the insert state I0 and
+// the running row bounds change from cell to cell), but every value of row i depends on row i - 1 only, so the band
+// columns of a row are computed 64 at a time with exact scans (below).  Row state lives in an LDS ring, trace bytes go
+// to HBM scratch (the trace of a pair can reach LA x LB bytes; 288 GB of HBM take tens of thousands of them at once).
+// Every float operation is the reference's, in its order (-ffp-contract=off), so scores and paths are bit-identical:
+// tests/test_gpu_xdrop.py runs the kernel on the reference's own -test_xdrop vectors (explicit score matrices, through
+// rsk_xdrop_fwd / rsk_xdrop_bwd), on the reference's per-stage fixtures of real long-chain pairs, and against the CPU
+// oracle's restatement (oracle/rsk_oracle.c rsko_xdrop_*) on seeded pairs with the length tail.
+// This is the only implementation of the gapped extensions in the product: there is no host or thread-per-extension form.
 //
-// Algorithmic bytes per extension: 16 B of table offsets per row + 16 B per cell (column offsets), 16 B of
-// row state and 1 B of trace per cell.  Latency-bound scalar-style code by nature; what makes it fast is
-// the number of extensions in flight, not the kernel (roofline: none that is meaningful).
-#include <hip/hip_runtime.h>
-
+// Algorithmic bytes per extension: 16 B of table offsets per row + 16 B per cell (column offsets), 1 B of trace per cell.
 #include <hipcub/hipcub.hpp>
 #include <algorithm>
 #include <chrono>
@@ -76,228 +74,29 @@ struct xd_args {
     // the worst split) and the two extensions of a pair divide it by the start they find there
     int per_pair;                    // row_off / tb_off / path_off are indexed by request; the backward extension follows the forward one
     const uint8_t *valid;            // per request (optional): 0 = no extension wanted
+    // EXPLICIT form (rsk_xdrop_fwd / rsk_xdrop_bwd): scores from smx[posA * smx_ld + posB]; a_len / b_len hold the matrix
+    // shape, ia = ib = {0}; only the extension of direction only_dir (0 forward, 1 backward) is computed
+    const float *smx;
+    uint32_t smx_ld;
+    int only_dir;                    // -1 = both
 };
 
-// One extension = XDropFwd(Mem, X, Open, Ext, Sub, LoA, aLA, LoB, aLB): thread e = 2 * request + direction.
-// direction 0 (forward):  local (i, j) >= 1 is the residue pair (LoA + i - 1, LoB + j - 1), extents LA - LoA, LB - LoB;
-// direction 1 (backward): XDropBwd = the same DP on the reversed prefixes of lengths RLA = LoA, RLB = LoB
-//                         (HiA = LoA - 1): local (i, j) is the residue pair (RLA - i, RLB - j); its path is reversed.
-__global__ __launch_bounds__(256) void k_xdrop(xd_args a)
-{
-    __shared__ float tab[XD_TABLE_FLOATS];
-    for (int i = threadIdx.x; i < XD_TABLE_FLOATS; i += blockDim.x) tab[i] = c_xd_tables.t[i];
-    __syncthreads();
-    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= 2 * a.nreq) return;
-    const uint32_t req = e >> 1, dir = e & 1;
-    if (a.valid && !a.valid[req]) { a.path_start[e] = 0; a.path_len[e] = 0; a.score[e] = 0.0f; return; }
-    const uint32_t A = a.ia[req], B = a.ib[req];
-    const uint32_t LoA = a.lo_a[req], LoB = a.lo_b[req];
-    const uint32_t LA = dir ? LoA : a.a_len[A] - LoA, LB = dir ? LoB : a.b_len[B] - LoB;      // extents of this extension
-    uint64_t row_o, tb_o, path_o;
-    if (a.per_pair) {
-        row_o = a.row_off[req]; tb_o = a.tb_off[req]; path_o = a.path_off[req];
-        if (dir) {                                                                              // behind the forward extension's share
-            const uint64_t FA = a.a_len[A] - LoA, FB = a.b_len[B] - LoB;
-            row_o += 2 * (FB + 9);
-            tb_o += ((FA + 9) * (FB + 9) + 15) & ~15ull;
-            path_o += FA + FB + 2;
-        }
-    } else { row_o = a.row_off[e]; tb_o = a.tb_off[e]; path_o = a.path_off[e]; }
-    const uint16_t *RA = a.a_ra + (size_t) a.a_off[A] * 8, *CB = a.b_cb + (size_t) a.b_off[B] * 8;
-    const char *tabb = (const char *) tab;
-    const uint32_t toffb[8] = { 0 * 4, 400 * 4, 656 * 4, 912 * 4, 1168 * 4, 1424 * 4, 1680 * 4, 1936 * 4 };
-    char *slot = a.paths + path_o;
-    const uint32_t cap = LA + LB + 2;
-    a.path_start[e] = 0;
-    a.path_len[e] = 0;
-    // residue of local row i / column j
-    auto posA = [&](uint32_t i) { return dir ? LoA - i : LoA + i - 1; };
-    auto posB = [&](uint32_t j) { return dir ? LoB - j : LoB + j - 1; };
-    uint32_t rowo[8];                 // table row offsets of the current row (bytes, table base included)
-    auto set_row = [&](uint32_t i) {
-        const uint4 w = *(const uint4 *) (RA + (size_t) posA(i) * 8);
-        const uint32_t ww[4] = { w.x, w.y, w.z, w.w };
-#pragma unroll
-        for (int f = 0; f < 8; ++f) rowo[f] = toffb[f] + ((f & 1) ? (ww[f >> 1] >> 16) : (ww[f >> 1] & 0xFFFFu));
-    };
-    auto sub = [&](uint32_t j) {      // SubstScore: Total = 0; Total += feature f, f = 0..7
-        const uint4 w = *(const uint4 *) (CB + (size_t) posB(j) * 8);
-        const uint32_t ww[4] = { w.x, w.y, w.z, w.w };
-        float Total = 0.0f;
-#pragma unroll
-        for (int f = 0; f < 8; ++f) Total += *(const float *) (tabb + rowo[f] + ((f & 1) ? (ww[f >> 1] >> 16) : (ww[f >> 1] & 0xFFFFu)));
-        return Total;
-    };
-    if (LA == 1 || LB == 1) {         // xdropfwd.cpp:84-92
-        set_row(1);
-        const float Score = sub(1);
-        if (Score > 0) { slot[0] = 'M'; a.path_len[e] = 1; }
-        a.score[e] = Score;
-        return;
-    }
-    const float Open = a.open, Ext = a.ext, X = a.X;
-    const float AbsOpen = -Open, AbsExt = -Ext;
-    // Row state: the reference's Mrow[] / Drow[] interleaved as MD[j] = {Mrow[j], Drow[j]}, so a cell is ONE 8-byte load
-    // and ONE 8-byte store (the kernel is bound by the rate of its scattered memory transactions).  The row extensions
-    // below write single components of other columns; when they hit the current column j they act on the pending values.
-    float2 *MD = (float2 *) (a.rows + row_o) + 1;               // MD[-1] is valid
-    uint8_t *TB = a.tb + tb_o;
-    const uint32_t Cols = LB + 1 + 8;                            // XDPMem::Alloc(LA + 1, LB + 1)
-    MD[-1].x = XD_MINUS_INF;
-    MD[0].y = XD_MINUS_INF;
-    MD[1].y = XD_MINUS_INF;
-    float BestScore = 0;
-    uint32_t Besti = 0, Bestj = 0;
-    uint32_t prev_jlo = 0, prev_jhi = 0, jlo = 1, jhi = 1;
-    float M0 = BestScore;
-    for (uint32_t i = 1; i <= LA; ++i) {
-        if (jlo == prev_jlo) { MD[jlo - 1].x = XD_MINUS_INF; MD[jlo].y = XD_MINUS_INF; }
-        uint32_t endj = min(prev_jhi + 1, LB);
-        for (uint32_t j = endj + 1; j <= min(jhi + 1, LB); ++j) { MD[j - 1].x = XD_MINUS_INF; MD[j].y = XD_MINUS_INF; }
-        uint32_t next_jlo = 0xFFFFFFFFu, next_jhi = 0xFFFFFFFFu;
-        float I0 = XD_MINUS_INF;
-        set_row(i);
-        // trace bytes of the row: four consecutive cells that start on a dword boundary go out as one store
-        uint32_t tb_acc = 0, tb_cnt = 0;
-        const size_t tb_row = (size_t) i * Cols;
-        auto tb_flush = [&](size_t next_addr) {                  // bytes [next_addr - tb_cnt, next_addr) are pending
-            for (uint32_t k = 0; k < tb_cnt; ++k) TB[next_addr - tb_cnt + k] = (uint8_t) (tb_acc >> (8 * k));
-            tb_cnt = 0; tb_acc = 0;
-        };
-        for (uint32_t j = jlo; j <= jhi; ++j) {
-            uint8_t TraceBits = 0;
-            const float SavedM0 = M0;
-            const float2 md0 = MD[j];
-            float m_new, d_cur = md0.y;
-            // MATCH
-            float xM = M0;
-            if (d_cur > xM) { xM = d_cur; TraceBits = XD_DM; }
-            if (I0 > xM) { xM = I0; TraceBits = XD_IM; }
-            M0 = md0.x;
-            float s = sub(j);
-            s += xM;
-            m_new = s;                                           // Mrow[j] = s
-            const float h = s - BestScore + X;
-            if (h > 0) { next_jlo = min(next_jlo, j + 1); next_jhi = j + 1; }
-            if (h > AbsOpen) next_jlo = min(next_jlo, j);
-            if (h > AbsExt && j == jhi && jhi + 1 < LB) {        // match-insert may extend the current row
-                ++jhi;
-                const uint32_t new_endj = max(min(jhi + 1, LB), endj);
-                for (uint32_t j2 = endj + 1; j2 <= new_endj; ++j2) {
-                    if (j2 - 1 > j) MD[j2 - 1].x = XD_MINUS_INF;
-                    if (j2 == j) d_cur = XD_MINUS_INF;           // Drow[j] of the current column: read again below
-                    else MD[j2].y = XD_MINUS_INF;
-                }
-                endj = new_endj;
-            }
-            if (s >= BestScore) { BestScore = s; Besti = i; Bestj = j; }
-            // DELETE
-            float d_new = d_cur;
-            if (j != jlo) {
-                const float md = SavedM0 + Open;
-                float d = d_cur;
-                d += Ext;
-                if (md >= d) { d = md; TraceBits |= XD_MD; }
-                d_new = d;                                       // Drow[j] = d
-                const float hd = d - BestScore + X;
-                if (hd > 0) { next_jlo = min(next_jlo, j - 1); next_jhi = max(next_jhi, j - 1); }
-            }
-            // INSERT
-            {
-                const float mi = SavedM0 + Open;
-                I0 += Ext;
-                if (mi >= I0) { I0 = mi; TraceBits |= XD_MI; }
-                const float hi = I0 - BestScore + X;
-                if (hi > 0) { next_jlo = min(next_jlo, j + 1); next_jhi = max(next_jhi, j + 1); }
-                if (hi > AbsExt && j == jhi && jhi + 1 < LB) {
-                    ++jhi;
-                    const uint32_t new_endj = max(min(jhi + 1, LB), endj);
-                    for (uint32_t j2 = endj + 1; j2 <= new_endj; ++j2) {
-                        if (j2 - 1 == j) m_new = XD_MINUS_INF;   // Mrow[j] of the current column, after its store
-                        else MD[j2 - 1].x = XD_MINUS_INF;
-                        if (j2 == j) d_new = XD_MINUS_INF;
-                        else MD[j2].y = XD_MINUS_INF;
-                    }
-                    endj = new_endj;
-                }
-            }
-            MD[j] = make_float2(m_new, d_new);
-            const size_t addr = tb_row + j;
-            const uint32_t off = (uint32_t) ((uintptr_t) (TB + addr) & 3);
-            if (off == tb_cnt) {                                  // continues (or starts, off == 0) an aligned run
-                tb_acc |= (uint32_t) TraceBits << (8 * off);
-                if (++tb_cnt == 4) { *(uint32_t *) (TB + addr - 3) = tb_acc; tb_cnt = 0; tb_acc = 0; }
-            } else {
-                tb_flush(addr);
-                TB[addr] = TraceBits;
-            }
-        }
-        tb_flush(tb_row + jhi + 1);
-        if (jhi < LB) {                                             // end of Drow[]
-            const uint32_t jhi1 = jhi + 1;
-            uint8_t t = 0;
-            const float md = M0 + Open;
-            float d = MD[jhi1].y;
-            d += Ext;
-            if (md >= d) { d = md; t = XD_MD; }
-            MD[jhi1].y = d;
-            TB[tb_row + jhi1] = t;
-        }
-        if (next_jlo == 0xFFFFFFFFu) break;
-        prev_jlo = jlo; prev_jhi = jhi;
-        jlo = next_jlo; jhi = next_jhi;
-        if (jlo > LB) jlo = LB;
-        if (jhi > LB) jhi = LB;
-        if (jlo == prev_jlo) { M0 = XD_MINUS_INF; MD[jlo].y = XD_MINUS_INF; }
-        else M0 = MD[jlo - 1].x;
-    }
-    if (BestScore <= 0.0f) { a.score[e] = 0.0f; return; }
-    // traceback (xdropfwd.cpp:10-67): stops when the first row or column is reached.  XDropFwd returns the
-    // walk reversed, XDropBwd reverses it once more: the forward extension writes from the end of its slot
-    // downwards (so that the slot reads in path order), the backward extension writes the walk as it goes.
-    uint32_t i = Besti, j = Bestj, n = 0;
-    char State = 'M';
-    for (;;) {
-        if (dir) slot[n] = State;
-        else slot[cap - 1 - n] = State;
-        ++n;
-        if (i == 1 || j == 1) break;
-        char Next;
-        if (State == 'M') {
-            const uint8_t c = TB[(size_t) i * Cols + j];
-            Next = (c & XD_DM) ? 'D' : (c & XD_IM) ? 'I' : 'M';
-            --i; --j;
-        } else if (State == 'D') {
-            Next = (TB[(size_t) i * Cols + j + 1] & XD_MD) ? 'M' : 'D';
-            --i;
-        } else {
-            Next = (TB[(size_t) (i + 1) * Cols + j] & XD_MI) ? 'M' : 'I';
-            --j;
-        }
-        State = Next;
-    }
-    a.path_start[e] = dir ? 0 : cap - n;
-    a.path_len[e] = n;
-    a.score[e] = BestScore;
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
-// k_xdrop_wave: the same extension with ONE WAVE per extension.  What the sequential formulation hides: every value of
-// row i depends on row i - 1 only -- Mrow[j] = Sub + max(M'[j-1], D'[j], I0), Drow[j] = max(M'[j-1] + Open, D'[j] + Ext),
-// and even the insert state I0 is a running max over the PREVIOUS row's M (I0 <- max(I0 + Ext, M'[j-1] + Open)).  So the
-// columns jlo .. jhi-1 of a row are computed 64 at a time, one per lane:
+// k_xdrop_wave: ONE WAVE per extension.  Every value of row i depends on row i - 1 only --
+// Mrow[j] = Sub + max(M'[j-1], D'[j], I0), Drow[j] = max(M'[j-1] + Open, D'[j] + Ext), and even the insert state I0 is a
+// running max over the PREVIOUS row's M (I0 <- max(I0 + Ext, M'[j-1] + Open)).  So the columns jlo .. jhi of a row are
+// computed 64 at a time, one per lane:
 //   * I0: a max-plus scan whose float additions must happen in the reference's order; f(x) = x + Ext is monotone, so
-//     max(f(a), f(b)) = f(max(a, b)) holds exactly and the chain is evaluated lane to lane with v_add + v_max on
-//     DPP wave_shr:1 operands (n steps for n columns; only this 2-instruction chain is serial);
+//     max(f(a), f(b)) = f(max(a, b)) holds exactly: a doubling scan whose step d applies f d times, add by add;
 //   * BestScore as seen by column j = max(BestScore, prefix max of the row's earlier cells) -- max is associative, the
-//     6-step shuffle scan is exact; the best cell is the LAST one that reaches the row maximum (the reference updates on >=);
+//     6-step DPP scan is exact; the best cell is the LAST one that reaches the row maximum (the reference updates on >=);
 //   * the band of the next row: next_jlo is a min over per-cell candidates; next_jhi is the fold of "assign j+1" (h > 0)
 //     and "max" (hd, hi) events in cell order, including the reference's UINT_MAX start value that max() cannot leave:
 //     the last assigning cell and the events after it decide.
-// The last column of the band (whose tests may extend the row, cell by cell) and everything after it run as the
-// sequential code, executed uniformly by the wave.  Row state and trace bytes are the same HBM arrays, accessed
-// coalesced.  Same results as k_xdrop bit for bit (tests/test_gpu_xdrop.py runs both).
+// The cells a row grows by (the last band column's tests may extend the row, cell by cell) run one at a time, executed
+// uniformly by the wave.  An extension whose band outgrows the LDS ring is run again on HBM rows (same code, RING = false).
+// EXPLICIT = true takes the substitution scores from a caller matrix instead of the profile tables (rsk_xdrop_fwd / _bwd:
+// the form the reference's own self-test drives XDropFwd / XDropBwd in, test_xdrop.cpp:81-175).
 #define XDW_WAVES 4
 #ifdef XDW_PROF
 // debug build only (tools/exp): wave-cycles per phase, rows, chunks, sequential cells, traceback steps
@@ -330,11 +129,11 @@ template <bool RING> struct xdw_rows {
 };
 
 // returns false iff RING and the band outgrew the ring (nothing final has been written then)
-template <bool RING>
+template <bool RING, bool EXPLICIT>
 __device__ __forceinline__ bool xdw_extend(const xd_args &a, const float *tab, float2 *ring, uint32_t e, uint32_t lane)
 {
     const uint32_t req = e >> 1, dir = e & 1;
-    if (a.valid && !a.valid[req]) { a.path_start[e] = 0; a.path_len[e] = 0; a.score[e] = 0.0f; return true; }
+    if ((a.valid && a.valid[req] != 1) || (a.only_dir >= 0 && (int) dir != a.only_dir)) { a.path_start[e] = 0; a.path_len[e] = 0; a.score[e] = 0.0f; return true; }
     const uint32_t A = a.ia[req], B = a.ib[req];
     const uint32_t LoA = a.lo_a[req], LoB = a.lo_b[req];
     const uint32_t LA = dir ? LoA : a.a_len[A] - LoA, LB = dir ? LoB : a.b_len[B] - LoB;      // extents of this extension
@@ -348,7 +147,7 @@ __device__ __forceinline__ bool xdw_extend(const xd_args &a, const float *tab, f
             path_o += FA + FB + 2;
         }
     } else { row_o = a.row_off[e]; tb_o = a.tb_off[e]; path_o = a.path_off[e]; }
-    const uint16_t *RA = a.a_ra + (size_t) a.a_off[A] * 8, *CB = a.b_cb + (size_t) a.b_off[B] * 8;
+    const uint16_t *RA = EXPLICIT ? nullptr : a.a_ra + (size_t) a.a_off[A] * 8, *CB = EXPLICIT ? nullptr : a.b_cb + (size_t) a.b_off[B] * 8;
     const char *tabb = (const char *) tab;
     const uint32_t toffb[8] = { 0 * 4, 400 * 4, 656 * 4, 912 * 4, 1168 * 4, 1424 * 4, 1680 * 4, 1936 * 4 };
     char *slot = a.paths + path_o;
@@ -358,16 +157,26 @@ __device__ __forceinline__ bool xdw_extend(const xd_args &a, const float *tab, f
     auto posA = [&](uint32_t i) { return dir ? LoA - i : LoA + i - 1; };
     auto posB = [&](uint32_t j) { return dir ? LoB - j : LoB + j - 1; };
     uint32_t rowo[8];
+    const float *srow = nullptr;      // EXPLICIT: the matrix row of the current DP row
     // The 16-byte profile records of the row (A side) and of the columns (B side) are requested one step ahead of their
-    // use: an extension is a chain of dependent steps, what it waits for is memory latency.
-    auto load_ra = [&](uint32_t i) { return *(const uint4 *) (RA + (size_t) posA(i) * 8); };
-    auto load_cb = [&](uint32_t j) { return *(const uint4 *) (CB + (size_t) posB(j) * 8); };
+    // use: an extension is a chain of dependent steps, what it waits for is memory latency.  (EXPLICIT: the "record" of a
+    // row is its matrix row index, the record of a column the score itself -- load_cb is only called for the current row.)
+    auto load_ra = [&](uint32_t i) {
+        if constexpr (EXPLICIT) return make_uint4(posA(i), 0, 0, 0);
+        return *(const uint4 *) (RA + (size_t) posA(i) * 8);
+    };
+    auto load_cb = [&](uint32_t j) {
+        if constexpr (EXPLICIT) return make_uint4(__builtin_bit_cast(uint32_t, srow[posB(j)]), 0, 0, 0);
+        return *(const uint4 *) (CB + (size_t) posB(j) * 8);
+    };
     auto set_row_w = [&](const uint4 w) {
+        if constexpr (EXPLICIT) { srow = a.smx + (size_t) w.x * a.smx_ld; return; }
         const uint32_t ww[4] = { w.x, w.y, w.z, w.w };
 #pragma unroll
         for (int f = 0; f < 8; ++f) rowo[f] = toffb[f] + ((f & 1) ? (ww[f >> 1] >> 16) : (ww[f >> 1] & 0xFFFFu));
     };
     auto sub_w = [&](const uint4 w) { // SubstScore: Total = 0; Total += feature f, f = 0..7
+        if constexpr (EXPLICIT) return __builtin_bit_cast(float, w.x);
         const uint32_t ww[4] = { w.x, w.y, w.z, w.w };
         float Total = 0.0f;
 #pragma unroll
@@ -669,26 +478,107 @@ __device__ __forceinline__ bool xdw_extend(const xd_args &a, const float *tab, f
 #undef MD
 }
 
+template <bool EXPLICIT>
 __global__ __launch_bounds__(64 * XDW_WAVES) void k_xdrop_wave(xd_args a)
 {
     __shared__ float tab[XD_TABLE_FLOATS];
     __shared__ float2 ring[XDW_WAVES][XDW_RING];
-    for (int i = threadIdx.x; i < XD_TABLE_FLOATS; i += blockDim.x) tab[i] = c_xd_tables.t[i];
-    __syncthreads();
+    if (!EXPLICIT) {
+        for (int i = threadIdx.x; i < XD_TABLE_FLOATS; i += blockDim.x) tab[i] = c_xd_tables.t[i];
+        __syncthreads();
+    }
     const uint32_t e = blockIdx.x * XDW_WAVES + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
     if (e >= 2 * a.nreq) return;
-    if (!xdw_extend<true>(a, tab, ring[threadIdx.x >> 6], e, lane)) xdw_extend<false>(a, tab, nullptr, e, lane);
+    if (!xdw_extend<true, EXPLICIT>(a, tab, ring[threadIdx.x >> 6], e, lane)) xdw_extend<false, EXPLICIT>(a, tab, nullptr, e, lane);
 }
 
-// launch of either form: RSK_XDROP_WAVE=0 selects the thread-per-extension kernel (tests run both)
 static void xd_launch(rsk_ctx *ctx, const xd_args &xa, size_t nreq)
 {
-    const char *ev = getenv("RSK_XDROP_WAVE");
-    if (!(ev && atoi(ev) == 0))
-        hipLaunchKernelGGL(k_xdrop_wave, dim3((unsigned) ((2 * nreq + XDW_WAVES - 1) / XDW_WAVES)), dim3(64 * XDW_WAVES), 0, ctx->stream, xa);
-    else
-        hipLaunchKernelGGL(k_xdrop, dim3((unsigned) ((2 * nreq + 255) / 256)), dim3(256), 0, ctx->stream, xa);
+    hipLaunchKernelGGL(k_xdrop_wave<false>, dim3((unsigned) ((2 * nreq + XDW_WAVES - 1) / XDW_WAVES)), dim3(64 * XDW_WAVES), 0, ctx->stream, xa);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// rsk_xdrop_fwd / rsk_xdrop_bwd: ONE extension on an explicit LA x LB score matrix -- the form the reference's own
+// self-test drives XDropFwd / XDropBwd in (test_xdrop.cpp:81-175), so its vectors pin this kernel directly.
+// ---------------------------------------------------------------------------------------------------------------------
+static int xd_explicit(rsk_ctx *ctx, const char *who, const float *S, uint32_t LA, uint32_t LB, float X, float open, float ext, uint32_t lo_a,
+                       uint32_t lo_b, int dir, float *score, char *path, size_t path_cap, uint32_t *path_len)
+{
+    if (!ctx || !S || !score || !path) { rsk_set_error("%s: NULL argument", who); return RSK_E_INVALID; }
+    if (open > 0 || ext > 0) { rsk_set_error("%s: gap penalties must be <= 0", who); return RSK_E_INVALID; }
+    // forward: extents LA - lo_a, LB - lo_b >= 1; backward: lo_a, lo_b >= 1 (the reference asserts the same, xdropbwd.cpp:37-38)
+    if (lo_a > LA || lo_b > LB || (dir == 0 && (lo_a >= LA || lo_b >= LB)) || (dir == 1 && (lo_a == 0 || lo_b == 0))) {
+        rsk_set_error("%s: start (%u, %u) outside the %u x %u matrix", who, lo_a, lo_b, LA, LB);
+        return RSK_E_INVALID;
+    }
+    RSK_HIP(hipSetDevice(ctx->device));
+    const uint64_t EA = dir ? lo_a : LA - lo_a, EB = dir ? lo_b : LB - lo_b;
+    const size_t tb_bytes = (size_t) ((EA + 9) * (EB + 9) + 15) & ~(size_t) 15, row_floats = 2 * (EB + 9), slot = EA + EB + 2;
+    struct ws_t {
+        rsk_ctx *ctx;
+        std::vector<void *> all;
+        ~ws_t() { for (void *p : all) rsk_pool_free(ctx, p); }
+    } ws{ ctx, {} };
+    auto dalloc = [&](void **p, size_t bytes) -> int {
+        int r = rsk_pool_alloc(ctx, p, std::max<size_t>(bytes, 16));
+        if (r == RSK_OK) ws.all.push_back(*p);
+        return r;
+    };
+    float *d_S, *d_rows, *d_score;
+    uint32_t *d_u;                    // a_len, b_len, ia = ib = 0, lo_a, lo_b, path_start[2], path_len[2]
+    uint64_t *d_off;                  // row_off[2], tb_off[2], path_off[2] (both directions share the slots: only one runs)
+    uint8_t *d_tb;
+    char *d_paths;
+    int rc;
+    if ((rc = dalloc((void **) &d_S, (size_t) LA * LB * 4)) || (rc = dalloc((void **) &d_rows, row_floats * 4)) || (rc = dalloc((void **) &d_score, 8)) ||
+        (rc = dalloc((void **) &d_u, 9 * 4)) || (rc = dalloc((void **) &d_off, 6 * 8)) || (rc = dalloc((void **) &d_tb, tb_bytes)) ||
+        (rc = dalloc((void **) &d_paths, slot)))
+        return rc;
+    const uint32_t h_u[9] = { LA, LB, 0, lo_a, lo_b, 0, 0, 0, 0 };
+    const uint64_t h_off[6] = { 0, 0, 0, 0, 0, 0 };
+    RSK_HIP(hipMemcpyAsync(d_S, S, (size_t) LA * LB * 4, hipMemcpyHostToDevice, ctx->stream));
+    RSK_HIP(hipMemcpyAsync(d_u, h_u, sizeof(h_u), hipMemcpyHostToDevice, ctx->stream));
+    RSK_HIP(hipMemcpyAsync(d_off, h_off, sizeof(h_off), hipMemcpyHostToDevice, ctx->stream));
+    RSK_HIP(hipMemsetAsync(d_tb, 0, tb_bytes, ctx->stream));
+    RSK_HIP(hipMemsetAsync(d_rows, 0, row_floats * 4, ctx->stream));
+    xd_args a = {};
+    a.a_len = d_u; a.b_len = d_u + 1; a.ia = d_u + 2; a.ib = d_u + 2; a.lo_a = d_u + 3; a.lo_b = d_u + 4;
+    a.path_start = d_u + 5; a.path_len = d_u + 7;
+    a.nreq = 1; a.X = X; a.open = open; a.ext = ext;
+    a.rows = d_rows; a.row_off = d_off; a.tb = d_tb; a.tb_off = d_off + 2; a.score = d_score; a.paths = d_paths; a.path_off = d_off + 4;
+    a.smx = d_S; a.smx_ld = LB; a.only_dir = dir;
+    hipLaunchKernelGGL(k_xdrop_wave<true>, dim3(1), dim3(64 * XDW_WAVES), 0, ctx->stream, a);
+    RSK_HIP(hipGetLastError());
+    float h_score[2];
+    uint32_t h_res[4];
+    RSK_HIP(hipMemcpyAsync(h_score, d_score, 8, hipMemcpyDeviceToHost, ctx->stream));
+    RSK_HIP(hipMemcpyAsync(h_res, d_u + 5, 16, hipMemcpyDeviceToHost, ctx->stream));
+    RSK_HIP(hipStreamSynchronize(ctx->stream));
+    const uint32_t len = h_res[2 + dir];
+    *score = h_score[dir];
+    if (path_len) *path_len = len;
+    if ((size_t) len + 1 > path_cap) { rsk_set_error("%s: path buffer too small (%u needed)", who, len + 1); return RSK_E_INVALID; }
+    if (len) {
+        RSK_HIP(hipMemcpyAsync(path, d_paths + h_res[dir], len, hipMemcpyDeviceToHost, ctx->stream));
+        RSK_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    path[len] = 0;
+    return RSK_OK;
+}
+
+extern "C" int rsk_xdrop_fwd(rsk_ctx *ctx, const float *S, uint32_t LA, uint32_t LB, float X, float open, float ext, uint32_t lo_a, uint32_t lo_b,
+                             float *score, char *path, size_t path_cap, uint32_t *path_len)
+{
+    return xd_explicit(ctx, "rsk_xdrop_fwd", S, LA, LB, X, open, ext, lo_a, lo_b, 0, score, path, path_cap, path_len);
+}
+
+// XDropBwd(HiA, HiB) extends from (hi_a, hi_b) towards the starts = the backward extension of the start (hi_a + 1, hi_b + 1)
+extern "C" int rsk_xdrop_bwd(rsk_ctx *ctx, const float *S, uint32_t LA, uint32_t LB, float X, float open, float ext, uint32_t hi_a, uint32_t hi_b,
+                             float *score, char *path, size_t path_cap, uint32_t *path_len)
+{
+    if (hi_a >= LA || hi_b >= LB) { rsk_set_error("rsk_xdrop_bwd: (%u, %u) outside the %u x %u matrix", hi_a, hi_b, LA, LB); return RSK_E_INVALID; }
+    return xd_explicit(ctx, "rsk_xdrop_bwd", S, LA, LB, X, open, ext, hi_a + 1, hi_b + 1, 1, score, path, path_cap, path_len);
 }
 
 // XDropHSP's two extensions (xdrophsp.cpp:97-108) for a list of seeded pairs.  Host arrays in, host arrays out.
@@ -840,6 +730,7 @@ extern "C" int rsk_xdrop_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
         a.X = X; a.open = gap_open; a.ext = gap_ext;
         a.rows = d_rows; a.row_off = d_rowoff; a.tb = d_tb; a.tb_off = d_tboff;
         a.score = d_score; a.paths = d_paths; a.path_off = d_pathoff; a.path_start = d_pstart; a.path_len = d_plen;
+        a.only_dir = -1;
         if (trace) RSK_HIP(hipStreamSynchronize(ctx->stream));
         const auto t_c = now();
         xd_launch(ctx, a, m);
@@ -1113,7 +1004,7 @@ extern "C" int rsk_mkf_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db
         xa.X = x2; xa.open = gap_open; xa.ext = gap_ext;
         xa.rows = d_rows; xa.row_off = d_rowoff; xa.tb = d_tb; xa.tb_off = d_tboff;
         xa.score = d_xscore; xa.paths = d_paths; xa.path_off = d_pathoff; xa.path_start = d_pstart; xa.path_len = d_plen;
-        xa.per_pair = 1; xa.valid = d_valid;
+        xa.per_pair = 1; xa.valid = d_valid; xa.only_dir = -1;
         RSK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
         xd_launch(ctx, xa, m);
         RSK_HIP(hipEventRecord(ctx->ev1, ctx->stream));

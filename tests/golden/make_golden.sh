@@ -147,3 +147,9 @@ sort $TMP/tail_self_v.tsv | gzip -9n > $G/hits_taildb_self_verysensitive.tsv.gz
 #     long-chain pair of palms.bca, from the reference's own functions (checked against DSSAligner::AlignMKF inside the harness)
 $H xdrophsp $T/palms.bca $TMP/xdrophsp_palms.bin 39 -- -sensitive
 gzip -9n < $TMP/xdrophsp_palms.bin > $G/xdrophsp_palms_sensitive.bin.gz
+# 13b. the same for the 48-chain set with the length tail (17 .. 5,000 residues; 1,215 long-chain pairs): bands that outgrow
+#      the device kernel's LDS ring, extensions next to chain ends, short partners
+$H db $TMP/taildb.bca $TMP/taildb.rskdb -- -sensitive
+gzip -9n < $TMP/taildb.rskdb > $G/taildb_sensitive.rskdb.gz
+$H xdrophsp $TMP/taildb.bca $TMP/xdrophsp_taildb.bin 48 -- -sensitive
+gzip -9n < $TMP/xdrophsp_taildb.bin > $G/xdrophsp_taildb_sensitive.bin.gz

@@ -74,6 +74,12 @@ def lib():
         L.rsko_prefilter.argtypes = [u8p, u32p, C.c_uint32, u8p, u32p, C.c_uint32, u32p, u32p, u32p, C.c_size_t]
         L.rsko_prefilter_mode.restype = C.c_size_t
         L.rsko_prefilter_mode.argtypes = [u8p, u32p, C.c_uint32, u8p, u32p, C.c_uint32, C.c_int, u32p, u32p, u32p, C.c_size_t]
+        L.rsko_xdrop_fwd.restype = C.c_float
+        L.rsko_xdrop_fwd.argtypes = [f32p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_char_p, u32p]
+        L.rsko_xdrop_bwd.restype = C.c_float
+        L.rsko_xdrop_bwd.argtypes = L.rsko_xdrop_fwd.argtypes
+        L.rsko_merge_fwd_bwd.restype = None
+        L.rsko_merge_fwd_bwd.argtypes = [C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint32, C.c_uint32, C.c_char_p, u32p, C.c_char_p]
         L.rsko_rsb.restype = C.c_size_t
         L.rsko_rsb.argtypes = [u32p, u32p, u32p, C.c_size_t, C.c_uint32, C.c_uint32, u32p, u32p, u32p]
         _lib = L
@@ -134,6 +140,33 @@ def sw_fast_matrix(S, open_, ext):
     lo_i, lo_j, n = C.c_uint32(0xFFFFFFFF), C.c_uint32(0xFFFFFFFF), C.c_uint32()
     s = lib().rsko_sw_fast(_p(S, f32p), LA, LB, open_, ext, C.byref(lo_i), C.byref(lo_j), buf, C.byref(n), None)
     return s, lo_i.value, lo_j.value, buf.value.decode()
+
+
+def _xdrop(fn, S, X, open_, ext, a, b):
+    S = np.ascontiguousarray(S, np.float32)
+    LA, LB = S.shape
+    buf = C.create_string_buffer(LA + LB + 4)
+    n = C.c_uint32()
+    s = fn(_p(S, f32p), LA, LB, X, open_, ext, a, b, buf, C.byref(n))
+    return s, buf.value.decode()
+
+
+def xdrop_fwd(S, X, open_, ext, lo_a, lo_b):
+    """XDropFwd (xdropfwd.cpp:71) on an explicit score matrix, from (lo_a, lo_b) to the ends -> (score, path)"""
+    return _xdrop(lib().rsko_xdrop_fwd, S, X, open_, ext, lo_a, lo_b)
+
+
+def xdrop_bwd(S, X, open_, ext, hi_a, hi_b):
+    """XDropBwd (xdropbwd.cpp:28), from (hi_a, hi_b) to the starts -> (score, path)"""
+    return _xdrop(lib().rsko_xdrop_bwd, S, X, open_, ext, hi_a, hi_b)
+
+
+def merge_fwd_bwd(fwd_lo_a, fwd_lo_b, fwd_path, bwd_hi_a, bwd_hi_b, bwd_path):
+    """MergeFwdBwd (mergefwdback.cpp:6) -> (lo_a, lo_b, hi_a, hi_b, path)"""
+    out = (C.c_uint32 * 4)()
+    buf = C.create_string_buffer(len(fwd_path) + len(bwd_path) + 2)
+    lib().rsko_merge_fwd_bwd(fwd_lo_a, fwd_lo_b, fwd_path.encode(), bwd_hi_a, bwd_hi_b, bwd_path.encode(), out, buf)
+    return out[0], out[1], out[2], out[3], buf.value.decode()
 
 
 def sw_gapless_matrix(S):

@@ -277,15 +277,13 @@ def test_streamed_db_batches(ctx, tmpdir, monkeypatch):
     assert sorted(open(out1).read().splitlines()) == sorted(open(out2).read().splitlines())
 
 
-def test_long_chain_device_batch_equals_host_path(ctx, tmpdir, monkeypatch):
+def test_long_chain_device_batch_from_bca(ctx, tmpdir, monkeypatch):
     """The long-chain pairs go through ONE device batch after the chaining (rsk_mkf_align_pairs: mega-HSP scores, 8-mer
-    start, both X-drop extensions, MergeFwdBwd, LDDT / E-value); RSK_MKF_HOST=1 runs the same pairs one at a time on the
-    host threads (host X-drop mirror, pinned to the reference's -test_xdrop vectors).  Both must give the golden tables;
-    RSK_MKF_CAP=2 truncates the device seed lists so that MuKmerFilter::Align re-seeds on the host."""
-    for host in ("0", "1"):
-        monkeypatch.setenv("RSK_MKF_HOST", host)
-        run_bca(ctx, tmpdir, "palms.bca", "sensitive", COLS, "hits_palms_sensitive.tsv.gz")
-        run_bca(ctx, tmpdir, "edge.bca", "sensitive", COLS, "hits_edge_sensitive.tsv.gz")
-    monkeypatch.setenv("RSK_MKF_HOST", "0")
+    start, both X-drop extensions, MergeFwdBwd, LDDT / E-value), and so do the self-rev alignments of the long chains
+    (chain against its reversed copy, alignpair.cpp:7) when the search starts from a .bca: the library has no host X-drop.
+    RSK_MKF_CAP=2 truncates the device seed lists so that MuKmerFilter::Align re-seeds those pairs on the host before they
+    join the batch.  Golden tables either way."""
+    run_bca(ctx, tmpdir, "palms.bca", "sensitive", COLS, "hits_palms_sensitive.tsv.gz")
+    run_bca(ctx, tmpdir, "edge.bca", "sensitive", COLS, "hits_edge_sensitive.tsv.gz")
     monkeypatch.setenv("RSK_MKF_CAP", "2")
     run_bca(ctx, tmpdir, "palms.bca", "sensitive", COLS, "hits_palms_sensitive.tsv.gz")

@@ -1,7 +1,12 @@
-"""GPU parity of the gapped float X-drop extensions of the long-chain path (second half):
-rsk_xdrop_pairs (one GPU thread per extension) against the host mirror of XDropFwd / XDropBwd (rsk_xdrop_fwd/bwd on
-the explicit SetSMx_NoRev matrix from the oracle), which tests/test_xdrop_kat.py pins to the reference's own
--test_xdrop vectors.  Score bits and paths must be identical."""
+"""GPU parity of the gapped float X-drop extensions of the long-chain path (second half).  The product has
+ONE implementation, k_xdrop_wave (a wave per extension); it is checked against
+  * the reference's own per-stage outputs on real long-chain pairs (ref_harness xdrophsp fixtures: palms = the reference's
+    test chains, taildb = 48 chains of 17 .. 5,000 residues) -- extensions from the reference's start and the whole device
+    batch (start, gates, merge, statistics);
+  * the CPU oracle (oracle/rsk_oracle.c rsko_xdrop_*, itself pinned to those fixtures and to the reference's -test_xdrop
+    vectors: tests/test_oracle_xdrop.py, tests/test_xdrop_kat.py) on starts no fixture holds: chain edges, random starts,
+    other gap penalties, and bands wider than the kernel's LDS ring.
+Score bits and paths must be identical."""
 import ctypes as C
 import struct
 
@@ -37,16 +42,15 @@ def ctx():
     c.close()
 
 
-@pytest.mark.parametrize("kernel", ["wave", "thread"])
 @pytest.mark.parametrize("fixture,X,go,ge", [("palms_sensitive.rskdb.gz", 8.0, -0.685533, -0.051881),
                                              ("q100_sensitive.rskdb.gz", 8.0, -0.685533, -0.051881),
-                                             ("q100_sensitive.rskdb.gz", 2.5, -3.0, -1.0)])
-def test_xdrop_pairs_match_the_host_mirror(ctx, fixture, X, go, ge, kernel, monkeypatch):
-    """Both device forms of the extension (k_xdrop_wave: a wave per extension, the default; k_xdrop: a thread per extension)
-    against the host mirror of XDropFwd / XDropBwd, scores and paths bit for bit."""
+                                             ("q100_sensitive.rskdb.gz", 2.5, -3.0, -1.0),
+                                             ("taildb_sensitive.rskdb.gz", 8.0, -0.685533, -0.051881)])
+def test_xdrop_pairs_match_the_oracle(ctx, fixture, X, go, ge):
+    """rsk_xdrop_pairs against the oracle's XDropFwd / XDropBwd on the SetSMx_NoRev matrix, scores and paths bit for bit."""
     import reseek_amd
-    monkeypatch.setenv("RSK_XDROP_WAVE", "1" if kernel == "wave" else "0")
-    chains = fx.read_rskdb(fixture)[:14]
+    chains = fx.read_rskdb(fixture)
+    chains = chains[:14] if not fixture.startswith("taildb") else [c for c in chains if c.prof.shape[1] <= 1600][:14]
     db = reseek_amd.Db.from_chains(ctx, chains)
     rng = np.random.default_rng(5)
     ia, ib, la, lb = [], [], [], []
@@ -56,7 +60,8 @@ def test_xdrop_pairs_match_the_host_mirror(ctx, fixture, X, go, ge, kernel, monk
             LA, LB = chains[a].prof.shape[1], chains[b].prof.shape[1]
             if LA < 3 or LB < 3:
                 continue
-            # a start on a self-like diagonal (long extensions), a random one, and the edges 1 / L - 1
+            # a start on a self-like diagonal (long extensions), a random one, and the edges 1 / L - 1 (extents of one row /
+            # one column: xdropfwd.cpp:84-92)
             for (x, y) in ((min(LA, LB) // 2, min(LA, LB) // 2), (int(rng.integers(1, LA)), int(rng.integers(1, LB))), (1, 1), (LA - 1, LB - 1),
                            (1, LB - 1)):
                 ia.append(a); ib.append(int(b)); la.append(x); lb.append(y)
@@ -68,13 +73,34 @@ def test_xdrop_pairs_match_the_host_mirror(ctx, fixture, X, go, ge, kernel, monk
         if key not in cache:
             cache[key] = smx(chains[ia[k]].prof, chains[ib[k]].prof)
         S = cache[key]
-        hf, hpf = capi.xdrop_fwd(S, X, go, ge, la[k], lb[k])
-        hb, hpb = capi.xdrop_bwd(S, X, go, ge, la[k] - 1, lb[k] - 1)
+        hf, hpf = ol.xdrop_fwd(S, X, go, ge, la[k], lb[k])
+        hb, hpb = ol.xdrop_bwd(S, X, go, ge, la[k] - 1, lb[k] - 1)
         assert bits(sf) == bits(hf) and pf == hpf, (k, "fwd", ia[k], ib[k], la[k], lb[k])
         assert bits(sb) == bits(hb) and pb == hpb, (k, "bwd", ia[k], ib[k], la[k], lb[k])
         nlong += len(pf) > 40 or len(pb) > 40
     assert len(res) > 200 and nlong > 10
     db.close()
+
+
+def test_band_wider_than_the_lds_ring(ctx):
+    """Explicit score matrices whose band outgrows the kernel's 512-column LDS ring (the extension is then re-run on HBM
+    rows): mildly positive scores keep every column within X of the best, so the band spans the whole row.  The same entry
+    points the reference's -test_xdrop vectors go through (tests/test_xdrop_kat.py), against the oracle."""
+    rng = np.random.default_rng(11)
+    for (LA, LB, X, go, ge) in ((700, 900, 8.0, -0.685533, -0.051881), (1300, 640, 30.0, -1.0, -0.02), (600, 600, 8.0, -3.0, -1.0)):
+        S = (rng.random((LA, LB)) * 0.6 - 0.25).astype(np.float32)
+        S[np.arange(min(LA, LB)), np.arange(min(LA, LB))] += 0.5
+        for (a, b) in ((1, 1), (LA // 2, LB // 2), (LA - 2, 3)):
+            gf, gpf = capi.xdrop_fwd(ctx, S, X, go, ge, a, b)
+            of, opf = ol.xdrop_fwd(S, X, go, ge, a, b)
+            assert bits(gf) == bits(of) and gpf == opf, (LA, LB, a, b, "fwd")
+            gb, gpb = capi.xdrop_bwd(ctx, S, X, go, ge, a, b)
+            ob, opb = ol.xdrop_bwd(S, X, go, ge, a, b)
+            assert bits(gb) == bits(ob) and gpb == opb, (LA, LB, a, b, "bwd")
+    # the widest row of the first case must really have exceeded the ring for this test to mean anything
+    S = (np.random.default_rng(11).random((700, 900)) * 0.6 - 0.25).astype(np.float32)
+    _, p = ol.xdrop_fwd(S, 8.0, -0.685533, -0.051881, 1, 1)
+    assert len(p) > 600
 
 
 def test_xdrop_pairs_rejects_bad_starts(ctx):
@@ -88,20 +114,21 @@ def test_xdrop_pairs_rejects_bad_starts(ctx):
     db.close()
 
 
-def test_long_chain_stages_match_the_reference(ctx):
-    """Direct fixture of the reference's long-chain path (oracle/ref_harness xdrophsp on palms.bca, every long-chain pair,
+@pytest.mark.parametrize("name,min_gated,min_aln", [("palms", 500, 500), ("taildb", 900, 900)])
+def test_long_chain_stages_match_the_reference(ctx, name, min_gated, min_aln):
+    """Direct fixture of the reference's long-chain path (oracle/ref_harness xdrophsp on palms.bca / taildb.bca, every long-chain pair,
     each stage from the reference's own GetMegaHSPScore / StaticSubstScore / XDropFwd / XDropBwd / MergeFwdBwd and checked
     against DSSAligner::AlignMKF inside the harness):
       * rsk_xdrop_pairs from the reference's start -> forward / backward score bits and paths;
       * rsk_mkf_align_pairs from the reference's chained HSPs -> the start it derives (through the merged Lo), total score
         bits, merged path, E-value and LDDT bits, and the MinMegaHSPScore / TotalScore gates."""
     import reseek_amd
-    chains = fx.read_rskdb("palms_sensitive.rskdb.gz")
-    n, recs = fx.read_xdrophsp("xdrophsp_palms_sensitive.bin.gz")
+    chains = fx.read_rskdb(name + "_sensitive.rskdb.gz")
+    n, recs = fx.read_xdrophsp("xdrophsp_" + name + "_sensitive.bin.gz")
     assert n == len(chains)
     db = reseek_amd.Db.from_chains(ctx, chains)
     gated = [r for r in recs if r["gate"]]
-    assert len(gated) > 500
+    assert len(gated) > min_gated
     # 1. the two extensions from the reference's start
     res = ctx.xdrop_pairs(db, db, [r["i"] for r in gated], [r["j"] for r in gated], [r["lo_a"] for r in gated], [r["lo_b"] for r in gated],
                           8.0, -0.685533, -0.051881)
@@ -128,5 +155,5 @@ def test_long_chain_stages_match_the_reference(ctx):
             assert (a.lo_a, a.lo_b) == (r["mlo_a"], r["mlo_b"]), key
             assert bits(a.evalue) == r["evalue"] and bits(a.lddt) == r["lddt"], key
             naln += 1
-    assert naln > 500
+    assert naln > min_aln
     db.close()

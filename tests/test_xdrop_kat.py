@@ -1,17 +1,19 @@
 """The reference's own X-drop / SW self-test vectors (test_xdrop.cpp:177-187, swgaplessprof.cpp:158-166: nine
 hard-coded peptide pairs under BLOSUM62) plus 300 random peptide pairs, all run through the reference's SWFast,
 SWGapless, XDropFwd, XDropBwd and MergeFwdBwd by oracle/ref_harness `xdropkat` (tests/golden/make_golden.sh).
-Pins (a) the oracle's SWFast / gapless restatements and (b) the host X-drop code of the long-chain path
-(host/dssaligner.cpp, through the C-ABI) bit for bit.  No GPU needed."""
+Pins, bit for bit: (a) the oracle's SWFast / gapless / X-drop restatements (CPU tests) and (b) the PRODUCT's X-drop kernel
+(k_xdrop_wave on an explicit score matrix, through rsk_xdrop_fwd / rsk_xdrop_bwd: the -m gpu test at the end; the library
+has no host implementation of that DP)."""
 import gzip
 import os
 import struct
 
 import numpy as np
 
+import pytest
+
 import fixtures as fx
 import oracle_lib as ol
-from reseek_amd import capi
 
 
 def bits(x):
@@ -90,28 +92,43 @@ def test_oracle_swfast_and_gapless_match_the_reference():
             assert bi + 1 >= gcols and bj + 1 >= gcols
 
 
-def test_host_xdrop_fwd_bwd_merge_match_the_reference():
+def _xdrop_cases(fwd_fn, bwd_fn, merge_fn):
     n = nm = 0
     for k, c in enumerate(CASES):
         if c["xdrop"] is None:
             continue
         (ma, mb), fwd, bwd, merged = c["xdrop"]
         LA, LB = c["S"].shape
-        fs, fp = capi.xdrop_fwd(c["S"], c["X"], c["open"], c["ext"], ma + 1, mb + 1) if ma + 1 <= LA and mb + 1 <= LB else (None, None)
+        fs, fp = fwd_fn(c["S"], c["X"], c["open"], c["ext"], ma + 1, mb + 1)
         assert bits(fs) == bits(fwd[0]) and fp == fwd[3], (k, "fwd")
-        bs, bp = capi.xdrop_bwd(c["S"], c["X"], c["open"], c["ext"], ma, mb)
+        bs, bp = bwd_fn(c["S"], c["X"], c["open"], c["ext"], ma, mb)
         assert bits(bs) == bits(bwd[0]) and bp == bwd[3], (k, "bwd")
         n += 1
         if merged is not None:
-            assert capi.merge_fwd_bwd(LA, LB, ma + 1, mb + 1, fp, ma, mb, bp) == merged, (k, "merge")
+            assert merge_fn(LA, LB, ma + 1, mb + 1, fp, ma, mb, bp) == merged, (k, "merge")
             nm += 1
     assert n > 250 and nm > 250
 
 
-def test_xdrop_c_abi_rejects_bad_arguments():
+def test_oracle_xdrop_fwd_bwd_merge_match_the_reference():
+    _xdrop_cases(ol.xdrop_fwd, ol.xdrop_bwd, lambda LA, LB, *a: ol.merge_fwd_bwd(*a))
+
+
+def test_merge_c_abi_rejects_bad_arguments():
+    from reseek_amd import capi
+    with pytest.raises(RuntimeError):
+        capi.merge_fwd_bwd(5, 5, 1, 1, "", 0, 0, "")
+
+
+@pytest.mark.gpu
+def test_device_xdrop_kernel_matches_the_reference_self_test_vectors():
+    """k_xdrop_wave<EXPLICIT>: the kernel of the search's long-chain batch, fed the reference's own score matrices."""
+    import reseek_amd
+    from reseek_amd import capi
+    ctx = reseek_amd.Ctx(0)
+    _xdrop_cases(lambda *a: capi.xdrop_fwd(ctx, *a), lambda *a: capi.xdrop_bwd(ctx, *a), capi.merge_fwd_bwd)
     S = CASES[0]["S"]
-    import pytest
     with pytest.raises(RuntimeError):
-        capi.xdrop_bwd(S, 8.0, -3.0, -1.0, S.shape[0], 0)
+        capi.xdrop_bwd(ctx, S, 8.0, -3.0, -1.0, S.shape[0], 0)
     with pytest.raises(RuntimeError):
-        capi.merge_fwd_bwd(S.shape[0], S.shape[1], 1, 1, "", 0, 0, "")
+        capi.xdrop_fwd(ctx, S, 8.0, -3.0, -1.0, S.shape[0], 1)
