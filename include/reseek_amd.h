@@ -324,9 +324,17 @@ typedef struct rsk_search_opts {
     uint32_t shard_count;      /* shard_count: -db mode = a contiguous range of DB chains balanced by residues;     */
                                /* self search = the pairs (i <= j) whose j lies in a range balanced by DP cells.    */
                                /* The union of the shards' hit tables is the unsharded table.  0 or 1 = no shards. */
+    const char *devices;       /* multi-GPU (ONE process): "0,1,2,3" = the call drives these devices, one context + host thread */
+                               /* each, shards as above, one hits file (an id may repeat: several contexts on one device).  */
+                               /* NULL = the environment's RSK_DEVICES if set, else the device of ctx only.                  */
 } rsk_search_opts;
 int rsk_search(rsk_ctx *ctx, const char *query_path, const char *db_path, const rsk_search_opts *opts,
                const char *out_tsv, uint64_t *nhits, uint64_t *stats8);
+
+/* The shard bounds the searches use (pure host arithmetic, no device): kind 0 = self search, targets [lo, hi) of the
+ * triangle of pairs (i <= j) such that every shard covers the same number of DP cells; kind 1 = -db search, a contiguous
+ * range of chains with the same number of residues per shard.  The shards 0 .. count-1 tile [0, n) in order. */
+int rsk_shard_range(int kind, const uint32_t *lengths, uint64_t n, uint32_t index, uint32_t count, uint64_t *lo, uint64_t *hi);
 
 /* ---- `-search -fast -db` on several GPUs: the per-query top-B of the prefilter (RankedScoresBag,
  * rankedscoresbag.cpp:34-51) is a reduction over all targets, so the target-sharded form has one exchange between the

@@ -100,7 +100,8 @@ class SearchOpts(C.Structure):
     _fields_ = [("mode", C.c_char_p), ("columns", C.c_char_p), ("evalue", C.c_double), ("evalue_set", C.c_int),
                 ("mints", C.c_double), ("mints_set", C.c_int), ("pvalue", C.c_double), ("pvalue_set", C.c_int),
                 ("noself", C.c_int), ("selfrev0", C.c_int), ("idx_mode", C.c_int), ("rsb_size", C.c_uint32),
-                ("dbmu", C.c_char_p), ("keeptmp", C.c_int), ("shard_index", C.c_uint32), ("shard_count", C.c_uint32)]
+                ("dbmu", C.c_char_p), ("keeptmp", C.c_int), ("shard_index", C.c_uint32), ("shard_count", C.c_uint32),
+                ("devices", C.c_char_p)]
 
 
 SIGNATURES["rsk_search"] = (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(SearchOpts), C.c_char_p, C.POINTER(C.c_uint64),
@@ -111,6 +112,7 @@ SIGNATURES["rsk_fast_shard_finish"] = (C.c_int, [C.c_void_p, u32p, u32p, u32p, C
                                                  C.POINTER(C.c_uint64)])
 SIGNATURES["rsk_fast_shard_close"] = (None, [C.c_void_p])
 SIGNATURES["rsk_rsb_merge"] = (C.c_int, [u32p, u32p, u32p, C.c_size_t, C.c_uint32, C.c_uint32, u32p, u32p, u32p, C.POINTER(C.c_size_t)])
+SIGNATURES["rsk_shard_range"] = (C.c_int, [C.c_int, u32p, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)])
 SIGNATURES["rsk_bca_copy"] = (C.c_int, [C.c_char_p, C.c_char_p])
 SIGNATURES["rsk_bca_to_mu_fasta"] = (C.c_int, [C.c_char_p, C.c_char_p])
 
@@ -238,7 +240,7 @@ class Ctx:
         o = SearchOpts()
         o.mode = mode.encode()
         for k, v in kw.items():
-            if k in ("columns", "dbmu"):
+            if k in ("columns", "dbmu", "devices"):
                 setattr(o, k, v.encode() if v else None)
             elif k in ("evalue", "mints", "pvalue"):
                 setattr(o, k, float(v)); setattr(o, k + "_set", 1)
@@ -254,7 +256,8 @@ class Ctx:
         return FastShard(h)
 
     def search(self, query, out_tsv, mode, db=None, **kw):
-        """rsk_search with the options struct: columns, evalue, mints, pvalue, noself, selfrev0, idx_mode, rsb_size, dbmu, keeptmp."""
+        """rsk_search with the options struct: columns, evalue, mints, pvalue, noself, selfrev0, idx_mode, rsb_size, dbmu, keeptmp,
+        shard_index / shard_count (one process per GPU), devices ("0,1,...": one process, several devices)."""
         o = self._opts(mode, kw)
         n = C.c_uint64()
         st = (C.c_uint64 * 8)()
@@ -514,6 +517,14 @@ def merge_fwd_bwd(LA, LB, fwd_lo_a, fwd_lo_b, fwd_path, bwd_hi_a, bwd_hi_b, bwd_
     _check(lib().rsk_merge_fwd_bwd(LA, LB, fwd_lo_a, fwd_lo_b, fwd_path.encode(), bwd_hi_a, bwd_hi_b, bwd_path.encode(),
                                    C.byref(v[0]), C.byref(v[1]), C.byref(v[2]), C.byref(v[3]), buf, len(buf), C.byref(n)))
     return v[0].value, v[1].value, v[2].value, v[3].value, buf.value.decode()
+
+
+def shard_range(kind, lengths, index, count):
+    """rsk_shard_range: kind 0 = self-search targets balanced by DP cells, 1 = chain range balanced by residues -> (lo, hi)"""
+    L = np.ascontiguousarray(lengths, np.uint32)
+    lo, hi = C.c_uint64(), C.c_uint64()
+    _check(lib().rsk_shard_range(kind, _p(L, u32p), len(L), index, count, C.byref(lo), C.byref(hi)))
+    return lo.value, hi.value
 
 
 def dss_featurize(seq, x, y, z):

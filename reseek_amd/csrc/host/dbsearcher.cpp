@@ -32,6 +32,20 @@ static void check(int rc, const char *what)
     if (rc != RSK_OK) throw std::runtime_error(std::string(what) + ": " + rsk_last_error());
 }
 
+void DeviceBuffer::Make(rsk_ctx *Ctx, size_t Bytes, const char *What)
+{
+    Free();
+    if (!Ctx) throw std::runtime_error(std::string(What) + ": no GPU context");
+    if (hipSetDevice(Ctx->device) != hipSuccess) throw std::runtime_error(std::string(What) + ": hipSetDevice failed");
+    check(rsk_dev_malloc(Ctx, &m_Ptr, std::max<size_t>(Bytes, 16)), What);
+}
+
+void DeviceBuffer::Free()
+{
+    if (m_Ptr) (void) hipFree(m_Ptr);
+    m_Ptr = nullptr;
+}
+
 DBSearcher::~DBSearcher()
 {
     if (m_OwnsChains) {
@@ -424,6 +438,7 @@ void DBSearcher::Setup()
     m_DA.SetParams(*m_Params);
     m_DA.SetColumns(m_Opts.columns);
     m_DA.m_Ctx = m_Ctx;
+    if (m_Devices.empty() && m_OwnsChains) m_Devices = ParseDeviceList(getenv("RSK_DEVICES"));      // views / replicas stay on their context
     OnSetup();
 }
 
@@ -492,7 +507,19 @@ struct SecondaryCtx {
     struct Idle { int device; rsk_ctx *c; hipStream_t st; const char *role; };
     const char *role = "";
     static std::mutex &Lock() { static std::mutex m; return m; }
-    static std::vector<Idle> &IdleList() { static std::vector<Idle> v; return v; }
+    // The parked contexts keep their pools (that is the point), so two things bound what they can hold on to: the library's
+    // out-of-memory ladder (rsk_dev_malloc) destroys the idle contexts of the device before any allocation fails -- the
+    // hook is registered with the list -- and the list is destroyed with the process.
+    struct IdleHolder {
+        std::vector<Idle> v;
+        IdleHolder() { rsk_set_oom_hook(&SecondaryCtx::Trim); }
+        ~IdleHolder()
+        {
+            rsk_set_oom_hook(nullptr);
+            for (Idle &i : v) { rsk_ctx_destroy(i.c); if (i.st) (void) hipStreamDestroy(i.st); }
+        }
+    };
+    static std::vector<Idle> &IdleList() { static IdleHolder h; return h.v; }
     void Create(int dev, const char *Role)
     {
         device = dev;
@@ -505,6 +532,7 @@ struct SecondaryCtx {
         }
         check(rsk_ctx_create(dev, &c), "rsk_ctx_create");
         if (!(getenv("RSK_OWN_STREAMS") && atoi(getenv("RSK_OWN_STREAMS")) == 0)) {
+            (void) hipSetDevice(dev);                                   // a stream belongs to the calling thread's current device
             if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { st = nullptr; return; }
             rsk_ctx_set_stream(c, (void *) st);
         }
@@ -550,7 +578,7 @@ struct PinnedPool {
         }
         void *p = nullptr;
         cap = bytes + bytes / 8 + 4096;
-        if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) throw std::runtime_error("hipHostMalloc failed for the path buffer");
+        if (hipHostMalloc(&p, cap, hipHostMallocPortable) != hipSuccess) throw std::runtime_error("hipHostMalloc failed for the path buffer");
         return (char *) p;
     }
     void Put(char *p, size_t cap)
@@ -925,41 +953,31 @@ static void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOff
         const bool Swap = !Self && NA > NB;
         rsk_db *FilterQ = Swap ? S.m_Db : SrcA.m_Db, *FilterT = Swap ? SrcA.m_Db : S.m_Db;
         const size_t ldo = Swap ? NA : NB;
-        uint8_t *d_fwd = nullptr;
-        uint32_t *d_pq = nullptr, *d_pt = nullptr, *d_n = nullptr;
         const uint64_t total = Self ? SelfTotal : (uint64_t) NA * NB;
-        // survivor lists: sized for 1/16 of the pairs (the presets pass 0.3 % - 15 %), re-run with the exact count on overflow
+        // survivor lists: sized for 1/6 of the pairs (the presets pass 0.3 % of real SCOP40 pairs, 15 % of look-alike synthetic
+        // structures; 8 bytes per slot, 5.3 GB for the largest filter tile), re-run with the exact count on overflow
         // (the kernel counts every survivor; it only stops storing at `cap`)
         const uint64_t dense = Tri ? total : (uint64_t) NA * NB;
-        size_t cap = (size_t) std::min<uint64_t>(dense, std::max<uint64_t>(1u << 22, dense / 16));
+        size_t cap = (size_t) std::min<uint64_t>(dense, std::max<uint64_t>(1u << 22, dense / 6));
         auto hipok = [](hipError_t e, const char *w) { if (e != hipSuccess) throw std::runtime_error(std::string(w) + ": " + hipGetErrorString(e)); };
-        struct dev_bufs {
-            uint8_t *fwd = nullptr; uint32_t *pq = nullptr, *pt = nullptr, *n = nullptr;
-            ~dev_bufs() { (void) hipFree(fwd); (void) hipFree(pq); (void) hipFree(pt); (void) hipFree(n); }
-        } D;
-        hipok(hipMalloc((void **) &D.fwd, (size_t) (Swap ? NB : NA) * ldo), "hipMalloc fwd");
-        hipok(hipMalloc((void **) &D.n, 4), "hipMalloc n");
+        DeviceBuffer Fwd(ctx, (size_t) (Swap ? NB : NA) * ldo, "filter score matrix"), Count(ctx, 4, "survivor counter"), ListQ, ListT;
         uint32_t ns = 0;
         for (;;) {
-            hipok(hipMalloc((void **) &D.pq, std::max<size_t>(cap, 1) * 4), "hipMalloc pairs");
-            hipok(hipMalloc((void **) &D.pt, std::max<size_t>(cap, 1) * 4), "hipMalloc pairs");
-            check(rsk_mu_filter_dev(ctx, FilterQ, FilterT, Tri ? 1 : 0, P.m_ParaMuGapOpen, P.m_ParaMuGapExt, P.m_Omega, P.m_OmegaFwd, D.fwd, ldo,
-                                    D.pq, D.pt, nullptr, nullptr, cap, D.n),
+            ListQ.Make(ctx, cap * 4, "survivor list");
+            ListT.Make(ctx, cap * 4, "survivor list");
+            check(rsk_mu_filter_dev(ctx, FilterQ, FilterT, Tri ? 1 : 0, P.m_ParaMuGapOpen, P.m_ParaMuGapExt, P.m_Omega, P.m_OmegaFwd, Fwd.As<uint8_t>(), ldo,
+                                    ListQ.As<uint32_t>(), ListT.As<uint32_t>(), nullptr, nullptr, cap, Count.As<uint32_t>()),
                   "rsk_mu_filter_dev");
             check(rsk_ctx_sync(ctx), "rsk_ctx_sync");                  // the filter is queued on the context's stream; the copies below are not
-            hipok(hipMemcpy(&ns, D.n, 4, hipMemcpyDeviceToHost), "copy n");
+            hipok(hipMemcpy(&ns, Count.As<uint32_t>(), 4, hipMemcpyDeviceToHost), "copy n");
             if (ns <= cap) break;
-            (void) hipFree(D.pq); (void) hipFree(D.pt);
-            D.pq = D.pt = nullptr;
             cap = ns;
         }
-        d_fwd = D.fwd; d_pq = D.pq; d_pt = D.pt; d_n = D.n;
         tm.lap("  Mu filter kernels");
         std::vector<uint32_t> pq(ns), pt(ns);
-        hipok(hipMemcpy(pq.data(), d_pq, (size_t) ns * 4, hipMemcpyDeviceToHost), "copy pairs");
-        hipok(hipMemcpy(pt.data(), d_pt, (size_t) ns * 4, hipMemcpyDeviceToHost), "copy pairs");
-        (void) hipFree(D.fwd); (void) hipFree(D.pq); (void) hipFree(D.pt); (void) hipFree(D.n);
-        D.fwd = nullptr; D.pq = D.pt = D.n = nullptr;
+        hipok(hipMemcpy(pq.data(), ListQ.As<uint32_t>(), (size_t) ns * 4, hipMemcpyDeviceToHost), "copy pairs");
+        hipok(hipMemcpy(pt.data(), ListT.As<uint32_t>(), (size_t) ns * 4, hipMemcpyDeviceToHost), "copy pairs");
+        Fwd.Free(); ListQ.Free(); ListT.Free(); Count.Free();
         tm.lap("  survivors d2h + free");
         if (Swap) pq.swap(pt);                                               // back to (A-side, B-side)
         // deterministic order (the device list is unordered)
@@ -1161,9 +1179,121 @@ static void RunSelfRange(DBSearcher &Set, uint Lo, uint Hi, FILE *fTsv, PairCoun
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Several devices behind one DBSearcher.  The reference fans the pair space out over threads, one DSSAligner
+// each (dbsearcher.cpp:98-106, runself.cpp:72-101, runquery.cpp:82-125); here the fan-out is over DEVICES: one context and
+// one host thread per entry of m_Devices, each running one shard of the pair space -- a target range of the triangle
+// balanced by DP cells (self search) or a contiguous range of the -db chains balanced by residues, the other side
+// replicated -- through the same single-device code.  No collective on the data path: every shard appends its hit lines
+// to the searcher's hits file (whole lines per fwrite) and the counters are summed.
+// ---------------------------------------------------------------------------------------------
+std::vector<int> DBSearcher::ParseDeviceList(const char *Str)
+{
+    std::vector<int> v;
+    if (!Str) return v;
+    const char *p = Str;
+    while (*p) {
+        while (*p == ',' || *p == ' ') ++p;
+        if (!*p) break;
+        char *end = nullptr;
+        const long d = strtol(p, &end, 10);
+        if (end == p || d < 0 || d > 1023) throw std::runtime_error(std::string("RSK_DEVICES: cannot parse \"") + Str + "\"");
+        v.push_back((int) d);
+        p = end;
+    }
+    return v;
+}
+
+void DBSearcher::SelfShardRange(const uint32_t *Lens, uint64_t N, uint Index, uint Count, uint64_t &Lo, uint64_t &Hi)
+{
+    // cells of the pairs (i <= j) with target j < t, for every t: the shard bounds cut this curve into equal parts
+    std::vector<double> cum(N + 1, 0.0);
+    double pre = 0;
+    for (uint64_t j = 0; j < N; ++j) { pre += Lens[j]; cum[j + 1] = cum[j] + pre * Lens[j]; }
+    auto bound = [&](uint r) { return r >= Count ? N : (uint64_t) (std::lower_bound(cum.begin(), cum.end(), cum[N] * r / Count) - cum.begin()); };
+    Lo = std::min(N, bound(Index));
+    Hi = std::max(Lo, std::min(N, bound(Index + 1)));
+}
+
+void DBSearcher::ResidueShardRange(const uint32_t *Lens, uint64_t N, uint Index, uint Count, uint64_t &Lo, uint64_t &Hi)
+{
+    std::vector<uint64_t> cum(N + 1, 0);
+    for (uint64_t i = 0; i < N; ++i) cum[i + 1] = cum[i] + Lens[i];
+    auto bound = [&](uint r) { return r >= Count ? N : (uint64_t) (std::lower_bound(cum.begin(), cum.end(), cum[N] * r / Count) - cum.begin()); };
+    Lo = std::min(N, bound(Index));
+    Hi = std::max(Lo, std::min(N, bound(Index + 1)));
+}
+
+namespace {
+// One context per entry of the device list, on streams of their own; parked between calls like every helper context.
+struct DeviceTeam {
+    std::vector<std::unique_ptr<SecondaryCtx> > member;
+    explicit DeviceTeam(const std::vector<int> &Devices)
+    {
+        static const char *const roles[] = { "team0", "team1", "team2", "team3", "team4", "team5", "team6", "team7" };
+        for (size_t k = 0; k < Devices.size(); ++k) {
+            member.emplace_back(new SecondaryCtx);
+            member.back()->Create(Devices[k], roles[k % 8]);
+        }
+    }
+    rsk_ctx *ctx(size_t k) const { return member[k]->c; }
+};
+
+// a searcher over the same chains as `Of` that runs on another context: borrowed chains, own device arrays
+void MakeReplica(DBSearcher &R, const DBSearcher &Of, rsk_ctx *Ctx)
+{
+    R.MakeView(Of, 0, Of.GetDBChainCount());
+    R.m_Ctx = Ctx;
+    R.m_fTsv = Of.m_fTsv;
+    R.Setup();
+    R.m_MaxEvalue = Of.m_MaxEvalue;
+    R.m_StreamBatchChains = Of.m_StreamBatchChains;
+    R.m_StreamBatchResidues = Of.m_StreamBatchResidues;
+}
+
+// runs Shard(k, replica k) for every device on a thread of its own; counters of the replicas are summed into `Into`
+void OnEveryDevice(DBSearcher &Into, const std::function<void(uint, DBSearcher &)> &Shard)
+{
+    const uint D = (uint) Into.m_Devices.size();
+    DeviceTeam Team(Into.m_Devices);
+    std::vector<std::unique_ptr<DBSearcher> > Rep(D);
+    std::vector<std::exception_ptr> Err(D);
+    std::vector<std::thread> Th;
+    for (uint k = 0; k < D; ++k)
+        Th.emplace_back([&, k]() {
+            try {
+                (void) hipSetDevice(Into.m_Devices[k]);
+                Rep[k].reset(new DBSearcher);
+                MakeReplica(*Rep[k], Into, Team.ctx(k));
+                Shard(k, *Rep[k]);
+            } catch (...) {
+                Err[k] = std::current_exception();
+            }
+        });
+    for (auto &t : Th) t.join();
+    for (uint k = 0; k < D; ++k)
+        if (Err[k]) std::rethrow_exception(Err[k]);
+    uint64_t pairs = 0, alns = 0, fin = 0, fdis = 0, mkf = 0, hits = 0, sw = 0;
+    for (uint k = 0; k < D; ++k) {
+        const DBSearcher &R = *Rep[k];
+        pairs += R.m_ProcessedPairCount; alns += R.m_AlnCount; fin += R.m_MuFilterInputCount; fdis += R.m_MuFilterDiscardCount;
+        mkf += R.m_MKFPairCount; hits += R.m_HitCount; sw += R.m_SWCount;
+    }
+    Into.m_ProcessedPairCount = pairs; Into.m_AlnCount = alns; Into.m_MuFilterInputCount = fin; Into.m_MuFilterDiscardCount = fdis;
+    Into.m_MKFPairCount = mkf; Into.m_HitCount += hits; Into.m_SWCount += sw;
+}
+}   // namespace
+
+bool DBSearcher::OnSeveralDevices() const { return m_Devices.size() > 1 && !m_HasOnAlnOverride; }
+
 void DBSearcher::RunSelf()
 {
     if (!m_fTsv) m_fTsv = g_fTsv;
+    if (OnSeveralDevices()) {
+        const uint D = (uint) m_Devices.size();
+        OnEveryDevice(*this, [D](uint k, DBSearcher &Replica) { Replica.RunSelfShard(k, D); });
+        return;
+    }
     const uint N = GetDBChainCount();
     if (m_HasOnAlnOverride || (uint64_t) N * N <= FilterTilePairs()) {
         UploadToGpu();
@@ -1175,7 +1305,7 @@ void DBSearcher::RunSelf()
     uint64_t Hits = 0, SW = 0;
     RunSelfRange(*this, 0, N, m_fTsv, C, Hits, SW);
     C.store(*this);
-    m_HitCount += (uint) Hits;
+    m_HitCount += Hits;
     m_SWCount += SW;
 }
 
@@ -1195,11 +1325,11 @@ void DBSearcher::MakeView(const DBSearcher &Src, uint Lo, uint Hi)
 void DBSearcher::RunSelfShard(uint Index, uint Count)
 {
     const uint N = GetDBChainCount();
-    std::vector<double> cum(N + 1, 0.0);         // cells of the pairs (i <= j) up to target j
-    double pre = 0;
-    for (uint j = 0; j < N; ++j) { pre += m_DBChains[j]->GetSeqLength(); cum[j + 1] = cum[j] + pre * m_DBChains[j]->GetSeqLength(); }
-    auto bound = [&](uint r) { return r >= Count ? N : (uint) (std::lower_bound(cum.begin(), cum.end(), cum[N] * r / Count) - cum.begin()); };
-    const uint Lo = std::min(N, bound(Index)), Hi = std::max(Lo, std::min(N, bound(Index + 1)));
+    std::vector<uint32_t> Lens(N);
+    for (uint j = 0; j < N; ++j) Lens[j] = m_DBChains[j]->GetSeqLength();
+    uint64_t Lo64, Hi64;
+    SelfShardRange(Lens.data(), N, Index, Count, Lo64, Hi64);
+    const uint Lo = (uint) Lo64, Hi = (uint) Hi64;
     // this shard = the rectangle chains[0, Lo) x chains[Lo, Hi) plus the triangle of chains[Lo, Hi): no pair of the square
     // [Lo, Hi)^2 below its diagonal is ever scored (a single rectangular pass [0, Hi) x [Lo, Hi) made the first shard do
     // twice its share of the filter)
@@ -1207,7 +1337,7 @@ void DBSearcher::RunSelfShard(uint Index, uint Count)
     uint64_t Hits = 0, SW = 0;
     if (Hi > Lo) RunSelfRange(*this, Lo, Hi, m_fTsv, C, Hits, SW);
     C.store(*this);
-    m_HitCount = (uint) Hits;
+    m_HitCount = Hits;
     m_SWCount = SW;
 }
 
@@ -1215,6 +1345,21 @@ void DBSearcher::RunQuery(DBSearcher &DBChainsSource)
 {
     PhaseTimer tm("RunQuery");
     if (!m_fTsv) m_fTsv = g_fTsv;
+    if (OnSeveralDevices()) {
+        // contiguous ranges of the source chains balanced by residues, our chains replicated on every device
+        const uint D = (uint) m_Devices.size(), NS = DBChainsSource.GetDBChainCount();
+        std::vector<uint32_t> Lens(NS);
+        for (uint i = 0; i < NS; ++i) Lens[i] = DBChainsSource.m_DBChains[i]->GetSeqLength();
+        OnEveryDevice(*this, [&](uint k, DBSearcher &Replica) {
+            uint64_t Lo, Hi;
+            ResidueShardRange(Lens.data(), NS, k, D, Lo, Hi);
+            if (Hi <= Lo) return;
+            DBSearcher Part;
+            Part.MakeView(DBChainsSource, (uint) Lo, (uint) Hi);
+            Replica.RunQuery(Part);
+        });
+        return;
+    }
     UploadToGpu();
     DBChainsSource.m_Ctx = m_Ctx;
     const uint NA = DBChainsSource.GetDBChainCount(), NB = GetDBChainCount();
@@ -1249,6 +1394,23 @@ void DBSearcher::RunQuery(ChainReader2 &QCR)
 {
     if (!m_Ctx) m_Ctx = DefaultCtx();
     if (!m_fTsv) m_fTsv = g_fTsv;
+    if (OnSeveralDevices()) {
+        // every device streams its own range of what the reader has left (balanced by residues) past a replica of our chains
+        const uint D = (uint) m_Devices.size();
+        const uint64_t First = QCR.m_ChainIdx_BCA, End = QCR.m_EndIdx_BCA;
+        const std::string FN = QCR.m_CurrentFN;
+        const uint32_t *Lens = QCR.m_BCA.m_SeqLengths.data() + First;
+        OnEveryDevice(*this, [&](uint k, DBSearcher &Replica) {
+            uint64_t Lo, Hi;
+            ResidueShardRange(Lens, End - First, k, D, Lo, Hi);
+            if (Hi <= Lo) return;
+            ChainReader2 Part;
+            Part.OpenRange(FN, First + Lo, First + Hi);
+            Replica.RunQuery(Part);
+        });
+        QCR.m_ChainIdx_BCA = End;                          // consumed
+        return;
+    }
     UploadToGpu();
     SecondaryCtx loader;
     loader.Create(m_Ctx->device, "loader");
@@ -1322,22 +1484,21 @@ void DSSAligner::AlignPairOnGpu()
               "rsk_db_create");
         return db;
     };
-    rsk_db *a = mk(*m_ChainA, *m_ProfileA, m_MuLettersA, m_SelfRevScoreA), *b = mk(*m_ChainB, *m_ProfileB, m_MuLettersB, m_SelfRevScoreB);
+    struct sets { rsk_db *a = nullptr, *b = nullptr; ~sets() { rsk_db_destroy(a); rsk_db_destroy(b); } } two;
+    two.a = mk(*m_ChainA, *m_ProfileA, m_MuLettersA, m_SelfRevScoreA);
+    two.b = mk(*m_ChainB, *m_ProfileB, m_MuLettersB, m_SelfRevScoreB);
+    rsk_db *const a = two.a, *const b = two.b;
     bool pass = true;
     if (m_Params->m_Omega > 0 && m_MuLettersA && m_MuLettersB) {
         auto hipok = [](hipError_t e, const char *w) { if (e != hipSuccess) throw std::runtime_error(std::string(w) + ": " + hipGetErrorString(e)); };
-        uint8_t *d_fwd = nullptr;
-        uint32_t *d_p = nullptr;
-        hipok(hipMalloc((void **) &d_fwd, 16), "hipMalloc");
-        hipok(hipMalloc((void **) &d_p, 16), "hipMalloc");
-        const int rc = rsk_mu_filter_dev(m_Ctx, a, b, 0, m_Params->m_ParaMuGapOpen, m_Params->m_ParaMuGapExt, m_Params->m_Omega, m_Params->m_OmegaFwd,
-                                         d_fwd, 1, d_p, d_p + 1, nullptr, nullptr, 1, d_p + 2);
+        DeviceBuffer Fwd(m_Ctx, 16, "filter score"), List(m_Ctx, 16, "survivor list");
+        uint32_t *d_p = List.As<uint32_t>();
+        check(rsk_mu_filter_dev(m_Ctx, a, b, 0, m_Params->m_ParaMuGapOpen, m_Params->m_ParaMuGapExt, m_Params->m_Omega, m_Params->m_OmegaFwd,
+                                Fwd.As<uint8_t>(), 1, d_p, d_p + 1, nullptr, nullptr, 1, d_p + 2),
+              "rsk_mu_filter_dev");
+        check(rsk_ctx_sync(m_Ctx), "rsk_ctx_sync");
         uint32_t n = 0;
-        if (rc == RSK_OK) (void) rsk_ctx_sync(m_Ctx);
-        const hipError_t ce = rc == RSK_OK ? hipMemcpy(&n, d_p + 2, 4, hipMemcpyDeviceToHost) : hipSuccess;
-        (void) hipFree(d_fwd); (void) hipFree(d_p);
-        check(rc, "rsk_mu_filter_dev");
-        hipok(ce, "hipMemcpy");
+        hipok(hipMemcpy(&n, d_p + 2, 4, hipMemcpyDeviceToHost), "hipMemcpy");
         pass = n > 0;
     }
     if (pass) {
@@ -1349,11 +1510,17 @@ void DSSAligner::AlignPairOnGpu()
               "rsk_align_pairs");
         SetFromAln(out, paths.data() + out.path_off);
     }
-    rsk_db_destroy(a);
-    rsk_db_destroy(b);
 }
 
 }   // namespace reseek_amd
+
+extern "C" int rsk_shard_range(int kind, const uint32_t *lengths, uint64_t n, uint32_t index, uint32_t count, uint64_t *lo, uint64_t *hi)
+{
+    if ((n && !lengths) || !lo || !hi || count == 0 || index >= count || kind < 0 || kind > 1) { rsk_set_error("rsk_shard_range: invalid argument"); return RSK_E_INVALID; }
+    if (kind == 0) reseek_amd::DBSearcher::SelfShardRange(lengths, n, index, count, *lo, *hi);
+    else reseek_amd::DBSearcher::ResidueShardRange(lengths, n, index, count, *lo, *hi);
+    return RSK_OK;
+}
 
 extern "C" void rsk_ctx_trim(rsk_ctx *ctx)
 {
@@ -1378,6 +1545,10 @@ static bool parse_mode(const char *mode, SearchOptions &o)
 }
 
 void rsk_set_error(const char *fmt, ...);
+namespace reseek_amd {
+void FastDbOnContexts(const std::vector<rsk_ctx *> &Ctx, const char *query_path, const char *db_path, const SearchOptions &o, const char *out_tsv,
+                      const char *tmp_tsv, uint64_t *nhits, uint64_t *stats8);
+}
 
 static bool keep_tmp_env() { const char *e = getenv("RSK_KEEPTMP"); return e && *e && *e != '0'; }    // -keeptmp
 
@@ -1393,11 +1564,23 @@ static int search_impl(rsk_ctx *ctx, const char *query_rskdb, const char *db_rsk
         o2.mode = AM_Sensitive;                  // DM_AlwaysSensitive dssparams.cpp:27-42
         DSSParams Params2;
         Params2.SetDSSParams(o2);
+        const std::vector<int> devs = DBSearcher::ParseDeviceList(o.devices.empty() ? getenv("RSK_DEVICES") : o.devices.c_str());
+        if (prefilter_path && devs.size() > 1 && o.shard_count <= 1) {
+            // the two-stage path on several devices: one target shard per context, the top-B exchange in host memory
+            DeviceTeam Team(devs);
+            std::vector<rsk_ctx *> cs;
+            for (size_t k = 0; k < devs.size(); ++k) cs.push_back(Team.ctx(k));
+            const std::string tmp = std::string(out_tsv) + ".prefilter.tmp";
+            const bool keep = o.keeptmp || keep_tmp_env();
+            FastDbOnContexts(cs, query_rskdb, db_rskdb, o, out_tsv, keep ? tmp.c_str() : nullptr, nhits, stats8);
+            return RSK_OK;
+        }
         DBSearcher DBS;                       // SelfSearch search.cpp:20-37 / Search_NoMuFilter :39-60
         DBS.m_Params = prefilter_path ? &Params2 : &Params;
         DBS.m_SelfRevQueryFlavour = prefilter_path;      // PostMuFilter computes query self-rev scores itself (postmufilter.cpp:79)
         DBS.m_Opts = o;
         DBS.m_Ctx = ctx;
+        if (!o.devices.empty()) DBS.m_Devices = DBSearcher::ParseDeviceList(o.devices.c_str());
         DBS.LoadDB(query_rskdb);
         DBS.Setup();
         for (USERFIELD u : DBS.m_DA.m_UFs)
@@ -1442,11 +1625,8 @@ static int search_impl(rsk_ctx *ctx, const char *query_rskdb, const char *db_rsk
                     // -db mode: contiguous target shards balanced by residues, the query set is replicated
                     BCAData B;
                     B.Open(dbfn);
-                    const uint64_t NS = B.GetChainCount();
-                    std::vector<uint64_t> cum(NS + 1, 0);
-                    for (uint64_t i = 0; i < NS; ++i) cum[i + 1] = cum[i] + B.m_SeqLengths[i];
-                    auto bound = [&](uint r) { return r >= o.shard_count ? NS : (uint64_t) (std::lower_bound(cum.begin(), cum.end(), cum[NS] * r / o.shard_count) - cum.begin()); };
-                    const uint64_t Lo = std::min(NS, bound(o.shard_index)), Hi = std::max(Lo, std::min(NS, bound(o.shard_index + 1)));
+                    uint64_t Lo, Hi;
+                    DBSearcher::ResidueShardRange(B.m_SeqLengths.data(), B.GetChainCount(), o.shard_index, o.shard_count, Lo, Hi);
                     CR.OpenRange(dbfn, Lo, Hi);
                 } else
                     CR.Open(dbfn);
@@ -1462,12 +1642,12 @@ static int search_impl(rsk_ctx *ctx, const char *query_rskdb, const char *db_rsk
             if (o.shard_count > 1) {
                 // -db mode: contiguous target shards balanced by residues, the query set is replicated
                 const uint NS = Src.GetDBChainCount();
-                std::vector<uint64_t> cum(NS + 1, 0);
-                for (uint i = 0; i < NS; ++i) cum[i + 1] = cum[i] + Src.m_DBChains[i]->GetSeqLength();
-                auto bound = [&](uint r) { return r >= o.shard_count ? NS : (uint) (std::lower_bound(cum.begin(), cum.end(), cum[NS] * r / o.shard_count) - cum.begin()); };
-                const uint Lo = std::min(NS, bound(o.shard_index)), Hi = std::max(Lo, std::min(NS, bound(o.shard_index + 1)));
+                std::vector<uint32_t> Lens(NS);
+                for (uint i = 0; i < NS; ++i) Lens[i] = Src.m_DBChains[i]->GetSeqLength();
+                uint64_t Lo, Hi;
+                DBSearcher::ResidueShardRange(Lens.data(), NS, o.shard_index, o.shard_count, Lo, Hi);
                 DBSearcher View;
-                View.MakeView(Src, Lo, Hi);
+                View.MakeView(Src, (uint) Lo, (uint) Hi);
                 if (Hi > Lo) DBS.RunQuery(View);
             } else
                 DBS.RunQuery(Src);
@@ -1518,5 +1698,6 @@ extern "C" int rsk_search(rsk_ctx *ctx, const char *query_path, const char *db_p
     o.keeptmp = opts->keeptmp != 0;
     o.shard_index = opts->shard_index;
     o.shard_count = opts->shard_count;
+    if (opts->devices) o.devices = opts->devices;
     return search_impl(ctx, query_path, db_path, o, out_tsv, nhits, stats8);
 }

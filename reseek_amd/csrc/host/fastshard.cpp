@@ -9,9 +9,12 @@
 // equal-scoring candidates its quicksort leaves in front (arrival-order dependent); the two agree whenever no
 // query has more than B candidates or the B-th score is not tied, and in every case the kept set is a valid top-B.
 #include <algorithm>
+#include <exception>
+#include <functional>
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "reseek_host.h"
@@ -97,15 +100,10 @@ static bool parse_opts(const rsk_search_opts *opts, SearchOptions &o)
     return true;
 }
 
-extern "C" int rsk_fast_shard_open(rsk_ctx *ctx, const char *query_path, const char *db_path, const rsk_search_opts *opts, rsk_fast_shard **out)
+// stage 1 of one shard (throws): S->o holds the options incl. shard_index / shard_count
+static void FastShardOpen(rsk_fast_shard *S, rsk_ctx *ctx, const char *query_path, const char *db_path)
 {
-    if (!ctx || !query_path || !db_path || !opts || !out) { rsk_set_error("rsk_fast_shard_open: NULL argument"); return RSK_E_INVALID; }
-    *out = nullptr;
-    std::unique_ptr<rsk_fast_shard> S(new rsk_fast_shard);
-    if (!parse_opts(opts, S->o)) { rsk_set_error("rsk_fast_shard_open: mode must be \"fast\" (the other modes shard through rsk_search)"); return RSK_E_INVALID; }
-    if (S->o.shard_index >= S->o.shard_count) { rsk_set_error("rsk_fast_shard_open: shard_index >= shard_count"); return RSK_E_INVALID; }
-    if (opts->idx_mode < 0 || opts->idx_mode > 2) { rsk_set_error("rsk_fast_shard_open: idx_mode must be 0, 1 or 2"); return RSK_E_INVALID; }
-    try {
+    {
         S->ctx = ctx;
         S->db_path = db_path;
         if (!(S->db_path.size() >= 4 && S->db_path.compare(S->db_path.size() - 4, 4, ".bca") == 0))
@@ -129,21 +127,15 @@ extern "C" int rsk_fast_shard_open(rsk_ctx *ctx, const char *query_path, const c
             std::vector<std::vector<byte> > All;
             ReadMuFasta(S->o.dbmu, Labels, All);
             S->NT = All.size();
-            std::vector<uint64_t> cum(S->NT + 1, 0);
-            for (uint64_t i = 0; i < S->NT; ++i) cum[i + 1] = cum[i] + All[i].size();
-            auto bound = [&](uint r) { return r >= S->o.shard_count ? S->NT : (uint64_t) (std::lower_bound(cum.begin(), cum.end(), cum[S->NT] * r / S->o.shard_count) - cum.begin()); };
-            S->Lo = std::min(S->NT, bound(S->o.shard_index));
-            S->Hi = std::max(S->Lo, std::min(S->NT, bound(S->o.shard_index + 1)));
+            std::vector<uint32_t> Lens(S->NT);
+            for (uint64_t i = 0; i < S->NT; ++i) Lens[i] = (uint32_t) All[i].size();
+            DBSearcher::ResidueShardRange(Lens.data(), S->NT, S->o.shard_index, S->o.shard_count, S->Lo, S->Hi);
             TSeqs.assign(All.begin() + S->Lo, All.begin() + S->Hi);
         } else {
             BCAData B;
             B.Open(S->db_path);
             S->NT = B.GetChainCount();
-            std::vector<uint64_t> cum(S->NT + 1, 0);
-            for (uint64_t i = 0; i < S->NT; ++i) cum[i + 1] = cum[i] + B.m_SeqLengths[i];
-            auto bound = [&](uint r) { return r >= S->o.shard_count ? S->NT : (uint64_t) (std::lower_bound(cum.begin(), cum.end(), cum[S->NT] * r / S->o.shard_count) - cum.begin()); };
-            S->Lo = std::min(S->NT, bound(S->o.shard_index));
-            S->Hi = std::max(S->Lo, std::min(S->NT, bound(S->o.shard_index + 1)));
+            DBSearcher::ResidueShardRange(B.m_SeqLengths.data(), S->NT, S->o.shard_index, S->o.shard_count, S->Lo, S->Hi);
             MuSeqSource SS;
             SS.m_IsFasta = false;
             SS.m_Params = &S->Params;
@@ -174,6 +166,19 @@ extern "C" int rsk_fast_shard_open(rsk_ctx *ctx, const char *query_path, const c
             for (uint32_t &t : ht) t += (uint32_t) S->Lo;
             TopB(hq.data(), ht.data(), hs.data(), hq.size(), NQ, S->o.rsb_size, S->cq, S->ct, S->cs);
         }
+    }
+}
+
+extern "C" int rsk_fast_shard_open(rsk_ctx *ctx, const char *query_path, const char *db_path, const rsk_search_opts *opts, rsk_fast_shard **out)
+{
+    if (!ctx || !query_path || !db_path || !opts || !out) { rsk_set_error("rsk_fast_shard_open: NULL argument"); return RSK_E_INVALID; }
+    *out = nullptr;
+    std::unique_ptr<rsk_fast_shard> S(new rsk_fast_shard);
+    if (!parse_opts(opts, S->o)) { rsk_set_error("rsk_fast_shard_open: mode must be \"fast\" (the other modes shard through rsk_search)"); return RSK_E_INVALID; }
+    if (S->o.shard_index >= S->o.shard_count) { rsk_set_error("rsk_fast_shard_open: shard_index >= shard_count"); return RSK_E_INVALID; }
+    if (opts->idx_mode < 0 || opts->idx_mode > 2) { rsk_set_error("rsk_fast_shard_open: idx_mode must be 0, 1 or 2"); return RSK_E_INVALID; }
+    try {
+        FastShardOpen(S.get(), ctx, query_path, db_path);
     } catch (const std::exception &e) {
         rsk_set_error("rsk_fast_shard_open: %s", e.what());
         return RSK_E_INVALID;
@@ -189,11 +194,11 @@ extern "C" int rsk_fast_shard_candidates(rsk_fast_shard *S, const uint32_t **q, 
     return RSK_OK;
 }
 
-extern "C" int rsk_fast_shard_finish(rsk_fast_shard *S, const uint32_t *q, const uint32_t *t, const uint32_t *score, size_t n,
-                                     const char *out_tsv, const char *tmp_tsv, uint64_t *nhits, uint64_t *stats8)
+// stage 2 of one shard (throws)
+static void FastShardFinish(rsk_fast_shard *S, const uint32_t *q, const uint32_t *t, const uint32_t *score, size_t n, const char *out_tsv,
+                            const char *tmp_tsv, uint64_t *nhits, uint64_t *stats8)
 {
-    if (!S || !out_tsv || (n && (!q || !t || !score))) { rsk_set_error("rsk_fast_shard_finish: NULL argument"); return RSK_E_INVALID; }
-    try {
+    {
         const uint NQ = S->Q.GetDBChainCount();
         std::vector<uint32_t> mq, mt, ms;
         TopB(q, t, score, n, NQ, S->o.rsb_size, mq, mt, ms);
@@ -249,11 +254,80 @@ extern "C" int rsk_fast_shard_finish(rsk_fast_shard *S, const uint32_t *q, const
             stats8[3] = S->Q.m_MuFilterDiscardCount; stats8[4] = S->Q.m_MKFPairCount; stats8[5] = S->Q.m_SWCount;
             stats8[6] = S->Q.m_HitCount; stats8[7] = 1;
         }
+    }
+}
+
+extern "C" int rsk_fast_shard_finish(rsk_fast_shard *S, const uint32_t *q, const uint32_t *t, const uint32_t *score, size_t n,
+                                     const char *out_tsv, const char *tmp_tsv, uint64_t *nhits, uint64_t *stats8)
+{
+    if (!S || !out_tsv || (n && (!q || !t || !score))) { rsk_set_error("rsk_fast_shard_finish: NULL argument"); return RSK_E_INVALID; }
+    try {
+        FastShardFinish(S, q, t, score, n, out_tsv, tmp_tsv, nhits, stats8);
     } catch (const std::exception &e) {
         rsk_set_error("rsk_fast_shard_finish: %s", e.what());
         return RSK_E_INVALID;
     }
     return RSK_OK;
 }
+
+// `-search -fast -db` on several devices of ONE process: one target shard per context, each stage on a host thread per
+// shard; the exchange between the stages (all ranks' local top-B lists -> every rank) is a concatenation in host memory.
+// The shards' hit tables are appended to out_tsv in shard order; the hand-off file of the merged bags goes to tmp_tsv.
+namespace reseek_amd {
+void FastDbOnContexts(const std::vector<rsk_ctx *> &Ctx, const char *query_path, const char *db_path, const SearchOptions &o, const char *out_tsv,
+                      const char *tmp_tsv, uint64_t *nhits, uint64_t *stats8)
+{
+    const uint D = (uint) Ctx.size();
+    std::vector<std::unique_ptr<rsk_fast_shard> > Sh(D);
+    std::vector<std::exception_ptr> Err(D);
+    auto on_all = [&](const std::function<void(uint)> &fn) {
+        std::vector<std::thread> Th;
+        for (uint k = 0; k < D; ++k)
+            Th.emplace_back([&, k]() { try { fn(k); } catch (...) { Err[k] = std::current_exception(); } });
+        for (auto &t : Th) t.join();
+        for (uint k = 0; k < D; ++k)
+            if (Err[k]) std::rethrow_exception(Err[k]);
+    };
+    on_all([&](uint k) {
+        Sh[k].reset(new rsk_fast_shard);
+        Sh[k]->o = o;
+        Sh[k]->o.mode = AM_Fast;
+        Sh[k]->o.shard_index = k;
+        Sh[k]->o.shard_count = D;
+        FastShardOpen(Sh[k].get(), Ctx[k], query_path, db_path);
+    });
+    std::vector<uint32_t> aq, at, as;
+    for (uint k = 0; k < D; ++k) {
+        aq.insert(aq.end(), Sh[k]->cq.begin(), Sh[k]->cq.end());
+        at.insert(at.end(), Sh[k]->ct.begin(), Sh[k]->ct.end());
+        as.insert(as.end(), Sh[k]->cs.begin(), Sh[k]->cs.end());
+    }
+    std::vector<uint64_t> Hits(D, 0);
+    std::vector<std::vector<uint64_t> > Stats(D, std::vector<uint64_t>(8, 0));
+    on_all([&](uint k) {
+        const std::string part = std::string(out_tsv) + ".shard" + std::to_string(k);
+        FastShardFinish(Sh[k].get(), aq.data(), at.data(), as.data(), aq.size(), part.c_str(), k == 0 ? tmp_tsv : nullptr, &Hits[k], Stats[k].data());
+    });
+    FILE *f = fopen(out_tsv, "w");
+    if (!f) throw std::runtime_error(std::string("cannot create ") + out_tsv);
+    std::vector<char> buf(1 << 20);
+    for (uint k = 0; k < D; ++k) {
+        const std::string part = std::string(out_tsv) + ".shard" + std::to_string(k);
+        if (FILE *g = fopen(part.c_str(), "r")) {
+            size_t got;
+            while ((got = fread(buf.data(), 1, buf.size(), g)) > 0)
+                if (fwrite(buf.data(), 1, got, f) != got) { fclose(g); fclose(f); throw std::runtime_error("short write to the hits file"); }
+            fclose(g);
+        }
+        remove(part.c_str());
+    }
+    fclose(f);
+    if (nhits) { *nhits = 0; for (uint k = 0; k < D; ++k) *nhits += Hits[k]; }
+    if (stats8) {
+        for (int c = 0; c < 7; ++c) { stats8[c] = 0; for (uint k = 0; k < D; ++k) stats8[c] += Stats[k][c]; }
+        stats8[7] = 1;
+    }
+}
+}   // namespace reseek_amd
 
 extern "C" void rsk_fast_shard_close(rsk_fast_shard *S) { delete S; }

@@ -84,26 +84,21 @@ void MuPreFilterScan(rsk_ctx *ctx, const std::vector<uint32_t> &qlen, const std:
     auto hipok = [](hipError_t e, const char *w) { if (e != hipSuccess) throw std::runtime_error(std::string(w) + ": " + hipGetErrorString(e)); };
     // every (query, target) can appear at most once
     size_t cap = (size_t) std::min<uint64_t>((uint64_t) NQ * NT, 1ull << 28);
-    uint32_t *d_q = nullptr, *d_t = nullptr, *d_s = nullptr, *d_n = nullptr;
     hq.clear(); ht.clear(); hs.clear();
+    DeviceBuffer Count(ctx, 4, "prefilter result counter");
     for (;;) {
-        hipok(hipMalloc((void **) &d_q, std::max<size_t>(cap, 1) * 4), "hipMalloc");
-        hipok(hipMalloc((void **) &d_t, std::max<size_t>(cap, 1) * 4), "hipMalloc");
-        hipok(hipMalloc((void **) &d_s, std::max<size_t>(cap, 1) * 4), "hipMalloc");
-        hipok(hipMalloc((void **) &d_n, 4), "hipMalloc");
-        const int rc = rsk_mu_prefilter_dev(ctx, qdb, tdb, idx_mode, d_q, d_t, d_s, cap, d_n);
+        DeviceBuffer Q(ctx, cap * 4, "prefilter results"), T(ctx, cap * 4, "prefilter results"), S(ctx, cap * 4, "prefilter results");
+        check(rsk_mu_prefilter_dev(ctx, qdb, tdb, idx_mode, Q.As<uint32_t>(), T.As<uint32_t>(), S.As<uint32_t>(), cap, Count.As<uint32_t>()), "rsk_mu_prefilter_dev");
+        check(rsk_ctx_sync(ctx), "rsk_ctx_sync");
         uint32_t n = 0;
-        if (rc == RSK_OK) check(rsk_ctx_sync(ctx), "rsk_ctx_sync");
-        if (rc == RSK_OK) hipok(hipMemcpy(&n, d_n, 4, hipMemcpyDeviceToHost), "copy n");
-        if (rc == RSK_OK && n <= cap) {
+        hipok(hipMemcpy(&n, Count.As<uint32_t>(), 4, hipMemcpyDeviceToHost), "copy n");
+        if (n <= cap) {
             hq.resize(n); ht.resize(n); hs.resize(n);
-            hipok(hipMemcpy(hq.data(), d_q, (size_t) n * 4, hipMemcpyDeviceToHost), "copy");
-            hipok(hipMemcpy(ht.data(), d_t, (size_t) n * 4, hipMemcpyDeviceToHost), "copy");
-            hipok(hipMemcpy(hs.data(), d_s, (size_t) n * 4, hipMemcpyDeviceToHost), "copy");
+            hipok(hipMemcpy(hq.data(), Q.As<uint32_t>(), (size_t) n * 4, hipMemcpyDeviceToHost), "copy");
+            hipok(hipMemcpy(ht.data(), T.As<uint32_t>(), (size_t) n * 4, hipMemcpyDeviceToHost), "copy");
+            hipok(hipMemcpy(hs.data(), S.As<uint32_t>(), (size_t) n * 4, hipMemcpyDeviceToHost), "copy");
+            break;
         }
-        (void) hipFree(d_q); (void) hipFree(d_t); (void) hipFree(d_s); (void) hipFree(d_n);
-        check(rc, "rsk_mu_prefilter_dev");
-        if (n <= cap) break;
         cap = n;                               // the count is exact even when the list was truncated
     }
     tm.lap("index + scan (GPU)");

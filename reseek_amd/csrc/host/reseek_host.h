@@ -85,6 +85,7 @@ struct SearchOptions {
     bool fast_set() const { return mode == AM_Fast; }  // optset_fast
     bool keeptmp = false;                              // -keeptmp
     uint shard_index = 0, shard_count = 0;             // multi-GPU: this rank's shard of the targets (0/0 or x/1 = everything)
+    std::string devices;                               // one process, several devices: "0,1,2,3" (DBSearcher::m_Devices); "" = RSK_DEVICES
     size_t batch_pairs = 1u << 20;                     // upper bound of pairs per GPU alignment batch
     uint64_t batch_cells = 24ull << 30;                // ... and of DP cells per batch (~1 trace byte per cell in HBM)
 };
@@ -103,6 +104,23 @@ void CloseOutputFiles();                                // output.cpp:15
 // A library needs a device context where the reference has none: DBSearcher / DSSAligner objects whose m_Ctx was never
 // set use this one (created on first use on device RSK_DEVICE, default 0; destroyed at exit).
 rsk_ctx *DefaultCtx();
+
+// A device allocation made by the host layer itself (survivor lists, counters): on the context's device, through the
+// library's out-of-memory ladder (cached pool blocks and idle helper contexts are released before it fails), freed on
+// every exit path.  Make() also makes the context's device the calling thread's current one, so the caller's plain
+// hipMemcpy calls on the buffer are safe in a process that drives several devices.
+class DeviceBuffer {
+    void *m_Ptr = nullptr;
+public:
+    DeviceBuffer() = default;
+    DeviceBuffer(rsk_ctx *Ctx, size_t Bytes, const char *What) { Make(Ctx, Bytes, What); }
+    DeviceBuffer(const DeviceBuffer &) = delete;
+    DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+    ~DeviceBuffer() { Free(); }
+    void Make(rsk_ctx *Ctx, size_t Bytes, const char *What);     // throws std::runtime_error
+    void Free();
+    template <class T> T *As() const { return (T *) m_Ptr; }
+};
 
 class DSSParams {
 public:
@@ -372,7 +390,7 @@ public:
     std::vector<float> m_DBSelfRevScores;
     std::vector<std::vector<std::vector<byte> > > m_RevProfiles;   // LoadBCA -> ComputeSelfRevScores: profiles of the reversed chains
     double m_MaxEvalue = 10;
-    uint m_HitCount = 0;
+    uint64_t m_HitCount = 0;
     uint64_t m_ProcessedPairCount = 0;
     // run statistics (cf. DSSAligner::Stats dssaligner.cpp:1088)
     uint64_t m_AlnCount = 0, m_MuFilterInputCount = 0, m_MuFilterDiscardCount = 0, m_MKFPairCount = 0, m_SWCount = 0;
@@ -406,6 +424,16 @@ public:
     void LoadChains(std::vector<PDBChain *> &Chains);   // take ownership, featurise on the host threads, self-rev scores on the GPU
     bool m_OwnsChains = true;
     void MakeView(const DBSearcher &Src, uint Lo, uint Hi);
+    // Devices this searcher drives.  Empty or one entry = the device of m_Ctx.  Setup() fills it from
+    // RSK_DEVICES ("0,1,2,3"; an id may repeat = several contexts on one device) unless the caller set it.  With several
+    // entries RunSelf / RunQuery run one shard per entry, each on a host thread and a context of its own.
+    std::vector<int> m_Devices;
+    bool OnSeveralDevices() const;
+    static std::vector<int> ParseDeviceList(const char *Str);      // "0,1,2" -> {0, 1, 2}; throws on anything else
+    // shard bounds (pure arithmetic): targets [Lo, Hi) of the self-search triangle with equal DP cells per shard; contiguous
+    // chain ranges with equal residues per shard
+    static void SelfShardRange(const uint32_t *Lens, uint64_t N, uint Index, uint Count, uint64_t &Lo, uint64_t &Hi);
+    static void ResidueShardRange(const uint32_t *Lens, uint64_t N, uint Index, uint Count, uint64_t &Lo, uint64_t &Hi);
     void RunSelfShard(uint Index, uint Count);          // one rank's part of the self-search triangle
     bool Reject(DSSAligner &DA, bool Up) const;         // dbsearcher.cpp:258
     void BaseOnAln(DSSAligner &DA, bool Up);            // dbsearcher.cpp:267

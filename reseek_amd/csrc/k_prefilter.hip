@@ -448,22 +448,22 @@ __global__ __launch_bounds__(PF_THREADS) void k_prefilter(pf_args a)
 // ---------------------------------------------------------------------------------------------
 // host: index build (P10) + launch
 // ---------------------------------------------------------------------------------------------
-int rsk_build_mudex(rsk_db *db, int mode)
+int rsk_build_mudex(rsk_ctx *ctx, rsk_db *db, int mode)
 {
     if (db->mudex_built && db->mudex_mode == mode) return RSK_OK;
     if (db->n > 65535) { rsk_set_error("k-mer prefilter: at most 65535 query chains (uint16 query index, prefiltermu.cpp:296)"); return RSK_E_RANGE; }
     for (uint32_t L : db->len)
         if (L > 65535) { rsk_set_error("k-mer prefilter: query longer than 65535 (uint16 position)"); return RSK_E_RANGE; }
     if (db->d_pf_postings) { (void) hipFree(db->d_pf_postings); db->d_pf_postings = nullptr; db->hbm_bytes -= db->pf_postings * 4; }
-    // temporaries through the context's pool (returned on every exit path); everything on the context's stream
-    rsk_ctx *ctx = db->ctx;
+    // temporaries through the CALLING context's pool (returned on every exit path); everything on that context's stream
+    // (the context that created the set may be another thread's, e.g. the -db loader's)
     rsk_scratch ws(ctx);
     uint32_t *d_cnt, *d_start;
     unsigned long long *d_total, total = 0;
     void *d_tmp;
     int rc;
     if (!db->d_pf_table) {
-        RSK_HIP(hipMalloc((void **) &db->d_pf_table, (size_t) PF_DICT * sizeof(uint2)));
+        { const int rc_ = rsk_dev_malloc(nullptr, (void **) &db->d_pf_table, (size_t) PF_DICT * sizeof(uint2)); if (rc_ != RSK_OK) return rc_; }
         db->hbm_bytes += (size_t) PF_DICT * sizeof(uint2);
     }
     if ((rc = ws.alloc(&d_cnt, (size_t) PF_DICT)) || (rc = ws.alloc(&d_start, (size_t) PF_DICT)) || (rc = ws.alloc(&d_total, 1))) return rc;
@@ -480,7 +480,7 @@ int rsk_build_mudex(rsk_db *db, int mode)
     if ((rc = ws.alloc(&d_tmp, std::max<size_t>(tmp_bytes, 16))) != RSK_OK) return rc;
     RSK_HIP(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_cnt, d_start, (int) PF_DICT, ctx->stream));
     hipLaunchKernelGGL(k_pf_make_table, dim3((PF_DICT + 255) / 256), dim3(256), 0, ctx->stream, d_start, d_cnt, (uint2 *) db->d_pf_table);
-    RSK_HIP(hipMalloc((void **) &db->d_pf_postings, std::max<size_t>((size_t) total, 1) * 4));
+    { const int rc_ = rsk_dev_malloc(nullptr, (void **) &db->d_pf_postings, std::max<size_t>((size_t) total, 1) * 4); if (rc_ != RSK_OK) return rc_; }
     if (db->n) hipLaunchKernelGGL(k_pf_hood, dim3(db->n), dim3(256), 0, ctx->stream, db->d_mu, db->d_off, db->d_len, mode, 1, d_cnt,
                                   (const uint2 *) db->d_pf_table, db->d_pf_postings, d_total);
     RSK_HIP(hipGetLastError());
@@ -502,7 +502,7 @@ extern "C" int rsk_mu_prefilter_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db 
     if (rc != RSK_OK) return rc;
     if (neighbourhood < -1 || neighbourhood > 2) { rsk_set_error("rsk_mu_prefilter_dev: neighbourhood must be -1, 0, 1 or 2"); return RSK_E_INVALID; }
     if (neighbourhood == -1) neighbourhood = q->n <= 100 ? 1 : 2;      // MAX_QUERY_CHAINS_FOR_QUERY_NEIGHBORHOOD muprefilter.cpp:78-87
-    if ((rc = rsk_build_mudex(const_cast<rsk_db *>(q), neighbourhood)) != RSK_OK) return rc;
+    if ((rc = rsk_build_mudex(ctx, const_cast<rsk_db *>(q), neighbourhood)) != RSK_OK) return rc;
     for (uint32_t L : t->len)
         if (L > 65534) { rsk_set_error("rsk_mu_prefilter_dev: target longer than 65534"); return RSK_E_RANGE; }
     rsk_scratch ws(ctx);                       // every temporary goes back to the pool on every exit path

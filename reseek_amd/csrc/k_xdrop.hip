@@ -634,10 +634,9 @@ extern "C" int rsk_xdrop_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
         ~ws_t() { for (void *p : all) (void) hipFree(p); }
         int alloc(void **p, size_t bytes)
         {
-            hipError_t e = hipMalloc(p, bytes ? bytes : 16);
-            if (e != hipSuccess) return rsk_hip_fail(e, "hipMalloc", __FILE__, __LINE__);
-            all.push_back(*p);
-            return RSK_OK;
+            const int rc_ = rsk_dev_malloc(nullptr, p, bytes ? bytes : 16);
+            if (rc_ == RSK_OK) all.push_back(*p);
+            return rc_;
         }
     };
     // sub-batches bounded by the trace scratch (the rest is small)

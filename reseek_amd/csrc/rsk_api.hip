@@ -64,6 +64,31 @@ int rsk_scratch::alloc(void **p, size_t bytes)
     return r;
 }
 
+static std::atomic<void (*)(int)> g_oom_hook{nullptr};
+void rsk_set_oom_hook(void (*release_idle)(int device)) { g_oom_hook.store(release_idle); }
+
+int rsk_dev_malloc(rsk_ctx *ctx, void **p, size_t bytes)
+{
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipSuccess) return RSK_OK;
+    (void) hipGetLastError();
+    if (ctx) {
+        rsk_pool_release(ctx);
+        if ((e = hipMalloc(p, bytes)) == hipSuccess) return RSK_OK;
+        (void) hipGetLastError();
+    }
+    if (auto hook = g_oom_hook.load()) {
+        int dev = 0;
+        (void) hipGetDevice(&dev);
+        hook(dev);
+        if ((e = hipMalloc(p, bytes)) == hipSuccess) return RSK_OK;
+        (void) hipGetLastError();
+    }
+    *p = nullptr;
+    rsk_set_error("out of device memory allocating %zu bytes (%s)", bytes, hipGetErrorString(e));
+    return RSK_E_NOMEM;
+}
+
 int rsk_pool_alloc(rsk_ctx *ctx, void **p, size_t bytes)
 {
     size_t cls = 256;
@@ -85,15 +110,11 @@ int rsk_pool_alloc(rsk_ctx *ctx, void **p, size_t bytes)
     }
     static const bool trace = getenv("RSK_TRACE") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
-    hipError_t e = hipMalloc(p, cls);
+    const int rc = rsk_dev_malloc(ctx, p, cls);      // on failure: drops this context's cached blocks, then the idle helper contexts' pools
     if (trace && cls >= (64u << 20))
         fprintf(stderr, "[pool] hipMalloc %.2f GB (pool of this context %.2f GB) took %.2f ms\n", cls / 1073741824.0, ctx->pool_bytes / 1073741824.0,
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-    if (e != hipSuccess) {
-        rsk_pool_release(ctx);                       // drop cached blocks and retry once
-        e = hipMalloc(p, cls);
-        if (e != hipSuccess) { rsk_set_error("out of device memory allocating %zu bytes", cls); *p = nullptr; return RSK_E_NOMEM; }
-    }
+    if (rc != RSK_OK) return rc;
     ctx->pool_live[*p] = cls;
     ctx->pool_bytes += cls;
     return RSK_OK;
@@ -130,7 +151,7 @@ int rsk_pinned(rsk_ctx *ctx, int slot, size_t bytes, void **p)
         ctx->pin_bytes[slot] = 0;
         size_t cap = 1 << 20;
         while (cap < bytes) cap <<= 1;
-        if (hipHostMalloc(&ctx->pin[slot], cap, hipHostMallocDefault) != hipSuccess) {
+        if (hipHostMalloc(&ctx->pin[slot], cap, hipHostMallocPortable) != hipSuccess) {
             rsk_set_error("out of pinned host memory allocating %zu bytes", cap);
             return RSK_E_NOMEM;
         }
@@ -195,11 +216,12 @@ __global__ void k_db_derive(const uint8_t *prof, size_t npad, uint16_t *cb, uint
 }
 
 template <class T>
-static int dev_upload(T **d, const T *h, size_t count, uint64_t &bytes)
+static int dev_upload(rsk_ctx *ctx, T **d, const T *h, size_t count, uint64_t &bytes)
 {
     *d = nullptr;
     if (count == 0) return RSK_OK;
-    RSK_HIP(hipMalloc((void **) d, count * sizeof(T) + 64));      // slack: kernels read whole dwords / strips past the last padded chain
+    const int rc = rsk_dev_malloc(ctx, (void **) d, count * sizeof(T) + 64);      // slack: kernels read whole dwords / strips past the last padded chain
+    if (rc != RSK_OK) return rc;
     RSK_HIP(hipMemcpy(*d, h, count * sizeof(T), hipMemcpyHostToDevice));
     bytes += count * sizeof(T);
     return RSK_OK;
@@ -236,8 +258,8 @@ extern "C" int rsk_db_create(rsk_ctx *ctx, uint32_t n, const uint32_t *lengths, 
     db->nres = nres;
     db->npad = o;
     int rc;
-    if ((rc = dev_upload(&db->d_len, db->len.data(), n, db->hbm_bytes)) != RSK_OK) return rc;
-    if ((rc = dev_upload(&db->d_off, db->off.data(), (size_t) n + 1, db->hbm_bytes)) != RSK_OK) return rc;
+    if ((rc = dev_upload(ctx, &db->d_len, db->len.data(), n, db->hbm_bytes)) != RSK_OK) return rc;
+    if ((rc = dev_upload(ctx, &db->d_off, db->off.data(), (size_t) n + 1, db->hbm_bytes)) != RSK_OK) return rc;
     // packing into the padded device layout runs on the host threads, chains are independent (src[i] = residues before chain i)
     std::vector<uint64_t> src((size_t) n + 1, 0);
     for (uint32_t i = 0; i < n; ++i) src[i + 1] = src[i] + lengths[i];
@@ -264,7 +286,7 @@ extern "C" int rsk_db_create(rsk_ctx *ctx, uint32_t n, const uint32_t *lengths, 
             rsk_set_error("rsk_db_create: Mu letter %u out of range in chain %u", c, i);
             return RSK_E_INVALID;
         }
-        if ((rc = dev_upload(&db->d_mu, db->h_mu.data(), db->h_mu.size(), db->hbm_bytes)) != RSK_OK) return rc;
+        if ((rc = dev_upload(ctx, &db->d_mu, db->h_mu.data(), db->h_mu.size(), db->hbm_bytes)) != RSK_OK) return rc;
     }
     if (prof) {
         std::unique_ptr<uint8_t[]> hp_mem(new uint8_t[(size_t) RSK_NFEAT * o + 1]);   // not value-initialised: chains are copied, pads zeroed below
@@ -295,12 +317,12 @@ extern "C" int rsk_db_create(rsk_ctx *ctx, uint32_t n, const uint32_t *lengths, 
             rsk_set_error("rsk_db_create: profile letter %u out of range (chain %u feature %d)", mx, i, f);
             return RSK_E_INVALID;
         }
-        if ((rc = dev_upload(&db->d_prof, hp, (size_t) RSK_NFEAT * o, db->hbm_bytes)) != RSK_OK) return rc;
+        if ((rc = dev_upload(ctx, &db->d_prof, hp, (size_t) RSK_NFEAT * o, db->hbm_bytes)) != RSK_OK) return rc;
         // the float-SW kernels read letter * 4 (column offsets) and letter * alphabet * 4 (row offsets) per feature,
         // residue-major: derived on the device from the bytes just uploaded
         const size_t nrec = ((size_t) o + 64) * 8;
-        RSK_HIP(hipMalloc((void **) &db->d_prof_cb, nrec * 2));
-        RSK_HIP(hipMalloc((void **) &db->d_prof_ra, nrec * 2));
+        if ((rc = rsk_dev_malloc(ctx, (void **) &db->d_prof_cb, nrec * 2)) != RSK_OK) return rc;
+        if ((rc = rsk_dev_malloc(ctx, (void **) &db->d_prof_ra, nrec * 2)) != RSK_OK) return rc;
         db->hbm_bytes += nrec * 4;
         RSK_HIP(hipMemsetAsync(db->d_prof_cb + (size_t) o * 8, 0, 64 * 8 * 2, ctx->stream));
         RSK_HIP(hipMemsetAsync(db->d_prof_ra + (size_t) o * 8, 0, 64 * 8 * 2, ctx->stream));
@@ -319,15 +341,15 @@ extern "C" int rsk_db_create(rsk_ctx *ctx, uint32_t n, const uint32_t *lengths, 
                 for (uint32_t k = db->off[i] + lengths[i]; k < db->off[i + 1]; ++k) hx[k] = hy[k] = hz[k] = 0.f;
             }
         });
-        if ((rc = dev_upload(&db->d_x, hx.get(), (size_t) o, db->hbm_bytes)) != RSK_OK) return rc;
-        if ((rc = dev_upload(&db->d_y, hy.get(), (size_t) o, db->hbm_bytes)) != RSK_OK) return rc;
-        if ((rc = dev_upload(&db->d_z, hz.get(), (size_t) o, db->hbm_bytes)) != RSK_OK) return rc;
+        if ((rc = dev_upload(ctx, &db->d_x, hx.get(), (size_t) o, db->hbm_bytes)) != RSK_OK) return rc;
+        if ((rc = dev_upload(ctx, &db->d_y, hy.get(), (size_t) o, db->hbm_bytes)) != RSK_OK) return rc;
+        if ((rc = dev_upload(ctx, &db->d_z, hz.get(), (size_t) o, db->hbm_bytes)) != RSK_OK) return rc;
     }
     {
         std::vector<float> sr(n, FLT_MAX);
         if (selfrev) sr.assign(selfrev, selfrev + n);
         db->h_selfrev = sr;
-        if ((rc = dev_upload(&db->d_selfrev, sr.data(), n, db->hbm_bytes)) != RSK_OK) return rc;
+        if ((rc = dev_upload(ctx, &db->d_selfrev, sr.data(), n, db->hbm_bytes)) != RSK_OK) return rc;
     }
     *out = owner.release();
     return RSK_OK;

@@ -76,6 +76,12 @@ struct rsk_scratch {
 };
 
 int rsk_pool_alloc(rsk_ctx *ctx, void **p, size_t bytes);
+// hipMalloc on the current device with the out-of-memory ladder every device allocation of the library goes through:
+// on failure (1) the cached blocks of `ctx` (may be NULL) are released, (2) the host layer's hook runs -- it destroys the
+// idle helper contexts parked for this device, whose pools can hold tens of GB of scratch (host/dbsearcher.cpp
+// SecondaryCtx) -- and the allocation is tried again after each step.  Sets the error text and returns RSK_E_NOMEM.
+int rsk_dev_malloc(rsk_ctx *ctx, void **p, size_t bytes);
+void rsk_set_oom_hook(void (*release_idle)(int device));
 // Waits for the context's stream without spinning: the long waits (tens of ms of kernels) of several host threads would
 // otherwise each burn a core of a CPU-quota'd container.
 int rsk_stream_wait(rsk_ctx *ctx);
@@ -154,7 +160,7 @@ int rsk_launch_gapless_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, con
                              const uint32_t *d_it, size_t npairs, int32_t *d_scores,
                              uint32_t *d_besti, uint32_t *d_bestj);
 int rsk_build_rings(rsk_db *db);
-int rsk_build_mudex(rsk_db *db, int mode);
+int rsk_build_mudex(rsk_ctx *ctx, rsk_db *db, int mode);
 int rsk_build_len_perm(rsk_db *db);
 
 // k_sw_float.hip: CalcEvalue + path packing for alignments whose paths already sit on the device (see the definition)

@@ -1,0 +1,131 @@
+"""SURVEY 8e from ONE process: a DBSearcher that drives several device contexts (DBSearcher::m_Devices / RSK_DEVICES /
+rsk_search_opts.devices) -- one context, one host thread and one shard of the pair space per list entry, hit lines into one
+file.  The GPU box has one device, so the list repeats device 0 ("0,0", "0,0,0"): the shards then run CONCURRENTLY on
+separate contexts and streams of that device, which is the part a single GPU can check (ranges, replication, concurrent
+writers, counters); nothing here depends on the entries being distinct devices.  The tables must equal the reference
+binary's goldens.  The C++ form of the same (tests/ref_shaped/search_main.cpp -devices, and the reference's own search.cpp
+under RSK_DEVICES) is in the second half."""
+import gzip
+import os
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+import fixtures as fx
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COLS = "query+target+qlo+qhi+ql+tlo+thi+tl+pctid+pvalue+evalue+cigar+dpscore+lddt+newts+ids+gaps+aq"
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import reseek_amd
+    c = reseek_amd.Ctx(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def work():
+    d = tempfile.mkdtemp(prefix="rsk_multidev_")
+    for name in ("q100.bca", "palms.bca", "tailq.bca", "taildb.bca"):
+        with gzip.open(os.path.join(fx.GOLDEN, name + ".gz"), "rb") as f, open(os.path.join(d, name), "wb") as g:
+            g.write(f.read())
+    yield d
+    shutil.rmtree(d, ignore_errors=True)
+
+
+def table(path):
+    return sorted(open(path).read().splitlines())
+
+
+def golden(name):
+    return ["\t".join(r) for r in fx.read_tsv(name)]
+
+
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0"])
+def test_self_search_on_several_contexts(ctx, work, devices):
+    out = os.path.join(work, "self.tsv")
+    n, st = ctx.search(os.path.join(work, "q100.bca"), out, "sensitive", columns=COLS, devices=devices)
+    assert table(out) == golden("hits_q100_sensitive.tsv.gz") and n == len(golden("hits_q100_sensitive.tsv.gz"))
+    assert st[0] == 5050 and st[4] == 490                 # the counters of the shards add up to the single-context run's
+    n, st = ctx.search(os.path.join(work, "palms.bca"), out, "sensitive", columns=COLS, devices=devices)       # long-chain pairs in every shard
+    assert table(out) == golden("hits_palms_sensitive.tsv.gz")
+    n, st = ctx.search(os.path.join(work, "q100.bca"), out, "verysensitive", columns=COLS, devices=devices)
+    assert table(out) == golden("hits_q100_verysensitive.tsv.gz") and st[0] == 5050
+
+
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0"])
+def test_db_search_on_several_contexts(ctx, work, devices, monkeypatch):
+    out = os.path.join(work, "db.tsv")
+    q = os.path.join(work, "q100.bca")
+    n, st = ctx.search(q, out, "sensitive", db=q, columns=COLS, devices=devices)       # every context streams its own range of the -db file
+    assert table(out) == golden("hits_q100_db_q100_sensitive.tsv.gz") and st[0] == 10000
+    monkeypatch.setenv("RSK_STREAM_CHAINS", "7")                                        # several streamed batches per context
+    n, st = ctx.search(os.path.join(work, "tailq.bca"), out, "verysensitive", db=os.path.join(work, "taildb.bca"), columns=COLS, devices=devices)
+    assert table(out) == golden("hits_tail_db_verysensitive.tsv.gz")
+    n, st = ctx.search(os.path.join(work, "tailq.bca"), out, "sensitive", db=os.path.join(work, "taildb.bca"), columns=COLS, devices=devices)
+    assert table(out) == golden("hits_tail_db_sensitive.tsv.gz")
+
+
+def test_fast_db_two_stage_on_several_contexts(ctx, work):
+    """-fast -db: target shards per context, the per-query top-B exchange in host memory, PostMuFilter per shard; hit table
+    and merged hand-off file equal the reference's."""
+    out = os.path.join(work, "fastdb.tsv")
+    q = os.path.join(work, "q100.bca")
+    for devices in ("0,0", "0,0,0"):
+        n, st = ctx.search(q, out, "fast", db=q, columns=COLS, devices=devices, keeptmp=1)
+        want = golden("hits_q100_db_q100_fast.tsv.gz")
+        assert table(out) == want and n == len(want)
+        with gzip.open(os.path.join(fx.GOLDEN, "prefilter_q100_db_q100_fast_tmp.tsv.gz"), "rt") as f:
+            assert open(out + ".prefilter.tmp").read() == f.read()
+
+
+def test_environment_list_and_bad_lists(ctx, work, monkeypatch):
+    out = os.path.join(work, "env.tsv")
+    monkeypatch.setenv("RSK_DEVICES", "0, 0")
+    ctx.search(os.path.join(work, "q100.bca"), out, "sensitive", columns=COLS)
+    assert table(out) == golden("hits_q100_sensitive.tsv.gz")
+    monkeypatch.delenv("RSK_DEVICES")
+    from reseek_amd import capi
+    with pytest.raises(capi.RskError):
+        ctx.search(os.path.join(work, "q100.bca"), out, "sensitive", devices="0,x")
+
+
+# ---- the same from C++ ---------------------------------------------------------------------------------------------------
+def _compile(src, exe):
+    cxx = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else "g++"
+    cmd = [cxx] + (["-x", "c++"] if cxx.endswith("hipcc") else []) + [
+        "-std=c++17", "-O1", "-I", os.path.join(ROOT, "reseek_amd", "csrc", "host"), src, "-L", os.path.join(ROOT, "reseek_amd"), "-lrsk",
+        "-Wl,-rpath," + os.path.join(ROOT, "reseek_amd"), "-pthread", "-o", exe]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+
+
+def _run(exe, work, args, gold, env=None):
+    out = os.path.join(work, "cpp_hits.tsv")
+    if os.path.exists(out):
+        os.remove(out)
+    r = subprocess.run([exe] + args + ["-output", out, "-columns", COLS], capture_output=True, text=True, cwd=work, env=dict(os.environ, **(env or {})))
+    assert r.returncode == 0, r.stderr
+    assert table(out) == golden(gold)
+
+
+def test_cpp_driver_with_a_device_list(work):
+    exe = os.path.join(work, "search_main")
+    _compile(os.path.join(ROOT, "tests", "ref_shaped", "search_main.cpp"), exe)
+    _run(exe, work, ["q100.bca", "-sensitive", "-devices", "0,0"], "hits_q100_sensitive.tsv.gz")
+    _run(exe, work, ["palms.bca", "-sensitive", "-devices", "0,0,0"], "hits_palms_sensitive.tsv.gz")
+    _run(exe, work, ["q100.bca", "-db", "q100.bca", "-sensitive", "-devices", "0,0"], "hits_q100_db_q100_sensitive.tsv.gz")
+
+
+def test_the_reference_search_cpp_runs_on_a_device_list(work):
+    """oracle/_ref/search_refsrc = the reference's own search.cpp compiled against reseek_host.h: DBSearcher::RunSelf /
+    RunQuery(ChainReader2 &) fan out over RSK_DEVICES without the caller knowing."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "search_refsrc")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/search_refsrc not built (make -f oracle/Makefile.ref where /root/reference exists)")
+    _run(exe, work, ["q100.bca", "-sensitive"], "hits_q100_sensitive.tsv.gz", env={"RSK_DEVICES": "0,0"})
+    _run(exe, work, ["q100.bca", "-db", "q100.bca", "-sensitive"], "hits_q100_db_q100_sensitive.tsv.gz", env={"RSK_DEVICES": "0,0,0"})

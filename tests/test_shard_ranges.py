@@ -1,0 +1,74 @@
+"""CPU: the shard arithmetic behind the multi-GPU searches, through the C-ABI (rsk_shard_range; no device).
+kind 0 = self search: shard r scores the pairs (i <= j) whose target j lies in [lo_r, hi_r) -- the rectangle
+chains[0, lo) x chains[lo, hi) plus the triangle of chains[lo, hi) -- with equal DP cells per shard;
+kind 1 = -db search: contiguous chain ranges with equal residues.  The same function serves the one-process form
+(DBSearcher::m_Devices / RSK_DEVICES: one context per device) and the one-process-per-GPU form (shard_index / shard_count)."""
+import numpy as np
+import pytest
+
+import fixtures as fx
+from reseek_amd import capi
+
+
+def lengths_sets():
+    rng = np.random.default_rng(3)
+    yield "scop40", fx.scop40_lengths().astype(np.uint32)
+    yield "lognormal_tail", np.clip(rng.lognormal(np.log(250), 0.75, 20000), 20, 5000).astype(np.uint32)
+    yield "sorted", np.sort(fx.scop40_lengths()[:3000]).astype(np.uint32)
+    yield "tiny", np.array([7, 300, 12], np.uint32)
+
+
+@pytest.mark.parametrize("count", [1, 2, 3, 8])
+@pytest.mark.parametrize("kind", [0, 1])
+def test_shards_tile_the_set_in_order(kind, count):
+    for name, L in lengths_sets():
+        prev = 0
+        for r in range(count):
+            lo, hi = capi.shard_range(kind, L, r, count)
+            assert lo == prev and lo <= hi <= len(L), (name, r)
+            prev = hi
+        assert prev == len(L), name
+
+
+@pytest.mark.parametrize("count", [2, 3, 8])
+def test_self_shards_balance_cells_and_cover_every_pair_once(count):
+    for name, L in lengths_sets():
+        if len(L) < 100:
+            continue
+        Lf = L.astype(np.float64)
+        pre = np.cumsum(Lf)                                  # residues of chains 0..j
+        cells_of_target = pre * Lf                           # cells of the pairs (i <= j) of target j
+        total = cells_of_target.sum()
+        shares, pairs = [], 0
+        for r in range(count):
+            lo, hi = capi.shard_range(0, L, r, count)
+            shares.append(cells_of_target[lo:hi].sum())
+            # rectangle [0, lo) x [lo, hi) + triangle of [lo, hi)
+            pairs += lo * (hi - lo) + (hi - lo) * (hi - lo + 1) // 2
+        assert pairs == len(L) * (len(L) + 1) // 2, name
+        assert abs(sum(shares) - total) <= 1e-6 * total
+        # each share within one target's worth of the ideal
+        biggest = cells_of_target.max()
+        for s in shares:
+            assert abs(s - total / count) <= biggest + 1e-6 * total, (name, shares)
+
+
+@pytest.mark.parametrize("count", [2, 3, 8])
+def test_residue_shards_balance_residues(count):
+    for name, L in lengths_sets():
+        if len(L) < 100:
+            continue
+        total = int(L.astype(np.int64).sum())
+        for r in range(count):
+            lo, hi = capi.shard_range(1, L, r, count)
+            assert abs(int(L[lo:hi].astype(np.int64).sum()) - total / count) <= int(L.max()), (name, r)
+
+
+def test_more_shards_than_chains_and_bad_arguments():
+    L = np.array([50, 60], np.uint32)
+    got = [capi.shard_range(1, L, r, 8) for r in range(8)]
+    assert sum(hi - lo for lo, hi in got) == 2 and all(lo <= hi for lo, hi in got)
+    with pytest.raises(RuntimeError):
+        capi.shard_range(0, L, 3, 3)
+    with pytest.raises(RuntimeError):
+        capi.shard_range(2, L, 0, 1)
