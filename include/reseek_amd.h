@@ -277,6 +277,8 @@ int rsk_dss_densities(rsk_ctx *ctx, uint32_t n, const uint32_t *len, const float
                       int W, int w1, int w2, double radius, double eps,
                       double *dens_fwd, double *sdens_fwd, double *dens_rev, double *sdens_rev,
                       int nen_W, int nen_w, uint32_t *nen_fwd, uint32_t *ren_fwd, uint32_t *nen_rev, uint32_t *ren_rev);
+/* The same two features of ONE chain as the host computes them (glibc exp): the yardstick of the acceptance margin above. */
+int rsk_dss_densities_host(const float *x, const float *y, const float *z, uint32_t L, double *dens, double *sdens);
 int rsk_dss_featurize_reversed(const char *seq, const float *x, const float *y, const float *z, uint32_t L, uint8_t *prof);
 int rsk_bca_info(const char *path, uint64_t *nchains, uint64_t *nresidues, uint32_t *max_len, uint32_t *max_label);
 int rsk_bca_read_chain(const char *path, uint64_t idx, char *label, size_t label_cap, char *seq, float *x, float *y,

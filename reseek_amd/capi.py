@@ -112,6 +112,7 @@ SIGNATURES["rsk_fast_shard_finish"] = (C.c_int, [C.c_void_p, u32p, u32p, u32p, C
                                                  C.POINTER(C.c_uint64)])
 SIGNATURES["rsk_fast_shard_close"] = (None, [C.c_void_p])
 SIGNATURES["rsk_rsb_merge"] = (C.c_int, [u32p, u32p, u32p, C.c_size_t, C.c_uint32, C.c_uint32, u32p, u32p, u32p, C.POINTER(C.c_size_t)])
+SIGNATURES["rsk_dss_densities_host"] = (C.c_int, [f32p, f32p, f32p, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double)])
 SIGNATURES["rsk_shard_range"] = (C.c_int, [C.c_int, u32p, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)])
 SIGNATURES["rsk_bca_copy"] = (C.c_int, [C.c_char_p, C.c_char_p])
 SIGNATURES["rsk_bca_to_mu_fasta"] = (C.c_int, [C.c_char_p, C.c_char_p])
@@ -517,6 +518,16 @@ def merge_fwd_bwd(LA, LB, fwd_lo_a, fwd_lo_b, fwd_path, bwd_hi_a, bwd_hi_b, bwd_
     _check(lib().rsk_merge_fwd_bwd(LA, LB, fwd_lo_a, fwd_lo_b, fwd_path.encode(), bwd_hi_a, bwd_hi_b, bwd_path.encode(),
                                    C.byref(v[0]), C.byref(v[1]), C.byref(v[2]), C.byref(v[3]), buf, len(buf), C.byref(n)))
     return v[0].value, v[1].value, v[2].value, v[3].value, buf.value.decode()
+
+
+def dss_densities_host(x, y, z):
+    """DSS::GetDensity / GetSSDensity(Pos, 's') of one chain with the host's libm exp -> (dens, sdens) float64 [L]"""
+    x, y, z = (np.ascontiguousarray(v, np.float32) for v in (x, y, z))
+    L = len(x)
+    d, s = np.zeros(L, np.float64), np.zeros(L, np.float64)
+    f64p = C.POINTER(C.c_double)
+    _check(lib().rsk_dss_densities_host(_p(x, f32p), _p(y, f32p), _p(z, f32p), L, _p(d, f64p), _p(s, f64p)))
+    return d, s
 
 
 def shard_range(kind, lengths, index, count):

@@ -667,6 +667,25 @@ extern "C" int rsk_dss_featurize(const char *seq, const float *x, const float *y
     return RSK_OK;
 }
 
+// The host's (glibc libm exp) values of the two density features of one chain -- what DSS::UseDeviceDensities' margin is
+// measured against (tests/test_gpu_dss_density.py).  dens / sdens: L doubles each, DBL_MAX = no value.
+extern "C" int rsk_dss_densities_host(const float *x, const float *y, const float *z, uint32_t L, double *dens, double *sdens)
+{
+    if (!x || !y || !z || !dens || !sdens) { rsk_set_error("rsk_dss_densities_host: NULL argument"); return RSK_E_INVALID; }
+    try {
+        PDBChain C;
+        C.m_Seq.assign(L, 'A');
+        C.m_Xs.assign(x, x + L); C.m_Ys.assign(y, y + L); C.m_Zs.assign(z, z + L);
+        DSS D;
+        D.Init(C);
+        for (uint32_t Pos = 0; Pos < L; ++Pos) { dens[Pos] = D.GetDensity(Pos); sdens[Pos] = D.GetSSDensity(Pos, 's'); }
+    } catch (const std::exception &e) {
+        rsk_set_error("rsk_dss_densities_host: %s", e.what());
+        return RSK_E_INVALID;
+    }
+    return RSK_OK;
+}
+
 extern "C" int rsk_dss_featurize_reversed(const char *seq, const float *x, const float *y, const float *z, uint32_t L, uint8_t *prof)
 {
     if (!seq || !x || !y || !z || !prof) { rsk_set_error("rsk_dss_featurize_reversed: NULL argument"); return RSK_E_INVALID; }

@@ -326,7 +326,7 @@ __global__ __launch_bounds__(64 * SWF_WAVES) __attribute__((amdgpu_waves_per_eu(
 // "query profile" in LDS,
 //     QP[f][c][i] = feature table f, strip-chain letter of residue i, against step-chain letter c
 //     (132 (f,c) combinations x 528 B per residue: SWQ_MAX_L residues per profile; a longer strip chain is
-//     processed in segments of SWQ_MAX_G strips, one profile after the other, rows meeting through `bnd`),
+//     processed in segments of up to SWQ_MAX_G strips, one profile after the other, rows meeting through `bnd`),
 // stored as records of R consecutive residues, so that a lane fetches the S-contributions of its
 // whole strip for one feature with R/4 ds_read_b128 and no per-cell address arithmetic
 // (the legacy kernel above spends 8 ds_read_b32 + 16 address ops per cell).  Waves claim batches
@@ -345,10 +345,14 @@ __global__ __launch_bounds__(64 * SWF_WAVES) __attribute__((amdgpu_waves_per_eu(
 #define SWQ_MAX_L (SWQ_MAX_G * SWQ_R)
 #define SWQ_LDS_BYTES(G) ((size_t) SWQ_NFC * (SWQ_R / 4) * (G) * 16 + 16)
 
-// one workgroup item: `count` consecutive pairs (sorted order) of one group.  Its trace blocks, one per (segment, wave
-// batch), are ncol columns each and start at tb + tb_base: block (seg, b) is number seg * nb_full + b, nb_full = the
-// batches of a full segment (every segment before the last has SWQ_MAX_G strips).
-struct swq_item { uint32_t first, count, ncol, pad; uint64_t tb_base; };
+// one workgroup item: `count` consecutive pairs (sorted order) of one group.
+// gs = strips per PASS.  A wave batch is floor(64 / gs) pairs, gs lanes each; a strip chain of more than gs strips is done in
+// several passes over the step chains -- pass k covers the strips [k * gs, (k + 1) * gs), the rows of consecutive passes meet
+// through `bnd` -- run back to back by the wave that claimed the batch.  The host picks gs per group so that the lanes are
+// full: 22 - 25 strips (253 - 300 residues) in one pass use 44 - 50 lanes of 64, in two passes of 11 - 13 strips 55 - 60.
+// An LDS profile (one "segment") holds floor(G / gs) passes.  The trace blocks, one per (pass, wave batch), are ncol columns
+// each and start at tb + tb_base: block (pass, b) is number pass * nbatch + b with nbatch = ceil(count / (64 / gs)).
+struct swq_item { uint32_t first, count, ncol, gs; uint64_t tb_base; };
 
 // comparison -> 64-lane mask in an SGPR pair (lanes outside EXEC read 0)
 #define SWQ_MASK_GT(m, x, y) asm volatile("v_cmp_gt_f32_e64 %0, %1, %2" : "=s"(m) : "v"(x), "v"(y))
@@ -374,19 +378,29 @@ __global__ __launch_bounds__(64 * SWQ_NW) void k_sw_qp(swf_args a, const swq_ite
     const uint32_t strip_chain = T ? a.ib[it.first] : a.ia[it.first];
     const uint32_t LA = T ? a.b_len[strip_chain] : a.a_len[strip_chain];     // strip chain length
     const uint32_t gtot = (LA + R - 1) / R;        // strips of the whole chain
-    const uint32_t nseg = (gtot + G - 1) / G;      // segments of up to G strips: one LDS profile each
+    const uint32_t gs = it.gs;                     // strips per pass
+    const uint32_t npf = G / gs;                   // passes per LDS profile
+    const uint32_t Gs = npf * gs;                  // strips per segment (<= G)
+    const uint32_t nseg = (gtot + Gs - 1) / Gs;
+    const uint32_t npw = 64 / gs;                  // pairs per wave batch
+    const uint32_t nbatch = (it.count + npw - 1) / npw;
     uint32_t *next_batch = (uint32_t *) (qp + (size_t) SWQ_NFC * (R / 4) * G * 4);
     const int lane = threadIdx.x & 63;
+    const uint32_t pr = lane / gs, st = lane - pr * gs;
     const float Open = a.open, Ext = a.ext;
     for (uint32_t seg = 0; seg < nseg; ++seg) {
-    const uint32_t sbase = seg * G;                // first strip of this segment
-    const uint32_t g = min(G, gtot - sbase);
-    if (seg) { __threadfence(); __syncthreads(); } // every wave is done with the previous profile; its boundary rows are in L2
+    const uint32_t sbase = seg * Gs;               // first strip of this segment
+    const uint32_t g = min(Gs, gtot - sbase);
+    // every wave is done with the previous profile.  The boundary rows (and the running best cells) are handed on within
+    // this workgroup only -- an item runs on one CU, whose L1 is write-through and sees its own stores -- so they are plain
+    // loads and stores ordered by s_waitcnt / the barrier.  (Agent-scope accesses go past the XCD's L2 on this part: measured, 31 ms instead of 23 for the 64-query
+    // benchmark once most groups ran in two passes.)
+    if (seg) { __threadfence_block(); __syncthreads(); }
     {
         const uint8_t *sp = T ? (a.b_prof + a.b_off[strip_chain]) : (a.a_prof + a.a_off[strip_chain]);
         const size_t snpad = T ? a.b_npad : a.a_npad;
         // float4 ((fc * (R/4) + quad) * G + strip) holds residues (sbase + strip) * R + quad * 4 + 0..3 of row
-        // fc: the ds_read_b128 of the g lanes of a pair are 16 B apart, and the R/4 quads of a lane sit at
+        // fc: the ds_read_b128 of the lanes of a pair are 16 B apart, and the R/4 quads of a lane sit at
         // immediate offsets (quad * G * 16 B) from one address.  One record per thread and iteration.
         const uint32_t per_fc = (R / 4) * g, tot = SWQ_NFC * per_fc;
         for (uint32_t idx = threadIdx.x; idx < tot; idx += blockDim.x) {
@@ -411,15 +425,7 @@ __global__ __launch_bounds__(64 * SWQ_NW) void k_sw_qp(swf_args a, const swq_ite
         if (threadIdx.x == 0) *next_batch = 0;
     }
     __syncthreads();
-    const uint32_t npw = 64 / g;                   // pairs per wave pass
-    const uint32_t nbatch = (it.count + npw - 1) / npw;
-    const uint32_t pr = lane / g, st = lane - pr * g;
-    const uint32_t i0 = (sbase + st) * R;
-    const swq_ldsp qpl = (swq_ldsp) qp4 + st;      // this lane's float4 slot within a quad block
-    // rows of different segments meet through `bnd` (HBM, agent-scope accesses): the last strip of segment s
-    // leaves {M, D/I} of its bottom row per step, strip 0 of segment s + 1 takes them as the row above
-    const bool reads_bnd = seg > 0 && st == 0;
-    const bool writes_bnd = seg + 1 < nseg && st == g - 1;
+    const uint32_t npass = (g + gs - 1) / gs;      // passes of this segment
     for (;;) {
         uint32_t b = 0;
         if (lane == 0) b = atomicAdd(next_batch, 1u);
@@ -431,44 +437,73 @@ __global__ __launch_bounds__(64 * SWQ_NW) void k_sw_qp(swf_args a, const swq_ite
         const uint32_t step_chain = T ? a.ia[p] : a.ib[p];
         const uint32_t LB = T ? a.a_len[step_chain] : a.b_len[step_chain];
         const uint16_t *bcb = T ? (a.a_cb + (size_t) a.a_off[step_chain] * 8) : (a.b_cb + (size_t) a.b_off[step_chain] * 8);
-        // trace block of this (segment, batch): wave-uniform address in SGPRs
+        // two rows of LB words per pair: a pass reads the row its predecessor wrote and writes the other one (reading and
+        // writing one row in place puts loads and stores of the same cache lines in flight together: measured, +0.8 ms of 24)
+        long long *bnd2 = gtot > gs ? (long long *) (a.bnd + a.bnd_off[p]) : nullptr;
+        // best cell of the pair over the passes of this segment (kept by the pair's lane st == 0)
+        float pbest = 0.0f;
+        uint32_t pbi = 0xFFFFFFFFu, pbj = 0xFFFFFFFFu;
+        for (uint32_t pass = 0; pass < npass; ++pass) {
+        const uint32_t gl = min(gs, g - pass * gs);                       // strips of this pass
+        const uint32_t sp = pass * gs + st;                              // this lane's strip within the segment
+        const bool on = active && st < gl;
+        const uint32_t i0 = (sbase + sp) * R;
+        const swq_ldsp qpl = (swq_ldsp) qp4 + sp;                        // this lane's float4 slot within a quad block
+        const bool first = seg == 0 && pass == 0;                        // the pass that holds row 0
+        const bool last = sbase + pass * gs + gl >= gtot;                // ... the last row
+        const bool reads_bnd = !first && st == 0;
+        const bool writes_bnd = !last && st == gl - 1;
+        // trace block of this (pass, batch): wave-uniform address in SGPRs
         const unsigned long long *tblk;
         {
-            const uint32_t nb_full = (it.count + (64 / G) - 1) / (64 / G);
-            const unsigned long long t0 = (unsigned long long) (a.tb + it.tb_base) + (unsigned long long) (seg * nb_full + b) * it.ncol * SWQ_COL_BYTES;
+            const unsigned long long t0 = (unsigned long long) (a.tb + it.tb_base) +
+                                          (unsigned long long) ((seg * npf + pass) * nbatch + b) * it.ncol * SWQ_COL_BYTES;
             const unsigned lo = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) t0);
             const unsigned hi = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) (t0 >> 32));
             tblk = (const unsigned long long *) (((unsigned long long) hi << 32) | lo);
         }
-        long long *bnd = nseg > 1 ? (long long *) (a.bnd + a.bnd_off[p]) : nullptr;
 
         float Md[R], In[R], rb[R];
         uint32_t rj[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) { Md[r] = SWF_MINUS_INF; In[r] = SWF_MINUS_INF; rb[r] = 0.0f; rj[r] = 0; }
-        if (st == 0 && seg == 0) Md[0] = 0.0f;
+        if (st == 0 && first) Md[0] = 0.0f;
         float hand_m = SWF_MINUS_INF, hand_d = SWF_MINUS_INF, carry_in = SWF_MINUS_INF;
-        uint32_t ncol = active ? (LB + st) : 0;
+        uint32_t ncol = on ? (LB + st) : 0;
 #pragma unroll
         for (int s = 32; s >= 1; s >>= 1) ncol = max(ncol, (uint32_t) __shfl_xor((int) ncol, s, 64));
         uint4 cbn = make_uint4(0, 0, 0, 0);
-        if (active) cbn = *(const uint4 *) bcb;
-        long long bnn = 0;                         // boundary words of the next step (strip 0 of a later segment)
-        if (seg && reads_bnd && active) bnn = __hip_atomic_load(bnd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (on) cbn = *(const uint4 *) bcb;
+        // Rows of consecutive passes meet through `bnd` (one 8-byte word {M, D/I} per step).  Both directions are kept off
+        // the step's critical path: every lane requests the word of its NEXT column right after it has consumed this step's
+        // (only strip 0 uses it; the loop-carried register is then written by the load itself -- a copy would make the
+        // compiler wait for the load on the spot), and the bottom row of a step is stored one step later at the same point,
+        // so that the wait at the top of a step only ever covers operations issued a whole step earlier.
+        // (a pass that has nothing to read points the load at a word of the pair's own offset table)
+        const uint32_t gpass = seg * npf + pass;                        // pass index over the whole chain
+        long long *bnd = bnd2 ? bnd2 + (size_t) (gpass & 1) * LB : nullptr;                 // written by this pass
+        const long long *bsrc = first ? (const long long *) (a.tb_off + p) : bnd2 + (size_t) ((gpass & 1) ^ 1) * LB;
+        long long bnn = *bsrc;                     // boundary word of strip 0's column `col`
 
         for (uint32_t col = 0; col < ncol; ++col) {
             const int j = (int) col - (int) st;
             float in_m = dpp_shr1_f(hand_m);
             float in_d = dpp_shr1_f(hand_d);
-            if (active && j >= 0 && (uint32_t) j < LB) {
+            if (on && j >= 0 && (uint32_t) j < LB) {
                 const uint4 cb = cbn;
+                if (reads_bnd) {
+                    in_m = __builtin_bit_cast(float, (int) (uint32_t) (unsigned long long) bnn);
+                    in_d = __builtin_bit_cast(float, (int) ((unsigned long long) bnn >> 32));
+                }
+                // everything this step fetched is consumed: request the next step's data, then store the previous step's
+                // bottom row -- all of it has the 12 rows below to complete
                 cbn = *(const uint4 *) (bcb + (size_t) (j + 1) * 8);
-                if (seg) {                         // wave-uniform
-                    if (reads_bnd) {
-                        in_m = __builtin_bit_cast(float, (int) (uint32_t) (unsigned long long) bnn);
-                        in_d = __builtin_bit_cast(float, (int) ((unsigned long long) bnn >> 32));
-                        if ((uint32_t) j + 1 < LB) bnn = __hip_atomic_load(bnd + j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
+                bnn = bsrc[first ? 0u : min((uint32_t) j + 1, LB - 1)];
+                if (!last) {                       // wave-uniform
+                    // {hand_m, hand_d} still hold the bottom row of this lane's previous step (column j - 1)
+                    if (writes_bnd && j > 0)
+                        bnd[j - 1] = (long long) ((unsigned long long) (uint32_t) __builtin_bit_cast(int, hand_m) |
+                                                  ((unsigned long long) (uint32_t) __builtin_bit_cast(int, hand_d) << 32));
                 }
                 const uint32_t cbw[4] = { cb.x, cb.y, cb.z, cb.w };
                 swq_ldsp rec[8];
@@ -478,8 +513,8 @@ __global__ __launch_bounds__(64 * SWQ_NW) void k_sw_qp(swf_args a, const swq_ite
                     const uint32_t fcb = f == 0 ? 0 : 20 + (f - 1) * 16;
                     rec[f] = qpl + (fcb + (c4 >> 2)) * ((R / 4) * G);
                 }
-                float ch = (st == 0 && seg == 0) ? SWF_MINUS_INF : in_d;
-                if (st != 0 || seg != 0) Md[0] = carry_in;
+                float ch = (st == 0 && first) ? SWF_MINUS_INF : in_d;
+                if (st != 0 || !first) Md[0] = carry_in;
                 else if (j > 0) Md[0] = SWF_MINUS_INF;
                 float carry = SWF_MINUS_INF;
                 const unsigned long long *tcol = tblk + (size_t) col * (SWQ_COL_BYTES / 8);
@@ -527,37 +562,44 @@ __global__ __launch_bounds__(64 * SWQ_NW) void k_sw_qp(swf_args a, const swq_ite
                 }
                 hand_m = carry;
                 hand_d = ch;
-                if (nseg > 1) {                    // wave-uniform
-                    if (writes_bnd) {
-                        const unsigned long long bw = (unsigned long long) (uint32_t) __builtin_bit_cast(int, carry) |
-                                                      ((unsigned long long) (uint32_t) __builtin_bit_cast(int, ch) << 32);
-                        __hip_atomic_store(bnd + j, (long long) bw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
             }
             carry_in = in_m;
         }
+        if (!last && writes_bnd && on && LB > 0)   // the bottom row of the last column
+            bnd[LB - 1] = (long long) ((unsigned long long) (uint32_t) __builtin_bit_cast(int, hand_m) |
+                                       ((unsigned long long) (uint32_t) __builtin_bit_cast(int, hand_d) << 32));
         // best cell of the pair: highest score, then smallest i, then smallest j (sw.cpp:153-158 scans row-major with >)
         float best = 0.0f;
         uint32_t bi = 0xFFFFFFFFu, bj = 0xFFFFFFFFu;
+        if (on) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const uint32_t ii = T ? rj[r] : i0 + r, jj = T ? i0 + r : rj[r];
-            if (rb[r] > best || (rb[r] == best && best > 0.0f && (ii < bi || (ii == bi && jj < bj)))) { best = rb[r]; bi = ii; bj = jj; }
+            for (int r = 0; r < R; ++r) {
+                const uint32_t ii = T ? rj[r] : i0 + r, jj = T ? i0 + r : rj[r];
+                if (rb[r] > best || (rb[r] == best && best > 0.0f && (ii < bi || (ii == bi && jj < bj)))) { best = rb[r]; bi = ii; bj = jj; }
+            }
         }
-        for (uint32_t dlt = 1; dlt < g; ++dlt) {
+        for (uint32_t dlt = 1; dlt < gl; ++dlt) {
             const int src = (lane + dlt) & 63;
             const float ob = __shfl(best, src, 64);
             const uint32_t oi = (uint32_t) __shfl((int) bi, src, 64), oj = (uint32_t) __shfl((int) bj, src, 64);
-            if (st + dlt < g) {
+            if (st + dlt < gl) {
                 if (ob > best || (ob == best && ob > 0.0f && (oi < bi || (oi == bi && oj < bj)))) { best = ob; bi = oi; bj = oj; }
             }
         }
+        if (best > pbest || (best == pbest && best > 0.0f && (bi < pbi || (bi == pbi && bj < pbj)))) { pbest = best; pbi = bi; pbj = bj; }
+        if (!last) {
+            // the boundary words of this pass have left the wave before its next pass reads them (same CU, same L1); a later
+            // segment is behind the workgroup barrier above
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        }   // passes
         if (active && st == 0) {
+            float best = pbest;
+            uint32_t bi = pbi, bj = pbj;
             if (seg) {                             // merge with the best of the earlier segments (same rule)
-                const float ob = __builtin_bit_cast(float, __hip_atomic_load((int *) a.score + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                const uint32_t oi = (uint32_t) __hip_atomic_load((int *) a.besti + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t oj = (uint32_t) __hip_atomic_load((int *) a.bestj + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float ob = __builtin_bit_cast(float, __hip_atomic_load((int *) a.score + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                const uint32_t oi = (uint32_t) __hip_atomic_load((int *) a.besti + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const uint32_t oj = (uint32_t) __hip_atomic_load((int *) a.bestj + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (ob > best || (ob == best && ob > 0.0f && (oi < bi || (oi == bi && oj < bj)))) { best = ob; bi = oi; bj = oj; }
             }
             a.score[p] = best;
@@ -583,14 +625,13 @@ __device__ __forceinline__ uint32_t swf_trace_flags(const uint8_t *T, uint32_t c
         // k_sw_float: one byte per cell, the four rows of a dword in big-endian order
         bits = (cls == 2 ? T[(size_t) j * ld + (i ^ 3u)] : T[(size_t) i * ld + (j ^ 3u)]) & 31u;
     } else {
-        // k_sw_qp: block (segment, wave batch) -> column -> row -> mask; this pair's cell is bit `lane` of the mask
+        // k_sw_qp: block (pass, wave batch) -> column -> row -> mask; this pair's cell is bit `lane` of the mask
         const uint32_t srow = cls == 0 ? i : j, step = cls == 0 ? j : i;
         const uint32_t strip = srow / SWQ_R, r = srow - strip * SWQ_R;
-        const uint32_t seg = strip / SWQ_MAX_G, st = strip - seg * SWQ_MAX_G;
-        const uint32_t g = min((uint32_t) SWQ_MAX_G, gtot - seg * SWQ_MAX_G), npw = 64 / g;
-        const uint32_t nb_full = (it.count + (64 / SWQ_MAX_G) - 1) / (64 / SWQ_MAX_G);
-        const uint32_t b = pidx / npw, lane = (pidx - b * npw) * g + st;
-        const unsigned long long *M = (const unsigned long long *) (T + ((size_t) (seg * nb_full + b) * it.ncol + step + st) * SWQ_COL_BYTES) + r * 5;
+        const uint32_t pass = strip / it.gs, st = strip - pass * it.gs;      // pass index over the whole chain
+        const uint32_t npw = 64 / it.gs, nbatch = (it.count + npw - 1) / npw;
+        const uint32_t b = pidx / npw, lane = (pidx - b * npw) * it.gs + st;
+        const unsigned long long *M = (const unsigned long long *) (T + ((size_t) (pass * nbatch + b) * it.ncol + step + st) * SWQ_COL_BYTES) + r * 5;
         if (which == 0) bits = ((uint32_t) (M[0] >> lane) & 1u) << 4 | ((uint32_t) (M[1] >> lane) & 1u) << 3 | ((uint32_t) (M[2] >> lane) & 1u) << 2;
         else if (which == 1) bits = ((uint32_t) (M[3] >> lane) & 1u) << 1;
         else bits = (uint32_t) (M[4] >> lane) & 1u;
@@ -1138,10 +1179,33 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
             const uint32_t chain = (uint32_t) ((ord[k].key >> 24) & 0xFFFFFFFFu);
             size_t e = k;
             while (e < end && (uint32_t) ((ord[e].key >> 24) & 0xFFFFFFFFu) == chain) ++e;
-            const uint32_t g = std::min<uint32_t>((sdb->len[chain] + SWQ_R - 1) / SWQ_R, SWQ_MAX_G);
-            const uint32_t npw = 64 / g;
+            // strips per pass (swq_item::gs): the pass count P that minimises the group's wave steps.  A wave batch of
+            // floor(64 / gs) pairs runs ceil(gtot / gs) column loops of (its longest step chain + gs - 1) steps, plus a fixed
+            // cost per loop (claim, prologue, best-cell reduction, boundary fence); the group's pairs are in order of
+            // decreasing step-chain length, so the first pair of a batch has the longest.
+            const uint32_t gtot = (sdb->len[chain] + SWQ_R - 1) / SWQ_R;
+            uint32_t gs = std::min<uint32_t>(gtot, SWQ_MAX_G);
+            static const double pass_step_cost = getenv("RSK_SWQ_PASS_COST") ? atof(getenv("RSK_SWQ_PASS_COST")) : 1.12;
+            if (!(getenv("RSK_SWQ_PASSES") && atoi(getenv("RSK_SWQ_PASSES")) == 0)) {
+                const uint32_t Pmin = (gtot + SWQ_MAX_G - 1) / SWQ_MAX_G;
+                double best_cost = 0;
+                for (uint32_t P = Pmin; P <= Pmin + 5 && P <= gtot; ++P) {
+                    const uint32_t cand = (gtot + P - 1) / P, npw_c = 64 / cand, loops = (gtot + cand - 1) / cand;
+                    uint64_t steps = 0;
+                    for (size_t q = k; q < e; q += npw_c) {
+                        const uint32_t pq = ord[q].idx;
+                        steps += (c == 0 ? dbb->len[ib[pq]] : dba->len[ia[pq]]) + cand + 10;
+                    }
+                    const double cost = (double) steps * loops;
+                    // a step of a chain done in several passes costs ~8 % more (boundary word load + store per step); measured on the
+                    // 64 x 11,211 benchmark: 1.12 is the best threshold (24.2 ms; 1.0: 27.3, 1.2: 24.7, one pass everywhere: 25.1)
+                    const double adj = cost * (loops > 1 ? pass_step_cost : 1.0);
+                    if (P == Pmin || adj < best_cost) { best_cost = adj; gs = cand; }
+                }
+            }
+            const uint32_t npw = 64 / gs;
             const size_t chunk = (size_t) npw * SWQ_NW * 2;
-            for (size_t s = k; s < e; s += chunk) qitems[c].push_back(swq_item{ (uint32_t) s, (uint32_t) std::min(chunk, e - s), 0, 0, 0 });
+            for (size_t s = k; s < e; s += chunk) qitems[c].push_back(swq_item{ (uint32_t) s, (uint32_t) std::min(chunk, e - s), 0, gs, 0 });
             k = e;
         }
         // longest-running workgroups first
@@ -1195,15 +1259,12 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
                 qp_item[it.first + k] = (uint32_t) q;
             }
             const uint32_t gtot = (Ls + SWQ_R - 1) / SWQ_R;
-            uint64_t nblocks = 0;
-            for (uint32_t s0 = 0; s0 < gtot; s0 += SWQ_MAX_G) {
-                const uint32_t npw = 64 / std::min<uint32_t>(SWQ_MAX_G, gtot - s0);
-                nblocks += (it.count + npw - 1) / npw;
-            }
-            // column index = step + strip-in-segment.  A block is written by ONE wave through its CU's scalar cache: blocks
+            const uint32_t npw = 64 / it.gs;
+            const uint64_t nblocks = (uint64_t) ((gtot + it.gs - 1) / it.gs) * ((it.count + npw - 1) / npw);      // passes x wave batches
+            // column index = step + strip-in-pass.  A block is written by ONE wave through its CU's scalar cache: blocks
             // start on 128-byte lines and span whole lines (ncol a multiple of 4: 4 x 480 B = 15 lines), so no cache line is
             // ever shared between the scalar caches of two CUs
-            it.ncol = (lmax + std::min<uint32_t>(SWQ_MAX_G, gtot) + 3) & ~3u;
+            it.ncol = (lmax + it.gs + 3) & ~3u;
             tbo = (tbo + 127) & ~(uint64_t) 127;
             it.tb_base = tbo;
             tbo += nblocks * it.ncol * SWQ_COL_BYTES;
@@ -1218,9 +1279,9 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
         bnd_off[k] = bno;
         tb_off[k] = tbo;
         if (c == 0) {                                           // trace: the item's blocks (above)
-            if (LA > SWQ_MAX_L) bno += 2 * (uint64_t) LB;       // multi-segment strip chain: 2 words per step
+            if ((LA + SWQ_R - 1) / SWQ_R > qitems[0][qp_item[k]].gs) bno += 4 * (uint64_t) LB;       // several passes: two rows of 2 words per step
         } else if (c == 1) {
-            if (LB > SWQ_MAX_L) bno += 2 * (uint64_t) LA;
+            if ((LB + SWQ_R - 1) / SWQ_R > qitems[1][qp_item[k]].gs) bno += 4 * (uint64_t) LA;
         }
         else if (c == 2) {
             if (LA > 64 * SWF_R) bno += 2 * (uint64_t) LB;      // multi-group pair: 2 words per step

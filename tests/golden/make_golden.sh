@@ -134,6 +134,11 @@ ls -la $G
 python3 $G/make_tail_bca.py subset $T/q100.bca $TMP/q32.bca 32
 $R -search $TMP/q32.bca -db $T/q100.bca -verysensitive -columns $COLS -output $TMP/q32v.tsv -threads 1 -quiet >/dev/null 2>&1
 sort $TMP/q32v.tsv | gzip -9n > $G/hits_q32_db_q100_verysensitive.tsv.gz
+# BASELINE configs[0], literally: `reseek -search <32-chain .bca subset> -sensitive`, all-vs-all, on the CPU (all columns + default columns)
+$R -search $TMP/q32.bca -sensitive -columns $COLS -output $TMP/q32s.tsv -threads 1 -quiet >/dev/null 2>&1
+sort $TMP/q32s.tsv | gzip -9n > $G/hits_q32_sensitive.tsv.gz
+$R -search $TMP/q32.bca -sensitive -output $TMP/q32s_std.tsv -threads 1 -quiet >/dev/null 2>&1
+sort $TMP/q32s_std.tsv | gzip -9n > $G/hits_q32_sensitive_std.tsv.gz
 python3 $G/make_tail_bca.py tail $TMP/tailq.bca $TMP/taildb.bca
 gzip -9n < $TMP/tailq.bca > $G/tailq.bca.gz
 gzip -9n < $TMP/taildb.bca > $G/taildb.bca.gz

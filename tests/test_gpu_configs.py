@@ -51,6 +51,16 @@ def check(ctx, work, q, db, mode, golden, **kw):
     return st
 
 
+def test_config0_literal_32_chain_subset_sensitive(ctx, work):
+    """BASELINE configs[0] as written: `reseek -search <32-chain .bca subset> -sensitive`, all-vs-all, bit-exact hit table
+    (all columns and the default columns) against the reference binary run on the CPU."""
+    st = check(ctx, work, "q32.bca", None, "sensitive", "hits_q32_sensitive.tsv.gz")
+    assert st[0] == 32 * 33 // 2
+    out = os.path.join(work, "out_std.tsv")
+    n, _ = ctx.search(os.path.join(work, "q32.bca"), out, "sensitive")
+    assert sorted(open(out).read().splitlines()) == ["\t".join(r) for r in fx.read_tsv("hits_q32_sensitive_std.tsv.gz")] and n == 60
+
+
 def test_config4_shape_verysensitive_db_real_chains(ctx, work):
     st = check(ctx, work, "q32.bca", "q100.bca", "verysensitive", "hits_q32_db_q100_verysensitive.tsv.gz")
     assert st[0] == 3200 and st[5] == 3200 and st[4] == 0       # every pair through SW + traceback, no filter, no MKF

@@ -162,6 +162,43 @@ def test_device_densities_match_a_numpy_restatement(ctx):
         o += L
 
 
+def test_acceptance_margin_is_orders_above_the_observed_device_vs_libm_difference(ctx):
+    """DSS::UseDeviceDensities keeps a chain's device densities only if every binned quantity is further than 1e-9 from all
+    bin boundaries.  The bound behind that margin, measured: over 4,000 SCOP40-length chains and their reversed copies
+    (> 1e8 device exp() evaluations) the device values differ from the host's (glibc exp, same summation order) by less
+    than 1e-12 absolute -- a density is a sum of <= 100 terms in (0, 1], each within an ulp or two -- so the margin is more
+    than a thousand times the largest difference ever seen and a letter cannot flip inside it."""
+    from scipy.signal import lfilter
+    from reseek_amd import capi
+    rng = np.random.default_rng(2024)
+    lens = fx.scop40_lengths()[rng.choice(11211, 4000, replace=False)].astype(np.uint32)
+    tot = int(lens.sum())
+    d = lfilter([0.6], [1.0, -0.8], rng.normal(0, 1, (tot, 3)) / 0.6, axis=0)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    walk = np.cumsum(3.8 * d, axis=0)
+    start = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    for k in range(len(lens)):                                          # every chain around the origin, .bca-like magnitudes
+        walk[start[k]:start[k + 1]] -= walk[start[k]:start[k + 1]].mean(axis=0)
+    xyz = [np.ascontiguousarray(walk[:, k], np.float32) for k in range(3)]
+    r = ctx.dss_densities(lens, *xyz)
+    nexp = 0
+    worst = 0.0
+    for k in range(len(lens)):
+        sl = slice(int(start[k]), int(start[k + 1]))
+        L = int(lens[k])
+        hd, hs = capi.dss_densities_host(xyz[0][sl], xyz[1][sl], xyz[2][sl])
+        hdr, hsr = capi.dss_densities_host(xyz[0][sl][::-1], xyz[1][sl][::-1], xyz[2][sl][::-1])
+        for got, want in ((r["dens_fwd"][sl], hd), (r["sdens_fwd"][sl], hs), (r["dens_rev"][sl], hdr), (r["sdens_rev"][sl], hsr)):
+            assert np.array_equal(got == DBL_MAX, want == DBL_MAX), k
+            m = want != DBL_MAX
+            if m.any():
+                worst = max(worst, float(np.abs(got[m] - want[m]).max()))
+        nexp += 2 * sum(min(L - 1, p + 50) - max(0, p - 50) for p in range(1, L - 1))      # window terms, chain + reversed copy
+    assert nexp > 1e8, nexp
+    assert worst < 1e-12, worst                                          # margin 1e-9 >= 1000 x the worst difference
+    print("device-vs-libm densities: %.3g exps, max |diff| = %.3g" % (nexp, worst))
+
+
 def test_rejects_bad_windows(ctx):
     import reseek_amd
     one = np.zeros(4, np.float32)
