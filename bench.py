@@ -417,12 +417,20 @@ def main():
     out = torch.zeros((max(nb, 1), max(nb, 1)), dtype=torch.int16, device="cuda")
     outq = torch.zeros((max(lo, 1), max(nb, 1)), dtype=torch.int16, device="cuda") if dbq is not None else None
     summary = torch.zeros(2, dtype=torch.int64, device="cuda")
+    # what a search keeps of the pair space: the kernel itself appends {query, target, score} (indices of the whole set)
+    # for the pairs scoring >= HIT_MIN; the dense uint16 matrix is written as well (it is the contract's output)
+    HIT_MIN, HIT_CAP = 120, 1 << 22
+    rec = torch.zeros((HIT_CAP, 3), dtype=torch.int32, device="cuda")
+    recq = torch.zeros((HIT_CAP, 3), dtype=torch.int32, device="cuda") if dbq is not None else None
+    cnt = torch.zeros(2, dtype=torch.int32, device="cuda")
 
     def step():
         if dbq is not None:
-            ctx.mu_gapless_matrix_dev(dbq, db, False, outq.data_ptr(), nb)
+            ctx.mu_gapless_hits_dev(dbq, db, False, HIT_MIN, recq.data_ptr(), HIT_CAP, cnt[1:].data_ptr(), d_scores_ptr=outq.data_ptr(), ldo=nb,
+                                    q_base=0, t_base=lo)
         if db is not None:
-            ctx.mu_gapless_matrix_dev(db, db, True, out.data_ptr(), nb)
+            ctx.mu_gapless_hits_dev(db, db, True, HIT_MIN, rec.data_ptr(), HIT_CAP, cnt.data_ptr(), d_scores_ptr=out.data_ptr(), ldo=nb,
+                                    q_base=lo, t_base=lo)
 
     def barrier():
         if dist is not None:
@@ -436,35 +444,44 @@ def main():
     for _ in range(args.steps):
         step()
     if dist is not None:
-        # the path's only collective: gather of the per-rank hit buffers (query, target, score) onto rank 0
+        # the path's only collective: gather of the per-rank hit records (query, target, score) the kernels appended --
+        # device buffers, all_gather over RCCL / xGMI, nothing goes through the host
         from reseek_amd import dist as rdist
-        # scores are uint16 stored in an int16 tensor: >= 120 unsigned  <=>  >= 120 or negative as int16
-        hit = torch.nonzero((out >= 120) | (out < 0))
-        hit = hit[hit[:, 1] >= hit[:, 0]]                      # i <= j (entries below the diagonal are by-products)
-        rows = torch.cat([(hit + lo).to(torch.int32), (out[hit[:, 0], hit[:, 1]].to(torch.int32) & 0xFFFF)[:, None]], dim=1)
-        if outq is not None:
-            hq = torch.nonzero((outq >= 120) | (outq < 0))
-            rq = torch.cat([hq[:, :1].to(torch.int32), (hq[:, 1:] + lo).to(torch.int32),
-                            (outq[hq[:, 0], hq[:, 1]].to(torch.int32) & 0xFFFF)[:, None]], dim=1)
-            rows = torch.cat([rows, rq], dim=0)
-        gathered = rdist.gather_rows(rows.cpu().numpy(), dst=0, device=coll_dev)
-        summary[0] = 0 if gathered is None else gathered.shape[0]
+        torch.cuda.synchronize()
+        c = cnt.cpu()
+        rows = rec[:min(int(c[0]), HIT_CAP)] if db is not None else rec[:0]
+        if recq is not None:
+            rows = torch.cat([rows, recq[:min(int(c[1]), HIT_CAP)]], dim=0)
+        if one_device:
+            gathered = rdist.gather_rows(rows.cpu().numpy(), dst=0, device=coll_dev, all_ranks=True)
+        else:
+            gathered = rdist.gather_records_device(rows)
+        summary[0] = gathered.shape[0]
     barrier()
     dt = time.perf_counter() - t0
     # per-launch kernel time (the library's HIP events on the launch stream) and work of this rank's launches, untimed pass
     kernel_ms, pairs, cells, slots = 0.0, 0, 0, 0
     if dbq is not None:
-        ctx.mu_gapless_matrix_dev(dbq, db, False, outq.data_ptr(), nb)
+        ctx.mu_gapless_hits_dev(dbq, db, False, HIT_MIN, recq.data_ptr(), HIT_CAP, cnt[1:].data_ptr(), d_scores_ptr=outq.data_ptr(), ldo=nb,
+                                q_base=0, t_base=lo)
         torch.cuda.synchronize()
         kernel_ms += ctx.last_kernel_ms()
         w = ctx.mu_gapless_last_work()
         pairs, cells, slots = pairs + w[0], cells + w[1], slots + w[2]
     if db is not None:
-        ctx.mu_gapless_matrix_dev(db, db, True, out.data_ptr(), nb)
+        ctx.mu_gapless_hits_dev(db, db, True, HIT_MIN, rec.data_ptr(), HIT_CAP, cnt.data_ptr(), d_scores_ptr=out.data_ptr(), ldo=nb,
+                                q_base=lo, t_base=lo)
         torch.cuda.synchronize()
         kernel_ms += ctx.last_kernel_ms()
         w = ctx.mu_gapless_last_work()
         pairs, cells, slots = pairs + w[0], cells + w[1], slots + w[2]
+
+    # the same pass without the dense matrix (hit records only: what a search needs), untimed, for the record
+    kernel_ms_hits_only = None
+    if db is not None and dbq is None:
+        ctx.mu_gapless_hits_dev(db, db, True, HIT_MIN, rec.data_ptr(), HIT_CAP, cnt.data_ptr(), q_base=lo, t_base=lo)
+        torch.cuda.synchronize()
+        kernel_ms_hits_only = ctx.last_kernel_ms()
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
     tot = torch.tensor([float(cells), float(pairs)], dtype=torch.float64, device=coll_dev)
@@ -485,16 +502,25 @@ def main():
         blk = lens[lo:hi]
         alg_bytes = float((blk * (nb - np.arange(nb))).sum() + np.cumsum(blk[::-1])[::-1].sum() + 8.0 * pairs +
                           (lens[:lo].sum() * nb + blk.sum() * lo))       # triangle of the block + rectangle above it
-        # HBM traffic per launch: rocprofv3 PMC counters of this same command, committed under profiles/
-        # (FETCH_SIZE doubled on gfx950 as MI355X_MICROARCH.md prescribes; separate --pmc passes)
-        traffic = None
+        # HBM traffic per launch: rocprofv3 PMC counters of this same command (tools/prof_bench.sh -> tools/prof_traffic_json.py),
+        # committed under profiles/ together with the sha256 of the kernel's source file: reported only while that file is
+        # unchanged and the workload is the one that was profiled -- otherwise null, with the reason
+        traffic, traffic_src = None, None
         try:
-            with open(os.path.join(ROOT, "profiles", "r02u_traffic.json")) as f:
+            import hashlib
+            with open(os.path.join(ROOT, "profiles", "r03_traffic.json")) as f:
                 tj = json.load(f)
-            if n == 11211 and not args.chains:
+            with open(os.path.join(ROOT, tj["kernel_source"]), "rb") as f:
+                sha = hashlib.sha256(f.read()).hexdigest()
+            if sha != tj["kernel_source_sha256"]:
+                traffic_src = "profiles/r03_traffic.json is STALE (%s changed since the counters were collected): re-run tools/prof_bench.sh" % tj["kernel_source"]
+            elif n != 11211 or args.chains or world != 1:
+                traffic_src = "profiles/r03_traffic.json holds the 1-GPU full-set workload only"
+            else:
                 traffic = float(tj["traffic_bytes_per_launch"])
-        except (OSError, ValueError, KeyError):
-            traffic = None
+                traffic_src = "profiles/r03_traffic.json (rocprofv3 PMC FETCH_SIZE x 2 + WRITE_SIZE per dispatch, same command; kernel source sha256 verified)"
+        except (OSError, ValueError, KeyError) as e:
+            traffic_src = "no traffic record (%s)" % e
         res = {
             "metric": "aligned cells/sec (SCOP40-shaped all-vs-all, gapless int Mu kernel)",
             "value": cells_per_s, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -504,6 +530,9 @@ def main():
             "config": {"workload": "BASELINE configs[1]: SCOP40-shaped (%d chains, %d residues%s) all-vs-all "
                                    "i<=j, swgaplessint kernel only" % (n, int(nres), " per GPU" if args.weak else ""),
                        "pairs_total": int(total_pairs), "cells_total": total_cells, "pairs_rank0": pairs, "cells_rank0": cells,
+                       "hit_records": {"min_score": HIT_MIN, "rank0_per_step": int(cnt.sum().item()),
+                                       "gathered_all_ranks": int(summary[0].item()) if dist is not None else None,
+                                       "note": "appended by the kernel (rsk_mu_gapless_hits_dev) next to the dense uint16 matrix"},
                        "sharding": "one independent set per GPU (--weak)" if args.weak else
                                    "one set; rank r takes the targets [lo, hi) of the triangle, ranges balanced by DP cells: "
                                    "rectangle chains[0:lo) x chains[lo:hi) + triangle of chains[lo:hi); no data-path collective, "
@@ -516,10 +545,11 @@ def main():
                         "per 2 cells); peak = VOP3P issue rate 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz (ubench: 36-37); "
                         "LDS 2 B/cell; kernel time from HIP events on the launch stream",
                 "kernel_ms": kernel_ms, "cell_slots_issued": slots, "slot_efficiency": cells / max(1, slots),
+                "kernel_ms_hit_records_only": kernel_ms_hits_only,
                 "hbm": {"bound": "hbm", "achieved": alg_bytes / (kernel_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
                         "unit": "GB/s", "frac": alg_bytes / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                         "algorithmic_bytes": alg_bytes, "traffic": traffic},
-                "traffic": traffic, "traffic_source": "profiles/r02u_traffic.json (rocprofv3 PMC, same workload)" if traffic else None},
+                "traffic": traffic, "traffic_source": traffic_src},
         }
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(seqs)

@@ -85,6 +85,15 @@ uint64_t rsk_db_hbm_bytes(const rsk_db *db);
  * (a pair of such chains could saturate); queries longer than 1022 take a per-pair kernel inside the same call. */
 int rsk_mu_gapless_matrix_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int self_triangle,
                               uint16_t *d_scores, size_t ldo);
+/* The same pass with the search's view of the result: every scored pair whose score is >= min_score is appended to
+ * d_records as three uint32 {q_base + query, t_base + target, score} (self_triangle: {min, max} of the two chain ids, every
+ * unordered pair at most once); *d_count = hits found (device, reset by the call; records beyond `capacity` are dropped:
+ * enlarge and repeat).  d_scores may be NULL: no dense matrix is written at all -- the hit list is then the only HBM
+ * write of the pass.  q_base / t_base turn the indices of a shard into indices of the whole set (multi-GPU: the ranks'
+ * record buffers are gathered as they are).  Asynchronous on the context stream. */
+int rsk_mu_gapless_hits_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int self_triangle, uint16_t *d_scores, size_t ldo,
+                            uint32_t min_score, uint32_t q_base, uint32_t t_base, uint32_t *d_records, uint32_t capacity,
+                            uint32_t *d_count);
 /* Pair-list form with the position of the first strict maximum in row-major order (Besti/Bestj of
  * SWFastGapless_Int; RSK_NO_POS when the score is 0).  besti/bestj may be NULL.  Synchronous. */
 int rsk_mu_gapless_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, const uint32_t *iq,

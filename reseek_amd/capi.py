@@ -33,6 +33,8 @@ SIGNATURES = {
     "rsk_db_nresidues": (C.c_uint64, [C.c_void_p]),
     "rsk_db_hbm_bytes": (C.c_uint64, [C.c_void_p]),
     "rsk_mu_gapless_matrix_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
+    "rsk_mu_gapless_hits_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
+                                          C.c_void_p, C.c_uint32, C.c_void_p]),
     "rsk_mu_gapless_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, u32p, u32p, C.c_size_t, i32p, u32p, u32p]),
     "rsk_mu_gapless_last_work": (C.c_int, [C.c_void_p, u64p, u64p, u64p]),
     "rsk_mu_sw_matrix_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
@@ -178,6 +180,12 @@ class Ctx:
     # ---- D1 gapless -------------------------------------------------------------------------
     def mu_gapless_matrix_dev(self, q, t, self_triangle, d_scores_ptr, ldo):
         _check(lib().rsk_mu_gapless_matrix_dev(self.h, q.h, t.h, int(self_triangle), C.c_void_p(d_scores_ptr), ldo))
+
+    def mu_gapless_hits_dev(self, q, t, self_triangle, min_score, rec_ptr, capacity, count_ptr, d_scores_ptr=0, ldo=0, q_base=0, t_base=0):
+        """rsk_mu_gapless_hits_dev: device-side hit records {q, t, score} (uint32 x 3) for scores >= min_score; the dense
+        matrix is optional (d_scores_ptr = 0: not written)."""
+        _check(lib().rsk_mu_gapless_hits_dev(self.h, q.h, t.h, int(self_triangle), C.c_void_p(d_scores_ptr) if d_scores_ptr else None, ldo,
+                                             int(min_score), int(q_base), int(t_base), C.c_void_p(rec_ptr), int(capacity), C.c_void_p(count_ptr)))
 
     def mu_gapless_pairs(self, q, t, iq, it, positions=False):
         iq = np.ascontiguousarray(iq, np.uint32)

@@ -136,6 +136,21 @@ int rsk_build_rings(rsk_db *db)
 // ---------------------------------------------------------------------------------------------
 // ring kernel
 // ---------------------------------------------------------------------------------------------
+// Hit emission (optional): every scored pair whose score reaches min_score is appended as a record {q_base + query,
+// t_base + target, score} (self triangle: {min, max} of the two chain ids, each unordered pair once) -- what a search keeps
+// of the pair space, a few records per million pairs, instead of an n x n matrix the host would have to scan.
+// *count is the number of hits found; records beyond cap are not stored (the caller enlarges and repeats).
+struct gl_hits {
+    uint32_t *rec;           // [cap][3], NULL = no emission
+    uint32_t *count;
+    uint32_t cap, min_score, q_base, t_base;
+};
+__device__ __forceinline__ void gl_emit(const gl_hits &h, uint32_t a, uint32_t b, uint32_t score)
+{
+    const uint32_t k = atomicAdd(h.count, 1u);
+    if (k < h.cap) { h.rec[3 * (size_t) k] = a; h.rec[3 * (size_t) k + 1] = b; h.rec[3 * (size_t) k + 2] = score; }
+}
+
 template <int D> struct RingGeom {
     static constexpr int P = 128 * D;          // row slots on the ring
     static constexpr int RSB = 2 * P;          // bytes per profile row
@@ -223,7 +238,7 @@ __global__ __launch_bounds__(64 * NW) void k_gapless_ring(const rsk_ring *__rest
                                                           const uint32_t *__restrict__ t_perm,   // self triangle: processing order
                                                           const uint32_t *__restrict__ t_claim,  // positions of each aligned block, longest first
                                                           uint32_t tb_size, int self_triangle,
-                                                          uint16_t *__restrict__ out, size_t ldo)
+                                                          uint16_t *__restrict__ out, size_t ldo, gl_hits hits)
 {
     typedef RingGeom<D> Gm;
     constexpr int P = Gm::P, RSB = Gm::RSB, NQMAX = Gm::NQMAX, M = Gm::M;
@@ -280,6 +295,7 @@ __global__ __launch_bounds__(64 * NW) void k_gapless_ring(const rsk_ring *__rest
         t = __builtin_amdgcn_readfirstlane(t);
         if (t >= t1) break;
         t = __builtin_amdgcn_readfirstlane(t_claim[t]);                       // longest targets of the block first (LPT)
+        const uint32_t tpos = t;                                              // position in the processing order
         if (self_triangle) {
             if (t < rg.min_q) continue;                                       // positions before the ring's first member
             t = __builtin_amdgcn_readfirstlane(t_perm[t]);                    // position -> chain
@@ -324,8 +340,15 @@ __global__ __launch_bounds__(64 * NW) void k_gapless_ring(const rsk_ring *__rest
             const int v = wres[k];
             wres[k] = FLOOR32;
             const uint32_t qid = ring_qid[rg.qid_off + k];
-            const size_t o = self_triangle ? (size_t) min(qid, t) * ldo + max(qid, t) : (size_t) qid * ldo + t;
-            out[o] = (uint16_t) (v + 32768);
+            const uint32_t sc = (uint32_t) (v + 32768);
+            if (out) {
+                const size_t o = self_triangle ? (size_t) min(qid, t) * ldo + max(qid, t) : (size_t) qid * ldo + t;
+                out[o] = (uint16_t) sc;
+            }
+            // a ring sees every target from its first member's position on, so the pairs of two of its own members are
+            // scored twice: the one whose target comes later in the order reports
+            if (hits.rec && sc >= hits.min_score && (!self_triangle || tpos >= rg.min_q + k))
+                gl_emit(hits, hits.q_base + (self_triangle ? min(qid, t) : qid), hits.t_base + (self_triangle ? max(qid, t) : t), sc);
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     }
@@ -342,7 +365,7 @@ __global__ __launch_bounds__(1024) void k_gapless_pairs(const uint8_t *__restric
                                                         const uint32_t *__restrict__ iq, const uint32_t *__restrict__ it,
                                                         uint32_t npairs, int32_t *__restrict__ scores,
                                                         uint32_t *__restrict__ besti, uint32_t *__restrict__ bestj,
-                                                        uint16_t *__restrict__ out16, size_t ldo)
+                                                        uint16_t *__restrict__ out16, size_t ldo, gl_hits hits)
 {
     // one workgroup (64..1024 threads) per pair
     __shared__ signed char mat[1296];
@@ -385,6 +408,7 @@ __global__ __launch_bounds__(1024) void k_gapless_pairs(const uint8_t *__restric
         if (besti) besti[p] = sc ? (uint32_t) (0xFFFFFF - ((best >> 24) & 0xFFFFFF)) : RSK_NO_POS;
         if (bestj) bestj[p] = sc ? (uint32_t) (0xFFFFFF - (best & 0xFFFFFF)) : RSK_NO_POS;
         if (out16) out16[(size_t) a * ldo + b] = (uint16_t) min(sc, 65535);
+        if (hits.rec && (uint32_t) sc >= hits.min_score) gl_emit(hits, hits.q_base + a, hits.t_base + b, (uint32_t) min(sc, 65535));
     }
 }
 
@@ -393,7 +417,7 @@ __global__ __launch_bounds__(1024) void k_gapless_pairs(const uint8_t *__restric
 // ---------------------------------------------------------------------------------------------
 template <int D, int NW>
 static int launch_ring_class(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, const uint2 *d_work, uint32_t nwork,
-                             int self_triangle, uint16_t *d_scores, size_t ldo, uint32_t tb_size)
+                             int self_triangle, uint16_t *d_scores, size_t ldo, uint32_t tb_size, const gl_hits &hits)
 {
     if (nwork == 0) return RSK_OK;
     constexpr size_t lds = ring_lds_bytes<D, NW>();
@@ -405,7 +429,7 @@ static int launch_ring_class(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, con
     if (arc != RSK_OK) return arc;
     hipLaunchKernelGGL((k_gapless_ring<D, NW>), dim3(nwork), dim3(64 * NW), lds, ctx->stream, q->d_ring_tab, d_work,
                        q->d_ring_letters, q->d_ring_laneq, q->d_ring_qid, t->d_mu, t->d_off, t->d_len, t->n, q->d_ring_perm,
-                       self_triangle ? q->d_tri_claim : t->d_nat_claim, tb_size, self_triangle, d_scores, ldo);
+                       self_triangle ? q->d_tri_claim : t->d_nat_claim, tb_size, self_triangle, d_scores, ldo, hits);
     RSK_HIP(hipGetLastError());
     return RSK_OK;
 }
@@ -429,8 +453,11 @@ static int build_claim_order(const rsk_db *db, const uint32_t *perm, uint32_t **
 }
 
 int rsk_launch_gapless_rings(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int self_triangle,
-                             uint16_t *d_scores, size_t ldo)
+                             uint16_t *d_scores, size_t ldo, uint32_t min_score, uint32_t q_base, uint32_t t_base, uint32_t *d_rec,
+                             uint32_t capacity, uint32_t *d_count)
 {
+    gl_hits hits = {};
+    hits.rec = d_rec; hits.count = d_count; hits.cap = capacity; hits.min_score = min_score; hits.q_base = q_base; hits.t_base = t_base;
     int rc = rsk_upload_mu_tables(ctx);
     if (rc != RSK_OK) return rc;
     if (self_triangle) rc = build_claim_order(q, q->h_ring_perm.data(), &const_cast<rsk_db *>(q)->d_tri_claim);
@@ -531,15 +558,15 @@ int rsk_launch_gapless_rings(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int
 
     RSK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     rc = launch_ring_class<8, 16>(ctx, q, t, (const uint2 *) q->d_work + q->work_count[0], q->work_count[1], self_triangle,
-                                  d_scores, ldo, RING_TB);
+                                  d_scores, ldo, RING_TB, hits);
     if (rc != RSK_OK) return rc;
-    rc = launch_ring_class<4, 8>(ctx, q, t, (const uint2 *) q->d_work, q->work_count[0], self_triangle, d_scores, ldo, RING_TB);
+    rc = launch_ring_class<4, 8>(ctx, q, t, (const uint2 *) q->d_work, q->work_count[0], self_triangle, d_scores, ldo, RING_TB, hits);
     if (rc != RSK_OK) return rc;
     // queries too long for a ring: per-pair kernel over (long q) x targets
     if (q->long_pairs) {                               // list built with the work list (cached per target set + triangle flag)
         hipLaunchKernelGGL(k_gapless_pairs, dim3(q->long_pairs), dim3(1024), 0, ctx->stream, q->d_mu, q->d_off, q->d_len,
                            t->d_mu, t->d_off, t->d_len, q->d_long_iq, q->d_long_it, q->long_pairs, (int32_t *) nullptr, (uint32_t *) nullptr,
-                           (uint32_t *) nullptr, d_scores, ldo);
+                           (uint32_t *) nullptr, d_scores, ldo, hits);
         RSK_HIP(hipGetLastError());
     }
     RSK_HIP(hipEventRecord(ctx->ev1, ctx->stream));
@@ -555,7 +582,7 @@ int rsk_launch_gapless_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, con
     RSK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     hipLaunchKernelGGL(k_gapless_pairs, dim3((unsigned) npairs), dim3(npairs > 4096 ? 64 : 1024), 0, ctx->stream, q->d_mu, q->d_off,
                        q->d_len, t->d_mu, t->d_off, t->d_len, d_iq, d_it, (uint32_t) npairs, d_scores, d_besti, d_bestj,
-                       (uint16_t *) nullptr, (size_t) 0);
+                       (uint16_t *) nullptr, (size_t) 0, gl_hits{});
     RSK_HIP(hipGetLastError());
     RSK_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     return RSK_OK;

@@ -381,30 +381,46 @@ extern "C" uint64_t rsk_db_hbm_bytes(const rsk_db *db) { return db ? db->hbm_byt
 
 // ---- D1 gapless -----------------------------------------------------------------------------
 
+static int gapless_dense_checks(const char *who, rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int self_triangle, const uint16_t *d_scores, size_t ldo)
+{
+    if (!ctx || !q || !t) { rsk_set_error("%s: NULL argument", who); return RSK_E_INVALID; }
+    if (!q->d_mu || !t->d_mu) { rsk_set_error("%s: chain set has no Mu letters", who); return RSK_E_INVALID; }
+    if (d_scores && ldo < t->n) { rsk_set_error("%s: ldo < number of targets", who); return RSK_E_INVALID; }
+    if (self_triangle && q != t) { rsk_set_error("%s: self_triangle needs q == t", who); return RSK_E_INVALID; }
+    // uint16 scores: the largest score is 4 * min(LA, LB), so a pair of chains > 16383 could saturate; the pair-list form
+    // (int32 scores) has no such limit
+    uint32_t mq = 0, mt = 0;
+    for (uint32_t L : q->len) mq = std::max(mq, L);
+    for (uint32_t L : t->len) mt = std::max(mt, L);
+    if (std::min(mq, mt) > 16383) {
+        rsk_set_error("%s: chains of %u and %u residues could exceed the uint16 score range (use rsk_mu_gapless_pairs)", who, mq, mt);
+        return RSK_E_RANGE;
+    }
+    return RSK_OK;
+}
+
 extern "C" int rsk_mu_gapless_matrix_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int self_triangle,
                                          uint16_t *d_scores, size_t ldo)
 {
-    if (!ctx || !q || !t || !d_scores) { rsk_set_error("rsk_mu_gapless_matrix_dev: NULL argument"); return RSK_E_INVALID; }
-    if (!q->d_mu || !t->d_mu) { rsk_set_error("rsk_mu_gapless_matrix_dev: chain set has no Mu letters"); return RSK_E_INVALID; }
-    if (ldo < t->n) { rsk_set_error("rsk_mu_gapless_matrix_dev: ldo < number of targets"); return RSK_E_INVALID; }
-    if (self_triangle && q != t) { rsk_set_error("rsk_mu_gapless_matrix_dev: self_triangle needs q == t"); return RSK_E_INVALID; }
-    // uint16 output: the largest score is 4 * min(LA, LB), so a pair of chains > 16383 could saturate; the pair-list form
-    // (int32 scores) has no such limit
-    {
-        uint32_t mq = 0, mt = 0;
-        for (uint32_t L : q->len) mq = std::max(mq, L);
-        for (uint32_t L : t->len) mt = std::max(mt, L);
-        if (std::min(mq, mt) > 16383) {
-            rsk_set_error("rsk_mu_gapless_matrix_dev: chains of %u and %u residues could exceed the uint16 score range (use rsk_mu_gapless_pairs)", mq, mt);
-            return RSK_E_RANGE;
-        }
-    }
+    if (!d_scores) { rsk_set_error("rsk_mu_gapless_matrix_dev: NULL argument"); return RSK_E_INVALID; }
+    int rc = gapless_dense_checks("rsk_mu_gapless_matrix_dev", ctx, q, t, self_triangle, d_scores, ldo);
+    if (rc != RSK_OK) return rc;
     RSK_HIP(hipSetDevice(ctx->device));
-    if (!q->rings_built) {
-        int rc = rsk_build_rings(const_cast<rsk_db *>(q));
-        if (rc != RSK_OK) return rc;
-    }
-    return rsk_launch_gapless_rings(ctx, q, t, self_triangle, d_scores, ldo);
+    if (!q->rings_built && (rc = rsk_build_rings(const_cast<rsk_db *>(q))) != RSK_OK) return rc;
+    return rsk_launch_gapless_rings(ctx, q, t, self_triangle, d_scores, ldo, 0, 0, 0, nullptr, 0, nullptr);
+}
+
+extern "C" int rsk_mu_gapless_hits_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int self_triangle, uint16_t *d_scores, size_t ldo,
+                                       uint32_t min_score, uint32_t q_base, uint32_t t_base, uint32_t *d_records, uint32_t capacity,
+                                       uint32_t *d_count)
+{
+    if (!d_records || !d_count) { rsk_set_error("rsk_mu_gapless_hits_dev: NULL record buffer / counter"); return RSK_E_INVALID; }
+    int rc = gapless_dense_checks("rsk_mu_gapless_hits_dev", ctx, q, t, self_triangle, d_scores, ldo);
+    if (rc != RSK_OK) return rc;
+    RSK_HIP(hipSetDevice(ctx->device));
+    if (!q->rings_built && (rc = rsk_build_rings(const_cast<rsk_db *>(q))) != RSK_OK) return rc;
+    RSK_HIP(hipMemsetAsync(d_count, 0, 4, ctx->stream));
+    return rsk_launch_gapless_rings(ctx, q, t, self_triangle, d_scores, ldo, min_score, q_base, t_base, d_records, capacity, d_count);
 }
 
 extern "C" int rsk_mu_gapless_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, const uint32_t *iq,

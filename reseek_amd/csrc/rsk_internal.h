@@ -155,7 +155,8 @@ struct rsk_db {
 
 // kernels (k_mu_gapless.hip)
 int rsk_launch_gapless_rings(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int self_triangle,
-                             uint16_t *d_scores, size_t ldo);
+                             uint16_t *d_scores, size_t ldo, uint32_t min_score, uint32_t q_base, uint32_t t_base, uint32_t *d_rec,
+                             uint32_t capacity, uint32_t *d_count);
 int rsk_launch_gapless_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, const uint32_t *d_iq,
                              const uint32_t *d_it, size_t npairs, int32_t *d_scores,
                              uint32_t *d_besti, uint32_t *d_bestj);

@@ -42,6 +42,25 @@ def _all_gather_padded(local, group=None, device=None):
     return [b[:c].cpu().numpy() for b, c in zip(bufs, counts)]
 
 
+def gather_records_device(rec, group=None):
+    """Variable-length gather of fixed-width DEVICE records (torch tensor [n_r, k] on this rank's GPU, e.g. the hit records
+    rsk_mu_gapless_hits_dev appended): counts, then one all_gather of buffers padded to the largest count -- device to
+    device over RCCL / xGMI, nothing crosses the host.  -> the concatenation in rank order, a device tensor, on every rank."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    cnt = torch.tensor([rec.shape[0]], dtype=torch.int64, device=rec.device)
+    cnts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(cnts, cnt, group=group)
+    counts = [int(c.item()) for c in cnts]
+    m = max(max(counts), 1)
+    buf = torch.zeros((m,) + tuple(rec.shape[1:]), dtype=rec.dtype, device=rec.device)
+    buf[:rec.shape[0]] = rec
+    bufs = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(bufs, buf, group=group)
+    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+
+
 def gather_rows(rows, dst=0, group=None, device=None, all_ranks=False):
     """Variable-length gather of fixed-width records (int32 [n_r, k] per rank): all_gather of the counts, then an
     all_gather of buffers padded to the largest count (hit buffers are tiny compared with the pair space, so padding

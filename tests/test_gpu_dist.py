@@ -44,3 +44,9 @@ def test_bench_strong_scaling_world2_gloo_one_device():
     n = 1500
     assert res["config"]["pairs_total"] == n * (n + 1) // 2      # the shards partition the triangle
     assert res["value"] > 0
+    # the hit records the kernels appended on both ranks (gathered) == the records of the unsharded run on the same set
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--chains", "1500", "--no-cpu-baseline",
+                          "--no-search", "--no-live"], capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert one.returncode == 0, one.stderr[-2000:]
+    r1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["config"]["hit_records"]["gathered_all_ranks"] == r1["config"]["hit_records"]["rank0_per_step"] > 0

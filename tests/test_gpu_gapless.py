@@ -179,3 +179,56 @@ def test_uint16_range_contract(ctx):
     want = ol.mu_gapless_pairs(big + small, ia.ravel(), ib.ravel() + 2).reshape(2, 3)
     assert np.array_equal(got, want)
     dbig.close(); dsmall.close()
+
+
+def test_device_hit_records_equal_the_thresholded_matrix():
+    """rsk_mu_gapless_hits_dev: the kernel appends {q, t, score} for every pair reaching min_score (what a search keeps of
+    the pair space) -- must be exactly the entries >= min_score of the dense matrix, each unordered pair once in triangle
+    mode (pairs of two members of one ring are scored twice there), also without a dense matrix, also with index bases
+    (shards), also when the record buffer is too small (count stays exact)."""
+    import torch
+    import reseek_amd
+    rng = np.random.default_rng(23)
+    lens = np.concatenate([rng.integers(5, 400, 700), [1030, 1500, 9, 1]])          # two chains beyond a ring: per-pair kernel
+    seqs = [rng.integers(0, 36, int(L)).astype(np.uint8) for L in lens]
+    for k in range(0, 200, 7):                                                       # planted near-copies: real hits
+        src = seqs[k]
+        seqs[k + 1] = src[:len(seqs[k + 1])].copy() if len(src) >= len(seqs[k + 1]) else np.concatenate([src, seqs[k + 1][len(src):]])
+    ctx = reseek_amd.Ctx(0, stream=torch.cuda.current_stream().cuda_stream)
+    db = reseek_amd.Db.from_mu_seqs(ctx, seqs)
+    n = len(seqs)
+    dense = torch.zeros((n, n), dtype=torch.int32, device="cuda").to(torch.uint16)
+    ctx.mu_gapless_matrix_dev(db, db, True, dense.data_ptr(), n)
+    torch.cuda.synchronize()
+    D = dense.cpu().numpy().astype(np.int64)
+    thr = 60
+    ii, jj = np.triu_indices(n)
+    keep = D[ii, jj] >= thr
+    want = sorted(zip(ii[keep].tolist(), jj[keep].tolist(), D[ii, jj][keep].tolist()))
+    assert 50 < len(want) < 60000
+    cap = 1 << 17
+    rec = torch.zeros((cap, 3), dtype=torch.int32, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for with_dense in (False, True):
+        d2 = torch.zeros((n, n), dtype=torch.int32, device="cuda").to(torch.uint16) if with_dense else None
+        ctx.mu_gapless_hits_dev(db, db, True, thr, rec.data_ptr(), cap, cnt.data_ptr(), d_scores_ptr=d2.data_ptr() if with_dense else 0, ldo=n)
+        torch.cuda.synchronize()
+        m = int(cnt.item())
+        got = sorted(map(tuple, rec[:m].cpu().numpy().tolist()))
+        assert got == want, (m, len(want))
+        if with_dense:
+            assert np.array_equal(d2.cpu().numpy().astype(np.int64)[ii, jj], D[ii, jj])
+    # rectangular block with bases, as a shard of a larger set emits them
+    qa = reseek_amd.Db.from_mu_seqs(ctx, seqs[:300])
+    tb = reseek_amd.Db.from_mu_seqs(ctx, seqs[300:])
+    ctx.mu_gapless_hits_dev(qa, tb, False, thr, rec.data_ptr(), cap, cnt.data_ptr(), q_base=0, t_base=300)
+    torch.cuda.synchronize()
+    m = int(cnt.item())
+    got = sorted(map(tuple, rec[:m].cpu().numpy().tolist()))
+    assert got == [w for w in want if w[0] < 300 <= w[1]]
+    # a buffer that is too small: the count is still exact, the stored records are a subset
+    ctx.mu_gapless_hits_dev(db, db, True, thr, rec.data_ptr(), 10, cnt.data_ptr())
+    torch.cuda.synchronize()
+    assert int(cnt.item()) == len(want)
+    assert set(map(tuple, rec[:10].cpu().numpy().tolist())) <= set(want)
+    db.close(); qa.close(); tb.close(); ctx.close()

@@ -13,4 +13,5 @@ rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc3 -o pmc -- $CMD > $OUT/pmc3.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc4 -o pmc -- $CMD > $OUT/pmc4.log 2>&1
 find $OUT -name "*.csv" | head -30
 python3 $GRAFT_REPO_ROOT/tools/prof_summary.py $OUT > $OUT/summary.txt 2>&1
-cat $OUT/summary.txt
+python3 $GRAFT_REPO_ROOT/tools/prof_traffic_json.py $OUT > $OUT/traffic.json 2> $OUT/traffic.err
+cat $OUT/summary.txt $OUT/traffic.json
