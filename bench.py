@@ -328,6 +328,99 @@ def search_vs_reference(nsample=1500, reps=3):
     return out
 
 
+def config_shares(which=("config2", "config3", "config4")):
+    """Driver-visible numbers for BASELINE configs[2..4] beside the headline (each a whole `rsk_search` call from .bca files,
+    second of two runs where a run is short, with an equality bit of the sorted hit table against oracle/_ref/reseek on a
+    sample of the same files):
+      config2  `-search Q -db Q -fast`, Q = the 11,211-chain SCOP40-shaped synthetic .bca: Mu k-mer prefilter + two-hit
+               diagonals on the GPU, then the candidates under the sensitive preset (search.cpp:76-111)
+      config3  256 queries x 125,000-chain DB `-sensitive`  = one GPU's share of "256 x 1M, pairs sharded over 8 GPUs"
+      config4  1000 queries x 87,500-chain DB `-verysensitive` = one GPU's share of "1k x 700k (PDB scale)"
+    The databases are written by tools/bench_search.py write_bca_fast (seeded; SCOP40 length distribution)."""
+    import torch
+    import reseek_amd
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_search
+    ref = os.path.join(ROOT, "oracle", "_ref", "reseek")
+    lens = scop40_lengths()
+    cores = usable_cpus()
+    ctx = reseek_amd.Ctx(0, stream=torch.cuda.current_stream().cuda_stream)
+    out = {}
+
+    def sample_check(td, q, db, mode, nq_s, ndb_s):
+        """reference binary vs ours on the first nq_s queries x an every-k-th-chain sample of the DB -> dict"""
+        if not os.path.exists(ref):
+            return {"identical": None, "note": "oracle/_ref/reseek did not travel"}
+        sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+        import make_tail_bca
+        qs, dbs = os.path.join(td, "qs.bca"), os.path.join(td, "dbs.bca")
+        rq, lq = make_tail_bca.read_bca(q)
+        bench_search.write_bca_records(qs, rq[:nq_s], labels=lq[:nq_s])
+        if db == q:
+            dbs = qs
+        else:
+            rd, ld = make_tail_bca.read_bca(db) if os.path.getsize(db) < (200 << 20) else (None, None)
+            if rd is None:
+                return {"identical": None, "note": "DB too large to sample in Python"}
+            idx = np.linspace(0, len(rd) - 1, ndb_s).astype(np.int64)
+            bench_search.write_bca_records(dbs, [rd[i] for i in idx], labels=[ld[i] for i in idx])
+        ours, theirs = os.path.join(td, "ours_s.tsv"), os.path.join(td, "ref_s.tsv")
+        ctx.search(qs, ours, mode, db=dbs)
+        t0 = time.perf_counter()
+        subprocess.run([ref, "-search", qs, "-db", dbs, "-" + mode, "-output", theirs, "-threads", "1"], check=True, stdout=subprocess.DEVNULL,
+                       stderr=subprocess.DEVNULL, cwd=td, timeout=900)
+        tr = time.perf_counter() - t0
+        a, b = sorted(open(theirs).read().splitlines()), sorted(open(ours).read().splitlines())
+        return {"identical": a == b, "rows": len(a), "sample": "%d queries x %d DB chains, reference -threads 1 (%.1f s)" % (nq_s, ndb_s if db != q else nq_s, tr)}
+
+    def run(name, what, q, db, mode, reps):
+        hits = q + ".hits.tsv"
+        best = None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            nh, st = ctx.search(q, hits, mode, db=db)
+            dt = time.perf_counter() - t0
+            best = {"what": what, "seconds": dt, "chain_pairs": int(st[0]) if not st[7] else None, "prefilter_candidates": int(st[0]) if st[7] else None,
+                    "sw_pairs": int(st[5]), "long_chain_pairs": int(st[4]), "hits": int(nh), "tsv_bytes": os.path.getsize(hits)}
+        os.remove(hits)
+        return best
+
+    try:
+        with tempfile.TemporaryDirectory() as td:
+            if "config2" in which:
+                rng = np.random.default_rng(7)
+                q = os.path.join(td, "syn11211.bca")
+                bench_search.write_bca(q, lens, rng)                   # the set of search_bca / the full-size goldens
+                e = run("config2", "-search Q -db Q -fast, Q = 11,211 synthetic chains (prefilter + two-hit diagonals on the GPU, candidates "
+                        "under the sensitive preset)", q, q, "fast", 1)
+                e["chain_pairs"] = 11211 * 11211
+                e["chain_pairs_per_sec"] = e["chain_pairs"] / e["seconds"]
+                e["vs_reference_on_sample"] = sample_check(td, q, q, "fast", 400, 400)
+                out["config2_fast_db_11211x11211"] = e
+            for key, nq, ndb, mode, tag in (("config3", 256, 125000, "sensitive", "config3_share_256x125000_sensitive"),
+                                            ("config4", 1000, 87500, "verysensitive", "config4_share_1000x87500_verysensitive")):
+                if key not in which:
+                    continue
+                rng = np.random.default_rng(11)
+                q, db = os.path.join(td, key + "_q.bca"), os.path.join(td, key + "_db.bca")
+                bench_search.write_bca_fast(q, lens[rng.choice(len(lens), nq)], rng, "q")
+                t0 = time.perf_counter()
+                bench_search.write_bca_fast(db, lens[rng.choice(len(lens), ndb)], rng, "d")
+                tgen = time.perf_counter() - t0
+                e = run(key, "-search Q -db DB -%s, %d queries x %d-chain .bca DB (one GPU's share; DSS featurisation + self-rev of the DB "
+                        "inside the call)" % (mode, nq, ndb), q, db, mode, 2 if key == "config3" else 1)
+                e["chain_pairs_per_sec"] = e["chain_pairs"] / e["seconds"]
+                e["db_generation_seconds"] = tgen
+                e["vs_reference_on_sample"] = sample_check(td, q, db, mode, 32 if key == "config3" else 8, 1500 if key == "config3" else 600)
+                out[tag] = e
+                os.remove(db)
+    finally:
+        ctx.close()
+    out["kernel_time_split"] = "rocprofv3 kernel traces of these three calls: profiles/r03_search_*_rocprofv3.txt (tools/prof_search.sh)"
+    out["reference_cores_on_this_box"] = cores
+    return out
+
+
 def search_sharded_leg(ctx, seqs, rank, world, dist, coll_dev):
     """N > 1: the whole `-search -sensitive` all-vs-all call with the triangle cut into target ranges, one per rank
     (rsk_search shard_index / shard_count), hit tables gathered on rank 0 over the process group; max-over-ranks wall
@@ -367,6 +460,8 @@ def main():
     ap.add_argument("--no-search", action="store_true", help="skip the end-to-end -search legs (rank 0, 1 GPU only)")
     ap.add_argument("--no-live", action="store_true", help="skip the live-path kernel rooflines (rank 0, 1 GPU only)")
     ap.add_argument("--live-only", action="store_true", help="only the live-path kernels (the command tools/prof_live.sh profiles)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE configs[2..4] legs (rank 0, 1 GPU only)")
+    ap.add_argument("--configs-only", default="", help="only these legs, e.g. config3,config4 (prints their JSON and exits)")
     args = ap.parse_args()
 
     import torch
@@ -413,6 +508,9 @@ def main():
     dbq = reseek_amd.Db.from_mu_seqs(ctx, seqs[:lo]) if lo and nb else None
     if args.live_only:
         print(json.dumps({"roofline_live": live_kernels(ctx, seqs, db, reps=1)}))
+        return
+    if args.configs_only:
+        print(json.dumps({"configs": config_shares(tuple(args.configs_only.split(",")))}))
         return
     out = torch.zeros((max(nb, 1), max(nb, 1)), dtype=torch.int16, device="cuda")
     outq = torch.zeros((max(lo, 1), max(nb, 1)), dtype=torch.int16, device="cuda") if dbq is not None else None
@@ -568,6 +666,11 @@ def main():
                 res["search_bca"] = search_vs_reference()
             except Exception as e:  # noqa: BLE001 -- the kernel metric above stands on its own
                 sys.stderr.write("bench: end-to-end search leg failed: %s\n" % e)
+        if not args.no_configs and not args.no_search and world == 1 and not args.chains:
+            try:
+                res["configs"] = config_shares()
+            except Exception as e:  # noqa: BLE001
+                sys.stderr.write("bench: configs[2..4] leg failed: %s\n" % e)
         print(json.dumps(res))
     if dist is not None:
         dist.barrier()

@@ -56,6 +56,41 @@ def gen_bca_chains(lens, rng):
     return recs
 
 
+def write_bca_fast(path, lens, rng, label_prefix="syn"):
+    """A large synthetic .bca in one vectorised pass (the databases of BASELINE configs 3 / 4 have 10^5 - 10^6 chains; the
+    per-chain generator above takes ~0.5 ms per chain): ONE persistent random walk over all residues, cut at the chain
+    boundaries, every chain centred on the origin.  Same layout as write_bca_records; different data than gen_bca_chains."""
+    lens = np.asarray(lens, np.int64)
+    n, tot = len(lens), int(lens.sum())
+    start = np.concatenate([[0], np.cumsum(lens)])
+    d = lfilter([0.6], [1.0, -0.8], rng.normal(0, 1, (tot, 3)).astype(np.float32) / 0.6, axis=0)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    xyz = np.cumsum(3.8 * d.astype(np.float64), axis=0)
+    first = xyz[start[:-1]] - 3.8 * d[start[:-1]]                          # walk position just before each chain
+    mean = (np.add.reduceat(xyz, start[:-1], axis=0) / lens[:, None])
+    xyz -= np.repeat(mean, lens, axis=0)
+    del first
+    ic = np.clip(((xyz.astype(np.float32) + 1000) * 10 + 0.5), 0, 65535).astype(np.uint16)
+    aa = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", np.uint8)[rng.integers(0, 20, tot)]
+    with open(path, "wb") as f:
+        f.write(struct.pack("<IQQQ", 0xBCABCA, n, 0, 0))
+        # per chain: L sequence bytes, then 3L uint16 coordinates (x, y, z interleaved)
+        blob = np.empty(7 * tot, np.uint8)
+        off = np.repeat(7 * start[:-1], lens) + (np.arange(tot) - np.repeat(start[:-1], lens))          # sequence byte of residue k
+        blob[off] = aa
+        cbase = np.repeat(7 * start[:-1] + lens, lens) + 6 * (np.arange(tot) - np.repeat(start[:-1], lens))
+        icb = ic.view(np.uint8).reshape(tot, 6)
+        for b in range(6):
+            blob[cbase + b] = icb[:, b]
+        f.write(blob.tobytes())
+        pos = f.tell()
+        f.write(lens.astype(np.uint32).tobytes())
+        lab = b"".join(("%s%06d" % (label_prefix, k)).encode() + b"\0" for k in range(n))
+        f.write(lab)
+        f.seek(4)
+        f.write(struct.pack("<QQQ", n, pos, len(lab)))
+
+
 def write_bca_records(path, recs, labels=None):
     """bcadata.cpp layout: magic, #chains, offset of the length table, label bytes; per chain sequence + 3L uint16
     coordinates; uint32 lengths; NUL-terminated labels."""
