@@ -221,8 +221,7 @@ int rsk_xdrop_pairs(rsk_ctx *ctx, const rsk_db *a, const rsk_db *b, const uint32
                     uint32_t *fwd_len, uint64_t *bwd_off, uint32_t *bwd_len);
 
 /* P9 after the chaining, in ONE device batch (what DBSearcher's long-chain stage uses): per pair the chained seed HSPs
- * (MuKmerFilter::ChainHSPs mukmerfilter.cpp:391, kept on the host: Chainer::Chain sorts with libc qsort on a comparator that
- * is no total order) as a CSR list hsp_first[npairs + 1] / hsp_lo_a / hsp_lo_b / hsp_len ->
+ * (MuKmerFilter::ChainHSPs mukmerfilter.cpp:391; rsk_mkf_chain_align_pairs below chains on the device as well) as a CSR list hsp_first[npairs + 1] / hsp_lo_a / hsp_lo_b / hsp_len ->
  *   PostAlignMKF (dssaligner.cpp:1395: GetMegaHSPScore :488 of every HSP, sum < min_mega_score => no alignment, best HSP),
  *   XDropHSP (xdrophsp.cpp:42: best 8-mer of that HSP = start, XDropFwd + XDropBwd with X = x2, total < 10 => no alignment),
  *   MergeFwdBwd (mergefwdback.cpp:6) and CalcEvalue (dssaligner.cpp:852).
@@ -233,6 +232,17 @@ int rsk_mkf_align_pairs(rsk_ctx *ctx, const rsk_db *a, const rsk_db *b, const ui
                         const uint32_t *hsp_first, const int32_t *hsp_lo_a, const int32_t *hsp_lo_b, const int32_t *hsp_len, float x2,
                         float gap_open, float gap_ext, float min_mega_score, float min_fwd_score, rsk_aln *out, uint8_t *status, char *paths,
                         size_t paths_bytes);
+
+/* The same batch starting one step earlier, from the UNCHAINED seed HSPs of every pair (what rsk_mkf_seed_pairs keeps: lo_a, lo_b,
+ * len, integer score per HSP; at most 64 per pair): MuKmerFilter::ChainHSPs (mukmerfilter.cpp:391) / Chainer::Chain (chainer.cpp:31)
+ * run on the device too, then everything above.  status[p] as above, plus 3 = the reference's chaining of this pair depends
+ * on how libc qsort orders two equal interval end points (two HSPs ending at one query position with equal chain scores,
+ * chainer.cpp:11-29,121-124): nothing is aligned for it here, the caller chains that pair with qsort itself and passes it to
+ * rsk_mkf_align_pairs.  A chain whose total score is <= 0 counts as "no alignment" (status 0, dssaligner.cpp:1397). */
+int rsk_mkf_chain_align_pairs(rsk_ctx *ctx, const rsk_db *a, const rsk_db *b, const uint32_t *ia, const uint32_t *ib, size_t npairs,
+                              const uint32_t *hsp_first, const int32_t *hsp_lo_a, const int32_t *hsp_lo_b, const int32_t *hsp_len,
+                              const int32_t *hsp_score, float x2, float gap_open, float gap_ext, float min_mega_score, float min_fwd_score,
+                              rsk_aln *out, uint8_t *status, char *paths, size_t paths_bytes);
 
 /* ---- P10/P11/P12: Mu k-mer prefilter ----------------------------------------------------------------
  * Batch form of MuDex::FromSeqDB (mudex.cpp:386; index of the QUERY set, built once and cached in q)

@@ -79,6 +79,8 @@ SIGNATURES["rsk_xdrop_pairs"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, u
                                            C.POINTER(C.c_uint64), u32p])
 SIGNATURES["rsk_mkf_align_pairs"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, u32p, u32p, C.c_size_t, u32p, i32p, i32p, i32p, C.c_float,
                                                C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(Aln), u8p, C.c_char_p, C.c_size_t])
+SIGNATURES["rsk_mkf_chain_align_pairs"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, u32p, u32p, C.c_size_t, u32p, i32p, i32p, i32p, i32p, C.c_float,
+                                                     C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(Aln), u8p, C.c_char_p, C.c_size_t])
 SIGNATURES["rsk_xdrop_fwd"] = (C.c_int, [C.c_void_p, f32p, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32,
                                          f32p, C.c_char_p, C.c_size_t, u32p])
 SIGNATURES["rsk_xdrop_bwd"] = SIGNATURES["rsk_xdrop_fwd"]
@@ -295,8 +297,9 @@ class Ctx:
                 for k in range(n)]
 
     def mkf_align_pairs(self, a, b, ia, ib, hsp_first, hsp_lo_a, hsp_lo_b, hsp_len, x2=8.0, gap_open=GAP_OPEN, gap_ext=GAP_EXT,
-                        min_mega_score=-4.0, min_fwd_score=7.0):
-        """rsk_mkf_align_pairs -> (list of (Aln, path str), status uint8[n])"""
+                        min_mega_score=-4.0, min_fwd_score=7.0, hsp_score=None):
+        """rsk_mkf_align_pairs -> (list of (Aln, path str), status uint8[n]); with hsp_score the lists are the UNCHAINED seed HSPs and
+        rsk_mkf_chain_align_pairs chains them on the device first (status 3 = tied chain, left to the caller)"""
         ia = np.ascontiguousarray(ia, np.uint32)
         ib = np.ascontiguousarray(ib, np.uint32)
         hf = np.ascontiguousarray(hsp_first, np.uint32)
@@ -307,8 +310,14 @@ class Ctx:
         buf = C.create_string_buffer(nbytes)
         out = (Aln * max(1, n))()
         status = np.zeros(max(1, n), np.uint8)
-        _check(lib().rsk_mkf_align_pairs(self.h, a.h, b.h, _p(ia, u32p), _p(ib, u32p), n, _p(hf, u32p), _p(hla, i32p), _p(hlb, i32p), _p(hl, i32p),
-                                         x2, gap_open, gap_ext, min_mega_score, min_fwd_score, out, _p(status, u8p), buf, nbytes))
+        if hsp_score is not None:
+            hs = np.ascontiguousarray(hsp_score, np.int32)
+            _check(lib().rsk_mkf_chain_align_pairs(self.h, a.h, b.h, _p(ia, u32p), _p(ib, u32p), n, _p(hf, u32p), _p(hla, i32p), _p(hlb, i32p),
+                                                   _p(hl, i32p), _p(hs, i32p), x2, gap_open, gap_ext, min_mega_score, min_fwd_score, out,
+                                                   _p(status, u8p), buf, nbytes))
+        else:
+            _check(lib().rsk_mkf_align_pairs(self.h, a.h, b.h, _p(ia, u32p), _p(ib, u32p), n, _p(hf, u32p), _p(hla, i32p), _p(hlb, i32p), _p(hl, i32p),
+                                             x2, gap_open, gap_ext, min_mega_score, min_fwd_score, out, _p(status, u8p), buf, nbytes))
         raw = buf.raw
         return [(out[k], raw[out[k].path_off:out[k].path_off + out[k].path_len].decode()) for k in range(n)], status[:n]
 

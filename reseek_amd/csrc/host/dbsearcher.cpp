@@ -849,64 +849,130 @@ void RunMKFPairs(rsk_ctx *Ctx, const DSSParams &P, const std::string &Columns, D
         DA.SetQuery(*SrcA.m_DBChains[i], SrcA.m_DBProfiles[i], SrcA.m_DBMuLettersVec[i], SrcA.m_DBMuKmersVec[i], SrcA.m_DBSelfRevScores[i]);
         DA.SetTarget(*SrcB.m_DBChains[j], SrcB.m_DBProfiles[j], SrcB.m_DBMuLettersVec[j], SrcB.m_DBMuKmersVec[j], SrcB.m_DBSelfRevScores[j]);
     };
-    // stage 1 (host threads): chain the seed HSPs of every record (MuKmerFilter::ChainHSPs mukmerfilter.cpp:391 ->
-    // Chainer::Chain, libc qsort on a comparator that is no total order: the one step that stays on the host).
+    // stage 1 + 2 (GPU, one batch): the seed HSPs of every record -> chain (Chainer::Chain), mega-HSP scores + gates, start of
+    // the gapped extensions, both extensions, merge, statistics (rsk_mkf_chain_align_pairs).  Two kinds of pairs make a second,
+    // small batch after a host step: records whose seed list was truncated on the device (MuKmerFilter::Align re-seeds them)
+    // and pairs whose chain depends on libc qsort's order of equal end points (status 3) -- both chained by ChainHSPs here.
     struct Chained { std::vector<int32_t> lo_a, lo_b, len; };
-    std::vector<Chained> chains(recs.size());
-    parallel([&](DSSAligner &DA, size_t r, unsigned) {
-        const Rec &R = recs[r];
-        if (R.nkept > CAP) {                                          // seed list truncated on the device: seeds from MuKmerFilter::Align
-            set_pair(DA, r);
-            DA.m_MKF.Align(*DA.m_MuLettersB, *DA.m_MuKmersB);
-        } else
-            DA.m_MKF.SetSeedHSPs(R.kept.data(), R.nkept);
-        if (DA.m_MKF.m_BestChainScore <= 0) return;                   // PostAlignMKF dssaligner.cpp:1397
-        Chained &C = chains[r];
-        C.lo_a.assign(DA.m_MKF.m_ChainHSPLois.begin(), DA.m_MKF.m_ChainHSPLois.end());
-        C.lo_b.assign(DA.m_MKF.m_ChainHSPLojs.begin(), DA.m_MKF.m_ChainHSPLojs.end());
-        C.len.assign(DA.m_MKF.m_ChainHSPLens.begin(), DA.m_MKF.m_ChainHSPLens.end());
-    });
-    // stage 2 (GPU, one batch): mega-HSP scores + gates, start of the gapped extensions, both extensions, merge, statistics
     std::vector<size_t> slot(recs.size(), (size_t) -1);
     std::vector<uint32_t> xa, xb, first(1, 0);
-    std::vector<int32_t> hla, hlb, hlen;
+    std::vector<int32_t> hla, hlb, hlen, hsc;
+    std::vector<size_t> host_recs;                                      // records of the second batch
     size_t xbytes = 0;
     for (size_t r = 0; r < recs.size(); ++r) {
-        if (chains[r].len.empty()) continue;
+        const Rec &R = recs[r];
+        if (R.nkept > CAP) { host_recs.push_back(r); continue; }
         slot[r] = xa.size();
-        const uint i = Pairs[recs[r].pair].first, j = Pairs[recs[r].pair].second;
+        const uint i = Pairs[R.pair].first, j = Pairs[R.pair].second;
         xa.push_back(i); xb.push_back(j);
-        hla.insert(hla.end(), chains[r].lo_a.begin(), chains[r].lo_a.end());
-        hlb.insert(hlb.end(), chains[r].lo_b.begin(), chains[r].lo_b.end());
-        hlen.insert(hlen.end(), chains[r].len.begin(), chains[r].len.end());
+        for (uint32_t k = 0; k < R.nkept; ++k) {
+            hla.push_back(R.kept[4 * k]); hlb.push_back(R.kept[4 * k + 1]); hlen.push_back(R.kept[4 * k + 2]); hsc.push_back(R.kept[4 * k + 3]);
+        }
         first.push_back((uint32_t) hla.size());
         xbytes += (size_t) SrcA.m_DBChains[i]->GetSeqLength() + SrcB.m_DBChains[j]->GetSeqLength() + 1;
     }
-    const size_t nx = xa.size();
+    size_t nx = xa.size();
     std::vector<rsk_aln> xout(nx);
     std::vector<uint8_t> xstatus(nx);
     std::unique_ptr<char[]> xpaths_mem(new char[xbytes + 16]);         // hundreds of MB: not value-initialised
-    char *const xpaths = xpaths_mem.get();
+    char *xpaths = xpaths_mem.get();
     if (nx)
-        check(rsk_mkf_align_pairs(Ctx, SrcA.m_Db, SrcB.m_Db, xa.data(), xb.data(), nx, first.data(), hla.data(), hlb.data(), hlen.data(),
-                                  float(P.m_MKF_X2), P.m_GapOpen, P.m_GapExt, P.m_MKF_MinMegaHSPScore, P.m_MinFwdScore, xout.data(), xstatus.data(),
-                                  xpaths, xbytes + 16),
-              "rsk_mkf_align_pairs");
+        check(rsk_mkf_chain_align_pairs(Ctx, SrcA.m_Db, SrcB.m_Db, xa.data(), xb.data(), nx, first.data(), hla.data(), hlb.data(), hlen.data(),
+                                        hsc.data(), float(P.m_MKF_X2), P.m_GapOpen, P.m_GapExt, P.m_MKF_MinMegaHSPScore, P.m_MinFwdScore, xout.data(),
+                                        xstatus.data(), xpaths, xbytes + 16),
+              "rsk_mkf_chain_align_pairs");
+    for (size_t r = 0; r < recs.size(); ++r)
+        if (slot[r] != (size_t) -1 && xstatus[slot[r]] == 3) { host_recs.push_back(r); slot[r] = (size_t) -1; }
+    // second batch: chained on the host threads
+    std::vector<rsk_aln> yout;
+    std::vector<uint8_t> ystatus;
+    std::unique_ptr<char[]> ypaths_mem;
+    std::vector<size_t> yslot(recs.size(), (size_t) -1);
+    if (!host_recs.empty()) {
+        std::vector<Chained> chains(host_recs.size());
+        const size_t saved_T = recs.size();
+        (void) saved_T;
+        std::atomic<size_t> nexth{0};
+        auto body = [&]() {
+            DSSAligner DA;
+            DA.SetParams(P);
+            for (;;) {
+                const size_t h = nexth.fetch_add(1);
+                if (h >= host_recs.size()) break;
+                const size_t r = host_recs[h];
+                const Rec &R = recs[r];
+                if (R.nkept > CAP) {                                      // seed list truncated on the device: seeds from MuKmerFilter::Align
+                    set_pair(DA, r);
+                    DA.m_MKF.Align(*DA.m_MuLettersB, *DA.m_MuKmersB);
+                } else
+                    DA.m_MKF.SetSeedHSPs(R.kept.data(), R.nkept);
+                if (DA.m_MKF.m_BestChainScore <= 0) continue;             // PostAlignMKF dssaligner.cpp:1397
+                Chained &C = chains[h];
+                C.lo_a.assign(DA.m_MKF.m_ChainHSPLois.begin(), DA.m_MKF.m_ChainHSPLois.end());
+                C.lo_b.assign(DA.m_MKF.m_ChainHSPLojs.begin(), DA.m_MKF.m_ChainHSPLojs.end());
+                C.len.assign(DA.m_MKF.m_ChainHSPLens.begin(), DA.m_MKF.m_ChainHSPLens.end());
+            }
+            DA.UnsetQuery();
+        };
+        {
+            const unsigned TH = (unsigned) std::max<size_t>(1, std::min<size_t>(T, host_recs.size() / 8 + 1));
+            std::vector<std::thread> ts;
+            std::vector<std::string> errs(TH);
+            for (unsigned t = 0; t < TH; ++t)
+                ts.emplace_back([&, t]() { try { body(); } catch (const std::exception &e) { errs[t] = e.what(); } });
+            for (auto &t : ts) t.join();
+            for (auto &e : errs)
+                if (!e.empty()) throw std::runtime_error(e);
+        }
+        std::vector<uint32_t> ya, yb, yfirst(1, 0);
+        std::vector<int32_t> yla, ylb, ylen;
+        size_t ybytes = 0;
+        for (size_t h = 0; h < host_recs.size(); ++h) {
+            if (chains[h].len.empty()) continue;
+            const size_t r = host_recs[h];
+            yslot[r] = ya.size();
+            const uint i = Pairs[recs[r].pair].first, j = Pairs[recs[r].pair].second;
+            ya.push_back(i); yb.push_back(j);
+            yla.insert(yla.end(), chains[h].lo_a.begin(), chains[h].lo_a.end());
+            ylb.insert(ylb.end(), chains[h].lo_b.begin(), chains[h].lo_b.end());
+            ylen.insert(ylen.end(), chains[h].len.begin(), chains[h].len.end());
+            yfirst.push_back((uint32_t) yla.size());
+            ybytes += (size_t) SrcA.m_DBChains[i]->GetSeqLength() + SrcB.m_DBChains[j]->GetSeqLength() + 1;
+        }
+        yout.resize(ya.size());
+        ystatus.resize(ya.size());
+        ypaths_mem.reset(new char[ybytes + 16]);
+        if (!ya.empty())
+            check(rsk_mkf_align_pairs(Ctx, SrcA.m_Db, SrcB.m_Db, ya.data(), yb.data(), ya.size(), yfirst.data(), yla.data(), ylb.data(), ylen.data(),
+                                      float(P.m_MKF_X2), P.m_GapOpen, P.m_GapExt, P.m_MKF_MinMegaHSPScore, P.m_MinFwdScore, yout.data(), ystatus.data(),
+                                      ypaths_mem.get(), ybytes + 16),
+                  "rsk_mkf_align_pairs");
+    }
+    if (getenv("RSK_TRACE") && !host_recs.empty())
+        fprintf(stderr, "[RunMKFPairs] %zu pairs chained on the host (truncated seed lists / chains tied under qsort)\n", host_recs.size());
     const auto t_host1 = std::chrono::steady_clock::now();
     // stage 3 (host threads): the aligned pairs become DSSAligner results and go to the caller
     std::mutex lock;
     parallel([&](DSSAligner &DA, size_t r, unsigned worker) {
         const Rec &R = recs[r];
         const uint i = Pairs[R.pair].first, j = Pairs[R.pair].second;
-        const size_t k = slot[r];
         // status 2 (the start XDropHSP derives lies outside a chain: only possible for chains shorter than 8, where the
         // reference's own extents wrap around) counts as "no alignment"
-        if (k == (size_t) -1 || xstatus[k] != 1 || xout[k].path_len == 0) return;       // nothing to report (m_Path empty)
+        const rsk_aln *aln = nullptr;
+        const char *path = nullptr;
+        if (slot[r] != (size_t) -1) {
+            const size_t k = slot[r];
+            if (xstatus[k] == 1 && xout[k].path_len) { aln = &xout[k]; path = xpaths + xout[k].path_off; }
+        } else if (yslot[r] != (size_t) -1) {
+            const size_t k = yslot[r];
+            if (ystatus[k] == 1 && yout[k].path_len) { aln = &yout[k]; path = ypaths_mem.get() + yout[k].path_off; }
+        }
+        if (!aln) return;                                                    // nothing to report (m_Path empty)
         DA.ClearAlign();
         DA.m_ChainA = SrcA.m_DBChains[i]; DA.m_ProfileA = SrcA.m_DBProfiles[i];
         DA.m_ChainB = SrcB.m_DBChains[j]; DA.m_ProfileB = SrcB.m_DBProfiles[j];
         DA.m_SelfRevScoreA = SrcA.m_DBSelfRevScores[i]; DA.m_SelfRevScoreB = SrcB.m_DBSelfRevScores[j];
-        DA.SetFromAln(xout[k], xpaths + xout[k].path_off);
+        DA.SetFromAln(*aln, path);
         if (OnHitOfWorker) { (*OnHitOfWorker)(DA, i, j, worker); return; }
         std::lock_guard<std::mutex> g(lock);
         OnHit(DA, i, j);

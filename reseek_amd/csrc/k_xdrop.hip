@@ -778,19 +778,87 @@ extern "C" int rsk_xdrop_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
 //   PostAlignMKF dssaligner.cpp:1395-1430 (GetMegaHSPScore :488 of every chained HSP, the MinMegaHSPScore gate, best HSP),
 //   XDropHSP xdrophsp.cpp:42-117 (best 8-mer of that HSP = start, XDropFwd + XDropBwd, TotalScore < 10 => no alignment),
 //   MergeFwdBwd mergefwdback.cpp:6, CalcEvalue dssaligner.cpp:852 (LDDT, test statistic, E-value).
-// Only the chaining (Chainer::Chain: libc qsort on a comparator that is no total order) stays on the host.
+// The chaining of the seed HSPs (MuKmerFilter::ChainHSPs mukmerfilter.cpp:391 -> Chainer::Chain chainer.cpp:31) runs on the
+// device as well (k_mkf_chain, rsk_mkf_chain_align_pairs) for every pair whose outcome is defined: the reference sorts the
+// interval end points with libc qsort on a comparator that returns 0 for two end points of the same kind at the same
+// position (chainer.cpp:11-29), and the sweep takes the FIRST of two intervals that end at one position with equal chain
+// scores -- whichever qsort left in front.  Those pairs (status 3) go back to the caller, which chains them with the
+// same libc qsort on the host (rsk_mkf_align_pairs takes chained lists).
 // ---------------------------------------------------------------------------------------------
 struct mkfa_args {
     const uint16_t *a_ra, *b_cb;
     const uint32_t *a_off, *b_off, *a_len, *b_len;
     const uint32_t *ia, *ib;
     const uint32_t *hsp_first;       // [npairs + 1]
+    const uint32_t *hsp_cnt;         // optional: HSPs of pair p = hsp_cnt[p] entries from hsp_first[p] (lists chained on the device)
     const int32_t *hsp_lo_a, *hsp_lo_b, *hsp_len;
     uint32_t npairs;
     float min_mega;
     uint8_t *valid;                  // 1 = extensions wanted, 0 = no alignment, 2 = start outside 1..L-1 (host decides)
     uint32_t *lo_a, *lo_b;           // start of the gapped extensions
 };
+
+// Chainer::Chain (chainer.cpp:31-176) over the seed HSPs of one pair, one thread per pair (a pair has at most MKF_CHAIN_MAX
+// HSPs: the seeding keeps 32).  Intervals [Lo_i, Lo_i + Len - 1] on the query with the HSP's integer score: sweep over
+// the 2N end points in order of position, starts before ends at one position; at a start the interval's chain score is
+// its score plus the best chain that has ended; at an end it becomes the best ended chain if strictly better.  The
+// chain is reported end -> start (the order ChainHSPs hands it to PostAlignMKF, whose float sums follow it).
+// The pair's HSP list is rewritten in place to that chain, cnt[p] = its length, 0 if the chain's total score is <= 0
+// (PostAlignMKF dssaligner.cpp:1397).  valid[p] = 3 marks a sweep whose outcome depends on the order of two equal end points.
+#define MKF_CHAIN_MAX 64
+__global__ __launch_bounds__(64) void k_mkf_chain(const uint32_t *first, int32_t *lo_a, int32_t *lo_b, int32_t *len, const int32_t *score,
+                                                 uint32_t npairs, uint32_t *cnt, uint8_t *valid)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npairs) return;
+    const uint32_t h0 = first[p], N = first[p + 1] - h0;
+    valid[p] = 0;
+    cnt[p] = 0;
+    if (N == 0) return;
+    if (N > MKF_CHAIN_MAX) { valid[p] = 3; return; }
+    // end points as sortable keys: position, then starts before ends, then the HSP's index
+    uint32_t key[2 * MKF_CHAIN_MAX];
+    for (uint32_t i = 0; i < N; ++i) {
+        const uint32_t lo = (uint32_t) lo_a[h0 + i], hi = lo + (uint32_t) len[h0 + i] - 1;
+        key[2 * i] = (lo << 8) | i;
+        key[2 * i + 1] = (hi << 8) | 0x80u | i;
+    }
+    for (uint32_t i = 1; i < 2 * N; ++i) {          // insertion sort: the lists are a few entries long
+        const uint32_t k = key[i];
+        uint32_t j = i;
+        for (; j > 0 && key[j - 1] > k; --j) key[j] = key[j - 1];
+        key[j] = k;
+    }
+    float cs[MKF_CHAIN_MAX];
+    uint32_t tb[MKF_CHAIN_MAX], endpos[MKF_CHAIN_MAX];
+    const uint32_t NONE = 0xFFFFFFFFu;
+    uint32_t best_end = NONE;
+    bool tied = false;
+    for (uint32_t e = 0; e < 2 * N; ++e) {
+        const uint32_t i = key[e] & 0x7Fu, pos = key[e] >> 8;
+        if (!(key[e] & 0x80u)) {
+            tb[i] = best_end;
+            cs[i] = best_end == NONE ? (float) score[h0 + i] : cs[best_end] + (float) score[h0 + i];
+        } else {
+            endpos[i] = pos;
+            if (best_end == NONE || cs[i] > cs[best_end]) best_end = i;
+            else if (cs[i] == cs[best_end] && endpos[best_end] == pos) tied = true;      // which of the two qsort leaves first decides
+        }
+    }
+    if (tied) { valid[p] = 3; return; }
+    // chain end -> start, then the list in place (the entries are read before they are overwritten: copy out first)
+    int32_t ca[MKF_CHAIN_MAX], cb[MKF_CHAIN_MAX], cl[MKF_CHAIN_MAX];
+    uint32_t n = 0;
+    float total = 0;
+    for (uint32_t i = best_end; i != NONE; i = tb[i]) {
+        total += (float) score[h0 + i];
+        ca[n] = lo_a[h0 + i]; cb[n] = lo_b[h0 + i]; cl[n] = len[h0 + i];
+        ++n;
+    }
+    if ((int) total <= 0) return;
+    for (uint32_t k = 0; k < n; ++k) { lo_a[h0 + k] = ca[k]; lo_b[h0 + k] = cb[k]; len[h0 + k] = cl[k]; }
+    cnt[p] = n;
+}
 
 // one thread per pair; every sum in the reference's order
 __global__ __launch_bounds__(256) void k_mkf_start(mkfa_args a)
@@ -804,7 +872,8 @@ __global__ __launch_bounds__(256) void k_mkf_start(mkfa_args a)
     const uint16_t *RA = a.a_ra + (size_t) a.a_off[A] * 8, *CB = a.b_cb + (size_t) a.b_off[B] * 8;
     const char *tabb = (const char *) tab;
     const uint32_t toffb[8] = { 0 * 4, 400 * 4, 656 * 4, 912 * 4, 1168 * 4, 1424 * 4, 1680 * 4, 1936 * 4 };
-    const uint32_t h0 = a.hsp_first[p], h1 = a.hsp_first[p + 1];
+    const uint32_t h0 = a.hsp_first[p], h1 = a.hsp_cnt ? h0 + a.hsp_cnt[p] : a.hsp_first[p + 1];
+    if (a.hsp_cnt && a.valid[p] == 3) return;     // k_mkf_chain: tied chain, the caller decides
     a.valid[p] = 0; a.lo_a[p] = 0; a.lo_b[p] = 0;
     if (h1 == h0) return;
     float MegaTotal = 0, BestMega = 0;
@@ -898,10 +967,35 @@ __global__ __launch_bounds__(256) void k_mkf_merge(mkfm_args a)
     }
 }
 
+static int mkf_batch(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *dbb, const uint32_t *ia, const uint32_t *ib, size_t npairs,
+                     const uint32_t *hsp_first, const int32_t *hsp_lo_a, const int32_t *hsp_lo_b, const int32_t *hsp_len,
+                     const int32_t *hsp_score /* non-NULL: unchained seed HSPs, chained on the device */, float x2, float gap_open, float gap_ext,
+                     float min_mega_score, float min_fwd_score, rsk_aln *out, uint8_t *status, char *paths, size_t paths_bytes);
+
 extern "C" int rsk_mkf_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *dbb, const uint32_t *ia, const uint32_t *ib, size_t npairs,
                                    const uint32_t *hsp_first, const int32_t *hsp_lo_a, const int32_t *hsp_lo_b, const int32_t *hsp_len, float x2,
                                    float gap_open, float gap_ext, float min_mega_score, float min_fwd_score, rsk_aln *out, uint8_t *status,
                                    char *paths, size_t paths_bytes)
+{
+    return mkf_batch(ctx, dba, dbb, ia, ib, npairs, hsp_first, hsp_lo_a, hsp_lo_b, hsp_len, nullptr, x2, gap_open, gap_ext, min_mega_score,
+                     min_fwd_score, out, status, paths, paths_bytes);
+}
+
+extern "C" int rsk_mkf_chain_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *dbb, const uint32_t *ia, const uint32_t *ib, size_t npairs,
+                                         const uint32_t *hsp_first, const int32_t *hsp_lo_a, const int32_t *hsp_lo_b, const int32_t *hsp_len,
+                                         const int32_t *hsp_score, float x2, float gap_open, float gap_ext, float min_mega_score,
+                                         float min_fwd_score, rsk_aln *out, uint8_t *status, char *paths, size_t paths_bytes)
+{
+    if (npairs && hsp_first && hsp_first[npairs] && !hsp_score) { rsk_set_error("rsk_mkf_chain_align_pairs: NULL HSP scores"); return RSK_E_INVALID; }
+    static const int32_t none = 0;
+    return mkf_batch(ctx, dba, dbb, ia, ib, npairs, hsp_first, hsp_lo_a, hsp_lo_b, hsp_len, hsp_score ? hsp_score : &none, x2, gap_open, gap_ext,
+                     min_mega_score, min_fwd_score, out, status, paths, paths_bytes);
+}
+
+static int mkf_batch(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *dbb, const uint32_t *ia, const uint32_t *ib, size_t npairs,
+                     const uint32_t *hsp_first, const int32_t *hsp_lo_a, const int32_t *hsp_lo_b, const int32_t *hsp_len, const int32_t *hsp_score,
+                     float x2, float gap_open, float gap_ext, float min_mega_score, float min_fwd_score, rsk_aln *out, uint8_t *status,
+                     char *paths, size_t paths_bytes)
 {
     if (!ctx || !dba || !dbb || (npairs && (!ia || !ib || !hsp_first || !out || !status || !paths))) { rsk_set_error("rsk_mkf_align_pairs: NULL argument"); return RSK_E_INVALID; }
     if (!dba->d_prof_ra || !dbb->d_prof_cb || !dba->d_x || !dbb->d_x) { rsk_set_error("rsk_mkf_align_pairs: chain sets need profiles and coordinates"); return RSK_E_INVALID; }
@@ -961,8 +1055,8 @@ extern "C" int rsk_mkf_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db
         const uint32_t h_lo = hsp_first[done], h_hi = hsp_first[p1];
         std::vector<uint32_t> first(m + 1);
         for (size_t k = 0; k <= m; ++k) first[k] = hsp_first[done + k] - h_lo;
-        uint32_t *d_ia, *d_ib, *d_first, *d_loa, *d_lob, *d_pstart, *d_plen, *d_mloa, *d_mlob, *d_mplen;
-        int32_t *d_hla, *d_hlb, *d_hlen;
+        uint32_t *d_ia, *d_ib, *d_first, *d_loa, *d_lob, *d_pstart, *d_plen, *d_mloa, *d_mlob, *d_mplen, *d_hcnt = nullptr;
+        int32_t *d_hla, *d_hlb, *d_hlen, *d_hsc = nullptr;
         uint8_t *d_valid, *d_tb;
         uint64_t *d_rowoff, *d_tboff, *d_pathoff, *d_mpoff, *d_mpstart;
         float *d_rows, *d_xscore, *d_mscore;
@@ -978,6 +1072,7 @@ extern "C" int rsk_mkf_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db
             (rc = dalloc((void **) &d_mloa, m * 4)) || (rc = dalloc((void **) &d_mlob, m * 4)) || (rc = dalloc((void **) &d_mpstart, m * 8)) ||
             (rc = dalloc((void **) &d_mplen, m * 4)))
             return rc;
+        if (hsp_score && ((rc = dalloc((void **) &d_hsc, nhb * 4)) || (rc = dalloc((void **) &d_hcnt, m * 4)))) return rc;
         RSK_HIP(hipMemcpyAsync(d_ia, ia + done, m * 4, hipMemcpyHostToDevice, ctx->stream));
         RSK_HIP(hipMemcpyAsync(d_ib, ib + done, m * 4, hipMemcpyHostToDevice, ctx->stream));
         RSK_HIP(hipMemcpyAsync(d_first, first.data(), (m + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -985,6 +1080,7 @@ extern "C" int rsk_mkf_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db
             RSK_HIP(hipMemcpyAsync(d_hla, hsp_lo_a + h_lo, (size_t) (h_hi - h_lo) * 4, hipMemcpyHostToDevice, ctx->stream));
             RSK_HIP(hipMemcpyAsync(d_hlb, hsp_lo_b + h_lo, (size_t) (h_hi - h_lo) * 4, hipMemcpyHostToDevice, ctx->stream));
             RSK_HIP(hipMemcpyAsync(d_hlen, hsp_len + h_lo, (size_t) (h_hi - h_lo) * 4, hipMemcpyHostToDevice, ctx->stream));
+            if (hsp_score) RSK_HIP(hipMemcpyAsync(d_hsc, hsp_score + h_lo, (size_t) (h_hi - h_lo) * 4, hipMemcpyHostToDevice, ctx->stream));
         }
         RSK_HIP(hipMemcpyAsync(d_rowoff, row_off.data(), m * 8, hipMemcpyHostToDevice, ctx->stream));
         RSK_HIP(hipMemcpyAsync(d_tboff, tb_off.data(), m * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -996,6 +1092,11 @@ extern "C" int rsk_mkf_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db
         sa.a_ra = dba->d_prof_ra; sa.b_cb = dbb->d_prof_cb; sa.a_off = dba->d_off; sa.b_off = dbb->d_off; sa.a_len = dba->d_len; sa.b_len = dbb->d_len;
         sa.ia = d_ia; sa.ib = d_ib; sa.hsp_first = d_first; sa.hsp_lo_a = d_hla; sa.hsp_lo_b = d_hlb; sa.hsp_len = d_hlen;
         sa.npairs = (uint32_t) m; sa.min_mega = min_mega_score; sa.valid = d_valid; sa.lo_a = d_loa; sa.lo_b = d_lob;
+        if (hsp_score) {
+            hipLaunchKernelGGL(k_mkf_chain, dim3((unsigned) ((m + 63) / 64)), dim3(64), 0, ctx->stream, d_first, d_hla, d_hlb, d_hlen, d_hsc, (uint32_t) m,
+                               d_hcnt, d_valid);
+            sa.hsp_cnt = d_hcnt;
+        }
         hipLaunchKernelGGL(k_mkf_start, dim3((unsigned) ((m + 255) / 256)), dim3(256), 0, ctx->stream, sa);
         xd_args xa = {};
         xa.a_ra = dba->d_prof_ra; xa.b_cb = dbb->d_prof_cb; xa.a_off = dba->d_off; xa.b_off = dbb->d_off; xa.a_len = dba->d_len; xa.b_len = dbb->d_len;

@@ -74,3 +74,61 @@ def test_other_thresholds_and_short_chains_vs_oracle(ctx):
             if f:
                 assert recs[p][0] == nk and np.array_equal(recs[p][1], kept)
     db.close()
+
+
+def test_device_chaining_equals_the_reference_chains(ctx):
+    """rsk_mkf_chain_align_pairs (k_mkf_chain = Chainer::Chain on the device, then the long-chain batch) against the same batch
+    fed the chains the REFERENCE built from the same seed HSPs (mkfkat fixture: kept HSPs + chain of every palms pair,
+    MuKmerFilter::Align + ChainHSPs of the reference): every pair that is not flagged as qsort-dependent must come out
+    identical -- gates, score bits, path, E-value bits."""
+    import struct
+    import reseek_amd
+    chains = fx.read_rskdb("palms_sensitive.rskdb.gz")
+    n, kat = fx.read_mkfkat("mkfkat_palms_sensitive.bin.gz")
+    db = reseek_amd.Db.from_chains(ctx, chains)
+    pairs = [(i, j) for i in range(n) for j in range(n) if len(kat[(i, j)][0])]
+    assert len(pairs) > 100
+    ia, ib = [p[0] for p in pairs], [p[1] for p in pairs]
+    kept = [kat[p][0] for p in pairs]
+    first_u = np.concatenate([[0], np.cumsum([len(k) for k in kept])]).astype(np.uint32)
+    ku = np.concatenate(kept).astype(np.int32)
+    out_dev, st_dev = ctx.mkf_align_pairs(db, db, ia, ib, first_u, ku[:, 0], ku[:, 1], ku[:, 2], hsp_score=ku[:, 3])
+    # reference chains; a pair whose best chain score is <= 0 has no alignment (dssaligner.cpp:1397): empty list
+    ch = [kat[p][2] if kat[p][1] > 0 else kat[p][2][:0] for p in pairs]
+    first_c = np.concatenate([[0], np.cumsum([len(c) for c in ch])]).astype(np.uint32)
+    kc = np.concatenate([c for c in ch if len(c)] or [np.zeros((0, 3), np.int32)]).astype(np.int32)
+    out_ref, st_ref = ctx.mkf_align_pairs(db, db, ia, ib, first_c, kc[:, 0], kc[:, 1], kc[:, 2])
+    bits = lambda x: struct.unpack("<I", struct.pack("<f", x))[0]
+    ntie = naln = 0
+    for k, p in enumerate(pairs):
+        if st_dev[k] == 3:
+            ntie += 1
+            continue
+        (a, pa), (b, pb) = out_dev[k], out_ref[k]
+        assert st_dev[k] == st_ref[k], p
+        assert pa == pb and bits(a.score) == bits(b.score), p
+        if pa:
+            assert (a.lo_a, a.lo_b) == (b.lo_a, b.lo_b) and bits(a.evalue) == bits(b.evalue) and bits(a.lddt) == bits(b.lddt), p
+            naln += 1
+    assert naln > 100 and ntie < len(pairs) // 10
+    db.close()
+
+
+def test_chains_that_depend_on_qsort_order_are_flagged(ctx):
+    """Two seed HSPs ending at one query position with equal chain scores: the reference keeps whichever libc qsort leaves in
+    front (chainer.cpp:11-29, 121-124), so the device reports status 3 and aligns nothing for the pair; lists without such a
+    tie (also with equal scores at different ends, or equal ends with different scores) are chained."""
+    import reseek_amd
+    chains = fx.read_rskdb("palms_sensitive.rskdb.gz")[:2]
+    db = reseek_amd.Db.from_chains(ctx, chains)
+
+    def status(hsps):
+        h = np.array(hsps, np.int32)
+        _, st = ctx.mkf_align_pairs(db, db, [0], [1], np.array([0, len(h)], np.uint32), h[:, 0], h[:, 1], h[:, 2], hsp_score=h[:, 3])
+        return int(st[0])
+
+    assert status([(10, 10, 31, 60), (20, 25, 21, 60)]) == 3            # both end at query position 40, scores equal
+    assert status([(10, 10, 31, 60), (20, 25, 21, 61)]) != 3            # same end, different scores
+    assert status([(10, 10, 31, 60), (20, 25, 22, 60)]) != 3            # equal scores, different ends
+    assert status([(10, 10, 20, 50), (40, 42, 11, 30), (25, 30, 26, 80)]) == 3   # [10,29]+[40,50] = 50 + 30 ties with [25,50] = 80 (overlaps the first) at end 50
+    db.close()
