@@ -175,14 +175,14 @@ def live_kernels(ctx, seqs, db, reps=3):
       k_sw_qp     float SW + trace, 64 queries x all chains (query-profile kernel; the -db / -verysensitive regime)
     Bounds: VALU issue (one wave64 instruction per 4 cycles per SIMD for mixed VOP2/VOP3/DPP streams, profiles/r02_ubench_valu.txt)
     and, for k_sw_float, the LDS (8 random ds_read_b32 per cell).  `pmc` = issue / LDS-busy fractions from the rocprofv3
-    counter passes of `bench.py --live-only` committed as profiles/r02_live_pmc.json (tools/prof_live.sh)."""
+    counter passes of `bench.py --live-only` committed as profiles/r03_live_pmc.json (tools/prof_live.sh)."""
     import torch
     import reseek_amd
     n = len(seqs)
     lens = np.array([len(s) for s in seqs], np.float64)
     tri_cells = float((lens * np.cumsum(lens[::-1])[::-1]).sum())
     out8 = torch.zeros((n, n), dtype=torch.uint8, device="cuda")
-    pmc = _load_json("r02_live_pmc.json") or {}
+    pmc = _load_json("r03_live_pmc.json") or {}
     res = []
 
     def med(f):

@@ -18,8 +18,8 @@
 //     A wave works on floor(64/g) pairs at once.
 //   * S(i,j) is fused: the 8 weighted feature tables (8.8 KB) sit in LDS; each lane keeps the table
 //     row offsets of its 16 A-rows packed in registers, the B column contributes 8 byte offsets.
-//   * trace bytes of the 16 rows of a lane are one 16-byte store into a column-major TB[j][i] block
-//     in HBM (the only HBM-heavy stream of the path: 1 B per cell).
+//   * trace bytes of the 16 rows of a lane are one 16-byte store into the wave's step-major trace block
+//     [step][lane][16] in HBM: 1 KB of consecutive bytes per step (the only HBM-heavy stream of the path: 1 B per cell).
 //   * a second kernel walks the trace (one thread per pair), a third computes LDDT over the aligned
 //     columns (one wave per pair).
 #include <algorithm>
@@ -80,6 +80,12 @@ static int swf_upload_tables(rsk_ctx *ctx)
 
 struct swf_item {            // one wave's work: pairs [first, first+count), g lanes per pair, row groups of g strips
     uint32_t first, count, g, ngroups;
+    // trace block of the item: ngroups x ncol steps of 64 lanes x 16 B (one trace byte per register row), step-major --
+    // the 64 lanes of a step store 1 KB of consecutive bytes.  (Round 2 kept a [column][row] block per PAIR: the systolic
+    // skew puts neighbouring lanes on different columns, so every 16-byte store hit a line of its own and the writes
+    // reached HBM as partial lines, 22 GB for 11 GB of trace.)
+    uint32_t ncol, pad;
+    uint64_t tb_base;
 };
 
 struct swf_args {
@@ -203,7 +209,7 @@ __global__ __launch_bounds__(64 * SWF_WAVES) __attribute__((amdgpu_waves_per_eu(
     if (st == 0 && rg == 0) Md[0] = 0.0f;   // DPM[0][0] = 0 (sw.cpp:117)
     float hand_m = SWF_MINUS_INF, hand_d = SWF_MINUS_INF;   // bottom row of this strip at its previous column
     float carry_in = SWF_MINUS_INF;                         // DPM[i0][j] from the lane above (arrives one step early)
-    uint8_t *tbp = a.tb + a.tb_off[p] + i0;
+    uint8_t *tbp = a.tb + it.tb_base + ((size_t) rg * it.ncol * 64 + lane) * 16;      // + step * 1024
 
     uint32_t ncol = lane_has_rows ? (LB + st) : 0;
 #pragma unroll
@@ -281,9 +287,8 @@ __global__ __launch_bounds__(64 * SWF_WAVES) __attribute__((amdgpu_waves_per_eu(
             hand_m = carry;      // DPM[i0+16][j+1]
             hand_d = ch;         // DPD[i0+16][j] (normal) / DPI[i][j0+16] (transposed)
             {
-                uint32_t *tq = (uint32_t *) (tbp + (size_t) j * LApad);
-#pragma unroll
-                for (int k = 0; k < SWF_R / 4; ++k) tq[k] = tbw[k];
+                static_assert(SWF_R == 16, "one 16-byte trace record per lane and step");
+                *(uint4 *) (tbp + (size_t) col * 1024) = make_uint4(tbw[0], tbw[1], tbw[2], tbw[3]);
             }
             if (writes_bnd) {
                 __hip_atomic_store(bnd + 2 * j, __builtin_bit_cast(int, hand_m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -622,8 +627,13 @@ __device__ __forceinline__ uint32_t swf_trace_flags(const uint8_t *T, uint32_t c
 {
     uint32_t bits;
     if (cls >= 2) {
-        // k_sw_float: one byte per cell, the four rows of a dword in big-endian order
-        bits = (cls == 2 ? T[(size_t) j * ld + (i ^ 3u)] : T[(size_t) i * ld + (j ^ 3u)]) & 31u;
+        // k_sw_float: step-major block of the pair's wave item, T = its start + the pair's first lane; record (step, lane)
+        // holds the 16 rows of the lane's strip, one byte per cell, the four rows of a dword in big-endian order.
+        // ld = steps per row group of the item; gtot = strips of the strip chain
+        const uint32_t srow = cls == 2 ? i : j, step = cls == 2 ? j : i;
+        const uint32_t sa = srow / SWF_R, r = srow - sa * SWF_R;
+        const uint32_t g = min(gtot, 64u), rg = sa / g, st = sa - rg * g;
+        bits = T[(((size_t) rg * ld + step + st) * 64 + st) * 16 + (r ^ 3u)] & 31u;
     } else {
         // k_sw_qp: block (pass, wave batch) -> column -> row -> mask; this pair's cell is bit `lane` of the mask
         const uint32_t srow = cls == 0 ? i : j, step = cls == 0 ? j : i;
@@ -660,14 +670,16 @@ __global__ void k_traceback(const uint8_t *tb, const uint64_t *tb_off, const uin
     if (score[p] == 0.0f) return;                     // sw.cpp:200-201
     const uint32_t cls = (p >= cl.first[1]) + (p >= cl.first[2]) + (p >= cl.first[3]);
     const uint32_t LA = a_len[ia[p]], LB = b_len[ib[p]];
-    const uint32_t ld = cls == 0 ? LB : cls == 1 ? LA
-                      : cls == 2 ? SWF_PADR(LA) : SWF_PADR(LB);
+    uint32_t ld = 0;
     swq_item it = {};
     uint32_t pidx = 0, gtot = 1;
     if (cls < 2) {                                    // k_sw_qp pairs: the trace lives in the blocks of the pair's workgroup item
         it = (cls == 0 ? qitems0 : qitems1)[qp_item[p]];
         pidx = p - it.first;
         gtot = ((cls == 0 ? LA : LB) + SWQ_R - 1) / SWQ_R;
+    } else {                                          // k_sw_float pairs: steps per row group of the wave item, strips of the strip chain
+        ld = qp_item[p];
+        gtot = max(1u, ((cls == 2 ? LA : LB) + SWF_R - 1) / SWF_R);
     }
     const uint8_t *T = tb + (cls < 2 ? it.tb_base : tb_off[p]);
     uint32_t i = besti[p] + 1, j = bestj[p] + 1;      // 1-based
@@ -1223,7 +1235,12 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
             uint32_t ngroups = 1;
             if (g > 64) { ngroups = (g + 63) / 64; g = 64; }
             const uint32_t cnt = (uint32_t) std::min<size_t>(64 / g, cl.first[c + 1] - k);
-            items.push_back(swf_item{ (uint32_t) k, cnt, g, ngroups });
+            uint32_t lmax = 0;                                   // longest step chain of the item
+            for (uint32_t q = 0; q < cnt; ++q) {
+                const uint32_t pq = ord[k + q].idx;
+                lmax = std::max(lmax, tr ? dba->len[ia[pq]] : dbb->len[ib[pq]]);
+            }
+            items.push_back(swf_item{ (uint32_t) k, cnt, g, ngroups, lmax + g - 1, 0, 0 });
             if (!tr) ++nitems_normal;
             k += cnt;
         }
@@ -1269,7 +1286,17 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
             it.tb_base = tbo;
             tbo += nblocks * it.ncol * SWQ_COL_BYTES;
         }
-    for (size_t k = cl.first[2]; k < npairs; ++k) qp_item[k] = 0;
+    // trace blocks of the per-pair items (swf_item): ngroups x ncol steps of 1 KB; a pair's trace offset = its item's block
+    // + its first lane's record, its entry of qp_item = the item's steps per row group (k_traceback's decode)
+    for (swf_item &it : items) {
+        tbo = (tbo + 127) & ~(uint64_t) 127;
+        it.tb_base = tbo;
+        tbo += (uint64_t) it.ngroups * it.ncol * 1024;
+        for (uint32_t q = 0; q < it.count; ++q) {
+            tb_off[it.first + q] = it.tb_base + (uint64_t) q * it.g * 16;
+            qp_item[it.first + q] = it.ncol;
+        }
+    }
     for (size_t k = 0; k < npairs; ++k) {
         const uint32_t p = ord[k].idx;
         const uint32_t c = (uint32_t) (ord[k].key >> 62);
@@ -1277,7 +1304,7 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
         slot[p] = (uint32_t) k;
         const uint32_t LA = dba->len[ia[p]], LB = dbb->len[ib[p]];
         bnd_off[k] = bno;
-        tb_off[k] = tbo;
+        if (c < 2) tb_off[k] = 0;                                // the item's blocks (swq_item::tb_base)
         if (c == 0) {                                           // trace: the item's blocks (above)
             if ((LA + SWQ_R - 1) / SWQ_R > qitems[0][qp_item[k]].gs) bno += 4 * (uint64_t) LB;       // several passes: two rows of 2 words per step
         } else if (c == 1) {
@@ -1285,9 +1312,7 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
         }
         else if (c == 2) {
             if (LA > 64 * SWF_R) bno += 2 * (uint64_t) LB;      // multi-group pair: 2 words per step
-            tbo += (uint64_t) SWF_PADR(LA) * LB;
-        } else tbo += (uint64_t) SWF_PADR(LB) * LA;
-        tbo = (tbo + 15) & ~(uint64_t) 15;
+        }
         pe += (uint64_t) LA + LB + 1;
         path_end[k] = pe;
         sc_off[k] = so;

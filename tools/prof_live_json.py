@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""rocprofv3 PMC databases of tools/prof_live.sh -> per-kernel fractions for bench.py's roofline_live (profiles/r02_live_pmc.json).
+"""rocprofv3 PMC databases of tools/prof_live.sh -> per-kernel fractions for bench.py's roofline_live (profiles/r03_live_pmc.json).
 Per kernel, the LONGEST dispatch (the timed workload; warm-up dispatches of the same kernel are equal or shorter):
   valu_issue_frac = SQ_INSTS_VALU * 4 cycles / (1024 SIMDs * cycles),  cycles = GRBM_GUI_ACTIVE / 8 XCDs
   lds_busy_frac   = SQ_LDS_IDX_ACTIVE / (256 CUs * cycles), lds_conflict_frac = SQ_LDS_BANK_CONFLICT / (256 * cycles)
