@@ -13,7 +13,12 @@ full11211_<mode>[_<tag>].md5.txt.  `tests/test_gpu_full_golden.py` regenerates t
 the .bca is part of the golden, so a generator drift is told apart from a search difference) and requires rsk_search to
 reproduce the md5.
 
-usage: make_full_golden.py MODE [--perturb] [--chains N] [--workdir DIR]
+A run that was interrupted still pins a well-defined part of the table: with one thread the reference walks the pairs
+row-major (GetNextPairSelf runself.cpp:72-99: i, then j >= i) and writes both orientations of a hit at once, so the file is
+complete for every pair whose smaller chain index is below the row it was working on.  `--prefix-from FILE` stores the row
+count and md5 of exactly those rows (full11211_<mode>_prefix.md5.txt, "rows_with_min_index_below").
+
+usage: make_full_golden.py MODE [--perturb] [--chains N] [--workdir DIR] [--prefix-from PARTIAL.tsv]
   --perturb  run the reference under glibc's MALLOC_PERTURB_=255 (malloc'ed memory reads 0): what a trace cell the
              banded X-drop never wrote holds is then defined (xdpmem.h:96-108 allocates without clearing).
 """
@@ -63,6 +68,38 @@ def table_md5(path):
     return h.hexdigest(), len(lines)
 
 
+def chain_index(label):
+    return int(label[3:])                   # "syn01234"
+
+
+def prefix_md5(lines, cut):
+    """md5 over the sorted rows whose two chains' smaller index is < cut (bytes lines without newline)"""
+    keep = []
+    for ln in lines:
+        f = ln.split(b"\t")
+        if len(f) >= 2 and min(chain_index(f[0].decode()), chain_index(f[1].decode())) < cut:
+            keep.append(ln)
+    keep.sort()
+    h = hashlib.md5()
+    for ln in keep:
+        h.update(ln + b"\n")
+    return h.hexdigest(), len(keep)
+
+
+def prefix_golden(mode, partial, bca_md5):
+    data = open(partial, "rb").read()
+    lines = data.split(b"\n")[:-1]           # whatever follows the last newline is a torn line
+    last = lines[-1].split(b"\t")
+    cut = min(chain_index(last[0].decode()), chain_index(last[1].decode()))      # the row in progress: everything below it is complete
+    md5, rows = prefix_md5(lines, cut)
+    rec = {"chains": 11211, "mode": mode, "bca_md5": bca_md5, "rows_with_min_index_below": cut, "rows": rows, "sorted_rows_md5": md5,
+           "reference_threads": 1, "command": "reseek -search syn11211.bca -%s -output ref.tsv -threads 1 (interrupted; complete for the rows counted here)" % mode}
+    out = os.path.join(ROOT, "tests", "golden", "full11211_%s_prefix.md5.txt" % mode)
+    with open(out, "w") as f:
+        f.write(json.dumps(rec, indent=1) + "\n")
+    print(json.dumps(rec))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("mode")
@@ -70,8 +107,12 @@ def main():
     ap.add_argument("--chains", type=int, default=0)
     ap.add_argument("--workdir", default="/tmp/full_golden")
     ap.add_argument("--threads", type=int, default=1)
+    ap.add_argument("--prefix-from", default="")
     a = ap.parse_args()
     os.makedirs(a.workdir, exist_ok=True)
+    if a.prefix_from:
+        bca = os.path.join(a.workdir, "syn11211.bca")
+        return prefix_golden(a.mode, a.prefix_from, file_md5(bca))
     n = a.chains or 11211
     bca = os.path.join(a.workdir, "syn%d.bca" % n)
     if not os.path.exists(bca):
