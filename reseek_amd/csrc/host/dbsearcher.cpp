@@ -1369,6 +1369,7 @@ void DBSearcher::RunSelf()
     // a set whose dense pair matrix exceeds one filter pass (~65 k chains): target blocks, as the shards of a multi-GPU run
     PairCounters C;
     uint64_t Hits = 0, SW = 0;
+    if (m_Db) { rsk_db_destroy(m_Db); m_Db = nullptr; }      // as in RunSelfShard: the blocks upload their own views
     RunSelfRange(*this, 0, N, m_fTsv, C, Hits, SW);
     C.store(*this);
     m_HitCount += Hits;
@@ -1401,6 +1402,9 @@ void DBSearcher::RunSelfShard(uint Index, uint Count)
     // twice its share of the filter)
     PairCounters C;
     uint64_t Hits = 0, SW = 0;
+    // the blocks below upload their own views: the whole set's device copy (left by the self-rev pass of LoadDB) would only
+    // double the HBM the largest sets need; a later call re-uploads it on demand
+    if (m_Db) { rsk_db_destroy(m_Db); m_Db = nullptr; }
     if (Hi > Lo) RunSelfRange(*this, Lo, Hi, m_fTsv, C, Hits, SW);
     C.store(*this);
     m_HitCount = Hits;

@@ -122,9 +122,9 @@ def main_qdb():
     ctx = reseek_amd.Ctx(0, stream=torch.cuda.current_stream().cuda_stream)
     with tempfile.TemporaryDirectory() as td:
         q, db, out = os.path.join(td, "q.bca"), os.path.join(td, "db.bca"), os.path.join(td, "hits.tsv")
-        write_bca(q, lens[rng.choice(len(lens), nq)], rng)
+        write_bca_fast(q, lens[rng.choice(len(lens), nq)], rng, "q")      # the generator and seed of bench.py's configs legs
         t0 = time.perf_counter()
-        write_bca(db, lens[rng.choice(len(lens), nd)], rng)
+        write_bca_fast(db, lens[rng.choice(len(lens), nd)], rng, "d")
         tgen = time.perf_counter() - t0
         res = {}
         for rep in range(2):

@@ -29,6 +29,11 @@ run q100.bca -db q100.bca -sensitive -output $W/c.tsv
 run q100.bca -db palms.bca -sensitive -output $W/d.tsv
 run q100.bca -db q100.bca -fast -output $W/e.tsv
 run q100.bca -verysensitive -output $W/f.tsv
+# r03: one searcher driving several device contexts (host thread + context per list entry, concurrent writers of one hits file)
+run q100.bca -sensitive -devices 0,0,0 -output $W/g.tsv
+run palms.bca -sensitive -devices 0,0 -output $W/h.tsv
+run q100.bca -db palms.bca -sensitive -devices 0,0,0 -output $W/i.tsv
+run q100.bca -db q100.bca -fast -devices 0,0 -output $W/j.tsv
 wc -l $W/*.tsv >> $OUT/report.txt
 echo "ThreadSanitizer warnings: $(grep -c 'WARNING: ThreadSanitizer' $OUT/report.txt)" | tee -a $OUT/report.txt
 grep -A12 "WARNING: ThreadSanitizer" $OUT/report.txt | head -80
