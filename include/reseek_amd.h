@@ -72,6 +72,9 @@ void rsk_db_destroy(rsk_db *db);
 uint32_t rsk_db_nchains(const rsk_db *db);
 uint64_t rsk_db_nresidues(const rsk_db *db);
 uint64_t rsk_db_hbm_bytes(const rsk_db *db);
+/* Residue characters of the chains (PDBChain::m_Seq, concatenated in chain order, sum of the lengths bytes; host memory):
+ * optional, only the pctid column needs them (rsk_aln.nident). */
+int rsk_db_set_seq(rsk_db *db, const char *seq);
 
 /* ---- D1: gapless integer Mu score ------------------------------------------------------------
  * Batch form of SWFastGapless_Int (swgaplessint.cpp:7) == SWFastPinopGapless
@@ -143,6 +146,8 @@ typedef struct rsk_aln {
     uint64_t path_off;      /* offset of the NUL-terminated path (chars M/D/I) in `paths` */
     float lddt, ts;         /* GetLDDT(), m_NewTestStatisticA (-FLT_MAX if skipped) */
     float pvalue, evalue, qual; /* m_PvalueA, m_EvalueA, m_QualityA (FLT_MAX if skipped) */
+    uint32_t nident;        /* M columns with equal residue characters (numerator of GetPctId dssaligner.cpp:1325; the denominator is */
+                            /* ids); RSK_NO_POS when the statistics were skipped or a chain set has no sequence (rsk_db_set_seq) */
 } rsk_aln;
 /* Bytes the `paths` buffer of rsk_align_pairs must hold for this pair list. */
 size_t rsk_align_paths_bytes(const rsk_db *a, const rsk_db *b, const uint32_t *ia, const uint32_t *ib,

@@ -32,6 +32,7 @@ SIGNATURES = {
     "rsk_db_nchains": (C.c_uint32, [C.c_void_p]),
     "rsk_db_nresidues": (C.c_uint64, [C.c_void_p]),
     "rsk_db_hbm_bytes": (C.c_uint64, [C.c_void_p]),
+    "rsk_db_set_seq": (C.c_int, [C.c_void_p, C.c_char_p]),
     "rsk_mu_gapless_matrix_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
     "rsk_mu_gapless_hits_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
                                           C.c_void_p, C.c_uint32, C.c_void_p]),
@@ -50,7 +51,7 @@ class Aln(C.Structure):
     _fields_ = [("score", C.c_float), ("lo_a", C.c_uint32), ("lo_b", C.c_uint32), ("hi_a", C.c_uint32),
                 ("hi_b", C.c_uint32), ("ids", C.c_uint32), ("gaps", C.c_uint32), ("path_len", C.c_uint32),
                 ("path_off", C.c_uint64), ("lddt", C.c_float), ("ts", C.c_float), ("pvalue", C.c_float),
-                ("evalue", C.c_float), ("qual", C.c_float)]
+                ("evalue", C.c_float), ("qual", C.c_float), ("nident", C.c_uint32)]
 
 
 SIGNATURES["rsk_align_paths_bytes"] = (C.c_size_t, [C.c_void_p, C.c_void_p, u32p, u32p, C.c_size_t])

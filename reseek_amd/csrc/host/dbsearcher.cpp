@@ -482,6 +482,14 @@ void DBSearcher::UploadToGpu()
     });
     check(rsk_db_create(m_Ctx, n, len.data(), mu.get(), prof.get(), x.get(), y.get(), z.get(), m_DBSelfRevScores.data(), &m_Db),
           "rsk_db_create");
+    // residue characters: the statistics kernel counts the identical columns of an alignment (GetPctId) while it walks the path
+    {
+        std::unique_ptr<char[]> seq(new char[tot + 1]);
+        rsk_parallel_for(n, 512, [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; ++i) memcpy(&seq[start[i]], m_DBChains[i]->m_Seq.data(), len[i]);
+        });
+        check(rsk_db_set_seq(m_Db, seq.get()), "rsk_db_set_seq");
+    }
 }
 
 // Align a batch of (ia, ib) pairs of one chain set on the GPU and replay the hits.

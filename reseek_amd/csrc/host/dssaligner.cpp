@@ -183,7 +183,7 @@ void DSSAligner::ClearAlign()
 {
     m_Path.clear();
     m_LoA = m_LoB = m_HiA = m_HiB = UINT_MAX;
-    m_Ids = m_Gaps = UINT_MAX;
+    m_Ids = m_Gaps = m_IdentCount = UINT_MAX;
     m_PvalueA = m_PvalueB = m_EvalueA = m_EvalueB = FLT_MAX;
     m_TestStatisticA = m_TestStatisticB = -FLT_MAX;
     m_NewTestStatisticA = m_NewTestStatisticB = -FLT_MAX;
@@ -200,6 +200,7 @@ void DSSAligner::SetFromAln(const rsk_aln &a, const char *Path)
     if (a.hi_a != RSK_NO_POS) { m_HiA = a.hi_a; m_HiB = a.hi_b; }      // the long-chain batch sets Hi also below MinFwdScore (PostAlignMKF)
     if (a.evalue != FLT_MAX) {
         m_HiA = a.hi_a; m_HiB = a.hi_b; m_Ids = a.ids; m_Gaps = a.gaps;
+        m_IdentCount = a.nident == RSK_NO_POS ? UINT_MAX : a.nident;
         m_LDDT = a.lddt;
         m_NewTestStatisticA = m_NewTestStatisticB = a.ts;
         m_PvalueA = m_PvalueB = a.pvalue;
@@ -630,6 +631,8 @@ double DSSAligner::GetTCovPct(bool Top) const
 
 float DSSAligner::GetPctId() const                    // dssaligner.cpp:1325: identical residues / aligned columns
 {
+    // the batch kernels counted the identical columns while walking the path (rsk_aln.nident): same integers, same division
+    if (m_IdentCount != UINT_MAX && m_Ids != UINT_MAX) return m_Ids == 0 ? 0 : (m_IdentCount * 100.0f) / m_Ids;
     uint PosA = m_LoA, PosB = m_LoB, N = 0, n = 0;
     const char *SeqA = m_ChainA->m_Seq.data(), *SeqB = m_ChainB->m_Seq.data();
     const char *P = m_Path.data();

@@ -303,6 +303,7 @@ public:
     float m_TestStatisticA = -FLT_MAX, m_TestStatisticB = -FLT_MAX;
     float m_NewTestStatisticA = -FLT_MAX, m_NewTestStatisticB = -FLT_MAX;
     uint m_Ids = UINT_MAX, m_Gaps = UINT_MAX;
+    uint m_IdentCount = UINT_MAX;                       // M columns with equal residues, counted on the device (UINT_MAX: GetPctId walks the path)
     float m_SelfRevScoreA = FLT_MAX, m_SelfRevScoreB = FLT_MAX;
     float m_AlnFwdScore = 0;
     float m_LDDT = FLT_MAX;

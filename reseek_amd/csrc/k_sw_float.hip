@@ -734,7 +734,7 @@ __global__ __launch_bounds__(256) void k_lddt(const char *paths, const uint64_t 
                                               const float *bx, const float *by, const float *bz,
                                               uint32_t npairs, uint32_t *scratch_pos, const uint64_t *scratch_off,
                                               float *frac_scratch, float *lddt_out, uint32_t *counts_out,
-                                              const float *score, float min_fwd_score)
+                                              const float *score, float min_fwd_score, const uint8_t *a_seq, const uint8_t *b_seq)
 {
     // per wave: coordinates of A and B at the aligned columns ({ax, ay, az, bx} / {by, bz}) and per-column counters
     // (considered | preserved << 16; at most 4 * 255 each)
@@ -748,7 +748,7 @@ __global__ __launch_bounds__(256) void k_lddt(const char *paths, const uint64_t 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // CalcEvalue leaves everything unset below m_MinFwdScore (dssaligner.cpp:861): no LDDT needed for those pairs
     if (score[p] < min_fwd_score || score[p] == 0.0f) {
-        if (lane == 0) { lddt_out[p] = 0.0f; counts_out[3 * p] = 0; counts_out[3 * p + 1] = 0; counts_out[3 * p + 2] = 0; }
+        if (lane == 0) { lddt_out[p] = 0.0f; counts_out[4 * p] = 0; counts_out[4 * p + 1] = 0; counts_out[4 * p + 2] = 0; counts_out[4 * p + 3] = RSK_NO_POS; }
         return;
     }
     const uint32_t len = path_len[p];
@@ -758,21 +758,27 @@ __global__ __launch_bounds__(256) void k_lddt(const char *paths, const uint64_t 
     // expand the path with wave-wide prefix counts (GetPosABs dssaligner.cpp:1282): 64 path characters per step
     const char *P = paths + path_start[p];
     const uint32_t la0 = lo_a[p], lb0 = lo_b[p];
-    uint32_t nM = 0, nD = 0, nI = 0;
+    uint32_t nM = 0, nD = 0, nI = 0, nIdent = 0;
+    // GetPctId dssaligner.cpp:1325: M columns whose two residue characters are equal -- counted while the path is walked
+    // anyway (the host then needs neither chain's sequence for the pctid column)
+    const uint8_t *SA = a_seq ? a_seq + a_off[ia[p]] : nullptr, *SB = b_seq ? b_seq + b_off[ib[p]] : nullptr;
     const unsigned long long lt = (1ull << lane) - 1ull;
     for (uint32_t base = 0; base < len; base += 64) {
         const uint32_t c = base + lane;
         const char ch = c < len ? P[c] : 0;
         const unsigned long long mM = __ballot(ch == 'M'), mD = __ballot(ch == 'D'), mI = __ballot(ch == 'I');
+        bool same = false;
         if (ch == 'M') {
             const uint32_t kM = nM + (uint32_t) __popcll(mM & lt), kD = nD + (uint32_t) __popcll(mD & lt), kI = nI + (uint32_t) __popcll(mI & lt);
             posA[kM] = la0 + kM + kD;
             posB[kM] = lb0 + kM + kI;
+            if (SA && SB) same = SA[la0 + kM + kD] == SB[lb0 + kM + kI];
         }
+        nIdent += (uint32_t) __popcll(__ballot(same));
         nM += (uint32_t) __popcll(mM); nD += (uint32_t) __popcll(mD); nI += (uint32_t) __popcll(mI);
     }
     const uint32_t ncols = nM;
-    if (lane == 0) { counts_out[3 * p] = nM; counts_out[3 * p + 1] = nD; counts_out[3 * p + 2] = nI; }
+    if (lane == 0) { counts_out[4 * p] = nM; counts_out[4 * p + 1] = nD; counts_out[4 * p + 2] = nI; counts_out[4 * p + 3] = (SA && SB) ? nIdent : RSK_NO_POS; }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     if (ncols == 0) { if (lane == 0) lddt_out[p] = 0.0f; return; }
     const float *AX = ax + a_off[ia[p]], *AY = ay + a_off[ia[p]], *AZ = az + a_off[ia[p]];
@@ -942,7 +948,7 @@ __global__ __launch_bounds__(256) void k_lddt_long(const uint32_t *list, uint32_
     if (blockIdx.x >= nlist) return;
     const uint32_t p = list[blockIdx.x];                                // candidates: min(LA, LB) allows that many columns
     if (score[p] < min_fwd_score || score[p] == 0.0f) return;
-    const uint32_t C = counts_out[3 * p];
+    const uint32_t C = counts_out[4 * p];
     if (C <= LDDT_LDS_COLS || C > cap) return;                          // k_lddt did it / the other launch does it
     const int tid = threadIdx.x;
     const uint32_t *posA = scratch_pos + 2 * scratch_off[p];
@@ -1354,7 +1360,7 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
     // device results: one blob, copied back in one piece
     swf_blob rb;
     const size_t r_score = rb.add(npairs * 4), r_loa = rb.add(npairs * 4), r_lob = rb.add(npairs * 4), r_plen = rb.add(npairs * 4);
-    const size_t r_lddt = rb.add(npairs * 4), r_counts = rb.add(npairs * 12), r_outoff = rb.add((npairs + 1) * 8);
+    const size_t r_lddt = rb.add(npairs * 4), r_counts = rb.add(npairs * 16), r_outoff = rb.add((npairs + 1) * 8);
     char *RD = nullptr;
     if ((rc = dalloc((void **) &RD, rb.bytes)) != RSK_OK) return rc;
     float *d_score = (float *) (RD + r_score), *d_lddt = (float *) (RD + r_lddt);
@@ -1424,7 +1430,7 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
         if ((rc = dalloc((void **) &d_frac, so * 4)) != RSK_OK) return rc;
         hipLaunchKernelGGL(k_lddt, dim3((unsigned) ((npairs + 3) / 4)), dim3(256), 0, ctx->stream, d_paths, d_pstart, d_plen, d_loa, d_lob,
                            d_ia, d_ib, dba->d_off, dbb->d_off, dba->d_x, dba->d_y, dba->d_z, dbb->d_x, dbb->d_y, dbb->d_z,
-                           (uint32_t) npairs, d_pos, d_scoff, d_frac, d_lddt, d_counts, d_score, min_fwd_score);
+                           (uint32_t) npairs, d_pos, d_scoff, d_frac, d_lddt, d_counts, d_score, min_fwd_score, dba->d_seq, dbb->d_seq);
         for (int c = 0; c < 2; ++c) {
             const uint32_t nl = (uint32_t) lddt_list[c].size(), cap = c == 0 ? 1024u : (uint32_t) LDDT_LONG_COLS;
             if (nl == 0) continue;
@@ -1472,17 +1478,18 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
         o.score = h_score[k];
         o.lo_a = h_loa[k]; o.lo_b = h_lob[k];
         o.path_len = h_plen[k];
-        o.hi_a = o.hi_b = o.ids = o.gaps = RSK_NO_POS;
+        o.hi_a = o.hi_b = o.ids = o.gaps = o.nident = RSK_NO_POS;
         o.lddt = o.pvalue = o.evalue = o.qual = FLT_MAX;
         o.ts = -FLT_MAX;
         o.path_off = paths ? h_outoff[p] : 0;
         // CalcEvalue dssaligner.cpp:852-904 (the double-precision pow stays on the host: libm)
         if (want_stats && paths && !(o.score < min_fwd_score)) {
-            const uint32_t nM = h_counts[3 * k], nD = h_counts[3 * k + 1], nI = h_counts[3 * k + 2];
+            const uint32_t nM = h_counts[4 * k], nD = h_counts[4 * k + 1], nI = h_counts[4 * k + 2];
             o.hi_a = o.lo_a + nM + nD - 1;
             o.hi_b = o.lo_b + nM + nI - 1;
             o.ids = nM;
             o.gaps = nD + nI;
+            o.nident = h_counts[4 * k + 3];
             const float sra = dba->h_selfrev[ia[p]], srb = dbb->h_selfrev[ib[p]];
             float rev = 0;
             if (sra != FLT_MAX && srb != FLT_MAX) rev = (sra + srb) / 2;
@@ -1548,7 +1555,7 @@ int rsk_paths_stats_pack(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *dbb, siz
     char *d_packed;
     if ((rc = dalloc((void **) &d_scoff, (npairs + 1) * 8)) || (rc = dalloc((void **) &d_sizes, (npairs + 1) * 8)) ||
         (rc = dalloc((void **) &d_outoff, (npairs + 1) * 8)) || (rc = dalloc((void **) &d_pos, 2 * so * 4)) || (rc = dalloc((void **) &d_frac, so * 4)) ||
-        (rc = dalloc((void **) &d_counts, npairs * 12)) || (rc = dalloc((void **) &d_lddt, npairs * 4)) || (rc = dalloc((void **) &d_ident, npairs * 4)) ||
+        (rc = dalloc((void **) &d_counts, npairs * 16)) || (rc = dalloc((void **) &d_lddt, npairs * 4)) || (rc = dalloc((void **) &d_ident, npairs * 4)) ||
         (rc = dalloc((void **) &d_packed, need + 16)))
         return rc;
     RSK_HIP(hipMemcpyAsync(d_scoff, sc_off.data(), (npairs + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -1560,7 +1567,7 @@ int rsk_paths_stats_pack(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *dbb, siz
         }
     hipLaunchKernelGGL(k_lddt, dim3((unsigned) ((npairs + 3) / 4)), dim3(256), 0, ctx->stream, d_paths, d_pstart, d_plen, d_loa, d_lob, d_ia, d_ib,
                        dba->d_off, dbb->d_off, dba->d_x, dba->d_y, dba->d_z, dbb->d_x, dbb->d_y, dbb->d_z, (uint32_t) npairs, d_pos, d_scoff, d_frac,
-                       d_lddt, d_counts, d_score, min_fwd_score);
+                       d_lddt, d_counts, d_score, min_fwd_score, dba->d_seq, dbb->d_seq);
     for (int c = 0; c < 2; ++c) {
         const uint32_t nl = (uint32_t) lddt_list[c].size(), cap = c == 0 ? 1024u : (uint32_t) LDDT_LONG_COLS;
         if (nl == 0) continue;
@@ -1584,14 +1591,14 @@ int rsk_paths_stats_pack(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *dbb, siz
                        (uint32_t) npairs, d_packed);
     RSK_HIP(hipGetLastError());
     std::vector<float> h_score(npairs), h_lddt(npairs);
-    std::vector<uint32_t> h_loa(npairs), h_lob(npairs), h_plen(npairs), h_counts(3 * npairs);
+    std::vector<uint32_t> h_loa(npairs), h_lob(npairs), h_plen(npairs), h_counts(4 * npairs);
     std::vector<uint64_t> h_outoff(npairs + 1);
     RSK_HIP(hipMemcpyAsync(h_score.data(), d_score, npairs * 4, hipMemcpyDeviceToHost, ctx->stream));
     RSK_HIP(hipMemcpyAsync(h_lddt.data(), d_lddt, npairs * 4, hipMemcpyDeviceToHost, ctx->stream));
     RSK_HIP(hipMemcpyAsync(h_loa.data(), d_loa, npairs * 4, hipMemcpyDeviceToHost, ctx->stream));
     RSK_HIP(hipMemcpyAsync(h_lob.data(), d_lob, npairs * 4, hipMemcpyDeviceToHost, ctx->stream));
     RSK_HIP(hipMemcpyAsync(h_plen.data(), d_plen, npairs * 4, hipMemcpyDeviceToHost, ctx->stream));
-    RSK_HIP(hipMemcpyAsync(h_counts.data(), d_counts, npairs * 12, hipMemcpyDeviceToHost, ctx->stream));
+    RSK_HIP(hipMemcpyAsync(h_counts.data(), d_counts, npairs * 16, hipMemcpyDeviceToHost, ctx->stream));
     RSK_HIP(hipMemcpyAsync(h_outoff.data(), d_outoff, (npairs + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
     RSK_HIP(hipStreamSynchronize(ctx->stream));
     if (h_outoff[npairs]) {
@@ -1605,14 +1612,14 @@ int rsk_paths_stats_pack(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *dbb, siz
             o.score = h_score[p];
             o.lo_a = h_loa[p]; o.lo_b = h_lob[p];
             o.path_len = h_plen[p];
-            o.hi_a = o.hi_b = o.ids = o.gaps = RSK_NO_POS;
+            o.hi_a = o.hi_b = o.ids = o.gaps = o.nident = RSK_NO_POS;
             o.lddt = o.pvalue = o.evalue = o.qual = FLT_MAX;
             o.ts = -FLT_MAX;
             o.path_off = h_outoff[p];
             if (o.path_len == 0) continue;
             // PostAlignMKF sets Hi from the path counts before CalcEvalue (dssaligner.cpp:1425-1428): also below MinFwdScore
             uint32_t nM = 0, nD = 0, nI = 0;
-            if (!(o.score < min_fwd_score)) { nM = h_counts[3 * p]; nD = h_counts[3 * p + 1]; nI = h_counts[3 * p + 2]; }
+            if (!(o.score < min_fwd_score)) { nM = h_counts[4 * p]; nD = h_counts[4 * p + 1]; nI = h_counts[4 * p + 2]; }
             else
                 for (const char *c = paths + o.path_off; *c; ++c) { nM += *c == 'M'; nD += *c == 'D'; nI += *c == 'I'; }
             o.hi_a = o.lo_a + nM + nD - 1;
@@ -1620,6 +1627,7 @@ int rsk_paths_stats_pack(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *dbb, siz
             if (o.score < min_fwd_score) continue;                         // CalcEvalue dssaligner.cpp:861
             o.ids = nM;
             o.gaps = nD + nI;
+            o.nident = h_counts[4 * p + 3];
             const float sra = dba->h_selfrev[ia[p]], srb = dbb->h_selfrev[ib[p]];
             float rev = 0;
             if (sra != FLT_MAX && srb != FLT_MAX) rev = (sra + srb) / 2;

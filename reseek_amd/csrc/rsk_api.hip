@@ -365,10 +365,26 @@ int rsk_db_update_selfrev(rsk_db *db, const float *selfrev)
     return RSK_OK;
 }
 
+extern "C" int rsk_db_set_seq(rsk_db *db, const char *seq)
+{
+    if (!db || (db->nres && !seq)) { rsk_set_error("rsk_db_set_seq: NULL argument"); return RSK_E_INVALID; }
+    if (db->n == 0) return RSK_OK;
+    std::vector<uint8_t> h((size_t) db->npad + 64, 0);
+    uint64_t src = 0;
+    for (uint32_t i = 0; i < db->n; ++i) { memcpy(&h[db->off[i]], seq + src, db->len[i]); src += db->len[i]; }
+    if (!db->d_seq) {
+        const int rc = rsk_dev_malloc(nullptr, (void **) &db->d_seq, h.size());
+        if (rc != RSK_OK) return rc;
+        db->hbm_bytes += h.size();
+    }
+    RSK_HIP(hipMemcpy(db->d_seq, h.data(), h.size(), hipMemcpyHostToDevice));
+    return RSK_OK;
+}
+
 extern "C" void rsk_db_destroy(rsk_db *db)
 {
     if (!db) return;
-    void *ptrs[] = { db->d_len, db->d_off, db->d_mu, db->d_prof, db->d_x, db->d_y, db->d_z, db->d_selfrev,
+    void *ptrs[] = { db->d_seq, db->d_len, db->d_off, db->d_mu, db->d_prof, db->d_x, db->d_y, db->d_z, db->d_selfrev,
                      db->d_ring_tab, db->d_ring_letters, db->d_ring_laneq, db->d_ring_qid, db->d_ring_perm, db->d_tri_claim, db->d_nat_claim, db->d_work, db->d_prof_cb, db->d_prof_ra, db->d_pf_table, db->d_pf_postings, db->d_len_perm, db->d_len_rank, db->d_long_iq, db->d_long_it };
     for (void *p : ptrs)
         if (p) (void) hipFree(p);

@@ -119,6 +119,7 @@ struct rsk_db {
     std::vector<float> h_selfrev;
     float *d_x = nullptr, *d_y = nullptr, *d_z = nullptr;
     float *d_selfrev = nullptr;
+    uint8_t *d_seq = nullptr;  // npad bytes: residue characters (optional, rsk_db_set_seq), chains at off[] like d_mu
     uint64_t hbm_bytes = 0;
     // gapless ring cache (built lazily when the chain set is used as the query side)
     bool rings_built = false;
