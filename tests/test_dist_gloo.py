@@ -98,3 +98,37 @@ def test_gather_text_world3_gloo():
         assert p.exitcode == 0
     want = "".join("q0\tt%d\t%d\n" % (k, k * k) for k in range(5)) + "".join("q2\tt%d\t%d\n" % (k, k * k) for k in range(11))
     assert got == want
+
+
+def _records_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(7 + rank)
+    n = 0 if rank == 1 else 11 + 50 * rank                 # one rank without hits
+    rec = torch.from_numpy(rng.integers(0, 1 << 20, (n, 3)).astype(np.int32))
+    got = rdist.gather_records_device(rec)                 # tensors in, tensor out: the same call runs on GPU buffers over RCCL
+    dist.barrier()
+    q.put((rank, got.numpy().copy()))
+    dist.destroy_process_group()
+
+
+def test_gather_records_world3_gloo():
+    """the N > 1 leg of bench.py: per-rank hit-record buffers (tensors; on the GPU the buffers the kernel appended to) ->
+    every rank, rank order, no host round trip in the call itself"""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_records_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = np.concatenate([np.random.default_rng(7 + r).integers(0, 1 << 20, (0 if r == 1 else 11 + 50 * r, 3)).astype(np.int32) for r in range(world)])
+    for r in range(world):
+        assert np.array_equal(res[r], want)
