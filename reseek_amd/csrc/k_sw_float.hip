@@ -1203,7 +1203,7 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
             // decreasing step-chain length, so the first pair of a batch has the longest.
             const uint32_t gtot = (sdb->len[chain] + SWQ_R - 1) / SWQ_R;
             uint32_t gs = std::min<uint32_t>(gtot, SWQ_MAX_G);
-            static const double pass_step_cost = getenv("RSK_SWQ_PASS_COST") ? atof(getenv("RSK_SWQ_PASS_COST")) : 1.12;
+            const double pass_step_cost = getenv("RSK_SWQ_PASS_COST") ? atof(getenv("RSK_SWQ_PASS_COST")) : 1.12;
             if (!(getenv("RSK_SWQ_PASSES") && atoi(getenv("RSK_SWQ_PASSES")) == 0)) {
                 const uint32_t Pmin = (gtot + SWQ_MAX_G - 1) / SWQ_MAX_G;
                 double best_cost = 0;

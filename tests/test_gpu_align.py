@@ -26,15 +26,22 @@ def ctx():
     c.close()
 
 
-@pytest.fixture(autouse=True, params=["per-pair kernel for small groups (default)", "query-profile kernel for every group"])
+@pytest.fixture(autouse=True, params=["per-pair kernel for small groups (default)", "query-profile kernel for every group",
+                                      "query-profile kernel, strip chains split into as many passes as the model allows",
+                                      "query-profile kernel, one pass per segment"])
 def kernel_choice(request, monkeypatch):
     """rsk_align_pairs sends a group of pairs that share a chain to k_sw_qp only when the group fills ~10 waves
-    (RSK_SWQ_MIN_LANES, default 640); every test here runs under the default and with the threshold at 1, so both
-    float-SW kernels see all the cases."""
+    (RSK_SWQ_MIN_LANES); every test here runs under the default and with the threshold at 1, so both float-SW kernels see
+    all the cases -- and k_sw_qp with its pass choice pushed to both ends (RSK_SWQ_PASS_COST weights a multi-pass step:
+    0.01 = split whenever that saves steps, up to six passes; RSK_SWQ_PASSES=0 = never split below a segment)."""
+    for v in ("RSK_SWQ_MIN_LANES", "RSK_SWQ_PASS_COST", "RSK_SWQ_PASSES"):
+        monkeypatch.delenv(v, raising=False)
     if request.param.startswith("query-profile"):
         monkeypatch.setenv("RSK_SWQ_MIN_LANES", "1")
-    else:
-        monkeypatch.delenv("RSK_SWQ_MIN_LANES", raising=False)
+    if "as many passes" in request.param:
+        monkeypatch.setenv("RSK_SWQ_PASS_COST", "0.01")
+    if "one pass" in request.param:
+        monkeypatch.setenv("RSK_SWQ_PASSES", "0")
 
 
 def check_against_records(ctx, chains, recs, min_fwd):
