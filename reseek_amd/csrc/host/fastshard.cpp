@@ -79,6 +79,8 @@ struct rsk_fast_shard {
     std::string db_path;
     uint64_t Lo = 0, Hi = 0, NT = 0;                       // this rank's target range [Lo, Hi) of NT DB chains
     std::vector<uint32_t> cq, ct, cs;                      // local top-B triples (global target indexes)
+    bool keep_all = false;                                 // in-process form: keep every (query, global target, score) triple of the shard
+    std::vector<uint32_t> aq, at, as;
 };
 
 static bool parse_opts(const rsk_search_opts *opts, SearchOptions &o)
@@ -164,7 +166,8 @@ static void FastShardOpen(rsk_fast_shard *S, rsk_ctx *ctx, const char *query_pat
             std::vector<uint32_t> hq, ht, hs;
             MuPreFilterScan(ctx, qlen, qmu, tdb, NTl, S->o.idx_mode, hq, ht, hs);
             for (uint32_t &t : ht) t += (uint32_t) S->Lo;
-            TopB(hq.data(), ht.data(), hs.data(), hq.size(), NQ, S->o.rsb_size, S->cq, S->ct, S->cs);
+            if (S->keep_all) { S->aq.swap(hq); S->at.swap(ht); S->as.swap(hs); }
+            else TopB(hq.data(), ht.data(), hs.data(), hq.size(), NQ, S->o.rsb_size, S->cq, S->ct, S->cs);
         }
     }
 }
@@ -271,8 +274,11 @@ extern "C" int rsk_fast_shard_finish(rsk_fast_shard *S, const uint32_t *q, const
 }
 
 // `-search -fast -db` on several devices of ONE process: one target shard per context, each stage on a host thread per
-// shard; the exchange between the stages (all ranks' local top-B lists -> every rank) is a concatenation in host memory.
-// The shards' hit tables are appended to out_tsv in shard order; the hand-off file of the merged bags goes to tmp_tsv.
+// shard.  Within one process the exchange between the stages can be EXACT: every shard keeps all its (query, target, score)
+// triples, their concatenation goes through the same replay of RankedScoresBag as the single-device path (rsk_rsb_select:
+// truncation at 2B, the reference's quicksort tie order), so candidates, hit table and hand-off file are the reference's
+// whatever the shard count -- the one-process-per-GPU form (rsk_fast_shard_*) exchanges top-B lists and has to settle ties
+// at the cut by a rule of its own (above).  The shards' hit tables are appended to out_tsv in shard order.
 namespace reseek_amd {
 void FastDbOnContexts(const std::vector<rsk_ctx *> &Ctx, const char *query_path, const char *db_path, const SearchOptions &o, const char *out_tsv,
                       const char *tmp_tsv, uint64_t *nhits, uint64_t *stats8)
@@ -294,19 +300,30 @@ void FastDbOnContexts(const std::vector<rsk_ctx *> &Ctx, const char *query_path,
         Sh[k]->o.mode = AM_Fast;
         Sh[k]->o.shard_index = k;
         Sh[k]->o.shard_count = D;
+        Sh[k]->keep_all = true;
         FastShardOpen(Sh[k].get(), Ctx[k], query_path, db_path);
     });
     std::vector<uint32_t> aq, at, as;
-    for (uint k = 0; k < D; ++k) {
-        aq.insert(aq.end(), Sh[k]->cq.begin(), Sh[k]->cq.end());
-        at.insert(at.end(), Sh[k]->ct.begin(), Sh[k]->ct.end());
-        as.insert(as.end(), Sh[k]->cs.begin(), Sh[k]->cs.end());
+    {
+        std::vector<uint32_t> uq, ut, us;
+        for (uint k = 0; k < D; ++k) {
+            uq.insert(uq.end(), Sh[k]->aq.begin(), Sh[k]->aq.end());
+            ut.insert(ut.end(), Sh[k]->at.begin(), Sh[k]->at.end());
+            us.insert(us.end(), Sh[k]->as.begin(), Sh[k]->as.end());
+            std::vector<uint32_t>().swap(Sh[k]->aq); std::vector<uint32_t>().swap(Sh[k]->at); std::vector<uint32_t>().swap(Sh[k]->as);
+        }
+        aq.resize(uq.size()); at.resize(uq.size()); as.resize(uq.size());
+        size_t nout = 0;
+        if (rsk_rsb_select(uq.data(), ut.data(), us.data(), uq.size(), Sh[0]->Q.GetDBChainCount(), o.rsb_size, aq.data(), at.data(), as.data(), &nout,
+                           tmp_tsv && *tmp_tsv ? tmp_tsv : nullptr) != RSK_OK)
+            throw std::runtime_error(std::string("rsk_rsb_select: ") + rsk_last_error());
+        aq.resize(nout); at.resize(nout); as.resize(nout);
     }
     std::vector<uint64_t> Hits(D, 0);
     std::vector<std::vector<uint64_t> > Stats(D, std::vector<uint64_t>(8, 0));
     on_all([&](uint k) {
         const std::string part = std::string(out_tsv) + ".shard" + std::to_string(k);
-        FastShardFinish(Sh[k].get(), aq.data(), at.data(), as.data(), aq.size(), part.c_str(), k == 0 ? tmp_tsv : nullptr, &Hits[k], Stats[k].data());
+        FastShardFinish(Sh[k].get(), aq.data(), at.data(), as.data(), aq.size(), part.c_str(), nullptr, &Hits[k], Stats[k].data());
     });
     FILE *f = fopen(out_tsv, "w");
     if (!f) throw std::runtime_error(std::string("cannot create ") + out_tsv);

@@ -84,6 +84,20 @@ def test_fast_db_two_stage_on_several_contexts(ctx, work):
             assert open(out + ".prefilter.tmp").read() == f.read()
 
 
+def test_fast_db_top_b_cut_is_the_single_device_one(ctx, work):
+    """A bag of 5 (-rsb_size) makes every query overflow its bag, so the kept candidates depend on the reference's
+    truncation sequence and quicksort tie order (rankedscoresbag.cpp:34-51).  Within one process the shards' complete triple
+    lists go through the same replay as the single-device path: identical hit table and hand-off file for any device list."""
+    q = os.path.join(work, "q100.bca")
+    outs = []
+    for devices in (None, "0,0", "0,0,0"):
+        out = os.path.join(work, "rsb5_%s.tsv" % (devices or "one").replace(",", "_"))
+        kw = {"devices": devices} if devices else {}
+        n, st = ctx.search(q, out, "fast", db=q, columns=COLS, rsb_size=5, keeptmp=1, **kw)
+        outs.append((table(out), open(out + ".prefilter.tmp").read(), n))
+    assert outs[0][0] and outs[0] == outs[1] == outs[2]
+
+
 def test_environment_list_and_bad_lists(ctx, work, monkeypatch):
     out = os.path.join(work, "env.tsv")
     monkeypatch.setenv("RSK_DEVICES", "0, 0")
