@@ -365,19 +365,26 @@ int rsk_shard_range(int kind, const uint32_t *lengths, uint64_t n, uint32_t inde
 /* ---- `-search -fast -db` on several GPUs: the per-query top-B of the prefilter (RankedScoresBag,
  * rankedscoresbag.cpp:34-51) is a reduction over all targets, so the target-sharded form has one exchange between the
  * two stages of cmd_search (search.cpp:76-111).  One process per GPU:
- *   rsk_fast_shard_open        loads the queries (self-rev under the sensitive preset, postmufilter.cpp:79), runs MuPreFilter
+ *   rsk_fast_shard_open        loads the queries (self-rev under the sensitive preset, postmufilter.cpp:79) and runs MuPreFilter
  *                              (muprefilter.cpp:70) over target range shard_index of shard_count (contiguous, balanced by
- *                              residues) and keeps the local top rsb_size targets per query;
- *   rsk_fast_shard_candidates  -> that list as (query, GLOBAL target index, score) arrays owned by the handle;
- *                              the caller all-gathers the lists of all ranks (reseek_amd/dist.py: RCCL all_gather);
- *   rsk_fast_shard_finish      merges them (top rsb_size per query), runs PostMuFilter (postmufilter.cpp:190: AlignBags,
- *                              Accept, ToTsv) on the candidates whose target lies in this rank's range and writes this
- *                              rank's hit table; tmp_tsv (optional) receives the hand-off file of the MERGED bags.
- * Tie rule of both selections: higher score, then lower target index (rsk_rsb_merge).  The reference's own bag leaves
- * the choice among equal scores at the cut to its quicksort, i.e. to arrival order; the union of the ranks'
- * hit tables equals the single-GPU table whenever no query has more than rsb_size candidates or the cut is not tied. */
+ *                              residues);
+ *   rsk_fast_shard_triples     -> EVERY (query, GLOBAL target index, score) triple of the shard, arrays owned by the handle;
+ *                              the caller all-gathers them over the ranks (reseek_amd/dist.py: RCCL all_gather);
+ *   rsk_fast_shard_finish_exact  replays the reference's bags over the union (rsk_rsb_select: truncation at 2B, quicksort tie
+ *                              order of rankedscoresbag.cpp:34-51), runs PostMuFilter (postmufilter.cpp:190: AlignBags, Accept,
+ *                              ToTsv) on the selected candidates whose target lies in this rank's range and writes this rank's
+ *                              hit table; tmp_tsv (optional) receives the hand-off file.  Candidates, hand-off file and the
+ *                              union of the ranks' hit tables are the single-GPU ones -- the reference's -- for any shard count.
+ * A lighter exchange for very large candidate sets: rsk_fast_shard_candidates (the local top rsb_size per query) +
+ * rsk_fast_shard_finish (merge, top rsb_size per query).  Which equal-scoring candidates survive the reference's cut depends
+ * on every element its quicksort saw, so this form uses a tie rule of its own -- higher score, then lower target
+ * index (rsk_rsb_merge); the result equals the single-GPU table whenever no query has more than rsb_size candidates or the
+ * cut is not tied. */
 typedef struct rsk_fast_shard rsk_fast_shard;
 int rsk_fast_shard_open(rsk_ctx *ctx, const char *query_path, const char *db_path, const rsk_search_opts *opts, rsk_fast_shard **out);
+int rsk_fast_shard_triples(rsk_fast_shard *s, const uint32_t **q, const uint32_t **t, const uint32_t **score, size_t *n);
+int rsk_fast_shard_finish_exact(rsk_fast_shard *s, const uint32_t *q, const uint32_t *t, const uint32_t *score, size_t n, const char *out_tsv,
+                                const char *tmp_tsv, uint64_t *nhits, uint64_t *stats8);
 int rsk_fast_shard_candidates(rsk_fast_shard *s, const uint32_t **q, const uint32_t **t, const uint32_t **score, size_t *n);
 int rsk_fast_shard_finish(rsk_fast_shard *s, const uint32_t *q, const uint32_t *t, const uint32_t *score, size_t n, const char *out_tsv,
                           const char *tmp_tsv, uint64_t *nhits, uint64_t *stats8);

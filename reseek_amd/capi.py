@@ -115,6 +115,8 @@ SIGNATURES["rsk_fast_shard_open"] = (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_
 SIGNATURES["rsk_fast_shard_candidates"] = (C.c_int, [C.c_void_p, C.POINTER(u32p), C.POINTER(u32p), C.POINTER(u32p), C.POINTER(C.c_size_t)])
 SIGNATURES["rsk_fast_shard_finish"] = (C.c_int, [C.c_void_p, u32p, u32p, u32p, C.c_size_t, C.c_char_p, C.c_char_p, C.POINTER(C.c_uint64),
                                                  C.POINTER(C.c_uint64)])
+SIGNATURES["rsk_fast_shard_triples"] = SIGNATURES["rsk_fast_shard_candidates"]
+SIGNATURES["rsk_fast_shard_finish_exact"] = SIGNATURES["rsk_fast_shard_finish"]
 SIGNATURES["rsk_fast_shard_close"] = (None, [C.c_void_p])
 SIGNATURES["rsk_rsb_merge"] = (C.c_int, [u32p, u32p, u32p, C.c_size_t, C.c_uint32, C.c_uint32, u32p, u32p, u32p, C.POINTER(C.c_size_t)])
 SIGNATURES["rsk_dss_densities_host"] = (C.c_int, [f32p, f32p, f32p, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double)])
@@ -405,29 +407,36 @@ class Ctx:
 
 
 class FastShard:
-    """Handle of rsk_fast_shard_open: candidates() -> int32 [n, 3] (query, global target, score); finish(all ranks' rows)."""
+    """Handle of rsk_fast_shard_open.  Exact exchange: triples() -> int32 [n, 3] (query, global target, score) of the whole
+    shard, finish(all ranks' rows, exact=True).  Top-B exchange: candidates() / finish(rows) (own tie rule at the cut)."""
 
     def __init__(self, h):
         self.h = h
 
-    def candidates(self):
+    def _rows(self, fn):
         q, t, s = u32p(), u32p(), u32p()
         n = C.c_size_t()
-        _check(lib().rsk_fast_shard_candidates(self.h, C.byref(q), C.byref(t), C.byref(s), C.byref(n)))
+        _check(fn(self.h, C.byref(q), C.byref(t), C.byref(s), C.byref(n)))
         if n.value == 0:
             return np.zeros((0, 3), np.int32)
         f = lambda p: np.ctypeslib.as_array(p, shape=(n.value,)).astype(np.int32)      # noqa: E731
         return np.stack([f(q), f(t), f(s)], axis=1)
 
-    def finish(self, rows, out_tsv, tmp_tsv=None):
+    def candidates(self):
+        return self._rows(lib().rsk_fast_shard_candidates)
+
+    def triples(self):
+        return self._rows(lib().rsk_fast_shard_triples)
+
+    def finish(self, rows, out_tsv, tmp_tsv=None, exact=False):
         rows = np.ascontiguousarray(rows, np.int32).reshape(-1, 3)
         q = np.ascontiguousarray(rows[:, 0], np.uint32)
         t = np.ascontiguousarray(rows[:, 1], np.uint32)
         s = np.ascontiguousarray(rows[:, 2], np.uint32)
         nh = C.c_uint64()
         st = (C.c_uint64 * 8)()
-        _check(lib().rsk_fast_shard_finish(self.h, _p(q, u32p), _p(t, u32p), _p(s, u32p), len(q), out_tsv.encode(),
-                                           tmp_tsv.encode() if tmp_tsv else None, C.byref(nh), st))
+        fn = lib().rsk_fast_shard_finish_exact if exact else lib().rsk_fast_shard_finish
+        _check(fn(self.h, _p(q, u32p), _p(t, u32p), _p(s, u32p), len(q), out_tsv.encode(), tmp_tsv.encode() if tmp_tsv else None, C.byref(nh), st))
         return nh.value, list(st)
 
     def close(self):

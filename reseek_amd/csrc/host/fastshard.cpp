@@ -5,9 +5,15 @@
 //   rsk_fast_shard_candidates  -> the local (query, global target, score) triples            [caller: all_gather]
 //   rsk_fast_shard_finish      merge of every rank's triples, top-B per query, then PostMuFilter (AlignBags, Accept, ToTsv)
 //                              of the candidates whose target lies in this rank's range -> this rank's hit table
-// Tie rule of both selections: higher score first, then lower target index.  The reference's bag keeps whichever of the
-// equal-scoring candidates its quicksort leaves in front (arrival-order dependent); the two agree whenever no
-// query has more than B candidates or the B-th score is not tied, and in every case the kept set is a valid top-B.
+// Two forms of the exchange:
+//   exact  (rsk_fast_shard_triples / rsk_fast_shard_finish_exact, what reseek_amd/dist.py and the in-process device list
+//          use): every rank hands over ALL its (query, global target, score) triples; their union goes through the same
+//          replay of RankedScoresBag as the single-GPU path (rsk_rsb_select: truncation at 2B, the reference's quicksort
+//          tie order) -> candidates, hand-off file and hit table are the reference's for any shard count;
+//   top-B  (rsk_fast_shard_candidates / rsk_fast_shard_finish): B triples per query and rank.  Which equal-scoring
+//          candidates survive the reference's cut depends on every element its quicksort saw, so this form settles ties by a
+//          rule of its own -- higher score first, then lower target index; the two agree whenever no query has more than B
+//          candidates or the B-th score is not tied, and in every case the kept set is a valid top-B.
 #include <algorithm>
 #include <exception>
 #include <functional>
@@ -79,8 +85,7 @@ struct rsk_fast_shard {
     std::string db_path;
     uint64_t Lo = 0, Hi = 0, NT = 0;                       // this rank's target range [Lo, Hi) of NT DB chains
     std::vector<uint32_t> cq, ct, cs;                      // local top-B triples (global target indexes)
-    bool keep_all = false;                                 // in-process form: keep every (query, global target, score) triple of the shard
-    std::vector<uint32_t> aq, at, as;
+    std::vector<uint32_t> aq, at, as;                      // every triple of the shard (the exact exchange)
 };
 
 static bool parse_opts(const rsk_search_opts *opts, SearchOptions &o)
@@ -166,8 +171,7 @@ static void FastShardOpen(rsk_fast_shard *S, rsk_ctx *ctx, const char *query_pat
             std::vector<uint32_t> hq, ht, hs;
             MuPreFilterScan(ctx, qlen, qmu, tdb, NTl, S->o.idx_mode, hq, ht, hs);
             for (uint32_t &t : ht) t += (uint32_t) S->Lo;
-            if (S->keep_all) { S->aq.swap(hq); S->at.swap(ht); S->as.swap(hs); }
-            else TopB(hq.data(), ht.data(), hs.data(), hq.size(), NQ, S->o.rsb_size, S->cq, S->ct, S->cs);
+            S->aq.swap(hq); S->at.swap(ht); S->as.swap(hs);
         }
     }
 }
@@ -193,7 +197,21 @@ extern "C" int rsk_fast_shard_open(rsk_ctx *ctx, const char *query_path, const c
 extern "C" int rsk_fast_shard_candidates(rsk_fast_shard *S, const uint32_t **q, const uint32_t **t, const uint32_t **score, size_t *n)
 {
     if (!S || !q || !t || !score || !n) { rsk_set_error("rsk_fast_shard_candidates: NULL argument"); return RSK_E_INVALID; }
+    try {
+        if (S->cq.empty() && !S->aq.empty())
+            TopB(S->aq.data(), S->at.data(), S->as.data(), S->aq.size(), S->Q.GetDBChainCount(), S->o.rsb_size, S->cq, S->ct, S->cs);
+    } catch (const std::exception &e) {
+        rsk_set_error("rsk_fast_shard_candidates: %s", e.what());
+        return RSK_E_INVALID;
+    }
     *q = S->cq.data(); *t = S->ct.data(); *score = S->cs.data(); *n = S->cq.size();
+    return RSK_OK;
+}
+
+extern "C" int rsk_fast_shard_triples(rsk_fast_shard *S, const uint32_t **q, const uint32_t **t, const uint32_t **score, size_t *n)
+{
+    if (!S || !q || !t || !score || !n) { rsk_set_error("rsk_fast_shard_triples: NULL argument"); return RSK_E_INVALID; }
+    *q = S->aq.data(); *t = S->at.data(); *score = S->as.data(); *n = S->aq.size();
     return RSK_OK;
 }
 
@@ -273,12 +291,34 @@ extern "C" int rsk_fast_shard_finish(rsk_fast_shard *S, const uint32_t *q, const
     return RSK_OK;
 }
 
+// The exact exchange: the union of every rank's triples -> the reference's bags (rsk_rsb_select) -> stage 2 of this shard.
+static void FastShardFinishExact(rsk_fast_shard *S, const uint32_t *q, const uint32_t *t, const uint32_t *score, size_t n, const char *out_tsv,
+                                 const char *tmp_tsv, uint64_t *nhits, uint64_t *stats8)
+{
+    std::vector<uint32_t> sq(n), st(n), ss(n);
+    size_t nout = 0;
+    if (rsk_rsb_select(q, t, score, n, S->Q.GetDBChainCount(), S->o.rsb_size, sq.data(), st.data(), ss.data(), &nout, tmp_tsv && *tmp_tsv ? tmp_tsv : nullptr) !=
+        RSK_OK)
+        throw std::runtime_error(std::string("rsk_rsb_select: ") + rsk_last_error());
+    FastShardFinish(S, sq.data(), st.data(), ss.data(), nout, out_tsv, nullptr, nhits, stats8);
+}
+
+extern "C" int rsk_fast_shard_finish_exact(rsk_fast_shard *S, const uint32_t *q, const uint32_t *t, const uint32_t *score, size_t n,
+                                           const char *out_tsv, const char *tmp_tsv, uint64_t *nhits, uint64_t *stats8)
+{
+    if (!S || !out_tsv || (n && (!q || !t || !score))) { rsk_set_error("rsk_fast_shard_finish_exact: NULL argument"); return RSK_E_INVALID; }
+    try {
+        FastShardFinishExact(S, q, t, score, n, out_tsv, tmp_tsv, nhits, stats8);
+    } catch (const std::exception &e) {
+        rsk_set_error("rsk_fast_shard_finish_exact: %s", e.what());
+        return RSK_E_INVALID;
+    }
+    return RSK_OK;
+}
+
 // `-search -fast -db` on several devices of ONE process: one target shard per context, each stage on a host thread per
-// shard.  Within one process the exchange between the stages can be EXACT: every shard keeps all its (query, target, score)
-// triples, their concatenation goes through the same replay of RankedScoresBag as the single-device path (rsk_rsb_select:
-// truncation at 2B, the reference's quicksort tie order), so candidates, hit table and hand-off file are the reference's
-// whatever the shard count -- the one-process-per-GPU form (rsk_fast_shard_*) exchanges top-B lists and has to settle ties
-// at the cut by a rule of its own (above).  The shards' hit tables are appended to out_tsv in shard order.
+// shard, the exact exchange (top of the file) as a concatenation in host memory.  The shards' hit tables are appended to
+// out_tsv in shard order.
 namespace reseek_amd {
 void FastDbOnContexts(const std::vector<rsk_ctx *> &Ctx, const char *query_path, const char *db_path, const SearchOptions &o, const char *out_tsv,
                       const char *tmp_tsv, uint64_t *nhits, uint64_t *stats8)
@@ -300,7 +340,6 @@ void FastDbOnContexts(const std::vector<rsk_ctx *> &Ctx, const char *query_path,
         Sh[k]->o.mode = AM_Fast;
         Sh[k]->o.shard_index = k;
         Sh[k]->o.shard_count = D;
-        Sh[k]->keep_all = true;
         FastShardOpen(Sh[k].get(), Ctx[k], query_path, db_path);
     });
     std::vector<uint32_t> aq, at, as;

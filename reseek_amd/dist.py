@@ -92,8 +92,10 @@ def search_sharded(ctx, query, out_tsv, mode, db=None, group=None, device=None, 
     writes `out_tsv`.  -db mode: a contiguous target range balanced by residues with the queries replicated; self
     search: a target range of the triangle balanced by DP cells (rsk_search with shard_index = rank, shard_count = world
     size): no collective on the data path.  -fast -db: the prefilter's per-query top-B is a reduction over all targets,
-    so the ranks exchange their local top-B lists once (all_gather) between the prefilter and the alignment stage
-    (rsk_fast_shard_*).  Returns (hits of all ranks, stats) on rank 0, (local hits, stats) elsewhere."""
+    so the ranks exchange their prefilter triples once (all_gather) between the prefilter and the alignment stage
+    (rsk_fast_shard_*): all of them by default -- every rank then replays the reference's bags over the union and the
+    table is the single-GPU one --, or with exchange="topb" only the local top-B lists (own tie rule at the cut).
+    Returns (hits of all ranks, stats) on rank 0, (local hits, stats) elsewhere."""
     import os
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -101,10 +103,11 @@ def search_sharded(ctx, query, out_tsv, mode, db=None, group=None, device=None, 
     part = "%s.rank%d" % (out_tsv, rank)
     if mode == "fast" and db and world > 1:
         keeptmp = kw.pop("keeptmp", 0)
+        exact = kw.pop("exchange", "all") != "topb"
         sh = ctx.fast_shard_open(query, db, shard_index=rank, shard_count=world, **kw)
         try:
-            allrows = gather_rows(sh.candidates(), group=group, device=device, all_ranks=True)
-            nhits, stats = sh.finish(allrows, part, tmp_tsv=(out_tsv + ".prefilter.tmp") if keeptmp and rank == 0 else None)
+            allrows = gather_rows(sh.triples() if exact else sh.candidates(), group=group, device=device, all_ranks=True)
+            nhits, stats = sh.finish(allrows, part, tmp_tsv=(out_tsv + ".prefilter.tmp") if keeptmp and rank == 0 else None, exact=exact)
         finally:
             sh.close()
     else:

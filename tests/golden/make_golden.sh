@@ -92,6 +92,12 @@ sort $TMP/q100fast.tsv | gzip -9n > $G/hits_q100_db_q100_fast.tsv.gz
 gzip -9n < $TMP/kt/rce.*.tmp > $G/prefilter_q100_db_q100_fast_tmp.tsv.gz
 $R -search $T/q100.bca -db $T/q100.bca -fast -output $TMP/q100fast_std.tsv -threads 1 -quiet >/dev/null 2>&1
 sort $TMP/q100fast_std.tsv | gzip -9n > $G/hits_q100_db_q100_fast_std.tsv.gz
+#    a bag of 5 overflows for nearly every query: the kept candidates depend on RankedScoresBag's truncation sequence and
+#    quicksort tie order (rankedscoresbag.cpp:34-51) -- the fixture of the multi-GPU exchange tests
+mkdir -p $TMP/kt4
+TMPDIR=$TMP/kt4 $R -search $T/q100.bca -db $T/q100.bca -fast -rsb_size 5 -columns $COLS -output $TMP/q100fast_b5.tsv -threads 1 -keeptmp -quiet >/dev/null 2>&1
+sort $TMP/q100fast_b5.tsv | gzip -9n > $G/hits_q100_db_q100_fast_rsb5.tsv.gz
+gzip -9n < $TMP/kt4/rce.*.tmp > $G/prefilter_q100_db_q100_fast_rsb5_tmp.tsv.gz
 #    neighbourhood prefilter alone on Mu FASTA inputs (ref_harness prefhood = MuPreFilter + RankedScoresBag::ToScoreTsv)
 awk 'BEGIN{n=0} /^>/{n++} n<=80' $T/scop40.mu.fa > $TMP/sub80.mu.fa
 $H prefhood $TMP/sub80.mu.fa $TMP/sub1000.mu.fa $TMP/h80_scores.tsv $TMP/h80_tmp.tsv -- -fast -threads 1

@@ -36,16 +36,16 @@ def work():
     shutil.rmtree(d, ignore_errors=True)
 
 
-def run_shards(ctx, work, q, db, count, **kw):
+def run_shards(ctx, work, q, db, count, exact=False, **kw):
     shards = [ctx.fast_shard_open(q, db, shard_index=k, shard_count=count, columns=COLS, **kw) for k in range(count)]
     try:
-        local = [s.candidates() for s in shards]
+        local = [s.triples() if exact else s.candidates() for s in shards]
         allrows = np.concatenate(local[::-1])           # any rank order must do
         lines, hits = [], 0
         tmp = os.path.join(work, "merged.tmp")
         for k, s in enumerate(shards):
             out = os.path.join(work, "fs_%d_%d.tsv" % (count, k))
-            n, st = s.finish(allrows, out, tmp_tsv=tmp if k == 0 else None)
+            n, st = s.finish(allrows, out, tmp_tsv=tmp if k == 0 else None, exact=exact)
             got = open(out).read().splitlines()
             assert n == len(got)
             lines += got
@@ -85,6 +85,33 @@ def test_truncating_bags_are_shard_invariant(ctx, work):
     cand_ref = sum(int(ln.split("\t")[1]) for ln in open(out + ".prefilter.tmp").read().splitlines()[1:])
     cand_ours = sum(int(ln.split("\t")[1]) for ln in ref_tmp.splitlines()[1:])
     assert cand_ref == cand_ours
+
+
+def test_exact_exchange_reproduces_the_single_gpu_cut(ctx, work):
+    """The exchange of ALL triples (rsk_fast_shard_triples / _finish_exact): bags of 5 and 20 overflow for nearly every
+    query of q100 x q100, so the kept candidates depend on the reference's truncation sequence and quicksort tie order
+    (rankedscoresbag.cpp:34-51) -- hand-off file and hit table equal the unsharded rsk_search (the reference-exact path,
+    tests/test_prefilter_*.py goldens) for every shard count and any rank order."""
+    q = os.path.join(work, "q100.bca")
+    for B in (5, 20):
+        out = os.path.join(work, "unsharded_exact_b%d.tsv" % B)
+        n, st = ctx.search(q, out, "fast", db=q, columns=COLS, rsb_size=B, keeptmp=1)
+        want, want_tmp = sorted(open(out).read().splitlines()), open(out + ".prefilter.tmp").read()
+        assert n == len(want) and n > 0
+        for count in (1, 2, 3, 7):
+            lines, tmp, _ = run_shards(ctx, work, q, q, count, exact=True, rsb_size=B)
+            assert tmp == want_tmp, (B, count)
+            assert lines == want, (B, count)
+    # the reference binary itself on the bag of 5 (hit table + hand-off file), and the default bag, through the exact exchange
+    want = ["\t".join(r) for r in fx.read_tsv("hits_q100_db_q100_fast_rsb5.tsv.gz")]
+    with gzip.open(os.path.join(fx.GOLDEN, "prefilter_q100_db_q100_fast_rsb5_tmp.tsv.gz"), "rt") as f:
+        want_tmp = f.read()
+    for count in (1, 3):
+        lines, tmp, _ = run_shards(ctx, work, q, q, count, exact=True, rsb_size=5)
+        assert lines == want and tmp == want_tmp
+    want = ["\t".join(r) for r in fx.read_tsv("hits_q100_db_q100_fast.tsv.gz")]
+    lines, tmp, _ = run_shards(ctx, work, q, q, 3, exact=True)
+    assert lines == want
 
 
 def test_edge_chains_and_dbmu(ctx, work):

@@ -96,6 +96,10 @@ def test_fast_db_top_b_cut_is_the_single_device_one(ctx, work):
         n, st = ctx.search(q, out, "fast", db=q, columns=COLS, rsb_size=5, keeptmp=1, **kw)
         outs.append((table(out), open(out + ".prefilter.tmp").read(), n))
     assert outs[0][0] and outs[0] == outs[1] == outs[2]
+    want = sorted("\t".join(r) for r in fx.read_tsv("hits_q100_db_q100_fast_rsb5.tsv.gz"))     # the reference binary, -rsb_size 5
+    with gzip.open(os.path.join(fx.GOLDEN, "prefilter_q100_db_q100_fast_rsb5_tmp.tsv.gz"), "rt") as f:
+        assert outs[2][1] == f.read()
+    assert sorted(outs[2][0]) == want
 
 
 def test_environment_list_and_bad_lists(ctx, work, monkeypatch):

@@ -42,10 +42,11 @@ def main():
         with gzip.open(os.path.join(golden, "q100.bca.gz"), "rb") as f, open(bca, "wb") as g:
             g.write(f.read())
         ok = True
-        for mode, db, gold in (("sensitive", None, "hits_q100_sensitive.tsv.gz"), ("sensitive", bca, "hits_q100_db_q100_sensitive.tsv.gz"),
-                               ("fast", bca, "hits_q100_db_q100_fast.tsv.gz")):
+        # the last leg: bags of 5 overflow for nearly every query, the exchange has to reproduce the reference's cut
+        for mode, db, gold, kw in (("sensitive", None, "hits_q100_sensitive.tsv.gz", {}), ("sensitive", bca, "hits_q100_db_q100_sensitive.tsv.gz", {}),
+                                   ("fast", bca, "hits_q100_db_q100_fast.tsv.gz", {}), ("fast", bca, "hits_q100_db_q100_fast_rsb5.tsv.gz", {"rsb_size": 5})):
             out = os.path.join(td, "hits_rank%d.tsv" % rank)
-            n, st = rdist.search_sharded(ctx, bca, out, mode, db=db, columns=COLS, device=coll_dev)
+            n, st = rdist.search_sharded(ctx, bca, out, mode, db=db, columns=COLS, device=coll_dev, **kw)
             if rank == 0:
                 got = sorted(open(out).read().splitlines())
                 want = sorted(gzip.open(os.path.join(golden, gold)).read().decode().splitlines())
