@@ -131,6 +131,13 @@ __device__ __forceinline__ float swq_max(float x, float y)
     return r;
 }
 
+__device__ __forceinline__ float swq_max3_0(float x, float y)
+{
+    float r;
+    asm("v_max3_f32 %0, %1, %2, 0" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+
 // T = false: strips along A (rows), the wave steps over the columns of B; trace block TB[j][LApad].
 // T = true : strips along B (columns), the wave steps over the rows of A;  trace block TB[i][LBpad].
 // Built for 2 waves per SIMD (<= 256 VGPRs, no spills).  The kernel is bound by the LDS: 8 random ds_read_b32 per cell,
@@ -453,7 +460,9 @@ __global__ __launch_bounds__(64 * SWQ_NW) void k_sw_qp(swf_args a, const swq_ite
         const uint32_t sp = pass * gs + st;                              // this lane's strip within the segment
         const bool on = active && st < gl;
         const uint32_t i0 = (sbase + sp) * R;
-        const swq_ldsp qpl = (swq_ldsp) qp4 + sp;                        // this lane's float4 slot within a quad block
+        // this lane's float4 slot within a quad block, as an LDS byte address (and the same from feature 4's first row on)
+        const uint32_t qpl_lo = (uint32_t) (uintptr_t) ((swq_ldsp) qp4 + sp);
+        const uint32_t qpl_hi = qpl_lo + (20 + 3 * 16) * ((R / 4) * G * 16);
         const bool first = seg == 0 && pass == 0;                        // the pass that holds row 0
         const bool last = sbase + pass * gs + gl >= gtot;                // ... the last row
         const bool reads_bnd = !first && st == 0;
@@ -514,9 +523,15 @@ __global__ __launch_bounds__(64 * SWQ_NW) void k_sw_qp(swf_args a, const swq_ite
                 swq_ldsp rec[8];
 #pragma unroll
                 for (int f = 0; f < 8; ++f) {
-                    const uint32_t c4 = (f & 1) ? (cbw[f >> 1] >> 16) : (cbw[f >> 1] & 0xFFFFu);      // letter * 4
-                    const uint32_t fcb = f == 0 ? 0 : 20 + (f - 1) * 16;
-                    rec[f] = qpl + (fcb + (c4 >> 2)) * ((R / 4) * G);
+                    // byte address of the lane's record of row (f, letter): (letter * 4) * (row bytes / 4) + lane base, one
+                    // v_mad_u32_u16 that picks its half of the packed word itself; the feature's first row is a constant the
+                    // ds_read carries as its immediate (features 4..7 relative to a second base: 16-bit immediates)
+                    constexpr uint32_t ROWB = (R / 4) * G * 16;
+                    const uint32_t fcb = f == 0 ? 0 : 20 + (f - 1) * 16, fcb4 = 20 + 3 * 16;
+                    uint32_t ad;
+                    if (f & 1) asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(ad) : "v"(cbw[f >> 1]), "s"(ROWB / 4), "v"(f < 4 ? qpl_lo : qpl_hi));
+                    else asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(ad) : "v"(cbw[f >> 1]), "s"(ROWB / 4), "v"(f < 4 ? qpl_lo : qpl_hi));
+                    rec[f] = (swq_ldsp) (uintptr_t) (ad + (f < 4 ? fcb : fcb - fcb4) * ROWB);
                 }
                 float ch = (st == 0 && first) ? SWF_MINUS_INF : in_d;
                 if (st != 0 || !first) Md[0] = carry_in;
@@ -545,9 +560,10 @@ __global__ __launch_bounds__(64 * SWQ_NW) void k_sw_qp(swf_args a, const swq_ite
                         SWQ_MASK_GT(tc[0], d, m);            // TB_DM candidate (sw.cpp:127)
                         const float x1 = swq_max(m, d);
                         SWQ_MASK_GT(tc[1], n, x1);           // TB_IM (sw.cpp:135)
-                        const float x2 = swq_max(x1, n);
-                        SWQ_MASK_0GE(tc[2], x2);             // TB_SM (sw.cpp:143)
-                        const float xM = swq_max(x2, 0.0f) + S4[rr];
+                        // max(m, d, n, 0) in one v_max3: it is 0 exactly when max(m, d, n) <= 0, the TB_SM test (sw.cpp:143)
+                        const float xc = swq_max3_0(x1, n);
+                        SWQ_MASK_0GE(tc[2], xc);
+                        const float xM = xc + S4[rr];
                         if (xM > rb[r]) { rb[r] = xM; rj[r] = (uint32_t) j; }
                         carry = xM;
                         const float md = m + Open;
