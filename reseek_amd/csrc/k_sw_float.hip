@@ -637,40 +637,11 @@ __global__ __launch_bounds__(64 * SWQ_NW) void k_sw_qp(swf_args a, const swq_ite
 // 0 = k_sw_qp strips along A, 1 = k_sw_qp strips along B, 2 = k_sw_float<false>, 3 = k_sw_float<true>.
 struct swf_classes { uint32_t first[5]; };
 
-// which: 0 = the three "into M" bits (DM, IM, SM), 1 = MD, 2 = MI -- a traceback step needs only those of its state
-__device__ __forceinline__ uint32_t swf_trace_flags(const uint8_t *T, uint32_t cls, uint32_t ld, uint32_t i, uint32_t j, const swq_item &it,
-                                                    uint32_t pidx, uint32_t gtot, int which)
-{
-    uint32_t bits;
-    if (cls >= 2) {
-        // k_sw_float: step-major block of the pair's wave item, T = its start + the pair's first lane; record (step, lane)
-        // holds the 16 rows of the lane's strip, one byte per cell, the four rows of a dword in big-endian order.
-        // ld = steps per row group of the item; gtot = strips of the strip chain
-        const uint32_t srow = cls == 2 ? i : j, step = cls == 2 ? j : i;
-        const uint32_t sa = srow / SWF_R, r = srow - sa * SWF_R;
-        const uint32_t g = min(gtot, 64u), rg = sa / g, st = sa - rg * g;
-        bits = T[(((size_t) rg * ld + step + st) * 64 + st) * 16 + (r ^ 3u)] & 31u;
-    } else {
-        // k_sw_qp: block (pass, wave batch) -> column -> row -> mask; this pair's cell is bit `lane` of the mask
-        const uint32_t srow = cls == 0 ? i : j, step = cls == 0 ? j : i;
-        const uint32_t strip = srow / SWQ_R, r = srow - strip * SWQ_R;
-        const uint32_t pass = strip / it.gs, st = strip - pass * it.gs;      // pass index over the whole chain
-        const uint32_t npw = 64 / it.gs, nbatch = (it.count + npw - 1) / npw;
-        const uint32_t b = pidx / npw, lane = (pidx - b * npw) * it.gs + st;
-        const unsigned long long *M = (const unsigned long long *) (T + ((size_t) (pass * nbatch + b) * it.ncol + step + st) * SWQ_COL_BYTES) + r * 5;
-        if (which == 0) bits = ((uint32_t) (M[0] >> lane) & 1u) << 4 | ((uint32_t) (M[1] >> lane) & 1u) << 3 | ((uint32_t) (M[2] >> lane) & 1u) << 2;
-        else if (which == 1) bits = ((uint32_t) (M[3] >> lane) & 1u) << 1;
-        else bits = (uint32_t) (M[4] >> lane) & 1u;
-    }
-    uint32_t t = 0;
-    if (bits & 4) t = TB_SM;
-    else if (bits & 8) t = TB_IM;
-    else if (bits & 16) t = TB_DM;
-    if (bits & 2) t |= TB_MD;
-    if (bits & 1) t |= TB_MI;
-    return t;
-}
-
+// One step of the walk examines ONE cell whatever the state (M: the cell it stands on, D / I: the reference's TB[i-1][j] /
+// TB[i][j-1]) and needs the three "into M" bits (DM, IM, SM), the MD bit or the MI bit of it.  The body is branch-free over
+// the state -- the lanes of a wave are in different states, and a branch per state put three dependent memory waits and
+// three address computations into every iteration -- and the per-pair constants of the address (block, lane, strips per
+// pass) are computed once.
 __global__ void k_traceback(const uint8_t *tb, const uint64_t *tb_off, const uint32_t *ia, const uint32_t *a_len,
                             const uint32_t *ib, const uint32_t *b_len, swf_classes cl,
                             const float *score, const uint32_t *besti, const uint32_t *bestj, uint32_t npairs,
@@ -685,23 +656,35 @@ __global__ void k_traceback(const uint8_t *tb, const uint64_t *tb_off, const uin
     lo_b[p] = RSK_NO_POS;
     if (score[p] == 0.0f) return;                     // sw.cpp:200-201
     const uint32_t cls = (p >= cl.first[1]) + (p >= cl.first[2]) + (p >= cl.first[3]);
+    const bool rows_are_a = cls == 0 || cls == 2;     // strips along A: the strip row is i, the wave step is j
     const uint32_t LA = a_len[ia[p]], LB = b_len[ib[p]];
-    uint32_t ld = 0;
-    swq_item it = {};
-    uint32_t pidx = 0, gtot = 1;
-    if (cls < 2) {                                    // k_sw_qp pairs: the trace lives in the blocks of the pair's workgroup item
-        it = (cls == 0 ? qitems0 : qitems1)[qp_item[p]];
-        pidx = p - it.first;
-        gtot = ((cls == 0 ? LA : LB) + SWQ_R - 1) / SWQ_R;
-    } else {                                          // k_sw_float pairs: steps per row group of the wave item, strips of the strip chain
-        ld = qp_item[p];
-        gtot = max(1u, ((cls == 2 ? LA : LB) + SWF_R - 1) / SWF_R);
+    const uint8_t *T;
+    // k_sw_qp pairs (cls < 2): the trace lives in the blocks of the pair's workgroup item ([step][row][5 masks], SWQ_COL_BYTES per step)
+    uint32_t q_gs = 1, q_lane0 = 0;
+    size_t q_block = 0, q_pass_stride = 0;
+    // k_sw_float pairs: step-major block of the pair's wave item, T = its start + the pair's first lane; record (step, lane)
+    // holds the 16 rows of the lane's strip, one byte per cell, the four rows of a dword in big-endian order
+    uint32_t f_ld = 0, f_g = 1;
+    float inv = 1.0f;                                 // 1 / strips per pass (per row group): quotients of small integers, exact below
+    if (cls < 2) {
+        const swq_item it = (cls == 0 ? qitems0 : qitems1)[qp_item[p]];
+        const uint32_t pidx = p - it.first, npw = 64 / it.gs, nbatch = (it.count + npw - 1) / npw, b = pidx / npw;
+        q_gs = it.gs;
+        q_lane0 = (pidx - b * npw) * it.gs;
+        q_block = (size_t) it.ncol * SWQ_COL_BYTES;
+        q_pass_stride = (size_t) nbatch * q_block;
+        T = tb + it.tb_base + (size_t) b * q_block;
+        inv = 1.0f / (float) q_gs;
+    } else {
+        f_ld = qp_item[p];                            // steps per row group of the item
+        f_g = min(max(1u, ((rows_are_a ? LA : LB) + SWF_R - 1) / SWF_R), 64u);
+        T = tb + tb_off[p];
+        inv = 1.0f / (float) f_g;
     }
-    const uint8_t *T = tb + (cls < 2 ? it.tb_base : tb_off[p]);
     uint32_t i = besti[p] + 1, j = bestj[p] + 1;      // 1-based
     const uint32_t Besti = i, Bestj = j;
     uint64_t w = path_end[p];                          // the path is written backwards from here
-    int state = 0;                                    // 0 M, 1 D, 2 I
+    uint32_t state = 0;                               // 0 M, 1 D, 2 I
     uint32_t n = 0;
     // characters are collected four at a time and stored as one aligned dword (a byte store per step made
     // this kernel store-request bound); `acc` holds the `nacc` characters below address w - nacc
@@ -709,24 +692,51 @@ __global__ void k_traceback(const uint8_t *tb, const uint64_t *tb_off, const uin
     for (;;) {
         const uint32_t ch = state == 0 ? 'M' : (state == 1 ? 'D' : 'I');
         ++n;
-        if (nacc == 0 && (w & 3) != 0) paths[--w] = (char) ch;            // head: up to 3 bytes down to a dword boundary
-        else {
-            acc = (acc << 8) | ch;
-            if (++nacc == 4) { w -= 4; *(uint32_t *) (paths + w) = acc; nacc = 0; }
+#define PATH_STORE() do { \
+        if (nacc == 0 && (w & 3) != 0) paths[--w] = (char) ch;            /* head: up to 3 bytes down to a dword boundary */ \
+        else { \
+            acc = (acc << 8) | ch; \
+            if (++nacc == 4) { w -= 4; *(uint32_t *) (paths + w) = acc; nacc = 0; } \
+        } } while (0)
+        const uint32_t ci = state == 2 ? i : i - 1, cj = state == 1 ? j : j - 1;       // 0-based cell (sw.cpp:33-70)
+        const uint32_t srow = rows_are_a ? ci : cj, step = rows_are_a ? cj : ci;
+        uint32_t dm, im, sm, md, mi;                  // only the bits of the current state are meaningful
+        if (cls < 2) {
+            const uint32_t strip = srow / SWQ_R, r = srow - strip * SWQ_R;
+            const uint32_t pass = (uint32_t) (((float) strip + 0.5f) * inv), st = strip - pass * q_gs;      // pass over the whole chain
+            const uint32_t lane = q_lane0 + st, t = step + st;
+            const uint8_t *blk = T + (size_t) pass * q_pass_stride;
+            // the cell's masks {DM, IM, SM, MD, MI}: state M needs the first three, D the fourth, I the fifth.  Both loads are
+            // issued whatever the state (one wait per step), before this step's path store: the wait that follows must not
+            // cover a store
+            const uint8_t *rec = blk + (size_t) t * SWQ_COL_BYTES + r * 40;
+            typedef unsigned tb_v4u __attribute__((ext_vector_type(4)));
+            typedef unsigned tb_v2u __attribute__((ext_vector_type(2)));
+            tb_v4u q;
+            tb_v2u q2;
+            asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx2 %1, %3, off"
+                         : "=&v"(q), "=&v"(q2) : "v"(rec + (state == 0 ? 0 : 24)), "v"(rec + 16) : "memory");
+            PATH_STORE();
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(q), "+v"(q2) :: "memory");
+            const uint32_t b0 = (lane < 32 ? q.x >> lane : q.y >> (lane - 32)) & 1u, b1 = (lane < 32 ? q.z >> lane : q.w >> (lane - 32)) & 1u;
+            const uint32_t b2 = (lane < 32 ? q2.x >> lane : q2.y >> (lane - 32)) & 1u;
+            dm = md = b0; im = mi = b1; sm = b2;
+        } else {
+            const uint32_t sa = srow / SWF_R, r = srow - sa * SWF_R;
+            const uint32_t rg = (uint32_t) (((float) sa + 0.5f) * inv), st = sa - rg * f_g;
+            const uint32_t bits = T[(((size_t) rg * f_ld + step + st) * 64 + st) * 16 + (r ^ 3u)];
+            PATH_STORE();
+            dm = (bits >> 4) & 1u; im = (bits >> 3) & 1u; sm = (bits >> 2) & 1u; md = (bits >> 1) & 1u; mi = bits & 1u;
         }
         if (state == 0) {
-            const uint32_t t = swf_trace_flags(T, cls, ld, i - 1, j - 1, it, pidx, gtot, 0);
-            if (t & TB_DM) state = 1;
-            else if (t & TB_IM) state = 2;
-            else if (t & TB_SM) break;
+            if (sm) break;                            // precedence as TraceBackBitSW reads its flags: stop, then I, then D
+            state = im ? 2u : (dm ? 1u : 0u);
             --i; --j;
         } else if (state == 1) {
-            const uint32_t t = swf_trace_flags(T, cls, ld, i - 1, j, it, pidx, gtot, 1);
-            state = (t & TB_MD) ? 0 : 1;
+            state = md ? 0u : 1u;
             --i;
         } else {
-            const uint32_t t = swf_trace_flags(T, cls, ld, i, j - 1, it, pidx, gtot, 2);
-            state = (t & TB_MI) ? 0 : 2;
+            state = mi ? 0u : 2u;
             --j;
         }
     }
