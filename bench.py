@@ -254,7 +254,7 @@ def live_kernels(ctx, seqs, db, reps=3):
     order = np.random.default_rng(4).permutation(n)[:nq].astype(np.uint32)
     qa = np.repeat(order, n)
     qb = np.tile(np.arange(n, dtype=np.uint32), nq)
-    res.append(sw_entry("k_sw_qp", "float SW + trace, %d queries x %d chains (query-profile kernel)" % (nq, n), qa, qb, 0.0, 26.0, False))
+    res.append(sw_entry("k_sw_qp", "float SW + trace, %d queries x %d chains (query-profile kernel)" % (nq, n), qa, qb, 0.0, 23.0, False))      # 278 VALU instructions per 12-row column in the ISA of the hot loop
     return res
 
 
