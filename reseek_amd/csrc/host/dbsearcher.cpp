@@ -716,6 +716,7 @@ std::vector<std::pair<size_t, size_t> > AlignBatches(const SearchOptions &O, con
     std::vector<std::pair<size_t, size_t> > out;
     // RSK_BATCH_PAIRS lowers the batch size so that tests reach the multi-batch pipeline with small inputs
     const size_t maxp = std::max<size_t>(1, getenv("RSK_BATCH_PAIRS") ? (size_t) atoll(getenv("RSK_BATCH_PAIRS")) : O.batch_pairs);
+    const uint64_t maxc = getenv("RSK_BATCH_CELLS") ? std::max<uint64_t>(1, (uint64_t) atoll(getenv("RSK_BATCH_CELLS"))) : O.batch_cells;
     size_t b = 0;
     uint64_t cells = 0;
     // flat length tables: the loop below runs over tens of millions of pairs (two pointer chases per pair took 0.1 s)
@@ -724,7 +725,7 @@ std::vector<std::pair<size_t, size_t> > AlignBatches(const SearchOptions &O, con
     for (size_t j = 0; j < lb.size(); ++j) lb[j] = B.m_DBChains[j]->GetSeqLength();
     for (size_t k = 0; k < ia.size(); ++k) {
         const uint64_t c = (uint64_t) la[ia[k]] * lb[ib[k]];
-        if (k > b && (k - b >= maxp || cells + c > O.batch_cells)) { out.emplace_back(b, k); b = k; cells = 0; }
+        if (k > b && (k - b >= maxp || cells + c > maxc)) { out.emplace_back(b, k); b = k; cells = 0; }
         cells += c;
     }
     if (b < ia.size()) out.emplace_back(b, ia.size());

@@ -87,7 +87,10 @@ struct SearchOptions {
     uint shard_index = 0, shard_count = 0;             // multi-GPU: this rank's shard of the targets (0/0 or x/1 = everything)
     std::string devices;                               // one process, several devices: "0,1,2,3" (DBSearcher::m_Devices); "" = RSK_DEVICES
     size_t batch_pairs = 1u << 20;                     // upper bound of pairs per GPU alignment batch
-    uint64_t batch_cells = 24ull << 30;                // ... and of DP cells per batch (~1 trace byte per cell in HBM)
+    // ... and of DP cells per batch (~0.8 trace byte per cell in HBM).  10 G: the trace block stays below the size from which
+    // a fresh hipMalloc costs ~30 ms per GB (a 32 GB block: 1 s per context of a cold call), and two stages in flight overlap
+    // better than with 24 G batches (1000 x 30,000 -verysensitive: 2.45 s cold and warm against 4.4 / 2.7 s)
+    uint64_t batch_cells = 10ull << 30;
 };
 
 enum DECIDE_MODE {                                      // dssparams.h:16-25
