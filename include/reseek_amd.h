@@ -127,6 +127,10 @@ int rsk_mu_filter_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int self_t
                       int gap_ext, float omega, float omega_fwd, uint8_t *d_fwd, size_t ldo,
                       uint32_t *d_pairs_q, uint32_t *d_pairs_t, int32_t *d_pairs_fwd,
                       int32_t *d_pairs_rev, size_t capacity, uint32_t *d_npairs);
+/* The survivor list of rsk_mu_filter_dev in a deterministic order: both device columns sorted in place by (d_major[k],
+ * d_minor[k]) ascending -- the order the reference walks its pairs in (GetNextPairSelf runself.cpp:72-99,
+ * runquery.cpp:82).  major_bound = an exclusive upper bound of the major index (0 = unknown): only its bits are sorted. */
+int rsk_pairs_sort_dev(rsk_ctx *ctx, uint32_t *d_major, uint32_t *d_minor, size_t n, uint32_t major_bound);
 /* Counters of the last rsk_mu_filter_dev call (m_MuFilterInputCount and the number of pairs that
  * needed the reverse pass, cf. dssaligner.h:90-96). */
 int rsk_mu_filter_last_work(rsk_ctx *ctx, uint64_t *pairs, uint64_t *candidates);

@@ -44,6 +44,7 @@ SIGNATURES = {
                                     C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                     C.c_void_p]),
     "rsk_mu_filter_last_work": (C.c_int, [C.c_void_p, u64p, u64p]),
+    "rsk_pairs_sort_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32]),
 }
 
 
@@ -213,6 +214,10 @@ class Ctx:
         _check(lib().rsk_mu_filter_dev(self.h, q.h, t.h, int(self_triangle), gap_open, gap_ext, omega, omega_fwd,
                                        C.c_void_p(d_fwd), ldo, C.c_void_p(d_pq), C.c_void_p(d_pt), C.c_void_p(d_pf),
                                        C.c_void_p(d_pr), capacity, C.c_void_p(d_n)))
+
+    def pairs_sort_dev(self, d_major, d_minor, n, major_bound=0):
+        """sorts the device pair list (two uint32 columns, device pointers) by (major, minor) in place"""
+        _check(lib().rsk_pairs_sort_dev(self.h, C.c_void_p(d_major), C.c_void_p(d_minor), n, major_bound))
 
     def mu_filter_last_work(self):
         a, b = C.c_uint64(), C.c_uint64()

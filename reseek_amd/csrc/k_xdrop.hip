@@ -640,7 +640,7 @@ extern "C" int rsk_xdrop_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
         }
     };
     // sub-batches bounded by the trace scratch (the rest is small)
-    const uint64_t TB_BUDGET = 24ull << 30;
+    const uint64_t TB_BUDGET = 12ull << 30;            // below the block size from which a fresh hipMalloc costs ~30 ms per GB (cold calls)
     const bool trace = getenv("RSK_TRACE") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
@@ -1034,7 +1034,7 @@ static int mkf_batch(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *dbb, const u
         return RSK_OK;
     };
     // sub-batches bounded by the trace scratch: per pair (LA + 18)(LB + 18) bytes cover any split into the two extensions
-    const uint64_t TB_BUDGET = 24ull << 30;
+    const uint64_t TB_BUDGET = 12ull << 30;            // below the block size from which a fresh hipMalloc costs ~30 ms per GB (cold calls)
     size_t done = 0, poff = 0;
     while (done < npairs) {
         const auto t0 = now();

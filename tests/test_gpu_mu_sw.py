@@ -173,3 +173,25 @@ def test_pair_list_filter_matches_oracle(ctx):
     ok, fwd, rev = ctx.mu_filter_pairs(q, q, np.zeros(0, np.uint32), np.zeros(0, np.uint32), 12.0, 20.0)
     assert len(ok) == 0
     q.close()
+
+
+def test_pairs_sort_dev_orders_the_survivor_list(ctx):
+    """rsk_pairs_sort_dev: the filter appends survivors in no particular order; the host layer wants them by (A-side chain,
+    B-side chain), the order the reference walks its pairs in (runself.cpp:72-99).  Duplicates, a single pair, an empty
+    list, indices that need 17 and 32 bits."""
+    import torch
+    rng = np.random.default_rng(17)
+    for n, bound in ((0, 0), (1, 5), (1000, 7), (300_000, 70_000), (1_500_000, 0)):
+        hi = bound if bound else 2 ** 32 - 1
+        a = rng.integers(0, hi, n, dtype=np.uint64).astype(np.uint32)
+        b = rng.integers(0, 2 ** 32 - 1, n, dtype=np.uint64).astype(np.uint32)
+        if n > 10:
+            a[5:10] = a[4]                     # runs of one major index
+            b[7] = b[6]                        # a duplicate pair
+        da = torch.from_numpy(a.view(np.int32)).cuda()
+        db = torch.from_numpy(b.view(np.int32)).cuda()
+        ctx.pairs_sort_dev(da.data_ptr(), db.data_ptr(), n, bound)
+        torch.cuda.synchronize()
+        ga, gb = da.cpu().numpy().view(np.uint32), db.cpu().numpy().view(np.uint32)
+        order = np.lexsort((b, a))
+        assert np.array_equal(ga, a[order]) and np.array_equal(gb, b[order]), (n, bound)
