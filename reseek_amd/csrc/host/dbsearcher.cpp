@@ -741,17 +741,20 @@ void ForEachAlignedBatch(const DSSParams &P, rsk_ctx *ctx, const SearchOptions &
 {
     const auto batches = AlignBatches(O, SrcA, SrcB, ia, ib);
     PinnedPool Pool;                                                     // outlives every batch of the loop below
-    // Two GPU stages in flight (batches k + 1 and k + 2 while k is replayed), each on a context of its own (device
-    // pool, staging buffers): the host part of rsk_align_pairs (grouping the pairs, work items, statistics) is a
-    // quarter of a stage, with a single stage in flight the GPU idles through it.  The chain sets are read-only here.
-    // The second context launches on the default stream, like the caller's unless rsk_ctx_set_stream gave it another
-    // one: kernels of the two stages run one after the other, what overlaps is host work with kernels.
-    SecondaryCtx second;
-    const int inflight = getenv("RSK_ALIGN_INFLIGHT") ? std::max(1, std::min(2, atoi(getenv("RSK_ALIGN_INFLIGHT")))) : 2;
+    // Several GPU stages in flight while batch k is replayed, each on a context of its own (device pool, staging buffers,
+    // stream): the host part of rsk_align_pairs (grouping the pairs, work items, statistics) is a quarter of a stage, with a
+    // single stage in flight the GPU idles through it.  The chain sets are read-only here.
+    // Up to three stages in flight: with two, both were launched at the same moment and stayed in phase (host part, then
+    // kernels, on both contexts at once), so the GPU idled through every host part.
+    SecondaryCtx second, third;
+    const int inflight = getenv("RSK_ALIGN_INFLIGHT") ? std::max(1, std::min(3, atoi(getenv("RSK_ALIGN_INFLIGHT")))) : 3;
     if (inflight > 1 && batches.size() >= 3) second.Create(ctx->device, "align");
+    if (inflight > 2 && batches.size() >= 4) third.Create(ctx->device, "align");
+    const size_t nctx = 1 + (second.c ? 1 : 0) + (third.c ? 1 : 0);
+    rsk_ctx *const ring[3] = { ctx, second.c ? second.c : ctx, third.c ? third.c : (second.c ? second.c : ctx) };
     auto launch = [&](size_t k) {
         const auto be = batches[k];
-        rsk_ctx *c = (second.c && (k & 1)) ? second.c : ctx;
+        rsk_ctx *c = ring[k % nctx];
         return std::async(std::launch::async, [&, be, c]() {
             return AlignBatch(P, c, Pool, SrcA, SrcB, std::vector<uint32_t>(ia.begin() + be.first, ia.begin() + be.second),
                               std::vector<uint32_t>(ib.begin() + be.first, ib.begin() + be.second));
@@ -764,7 +767,7 @@ void ForEachAlignedBatch(const DSSParams &P, rsk_ctx *ctx, const SearchOptions &
     // database) start with both stages
     static std::atomic<bool> tables_up{false};
     if (!batches.empty()) q.push_back(launch(launched++));
-    if (tables_up.load() && second.c && launched < batches.size()) q.push_back(launch(launched++));
+    while (tables_up.load() && q.size() < nctx && launched < batches.size()) q.push_back(launch(launched++));
     for (size_t k = 0; k < batches.size(); ++k) {
         std::unique_ptr<AlignedBatch> cur;
         try {
@@ -776,7 +779,7 @@ void ForEachAlignedBatch(const DSSParams &P, rsk_ctx *ctx, const SearchOptions &
         }
         tables_up.store(true);
         q.pop_front();
-        while (launched < batches.size() && q.size() < (second.c ? 2u : 1u)) q.push_back(launch(launched++));
+        while (launched < batches.size() && q.size() < nctx) q.push_back(launch(launched++));
         try {
             OnBatch(cur->ia, cur->ib, cur->out, cur->paths);
         } catch (...) {
