@@ -35,9 +35,12 @@ MU_FREQ = np.array([
     0.0385, 0.0368, 0.0039, 0.0297, 0.0100, 0.0120, 0.0206, 0.0263, 0.0104, 0.0530])
 MU_CHARS = "ABCDEFGHIJLKMNOPQRSTUVWXYZabcdefghij"   # sic: letter 10 = L, 11 = K (alpha.cpp g_LetterToCharMu)
 
-# Packed-int16 VALU peak: 256 CUs x 4 SIMDs x 64 lanes / 4 cycles x 2.4 GHz.  VOP3P (v_pk_*) issues at one
-# wave64 instruction per 4 cycles per SIMD on gfx950 (tools/ubench_valu.hip measures 36-37 T lane-ops/s;
-# 32-bit VOP2 ops run at twice that).  One lane-op (add or max of a packed pair) per DP cell.
+# Packed VALU peak: 256 CUs x 4 SIMDs x 64 lanes / 4 cycles x 2.4 GHz.  VOP3P (v_pk_*: packed int16 and packed f16 alike)
+# issues at one wave64 instruction per 4 cycles per SIMD on gfx950 (tools/ubench_valu.hip measures 35-37 T lane-ops/s for
+# v_pk_add_i16, v_pk_max_i16, v_pk_add_f16, v_pk_maximum3_f16; 32-bit VOP2 ops run at twice that).  A lane-op = one lane of
+# one packed instruction = two DP cells' worth of one operation.
+# Gapless kernel: per 4 cells (a ring dword, two target letters) two clamped adds and one three-operand maximum.
+GAPLESS_LANEOPS_PER_CELL = 0.75
 PEAK_VALU_LANEOPS = 256 * 4 * 16 * 2.4e9
 PEAK_HBM_GBS = 8000.0
 
@@ -623,7 +626,7 @@ def main():
             "metric": "aligned cells/sec (SCOP40-shaped all-vs-all, gapless int Mu kernel)",
             "value": cells_per_s, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None,
-            "dtype": "int16", "data": "synthetic",
+            "dtype": "f16", "data": "synthetic",
             "chain_pairs_per_sec": total_pairs * args.steps / dt,
             "config": {"workload": "BASELINE configs[1]: SCOP40-shaped (%d chains, %d residues%s) all-vs-all "
                                    "i<=j, swgaplessint kernel only" % (n, int(nres), " per GPU" if args.weak else ""),
@@ -637,11 +640,15 @@ def main():
                                    "hit buffers gathered over RCCL"},
             "roofline": {
                 "bound": "valu", "kernel": "k_gapless_ring<8,16> (+<4,8>)",
-                "achieved": k_cells_per_s / 1e12, "peak": PEAK_VALU_LANEOPS / 1e12, "unit": "T lane-ops/s",
-                "frac": k_cells_per_s / PEAK_VALU_LANEOPS,
-                "note": "algorithmic work = 1 packed-int16 VALU lane-op per DP cell (v_pk_add_i16 clamp + v_pk_max_i16 "
-                        "per 2 cells); peak = VOP3P issue rate 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz (ubench: 36-37); "
-                        "LDS 2 B/cell; kernel time from HIP events on the launch stream",
+                "achieved": k_cells_per_s * GAPLESS_LANEOPS_PER_CELL / 1e12, "peak": PEAK_VALU_LANEOPS / 1e12, "unit": "T lane-ops/s",
+                "frac": k_cells_per_s * GAPLESS_LANEOPS_PER_CELL / PEAK_VALU_LANEOPS,
+                "lane_ops_per_cell": GAPLESS_LANEOPS_PER_CELL,
+                "note": "work = 0.75 packed VALU lane-op per DP cell: scores as n/2048 in packed half floats (exact), per ring "
+                        "dword and pair of target letters two v_pk_add_f16 clamp (add + floor at 0) and one v_pk_maximum3_f16 "
+                        "(r02: packed int16, add-saturate + max per letter = 1 lane-op per cell, 31 T cells/s); pairs that reach "
+                        "the clamp's ceiling (2048) are rescored in integers by the wave that found them; peak = VOP3P issue "
+                        "rate 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz (ubench: 35-37); LDS 2 B/cell; kernel time from HIP "
+                        "events on the launch stream",
                 "kernel_ms": kernel_ms, "cell_slots_issued": slots, "slot_efficiency": cells / max(1, slots),
                 "kernel_ms_hit_records_only": kernel_ms_hits_only,
                 "hbm": {"bound": "hbm", "achieved": alg_bytes / (kernel_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,

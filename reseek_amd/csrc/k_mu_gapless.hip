@@ -12,9 +12,14 @@
 //   * One wave walks ONE target chain; the target letter is wave-uniform (scalar loads), so the
 //     score row for that letter is read from an LDS-resident query profile with perfectly
 //     contiguous ds_read_b128 (no bank conflicts): prof[c][slot] = IntScoreMx_Mu[c][ring row].
-//   * Values live in a biased domain G = H - 32768: v_pk_add_i16 ... clamp is then both the add
-//     and the max(0, .) floor; separator rows / pad letters hold -32768 and reset a diagonal.
-//     v_pk_max_i16 tracks the best per ring slot.  => 2 packed VALU ops per 2 cells.
+//   * Values are packed HALF floats scaled by 2^-11 (score n = n / 2048: every integer 0..2048 is exact, and so is every
+//     sum the recurrence forms).  v_pk_add_f16 ... clamp is then both the add and the max(0, .) floor (the clamp of a float
+//     op is [0, 1]); separator rows / pad letters hold -1.0 and reset a diagonal.  The best per ring slot over the two letters
+//     of a pair-step is ONE v_pk_maximum3_f16 (gfx950) => 3 packed VALU ops per 4 cells (r01-r02: packed int16 in a biased
+//     domain, add-saturate + max per letter = 4 ops per 4 cells; the packed int16 unit has no three-operand maximum).
+//     The clamp is also a CEILING at 2048: a pair whose best reads 2048 (possible from two chains of >= 512 residues on,
+//     the matrix maximum is 4: in practice self pairs of long chains) is scored again, exactly, by the wave that found it
+//     (one diagonal per lane, integers) before anything is reported.
 //   * A diagonal moves one row per target letter.  Letters are processed in pairs: the second
 //     letter of a pair reads a copy of the profile shifted by one row (no data movement); after
 //     the pair every value moves up one dword = a register rename plus ONE v_mov_b32_dpp
@@ -33,8 +38,9 @@
 typedef short v2s __attribute__((ext_vector_type(2)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 
-#define FLOOR2 ((int) 0x80008000)
-#define FLOOR32 (-32768)
+#define GL_SCALE 2048               // scores are stored as n / GL_SCALE in half floats
+#define GL_CAP_BITS 0x3C00          // 1.0 = the clamp's ceiling = score 2048
+#define GL_RESET_BITS 0xBC00        // -1.0: pad letters and separator rows
 #define RING_TB 256          // targets per work item
 #define RING_MAX_BLOCK 1024   // largest query block (1 + L rounded up to 8) that fits a D = 8 ring
 
@@ -165,13 +171,31 @@ template <int D, int NW> constexpr size_t ring_lds_bytes()
     return 2 * (size_t) RingGeom<D>::PROF_BYTES + (size_t) NW * RingGeom<D>::NQMAX * 4 + 1312 + RingGeom<D>::P + 16;
 }
 
-__device__ __forceinline__ int pk_addsat(int a, int b)
+// (a + b) clamped to [0, 1] per half
+__device__ __forceinline__ int pk_add_clamp01(int a, int b)
 {
-    return __builtin_bit_cast(int, __builtin_elementwise_add_sat(__builtin_bit_cast(v2s, a), __builtin_bit_cast(v2s, b)));
+    int r;
+    asm("v_pk_add_f16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
+__device__ __forceinline__ int pk_max3_f16(int a, int b, int c)
+{
+    int r;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// maximum of two packed values that are known to be >= 0: non-negative half floats order like their bit patterns
 __device__ __forceinline__ int pk_max(int a, int b)
 {
     return __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(v2s, a), __builtin_bit_cast(v2s, b)));
+}
+__device__ __forceinline__ unsigned short gl_half_bits(int score)      // score / 2048 as a half float; |score| <= 2048
+{
+    return __builtin_bit_cast(unsigned short, (_Float16) ((float) score * (1.0f / GL_SCALE)));
+}
+__device__ __forceinline__ uint32_t gl_score_of_bits(int bits)         // inverse, bits of a half float in [0, 1]
+{
+    return (uint32_t) ((float) __builtin_bit_cast(_Float16, (unsigned short) bits) * (float) GL_SCALE);
 }
 __device__ __forceinline__ int dpp_wave_ror1(int x)
 {
@@ -185,8 +209,7 @@ __device__ __forceinline__ int dpp_wave_ror1(int x)
 // the ring by itself).  The LDS profile keeps the b128 blocks of all lanes contiguous (block m of lane l
 // at m*1024 + 16*l: conflict-free), only the builder knows the slot permutation.
 template <int D, int R>
-__device__ __forceinline__ void ring_pairstep(int (&G)[D], int (&E)[D], int (&O)[D], const char *lane_p1, const char *lane_p2,
-                                              unsigned c0, unsigned c1)
+__device__ __forceinline__ void ring_pairstep(int (&G)[D], int (&E)[D], const char *lane_p1, const char *lane_p2, unsigned c0, unsigned c1)
 {
     constexpr int M = D / 4;
     constexpr int RSB = RingGeom<D>::RSB;
@@ -204,26 +227,21 @@ __device__ __forceinline__ void ring_pairstep(int (&G)[D], int (&E)[D], int (&O)
 #pragma unroll
     for (int k = 0; k < D; ++k) {
         const int p = (k - R + D) % D;
-        G[p] = pk_addsat(G[p], S[k >> 2][k & 3]);
-        E[k] = pk_max(E[k], G[p]);
-    }
-#pragma unroll
-    for (int k = 0; k < D; ++k) {
-        const int p = (k - R + D) % D;
-        G[p] = pk_addsat(G[p], T[k >> 2][k & 3]);
-        O[k] = pk_max(O[k], G[p]);
+        const int g1 = pk_add_clamp01(G[p], S[k >> 2][k & 3]);
+        G[p] = pk_add_clamp01(g1, T[k >> 2][k & 3]);
+        E[k] = pk_max3_f16(E[k], g1, G[p]);
     }
     constexpr int pl = (D - 1 - R + D) % D;
     G[pl] = dpp_wave_ror1(G[pl]);
 }
 
 template <int D, int R0>
-__device__ __forceinline__ void ring_8letters(int (&G)[D], int (&E)[D], int (&O)[D], const char *lane_p1, const char *lane_p2, uint2 Lc)
+__device__ __forceinline__ void ring_8letters(int (&G)[D], int (&E)[D], const char *lane_p1, const char *lane_p2, uint2 Lc)
 {
-    ring_pairstep<D, (R0 + 0) % D>(G, E, O, lane_p1, lane_p2, Lc.x & 0xFF, (Lc.x >> 8) & 0xFF);
-    ring_pairstep<D, (R0 + 1) % D>(G, E, O, lane_p1, lane_p2, (Lc.x >> 16) & 0xFF, Lc.x >> 24);
-    ring_pairstep<D, (R0 + 2) % D>(G, E, O, lane_p1, lane_p2, Lc.y & 0xFF, (Lc.y >> 8) & 0xFF);
-    ring_pairstep<D, (R0 + 3) % D>(G, E, O, lane_p1, lane_p2, (Lc.y >> 16) & 0xFF, Lc.y >> 24);
+    ring_pairstep<D, (R0 + 0) % D>(G, E, lane_p1, lane_p2, Lc.x & 0xFF, (Lc.x >> 8) & 0xFF);
+    ring_pairstep<D, (R0 + 1) % D>(G, E, lane_p1, lane_p2, (Lc.x >> 16) & 0xFF, Lc.x >> 24);
+    ring_pairstep<D, (R0 + 2) % D>(G, E, lane_p1, lane_p2, Lc.y & 0xFF, (Lc.y >> 8) & 0xFF);
+    ring_pairstep<D, (R0 + 3) % D>(G, E, lane_p1, lane_p2, (Lc.y >> 16) & 0xFF, Lc.y >> 24);
 }
 
 template <int D, int NW>
@@ -238,7 +256,9 @@ __global__ __launch_bounds__(64 * NW) void k_gapless_ring(const rsk_ring *__rest
                                                           const uint32_t *__restrict__ t_perm,   // self triangle: processing order
                                                           const uint32_t *__restrict__ t_claim,  // positions of each aligned block, longest first
                                                           uint32_t tb_size, int self_triangle,
-                                                          uint16_t *__restrict__ out, size_t ldo, gl_hits hits)
+                                                          uint16_t *__restrict__ out, size_t ldo, gl_hits hits,
+                                                          const uint8_t *__restrict__ q_mu, const uint32_t *__restrict__ q_off,
+                                                          const uint32_t *__restrict__ q_len)
 {
     typedef RingGeom<D> Gm;
     constexpr int P = Gm::P, RSB = Gm::RSB, NQMAX = Gm::NQMAX, M = Gm::M;
@@ -260,7 +280,7 @@ __global__ __launch_bounds__(64 * NW) void k_gapless_ring(const rsk_ring *__rest
 
     for (int i = tid; i < 1296; i += nthreads) mat[i] = c_mu_int[i];
     for (int i = tid; i < P; i += nthreads) rl[i] = ring_letters[rg.letters_off + i];
-    for (int i = tid; i < NW * NQMAX; i += nthreads) res[i] = FLOOR32;
+    for (int i = tid; i < NW * NQMAX; i += nthreads) res[i] = 0;
     __syncthreads();
     // build both profile copies, 8 slots (16 bytes) per store
     for (int idx = tid; idx < Gm::NROWS * (P / 8); idx += nthreads) {
@@ -272,7 +292,7 @@ __global__ __launch_bounds__(64 * NW) void k_gapless_ring(const rsk_ring *__rest
         for (int k = 0; k < 9; ++k) {
             const int s = (8 * rg + k) & (P - 1);
             const unsigned l = rl[s];
-            const short v = (c == 36 || l == 0xFF) ? (short) -32768 : (short) mat[c * 36 + l];
+            const short v = (short) ((c == 36 || l == 0xFF) ? GL_RESET_BITS : gl_half_bits(mat[c * 36 + l]));
             if (k < 8) v1[k] = v;
             if (k > 0) v2[k - 1] = v;
         }
@@ -304,16 +324,16 @@ __global__ __launch_bounds__(64 * NW) void k_gapless_ring(const rsk_ring *__rest
         const uint32_t tlen = __builtin_amdgcn_readfirstlane(t_len[t]);
         const uint2 *lp = (const uint2 *) (t_mu + toff);
         const uint32_t nch = (tlen + 7) >> 3;
-        int G[D], E[D], O[D];
+        int G[D], E[D];
 #pragma unroll
-        for (int k = 0; k < D; ++k) { G[k] = FLOOR2; E[k] = FLOOR2; O[k] = FLOOR2; }
+        for (int k = 0; k < D; ++k) { G[k] = 0; E[k] = 0; }
         // a full rotation of the register names takes D pair-steps = 2*D letters
         if (D == 4) {
             uint2 L = lp[0];
             for (uint32_t ch = 0; ch < nch; ++ch) {
                 const uint2 Lc = L;
                 L = lp[ch + 1];   // prefetch (the chain set has >= 64 bytes of tail padding)
-                ring_8letters<D, 0>(G, E, O, lane_p1, lane_p2, Lc);
+                ring_8letters<D, 0>(G, E, lane_p1, lane_p2, Lc);
             }
         } else {
             uint2 L0 = lp[0], L1 = lp[1];
@@ -321,26 +341,51 @@ __global__ __launch_bounds__(64 * NW) void k_gapless_ring(const rsk_ring *__rest
             for (; ch + 2 <= nch; ch += 2) {
                 const uint2 Lc0 = L0, Lc1 = L1;
                 L0 = lp[ch + 2]; L1 = lp[ch + 3];
-                ring_8letters<D, 0>(G, E, O, lane_p1, lane_p2, Lc0);
-                ring_8letters<D, 4>(G, E, O, lane_p1, lane_p2, Lc1);
+                ring_8letters<D, 0>(G, E, lane_p1, lane_p2, Lc0);
+                ring_8letters<D, 4>(G, E, lane_p1, lane_p2, Lc1);
             }
-            if (ch < nch) ring_8letters<D, 0>(G, E, O, lane_p1, lane_p2, L0);   // odd tail: the target ends here, names need not close
+            if (ch < nch) ring_8letters<D, 0>(G, E, lane_p1, lane_p2, L0);   // odd tail: the target ends here, names need not close
         }
         // per-query reduction
 #pragma unroll
         for (int m = 0; m < M; ++m) {
-            int b = pk_max(pk_max(E[4 * m], E[4 * m + 1]), pk_max(E[4 * m + 2], E[4 * m + 3]));
-            b = pk_max(b, pk_max(pk_max(O[4 * m], O[4 * m + 1]), pk_max(O[4 * m + 2], O[4 * m + 3])));
-            const int lo = (int) (short) (b & 0xFFFF), hi = b >> 16;
-            const int v = max(lo, hi);
+            const int b = pk_max(pk_max(E[4 * m], E[4 * m + 1]), pk_max(E[4 * m + 2], E[4 * m + 3]));
+            const int v = max(b & 0xFFFF, (int) ((unsigned) b >> 16));        // half-float bits, >= 0: ordered like integers
             if (lq[m] != 0xFF) atomicMax(&wres[lq[m]], v);
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        for (uint32_t k = lane; k < rg.nq; k += 64) {
-            const int v = wres[k];
-            wres[k] = FLOOR32;
-            const uint32_t qid = ring_qid[rg.qid_off + k];
-            const uint32_t sc = (uint32_t) (v + 32768);
+        for (uint32_t kb = 0; kb < rg.nq; kb += 64) {
+            const uint32_t k = kb + lane;
+            const bool have = k < rg.nq;
+            int v = 0;
+            uint32_t qid = 0;
+            if (have) { v = wres[k]; wres[k] = 0; qid = ring_qid[rg.qid_off + k]; }
+            uint32_t sc = gl_score_of_bits(v);
+            // the clamp's ceiling: score these pairs again, exactly -- the wave walks the diagonals of one pair at a time
+            // (x = max(0, x) + s in integers; a lane per diagonal)
+            unsigned long long capped = __ballot(have && v >= GL_CAP_BITS);
+            while (capped) {
+                const int l = __builtin_ctzll(capped);
+                capped &= capped - 1;
+                const uint32_t cq = (uint32_t) __builtin_amdgcn_readlane((int) qid, l);
+                const uint8_t *A = q_mu + q_off[cq];
+                const uint8_t *B = t_mu + toff;
+                const int LA = (int) q_len[cq], LB = (int) tlen;
+                int best = 0;
+                for (int d = lane; d < LA + LB - 1; d += 64) {
+                    int i = d < LB ? 0 : d - LB + 1;
+                    int j = d < LB ? LB - 1 - d : 0;
+                    int x = 0;
+                    for (; i < LA && j < LB; ++i, ++j) {
+                        x = max(x, 0) + mat[A[i] * 36 + B[j]];
+                        best = max(best, x);
+                    }
+                }
+#pragma unroll
+                for (int sft = 32; sft >= 1; sft >>= 1) best = max(best, __shfl_xor(best, sft, 64));
+                if (lane == l) sc = (uint32_t) min(best, 65535);
+            }
+            if (!have) continue;
             if (out) {
                 const size_t o = self_triangle ? (size_t) min(qid, t) * ldo + max(qid, t) : (size_t) qid * ldo + t;
                 out[o] = (uint16_t) sc;
@@ -429,7 +474,7 @@ static int launch_ring_class(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, con
     if (arc != RSK_OK) return arc;
     hipLaunchKernelGGL((k_gapless_ring<D, NW>), dim3(nwork), dim3(64 * NW), lds, ctx->stream, q->d_ring_tab, d_work,
                        q->d_ring_letters, q->d_ring_laneq, q->d_ring_qid, t->d_mu, t->d_off, t->d_len, t->n, q->d_ring_perm,
-                       self_triangle ? q->d_tri_claim : t->d_nat_claim, tb_size, self_triangle, d_scores, ldo, hits);
+                       self_triangle ? q->d_tri_claim : t->d_nat_claim, tb_size, self_triangle, d_scores, ldo, hits, q->d_mu, q->d_off, q->d_len);
     RSK_HIP(hipGetLastError());
     return RSK_OK;
 }

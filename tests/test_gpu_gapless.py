@@ -105,6 +105,37 @@ def test_low_complexity_high_scores(ctx):
     assert got[3, 3] == 4 * 1023
 
 
+def test_scores_around_the_half_float_ceiling(ctx):
+    """The ring kernel keeps scores as n / 2048 in half floats whose clamp tops out at 2048; a pair that reads 2048 is scored
+    again in integers by the wave that found it.  Chains whose scores straddle the ceiling (2044, 2048, 2052, 3000+),
+    triangle and rectangle, dense matrix and hit records."""
+    import torch
+    import reseek_amd
+    rng = np.random.default_rng(8)
+    seqs = [np.full(L, 1, np.uint8) for L in (511, 512, 513, 760)]           # self score 4 per residue
+    mixed = rng.integers(0, 36, 900).astype(np.uint8)
+    seqs += [mixed, np.concatenate([mixed[:700], rng.integers(0, 36, 150).astype(np.uint8)])]      # a long near-copy
+    seqs += [rng.integers(0, 36, int(L)).astype(np.uint8) for L in (40, 300, 1010)]
+    got = run_matrix(ctx, seqs, tri=True)
+    ia, ib = np.triu_indices(len(seqs))
+    want = ol.mu_gapless_pairs(seqs, ia, ib)
+    assert np.array_equal(got[ia, ib], want)
+    assert (want == 2044).any() and (want == 2048).any() and (want == 2052).any() and (want > 2500).sum() >= 2
+    rect = run_matrix(ctx, seqs[:5], seqs[3:])
+    qa, qb = np.meshgrid(np.arange(5), np.arange(len(seqs) - 3), indexing="ij")
+    assert np.array_equal(rect, ol.mu_gapless_pairs(seqs, qa.ravel(), qb.ravel() + 3).reshape(rect.shape))
+    c2 = reseek_amd.Ctx(0, stream=torch.cuda.current_stream().cuda_stream)
+    db = reseek_amd.Db.from_mu_seqs(c2, seqs)
+    rec = torch.zeros((256, 3), dtype=torch.int32, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    c2.mu_gapless_hits_dev(db, db, True, 2000, rec.data_ptr(), 256, cnt.data_ptr())
+    torch.cuda.synchronize()
+    k = int(cnt.item())
+    keep = want >= 2000
+    assert sorted(map(tuple, rec[:k].cpu().numpy().tolist())) == sorted(zip(ia[keep].tolist(), ib[keep].tolist(), want[keep].tolist()))
+    db.close(); c2.close()
+
+
 def test_scop40_scale_properties(ctx):
     """BASELINE config[1] shape (11,211 chains, SCOP40 lengths): size-independent properties --
     symmetry of the score under swapping roles, self score == sum of diagonal self scores, and a

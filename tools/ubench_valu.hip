@@ -55,6 +55,12 @@ template <int MODE> __global__ __launch_bounds__(256) void k(int *out, int seed)
             if (MODE == 46) asm volatile("v_max_i32 %0, %1, %2" : "=v"(a[i]) : "v"(a[(i + 5) & 15]), "v"(a[(i + 9) & 15]));
             if (MODE == 47) asm volatile("v_add_u32 %0, %0, %1\n\tv_max_i32 %0, %0, %2\n\tv_subrev_u32 %0, %3, %0" : "+v"(a[i]) : "v"(s), "v"(a[(i + 3) & 15]), "s"(seed));
             if (MODE == 5) asm volatile("v_pk_add_i16 %0, %0, %1 clamp\n\tv_pk_max_i16 %0, %0, %1" : "+v"(a[i]) : "v"(s));
+            if (MODE == 50) asm volatile("v_pk_maximum3_f16 %0, %0, %1, %2" : "+v"(a[i]) : "v"(s), "v"(seed));
+            if (MODE == 51) asm volatile("v_pk_add_f16 %0, %0, %1" : "+v"(a[i]) : "v"(s));
+            if (MODE == 52) asm volatile("v_pk_max_f16 %0, %0, %1" : "+v"(a[i]) : "v"(s));
+            if (MODE == 53) asm volatile("v_pk_maximum3_f16 %0, %0, %1, 0" : "+v"(a[i]) : "v"(s));
+            if (MODE == 54) asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(a[i]) : "s"(0xFFFF), "v"(s));
+            if (MODE == 55) asm volatile("v_pk_add_f16 %0, %0, %1\n\tv_pk_maximum3_f16 %0, %0, %1, %2" : "+v"(a[i]) : "v"(s), "v"(seed));
         }
         if (MODE == 6) {
 #pragma unroll
@@ -93,6 +99,12 @@ int main()
     run<3>("v_max_i32", 16, 8);
     run<4>("v_mov_b32_dpp wave_ror:1", 16, 8);
     run<5>("pk_add+pk_max dep pair", 32, 8);
+    run<50>("v_pk_maximum3_f16", 16, 8);
+    run<51>("v_pk_add_f16", 16, 8);
+    run<52>("v_pk_max_f16", 16, 8);
+    run<53>("v_pk_maximum3_f16 x, y, 0", 16, 8);
+    run<54>("v_bfi_b32", 16, 8);
+    run<55>("pk_add_f16+pk_maximum3_f16 dep pair", 32, 8);
     run<6>("ds_read_b128 (B per lane=16)", 4, 4);
     run<7>("v_max3_i16", 16, 8);
     run<8>("v_max3_i16 op_sel hi", 16, 8);
