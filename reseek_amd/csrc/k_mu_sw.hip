@@ -77,10 +77,36 @@ struct musw_args {
 typedef short v2s __attribute__((ext_vector_type(2)));
 typedef unsigned short v2us __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ int pk_add(int a, int b) { return __builtin_bit_cast(int, __builtin_bit_cast(v2s, a) + __builtin_bit_cast(v2s, b)); }
-__device__ __forceinline__ int pk_max(int a, int b) { return __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(v2s, a), __builtin_bit_cast(v2s, b))); }
-// unsigned saturating subtract: floors at 0
-__device__ __forceinline__ int pk_subs(int a, int b) { return __builtin_bit_cast(int, __builtin_elementwise_sub_sat(__builtin_bit_cast(v2us, a), __builtin_bit_cast(v2us, b))); }
+// Packed HALF floats holding integers: every value the recurrence can form below the saturation test (best > 250) is an
+// integer of magnitude <= 2048 and therefore exact; beyond 2048 a half float rounds, but such a pair is already saturated
+// (the reported value is 255 whatever the exact maximum).  What the float unit buys: a three-operand maximum
+// (v_pk_maximum3_f16, gfx950) -- the packed int16 unit has none -- at the same issue rate (tools/ubench_valu.hip).
+__device__ __forceinline__ int pk_addh(int a, int b)
+{
+    int r;
+    asm("v_pk_add_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ int pk_max3h(int a, int b, int c)
+{
+    int r;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ int pk_max3h_0(int a, int b)               // max(a, b, 0)
+{
+    int r;
+    asm("v_pk_maximum3_f16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ unsigned musw_half_bits(int v)             // integer |v| <= 2048 as half-float bits
+{
+    return (unsigned) __builtin_bit_cast(unsigned short, (_Float16) (float) v);
+}
+__device__ __forceinline__ int musw_int_of_half(int bits)             // non-negative half float -> integer (rounded values stay > 250)
+{
+    return (int) (float) __builtin_bit_cast(_Float16, (unsigned short) bits);
+}
 // (lo half of a, hi half of b)
 __device__ __forceinline__ int pk_lo_hi(int a, int b)
 {
@@ -89,13 +115,14 @@ __device__ __forceinline__ int pk_lo_hi(int a, int b)
     return r;
 }
 
-// Two cells per VALU op: the 32 rows of a strip are 16 registers of packed int16, row r in the low
+// Two cells per VALU op: the 32 rows of a strip are 16 registers of packed half floats, row r in the low
 // half and row r + 16 in the high half.  The high half runs ONE COLUMN BEHIND the low half (the same
 // systolic skew that separates neighbouring lanes, applied inside the lane), so the vertical F chain
 // row 15 -> row 16 crosses from the low half of one step to the high half of the next; the next lane
-// is two columns behind.  E and F are kept floored at 0 with unsigned saturating subtracts (a negative
-// E or F is equivalent to 0 in H = max(0, ...)), which also removes the explicit max(., 0).
-// Per 2 cells: bfi (merge the two profile rows), add, max E, max F, max best, sub, sub, max, sub, max.
+// is two columns behind.  E and F are kept floored at 0 (a negative E or F is equivalent to 0 in H = max(0, ...)), which
+// removes the explicit max(., 0) from H: the floor is the third operand of the maximum that updates E / F.
+// Per 2 cells: bfi (merge the two profile rows), add, max3 (H), add, add, max3 (E), add, max3 (F), and half a max3 for the
+// running best (two rows at a time) = 8.5 packed ops (r01-r02, packed int16: 10).
 __global__ __launch_bounds__(1024) void k_mu_sw(musw_args a, uint32_t gmax)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -135,7 +162,7 @@ __global__ __launch_bounds__(1024) void k_mu_sw(musw_args a, uint32_t gmax)
                 int vlo = MUSW_PADSCORE, vhi = MUSW_PADSCORE;
                 if (c < 36 && ilo < LQ) vlo = mat[c * 36 + Q[a.reverse ? (LQ - 1 - ilo) : ilo]];
                 if (c < 36 && ihi < LQ) vhi = mat[c * 36 + Q[a.reverse ? (LQ - 1 - ihi) : ihi]];
-                prof[idx] = (vlo & 0xFFFF) | (vhi << 16);
+                prof[idx] = (int) (musw_half_bits(vlo) | (musw_half_bits(vhi) << 16));
             }
             __syncthreads();
         }
@@ -171,7 +198,7 @@ __global__ __launch_bounds__(1024) void k_mu_sw(musw_args a, uint32_t gmax)
         int best = 0;
         int bot_h = 0, bot_f = 0;      // (row 15 | row 31) H and outgoing F of the previous step
         int diag_in = 0;               // H above the top rows at the previous column
-        const int open2 = (a.open & 0xFFFF) * 0x10001, ext2 = (a.ext & 0xFFFF) * 0x10001;
+        const int nopen2 = (int) (musw_half_bits(-a.open) * 0x10001u), next2 = (int) (musw_half_bits(-a.ext) * 0x10001u);
         const char *lane_prof = (const char *) prof + st * 16;
         const uint32_t kstride = g * 16, RS = g * 64;         // bytes between k blocks / letter rows
         const int top_mask = st == 0 ? (int) 0xFFFF0000 : -1; // the very first rows have no strip above: H = F = 0
@@ -202,25 +229,28 @@ __global__ __launch_bounds__(1024) void k_mu_sw(musw_args a, uint32_t gmax)
             int diag = diag_in;
             int F = up_f;
             diag_in = up_h;
+            int hprev = 0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int S = pk_lo_hi(Pl[r >> 2][r & 3], Ph[r >> 2][r & 3]);
-                int h = pk_add(diag, S);
-                h = pk_max(h, E[r]);
-                h = pk_max(h, F);
+                const int h = pk_max3h(pk_addh(diag, S), E[r], F);
                 diag = Hin[r];
                 Hout[r] = h;
-                best = pk_max(best, h);
-                const int ho = pk_subs(h, open2);
-                E[r] = pk_max(pk_subs(E[r], ext2), ho);
-                F = pk_max(pk_subs(F, ext2), ho);
+                if (r & 1) best = pk_max3h(best, hprev, h);
+                hprev = h;
+                const int ho = pk_addh(h, nopen2);
+                E[r] = pk_max3h_0(pk_addh(E[r], next2), ho);
+                F = pk_max3h_0(pk_addh(F, next2), ho);
             }
             bot_h = Hout[15];
             bot_f = F;
         };
         int thr_l = -1;                               // inactive lanes count as decided
         if (a.thr) {
-            if (active) thr_l = a.thr[a.rowstart[q] + k0 + pr];
+            if (active) {                               // in the order of half-float bits (non-negative values order like integers)
+                const int tv = a.thr[a.rowstart[q] + k0 + pr];
+                thr_l = tv < 0 ? -1 : (int) musw_half_bits(min(tv, 2047));
+            }
             pbest[wave * 64 + lane] = 0;
         }
         // an odd step count is rounded up: the extra step only sees pad letters / finished columns
@@ -242,6 +272,7 @@ __global__ __launch_bounds__(1024) void k_mu_sw(musw_args a, uint32_t gmax)
             if (st + d < g) red = max(red, o);
         }
         if (active && st == 0) {
+            red = musw_int_of_half(red);
             const uint8_t v = (uint8_t) (red > 250 ? 255 : red);
             if (a.list) a.out[a.rowstart[q] + k0 + pr] = v;
             else if (a.tri) a.out[(size_t) min(q, t) * a.ldo + max(q, t)] = v;
