@@ -333,7 +333,7 @@ def search_vs_reference(nsample=1500, reps=3):
 
 def config_shares(which=("config2", "config3", "config4")):
     """Driver-visible numbers for BASELINE configs[2..4] beside the headline (each a whole `rsk_search` call from .bca files,
-    second of two runs where a run is short, with an equality bit of the sorted hit table against oracle/_ref/reseek on a
+    second of two runs for the -db shares (config2: one run), with an equality bit of the sorted hit table against oracle/_ref/reseek on a
     sample of the same files):
       config2  `-search Q -db Q -fast`, Q = the 11,211-chain SCOP40-shaped synthetic .bca: Mu k-mer prefilter + two-hit
                diagonals on the GPU, then the candidates under the sensitive preset (search.cpp:76-111)
@@ -411,7 +411,7 @@ def config_shares(which=("config2", "config3", "config4")):
                 bench_search.write_bca_fast(db, lens[rng.choice(len(lens), ndb)], rng, "d")
                 tgen = time.perf_counter() - t0
                 e = run(key, "-search Q -db DB -%s, %d queries x %d-chain .bca DB (one GPU's share; DSS featurisation + self-rev of the DB "
-                        "inside the call)" % (mode, nq, ndb), q, db, mode, 2 if key == "config3" else 1)
+                        "inside the call)" % (mode, nq, ndb), q, db, mode, 2)
                 e["chain_pairs_per_sec"] = e["chain_pairs"] / e["seconds"]
                 e["db_generation_seconds"] = tgen
                 e["vs_reference_on_sample"] = sample_check(td, q, db, mode, 32 if key == "config3" else 8, 1500 if key == "config3" else 600)
@@ -667,6 +667,14 @@ def main():
                 sys.stderr.write("bench: live-kernel leg failed: %s\n" % e)
         if search_n is not None:
             res["search"] = search_n
+        if world == 1:
+            # the legs below are whole searches on contexts of their own: give the kernel legs' device memory back first (the
+            # pools of this context and of the parked helper contexts hold tens of GB of trace scratch)
+            try:
+                reseek_amd.capi.lib().rsk_ctx_trim(ctx.h)
+                torch.cuda.empty_cache()
+            except Exception as e:  # noqa: BLE001
+                sys.stderr.write("bench: trim failed: %s\n" % e)
         if not args.no_search and world == 1 and not args.chains:
             try:
                 res["search"] = search_end_to_end(seqs)
