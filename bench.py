@@ -173,7 +173,7 @@ def _load_json(name):
 def live_kernels(ctx, seqs, db, reps=3):
     """`roofline_live`: the kernels reseek -search actually runs (the gapless kernel of `value` has no caller in the
     reference), timed with the library's HIP events on the launch stream, on the same SCOP40-shaped set:
-      k_mu_sw     Mu SW filter forward pass over the whole triangle (parasail_mu.cpp:120), packed half floats holding integers (8.5 ops per cell pair)
+      k_mu_sw     Mu SW filter forward pass over the whole triangle (parasail_mu.cpp:120), packed half floats holding integers, two queries per register (k_mu_sw2: 7.5 ops per cell pair)
       k_sw_float  float SW + trace of the -sensitive filter survivors (sw.cpp:79; per-pair kernel)
       k_sw_qp     float SW + trace, 64 queries x all chains (query-profile kernel; the -db / -verysensitive regime)
     Bounds: VALU issue (one wave64 instruction per 4 cycles per SIMD for mixed VOP2/VOP3/DPP streams, profiles/r02_ubench_valu.txt)
@@ -201,9 +201,9 @@ def live_kernels(ctx, seqs, db, reps=3):
     ms = med(lambda: ctx.mu_sw_matrix_dev(db, db, True, False, out8.data_ptr(), n))
     alg = float((lens * (n - np.arange(n))).sum() + np.cumsum(lens[::-1])[::-1].sum() + n * (n + 1) / 2)      # LA + LB + 1 per pair
     res.append({"kernel": "k_mu_sw", "what": "Mu SW filter, forward pass, all pairs i<=j", "kernel_ms": ms, "cells": tri_cells,
-                "cells_per_s": tri_cells / ms * 1e3, "bound": "valu", "valu_ops_per_cell": 4.25, "unit": "T lane-ops/s",
-                "achieved": tri_cells * 4.25 / ms * 1e3 / 1e12, "peak": PEAK_VALU_LANEOPS / 1e12,
-                "frac": tri_cells * 4.25 / ms * 1e3 / PEAK_VALU_LANEOPS,
+                "cells_per_s": tri_cells / ms * 1e3, "bound": "valu", "valu_ops_per_cell": 3.75, "unit": "T lane-ops/s",
+                "achieved": tri_cells * 3.75 / ms * 1e3 / 1e12, "peak": PEAK_VALU_LANEOPS / 1e12,
+                "frac": tri_cells * 3.75 / ms * 1e3 / PEAK_VALU_LANEOPS,
                 "hbm": {"algorithmic_bytes": alg, "achieved_GBs": alg / ms * 1e3 / 1e9, "frac": alg / ms * 1e3 / 1e9 / PEAK_HBM_GBS},
                 "pmc": pmc.get("k_mu_sw")})
     # --- survivors of the -sensitive filter -> float SW (per-pair kernel)

@@ -282,6 +282,154 @@ __global__ __launch_bounds__(1024) void k_mu_sw(musw_args a, uint32_t gmax)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_mu_sw2 -- the dense forward pass (every query against one implicit target range) with TWO QUERIES per packed register.
+// k_mu_sw packs rows r and r + 16 of ONE query into a dword; the vertical F chain between the halves forces the high half
+// to run one column behind, i.e. on the PREVIOUS target letter: two profile rows per step (8 ds_read_b128), a v_bfi per cell
+// pair to merge them and two alignbit / and per step for the crossing.  When the target range is the same for many queries
+// -- the forward pass of a search, 300 ms of a 460 ms all-vs-all -- two queries of neighbouring length can share a register
+// instead: low half = row r of query A, high half = row r of query B, both against the SAME target column.  One profile
+// row per step (4 ds_read_b128), no merge, no crossing: 7.5 packed ops per cell pair instead of 8.5, 16-row strips (half the
+// padding of a chain's last strip), lanes one column apart.  The profile of a query pair has the bytes of a one-query
+// profile of twice the length, so the launch geometry of k_mu_sw is reused with the pair's "virtual length" 2 * max(LA, LB)
+// (work items, classes, LDS sizes: run_mu_sw_querypairs); queries of more than 1024 residues stay with k_mu_sw.
+// In the self triangle the pair (A, B) of ranks (r, r + 1) takes the targets of rank >= r: B meets A once more as a target
+// (the same score lands in the same cell), everything else is the triangle.
+// ---------------------------------------------------------------------------------------------
+#define MUSW2_R 16
+#define MUSW_NOQ 0xFFFFFFFFu
+__global__ __launch_bounds__(1024) void k_mu_sw2(musw_args a, uint32_t gmax, const uint2 *__restrict__ qpairs)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // dword (c, k, st, w) = row 16*st + 4*k + w of query A (low half) and of query B (high half) against letter c:
+    // P[((c*4 + k)*g + st)*4 + w]; a lane's four b128 reads per letter row are conflict-free across the strips of a group
+    int *prof = (int *) smem;
+    signed char *mat = (signed char *) (prof + (size_t) 37 * gmax * 16);
+    uint32_t *wg_item = (uint32_t *) (mat + 1312);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t nwaves = blockDim.x >> 6;
+    for (int i = tid; i < 1296; i += blockDim.x) mat[i] = (signed char) c_mu_int[i];
+    uint32_t cur_p = 0xFFFFFFFFu, qa = 0, qb = MUSW_NOQ, g = 1;
+    const uint32_t nitems = *a.nitems;
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) { wg_item[0] = atomicAdd(a.counter, 1u); wg_item[1] = 0; }
+        __syncthreads();
+        const uint32_t item = wg_item[0];
+        if (item >= nitems) break;
+        const uint2 it = a.items[item];
+        const uint32_t p = it.x;
+        if (p != cur_p) {
+            cur_p = p;
+            qa = qpairs[p].x; qb = qpairs[p].y;
+            const uint32_t LA = a.q_len[qa], LBq = qb != MUSW_NOQ ? a.q_len[qb] : 0u;
+            g = (max(LA, LBq) + MUSW2_R - 1) / MUSW2_R;
+            const uint8_t *QA = a.q_mu + a.q_off[qa], *QB = a.q_mu + (qb != MUSW_NOQ ? a.q_off[qb] : 0u);
+            const uint32_t per_c = g * 16;
+            for (uint32_t idx = tid; idx < 37 * per_c; idx += blockDim.x) {
+                const uint32_t c = idx / per_c, rem = idx - c * per_c;
+                const uint32_t k = rem / (g * 4), rem2 = rem - k * (g * 4);
+                const uint32_t sst = rem2 >> 2, w = rem2 & 3;
+                const uint32_t i = sst * MUSW2_R + 4 * k + w;
+                int va = MUSW_PADSCORE, vb = MUSW_PADSCORE;
+                if (c < 36 && i < LA) va = mat[c * 36 + QA[a.reverse ? (LA - 1 - i) : i]];
+                if (c < 36 && i < LBq) vb = mat[c * 36 + QB[a.reverse ? (LBq - 1 - i) : i]];
+                prof[idx] = (int) (musw_half_bits(va) | (musw_half_bits(vb) << 16));
+            }
+            __syncthreads();
+        }
+        const uint32_t ppw = 64 / g;                 // targets per wave, each against both queries
+        const uint32_t cnt = a.cnt[p];
+        const uint32_t chunk_end = min(cnt, it.y + ppw * nwaves * MUSW_CHUNK);
+        const uint32_t pr = lane / g, st = lane - pr * g;
+        for (;;) {
+        uint32_t bq = 0;
+        if (lane == 0) bq = atomicAdd(&wg_item[1], 1u);
+        bq = (uint32_t) __builtin_amdgcn_readfirstlane((int) bq);
+        const uint32_t k0 = it.y + bq * ppw;
+        if (k0 >= chunk_end) break;
+        const bool active = (pr < ppw) && (k0 + pr < chunk_end);
+        uint32_t t = 0, LB = 0;
+        const uint8_t *B = a.t_mu;
+        if (active) {
+            t = a.perm[a.first[p] + k0 + pr];
+            LB = a.t_len[t];
+            B = a.t_mu + a.t_off[t];
+        }
+        uint32_t ncol = active ? (LB + st) : 0;      // strip st is st columns behind strip 0
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) ncol = max(ncol, (uint32_t) __shfl_xor((int) ncol, s, 64));
+        if (ncol == 0) continue;
+        int HA[16], HB[16], E[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { HA[r] = 0; HB[r] = 0; E[r] = 0; }
+        int best = 0;
+        int bot_h = 0, bot_f = 0;      // bottom row of this strip at its previous step: H and the outgoing F
+        int diag_in = 0;               // H above the top row at the previous column
+        const int nopen2 = (int) (musw_half_bits(-a.open) * 0x10001u), next2 = (int) (musw_half_bits(-a.ext) * 0x10001u);
+        const char *lane_prof = (const char *) prof + st * 16;
+        const uint32_t kstride = g * 16, RS = g * 64;
+        const int top_mask = st == 0 ? 0 : -1;       // the first strip has nothing above it: H = F = 0
+        unsigned lw = active ? *(const unsigned *) B : 0u;
+        unsigned lw_next = 0;
+        auto step = [&](const int (&Hin)[16], int (&Hout)[16], uint32_t col) {
+            const int j = (int) col - (int) st;
+            const int up_h = dpp_wave_shr1(bot_h) & top_mask, up_f = dpp_wave_shr1(bot_f) & top_mask;
+            unsigned c = 36;
+            if (j >= 0 && (uint32_t) j < LB) {
+                const int jm = j & 3;
+                if (jm == 0) {
+                    if (j) lw = lw_next;
+                    lw_next = *(const unsigned *) (B + j + 4);
+                }
+                c = (lw >> (8 * jm)) & 0xFF;
+            }
+            const char *row = lane_prof + c * RS;
+            v4i P[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) P[k] = *(const v4i *) (row + k * kstride);
+            int diag = diag_in;
+            int F = up_f;
+            diag_in = up_h;
+            int hprev = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int h = pk_max3h(pk_addh(diag, P[r >> 2][r & 3]), E[r], F);
+                diag = Hin[r];
+                Hout[r] = h;
+                if (r & 1) best = pk_max3h(best, hprev, h);
+                hprev = h;
+                const int ho = pk_addh(h, nopen2);
+                E[r] = pk_max3h_0(pk_addh(E[r], next2), ho);
+                F = pk_max3h_0(pk_addh(F, next2), ho);
+            }
+            bot_h = Hout[15];
+            bot_f = F;
+        };
+        for (uint32_t col = 0; col < ncol; col += 2) {
+            step(HA, HB, col);
+            step(HB, HA, col + 1);
+        }
+        int ra = best & 0xFFFF, rb = (int) ((unsigned) best >> 16);      // half-float bits >= 0: ordered like integers
+        for (uint32_t d = 1; d < g; ++d) {
+            const int o = __shfl(best, (int) ((lane + d) & 63), 64);
+            if (st + d < g) { ra = max(ra, o & 0xFFFF); rb = max(rb, (int) ((unsigned) o >> 16)); }
+        }
+        if (active && st == 0) {
+            const int sa = musw_int_of_half(ra), sb = musw_int_of_half(rb);
+            const uint8_t va = (uint8_t) (sa > 250 ? 255 : sa), vb = (uint8_t) (sb > 250 ? 255 : sb);
+            if (a.tri) {
+                a.out[(size_t) min(qa, t) * a.ldo + max(qa, t)] = va;
+                if (qb != MUSW_NOQ) a.out[(size_t) min(qb, t) * a.ldo + max(qb, t)] = vb;
+            } else {
+                a.out[(size_t) qa * a.ldo + t] = va;
+                if (qb != MUSW_NOQ) a.out[(size_t) qb * a.ldo + t] = vb;
+            }
+        }
+        }   // batches
+    }
+}
+
 // Any length: one thread per pair, DP rows in global scratch (rare: both chains > 2048).
 __global__ void k_mu_sw_slow(musw_args a, const uint2 *pairs, const uint32_t *pair_k, uint32_t npairs, int *scratch,
                              size_t scratch_stride)
@@ -591,6 +739,91 @@ static int run_mu_sw_lists(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, musw_
     return RSK_OK;
 }
 
+static uint32_t item_exact_implicit(const rsk_db *q, uint32_t nt, int self_triangle);
+
+// The dense forward pass through k_mu_sw2: queries of <= 1024 residues are paired in order of length (virtual query p =
+// (A, B), virtual length 2 * max(LA, LB): the work-item kernels and the class geometry of k_mu_sw apply unchanged), the rest
+// -- and nothing else -- goes through k_mu_sw.  base.cnt / base.first describe the implicit lists per REAL query.
+static int run_mu_sw_querypairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, musw_args base, int self_triangle, musw_ws &ws)
+{
+    const uint32_t nq = q->n, nt = t->n;
+    std::vector<uint32_t> order(nq);
+    for (uint32_t i = 0; i < nq; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return q->len[x] < q->len[y]; });   // == rsk_build_len_perm's order
+    std::vector<uint2> qp;
+    std::vector<uint32_t> vlen, vcnt, vfirst, cnt_old(nq, 0);
+    bool any_old = false;
+    uint64_t nitems_ub = 16;
+    bool has_class[3] = { false, false, false };
+    for (uint32_t k = 0; k < nq;) {
+        const uint32_t A = order[k];
+        if (q->len[A] > 1024) { cnt_old[A] = self_triangle ? nt - t->h_len_rank[A] : nt; any_old = true; ++k; continue; }
+        uint32_t Bq = MUSW_NOQ;
+        if (k + 1 < nq && q->len[order[k + 1]] <= 1024) Bq = order[k + 1];
+        const uint32_t L = std::max(q->len[A], Bq != MUSW_NOQ ? q->len[Bq] : 0u), vl = 2 * std::max(L, 1u);
+        const uint32_t c = self_triangle ? nt - t->h_len_rank[A] : nt;
+        qp.push_back(make_uint2(A, Bq));
+        vlen.push_back(vl); vcnt.push_back(c); vfirst.push_back(self_triangle ? t->h_len_rank[A] : 0u);
+        const uint32_t g = (vl + MUSW_R - 1) / MUSW_R, lp = g * MUSW_R;
+        const int cls = lp <= 416 ? 0 : lp <= 1024 ? 1 : 2;
+        has_class[cls] = true;
+        const uint32_t per_wg = (64 / g) * musw_class_waves[cls] * MUSW_CHUNK;
+        nitems_ub += (c + per_wg - 1) / per_wg;
+        k += Bq != MUSW_NOQ ? 2 : 1;
+    }
+    int rc;
+    const uint32_t npv = (uint32_t) qp.size();
+    if (npv) {
+        uint2 *d_qp = nullptr;
+        uint32_t *d_vlen = nullptr, *d_vcnt = nullptr, *d_vfirst = nullptr;
+        if ((rc = ws.alloc(&d_qp, npv)) != RSK_OK || (rc = ws.alloc(&d_vlen, npv)) != RSK_OK || (rc = ws.alloc(&d_vcnt, npv)) != RSK_OK ||
+            (rc = ws.alloc(&d_vfirst, npv)) != RSK_OK)
+            return rc;
+        if ((rc = ws.alloc(&ws.item_start, (size_t) nq + 1)) != RSK_OK || (rc = ws.alloc(&ws.nitems, 1)) != RSK_OK ||
+            (rc = ws.alloc(&ws.counter, 1)) != RSK_OK || (rc = ws.alloc(&ws.items, (size_t) std::min<uint64_t>(nitems_ub, 0xFFFFFFF0ull))) != RSK_OK)
+            return rc;
+        // (synchronous copies of a few hundred KB: the vectors die with this call)
+        RSK_HIP(hipStreamSynchronize(ctx->stream));
+        RSK_HIP(hipMemcpy(d_qp, qp.data(), (size_t) npv * sizeof(uint2), hipMemcpyHostToDevice));
+        RSK_HIP(hipMemcpy(d_vlen, vlen.data(), (size_t) npv * 4, hipMemcpyHostToDevice));
+        RSK_HIP(hipMemcpy(d_vcnt, vcnt.data(), (size_t) npv * 4, hipMemcpyHostToDevice));
+        RSK_HIP(hipMemcpy(d_vfirst, vfirst.data(), (size_t) npv * 4, hipMemcpyHostToDevice));
+        for (int cls = 0; cls < MUSW_NCLASS; ++cls) {
+            if (!has_class[cls]) continue;
+            RSK_HIP(hipMemsetAsync(ws.counter, 0, 4, ctx->stream));
+            hipLaunchKernelGGL(k_musw_scan_items, dim3(1), dim3(1024), 0, ctx->stream, d_vlen, d_vcnt, npv, cls, ws.item_start, ws.nitems);
+            hipLaunchKernelGGL(k_musw_fill_items, dim3(npv), dim3(64), 0, ctx->stream, d_vlen, d_vcnt, d_vfirst, base.perm, (const uint32_t *) nullptr,
+                               (const uint32_t *) nullptr, npv, cls, ws.item_start, ws.items, (uint32_t *) nullptr);
+            musw_args a = base;
+            a.items = ws.items; a.nitems = ws.nitems; a.counter = ws.counter;
+            a.cnt = d_vcnt; a.first = d_vfirst;
+            const uint32_t gmax = musw_class_lqpad[cls] / MUSW_R;
+            const uint32_t waves = musw_class_waves[cls];
+            const size_t lds = (size_t) 37 * gmax * 64 + 1312 + 16;
+            static std::atomic<int> attr_set[64];
+            const int arc = rsk_once_per_device(attr_set, ctx->device, [&]() -> int {
+                RSK_HIP(hipFuncSetAttribute((const void *) k_mu_sw2, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+                return RSK_OK;
+            });
+            if (arc != RSK_OK) return arc;
+            const int wg_per_cu = std::max(1, std::min<int>(20 / (int) waves, (int) (163840 / lds)));
+            hipLaunchKernelGGL(k_mu_sw2, dim3(ctx->num_cus * wg_per_cu), dim3(64 * waves), lds, ctx->stream, a, gmax, (const uint2 *) d_qp);
+            RSK_HIP(hipGetLastError());
+        }
+    }
+    if (any_old) {
+        uint32_t *d_cnt_old = nullptr;
+        if ((rc = ws.alloc(&d_cnt_old, nq)) != RSK_OK) return rc;
+        RSK_HIP(hipStreamSynchronize(ctx->stream));
+        RSK_HIP(hipMemcpy(d_cnt_old, cnt_old.data(), (size_t) nq * 4, hipMemcpyHostToDevice));
+        musw_args b = base;
+        b.cnt = d_cnt_old;
+        // (item bound of the whole query set: an upper bound for the few long queries left here)
+        if ((rc = run_mu_sw_lists(ctx, q, t, b, item_exact_implicit(q, nt, self_triangle), ws)) != RSK_OK) return rc;
+    }
+    return RSK_OK;
+}
+
 static uint32_t item_exact_implicit(const rsk_db *q, uint32_t nt, int self_triangle)
 {
     uint64_t n = 16;
@@ -657,7 +890,8 @@ extern "C" int rsk_mu_sw_matrix_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db 
     a.perm = t->d_len_perm; a.tri = self_triangle ? 1 : 0;
     a.reverse = reverse_query ? 1 : 0; a.open = gap_open; a.ext = gap_ext;
     a.out = d_scores; a.ldo = ldo;
-    rc = run_mu_sw_lists(ctx, q, t, a, item_exact_implicit(q, t->n, self_triangle), ws);
+    const bool pairs2 = !(getenv("RSK_MUSW_QUERY_PAIRS") && atoi(getenv("RSK_MUSW_QUERY_PAIRS")) == 0);
+    rc = pairs2 ? run_mu_sw_querypairs(ctx, q, t, a, self_triangle, ws) : run_mu_sw_lists(ctx, q, t, a, item_exact_implicit(q, t->n, self_triangle), ws);
     if (rc != RSK_OK) return rc;
     RSK_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     RSK_HIP(hipStreamSynchronize(ctx->stream));   // workspace is freed on return
@@ -694,7 +928,10 @@ extern "C" int rsk_mu_filter_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t,
     a.reverse = 0; a.open = gap_open; a.ext = gap_ext;
     a.out = d_fwd; a.ldo = ldo;
     const uint64_t total = self_triangle ? (uint64_t) nq * (nq + 1) / 2 : (uint64_t) nq * t->n;
-    if ((rc = run_mu_sw_lists(ctx, q, t, a, item_exact_implicit(q, t->n, self_triangle), ws)) != RSK_OK) return rc;
+    const bool pairs2 = !(getenv("RSK_MUSW_QUERY_PAIRS") && atoi(getenv("RSK_MUSW_QUERY_PAIRS")) == 0);
+    if ((rc = pairs2 ? run_mu_sw_querypairs(ctx, q, t, a, self_triangle, ws)
+                     : run_mu_sw_lists(ctx, q, t, a, item_exact_implicit(q, t->n, self_triangle), ws)) != RSK_OK)
+        return rc;
     // candidates with fwd' >= OmegaFwd -> CSR lists
     uint32_t *ccnt = nullptr, *rowstart = nullptr, *list = nullptr;
     uint8_t *rev = nullptr;
