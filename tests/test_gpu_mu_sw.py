@@ -195,3 +195,35 @@ def test_pairs_sort_dev_orders_the_survivor_list(ctx):
         ga, gb = da.cpu().numpy().view(np.uint32), db.cpu().numpy().view(np.uint32)
         order = np.lexsort((b, a))
         assert np.array_equal(ga, a[order]) and np.array_equal(gb, b[order]), (n, bound)
+
+
+def test_two_queries_per_register_equals_one(ctx, monkeypatch):
+    """k_mu_sw2 (dense forward pass: rows of two queries of neighbouring length share a packed register) against k_mu_sw
+    (RSK_MUSW_QUERY_PAIRS=0) and the oracle: odd query counts (a lone last query), lengths across every class boundary of
+    the pair kernel (208 / 512 / 1024 residues) and beyond it (k_mu_sw takes those), self triangle, rectangle with unsorted
+    targets, reversed queries, saturated and empty-ish chains."""
+    rng = np.random.default_rng(31)
+    lens = [1, 2, 15, 16, 17, 100, 207, 208, 209, 300, 511, 512, 513, 800, 1023, 1024, 1025, 1400, 2048]
+    seqs = [rng.integers(0, 36, L).astype(np.uint8) for L in lens]
+    seqs += [rng.integers(0, 3, L).astype(np.uint8) for L in (33, 260, 900)]          # low complexity: saturation
+    seqs = [seqs[i] for i in rng.permutation(len(seqs))]
+    assert len(seqs) % 2 == 0
+    seqs.append(rng.integers(0, 36, 77).astype(np.uint8))                             # odd count
+    ts = [rng.integers(0, 36, int(L)).astype(np.uint8) for L in rng.integers(3, 700, 41)]
+    two = (run_sw_matrix(ctx, seqs, tri=True), run_sw_matrix(ctx, seqs, tri=True, reverse=True), run_sw_matrix(ctx, seqs, ts),
+           run_sw_matrix(ctx, seqs, ts, reverse=True))
+    monkeypatch.setenv("RSK_MUSW_QUERY_PAIRS", "0")
+    one = (run_sw_matrix(ctx, seqs, tri=True), run_sw_matrix(ctx, seqs, tri=True, reverse=True), run_sw_matrix(ctx, seqs, ts),
+           run_sw_matrix(ctx, seqs, ts, reverse=True))
+    monkeypatch.delenv("RSK_MUSW_QUERY_PAIRS")
+    n = len(seqs)
+    iu = np.triu_indices(n)
+    for k in range(2):
+        assert np.array_equal(two[k][iu], one[k][iu])
+    for k in (2, 3):
+        assert np.array_equal(two[k], one[k])
+    for i in range(n):
+        for j in range(0, len(ts), 5):
+            assert two[2][i, j] == ol.mu_sw(seqs[i], ts[j])[0]
+        for j in range(i, n, 3):
+            assert two[0][i, j] == ol.mu_sw(seqs[i], seqs[j])[0]
