@@ -92,7 +92,7 @@ def main():
     ndb = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     threads = int(sys.argv[4]) if len(sys.argv) > 4 else 1
     res = compare(n, mode, ndb, threads, seed=int(os.environ.get("RSK_COMPARE_SEED", "21")), keep=os.environ.get("RSK_COMPARE_KEEP"),
-                  long_chains=int(os.environ.get("RSK_COMPARE_LONG", "0")))
+                  long_chains=int(os.environ.get("RSK_COMPARE_LONG", "0")), tail=os.environ.get("RSK_COMPARE_TAIL", "0") == "1")
     print(json.dumps(res, indent=1))
     if not res["identical"]:
         sys.exit(1)
