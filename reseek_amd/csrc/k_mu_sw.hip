@@ -945,6 +945,7 @@ extern "C" int rsk_mu_filter_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t,
     RSK_HIP(hipStreamSynchronize(ctx->stream));
     ctx->mf_pairs = total;
     ctx->mf_candidates = ncand;
+    if (getenv("RSK_TRACE")) fprintf(stderr, "[rsk_mu_filter_dev] %llu pairs, %u candidates for the reverse pass (%.1f %%)\n", (unsigned long long) total, ncand, 100.0 * ncand / (double) std::max<uint64_t>(total, 1));
     if (ncand) {
         int16_t *thr = nullptr;
         const bool early = !(getenv("RSK_MUSW_EARLY_EXIT") && atoi(getenv("RSK_MUSW_EARLY_EXIT")) == 0);
