@@ -42,6 +42,10 @@ extern "C" {
 typedef struct rsk_ctx rsk_ctx;   /* one per process/GPU: device, stream, scratch */
 typedef struct rsk_db rsk_db;     /* a chain set resident in HBM as SoA */
 
+/* Bumped whenever a struct layout or a signature of this header changes (INTEGRATION.md lists the breaks):
+ * 4 = rsk_search_opts leads with struct_size; rsk_shutdown added. */
+#define RSK_ABI_VERSION 4
+int rsk_abi_version(void);        /* the RSK_ABI_VERSION the library was built with */
 const char *rsk_version(void);
 const char *rsk_last_error(void);
 
@@ -55,6 +59,10 @@ int rsk_ctx_sync(rsk_ctx *ctx);
 /* Device scratch is cached: per context in an allocator pool, and the search drivers keep their helper contexts (own
  * streams, own pools) idle per device between calls.  rsk_ctx_trim returns all of that to the device (hipFree). */
 void rsk_ctx_trim(rsk_ctx *ctx);
+/* Destroys every parked helper context of every device (their streams and pools).  Optional: call it before the process
+ * unloads the HIP runtime if the device memory must be returned earlier than process exit; the library itself makes no
+ * HIP call from a static destructor. */
+void rsk_shutdown(void);
 /* Average duration (ms) of the device work enqueued by the last compute call, measured with HIP
  * events on the context stream; < 0 if none. */
 float rsk_ctx_last_kernel_ms(rsk_ctx *ctx);
@@ -336,6 +344,9 @@ int rsk_search_rskdb(rsk_ctx *ctx, const char *query_rskdb, const char *db_rskdb
  * (myutils options of search.cpp / dssparams.cpp / dbsearcher.cpp / muprefilter.cpp / postmufilter.cpp).
  * Zero-initialise, set `mode`; fields left 0/NULL mean "option not given". */
 typedef struct rsk_search_opts {
+    uint32_t struct_size;      /* = sizeof(rsk_search_opts) of the header the CALLER was built with (required, first member  */
+                               /* since ABI 4): the library reads no member beyond it, so a caller built against an older    */
+                               /* header keeps working when members are appended; 0 or a size that cuts `mode` is rejected.  */
     const char *mode;          /* "fast" | "sensitive" | "verysensitive" */
     const char *columns;       /* -columns */
     double evalue;             /* -evalue; used when evalue_set != 0 */

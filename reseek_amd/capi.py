@@ -26,6 +26,8 @@ SIGNATURES = {
     "rsk_ctx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rsk_ctx_sync": (C.c_int, [C.c_void_p]),
     "rsk_ctx_trim": (None, [C.c_void_p]),
+    "rsk_shutdown": (None, []),
+    "rsk_abi_version": (C.c_int, []),
     "rsk_ctx_last_kernel_ms": (C.c_float, [C.c_void_p]),
     "rsk_db_create": (C.c_int, [C.c_void_p, C.c_uint32, u32p, u8p, u8p, f32p, f32p, f32p, f32p, C.POINTER(C.c_void_p)]),
     "rsk_db_destroy": (None, [C.c_void_p]),
@@ -103,7 +105,7 @@ GAP_EXT = -0.051881      # namedparams.cpp:46
 
 
 class SearchOpts(C.Structure):
-    _fields_ = [("mode", C.c_char_p), ("columns", C.c_char_p), ("evalue", C.c_double), ("evalue_set", C.c_int),
+    _fields_ = [("struct_size", C.c_uint32), ("mode", C.c_char_p), ("columns", C.c_char_p), ("evalue", C.c_double), ("evalue_set", C.c_int),
                 ("mints", C.c_double), ("mints_set", C.c_int), ("pvalue", C.c_double), ("pvalue_set", C.c_int),
                 ("noself", C.c_int), ("selfrev0", C.c_int), ("idx_mode", C.c_int), ("rsb_size", C.c_uint32),
                 ("dbmu", C.c_char_p), ("keeptmp", C.c_int), ("shard_index", C.c_uint32), ("shard_count", C.c_uint32),
@@ -257,6 +259,7 @@ class Ctx:
     @staticmethod
     def _opts(mode, kw):
         o = SearchOpts()
+        o.struct_size = C.sizeof(SearchOpts)
         o.mode = mode.encode()
         for k, v in kw.items():
             if k in ("columns", "dbmu", "devices"):

@@ -521,11 +521,9 @@ struct SecondaryCtx {
     struct IdleHolder {
         std::vector<Idle> v;
         IdleHolder() { rsk_set_oom_hook(&SecondaryCtx::Trim); }
-        ~IdleHolder()
-        {
-            rsk_set_oom_hook(nullptr);
-            for (Idle &i : v) { rsk_ctx_destroy(i.c); if (i.st) (void) hipStreamDestroy(i.st); }
-        }
+        // Static destruction runs in an unspecified order relative to the HIP runtime's own teardown: no HIP call here.
+        // The driver reclaims the parked contexts with the process; rsk_ctx_trim(ctx) / rsk_shutdown() release them earlier.
+        ~IdleHolder() { rsk_set_oom_hook(nullptr); }
     };
     static std::vector<Idle> &IdleList() { static IdleHolder h; return h.v; }
     void Create(int dev, const char *Role)
@@ -538,9 +536,9 @@ struct SecondaryCtx {
             for (size_t k = 0; k < v.size(); ++k)
                 if (v[k].device == dev && strcmp(v[k].role, Role) == 0) { c = v[k].c; st = v[k].st; v.erase(v.begin() + k); return; }
         }
+        rsk_device_guard on(dev);                                       // the calling thread keeps ITS current device (a stream belongs to the device current at creation)
         check(rsk_ctx_create(dev, &c), "rsk_ctx_create");
         if (!(getenv("RSK_OWN_STREAMS") && atoi(getenv("RSK_OWN_STREAMS")) == 0)) {
-            (void) hipSetDevice(dev);                                   // a stream belongs to the calling thread's current device
             if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { st = nullptr; return; }
             rsk_ctx_set_stream(c, (void *) st);
         }
@@ -1633,6 +1631,36 @@ static bool parse_mode(const char *mode, SearchOptions &o)
 
 void rsk_set_error(const char *fmt, ...);
 namespace reseek_amd {
+// rsk_search_opts -> SearchOptions.  Reads no member beyond opts->struct_size (members appended to the struct by later
+// headers read as "not given" for a caller built with an older one).
+int ParseSearchOpts(const rsk_search_opts *opts, SearchOptions &o, const char *who)
+{
+    const size_t have = opts->struct_size;
+#define RSK_OPT_HAS(f) (have >= offsetof(rsk_search_opts, f) + sizeof(opts->f))
+    if (!RSK_OPT_HAS(mode) || have > 4096) {
+        rsk_set_error("%s: opts.struct_size = %zu; set it to sizeof(rsk_search_opts) (first member since ABI 4)", who, have);
+        return RSK_E_INVALID;
+    }
+    if (!parse_mode(opts->mode, o)) { rsk_set_error("%s: mode must be fast, sensitive or verysensitive", who); return RSK_E_INVALID; }
+    if (RSK_OPT_HAS(columns) && opts->columns) o.columns = opts->columns;
+    if (RSK_OPT_HAS(evalue_set) && opts->evalue_set) { o.evalue_set = true; o.evalue = opts->evalue; }
+    if (RSK_OPT_HAS(mints_set) && opts->mints_set) { o.mints_set = true; o.mints = opts->mints; }
+    if (RSK_OPT_HAS(pvalue_set) && opts->pvalue_set) { o.pvalue_set = true; o.pvalue = opts->pvalue; }
+    if (RSK_OPT_HAS(noself)) o.noself = opts->noself != 0;
+    if (RSK_OPT_HAS(selfrev0)) o.selfrev0 = opts->selfrev0 != 0;
+    if (RSK_OPT_HAS(idx_mode)) {
+        if (opts->idx_mode < 0 || opts->idx_mode > 2) { rsk_set_error("%s: idx_mode must be 0, 1 or 2", who); return RSK_E_INVALID; }
+        o.idx_mode = opts->idx_mode == 0 ? -1 : opts->idx_mode;
+    }
+    if (RSK_OPT_HAS(rsb_size) && opts->rsb_size) o.rsb_size = opts->rsb_size;
+    if (RSK_OPT_HAS(dbmu) && opts->dbmu) o.dbmu = opts->dbmu;
+    if (RSK_OPT_HAS(keeptmp)) o.keeptmp = opts->keeptmp != 0;
+    if (RSK_OPT_HAS(shard_index)) o.shard_index = opts->shard_index;
+    if (RSK_OPT_HAS(shard_count)) o.shard_count = opts->shard_count;
+    if (RSK_OPT_HAS(devices) && opts->devices) o.devices = opts->devices;
+#undef RSK_OPT_HAS
+    return RSK_OK;
+}
 void FastDbOnContexts(const std::vector<rsk_ctx *> &Ctx, const char *query_path, const char *db_path, const SearchOptions &o, const char *out_tsv,
                       const char *tmp_tsv, uint64_t *nhits, uint64_t *stats8);
 }
@@ -1771,20 +1799,11 @@ extern "C" int rsk_search(rsk_ctx *ctx, const char *query_path, const char *db_p
 {
     if (!ctx || !query_path || !out_tsv || !opts) { rsk_set_error("rsk_search: NULL argument"); return RSK_E_INVALID; }
     SearchOptions o;
-    if (!parse_mode(opts->mode, o)) { rsk_set_error("rsk_search: mode must be fast, sensitive or verysensitive"); return RSK_E_INVALID; }
-    if (opts->columns) o.columns = opts->columns;
-    if (opts->evalue_set) { o.evalue_set = true; o.evalue = opts->evalue; }
-    if (opts->mints_set) { o.mints_set = true; o.mints = opts->mints; }
-    if (opts->pvalue_set) { o.pvalue_set = true; o.pvalue = opts->pvalue; }
-    o.noself = opts->noself != 0;
-    o.selfrev0 = opts->selfrev0 != 0;
-    if (opts->idx_mode < 0 || opts->idx_mode > 2) { rsk_set_error("rsk_search: idx_mode must be 0, 1 or 2"); return RSK_E_INVALID; }
-    o.idx_mode = opts->idx_mode == 0 ? -1 : opts->idx_mode;
-    if (opts->rsb_size) o.rsb_size = opts->rsb_size;
-    if (opts->dbmu) o.dbmu = opts->dbmu;
-    o.keeptmp = opts->keeptmp != 0;
-    o.shard_index = opts->shard_index;
-    o.shard_count = opts->shard_count;
-    if (opts->devices) o.devices = opts->devices;
+    const int rc = reseek_amd::ParseSearchOpts(opts, o, "rsk_search");
+    if (rc != RSK_OK) return rc;
     return search_impl(ctx, query_path, db_path, o, out_tsv, nhits, stats8);
 }
+
+extern "C" int rsk_abi_version(void) { return RSK_ABI_VERSION; }
+
+extern "C" void rsk_shutdown(void) { reseek_amd::SecondaryCtx::Trim(-1); }

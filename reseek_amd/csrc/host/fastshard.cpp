@@ -88,24 +88,7 @@ struct rsk_fast_shard {
     std::vector<uint32_t> aq, at, as;                      // every triple of the shard (the exact exchange)
 };
 
-static bool parse_opts(const rsk_search_opts *opts, SearchOptions &o)
-{
-    const std::string m = opts->mode ? opts->mode : "";
-    if (m != "fast") return false;
-    o.mode = AM_Fast;
-    if (opts->columns) o.columns = opts->columns;
-    if (opts->evalue_set) { o.evalue_set = true; o.evalue = opts->evalue; }
-    if (opts->mints_set) { o.mints_set = true; o.mints = opts->mints; }
-    if (opts->pvalue_set) { o.pvalue_set = true; o.pvalue = opts->pvalue; }
-    o.noself = opts->noself != 0;
-    o.selfrev0 = opts->selfrev0 != 0;
-    o.idx_mode = opts->idx_mode == 0 ? -1 : opts->idx_mode;
-    if (opts->rsb_size) o.rsb_size = opts->rsb_size;
-    if (opts->dbmu) o.dbmu = opts->dbmu;
-    o.shard_index = opts->shard_index;
-    o.shard_count = opts->shard_count ? opts->shard_count : 1;
-    return true;
-}
+namespace reseek_amd { int ParseSearchOpts(const rsk_search_opts *opts, SearchOptions &o, const char *who); }
 
 // stage 1 of one shard (throws): S->o holds the options incl. shard_index / shard_count
 static void FastShardOpen(rsk_fast_shard *S, rsk_ctx *ctx, const char *query_path, const char *db_path)
@@ -181,9 +164,10 @@ extern "C" int rsk_fast_shard_open(rsk_ctx *ctx, const char *query_path, const c
     if (!ctx || !query_path || !db_path || !opts || !out) { rsk_set_error("rsk_fast_shard_open: NULL argument"); return RSK_E_INVALID; }
     *out = nullptr;
     std::unique_ptr<rsk_fast_shard> S(new rsk_fast_shard);
-    if (!parse_opts(opts, S->o)) { rsk_set_error("rsk_fast_shard_open: mode must be \"fast\" (the other modes shard through rsk_search)"); return RSK_E_INVALID; }
+    { const int rc = reseek_amd::ParseSearchOpts(opts, S->o, "rsk_fast_shard_open"); if (rc != RSK_OK) return rc; }
+    if (S->o.mode != AM_Fast) { rsk_set_error("rsk_fast_shard_open: mode must be \"fast\" (the other modes shard through rsk_search)"); return RSK_E_INVALID; }
+    if (!S->o.shard_count) S->o.shard_count = 1;
     if (S->o.shard_index >= S->o.shard_count) { rsk_set_error("rsk_fast_shard_open: shard_index >= shard_count"); return RSK_E_INVALID; }
-    if (opts->idx_mode < 0 || opts->idx_mode > 2) { rsk_set_error("rsk_fast_shard_open: idx_mode must be 0, 1 or 2"); return RSK_E_INVALID; }
     try {
         FastShardOpen(S.get(), ctx, query_path, db_path);
     } catch (const std::exception &e) {

@@ -124,7 +124,7 @@ int rsk_build_rings(rsk_db *db)
     auto up = [&](void **d, const void *h, size_t bytes) -> int {
         *d = nullptr;
         if (!bytes) return RSK_OK;
-        { const int rc_ = rsk_dev_malloc(nullptr, d, bytes); if (rc_ != RSK_OK) return rc_; }
+        { const int rc_ = rsk_db_malloc(db, nullptr, d, bytes); if (rc_ != RSK_OK) return rc_; }
         RSK_HIP(hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice));
         db->hbm_bytes += bytes;
         return RSK_OK;
@@ -492,7 +492,7 @@ static int build_claim_order(const rsk_db *db, const uint32_t *perm, uint32_t **
             return db->len[perm ? perm[x] : x] > db->len[perm ? perm[y] : y];
         });
     }
-    { const int rc_ = rsk_dev_malloc(nullptr, (void **) d_out, std::max<size_t>(db->n, 1) * 4); if (rc_ != RSK_OK) return rc_; }
+    { const int rc_ = rsk_db_malloc(db, nullptr, (void **) d_out, std::max<size_t>(db->n, 1) * 4); if (rc_ != RSK_OK) return rc_; }
     RSK_HIP(hipMemcpy(*d_out, claim.data(), (size_t) db->n * 4, hipMemcpyHostToDevice));
     return RSK_OK;
 }
@@ -569,7 +569,7 @@ int rsk_launch_gapless_rings(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int
         if (qm->d_work) (void) hipFree(qm->d_work);
         qm->d_work = nullptr;
         if (!all.empty()) {
-            { const int rc_ = rsk_dev_malloc(nullptr, (void **) &qm->d_work, all.size() * sizeof(uint2)); if (rc_ != RSK_OK) return rc_; }
+            { const int rc_ = rsk_db_malloc(qm, ctx, (void **) &qm->d_work, all.size() * sizeof(uint2)); if (rc_ != RSK_OK) return rc_; }
             RSK_HIP(hipMemcpy(qm->d_work, all.data(), all.size() * sizeof(uint2), hipMemcpyHostToDevice));
         }
         // queries too long for a ring: (long query, target) pairs of the per-pair kernel, part of the same cache
@@ -589,8 +589,8 @@ int rsk_launch_gapless_rings(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int
                 ++pos;
             }
             if (!iq.empty()) {
-                { const int rc_ = rsk_dev_malloc(nullptr, (void **) &qm->d_long_iq, iq.size() * 4); if (rc_ != RSK_OK) return rc_; }
-                { const int rc_ = rsk_dev_malloc(nullptr, (void **) &qm->d_long_it, it.size() * 4); if (rc_ != RSK_OK) return rc_; }
+                { const int rc_ = rsk_db_malloc(qm, ctx, (void **) &qm->d_long_iq, iq.size() * 4); if (rc_ != RSK_OK) return rc_; }
+                { const int rc_ = rsk_db_malloc(qm, ctx, (void **) &qm->d_long_it, it.size() * 4); if (rc_ != RSK_OK) return rc_; }
                 RSK_HIP(hipMemcpy(qm->d_long_iq, iq.data(), iq.size() * 4, hipMemcpyHostToDevice));
                 RSK_HIP(hipMemcpy(qm->d_long_it, it.data(), it.size() * 4, hipMemcpyHostToDevice));
                 qm->long_pairs = (uint32_t) iq.size();

@@ -856,8 +856,8 @@ int rsk_build_len_perm(rsk_db *db)
     for (uint32_t i = 0; i < db->n; ++i) perm[i] = i;
     std::stable_sort(perm.begin(), perm.end(), [&](uint32_t x, uint32_t y) { return db->len[x] < db->len[y]; });
     for (uint32_t k = 0; k < db->n; ++k) rank[perm[k]] = k;
-    { const int rc_ = rsk_dev_malloc(nullptr, (void **) &db->d_len_perm, std::max<size_t>(db->n, 1) * 4); if (rc_ != RSK_OK) return rc_; }
-    { const int rc_ = rsk_dev_malloc(nullptr, (void **) &db->d_len_rank, std::max<size_t>(db->n, 1) * 4); if (rc_ != RSK_OK) return rc_; }
+    { const int rc_ = rsk_db_malloc(db, nullptr, (void **) &db->d_len_perm, std::max<size_t>(db->n, 1) * 4); if (rc_ != RSK_OK) return rc_; }
+    { const int rc_ = rsk_db_malloc(db, nullptr, (void **) &db->d_len_rank, std::max<size_t>(db->n, 1) * 4); if (rc_ != RSK_OK) return rc_; }
     RSK_HIP(hipMemcpy(db->d_len_perm, perm.data(), (size_t) db->n * 4, hipMemcpyHostToDevice));
     RSK_HIP(hipMemcpy(db->d_len_rank, rank.data(), (size_t) db->n * 4, hipMemcpyHostToDevice));
     db->hbm_bytes += (uint64_t) db->n * 8;

@@ -89,6 +89,13 @@ int rsk_dev_malloc(rsk_ctx *ctx, void **p, size_t bytes)
     return RSK_E_NOMEM;
 }
 
+int rsk_db_malloc(const rsk_db *db, rsk_ctx *caller, void **p, size_t bytes)
+{
+    const int dev = db && db->ctx ? db->ctx->device : 0;
+    rsk_device_guard on(dev);
+    return rsk_dev_malloc(caller && caller->device == dev ? caller : nullptr, p, bytes);
+}
+
 int rsk_pool_alloc(rsk_ctx *ctx, void **p, size_t bytes)
 {
     size_t cls = 256;
@@ -373,7 +380,7 @@ extern "C" int rsk_db_set_seq(rsk_db *db, const char *seq)
     uint64_t src = 0;
     for (uint32_t i = 0; i < db->n; ++i) { memcpy(&h[db->off[i]], seq + src, db->len[i]); src += db->len[i]; }
     if (!db->d_seq) {
-        const int rc = rsk_dev_malloc(nullptr, (void **) &db->d_seq, h.size());
+        const int rc = rsk_db_malloc(db, nullptr, (void **) &db->d_seq, h.size());
         if (rc != RSK_OK) return rc;
         db->hbm_bytes += h.size();
     }

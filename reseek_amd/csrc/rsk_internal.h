@@ -82,6 +82,23 @@ int rsk_pool_alloc(rsk_ctx *ctx, void **p, size_t bytes);
 // SecondaryCtx) -- and the allocation is tried again after each step.  Sets the error text and returns RSK_E_NOMEM.
 int rsk_dev_malloc(rsk_ctx *ctx, void **p, size_t bytes);
 void rsk_set_oom_hook(void (*release_idle)(int device));
+// Makes `device` current for the calling thread and puts the previous one back on scope exit: library code that must
+// allocate on a particular device (a chain set's arrays, a helper context) does not leave the caller's thread on it.
+struct rsk_device_guard {
+    int prev = -1, cur = -1;
+    explicit rsk_device_guard(int device) : cur(device)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) (void) hipSetDevice(device);
+    }
+    rsk_device_guard(const rsk_device_guard &) = delete;
+    rsk_device_guard &operator=(const rsk_device_guard &) = delete;
+    ~rsk_device_guard() { if (prev >= 0 && prev != cur) (void) hipSetDevice(prev); }
+};
+// An array that belongs to a chain set (lazily built caches, rsk_db_set_seq): allocated on the SET's device whatever the
+// calling thread's current device is (the kernels that read it run on db->ctx->device), through the same OOM ladder.
+// `caller` = the context of the calling thread when it is on that device (its pool may be released), else NULL.
+int rsk_db_malloc(const struct rsk_db *db, rsk_ctx *caller, void **p, size_t bytes);
 // Waits for the context's stream without spinning: the long waits (tens of ms of kernels) of several host threads would
 // otherwise each burn a core of a CPU-quota'd container.
 int rsk_stream_wait(rsk_ctx *ctx);
