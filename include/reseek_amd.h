@@ -282,6 +282,14 @@ int rsk_mu_prefilter_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int nei
 int rsk_rsb_select(const uint32_t *q, const uint32_t *t, const uint32_t *score, size_t n, uint32_t nqueries,
                    uint32_t rsb_size, uint32_t *out_q, uint32_t *out_t, uint32_t *out_score, size_t *nout,
                    const char *tmp_tsv_path);
+/* The same selection from the device-sorted form of the triples: rsk_triples_sort_dev packs the three device columns of
+ * rsk_mu_prefilter_dev into keys query << 48 | target << 16 | score and sorts them ascending on the device (d_keys: n
+ * uint64) = grouped by query, targets ascending -- the arrival order of RankedScoresBag::AddScore with -threads 1
+ * (muprefilter.cpp:21-60); rsk_rsb_select_keys replays the bags from the host copy of those keys (one linear pass per query on
+ * the host threads; no grouping or sorting on the host).  Needs query < 65536 (as the prefilter does) and score < 65536. */
+int rsk_triples_sort_dev(rsk_ctx *ctx, const uint32_t *d_q, const uint32_t *d_t, const uint32_t *d_score, size_t n, uint64_t *d_keys);
+int rsk_rsb_select_keys(const uint64_t *keys, size_t n, uint32_t nqueries, uint32_t rsb_size, uint32_t *out_q, uint32_t *out_t,
+                        uint32_t *out_score, size_t *nout, const char *tmp_tsv_path);
 
 /* ---- (f) rows 1-2: per-chain featurisation and the .bca container (host code, no GPU needed) --------
  * rsk_dss_featurize: DSS::GetProfile (dss.cpp:716: AA, NENDist, Conf, NENConf, RENDist, DstNxtHlx, StrandDens,

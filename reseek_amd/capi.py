@@ -47,6 +47,9 @@ SIGNATURES = {
                                     C.c_void_p]),
     "rsk_mu_filter_last_work": (C.c_int, [C.c_void_p, u64p, u64p]),
     "rsk_pairs_sort_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32]),
+    "rsk_triples_sort_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rsk_rsb_select_keys": (C.c_int, [C.POINTER(C.c_uint64), C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                      C.POINTER(C.c_uint32), C.POINTER(C.c_size_t), C.c_char_p]),
 }
 
 
@@ -220,6 +223,10 @@ class Ctx:
     def pairs_sort_dev(self, d_major, d_minor, n, major_bound=0):
         """sorts the device pair list (two uint32 columns, device pointers) by (major, minor) in place"""
         _check(lib().rsk_pairs_sort_dev(self.h, C.c_void_p(d_major), C.c_void_p(d_minor), n, major_bound))
+
+    def triples_sort_dev(self, d_q, d_t, d_score, n, d_keys):
+        """prefilter triples (three uint32 device columns) -> n ascending uint64 keys query << 48 | target << 16 | score"""
+        _check(lib().rsk_triples_sort_dev(self.h, C.c_void_p(d_q), C.c_void_p(d_t), C.c_void_p(d_score), n, C.c_void_p(d_keys)))
 
     def mu_filter_last_work(self):
         a, b = C.c_uint64(), C.c_uint64()
@@ -507,6 +514,18 @@ class Db:
         if self.h:
             lib().rsk_db_destroy(self.h)
             self.h = None
+
+
+def rsb_select_keys(keys, nqueries, rsb_size=1500, tmp_tsv_path=None):
+    """rsk_rsb_select_keys: keys = query << 48 | target << 16 | score, ascending (rsk_triples_sort_dev) -> (q, t, score) kept"""
+    keys = np.ascontiguousarray(keys, np.uint64)
+    n = len(keys)
+    oq, ot, os_ = (np.zeros(max(n, 1), np.uint32) for _ in range(3))
+    nout = C.c_size_t()
+    _check(lib().rsk_rsb_select_keys(keys.ctypes.data_as(C.POINTER(C.c_uint64)), n, nqueries, rsb_size, _p(oq, u32p), _p(ot, u32p),
+                                     _p(os_, u32p), C.byref(nout), tmp_tsv_path.encode() if tmp_tsv_path else None))
+    m = nout.value
+    return oq[:m], ot[:m], os_[:m]
 
 
 def rsb_select(q, t, score, nqueries, rsb_size=1500, tmp_tsv_path=None):

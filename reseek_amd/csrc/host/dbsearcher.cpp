@@ -1208,6 +1208,44 @@ static void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOff
     tm.lap("MKF (GPU seeds + host)");
 }
 
+uint64_t RunMKFPairsBeside(rsk_ctx *Ctx, const DSSParams &Params, const std::string &Columns, DBSearcher &SrcA, DBSearcher &SrcB,
+                           const std::vector<std::pair<uint32_t, uint32_t> > &Pairs, const std::function<void()> &AlignJob,
+                           const std::function<bool(const DSSAligner &)> &Keep, bool Up, FILE *fTsv)
+{
+    struct sink { std::string lines; uint64_t hits = 0; char pad[64]; };
+    std::vector<sink> sinks(HostThreads(128));
+    const std::function<void(DSSAligner &, uint, uint, unsigned)> on_hit = [&](DSSAligner &DA, uint, uint, unsigned worker) {
+        if (!Keep(DA)) return;
+        sink &me = sinks[worker];
+        ++me.hits;
+        if (fTsv) DA.AppendTsv(me.lines, Up);
+    };
+    const bool beside = !Pairs.empty() && !(getenv("RSK_MKF_OVERLAP") && atoi(getenv("RSK_MKF_OVERLAP")) == 0);
+    if (beside) {
+        SecondaryCtx own;
+        own.Create(Ctx->device, "mkf");
+        std::future<void> job = std::async(std::launch::async, [&]() {
+            RunMKFPairs(own.c, Params, Columns, SrcA, SrcB, Pairs, [](DSSAligner &, uint, uint) {}, &on_hit);
+        });
+        try {
+            AlignJob();
+        } catch (...) {
+            job.wait();
+            throw;
+        }
+        job.get();
+    } else {
+        AlignJob();
+        RunMKFPairs(Ctx, Params, Columns, SrcA, SrcB, Pairs, [](DSSAligner &, uint, uint) {}, &on_hit);
+    }
+    uint64_t hits = 0;
+    for (sink &me : sinks) {
+        hits += me.hits;
+        if (fTsv && !me.lines.empty() && fwrite(me.lines.data(), 1, me.lines.size(), fTsv) != me.lines.size()) throw std::runtime_error("short write to the hits file");
+    }
+    return hits;
+}
+
 // Largest dense pair block one Mu-filter pass may cover: the forward-score matrix is one byte per pair in HBM and the
 // survivor counter is 32 bits.  RSK_FILTER_TILE_PAIRS lowers it (tests).
 static uint64_t FilterTilePairs()
@@ -1712,10 +1750,13 @@ static int search_impl(rsk_ctx *ctx, const char *query_rskdb, const char *db_rsk
             Src.m_Opts = o;
             Src.m_Ctx = ctx;
             Src.LoadDB(db_rskdb);
+            // the candidates go from stage to stage in memory, in the hand-off file's order; the file itself
+            // (rankedscoresbag.cpp:185-231) is written for -keeptmp only
             const std::string tmp = std::string(out_tsv) + ".prefilter.tmp";
-            MuPreFilter(Params, DBS, Src, tmp);
-            PostMuFilter(Params2, tmp, DBS, Src, out_tsv);
-            if (!o.keeptmp && !keep_tmp_env()) remove(tmp.c_str());
+            std::vector<uint32_t> pq, pt;
+            MuPreFilterToPairs(DBS, Src, pq, pt, o.keeptmp || keep_tmp_env() ? tmp : std::string());
+            if (pq.empty()) fprintf(stderr, "Warning: No hits found by mufilter pass\n");      // postmufilter.cpp:219-223 (no hits file)
+            else PostMuFilterPairs(Params2, DBS, Src, pq, pt, out_tsv);
             if (nhits) *nhits = DBS.m_HitCount;
             if (stats8) {
                 stats8[0] = DBS.m_ProcessedPairCount; stats8[1] = DBS.m_ProcessedPairCount - DBS.m_MKFPairCount; stats8[2] = DBS.m_MuFilterInputCount;

@@ -19,6 +19,7 @@
 #include <thread>
 
 #include "reseek_host.h"
+#include "../rsk_internal.h"
 
 namespace reseek_amd {
 
@@ -30,9 +31,15 @@ static void check(int rc, const char *what)
 void MuPreFilterLetters(rsk_ctx *ctx, const std::vector<uint32_t> &qlen, const std::vector<uint8_t> &qmu, rsk_db *tdb, uint NT, int idx_mode,
                         uint rsb_size, const std::string &OutputFN);
 
-void MuPreFilter(const DSSParams &Params, DBSearcher &QDB, DBSearcher &TDB, const std::string &OutputFN)
+int ReplaySortedKeys(RankedScoresBag &RSB, const uint64_t *keys, size_t n, uint32_t nqueries, uint32_t rsb_size);     // prefilter.cpp
+void MuPreFilterBags(rsk_ctx *ctx, const std::vector<uint32_t> &qlen, const std::vector<uint8_t> &qmu, rsk_db *tdb, uint NT, int idx_mode,
+                     uint rsb_size, RankedScoresBag &RSB);
+
+// MuPreFilter (muprefilter.cpp:70) up to the filled bags; OutputFN (may be empty) receives the hand-off file, pq / pt (may
+// be NULL) the candidate pairs in the file's order -- the single-process search hands them to PostMuFilterPairs in memory
+// and writes the file only for -keeptmp.
+static void MuPreFilterImpl(DBSearcher &QDB, DBSearcher &TDB, const std::string &OutputFN, std::vector<uint32_t> *pq, std::vector<uint32_t> *pt)
 {
-    (void) Params;
     rsk_ctx *ctx = QDB.m_Ctx;
     if (!ctx) throw std::runtime_error("MuPreFilter: no GPU context");
     TDB.m_Ctx = ctx;
@@ -69,7 +76,28 @@ void MuPreFilter(const DSSParams &Params, DBSearcher &QDB, DBSearcher &TDB, cons
     size_t qo = 0;
     for (uint i = 0; i < NQ; ++i)
         for (byte l : *QDB.m_DBMuLettersVec[i]) qmu[qo++] = l == 10 ? 11 : (l == 11 ? 10 : l);
-    MuPreFilterLetters(ctx, qlen, qmu, tdb, NT, QDB.m_Opts.idx_mode, QDB.m_Opts.rsb_size, OutputFN);
+    RankedScoresBag RSB;
+    MuPreFilterBags(ctx, qlen, qmu, tdb, NT, QDB.m_Opts.idx_mode, QDB.m_Opts.rsb_size, RSB);
+    PhaseTimer tm("MuPreFilter");
+    if (!OutputFN.empty()) {
+        FILE *f = fopen(OutputFN.c_str(), "w");
+        if (!f) throw std::runtime_error("MuPreFilter: cannot create " + OutputFN);
+        RSB.ToTsv(f);
+        fclose(f);
+        tm.lap("hand-off file");
+    }
+    if (pq && pt) { RSB.ToPairs(*pq, *pt); tm.lap("candidate pairs (memory)"); }
+}
+
+void MuPreFilter(const DSSParams &Params, DBSearcher &QDB, DBSearcher &TDB, const std::string &OutputFN)
+{
+    (void) Params;
+    MuPreFilterImpl(QDB, TDB, OutputFN, nullptr, nullptr);
+}
+
+void MuPreFilterToPairs(DBSearcher &QDB, DBSearcher &TDB, std::vector<uint32_t> &pq, std::vector<uint32_t> &pt, const std::string &KeepTmpFN)
+{
+    MuPreFilterImpl(QDB, TDB, KeepTmpFN, &pq, &pt);
 }
 
 // index of the query letters + scan of every target (muprefilter.cpp:90-126): (query, target, score) triples, unordered
@@ -104,18 +132,53 @@ void MuPreFilterScan(rsk_ctx *ctx, const std::vector<uint32_t> &qlen, const std:
     tm.lap("index + scan (GPU)");
 }
 
-// ... + per-query top-B + hand-off file (muprefilter.cpp:127-133)
+// scan, triples sorted on the device (query, then target = the arrival order of the reference's bags with -threads 1),
+// one download of the packed keys, bags replayed per query on the host threads (muprefilter.cpp:90-133)
+void MuPreFilterBags(rsk_ctx *ctx, const std::vector<uint32_t> &qlen, const std::vector<uint8_t> &qmu, rsk_db *tdb, uint NT, int idx_mode,
+                     uint rsb_size, RankedScoresBag &RSB)
+{
+    const uint NQ = (uint) qlen.size();
+    PhaseTimer tm("MuPreFilter");
+    rsk_db *qdb = nullptr;
+    check(rsk_db_create(ctx, NQ, qlen.data(), qmu.data(), nullptr, nullptr, nullptr, nullptr, nullptr, &qdb), "rsk_db_create");
+    struct db_guard { rsk_db *d; ~db_guard() { rsk_db_destroy(d); } } guard{ qdb };
+    auto hipok = [](hipError_t e, const char *w) { if (e != hipSuccess) throw std::runtime_error(std::string(w) + ": " + hipGetErrorString(e)); };
+    size_t cap = (size_t) std::min<uint64_t>((uint64_t) NQ * NT, 1ull << 28);      // every (query, target) can appear at most once
+    DeviceBuffer Count(ctx, 4, "prefilter result counter");
+    std::vector<uint64_t> keys;
+    for (;;) {
+        DeviceBuffer Q(ctx, cap * 4, "prefilter results"), T(ctx, cap * 4, "prefilter results"), S(ctx, cap * 4, "prefilter results");
+        check(rsk_mu_prefilter_dev(ctx, qdb, tdb, idx_mode, Q.As<uint32_t>(), T.As<uint32_t>(), S.As<uint32_t>(), cap, Count.As<uint32_t>()), "rsk_mu_prefilter_dev");
+        check(rsk_ctx_sync(ctx), "rsk_ctx_sync");
+        uint32_t n = 0;
+        hipok(hipMemcpy(&n, Count.As<uint32_t>(), 4, hipMemcpyDeviceToHost), "copy n");
+        if (n <= cap) {
+            tm.lap("index + scan (GPU)");
+            DeviceBuffer K(ctx, (size_t) std::max<uint32_t>(n, 1) * 8, "prefilter keys");
+            check(rsk_triples_sort_dev(ctx, Q.As<uint32_t>(), T.As<uint32_t>(), S.As<uint32_t>(), n, K.As<uint64_t>()), "rsk_triples_sort_dev");
+            keys.resize(n);
+            hipok(hipMemcpy(keys.data(), K.As<uint64_t>(), (size_t) n * 8, hipMemcpyDeviceToHost), "copy keys");
+            tm.lap("triples: device sort + d2h");
+            break;
+        }
+        cap = n;                               // the count is exact even when the list was truncated
+    }
+    if (ReplaySortedKeys(RSB, keys.data(), keys.size(), NQ, rsb_size) != RSK_OK) throw std::runtime_error(std::string("MuPreFilter: ") + rsk_last_error());
+    tm.lap("top-B bags (replay)");
+}
+
+// ... + hand-off file (muprefilter.cpp:127-133): the form compat.cpp's MuPreFilter(SeqDB &, MuSeqSource &) forwards to
 void MuPreFilterLetters(rsk_ctx *ctx, const std::vector<uint32_t> &qlen, const std::vector<uint8_t> &qmu, rsk_db *tdb, uint NT, int idx_mode,
                         uint rsb_size, const std::string &OutputFN)
 {
-    std::vector<uint32_t> hq, ht, hs;
-    MuPreFilterScan(ctx, qlen, qmu, tdb, NT, idx_mode, hq, ht, hs);
+    RankedScoresBag RSB;
+    MuPreFilterBags(ctx, qlen, qmu, tdb, NT, idx_mode, rsb_size, RSB);
     PhaseTimer tm("MuPreFilter");
-    size_t nout = 0;
-    check(rsk_rsb_select(hq.data(), ht.data(), hs.data(), hq.size(), (uint32_t) qlen.size(), rsb_size, nullptr, nullptr, nullptr, &nout,
-                         OutputFN.c_str()),
-          "rsk_rsb_select");
-    tm.lap("top-B bags + hand-off");
+    FILE *f = fopen(OutputFN.c_str(), "w");
+    if (!f) throw std::runtime_error("MuPreFilter: cannot create " + OutputFN);
+    RSB.ToTsv(f);
+    fclose(f);
+    tm.lap("hand-off file");
 }
 
 static bool Accept(const DSSAligner &DA, double MaxEvalue, double MaxPvalue, double MinTS)     // postmufilter.cpp:106-115
@@ -204,13 +267,29 @@ void PostMuFilterPairs(const DSSParams &Params, DBSearcher &Q, DBSearcher &DB, c
     DA.SetColumns(O.columns);
     DA.m_Ctx = ctx;
 
-    // DoMKF_Bags chainbag.cpp:6-21
+    // DoMKF_Bags chainbag.cpp:6-21: long-chain pairs leave the list (slices of the candidate list on the host threads,
+    // concatenated in order)
+    const uint NQc = Q.GetDBChainCount(), NTc = DB.GetDBChainCount();
+    std::vector<uint32_t> lenQ(NQc), lenT(NTc);
+    for (uint i = 0; i < NQc; ++i) lenQ[i] = Q.m_DBChains[i]->GetSeqLength();
+    for (uint j = 0; j < NTc; ++j) lenT[j] = DB.m_DBChains[j]->GetSeqLength();
     std::vector<uint32_t> fq, ft;
     std::vector<std::pair<uint32_t, uint32_t> > mkf;
-    for (size_t p = 0; p < pq.size(); ++p) {
-        const uint LA = Q.m_DBChains[pq[p]]->GetSeqLength(), LB = DB.m_DBChains[pt[p]]->GetSeqLength();
-        if (LA >= Params.m_MKFL || LB >= Params.m_MKFL) mkf.emplace_back(pq[p], pt[p]);
-        else { fq.push_back(pq[p]); ft.push_back(pt[p]); }
+    {
+        const size_t np = pq.size(), nsl = std::max<size_t>(1, std::min<size_t>(64, np / 65536 + 1));
+        std::vector<std::vector<uint32_t> > sq(nsl), st(nsl);
+        std::vector<std::vector<std::pair<uint32_t, uint32_t> > > sm(nsl);
+        rsk_parallel_for(nsl, 1, [&](size_t lo, size_t hi) {
+            for (size_t sl = lo; sl < hi; ++sl)
+                for (size_t p = np * sl / nsl, e = np * (sl + 1) / nsl; p < e; ++p) {
+                    if (lenQ[pq[p]] >= Params.m_MKFL || lenT[pt[p]] >= Params.m_MKFL) sm[sl].emplace_back(pq[p], pt[p]);
+                    else { sq[sl].push_back(pq[p]); st[sl].push_back(pt[p]); }
+                }
+        });
+        for (size_t sl = 0; sl < nsl; ++sl) {
+            fq.insert(fq.end(), sq[sl].begin(), sq[sl].end()); ft.insert(ft.end(), st[sl].begin(), st[sl].end());
+            mkf.insert(mkf.end(), sm[sl].begin(), sm[sl].end());
+        }
     }
     Q.m_MKFPairCount = mkf.size();
     Q.m_ProcessedPairCount = pq.size();
@@ -221,35 +300,36 @@ void PostMuFilterPairs(const DSSParams &Params, DBSearcher &Q, DBSearcher &DB, c
         check(rsk_mu_filter_pairs(ctx, Q.m_Db, DB.m_Db, fq.data(), ft.data(), fq.size(), Params.m_ParaMuGapOpen, Params.m_ParaMuGapExt,
                                   Params.m_Omega, Params.m_OmegaFwd, pass.data(), nullptr, nullptr),
               "rsk_mu_filter_pairs");
+        ia.reserve(fq.size() / 2); ib.reserve(fq.size() / 2);
         for (size_t p = 0; p < fq.size(); ++p)
             if (pass[p]) { ia.push_back(fq[p]); ib.push_back(ft[p]); }
         Q.m_MuFilterInputCount = fq.size();
         Q.m_MuFilterDiscardCount = fq.size() - ia.size();
     } else { ia.swap(fq); ib.swap(ft); }
     tm.lap("Mu filter (pair list)");
-    // SetSMx_NoRev + SWFast + CalcEvalue (chainbag.cpp:74-84) in batches
-    ForEachAlignedBatch(Params, ctx, O, Q, DB, ia, ib,
-                        [&](const std::vector<uint32_t> &bia, const std::vector<uint32_t> &bib, const std::vector<rsk_aln> &out, const char *paths) {
-        const size_t n = bia.size();
-        Q.m_SWCount += n;
-        for (size_t p = 0; p < n; ++p) {
-            // Accept (postmufilter.cpp:106-115) on the batch record: rejected pairs need no string work
-            if (!(out[p].evalue <= MaxEvalue || out[p].pvalue <= MaxPvalue || (out[p].evalue != FLT_MAX && out[p].ts >= MinTS))) continue;
-            const uint i = bia[p], j = bib[p];
-            DA.m_ChainA = Q.m_DBChains[i]; DA.m_ProfileA = Q.m_DBProfiles[i];
-            DA.m_ChainB = DB.m_DBChains[j]; DA.m_ProfileB = DB.m_DBProfiles[j];
-            DA.m_SelfRevScoreA = Q.m_DBSelfRevScores[i]; DA.m_SelfRevScoreB = DB.m_DBSelfRevScores[j];
-            DA.SetFromAln(out[p], paths + out[p].path_off);
-            if (Accept(DA, MaxEvalue, MaxPvalue, MinTS)) { DA.ToTsv(fTsv, true); ++Q.m_HitCount; }
-        }
-    });
-    tm.lap("align + replay");
-    // long chains: MKF (chainbag.cpp:58-65): seeding on the GPU, the rest on host threads
+    // SetSMx_NoRev + SWFast + CalcEvalue (chainbag.cpp:74-84) in batches; beside it, on a helper context, the long chains:
+    // MKF (chainbag.cpp:58-65)
     std::sort(mkf.begin(), mkf.end());
-    RunMKFPairs(ctx, Params, O.columns, Q, DB, mkf, [&](DSSAligner &TA, uint, uint) {
-        if (Accept(TA, MaxEvalue, MaxPvalue, MinTS)) { TA.ToTsv(fTsv, true); ++Q.m_HitCount; }
-    });
-    tm.lap("MKF");
+    auto align_job = [&]() {
+        ForEachAlignedBatch(Params, ctx, O, Q, DB, ia, ib,
+                            [&](const std::vector<uint32_t> &bia, const std::vector<uint32_t> &bib, const std::vector<rsk_aln> &out, const char *paths) {
+            const size_t n = bia.size();
+            Q.m_SWCount += n;
+            for (size_t p = 0; p < n; ++p) {
+                // Accept (postmufilter.cpp:106-115) on the batch record: rejected pairs need no string work
+                if (!(out[p].evalue <= MaxEvalue || out[p].pvalue <= MaxPvalue || (out[p].evalue != FLT_MAX && out[p].ts >= MinTS))) continue;
+                const uint i = bia[p], j = bib[p];
+                DA.m_ChainA = Q.m_DBChains[i]; DA.m_ProfileA = Q.m_DBProfiles[i];
+                DA.m_ChainB = DB.m_DBChains[j]; DA.m_ProfileB = DB.m_DBProfiles[j];
+                DA.m_SelfRevScoreA = Q.m_DBSelfRevScores[i]; DA.m_SelfRevScoreB = DB.m_DBSelfRevScores[j];
+                DA.SetFromAln(out[p], paths + out[p].path_off);
+                if (Accept(DA, MaxEvalue, MaxPvalue, MinTS)) { DA.ToTsv(fTsv, true); ++Q.m_HitCount; }
+            }
+        });
+    };
+    Q.m_HitCount += RunMKFPairsBeside(ctx, Params, O.columns, Q, DB, mkf, align_job,
+                                      [&](const DSSAligner &TA) { return Accept(TA, MaxEvalue, MaxPvalue, MinTS); }, true, fTsv);
+    tm.lap("align + replay | MKF side by side");
     fclose(fTsv);
 }
 

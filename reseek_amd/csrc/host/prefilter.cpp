@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "reseek_host.h"
+#include "../rsk_internal.h"
 
 void rsk_set_error(const char *fmt, ...);
 
@@ -71,30 +72,53 @@ void RankedScoresBag::Finish()
     for (uint q = 0; q < m_QueryCount; ++q) TruncateVecs(q);
 }
 
+// The selected candidates target-major: First[t] .. First[t + 1] = the queries (ascending) that kept target t.  This is the
+// order of the hand-off file (rankedscoresbag.cpp:185-231), hence of PostMuFilter's candidate pairs.
+void RankedScoresBag::GroupByTarget(std::vector<size_t> &First, std::vector<uint> &Queries, uint &TargetCount)
+{
+    Finish();
+    uint MaxT = 0;
+    size_t Total = 0;
+    for (uint q = 0; q < m_QueryCount; ++q)
+        for (uint t : m_QueryIdxToTargetIdxVec[q]) { MaxT = std::max(MaxT, t); ++Total; }
+    First.assign(Total ? (size_t) MaxT + 2 : 1, 0);
+    for (uint q = 0; q < m_QueryCount; ++q)
+        for (uint t : m_QueryIdxToTargetIdxVec[q]) ++First[(size_t) t + 1];
+    TargetCount = 0;
+    for (size_t t = 0; t + 1 < First.size(); ++t) { if (First[t + 1]) ++TargetCount; First[t + 1] += First[t]; }
+    Queries.resize(Total);
+    std::vector<size_t> Cur(First.begin(), First.end() - 1);
+    for (uint q = 0; q < m_QueryCount; ++q)                              // ascending q: every target's list comes out sorted
+        for (uint t : m_QueryIdxToTargetIdxVec[q]) Queries[Cur[t]++] = q;
+}
+
+// candidate pairs in hand-off order without the file (the single-process search hands them over in memory)
+void RankedScoresBag::ToPairs(std::vector<uint32_t> &pq, std::vector<uint32_t> &pt)
+{
+    std::vector<size_t> First;
+    std::vector<uint> Queries;
+    uint TargetCount = 0;
+    GroupByTarget(First, Queries, TargetCount);
+    pq.assign(Queries.begin(), Queries.end());
+    pt.resize(Queries.size());
+    rsk_parallel_for(First.size() - 1, 256, [&](size_t lo, size_t hi) {
+        for (size_t t = lo; t < hi; ++t)
+            for (size_t k = First[t]; k < First[t + 1]; ++k) pt[k] = (uint32_t) t;
+    });
+}
+
 // rankedscoresbag.cpp:185-231: "prefilter\t<#targets>", then one line per target (ascending) with its queries (ascending).
 // Same bytes as the reference's std::map + fprintf version, built with a counting sort and a hand-rolled integer
 // formatter (the map insertions and 15 M fprintf calls were 2 s of the SCOP40 x SCOP40 prefilter stage).
 void RankedScoresBag::ToTsv(FILE *f)
 {
     if (f == nullptr) return;
-    Finish();
-    uint MaxT = 0;
-    size_t Total = 0;
-    for (uint q = 0; q < m_QueryCount; ++q)
-        for (uint t : m_QueryIdxToTargetIdxVec[q]) { MaxT = std::max(MaxT, t); ++Total; }
-    std::vector<size_t> First((size_t) MaxT + 2, 0);
-    for (uint q = 0; q < m_QueryCount; ++q)
-        for (uint t : m_QueryIdxToTargetIdxVec[q]) ++First[(size_t) t + 1];
+    std::vector<size_t> First;
+    std::vector<uint> Queries;
     uint TargetCount = 0;
-    for (size_t t = 0; t <= MaxT; ++t) { if (Total && First[t + 1]) ++TargetCount; First[t + 1] += First[t]; }
-    std::vector<uint> Queries(Total);
-    {
-        std::vector<size_t> Cur(First.begin(), First.end() - 1);
-        for (uint q = 0; q < m_QueryCount; ++q)                          // ascending q: every target's list comes out sorted
-            for (uint t : m_QueryIdxToTargetIdxVec[q]) Queries[Cur[t]++] = q;
-    }
+    GroupByTarget(First, Queries, TargetCount);
     std::string Out;
-    Out.reserve(Total * 7 + (size_t) TargetCount * 16 + 64);
+    Out.reserve(Queries.size() * 7 + (size_t) TargetCount * 16 + 64);
     auto put = [&](uint v) {
         char b[12];
         int k = 12;
@@ -102,7 +126,7 @@ void RankedScoresBag::ToTsv(FILE *f)
         Out.append(b + k, (size_t) (12 - k));
     };
     Out += "prefilter\t"; put(TargetCount); Out += '\n';
-    for (size_t t = 0; Total && t <= MaxT; ++t) {
+    for (size_t t = 0; t + 1 < First.size(); ++t) {
         const size_t lo = First[t], hi = First[t + 1];
         if (lo == hi) continue;
         put((uint) t); Out += '\t'; put((uint) (hi - lo));
@@ -111,6 +135,66 @@ void RankedScoresBag::ToTsv(FILE *f)
         if (Out.size() > (64u << 20)) { fwrite(Out.data(), 1, Out.size(), f); Out.clear(); }
     }
     fwrite(Out.data(), 1, Out.size(), f);
+}
+
+// AddScore sequence of every query on the host threads: `items` holds per query (qstart) its triples in target order,
+// target in bits 16..47 and score in bits 0..15 of an element (a query's bag depends on its own triples only).
+static void ReplayGrouped(RankedScoresBag &RSB, const uint64_t *items, const size_t *qstart, uint32_t nqueries, size_t n)
+{
+    const unsigned T = (unsigned) std::max<size_t>(1, std::min<size_t>((size_t) HostThreads(64), n / 65536 + 1));
+    std::atomic<uint32_t> next{0};
+    auto body = [&]() {
+        for (;;) {
+            const uint32_t qi = next.fetch_add(1);
+            if (qi >= nqueries) return;
+            for (const uint64_t *x = items + qstart[qi], *e = items + qstart[qi + 1]; x != e; ++x)
+                RSB.AddScore(qi, (uint) ((*x >> 16) & 0xFFFFFFFFu), (uint16_t) (*x & 0xFFFF));
+            RSB.TruncateVecs(qi);
+        }
+    };
+    if (T == 1) body();
+    else {
+        std::vector<std::thread> ts;
+        for (unsigned k = 0; k < T; ++k) ts.emplace_back(body);
+        for (auto &th : ts) th.join();
+    }
+}
+
+// survivors in query order + the optional hand-off file
+static int EmitSelection(RankedScoresBag &RSB, uint32_t nqueries, size_t cap, uint32_t *out_q, uint32_t *out_t, uint32_t *out_score, size_t *nout,
+                         const char *tmp_tsv_path)
+{
+    size_t m = 0;
+    for (uint32_t qi = 0; qi < nqueries; ++qi) {
+        const auto &S = RSB.m_QueryIdxToScoreVec[qi];
+        const auto &T = RSB.m_QueryIdxToTargetIdxVec[qi];
+        for (size_t k = 0; k < S.size(); ++k) {
+            if (out_q && m < cap) { out_q[m] = qi; out_t[m] = T[k]; out_score[m] = S[k]; }
+            ++m;
+        }
+    }
+    *nout = m;
+    if (tmp_tsv_path && *tmp_tsv_path) {
+        FILE *f = fopen(tmp_tsv_path, "w");
+        if (!f) { rsk_set_error("rsk_rsb_select: cannot create %s", tmp_tsv_path); return RSK_E_INVALID; }
+        RSB.ToTsv(f);
+        fclose(f);
+    }
+    return RSK_OK;
+}
+
+// keys = query << 48 | target << 16 | score, ascending (rsk_triples_sort_dev) -> bags
+int ReplaySortedKeys(RankedScoresBag &RSB, const uint64_t *keys, size_t n, uint32_t nqueries, uint32_t rsb_size)
+{
+    if (n && (keys[n - 1] >> 48) >= nqueries) { rsk_set_error("rsk_rsb_select_keys: query index out of range"); return RSK_E_INVALID; }
+    std::vector<size_t> qstart((size_t) nqueries + 1, 0);
+    rsk_parallel_for((size_t) nqueries + 1, 64, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) qstart[i] = i > 0xFFFF ? n : (size_t) (std::lower_bound(keys, keys + n, (uint64_t) i << 48) - keys);
+    });
+    RSB.m_B = rsb_size;
+    RSB.Init(nqueries);
+    ReplayGrouped(RSB, keys, qstart.data(), nqueries, n);
+    return RSK_OK;
 }
 
 }   // namespace reseek_amd
@@ -137,46 +221,31 @@ extern "C" int rsk_rsb_select(const uint32_t *q, const uint32_t *t, const uint32
         for (size_t k = 0; k < n; ++k) byq[cur[q[k]]++] = ((uint64_t) t[k] << 16) | (uint16_t) score[k];
     }
     tm.lap("group by query");
+    // (a (query, target) pair occurs once: sorting a query's elements = target order)
+    rsk_parallel_for(nqueries, 16, [&](size_t lo, size_t hi) {
+        for (size_t qi = lo; qi < hi; ++qi) std::sort(byq.begin() + qstart[qi], byq.begin() + qstart[qi + 1]);
+    });
     RankedScoresBag RSB;
     RSB.m_B = rsb_size;
     RSB.Init(nqueries);
-    {
-        const unsigned T = (unsigned) std::max<size_t>(1, std::min<size_t>((size_t) HostThreads(64), n / 65536 + 1));
-        std::atomic<uint32_t> next{0};
-        auto body = [&]() {
-            for (;;) {
-                const uint32_t qi = next.fetch_add(1);
-                if (qi >= nqueries) return;
-                uint64_t *b = byq.data() + qstart[qi], *e = byq.data() + qstart[qi + 1];
-                std::sort(b, e);                                   // a (query, target) pair occurs once: order = target order
-                for (uint64_t *x = b; x != e; ++x) RSB.AddScore(qi, (uint) (*x >> 16), (uint16_t) (*x & 0xFFFF));
-                RSB.TruncateVecs(qi);
-            }
-        };
-        if (T == 1) body();
-        else {
-            std::vector<std::thread> ts;
-            for (unsigned k = 0; k < T; ++k) ts.emplace_back(body);
-            for (auto &th : ts) th.join();
-        }
-    }
+    ReplayGrouped(RSB, byq.data(), qstart.data(), nqueries, n);
     tm.lap("replay (threads)");
-    size_t m = 0;
-    for (uint32_t qi = 0; qi < nqueries; ++qi) {
-        const auto &S = RSB.m_QueryIdxToScoreVec[qi];
-        const auto &T = RSB.m_QueryIdxToTargetIdxVec[qi];
-        for (size_t k = 0; k < S.size(); ++k) {
-            if (out_q && m < n) { out_q[m] = qi; out_t[m] = T[k]; out_score[m] = S[k]; }
-            ++m;
-        }
-    }
-    *nout = m;
-    if (tmp_tsv_path && *tmp_tsv_path) {
-        FILE *f = fopen(tmp_tsv_path, "w");
-        if (!f) { rsk_set_error("rsk_rsb_select: cannot create %s", tmp_tsv_path); return RSK_E_INVALID; }
-        RSB.ToTsv(f);
-        fclose(f);
-    }
+    const int rc = EmitSelection(RSB, nqueries, n, out_q, out_t, out_score, nout, tmp_tsv_path);
+    if (rc != RSK_OK) return rc;
     tm.lap("hand-off file");
     return RSK_OK;
+}
+
+extern "C" int rsk_rsb_select_keys(const uint64_t *keys, size_t n, uint32_t nqueries, uint32_t rsb_size, uint32_t *out_q, uint32_t *out_t,
+                                   uint32_t *out_score, size_t *nout, const char *tmp_tsv_path)
+{
+    if ((n && !keys) || !nout || rsb_size == 0 || nqueries > 65536) { rsk_set_error("rsk_rsb_select_keys: bad argument"); return RSK_E_INVALID; }
+    PhaseTimer tm("rsk_rsb_select_keys");
+    RankedScoresBag RSB;
+    int rc = ReplaySortedKeys(RSB, keys, n, nqueries, rsb_size);
+    if (rc != RSK_OK) return rc;
+    tm.lap("replay (threads)");
+    rc = EmitSelection(RSB, nqueries, n, out_q, out_t, out_score, nout, tmp_tsv_path);
+    tm.lap("hand-off file");
+    return rc;
 }

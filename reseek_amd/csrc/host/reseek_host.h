@@ -379,6 +379,9 @@ public:
     void AddScore(uint QueryIdx, uint TargetIdx, uint16_t Score);
     void Finish();                                      // the final TruncateVecs pass of ToTsv
     void ToTsv(FILE *fTsv);                             // "prefilter\t<#targets>" + "TIdx\tK\tQIdx..." lines
+    // not in the reference: the selection target-major (the hand-off order) without the file
+    void GroupByTarget(std::vector<size_t> &First, std::vector<uint> &Queries, uint &TargetCount);
+    void ToPairs(std::vector<uint32_t> &pq, std::vector<uint32_t> &pt);
 };
 
 class DBSearcher {                                      // dbsearcher.h:14
@@ -468,6 +471,15 @@ void RunMKFPairs(rsk_ctx *Ctx, const DSSParams &Params, const std::string &Colum
                  const std::vector<std::pair<uint32_t, uint32_t> > &Pairs, const std::function<void(DSSAligner &, uint, uint)> &OnHit,
                  const std::function<void(DSSAligner &, uint, uint, unsigned)> *OnHitOfWorker = nullptr);
 
+// The long-chain job beside another job of the same search: RunMKFPairs on a helper context of `Ctx`'s device (own stream,
+// own host thread) while AlignJob() runs on the calling thread; a pair that ends with an alignment is offered to Keep
+// (called concurrently from the workers: no shared state), kept hits are formatted into per-worker buffers (ToTsv, Up) and
+// appended to fTsv after both jobs -- the order of the hits file stays "alignment job, then long-chain job".  Returns the
+// number of long-chain hits.
+uint64_t RunMKFPairsBeside(rsk_ctx *Ctx, const DSSParams &Params, const std::string &Columns, DBSearcher &SrcA, DBSearcher &SrcB,
+                           const std::vector<std::pair<uint32_t, uint32_t> > &Pairs, const std::function<void()> &AlignJob,
+                           const std::function<bool(const DSSAligner &)> &Keep, bool Up, FILE *fTsv);
+
 // [b, e) ranges of a pair list such that each batch has <= batch_pairs pairs and <= batch_cells DP cells
 std::vector<std::pair<size_t, size_t> > AlignBatches(const SearchOptions &O, const DBSearcher &A, const DBSearcher &B,
                                                      const std::vector<uint32_t> &ia, const std::vector<uint32_t> &ib);
@@ -511,5 +523,9 @@ void PostMuFilter(const DSSParams &Params, const std::string &MuFilterTsvFN, con
 void MuPreFilter(const DSSParams &Params, DBSearcher &QDB, DBSearcher &TDB, const std::string &OutputFN);
 void PostMuFilter(const DSSParams &Params, const std::string &MuFilterTsvFN, DBSearcher &Q, DBSearcher &DB,
                   const std::string &HitsFN);
+// ... and with the candidates handed over in memory, in the hand-off file's order (rsk_search; KeepTmpFN != "" also writes the file)
+void MuPreFilterToPairs(DBSearcher &QDB, DBSearcher &TDB, std::vector<uint32_t> &pq, std::vector<uint32_t> &pt, const std::string &KeepTmpFN);
+void PostMuFilterPairs(const DSSParams &Params, DBSearcher &Q, DBSearcher &DB, const std::vector<uint32_t> &pq, const std::vector<uint32_t> &pt,
+                       const std::string &HitsFN);
 
 }   // namespace reseek_amd

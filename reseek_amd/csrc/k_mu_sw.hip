@@ -969,63 +969,134 @@ extern "C" int rsk_mu_filter_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t,
 
 // Pair-list form of the filter (DSSAligner::AlignMuParaBags parasail_mu.cpp:183 as PostMuFilter calls it per
 // (query, target) candidate, chainbag.cpp:68-74): host arrays in, per-pair verdict out.
-static int musw_run_pairlist(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, const uint32_t *iq, const uint32_t *it,
-                             const std::vector<uint32_t> &sel, int reverse, int gap_open, int gap_ext, std::vector<uint8_t> &raw,
-                             const std::vector<int16_t> *thr_sel = nullptr)      // early-exit thresholds of the reverse pass, aligned with sel
+// ---- pair lists (prefilter candidates, self-rev) ------------------------------------------------------------------
+// The SW kernel wants a CSR by query with each query's partners by increasing length (the pairs of a wave then end
+// together).  r04: the lists never exist on the host -- the caller's two index columns go up once, keys (query << 32 |
+// partner length) are radix-sorted on the device with the list position as payload (a stable sort: equal keys keep the
+// caller's order), row starts are binary searches over the sorted keys, scores are scattered back to the caller's order
+// by the same payload, and the reverse pass's candidate list, thresholds and the final verdicts are kernels too.  (Three
+// rounds of host counting sorts / per-query std::sorts / gathers over 16.5 M candidates were 0.65 s of a 0.93 s call.)
+__global__ void k_mfp_keys(const uint32_t *iq, const uint32_t *it, const uint32_t *sel, size_t n, const uint32_t *t_len,
+                           unsigned long long *keys, uint32_t *vals)
 {
-    // CSR by query; within a query the targets by increasing length (the pairs of a wave then end together)
-    const size_t n = sel.size();
-    raw.assign(n, 0);
-    if (n == 0) return RSK_OK;
-    // counting sort by query, then each query's partners by (length, position in the caller's list) on the host worker
-    // threads (one comparison sort over tens of millions of candidates was the whole cost of this call)
-    std::vector<uint32_t> cnt(q->n, 0), rowstart((size_t) q->n + 1, 0), ord(n), list(n);
-    for (size_t k = 0; k < n; ++k) ++cnt[iq[sel[k]]];
-    for (uint32_t i = 0; i < q->n; ++i) rowstart[i + 1] = rowstart[i] + cnt[i];
-    {
-        std::vector<uint32_t> cursor(rowstart.begin(), rowstart.end() - 1);
-        for (size_t k = 0; k < n; ++k) ord[cursor[iq[sel[k]]]++] = (uint32_t) k;
+    const size_t k = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t p = sel ? sel[k] : (uint32_t) k;
+    keys[k] = ((unsigned long long) iq[p] << 32) | t_len[it[p]];
+    vals[k] = (uint32_t) k;
+}
+
+__global__ void k_mfp_rows(const unsigned long long *keys, size_t n, uint32_t nq, uint32_t *rowstart, uint32_t *cnt)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > nq) return;
+    auto lb = [&](uint32_t q) -> uint32_t {
+        size_t lo = 0, hi = n;
+        const unsigned long long key = (unsigned long long) q << 32;
+        while (lo < hi) { const size_t mid = lo + ((hi - lo) >> 1); if (keys[mid] < key) lo = mid + 1; else hi = mid; }
+        return (uint32_t) lo;
+    };
+    const uint32_t a = lb(i);
+    rowstart[i] = a;
+    if (i < nq) cnt[i] = (i + 1 == nq ? (uint32_t) n : lb(i + 1)) - a;
+}
+
+__global__ void k_mfp_gather(const uint32_t *it, const uint32_t *sel, const uint32_t *ord, size_t n, uint32_t *list, const int16_t *thr,
+                             int16_t *thr_sorted)
+{
+    const size_t k = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t o = ord[k];
+    list[k] = it[sel ? sel[o] : o];
+    if (thr) thr_sorted[k] = thr[o];
+}
+
+__global__ void k_mfp_scatter(const uint8_t *sorted, const uint32_t *ord, size_t n, uint8_t *raw)
+{
+    const size_t k = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) raw[ord[k]] = sorted[k];
+}
+
+// forward scores -> the list of pairs that need the reverse pass (fwd >= OmegaFwd, parasail_mu.cpp:141-146) and their
+// early-exit thresholds floor(fwd' - Omega)
+__global__ void k_mfp_candidates(const uint8_t *rawf, size_t n, float omega, float omega_fwd, uint32_t *cand, int16_t *thr, uint32_t *ncand)
+{
+    const size_t p = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    bool is = false;
+    float f = 0.0f;
+    if (p < n) {
+        f = rawf[p] == 255 ? 777.0f : (float) rawf[p];                     // parasail_mu.cpp:135-139
+        is = !(f < omega_fwd);
     }
-    rsk_parallel_for(q->n, 64, [&](size_t lo, size_t hi) {
-        for (size_t i = lo; i < hi; ++i)
-            std::sort(ord.begin() + rowstart[i], ord.begin() + rowstart[i + 1], [&](uint32_t x, uint32_t y) {
-                const uint32_t px = sel[x], py = sel[y];
-                const uint32_t lx = t->len[it[px]], ly = t->len[it[py]];
-                return lx != ly ? lx < ly : px < py;
-            });
-    });
-    rsk_parallel_for(n, 1 << 16, [&](size_t lo, size_t hi) { for (size_t k = lo; k < hi; ++k) list[k] = it[sel[ord[k]]]; });
+    const unsigned long long m = __ballot(is);
+    if (!m) return;
+    const int lane = threadIdx.x & 63;
+    uint32_t base = 0;
+    if (lane == __builtin_ctzll(m)) base = atomicAdd(ncand, (uint32_t) __popcll(m));
+    base = (uint32_t) __shfl((int) base, __builtin_ctzll(m), 64);
+    if (is) {
+        const uint32_t k = base + (uint32_t) __popcll(m & ((1ull << lane) - 1));
+        cand[k] = (uint32_t) p;
+        thr[k] = (int16_t) fminf(fmaxf(floorf(f - omega), -1.0f), 32767.0f);
+    }
+}
+
+// reverse scores of the candidates (aligned with cand) -> by pair position
+__global__ void k_mfp_rev_by_pos(const uint8_t *rawr, const uint32_t *cand, size_t ncand, uint8_t *rev_pos, uint8_t *is_cand)
+{
+    const size_t k = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < ncand) { rev_pos[cand[k]] = rawr[k]; is_cand[cand[k]] = 1; }
+}
+
+__global__ void k_mfp_verdict(const uint8_t *rawf, const uint8_t *rev_pos, const uint8_t *is_cand, size_t n, float omega, uint8_t *pass,
+                              int32_t *fwd, int32_t *rev)
+{
+    const size_t p = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int f = rawf[p] == 255 ? 777 : rawf[p];
+    const int r = is_cand[p] ? rev_pos[p] : 0;
+    const float score = is_cand[p] ? (float) f - (float) r : 0.0f;          // fwd < OmegaFwd: AlignMuQP_Para returns 0
+    pass[p] = !(score < omega);                                             // chainbag.cpp:71-73
+    if (fwd) fwd[p] = f;
+    if (rev) rev[p] = r;
+}
+
+// One pass of the SW kernel over the pairs sel[0..n) (NULL = all n pairs) of the device columns d_iq / d_it; d_raw[k] =
+// raw score of the k-th selected pair.
+static int musw_run_pairlist_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, const uint32_t *d_iq, const uint32_t *d_it, const uint32_t *d_sel,
+                                 size_t n, int reverse, int gap_open, int gap_ext, uint8_t *d_raw, const int16_t *d_thr)
+{
+    if (n == 0) return RSK_OK;
     musw_ws ws(ctx);
-    uint32_t *d_cnt = nullptr, *d_rowstart = nullptr, *d_list = nullptr;
+    unsigned long long *d_keys = nullptr, *d_keys2 = nullptr;
+    uint32_t *d_vals = nullptr, *d_ord = nullptr, *d_cnt = nullptr, *d_rowstart = nullptr, *d_list = nullptr;
     uint8_t *d_out = nullptr;
+    int16_t *d_thr_sorted = nullptr;
     int rc;
-    if ((rc = ws.alloc(&d_cnt, q->n)) != RSK_OK) return rc;
-    if ((rc = ws.alloc(&d_rowstart, (size_t) q->n + 1)) != RSK_OK) return rc;
-    if ((rc = ws.alloc(&d_list, n)) != RSK_OK) return rc;
-    if ((rc = ws.alloc(&d_out, n)) != RSK_OK) return rc;
-    RSK_HIP(hipMemcpyAsync(d_cnt, cnt.data(), (size_t) q->n * 4, hipMemcpyHostToDevice, ctx->stream));
-    RSK_HIP(hipMemcpyAsync(d_rowstart, rowstart.data(), ((size_t) q->n + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-    RSK_HIP(hipMemcpyAsync(d_list, list.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = ws.alloc(&d_keys, n)) || (rc = ws.alloc(&d_keys2, n)) || (rc = ws.alloc(&d_vals, n)) || (rc = ws.alloc(&d_ord, n)) ||
+        (rc = ws.alloc(&d_cnt, (size_t) q->n)) || (rc = ws.alloc(&d_rowstart, (size_t) q->n + 1)) || (rc = ws.alloc(&d_list, n)) ||
+        (rc = ws.alloc(&d_out, n)))
+        return rc;
+    if (d_thr && (rc = ws.alloc(&d_thr_sorted, n)) != RSK_OK) return rc;
+    const unsigned nb = (unsigned) ((n + 255) / 256);
+    hipLaunchKernelGGL(k_mfp_keys, dim3(nb), dim3(256), 0, ctx->stream, d_iq, d_it, d_sel, n, t->d_len, d_keys, d_vals);
+    int qbits = 1;
+    while (qbits < 32 && ((uint64_t) q->n >> qbits) != 0) ++qbits;
+    if ((rc = rsk_sort_pairs_u64_u32(ctx, d_keys, d_keys2, d_vals, d_ord, n, 32 + qbits)) != RSK_OK) return rc;      // stable (k_pairs_sort.hip)
+    hipLaunchKernelGGL(k_mfp_rows, dim3(q->n / 256 + 1), dim3(256), 0, ctx->stream, d_keys2, n, q->n, d_rowstart, d_cnt);
+    hipLaunchKernelGGL(k_mfp_gather, dim3(nb), dim3(256), 0, ctx->stream, d_it, d_sel, d_ord, n, d_list, d_thr, d_thr_sorted);
+    RSK_HIP(hipGetLastError());
     musw_args a = {};
     a.q_mu = q->d_mu; a.q_off = q->d_off; a.q_len = q->d_len;
     a.t_mu = t->d_mu; a.t_off = t->d_off; a.t_len = t->d_len;
     a.cnt = d_cnt; a.first = nullptr; a.perm = nullptr; a.tri = 0; a.list = d_list; a.rowstart = d_rowstart;
     a.reverse = reverse; a.open = gap_open; a.ext = gap_ext;
     a.out = d_out; a.ldo = 0;
-    std::vector<int16_t> thr_sorted;
-    if (thr_sel) {
-        int16_t *d_thr = nullptr;
-        thr_sorted.resize(n);
-        for (size_t k = 0; k < n; ++k) thr_sorted[k] = (*thr_sel)[ord[k]];
-        if ((rc = ws.alloc(&d_thr, n)) != RSK_OK) return rc;
-        RSK_HIP(hipMemcpyAsync(d_thr, thr_sorted.data(), n * 2, hipMemcpyHostToDevice, ctx->stream));
-        a.thr = d_thr;
-    }
+    a.thr = d_thr ? d_thr_sorted : nullptr;
     if ((rc = run_mu_sw_lists(ctx, q, t, a, item_upper_bound(q, n), ws)) != RSK_OK) return rc;
-    std::vector<uint8_t> sorted_raw(n);
-    RSK_HIP(hipMemcpyAsync(sorted_raw.data(), d_out, n, hipMemcpyDeviceToHost, ctx->stream));
-    RSK_HIP(hipStreamSynchronize(ctx->stream));
-    for (size_t k = 0; k < n; ++k) raw[ord[k]] = sorted_raw[k];
+    hipLaunchKernelGGL(k_mfp_scatter, dim3(nb), dim3(256), 0, ctx->stream, d_out, d_ord, n, d_raw);
+    RSK_HIP(hipGetLastError());
+    RSK_HIP(hipStreamSynchronize(ctx->stream));                              // the workspace goes back to the pool on return
     return RSK_OK;
 }
 
@@ -1036,45 +1107,54 @@ extern "C" int rsk_mu_filter_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *
     if (!q->d_mu || !t->d_mu) { rsk_set_error("rsk_mu_filter_pairs: chain set has no Mu letters"); return RSK_E_INVALID; }
     if (gap_open < 0 || gap_ext < 0) { rsk_set_error("rsk_mu_filter_pairs: gap costs must be >= 0"); return RSK_E_INVALID; }
     if (npairs > 0xFFFFFFF0ull) { rsk_set_error("rsk_mu_filter_pairs: too many pairs in one call"); return RSK_E_RANGE; }
-    for (size_t p = 0; p < npairs; ++p)
-        if (iq[p] >= q->n || it[p] >= t->n) { rsk_set_error("rsk_mu_filter_pairs: pair %zu out of range", p); return RSK_E_INVALID; }
+    {
+        std::atomic<size_t> bad{(size_t) -1};
+        rsk_parallel_for(npairs, 1 << 18, [&](size_t lo, size_t hi) {
+            for (size_t p = lo; p < hi; ++p)
+                if (iq[p] >= q->n || it[p] >= t->n) { size_t cur = bad.load(); while (p < cur && !bad.compare_exchange_weak(cur, p)) {} break; }
+        });
+        if (bad.load() != (size_t) -1) { rsk_set_error("rsk_mu_filter_pairs: pair %zu out of range", bad.load()); return RSK_E_INVALID; }
+    }
+    ctx->mf_pairs = npairs;
+    ctx->mf_candidates = 0;
+    if (npairs == 0) return RSK_OK;
     RSK_HIP(hipSetDevice(ctx->device));
     int rc = rsk_upload_mu_tables(ctx);
     if (rc != RSK_OK) return rc;
     RSK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-    std::vector<uint32_t> all(npairs);
-    for (size_t p = 0; p < npairs; ++p) all[p] = (uint32_t) p;
-    std::vector<uint8_t> rawf, rawr;
-    if ((rc = musw_run_pairlist(ctx, q, t, iq, it, all, 0, gap_open, gap_ext, rawf)) != RSK_OK) return rc;
-    std::vector<uint32_t> cand;
-    for (size_t p = 0; p < npairs; ++p) {
-        const float f = rawf[p] == 255 ? 777.0f : (float) rawf[p];          // parasail_mu.cpp:135-139
-        if (!(f < omega_fwd)) cand.push_back((uint32_t) p);                  // :141-146
-    }
+    rsk_scratch ws(ctx);
+    uint32_t *d_iq, *d_it, *d_cand, *d_ncand;
+    uint8_t *d_rawf, *d_rawr, *d_rev_pos, *d_is_cand, *d_pass;
+    int16_t *d_thr;
+    int32_t *d_fwd = nullptr, *d_rev = nullptr;
+    if ((rc = ws.alloc(&d_iq, npairs)) || (rc = ws.alloc(&d_it, npairs)) || (rc = ws.alloc(&d_cand, npairs)) || (rc = ws.alloc(&d_ncand, 1)) ||
+        (rc = ws.alloc(&d_rawf, npairs)) || (rc = ws.alloc(&d_rawr, npairs)) || (rc = ws.alloc(&d_rev_pos, npairs)) ||
+        (rc = ws.alloc(&d_is_cand, npairs)) || (rc = ws.alloc(&d_pass, npairs)) || (rc = ws.alloc(&d_thr, npairs)))
+        return rc;
+    if (fwd && (rc = ws.alloc(&d_fwd, npairs)) != RSK_OK) return rc;
+    if (rev && (rc = ws.alloc(&d_rev, npairs)) != RSK_OK) return rc;
+    RSK_HIP(hipMemcpyAsync(d_iq, iq, npairs * 4, hipMemcpyHostToDevice, ctx->stream));
+    RSK_HIP(hipMemcpyAsync(d_it, it, npairs * 4, hipMemcpyHostToDevice, ctx->stream));
+    RSK_HIP(hipMemsetAsync(d_ncand, 0, 4, ctx->stream));
+    RSK_HIP(hipMemsetAsync(d_is_cand, 0, npairs, ctx->stream));
+    if ((rc = musw_run_pairlist_dev(ctx, q, t, d_iq, d_it, nullptr, npairs, 0, gap_open, gap_ext, d_rawf, nullptr)) != RSK_OK) return rc;
+    const unsigned nb = (unsigned) ((npairs + 255) / 256);
+    hipLaunchKernelGGL(k_mfp_candidates, dim3(nb), dim3(256), 0, ctx->stream, d_rawf, npairs, omega, omega_fwd, d_cand, d_thr, d_ncand);
+    uint32_t ncand = 0;
+    RSK_HIP(hipMemcpyAsync(&ncand, d_ncand, 4, hipMemcpyDeviceToHost, ctx->stream));
+    RSK_HIP(hipStreamSynchronize(ctx->stream));
     // the caller does not ask for the reverse scores: pairs that have failed may stop early (see musw_args::thr)
-    std::vector<int16_t> thr;
     const bool early = !rev && !(getenv("RSK_MUSW_EARLY_EXIT") && atoi(getenv("RSK_MUSW_EARLY_EXIT")) == 0);
-    if (early) {
-        thr.resize(cand.size());
-        for (size_t c2 = 0; c2 < cand.size(); ++c2) {
-            const float f = rawf[cand[c2]] == 255 ? 777.0f : (float) rawf[cand[c2]];
-            thr[c2] = (int16_t) std::min(std::max(floorf(f - omega), -1.0f), 32767.0f);
-        }
-    }
-    if ((rc = musw_run_pairlist(ctx, q, t, iq, it, cand, 1, gap_open, gap_ext, rawr, early ? &thr : nullptr)) != RSK_OK) return rc;
+    if ((rc = musw_run_pairlist_dev(ctx, q, t, d_iq, d_it, d_cand, ncand, 1, gap_open, gap_ext, d_rawr, early ? d_thr : nullptr)) != RSK_OK) return rc;
+    if (ncand) hipLaunchKernelGGL(k_mfp_rev_by_pos, dim3((ncand + 255) / 256), dim3(256), 0, ctx->stream, d_rawr, d_cand, (size_t) ncand, d_rev_pos, d_is_cand);
+    hipLaunchKernelGGL(k_mfp_verdict, dim3(nb), dim3(256), 0, ctx->stream, d_rawf, d_rev_pos, d_is_cand, npairs, omega, d_pass, d_fwd, d_rev);
+    RSK_HIP(hipGetLastError());
     RSK_HIP(hipEventRecord(ctx->ev1, ctx->stream));
-    size_t c = 0;
-    for (size_t p = 0; p < npairs; ++p) {
-        const int f = rawf[p] == 255 ? 777 : rawf[p];
-        int r = 0;
-        float score = 0.0f;                                                  // fwd < OmegaFwd: AlignMuQP_Para returns 0
-        if (c < cand.size() && cand[c] == p) { r = rawr[c]; score = (float) f - (float) r; ++c; }
-        pass[p] = !(score < omega);                                          // chainbag.cpp:71-73
-        if (fwd) fwd[p] = f;
-        if (rev) rev[p] = r;
-    }
-    ctx->mf_pairs = npairs;
-    ctx->mf_candidates = cand.size();
+    RSK_HIP(hipMemcpyAsync(pass, d_pass, npairs, hipMemcpyDeviceToHost, ctx->stream));
+    if (fwd) RSK_HIP(hipMemcpyAsync(fwd, d_fwd, npairs * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (rev) RSK_HIP(hipMemcpyAsync(rev, d_rev, npairs * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RSK_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->mf_candidates = ncand;
     return RSK_OK;
 }
 

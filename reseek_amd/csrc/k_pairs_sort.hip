@@ -46,3 +46,47 @@ extern "C" int rsk_pairs_sort_dev(rsk_ctx *ctx, uint32_t *d_major, uint32_t *d_m
     RSK_HIP(hipStreamSynchronize(ctx->stream));
     return RSK_OK;
 }
+
+// (query, target, score) triples of rsk_mu_prefilter_dev (unordered) -> 64-bit keys query << 48 | target << 16 | score in
+// ascending order = grouped by query, a query's triples by target: the order RankedScoresBag sees them in with -threads 1
+// (targets ascending, muprefilter.cpp:21-60), so the host replay (rsk_rsb_select_keys) is one linear pass per query.
+__global__ void k_triples_pack(const uint32_t *q, const uint32_t *t, const uint32_t *s, size_t n, unsigned long long *keys)
+{
+    const size_t k = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) keys[k] = ((unsigned long long) q[k] << 48) | ((unsigned long long) t[k] << 16) | (s[k] & 0xFFFFu);
+}
+
+extern "C" int rsk_triples_sort_dev(rsk_ctx *ctx, const uint32_t *d_q, const uint32_t *d_t, const uint32_t *d_score, size_t n, uint64_t *d_keys)
+{
+    if (!ctx || (n && (!d_q || !d_t || !d_score || !d_keys))) { rsk_set_error("rsk_triples_sort_dev: NULL argument"); return RSK_E_INVALID; }
+    if (n == 0) return RSK_OK;
+    RSK_HIP(hipSetDevice(ctx->device));
+    rsk_scratch ws(ctx);
+    unsigned long long *d_in = nullptr;
+    void *d_tmp = nullptr;
+    int rc;
+    if ((rc = ws.alloc(&d_in, n)) != RSK_OK) return rc;
+    size_t tmp_bytes = 0;
+    RSK_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, d_in, (unsigned long long *) d_keys, n, 0, 64, ctx->stream));
+    if ((rc = ws.alloc((void **) &d_tmp, std::max<size_t>(tmp_bytes, 16))) != RSK_OK) return rc;
+    hipLaunchKernelGGL(k_triples_pack, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->stream, d_q, d_t, d_score, n, d_in);
+    RSK_HIP(hipGetLastError());
+    RSK_HIP(hipcub::DeviceRadixSort::SortKeys(d_tmp, tmp_bytes, d_in, (unsigned long long *) d_keys, n, 0, 64, ctx->stream));
+    RSK_HIP(hipStreamSynchronize(ctx->stream));
+    return RSK_OK;
+}
+
+int rsk_sort_pairs_u64_u32(rsk_ctx *ctx, const unsigned long long *d_keys_in, unsigned long long *d_keys_out, const uint32_t *d_vals_in,
+                           uint32_t *d_vals_out, size_t n, int end_bit)
+{
+    if (n == 0) return RSK_OK;
+    rsk_scratch ws(ctx);
+    void *d_tmp = nullptr;
+    size_t tmp_bytes = 0;
+    RSK_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_keys_in, d_keys_out, d_vals_in, d_vals_out, n, 0, end_bit, ctx->stream));
+    const int rc = ws.alloc(&d_tmp, std::max<size_t>(tmp_bytes, 16));
+    if (rc != RSK_OK) return rc;
+    RSK_HIP(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_keys_in, d_keys_out, d_vals_in, d_vals_out, n, 0, end_bit, ctx->stream));
+    RSK_HIP(hipStreamSynchronize(ctx->stream));            // the temporary goes back to the pool with `ws`
+    return RSK_OK;
+}

@@ -181,6 +181,10 @@ int rsk_launch_gapless_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, con
 int rsk_build_rings(rsk_db *db);
 int rsk_build_mudex(rsk_ctx *ctx, rsk_db *db, int mode);
 int rsk_build_len_perm(rsk_db *db);
+// k_pairs_sort.hip: stable radix sort of (64-bit key, 32-bit payload) pairs on bits [0, end_bit) of the key, queued on the
+// context's stream (temporaries from its pool)
+int rsk_sort_pairs_u64_u32(rsk_ctx *ctx, const unsigned long long *d_keys_in, unsigned long long *d_keys_out, const uint32_t *d_vals_in,
+                           uint32_t *d_vals_out, size_t n, int end_bit);
 
 // k_sw_float.hip: CalcEvalue + path packing for alignments whose paths already sit on the device (see the definition)
 int rsk_paths_stats_pack(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *dbb, size_t npairs, const uint32_t *ia, const uint32_t *ib,

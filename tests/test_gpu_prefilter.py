@@ -172,3 +172,42 @@ def test_scop40_full_neighbourhood_checksums(ctx):
         assert len(rq) == int(want["lines"])
         assert hashlib.md5(scores_text(labels, rq, rt, rs).encode()).hexdigest() == want["sorted_scores_md5"]
         assert hashlib.md5(open(tmp, "rb").read()).hexdigest() == want["tmp_tsv_md5"]
+
+
+def test_device_sorted_keys_and_key_replay(ctx, tmp_path):
+    """rsk_triples_sort_dev: the kernel's unordered triples -> query << 48 | target << 16 | score, ascending (numpy is the
+    check); rsk_rsb_select_keys on them == rsk_rsb_select on the triples (bags and hand-off file), with a bag size that
+    overflows.  Also a dense low-complexity set (every pair has many seeds: the bitmap spans and the >4096-diagonal rounds of
+    the scan) against the oracle."""
+    import torch
+    import reseek_amd
+    labels, seqs = fx.read_mu_fasta("scop40.mu.fa.gz", limit=600)
+    q = reseek_amd.Db.from_mu_seqs(ctx, seqs)
+    cap = 600 * 600
+    dq, dt, ds = (torch.zeros(cap, dtype=torch.int32, device="cuda") for _ in range(3))
+    dn = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ctx.mu_prefilter_dev(q, q, dq.data_ptr(), dt.data_ptr(), ds.data_ptr(), cap, dn.data_ptr(), neighbourhood=2)
+    torch.cuda.synchronize()
+    n = int(dn.item())
+    dk = torch.zeros(max(n, 1), dtype=torch.int64, device="cuda")
+    ctx.triples_sort_dev(dq.data_ptr(), dt.data_ptr(), ds.data_ptr(), n, dk.data_ptr())
+    hq, ht, hs = (x[:n].cpu().numpy().astype(np.uint64) for x in (dq, dt, ds))
+    want = np.sort((hq << np.uint64(48)) | (ht << np.uint64(16)) | hs)
+    got = dk[:n].cpu().numpy().view(np.uint64)
+    assert n > 1000 and np.array_equal(got, want)
+    fa, fb = str(tmp_path / "a.tsv"), str(tmp_path / "b.tsv")
+    a = reseek_amd.capi.rsb_select(hq, ht, hs, len(seqs), 40, tmp_tsv_path=fa)
+    b = reseek_amd.capi.rsb_select_keys(got, len(seqs), 40, tmp_tsv_path=fb)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b)) and open(fa, "rb").read() == open(fb, "rb").read()
+    q.close()
+    # dense: 40 low-complexity chains (three letters in long runs), neighbourhood index
+    rng = np.random.default_rng(3)
+    dense = []
+    for L in rng.integers(60, 700, 40):
+        runs = rng.integers(3, 40, int(L))
+        lets = rng.choice(np.array([17, 34, 35, 33, 14], np.uint8), int(L))
+        dense.append(np.repeat(lets, runs)[: int(L)].astype(np.uint8))
+    for mode in (0, 2):
+        gq, gt, gs, _ = run_prefilter(ctx, dense, cap=40 * 40 + 16, mode=mode)
+        oq, ot, os_ = ol.prefilter(dense, dense, mode=mode)
+        assert as_set(gq, gt, gs) == as_set(np.asarray(oq), np.asarray(ot), np.asarray(os_)), "dense set, mode %d" % mode

@@ -75,3 +75,23 @@ def test_empty_and_bad_arguments():
     import pytest
     with pytest.raises(capi.RskError):
         capi.rsb_merge(np.array([[7, 0, 1]], np.int32), 5, 10)        # query index out of range
+
+
+def test_sorted_key_replay_equals_the_triple_replay(tmp_path):
+    """rsk_rsb_select_keys (keys as rsk_triples_sort_dev leaves them: query << 48 | target << 16 | score, ascending) keeps
+    exactly what rsk_rsb_select keeps of the same triples in any order -- overflowing bags and tie-heavy scores included --
+    and writes the same hand-off file."""
+    for seed, nq, nt, dens, smax, B in ((3, 30, 2500, 0.6, 12, 50), (4, 7, 900, 0.9, 300, 1500), (5, 65, 400, 0.5, 5, 20)):
+        rows = make(seed, nq, nt, dens, smax)
+        rng = np.random.default_rng(seed)
+        shuf = rows[rng.permutation(len(rows))]
+        fa, fb = str(tmp_path / "a.tsv"), str(tmp_path / "b.tsv")
+        a = capi.rsb_select(shuf[:, 0], shuf[:, 1], shuf[:, 2], nq, B, tmp_tsv_path=fa)
+        keys = np.sort((rows[:, 0].astype(np.uint64) << np.uint64(48)) | (rows[:, 1].astype(np.uint64) << np.uint64(16)) | rows[:, 2].astype(np.uint64))
+        b = capi.rsb_select_keys(keys, nq, B, tmp_tsv_path=fb)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+        assert open(fa, "rb").read() == open(fb, "rb").read()
+    # empty input
+    q, t, s = capi.rsb_select_keys(np.zeros(0, np.uint64), 5, 10)
+    assert len(q) == 0
