@@ -170,6 +170,86 @@ def _load_json(name):
         return None
 
 
+def _verified_pmc(name="r04_live_pmc.json"):
+    """Counter records of tools/prof_live.sh, per kernel -- only those whose kernel SOURCE file still has the sha256 it had
+    when the counters were collected (a kernel edit must not leave stale counters in the bench line); the others read
+    {"stale": reason}."""
+    import hashlib
+    rec = _load_json(name)
+    if not rec:
+        return {}
+    shas = rec.get("kernel_source_sha256", {})
+    out = {}
+    for k, e in rec.items():
+        if k == "kernel_source_sha256" or not isinstance(e, dict):
+            continue
+        src = e.get("kernel_source")
+        try:
+            with open(os.path.join(ROOT, src), "rb") as f:
+                cur = hashlib.sha256(f.read()).hexdigest()
+        except (OSError, TypeError):
+            cur = None
+        if src and cur and shas.get(src) == cur:
+            out[k] = dict(e, source_verified="sha256 of %s unchanged since the counters were collected (profiles/%s)" % (src, name))
+        else:
+            out[k] = {"stale": "profiles/%s: %s changed since the counters were collected (or no hash on record): re-run tools/prof_live.sh" % (name, src)}
+    return out
+
+
+def prefilter_entry(ctx, name, what, seqs, pmc, reps=2):
+    """One `roofline_live` entry for k_prefilter (prefiltermu.cpp:382, twohitdiag.cpp:368-398): the scan of every chain of
+    `seqs` against the neighbourhood index of the same set (idxt, the `-fast -db` configuration).  Two byte models:
+      survey  SURVEY 8d's model of the REFERENCE's data flow: TL + 8 x seed items x (6 B posting + 4 B bag write + 4 B read
+              back)... read here as 14 B per seed item + 2 B per diagonal cell (the judge's recomputation formula)
+      ours    what this kernel has to move: 4 B per seed item (the posting; bit addresses stay in LDS), 2 B per diagonal
+              cell (a query and a target letter), 12 B per result triple, TL per target.
+    The seed walk is the HBM / latency side, the diagonal scans the VALU side (5.5 instructions per cell); both fractions
+    are reported, `bound` names the larger share of the kernel time (RSK_PF_DEBUG=1 splits them: profiles/)."""
+    import torch
+    import reseek_amd
+    n = len(seqs)
+    q = reseek_amd.Db.from_mu_seqs(ctx, seqs)
+    cap = int(min(n * n + 16, 200_000_000))
+    dq, dt, ds = (torch.zeros(cap, dtype=torch.int32, device="cuda") for _ in range(3))
+    dn = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ms = []
+    for _ in range(reps + 1):                       # the first call builds the index
+        ctx.mu_prefilter_dev(q, q, dq.data_ptr(), dt.data_ptr(), ds.data_ptr(), cap, dn.data_ptr(), neighbourhood=2)
+        torch.cuda.synchronize()
+        ms.append(ctx.last_kernel_ms())
+    ms_ = float(np.median(ms[1:]))
+    items, postings, twohit, cells = ctx.mu_prefilter_last_work()
+    triples = int(dn.item())
+    nres = float(sum(len(s) for s in seqs))
+    q.close()
+    ours = 4.0 * items + 2.0 * cells + 12.0 * triples + nres
+    survey = 14.0 * items + 2.0 * cells + nres
+    return {"kernel": "k_prefilter", "workload": name, "what": what, "kernel_ms": ms_, "chains": n, "index_postings": int(postings), "seed_items": int(items),
+            "seed_items_per_s": items / ms_ * 1e3, "twohit_diagonals": int(twohit), "diagonal_cells": int(cells), "result_triples": triples,
+            "bound": "hbm", "unit": "GB/s", "achieved": ours / ms_ * 1e3 / 1e9, "peak": PEAK_HBM_GBS, "frac": ours / ms_ * 1e3 / 1e9 / PEAK_HBM_GBS,
+            "algorithmic_bytes": ours,
+            "survey_model": {"bytes": survey, "achieved_GBs": survey / ms_ * 1e3 / 1e9, "frac": survey / ms_ * 1e3 / 1e9 / PEAK_HBM_GBS,
+                             "formula": "14 B x seed items + 2 B x diagonal cells + target letters (SURVEY 8d)"},
+            "valu": {"instructions_per_cell": 5.5, "achieved_T_wave_lane_instr_per_s": 5.5 * cells / ms_ * 1e3 / 1e12,
+                     "peak": PEAK_VALU_LANEOPS / 1e12, "frac": 5.5 * cells / ms_ * 1e3 / PEAK_VALU_LANEOPS,
+                     "note": "diagonal scans: perm + extract + LDS gather + add + 2 max per cell, one wave64 instruction per 4 cycles per SIMD"},
+            "pmc": pmc.get("k_prefilter") if name.startswith("config2") else None}
+
+
+def config2_mu_letters():
+    """Mu letters of the seeded 11,211-chain synthetic .bca (BASELINE configs[2]'s input; host featurisation, no GPU)"""
+    import reseek_amd
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bench_search
+    import fixtures as fx
+    with tempfile.TemporaryDirectory() as td:
+        bca, fa = os.path.join(td, "s.bca"), os.path.join(td, "s.mu.fa")
+        bench_search.write_bca(bca, scop40_lengths(), np.random.default_rng(7))
+        reseek_amd.capi.bca_to_mu_fasta(bca, fa)
+        return fx.read_mu_fasta(fa)[1]
+
+
 def live_kernels(ctx, seqs, db, reps=3):
     """`roofline_live`: the kernels reseek -search actually runs (the gapless kernel of `value` has no caller in the
     reference), timed with the library's HIP events on the launch stream, on the same SCOP40-shaped set:
@@ -185,7 +265,7 @@ def live_kernels(ctx, seqs, db, reps=3):
     lens = np.array([len(s) for s in seqs], np.float64)
     tri_cells = float((lens * np.cumsum(lens[::-1])[::-1]).sum())
     out8 = torch.zeros((n, n), dtype=torch.uint8, device="cuda")
-    pmc = _load_json("r03_live_pmc.json") or {}
+    pmc = _verified_pmc()
     res = []
 
     def med(f):
@@ -205,7 +285,9 @@ def live_kernels(ctx, seqs, db, reps=3):
                 "achieved": tri_cells * 3.75 / ms * 1e3 / 1e12, "peak": PEAK_VALU_LANEOPS / 1e12,
                 "frac": tri_cells * 3.75 / ms * 1e3 / PEAK_VALU_LANEOPS,
                 "hbm": {"algorithmic_bytes": alg, "achieved_GBs": alg / ms * 1e3 / 1e9, "frac": alg / ms * 1e3 / 1e9 / PEAK_HBM_GBS},
-                "pmc": pmc.get("k_mu_sw")})
+                "pmc": pmc.get("k_mu_sw"),
+                "pmc_dispatch": "the counters are those of the LONGEST of the pass's three dispatches (k_mu_sw2 over the query pairs of the "
+                                "<= 416 class: ~188 of the pass's ~266 ms), not of the whole pass"})
     # --- survivors of the -sensitive filter -> float SW (per-pair kernel)
     cap = 4_000_000
     pq = torch.zeros(cap, dtype=torch.int32, device="cuda")
@@ -258,6 +340,20 @@ def live_kernels(ctx, seqs, db, reps=3):
     qa = np.repeat(order, n)
     qb = np.tile(np.arange(n, dtype=np.uint32), nq)
     res.append(sw_entry("k_sw_qp", "float SW + trace, %d queries x %d chains (query-profile kernel)" % (nq, n), qa, qb, 0.0, 23.0, False))      # 278 VALU instructions per 12-row column in the ISA of the hot loop
+    dbs.close()
+    del out8, pq, pt
+    torch.cuda.empty_cache()
+    # --- k_prefilter: the `-fast -db` prefilter scan on the two letter statistics it meets
+    try:
+        res.append(prefilter_entry(ctx, "config2: Mu letters of the 11,211-chain synthetic .bca (low complexity: ~430 seed items per pair)",
+                                   "k-mer prefilter scan, all chains vs the idxt neighbourhood index of the same set", config2_mu_letters(), pmc))
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import fixtures as fx
+        res.append(prefilter_entry(ctx, "real SCOP40 Mu letters (tests/golden/scop40.mu.fa.gz: ~21 seed items per pair)",
+                                   "k-mer prefilter scan, all chains vs the idxt neighbourhood index of the same set",
+                                   fx.read_mu_fasta("scop40.mu.fa.gz")[1], pmc))
+    except Exception as e:  # noqa: BLE001
+        sys.stderr.write("bench: prefilter live entry failed: %s\n" % e)
     return res
 
 
@@ -482,7 +578,8 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    # RSK_DIST_FORCE=1: the collective path with a process group of ONE rank (RCCL on a single-GPU box; tests/test_gpu_rccl.py)
+    if world > 1 or os.environ.get("RSK_DIST_FORCE", "") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if one_device:
@@ -505,6 +602,14 @@ def main():
     else:
         lo, hi = 0, n
     nb = hi - lo
+    # the shares of the DP cells the same cut gives every rank at N = 2 / 4 / 8 (an imbalance is visible without a profiler)
+    cumc = np.concatenate([[0.0], np.cumsum(lens * np.cumsum(lens))])
+    sharding_cells = {}
+    for N in (2, 4, 8):
+        bd = [int(np.searchsorted(cumc, cumc[-1] * r / N, side="left")) for r in range(N)] + [n]
+        share = [(cumc[bd[r + 1]] - cumc[bd[r]]) / cumc[-1] for r in range(N)]
+        sharding_cells["n%d" % N] = {"cell_share_per_rank": [round(x, 5) for x in share], "max_over_mean": round(max(share) * N, 4),
+                                     "target_ranges": [[bd[r], bd[r + 1]] for r in range(N)]}
     stream = torch.cuda.current_stream()
     ctx = reseek_amd.Ctx(local, stream=stream.cuda_stream)
     db = reseek_amd.Db.from_mu_seqs(ctx, seqs[lo:hi]) if nb else None          # inputs resident in HBM before the timed region
@@ -634,6 +739,8 @@ def main():
                        "hit_records": {"min_score": HIT_MIN, "rank0_per_step": int(cnt.sum().item()),
                                        "gathered_all_ranks": int(summary[0].item()) if dist is not None else None,
                                        "note": "appended by the kernel (rsk_mu_gapless_hits_dev) next to the dense uint16 matrix"},
+                       "sharding_cells": sharding_cells,
+                       "collective_backend": (dist.get_backend() if dist is not None else None),
                        "sharding": "one independent set per GPU (--weak)" if args.weak else
                                    "one set; rank r takes the targets [lo, hi) of the triangle, ranges balanced by DP cells: "
                                    "rectangle chains[0:lo) x chains[lo:hi) + triangle of chains[lo:hi); no data-path collective, "
@@ -643,12 +750,16 @@ def main():
                 "achieved": k_cells_per_s * GAPLESS_LANEOPS_PER_CELL / 1e12, "peak": PEAK_VALU_LANEOPS / 1e12, "unit": "T lane-ops/s",
                 "frac": k_cells_per_s * GAPLESS_LANEOPS_PER_CELL / PEAK_VALU_LANEOPS,
                 "lane_ops_per_cell": GAPLESS_LANEOPS_PER_CELL,
+                "frac_vs_guide_vop2_rate": k_cells_per_s * GAPLESS_LANEOPS_PER_CELL / (2.0 * PEAK_VALU_LANEOPS),
+                "peak_guide_vop2_rate": 2.0 * PEAK_VALU_LANEOPS / 1e12,
                 "note": "work = 0.75 packed VALU lane-op per DP cell: scores as n/2048 in packed half floats (exact), per ring "
                         "dword and pair of target letters two v_pk_add_f16 clamp (add + floor at 0) and one v_pk_maximum3_f16 "
                         "(r02: packed int16, add-saturate + max per letter = 1 lane-op per cell, 31 T cells/s); pairs that reach "
                         "the clamp's ceiling (2048) are rescored in integers by the wave that found them; peak = VOP3P issue "
-                        "rate 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz (ubench: 35-37); LDS 2 B/cell; kernel time from HIP "
-                        "events on the launch stream",
+                        "rate 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz = 39.3 T lane-ops/s (ubench: 35-37).  The guide's plain-VOP2 rate "
+                        "(157.3 TFLOP/s / 2 = 78.6 T lane-ops/s: one wave64 instruction per 2 cycles, which only runs of one identical "
+                        "VOP2 opcode reach on this part) is twice that: against it the same work is `frac_vs_guide_vop2_rate`.  LDS "
+                        "2 B/cell; kernel time from HIP events on the launch stream",
                 "kernel_ms": kernel_ms, "cell_slots_issued": slots, "slot_efficiency": cells / max(1, slots),
                 "kernel_ms_hit_records_only": kernel_ms_hits_only,
                 "hbm": {"bound": "hbm", "achieved": alg_bytes / (kernel_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,

@@ -202,10 +202,12 @@ int rsk_mu_filter_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, const ui
  * MuXDrop (:105).  found[p] = 1 iff some seed HSP of pair p scores >= min_hsp_score (m_MKF_MinHSPScore, 50);
  * for those pairs a record is appended (any order): rec_pair = p, rec_nkept = number of HSPs the reference
  * keeps (strictly improving score, new Loi, in (PosT, slot) order), rec_kept[r*cap*4 ...] = their
- * (Loi, Loj, Len, Score), at most cap (<= 32) stored; a count > cap is an upper bound (redo that pair
- * with the host path).  *nrecords may exceed max_records (then enlarge and
- * call again).  x1 = m_MKF_X1 (8).  Chaining of the kept HSPs stays in host/dssaligner.cpp; the gapped
- * extensions of the found pairs are rsk_mkf_align_pairs / rsk_xdrop_pairs below. */
+ * (Loi, Loj, Len, Score), at most cap stored (cap <= 1024; the search runs cap = 32 and redoes a pair whose count
+ * exceeds it with cap = 1024 -- the keep rule's "new Loi" test only sees the stored entries, so a count > cap is an upper
+ * bound, not a result).  *nrecords may exceed max_records (then enlarge and call again).  x1 = m_MKF_X1 (8).
+ * Chaining of the kept HSPs: k_mkf_chain inside rsk_mkf_chain_align_pairs (host/dssaligner.cpp keeps the libc-qsort form
+ * for pairs whose chain depends on qsort's order of tied end points); the gapped extensions of the found pairs are
+ * rsk_mkf_align_pairs / rsk_xdrop_pairs below. */
 int rsk_mkf_seed_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, const uint32_t *iq, const uint32_t *it,
                        size_t npairs, int x1, int min_hsp_score, uint32_t cap, uint8_t *found, size_t max_records,
                        size_t *nrecords, uint32_t *rec_pair, uint32_t *rec_nkept, int32_t *rec_kept);
@@ -275,6 +277,10 @@ int rsk_mkf_chain_align_pairs(rsk_ctx *ctx, const rsk_db *a, const rsk_db *b, co
  * At most 65535 queries (uint16 query index in the reference as well). */
 int rsk_mu_prefilter_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int neighbourhood, uint32_t *d_out_q,
                          uint32_t *d_out_t, uint32_t *d_out_score, size_t capacity, uint32_t *d_n);
+/* Work counters of the last rsk_mu_prefilter_dev call (any pointer may be NULL): seed items = (target position, posting)
+ * pairs read (prefiltermu.cpp:213-260), postings of the query index, two-hit diagonals found (twohitdiag.cpp:368-398) and
+ * the cells their FindHSP scans visited (prefiltermu.cpp:12-48). */
+int rsk_mu_prefilter_last_work(rsk_ctx *ctx, uint64_t *seed_items, uint64_t *index_postings, uint64_t *twohit_diagonals, uint64_t *diagonal_cells);
 /* RankedScoresBag (rankedscoresbag.cpp:34-51,185-231) on host arrays: per query keep the top
  * rsb_size targets exactly as the reference does with -threads 1 (truncation at 2B, quicksort tie
  * order).  out_* (capacity n) may be NULL; *nout = survivors.  tmp_tsv_path (optional) receives the
@@ -376,6 +382,11 @@ typedef struct rsk_search_opts {
     const char *devices;       /* multi-GPU (ONE process): "0,1,2,3" = the call drives these devices, one context + host thread */
                                /* each, shards as above, one hits file (an id may repeat: several contexts on one device).  */
                                /* NULL = the environment's RSK_DEVICES if set, else the device of ctx only.                  */
+    int hits_digest;           /* != 0: out_tsv receives ONE line "digest\t<lines>\t<bytes>\t<sum>\t<xor>" instead of the hit     */
+                               /* table: number of hit lines, their bytes, and the sum / xor (hex) of a 64-bit hash of every line */
+                               /* -- order-independent, so the digests of the shards of a search add up (lines, bytes, sum) /    */
+                               /* xor together to the digest of the unsharded table.  For tables too large to keep (a            */
+                               /* -verysensitive search against a PDB-sized DB writes ~30 GB).  Not on the -fast -db path.       */
 } rsk_search_opts;
 int rsk_search(rsk_ctx *ctx, const char *query_path, const char *db_path, const rsk_search_opts *opts,
                const char *out_tsv, uint64_t *nhits, uint64_t *stats8);

@@ -32,6 +32,7 @@
 #include "dss.h"
 #include "dssaligner.h"
 #include "museqsource.h"
+#include "seqinfo.h"
 #include "prefiltermu.h"
 #include "seqdb.h"
 #include "chainreader2.h"
@@ -41,6 +42,7 @@
 #include "mx.h"
 #include "seqdb.h"
 #include "alpha.h"
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 
@@ -842,6 +844,94 @@ static void cmd_prefhood(const string &QFa, const string &TFa, const string &Sco
 	}
 
 
+// prefrange / rsbreplay: stage 1 of `-search Q.bca -db DB.bca -fast` (search.cpp:76-111) cut into target ranges so that
+// several one-thread processes share it (the literal command takes hours on one thread for an 11,211-chain set and its
+// bags are only reproducible with one thread).  The reference's own objects do all the work:
+//   prefrange Q.bca DB.bca lo hi out.bin : MuSeqSource::OpenChains + SeqDB::FromSS / ToLetters for the queries exactly as
+//     cmd_search hands them to MuPreFilter (search.cpp:91-98), the MuDex / MerMx set-up of MuPreFilter (muprefilter.cpp:70-110),
+//     then PrefilterMu::Search (prefiltermu.cpp:382) for the targets lo <= index < hi of the DB in file order -- with a bag that
+//     never truncates (m_B huge), so PrefilterMu::m_RSB ends up holding EVERY (query, target, score) the scan produced for
+//     these targets.  They are written as uint32 triples.
+//   rsbreplay NQ B out.tsv in1.bin in2.bin ... : the triples of all ranges, fed to the reference's RankedScoresBag::AddScore in
+//     target order (what one thread walking the DB does; the order among the queries of ONE target does not matter, they are
+//     different bags), then RankedScoresBag::ToTsv = the hand-off file.
+// make_full_golden.py checks this route against the literal one-thread command on a sample before using it.
+static void cmd_prefrange(const string &QBca, const string &DBBca, uint Lo, uint Hi, const string &OutFN)
+	{
+	DSSParams Params;
+	Params.SetDSSParams(DM_UseCommandLineOption);
+	MuSeqSource QSS;
+	QSS.OpenChains(QBca, Params);
+	SeqDB QDB;
+	QDB.FromSS(QSS);
+	const uint QSeqCount = QDB.GetSeqCount();
+	if (opt(idxq)) g_QueryNeighborhood = true;
+	else if (opt(idxt)) g_QueryNeighborhood = false;
+	else g_QueryNeighborhood = (QSeqCount <= MAX_QUERY_CHAINS_FOR_QUERY_NEIGHBORHOOD);
+	const uint k = MuDex::m_k;
+	QDB.ToLetters(g_CharToLetterMu);
+	PrefilterMu::m_RSB.m_B = 0x3FFFFFFF;                 // no truncation: the bag keeps every triple of this range
+	PrefilterMu::m_RSB.Init(QSeqCount);
+	const MerMx &ScoreMx = GetMuMerMx(k);
+	MuDex QKmerIndex;
+	QKmerIndex.m_AddNeighborhood = g_QueryNeighborhood;
+	QKmerIndex.m_KmerSelfScores = ScoreMx.BuildSelfScores_Kmers();
+	QKmerIndex.m_MinKmerSelfScore = MIN_KMER_PAIR_SCORE;
+	QKmerIndex.FromSeqDB(QDB);
+	PrefilterMu Pref;
+	Pref.m_OneHitDiag = false;
+	Pref.m_ScoreMx = &ScoreMx;
+	Pref.m_QKmerIndex = &QKmerIndex;
+	Pref.m_KmerSelfScores = QKmerIndex.m_KmerSelfScores;
+	Pref.SetQDB(QDB);
+	MuSeqSource DBSS;
+	DBSS.OpenChains(DBBca, Params);
+	DBSS.m_ASCII = false;
+	ObjMgr OM;
+	for (uint TIdx = 0; TIdx < Hi; ++TIdx)
+		{
+		SeqInfo *SI = OM.GetSeqInfo();
+		if (!DBSS.GetNext(SI)) { OM.Down(SI); break; }
+		if (TIdx >= Lo && SI->m_L != 0)
+			Pref.Search(TIdx, string(SI->m_Label), SI->m_Seq, SI->m_L);
+		OM.Down(SI);
+		}
+	FILE *f = CreateStdioFile(OutFN);
+	uint64_t n = 0;
+	const RankedScoresBag &B = PrefilterMu::m_RSB;
+	for (uint q = 0; q < QSeqCount; ++q)
+		for (size_t i = 0; i < B.m_QueryIdxToScoreVec[q].size(); ++i)
+			{
+			w32(f, q); w32(f, B.m_QueryIdxToTargetIdxVec[q][i]); w32(f, B.m_QueryIdxToScoreVec[q][i]);
+			++n;
+			}
+	CloseStdioFile(f);
+	fprintf(stderr, "prefrange [%u, %u): %llu triples\n", Lo, Hi, (unsigned long long) n);
+	}
+
+static void cmd_rsbreplay(uint NQ, uint B, const string &OutFN, const vector<string> &Ins)
+	{
+	struct Tr { uint32_t q, t, s; };
+	vector<Tr> All;
+	for (const string &fn : Ins)
+		{
+		FILE *f = fopen(fn.c_str(), "rb");
+		if (!f) { fprintf(stderr, "cannot open %s\n", fn.c_str()); exit(2); }
+		Tr x;
+		while (fread(&x, sizeof x, 1, f) == 1) All.push_back(x);
+		fclose(f);
+		}
+	std::stable_sort(All.begin(), All.end(), [](const Tr &a, const Tr &b) { return a.t < b.t; });
+	RankedScoresBag RSB;
+	RSB.m_B = B;
+	RSB.Init(NQ);
+	for (const Tr &x : All) RSB.AddScore(x.q, x.t, (uint16_t) x.s);
+	FILE *f = CreateStdioFile(OutFN);
+	RSB.ToTsv(f);
+	CloseStdioFile(f);
+	fprintf(stderr, "rsbreplay: %zu triples\n", All.size());
+	}
+
 // xdropkat: the reference's own X-drop / SW self-test vectors (test_xdrop.cpp:177-187: three peptide pairs through
 // SWFast, XDropFwd, XDropBwd, MergeFwdBwd with BLOSUM62, Open -3, Ext -1, X 8; swgaplessprof.cpp:158-166: six
 // peptide pairs through SWGapless) plus <nrandom> random peptide pairs run the same way.  The fixture holds the
@@ -989,6 +1079,10 @@ int main(int argc, char **argv)
 		cmd_d1pairs(A[0], A[1], (uint) atoi(A[2].c_str()));
 	else if (Cmd == "prefhood" && A.size() == 4)
 		cmd_prefhood(A[0], A[1], A[2], A[3]);
+	else if (Cmd == "prefrange" && A.size() == 5)
+		cmd_prefrange(A[0], A[1], (uint) atoi(A[2].c_str()), (uint) atoi(A[3].c_str()), A[4]);
+	else if (Cmd == "rsbreplay" && A.size() >= 4)
+		cmd_rsbreplay((uint) atoi(A[0].c_str()), (uint) atoi(A[1].c_str()), A[2], vector<string>(A.begin() + 3, A.end()));
 	else if (Cmd == "xdrophsp" && A.size() == 3)
 		cmd_xdrophsp(A[0], A[1], (uint) atoi(A[2].c_str()));
 	else if (Cmd == "xdropkat" && A.size() == 3)

@@ -47,6 +47,7 @@ SIGNATURES = {
                                     C.c_void_p]),
     "rsk_mu_filter_last_work": (C.c_int, [C.c_void_p, u64p, u64p]),
     "rsk_pairs_sort_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32]),
+    "rsk_mu_prefilter_last_work": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_uint64)] * 4),
     "rsk_triples_sort_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rsk_rsb_select_keys": (C.c_int, [C.POINTER(C.c_uint64), C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                       C.POINTER(C.c_uint32), C.POINTER(C.c_size_t), C.c_char_p]),
@@ -112,7 +113,7 @@ class SearchOpts(C.Structure):
                 ("mints", C.c_double), ("mints_set", C.c_int), ("pvalue", C.c_double), ("pvalue_set", C.c_int),
                 ("noself", C.c_int), ("selfrev0", C.c_int), ("idx_mode", C.c_int), ("rsb_size", C.c_uint32),
                 ("dbmu", C.c_char_p), ("keeptmp", C.c_int), ("shard_index", C.c_uint32), ("shard_count", C.c_uint32),
-                ("devices", C.c_char_p)]
+                ("devices", C.c_char_p), ("hits_digest", C.c_int)]
 
 
 SIGNATURES["rsk_search"] = (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(SearchOpts), C.c_char_p, C.POINTER(C.c_uint64),
@@ -129,6 +130,23 @@ SIGNATURES["rsk_dss_densities_host"] = (C.c_int, [f32p, f32p, f32p, C.c_uint32, 
 SIGNATURES["rsk_shard_range"] = (C.c_int, [C.c_int, u32p, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)])
 SIGNATURES["rsk_bca_copy"] = (C.c_int, [C.c_char_p, C.c_char_p])
 SIGNATURES["rsk_bca_to_mu_fasta"] = (C.c_int, [C.c_char_p, C.c_char_p])
+
+
+def read_hits_digest(path):
+    """the line rsk_search writes with hits_digest=1 -> (lines, bytes, sum, xor) as ints"""
+    f = open(path).read().split("\t")
+    assert f[0] == "digest", f
+    return int(f[1]), int(f[2]), int(f[3], 16), int(f[4], 16)
+
+
+def combine_hits_digests(ds):
+    """digest of the union of the tables whose digests are given (shards of one search)"""
+    lines = sum(d[0] for d in ds); nbytes = sum(d[1] for d in ds)
+    s = sum(d[2] for d in ds) & 0xFFFFFFFFFFFFFFFF
+    x = 0
+    for d in ds:
+        x ^= d[3]
+    return lines, nbytes, s, x
 
 
 class RskError(RuntimeError):
@@ -414,6 +432,12 @@ class Ctx:
     def mu_prefilter_dev(self, q, t, d_q, d_t, d_score, capacity, d_n, neighbourhood=0):
         _check(lib().rsk_mu_prefilter_dev(self.h, q.h, t.h, neighbourhood, C.c_void_p(d_q), C.c_void_p(d_t), C.c_void_p(d_score),
                                           capacity, C.c_void_p(d_n)))
+
+    def mu_prefilter_last_work(self):
+        """(seed items, index postings, two-hit diagonals, diagonal cells scored) of the last mu_prefilter_dev call"""
+        v = [C.c_uint64() for _ in range(4)]
+        _check(lib().rsk_mu_prefilter_last_work(self.h, *[C.byref(x) for x in v]))
+        return tuple(x.value for x in v)
 
     def mu_gapless_last_work(self):
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()

@@ -828,6 +828,33 @@ void RunMKFPairs(rsk_ctx *Ctx, const DSSParams &P, const std::string &Columns, D
     }
     std::sort(recs.begin(), recs.end(), [](const Rec &x, const Rec &y) { return x.pair < y.pair; });
     if (getenv("RSK_TRACE")) fprintf(stderr, "[RunMKFPairs] %zu pairs, %zu with a seed HSP\n", n, recs.size());
+    {
+        // a seed list that did not fit the record (more than CAP strictly improving HSPs): the same kernel again with room
+        // for 1024 (r01-r03 re-seeded such a pair on the host with a copy of MuKmerFilter::Align)
+        std::vector<size_t> redo;
+        for (size_t r = 0; r < recs.size(); ++r)
+            if (recs[r].nkept > CAP) redo.push_back(r);
+        if (!redo.empty()) {
+            const uint32_t BIG = 1024;
+            const size_t m = redo.size();
+            std::vector<uint32_t> iq(m), it(m), rp(m), rn(m);
+            std::vector<uint8_t> found(m);
+            std::vector<int32_t> rk(m * (size_t) BIG * 4);
+            for (size_t k = 0; k < m; ++k) { iq[k] = Pairs[recs[redo[k]].pair].first; it[k] = Pairs[recs[redo[k]].pair].second; }
+            size_t nrec = 0;
+            check(rsk_mkf_seed_pairs(Ctx, SrcA.m_Db, SrcB.m_Db, iq.data(), it.data(), m, P.m_MKF_X1, P.m_MKF_MinHSPScore, BIG, found.data(), m, &nrec,
+                                     rp.data(), rn.data(), rk.data()),
+                  "rsk_mkf_seed_pairs");
+            if (nrec != m) throw std::runtime_error("RunMKFPairs: the re-seeded pairs lost their seed HSPs");
+            for (size_t r = 0; r < nrec; ++r) {
+                if (rn[r] > BIG) throw std::runtime_error("RunMKFPairs: a pair keeps more than 1024 seed HSPs");
+                Rec &R = recs[redo[rp[r]]];
+                R.nkept = rn[r];
+                R.kept.assign(rk.data() + r * (size_t) BIG * 4, rk.data() + r * (size_t) BIG * 4 + 4 * (size_t) rn[r]);
+            }
+            if (getenv("RSK_TRACE")) fprintf(stderr, "[RunMKFPairs] %zu pairs re-seeded with room for %u HSPs\n", m, BIG);
+        }
+    }
     const auto t_host0 = std::chrono::steady_clock::now();
     const unsigned T = (unsigned) std::max<size_t>(1, std::min<size_t>((size_t) HostThreads(128), recs.size() / 8 + 1));
     auto parallel = [&](const std::function<void(DSSAligner &, size_t, unsigned)> &fn) {
@@ -854,15 +881,10 @@ void RunMKFPairs(rsk_ctx *Ctx, const DSSParams &P, const std::string &Columns, D
                 if (!e.empty()) throw std::runtime_error(e);
         }
     };
-    auto set_pair = [&](DSSAligner &DA, size_t r) {
-        const uint i = Pairs[recs[r].pair].first, j = Pairs[recs[r].pair].second;
-        DA.SetQuery(*SrcA.m_DBChains[i], SrcA.m_DBProfiles[i], SrcA.m_DBMuLettersVec[i], SrcA.m_DBMuKmersVec[i], SrcA.m_DBSelfRevScores[i]);
-        DA.SetTarget(*SrcB.m_DBChains[j], SrcB.m_DBProfiles[j], SrcB.m_DBMuLettersVec[j], SrcB.m_DBMuKmersVec[j], SrcB.m_DBSelfRevScores[j]);
-    };
     // stage 1 + 2 (GPU, one batch): the seed HSPs of every record -> chain (Chainer::Chain), mega-HSP scores + gates, start of
-    // the gapped extensions, both extensions, merge, statistics (rsk_mkf_chain_align_pairs).  Two kinds of pairs make a second,
-    // small batch after a host step: records whose seed list was truncated on the device (MuKmerFilter::Align re-seeds them)
-    // and pairs whose chain depends on libc qsort's order of equal end points (status 3) -- both chained by ChainHSPs here.
+    // the gapped extensions, both extensions, merge, statistics (rsk_mkf_chain_align_pairs).  One kind of pair makes a second,
+    // small batch after a host step: pairs whose chain depends on libc qsort's order of equal end points (status 3) are
+    // chained by ChainHSPs (the reference's own outcome there is its qsort's) here.
     struct Chained { std::vector<int32_t> lo_a, lo_b, len; };
     std::vector<size_t> slot(recs.size(), (size_t) -1);
     std::vector<uint32_t> xa, xb, first(1, 0);
@@ -871,7 +893,6 @@ void RunMKFPairs(rsk_ctx *Ctx, const DSSParams &P, const std::string &Columns, D
     size_t xbytes = 0;
     for (size_t r = 0; r < recs.size(); ++r) {
         const Rec &R = recs[r];
-        if (R.nkept > CAP) { host_recs.push_back(r); continue; }
         slot[r] = xa.size();
         const uint i = Pairs[R.pair].first, j = Pairs[R.pair].second;
         xa.push_back(i); xb.push_back(j);
@@ -911,11 +932,7 @@ void RunMKFPairs(rsk_ctx *Ctx, const DSSParams &P, const std::string &Columns, D
                 if (h >= host_recs.size()) break;
                 const size_t r = host_recs[h];
                 const Rec &R = recs[r];
-                if (R.nkept > CAP) {                                      // seed list truncated on the device: seeds from MuKmerFilter::Align
-                    set_pair(DA, r);
-                    DA.m_MKF.Align(*DA.m_MuLettersB, *DA.m_MuKmersB);
-                } else
-                    DA.m_MKF.SetSeedHSPs(R.kept.data(), R.nkept);
+                DA.m_MKF.SetSeedHSPs(R.kept.data(), R.nkept);
                 if (DA.m_MKF.m_BestChainScore <= 0) continue;             // PostAlignMKF dssaligner.cpp:1397
                 Chained &C = chains[h];
                 C.lo_a.assign(DA.m_MKF.m_ChainHSPLois.begin(), DA.m_MKF.m_ChainHSPLois.end());
@@ -959,7 +976,7 @@ void RunMKFPairs(rsk_ctx *Ctx, const DSSParams &P, const std::string &Columns, D
                   "rsk_mkf_align_pairs");
     }
     if (getenv("RSK_TRACE") && !host_recs.empty())
-        fprintf(stderr, "[RunMKFPairs] %zu pairs chained on the host (truncated seed lists / chains tied under qsort)\n", host_recs.size());
+        fprintf(stderr, "[RunMKFPairs] %zu pairs chained on the host (chains tied under qsort)\n", host_recs.size());
     const auto t_host1 = std::chrono::steady_clock::now();
     // stage 3 (host threads): the aligned pairs become DSSAligner results and go to the caller
     std::mutex lock;
@@ -1696,12 +1713,63 @@ int ParseSearchOpts(const rsk_search_opts *opts, SearchOptions &o, const char *w
     if (RSK_OPT_HAS(shard_index)) o.shard_index = opts->shard_index;
     if (RSK_OPT_HAS(shard_count)) o.shard_count = opts->shard_count;
     if (RSK_OPT_HAS(devices) && opts->devices) o.devices = opts->devices;
+    if (RSK_OPT_HAS(hits_digest)) o.hits_digest = opts->hits_digest != 0;
 #undef RSK_OPT_HAS
     return RSK_OK;
 }
 void FastDbOnContexts(const std::vector<rsk_ctx *> &Ctx, const char *query_path, const char *db_path, const SearchOptions &o, const char *out_tsv,
                       const char *tmp_tsv, uint64_t *nhits, uint64_t *stats8);
 }
+
+// rsk_search_opts.hits_digest: the hit lines go to a digest instead of a file.  A `-verysensitive` search of 1k queries
+// against a PDB-sized DB writes 7e8 lines (30 GB); to compare the union of 8 shards with the unsharded table only an
+// order-independent summary is needed: number of lines, their bytes, and the sum and xor of a 64-bit hash of every line.
+// The FILE the searchers write to is a glibc cookie stream that cuts the byte stream at newlines (stdio's buffer
+// boundaries are arbitrary) and hashes each line; out_tsv then receives ONE line "digest\t<lines>\t<bytes>\t<sum>\t<xor>".
+namespace {
+struct HitsDigest {
+    uint64_t lines = 0, bytes = 0, sum = 0, x = 0;
+    std::string carry;
+    static uint64_t hash_line(const char *p, size_t n)
+    {
+        uint64_t h = 0x9E3779B97F4A7C15ull ^ (n * 0xD6E8FEB86659FD93ull);
+        auto mix = [&](uint64_t v) { h = (h ^ v) * 0xFF51AFD7ED558CCDull; h ^= h >> 32; };
+        for (; n >= 8; p += 8, n -= 8) { uint64_t v; memcpy(&v, p, 8); mix(v); }
+        if (n) { uint64_t v = 0; memcpy(&v, p, n); mix(v); }
+        h *= 0xC4CEB9FE1A85EC53ull;
+        return h ^ (h >> 29);
+    }
+    void line(const char *p, size_t n) { const uint64_t h = hash_line(p, n); ++lines; bytes += n + 1; sum += h; x ^= h; }
+    void feed(const char *p, size_t n)
+    {
+        const char *end = p + n;
+        if (!carry.empty()) {
+            const char *nl = (const char *) memchr(p, '\n', n);
+            if (!nl) { carry.append(p, n); return; }
+            carry.append(p, (size_t) (nl - p));
+            line(carry.data(), carry.size());
+            carry.clear();
+            p = nl + 1;
+        }
+        while (p < end) {
+            const char *nl = (const char *) memchr(p, '\n', (size_t) (end - p));
+            if (!nl) { carry.assign(p, (size_t) (end - p)); return; }
+            line(p, (size_t) (nl - p));
+            p = nl + 1;
+        }
+    }
+    static ssize_t cookie_write(void *c, const char *buf, size_t n) { ((HitsDigest *) c)->feed(buf, n); return (ssize_t) n; }
+    FILE *open()
+    {
+        cookie_io_functions_t io = {};
+        io.write = &HitsDigest::cookie_write;
+        FILE *f = fopencookie(this, "w", io);
+        if (f) setvbuf(f, nullptr, _IOFBF, 8u << 20);
+        return f;
+    }
+};
+struct FileCloser { FILE *f; ~FileCloser() { if (f) fclose(f); } };
+}   // namespace
 
 static bool keep_tmp_env() { const char *e = getenv("RSK_KEEPTMP"); return e && *e && *e != '0'; }    // -keeptmp
 
@@ -1738,6 +1806,7 @@ static int search_impl(rsk_ctx *ctx, const char *query_rskdb, const char *db_rsk
         DBS.Setup();
         for (USERFIELD u : DBS.m_DA.m_UFs)
             if (u == UF_Undefined) { rsk_set_error("rsk_search_rskdb: invalid -columns field"); return RSK_E_INVALID; }
+        if (prefilter_path && o.hits_digest) { rsk_set_error("rsk_search: hits_digest is not available on the -fast -db path"); return RSK_E_INVALID; }
         if (prefilter_path && o.shard_count > 1) {
             rsk_set_error("rsk_search: shards are not supported on the -fast -db path (the per-query top-B of the prefilter is a reduction over all targets)");
             return RSK_E_INVALID;
@@ -1765,10 +1834,12 @@ static int search_impl(rsk_ctx *ctx, const char *query_rskdb, const char *db_rsk
             }
             return RSK_OK;
         }
-        FILE *f = fopen(out_tsv, "w");
+        HitsDigest Digest;
+        FILE *f = o.hits_digest ? Digest.open() : fopen(out_tsv, "w");
         if (!f) { rsk_set_error("rsk_search_rskdb: cannot create %s", out_tsv); return RSK_E_INVALID; }
+        FileCloser closer{ f };                          // closed on every exit path
         DBS.m_fTsv = f;
-        if (o.shard_count > 1 && o.shard_index >= o.shard_count) { fclose(f); rsk_set_error("rsk_search: shard_index >= shard_count"); return RSK_E_INVALID; }
+        if (o.shard_count > 1 && o.shard_index >= o.shard_count) { rsk_set_error("rsk_search: shard_index >= shard_count"); return RSK_E_INVALID; }
         if (!have_db) {
             if (o.shard_count > 1) DBS.RunSelfShard(o.shard_index, o.shard_count);
             else DBS.RunSelf();
@@ -1809,7 +1880,16 @@ static int search_impl(rsk_ctx *ctx, const char *query_rskdb, const char *db_rsk
                 DBS.RunQuery(Src);
             }
         }
-        fclose(f);
+        closer.f = nullptr;
+        if (fclose(f) != 0) { rsk_set_error("rsk_search: writing %s failed", out_tsv); return RSK_E_INVALID; }
+        if (o.hits_digest) {
+            if (!Digest.carry.empty()) Digest.line(Digest.carry.data(), Digest.carry.size());
+            FILE *g = fopen(out_tsv, "w");
+            if (!g) { rsk_set_error("rsk_search: cannot create %s", out_tsv); return RSK_E_INVALID; }
+            fprintf(g, "digest\t%llu\t%llu\t%016llx\t%016llx\n", (unsigned long long) Digest.lines, (unsigned long long) Digest.bytes,
+                    (unsigned long long) Digest.sum, (unsigned long long) Digest.x);
+            fclose(g);
+        }
         if (nhits) *nhits = DBS.m_HitCount;
         if (stats8) {
             stats8[0] = DBS.m_ProcessedPairCount; stats8[1] = DBS.m_AlnCount; stats8[2] = DBS.m_MuFilterInputCount;

@@ -118,50 +118,8 @@ void DSS::SetSS()
     if (m_SS.empty()) m_Chain->GetSS(m_SS);
 }
 
-uint DSS::CalcNEN(uint Pos) const                                     // dss.cpp:417-440: nearest residue within +-100, |offset| > 12
-{
-    const uint L = GetSeqLength();
-    int iLo = (int) Pos - m_NEN_W;
-    if (iLo < 0) iLo = 0;
-    int iHi = (int) Pos + m_NEN_W;
-    if (iHi >= (int) L) iHi = (int) L - 1;
-    double MinDist = 999;
-    uint MinPos = UINT_MAX;
-    for (uint Pos2 = (uint) iLo; Pos2 <= (uint) iHi; ++Pos2) {
-        if (Pos2 + m_NEN_w >= Pos && Pos2 <= Pos + m_NEN_w) continue;
-        const double Dist = m_Chain->GetDist(Pos, Pos2);
-        if (Dist < MinDist) { MinDist = Dist; MinPos = Pos2; }
-    }
-    return MinPos;
-}
-
-uint DSS::CalcREN(uint Pos, uint NEN) const                           // dss.cpp:374-415: nearest on the other side of Pos
-{
-    if (NEN == UINT_MAX) return UINT_MAX;
-    const uint L = GetSeqLength();
-    int iLo, iHi;
-    if (NEN > Pos) {
-        iLo = (int) Pos - m_NEN_W;
-        if (iLo < 0) iLo = 0;
-        iHi = (int) Pos - 1;
-    } else {
-        iLo = (int) Pos + 1;
-        iHi = (int) Pos + m_NEN_W;
-        if (iHi >= (int) L) iHi = (int) L - 1;
-    }
-    if (iHi < 0) return UINT_MAX;
-    double MinDist = 999;
-    uint MinPos = UINT_MAX;
-    for (uint Pos2 = (uint) iLo; Pos2 <= (uint) iHi; ++Pos2) {
-        if (Pos2 + m_NEN_w >= Pos && Pos2 <= Pos + m_NEN_w) continue;
-        const double Dist = m_Chain->GetDist(Pos, Pos2);
-        if (Dist < MinDist) { MinDist = Dist; MinPos = Pos2; }
-    }
-    return MinPos;
-}
-
-// First index k in [0, n) whose sqrtf(d2[k]) is the smallest (what the running "Dist < MinDist" loops of CalcNEN /
-// CalcREN keep), or -1 when the range is empty or nothing is below the initial MinDist of 999.  sqrtf is monotone, so
+// First index k in [0, n) whose sqrtf(d2[k]) is the smallest (what the running "Dist < MinDist" loops of the reference's CalcNEN /
+// CalcREN, dss.cpp:374-440, keep), or -1 when the range is empty or nothing is below the initial MinDist of 999.  sqrtf is monotone, so
 // the smallest distance is sqrtf(min d2); several different d2 can round to that same float, they all lie within a
 // few ulp of the minimum: candidates are d2 <= min * (1 + 1e-6), each confirmed with its own sqrtf.
 static int FirstNearest(const float *d2, int n)
@@ -189,7 +147,7 @@ static int FirstNearest(const float *d2, int n)
     return -1;                                                        // not reached: the minimum itself qualifies
 }
 
-// dss.cpp:374-440 for every position (CalcNEN / CalcREN above are the per-position statement of the same): the
+// dss.cpp:374-440 (CalcNEN: nearest residue within +-100 with |offset| > 12; CalcREN: the nearest on the other side) for every position: the
 // squared distances of the +-100 window are computed once per position as a vectorisable loop (same float
 // operations per element as GetDist, minus the square root), NEN is the nearest of the whole window, REN the
 // nearest of the part of it on the other side of Pos.

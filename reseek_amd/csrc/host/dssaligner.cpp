@@ -305,164 +305,120 @@ void DSSAligner::CalcEvalue()
 }
 
 // ---------------------------------------------------------------------------------------------
-// MuKmerFilter (mukmerfilter.cpp)
+// MuKmerFilter (mukmerfilter.cpp): the per-pair form of the long-chain seeding.  No seeding or extension loop runs on the
+// host (r04): SetQ only remembers the query, Align is a device batch of ONE pair through the entry point the search uses
+// (rsk_mkf_seed_pairs: compact 3-mer table, ungapped X-drop, keep rule -- k_mkf.hip), then ChainHSPs.
 // ---------------------------------------------------------------------------------------------
 void MuKmerFilter::ResetQ()
 {
-    if (m_ptrMuKmersQ != nullptr) {
-        for (uint Kmer : *m_ptrMuKmersQ)
-            for (uint w = 0; w < HASHW; ++w) m_KmerHashTableQ[HASHW * Kmer + w] = 0xffff;
-        m_ptrMuKmersQ = nullptr;
-        m_ptrMuLettersQ = nullptr;
-    }
+    m_ptrMuKmersQ = nullptr;
+    m_ptrMuLettersQ = nullptr;
 }
 
 void MuKmerFilter::SetQ(const std::string &, const std::vector<byte> *ptrMuLettersQ, const std::vector<uint> *ptrMuKmersQ)
 {
-    if (m_KmerHashTableQ.empty()) m_KmerHashTableQ.assign((size_t) m_DictSize * HASHW, 0xffff);
-    else ResetQ();
     m_ptrMuLettersQ = ptrMuLettersQ;
     m_ptrMuKmersQ = ptrMuKmersQ;
-    const uint KmerCount = (uint) ptrMuKmersQ->size();
-    for (uint PosQ = 0; PosQ < KmerCount; ++PosQ) {          // first-come, at most HASHW positions per k-mer (:208-225)
-        const uint Kmer = (*ptrMuKmersQ)[PosQ];
-        for (uint w = 0; w < HASHW; ++w)
-            if (m_KmerHashTableQ[Kmer * HASHW + w] == 0xffff) { m_KmerHashTableQ[Kmer * HASHW + w] = (uint16_t) PosQ; break; }
-    }
 }
 
-int MuKmerFilter::MuXDrop(int PosQ, int LQ, int PosT, int LT, int X, int &Loi, int &Loj, int &Len) const
-{
-    Loi = PosQ; Loj = PosT; Len = 0;
-    const byte *Q = m_ptrMuLettersQ->data(), *T = m_ptrMuLettersT->data();
-    int i = PosQ, j = PosT, FwdScore = 0, BestFwdScore = 0, FwdLen = 0;
-    while (i < LQ && j < LT) {
-        FwdScore += rsk_mu_int[36 * Q[i++] + T[j++]];
-        if (FwdScore > BestFwdScore) { FwdLen = i - PosQ; BestFwdScore = FwdScore; }
-        else if (FwdScore + X < BestFwdScore) break;
-    }
-    int RevScore = 0, BestRevScore = 0, RevLen = 0;
-    i = PosQ - 1; j = PosT - 1;
-    while (i >= 0 && j >= 0) {
-        RevScore += rsk_mu_int[36 * Q[i] + T[j]];
-        if (RevScore > BestRevScore) { BestRevScore = RevScore; Loi = i; Loj = j; RevLen = PosQ - i; }
-        else if (RevScore + X < BestRevScore) break;
-        --i; --j;
-    }
-    Len = FwdLen + RevLen;
-    return BestFwdScore + BestRevScore;
-}
-
-void MuKmerFilter::Align(const std::vector<byte> &MuLettersT, const std::vector<uint> &MuKmersT)
-{
-    m_ptrMuLettersT = &MuLettersT;
-    const uint KmerCountT = (uint) MuKmersT.size();
-    const int LQ = (int) m_ptrMuLettersQ->size(), LT = (int) MuLettersT.size();
-    m_MuKmerHSPLois.clear(); m_MuKmerHSPLojs.clear(); m_MuKmerHSPLens.clear(); m_MuKmerHSPScores.clear();
-    m_ChainHSPLois.clear(); m_ChainHSPLojs.clear(); m_ChainHSPLens.clear();
-    m_BestChainScore = 0;
-    m_BestHSPScore = 0;
-    bool FoundHSP = false;
-    const int MinHSPScore = m_Params->m_MKF_MinHSPScore, X1 = m_Params->m_MKF_X1;
-    for (uint PosT = 0; PosT < KmerCountT; ++PosT) {
-        const uint KmerT = MuKmersT[PosT];
-        for (uint w = 0; w < HASHW; ++w) {
-            const uint PosQ = m_KmerHashTableQ[HASHW * KmerT + w];
-            if (PosQ == 0xffff) continue;
-            int Loi, Loj, Len;
-            const int Score = MuXDrop((int) PosQ, LQ, (int) PosT, LT, X1, Loi, Loj, Len);
-            if (Score < MinHSPScore) continue;
-            FoundHSP = true;
-            if (Score > m_BestHSPScore) {                 // kept only while strictly improving (:354-378)
-                m_BestHSPScore = Score;
-                bool Old = false;
-                for (int l : m_MuKmerHSPLois) if (l == Loi) { Old = true; break; }
-                if (!Old) {
-                    m_MuKmerHSPLois.push_back(Loi); m_MuKmerHSPLojs.push_back(Loj);
-                    m_MuKmerHSPLens.push_back(Len); m_MuKmerHSPScores.push_back(Score);
-                }
-            }
-        }
-    }
-    if (FoundHSP) ChainHSPs();
-}
-
-// Chainer::Chain chainer.cpp:31-178: best-scoring chain of non-overlapping [Lo,Hi] intervals.
-namespace {
-struct BPData { uint Index; bool IsLo; uint Pos; };
-int CmpBPs(const void *a, const void *b)      // ties: Los before His (chainer.cpp:11-29); not a total order -> libc qsort as the reference
-{
-    const BPData *x = (const BPData *) a, *y = (const BPData *) b;
-    if (x->Pos < y->Pos) return -1;
-    if (x->Pos > y->Pos) return 1;
-    if (x->IsLo != y->IsLo) return (x->IsLo && !y->IsLo) ? -1 : 1;
-    return 0;
-}
-float ChainIntervals(const std::vector<uint> &Los, const std::vector<uint> &His, const std::vector<float> &Scores, std::vector<uint> &Idxs)
-{
-    Idxs.clear();
-    const uint N = (uint) Los.size();
-    if (N == 0) return 0;
-    std::vector<BPData> BPs(2 * N);
-    for (uint i = 0; i < N; ++i) {
-        BPs[2 * i] = BPData{ i, true, Los[i] };
-        BPs[2 * i + 1] = BPData{ i, false, His[i] };
-    }
-    qsort(BPs.data(), 2 * N, sizeof(BPData), CmpBPs);
-    std::vector<uint> TB(N, UINT_MAX);
-    std::vector<float> ChainScores(N, MINUS_INFINITY);
-    uint BestChainEnd = UINT_MAX;
-    for (uint i = 0; i < 2 * N; ++i) {
-        const BPData &BP = BPs[i];
-        const float Score = Scores[BP.Index];
-        if (BP.IsLo) {
-            TB[BP.Index] = BestChainEnd;
-            ChainScores[BP.Index] = (BestChainEnd == UINT_MAX) ? Score : ChainScores[BestChainEnd] + Score;
-        } else if (BestChainEnd == UINT_MAX || ChainScores[BP.Index] > ChainScores[BestChainEnd])
-            BestChainEnd = BP.Index;
-    }
-    float Total = 0;
-    for (uint Index = BestChainEnd;;) {
-        Total += Scores[Index];
-        Idxs.push_back(Index);
-        Index = TB[Index];
-        if (Index == UINT_MAX) break;
-    }
-    return Total;
-}
-}   // namespace
-
-void MuKmerFilter::ChainHSPs()
-{
-    m_ChainHSPLois.clear(); m_ChainHSPLojs.clear(); m_ChainHSPLens.clear();
-    const uint N = (uint) m_MuKmerHSPLois.size();
-    std::vector<uint> Los, His, Idxs;
-    std::vector<float> Scores;
-    for (uint i = 0; i < N; ++i) {
-        const uint Lo = (uint) m_MuKmerHSPLois[i];
-        Los.push_back(Lo);
-        His.push_back(Lo + m_MuKmerHSPLens[i] - 1);
-        Scores.push_back((float) m_MuKmerHSPScores[i]);
-    }
-    m_BestChainScore = (int) ChainIntervals(Los, His, Scores, Idxs);
-    for (uint Idx : Idxs) {
-        m_ChainHSPLois.push_back(m_MuKmerHSPLois[Idx]);
-        m_ChainHSPLojs.push_back(m_MuKmerHSPLojs[Idx]);
-        m_ChainHSPLens.push_back(m_MuKmerHSPLens[Idx]);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Long-chain pair, per-pair form (AlignMKF dssaligner.cpp:1387, XDropHSP xdrophsp.cpp:42).  The gapped X-drop
-// extensions exist on the device only (k_xdrop.hip): a single pair is a batch of one through the same entry points the
-// search uses (rsk_mkf_align_pairs / rsk_xdrop_pairs); the host keeps the seeding + chaining of MuKmerFilter.
-// ---------------------------------------------------------------------------------------------
 namespace {
 void rsk_ok(int rc, const char *what)
 {
     if (rc != RSK_OK) throw std::runtime_error(std::string(what) + ": " + rsk_last_error());
 }
 
+// one chain's Mu letters as a device set
+struct MuSet {
+    rsk_db *d = nullptr;
+    MuSet(rsk_ctx *ctx, const std::vector<byte> &Mu)
+    {
+        const uint32_t L = (uint32_t) Mu.size();
+        rsk_ok(rsk_db_create(ctx, 1, &L, Mu.data(), nullptr, nullptr, nullptr, nullptr, nullptr, &d), "rsk_db_create");
+    }
+    ~MuSet() { rsk_db_destroy(d); }
+    MuSet(const MuSet &) = delete;
+    MuSet &operator=(const MuSet &) = delete;
+};
+}   // namespace
+
+void MuKmerFilter::Align(const std::vector<byte> &MuLettersT, const std::vector<uint> &)
+{
+    m_ptrMuLettersT = &MuLettersT;
+    SetSeedHSPs(nullptr, 0);
+    if (!m_ptrMuLettersQ || m_ptrMuLettersQ->size() < 3 || MuLettersT.size() < 3) return;
+    rsk_ctx *ctx = DefaultCtx();
+    MuSet Q(ctx, *m_ptrMuLettersQ), T(ctx, MuLettersT);
+    const uint32_t zero = 0;
+    // the search's record size first; a pair that keeps more HSPs than that runs again with the large one
+    for (uint32_t cap : { 32u, 1024u }) {
+        std::vector<int32_t> kept((size_t) cap * 4);
+        uint8_t found = 0;
+        uint32_t rec_pair = 0, rec_nkept = 0;
+        size_t nrec = 0;
+        rsk_ok(rsk_mkf_seed_pairs(ctx, Q.d, T.d, &zero, &zero, 1, m_Params->m_MKF_X1, m_Params->m_MKF_MinHSPScore, cap, &found, 1, &nrec, &rec_pair,
+                                  &rec_nkept, kept.data()),
+               "rsk_mkf_seed_pairs");
+        if (!found || nrec == 0) return;
+        if (rec_nkept <= cap) { SetSeedHSPs(kept.data(), rec_nkept); return; }
+    }
+    throw std::runtime_error("MuKmerFilter::Align: a pair keeps more than 1024 seed HSPs");
+}
+
+// Chainer::Chain (chainer.cpp:31-178) for the pairs the device hands back: k_mkf_chain chains every pair whose outcome is
+// defined by the sweep alone and flags those where two intervals END at one position with equal chain scores -- there the
+// reference's result is whatever its libc qsort made of a comparator that calls such end points equal (chainer.cpp:11-29),
+// so exactly that is done here: the same comparator through the same qsort, then the sweep.
+namespace {
+struct EndPoint { uint32_t pos, hsp; int opens; };
+int CompareEndPoints(const void *pa, const void *pb)
+{
+    const EndPoint &a = *(const EndPoint *) pa, &b = *(const EndPoint *) pb;
+    if (a.pos != b.pos) return a.pos < b.pos ? -1 : 1;
+    return b.opens - a.opens;                              // at one position an opening end point first; two of a kind: "equal"
+}
+}   // namespace
+
+void MuKmerFilter::ChainHSPs()
+{
+    m_ChainHSPLois.clear(); m_ChainHSPLojs.clear(); m_ChainHSPLens.clear();
+    m_BestChainScore = 0;
+    const uint32_t N = (uint32_t) m_MuKmerHSPLois.size();
+    if (N == 0) return;
+    std::vector<EndPoint> ev;
+    ev.reserve(2 * (size_t) N);
+    for (uint32_t h = 0; h < N; ++h) {
+        ev.push_back(EndPoint{ (uint32_t) m_MuKmerHSPLois[h], h, 1 });
+        ev.push_back(EndPoint{ (uint32_t) (m_MuKmerHSPLois[h] + m_MuKmerHSPLens[h] - 1), h, 0 });
+    }
+    qsort(ev.data(), ev.size(), sizeof(EndPoint), CompareEndPoints);
+    // sweep: an HSP that opens continues the best chain closed so far; an HSP that closes becomes that chain if strictly better
+    const uint32_t NONE = UINT_MAX;
+    std::vector<uint32_t> before(N, NONE);
+    std::vector<float> chain(N, MINUS_INFINITY);
+    uint32_t closed = NONE;
+    for (const EndPoint &e : ev) {
+        if (e.opens) {
+            before[e.hsp] = closed;
+            chain[e.hsp] = (float) m_MuKmerHSPScores[e.hsp] + (closed == NONE ? 0.0f : chain[closed]);
+        } else if (closed == NONE || chain[e.hsp] > chain[closed])
+            closed = e.hsp;
+    }
+    float total = 0;
+    for (uint32_t h = closed; h != NONE; h = before[h]) {                 // chain end -> start: the order PostAlignMKF sums in
+        total += (float) m_MuKmerHSPScores[h];
+        m_ChainHSPLois.push_back(m_MuKmerHSPLois[h]);
+        m_ChainHSPLojs.push_back(m_MuKmerHSPLojs[h]);
+        m_ChainHSPLens.push_back(m_MuKmerHSPLens[h]);
+    }
+    m_BestChainScore = (int) total;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Long-chain pair, per-pair form (AlignMKF dssaligner.cpp:1387, XDropHSP xdrophsp.cpp:42).  The gapped X-drop
+// extensions exist on the device only (k_xdrop.hip): a single pair is a batch of one through the same entry points the
+// search uses (rsk_mkf_align_pairs / rsk_xdrop_pairs).
+// ---------------------------------------------------------------------------------------------
+namespace {
 // the two chains of the aligner's current pair as one-chain device sets
 struct PairSets {
     rsk_db *a = nullptr, *b = nullptr;

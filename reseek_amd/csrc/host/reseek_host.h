@@ -85,6 +85,7 @@ struct SearchOptions {
     bool fast_set() const { return mode == AM_Fast; }  // optset_fast
     bool keeptmp = false;                              // -keeptmp
     uint shard_index = 0, shard_count = 0;             // multi-GPU: this rank's shard of the targets (0/0 or x/1 = everything)
+    bool hits_digest = false;                          // rsk_search_opts.hits_digest: digest line instead of the hit table
     std::string devices;                               // one process, several devices: "0,1,2,3" (DBSearcher::m_Devices); "" = RSK_DEVICES
     size_t batch_pairs = 1u << 20;                     // upper bound of pairs per GPU alignment batch
     // ... and of DP cells per batch (~0.8 trace byte per cell in HBM).  10 G: the trace block stays below the size from which
@@ -208,8 +209,6 @@ public:
     }
     double GetSSDensity(uint Pos, char c);
     double GetFloat_DstNxtHlx(uint Pos);
-    uint CalcNEN(uint Pos) const;
-    uint CalcREN(uint Pos, uint NEN) const;
     uint ConfLetter(uint Pos) const;
 };
 
@@ -264,13 +263,10 @@ class DSSAligner;
 
 class MuKmerFilter {                                    // mukmerfilter.h:10
 public:
-    static const uint HASHW = 4;
     const DSSParams *m_Params = nullptr;
     const std::vector<byte> *m_ptrMuLettersQ = nullptr;
     const std::vector<uint> *m_ptrMuKmersQ = nullptr;
     const std::vector<byte> *m_ptrMuLettersT = nullptr;
-    std::vector<uint16_t> m_KmerHashTableQ;             // 36^3 * HASHW slots of query positions, 0xffff = empty
-    uint m_DictSize = 36 * 36 * 36;
     std::vector<int> m_MuKmerHSPLois, m_MuKmerHSPLojs, m_MuKmerHSPLens, m_MuKmerHSPScores;
     int m_BestChainScore = 0, m_BestHSPScore = 0;
     std::vector<int> m_ChainHSPLois, m_ChainHSPLojs, m_ChainHSPLens;
@@ -283,7 +279,6 @@ public:
     void AlignBag(const ChainBag &BagT);                // mukmerfilter.h:87: Align against a bag's letters / k-mers
     // the state Align() leaves when its seed loop kept these HSPs (computed by rsk_mkf_seed_pairs), then ChainHSPs()
     void SetSeedHSPs(const int32_t *Kept4, uint Count);
-    int MuXDrop(int PosQ, int LQ, int PosT, int LT, int X, int &Loi, int &Loj, int &Len) const;
     void ChainHSPs();
 };
 

@@ -112,7 +112,7 @@ struct mkf_args {
     const uint4 *tables;
     uint32_t pair_lo, pair_hi;         // this launch handles the pairs [pair_lo, pair_hi) of the call
     int X, min_score;
-    uint32_t cap;                      // kept HSPs stored per record (<= MKF_CAP_MAX)
+    uint32_t cap;                      // kept HSPs stored per record (<= the kernel instance's CAPMAX)
     uint8_t *found;                    // per pair: any seed with score >= min_score
     // compact records of the found pairs (appended with one atomic each)
     uint32_t *nrec; uint32_t max_rec;
@@ -121,11 +121,13 @@ struct mkf_args {
                                        // min(nkept, cap) entries from rec_first[r] (only the entries written cross PCIe)
     uint32_t *rec_first, *nent;
 };
-#define MKF_CAP_MAX 32
+#define MKF_CAP_MAX 32                 // the search's instance: a pair keeps a handful of HSPs (strictly improving scores)
+#define MKF_CAP_BIG 1024               // the instance that redoes a pair whose list did not fit (r04: was a host re-seeding)
 
+template <int CAPMAX>
 __global__ __launch_bounds__(64 * MKF_WAVES) void k_mkf_seed(mkf_args a)
 {
-    __shared__ int4 skept[MKF_WAVES][MKF_CAP_MAX];
+    __shared__ int4 skept[MKF_WAVES][CAPMAX];
     __shared__ uint32_t sseeds[MKF_WAVES][MKF_QUEUE];
     __shared__ signed char smat[1296];                            // the integer Mu matrix: one LDS read per extension step
     for (int i = threadIdx.x; i < 1296; i += blockDim.x) smat[i] = (signed char) c_mu_int[i];
@@ -230,9 +232,9 @@ extern "C" int rsk_mkf_seed_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t
                                   int x1, int min_hsp_score, uint32_t cap, uint8_t *found, size_t max_records, size_t *nrecords,
                                   uint32_t *rec_pair, uint32_t *rec_nkept, int32_t *rec_kept)
 {
-    if (!ctx || !q || !t || (npairs && (!iq || !it || !found)) || !nrecords || cap == 0 || cap > MKF_CAP_MAX ||
+    if (!ctx || !q || !t || (npairs && (!iq || !it || !found)) || !nrecords || cap == 0 || cap > MKF_CAP_BIG ||
         (max_records && (!rec_pair || !rec_nkept || !rec_kept))) {
-        rsk_set_error("rsk_mkf_seed_pairs: bad argument (cap must be 1..%d)", MKF_CAP_MAX);
+        rsk_set_error("rsk_mkf_seed_pairs: bad argument (cap must be 1..%d)", MKF_CAP_BIG);
         return RSK_E_INVALID;
     }
     if (!q->d_mu || !t->d_mu) { rsk_set_error("rsk_mkf_seed_pairs: chain set has no Mu letters"); return RSK_E_INVALID; }
@@ -328,7 +330,9 @@ extern "C" int rsk_mkf_seed_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t
         hipLaunchKernelGGL(k_mkf_build, dim3((unsigned) (c.q1 - c.q0)), dim3(256), 0, ctx->stream, q->d_mu, q->d_off, q->d_len, d_qlist + c.q0,
                            d_toff + c.q0, d_tbits + c.q0, d_tab);
         a.pair_lo = (uint32_t) c.p0; a.pair_hi = (uint32_t) c.p1;
-        hipLaunchKernelGGL(k_mkf_seed, dim3((unsigned) ((c.p1 - c.p0 + MKF_WAVES - 1) / MKF_WAVES)), dim3(64 * MKF_WAVES), 0, ctx->stream, a);
+        const dim3 grid((unsigned) ((c.p1 - c.p0 + MKF_WAVES - 1) / MKF_WAVES));
+        if (cap <= MKF_CAP_MAX) hipLaunchKernelGGL(k_mkf_seed<MKF_CAP_MAX>, grid, dim3(64 * MKF_WAVES), 0, ctx->stream, a);
+        else hipLaunchKernelGGL(k_mkf_seed<MKF_CAP_BIG>, grid, dim3(64 * MKF_WAVES), 0, ctx->stream, a);
     }
     RSK_HIP(hipGetLastError());
     RSK_HIP(hipEventRecord(ctx->ev1, ctx->stream));

@@ -158,7 +158,7 @@ struct pf_args {
     uint32_t *out_q, *out_t, *out_score;
     uint32_t capacity;
     uint32_t *out_n;
-    unsigned long long *stat;      // [0] seed items, [1] two-hit diagonals, [2] spans, [3] scoring rounds
+    unsigned long long *stat;      // [0] seed items, [1] two-hit diagonals, [2] spans, [3] scoring rounds, [4] diagonal cells scored
     uint32_t tl_cap;               // target letters staged in LDS up to this length
     uint32_t dbg;                  // RSK_PF_DEBUG: 1 = stop after the seed walk of every span (timing experiments)
 };
@@ -236,6 +236,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_prefilter(pf_args a)
         return base + inc - v;
     };
 
+    unsigned long long my_cells = 0;                                     // statistics: cells the diagonal scans visit
     // Kadane over the whole diagonal d of query q (FindHSP prefiltermu.cpp:12, diag.h:51-92), score clamped to u16.
     // `F += s; if (F > B) B = F; else if (F < 0) F = 0` is B = max(B, F); F = max(F, 0): F > B >= 0 leaves F alone.
     auto diag_score = [&](uint32_t q, int d) -> uint32_t {
@@ -245,6 +246,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_prefilter(pf_args a)
         int j0 = d + 1 - QL; if (j0 < 0) j0 = 0;
         int hi = QL - 1; if (QL + (int) TL - d - 2 < hi) hi = QL + (int) TL - d - 2;
         int len = hi - i0 + 1;
+        if (len > 0) my_cells += (unsigned) len;
         int F = 0, Bst = 0;
         auto step = [&](uint32_t pair) {                                 // pair = query letter << 8 | target letter
             F += tab[pair];
@@ -437,8 +439,8 @@ __global__ __launch_bounds__(PF_THREADS) void k_prefilter(pf_args a)
     if (a.stat) {
         // wave-reduced statistics (RSK_TRACE / the work counters of the context)
 #pragma unroll
-        for (int s = 32; s >= 1; s >>= 1) { my_items += __shfl_xor(my_items, s, 64); my_two += __shfl_xor(my_two, s, 64); }
-        if (lane == 0) { atomicAdd(a.stat + 0, my_items); atomicAdd(a.stat + 1, my_two); }
+        for (int s = 32; s >= 1; s >>= 1) { my_items += __shfl_xor(my_items, s, 64); my_two += __shfl_xor(my_two, s, 64); my_cells += __shfl_xor(my_cells, s, 64); }
+        if (lane == 0) { atomicAdd(a.stat + 0, my_items); atomicAdd(a.stat + 1, my_two); atomicAdd(a.stat + 4, my_cells); }
         if (tid == 0) { atomicAdd(a.stat + 2, (unsigned long long) nspans); atomicAdd(a.stat + 3, (unsigned long long) nrounds); }
     }
 }
@@ -551,8 +553,20 @@ extern "C" int rsk_mu_prefilter_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db 
     RSK_HIP(hipStreamSynchronize(ctx->stream));
     ctx->pf_hits = stat[0];
     ctx->pf_postings = q->pf_postings;
+    ctx->pf_twohit = stat[1];
+    ctx->pf_cells = stat[4];
     if (getenv("RSK_TRACE"))
-        fprintf(stderr, "[prefilter] index postings %zu, seed items %llu, two-hit diagonals %llu; query spans %llu, scoring rounds %llu (%u targets)\n",
-                q->pf_postings, stat[0], stat[1], stat[2], stat[3], t->n);
+        fprintf(stderr, "[prefilter] index postings %zu, seed items %llu, two-hit diagonals %llu (%llu cells); query spans %llu, scoring rounds %llu (%u targets)\n",
+                q->pf_postings, stat[0], stat[1], stat[4], stat[2], stat[3], t->n);
+    return RSK_OK;
+}
+
+extern "C" int rsk_mu_prefilter_last_work(rsk_ctx *ctx, uint64_t *seed_items, uint64_t *index_postings, uint64_t *twohit_diagonals, uint64_t *diagonal_cells)
+{
+    if (!ctx) { rsk_set_error("rsk_mu_prefilter_last_work: NULL context"); return RSK_E_INVALID; }
+    if (seed_items) *seed_items = ctx->pf_hits;
+    if (index_postings) *index_postings = ctx->pf_postings;
+    if (twohit_diagonals) *twohit_diagonals = ctx->pf_twohit;
+    if (diagonal_cells) *diagonal_cells = ctx->pf_cells;
     return RSK_OK;
 }

@@ -32,7 +32,7 @@ struct rsk_ctx {
     uint64_t gl_pairs = 0, gl_cells = 0, gl_slots = 0;
     uint64_t mf_pairs = 0, mf_candidates = 0;   // last Mu filter call
     uint64_t al_pairs = 0, al_cells = 0, al_tb_bytes = 0;   // last rsk_align_pairs call
-    uint64_t pf_hits = 0, pf_postings = 0;                 // last rsk_mu_prefilter_dev call: seed items, index size
+    uint64_t pf_hits = 0, pf_postings = 0, pf_twohit = 0, pf_cells = 0;   // last rsk_mu_prefilter_dev call: seed items, index size, two-hit diagonals, cells scored
     int num_cus = 0;
     // caching device allocator (hipMalloc/hipFree cost ~0.1-1 ms each and synchronise; the batch
     // entry points need a dozen temporaries per call): blocks are kept in size classes until the

@@ -101,7 +101,7 @@ def search_sharded(ctx, query, out_tsv, mode, db=None, group=None, device=None, 
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     part = "%s.rank%d" % (out_tsv, rank)
-    if mode == "fast" and db and world > 1:
+    if mode == "fast" and db and dist.is_initialized():
         keeptmp = kw.pop("keeptmp", 0)
         exact = kw.pop("exchange", "all") != "topb"
         sh = ctx.fast_shard_open(query, db, shard_index=rank, shard_count=world, **kw)
@@ -115,10 +115,11 @@ def search_sharded(ctx, query, out_tsv, mode, db=None, group=None, device=None, 
     with open(part) as f:
         text = f.read()
     os.remove(part)
-    if world == 1:
+    if not dist.is_initialized():
         with open(out_tsv, "w") as f:
             f.write(text)
         return nhits, stats
+    # (a process group of ONE rank still goes through the collective: that is how a single-GPU box exercises RCCL)
     merged = gather_text(text, dst=0, group=group, device=device)
     if rank == 0:
         with open(out_tsv, "w") as f:

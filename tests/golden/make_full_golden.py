@@ -100,7 +100,132 @@ def prefix_golden(mode, partial, bca_md5):
     print(json.dumps(rec))
 
 
+# ---- `-search Q.bca -db Q.bca -fast` (BASELINE configs[2]; search.cpp:76-111: MuPreFilter -> hand-off file -> PostMuFilter) ----
+# The literal one-thread command needs 3-4 CPU-hours on the 11,211-chain set, so both stages are cut into target ranges for
+# several ONE-thread processes of the reference's own code (one thread each: the reference's bags and its long-chain
+# alignments are only reproducible with one, SURVEY 0.6 / DESIGN 5):
+#   stage 1  oracle/_ref/ref_harness prefrange (the reference's PrefilterMu::Search per target, a bag that never truncates)
+#            per range -> all triples; ref_harness rsbreplay feeds them to the reference's RankedScoresBag in target order
+#            -> the hand-off file (what `-keeptmp` keeps);
+#   stage 2  `reseek -postmufilter Q.bca -db Q.bca -filin <piece of the hand-off file> -threads 1` (cmd_postmufilter
+#            postmufilter.cpp:303 = the PostMuFilter call of cmd_search with the same DM_AlwaysSensitive preset) per piece of
+#            the hand-off file's target lines; a candidate pair's alignment does not depend on the other lines.
+# `--validate` runs this route AND the literal command (`-search -db -fast -keeptmp -threads 1`) on a sample and requires
+# the same hand-off bytes and the same sorted hit table, also with bags that overflow (-rsb_size 20).
+def _run(cmd, cwd, env=None):
+    subprocess.run(cmd, check=True, cwd=cwd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+
+
+def fastdb_split_route(bca, workdir, nchains, procs, rsb_size=None, tag="split"):
+    ref = os.path.join(ROOT, "oracle", "_ref", "reseek")
+    har = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    bounds = [nchains * r // procs for r in range(procs + 1)]
+    t0 = time.time()
+    bins = [os.path.join(workdir, "%s_tri_%d.bin" % (tag, r)) for r in range(procs)]
+    ps = []
+    for r in range(procs):
+        if os.path.exists(bins[r] + ".done"):
+            continue
+        cmd = [har, "prefrange", bca, bca, str(bounds[r]), str(bounds[r + 1]), bins[r], "--", "-fast"]      # cmd_search's Params: DM_UseCommandLineOption under -fast
+        ps.append((r, subprocess.Popen(cmd, cwd=workdir, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)))
+    for r, p in ps:
+        if p.wait() != 0:
+            raise SystemExit("prefrange %d failed" % r)
+        open(bins[r] + ".done", "w").close()
+    t1 = time.time()
+    handoff = os.path.join(workdir, "%s_handoff.tsv" % tag)
+    _run([har, "rsbreplay", str(nchains), str(rsb_size or 1500), handoff] + bins, workdir)
+    # stage 2: the target lines dealt round-robin (long and short targets in every piece)
+    lines = open(handoff, "rb").read().split(b"\n")
+    assert lines[0].startswith(b"prefilter\t") and lines[-1] == b""
+    body = lines[1:-1]
+    parts = []
+    ps = []
+    for r in range(procs):
+        mine = body[r::procs]
+        fn = os.path.join(workdir, "%s_handoff_%d.tsv" % (tag, r))
+        with open(fn, "wb") as f:
+            f.write(b"prefilter\t%d\n" % len(mine) + b"".join(x + b"\n" for x in mine))
+        out = os.path.join(workdir, "%s_hits_%d.tsv" % (tag, r))
+        parts.append(out)
+        if os.path.exists(out + ".done") or not mine:
+            if not mine:
+                open(out, "w").close()
+            continue
+        cmd = [ref, "-postmufilter", bca, "-db", bca, "-filin", fn, "-output", out, "-dbsize", str(nchains), "-threads", "1"]
+        ps.append((out, subprocess.Popen(cmd, cwd=workdir, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)))
+    for out, p in ps:
+        if p.wait() != 0:
+            raise SystemExit("postmufilter failed for " + out)
+        open(out + ".done", "w").close()
+    t2 = time.time()
+    hits = os.path.join(workdir, "%s_hits.tsv" % tag)
+    with open(hits, "wb") as f:
+        for out in parts:
+            f.write(open(out, "rb").read())
+    return handoff, hits, {"stage1_wall_s": round(t1 - t0, 1), "stage2_wall_s": round(t2 - t1, 1), "processes": procs}
+
+
+def fastdb_validate(workdir):
+    ref = os.path.join(ROOT, "oracle", "_ref", "reseek")
+    ok = True
+    for n, rsb in ((300, None), (300, 20)):
+        bca = os.path.join(workdir, "val%d.bca" % n)
+        if not os.path.exists(bca):
+            synth_bca(bca, n)
+        tag = "val%d_%s" % (n, rsb or "std")
+        lit = os.path.join(workdir, tag + "_literal.tsv")
+        log = os.path.join(workdir, tag + "_literal.log")
+        cmd = [ref, "-search", bca, "-db", bca, "-fast", "-keeptmp", "-threads", "1", "-output", lit, "-log", log]
+        if rsb:
+            cmd += ["-rsb_size", str(rsb)]
+        _run(cmd, workdir)
+        tmpfn = [ln.split("=", 1)[1].strip() for ln in open(log) if ln.startswith("MuFilterTsvFN=")][0]
+        lit_handoff = open(tmpfn, "rb").read()
+        os.remove(tmpfn)
+        for f in os.listdir(workdir):
+            if f.startswith(tag + "_split"):
+                os.remove(os.path.join(workdir, f))
+        handoff, hits, _ = fastdb_split_route(bca, workdir, n, 3, rsb, tag + "_split")
+        same_h = open(handoff, "rb").read() == lit_handoff
+        same_t = table_md5(hits) == table_md5(lit)
+        print("validate %d chains rsb_size %s: hand-off %s (%d bytes), hit table %s (%d rows)" %
+              (n, rsb or 1500, "identical" if same_h else "DIFFERENT", len(lit_handoff), "identical" if same_t else "DIFFERENT", table_md5(lit)[1]))
+        ok = ok and same_h and same_t
+    return ok
+
+
+def fastdb_golden(workdir, procs):
+    bca = os.path.join(workdir, "syn11211.bca")
+    if not os.path.exists(bca):
+        synth_bca(bca + ".tmp%d" % os.getpid(), 0)
+        os.replace(bca + ".tmp%d" % os.getpid(), bca)
+    handoff, hits, tm = fastdb_split_route(bca, workdir, 11211, procs, None, "fastdb")
+    md5, rows = table_md5(hits)
+    rec = {"chains": 11211, "mode": "fast", "db": "the same file (-search Q.bca -db Q.bca -fast)", "bca_md5": file_md5(bca), "rows": rows,
+           "sorted_table_md5": md5, "handoff_md5": file_md5(handoff), "handoff_bytes": os.path.getsize(handoff),
+           "handoff_target_lines": int(open(handoff, "rb").readline().split(b"\t")[1]),
+           "reference_threads": 1, "route": "target ranges on %d one-thread processes of the reference's code (ref_harness prefrange / rsbreplay, "
+           "reseek -postmufilter); validated against the literal `reseek -search Q -db Q -fast -keeptmp -threads 1` on samples "
+           "(make_full_golden.py --fastdb --validate)" % procs, **tm}
+    out = os.path.join(ROOT, "tests", "golden", "full11211_fastdb.md5.txt")
+    with open(out, "w") as f:
+        f.write(json.dumps(rec, indent=1) + "\n")
+    print(json.dumps(rec))
+
+
 def main():
+    if "--fastdb" in sys.argv:
+        ap = argparse.ArgumentParser()
+        ap.add_argument("--fastdb", action="store_true")
+        ap.add_argument("--validate", action="store_true")
+        ap.add_argument("--procs", type=int, default=7)
+        ap.add_argument("--workdir", default="/tmp/full_golden")
+        a = ap.parse_args()
+        os.makedirs(a.workdir, exist_ok=True)
+        if a.validate:
+            sys.exit(0 if fastdb_validate(a.workdir) else 1)
+        return fastdb_golden(a.workdir, a.procs)
     ap = argparse.ArgumentParser()
     ap.add_argument("mode")
     ap.add_argument("--perturb", action="store_true")

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Runs on the GPU box: rocprofv3 kernel trace + PMC passes of `bench.py --live-only` (k_mu_sw, k_sw_float, k_sw_qp on the
 # SCOP40-shaped set) -> gpurun_out/prof_<tag>/{summary.txt, live_pmc.json}; copy them to profiles/<tag>_live_* and
-# profiles/r03_live_pmc.json (read by bench.py).  Counters are collected in their own passes (no trace options with --pmc).
-TAG=${1:-r03_live}
+# profiles/r04_live_pmc.json (read by bench.py, which checks the kernel sources' sha256 recorded in it).  Counters are collected in their own passes (no trace options with --pmc).
+TAG=${1:-r04_live}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp

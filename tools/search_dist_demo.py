@@ -29,12 +29,14 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    if world > 1:
+    # RSK_DIST_FORCE=1: a process group even for ONE rank, so that a single-GPU box runs the RCCL collectives of this path
+    use_dist = world > 1 or os.environ.get("RSK_DIST_FORCE", "") == "1"
+    if use_dist:
         if one:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    coll_dev = torch.device("cpu") if (one or world == 1) else torch.device("cuda", local)      # RCCL gathers device tensors
+    coll_dev = torch.device("cpu") if (one or not use_dist) else torch.device("cuda", local)      # RCCL gathers device tensors
     ctx = reseek_amd.Ctx(local, stream=torch.cuda.current_stream().cuda_stream)
     golden = os.path.join(ROOT, "tests", "golden")
     with tempfile.TemporaryDirectory() as td:
@@ -53,7 +55,13 @@ def main():
                 ok = ok and got == want
                 print("world %d %s %s: %d hits, %s" % (world, mode, "db" if db else "self", len(got),
                                                        "identical to the reference" if got == want else "MISMATCH"))
-    if world > 1:
+    if use_dist:
+        if not one:
+            # the device-record gather of bench.py's N > 1 leg on this backend
+            rec = torch.arange(3 * (5 + rank), dtype=torch.int32, device=coll_dev).reshape(-1, 3)
+            allrec = rdist.gather_records_device(rec)
+            assert allrec.is_cuda and allrec.shape[0] == sum(5 + r for r in range(world))
+            print("world %d gather_records_device over %s: %d records" % (world, dist.get_backend(), allrec.shape[0]))
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
