@@ -1037,6 +1037,38 @@ static void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOff
     std::vector<uint32_t> ia, ib;                // pairs for the full alignment
     std::vector<std::pair<uint32_t, uint32_t> > mkf;
     uint64_t npairs = 0;
+    // long-chain pairs: MKF path (dssaligner.cpp:809-813), one aligner per host thread as in the reference
+    // (dbsearcher.cpp:98-106); BaseOnAln serialises the output under m_Lock.
+    auto each_orientation = [&](DSSAligner &DA, uint i, uint j, auto &&fn) {
+        if (DA.m_Path.empty()) return;
+        if (Self) {
+            fn(DA, true);
+            if (i != joff + j) fn(DA, false);
+        } else
+            fn(DA, false);
+    };
+    // A plain DBSearcher runs its two jobs side by side: the long-chain job on a context of its own, its hit lines collected
+    // in memory (one buffer per worker thread: formatting under one lock was a tenth of the job) and appended after the
+    // alignment job's -- the order of the output file stays: Smith-Waterman hits, then long-chain hits.
+    struct sink { std::string lines; uint64_t hits = 0; char pad[64]; };
+    std::vector<sink> sinks(HostThreads(128));
+    const std::function<void(DSSAligner &, uint, uint, unsigned)> on_hit = [&](DSSAligner &DA, uint i, uint j, unsigned worker) {
+        sink &me = sinks[worker];
+        each_orientation(DA, i, j, [&](DSSAligner &D, bool Up) {
+            if (S.Reject(D, Up)) return;
+            ++me.hits;
+            if (S.m_fTsv && !(S.m_Opts.noself && D.m_ChainA->m_Label == D.m_ChainB->m_Label)) D.AppendTsv(me.lines, Up);
+        });
+    };
+    const bool may_overlap = !S.m_HasOnAlnOverride && !(getenv("RSK_MKF_OVERLAP") && atoi(getenv("RSK_MKF_OVERLAP")) == 0);
+    SecondaryCtx own;
+    std::future<void> job;
+    auto start_mkf_job = [&]() {
+        if (!may_overlap || mkf.empty()) return;
+        own.Create(ctx->device, "mkf");
+        job = std::async(std::launch::async, [&]() { RunMKFPairs(own.c, P, S.m_Opts.columns, SrcA, S, mkf, [](DSSAligner &, uint, uint) {}, &on_hit); });
+    };
+    struct JobJoin { std::future<void> &j; ~JobJoin() { if (j.valid()) j.wait(); } } join_on_exit{ job };      // an exception below must not leave the job running
     if (UseMu) {
         // Mu filter over the whole enumerated pair space on the GPU
         // The kernel keeps one chain's profile in LDS and streams the other set past it.  The Mu matrix is symmetric and
@@ -1047,59 +1079,7 @@ static void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOff
         rsk_db *FilterQ = Swap ? S.m_Db : SrcA.m_Db, *FilterT = Swap ? SrcA.m_Db : S.m_Db;
         const size_t ldo = Swap ? NA : NB;
         const uint64_t total = Self ? SelfTotal : (uint64_t) NA * NB;
-        // survivor lists: sized for 1/6 of the pairs (the presets pass 0.3 % of real SCOP40 pairs, 15 % of look-alike synthetic
-        // structures; 8 bytes per slot, 5.3 GB for the largest filter tile), re-run with the exact count on overflow
-        // (the kernel counts every survivor; it only stops storing at `cap`)
-        const uint64_t dense = Tri ? total : (uint64_t) NA * NB;
-        size_t cap = (size_t) std::min<uint64_t>(dense, std::max<uint64_t>(1u << 22, dense / 6));
-        auto hipok = [](hipError_t e, const char *w) { if (e != hipSuccess) throw std::runtime_error(std::string(w) + ": " + hipGetErrorString(e)); };
-        DeviceBuffer Fwd(ctx, (size_t) (Swap ? NB : NA) * ldo, "filter score matrix"), Count(ctx, 4, "survivor counter"), ListQ, ListT;
-        uint32_t ns = 0;
-        for (;;) {
-            ListQ.Make(ctx, cap * 4, "survivor list");
-            ListT.Make(ctx, cap * 4, "survivor list");
-            check(rsk_mu_filter_dev(ctx, FilterQ, FilterT, Tri ? 1 : 0, P.m_ParaMuGapOpen, P.m_ParaMuGapExt, P.m_Omega, P.m_OmegaFwd, Fwd.As<uint8_t>(), ldo,
-                                    ListQ.As<uint32_t>(), ListT.As<uint32_t>(), nullptr, nullptr, cap, Count.As<uint32_t>()),
-                  "rsk_mu_filter_dev");
-            check(rsk_ctx_sync(ctx), "rsk_ctx_sync");                  // the filter is queued on the context's stream; the copies below are not
-            hipok(hipMemcpy(&ns, Count.As<uint32_t>(), 4, hipMemcpyDeviceToHost), "copy n");
-            if (ns <= cap) break;
-            cap = ns;
-        }
-        tm.lap("  Mu filter kernels");
-        // deterministic order (the device list is unordered): by A-side chain, then B-side chain -- the order the reference walks
-        // its pairs in (runself.cpp:72-99, runquery.cpp:82) -- sorted on the device (8.7 M survivors through a host counting
-        // sort + per-chain sorts were 0.15 s), the two columns arrive ordered
-        uint32_t *const dA = Swap ? ListT.As<uint32_t>() : ListQ.As<uint32_t>(), *const dB = Swap ? ListQ.As<uint32_t>() : ListT.As<uint32_t>();
-        check(rsk_pairs_sort_dev(ctx, dA, dB, ns, (uint32_t) NA), "rsk_pairs_sort_dev");
-        std::vector<uint32_t> pa(ns), pb(ns);
-        hipok(hipMemcpy(pa.data(), dA, (size_t) ns * 4, hipMemcpyDeviceToHost), "copy pairs");
-        hipok(hipMemcpy(pb.data(), dB, (size_t) ns * 4, hipMemcpyDeviceToHost), "copy pairs");
-        Fwd.Free(); ListQ.Free(); ListT.Free(); Count.Free();
-        tm.lap("  survivors: device sort + d2h");
         uint64_t nmkf = 0, nskip = 0;
-        {
-            // the pairs this pass aligns: survivors of its shard that are neither skipped (-noself) nor long-chain pairs
-            // (slices on the host threads, concatenated in order)
-            const size_t nsl = std::max<size_t>(1, std::min<size_t>(64, ns / 65536 + 1));
-            std::vector<std::vector<uint32_t> > sa(nsl), sb(nsl);
-            rsk_parallel_for(nsl, 1, [&](size_t lo, size_t hi) {
-                for (size_t sl = lo; sl < hi; ++sl) {
-                    const size_t k0 = (size_t) ns * sl / nsl, k1 = (size_t) ns * (sl + 1) / nsl;
-                    sa[sl].reserve(k1 - k0); sb[sl].reserve(k1 - k0);
-                    for (size_t k = k0; k < k1; ++k) {
-                        const uint i = pa[k], j = pb[k];
-                        if (!InShard(i, j) || Skip(i, j) || IsMKF(i, j)) continue;
-                        sa[sl].push_back(i); sb[sl].push_back(j);
-                    }
-                }
-            });
-            size_t tot = 0;
-            for (size_t sl = 0; sl < nsl; ++sl) tot += sa[sl].size();
-            ia.reserve(tot); ib.reserve(tot);
-            for (size_t sl = 0; sl < nsl; ++sl) { ia.insert(ia.end(), sa[sl].begin(), sa[sl].end()); ib.insert(ib.end(), sb[sl].begin(), sb[sl].end()); }
-        }
-        tm.lap("  alignment pair list");
         // MKF pairs = either chain >= m_MKFL (both with k-mers): enumerated from the list of long chains,
         // not by walking the whole pair space
         std::vector<uint32_t> longB;
@@ -1131,6 +1111,63 @@ static void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOff
                 }
             }
         }
+        // The long-chain job does not depend on the filter (its pairs are known from the chain lengths): it starts NOW on a
+        // context of its own and runs under the filter kernels of this one (r04; r01-r03 started it after the filter, beside
+        // the alignment job only).
+        start_mkf_job();
+        tm.lap("  long-chain pair list (job started)");
+        // survivor lists: sized for 1/6 of the pairs (the presets pass 0.3 % of real SCOP40 pairs, 15 % of look-alike synthetic
+        // structures; 8 bytes per slot, 5.3 GB for the largest filter tile), re-run with the exact count on overflow
+        // (the kernel counts every survivor; it only stops storing at `cap`)
+        const uint64_t dense = Tri ? total : (uint64_t) NA * NB;
+        size_t cap = (size_t) std::min<uint64_t>(dense, std::max<uint64_t>(1u << 22, dense / 6));
+        auto hipok = [](hipError_t e, const char *w) { if (e != hipSuccess) throw std::runtime_error(std::string(w) + ": " + hipGetErrorString(e)); };
+        DeviceBuffer Fwd(ctx, (size_t) (Swap ? NB : NA) * ldo, "filter score matrix"), Count(ctx, 4, "survivor counter"), ListQ, ListT;
+        uint32_t ns = 0;
+        for (;;) {
+            ListQ.Make(ctx, cap * 4, "survivor list");
+            ListT.Make(ctx, cap * 4, "survivor list");
+            check(rsk_mu_filter_dev(ctx, FilterQ, FilterT, Tri ? 1 : 0, P.m_ParaMuGapOpen, P.m_ParaMuGapExt, P.m_Omega, P.m_OmegaFwd, Fwd.As<uint8_t>(), ldo,
+                                    ListQ.As<uint32_t>(), ListT.As<uint32_t>(), nullptr, nullptr, cap, Count.As<uint32_t>()),
+                  "rsk_mu_filter_dev");
+            check(rsk_ctx_sync(ctx), "rsk_ctx_sync");                  // the filter is queued on the context's stream; the copies below are not
+            hipok(hipMemcpy(&ns, Count.As<uint32_t>(), 4, hipMemcpyDeviceToHost), "copy n");
+            if (ns <= cap) break;
+            cap = ns;
+        }
+        tm.lap("  Mu filter kernels");
+        // deterministic order (the device list is unordered): by A-side chain, then B-side chain -- the order the reference walks
+        // its pairs in (runself.cpp:72-99, runquery.cpp:82) -- sorted on the device (8.7 M survivors through a host counting
+        // sort + per-chain sorts were 0.15 s), the two columns arrive ordered
+        uint32_t *const dA = Swap ? ListT.As<uint32_t>() : ListQ.As<uint32_t>(), *const dB = Swap ? ListQ.As<uint32_t>() : ListT.As<uint32_t>();
+        check(rsk_pairs_sort_dev(ctx, dA, dB, ns, (uint32_t) NA), "rsk_pairs_sort_dev");
+        std::vector<uint32_t> pa(ns), pb(ns);
+        hipok(hipMemcpy(pa.data(), dA, (size_t) ns * 4, hipMemcpyDeviceToHost), "copy pairs");
+        hipok(hipMemcpy(pb.data(), dB, (size_t) ns * 4, hipMemcpyDeviceToHost), "copy pairs");
+        Fwd.Free(); ListQ.Free(); ListT.Free(); Count.Free();
+        tm.lap("  survivors: device sort + d2h");
+        {
+            // the pairs this pass aligns: survivors of its shard that are neither skipped (-noself) nor long-chain pairs
+            // (slices on the host threads, concatenated in order)
+            const size_t nsl = std::max<size_t>(1, std::min<size_t>(64, ns / 65536 + 1));
+            std::vector<std::vector<uint32_t> > sa(nsl), sb(nsl);
+            rsk_parallel_for(nsl, 1, [&](size_t lo, size_t hi) {
+                for (size_t sl = lo; sl < hi; ++sl) {
+                    const size_t k0 = (size_t) ns * sl / nsl, k1 = (size_t) ns * (sl + 1) / nsl;
+                    sa[sl].reserve(k1 - k0); sb[sl].reserve(k1 - k0);
+                    for (size_t k = k0; k < k1; ++k) {
+                        const uint i = pa[k], j = pb[k];
+                        if (!InShard(i, j) || Skip(i, j) || IsMKF(i, j)) continue;
+                        sa[sl].push_back(i); sb[sl].push_back(j);
+                    }
+                }
+            });
+            size_t tot = 0;
+            for (size_t sl = 0; sl < nsl; ++sl) tot += sa[sl].size();
+            ia.reserve(tot); ib.reserve(tot);
+            for (size_t sl = 0; sl < nsl; ++sl) { ia.insert(ia.end(), sa[sl].begin(), sa[sl].end()); ib.insert(ib.end(), sb[sl].begin(), sb[sl].end()); }
+        }
+        tm.lap("  alignment pair list");
         npairs = total - nskip;
         S.m_MKFPairCount = nmkf;
         S.m_MuFilterInputCount = npairs - nmkf;
@@ -1171,46 +1208,10 @@ static void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOff
                                 ReplayBatch(S, SrcA, S, bia, bib, out, paths, Self, joff);
                             });
     };
-    // long-chain pairs: MKF path (dssaligner.cpp:809-813), one aligner per host thread as in the reference
-    // (dbsearcher.cpp:98-106); BaseOnAln serialises the output under m_Lock.
-    auto each_orientation = [&](DSSAligner &DA, uint i, uint j, auto &&fn) {
-        if (DA.m_Path.empty()) return;
-        if (Self) {
-            fn(DA, true);
-            if (i != joff + j) fn(DA, false);
-        } else
-            fn(DA, false);
-    };
-    // A plain DBSearcher with both jobs to do runs them side by side: the long-chain job on a context of its own, its
-    // hit lines collected in memory and appended after the alignment job's (the order of the output file stays: Smith-
-    // Waterman hits, then long-chain hits).  The host stages of one job run while the other job's kernels do (the
-    // contexts share the default stream, so the kernels themselves are not concurrent).
-    const bool overlap = !S.m_HasOnAlnOverride && !mkf.empty() && !ia.empty() && !(getenv("RSK_MKF_OVERLAP") && atoi(getenv("RSK_MKF_OVERLAP")) == 0);
-    if (overlap) {
-        SecondaryCtx own;
-        own.Create(ctx->device, "mkf");
-        // hit lines of the long-chain job: one buffer per worker thread (formatting under one lock was a tenth of the job)
-        struct sink { std::string lines; uint64_t hits = 0; char pad[64]; };
-        std::vector<sink> sinks(HostThreads(128));
-        const std::function<void(DSSAligner &, uint, uint, unsigned)> on_hit = [&](DSSAligner &DA, uint i, uint j, unsigned worker) {
-            sink &me = sinks[worker];
-            each_orientation(DA, i, j, [&](DSSAligner &D, bool Up) {
-                if (S.Reject(D, Up)) return;
-                ++me.hits;
-                if (S.m_fTsv && !(S.m_Opts.noself && D.m_ChainA->m_Label == D.m_ChainB->m_Label)) D.AppendTsv(me.lines, Up);
-            });
-        };
-        std::future<void> job = std::async(std::launch::async, [&]() {
-            RunMKFPairs(own.c, P, S.m_Opts.columns, SrcA, S, mkf, [](DSSAligner &, uint, uint) {}, &on_hit);
-        });
-        try {
-            align();
-        } catch (...) {
-            job.wait();
-            throw;
-        }
+    if (job.valid()) {
+        align();
         job.get();
-        tm.lap("align + replay | MKF side by side");
+        tm.lap("align + replay | long-chain job side by side (started before the filter)");
         for (sink &me : sinks) {
             S.m_HitCount += me.hits;
             if (!me.lines.empty() && fwrite(me.lines.data(), 1, me.lines.size(), S.m_fTsv) != me.lines.size()) throw std::runtime_error("short write to the hits file");

@@ -116,22 +116,37 @@ def _run(cmd, cwd, env=None):
     subprocess.run(cmd, check=True, cwd=cwd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 
 
-def fastdb_split_route(bca, workdir, nchains, procs, rsb_size=None, tag="split"):
+def _pool(jobs, procs):
+    """jobs = [(done_marker, cmd, cwd)]: runs those without a marker, `procs` at a time; a marker is written when a job ends
+    with status 0 (a run that is killed resumes with the pieces that are left)."""
+    todo = [j for j in jobs if not os.path.exists(j[0])]
+    running = []
+    while todo or running:
+        while todo and len(running) < procs:
+            j = todo.pop(0)
+            running.append((j, subprocess.Popen(j[1], cwd=j[2], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)))
+        time.sleep(0.2)
+        still = []
+        for j, p in running:
+            rc = p.poll()
+            if rc is None:
+                still.append((j, p))
+            elif rc != 0:
+                raise SystemExit("failed: " + " ".join(j[1]))
+            else:
+                open(j[0], "w").close()
+        running = still
+
+
+def fastdb_split_route(bca, workdir, nchains, procs, rsb_size=None, tag="split", pieces=None):
     ref = os.path.join(ROOT, "oracle", "_ref", "reseek")
     har = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
-    bounds = [nchains * r // procs for r in range(procs + 1)]
+    pieces = pieces or procs
+    bounds = [nchains * r // pieces for r in range(pieces + 1)]
     t0 = time.time()
-    bins = [os.path.join(workdir, "%s_tri_%d.bin" % (tag, r)) for r in range(procs)]
-    ps = []
-    for r in range(procs):
-        if os.path.exists(bins[r] + ".done"):
-            continue
-        cmd = [har, "prefrange", bca, bca, str(bounds[r]), str(bounds[r + 1]), bins[r], "--", "-fast"]      # cmd_search's Params: DM_UseCommandLineOption under -fast
-        ps.append((r, subprocess.Popen(cmd, cwd=workdir, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)))
-    for r, p in ps:
-        if p.wait() != 0:
-            raise SystemExit("prefrange %d failed" % r)
-        open(bins[r] + ".done", "w").close()
+    bins = [os.path.join(workdir, "%s_tri_%d.bin" % (tag, r)) for r in range(pieces)]
+    _pool([(bins[r] + ".done", [har, "prefrange", bca, bca, str(bounds[r]), str(bounds[r + 1]), bins[r], "--", "-fast"], workdir)      # cmd_search's Params: DM_UseCommandLineOption under -fast
+           for r in range(pieces)], procs)
     t1 = time.time()
     handoff = os.path.join(workdir, "%s_handoff.tsv" % tag)
     _run([har, "rsbreplay", str(nchains), str(rsb_size or 1500), handoff] + bins, workdir)
@@ -139,31 +154,26 @@ def fastdb_split_route(bca, workdir, nchains, procs, rsb_size=None, tag="split")
     lines = open(handoff, "rb").read().split(b"\n")
     assert lines[0].startswith(b"prefilter\t") and lines[-1] == b""
     body = lines[1:-1]
-    parts = []
-    ps = []
-    for r in range(procs):
-        mine = body[r::procs]
+    parts, jobs = [], []
+    for r in range(pieces):
+        mine = body[r::pieces]
         fn = os.path.join(workdir, "%s_handoff_%d.tsv" % (tag, r))
-        with open(fn, "wb") as f:
-            f.write(b"prefilter\t%d\n" % len(mine) + b"".join(x + b"\n" for x in mine))
         out = os.path.join(workdir, "%s_hits_%d.tsv" % (tag, r))
         parts.append(out)
-        if os.path.exists(out + ".done") or not mine:
-            if not mine:
-                open(out, "w").close()
+        if not mine:
+            open(out, "w").close()
             continue
-        cmd = [ref, "-postmufilter", bca, "-db", bca, "-filin", fn, "-output", out, "-dbsize", str(nchains), "-threads", "1"]
-        ps.append((out, subprocess.Popen(cmd, cwd=workdir, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)))
-    for out, p in ps:
-        if p.wait() != 0:
-            raise SystemExit("postmufilter failed for " + out)
-        open(out + ".done", "w").close()
+        if not os.path.exists(out + ".done"):
+            with open(fn, "wb") as f:
+                f.write(b"prefilter\t%d\n" % len(mine) + b"".join(x + b"\n" for x in mine))
+        jobs.append((out + ".done", [ref, "-postmufilter", bca, "-db", bca, "-filin", fn, "-output", out, "-dbsize", str(nchains), "-threads", "1"], workdir))
+    _pool(jobs, procs)
     t2 = time.time()
     hits = os.path.join(workdir, "%s_hits.tsv" % tag)
     with open(hits, "wb") as f:
         for out in parts:
             f.write(open(out, "rb").read())
-    return handoff, hits, {"stage1_wall_s": round(t1 - t0, 1), "stage2_wall_s": round(t2 - t1, 1), "processes": procs}
+    return handoff, hits, {"stage1_wall_s_this_run": round(t1 - t0, 1), "stage2_wall_s_this_run": round(t2 - t1, 1), "processes": procs, "pieces": pieces}
 
 
 def fastdb_validate(workdir):
@@ -200,12 +210,12 @@ def fastdb_golden(workdir, procs):
     if not os.path.exists(bca):
         synth_bca(bca + ".tmp%d" % os.getpid(), 0)
         os.replace(bca + ".tmp%d" % os.getpid(), bca)
-    handoff, hits, tm = fastdb_split_route(bca, workdir, 11211, procs, None, "fastdb")
+    handoff, hits, tm = fastdb_split_route(bca, workdir, 11211, procs, None, "fastdb", pieces=96)
     md5, rows = table_md5(hits)
     rec = {"chains": 11211, "mode": "fast", "db": "the same file (-search Q.bca -db Q.bca -fast)", "bca_md5": file_md5(bca), "rows": rows,
            "sorted_table_md5": md5, "handoff_md5": file_md5(handoff), "handoff_bytes": os.path.getsize(handoff),
            "handoff_target_lines": int(open(handoff, "rb").readline().split(b"\t")[1]),
-           "reference_threads": 1, "route": "target ranges on %d one-thread processes of the reference's code (ref_harness prefrange / rsbreplay, "
+           "reference_threads": 1, "route": "96 target ranges, %d one-thread processes at a time, of the reference's code (ref_harness prefrange / rsbreplay, "
            "reseek -postmufilter); validated against the literal `reseek -search Q -db Q -fast -keeptmp -threads 1` on samples "
            "(make_full_golden.py --fastdb --validate)" % procs, **tm}
     out = os.path.join(ROOT, "tests", "golden", "full11211_fastdb.md5.txt")

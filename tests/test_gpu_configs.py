@@ -120,3 +120,23 @@ def test_config3_one_gpu_share_properties(ctx, work):
         assert sorted(open(o).read().splitlines()) == sorted(rows)
     finally:
         del os.environ["RSK_STREAM_CHAINS"]
+
+
+def test_full_size_tool_machinery_at_small_scale():
+    """tools/bench_configs_full.py (BASELINE configs[3] / configs[4] at their stated size as 8 sequential shards; its full run is
+    committed as profiles/r04_configs_full.json) at 1/500 of the size: the 8-shard union equals the 3- and 1-shard unions --
+    config4 through rsk_search_opts.hits_digest, the order-independent digest that replaces a 30 GB table --, pairs and
+    hits add up, and the reference binary agrees on the sample."""
+    import json
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_configs_full.py"), "--scale", "0.002"], capture_output=True, text=True,
+                       cwd=ROOT, timeout=1200)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    d = json.loads(r.stdout)
+    for key in ("config3", "config4"):
+        e = d[key]
+        assert e["union_8_equals_3_equals_1"] and e["pairs_and_hits_add_up"], key
+        assert len(e["shards_8"]["shards"]) == 8 and e["shards_8"]["peak_host_rss_gb"] > 0
+        assert e["vs_reference_on_sample"]["identical"] in (True, None), e["vs_reference_on_sample"]
+    assert d["config4"]["hit_lines"].startswith("digest") and d["config4"]["shards_1"]["union_digest"][0] == d["config4"]["shards_1"]["hits"]

@@ -287,3 +287,41 @@ def test_long_chain_device_batch_from_bca(ctx, tmpdir, monkeypatch):
     run_bca(ctx, tmpdir, "edge.bca", "sensitive", COLS, "hits_edge_sensitive.tsv.gz")
     monkeypatch.setenv("RSK_MKF_CAP", "2")
     run_bca(ctx, tmpdir, "palms.bca", "sensitive", COLS, "hits_palms_sensitive.tsv.gz")
+
+
+def test_hits_digest_is_the_digest_of_the_table(ctx, tmp_path):
+    """rsk_search_opts.hits_digest: the one-line digest (lines, bytes, sum and xor of a 64-bit hash per line) equals the same
+    quantities computed here from the table the same search writes; shard digests combine to it."""
+    import gzip
+    from reseek_amd import capi
+    bca = str(tmp_path / "q100.bca")
+    with gzip.open(os.path.join(fx.GOLDEN, "q100.bca.gz"), "rb") as f, open(bca, "wb") as g:
+        g.write(f.read())
+    M = (1 << 64) - 1
+
+    def h64(b):
+        n = len(b)
+        h = 0x9E3779B97F4A7C15 ^ ((n * 0xD6E8FEB86659FD93) & M)
+        for i in range(0, n, 8):
+            v = int.from_bytes(b[i:i + 8], "little")
+            h = ((h ^ v) * 0xFF51AFD7ED558CCD) & M
+            h ^= h >> 32
+        h = (h * 0xC4CEB9FE1A85EC53) & M
+        return h ^ (h >> 29)
+
+    for mode in ("sensitive", "verysensitive"):
+        tab, dig = str(tmp_path / "t.tsv"), str(tmp_path / "d.tsv")
+        ctx.search(bca, tab, mode, db=bca)
+        ctx.search(bca, dig, mode, db=bca, hits_digest=1)
+        lines = open(tab, "rb").read().splitlines()
+        s = x = 0
+        for ln in lines:
+            v = h64(ln)
+            s = (s + v) & M
+            x ^= v
+        assert capi.read_hits_digest(dig) == (len(lines), os.path.getsize(tab), s, x), mode
+        parts = []
+        for k in range(3):
+            ctx.search(bca, dig, mode, db=bca, hits_digest=1, shard_index=k, shard_count=3)
+            parts.append(capi.read_hits_digest(dig))
+        assert capi.combine_hits_digests(parts) == (len(lines), os.path.getsize(tab), s, x), mode
