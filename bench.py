@@ -258,7 +258,7 @@ def live_kernels(ctx, seqs, db, reps=3):
       k_sw_qp     float SW + trace, 64 queries x all chains (query-profile kernel; the -db / -verysensitive regime)
     Bounds: VALU issue (one wave64 instruction per 4 cycles per SIMD for mixed VOP2/VOP3/DPP streams, profiles/r02_ubench_valu.txt)
     and, for k_sw_float, the LDS (8 random ds_read_b32 per cell).  `pmc` = issue / LDS-busy fractions from the rocprofv3
-    counter passes of `bench.py --live-only` committed as profiles/r03_live_pmc.json (tools/prof_live.sh)."""
+    counter passes of `bench.py --live-only` committed as profiles/r04_live_pmc.json (tools/prof_live.sh)."""
     import torch
     import reseek_amd
     n = len(seqs)
@@ -515,7 +515,7 @@ def config_shares(which=("config2", "config3", "config4")):
                 os.remove(db)
     finally:
         ctx.close()
-    out["kernel_time_split"] = "rocprofv3 kernel traces of these three calls: profiles/r03_search_*_rocprofv3.txt (tools/prof_search.sh)"
+    out["kernel_time_split"] = "rocprofv3 kernel traces of these three calls: profiles/r04_search_*_rocprofv3.txt (tools/prof_search.sh)"
     out["reference_cores_on_this_box"] = cores
     return out
 
@@ -714,17 +714,17 @@ def main():
         traffic, traffic_src = None, None
         try:
             import hashlib
-            with open(os.path.join(ROOT, "profiles", "r03_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r04_traffic.json")) as f:
                 tj = json.load(f)
             with open(os.path.join(ROOT, tj["kernel_source"]), "rb") as f:
                 sha = hashlib.sha256(f.read()).hexdigest()
             if sha != tj["kernel_source_sha256"]:
-                traffic_src = "profiles/r03_traffic.json is STALE (%s changed since the counters were collected): re-run tools/prof_bench.sh" % tj["kernel_source"]
+                traffic_src = "profiles/r04_traffic.json is STALE (%s changed since the counters were collected): re-run tools/prof_bench.sh" % tj["kernel_source"]
             elif n != 11211 or args.chains or world != 1:
-                traffic_src = "profiles/r03_traffic.json holds the 1-GPU full-set workload only"
+                traffic_src = "profiles/r04_traffic.json holds the 1-GPU full-set workload only"
             else:
                 traffic = float(tj["traffic_bytes_per_launch"])
-                traffic_src = "profiles/r03_traffic.json (rocprofv3 PMC FETCH_SIZE x 2 + WRITE_SIZE per dispatch, same command; kernel source sha256 verified)"
+                traffic_src = "profiles/r04_traffic.json (rocprofv3 PMC FETCH_SIZE x 2 + WRITE_SIZE per dispatch, same command; kernel source sha256 verified)"
         except (OSError, ValueError, KeyError) as e:
             traffic_src = "no traffic record (%s)" % e
         res = {

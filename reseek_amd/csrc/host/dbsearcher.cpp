@@ -1140,10 +1140,17 @@ static void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOff
         // its pairs in (runself.cpp:72-99, runquery.cpp:82) -- sorted on the device (8.7 M survivors through a host counting
         // sort + per-chain sorts were 0.15 s), the two columns arrive ordered
         uint32_t *const dA = Swap ? ListT.As<uint32_t>() : ListQ.As<uint32_t>(), *const dB = Swap ? ListQ.As<uint32_t>() : ListT.As<uint32_t>();
-        check(rsk_pairs_sort_dev(ctx, dA, dB, ns, (uint32_t) NA), "rsk_pairs_sort_dev");
+        const bool sort_on_device = ns <= 0x7FFFFFFFu;                // the device sort's item count is 31 bits; beyond it the host orders the list
+        if (sort_on_device) check(rsk_pairs_sort_dev(ctx, dA, dB, ns, (uint32_t) NA), "rsk_pairs_sort_dev");
         std::vector<uint32_t> pa(ns), pb(ns);
         hipok(hipMemcpy(pa.data(), dA, (size_t) ns * 4, hipMemcpyDeviceToHost), "copy pairs");
         hipok(hipMemcpy(pb.data(), dB, (size_t) ns * 4, hipMemcpyDeviceToHost), "copy pairs");
+        if (!sort_on_device) {
+            std::vector<uint64_t> key(ns);
+            rsk_parallel_for(ns, 1 << 20, [&](size_t lo, size_t hi) { for (size_t k = lo; k < hi; ++k) key[k] = ((uint64_t) pa[k] << 32) | pb[k]; });
+            std::sort(key.begin(), key.end());
+            rsk_parallel_for(ns, 1 << 20, [&](size_t lo, size_t hi) { for (size_t k = lo; k < hi; ++k) { pa[k] = (uint32_t) (key[k] >> 32); pb[k] = (uint32_t) key[k]; } });
+        }
         Fwd.Free(); ListQ.Free(); ListT.Free(); Count.Free();
         tm.lap("  survivors: device sort + d2h");
         {
@@ -1787,7 +1794,10 @@ static int search_impl(rsk_ctx *ctx, const char *query_rskdb, const char *db_rsk
         DSSParams Params2;
         Params2.SetDSSParams(o2);
         const std::vector<int> devs = DBSearcher::ParseDeviceList(o.devices.empty() ? getenv("RSK_DEVICES") : o.devices.c_str());
-        if (prefilter_path && devs.size() > 1 && o.shard_count <= 1) {
+        // (the several-device form streams its target shards from a .bca file; any other -db container keeps the one-device
+        // two-stage path below, which takes both -- a device list must not make a call fail that works without it)
+        const bool db_is_bca = have_db && std::string(db_rskdb).size() >= 4 && std::string(db_rskdb).compare(std::string(db_rskdb).size() - 4, 4, ".bca") == 0;
+        if (prefilter_path && devs.size() > 1 && o.shard_count <= 1 && db_is_bca) {
             // the two-stage path on several devices: one target shard per context, the top-B exchange in host memory
             DeviceTeam Team(devs);
             std::vector<rsk_ctx *> cs;
@@ -1796,6 +1806,13 @@ static int search_impl(rsk_ctx *ctx, const char *query_rskdb, const char *db_rsk
             const bool keep = o.keeptmp || keep_tmp_env();
             FastDbOnContexts(cs, query_rskdb, db_rskdb, o, out_tsv, keep ? tmp.c_str() : nullptr, nhits, stats8);
             return RSK_OK;
+        }
+        if (devs.size() == 1 && devs[0] != ctx->device) {
+            // a one-entry list names THE device of the call: the search runs on a helper context there
+            DeviceTeam Team(devs);
+            SearchOptions o1 = o;
+            o1.devices = std::to_string(devs[0]);
+            return search_impl(Team.ctx(0), query_rskdb, db_rskdb, o1, out_tsv, nhits, stats8);      // (o1.devices set: the environment is not consulted again)
         }
         DBSearcher DBS;                       // SelfSearch search.cpp:20-37 / Search_NoMuFilter :39-60
         DBS.m_Params = prefilter_path ? &Params2 : &Params;

@@ -344,24 +344,33 @@ void FastDbOnContexts(const std::vector<rsk_ctx *> &Ctx, const char *query_path,
     }
     std::vector<uint64_t> Hits(D, 0);
     std::vector<std::vector<uint64_t> > Stats(D, std::vector<uint64_t>(8, 0));
+    // the shards' part files are removed on EVERY exit path (a shard that throws must not leave the others' files behind)
+    struct PartFiles {
+        std::vector<std::string> names;
+        ~PartFiles() { for (const std::string &n : names) remove(n.c_str()); }
+    } Parts;
+    for (uint k = 0; k < D; ++k) Parts.names.push_back(std::string(out_tsv) + ".shard" + std::to_string(k));
     on_all([&](uint k) {
-        const std::string part = std::string(out_tsv) + ".shard" + std::to_string(k);
-        FastShardFinish(Sh[k].get(), aq.data(), at.data(), as.data(), aq.size(), part.c_str(), nullptr, &Hits[k], Stats[k].data());
+        FastShardFinish(Sh[k].get(), aq.data(), at.data(), as.data(), aq.size(), Parts.names[k].c_str(), nullptr, &Hits[k], Stats[k].data());
     });
     FILE *f = fopen(out_tsv, "w");
     if (!f) throw std::runtime_error(std::string("cannot create ") + out_tsv);
+    struct Closer { FILE *f; ~Closer() { if (f) fclose(f); } } closer{ f };
     std::vector<char> buf(1 << 20);
     for (uint k = 0; k < D; ++k) {
-        const std::string part = std::string(out_tsv) + ".shard" + std::to_string(k);
-        if (FILE *g = fopen(part.c_str(), "r")) {
-            size_t got;
-            while ((got = fread(buf.data(), 1, buf.size(), g)) > 0)
-                if (fwrite(buf.data(), 1, got, f) != got) { fclose(g); fclose(f); throw std::runtime_error("short write to the hits file"); }
-            fclose(g);
+        FILE *g = fopen(Parts.names[k].c_str(), "r");
+        if (!g) {
+            // a shard without candidates writes no hits file (postmufilter.cpp:219-223: "No hits found"); anything else is an error
+            if (Hits[k] == 0) continue;
+            throw std::runtime_error("the hits of shard " + std::to_string(k) + " are missing (" + Parts.names[k] + ")");
         }
-        remove(part.c_str());
+        size_t got;
+        while ((got = fread(buf.data(), 1, buf.size(), g)) > 0)
+            if (fwrite(buf.data(), 1, got, f) != got) { fclose(g); throw std::runtime_error("short write to the hits file"); }
+        fclose(g);
     }
-    fclose(f);
+    closer.f = nullptr;
+    if (fclose(f) != 0) throw std::runtime_error("short write to the hits file");
     if (nhits) { *nhits = 0; for (uint k = 0; k < D; ++k) *nhits += Hits[k]; }
     if (stats8) {
         for (int c = 0; c < 7; ++c) { stats8[c] = 0; for (uint k = 0; k < D; ++k) stats8[c] += Stats[k][c]; }

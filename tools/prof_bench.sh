@@ -1,8 +1,10 @@
 #!/bin/bash
 # Runs on the GPU box: rocprofv3 kernel trace + PMC passes of the bench command; summaries -> gpurun_out/prof_<tag>/
 TAG=${1:-r01}
-OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
-mkdir -p $OUT
+# rocprofv3 databases stay in /tmp on the box (gpurun merges back at most 64 MiB); the summaries are copied to gpurun_out/prof_<tag>/
+OUT=/tmp/rsk_prof/prof_$TAG
+KEEP=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT $KEEP
 export TMPDIR=/tmp
 CMD="python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-search --no-live"
 cd /tmp
@@ -15,3 +17,4 @@ find $OUT -name "*.csv" | head -30
 python3 $GRAFT_REPO_ROOT/tools/prof_summary.py $OUT > $OUT/summary.txt 2>&1
 python3 $GRAFT_REPO_ROOT/tools/prof_traffic_json.py $OUT > $OUT/traffic.json 2> $OUT/traffic.err
 cat $OUT/summary.txt $OUT/traffic.json
+cp $OUT/*.txt $OUT/*.json $OUT/*.log $OUT/*.err $KEEP/ 2>/dev/null

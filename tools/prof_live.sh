@@ -3,8 +3,10 @@
 # SCOP40-shaped set) -> gpurun_out/prof_<tag>/{summary.txt, live_pmc.json}; copy them to profiles/<tag>_live_* and
 # profiles/r04_live_pmc.json (read by bench.py, which checks the kernel sources' sha256 recorded in it).  Counters are collected in their own passes (no trace options with --pmc).
 TAG=${1:-r04_live}
-OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
-mkdir -p $OUT
+# rocprofv3 databases stay in /tmp on the box (gpurun merges back at most 64 MiB); the summaries are copied to gpurun_out/prof_<tag>/
+OUT=/tmp/rsk_prof/prof_$TAG
+KEEP=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT $KEEP
 export TMPDIR=/tmp
 CMD="python $GRAFT_REPO_ROOT/bench.py --live-only"
 cd /tmp
@@ -16,3 +18,4 @@ rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc4 -o pmc -- $CMD > $OUT/pmc4.log 2>&1
 python3 $GRAFT_REPO_ROOT/tools/prof_summary.py $OUT > $OUT/summary.txt 2>&1
 python3 $GRAFT_REPO_ROOT/tools/prof_live_json.py $OUT > $OUT/live_pmc.json 2> $OUT/live_pmc.err
 cat $OUT/live_pmc.json
+cp $OUT/*.txt $OUT/*.json $OUT/*.log $OUT/*.err $KEEP/ 2>/dev/null

@@ -2,8 +2,10 @@
 # Runs on the GPU box: rocprofv3 kernel trace of one tools/bench_search.py command -> gpurun_out/prof_<tag>/summary.txt
 # usage: prof_search.sh TAG qdb 1000 30000 verysensitive
 TAG=$1; shift
-OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
-mkdir -p $OUT
+# rocprofv3 databases stay in /tmp on the box (gpurun merges back at most 64 MiB); the summaries are copied to gpurun_out/prof_<tag>/
+OUT=/tmp/rsk_prof/prof_$TAG
+KEEP=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT $KEEP
 export TMPDIR=/tmp
 cd /tmp
 timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python $GRAFT_REPO_ROOT/tools/bench_search.py "$@" > $OUT/trace.log 2>&1 < /dev/null
@@ -21,3 +23,4 @@ PY
   grep '"seconds"' $OUT/trace.log
 } > $OUT/summary.txt 2>&1 < /dev/null
 cat $OUT/summary.txt
+cp $OUT/*.txt $OUT/*.json $OUT/*.log $OUT/*.err $KEEP/ 2>/dev/null
