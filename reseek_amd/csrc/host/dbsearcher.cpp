@@ -1114,7 +1114,8 @@ static void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOff
         // The long-chain job does not depend on the filter (its pairs are known from the chain lengths): it starts NOW on a
         // context of its own and runs under the filter kernels of this one (r04; r01-r03 started it after the filter, beside
         // the alignment job only).
-        start_mkf_job();
+        const bool early = !(getenv("RSK_MKF_EARLY") && atoi(getenv("RSK_MKF_EARLY")) == 0);      // 0: start it after the filter (r03 behaviour, for A/B timing)
+        if (early) start_mkf_job();
         tm.lap("  long-chain pair list (job started)");
         // survivor lists: sized for 1/6 of the pairs (the presets pass 0.3 % of real SCOP40 pairs, 15 % of look-alike synthetic
         // structures; 8 bytes per slot, 5.3 GB for the largest filter tile), re-run with the exact count on overflow
@@ -1215,6 +1216,7 @@ static void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOff
                                 ReplayBatch(S, SrcA, S, bia, bib, out, paths, Self, joff);
                             });
     };
+    if (!job.valid()) start_mkf_job();             // (RSK_MKF_EARLY=0, or no filter in this mode)
     if (job.valid()) {
         align();
         job.get();

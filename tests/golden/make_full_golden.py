@@ -215,6 +215,7 @@ def fastdb_golden(workdir, procs):
     rec = {"chains": 11211, "mode": "fast", "db": "the same file (-search Q.bca -db Q.bca -fast)", "bca_md5": file_md5(bca), "rows": rows,
            "sorted_table_md5": md5, "handoff_md5": file_md5(handoff), "handoff_bytes": os.path.getsize(handoff),
            "handoff_target_lines": int(open(handoff, "rb").readline().split(b"\t")[1]),
+           "candidates": sum(int(ln.split(b"\t", 2)[1]) for ln in open(handoff, "rb").read().split(b"\n")[1:-1]),
            "reference_threads": 1, "route": "96 target ranges, %d one-thread processes at a time, of the reference's code (ref_harness prefrange / rsbreplay, "
            "reseek -postmufilter); validated against the literal `reseek -search Q -db Q -fast -keeptmp -threads 1` on samples "
            "(make_full_golden.py --fastdb --validate)" % procs, **tm}

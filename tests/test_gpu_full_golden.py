@@ -66,3 +66,28 @@ def test_full_size_hit_table_equals_the_reference(bca, mode):
         got_md5, got_rows = mfg.prefix_md5(lines, prefix["rows_with_min_index_below"])
         assert (got_rows, got_md5) == (prefix["rows"], prefix["sorted_rows_md5"]), "rows below chain %d: %d vs %d" % (
             prefix["rows_with_min_index_below"], got_rows, prefix["rows"])
+
+
+def test_full_size_fast_db_equals_the_reference(bca):
+    """BASELINE configs[2] at full size: `-search Q.bca -db Q.bca -fast` (search.cpp:76-111: MuPreFilter over 11,211 x 11,211,
+    the per-query top-1500 bags, PostMuFilter of the 16.5 M candidates) must reproduce BOTH the reference's hand-off file
+    (-keeptmp: md5 of the bytes) and its sorted hit table (tests/golden/full11211_fastdb.md5.txt; the golden comes from
+    one-thread processes of the reference over target ranges, a route make_full_golden.py --fastdb --validate checks against
+    the literal one-thread command on samples)."""
+    import make_full_golden as mfg
+    import reseek_amd
+    g = golden("full11211_fastdb.md5.txt")
+    assert g, "no full-size golden for -fast -db"
+    path, md5, d = bca
+    assert g["bca_md5"] == md5, "the synthetic .bca differs from the one the golden was made from (generator drift, not a search difference)"
+    ctx = reseek_amd.Ctx(0)
+    out = os.path.join(d, "hits_fastdb.tsv")
+    nhits, st = ctx.search(path, out, "fast", db=path, keeptmp=1)
+    ctx.close()
+    tmp = out + ".prefilter.tmp"
+    assert st[7] == 1 and st[0] == g["candidates"], "prefilter candidates: %d vs %d" % (st[0], g["candidates"])
+    assert (os.path.getsize(tmp), mfg.file_md5(tmp)) == (g["handoff_bytes"], g["handoff_md5"]), "hand-off file differs from the reference's"
+    if g.get("sorted_table_md5"):
+        got_md5, got_rows = mfg.table_md5(out)
+        assert (got_rows, got_md5) == (g["rows"], g["sorted_table_md5"]), "hit table: %d rows vs %d" % (got_rows, g["rows"])
+        assert nhits == g["rows"]
