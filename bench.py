@@ -226,13 +226,19 @@ def prefilter_entry(ctx, name, what, seqs, pmc, reps=2):
     survey = 14.0 * items + 2.0 * cells + nres
     return {"kernel": "k_prefilter", "workload": name, "what": what, "kernel_ms": ms_, "chains": n, "index_postings": int(postings), "seed_items": int(items),
             "seed_items_per_s": items / ms_ * 1e3, "twohit_diagonals": int(twohit), "diagonal_cells": int(cells), "result_triples": triples,
-            "bound": "hbm", "unit": "GB/s", "achieved": ours / ms_ * 1e3 / 1e9, "peak": PEAK_HBM_GBS, "frac": ours / ms_ * 1e3 / 1e9 / PEAK_HBM_GBS,
-            "algorithmic_bytes": ours,
-            "survey_model": {"bytes": survey, "achieved_GBs": survey / ms_ * 1e3 / 1e9, "frac": survey / ms_ * 1e3 / 1e9 / PEAK_HBM_GBS,
-                             "formula": "14 B x seed items + 2 B x diagonal cells + target letters (SURVEY 8d)"},
-            "valu": {"instructions_per_cell": 5.5, "achieved_T_wave_lane_instr_per_s": 5.5 * cells / ms_ * 1e3 / 1e12,
-                     "peak": PEAK_VALU_LANEOPS / 1e12, "frac": 5.5 * cells / ms_ * 1e3 / PEAK_VALU_LANEOPS,
-                     "note": "diagonal scans: perm + extract + LDS gather + add + 2 max per cell, one wave64 instruction per 4 cycles per SIMD"},
+            # the diagonal scans are the larger share of the kernel time (RSK_PF_DEBUG=1 stops after the seed walk: 0.10 of 0.64 s on
+            # the config-2 letters, 30 of 93 ms on SCOP40), so the entry's bound is the VALU one; the byte models follow under `hbm`
+            "bound": "valu", "unit": "T lane-instr/s", "instructions_per_cell": 5.5, "achieved": 5.5 * cells / ms_ * 1e3 / 1e12,
+            "peak": PEAK_VALU_LANEOPS / 1e12, "frac": 5.5 * cells / ms_ * 1e3 / PEAK_VALU_LANEOPS,
+            "note": "diagonal scans (FindHSP): perm + extract + LDS gather + add + 2 max per cell = 5.5 wave64 instructions per cell "
+                    "at one instruction per 4 cycles per SIMD; the seed walk (one posting read, one LDS read, one or two LDS atomics "
+                    "per item) is latency / HBM bound and not in this fraction",
+            "hbm": {"algorithmic_bytes": ours, "achieved_GBs": ours / ms_ * 1e3 / 1e9, "frac": ours / ms_ * 1e3 / 1e9 / PEAK_HBM_GBS,
+                    "formula": "4 B x seed items (the posting) + 2 B x diagonal cells (letters; L2 / LDS resident in practice) + 12 B x "
+                               "result triples + target letters",
+                    "survey_model": {"bytes": survey, "achieved_GBs": survey / ms_ * 1e3 / 1e9, "frac": survey / ms_ * 1e3 / 1e9 / PEAK_HBM_GBS,
+                                     "formula": "14 B x seed items + 2 B x diagonal cells + target letters (SURVEY 8d)"},
+                    "posting_reads_GBs": 4.0 * items / ms_ * 1e3 / 1e9},
             "pmc": pmc.get("k_prefilter") if name.startswith("config2") else None}
 
 

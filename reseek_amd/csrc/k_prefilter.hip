@@ -364,12 +364,22 @@ __global__ __launch_bounds__(PF_THREADS) void k_prefilter(pf_args a)
         if (a.dbg == 1) { qa = qb; continue; }
 
         // ---- two-hit diagonals = set bits of seen2, compacted into the list in rounds of <= PF_LIST and scored
+        // (the waves claim 64 entries at a time: diagonal lengths run from 7 to the chain length along the list, and with a
+        // fixed share per wave the round ended when the wave holding the long ones did)
         auto score_list = [&](uint32_t n) {
+            if (tid == 0) sv[4] = 0;
             __syncthreads();
-            for (uint32_t i = tid; i < n; i += PF_THREADS) {
-                const uint32_t e = list[i];
-                const uint32_t sc = diag_score(qa + (e >> 14), (int) (e & 16383u));
-                if (sc > 0) atomicMax(&qmax[e >> 14], sc);
+            for (;;) {
+                uint32_t c = 0;
+                if (lane == 0) c = atomicAdd(&sv[4], 64u);
+                c = (uint32_t) __builtin_amdgcn_readfirstlane((int) c);
+                if (c >= n) break;
+                const uint32_t i = c + (uint32_t) lane;
+                if (i < n) {
+                    const uint32_t e = list[i];
+                    const uint32_t sc = diag_score(qa + (e >> 14), (int) (e & 16383u));
+                    if (sc > 0) atomicMax(&qmax[e >> 14], sc);
+                }
             }
             ++nrounds;
             __syncthreads();

@@ -147,3 +147,35 @@ def test_the_reference_search_cpp_runs_on_a_device_list(work):
         pytest.skip("oracle/_ref/search_refsrc not built (make -f oracle/Makefile.ref where /root/reference exists)")
     _run(exe, work, ["q100.bca", "-sensitive"], "hits_q100_sensitive.tsv.gz", env={"RSK_DEVICES": "0,0"})
     _run(exe, work, ["q100.bca", "-db", "q100.bca", "-sensitive"], "hits_q100_db_q100_sensitive.tsv.gz", env={"RSK_DEVICES": "0,0,0"})
+
+
+def test_the_callers_current_device_survives_a_several_device_search(ctx, work):
+    """a search over a device list creates helper contexts on other devices; the calling thread's current device
+    must be what it was (arrays that belong to a chain set are allocated on the SET's device whatever it is), so a chain
+    set used afterwards still works.  With two GPUs the list is "0,1" (distinct devices), on a one-GPU box "0,0"; a
+    one-entry list names the device of the call."""
+    import numpy as np
+    import torch
+    import reseek_amd
+    two = torch.cuda.device_count() >= 2
+    devices = "0,1" if two else "0,0"
+    torch.cuda.set_device(0)
+    before = torch.cuda.current_device()
+    out = os.path.join(work, "dev.tsv")
+    n, st = ctx.search(os.path.join(work, "q100.bca"), out, "sensitive", columns=COLS, devices=devices)
+    assert table(out) == golden("hits_q100_sensitive.tsv.gz")
+    assert torch.cuda.current_device() == before
+    # a chain set created and used on the caller's context AFTER that call (its lazily built arrays land on its own device)
+    rng = np.random.default_rng(5)
+    seqs = [rng.integers(0, 36, int(L)).astype(np.uint8) for L in rng.integers(20, 300, 64)]
+    db = reseek_amd.Db.from_mu_seqs(ctx, seqs)
+    o = torch.zeros((64, 64), dtype=torch.int16, device="cuda:0")
+    ctx.mu_gapless_matrix_dev(db, db, True, o.data_ptr(), 64)
+    ctx.sync()
+    import oracle_lib as ol
+    ia, ib = np.triu_indices(64)
+    assert np.array_equal(o.cpu().numpy().astype(np.uint16)[ia, ib].astype(np.int32), ol.mu_gapless_pairs(seqs, ia, ib))
+    db.close()
+    # one-entry list: the search runs on that device (device 1 when there is one)
+    n2, st2 = ctx.search(os.path.join(work, "q100.bca"), out, "sensitive", columns=COLS, devices="1" if two else "0")
+    assert table(out) == golden("hits_q100_sensitive.tsv.gz")
