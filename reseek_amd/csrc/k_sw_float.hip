@@ -371,8 +371,12 @@ struct swq_item { uint32_t first, count, ncol, gs; uint64_t tb_base; };
 #define SWQ_MASK_GE(m, x, y) asm volatile("v_cmp_ge_f32_e64 %0, %1, %2" : "=s"(m) : "v"(x), "v"(y))
 #define SWQ_MASK_0GE(m, y) asm volatile("v_cmp_ge_f32_e64 %0, 0, %1" : "=s"(m) : "v"(y))
 // two masks to trace memory (wave-uniform address, 16-byte aligned)
+#ifndef SWQ_EXPERIMENT_NO_TRACE_STORE
 #define SWQ_STORE2(m0, m1, ptr, off) \
     asm volatile("s_store_dwordx4 %0, %1, %2" :: "s"(__uint128_t(m0) | (__uint128_t(m1) << 64)), "s"(ptr), "n"(off) : "memory")
+#else   // timing experiment only (tools/exp): the masks are computed and dropped -- what the trace stores cost
+#define SWQ_STORE2(m0, m1, ptr, off) asm volatile("" :: "s"(m0), "s"(m1), "s"(ptr))
+#endif
 
 typedef float swq_v2f __attribute__((ext_vector_type(2)));
 typedef float swq_v4f __attribute__((ext_vector_type(4)));
@@ -655,6 +659,9 @@ __global__ void k_traceback(const uint8_t *tb, const uint64_t *tb_off, const uin
     lo_a[p] = RSK_NO_POS;
     lo_b[p] = RSK_NO_POS;
     if (score[p] == 0.0f) return;                     // sw.cpp:200-201
+#ifdef SWQ_EXPERIMENT_NO_TRACE_STORE
+    return;                                           // (timing experiment: there is no trace to walk)
+#endif
     const uint32_t cls = (p >= cl.first[1]) + (p >= cl.first[2]) + (p >= cl.first[3]);
     const bool rows_are_a = cls == 0 || cls == 2;     // strips along A: the strip row is i, the wave step is j
     const uint32_t LA = a_len[ia[p]], LB = b_len[ib[p]];
