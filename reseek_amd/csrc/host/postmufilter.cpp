@@ -145,7 +145,8 @@ void MuPreFilterBags(rsk_ctx *ctx, const std::vector<uint32_t> &qlen, const std:
     auto hipok = [](hipError_t e, const char *w) { if (e != hipSuccess) throw std::runtime_error(std::string(w) + ": " + hipGetErrorString(e)); };
     size_t cap = (size_t) std::min<uint64_t>((uint64_t) NQ * NT, 1ull << 28);      // every (query, target) can appear at most once
     DeviceBuffer Count(ctx, 4, "prefilter result counter");
-    std::vector<uint64_t> keys;
+    std::unique_ptr<uint64_t[]> keys;                  // ~1 GB on a dense set: not value-initialised
+    size_t nkeys = 0;
     for (;;) {
         DeviceBuffer Q(ctx, cap * 4, "prefilter results"), T(ctx, cap * 4, "prefilter results"), S(ctx, cap * 4, "prefilter results");
         check(rsk_mu_prefilter_dev(ctx, qdb, tdb, idx_mode, Q.As<uint32_t>(), T.As<uint32_t>(), S.As<uint32_t>(), cap, Count.As<uint32_t>()), "rsk_mu_prefilter_dev");
@@ -156,14 +157,15 @@ void MuPreFilterBags(rsk_ctx *ctx, const std::vector<uint32_t> &qlen, const std:
             tm.lap("index + scan (GPU)");
             DeviceBuffer K(ctx, (size_t) std::max<uint32_t>(n, 1) * 8, "prefilter keys");
             check(rsk_triples_sort_dev(ctx, Q.As<uint32_t>(), T.As<uint32_t>(), S.As<uint32_t>(), n, K.As<uint64_t>()), "rsk_triples_sort_dev");
-            keys.resize(n);
-            hipok(hipMemcpy(keys.data(), K.As<uint64_t>(), (size_t) n * 8, hipMemcpyDeviceToHost), "copy keys");
+            keys.reset(new uint64_t[std::max<uint32_t>(n, 1)]);
+            nkeys = n;
+            hipok(hipMemcpy(keys.get(), K.As<uint64_t>(), (size_t) n * 8, hipMemcpyDeviceToHost), "copy keys");
             tm.lap("triples: device sort + d2h");
             break;
         }
         cap = n;                               // the count is exact even when the list was truncated
     }
-    if (ReplaySortedKeys(RSB, keys.data(), keys.size(), NQ, rsb_size) != RSK_OK) throw std::runtime_error(std::string("MuPreFilter: ") + rsk_last_error());
+    if (ReplaySortedKeys(RSB, keys.get(), nkeys, NQ, rsb_size) != RSK_OK) throw std::runtime_error(std::string("MuPreFilter: ") + rsk_last_error());
     tm.lap("top-B bags (replay)");
 }
 

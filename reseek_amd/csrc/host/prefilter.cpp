@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdio>
+#include <functional>
 #include <map>
 #include <numeric>
 #include <thread>
@@ -45,16 +46,20 @@ void RankedScoresBag::TruncateVecs(uint QueryIdx)
     std::vector<uint16_t> &ScoreVec = m_QueryIdxToScoreVec[QueryIdx];
     const uint CurrentSize = (uint) ScoreVec.size();
     if (CurrentSize < m_B) return;
-    std::vector<uint> Order(CurrentSize);
+    // scratch of the calling thread, reused between calls (a replay truncates ~6 times per query: three fresh vectors per
+    // call were a quarter of its time)
+    static thread_local std::vector<uint> Order, NewTargetIdxVec;
+    static thread_local std::vector<uint16_t> NewScoreVec;
+    Order.resize(CurrentSize);
     std::iota(Order.begin(), Order.end(), 0u);
     QuickSortOrderDescRecurse(ScoreVec.data(), 0, (int) CurrentSize - 1, Order.data());
     std::vector<uint> &TargetIdxVec = m_QueryIdxToTargetIdxVec[QueryIdx];
-    std::vector<uint16_t> NewScoreVec(m_B);
-    std::vector<uint> NewTargetIdxVec(m_B);
+    NewScoreVec.resize(m_B);
+    NewTargetIdxVec.resize(m_B);
     for (uint k = 0; k < m_B; ++k) { NewScoreVec[k] = ScoreVec[Order[k]]; NewTargetIdxVec[k] = TargetIdxVec[Order[k]]; }
     m_QueryIdxToLoScore[QueryIdx] = NewScoreVec[m_B - 1];
-    TargetIdxVec.swap(NewTargetIdxVec);
-    ScoreVec.swap(NewScoreVec);
+    TargetIdxVec.assign(NewTargetIdxVec.begin(), NewTargetIdxVec.end());      // capacity stays (2 B entries)
+    ScoreVec.assign(NewScoreVec.begin(), NewScoreVec.end());
 }
 
 void RankedScoresBag::AddScore(uint QueryIdx, uint TargetIdx, uint16_t Score)
@@ -69,7 +74,8 @@ void RankedScoresBag::AddScore(uint QueryIdx, uint TargetIdx, uint16_t Score)
 
 void RankedScoresBag::Finish()
 {
-    for (uint q = 0; q < m_QueryCount; ++q) TruncateVecs(q);
+    // (bags are independent: on the host threads)
+    rsk_parallel_for(m_QueryCount, 64, [&](size_t lo, size_t hi) { for (size_t q = lo; q < hi; ++q) TruncateVecs((uint) q); });
 }
 
 // The selected candidates target-major: First[t] .. First[t + 1] = the queries (ascending) that kept target t.  This is the
@@ -77,19 +83,56 @@ void RankedScoresBag::Finish()
 void RankedScoresBag::GroupByTarget(std::vector<size_t> &First, std::vector<uint> &Queries, uint &TargetCount)
 {
     Finish();
-    uint MaxT = 0;
+    // counting sort by target on the host threads: slices of consecutive queries count their targets, the slices' counts are
+    // stacked per target in slice order (so a target's queries come out ascending), then every slice scatters its own
+    const unsigned T = (unsigned) std::max<size_t>(1, std::min<size_t>(HostThreads(32), (size_t) m_QueryCount / 256 + 1));
+    std::vector<uint> maxT(T, 0);
+    std::vector<size_t> tot(T, 0);
+    auto slice = [&](unsigned k, uint &lo, uint &hi) { lo = (uint) ((uint64_t) m_QueryCount * k / T); hi = (uint) ((uint64_t) m_QueryCount * (k + 1) / T); };
+    auto on_slices = [&](const std::function<void(unsigned)> &fn) {
+        if (T == 1) { fn(0); return; }
+        std::vector<std::thread> ts;
+        for (unsigned k = 0; k < T; ++k) ts.emplace_back(fn, k);
+        for (auto &t : ts) t.join();
+    };
+    on_slices([&](unsigned k) {
+        uint lo, hi;
+        slice(k, lo, hi);
+        for (uint q = lo; q < hi; ++q)
+            for (uint t : m_QueryIdxToTargetIdxVec[q]) { maxT[k] = std::max(maxT[k], t); ++tot[k]; }
+    });
     size_t Total = 0;
-    for (uint q = 0; q < m_QueryCount; ++q)
-        for (uint t : m_QueryIdxToTargetIdxVec[q]) { MaxT = std::max(MaxT, t); ++Total; }
-    First.assign(Total ? (size_t) MaxT + 2 : 1, 0);
-    for (uint q = 0; q < m_QueryCount; ++q)
-        for (uint t : m_QueryIdxToTargetIdxVec[q]) ++First[(size_t) t + 1];
-    TargetCount = 0;
-    for (size_t t = 0; t + 1 < First.size(); ++t) { if (First[t + 1]) ++TargetCount; First[t + 1] += First[t]; }
+    uint MaxT = 0;
+    for (unsigned k = 0; k < T; ++k) { Total += tot[k]; MaxT = std::max(MaxT, maxT[k]); }
+    const size_t NT = Total ? (size_t) MaxT + 1 : 0;
+    First.assign(NT + 1, 0);
     Queries.resize(Total);
-    std::vector<size_t> Cur(First.begin(), First.end() - 1);
-    for (uint q = 0; q < m_QueryCount; ++q)                              // ascending q: every target's list comes out sorted
-        for (uint t : m_QueryIdxToTargetIdxVec[q]) Queries[Cur[t]++] = q;
+    TargetCount = 0;
+    if (!Total) return;
+    std::vector<std::vector<uint32_t> > cnt(T);
+    on_slices([&](unsigned k) {
+        uint lo, hi;
+        slice(k, lo, hi);
+        cnt[k].assign(NT, 0);
+        for (uint q = lo; q < hi; ++q)
+            for (uint t : m_QueryIdxToTargetIdxVec[q]) ++cnt[k][t];
+    });
+    // First[t] and, per slice, its first position inside target t's run (cnt[k][t] becomes that offset)
+    size_t run = 0;
+    for (size_t t = 0; t < NT; ++t) {
+        First[t] = run;
+        size_t here = 0;
+        for (unsigned k = 0; k < T; ++k) { const uint32_t c = cnt[k][t]; cnt[k][t] = (uint32_t) here; here += c; }
+        if (here) ++TargetCount;
+        run += here;
+    }
+    First[NT] = run;
+    on_slices([&](unsigned k) {
+        uint lo, hi;
+        slice(k, lo, hi);
+        for (uint q = lo; q < hi; ++q)                                   // ascending q inside the slice
+            for (uint t : m_QueryIdxToTargetIdxVec[q]) Queries[First[t] + cnt[k][t]++] = q;
+    });
 }
 
 // candidate pairs in hand-off order without the file (the single-process search hands them over in memory)
