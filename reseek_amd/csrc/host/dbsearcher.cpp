@@ -1838,7 +1838,10 @@ static int search_impl(rsk_ctx *ctx, const char *query_rskdb, const char *db_rsk
             Src.m_SelfRevQueryFlavour = true;            // postmufilter.cpp:171
             Src.m_Opts = o;
             Src.m_Ctx = ctx;
-            Src.LoadDB(db_rskdb);
+            // `-search X -db X`: the two sides are the same file read under the same parameters and the same self-rev
+            // flavour (both stages of cmd_search load it with DM_AlwaysSensitive) -- one load, the DB side is a view of it
+            if (std::string(db_rskdb) == std::string(query_rskdb)) Src.MakeView(DBS, 0, DBS.GetDBChainCount());
+            else Src.LoadDB(db_rskdb);
             // the candidates go from stage to stage in memory, in the hand-off file's order; the file itself
             // (rankedscoresbag.cpp:185-231) is written for -keeptmp only
             const std::string tmp = std::string(out_tsv) + ".prefilter.tmp";
