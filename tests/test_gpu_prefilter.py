@@ -211,3 +211,21 @@ def test_device_sorted_keys_and_key_replay(ctx, tmp_path):
         gq, gt, gs, _ = run_prefilter(ctx, dense, cap=40 * 40 + 16, mode=mode)
         oq, ot, os_ = ol.prefilter(dense, dense, mode=mode)
         assert as_set(gq, gt, gs) == as_set(np.asarray(oq), np.asarray(ot), np.asarray(os_)), "dense set, mode %d" % mode
+
+
+def test_very_long_chains_and_the_diagonal_cut(ctx):
+    """Chains beyond 8,192 residues: QL + TL - 1 exceeds the 16,384 diagonals a query's bitmap holds, seeds on diagonals
+    > 16383 are dropped (prefiltermu.cpp:254) and the diagonal index wraps at 16 bits before that test (a reference quirk the
+    oracle restates).  Both roles, exact k-mers and the neighbourhood index, against the oracle."""
+    rng = np.random.default_rng(11)
+
+    def lowc(L):
+        runs = rng.integers(2, 30, L)
+        lets = rng.choice(np.array([17, 34, 35, 33, 14, 3], np.uint8), L)
+        return np.repeat(lets, runs)[:L].astype(np.uint8)
+
+    seqs = [lowc(17000), lowc(300), lowc(9000), lowc(40), lowc(700), lowc(66000)[:65000]]
+    for mode in (0, 2):
+        gq, gt, gs, _ = run_prefilter(ctx, seqs, cap=64, mode=mode)
+        oq, ot, os_ = ol.prefilter(seqs, seqs, mode=mode)
+        assert as_set(gq, gt, gs) == as_set(np.asarray(oq), np.asarray(ot), np.asarray(os_)), "mode %d" % mode
