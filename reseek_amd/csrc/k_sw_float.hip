@@ -830,27 +830,17 @@ __global__ __launch_bounds__(256) void k_lddt(const char *paths, const uint64_t 
             scnt[wv][c] = 0;
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        const uint32_t C = ncols, npair = C * (C - 1) / 2, per = (npair + 63) / 64;
-        const uint32_t t0 = (uint32_t) lane * per, t1 = min(npair, t0 + per);
+        const uint32_t C = ncols;
+        // Every unordered column pair once, in TILES of 64 x 64 columns (r04).  A lane keeps ONE column of the tile's first
+        // block in registers for the whole tile; inside a block the partner is the column s places further on (cyclically:
+        // s = 1 .. n / 2 covers every pair of the block's n columns once), between two blocks the partner is the same column
+        // for all lanes (a broadcast read).  No per-lane bookkeeping, no divergent reload of the held column, two LDS reads per
+        // test.  (r01-r03 cut the row-major list of pairs into 64 equal runs: every lane walked its own (ci, cj) and reloaded
+        // ci's coordinates whenever its row changed -- on most steps some lane did -- which doubled the LDS reads of a step.)
         // Two phases per step so that the expensive part runs on full waves: every lane tests one column pair (two squared
         // distances); the ~10 % that lie within R0 are compacted into a per-wave LDS queue (ballot + prefix count), and
         // whenever 64 are waiting each lane finishes one of them (two correctly rounded square roots, the four
-        // thresholds, the counters of both columns).  Before, the wave ran the square-root block on almost every step
-        // for the few lanes that needed it.
-        uint32_t ci = 0, cj = 1;
-        float4 p4 = make_float4(0, 0, 0, 0);
-        float2 p2 = make_float2(0, 0);
-        if (t0 < t1) {
-            // row of the first pair: largest ci with ci (2C - ci - 1) / 2 <= t0
-            const float twoc = (float) (2 * C - 1);
-            ci = (uint32_t) ((twoc - sqrtf(fmaxf(twoc * twoc - 8.0f * (float) t0, 0.0f))) * 0.5f);
-            ci = min(ci, C - 2);
-            while (ci > 0 && ci * (2 * C - ci - 1) / 2 > t0) --ci;
-            while ((ci + 1) * (2 * C - ci - 2) / 2 <= t0) ++ci;
-            cj = ci + 1 + (t0 - ci * (2 * C - ci - 1) / 2);
-            p4 = sc4[wv][ci];
-            p2 = sc2[wv][ci];
-        }
+        // thresholds, the counters of both columns).
         uint32_t qn = 0;                                          // entries waiting in the queue (wave-uniform)
         auto drain = [&](uint32_t n) {                            // the first n entries, one per lane
             if ((uint32_t) lane < n) {
@@ -876,13 +866,13 @@ __global__ __launch_bounds__(256) void k_lddt(const char *paths, const uint64_t 
             qn -= n;
         };
         const unsigned long long lt = (1ull << lane) - 1ull;
-        for (uint32_t k = 0; k < per; ++k) {
-            const bool live = t0 + k < t1;
+        // one test: column `mine` (this lane's, coordinates in p4 / p2) against column `other`; live = the lane takes part
+        auto test = [&](bool live, uint32_t mine, uint32_t other, const float4 &p4, const float2 &p2) {
             bool hit = false;
             float d1s = 0.0f, d2s = 0.0f;
             if (live) {
-                const float4 q4 = sc4[wv][cj];
-                const float2 q2 = sc2[wv][cj];
+                const float4 q4 = sc4[wv][other];
+                const float2 q2 = sc2[wv][other];
                 // (x1-x2)^2 == (x2-x1)^2 exactly, so the reference's (lower column) - (higher column) order is immaterial.
                 // pdbchain.cpp:320-335: dx*dx + dy*dy + dz*dz, every product and sum rounded separately (-ffp-contract=off);
                 // lane-wise packed ops (v_pk_add_f32 / v_pk_mul_f32) do the A-side and the B-side distance at once
@@ -899,18 +889,31 @@ __global__ __launch_bounds__(256) void k_lddt(const char *paths, const uint64_t 
             if (m) {
                 if (hit) {
                     const uint32_t slot = qn + (uint32_t) __popcll(m & lt);
-                    sq_cols[wv][slot] = ci | (cj << 16);
+                    sq_cols[wv][slot] = mine | (other << 16);
                     sq_d[wv][slot] = make_float2(d1s, d2s);
                 }
                 qn += (uint32_t) __popcll(m);
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 if (qn >= 64) drain(64);
             }
-            if (live && ++cj == C) {
-                ++ci;
-                cj = ci + 1;
-                if (ci < C - 1) { p4 = sc4[wv][ci]; p2 = sc2[wv][ci]; }
+        };
+        const uint32_t nblk = (C + 63) / 64;
+        for (uint32_t bi = 0; bi < nblk; ++bi) {
+            const uint32_t base_i = bi * 64, n = min(64u, C - base_i);      // this block's columns: base_i .. base_i + n - 1
+            const bool have = (uint32_t) lane < n;
+            const uint32_t mine = base_i + (uint32_t) lane;
+            float4 p4 = make_float4(0, 0, 0, 0);
+            float2 p2 = make_float2(0, 0);
+            if (have) { p4 = sc4[wv][mine]; p2 = sc2[wv][mine]; }
+            // pairs inside the block: partner = (lane + s) mod n; for even n the step s = n / 2 meets every pair from both ends
+            for (uint32_t sft = 1; 2 * sft <= n; ++sft) {
+                uint32_t o = (uint32_t) lane + sft;
+                if (o >= n) o -= n;
+                const bool live = have && !(2 * sft == n && (uint32_t) lane >= sft);
+                test(live, mine, base_i + o, p4, p2);
             }
+            // pairs with the columns of the later blocks: one partner column per step, the same for every lane
+            for (uint32_t cj = base_i + 64; cj < C; ++cj) test(have, mine, cj, p4, p2);
         }
         if (qn) drain(qn);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
