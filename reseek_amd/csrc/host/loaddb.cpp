@@ -1,0 +1,467 @@
+// loaddb.cpp -- DBSearcher: chain sets in host memory and on the device (ProfileLoader::Load profileloader.cpp:72,
+// DBSearcher::LoadDB / Setup dbsearcher.cpp:40-110): .bca / .rskdb reading, DSS featurisation of a batch (densities, SS,
+// Conf letters, neighbours from the device: k_dss.hip), self-rev scores (alignpair.cpp:7) as one device batch, upload.
+#include "host_internal.h"
+
+namespace reseek_amd {
+void DeviceBuffer::Make(rsk_ctx *Ctx, size_t Bytes, const char *What)
+{
+    Free();
+    if (!Ctx) throw std::runtime_error(std::string(What) + ": no GPU context");
+    if (hipSetDevice(Ctx->device) != hipSuccess) throw std::runtime_error(std::string(What) + ": hipSetDevice failed");
+    check(rsk_dev_malloc(Ctx, &m_Ptr, std::max<size_t>(Bytes, 16)), What);
+}
+
+void DeviceBuffer::Free()
+{
+    if (m_Ptr) (void) hipFree(m_Ptr);
+    m_Ptr = nullptr;
+}
+
+DBSearcher::~DBSearcher()
+{
+    if (m_OwnsChains) {
+        for (auto p : m_DBChains) delete p;
+        for (auto p : m_DBProfiles) delete p;
+        for (auto p : m_DBMuLettersVec) delete p;
+        for (auto p : m_DBMuKmersVec) delete p;
+    }
+    if (m_Db) rsk_db_destroy(m_Db);
+}
+
+void DBSearcher::AddChain(PDBChain *ptrChain, std::vector<std::vector<byte> > *ptrProfile, std::vector<byte> *ptrMuLetters)
+{
+    ptrChain->m_Idx = (uint) m_DBChains.size();
+    m_DBChains.push_back(ptrChain);
+    m_DBProfiles.push_back(ptrProfile);
+    m_DBMuLettersVec.push_back(ptrMuLetters);
+}
+
+// Mu 3-mers with pattern "111" (DSS::GetMuKmers dss.cpp:659-682): base-36 code of 3 consecutive letters.
+static void GetMuKmers(const std::vector<byte> &Mu, std::vector<uint> &Kmers)
+{
+    Kmers.clear();
+    const size_t L = Mu.size();
+    for (size_t i = 0; i + 3 <= L; ++i) Kmers.push_back(((uint) Mu[i] * 36 + Mu[i + 1]) * 36 + Mu[i + 2]);
+}
+
+static bool EndsWith(const std::string &s, const std::string &suf)
+{
+    return s.size() >= suf.size() && s.compare(s.size() - suf.size(), suf.size(), suf) == 0;
+}
+
+unsigned HostThreads(unsigned cap)
+{
+    if (const char *e = getenv("RSK_HOST_THREADS")) { const int v = atoi(e); if (v > 0) return (unsigned) v; }
+    static const unsigned avail = [] {
+        unsigned n = std::max(1u, std::thread::hardware_concurrency());
+        long long quota = -1, period = 0;
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                         // cgroup v2: "<quota|max> <period>"
+            char q[64];
+            if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+            fclose(f);
+        } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {      // cgroup v1
+            if (fscanf(g, "%lld", &quota) != 1) quota = -1;
+            fclose(g);
+            if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%lld", &period) != 1) period = 0; fclose(h); }
+        }
+        if (quota > 0 && period > 0) n = std::min<unsigned>(n, (unsigned) std::max<long long>(1, (quota + period - 1) / period));
+        return n;
+    }();
+    return std::max(1u, std::min(avail, cap));
+}
+
+namespace {
+}   // namespace
+
+// ProfileLoader::Load profileloader.cpp:72 for a .bca file: read, featurise (host threads), self-rev (GPU batch)
+void DBSearcher::LoadBCA(const std::string &FN)
+{
+    PhaseTimer tm("LoadBCA");
+    BCAData B;
+    B.Open(FN);
+    const uint64_t n = B.GetChainCount();
+    std::vector<PDBChain *> Chains;
+    Chains.reserve(n);
+    for (uint64_t k = 0; k < n; ++k) {
+        PDBChain *C = new PDBChain;
+        B.ReadChain(k, *C);
+        Chains.push_back(C);
+    }
+    tm.lap("read chains");
+    LoadChains(Chains);
+}
+
+// The chains become this searcher's set (ownership taken; Chains is left empty): DSS profile, Mu letters and Mu 3-mers
+// of every chain on the host threads, then the self-rev scores in one GPU batch.
+void DBSearcher::LoadChains(std::vector<PDBChain *> &Chains)
+{
+    PhaseTimer tm("LoadChains");
+    if (!m_Ctx) m_Ctx = DefaultCtx();
+    if (m_Opts.mode == AM_Invalid) m_Opts = g_Opts;
+    for (PDBChain *C : Chains) {
+        if (C->GetSeqLength() < 1) { delete C; continue; }              // m_MinChainLength = 1 (profileloader.cpp:82)
+        AddChain(C, new std::vector<std::vector<byte> >, new std::vector<byte>);
+        m_DBMuKmersVec.push_back(new std::vector<uint>);
+    }
+    Chains.clear();
+    const uint N = GetDBChainCount();
+    const unsigned T = HostThreads(128);
+    std::atomic<uint> next{0};
+    const bool WantRev = !m_Opts.selfrev0 && m_Ctx;
+    m_RevProfiles.clear();
+    if (WantRev) m_RevProfiles.resize(N);
+    // The per-residue quantities of the featurisation come from the device for the whole batch, chains and reversed
+    // chains (rsk_dss_densities, k_dss.hip): SS characters, Conf letters and nearest neighbours (float comparison chains:
+    // identical to the host's) and the two density features (two thirds of the host cost: libm exp), which
+    // DSS::UseDeviceDensities accepts chain by chain only where no binned value is near a bin boundary, so the letters
+    // stay the host's.  RSK_GPU_DENSITY=0: host only.
+    std::vector<uint64_t> roff;
+    std::unique_ptr<char[]> ssb;                             // [2][total]: SS of the chains, of the reversed chains
+    std::unique_ptr<uint8_t[]> confb;                        // [2][total]: Conf letters
+    std::unique_ptr<double[]> dens;                          // [4][total]: density / strand density of the chains, of the reversed chains
+    std::unique_ptr<uint32_t[]> nens;                        // [4][total]: NEN / REN of the chains, of the reversed chains
+    uint64_t rtotal = 0;
+    std::atomic<uint64_t> dens_fallbacks{0};
+    if (m_Ctx && N && !(getenv("RSK_GPU_DENSITY") && atoi(getenv("RSK_GPU_DENSITY")) == 0)) {
+        roff.assign((size_t) N + 1, 0);
+        for (uint i = 0; i < N; ++i) roff[i + 1] = roff[i] + m_DBChains[i]->GetSeqLength();
+        rtotal = roff[N];
+        std::unique_ptr<float[]> px(new float[rtotal + 1]), py(new float[rtotal + 1]), pz(new float[rtotal + 1]);
+        std::vector<uint32_t> len(N);
+        rsk_parallel_for(N, 256, [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; ++i) {
+                const PDBChain &C = *m_DBChains[i];
+                const uint L = C.GetSeqLength();
+                len[i] = L;
+                memcpy(&px[roff[i]], C.m_Xs.data(), 4 * (size_t) L);
+                memcpy(&py[roff[i]], C.m_Ys.data(), 4 * (size_t) L);
+                memcpy(&pz[roff[i]], C.m_Zs.data(), 4 * (size_t) L);
+            }
+        });
+        ssb.reset(new char[2 * rtotal + 2]);
+        confb.reset(new uint8_t[2 * rtotal + 2]);
+        dens.reset(new double[4 * rtotal + 4]);
+        nens.reset(new uint32_t[4 * rtotal + 4]);
+        DSS D0;
+        // device calls of at most 16 M residues (a self search loads its whole set here); RSK_DSS_CHUNK_RESIDUES: tests
+        const uint64_t chunk = getenv("RSK_DSS_CHUNK_RESIDUES") ? (uint64_t) std::max(1ll, atoll(getenv("RSK_DSS_CHUNK_RESIDUES"))) : (uint64_t) 16 << 20;
+        for (uint c0 = 0; c0 < N;) {
+            uint c1 = c0 + 1;
+            while (c1 < N && roff[c1 + 1] - roff[c0] <= chunk) ++c1;
+            const uint64_t o = roff[c0];
+            check(rsk_dss_densities(m_Ctx, c1 - c0, len.data() + c0, px.get() + o, py.get() + o, pz.get() + o, ssb.get() + o, ssb.get() + rtotal + o,
+                                    confb.get() + o, confb.get() + rtotal + o, D0.m_Density_W, D0.m_Density_w, D0.m_SSDensity_w, D0.m_Density_Radius,
+                                    D0.m_SSDensity_epsilon, dens.get() + o, dens.get() + rtotal + o, dens.get() + 2 * rtotal + o,
+                                    dens.get() + 3 * rtotal + o, D0.m_NEN_W, D0.m_NEN_w, nens.get() + o, nens.get() + rtotal + o,
+                                    nens.get() + 2 * rtotal + o, nens.get() + 3 * rtotal + o),
+                  "rsk_dss_densities");
+            c0 = c1;
+        }
+        tm.lap("densities (device)");
+    }
+    auto body = [&]() {
+        DSS D, DR;
+        D.SetParams(*m_Params);
+        DR.SetParams(*m_Params);
+        for (;;) {
+            const uint i = next.fetch_add(1);
+            if (i >= N) return;
+            // featurise into this thread's own vectors, then hand them over: the destination vector headers of
+            // neighbouring chains share cache lines, per-residue push_back on them would ping-pong between cores
+            std::vector<std::vector<byte> > Prof;
+            std::vector<byte> Mu;
+            std::vector<uint> Kmers;
+            D.Init(*m_DBChains[i]);
+            if (dens) {
+                D.UseDeviceLocal(ssb.get() + roff[i], confb.get() + roff[i]);
+                D.UseDeviceNENs(nens.get() + roff[i], nens.get() + rtotal + roff[i]);
+                if (!D.UseDeviceDensities(dens.get() + roff[i], dens.get() + rtotal + roff[i])) ++dens_fallbacks;
+            }
+            D.GetProfile(Prof);
+            D.GetMuLetters(Mu);
+            DSS::GetMuKmers(Mu, Kmers, m_Params->m_MKFPatternStr);
+            m_DBProfiles[i]->swap(Prof);
+            m_DBMuLettersVec[i]->swap(Mu);
+            m_DBMuKmersVec[i]->swap(Kmers);
+            if (WantRev) {
+                // profile of the reversed chain for ComputeSelfRevScores, while D still holds this chain's exp() table
+                PDBChain R;
+                std::vector<std::vector<byte> > RevProf;
+                m_DBChains[i]->GetReverse(R);
+                DR.Init(R);
+                if (!(dens && DR.UseDeviceDensities(dens.get() + 2 * rtotal + roff[i], dens.get() + 3 * rtotal + roff[i]))) {
+                    if (dens) ++dens_fallbacks;
+                    DR.InitReversed(R, D);
+                }
+                if (dens) {
+                    DR.UseDeviceLocal(ssb.get() + rtotal + roff[i], confb.get() + rtotal + roff[i]);
+                    DR.UseDeviceNENs(nens.get() + 2 * rtotal + roff[i], nens.get() + 3 * rtotal + roff[i]);
+                }
+                DR.GetProfile(RevProf);
+                m_RevProfiles[i].swap(RevProf);
+            }
+        }
+    };
+    std::vector<std::thread> ts;
+    for (unsigned t = 0; t < T; ++t) ts.emplace_back(body);
+    for (auto &t : ts) t.join();
+    tm.lap("featurise (host)");
+    if (dens && getenv("RSK_TRACE")) fprintf(stderr, "[LoadChains] %u chains: %llu chain featurisations redone on the host (density near a bin boundary)\n", N,
+                                             (unsigned long long) dens_fallbacks.load());
+    ComputeSelfRevScores();
+    tm.lap("self-rev scores");
+}
+
+// GetSelfRevScore alignpair.cpp:7-24 for every chain: AlignQueryTarget of the chain against its reversed copy
+// (profile of the reversed chain; the Mu letters / k-mers passed for BOTH sides are the un-reversed ones -- the
+// reference's behaviour), m_AlnFwdScore is the result.  Chains that take the MKF path (DoMKF: length >= m_MKFL) go through
+// the same device batch as the search's long-chain pairs (RunMKFPairs), against a view of the reversed chains.
+void DBSearcher::ComputeSelfRevScores()
+{
+    const uint N = GetDBChainCount();
+    m_DBSelfRevScores.assign(N, 0.0f);
+    if (m_Opts.selfrev0 || N == 0) return;
+    if (!m_Ctx) throw std::runtime_error("DBSearcher: self-rev scores need a GPU context");
+    DSSParams DAP = *m_Params;
+    bool HaveMu = true;
+    if (!m_SelfRevQueryFlavour) {
+        DAP.m_UsePara = false;
+        DAP.m_Omega = 0;
+        HaveMu = m_Params->m_Omega > 0;                                 // LoadDB dbsearcher.cpp:249-251
+    }
+    PhaseTimer tm("SelfRev");
+    // reversed chains and their profiles
+    std::vector<PDBChain> Rev(N);
+    std::vector<std::vector<std::vector<byte> > > RevProf(N);
+    if (m_RevProfiles.size() == N) {
+        // LoadBCA featurised the reversed chains together with the chains (shared exp() tables)
+        RevProf.swap(m_RevProfiles);                                    // (the long chains below reverse themselves)
+    } else {
+        const unsigned T = HostThreads(128);
+        std::atomic<uint> next{0};
+        auto body = [&]() {
+            DSS D;
+            D.SetParams(*m_Params);
+            for (;;) {
+                const uint i = next.fetch_add(1);
+                if (i >= N) return;
+                PDBChain R;
+                std::vector<std::vector<byte> > Prof;
+                m_DBChains[i]->GetReverse(R);
+                D.Init(R);
+                D.GetProfile(Prof);
+                std::swap(Rev[i], R);
+                RevProf[i].swap(Prof);
+            }
+        };
+        std::vector<std::thread> ts;
+        for (unsigned t = 0; t < T; ++t) ts.emplace_back(body);
+        for (auto &t : ts) t.join();
+    }
+    m_RevProfiles.clear();
+    tm.lap("reverse + featurise");
+    std::vector<uint32_t> gpu, mkf;
+    for (uint i = 0; i < N; ++i) {
+        const uint L = m_DBChains[i]->GetSeqLength();
+        const bool DoMKF = HaveMu && !m_DBMuKmersVec[i]->empty() && L >= DAP.m_MKFL;      // DoMKF dssaligner.cpp:715
+        (DoMKF ? mkf : gpu).push_back(i);
+    }
+    // The chains themselves go up once, as the set the search will use (UploadToGpu, its self-rev scores completed at the
+    // end of this function): it is the query side here.  Only the reversed profiles need a set of their own -- with the
+    // un-reversed Mu letters (what the reference passes for both sides) and, when long chains are present, the reversed
+    // coordinates (the long-chain batch computes the alignment statistics of every pair; only the score is used here).
+    std::vector<uint32_t> len(N);
+    std::vector<size_t> start((size_t) N + 1, 0);
+    for (uint i = 0; i < N; ++i) { len[i] = m_DBChains[i]->GetSeqLength(); start[i + 1] = start[i] + len[i]; }
+    const size_t tot = start[N];
+    std::vector<uint8_t> mu(tot), pr(tot * RSK_NFEAT);
+    std::vector<float> rx, ry, rz;
+    if (!mkf.empty()) { rx.resize(tot); ry.resize(tot); rz.resize(tot); }
+    rsk_parallel_for(N, 512, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) {
+            const uint L = len[i];
+            const size_t o = start[i];
+            memcpy(&mu[o], m_DBMuLettersVec[i]->data(), L);
+            for (int f = 0; f < RSK_NFEAT; ++f) memcpy(&pr[o * RSK_NFEAT + (size_t) f * L], RevProf[i][f].data(), L);
+            if (!rx.empty()) {
+                const PDBChain &C = *m_DBChains[i];
+                for (uint k = 0; k < L; ++k) { rx[o + k] = C.m_Xs[L - 1 - k]; ry[o + k] = C.m_Ys[L - 1 - k]; rz[o + k] = C.m_Zs[L - 1 - k]; }
+            }
+        }
+    });
+    tm.lap("pack");
+    UploadToGpu();
+    rsk_db *fdb = m_Db, *rdb = nullptr;
+    struct guard { rsk_db *d; ~guard() { if (d) rsk_db_destroy(d); } } g2{ nullptr };
+    check(rsk_db_create(m_Ctx, N, len.data(), mu.data(), pr.data(), rx.empty() ? nullptr : rx.data(), rx.empty() ? nullptr : ry.data(),
+                        rx.empty() ? nullptr : rz.data(), nullptr, &rdb),
+          "rsk_db_create");
+    g2.d = rdb;
+    tm.lap("upload");
+    if (!gpu.empty()) {
+        std::vector<uint32_t> idx = gpu;
+        if (DAP.m_Omega > 0) {                                           // MuFilter dssaligner.cpp:817-826 (self vs self letters)
+            std::vector<uint8_t> pass(idx.size());
+            check(rsk_mu_filter_pairs(m_Ctx, fdb, fdb, idx.data(), idx.data(), idx.size(), DAP.m_ParaMuGapOpen, DAP.m_ParaMuGapExt, DAP.m_Omega,
+                                      DAP.m_OmegaFwd, pass.data(), nullptr, nullptr),
+                  "rsk_mu_filter_pairs");
+            std::vector<uint32_t> keep;
+            for (size_t k = 0; k < idx.size(); ++k)
+                if (pass[k]) keep.push_back(idx[k]);
+            idx.swap(keep);
+        }
+        for (auto &be : AlignBatches(m_Opts, *this, *this, idx, idx)) {
+            const size_t b = be.first, m = be.second - be.first;
+            std::vector<rsk_aln> out(m);
+            check(rsk_align_pairs(m_Ctx, fdb, rdb, idx.data() + b, idx.data() + b, m, DAP.m_GapOpen, DAP.m_GapExt, DAP.m_MinFwdScore, out.data(),
+                                  nullptr, 0),
+                  "rsk_align_pairs");
+            for (size_t k = 0; k < m; ++k) m_DBSelfRevScores[idx[b + k]] = out[k].score;
+        }
+        tm.lap("GPU filter + SW");
+    }
+    if (!mkf.empty()) {
+        // B side of the long-chain batch: the reversed chains as a borrowed view (chain objects only for the long ones)
+        DBSearcher RevView;
+        RevView.m_OwnsChains = false;
+        RevView.m_Params = &DAP; RevView.m_Opts = m_Opts; RevView.m_Ctx = m_Ctx;
+        RevView.m_DBChains.assign(N, nullptr);
+        RevView.m_DBProfiles.resize(N);
+        for (uint i = 0; i < N; ++i) RevView.m_DBProfiles[i] = &RevProf[i];
+        RevView.m_DBMuLettersVec = m_DBMuLettersVec;
+        RevView.m_DBMuKmersVec = m_DBMuKmersVec;
+        RevView.m_DBSelfRevScores.assign(N, FLT_MAX);
+        std::vector<float> SelfRevA(N, FLT_MAX);
+        SelfRevA.swap(m_DBSelfRevScores);                                 // SetQuery(..., FLT_MAX) alignpair.cpp:14-17
+        std::vector<std::pair<uint32_t, uint32_t> > Pairs;
+        for (uint32_t i : mkf) {
+            if (Rev[i].GetSeqLength() == 0) m_DBChains[i]->GetReverse(Rev[i]);
+            RevView.m_DBChains[i] = &Rev[i];
+            Pairs.emplace_back(i, i);
+        }
+        RevView.m_Db = rdb;
+        std::vector<float> Score(N, 0.0f);
+        try {
+            RunMKFPairs(m_Ctx, DAP, "", *this, RevView, Pairs, [&](DSSAligner &DA, uint i, uint) { Score[i] = DA.m_AlnFwdScore; });
+        } catch (...) {
+            RevView.m_Db = nullptr;
+            SelfRevA.swap(m_DBSelfRevScores);
+            throw;
+        }
+        RevView.m_Db = nullptr;                                           // rdb belongs to the guard above
+        SelfRevA.swap(m_DBSelfRevScores);
+        for (uint32_t i : mkf) m_DBSelfRevScores[i] = Score[i];
+        tm.lap("long chains (device batch)");
+    }
+    if (m_Db) check(rsk_db_update_selfrev(m_Db, m_DBSelfRevScores.data()), "rsk_db_update_selfrev");
+}
+
+void DBSearcher::LoadDB(const std::string &DBFN)
+{
+    if (!m_Ctx) m_Ctx = DefaultCtx();
+    if (m_Opts.mode == AM_Invalid) m_Opts = g_Opts;
+    if (EndsWith(DBFN, ".bca")) { LoadBCA(DBFN); return; }
+    FILE *f = fopen(DBFN.c_str(), "rb");
+    if (!f) throw std::runtime_error("LoadDB: cannot open " + DBFN);
+    auto rd = [&](void *p, size_t n) { if (n && fread(p, 1, n, f) != n) { fclose(f); throw std::runtime_error("LoadDB: truncated " + DBFN); } };
+    char magic[8];
+    rd(magic, 8);
+    if (memcmp(magic, "RSKDB1\0\0", 8) != 0) { fclose(f); throw std::runtime_error("LoadDB: " + DBFN + " is not an RSKDB1 container"); }
+    uint32_t n, nfeat;
+    rd(&n, 4); rd(&nfeat, 4);
+    if (nfeat != RSK_NFEAT) { fclose(f); throw std::runtime_error("LoadDB: feature count mismatch"); }
+    for (uint32_t k = 0; k < n; ++k) {
+        uint32_t L, ll;
+        rd(&L, 4); rd(&ll, 4);
+        PDBChain *C = new PDBChain;
+        C->m_Label.resize(ll); rd(&C->m_Label[0], ll);
+        C->m_Seq.resize(L); rd(&C->m_Seq[0], L);
+        auto *Mu = new std::vector<byte>(L);
+        rd(Mu->data(), L);
+        auto *Prof = new std::vector<std::vector<byte> >(nfeat, std::vector<byte>(L));
+        for (uint32_t fi = 0; fi < nfeat; ++fi) rd((*Prof)[fi].data(), L);
+        C->m_Xs.resize(L); C->m_Ys.resize(L); C->m_Zs.resize(L);
+        rd(C->m_Xs.data(), 4 * (size_t) L); rd(C->m_Ys.data(), 4 * (size_t) L); rd(C->m_Zs.data(), 4 * (size_t) L);
+        float selfrev;
+        rd(&selfrev, 4);
+        uint32_t nk;
+        rd(&nk, 4);
+        std::vector<uint> stored(nk);
+        rd(stored.data(), 4 * (size_t) nk);
+        auto *Kmers = new std::vector<uint>;
+        GetMuKmers(*Mu, *Kmers);
+        if (*Kmers != stored) { fclose(f); throw std::runtime_error("LoadDB: stored Mu k-mers disagree with the letters"); }
+        AddChain(C, Prof, Mu);
+        m_DBMuKmersVec.push_back(Kmers);
+        m_DBSelfRevScores.push_back(m_Opts.selfrev0 ? 0.0f : selfrev);
+    }
+    fclose(f);
+}
+
+void DBSearcher::Setup()
+{
+    if (!m_Ctx) m_Ctx = DefaultCtx();
+    if (m_Opts.mode == AM_Invalid) m_Opts = g_Opts;
+    if (m_Opts.evalue_set) m_MaxEvalue = m_Opts.evalue;
+    else m_MaxEvalue = (m_Opts.mode == AM_VerySensitive) ? DBL_MAX : 10;
+    m_HitCount = 0;
+    m_ProcessedPairCount = 0;
+    m_DA.SetParams(*m_Params);
+    m_DA.SetColumns(m_Opts.columns);
+    m_DA.m_Ctx = m_Ctx;
+    if (m_Devices.empty() && m_OwnsChains) m_Devices = ParseDeviceList(getenv("RSK_DEVICES"));      // views / replicas stay on their context
+    OnSetup();
+}
+
+bool DBSearcher::Reject(DSSAligner &DA, bool Up) const
+{
+    if (!m_Opts.scores_are_not_evalues && DA.GetEvalue(Up) > m_MaxEvalue) return true;
+    if (m_Opts.mints_set && DA.GetNewTestStatistic(Up) < m_Opts.mints) return true;
+    return false;
+}
+
+void DBSearcher::BaseOnAln(DSSAligner &DA, bool Up)
+{
+    if (Reject(DA, Up)) return;
+    std::lock_guard<std::mutex> g(m_Lock);
+    ++m_HitCount;
+    DA.ToTsv(m_fTsv, Up, m_Opts.noself);
+    OnAln(DA, Up);
+}
+
+void DBSearcher::UploadToGpu()
+{
+    if (m_Db) return;
+    if (!m_Ctx) throw std::runtime_error("DBSearcher: no GPU context");
+    const uint n = GetDBChainCount();
+    std::vector<uint32_t> len(n);
+    std::vector<size_t> start((size_t) n + 1, 0);
+    for (uint i = 0; i < n; ++i) { len[i] = m_DBChains[i]->GetSeqLength(); start[i + 1] = start[i] + len[i]; }
+    const size_t tot = start[n];
+    std::unique_ptr<uint8_t[]> mu(new uint8_t[tot + 1]), prof(new uint8_t[tot * RSK_NFEAT + 1]);      // filled below, not value-initialised
+    std::unique_ptr<float[]> x(new float[tot + 1]), y(new float[tot + 1]), z(new float[tot + 1]);
+    rsk_parallel_for(n, 512, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) {
+            const uint L = len[i];
+            const size_t o = start[i];
+            memcpy(&mu[o], m_DBMuLettersVec[i]->data(), L);
+            for (int f = 0; f < RSK_NFEAT; ++f) memcpy(&prof[o * RSK_NFEAT + (size_t) f * L], (*m_DBProfiles[i])[f].data(), L);
+            memcpy(&x[o], m_DBChains[i]->m_Xs.data(), 4 * (size_t) L);
+            memcpy(&y[o], m_DBChains[i]->m_Ys.data(), 4 * (size_t) L);
+            memcpy(&z[o], m_DBChains[i]->m_Zs.data(), 4 * (size_t) L);
+        }
+    });
+    check(rsk_db_create(m_Ctx, n, len.data(), mu.get(), prof.get(), x.get(), y.get(), z.get(), m_DBSelfRevScores.data(), &m_Db),
+          "rsk_db_create");
+    // residue characters: the statistics kernel counts the identical columns of an alignment (GetPctId) while it walks the path
+    {
+        std::unique_ptr<char[]> seq(new char[tot + 1]);
+        rsk_parallel_for(n, 512, [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; ++i) memcpy(&seq[start[i]], m_DBChains[i]->m_Seq.data(), len[i]);
+        });
+        check(rsk_db_set_seq(m_Db, seq.get()), "rsk_db_set_seq");
+    }
+}
+
+}   // namespace reseek_amd

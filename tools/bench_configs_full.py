@@ -12,7 +12,7 @@ streams only its range, runquery.cpp:82-125) one after the other and reports per
 process: peak host RSS (VmHWM) and peak device memory in use (hipMemGetInfo sampled every 50 ms by a thread).  Checked here:
 the digests of the 8 shards combine to the digests of the 3-shard and the 1-shard run (same multiset of hit lines), pairs and
 hits add up; imbalance = max / mean of the shard seconds.  Reference equality: oracle/_ref/reseek -threads 1 on a sample of the
-same files that yields >= 10,000 rows (config3: all 256 queries x every 125th DB chain; config4: 16 queries x 700 chains).
+same files that yields >= 10,000 rows (config3: all 256 queries x every 100th DB chain; config4: 16 queries x 700 chains).
 
   python tools/bench_configs_full.py [config3] [config4] [--scale F] > profiles/r04_configs_full.json
 (--scale 0.01 for a quick run of the machinery.)  Prints one JSON object."""
@@ -102,7 +102,7 @@ def child_shards(q, db, mode, nshards, digest):
 
 
 def run_child(args):
-    r = subprocess.run([sys.executable, os.path.abspath(__file__)] + args, capture_output=True, text=True, cwd=ROOT)
+    r = subprocess.run([sys.executable, os.path.abspath(__file__)] + args, capture_output=True, text=True, cwd=ROOT, timeout=1500)
     if r.returncode != 0:
         raise SystemExit("child %s failed:\n%s\n%s" % (args, r.stdout[-2000:], r.stderr[-4000:]))
     for ln in r.stdout.splitlines():
@@ -195,7 +195,7 @@ def main():
             e = {"what": "-search Q -db DB -%s, %d queries x %d-chain .bca DB (DSS featurisation + self-rev of every DB chain inside the calls)" % (mode, nq, ndb),
                  "db_file_gb": os.path.getsize(db) / 2**30, "generation_seconds": tgen, "hit_lines": "digest (hits_digest)" if digest else "files"}
             runs = {}
-            for S in (8, 3, 1):
+            for S in [int(x) for x in os.environ.get("RSK_CFGFULL_SHARDS", "8,3,1").split(",")]:
                 r = run_child(["--child-shards", q, db, mode, str(S), "1" if digest else "0"])
                 secs = [s["seconds"] for s in r["shards"]]
                 r["seconds_total"] = float(sum(secs))
@@ -218,7 +218,7 @@ def main():
                                           runs["shards_8"]["hits"] == runs["shards_3"]["hits"] == runs["shards_1"]["hits"])
             if not nosample:
                 if key == "config3":
-                    e["vs_reference_on_sample"] = reference_sample(td, q, db, mode, nq, max(1, int(125 * min(1.0, scale * 8))), key)
+                    e["vs_reference_on_sample"] = reference_sample(td, q, db, mode, nq, max(1, int(100 * min(1.0, scale * 8))), key)
                 else:
                     e["vs_reference_on_sample"] = reference_sample(td, q, db, mode, 16, max(1, ndb // 700), key)
             out[key] = e

@@ -1,12 +1,16 @@
-# end-of-round measurement set: live-kernel PMC, bench line, search traces of the config-2/3/4 shapes and the self search
-# (copy gpurun_out/prof_<tag>/summary.txt and the bench json into profiles/ afterwards)
-TAG=${1:-r03}
-timeout 1500 bash tools/prof_live.sh ${TAG}_live > gpurun_out/${TAG}_live.log 2>&1 < /dev/null
-timeout 1700 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err < /dev/null
-tail -c 300 gpurun_out/${TAG}_bench.json
-timeout 600 bash tools/prof_search.sh ${TAG}_self 0 sensitive > /dev/null 2>&1 < /dev/null
-timeout 600 bash tools/prof_search.sh ${TAG}_c3 qdb 256 125000 sensitive > /dev/null 2>&1 < /dev/null
-timeout 600 bash tools/prof_search.sh ${TAG}_c4 qdb 1000 87500 verysensitive > /dev/null 2>&1 < /dev/null
-timeout 900 bash tools/prof_search.sh ${TAG}_c2 0 fast bca db > /dev/null 2>&1 < /dev/null
-RSK_ALIGN_INFLIGHT=1 timeout 600 bash tools/prof_search.sh ${TAG}_c4serial qdb 1000 30000 verysensitive > /dev/null 2>&1 < /dev/null
-echo done
+#!/bin/bash
+# round-end measurement set on the GPU box: full GPU test suite, profiles (bench / live / searches), the default bench line,
+# the full-size configs, the trace of a config-3-shaped search (loader vs search per batch)
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+T=${1:-r04}
+mkdir -p gpurun_out
+timeout 3000 python -m pytest tests/ -x -q -m gpu 2>&1 | tail -5 > gpurun_out/${T}_gpu_tests.txt
+cat gpurun_out/${T}_gpu_tests.txt
+bash tools/exp/round_profiles.sh $T > gpurun_out/${T}_round_profiles.log 2>&1
+python bench.py > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err
+tail -2 gpurun_out/${T}_bench.err
+timeout 3000 python tools/bench_configs_full.py > gpurun_out/${T}_configs_full.json 2> gpurun_out/${T}_configs_full.err
+tail -2 gpurun_out/${T}_configs_full.err
+RSK_TRACE=1 python tools/bench_search.py qdb 256 125000 sensitive > gpurun_out/${T}_trace_c3.json 2> gpurun_out/${T}_trace_c3.err
+grep seconds gpurun_out/${T}_trace_c3.json
+ls gpurun_out | head -50
