@@ -277,6 +277,11 @@ int rsk_mkf_chain_align_pairs(rsk_ctx *ctx, const rsk_db *a, const rsk_db *b, co
  * At most 65535 queries (uint16 query index in the reference as well). */
 int rsk_mu_prefilter_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int neighbourhood, uint32_t *d_out_q,
                          uint32_t *d_out_t, uint32_t *d_out_score, size_t capacity, uint32_t *d_n);
+/* The same scan for the targets t_lo <= index < t_hi of t only (target indices in the triples stay those of the whole set):
+ * a search scans the DB in a few contiguous target ranges so that the host replays the bags of range k (targets ascending:
+ * the reference's arrival order) while the device scans range k + 1. */
+int rsk_mu_prefilter_range_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int neighbourhood, uint32_t t_lo, uint32_t t_hi,
+                               uint32_t *d_out_q, uint32_t *d_out_t, uint32_t *d_out_score, size_t capacity, uint32_t *d_n);
 /* Work counters of the last rsk_mu_prefilter_dev call (any pointer may be NULL): seed items = (target position, posting)
  * pairs read (prefiltermu.cpp:213-260), postings of the query index, two-hit diagonals found (twohitdiag.cpp:368-398) and
  * the cells their FindHSP scans visited (prefiltermu.cpp:12-48). */

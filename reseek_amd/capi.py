@@ -47,6 +47,8 @@ SIGNATURES = {
                                     C.c_void_p]),
     "rsk_mu_filter_last_work": (C.c_int, [C.c_void_p, u64p, u64p]),
     "rsk_pairs_sort_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32]),
+    "rsk_mu_prefilter_range_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_size_t, C.c_void_p]),
     "rsk_mu_prefilter_last_work": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_uint64)] * 4),
     "rsk_triples_sort_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rsk_rsb_select_keys": (C.c_int, [C.POINTER(C.c_uint64), C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),

@@ -14,6 +14,8 @@
 #include <memory>
 #include <atomic>
 #include <cstring>
+#include <future>
+#include <chrono>
 #include <mutex>
 #include <stdexcept>
 #include <thread>
@@ -132,8 +134,11 @@ void MuPreFilterScan(rsk_ctx *ctx, const std::vector<uint32_t> &qlen, const std:
     tm.lap("index + scan (GPU)");
 }
 
-// scan, triples sorted on the device (query, then target = the arrival order of the reference's bags with -threads 1),
-// one download of the packed keys, bags replayed per query on the host threads (muprefilter.cpp:90-133)
+// scan + bags (muprefilter.cpp:90-133).  The DB is scanned in a few contiguous target ranges: the triples of a range are
+// sorted on the device (query, then target = the arrival order of the reference's bags with -threads 1) and downloaded as
+// packed keys, and while the device scans range k + 1 a host task replays range k into the bags (the ranges arrive in target
+// order, a query's bag sees its targets ascending over the whole DB; the final truncation follows the last range).
+int ReplayAppendSortedKeys(RankedScoresBag &RSB, const uint64_t *keys, size_t n, uint32_t nqueries, bool Final);      // prefilter.cpp
 void MuPreFilterBags(rsk_ctx *ctx, const std::vector<uint32_t> &qlen, const std::vector<uint8_t> &qmu, rsk_db *tdb, uint NT, int idx_mode,
                      uint rsb_size, RankedScoresBag &RSB)
 {
@@ -143,30 +148,52 @@ void MuPreFilterBags(rsk_ctx *ctx, const std::vector<uint32_t> &qlen, const std:
     check(rsk_db_create(ctx, NQ, qlen.data(), qmu.data(), nullptr, nullptr, nullptr, nullptr, nullptr, &qdb), "rsk_db_create");
     struct db_guard { rsk_db *d; ~db_guard() { rsk_db_destroy(d); } } guard{ qdb };
     auto hipok = [](hipError_t e, const char *w) { if (e != hipSuccess) throw std::runtime_error(std::string(w) + ": " + hipGetErrorString(e)); };
-    size_t cap = (size_t) std::min<uint64_t>((uint64_t) NQ * NT, 1ull << 28);      // every (query, target) can appear at most once
+    RSB.m_B = rsb_size;
+    RSB.Init(NQ);
+    // a few target ranges per scan (RSK_PF_RANGES; 1 = one scan).  Measured on the 11,211 x 11,211 synthetic set: 1 / 2 / 3 / 4 / 6
+    // ranges -> scans + bags 1.25 / 1.07 / 1.06 / 1.10 / 1.29 s (every launch ends with a tail of long targets): three.
+    uint nranges = (uint) std::min<uint64_t>(3, std::max<uint64_t>(1, (uint64_t) NQ * NT / (16u << 20)));
+    if (const char *e = getenv("RSK_PF_RANGES")) nranges = (uint) std::max(1, atoi(e));
+    nranges = std::max(1u, std::min(nranges, std::max(1u, NT)));
     DeviceBuffer Count(ctx, 4, "prefilter result counter");
-    std::unique_ptr<uint64_t[]> keys;                  // ~1 GB on a dense set: not value-initialised
-    size_t nkeys = 0;
-    for (;;) {
-        DeviceBuffer Q(ctx, cap * 4, "prefilter results"), T(ctx, cap * 4, "prefilter results"), S(ctx, cap * 4, "prefilter results");
-        check(rsk_mu_prefilter_dev(ctx, qdb, tdb, idx_mode, Q.As<uint32_t>(), T.As<uint32_t>(), S.As<uint32_t>(), cap, Count.As<uint32_t>()), "rsk_mu_prefilter_dev");
-        check(rsk_ctx_sync(ctx), "rsk_ctx_sync");
+    std::future<void> replay;                                            // the host task of the previous range
+    struct Join { std::future<void> &f; ~Join() { if (f.valid()) f.wait(); } } join_on_exit{ replay };
+    double t_scan = 0, t_keys = 0;
+    for (uint r = 0; r < nranges; ++r) {
+        const uint t_lo = (uint) ((uint64_t) NT * r / nranges), t_hi = (uint) ((uint64_t) NT * (r + 1) / nranges);
+        if (t_hi == t_lo) continue;
+        const auto c0 = std::chrono::steady_clock::now();
+        size_t cap = (size_t) std::min<uint64_t>((uint64_t) NQ * (t_hi - t_lo), 1ull << 28);      // every (query, target) can appear at most once
+        std::unique_ptr<uint64_t[]> keys;                                // ~1 GB per scan on a dense set: not value-initialised
         uint32_t n = 0;
-        hipok(hipMemcpy(&n, Count.As<uint32_t>(), 4, hipMemcpyDeviceToHost), "copy n");
-        if (n <= cap) {
-            tm.lap("index + scan (GPU)");
+        for (;;) {
+            DeviceBuffer Q(ctx, cap * 4, "prefilter results"), T(ctx, cap * 4, "prefilter results"), S(ctx, cap * 4, "prefilter results");
+            check(rsk_mu_prefilter_range_dev(ctx, qdb, tdb, idx_mode, t_lo, t_hi, Q.As<uint32_t>(), T.As<uint32_t>(), S.As<uint32_t>(), cap, Count.As<uint32_t>()),
+                  "rsk_mu_prefilter_dev");
+            check(rsk_ctx_sync(ctx), "rsk_ctx_sync");
+            hipok(hipMemcpy(&n, Count.As<uint32_t>(), 4, hipMemcpyDeviceToHost), "copy n");
+            if (n > cap) { cap = n; continue; }                          // the count is exact even when the list was truncated
+            const auto c1 = std::chrono::steady_clock::now();
+            t_scan += std::chrono::duration<double, std::milli>(c1 - c0).count();
             DeviceBuffer K(ctx, (size_t) std::max<uint32_t>(n, 1) * 8, "prefilter keys");
             check(rsk_triples_sort_dev(ctx, Q.As<uint32_t>(), T.As<uint32_t>(), S.As<uint32_t>(), n, K.As<uint64_t>()), "rsk_triples_sort_dev");
             keys.reset(new uint64_t[std::max<uint32_t>(n, 1)]);
-            nkeys = n;
             hipok(hipMemcpy(keys.get(), K.As<uint64_t>(), (size_t) n * 8, hipMemcpyDeviceToHost), "copy keys");
-            tm.lap("triples: device sort + d2h");
+            t_keys += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c1).count();
             break;
         }
-        cap = n;                               // the count is exact even when the list was truncated
+        if (replay.valid()) replay.get();                                // range r - 1 is in the bags (rethrows its error)
+        const bool Final = r + 1 == nranges;
+        std::shared_ptr<uint64_t[]> held(keys.release());
+        replay = std::async(std::launch::async, [&RSB, held, n, NQ, Final]() {
+            if (ReplayAppendSortedKeys(RSB, held.get(), n, NQ, Final) != RSK_OK) throw std::runtime_error(std::string("MuPreFilter: ") + rsk_last_error());
+        });
     }
-    if (ReplaySortedKeys(RSB, keys.get(), nkeys, NQ, rsb_size) != RSK_OK) throw std::runtime_error(std::string("MuPreFilter: ") + rsk_last_error());
-    tm.lap("top-B bags (replay)");
+    if (getenv("RSK_TRACE")) fprintf(stderr, "[MuPreFilter] %u target ranges: index + scans %.1f ms, triples sorted on the device + downloaded %.1f ms\n", nranges, t_scan, t_keys);
+    tm.lap("index + scans (GPU), bags of the earlier ranges beside them");
+    if (replay.valid()) replay.get();
+    else RSB.Finish();                                                   // (no target at all)
+    tm.lap("top-B bags of the last range");
 }
 
 // ... + hand-off file (muprefilter.cpp:127-133): the form compat.cpp's MuPreFilter(SeqDB &, MuSeqSource &) forwards to

@@ -182,7 +182,7 @@ void RankedScoresBag::ToTsv(FILE *f)
 
 // AddScore sequence of every query on the host threads: `items` holds per query (qstart) its triples in target order,
 // target in bits 16..47 and score in bits 0..15 of an element (a query's bag depends on its own triples only).
-static void ReplayGrouped(RankedScoresBag &RSB, const uint64_t *items, const size_t *qstart, uint32_t nqueries, size_t n)
+static void ReplayGrouped(RankedScoresBag &RSB, const uint64_t *items, const size_t *qstart, uint32_t nqueries, size_t n, bool Final = true)
 {
     const unsigned T = (unsigned) std::max<size_t>(1, std::min<size_t>((size_t) HostThreads(64), n / 65536 + 1));
     std::atomic<uint32_t> next{0};
@@ -192,7 +192,7 @@ static void ReplayGrouped(RankedScoresBag &RSB, const uint64_t *items, const siz
             if (qi >= nqueries) return;
             for (const uint64_t *x = items + qstart[qi], *e = items + qstart[qi + 1]; x != e; ++x)
                 RSB.AddScore(qi, (uint) ((*x >> 16) & 0xFFFFFFFFu), (uint16_t) (*x & 0xFFFF));
-            RSB.TruncateVecs(qi);
+            if (Final) RSB.TruncateVecs(qi);               // (more targets follow otherwise: the reference only truncates at 2 B entries and at the end)
         }
     };
     if (T == 1) body();
@@ -226,18 +226,25 @@ static int EmitSelection(RankedScoresBag &RSB, uint32_t nqueries, size_t cap, ui
     return RSK_OK;
 }
 
-// keys = query << 48 | target << 16 | score, ascending (rsk_triples_sort_dev) -> bags
-int ReplaySortedKeys(RankedScoresBag &RSB, const uint64_t *keys, size_t n, uint32_t nqueries, uint32_t rsb_size)
+// keys = query << 48 | target << 16 | score, ascending (rsk_triples_sort_dev), of ONE contiguous target range: the bags take
+// them in (the ranges of a scan arrive in target order); Final = this is the last range
+int ReplayAppendSortedKeys(RankedScoresBag &RSB, const uint64_t *keys, size_t n, uint32_t nqueries, bool Final)
 {
     if (n && (keys[n - 1] >> 48) >= nqueries) { rsk_set_error("rsk_rsb_select_keys: query index out of range"); return RSK_E_INVALID; }
     std::vector<size_t> qstart((size_t) nqueries + 1, 0);
     rsk_parallel_for((size_t) nqueries + 1, 64, [&](size_t lo, size_t hi) {
         for (size_t i = lo; i < hi; ++i) qstart[i] = i > 0xFFFF ? n : (size_t) (std::lower_bound(keys, keys + n, (uint64_t) i << 48) - keys);
     });
+    ReplayGrouped(RSB, keys, qstart.data(), nqueries, n, Final);
+    return RSK_OK;
+}
+
+// ... of the whole scan at once
+int ReplaySortedKeys(RankedScoresBag &RSB, const uint64_t *keys, size_t n, uint32_t nqueries, uint32_t rsb_size)
+{
     RSB.m_B = rsb_size;
     RSB.Init(nqueries);
-    ReplayGrouped(RSB, keys, qstart.data(), nqueries, n);
-    return RSK_OK;
+    return ReplayAppendSortedKeys(RSB, keys, n, nqueries, true);
 }
 
 }   // namespace reseek_amd

@@ -153,7 +153,7 @@ struct pf_args {
     const uint32_t *postings;      // q << 16 | pos, grouped by k-mer row, ascending inside a row
     const uint8_t *q_mu; const uint32_t *q_off; const uint32_t *q_len;
     const uint8_t *t_mu; const uint32_t *t_off; const uint32_t *t_len;
-    const uint32_t *t_order;       // targets by increasing length (the grid takes them longest first); NULL = index order
+    const uint32_t *t_order;       // the targets of this launch, longest first (workgroup b scans target t_order[b])
     uint32_t nt, nq;
     uint32_t *out_q, *out_t, *out_score;
     uint32_t capacity;
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_prefilter(pf_args a)
     uint32_t *wsum = sv + 16;                                            // per-wave partial sums of the block scans
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const uint32_t t = a.t_order ? a.t_order[a.nt - 1 - blockIdx.x] : blockIdx.x;
+    const uint32_t t = a.t_order[blockIdx.x];
     for (int i = tid; i < 36 * 256; i += PF_THREADS) tab[i] = (i & 255) < 36 ? c_mu_s8[(i >> 8) * 36 + (i & 255)] : (signed char) 0;
     const uint32_t TL = a.t_len[t];
     const uint8_t *T = a.t_mu + a.t_off[t];
@@ -519,7 +519,14 @@ int rsk_build_mudex(rsk_ctx *ctx, rsk_db *db, int mode)
 extern "C" int rsk_mu_prefilter_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int neighbourhood, uint32_t *d_out_q,
                                     uint32_t *d_out_t, uint32_t *d_out_score, size_t capacity, uint32_t *d_n)
 {
+    return rsk_mu_prefilter_range_dev(ctx, q, t, neighbourhood, 0, t ? t->n : 0, d_out_q, d_out_t, d_out_score, capacity, d_n);
+}
+
+extern "C" int rsk_mu_prefilter_range_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int neighbourhood, uint32_t t_lo, uint32_t t_hi,
+                                          uint32_t *d_out_q, uint32_t *d_out_t, uint32_t *d_out_score, size_t capacity, uint32_t *d_n)
+{
     if (!ctx || !q || !t || !d_out_q || !d_out_t || !d_out_score || !d_n) { rsk_set_error("rsk_mu_prefilter_dev: NULL argument"); return RSK_E_INVALID; }
+    if (t_lo > t_hi || t_hi > t->n) { rsk_set_error("rsk_mu_prefilter_range_dev: target range [%u, %u) outside the set of %u", t_lo, t_hi, t->n); return RSK_E_INVALID; }
     if (!q->d_mu || !t->d_mu) { rsk_set_error("rsk_mu_prefilter_dev: chain set has no Mu letters"); return RSK_E_INVALID; }
     RSK_HIP(hipSetDevice(ctx->device));
     int rc = pf_upload_tables(ctx);
@@ -529,8 +536,15 @@ extern "C" int rsk_mu_prefilter_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db 
     if ((rc = rsk_build_mudex(ctx, const_cast<rsk_db *>(q), neighbourhood)) != RSK_OK) return rc;
     for (uint32_t L : t->len)
         if (L > 65534) { rsk_set_error("rsk_mu_prefilter_dev: target longer than 65534"); return RSK_E_RANGE; }
-    if ((rc = rsk_build_len_perm(const_cast<rsk_db *>(t))) != RSK_OK) return rc;      // cached: the grid takes the longest targets first
     rsk_scratch ws(ctx);                       // every temporary goes back to the pool on every exit path
+    // the targets of the range, longest first (the grid's order: a long target's workgroup must not start last)
+    const uint32_t ntr = t_hi - t_lo;
+    std::vector<uint32_t> order(ntr);
+    for (uint32_t k = 0; k < ntr; ++k) order[k] = t_lo + k;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return t->len[x] > t->len[y]; });
+    uint32_t *d_order;
+    if ((rc = ws.alloc(&d_order, (size_t) std::max<uint32_t>(ntr, 1))) != RSK_OK) return rc;
+    if (ntr) RSK_HIP(hipMemcpyAsync(d_order, order.data(), (size_t) ntr * 4, hipMemcpyHostToDevice, ctx->stream));
     unsigned long long *d_stat;
     if ((rc = ws.alloc(&d_stat, 8)) != RSK_OK) return rc;
     RSK_HIP(hipMemsetAsync(d_stat, 0, 64, ctx->stream));
@@ -538,13 +552,13 @@ extern "C" int rsk_mu_prefilter_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db 
     pf_args a = {};
     a.table = (const uint2 *) q->d_pf_table; a.postings = q->d_pf_postings;
     a.q_mu = q->d_mu; a.q_off = q->d_off; a.q_len = q->d_len;
-    a.t_mu = t->d_mu; a.t_off = t->d_off; a.t_len = t->d_len; a.t_order = t->d_len_perm; a.nt = t->n; a.nq = q->n;
+    a.t_mu = t->d_mu; a.t_off = t->d_off; a.t_len = t->d_len; a.t_order = d_order; a.nt = ntr; a.nq = q->n;
     a.out_q = d_out_q; a.out_t = d_out_t; a.out_score = d_out_score;
     a.capacity = (uint32_t) std::min<size_t>(capacity, 0xFFFFFFFFu);
     a.out_n = d_n;
     a.stat = d_stat;
     uint32_t maxTL = 0;
-    for (uint32_t L : t->len) maxTL = std::max(maxTL, L);
+    for (uint32_t k = t_lo; k < t_hi; ++k) maxTL = std::max(maxTL, t->len[k]);
     // two workgroups per CU (the seed walk is latency-bound): each may use half of the 160 KB; target letters as far as
     // they fit (longer targets are read from HBM in place)
     const uint32_t tl_cap = (uint32_t) std::min<size_t>(maxTL, (81000 - PF_LDS_FIXED - 48) & ~(size_t) 15);
@@ -553,8 +567,8 @@ extern "C" int rsk_mu_prefilter_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db 
     const size_t lds = PF_LDS_FIXED + (((size_t) tl_cap + 8 + 31) & ~(size_t) 15);
     RSK_HIP(hipFuncSetAttribute((const void *) k_prefilter, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));   // depends on the call's targets
     RSK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-    if (t->n && q->n) {
-        hipLaunchKernelGGL(k_prefilter, dim3(t->n), dim3(PF_THREADS), lds, ctx->stream, a);
+    if (ntr && q->n) {
+        hipLaunchKernelGGL(k_prefilter, dim3(ntr), dim3(PF_THREADS), lds, ctx->stream, a);
         RSK_HIP(hipGetLastError());
     }
     RSK_HIP(hipEventRecord(ctx->ev1, ctx->stream));
@@ -566,8 +580,8 @@ extern "C" int rsk_mu_prefilter_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db 
     ctx->pf_twohit = stat[1];
     ctx->pf_cells = stat[4];
     if (getenv("RSK_TRACE"))
-        fprintf(stderr, "[prefilter] index postings %zu, seed items %llu, two-hit diagonals %llu (%llu cells); query spans %llu, scoring rounds %llu (%u targets)\n",
-                q->pf_postings, stat[0], stat[1], stat[4], stat[2], stat[3], t->n);
+        fprintf(stderr, "[prefilter] index postings %zu, seed items %llu, two-hit diagonals %llu (%llu cells); query spans %llu, scoring rounds %llu (targets %u .. %u)\n",
+                q->pf_postings, stat[0], stat[1], stat[4], stat[2], stat[3], t_lo, t_hi);
     return RSK_OK;
 }
 

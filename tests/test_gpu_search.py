@@ -325,3 +325,20 @@ def test_hits_digest_is_the_digest_of_the_table(ctx, tmp_path):
             ctx.search(bca, dig, mode, db=bca, hits_digest=1, shard_index=k, shard_count=3)
             parts.append(capi.read_hits_digest(dig))
         assert capi.combine_hits_digests(parts) == (len(lines), os.path.getsize(tab), s, x), mode
+
+
+@pytest.mark.parametrize("ranges", ["3", "7"])
+def test_fast_db_scanned_in_target_ranges(ctx, tmpdir, monkeypatch, ranges):
+    """The prefilter of `-search -fast -db` scans the DB in contiguous target ranges and replays the bags of range k while
+    the device scans range k + 1 (a set the size of q100 takes one range; RSK_PF_RANGES forces several).  The hand-off file
+    and the hit table must stay the reference's -- also with bags of 5 that overflow in every range (-rsb_size 5: the
+    truncation sequence of a bag runs across the ranges)."""
+    monkeypatch.setenv("RSK_PF_RANGES", ranges)
+    q = unpack_bca("q100.bca", tmpdir)
+    out = os.path.join(tmpdir, "out_ranges.tsv")
+    ctx.search(q, out, "fast", db=q, columns=COLS, keeptmp=1)
+    assert sorted(open(out).read().splitlines()) == ["\t".join(r) for r in fx.read_tsv("hits_q100_db_q100_fast.tsv.gz")]
+    assert open(out + ".prefilter.tmp").read() == gzip.open(os.path.join(fx.GOLDEN, "prefilter_q100_db_q100_fast_tmp.tsv.gz")).read().decode()
+    ctx.search(q, out, "fast", db=q, columns=COLS, keeptmp=1, rsb_size=5)
+    assert sorted(open(out).read().splitlines()) == ["\t".join(r) for r in fx.read_tsv("hits_q100_db_q100_fast_rsb5.tsv.gz")]
+    assert open(out + ".prefilter.tmp").read() == gzip.open(os.path.join(fx.GOLDEN, "prefilter_q100_db_q100_fast_rsb5_tmp.tsv.gz")).read().decode()
