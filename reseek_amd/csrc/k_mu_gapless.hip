@@ -42,12 +42,12 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 #define GL_CAP_BITS 0x3C00          // 1.0 = the clamp's ceiling = score 2048
 #define GL_RESET_BITS 0xBC00        // -1.0: pad letters and separator rows
 #define RING_TB 256          // targets per work item
-#define RING_MAX_BLOCK 1024   // largest query block (1 + L rounded up to 8) that fits a D = 8 ring
+#define RING_SUB 1024        // slots of one sub-ring of a D = 16 ring: the largest query block (1 + L rounded up to 4)
 
 // ---------------------------------------------------------------------------------------------
 // host: pack queries onto rings
 // ---------------------------------------------------------------------------------------------
-static inline uint32_t qblock(uint32_t L) { return (1 + L + 7) / 8 * 8; }
+static inline uint32_t qblock(uint32_t L) { return (1 + L + 3) / 4 * 4; }
 
 int rsk_build_rings(rsk_db *db)
 {
@@ -56,22 +56,23 @@ int rsk_build_rings(rsk_db *db)
     std::vector<uint32_t> qids;
     std::vector<rsk_ring> rings;
     db->long_q.clear();
-    // Best-fit-decreasing bin packing of the query blocks into 1024-slot rings (capacity quantum, not order, is
-    // what a ring loses: consecutive chains of a length-sorted set leave 1024 mod block unused).  Any grouping
-    // is valid because the chain set is then PROCESSED in ring order: position p of the permuted order
-    // `ring_perm` is the p-th ring member; in self-triangle mode a ring takes the targets at positions >= its
-    // first member, so every unordered pair is scored at least once (the score is symmetric) and stored at
-    // out[min][max].  Chains too long for a ring come last in the order (per-pair kernel).
+    // Best-fit-decreasing bin packing of the query blocks into 1024-slot sub-rings (capacity quantum, not order, is
+    // what a ring loses: consecutive chains of a length-sorted set leave 1024 mod block unused); two bins make one ring
+    // (sub-ring A in the low halves of the ring dwords, B in the high halves).  Any grouping is valid because the chain set
+    // is then PROCESSED in ring order: position p of the permuted order `ring_perm` is the p-th ring member; in
+    // self-triangle mode a ring takes the targets at positions >= its first member, so every unordered pair is scored at
+    // least once (the score is symmetric) and stored at out[min][max].  Chains too long for a ring come last in the
+    // order (per-pair kernel).
     std::vector<uint32_t> items;
     for (uint32_t i = 0; i < n; ++i) {
-        if (qblock(db->len[i]) > RING_MAX_BLOCK) db->long_q.push_back(i);
+        if (qblock(db->len[i]) > RING_SUB) db->long_q.push_back(i);
         else items.push_back(i);
     }
     std::stable_sort(items.begin(), items.end(), [&](uint32_t x, uint32_t y) { return qblock(db->len[x]) > qblock(db->len[y]); });
     struct bin { uint32_t used = 0; std::vector<uint32_t> members; };
     std::vector<bin> bins;
     std::multimap<uint32_t, uint32_t> by_free;          // free slots -> bin index
-    const uint32_t CAP = 1024, NQCAP = 128;
+    const uint32_t CAP = RING_SUB, NQCAP = 64;          // 128 members per ring: the per-wave result words in LDS
     for (uint32_t q : items) {
         const uint32_t b = qblock(db->len[q]);
         auto it = by_free.lower_bound(b);               // tightest bin that still takes the block
@@ -83,27 +84,35 @@ int rsk_build_rings(rsk_db *db)
         bins[bi].members.push_back(q);
         if (bins[bi].used < CAP) by_free.insert({ CAP - bins[bi].used, bi });
     }
-    for (const bin &B : bins) {
-        const uint32_t bestD = B.used <= 512 ? 4 : 8;
+    // fullest bins first, so that the two bins of a ring are about equally full and only the last rings are small
+    std::stable_sort(bins.begin(), bins.end(), [](const bin &x, const bin &y) { return x.used > y.used; });
+    for (size_t b0 = 0; b0 < bins.size(); b0 += 2) {
+        const bin *sub[2] = { &bins[b0], b0 + 1 < bins.size() ? &bins[b0 + 1] : nullptr };
+        const uint32_t bestD = sub[0]->used <= 512 ? 8 : 16;         // sub[0] is the fuller one
         rsk_ring r;
         r.D = bestD;
-        r.nq = (uint32_t) B.members.size();
+        r.nq = (uint32_t) (sub[0]->members.size() + (sub[1] ? sub[1]->members.size() : 0));
         r.min_q = 0;                                    // position in the permuted order, set below
         r.letters_off = (uint32_t) letters.size();
         r.laneq_off = (uint32_t) laneq.size();
         r.qid_off = (uint32_t) qids.size();
-        const uint32_t P = 128 * bestD;
-        letters.resize(letters.size() + P, 0xFF);
-        laneq.resize(laneq.size() + (bestD / 4) * 64, 0xFF);
-        uint8_t *rl = &letters[r.letters_off];
-        uint8_t *lq = &laneq[r.laneq_off];
-        uint32_t s = 0;
-        for (uint32_t k = 0; k < r.nq; ++k) {
-            const uint32_t q = B.members[k], L = db->len[q], b = qblock(L);
-            memcpy(rl + s + 1, &db->h_mu[db->off[q]], L);     // slot s = separator, then the L rows
-            for (uint32_t g = s / 8; g < (s + b) / 8; ++g) lq[g] = (uint8_t) k;   // granule g = slots [8g, 8g+8)
-            qids.push_back(q);
-            s += b;
+        const uint32_t SR = 64 * bestD;                 // slots of a sub-ring
+        letters.resize(letters.size() + 2 * SR, 0xFF);
+        laneq.resize(laneq.size() + 2 * (SR / 4), 0xFF);
+        uint32_t k = 0;
+        for (int h = 0; h < 2; ++h) {
+            if (!sub[h]) break;
+            uint8_t *rl = &letters[r.letters_off + h * SR];
+            uint8_t *lq = &laneq[r.laneq_off + h * (SR / 4)];
+            uint32_t s = 0;
+            for (uint32_t q : sub[h]->members) {
+                const uint32_t L = db->len[q], b = qblock(L);
+                memcpy(rl + s + 1, &db->h_mu[db->off[q]], L);     // slot s = separator, then the L rows
+                for (uint32_t g = s / 4; g < (s + b) / 4; ++g) lq[g] = (uint8_t) k;   // granule g = slots [4g, 4g+4)
+                qids.push_back(q);
+                s += b;
+                ++k;
+            }
         }
         rings.push_back(r);
     }
@@ -120,7 +129,7 @@ int rsk_build_rings(rsk_db *db)
     db->h_ring_perm = perm;
     db->rings = rings;
     db->ring_slots_total = 0;
-    for (auto &r : rings) db->ring_slots_total += 128ull * r.D;
+    for (auto &r : rings) db->ring_slots_total += 128ull * r.D;      // two sub-rings of 64 * D slots
     auto up = [&](void **d, const void *h, size_t bytes) -> int {
         *d = nullptr;
         if (!bytes) return RSK_OK;
@@ -158,17 +167,17 @@ __device__ __forceinline__ void gl_emit(const gl_hits &h, uint32_t a, uint32_t b
 }
 
 template <int D> struct RingGeom {
-    static constexpr int P = 128 * D;          // row slots on the ring
-    static constexpr int RSB = 2 * P;          // bytes per profile row
-    static constexpr int NROWS = 37;           // 36 letters + the pad letter (all -32768)
+    static constexpr int SR = 64 * D;          // slots of one sub-ring (A = low halves, B = high halves of the ring dwords)
+    static constexpr int RSB = 4 * SR;         // bytes per profile row: one dword per ring dword
+    static constexpr int NROWS = 37;           // 36 letters + the pad letter (all -1.0)
     static constexpr int PROF_BYTES = NROWS * RSB;
-    static constexpr int NQMAX = P / 8;        // a query block is >= 8 slots
+    static constexpr int NQMAX = 128;          // members of a ring (64 per sub-ring, rsk_build_rings)
     static constexpr int M = D / 4;            // b128 groups per lane
 };
 
 template <int D, int NW> constexpr size_t ring_lds_bytes()
 {
-    return 2 * (size_t) RingGeom<D>::PROF_BYTES + (size_t) NW * RingGeom<D>::NQMAX * 4 + 1312 + RingGeom<D>::P + 16;
+    return (size_t) RingGeom<D>::PROF_BYTES + (size_t) NW * RingGeom<D>::NQMAX * 4 + 1312 + 2 * RingGeom<D>::SR + 16;
 }
 
 // (a + b) clamped to [0, 1] per half
@@ -199,17 +208,18 @@ __device__ __forceinline__ uint32_t gl_score_of_bits(int bits)         // invers
 }
 __device__ __forceinline__ int dpp_wave_ror1(int x)
 {
-    return __builtin_amdgcn_update_dpp(x, x, 0x13C /* wave_ror:1 */, 0xF, 0xF, false);
+    return __builtin_amdgcn_mov_dpp(x, 0x13C /* wave_ror:1 */, 0xF, 0xF, false);      // no tied operand: the source stays live
 }
 
-// One pair of target letters (c0, c1) with compile-time rotation state R (0..D-1).
-// A lane owns D CONSECUTIVE ring dwords (ring dword D*lane + k, k = 0..D-1); logical dword k lives in
-// physical register G[(k - R) mod D], so "every value moves up one ring dword" is a change of R plus
-// ONE v_mov_b32_dpp wave_ror:1 for the dword that crosses to the next lane (lane 63 -> lane 0 closes
-// the ring by itself).  The LDS profile keeps the b128 blocks of all lanes contiguous (block m of lane l
-// at m*1024 + 16*l: conflict-free), only the builder knows the slot permutation.
-template <int D, int R>
-__device__ __forceinline__ void ring_pairstep(int (&G)[D], int (&E)[D], const char *lane_p1, const char *lane_p2, unsigned c0, unsigned c1)
+// One pair of target letters (c0, c1).  A lane owns D CONSECUTIVE ring dwords (ring dword D*lane + k, k = 0..D-1); a
+// dword holds slot D*lane + k of sub-ring A in its low half and the same slot of sub-ring B in its high half, so "every
+// value moves up one row per letter" is a move by one whole dword: the add of the next letter simply takes its
+// neighbour's register as the source (no instruction), and only the dword that crosses to the next lane costs ONE
+// v_mov_b32_dpp wave_ror:1 (lane 63 -> lane 0 closes both sub-rings).  G[k] = the value standing at dword k before the
+// letter's score is added.  The LDS profile keeps the b128 blocks of all lanes contiguous (block m of lane l at
+// m*1024 + 16*l: conflict-free), only the builder knows the slot permutation.
+template <int D>
+__device__ __forceinline__ void ring_pairstep(int (&G)[D], int (&E)[D], const char *lane_p, unsigned c0, unsigned c1)
 {
     constexpr int M = D / 4;
     constexpr int RSB = RingGeom<D>::RSB;
@@ -217,31 +227,34 @@ __device__ __forceinline__ void ring_pairstep(int (&G)[D], int (&E)[D], const ch
     // row offsets are wave-uniform: multiply on the scalar unit, then ONE VOP2 add per address
     const unsigned o0 = (unsigned) __builtin_amdgcn_readfirstlane((int) (c0 * (unsigned) RSB));
     const unsigned o1 = (unsigned) __builtin_amdgcn_readfirstlane((int) (c1 * (unsigned) RSB));
-    const char *a0 = lane_p1 + o0;
-    const char *a1 = lane_p2 + o1;
+    const char *a0 = lane_p + o0;
+    const char *a1 = lane_p + o1;
 #pragma unroll
     for (int m = 0; m < M; ++m) {
         S[m] = *(const v4i *) (a0 + m * 1024);
         T[m] = *(const v4i *) (a1 + m * 1024);
     }
+    int g1[D], g2[D];
 #pragma unroll
-    for (int k = 0; k < D; ++k) {
-        const int p = (k - R + D) % D;
-        const int g1 = pk_add_clamp01(G[p], S[k >> 2][k & 3]);
-        G[p] = pk_add_clamp01(g1, T[k >> 2][k & 3]);
-        E[k] = pk_max3_f16(E[k], g1, G[p]);
+    for (int k = D - 1; k >= 0; --k) g1[k] = pk_add_clamp01(G[k], S[k >> 2][k & 3]);
+    const int x1 = dpp_wave_ror1(g1[D - 1]);
+#pragma unroll
+    for (int k = D - 1; k >= 0; --k) {
+        g2[k] = pk_add_clamp01(k ? g1[k - 1] : x1, T[k >> 2][k & 3]);
+        E[k] = pk_max3_f16(E[k], g1[k], g2[k]);
     }
-    constexpr int pl = (D - 1 - R + D) % D;
-    G[pl] = dpp_wave_ror1(G[pl]);
+    G[0] = dpp_wave_ror1(g2[D - 1]);
+#pragma unroll
+    for (int k = 1; k < D; ++k) G[k] = g2[k - 1];
 }
 
-template <int D, int R0>
-__device__ __forceinline__ void ring_8letters(int (&G)[D], int (&E)[D], const char *lane_p1, const char *lane_p2, uint2 Lc)
+template <int D>
+__device__ __forceinline__ void ring_8letters(int (&G)[D], int (&E)[D], const char *lane_p, uint2 Lc)
 {
-    ring_pairstep<D, (R0 + 0) % D>(G, E, lane_p1, lane_p2, Lc.x & 0xFF, (Lc.x >> 8) & 0xFF);
-    ring_pairstep<D, (R0 + 1) % D>(G, E, lane_p1, lane_p2, (Lc.x >> 16) & 0xFF, Lc.x >> 24);
-    ring_pairstep<D, (R0 + 2) % D>(G, E, lane_p1, lane_p2, Lc.y & 0xFF, (Lc.y >> 8) & 0xFF);
-    ring_pairstep<D, (R0 + 3) % D>(G, E, lane_p1, lane_p2, (Lc.y >> 16) & 0xFF, Lc.y >> 24);
+    ring_pairstep<D>(G, E, lane_p, Lc.x & 0xFF, (Lc.x >> 8) & 0xFF);
+    ring_pairstep<D>(G, E, lane_p, (Lc.x >> 16) & 0xFF, Lc.x >> 24);
+    ring_pairstep<D>(G, E, lane_p, Lc.y & 0xFF, (Lc.y >> 8) & 0xFF);
+    ring_pairstep<D>(G, E, lane_p, (Lc.y >> 16) & 0xFF, Lc.y >> 24);
 }
 
 template <int D, int NW>
@@ -261,14 +274,13 @@ __global__ __launch_bounds__(64 * NW) void k_gapless_ring(const rsk_ring *__rest
                                                           const uint32_t *__restrict__ q_len)
 {
     typedef RingGeom<D> Gm;
-    constexpr int P = Gm::P, RSB = Gm::RSB, NQMAX = Gm::NQMAX, M = Gm::M;
+    constexpr int SR = Gm::SR, NQMAX = Gm::NQMAX, M = Gm::M;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    short *prof1 = (short *) smem;
-    short *prof2 = (short *) (smem + Gm::PROF_BYTES);
-    int *res = (int *) (smem + 2 * Gm::PROF_BYTES);
+    int *prof = (int *) smem;
+    int *res = (int *) (smem + Gm::PROF_BYTES);
     signed char *mat = (signed char *) (res + NW * NQMAX);
     unsigned char *rl = (unsigned char *) (mat + 1312);
-    uint32_t &next_t = *(uint32_t *) (rl + P);   // all LDS lives in the dynamic region (keeps it 16-byte aligned)
+    uint32_t &next_t = *(uint32_t *) (rl + 2 * SR);   // all LDS lives in the dynamic region (keeps it 16-byte aligned)
 
     const int tid = threadIdx.x;
     const int nthreads = 64 * NW;
@@ -279,35 +291,35 @@ __global__ __launch_bounds__(64 * NW) void k_gapless_ring(const rsk_ring *__rest
     if (tid == 0) next_t = t0;
 
     for (int i = tid; i < 1296; i += nthreads) mat[i] = c_mu_int[i];
-    for (int i = tid; i < P; i += nthreads) rl[i] = ring_letters[rg.letters_off + i];
+    for (int i = tid; i < 2 * SR; i += nthreads) rl[i] = ring_letters[rg.letters_off + i];
     for (int i = tid; i < NW * NQMAX; i += nthreads) res[i] = 0;
     __syncthreads();
-    // build both profile copies, 8 slots (16 bytes) per store
-    for (int idx = tid; idx < Gm::NROWS * (P / 8); idx += nthreads) {
-        const int c = idx / (P / 8), g = idx - c * (P / 8);
+    // build the profile, 4 ring dwords (16 bytes: 4 slots of A and of B) per store
+    for (int idx = tid; idx < Gm::NROWS * (SR / 4); idx += nthreads) {
+        const int c = idx / (SR / 4), g = idx - c * (SR / 4);
         // LDS block g = (b128 block m = g / 64 of lane g % 64) holds ring granule M * lane + m
-        const int rg = M * (g & 63) + (g >> 6);
-        short v1[8], v2[8];
+        const int gr = M * (g & 63) + (g >> 6);
+        v4i v;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            const int s = (8 * rg + k) & (P - 1);
-            const unsigned l = rl[s];
-            const short v = (short) ((c == 36 || l == 0xFF) ? GL_RESET_BITS : gl_half_bits(mat[c * 36 + l]));
-            if (k < 8) v1[k] = v;
-            if (k > 0) v2[k - 1] = v;
+        for (int k = 0; k < 4; ++k) {
+            const unsigned la = rl[4 * gr + k], lb = rl[SR + 4 * gr + k];
+            const unsigned lo = (c == 36 || la == 0xFF) ? GL_RESET_BITS : gl_half_bits(mat[c * 36 + la]);
+            const unsigned hi = (c == 36 || lb == 0xFF) ? GL_RESET_BITS : gl_half_bits(mat[c * 36 + lb]);
+            v[k] = (int) (lo | (hi << 16));
         }
-        *(v4i *) (prof1 + (size_t) c * P + 8 * g) = *(const v4i *) v1;
-        *(v4i *) (prof2 + (size_t) c * P + 8 * g) = *(const v4i *) v2;
+        *(v4i *) (prof + (size_t) c * SR + 4 * g) = v;
     }
     __syncthreads();
 
     const int wave = tid >> 6, lane = tid & 63;
-    const char *lane_p1 = (const char *) prof1 + lane * 16;
-    const char *lane_p2 = (const char *) prof2 + lane * 16;
+    const char *lane_p = (const char *) prof + lane * 16;
     int *wres = res + wave * NQMAX;
-    int lq[M];
+    int lqa[M], lqb[M];
 #pragma unroll
-    for (int m = 0; m < M; ++m) lq[m] = ring_laneq[rg.laneq_off + M * lane + m];
+    for (int m = 0; m < M; ++m) {
+        lqa[m] = ring_laneq[rg.laneq_off + M * lane + m];
+        lqb[m] = ring_laneq[rg.laneq_off + SR / 4 + M * lane + m];
+    }
 
     for (;;) {
         uint32_t t = 0;
@@ -323,35 +335,46 @@ __global__ __launch_bounds__(64 * NW) void k_gapless_ring(const rsk_ring *__rest
         const uint32_t toff = __builtin_amdgcn_readfirstlane(t_off[t]);
         const uint32_t tlen = __builtin_amdgcn_readfirstlane(t_len[t]);
         const uint2 *lp = (const uint2 *) (t_mu + toff);
-        const uint32_t nch = (tlen + 7) >> 3;
+        const uint32_t nfull = tlen >> 3;                                     // whole 8-letter words
         int G[D], E[D];
 #pragma unroll
         for (int k = 0; k < D; ++k) { G[k] = 0; E[k] = 0; }
-        // a full rotation of the register names takes D pair-steps = 2*D letters
-        if (D == 4) {
-            uint2 L = lp[0];
-            for (uint32_t ch = 0; ch < nch; ++ch) {
-                const uint2 Lc = L;
-                L = lp[ch + 1];   // prefetch (the chain set has >= 64 bytes of tail padding)
-                ring_8letters<D, 0>(G, E, lane_p1, lane_p2, Lc);
-            }
-        } else {
-            uint2 L0 = lp[0], L1 = lp[1];
-            uint32_t ch = 0;
-            for (; ch + 2 <= nch; ch += 2) {
-                const uint2 Lc0 = L0, Lc1 = L1;
-                L0 = lp[ch + 2]; L1 = lp[ch + 3];
-                ring_8letters<D, 0>(G, E, lane_p1, lane_p2, Lc0);
-                ring_8letters<D, 4>(G, E, lane_p1, lane_p2, Lc1);
-            }
-            if (ch < nch) ring_8letters<D, 0>(G, E, lane_p1, lane_p2, L0);   // odd tail: the target ends here, names need not close
+        uint2 L0 = lp[0], L1 = lp[1];
+        uint32_t ch = 0;
+        for (; ch + 2 <= nfull; ch += 2) {
+            const uint2 Lc0 = L0, Lc1 = L1;
+            L0 = lp[ch + 2]; L1 = lp[ch + 3];   // prefetch (the chain set has >= 64 bytes of tail padding)
+            ring_8letters<D>(G, E, lane_p, Lc0);
+            ring_8letters<D>(G, E, lane_p, Lc1);
         }
-        // per-query reduction
+        if (ch < nfull) { ring_8letters<D>(G, E, lane_p, L0); L0 = L1; }
+        // the last tlen % 8 letters, two at a time (chains are padded with the pad letter, whose row resets)
+        {
+            unsigned long long w = ((unsigned long long) L0.y << 32) | L0.x;
+            for (uint32_t np = ((tlen & 7) + 1) >> 1; np; --np) {
+                ring_pairstep<D>(G, E, lane_p, (unsigned) w & 0xFF, (unsigned) (w >> 8) & 0xFF);
+                w >>= 16;
+            }
+        }
+        // per-query reduction: the granules of a lane mostly belong to one query -- one LDS atomic per run
+        {
+            int va[M], vb[M];
 #pragma unroll
-        for (int m = 0; m < M; ++m) {
-            const int b = pk_max(pk_max(E[4 * m], E[4 * m + 1]), pk_max(E[4 * m + 2], E[4 * m + 3]));
-            const int v = max(b & 0xFFFF, (int) ((unsigned) b >> 16));        // half-float bits, >= 0: ordered like integers
-            if (lq[m] != 0xFF) atomicMax(&wres[lq[m]], v);
+            for (int m = 0; m < M; ++m) {
+                const int b = pk_max(pk_max(E[4 * m], E[4 * m + 1]), pk_max(E[4 * m + 2], E[4 * m + 3]));
+                va[m] = b & 0xFFFF;                                           // half-float bits, >= 0: ordered like integers
+                vb[m] = (int) ((unsigned) b >> 16);
+            }
+            int ca = lqa[0], xa = va[0], cb = lqb[0], xb = vb[0];
+#pragma unroll
+            for (int m = 1; m < M; ++m) {
+                if (lqa[m] == ca) xa = max(xa, va[m]);
+                else { if (ca != 0xFF) atomicMax(&wres[ca], xa); ca = lqa[m]; xa = va[m]; }
+                if (lqb[m] == cb) xb = max(xb, vb[m]);
+                else { if (cb != 0xFF) atomicMax(&wres[cb], xb); cb = lqb[m]; xb = vb[m]; }
+            }
+            if (ca != 0xFF) atomicMax(&wres[ca], xa);
+            if (cb != 0xFF) atomicMax(&wres[cb], xb);
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         for (uint32_t kb = 0; kb < rg.nq; kb += 64) {
@@ -514,7 +537,7 @@ int rsk_launch_gapless_rings(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int
     for (uint32_t i = 0; i < t->n; ++i) {
         const uint32_t L = t->len[self_triangle ? q->h_ring_perm[i] : i];
         pre_len[i + 1] = pre_len[i] + L;
-        pre_slots[i + 1] = pre_slots[i] + (uint64_t) ((L + 7) / 8 * 8);
+        pre_slots[i + 1] = pre_slots[i] + (uint64_t) ((L + 1) / 2 * 2);        // letters go in pairs
     }
     uint64_t pairs = 0, cells = 0, slots = 0;
     if (self_triangle) {                                  // the pair space of the contract: every unordered pair once
@@ -527,7 +550,7 @@ int rsk_launch_gapless_rings(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int
     }
     uint32_t nD4 = 0, nD8 = 0;
     for (auto &r : q->rings) {
-        (r.D == 4 ? nD4 : nD8)++;
+        (r.D == 8 ? nD4 : nD8)++;
         const uint32_t ts = self_triangle ? r.min_q : 0;
         slots += 128ull * r.D * (pre_slots[t->n] - pre_slots[ts]);
     }
@@ -550,7 +573,7 @@ int rsk_launch_gapless_rings(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int
         std::vector<uint64_t> cost[2];
         for (uint32_t ri = 0; ri < q->rings.size(); ++ri) {
             const rsk_ring &r = q->rings[ri];
-            const int c = r.D == 4 ? 0 : 1;
+            const int c = r.D == 8 ? 0 : 1;
             const uint32_t ts = self_triangle ? (r.min_q / TB[c]) * TB[c] : 0;
             for (uint32_t t0 = ts; t0 < t->n; t0 += TB[c]) {
                 const uint32_t lo = std::max(t0, self_triangle ? r.min_q : 0u), hi = std::min(t->n, t0 + TB[c]);
@@ -602,10 +625,10 @@ int rsk_launch_gapless_rings(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int
     (void) nD4; (void) nD8;
 
     RSK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-    rc = launch_ring_class<8, 16>(ctx, q, t, (const uint2 *) q->d_work + q->work_count[0], q->work_count[1], self_triangle,
+    rc = launch_ring_class<16, 16>(ctx, q, t, (const uint2 *) q->d_work + q->work_count[0], q->work_count[1], self_triangle,
                                   d_scores, ldo, RING_TB, hits);
     if (rc != RSK_OK) return rc;
-    rc = launch_ring_class<4, 8>(ctx, q, t, (const uint2 *) q->d_work, q->work_count[0], self_triangle, d_scores, ldo, RING_TB, hits);
+    rc = launch_ring_class<8, 16>(ctx, q, t, (const uint2 *) q->d_work, q->work_count[0], self_triangle, d_scores, ldo, RING_TB, hits);
     if (rc != RSK_OK) return rc;
     // queries too long for a ring: per-pair kernel over (long q) x targets
     if (q->long_pairs) {                               // list built with the work list (cached per target set + triangle flag)
