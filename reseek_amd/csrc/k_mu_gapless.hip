@@ -37,6 +37,7 @@
 
 typedef short v2s __attribute__((ext_vector_type(2)));
 typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 #define GL_SCALE 2048               // scores are stored as n / GL_SCALE in half floats
 #define GL_CAP_BITS 0x3C00          // 1.0 = the clamp's ceiling = score 2048
@@ -219,20 +220,24 @@ __device__ __forceinline__ int dpp_wave_ror1(int x)
 // letter's score is added.  The LDS profile keeps the b128 blocks of all lanes contiguous (block m of lane l at
 // m*1024 + 16*l: conflict-free), only the builder knows the slot permutation.
 template <int D>
-__device__ __forceinline__ void ring_pairstep(int (&G)[D], int (&E)[D], const char *lane_p, unsigned c0, unsigned c1)
+__device__ __forceinline__ void ring_pairstep(int (&G)[D], int (&E)[D], v2f lane_pp, unsigned c0, unsigned c1)
 {
     constexpr int M = D / 4;
     constexpr int RSB = RingGeom<D>::RSB;
     v4i S[M], T[M];
-    // row offsets are wave-uniform: multiply on the scalar unit, then ONE VOP2 add per address
+    // row offsets are wave-uniform: multiply on the scalar unit, then ONE VALU op for the two addresses of the step --
+    // v_pk_add_f32 on the BIT PATTERNS: an LDS byte address (< 2^23) read as a float is a denormal, and denormals add like
+    // the integers they spell (this code object runs with fp32 denormals enabled: .amdhsa_float_denorm_mode_32 3)
     const unsigned o0 = (unsigned) __builtin_amdgcn_readfirstlane((int) (c0 * (unsigned) RSB));
     const unsigned o1 = (unsigned) __builtin_amdgcn_readfirstlane((int) (c1 * (unsigned) RSB));
-    const char *a0 = lane_p + o0;
-    const char *a1 = lane_p + o1;
+    const unsigned long long oo = ((unsigned long long) o1 << 32) | o0;
+    unsigned long long ad;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(ad) : "v"(lane_pp), "s"(oo));
+    const unsigned a0 = (unsigned) ad, a1 = (unsigned) (ad >> 32);
 #pragma unroll
     for (int m = 0; m < M; ++m) {
-        S[m] = *(const v4i *) (a0 + m * 1024);
-        T[m] = *(const v4i *) (a1 + m * 1024);
+        S[m] = *(const v4i __attribute__((address_space(3))) *) (uintptr_t) (a0 + m * 1024);
+        T[m] = *(const v4i __attribute__((address_space(3))) *) (uintptr_t) (a1 + m * 1024);
     }
     int g1[D], g2[D];
 #pragma unroll
@@ -249,7 +254,7 @@ __device__ __forceinline__ void ring_pairstep(int (&G)[D], int (&E)[D], const ch
 }
 
 template <int D>
-__device__ __forceinline__ void ring_8letters(int (&G)[D], int (&E)[D], const char *lane_p, uint2 Lc)
+__device__ __forceinline__ void ring_8letters(int (&G)[D], int (&E)[D], v2f lane_p, uint2 Lc)
 {
     ring_pairstep<D>(G, E, lane_p, Lc.x & 0xFF, (Lc.x >> 8) & 0xFF);
     ring_pairstep<D>(G, E, lane_p, (Lc.x >> 16) & 0xFF, Lc.x >> 24);
@@ -312,7 +317,9 @@ __global__ __launch_bounds__(64 * NW) void k_gapless_ring(const rsk_ring *__rest
     __syncthreads();
 
     const int wave = tid >> 6, lane = tid & 63;
-    const char *lane_p = (const char *) prof + lane * 16;
+    // this lane's first b128 block of a profile row, as an LDS byte address, twice (see ring_pairstep)
+    const unsigned lane_a = (unsigned) (uintptr_t) (const __attribute__((address_space(3))) char *) prof + lane * 16;
+    const v2f lane_p = { __builtin_bit_cast(float, lane_a), __builtin_bit_cast(float, lane_a) };
     int *wres = res + wave * NQMAX;
     int lqa[M], lqb[M];
 #pragma unroll
