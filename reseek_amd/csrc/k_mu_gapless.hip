@@ -42,7 +42,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #define GL_SCALE 2048               // scores are stored as n / GL_SCALE in half floats
 #define GL_CAP_BITS 0x3C00          // 1.0 = the clamp's ceiling = score 2048
 #define GL_RESET_BITS 0xBC00        // -1.0: pad letters and separator rows
-#define RING_TB 256          // targets per work item
+#define RING_TB_MAX 1024     // targets per work item (a workgroup builds one LDS profile per item), see ring_target_block
 #define RING_SUB 1024        // slots of one sub-ring of a D = 16 ring: the largest query block (1 + L rounded up to 4)
 
 // ---------------------------------------------------------------------------------------------
@@ -327,6 +327,10 @@ __global__ __launch_bounds__(64 * NW) void k_gapless_ring(const rsk_ring *__rest
         lqa[m] = ring_laneq[rg.laneq_off + M * lane + m];
         lqb[m] = ring_laneq[rg.laneq_off + SR / 4 + M * lane + m];
     }
+    // chain ids of the ring's members (at most 128): lane l reports members l and 64 + l
+    uint32_t qid2[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) qid2[h] = (uint32_t) (64 * h + lane) < rg.nq ? ring_qid[rg.qid_off + 64 * h + lane] : 0u;
 
     for (;;) {
         uint32_t t = 0;
@@ -389,7 +393,7 @@ __global__ __launch_bounds__(64 * NW) void k_gapless_ring(const rsk_ring *__rest
             const bool have = k < rg.nq;
             int v = 0;
             uint32_t qid = 0;
-            if (have) { v = wres[k]; wres[k] = 0; qid = ring_qid[rg.qid_off + k]; }
+            if (have) { v = wres[k]; wres[k] = 0; qid = kb ? qid2[1] : qid2[0]; }
             uint32_t sc = gl_score_of_bits(v);
             // the clamp's ceiling: score these pairs again, exactly -- the wave walks the diagonals of one pair at a time
             // (x = max(0, x) + s in integers; a lane per diagonal)
@@ -509,15 +513,27 @@ static int launch_ring_class(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, con
     return RSK_OK;
 }
 
-// positions of every aligned RING_TB block ordered by decreasing target length: the waves of a workgroup claim the
-// long targets first, so the block ends without one wave still walking a long chain (LPT scheduling)
-static int build_claim_order(const rsk_db *db, const uint32_t *perm, uint32_t **d_out)
+// Targets per work item.  An item costs one profile build (37 rows of the whole LDS, nothing else runs on the CU meanwhile),
+// so the blocks are as large as the launch allows while it still has several items per CU: measured on the 11,211-chain
+// triangle (935 rings), 128 / 256 / 512 / 1024 / 2048 targets: 45.1 / 43.6 / 42.9 / 42.6 / 43.0 ms.
+static uint32_t ring_target_block(size_t nrings, uint32_t nt)
 {
-    if (*d_out) return RSK_OK;
+    uint32_t tb = RING_TB_MAX;
+    while (tb > 64 && nrings * ((nt + tb - 1) / tb) < 2048) tb /= 2;
+    return tb;
+}
+
+// positions of every aligned block of `tb` targets ordered by decreasing target length: the waves of a workgroup claim the
+// long targets first, so the block ends without one wave still walking a long chain (LPT scheduling)
+static int build_claim_order(const rsk_db *db, const uint32_t *perm, uint32_t **d_out, uint32_t *built_tb, uint32_t tb)
+{
+    if (*d_out && *built_tb == tb) return RSK_OK;
+    if (*d_out) { (void) hipFree(*d_out); *d_out = nullptr; }
+    *built_tb = tb;
     std::vector<uint32_t> claim(db->n);
     for (uint32_t i = 0; i < db->n; ++i) claim[i] = i;
-    for (uint32_t b = 0; b < db->n; b += RING_TB) {
-        const uint32_t e = std::min(db->n, b + RING_TB);
+    for (uint32_t b = 0; b < db->n; b += tb) {
+        const uint32_t e = std::min(db->n, b + tb);
         std::stable_sort(claim.begin() + b, claim.begin() + e, [&](uint32_t x, uint32_t y) {
             return db->len[perm ? perm[x] : x] > db->len[perm ? perm[y] : y];
         });
@@ -535,8 +551,9 @@ int rsk_launch_gapless_rings(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int
     hits.rec = d_rec; hits.count = d_count; hits.cap = capacity; hits.min_score = min_score; hits.q_base = q_base; hits.t_base = t_base;
     int rc = rsk_upload_mu_tables(ctx);
     if (rc != RSK_OK) return rc;
-    if (self_triangle) rc = build_claim_order(q, q->h_ring_perm.data(), &const_cast<rsk_db *>(q)->d_tri_claim);
-    else rc = build_claim_order(t, nullptr, &const_cast<rsk_db *>(t)->d_nat_claim);
+    const uint32_t tb = ring_target_block(q->rings.size(), t->n);
+    if (self_triangle) rc = build_claim_order(q, q->h_ring_perm.data(), &const_cast<rsk_db *>(q)->d_tri_claim, &const_cast<rsk_db *>(q)->tri_claim_tb, tb);
+    else rc = build_claim_order(t, nullptr, &const_cast<rsk_db *>(t)->d_nat_claim, &const_cast<rsk_db *>(t)->nat_claim_tb, tb);
     if (rc != RSK_OK) return rc;
     // work accounting (host side, O(rings))
     // targets in processing order: the ring permutation of the (same) chain set in self-triangle mode
@@ -574,8 +591,8 @@ int rsk_launch_gapless_rings(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int
     // work list: one workgroup per (ring, block of targets); only blocks that contain work, the
     // expensive ones first.  Cached per (target set, triangle flag) in the query chain set.
     rsk_db *qm = const_cast<rsk_db *>(q);
-    if (qm->work_for != t->uid || qm->work_tri != self_triangle) {
-        const uint32_t TB[2] = { RING_TB, RING_TB };   // targets per workgroup (the claim order is built for this block size)
+    if (qm->work_for != t->uid || qm->work_tri != self_triangle || qm->work_tb != tb) {
+        const uint32_t TB[2] = { tb, tb };             // targets per workgroup (the claim order is built for this block size)
         std::vector<uint2> w[2];
         std::vector<uint64_t> cost[2];
         for (uint32_t ri = 0; ri < q->rings.size(); ++ri) {
@@ -628,14 +645,15 @@ int rsk_launch_gapless_rings(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int
         }
         qm->work_for = t->uid;
         qm->work_tri = self_triangle;
+        qm->work_tb = tb;
     }
     (void) nD4; (void) nD8;
 
     RSK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     rc = launch_ring_class<16, 16>(ctx, q, t, (const uint2 *) q->d_work + q->work_count[0], q->work_count[1], self_triangle,
-                                  d_scores, ldo, RING_TB, hits);
+                                  d_scores, ldo, tb, hits);
     if (rc != RSK_OK) return rc;
-    rc = launch_ring_class<8, 16>(ctx, q, t, (const uint2 *) q->d_work, q->work_count[0], self_triangle, d_scores, ldo, RING_TB, hits);
+    rc = launch_ring_class<8, 16>(ctx, q, t, (const uint2 *) q->d_work, q->work_count[0], self_triangle, d_scores, ldo, tb, hits);
     if (rc != RSK_OK) return rc;
     // queries too long for a ring: per-pair kernel over (long q) x targets
     if (q->long_pairs) {                               // list built with the work list (cached per target set + triangle flag)

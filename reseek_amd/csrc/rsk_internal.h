@@ -148,11 +148,13 @@ struct rsk_db {
     uint32_t *d_ring_qid = nullptr;
     uint32_t *d_ring_perm = nullptr;    // processing order of the chains in self-triangle mode (ring members, then long chains)
     std::vector<uint32_t> h_ring_perm;
-    uint32_t *d_tri_claim = nullptr;    // per 256-position block of ring_perm: positions by decreasing chain length
+    uint32_t *d_tri_claim = nullptr;    // per tri_claim_tb-position block of ring_perm: positions by decreasing chain length
     uint32_t *d_nat_claim = nullptr;    // same for the natural chain order (rectangular mode, this set as targets)
+    uint32_t tri_claim_tb = 0, nat_claim_tb = 0;   // block size the two orders were built for
     // gapless work list cache (valid for one target set + triangle flag)
     uint64_t work_for = 0;              // uid of the target set the list was built for
     int work_tri = -1;
+    uint32_t work_tb = 0;               // targets per work item of the cached list
     void *d_work = nullptr;             // uint2 (ring, first target) entries, D = 4 class first
     uint32_t work_count[2] = { 0, 0 };
     uint32_t *d_long_iq = nullptr, *d_long_it = nullptr;   // (long query, target) pairs of the per-pair kernel, same cache key

@@ -1,10 +1,12 @@
 #!/bin/bash
-# build_variant.sh NAME "-DSWF_R=12 -DSWF_WPE=3" FILE.hip : librsk_NAME.so with one source recompiled under extra flags
+# build/var_<name>/librsk.so = the library with ONE source recompiled under extra -D flags (timing experiments; RSK_LIB selects it)
+# usage: tools/exp/build_variant.sh <name> <source.hip> <flags...>
 set -e
 cd "$(dirname "$0")/../.."
-NAME=$1; FLAGS=$2; SRC=$3
-mkdir -p build/var_$NAME
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I include $FLAGS -c reseek_amd/csrc/$SRC -o build/var_$NAME/$SRC.o
-OBJS=$(ls build/obj/*.o | grep -v "/$SRC.o")
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS build/var_$NAME/$SRC.o -o reseek_amd/librsk_$NAME.so
-echo built reseek_amd/librsk_$NAME.so
+name=$1; src=$2; shift 2
+python __graft_entry__.py > /dev/null
+mkdir -p build/var_$name
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I include "$@" -c reseek_amd/csrc/$src -o build/var_$name/$src.o
+objs=$(ls build/obj/*.o | grep -v "/$src.o")
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs build/var_$name/$src.o -o build/var_$name/librsk.so
+echo build/var_$name/librsk.so
