@@ -45,12 +45,6 @@ static const uint32_t musw_class_waves[MUSW_NCLASS] = { 4, 8, 16 };
 // of waiting at the item barrier for the slowest wave.
 #define MUSW_CHUNK 4
 
-__device__ __forceinline__ int dpp_wave_shr1(int x)
-{
-    // lane l <- lane l-1 (lane 0 keeps its own value; callers ignore it there)
-    return __builtin_amdgcn_update_dpp(x, x, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
-}
-
 struct musw_args {
     const uint8_t *q_mu; const uint32_t *q_off; const uint32_t *q_len;
     const uint8_t *t_mu; const uint32_t *t_off; const uint32_t *t_len;
@@ -115,6 +109,58 @@ __device__ __forceinline__ int pk_lo_hi(int a, int b)
     return r;
 }
 
+// The target letters of a lane whose column advances by one per step, four columns at a time: the lane keeps the two dwords
+// that hold letters j0 .. j0+3 (j0 = the lane's column at a step count that is a multiple of 4; j0 & 3 never changes, so
+// ONE v_alignbyte_b32 cuts the four letters out), a third dword is in flight.  Letters outside [0, LB) read as the pad
+// letter: a dword is patched when it enters the window, and only the few dwords that straddle an end take that path.
+// (r01-r04 fetched per column under a lane-dependent `j & 3 == 0` test: ~20 VALU ops and two divergent branches per column.)
+#define MUSW_PAD4 0x24242424u
+struct musw_letters {
+    const uint8_t *B;
+    uint32_t LB, nfull, lastq;
+    unsigned w0, w1, w2, sh;
+    int idx;                                         // dword index of w0 (negative while the lane waits for its first column)
+    __device__ __forceinline__ unsigned patched(unsigned raw, int i) const
+    {
+        if ((unsigned) i < nfull) return raw;        // every letter of the dword is inside the chain
+        const int nb = (int) LB - 4 * i;             // letters of the chain from this dword's first byte on
+        if (i < 0 || nb <= 0) return MUSW_PAD4;
+        const unsigned m = (1u << (8 * nb)) - 1u;    // 1 <= nb <= 3
+        return (raw & m) | (MUSW_PAD4 & ~m);
+    }
+    __device__ __forceinline__ unsigned load(int i) const
+    {
+        const int ic = min(max(i, 0), (int) lastq);  // stays inside the chain's padded bytes (+ the set's tail slack)
+        return *(const unsigned *) (B + 4 * ic);
+    }
+    __device__ __forceinline__ void start(const uint8_t *b, uint32_t lb, int j0)
+    {
+        B = b; LB = lb; nfull = lb >> 2; lastq = (lb + 3) >> 2;
+        sh = (unsigned) j0 & 3u;
+        idx = j0 >> 2;
+        w0 = patched(load(idx), idx);
+        w1 = patched(load(idx + 1), idx + 1);
+        w2 = load(idx + 2);
+    }
+    // letters of the next four columns (byte k = column j0 + k), then the window moves on by one dword
+    __device__ __forceinline__ unsigned next4()
+    {
+        const unsigned l4 = __builtin_amdgcn_alignbyte(w1, w0, sh);
+        w0 = w1;
+        w1 = patched(w2, idx + 2);
+        ++idx;
+        w2 = load(idx + 2);
+        return l4;
+    }
+};
+// lane l <- (lane l-1's x) & m, 0 from outside the wave: the hand-down and its mask in one VOP2 with a DPP source
+__device__ __forceinline__ int dpp_wave_shr1_and(int x, int m)
+{
+    int r;
+    asm("v_and_b32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(r) : "v"(x), "v"(m));
+    return r;
+}
+
 // Two cells per VALU op: the 32 rows of a strip are 16 registers of packed half floats, row r in the low
 // half and row r + 16 in the high half.  The high half runs ONE COLUMN BEHIND the low half (the same
 // systolic skew that separates neighbouring lanes, applied inside the lane), so the vertical F chain
@@ -123,13 +169,16 @@ __device__ __forceinline__ int pk_lo_hi(int a, int b)
 // removes the explicit max(., 0) from H: the floor is the third operand of the maximum that updates E / F.
 // Per 2 cells: bfi (merge the two profile rows), add, max3 (H), add, add, max3 (E), add, max3 (F), and half a max3 for the
 // running best (two rows at a time) = 8.5 packed ops (r01-r02, packed int16: 10).
-__global__ __launch_bounds__(1024) void k_mu_sw(musw_args a, uint32_t gmax)
+// GMAX = strips of the class's longest query: the profile is laid out for GMAX strips whatever the query's own count, so that
+// the four b128 blocks of a letter row sit at immediate offsets from one address (see k_mu_sw2).
+template <int GMAX>
+__global__ __launch_bounds__(1024) void k_mu_sw(musw_args a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // int16 query profile, dword (c, k, st, w) = rows 32*st + 4*k + w (low half) and + 16 (high half) against letter c:
-    // P[((c*4 + k)*g + st)*4 + w]; a lane's four b128 reads per letter row are conflict-free across the strips of a pair
+    // query profile (packed half floats), dword (c, k, st, w) = rows 32*st + 4*k + w (low half) and + 16 (high half) against
+    // letter c: P[((c*4 + k)*GMAX + st)*4 + w]; a lane's four b128 reads per letter row are conflict-free across the strips of a pair
     int *prof = (int *) smem;
-    signed char *mat = (signed char *) (prof + (size_t) 37 * gmax * 16);
+    signed char *mat = (signed char *) (prof + (size_t) 37 * GMAX * 16);
     uint32_t *wg_item = (uint32_t *) (mat + 1312);           // [0] item, [1] batch counter of the item
     int *pbest = (int *) (wg_item + 4);                      // per wave 64 running pair maxima (early exit of the reverse pass)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -162,7 +211,7 @@ __global__ __launch_bounds__(1024) void k_mu_sw(musw_args a, uint32_t gmax)
                 int vlo = MUSW_PADSCORE, vhi = MUSW_PADSCORE;
                 if (c < 36 && ilo < LQ) vlo = mat[c * 36 + Q[a.reverse ? (LQ - 1 - ilo) : ilo]];
                 if (c < 36 && ihi < LQ) vhi = mat[c * 36 + Q[a.reverse ? (LQ - 1 - ihi) : ihi]];
-                prof[idx] = (int) (musw_half_bits(vlo) | (musw_half_bits(vhi) << 16));
+                prof[((c * 4 + k) * GMAX + sst) * 4 + w] = (int) (musw_half_bits(vlo) | (musw_half_bits(vhi) << 16));
             }
             __syncthreads();
         }
@@ -199,33 +248,27 @@ __global__ __launch_bounds__(1024) void k_mu_sw(musw_args a, uint32_t gmax)
         int bot_h = 0, bot_f = 0;      // (row 15 | row 31) H and outgoing F of the previous step
         int diag_in = 0;               // H above the top rows at the previous column
         const int nopen2 = (int) (musw_half_bits(-a.open) * 0x10001u), next2 = (int) (musw_half_bits(-a.ext) * 0x10001u);
-        const char *lane_prof = (const char *) prof + st * 16;
-        const uint32_t kstride = g * 16, RS = g * 64;         // bytes between k blocks / letter rows
-        const int top_mask = st == 0 ? (int) 0xFFFF0000 : -1; // the very first rows have no strip above: H = F = 0
-        unsigned lw = active ? *(const unsigned *) B : 0u;    // letters j..j+3 (chains are padded to 16 in HBM)
-        unsigned lw_next = 0;
-        unsigned c_prev = 36;
+        // this lane's block of a letter row's first quarter, as an LDS byte address
+        const unsigned lane_prof = (unsigned) (uintptr_t) (const __attribute__((address_space(3))) char *) prof + st * 16;
+        constexpr uint32_t kstride = GMAX * 16, RS = GMAX * 64;       // bytes between k blocks / letter rows
+        const int top_mask = st == 0 ? 0 : -1;                // the very first rows have no strip above: H = F = 0
+        musw_letters tl;
+        tl.start(B, LB, -2 * (int) st);                       // column of the low half; the high half is one column behind
+        unsigned rowh = 36u * RS + lane_prof;                 // letter row of the previous column
 
-        auto step = [&](const int (&Hin)[16], int (&Hout)[16], uint32_t col) {
-            const int j = (int) col - 2 * (int) st;            // column of the low half; the high half is at j - 1
+        auto step = [&](const int (&Hin)[16], int (&Hout)[16], unsigned c) {
             // rows above: low half <- high half of the previous lane (its previous step), high half <- own low half
-            const int xh = dpp_wave_shr1(bot_h), xf = dpp_wave_shr1(bot_f);
-            const int up_h = (int) __builtin_amdgcn_alignbit((unsigned) bot_h, (unsigned) xh, 16) & top_mask;
-            const int up_f = (int) __builtin_amdgcn_alignbit((unsigned) bot_f, (unsigned) xf, 16) & top_mask;
-            unsigned c = 36;
-            if (j >= 0 && (uint32_t) j < LB) {
-                const int jm = j & 3;
-                if (jm == 0) {
-                    if (j) lw = lw_next;
-                    lw_next = *(const unsigned *) (B + j + 4);   // prefetch the next 4 letters
-                }
-                c = (lw >> (8 * jm)) & 0xFF;
-            }
-            const char *rowl = lane_prof + c * RS, *rowh = lane_prof + c_prev * RS;
-            c_prev = c;
+            const int xh = dpp_wave_shr1_and(bot_h, top_mask), xf = dpp_wave_shr1_and(bot_f, top_mask);
+            const int up_h = (int) __builtin_amdgcn_alignbit((unsigned) bot_h, (unsigned) xh, 16);
+            const int up_f = (int) __builtin_amdgcn_alignbit((unsigned) bot_f, (unsigned) xf, 16);
+            const unsigned rowl = __umul24(c, RS) + lane_prof;
             v4i Pl[4], Ph[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { Pl[k] = *(const v4i *) (rowl + k * kstride); Ph[k] = *(const v4i *) (rowh + k * kstride); }
+            for (int k = 0; k < 4; ++k) {
+                Pl[k] = *(const v4i __attribute__((address_space(3))) *) (uintptr_t) (rowl + k * kstride);
+                Ph[k] = *(const v4i __attribute__((address_space(3))) *) (uintptr_t) (rowh + k * kstride);
+            }
+            rowh = rowl;
             int diag = diag_in;
             int F = up_f;
             diag_in = up_h;
@@ -253,11 +296,14 @@ __global__ __launch_bounds__(1024) void k_mu_sw(musw_args a, uint32_t gmax)
             }
             pbest[wave * 64 + lane] = 0;
         }
-        // an odd step count is rounded up: the extra step only sees pad letters / finished columns
-        for (uint32_t col = 0; col < ncol; col += 2) {
-            step(HA, HB, col);
-            step(HB, HA, col + 1);
-            if (a.thr && (col & 6) == 6) {           // every 8 columns: has every pair of this wave failed already?
+        // a step count that is not a multiple of 4 is rounded up: the extra steps only see pad letters / finished columns
+        for (uint32_t col = 0; col < ncol; col += 4) {
+            const unsigned l4 = tl.next4();
+            step(HA, HB, l4 & 0xFF);
+            step(HB, HA, (l4 >> 8) & 0xFF);
+            step(HA, HB, (l4 >> 16) & 0xFF);
+            step(HB, HA, l4 >> 24);
+            if (a.thr && (col & 4)) {                // every 8 columns: has every pair of this wave failed already?
                 const int mine = max(best & 0xFFFF, (int) ((unsigned) best >> 16));
                 __hip_atomic_fetch_max(&pbest[wave * 64 + pr], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -298,13 +344,17 @@ __global__ __launch_bounds__(1024) void k_mu_sw(musw_args a, uint32_t gmax)
 // ---------------------------------------------------------------------------------------------
 #define MUSW2_R 16
 #define MUSW_NOQ 0xFFFFFFFFu
-__global__ __launch_bounds__(1024) void k_mu_sw2(musw_args a, uint32_t gmax, const uint2 *__restrict__ qpairs)
+// GMAX = strips of the class's longest query pair: the profile is laid out for GMAX strips whatever the pair's own count, so
+// that the four b128 blocks of a letter row sit at IMMEDIATE offsets from one address (one v_mad per column instead of
+// a 64-bit multiply and three adds).
+template <int GMAX>
+__global__ __launch_bounds__(1024) void k_mu_sw2(musw_args a, const uint2 *__restrict__ qpairs)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // dword (c, k, st, w) = row 16*st + 4*k + w of query A (low half) and of query B (high half) against letter c:
-    // P[((c*4 + k)*g + st)*4 + w]; a lane's four b128 reads per letter row are conflict-free across the strips of a group
+    // P[((c*4 + k)*GMAX + st)*4 + w]; a lane's four b128 reads per letter row are conflict-free across the strips of a group
     int *prof = (int *) smem;
-    signed char *mat = (signed char *) (prof + (size_t) 37 * gmax * 16);
+    signed char *mat = (signed char *) (prof + (size_t) 37 * GMAX * 16);
     uint32_t *wg_item = (uint32_t *) (mat + 1312);
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t nwaves = blockDim.x >> 6;
@@ -334,7 +384,7 @@ __global__ __launch_bounds__(1024) void k_mu_sw2(musw_args a, uint32_t gmax, con
                 int va = MUSW_PADSCORE, vb = MUSW_PADSCORE;
                 if (c < 36 && i < LA) va = mat[c * 36 + QA[a.reverse ? (LA - 1 - i) : i]];
                 if (c < 36 && i < LBq) vb = mat[c * 36 + QB[a.reverse ? (LBq - 1 - i) : i]];
-                prof[idx] = (int) (musw_half_bits(va) | (musw_half_bits(vb) << 16));
+                prof[((c * 4 + k) * GMAX + sst) * 4 + w] = (int) (musw_half_bits(va) | (musw_half_bits(vb) << 16));
             }
             __syncthreads();
         }
@@ -367,27 +417,18 @@ __global__ __launch_bounds__(1024) void k_mu_sw2(musw_args a, uint32_t gmax, con
         int bot_h = 0, bot_f = 0;      // bottom row of this strip at its previous step: H and the outgoing F
         int diag_in = 0;               // H above the top row at the previous column
         const int nopen2 = (int) (musw_half_bits(-a.open) * 0x10001u), next2 = (int) (musw_half_bits(-a.ext) * 0x10001u);
-        const char *lane_prof = (const char *) prof + st * 16;
-        const uint32_t kstride = g * 16, RS = g * 64;
+        // this lane's block of a letter row's first quarter, as an LDS byte address
+        const unsigned lane_prof = (unsigned) (uintptr_t) (const __attribute__((address_space(3))) char *) prof + st * 16;
+        constexpr uint32_t kstride = GMAX * 16, RS = GMAX * 64;
         const int top_mask = st == 0 ? 0 : -1;       // the first strip has nothing above it: H = F = 0
-        unsigned lw = active ? *(const unsigned *) B : 0u;
-        unsigned lw_next = 0;
-        auto step = [&](const int (&Hin)[16], int (&Hout)[16], uint32_t col) {
-            const int j = (int) col - (int) st;
-            const int up_h = dpp_wave_shr1(bot_h) & top_mask, up_f = dpp_wave_shr1(bot_f) & top_mask;
-            unsigned c = 36;
-            if (j >= 0 && (uint32_t) j < LB) {
-                const int jm = j & 3;
-                if (jm == 0) {
-                    if (j) lw = lw_next;
-                    lw_next = *(const unsigned *) (B + j + 4);
-                }
-                c = (lw >> (8 * jm)) & 0xFF;
-            }
-            const char *row = lane_prof + c * RS;
+        musw_letters tl;
+        tl.start(B, LB, -(int) st);                  // strip st is st columns behind strip 0
+        auto step = [&](const int (&Hin)[16], int (&Hout)[16], unsigned c) {
+            const int up_h = dpp_wave_shr1_and(bot_h, top_mask), up_f = dpp_wave_shr1_and(bot_f, top_mask);
+            const unsigned row = __umul24(c, RS) + lane_prof;
             v4i P[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) P[k] = *(const v4i *) (row + k * kstride);
+            for (int k = 0; k < 4; ++k) P[k] = *(const v4i __attribute__((address_space(3))) *) (uintptr_t) (row + k * kstride);
             int diag = diag_in;
             int F = up_f;
             diag_in = up_h;
@@ -406,9 +447,13 @@ __global__ __launch_bounds__(1024) void k_mu_sw2(musw_args a, uint32_t gmax, con
             bot_h = Hout[15];
             bot_f = F;
         };
-        for (uint32_t col = 0; col < ncol; col += 2) {
-            step(HA, HB, col);
-            step(HB, HA, col + 1);
+        // a step count that is not a multiple of 4 is rounded up: the extra steps only see pad letters / finished columns
+        for (uint32_t col = 0; col < ncol; col += 4) {
+            const unsigned l4 = tl.next4();
+            step(HA, HB, l4 & 0xFF);
+            step(HB, HA, (l4 >> 8) & 0xFF);
+            step(HA, HB, (l4 >> 16) & 0xFF);
+            step(HB, HA, l4 >> 24);
         }
         int ra = best & 0xFFFF, rb = (int) ((unsigned) best >> 16);      // half-float bits >= 0: ordered like integers
         for (uint32_t d = 1; d < g; ++d) {
@@ -716,12 +761,18 @@ static int run_mu_sw_lists(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, musw_
             const size_t lds = (size_t) 37 * gmax * 64 + 1312 + 16 + (size_t) waves * 256;
             static std::atomic<int> attr_set[64];
             const int arc = rsk_once_per_device(attr_set, ctx->device, [&]() -> int {
-                RSK_HIP(hipFuncSetAttribute((const void *) k_mu_sw, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+                RSK_HIP(hipFuncSetAttribute((const void *) k_mu_sw<13>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+                RSK_HIP(hipFuncSetAttribute((const void *) k_mu_sw<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+                RSK_HIP(hipFuncSetAttribute((const void *) k_mu_sw<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
                 return RSK_OK;
             });
             if (arc != RSK_OK) return arc;
             const int wg_per_cu = std::max(1, std::min<int>(20 / (int) waves, (int) (163840 / lds)));
-            hipLaunchKernelGGL(k_mu_sw, dim3(ctx->num_cus * wg_per_cu), dim3(64 * waves), lds, ctx->stream, a, gmax);
+            static_assert(MUSW_NCLASS == 3, "one k_mu_sw instance per class");
+            const dim3 grid(ctx->num_cus * wg_per_cu), block(64 * waves);
+            if (gmax == 13) hipLaunchKernelGGL(k_mu_sw<13>, grid, block, lds, ctx->stream, a);
+            else if (gmax == 32) hipLaunchKernelGGL(k_mu_sw<32>, grid, block, lds, ctx->stream, a);
+            else hipLaunchKernelGGL(k_mu_sw<64>, grid, block, lds, ctx->stream, a);
         } else {
             // slow path: needs the item count on the host to size the launch
             uint32_t n = 0;
@@ -802,12 +853,18 @@ static int run_mu_sw_querypairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, 
             const size_t lds = (size_t) 37 * gmax * 64 + 1312 + 16;
             static std::atomic<int> attr_set[64];
             const int arc = rsk_once_per_device(attr_set, ctx->device, [&]() -> int {
-                RSK_HIP(hipFuncSetAttribute((const void *) k_mu_sw2, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+                RSK_HIP(hipFuncSetAttribute((const void *) k_mu_sw2<13>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+                RSK_HIP(hipFuncSetAttribute((const void *) k_mu_sw2<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+                RSK_HIP(hipFuncSetAttribute((const void *) k_mu_sw2<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
                 return RSK_OK;
             });
             if (arc != RSK_OK) return arc;
             const int wg_per_cu = std::max(1, std::min<int>(20 / (int) waves, (int) (163840 / lds)));
-            hipLaunchKernelGGL(k_mu_sw2, dim3(ctx->num_cus * wg_per_cu), dim3(64 * waves), lds, ctx->stream, a, gmax, (const uint2 *) d_qp);
+            static_assert(MUSW_NCLASS == 3, "one k_mu_sw2 instance per class");
+            const dim3 grid(ctx->num_cus * wg_per_cu), block(64 * waves);
+            if (gmax == 13) hipLaunchKernelGGL(k_mu_sw2<13>, grid, block, lds, ctx->stream, a, (const uint2 *) d_qp);
+            else if (gmax == 32) hipLaunchKernelGGL(k_mu_sw2<32>, grid, block, lds, ctx->stream, a, (const uint2 *) d_qp);
+            else hipLaunchKernelGGL(k_mu_sw2<64>, grid, block, lds, ctx->stream, a, (const uint2 *) d_qp);
             RSK_HIP(hipGetLastError());
         }
     }
