@@ -86,6 +86,55 @@ def test_random_lengths_vs_oracle_including_long_and_tiny(ctx):
     assert want.max() > 300
 
 
+def test_ring_geometry_edges(ctx):
+    """The ring kernel's layout cases: sub-rings that hit the 64-member cap (tiny chains), a small (D = 8) ring, a ring whose
+    second sub-ring is empty, query blocks of every size modulo 4 next to chains that fill a whole sub-ring (1019 .. 1023
+    residues), and targets of every length modulo 8 (whole 8-letter words, then the tail two letters at a time)."""
+    rng = np.random.default_rng(23)
+    # 150 chains of 1 .. 6 residues: blocks of 4 or 8 slots, more than 64 members in 1024 slots
+    tiny = [rng.integers(0, 36, int(L)).astype(np.uint8) for L in rng.integers(1, 7, 150)]
+    got = run_matrix(ctx, tiny, tri=True)
+    ia, ib = np.triu_indices(len(tiny))
+    assert np.array_equal(got[ia, ib], ol.mu_gapless_pairs(tiny, ia, ib))
+    # one chain per sub-ring, an odd number of sub-rings, all block remainders
+    lens = [1019, 1020, 1021, 1022, 1023, 3, 4, 5, 6, 7, 8, 130, 131, 132, 133, 509, 510, 511, 512]
+    big = [rng.integers(0, 36, int(L)).astype(np.uint8) for L in lens]
+    big[6] = big[11][40:44].copy()                       # a 4-residue chain that matches inside a longer one
+    got = run_matrix(ctx, big, tri=True)
+    ia, ib = np.triu_indices(len(big))
+    assert np.array_equal(got[ia, ib], ol.mu_gapless_pairs(big, ia, ib))
+    # every target length 1 .. 40 against a few queries (rectangular mode, small target blocks)
+    qs = [rng.integers(0, 36, int(L)).astype(np.uint8) for L in (37, 200, 64, 9)]
+    ts = [rng.integers(0, 36, int(L)).astype(np.uint8) for L in range(1, 41)]
+    ts += [q[: 1 + k].copy() for k, q in enumerate(qs * 3)] + [np.concatenate([qs[1], qs[1]])[:333]]
+    got = run_matrix(ctx, qs, ts)
+    iq, it = np.meshgrid(np.arange(len(qs)), np.arange(len(ts)), indexing="ij")
+    want = ol.mu_gapless_pairs(qs + ts, iq.ravel(), it.ravel() + len(qs)).reshape(len(qs), len(ts))
+    assert np.array_equal(got, want)
+
+
+def test_many_target_blocks_few_queries(ctx):
+    """A handful of queries against several thousand targets: the launch picks small target blocks (many work items of few
+    rings); scores against the oracle on a sample, the whole matrix against the pair-list kernel."""
+    import reseek_amd
+    rng = np.random.default_rng(29)
+    qs = [rng.integers(0, 36, int(L)).astype(np.uint8) for L in rng.integers(30, 400, 9)]
+    ts = [rng.integers(0, 36, int(L)).astype(np.uint8) for L in rng.integers(1, 300, 5000)]
+    for k in range(0, 5000, 50):
+        ts[k] = qs[k % 9][: max(1, len(qs[k % 9]) - k % 7)].copy()
+    got = run_matrix(ctx, qs, ts)
+    sel_q = rng.integers(0, 9, 3000)
+    sel_t = rng.integers(0, 5000, 3000)
+    want = ol.mu_gapless_pairs(qs + ts, sel_q, sel_t + len(qs))
+    assert np.array_equal(got[sel_q, sel_t], want)
+    q = reseek_amd.Db.from_mu_seqs(ctx, qs)
+    t = reseek_amd.Db.from_mu_seqs(ctx, ts)
+    iq, it = np.meshgrid(np.arange(9, dtype=np.uint32), np.arange(5000, dtype=np.uint32), indexing="ij")
+    sc, _, _ = ctx.mu_gapless_pairs(q, t, iq.ravel(), it.ravel(), positions=True)
+    assert np.array_equal(got.ravel(), np.minimum(sc, 65535))
+    q.close(); t.close()
+
+
 def test_rectangular_query_vs_db(ctx):
     rng = np.random.default_rng(5)
     qs = [rng.integers(0, 36, int(L)).astype(np.uint8) for L in rng.integers(20, 300, 17)]
