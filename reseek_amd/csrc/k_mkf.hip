@@ -132,7 +132,10 @@ __global__ __launch_bounds__(64 * MKF_WAVES) void k_mkf_seed(mkf_args a)
     __shared__ signed char smat[1296];                            // the integer Mu matrix: one LDS read per extension step
     for (int i = threadIdx.x; i < 1296; i += blockDim.x) smat[i] = (signed char) c_mu_int[i];
     __syncthreads();
-    const uint32_t p = a.pair_lo + blockIdx.x * MKF_WAVES + (threadIdx.x >> 6);
+    // the wave's pair: one value for its 64 lanes (readfirstlane tells the compiler so: lengths, table geometry and loop
+    // bounds derived from it stay in SGPRs)
+    const uint32_t wv = (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    const uint32_t p = a.pair_lo + blockIdx.x * MKF_WAVES + wv;
     if (p >= a.pair_hi) return;
     const int lane = threadIdx.x & 63;
     const uint32_t q = a.iq[p], t = a.it[p];
@@ -140,8 +143,8 @@ __global__ __launch_bounds__(64 * MKF_WAVES) void k_mkf_seed(mkf_args a)
     const int LQ = (int) a.q_len[q], LT = (int) a.t_len[t];
     const uint32_t slot = a.qslot[p], bits = a.tab_bits[slot], hmask = (1u << bits) - 1;
     const uint4 *tab = a.tables + a.tab_off[slot];
-    int4 *kept = skept[threadIdx.x >> 6];
-    uint32_t *queue = sseeds[threadIdx.x >> 6];
+    int4 *kept = skept[wv];
+    uint32_t *queue = sseeds[wv];
     int best = 0;
     uint32_t nk = 0, qn = 0;
     bool found = false;

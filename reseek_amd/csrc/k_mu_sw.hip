@@ -608,7 +608,7 @@ __global__ __launch_bounds__(256) void k_musw_candidates(const uint8_t *fwd, siz
                                                          uint32_t nq, float omega_fwd, int pass, uint32_t *ccnt,
                                                          const uint32_t *rowstart, uint32_t *list, int16_t *thr, float omega)
 {
-    const uint32_t q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t q = blockIdx.x * (blockDim.x >> 6) + (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));      // wave-uniform
     if (q >= nq) return;
     const int lane = threadIdx.x & 63;
     const uint32_t f0 = first[q], n = cnt[q];
@@ -671,7 +671,7 @@ __global__ __launch_bounds__(256) void k_musw_survivors(const uint8_t *fwd, size
                                                         uint32_t *pairs_q, uint32_t *pairs_t, int32_t *pairs_fwd, int32_t *pairs_rev,
                                                         uint32_t capacity, uint32_t *npairs)
 {
-    const uint32_t q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t q = blockIdx.x * (blockDim.x >> 6) + (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));      // wave-uniform
     if (q >= nq) return;
     const int lane = threadIdx.x & 63;
     const uint32_t n = ccnt[q], rs = rowstart[q];

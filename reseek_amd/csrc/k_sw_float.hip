@@ -152,7 +152,7 @@ __global__ __launch_bounds__(64 * SWF_WAVES) __attribute__((amdgpu_waves_per_eu(
     for (int i = threadIdx.x; i < SWF_TABLE_FLOATS; i += blockDim.x) tab[i] = c_swf_tables.t[i];
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const uint32_t item_id = blockIdx.x * SWF_WAVES + (threadIdx.x >> 6);
+    const uint32_t item_id = blockIdx.x * SWF_WAVES + (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));      // wave-uniform
     if (item_id >= a.nitems) return;
     const swf_item it = a.items[item_base + item_id];
     const uint32_t g = it.g;
@@ -776,9 +776,12 @@ __global__ __launch_bounds__(256) void k_lddt(const char *paths, const uint64_t 
     __shared__ uint32_t scnt[4][LDDT_LDS_COLS];
     __shared__ uint32_t sq_cols[4][128];            // queue of column pairs within R0: (ci | cj << 16), squared distances
     __shared__ float2 sq_d[4][128];
-    const uint32_t p = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    // the wave's pair: the same for its 64 lanes, which the compiler cannot see in `threadIdx.x >> 6` -- without the
+    // readfirstlane every count, loop bound and queue length below would live in VGPRs and every loop test be a v_cmp
+    const int wv = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    const uint32_t p = blockIdx.x * (blockDim.x >> 6) + (uint32_t) wv;
     if (p >= npairs) return;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
     // CalcEvalue leaves everything unset below m_MinFwdScore (dssaligner.cpp:861): no LDDT needed for those pairs
     if (score[p] < min_fwd_score || score[p] == 0.0f) {
         if (lane == 0) { lddt_out[p] = 0.0f; counts_out[4 * p] = 0; counts_out[4 * p + 1] = 0; counts_out[4 * p + 2] = 0; counts_out[4 * p + 3] = RSK_NO_POS; }
@@ -865,34 +868,33 @@ __global__ __launch_bounds__(256) void k_lddt(const char *paths, const uint64_t 
             }
             qn -= n;
         };
-        const unsigned long long lt = (1ull << lane) - 1ull;
-        // one test: column `mine` (this lane's, coordinates in p4 / p2) against column `other`; live = the lane takes part
-        auto test = [&](bool live, uint32_t mine, uint32_t other, const float4 &p4, const float2 &p2) {
-            bool hit = false;
-            float d1s = 0.0f, d2s = 0.0f;
-            if (live) {
-                const float4 q4 = sc4[wv][other];
-                const float2 q2 = sc2[wv][other];
-                // (x1-x2)^2 == (x2-x1)^2 exactly, so the reference's (lower column) - (higher column) order is immaterial.
-                // pdbchain.cpp:320-335: dx*dx + dy*dy + dz*dz, every product and sum rounded separately (-ffp-contract=off);
-                // lane-wise packed ops (v_pk_add_f32 / v_pk_mul_f32) do the A-side and the B-side distance at once
-                swq_v2f X = swq_v2f{ p4.x, p4.y } - swq_v2f{ q4.x, q4.y };
-                swq_v2f Y = swq_v2f{ p4.z, p4.w } - swq_v2f{ q4.z, q4.w };
-                swq_v2f Z = swq_v2f{ p2.x, p2.y } - swq_v2f{ q2.x, q2.y };
-                swq_v2f D = X * X;
-                D += Y * Y;
-                D += Z * Z;
-                d1s = D.x; d2s = D.y;
-                hit = !(d1s > R0sq && d2s > R0sq);
-            }
-            const unsigned long long m = __ballot(hit);
+        // one test: column `mine` (this lane's, coordinates in p4 / p2) against column `other`; `live` = the lanes that take part.
+        // Every lane computes (a lane without a column holds coordinates far outside any structure, `other` is always a
+        // staged column): the two comparisons write their lane masks straight to SGPRs, the rest of the decision is scalar
+        // (and with `live`, branch on the result, queue length), the queue slot of a hit is two v_mbcnt on the mask.
+        // (r04a: `hit` was a per-lane flag set inside `if (live)`, which the compiler turned back into a mask with two more VALU
+        // ops, and the slot was and / and / bcnt / bcnt / add: 22 -> 15 VALU instructions per test.)
+        auto test = [&](unsigned long long live, uint32_t mine, uint32_t other, const float4 &p4, const float2 &p2) {
+            const float4 q4 = sc4[wv][other];
+            const float2 q2 = sc2[wv][other];
+            // (x1-x2)^2 == (x2-x1)^2 exactly, so the reference's (lower column) - (higher column) order is immaterial.
+            // pdbchain.cpp:320-335: dx*dx + dy*dy + dz*dz, every product and sum rounded separately (-ffp-contract=off);
+            // lane-wise packed ops (v_pk_add_f32 / v_pk_mul_f32) do the A-side and the B-side distance at once
+            swq_v2f X = swq_v2f{ p4.x, p4.y } - swq_v2f{ q4.x, q4.y };
+            swq_v2f Y = swq_v2f{ p4.z, p4.w } - swq_v2f{ q4.z, q4.w };
+            swq_v2f Z = swq_v2f{ p2.x, p2.y } - swq_v2f{ q2.x, q2.y };
+            swq_v2f D = X * X;
+            D += Y * Y;
+            D += Z * Z;
+            // lddt.cpp:88: skipped when both squared distances exceed R0^2
+            const unsigned long long m = (__builtin_amdgcn_ballot_w64(!(D.x > R0sq)) | __builtin_amdgcn_ballot_w64(!(D.y > R0sq))) & live;
             if (m) {
-                if (hit) {
-                    const uint32_t slot = qn + (uint32_t) __popcll(m & lt);
+                if (__builtin_amdgcn_inverse_ballot_w64(m)) {
+                    const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, qn));
                     sq_cols[wv][slot] = mine | (other << 16);
-                    sq_d[wv][slot] = make_float2(d1s, d2s);
+                    sq_d[wv][slot] = make_float2(D.x, D.y);
                 }
-                qn += (uint32_t) __popcll(m);
+                qn += (uint32_t) __builtin_popcountll(m);
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 if (qn >= 64) drain(64);
             }
@@ -901,19 +903,21 @@ __global__ __launch_bounds__(256) void k_lddt(const char *paths, const uint64_t 
         for (uint32_t bi = 0; bi < nblk; ++bi) {
             const uint32_t base_i = bi * 64, n = min(64u, C - base_i);      // this block's columns: base_i .. base_i + n - 1
             const bool have = (uint32_t) lane < n;
+            const unsigned long long have_m = n == 64 ? ~0ull : (1ull << n) - 1ull;
             const uint32_t mine = base_i + (uint32_t) lane;
-            float4 p4 = make_float4(0, 0, 0, 0);
-            float2 p2 = make_float2(0, 0);
+            float4 p4 = make_float4(1e15f, 1e15f, 1e15f, 1e15f);             // no column: 1e30 from everything
+            float2 p2 = make_float2(1e15f, 1e15f);
             if (have) { p4 = sc4[wv][mine]; p2 = sc2[wv][mine]; }
             // pairs inside the block: partner = (lane + s) mod n; for even n the step s = n / 2 meets every pair from both ends
+            // (only its lanes < s take part)
             for (uint32_t sft = 1; 2 * sft <= n; ++sft) {
                 uint32_t o = (uint32_t) lane + sft;
                 if (o >= n) o -= n;
-                const bool live = have && !(2 * sft == n && (uint32_t) lane >= sft);
-                test(live, mine, base_i + o, p4, p2);
+                if (!have) o = 0;
+                test(2 * sft == n ? (1ull << sft) - 1ull : have_m, mine, base_i + o, p4, p2);
             }
             // pairs with the columns of the later blocks: one partner column per step, the same for every lane
-            for (uint32_t cj = base_i + 64; cj < C; ++cj) test(have, mine, cj, p4, p2);
+            for (uint32_t cj = base_i + 64; cj < C; ++cj) test(have_m, mine, cj, p4, p2);
         }
         if (qn) drain(qn);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -1058,7 +1062,7 @@ __global__ void k_path_sizes(const uint32_t *slot, const uint32_t *path_len, uin
 __global__ void k_path_pack(const uint32_t *slot, const uint32_t *path_len, const uint64_t *path_start, const char *paths,
                             const uint64_t *out_off, uint32_t npairs, char *out)
 {
-    const uint32_t p = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t p = blockIdx.x * (blockDim.x >> 6) + (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));      // wave-uniform
     if (p >= npairs) return;
     const uint32_t k = slot[p], len = path_len[k];
     const char *src = paths + path_start[k];

@@ -487,10 +487,13 @@ __global__ __launch_bounds__(64 * XDW_WAVES) void k_xdrop_wave(xd_args a)
         for (int i = threadIdx.x; i < XD_TABLE_FLOATS; i += blockDim.x) tab[i] = c_xd_tables.t[i];
         __syncthreads();
     }
-    const uint32_t e = blockIdx.x * XDW_WAVES + (threadIdx.x >> 6);
+    // the wave's extension: one value for its 64 lanes (readfirstlane tells the compiler so: counts and loop bounds derived
+    // from it stay in SGPRs, loop tests are scalar)
+    const uint32_t wv = (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    const uint32_t e = blockIdx.x * XDW_WAVES + wv;
     const uint32_t lane = threadIdx.x & 63;
     if (e >= 2 * a.nreq) return;
-    if (!xdw_extend<true, EXPLICIT>(a, tab, ring[threadIdx.x >> 6], e, lane)) xdw_extend<false, EXPLICIT>(a, tab, nullptr, e, lane);
+    if (!xdw_extend<true, EXPLICIT>(a, tab, ring[wv], e, lane)) xdw_extend<false, EXPLICIT>(a, tab, nullptr, e, lane);
 }
 
 static void xd_launch(rsk_ctx *ctx, const xd_args &xa, size_t nreq)
@@ -592,7 +595,7 @@ __global__ void k_xd_sizes(const uint32_t *path_len, uint32_t n2, uint64_t *size
 __global__ void k_xd_pack(const char *paths, const uint64_t *path_off, const uint32_t *path_start, const uint32_t *path_len, const uint64_t *out_off,
                           uint32_t n2, char *out)
 {
-    const uint32_t e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t e = blockIdx.x * (blockDim.x >> 6) + (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));      // wave-uniform
     if (e >= n2) return;
     const uint32_t len = path_len[e];
     const char *src = paths + path_off[e] + path_start[e];
@@ -928,7 +931,7 @@ struct mkfm_args {
 // MergeFwdBwd mergefwdback.cpp:6-26 + the TotalScore gate of XDropHSP (xdrophsp.cpp:111-115); one wave per pair
 __global__ __launch_bounds__(256) void k_mkf_merge(mkfm_args a)
 {
-    const uint32_t p = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t p = blockIdx.x * (blockDim.x >> 6) + (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));      // wave-uniform
     if (p >= a.npairs) return;
     const int lane = threadIdx.x & 63;
     const uint64_t mo = a.mpath_off[p];

@@ -2,7 +2,8 @@
 # Runs on the GPU box: two rocprofv3 --pmc passes (no trace options) of one tools/bench_search.py command; per-kernel
 # counter averages -> gpurun_out/prof_<tag>/pmc_summary.txt.   usage: prof_search_pmc.sh TAG qdb 256 30000 sensitive
 TAG=$1; shift
-OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
+OUT=/tmp/rsk_prof/prof_$TAG   # rocprofv3 databases stay in /tmp on the box; only the summary goes back
+KEEP=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG; mkdir -p $KEEP
 mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
 timeout 900 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT -d $OUT/pmc1 -o pmc -- python $GRAFT_REPO_ROOT/tools/bench_search.py "$@" > $OUT/pmc1.log 2>&1 < /dev/null
 timeout 900 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $OUT/pmc2 -o pmc -- python $GRAFT_REPO_ROOT/tools/bench_search.py "$@" > $OUT/pmc2.log 2>&1 < /dev/null
@@ -25,3 +26,4 @@ for name, d in sorted(acc.items(), key=lambda kv: -kv[1]["_ms"] * kv[1]["_n"]):
 PY
 } > $OUT/pmc_summary.txt 2>&1 < /dev/null
 cat $OUT/pmc_summary.txt
+cp $OUT/pmc_summary.txt $KEEP/
