@@ -353,7 +353,9 @@ __global__ __launch_bounds__(64 * SWF_WAVES) __attribute__((amdgpu_waves_per_eu(
 #define SWQ_COL_BYTES (SWQ_R * 5 * 8)             // trace of one column of a wave batch: R rows x 5 masks of 64 lanes
 #define SWQ_NW 16
 #define SWQ_NFC 132                               // 20 + 7 * 16 (feature, step letter) combinations
+#ifndef SWQ_MAX_G
 #define SWQ_MAX_G ((163840 - 256) / (SWQ_NFC * SWQ_R * 4))
+#endif
 #define SWQ_MAX_L (SWQ_MAX_G * SWQ_R)
 #define SWQ_LDS_BYTES(G) ((size_t) SWQ_NFC * (SWQ_R / 4) * (G) * 16 + 16)
 
@@ -1261,6 +1263,7 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
                     if (P == Pmin || adj < best_cost) { best_cost = adj; gs = cand; }
                 }
             }
+            if (getenv("RSK_SWQ_GS") && atoi(getenv("RSK_SWQ_GS")) > 0) gs = std::min<uint32_t>((uint32_t) atoi(getenv("RSK_SWQ_GS")), SWQ_MAX_G);      // experiments: fixed lane groups
             const uint32_t npw = 64 / gs;
             const size_t chunk = (size_t) npw * SWQ_NW * 2;
             for (size_t s = k; s < e; s += chunk) qitems[c].push_back(swq_item{ (uint32_t) s, (uint32_t) std::min(chunk, e - s), 0, gs, 0 });
