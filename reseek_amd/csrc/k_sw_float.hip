@@ -337,78 +337,81 @@ __global__ __launch_bounds__(64 * SWF_WAVES) __attribute__((amdgpu_waves_per_eu(
 // its filter survivors).  One workgroup = one group: it first expands the strip chain into a
 // "query profile" in LDS,
 //     QP[f][c][i] = feature table f, strip-chain letter of residue i, against step-chain letter c
-//     (132 (f,c) combinations x 528 B per residue: SWQ_MAX_L residues per profile; a longer strip chain is
-//     processed in segments of up to SWQ_MAX_G strips, one profile after the other, rows meeting through `bnd`),
+//     (132 (f, c) rows x 4 B per residue),
 // stored as records of R consecutive residues, so that a lane fetches the S-contributions of its
-// whole strip for one feature with R/4 ds_read_b128 and no per-cell address arithmetic
+// whole strip for one feature with ceil(R/4) ds_read_b128 and no per-cell address arithmetic
 // (the legacy kernel above spends 8 ds_read_b32 + 16 address ops per cell).  Waves claim batches
-// of floor(64/g) pairs from an LDS counter.
+// of 4 pairs from an LDS counter.
+//
+// Geometry (r04c): a pair ALWAYS takes 16 lanes, and what adapts to the chain is R, the rows a lane keeps
+// (R = 4 .. 12, a template parameter): a chain of L residues runs in P = ceil(L / 192) passes of 16 strips of
+// R = ceil(L / 16P) rows.  The lanes of a pair then sit on a 16-lane boundary, a (f, c) row of the profile is a whole
+// number of 256-byte bank rows (16 strips x 16 B per quad of residues), and the 16 lanes of every ds_read_b128 lane
+// group {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... -- which always belong to two different pairs, i.e. read two
+// unrelated rows -- have 16 different strip numbers = 16 different 16-byte bank slots: NO bank conflicts whatever the
+// letters.  (r01-r04b gave a pair ceil(L / 12) lanes of 12 rows and packed floor(64 / g) pairs into a wave: rows of
+// 1200 B at arbitrary bank offsets, 44 % of the LDS cycles were conflicts and 19 % of the wave cycles were spent waiting
+// to issue LDS instructions; measured on 181..192-residue queries, where both layouts fill all 64 lanes: 22.3 -> 19.8 ms.)
+// The LDS holds 4 quads of a row = 4 / ceil(R/4) passes (one "segment"); longer chains are processed in segments, one profile
+// after the other, rows meeting through `bnd`.
 // Trace: the 5 comparisons of a cell are v_cmp's that write their 64-lane masks to SGPR pairs, and the masks leave
 // the wave through SCALAR stores (s_store_dwordx4, two masks each): no VALU op folds bits into a word and no
 // vector store carries them (round 1 shifted them into a dword with v_addc_co, 5 extra VALU ops per cell, and
 // wrote 8 B per lane and column at a lane stride).  The trace of a wave batch is a block of [column][row][bit]
-// qwords (SWQ_COL_BYTES per column), bit `lane` of a qword = that lane's cell; k_traceback picks its lane's bit.
+// qwords (SWQ_COLB(R) per column), bit `lane` of a qword = that lane's cell; k_traceback picks its lane's bit.
 // ---------------------------------------------------------------------------------------------
-#define SWQ_R 12
-#define SWQ_COL_BYTES (SWQ_R * 5 * 8)             // trace of one column of a wave batch: R rows x 5 masks of 64 lanes
+#define SWQ_RMIN 4
+#define SWQ_RMAX 12
+#define SWQ_GS 16                                  // lanes (strips per pass) of a pair
+#define SWQ_NPW (64 / SWQ_GS)                      // pairs per wave batch
+#define SWQ_NQ(R) (((R) + 3) / 4)                  // ds_read_b128 per feature and step
+#define SWQ_NPF(R) (4 / SWQ_NQ(R))                 // passes per LDS profile
+#define SWQ_COLB(R) (((R) * 40 + 15) & ~15)        // trace of one column of a wave batch: R rows x 5 masks of 64 lanes
 #define SWQ_NW 16
 #define SWQ_NFC 132                               // 20 + 7 * 16 (feature, step letter) combinations
-#ifndef SWQ_MAX_G
-#define SWQ_MAX_G ((163840 - 256) / (SWQ_NFC * SWQ_R * 4))
-#endif
-#define SWQ_MAX_L (SWQ_MAX_G * SWQ_R)
-#define SWQ_LDS_BYTES(G) ((size_t) SWQ_NFC * (SWQ_R / 4) * (G) * 16 + 16)
+#define SWQ_LDS_BYTES ((size_t) SWQ_NFC * 4 * SWQ_GS * 16 + 16)
 
-// one workgroup item: `count` consecutive pairs (sorted order) of one group.
-// gs = strips per PASS.  A wave batch is floor(64 / gs) pairs, gs lanes each; a strip chain of more than gs strips is done in
-// several passes over the step chains -- pass k covers the strips [k * gs, (k + 1) * gs), the rows of consecutive passes meet
-// through `bnd` -- run back to back by the wave that claimed the batch.  The host picks gs per group so that the lanes are
-// full: 22 - 25 strips (253 - 300 residues) in one pass use 44 - 50 lanes of 64, in two passes of 11 - 13 strips 55 - 60.
-// An LDS profile (one "segment") holds floor(G / gs) passes.  The trace blocks, one per (pass, wave batch), are ncol columns
-// each and start at tb + tb_base: block (pass, b) is number pass * nbatch + b with nbatch = ceil(count / (64 / gs)).
-struct swq_item { uint32_t first, count, ncol, gs; uint64_t tb_base; };
+// one workgroup item: `count` consecutive pairs (sorted order) of one group, R rows per lane.
+// A wave batch is 4 pairs, 16 lanes each; pass k covers the strips [16k, 16k + 16), the rows of consecutive passes meet
+// through `bnd` -- run back to back by the wave that claimed the batch.  The trace blocks, one per (pass, wave batch), are
+// ncol columns each and start at tb + tb_base: block (pass, b) is number pass * nbatch + b with nbatch = ceil(count / 4).
+struct swq_item { uint32_t first, count, ncol, R; uint64_t tb_base; };
 
 // comparison -> 64-lane mask in an SGPR pair (lanes outside EXEC read 0)
 #define SWQ_MASK_GT(m, x, y) asm volatile("v_cmp_gt_f32_e64 %0, %1, %2" : "=s"(m) : "v"(x), "v"(y))
 #define SWQ_MASK_GE(m, x, y) asm volatile("v_cmp_ge_f32_e64 %0, %1, %2" : "=s"(m) : "v"(x), "v"(y))
 #define SWQ_MASK_0GE(m, y) asm volatile("v_cmp_ge_f32_e64 %0, 0, %1" : "=s"(m) : "v"(y))
-// two masks to trace memory (wave-uniform address, 16-byte aligned)
+// two masks / one mask to trace memory (wave-uniform address)
 #ifndef SWQ_EXPERIMENT_NO_TRACE_STORE
 #define SWQ_STORE2(m0, m1, ptr, off) \
     asm volatile("s_store_dwordx4 %0, %1, %2" :: "s"(__uint128_t(m0) | (__uint128_t(m1) << 64)), "s"(ptr), "n"(off) : "memory")
+#define SWQ_STORE1(m0, ptr, off) asm volatile("s_store_dwordx2 %0, %1, %2" :: "s"(m0), "s"(ptr), "n"(off) : "memory")
 #else   // timing experiment only (tools/exp): the masks are computed and dropped -- what the trace stores cost
 #define SWQ_STORE2(m0, m1, ptr, off) asm volatile("" :: "s"(m0), "s"(m1), "s"(ptr))
+#define SWQ_STORE1(m0, ptr, off) asm volatile("" :: "s"(m0), "s"(ptr))
 #endif
 
 typedef float swq_v2f __attribute__((ext_vector_type(2)));
 typedef float swq_v4f __attribute__((ext_vector_type(4)));
-typedef const volatile __attribute__((address_space(3))) swq_v4f *swq_ldsp;   // volatile: see the fetch in k_sw_qp
-// G = strips per LDS profile (SWQ_MAX_G: the whole LDS of a CU).  Smaller profiles with several workgroups per CU were
-// measured on the SCOP40-shaped -sensitive survivors (groups of tens of pairs) and lost to the per-pair kernel at every
-// group-size threshold (profiles/r02c_sw_float_notes.txt), so one geometry is instantiated.
-template <bool T, int G>
-__global__ __launch_bounds__(64 * SWQ_NW) void k_sw_qp(swf_args a, const swq_item *items)
+typedef const volatile __attribute__((address_space(3))) swq_v4f *swq_ldsp;   // volatile: see the fetch in swq_group
+
+template <bool T, int R>
+__device__ __forceinline__ void swq_group(const swf_args &a, const swq_item &it, float4 *qp4)
 {
-    extern __shared__ float4 qp4[];
-    float *qp = (float *) qp4;
-    constexpr int R = SWQ_R;
-    const swq_item it = items[blockIdx.x];
+    constexpr int NQ = SWQ_NQ(R), NPF = SWQ_NPF(R), G = SWQ_GS * NPF, COLB = SWQ_COLB(R);
+    constexpr uint32_t ROWB = NQ * G * 16;           // bytes of a (f, c) row: a multiple of 256
     const uint32_t strip_chain = T ? a.ib[it.first] : a.ia[it.first];
     const uint32_t LA = T ? a.b_len[strip_chain] : a.a_len[strip_chain];     // strip chain length
     const uint32_t gtot = (LA + R - 1) / R;        // strips of the whole chain
-    const uint32_t gs = it.gs;                     // strips per pass
-    const uint32_t npf = G / gs;                   // passes per LDS profile
-    const uint32_t Gs = npf * gs;                  // strips per segment (<= G)
-    const uint32_t nseg = (gtot + Gs - 1) / Gs;
-    const uint32_t npw = 64 / gs;                  // pairs per wave batch
-    const uint32_t nbatch = (it.count + npw - 1) / npw;
-    uint32_t *next_batch = (uint32_t *) (qp + (size_t) SWQ_NFC * (R / 4) * G * 4);
+    const uint32_t nseg = (gtot + G - 1) / G;
+    const uint32_t nbatch = (it.count + SWQ_NPW - 1) / SWQ_NPW;
+    uint32_t *next_batch = (uint32_t *) (qp4 + (size_t) SWQ_NFC * 4 * SWQ_GS);
     const int lane = threadIdx.x & 63;
-    const uint32_t pr = lane / gs, st = lane - pr * gs;
+    const uint32_t pr = lane / SWQ_GS, st = lane % SWQ_GS;
     const float Open = a.open, Ext = a.ext;
     for (uint32_t seg = 0; seg < nseg; ++seg) {
-    const uint32_t sbase = seg * Gs;               // first strip of this segment
-    const uint32_t g = min(Gs, gtot - sbase);
+    const uint32_t sbase = seg * G;                // first strip of this segment
+    const uint32_t g = min((uint32_t) G, gtot - sbase);
     // every wave is done with the previous profile.  The boundary rows (and the running best cells) are handed on within
     // this workgroup only -- an item runs on one CU, whose L1 is write-through and sees its own stores -- so they are plain
     // loads and stores ordered by s_waitcnt / the barrier.  (Agent-scope accesses go past the XCD's L2 on this part: measured, 31 ms instead of 23 for the 64-query
@@ -417,10 +420,10 @@ __global__ __launch_bounds__(64 * SWQ_NW) void k_sw_qp(swf_args a, const swq_ite
     {
         const uint8_t *sp = T ? (a.b_prof + a.b_off[strip_chain]) : (a.a_prof + a.a_off[strip_chain]);
         const size_t snpad = T ? a.b_npad : a.a_npad;
-        // float4 ((fc * (R/4) + quad) * G + strip) holds residues (sbase + strip) * R + quad * 4 + 0..3 of row
-        // fc: the ds_read_b128 of the lanes of a pair are 16 B apart, and the R/4 quads of a lane sit at
-        // immediate offsets (quad * G * 16 B) from one address.  One record per thread and iteration.
-        const uint32_t per_fc = (R / 4) * g, tot = SWQ_NFC * per_fc;
+        // float4 ((fc * NQ + quad) * G + strip) holds residues (sbase + strip) * R + quad * 4 + 0..3 of row fc: the
+        // ds_read_b128 of the lanes of a pair are 16 B apart, and the NQ quads of a lane sit at immediate offsets
+        // (quad * G * 16 B) from one address.  One record per thread and iteration.
+        const uint32_t per_fc = NQ * g, tot = SWQ_NFC * per_fc;
         for (uint32_t idx = threadIdx.x; idx < tot; idx += blockDim.x) {
             const uint32_t fc = idx / per_fc, rem = idx - fc * per_fc;
             const uint32_t quad = rem / g, strip = rem - quad * g;
@@ -430,54 +433,53 @@ __global__ __launch_bounds__(64 * SWQ_NW) void k_sw_qp(swf_args a, const swq_ite
             const uint32_t as = f == 0 ? 20 : 16, tof = f == 0 ? 0 : 400 + (f - 1) * 256;
             const float padv = f == 0 ? -1e30f : 0.0f;      // rows below the chain end: S = -1e30, never a maximum
             float v[4] = { padv, padv, padv, padv };
-            if (i < LA) {
-                const uint32_t l4 = *(const uint32_t *) (sp + (size_t) f * snpad + i);      // i % 4 == 0, chains padded to 16
 #pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const uint32_t letter = (l4 >> (8 * w)) & 0xFFu;
-                    if (i + w < LA) v[w] = c_swf_tables.t[tof + (T ? c * as + letter : letter * as + c)];
+            for (int w = 0; w < 4; ++w) {
+                if (quad * 4 + w < (uint32_t) R && i + w < LA) {
+                    const uint32_t letter = sp[(size_t) f * snpad + i + w];
+                    v[w] = c_swf_tables.t[tof + (T ? c * as + letter : letter * as + c)];
                 }
             }
-            qp4[(fc * (R / 4) + quad) * G + strip] = make_float4(v[0], v[1], v[2], v[3]);
+            qp4[(fc * NQ + quad) * G + strip] = make_float4(v[0], v[1], v[2], v[3]);
         }
         if (threadIdx.x == 0) *next_batch = 0;
     }
     __syncthreads();
-    const uint32_t npass = (g + gs - 1) / gs;      // passes of this segment
+    const uint32_t npass = (g + SWQ_GS - 1) / SWQ_GS;      // passes of this segment
     for (;;) {
         uint32_t b = 0;
         if (lane == 0) b = atomicAdd(next_batch, 1u);
         b = (uint32_t) __builtin_amdgcn_readfirstlane((int) b);
         if (b >= nbatch) break;
-        const uint32_t pidx = b * npw + pr;
-        const bool active = pr < npw && pidx < it.count;
+        const uint32_t pidx = b * SWQ_NPW + pr;
+        const bool active = pidx < it.count;
         const uint32_t p = it.first + (active ? pidx : 0);
         const uint32_t step_chain = T ? a.ia[p] : a.ib[p];
         const uint32_t LB = T ? a.a_len[step_chain] : a.b_len[step_chain];
         const uint16_t *bcb = T ? (a.a_cb + (size_t) a.a_off[step_chain] * 8) : (a.b_cb + (size_t) a.b_off[step_chain] * 8);
         // two rows of LB words per pair: a pass reads the row its predecessor wrote and writes the other one (reading and
         // writing one row in place puts loads and stores of the same cache lines in flight together: measured, +0.8 ms of 24)
-        long long *bnd2 = gtot > gs ? (long long *) (a.bnd + a.bnd_off[p]) : nullptr;
+        long long *bnd2 = gtot > SWQ_GS ? (long long *) (a.bnd + a.bnd_off[p]) : nullptr;
         // best cell of the pair over the passes of this segment (kept by the pair's lane st == 0)
         float pbest = 0.0f;
         uint32_t pbi = 0xFFFFFFFFu, pbj = 0xFFFFFFFFu;
         for (uint32_t pass = 0; pass < npass; ++pass) {
-        const uint32_t gl = min(gs, g - pass * gs);                       // strips of this pass
-        const uint32_t sp = pass * gs + st;                              // this lane's strip within the segment
+        const uint32_t gl = min((uint32_t) SWQ_GS, g - pass * SWQ_GS);   // strips of this pass
+        const uint32_t sp = pass * SWQ_GS + st;                          // this lane's strip within the segment
         const bool on = active && st < gl;
         const uint32_t i0 = (sbase + sp) * R;
         // this lane's float4 slot within a quad block, as an LDS byte address (and the same from feature 4's first row on)
         const uint32_t qpl_lo = (uint32_t) (uintptr_t) ((swq_ldsp) qp4 + sp);
-        const uint32_t qpl_hi = qpl_lo + (20 + 3 * 16) * ((R / 4) * G * 16);
+        const uint32_t qpl_hi = qpl_lo + (20 + 3 * 16) * ROWB;
         const bool first = seg == 0 && pass == 0;                        // the pass that holds row 0
-        const bool last = sbase + pass * gs + gl >= gtot;                // ... the last row
+        const bool last = sbase + pass * SWQ_GS + gl >= gtot;            // ... the last row
         const bool reads_bnd = !first && st == 0;
         const bool writes_bnd = !last && st == gl - 1;
         // trace block of this (pass, batch): wave-uniform address in SGPRs
         const unsigned long long *tblk;
         {
             const unsigned long long t0 = (unsigned long long) (a.tb + it.tb_base) +
-                                          (unsigned long long) ((seg * npf + pass) * nbatch + b) * it.ncol * SWQ_COL_BYTES;
+                                          (unsigned long long) ((seg * NPF + pass) * nbatch + b) * it.ncol * COLB;
             const unsigned lo = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) t0);
             const unsigned hi = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) (t0 >> 32));
             tblk = (const unsigned long long *) (((unsigned long long) hi << 32) | lo);
@@ -500,7 +502,7 @@ __global__ __launch_bounds__(64 * SWQ_NW) void k_sw_qp(swf_args a, const swq_ite
         // compiler wait for the load on the spot), and the bottom row of a step is stored one step later at the same point,
         // so that the wait at the top of a step only ever covers operations issued a whole step earlier.
         // (a pass that has nothing to read points the load at a word of the pair's own offset table)
-        const uint32_t gpass = seg * npf + pass;                        // pass index over the whole chain
+        const uint32_t gpass = seg * NPF + pass;                        // pass index over the whole chain
         long long *bnd = bnd2 ? bnd2 + (size_t) (gpass & 1) * LB : nullptr;                 // written by this pass
         const long long *bsrc = first ? (const long long *) (a.tb_off + p) : bnd2 + (size_t) ((gpass & 1) ^ 1) * LB;
         long long bnn = *bsrc;                     // boundary word of strip 0's column `col`
@@ -516,7 +518,7 @@ __global__ __launch_bounds__(64 * SWQ_NW) void k_sw_qp(swf_args a, const swq_ite
                     in_d = __builtin_bit_cast(float, (int) ((unsigned long long) bnn >> 32));
                 }
                 // everything this step fetched is consumed: request the next step's data, then store the previous step's
-                // bottom row -- all of it has the 12 rows below to complete
+                // bottom row -- all of it has the rows below to complete
                 cbn = *(const uint4 *) (bcb + (size_t) (j + 1) * 8);
                 bnn = bsrc[first ? 0u : min((uint32_t) j + 1, LB - 1)];
                 if (!last) {                       // wave-uniform
@@ -532,7 +534,6 @@ __global__ __launch_bounds__(64 * SWQ_NW) void k_sw_qp(swf_args a, const swq_ite
                     // byte address of the lane's record of row (f, letter): (letter * 4) * (row bytes / 4) + lane base, one
                     // v_mad_u32_u16 that picks its half of the packed word itself; the feature's first row is a constant the
                     // ds_read carries as its immediate (features 4..7 relative to a second base: 16-bit immediates)
-                    constexpr uint32_t ROWB = (R / 4) * G * 16;
                     const uint32_t fcb = f == 0 ? 0 : 20 + (f - 1) * 16, fcb4 = 20 + 3 * 16;
                     uint32_t ad;
                     if (f & 1) asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(ad) : "v"(cbw[f >> 1]), "s"(ROWB / 4), "v"(f < 4 ? qpl_lo : qpl_hi));
@@ -543,21 +544,25 @@ __global__ __launch_bounds__(64 * SWQ_NW) void k_sw_qp(swf_args a, const swq_ite
                 if (st != 0 || !first) Md[0] = carry_in;
                 else if (j > 0) Md[0] = SWF_MINUS_INF;
                 float carry = SWF_MINUS_INF;
-                const unsigned long long *tcol = tblk + (size_t) col * (SWQ_COL_BYTES / 8);
+                const unsigned long long *tcol = (const unsigned long long *) ((const char *) tblk + (size_t) col * COLB);
 #pragma unroll
-                for (int q = 0; q < R / 4; ++q) {
+                for (int q = 0; q < NQ; ++q) {
                     // volatile keeps each fetch one ds_read_b128 (the SLP vectoriser would split it into b64 halves)
                     swq_v4f v[8];
 #pragma unroll
                     for (int f = 0; f < 8; ++f) v[f] = rec[f][q * G];
                     swq_v2f Slo = v[0].lo, Shi = v[0].hi;              // v_pk_add_f32: two residues per add
 #pragma unroll
-                    for (int f = 1; f < 8; ++f) { Slo += v[f].lo; Shi += v[f].hi; }
+                    for (int f = 1; f < 8; ++f) {
+                        Slo += v[f].lo;
+                        if (q * 4 + 2 < R) Shi += v[f].hi;
+                    }
                     const float S4[4] = { Slo.x, Slo.y, Shi.x, Shi.y };
                     unsigned long long tm[10];                           // masks of two cells
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr) {
                         const int r = q * 4 + rr;
+                        if (r >= R) continue;
                         unsigned long long *tc = tm + 5 * (rr & 1);
                         const float m = Md[r];
                         const float d = T ? In[r] : ch;
@@ -584,6 +589,10 @@ __global__ __launch_bounds__(64 * SWQ_NW) void k_sw_qp(swf_args a, const swq_ite
                         if (rr & 1) {                        // rows r - 1 and r: 80 bytes
 #pragma unroll
                             for (int k = 0; k < 10; k += 2) SWQ_STORE2(tm[k], tm[k + 1], tcol, (r >> 1) * 80 + k * 8);
+                        } else if (r == R - 1) {             // an odd R: the last row alone, 40 bytes
+                            SWQ_STORE2(tm[0], tm[1], tcol, (r >> 1) * 80);
+                            SWQ_STORE2(tm[2], tm[3], tcol, (r >> 1) * 80 + 16);
+                            SWQ_STORE1(tm[4], tcol, (r >> 1) * 80 + 32);
                         }
                     }
                 }
@@ -635,6 +644,27 @@ __global__ __launch_bounds__(64 * SWQ_NW) void k_sw_qp(swf_args a, const swq_ite
         }
     }
     }
+}
+
+// One code object for every R: a group's item names its R and the workgroup branches (wave-uniform) to that instance, so
+// that one launch per orientation covers all the groups of a call -- a launch per R would end in nine tails of
+// one-workgroup-per-CU items.
+template <bool T>
+__global__ __launch_bounds__(64 * SWQ_NW) void k_sw_qp(swf_args a, const swq_item *items)
+{
+    extern __shared__ float4 qp4[];
+    const swq_item it = items[blockIdx.x];
+    switch (it.R) {
+    case 4: swq_group<T, 4>(a, it, qp4); break;
+    case 5: swq_group<T, 5>(a, it, qp4); break;
+    case 6: swq_group<T, 6>(a, it, qp4); break;
+    case 7: swq_group<T, 7>(a, it, qp4); break;
+    case 8: swq_group<T, 8>(a, it, qp4); break;
+    case 9: swq_group<T, 9>(a, it, qp4); break;
+    case 10: swq_group<T, 10>(a, it, qp4); break;
+    case 11: swq_group<T, 11>(a, it, qp4); break;
+    default: swq_group<T, 12>(a, it, qp4); break;
+    }
     asm volatile("s_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory");     // the trace masks sit in the scalar data cache
 }
 
@@ -668,22 +698,23 @@ __global__ void k_traceback(const uint8_t *tb, const uint64_t *tb_off, const uin
     const bool rows_are_a = cls == 0 || cls == 2;     // strips along A: the strip row is i, the wave step is j
     const uint32_t LA = a_len[ia[p]], LB = b_len[ib[p]];
     const uint8_t *T;
-    // k_sw_qp pairs (cls < 2): the trace lives in the blocks of the pair's workgroup item ([step][row][5 masks], SWQ_COL_BYTES per step)
-    uint32_t q_gs = 1, q_lane0 = 0;
-    size_t q_block = 0, q_pass_stride = 0;
+    // k_sw_qp pairs (cls < 2): the trace lives in the blocks of the pair's workgroup item ([step][row][5 masks], SWQ_COLB(R) per step)
+    uint32_t q_R = SWQ_RMAX, q_colb = SWQ_COLB(SWQ_RMAX), q_lane0 = 0;
+    size_t q_pass_stride = 0;
     // k_sw_float pairs: step-major block of the pair's wave item, T = its start + the pair's first lane; record (step, lane)
     // holds the 16 rows of the lane's strip, one byte per cell, the four rows of a dword in big-endian order
     uint32_t f_ld = 0, f_g = 1;
     float inv = 1.0f;                                 // 1 / strips per pass (per row group): quotients of small integers, exact below
     if (cls < 2) {
         const swq_item it = (cls == 0 ? qitems0 : qitems1)[qp_item[p]];
-        const uint32_t pidx = p - it.first, npw = 64 / it.gs, nbatch = (it.count + npw - 1) / npw, b = pidx / npw;
-        q_gs = it.gs;
-        q_lane0 = (pidx - b * npw) * it.gs;
-        q_block = (size_t) it.ncol * SWQ_COL_BYTES;
+        const uint32_t pidx = p - it.first, nbatch = (it.count + SWQ_NPW - 1) / SWQ_NPW, b = pidx / SWQ_NPW;
+        q_R = it.R;
+        q_colb = SWQ_COLB(q_R);
+        q_lane0 = (pidx - b * SWQ_NPW) * SWQ_GS;
+        const size_t q_block = (size_t) it.ncol * q_colb;
         q_pass_stride = (size_t) nbatch * q_block;
         T = tb + it.tb_base + (size_t) b * q_block;
-        inv = 1.0f / (float) q_gs;
+        inv = 1.0f / (float) q_R;
     } else {
         f_ld = qp_item[p];                            // steps per row group of the item
         f_g = min(max(1u, ((rows_are_a ? LA : LB) + SWF_R - 1) / SWF_R), 64u);
@@ -711,14 +742,18 @@ __global__ void k_traceback(const uint8_t *tb, const uint64_t *tb_off, const uin
         const uint32_t srow = rows_are_a ? ci : cj, step = rows_are_a ? cj : ci;
         uint32_t dm, im, sm, md, mi;                  // only the bits of the current state are meaningful
         if (cls < 2) {
-            const uint32_t strip = srow / SWQ_R, r = srow - strip * SWQ_R;
-            const uint32_t pass = (uint32_t) (((float) strip + 0.5f) * inv), st = strip - pass * q_gs;      // pass over the whole chain
+            // strip = srow / R through the reciprocal, corrected by one either way (rows per lane R = 4 .. 12 per item)
+            uint32_t strip = (uint32_t) (((float) srow + 0.5f) * inv);
+            if (strip * q_R > srow) --strip;
+            else if ((strip + 1) * q_R <= srow) ++strip;
+            const uint32_t r = srow - strip * q_R;
+            const uint32_t pass = strip / SWQ_GS, st = strip % SWQ_GS;      // pass over the whole chain
             const uint32_t lane = q_lane0 + st, t = step + st;
             const uint8_t *blk = T + (size_t) pass * q_pass_stride;
             // the cell's masks {DM, IM, SM, MD, MI}: state M needs the first three, D the fourth, I the fifth.  Both loads are
             // issued whatever the state (one wait per step), before this step's path store: the wait that follows must not
             // cover a store
-            const uint8_t *rec = blk + (size_t) t * SWQ_COL_BYTES + r * 40;
+            const uint8_t *rec = blk + (size_t) t * q_colb + r * 40;
             typedef unsigned tb_v4u __attribute__((ext_vector_type(4)));
             typedef unsigned tb_v2u __attribute__((ext_vector_type(2)));
             tb_v4u q;
@@ -1161,8 +1196,7 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
     const uint32_t min_lanes = getenv("RSK_SWQ_MIN_LANES") ? (uint32_t) atoi(getenv("RSK_SWQ_MIN_LANES")) : 4096;
     auto qp_bucket = [&](uint32_t count, uint32_t L) -> int {
         if (L == 0) return -1;
-        const uint32_t g = std::min<uint32_t>((L + SWQ_R - 1) / SWQ_R, SWQ_MAX_G);
-        return (uint64_t) count * g >= min_lanes ? 0 : -1;
+        return (uint64_t) count * SWQ_GS >= min_lanes ? 0 : -1;
     };
     auto qp_ok = [&](uint32_t count, uint32_t L) { return qp_bucket(count, L) >= 0; };
     std::vector<uint32_t> cntA(dba->n, 0), cntB;
@@ -1239,34 +1273,26 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
             const uint32_t chain = (uint32_t) ((ord[k].key >> 24) & 0xFFFFFFFFu);
             size_t e = k;
             while (e < end && (uint32_t) ((ord[e].key >> 24) & 0xFFFFFFFFu) == chain) ++e;
-            // strips per pass (swq_item::gs): the pass count P that minimises the group's wave steps.  A wave batch of
-            // floor(64 / gs) pairs runs ceil(gtot / gs) column loops of (its longest step chain + gs - 1) steps, plus a fixed
-            // cost per loop (claim, prologue, best-cell reduction, boundary fence); the group's pairs are in order of
-            // decreasing step-chain length, so the first pair of a batch has the longest.
-            const uint32_t gtot = (sdb->len[chain] + SWQ_R - 1) / SWQ_R;
-            uint32_t gs = std::min<uint32_t>(gtot, SWQ_MAX_G);
-            const double pass_step_cost = getenv("RSK_SWQ_PASS_COST") ? atof(getenv("RSK_SWQ_PASS_COST")) : 1.12;
-            if (!(getenv("RSK_SWQ_PASSES") && atoi(getenv("RSK_SWQ_PASSES")) == 0)) {
-                const uint32_t Pmin = (gtot + SWQ_MAX_G - 1) / SWQ_MAX_G;
+            // rows per lane (swq_item::R): a pair takes 16 lanes whatever its chain, a chain of L residues runs in P passes of
+            // 16 strips of R = ceil(L / 16P) rows, R <= 12.  A step of a pass costs ~38 + 20 R VALU instructions (ISA of the hot
+            // loop), a step of a chain done in several passes ~5 % more (boundary word load + store): the P of least cost,
+            // which is the smallest possible one except just above a multiple of 192 residues.
+            const uint32_t Ls = sdb->len[chain];
+            uint32_t rmax = SWQ_RMAX;
+            if (getenv("RSK_SWQ_MAXR")) rmax = std::min<uint32_t>(SWQ_RMAX, std::max<uint32_t>(SWQ_RMIN, (uint32_t) atoi(getenv("RSK_SWQ_MAXR"))));      // tests: more passes / segments
+            uint32_t R = rmax;
+            {
+                const uint32_t Pmin = std::max<uint32_t>(1, (Ls + SWQ_GS * rmax - 1) / (SWQ_GS * rmax));
                 double best_cost = 0;
-                for (uint32_t P = Pmin; P <= Pmin + 5 && P <= gtot; ++P) {
-                    const uint32_t cand = (gtot + P - 1) / P, npw_c = 64 / cand, loops = (gtot + cand - 1) / cand;
-                    uint64_t steps = 0;
-                    for (size_t q = k; q < e; q += npw_c) {
-                        const uint32_t pq = ord[q].idx;
-                        steps += (c == 0 ? dbb->len[ib[pq]] : dba->len[ia[pq]]) + cand + 10;
-                    }
-                    const double cost = (double) steps * loops;
-                    // a step of a chain done in several passes costs ~8 % more (boundary word load + store per step); measured on the
-                    // 64 x 11,211 benchmark: 1.12 is the best threshold (24.2 ms; 1.0: 27.3, 1.2: 24.7, one pass everywhere: 25.1)
-                    const double adj = cost * (loops > 1 ? pass_step_cost : 1.0);
-                    if (P == Pmin || adj < best_cost) { best_cost = adj; gs = cand; }
+                for (uint32_t P = Pmin; P <= Pmin + 2; ++P) {
+                    const uint32_t cand = std::max<uint32_t>(SWQ_RMIN, (Ls + SWQ_GS * P - 1) / (SWQ_GS * P));
+                    const uint32_t passes = ((Ls + cand - 1) / cand + SWQ_GS - 1) / SWQ_GS;
+                    const double cost = (double) passes * (38.0 + 20.0 * cand) * (passes > 1 ? 1.05 : 1.0);
+                    if (P == Pmin || cost < best_cost) { best_cost = cost; R = cand; }
                 }
             }
-            if (getenv("RSK_SWQ_GS") && atoi(getenv("RSK_SWQ_GS")) > 0) gs = std::min<uint32_t>((uint32_t) atoi(getenv("RSK_SWQ_GS")), SWQ_MAX_G);      // experiments: fixed lane groups
-            const uint32_t npw = 64 / gs;
-            const size_t chunk = (size_t) npw * SWQ_NW * 2;
-            for (size_t s = k; s < e; s += chunk) qitems[c].push_back(swq_item{ (uint32_t) s, (uint32_t) std::min(chunk, e - s), 0, gs, 0 });
+            const size_t chunk = (size_t) SWQ_NPW * SWQ_NW * 2;
+            for (size_t s = k; s < e; s += chunk) qitems[c].push_back(swq_item{ (uint32_t) s, (uint32_t) std::min(chunk, e - s), 0, R, 0 });
             k = e;
         }
         // longest-running workgroups first
@@ -1324,16 +1350,15 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
                 lmax = std::max(lmax, c == 0 ? dbb->len[ib[p]] : dba->len[ia[p]]);          // step chains
                 qp_item[it.first + k] = (uint32_t) q;
             }
-            const uint32_t gtot = (Ls + SWQ_R - 1) / SWQ_R;
-            const uint32_t npw = 64 / it.gs;
-            const uint64_t nblocks = (uint64_t) ((gtot + it.gs - 1) / it.gs) * ((it.count + npw - 1) / npw);      // passes x wave batches
+            const uint32_t gtot = (Ls + it.R - 1) / it.R;
+            const uint64_t nblocks = (uint64_t) ((gtot + SWQ_GS - 1) / SWQ_GS) * ((it.count + SWQ_NPW - 1) / SWQ_NPW);      // passes x wave batches
             // column index = step + strip-in-pass.  A block is written by ONE wave through its CU's scalar cache: blocks
-            // start on 128-byte lines and span whole lines (ncol a multiple of 4: 4 x 480 B = 15 lines), so no cache line is
-            // ever shared between the scalar caches of two CUs
-            it.ncol = (lmax + it.gs + 3) & ~3u;
+            // start on 128-byte lines and span whole lines (ncol a multiple of 8, column bytes a multiple of 16), so no cache
+            // line is ever shared between the scalar caches of two CUs
+            it.ncol = (lmax + SWQ_GS + 7) & ~7u;
             tbo = (tbo + 127) & ~(uint64_t) 127;
             it.tb_base = tbo;
-            tbo += nblocks * it.ncol * SWQ_COL_BYTES;
+            tbo += nblocks * it.ncol * SWQ_COLB(it.R);
         }
     // trace blocks of the per-pair items (swf_item): ngroups x ncol steps of 1 KB; a pair's trace offset = its item's block
     // + its first lane's record, its entry of qp_item = the item's steps per row group (k_traceback's decode)
@@ -1355,9 +1380,9 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
         bnd_off[k] = bno;
         if (c < 2) tb_off[k] = 0;                                // the item's blocks (swq_item::tb_base)
         if (c == 0) {                                           // trace: the item's blocks (above)
-            if ((LA + SWQ_R - 1) / SWQ_R > qitems[0][qp_item[k]].gs) bno += 4 * (uint64_t) LB;       // several passes: two rows of 2 words per step
+            if (LA > SWQ_GS * qitems[0][qp_item[k]].R) bno += 4 * (uint64_t) LB;       // several passes: two rows of 2 words per step
         } else if (c == 1) {
-            if ((LB + SWQ_R - 1) / SWQ_R > qitems[1][qp_item[k]].gs) bno += 4 * (uint64_t) LA;
+            if (LB > SWQ_GS * qitems[1][qp_item[k]].R) bno += 4 * (uint64_t) LA;
         }
         else if (c == 2) {
             if (LA > 64 * SWF_R) bno += 2 * (uint64_t) LB;      // multi-group pair: 2 words per step
@@ -1439,8 +1464,8 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
     {
         static std::atomic<int> attr_done[64];      // per device: the attribute belongs to the device's code object
         const int arc = rsk_once_per_device(attr_done, ctx->device, [&]() -> int {
-            RSK_HIP(hipFuncSetAttribute((const void *) k_sw_qp<false, SWQ_MAX_G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) SWQ_LDS_BYTES(SWQ_MAX_G)));
-            RSK_HIP(hipFuncSetAttribute((const void *) k_sw_qp<true, SWQ_MAX_G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) SWQ_LDS_BYTES(SWQ_MAX_G)));
+            RSK_HIP(hipFuncSetAttribute((const void *) k_sw_qp<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) SWQ_LDS_BYTES));
+            RSK_HIP(hipFuncSetAttribute((const void *) k_sw_qp<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) SWQ_LDS_BYTES));
             RSK_HIP(hipFuncSetAttribute((const void *) k_lddt_long, hipFuncAttributeMaxDynamicSharedMemorySize, LDDT_LONG_COLS * 32));
             return RSK_OK;
         });
@@ -1450,8 +1475,8 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
         if (qitems[c].empty()) continue;
         const swq_item *d_q = (const swq_item *) (D + o_q[c]);
         const dim3 grid((unsigned) qitems[c].size()), block(64 * SWQ_NW);
-        if (c == 0) hipLaunchKernelGGL((k_sw_qp<false, SWQ_MAX_G>), grid, block, SWQ_LDS_BYTES(SWQ_MAX_G), ctx->stream, a, d_q);
-        else hipLaunchKernelGGL((k_sw_qp<true, SWQ_MAX_G>), grid, block, SWQ_LDS_BYTES(SWQ_MAX_G), ctx->stream, a, d_q);
+        if (c == 0) hipLaunchKernelGGL(k_sw_qp<false>, grid, block, SWQ_LDS_BYTES, ctx->stream, a, d_q);
+        else hipLaunchKernelGGL(k_sw_qp<true>, grid, block, SWQ_LDS_BYTES, ctx->stream, a, d_q);
     }
     if (nitems_normal) {
         a.nitems = nitems_normal;

@@ -27,21 +27,22 @@ def ctx():
 
 
 @pytest.fixture(autouse=True, params=["per-pair kernel for small groups (default)", "query-profile kernel for every group",
-                                      "query-profile kernel, strip chains split into as many passes as the model allows",
-                                      "query-profile kernel, one pass per segment"])
+                                      "query-profile kernel, at most 5 rows per lane (an odd row count; passes and LDS segments for every chain above 80 / 160 residues)",
+                                      "query-profile kernel, at most 8 rows per lane (two passes per LDS segment)"])
 def kernel_choice(request, monkeypatch):
-    """rsk_align_pairs sends a group of pairs that share a chain to k_sw_qp only when the group fills ~10 waves
+    """rsk_align_pairs sends a group of pairs that share a chain to k_sw_qp only when the group fills ~4 waves
     (RSK_SWQ_MIN_LANES); every test here runs under the default and with the threshold at 1, so both float-SW kernels see
-    all the cases -- and k_sw_qp with its pass choice pushed to both ends (RSK_SWQ_PASS_COST weights a multi-pass step:
-    0.01 = split whenever that saves steps, up to six passes; RSK_SWQ_PASSES=0 = never split below a segment)."""
-    for v in ("RSK_SWQ_MIN_LANES", "RSK_SWQ_PASS_COST", "RSK_SWQ_PASSES"):
+    all the cases -- and k_sw_qp with its rows per lane capped (RSK_SWQ_MAXR: 12 by default; a chain of L residues runs in
+    ceil(L / 16R) passes of 16 strips, 4 / ceil(R / 4) passes per LDS profile), which walks the odd-row trace store, the
+    boundary rows between passes and the segment hand-over on chains of ordinary length."""
+    for v in ("RSK_SWQ_MIN_LANES", "RSK_SWQ_MAXR"):
         monkeypatch.delenv(v, raising=False)
     if request.param.startswith("query-profile"):
         monkeypatch.setenv("RSK_SWQ_MIN_LANES", "1")
-    if "as many passes" in request.param:
-        monkeypatch.setenv("RSK_SWQ_PASS_COST", "0.01")
-    if "one pass" in request.param:
-        monkeypatch.setenv("RSK_SWQ_PASSES", "0")
+    if "at most 5" in request.param:
+        monkeypatch.setenv("RSK_SWQ_MAXR", "5")
+    if "at most 8" in request.param:
+        monkeypatch.setenv("RSK_SWQ_MAXR", "8")
 
 
 def check_against_records(ctx, chains, recs, min_fwd):
