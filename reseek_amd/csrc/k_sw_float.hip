@@ -391,6 +391,19 @@ struct swq_item { uint32_t first, count, ncol, R; uint64_t tb_base; };
 #define SWQ_STORE1(m0, ptr, off) asm volatile("" :: "s"(m0), "s"(ptr))
 #endif
 
+// Best cell of a row (sw.cpp:153-158: highest score, first column): the running pair {~column, score} is kept as ONE 64-bit
+// value and updated by v_max_f64 -- positive floats order like their bit patterns, and so do positive doubles: the score
+// in the high word decides, among equal scores the larger ~column = the earlier column wins, and a score <= 0 (a negative
+// or zero double) never displaces the initial {0, +0.0}.  One instruction per cell instead of v_cmp_gt_f32 + 2
+// v_cndmask_b32 (tools/exp/ubench_f64max.hip: v_max_f64 issues at the rate of the 32-bit ops).  The operand {~column, xM}
+// must be an aligned register pair: xM = xc + S is formed directly in v127 next to ~column in v126 (two registers the
+// asm statements of a step name themselves; ~column is a per-step constant, so the allocator keeps it there).
+// The update of row r is issued at the end of row r + 1's code (volatile, like the mask comparisons it follows): by then
+// row r + 1 has read its old diagonal value, so v127 is copied straight into that register -- the one move per cell the
+// diagonal rotation needs anyway.
+#define SWQ_BEST64(acc, xm, xc, s, nj) \
+    asm volatile("v_add_f32_e32 v127, %2, %3\n\tv_max_f64 %0, %0, v[126:127]" : "+v"(acc), "={v127}"(xm) : "v"(xc), "v"(s), "{v126}"(nj))
+
 typedef float swq_v2f __attribute__((ext_vector_type(2)));
 typedef float swq_v4f __attribute__((ext_vector_type(4)));
 typedef const volatile __attribute__((address_space(3))) swq_v4f *swq_ldsp;   // volatile: see the fetch in swq_group
@@ -485,10 +498,12 @@ __device__ __forceinline__ void swq_group(const swf_args &a, const swq_item &it,
             tblk = (const unsigned long long *) (((unsigned long long) hi << 32) | lo);
         }
 
-        float Md[R], In[R], rb[R];
-        uint32_t rj[R];
+        float Md[R], In[R];
+        double rbj[R];                             // {~column, score}: see SWQ_BEST64
 #pragma unroll
-        for (int r = 0; r < R; ++r) { Md[r] = SWF_MINUS_INF; In[r] = SWF_MINUS_INF; rb[r] = 0.0f; rj[r] = 0; }
+        for (int r = 0; r < R; ++r) rbj[r] = 0.0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) { Md[r] = SWF_MINUS_INF; In[r] = SWF_MINUS_INF; }
         if (st == 0 && first) Md[0] = 0.0f;
         float hand_m = SWF_MINUS_INF, hand_d = SWF_MINUS_INF, carry_in = SWF_MINUS_INF;
         uint32_t ncol = on ? (LB + st) : 0;
@@ -543,7 +558,8 @@ __device__ __forceinline__ void swq_group(const swf_args &a, const swq_item &it,
                 float ch = (st == 0 && first) ? SWF_MINUS_INF : in_d;
                 if (st != 0 || !first) Md[0] = carry_in;
                 else if (j > 0) Md[0] = SWF_MINUS_INF;
-                float carry = SWF_MINUS_INF;
+                float xc_p = 0.0f, S_p = 0.0f;                           // the row above: its best-cell update is still to come
+                const uint32_t nj = ~(uint32_t) j;
                 const unsigned long long *tcol = (const unsigned long long *) ((const char *) tblk + (size_t) col * COLB);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
@@ -567,16 +583,12 @@ __device__ __forceinline__ void swq_group(const swf_args &a, const swq_item &it,
                         const float m = Md[r];
                         const float d = T ? In[r] : ch;
                         const float n = T ? ch : In[r];
-                        Md[r] = carry;
                         SWQ_MASK_GT(tc[0], d, m);            // TB_DM candidate (sw.cpp:127)
                         const float x1 = swq_max(m, d);
                         SWQ_MASK_GT(tc[1], n, x1);           // TB_IM (sw.cpp:135)
                         // max(m, d, n, 0) in one v_max3: it is 0 exactly when max(m, d, n) <= 0, the TB_SM test (sw.cpp:143)
                         const float xc = swq_max3_0(x1, n);
                         SWQ_MASK_0GE(tc[2], xc);
-                        const float xM = xc + S4[rr];
-                        if (xM > rb[r]) { rb[r] = xM; rj[r] = (uint32_t) j; }
-                        carry = xM;
                         const float md = m + Open;
                         const float de = d + Ext;
                         SWQ_MASK_GE(tc[3], md, de);          // TB_MD (sw.cpp:166)
@@ -586,6 +598,14 @@ __device__ __forceinline__ void swq_group(const swf_args &a, const swq_item &it,
                         const float ni = swq_max(md, ne);
                         if (T) { ch = ni; In[r] = dd; }
                         else { ch = dd; In[r] = ni; }
+                        // xM of the row above = the diagonal value of this row at the next step (and its best-cell update)
+                        if (r > 0) {
+                            float xM;
+                            SWQ_BEST64(rbj[r - 1], xM, xc_p, S_p, nj);
+                            Md[r] = xM;
+                        } else Md[0] = SWF_MINUS_INF;
+                        xc_p = xc;
+                        S_p = S4[rr];
                         if (rr & 1) {                        // rows r - 1 and r: 80 bytes
 #pragma unroll
                             for (int k = 0; k < 10; k += 2) SWQ_STORE2(tm[k], tm[k + 1], tcol, (r >> 1) * 80 + k * 8);
@@ -596,7 +616,11 @@ __device__ __forceinline__ void swq_group(const swf_args &a, const swq_item &it,
                         }
                     }
                 }
-                hand_m = carry;
+                {
+                    float xM;
+                    SWQ_BEST64(rbj[R - 1], xM, xc_p, S_p, nj);
+                    hand_m = xM;
+                }
                 hand_d = ch;
             }
             carry_in = in_m;
@@ -610,8 +634,11 @@ __device__ __forceinline__ void swq_group(const swf_args &a, const swq_item &it,
         if (on) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const uint32_t ii = T ? rj[r] : i0 + r, jj = T ? i0 + r : rj[r];
-                if (rb[r] > best || (rb[r] == best && best > 0.0f && (ii < bi || (ii == bi && jj < bj)))) { best = rb[r]; bi = ii; bj = jj; }
+                const unsigned long long w = __builtin_bit_cast(unsigned long long, rbj[r]);
+                const float rbr = __builtin_bit_cast(float, (uint32_t) (w >> 32));
+                const uint32_t rjr = ~(uint32_t) w;
+                const uint32_t ii = T ? rjr : i0 + r, jj = T ? i0 + r : rjr;
+                if (rbr > best || (rbr == best && best > 0.0f && (ii < bi || (ii == bi && jj < bj)))) { best = rbr; bi = ii; bj = jj; }
             }
         }
         for (uint32_t dlt = 1; dlt < gl; ++dlt) {
