@@ -752,7 +752,7 @@ def main():
                                    "rectangle chains[0:lo) x chains[lo:hi) + triangle of chains[lo:hi); no data-path collective, "
                                    "hit buffers gathered over RCCL"},
             "roofline": {
-                "bound": "valu", "kernel": "k_gapless_ring<8,16> (+<4,8>)",
+                "bound": "valu", "kernel": "k_gapless_ring<16,16> (+<8,16>)",
                 "achieved": k_cells_per_s * GAPLESS_LANEOPS_PER_CELL / 1e12, "peak": PEAK_VALU_LANEOPS / 1e12, "unit": "T lane-ops/s",
                 "frac": k_cells_per_s * GAPLESS_LANEOPS_PER_CELL / PEAK_VALU_LANEOPS,
                 "lane_ops_per_cell": GAPLESS_LANEOPS_PER_CELL,

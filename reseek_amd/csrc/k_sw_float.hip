@@ -357,8 +357,13 @@ __global__ __launch_bounds__(64 * SWF_WAVES) __attribute__((amdgpu_waves_per_eu(
 // Trace: the 5 comparisons of a cell are v_cmp's that write their 64-lane masks to SGPR pairs, and the masks leave
 // the wave through SCALAR stores (s_store_dwordx4, two masks each): no VALU op folds bits into a word and no
 // vector store carries them (round 1 shifted them into a dword with v_addc_co, 5 extra VALU ops per cell, and
-// wrote 8 B per lane and column at a lane stride).  The trace of a wave batch is a block of [column][row][bit]
-// qwords (SWQ_COLB(R) per column), bit `lane` of a qword = that lane's cell; k_traceback picks its lane's bit.
+// wrote 8 B per lane and column at a lane stride).  A cell's record is FOUR masks, 32 bytes: the three "into M" flags
+// {DM, IM, SM} are read by TraceBackBitSW in the order stop, I, D (sw.cpp:33-50), i.e. they encode one of four moves, so
+// two masks carry them -- {SM | IM, SM | (DM & ~IM)}, three scalar ops on the SGPR pairs -- next to MD and MI.
+// The trace of a wave batch is a block of records indexed [step - row + R - 1][row]: the cells of a lane's DIAGONAL are
+// consecutive records.  k_traceback, which walks diagonals, finds four steps in one 128-byte line and needs one 16-byte
+// load per step; with the [step][row] order of r01-r04b (40-byte records, two loads) every step was a line of its own and
+// the kernel ran at the HBM's random-line rate.  For the writer the row offsets are immediates either way.
 // ---------------------------------------------------------------------------------------------
 #define SWQ_RMIN 4
 #define SWQ_RMAX 12
@@ -366,7 +371,7 @@ __global__ __launch_bounds__(64 * SWF_WAVES) __attribute__((amdgpu_waves_per_eu(
 #define SWQ_NPW (64 / SWQ_GS)                      // pairs per wave batch
 #define SWQ_NQ(R) (((R) + 3) / 4)                  // ds_read_b128 per feature and step
 #define SWQ_NPF(R) (4 / SWQ_NQ(R))                 // passes per LDS profile
-#define SWQ_COLB(R) (((R) * 40 + 15) & ~15)        // trace of one column of a wave batch: R rows x 5 masks of 64 lanes
+#define SWQ_COLB(R) ((R) * 32)                     // trace of one (step - row) column of a wave batch: R rows x 4 masks of 64 lanes
 #define SWQ_NW 16
 #define SWQ_NFC 132                               // 20 + 7 * 16 (feature, step letter) combinations
 #define SWQ_LDS_BYTES ((size_t) SWQ_NFC * 4 * SWQ_GS * 16 + 16)
@@ -385,10 +390,8 @@ struct swq_item { uint32_t first, count, ncol, R; uint64_t tb_base; };
 #ifndef SWQ_EXPERIMENT_NO_TRACE_STORE
 #define SWQ_STORE2(m0, m1, ptr, off) \
     asm volatile("s_store_dwordx4 %0, %1, %2" :: "s"(__uint128_t(m0) | (__uint128_t(m1) << 64)), "s"(ptr), "n"(off) : "memory")
-#define SWQ_STORE1(m0, ptr, off) asm volatile("s_store_dwordx2 %0, %1, %2" :: "s"(m0), "s"(ptr), "n"(off) : "memory")
 #else   // timing experiment only (tools/exp): the masks are computed and dropped -- what the trace stores cost
 #define SWQ_STORE2(m0, m1, ptr, off) asm volatile("" :: "s"(m0), "s"(m1), "s"(ptr))
-#define SWQ_STORE1(m0, ptr, off) asm volatile("" :: "s"(m0), "s"(ptr))
 #endif
 
 // Best cell of a row (sw.cpp:153-158: highest score, first column): the running pair {~column, score} is kept as ONE 64-bit
@@ -574,12 +577,11 @@ __device__ __forceinline__ void swq_group(const swf_args &a, const swq_item &it,
                         if (q * 4 + 2 < R) Shi += v[f].hi;
                     }
                     const float S4[4] = { Slo.x, Slo.y, Shi.x, Shi.y };
-                    unsigned long long tm[10];                           // masks of two cells
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr) {
                         const int r = q * 4 + rr;
                         if (r >= R) continue;
-                        unsigned long long *tc = tm + 5 * (rr & 1);
+                        unsigned long long tc[5];
                         const float m = Md[r];
                         const float d = T ? In[r] : ch;
                         const float n = T ? ch : In[r];
@@ -606,13 +608,11 @@ __device__ __forceinline__ void swq_group(const swf_args &a, const swq_item &it,
                         } else Md[0] = SWF_MINUS_INF;
                         xc_p = xc;
                         S_p = S4[rr];
-                        if (rr & 1) {                        // rows r - 1 and r: 80 bytes
-#pragma unroll
-                            for (int k = 0; k < 10; k += 2) SWQ_STORE2(tm[k], tm[k + 1], tcol, (r >> 1) * 80 + k * 8);
-                        } else if (r == R - 1) {             // an odd R: the last row alone, 40 bytes
-                            SWQ_STORE2(tm[0], tm[1], tcol, (r >> 1) * 80);
-                            SWQ_STORE2(tm[2], tm[3], tcol, (r >> 1) * 80 + 16);
-                            SWQ_STORE1(tm[4], tcol, (r >> 1) * 80 + 32);
+                        // the record of (step, row r) sits in column step - r + R - 1 of the block: R - 1 - r columns on
+                        {
+                            const unsigned long long b1 = tc[2] | tc[1], b0 = tc[2] | (tc[0] & ~tc[1]);
+                            SWQ_STORE2(b1, b0, tcol, (R - 1 - r) * COLB + r * 32);
+                            SWQ_STORE2(tc[3], tc[4], tcol, (R - 1 - r) * COLB + r * 32 + 16);
                         }
                     }
                 }
@@ -725,7 +725,7 @@ __global__ void k_traceback(const uint8_t *tb, const uint64_t *tb_off, const uin
     const bool rows_are_a = cls == 0 || cls == 2;     // strips along A: the strip row is i, the wave step is j
     const uint32_t LA = a_len[ia[p]], LB = b_len[ib[p]];
     const uint8_t *T;
-    // k_sw_qp pairs (cls < 2): the trace lives in the blocks of the pair's workgroup item ([step][row][5 masks], SWQ_COLB(R) per step)
+    // k_sw_qp pairs (cls < 2): the trace lives in the blocks of the pair's workgroup item ([step - row + R - 1][row][4 masks], SWQ_COLB(R) per column)
     uint32_t q_R = SWQ_RMAX, q_colb = SWQ_COLB(SWQ_RMAX), q_lane0 = 0;
     size_t q_pass_stride = 0;
     // k_sw_float pairs: step-major block of the pair's wave item, T = its start + the pair's first lane; record (step, lane)
@@ -777,21 +777,19 @@ __global__ void k_traceback(const uint8_t *tb, const uint64_t *tb_off, const uin
             const uint32_t pass = strip / SWQ_GS, st = strip % SWQ_GS;      // pass over the whole chain
             const uint32_t lane = q_lane0 + st, t = step + st;
             const uint8_t *blk = T + (size_t) pass * q_pass_stride;
-            // the cell's masks {DM, IM, SM, MD, MI}: state M needs the first three, D the fourth, I the fifth.  Both loads are
-            // issued whatever the state (one wait per step), before this step's path store: the wait that follows must not
-            // cover a store
-            const uint8_t *rec = blk + (size_t) t * q_colb + r * 40;
+            // the cell's masks {SM | IM, SM | (DM & ~IM), MD, MI}: state M needs the first two, D / I the second two: one
+            // 16-byte load, issued before this step's path store (the wait that follows must not cover a store).
+            // (Measured and not kept: a walker in state M fetching the records of rows r .. r - 3 of its diagonal at once
+            // and taking the next three steps from registers -- 2.15 vs 2.02 ms per 350 k-pair batch.)
+            const uint8_t *rec = blk + (size_t) (t + q_R - 1 - r) * q_colb + r * 32;
             typedef unsigned tb_v4u __attribute__((ext_vector_type(4)));
-            typedef unsigned tb_v2u __attribute__((ext_vector_type(2)));
             tb_v4u q;
-            tb_v2u q2;
-            asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx2 %1, %3, off"
-                         : "=&v"(q), "=&v"(q2) : "v"(rec + (state == 0 ? 0 : 24)), "v"(rec + 16) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(q) : "v"(rec + (state == 0 ? 0 : 16)) : "memory");
             PATH_STORE();
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(q), "+v"(q2) :: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(q) :: "memory");
             const uint32_t b0 = (lane < 32 ? q.x >> lane : q.y >> (lane - 32)) & 1u, b1 = (lane < 32 ? q.z >> lane : q.w >> (lane - 32)) & 1u;
-            const uint32_t b2 = (lane < 32 ? q2.x >> lane : q2.y >> (lane - 32)) & 1u;
-            dm = md = b0; im = mi = b1; sm = b2;
+            // state M: b0 = stop or I, b1 = stop or D
+            md = b0; mi = b1; sm = b0 & b1; im = b0; dm = b1;
         } else {
             const uint32_t sa = srow / SWF_R, r = srow - sa * SWF_R;
             const uint32_t rg = (uint32_t) (((float) sa + 0.5f) * inv), st = sa - rg * f_g;
@@ -1382,7 +1380,7 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
             // column index = step + strip-in-pass.  A block is written by ONE wave through its CU's scalar cache: blocks
             // start on 128-byte lines and span whole lines (ncol a multiple of 8, column bytes a multiple of 16), so no cache
             // line is ever shared between the scalar caches of two CUs
-            it.ncol = (lmax + SWQ_GS + 7) & ~7u;
+            it.ncol = (lmax + SWQ_GS + it.R - 1 + 7) & ~7u;          // + the R - 1 columns of the diagonal order
             tbo = (tbo + 127) & ~(uint64_t) 127;
             it.tb_base = tbo;
             tbo += nblocks * it.ncol * SWQ_COLB(it.R);

@@ -151,19 +151,21 @@ def test_tiny_and_ragged_chains(ctx):
 
 
 def test_long_strip_chains_in_groups(ctx):
-    """Chains longer than one LDS query profile (300 residues) that have many partners: k_sw_qp runs them in
-    segments whose rows meet through HBM.  Both orientations (long chain first / second), lengths around the
-    segment boundaries, a repeat for ties."""
+    """Strip chains with many partners at the edges of k_sw_qp's geometry (16 lanes per pair, R = ceil(L / 16P) rows per lane,
+    R <= 12): 63..65 (R = 4 with idle lanes / R = 5), 97 (R = 7: an odd row count, the last quad of a lane half used),
+    191..193 (one pass of R = 12 / two passes of R = 7), 256 / 257 (two passes in one LDS profile / R = 9: a second
+    segment), 300.., 384 / 385 (two passes of R = 12 / three passes), 599, 601, 913 (passes and segments whose rows meet
+    through HBM).  Both orientations (long chain first / second), a repeat for ties."""
     import copy
     import reseek_amd
     chains = fx.read_rskdb("q100_sensitive.rskdb.gz")
     rng = np.random.default_rng(7)
     longs = []
-    for L in (300, 301, 312, 599, 601, 913):
+    for L in (63, 64, 65, 97, 191, 192, 193, 256, 257, 300, 301, 312, 384, 385, 599, 601, 913):
         c = copy.copy(chains[0])
         c.mu = rng.integers(0, 36, L).astype(np.uint8)
         c.prof = np.concatenate([rng.integers(0, 20, (1, L)), rng.integers(0, 16, (7, L))]).astype(np.uint8)
-        src = chains[len(longs) + 1].prof
+        src = chains[len(longs) % 12 + 1].prof
         reps = (L + src.shape[1] - 1) // src.shape[1]
         c.prof[:, :] = np.tile(src, (1, reps))[:, :L]      # real profile, repeated: long alignments across segments
         c.x = np.cumsum(rng.normal(0, 2.2, L)).astype(np.float32)

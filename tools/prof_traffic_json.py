@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """FETCH_SIZE / WRITE_SIZE passes of tools/prof_bench.sh -> the `roofline.traffic` record bench.py reports
-(profiles/<round>_traffic.json).  Per dispatch of the dominant kernel (k_gapless_ring<8,16>): HBM bytes = 2 x FETCH_SIZE KB
+(profiles/<round>_traffic.json).  Per dispatch of the dominant kernel (k_gapless_ring<16,16>): HBM bytes = 2 x FETCH_SIZE KB
 (gfx950 reports half of wide coalesced reads: MI355X_MICROARCH.md, HBM / rocprofv3 section) + WRITE_SIZE KB.  The record
 carries the sha256 of the kernel's source file: bench.py reports the traffic only while that file is unchanged, so a stale
 number cannot ride along silently."""
@@ -13,7 +13,7 @@ import sys
 
 root = sys.argv[1]
 repo = os.environ.get("GRAFT_REPO_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = "k_gapless_ring<8, 16>"
+KERNEL = "k_gapless_ring<16, 16>"
 SRC = "reseek_amd/csrc/k_mu_gapless.hip"
 
 
@@ -27,7 +27,7 @@ def per_dispatch(counter):
             continue
         per = {}
         for name, cn, v, did in rows:
-            if cn == counter and "k_gapless_ring" in name and "8" in name.split("k_gapless_ring")[1][:6]:
+            if cn == counter and KERNEL in name:
                 per[did] = per.get(did, 0.0) + v
         vals += list(per.values())
     return vals
