@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """k_sw_qp alone on queries of a chosen length window against all chains of the SCOP40-shaped set (experiments on the
-lane-group geometry: RSK_SWQ_GS / RSK_SWQ_PASSES / RSK_LIB variants).  usage: swq_conflict.py Lmin Lmax [nq]"""
+lane-group geometry: RSK_SWQ_MAXR / RSK_LIB variants).  usage: swq_conflict.py Lmin Lmax [nq] [t]   (t: the shared chain on the B side -> k_sw_qp<true>)"""
 import os
 import sys
 
@@ -27,6 +27,8 @@ cand = np.nonzero((li >= lmin) & (li <= lmax))[0]
 order = np.random.default_rng(4).permutation(cand)[:nq].astype(np.uint32)
 qa = np.repeat(order, n)
 qb = np.tile(np.arange(n, dtype=np.uint32), len(order))
+if len(sys.argv) > 4 and sys.argv[4] == "t":
+    qa, qb = qb, qa
 ctx.align_pairs(dbs, dbs, qa, qb, min_fwd_score=0.0, collect=False)
 v = []
 for _ in range(3):
@@ -34,5 +36,5 @@ for _ in range(3):
     v.append(ctx.last_kernel_ms())
 p_, cells, tb = ctx.align_last_work()
 ms = float(np.median(v))
-print("L %d..%d nq %d lib %s GS %s PASSES %s: %.3f ms  %.4f T cells/s" % (lmin, lmax, len(order), os.path.basename(os.path.dirname(os.environ.get("RSK_LIB", "default/"))),
-      os.environ.get("RSK_SWQ_GS"), os.environ.get("RSK_SWQ_PASSES"), ms, cells / ms * 1e3 / 1e12))
+print("L %d..%d nq %d lib %s %s MAXR %s: %.3f ms  %.4f T cells/s" % (lmin, lmax, len(order), os.path.basename(os.path.dirname(os.environ.get("RSK_LIB", "default/"))),
+      "shared chain = B" if len(sys.argv) > 4 else "shared chain = A", os.environ.get("RSK_SWQ_MAXR"), ms, cells / ms * 1e3 / 1e12))
