@@ -342,3 +342,36 @@ def test_fast_db_scanned_in_target_ranges(ctx, tmpdir, monkeypatch, ranges):
     ctx.search(q, out, "fast", db=q, columns=COLS, keeptmp=1, rsb_size=5)
     assert sorted(open(out).read().splitlines()) == ["\t".join(r) for r in fx.read_tsv("hits_q100_db_q100_fast_rsb5.tsv.gz")]
     assert open(out + ".prefilter.tmp").read() == gzip.open(os.path.join(fx.GOLDEN, "prefilter_q100_db_q100_fast_rsb5_tmp.tsv.gz")).read().decode()
+
+
+def test_malformed_rskdb_containers_are_errors(ctx, tmpdir):
+    """LoadDB reads the container in one piece and indexes the records before any chain is built: a file cut anywhere
+    (header, inside a record, inside the stored k-mers), a wrong magic, a wrong feature count and stored Mu k-mers that
+    disagree with the letters are errors of the call (an RskError with a message), never a crash or a silent short read;
+    the intact file still searches afterwards."""
+    import struct
+    import reseek_amd
+    src = unpack("q10_sensitive.rskdb.gz", tmpdir) if os.path.exists(os.path.join(fx.GOLDEN, "q10_sensitive.rskdb.gz")) else unpack("q100_sensitive.rskdb.gz", tmpdir)
+    buf = open(src, "rb").read()
+    out = os.path.join(tmpdir, "malformed.tsv")
+    L0, ll0 = struct.unpack_from("<II", buf, 16)
+    first_len = 8 + ll0 + L0 * (2 + 8) + 12 * L0 + 4
+    (nk0,) = struct.unpack_from("<I", buf, 16 + first_len)
+    cases = {
+        "header only": buf[:12],
+        "cut inside the first record": buf[:16 + first_len // 2],
+        "cut inside the first record's k-mers": buf[:16 + first_len + 4 + 2 * nk0],
+        "cut before the last byte": buf[:-1],
+        "wrong magic": b"RSKDB2\0\0" + buf[8:],
+        "wrong feature count": buf[:12] + struct.pack("<I", 7) + buf[16:],
+        "k-mers disagree": buf[:16 + first_len + 4] + struct.pack("<I", 46655 - struct.unpack_from("<I", buf, 16 + first_len + 4)[0]) + buf[16 + first_len + 8:],
+    }
+    for what, data in cases.items():
+        bad = os.path.join(tmpdir, "bad.rskdb")
+        with open(bad, "wb") as f:
+            f.write(data)
+        with pytest.raises(reseek_amd.RskError) as e:
+            ctx.search_rskdb(bad, out, "sensitive")
+        assert "LoadDB" in str(e.value), (what, str(e.value))
+    n, _ = ctx.search_rskdb(src, out, "sensitive")
+    assert n > 0
