@@ -22,6 +22,9 @@
 //     [step][lane][16] in HBM: 1 KB of consecutive bytes per step (the only HBM-heavy stream of the path: 1 B per cell).
 //   * a second kernel walks the trace (one thread per pair), a third computes LDDT over the aligned
 //     columns (one wave per pair).
+// That is the per-pair kernel (k_sw_float).  Groups of pairs that share a chain -- a query against a database -- take the
+// query-profile kernel k_sw_qp further down: 16 lanes per pair, R = 4 .. 12 rows per lane, the shared chain expanded into
+// an LDS profile whose rows are whole 256-byte bank rows, trace as four SGPR masks per cell in diagonal order.
 #include <algorithm>
 #include <atomic>
 #include <cfloat>
@@ -1290,6 +1293,8 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
     std::vector<swf_item> items;
     uint32_t nitems_normal = 0;
     // items of the query-profile kernel: a group is cut into chunks of a few wave passes per workgroup
+    uint32_t swq_rmax = SWQ_RMAX;
+    if (const char *e = getenv("RSK_SWQ_MAXR")) swq_rmax = std::min<uint32_t>(SWQ_RMAX, std::max<uint32_t>(SWQ_RMIN, (uint32_t) atoi(e)));      // tests: more passes / segments
     for (int c = 0; c < 2; ++c) {
         const rsk_db *sdb = c == 0 ? dba : dbb;
         size_t k = cl.first[c];
@@ -1303,8 +1308,7 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
             // loop), a step of a chain done in several passes ~5 % more (boundary word load + store): the P of least cost,
             // which is the smallest possible one except just above a multiple of 192 residues.
             const uint32_t Ls = sdb->len[chain];
-            uint32_t rmax = SWQ_RMAX;
-            if (getenv("RSK_SWQ_MAXR")) rmax = std::min<uint32_t>(SWQ_RMAX, std::max<uint32_t>(SWQ_RMIN, (uint32_t) atoi(getenv("RSK_SWQ_MAXR"))));      // tests: more passes / segments
+            const uint32_t rmax = swq_rmax;
             uint32_t R = rmax;
             {
                 const uint32_t Pmin = std::max<uint32_t>(1, (Ls + SWQ_GS * rmax - 1) / (SWQ_GS * rmax));
