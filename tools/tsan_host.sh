@@ -19,6 +19,7 @@ $CXX -shared -fPIC -fsanitize=thread $OBJS build/tsan/*.cpp.o -L/opt/rocm/lib -l
 $CXX -std=c++17 -O1 -g -fsanitize=thread -I reseek_amd/csrc/host tests/ref_shaped/search_main.cpp -L reseek_amd -lrsk_tsan -Wl,-rpath,$PWD/reseek_amd -Wl,-rpath,/opt/rocm/lib -pthread -o build/tsan/search_main || exit 1
 W=$(mktemp -d)
 for n in q100 palms; do gzip -dc tests/golden/$n.bca.gz > $W/$n.bca; done
+for n in q100_sensitive palms_sensitive; do gzip -dc tests/golden/$n.rskdb.gz > $W/$n.rskdb; done      # RSKDB1 containers: the loader builds the chains on the host threads
 export TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0 history_size=4 suppressions=$PWD/tools/tsan.supp"
 export RSK_BATCH_PAIRS=700 RSK_STREAM_CHAINS=9        # many alignment batches and streamed DB batches on small inputs
 : > $OUT/report.txt
@@ -34,6 +35,9 @@ run q100.bca -sensitive -devices 0,0,0 -output $W/g.tsv
 run palms.bca -sensitive -devices 0,0 -output $W/h.tsv
 run q100.bca -db palms.bca -sensitive -devices 0,0,0 -output $W/i.tsv
 run q100.bca -db q100.bca -fast -devices 0,0 -output $W/j.tsv
+# r04: the container loader (chains built in parallel) and the parallel release of a chain set
+run q100_sensitive.rskdb -sensitive -output $W/k.tsv
+run q100_sensitive.rskdb -db palms_sensitive.rskdb -sensitive -output $W/l.tsv
 wc -l $W/*.tsv >> $OUT/report.txt
 echo "ThreadSanitizer warnings: $(grep -c 'WARNING: ThreadSanitizer' $OUT/report.txt)" | tee -a $OUT/report.txt
 grep -A12 "WARNING: ThreadSanitizer" $OUT/report.txt | head -80
