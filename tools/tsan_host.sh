@@ -37,7 +37,7 @@ run q100.bca -db palms.bca -sensitive -devices 0,0,0 -output $W/i.tsv
 run q100.bca -db q100.bca -fast -devices 0,0 -output $W/j.tsv
 # r04: the container loader (chains built in parallel) and the parallel release of a chain set
 run q100_sensitive.rskdb -sensitive -output $W/k.tsv
-run q100_sensitive.rskdb -db palms_sensitive.rskdb -sensitive -output $W/l.tsv
+run palms_sensitive.rskdb -sensitive -output $W/l.tsv
 wc -l $W/*.tsv >> $OUT/report.txt
 echo "ThreadSanitizer warnings: $(grep -c 'WARNING: ThreadSanitizer' $OUT/report.txt)" | tee -a $OUT/report.txt
 grep -A12 "WARNING: ThreadSanitizer" $OUT/report.txt | head -80
