@@ -737,7 +737,7 @@ def main():
             "metric": "aligned cells/sec (SCOP40-shaped all-vs-all, gapless int Mu kernel)",
             "value": cells_per_s, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None,
-            "dtype": "f16", "data": "synthetic",
+            "dtype": "int (exact: integer scores n/2048 carried in packed f16, every sum exact on [0, 2048]; int32 rescoring at the 2048 ceiling)", "data": "synthetic",
             "chain_pairs_per_sec": total_pairs * args.steps / dt,
             "config": {"workload": "BASELINE configs[1]: SCOP40-shaped (%d chains, %d residues%s) all-vs-all "
                                    "i<=j, swgaplessint kernel only" % (n, int(nres), " per GPU" if args.weak else ""),

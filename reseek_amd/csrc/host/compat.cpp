@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <stdexcept>
@@ -58,6 +59,16 @@ rsk_ctx *DefaultCtx()
         check(rsk_ctx_create(e ? atoi(e) : 0, &h.c), "rsk_ctx_create");
     }
     return h.c;
+}
+
+std::mutex &CtxMutex(rsk_ctx *ctx)
+{
+    static std::mutex reg;
+    static std::map<rsk_ctx *, std::unique_ptr<std::mutex>> m;
+    std::lock_guard<std::mutex> g(reg);
+    std::unique_ptr<std::mutex> &p = m[ctx];
+    if (!p) p.reset(new std::mutex);
+    return *p;
 }
 
 void DSSParams::SetDSSParams(DECIDE_MODE DM)

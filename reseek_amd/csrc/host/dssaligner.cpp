@@ -346,7 +346,8 @@ void MuKmerFilter::Align(const std::vector<byte> &MuLettersT, const std::vector<
     m_ptrMuLettersT = &MuLettersT;
     SetSeedHSPs(nullptr, 0);
     if (!m_ptrMuLettersQ || m_ptrMuLettersQ->size() < 3 || MuLettersT.size() < 3) return;
-    rsk_ctx *ctx = DefaultCtx();
+    rsk_ctx *ctx = m_Ctx ? m_Ctx : DefaultCtx();       // the owning aligner's context (and device)
+    std::lock_guard<std::mutex> lock(CtxMutex(ctx));
     MuSet Q(ctx, *m_ptrMuLettersQ), T(ctx, MuLettersT);
     const uint32_t zero = 0;
     // the search's record size first; a pair that keeps more HSPs than that runs again with the large one
@@ -496,6 +497,7 @@ float DSSAligner::XDropHSP(uint Loi_in, uint Loj_in, uint Len, uint &Loi_out, ui
     if (std::min(StartA, StartB) < K / 2) { StartA += K / 2; StartB += K / 2; }
     if (StartA >= LA || StartB >= LB) return 0;                  // (the reference's extents would wrap around)
     if (!m_Ctx) m_Ctx = DefaultCtx();
+    std::lock_guard<std::mutex> lock(CtxMutex(m_Ctx));
     PairSets Sets(m_Ctx, *this);
     const uint32_t zero = 0, lo_a = StartA, lo_b = StartB;
     float ScoreFwd = 0, ScoreBwd = 0;
@@ -515,6 +517,7 @@ float DSSAligner::XDropHSP(uint Loi_in, uint Loj_in, uint Len, uint &Loi_out, ui
 void DSSAligner::AlignMKF()
 {
     ClearAlign();
+    m_MKF.m_Ctx = m_Ctx;
     m_MKF.Align(*m_MuLettersB, *m_MuKmersB);
     PostAlignMKF();
 }
@@ -548,6 +551,7 @@ void DSSAligner::PostAlignMKF()
     const size_t M = m_MKF.m_ChainHSPLois.size();
     if (M == 0) return;
     if (!m_Ctx) m_Ctx = DefaultCtx();
+    std::lock_guard<std::mutex> lock(CtxMutex(m_Ctx));
     PairSets Sets(m_Ctx, *this);
     std::vector<int32_t> lo_a(m_MKF.m_ChainHSPLois.begin(), m_MKF.m_ChainHSPLois.end()), lo_b(m_MKF.m_ChainHSPLojs.begin(), m_MKF.m_ChainHSPLojs.end()),
         len(m_MKF.m_ChainHSPLens.begin(), m_MKF.m_ChainHSPLens.end());

@@ -399,6 +399,9 @@ void DBSearcher::LoadDB(const std::string &DBFN)
     memcpy(&n, buf.data() + 8, 4);
     memcpy(&nfeat, buf.data() + 12, 4);
     if (nfeat != RSK_NFEAT) throw std::runtime_error("LoadDB: feature count mismatch");
+    // a record is at least 16 bytes (L, label length, self-rev score, k-mer count): a chain count the file cannot hold is an
+    // error of the call before anything is sized by it
+    if ((size_t) n > (buf.size() - 16) / 16) throw std::runtime_error("LoadDB: truncated " + DBFN + " (chain count exceeds the file)");
     // record: L, label length, label, residue characters[L], Mu letters[L], profile[nfeat][L], x[L], y[L], z[L] (float),
     // self-rev score, k-mer count, k-mers
     std::vector<size_t> rec((size_t) n + 1);
@@ -421,7 +424,7 @@ void DBSearcher::LoadDB(const std::string &DBFN)
     const size_t base = m_DBChains.size();
     m_DBChains.resize(base + n); m_DBProfiles.resize(base + n); m_DBMuLettersVec.resize(base + n);
     m_DBMuKmersVec.resize(base + n); m_DBSelfRevScores.resize(base + n);
-    std::atomic<bool> bad{false};
+    std::atomic<bool> bad{false}, bad_letters{false};
     rsk_parallel_for(n, 64, [&](size_t lo, size_t hi) {
         for (size_t k = lo; k < hi; ++k) {
             const char *p = buf.data() + rec[k];
@@ -434,6 +437,18 @@ void DBSearcher::LoadDB(const std::string &DBFN)
             auto *Mu = new std::vector<byte>((const byte *) p, (const byte *) p + L); p += L;
             auto *Prof = new std::vector<std::vector<byte> >(nfeat);
             for (uint32_t fi = 0; fi < nfeat; ++fi) { (*Prof)[fi].assign((const byte *) p, (const byte *) p + L); p += L; }
+            // letters index the device tables (36 x 36 Mu matrix, 20 / 16-letter feature tables): out-of-range letters are an
+            // error of the call, not an out-of-bounds read in a kernel
+            {
+                byte worst = 0;
+                for (byte c : *Mu) worst = std::max(worst, c);
+                if (worst >= 36) bad_letters = true;
+                for (uint32_t fi = 0; fi < nfeat; ++fi) {
+                    worst = 0;
+                    for (byte c : (*Prof)[fi]) worst = std::max(worst, c);
+                    if (worst >= (fi == 0 ? 20 : 16)) bad_letters = true;
+                }
+            }
             C->m_Xs.resize(L); C->m_Ys.resize(L); C->m_Zs.resize(L);
             memcpy(C->m_Xs.data(), p, 4 * (size_t) L); p += 4 * (size_t) L;
             memcpy(C->m_Ys.data(), p, 4 * (size_t) L); p += 4 * (size_t) L;
@@ -453,7 +468,16 @@ void DBSearcher::LoadDB(const std::string &DBFN)
             m_DBSelfRevScores[base + k] = m_Opts.selfrev0 ? 0.0f : selfrev;
         }
     });
-    if (bad) throw std::runtime_error("LoadDB: stored Mu k-mers disagree with the letters");
+    if (bad || bad_letters) {
+        // the call fails as a whole: the chains it appended are released again
+        for (size_t k = base; k < base + n; ++k) {
+            delete m_DBChains[k]; delete m_DBProfiles[k]; delete m_DBMuLettersVec[k]; delete m_DBMuKmersVec[k];
+        }
+        m_DBChains.resize(base); m_DBProfiles.resize(base); m_DBMuLettersVec.resize(base);
+        m_DBMuKmersVec.resize(base); m_DBSelfRevScores.resize(base);
+        throw std::runtime_error(bad_letters ? "LoadDB: " + DBFN + " holds letters outside the Mu / feature alphabets"
+                                             : "LoadDB: stored Mu k-mers disagree with the letters");
+    }
     tm.lap("read + build chains");
 }
 

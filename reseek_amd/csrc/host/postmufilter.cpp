@@ -154,6 +154,9 @@ void MuPreFilterBags(rsk_ctx *ctx, const std::vector<uint32_t> &qlen, const std:
     // ranges -> scans + bags 1.25 / 1.07 / 1.06 / 1.10 / 1.29 s (every launch ends with a tail of long targets): three.
     uint nranges = (uint) std::min<uint64_t>(3, std::max<uint64_t>(1, (uint64_t) NQ * NT / (16u << 20)));
     if (const char *e = getenv("RSK_PF_RANGES")) nranges = (uint) std::max(1, atoi(e));
+    // every (query, target) pair appears at most once: ranges of fewer than 2^31 pairs keep the 32-bit triple counter of a
+    // scan (and its result buffers, ~16 bytes per triple) in range whatever the query set and the DB
+    nranges = (uint) std::max<uint64_t>(nranges, ((uint64_t) NQ * NT >> 31) + 1);
     nranges = std::max(1u, std::min(nranges, std::max(1u, NT)));
     DeviceBuffer Count(ctx, 4, "prefilter result counter");
     std::future<void> replay;                                            // the host task of the previous range

@@ -108,6 +108,10 @@ void CloseOutputFiles();                                // output.cpp:15
 // A library needs a device context where the reference has none: DBSearcher / DSSAligner objects whose m_Ctx was never
 // set use this one (created on first use on device RSK_DEVICE, default 0; destroyed at exit).
 rsk_ctx *DefaultCtx();
+// An rsk_ctx (stream, events, allocator pool) is not thread-safe.  The reference's callers keep one DSSAligner per thread
+// (AlignBags / AlignMKF behind chainbag.cpp:44); here such aligners may share one context, so every batch-of-one call the
+// mirror classes make (MuKmerFilter::Align, DSSAligner::XDropHSP / PostAlignMKF) holds this per-context mutex.
+std::mutex &CtxMutex(rsk_ctx *ctx);
 
 // A device allocation made by the host layer itself (survivor lists, counters): on the context's device, through the
 // library's out-of-memory ladder (cached pool blocks and idle helper contexts are released before it fails), freed on
@@ -264,6 +268,7 @@ class DSSAligner;
 class MuKmerFilter {                                    // mukmerfilter.h:10
 public:
     const DSSParams *m_Params = nullptr;
+    rsk_ctx *m_Ctx = nullptr;                           // the owning DSSAligner's context (null: DefaultCtx())
     const std::vector<byte> *m_ptrMuLettersQ = nullptr;
     const std::vector<uint> *m_ptrMuKmersQ = nullptr;
     const std::vector<byte> *m_ptrMuLettersT = nullptr;

@@ -134,6 +134,14 @@ static int search_impl(rsk_ctx *ctx, const char *query_rskdb, const char *db_rsk
         o2.mode = AM_Sensitive;                  // DM_AlwaysSensitive dssparams.cpp:27-42
         DSSParams Params2;
         Params2.SetDSSParams(o2);
+        // option errors are errors of the call on every route below (one device, a device list, a named device)
+        {
+            DSSAligner Cols;
+            Cols.SetColumns(o.columns);
+            for (USERFIELD u : Cols.m_UFs)
+                if (u == UF_Undefined) { rsk_set_error("rsk_search_rskdb: invalid -columns field"); return RSK_E_INVALID; }
+        }
+        if (prefilter_path && o.hits_digest) { rsk_set_error("rsk_search: hits_digest is not available on the -fast -db path"); return RSK_E_INVALID; }
         const std::vector<int> devs = DBSearcher::ParseDeviceList(o.devices.empty() ? getenv("RSK_DEVICES") : o.devices.c_str());
         // (the several-device form streams its target shards from a .bca file; any other -db container keeps the one-device
         // two-stage path below, which takes both -- a device list must not make a call fail that works without it)
@@ -163,9 +171,6 @@ static int search_impl(rsk_ctx *ctx, const char *query_rskdb, const char *db_rsk
         if (!o.devices.empty()) DBS.m_Devices = DBSearcher::ParseDeviceList(o.devices.c_str());
         DBS.LoadDB(query_rskdb);
         DBS.Setup();
-        for (USERFIELD u : DBS.m_DA.m_UFs)
-            if (u == UF_Undefined) { rsk_set_error("rsk_search_rskdb: invalid -columns field"); return RSK_E_INVALID; }
-        if (prefilter_path && o.hits_digest) { rsk_set_error("rsk_search: hits_digest is not available on the -fast -db path"); return RSK_E_INVALID; }
         if (prefilter_path && o.shard_count > 1) {
             rsk_set_error("rsk_search: shards are not supported on the -fast -db path (the per-query top-B of the prefilter is a reduction over all targets)");
             return RSK_E_INVALID;

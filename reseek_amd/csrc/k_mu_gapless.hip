@@ -4,28 +4,31 @@
 // swfastpinopgapless.cpp:6:  x(i,j) = max(0, x(i-1,j-1)) + IntScoreMx_Mu[a_i][b_j], best = max x.
 // Because best starts at 0 and only x > 0 matters, H = max(0, H_prev + s) gives the same best.
 //
-// MI355X design ("ring" kernel; the path is VALU/LDS bound, there is no GEMM in it):
-//   * Every diagonal of a gapless DP is independent.  Several query chains are laid out, each
-//     preceded by one separator row, on a circular array ("ring") of P = 128*D row slots.  A wave
-//     holds the P running diagonal values as packed int16 pairs: lane l owns ring dwords
-//     w = 256*m + 4*l + i (m < D/4, i < 4), i.e. D VGPRs of state.
-//   * One wave walks ONE target chain; the target letter is wave-uniform (scalar loads), so the
-//     score row for that letter is read from an LDS-resident query profile with perfectly
-//     contiguous ds_read_b128 (no bank conflicts): prof[c][slot] = IntScoreMx_Mu[c][ring row].
+// MI355X design ("ring" kernel; the path is VALU/LDS bound, there is no GEMM in it) -- the r04 form, DESIGN.md 4.1:
+//   * Every diagonal of a gapless DP is independent.  Several query chains, each preceded by one separator row, are laid
+//     out on a circular array.  A ring is TWO sub-rings of 64*D slots (D = 16: 1024 each; D = 8 for the short tail): sub-ring
+//     A lives in the low halves and sub-ring B in the high halves of 64*D ring dwords, and lane l owns the D CONSECUTIVE
+//     dwords D*l .. D*l + D - 1 (D VGPRs of running diagonal values, D of per-slot bests).
+//   * One wave walks ONE target chain; the target letter is wave-uniform, so the score row of that letter comes from the
+//     LDS-resident query profile (one copy, 2048 slots of a D = 16 ring) with D/4 contiguous, conflict-free ds_read_b128;
+//     the two LDS row addresses of a pair of letters are ONE v_pk_add_f32 on the address bit patterns (denormals add like
+//     the integers they spell; the code object runs with fp32 denormals on).
 //   * Values are packed HALF floats scaled by 2^-11 (score n = n / 2048: every integer 0..2048 is exact, and so is every
-//     sum the recurrence forms).  v_pk_add_f16 ... clamp is then both the add and the max(0, .) floor (the clamp of a float
-//     op is [0, 1]); separator rows / pad letters hold -1.0 and reset a diagonal.  The best per ring slot over the two letters
-//     of a pair-step is ONE v_pk_maximum3_f16 (gfx950) => 3 packed VALU ops per 4 cells (r01-r02: packed int16 in a biased
-//     domain, add-saturate + max per letter = 4 ops per 4 cells; the packed int16 unit has no three-operand maximum).
-//     The clamp is also a CEILING at 2048: a pair whose best reads 2048 (possible from two chains of >= 512 residues on,
-//     the matrix maximum is 4: in practice self pairs of long chains) is scored again, exactly, by the wave that found it
-//     (one diagonal per lane, integers) before anything is reported.
-//   * A diagonal moves one row per target letter.  Letters are processed in pairs: the second
-//     letter of a pair reads a copy of the profile shifted by one row (no data movement); after
-//     the pair every value moves up one dword = a register rename plus ONE v_mov_b32_dpp
-//     wave_ror:1 per 4 dwords.
-//   * Per target the per-slot bests are reduced per query (in-lane, then LDS atomic max), and the
-//     uint16 scores go to out[query][target].
+//     sum the recurrence forms).  v_pk_add_f16 ... clamp is both the add and the max(0, .) floor (the clamp of a float op is
+//     [0, 1]); separator rows / pad letters hold -1.0 and reset a diagonal.  The best per ring slot over the two letters of
+//     a pair-step is ONE v_pk_maximum3_f16 (gfx950) => 0.75 packed VALU op per cell.
+//     The clamp is also a CEILING at 2048: a pair whose best reads 2048 (two chains of >= 512 residues; in practice self
+//     pairs of long chains) is scored again, exactly, in int32 by the wave that found it before anything is reported.
+//   * A diagonal moves one row per target letter.  Because the two halves of a dword belong to DIFFERENT sub-rings, that is
+//     a move by one whole dword: the add of the next letter reads its neighbour's register (no instruction), and only the
+//     dword that crosses to the next lane costs one v_mov_b32_dpp wave_ror:1 per letter (lane 63 -> lane 0 closes both
+//     sub-rings).  Per pair of letters and lane: 3*D packed add / max3 + 2 DPP + 1 address op.
+//     (r01-r04a kept CONSECUTIVE rows in the two halves of a dword -- a value then moves half a dword per letter, which took a
+//     second, row-shifted copy of the profile for the odd letters: twice the LDS per slot, half the D.)
+//   * Sub-rings are bin-packed (best fit decreasing, <= 64 members) and paired fullest first; a work item = (ring, block of
+//     <= 1024 targets claimed longest first); per target the per-slot bests are reduced per query (in-lane, then LDS atomic
+//     max); hit records {query, target, score} above a threshold are appended by the kernel, the dense uint16 matrix
+//     out[query][target] is optional.
 // A simple per-pair kernel covers chains too long for a ring and returns best-cell positions.
 #include <stdio.h>
 #include <string.h>
@@ -495,7 +498,7 @@ __global__ __launch_bounds__(1024) void k_gapless_pairs(const uint8_t *__restric
 // launchers
 // ---------------------------------------------------------------------------------------------
 template <int D, int NW>
-static int launch_ring_class(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, const uint2 *d_work, uint32_t nwork,
+static int launch_ring_class(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, const uint2 *d_work, uint32_t nwork, const uint32_t *d_claim,
                              int self_triangle, uint16_t *d_scores, size_t ldo, uint32_t tb_size, const gl_hits &hits)
 {
     if (nwork == 0) return RSK_OK;
@@ -508,7 +511,7 @@ static int launch_ring_class(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, con
     if (arc != RSK_OK) return arc;
     hipLaunchKernelGGL((k_gapless_ring<D, NW>), dim3(nwork), dim3(64 * NW), lds, ctx->stream, q->d_ring_tab, d_work,
                        q->d_ring_letters, q->d_ring_laneq, q->d_ring_qid, t->d_mu, t->d_off, t->d_len, t->n, q->d_ring_perm,
-                       self_triangle ? q->d_tri_claim : t->d_nat_claim, tb_size, self_triangle, d_scores, ldo, hits, q->d_mu, q->d_off, q->d_len);
+                       d_claim, tb_size, self_triangle, d_scores, ldo, hits, q->d_mu, q->d_off, q->d_len);
     RSK_HIP(hipGetLastError());
     return RSK_OK;
 }
@@ -525,11 +528,12 @@ static uint32_t ring_target_block(size_t nrings, uint32_t nt)
 
 // positions of every aligned block of `tb` targets ordered by decreasing target length: the waves of a workgroup claim the
 // long targets first, so the block ends without one wave still walking a long chain (LPT scheduling)
-static int build_claim_order(const rsk_db *db, const uint32_t *perm, uint32_t **d_out, uint32_t *built_tb, uint32_t tb)
+static int build_claim_order(const rsk_db *db, const uint32_t *perm, std::map<uint32_t, uint32_t *> &cache, std::mutex &m, uint32_t tb,
+                             const uint32_t **d_out)
 {
-    if (*d_out && *built_tb == tb) return RSK_OK;
-    if (*d_out) { (void) hipFree(*d_out); *d_out = nullptr; }
-    *built_tb = tb;
+    std::lock_guard<std::mutex> g(m);
+    auto it = cache.find(tb);
+    if (it != cache.end()) { *d_out = it->second; return RSK_OK; }
     std::vector<uint32_t> claim(db->n);
     for (uint32_t i = 0; i < db->n; ++i) claim[i] = i;
     for (uint32_t b = 0; b < db->n; b += tb) {
@@ -538,8 +542,11 @@ static int build_claim_order(const rsk_db *db, const uint32_t *perm, uint32_t **
             return db->len[perm ? perm[x] : x] > db->len[perm ? perm[y] : y];
         });
     }
-    { const int rc_ = rsk_db_malloc(db, nullptr, (void **) d_out, std::max<size_t>(db->n, 1) * 4); if (rc_ != RSK_OK) return rc_; }
-    RSK_HIP(hipMemcpy(*d_out, claim.data(), (size_t) db->n * 4, hipMemcpyHostToDevice));
+    uint32_t *d = nullptr;
+    { const int rc_ = rsk_db_malloc(db, nullptr, (void **) &d, std::max<size_t>(db->n, 1) * 4); if (rc_ != RSK_OK) return rc_; }
+    if (hipMemcpy(d, claim.data(), (size_t) db->n * 4, hipMemcpyHostToDevice) != hipSuccess) { (void) hipFree(d); RSK_HIP(hipErrorUnknown); }
+    cache[tb] = d;
+    *d_out = d;
     return RSK_OK;
 }
 
@@ -552,8 +559,9 @@ int rsk_launch_gapless_rings(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int
     int rc = rsk_upload_mu_tables(ctx);
     if (rc != RSK_OK) return rc;
     const uint32_t tb = ring_target_block(q->rings.size(), t->n);
-    if (self_triangle) rc = build_claim_order(q, q->h_ring_perm.data(), &const_cast<rsk_db *>(q)->d_tri_claim, &const_cast<rsk_db *>(q)->tri_claim_tb, tb);
-    else rc = build_claim_order(t, nullptr, &const_cast<rsk_db *>(t)->d_nat_claim, &const_cast<rsk_db *>(t)->nat_claim_tb, tb);
+    const uint32_t *d_claim = nullptr;
+    if (self_triangle) rc = build_claim_order(q, q->h_ring_perm.data(), const_cast<rsk_db *>(q)->tri_claims, const_cast<rsk_db *>(q)->claim_mutex, tb, &d_claim);
+    else rc = build_claim_order(t, nullptr, const_cast<rsk_db *>(t)->nat_claims, const_cast<rsk_db *>(t)->claim_mutex, tb, &d_claim);
     if (rc != RSK_OK) return rc;
     // work accounting (host side, O(rings))
     // targets in processing order: the ring permutation of the (same) chain set in self-triangle mode
@@ -650,10 +658,10 @@ int rsk_launch_gapless_rings(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int
     (void) nD4; (void) nD8;
 
     RSK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-    rc = launch_ring_class<16, 16>(ctx, q, t, (const uint2 *) q->d_work + q->work_count[0], q->work_count[1], self_triangle,
+    rc = launch_ring_class<16, 16>(ctx, q, t, (const uint2 *) q->d_work + q->work_count[0], q->work_count[1], d_claim, self_triangle,
                                   d_scores, ldo, tb, hits);
     if (rc != RSK_OK) return rc;
-    rc = launch_ring_class<8, 16>(ctx, q, t, (const uint2 *) q->d_work, q->work_count[0], self_triangle, d_scores, ldo, tb, hits);
+    rc = launch_ring_class<8, 16>(ctx, q, t, (const uint2 *) q->d_work, q->work_count[0], d_claim, self_triangle, d_scores, ldo, tb, hits);
     if (rc != RSK_OK) return rc;
     // queries too long for a ring: per-pair kernel over (long q) x targets
     if (q->long_pairs) {                               // list built with the work list (cached per target set + triangle flag)

@@ -392,9 +392,11 @@ extern "C" void rsk_db_destroy(rsk_db *db)
 {
     if (!db) return;
     void *ptrs[] = { db->d_seq, db->d_len, db->d_off, db->d_mu, db->d_prof, db->d_x, db->d_y, db->d_z, db->d_selfrev,
-                     db->d_ring_tab, db->d_ring_letters, db->d_ring_laneq, db->d_ring_qid, db->d_ring_perm, db->d_tri_claim, db->d_nat_claim, db->d_work, db->d_prof_cb, db->d_prof_ra, db->d_pf_table, db->d_pf_postings, db->d_len_perm, db->d_len_rank, db->d_long_iq, db->d_long_it };
+                     db->d_ring_tab, db->d_ring_letters, db->d_ring_laneq, db->d_ring_qid, db->d_ring_perm, db->d_work, db->d_prof_cb, db->d_prof_ra, db->d_pf_table, db->d_pf_postings, db->d_len_perm, db->d_len_rank, db->d_long_iq, db->d_long_it };
     for (void *p : ptrs)
         if (p) (void) hipFree(p);
+    for (auto &kv : db->tri_claims) (void) hipFree(kv.second);
+    for (auto &kv : db->nat_claims) (void) hipFree(kv.second);
     delete db;
 }
 

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <map>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <algorithm>
@@ -148,9 +149,12 @@ struct rsk_db {
     uint32_t *d_ring_qid = nullptr;
     uint32_t *d_ring_perm = nullptr;    // processing order of the chains in self-triangle mode (ring members, then long chains)
     std::vector<uint32_t> h_ring_perm;
-    uint32_t *d_tri_claim = nullptr;    // per tri_claim_tb-position block of ring_perm: positions by decreasing chain length
-    uint32_t *d_nat_claim = nullptr;    // same for the natural chain order (rectangular mode, this set as targets)
-    uint32_t tri_claim_tb = 0, nat_claim_tb = 0;   // block size the two orders were built for
+    // claim orders of the gapless kernel, one per target-block size `tb` the set has been used with (the block size depends
+    // on the OTHER operand of a call): per tb-position block of ring_perm (tri) / of the natural chain order (nat), the
+    // positions by decreasing chain length.  Built under claim_mutex, never freed while the set lives -- two contexts that use
+    // the set with different partners cannot free an array the other one has handed to a launch.
+    std::map<uint32_t, uint32_t *> tri_claims, nat_claims;
+    std::mutex claim_mutex;
     // gapless work list cache (valid for one target set + triangle flag)
     uint64_t work_for = 0;              // uid of the target set the list was built for
     int work_tri = -1;

@@ -365,6 +365,12 @@ def test_malformed_rskdb_containers_are_errors(ctx, tmpdir):
         "wrong magic": b"RSKDB2\0\0" + buf[8:],
         "wrong feature count": buf[:12] + struct.pack("<I", 7) + buf[16:],
         "k-mers disagree": buf[:16 + first_len + 4] + struct.pack("<I", 46655 - struct.unpack_from("<I", buf, 16 + first_len + 4)[0]) + buf[16 + first_len + 8:],
+        # a chain count the file cannot hold must fail before anything is sized by it (~34 GB vector)
+        "hostile chain count": buf[:8] + struct.pack("<I", 0xFFFFFFF0) + buf[12:],
+        # letters index device tables: a feature letter beyond its alphabet (16 in a 16-letter feature) and a Mu letter >= 36
+        "feature letter out of range": buf[:16 + 8 + ll0 + 2 * L0 + L0] + b"\x10" + buf[16 + 8 + ll0 + 2 * L0 + L0 + 1:],
+        "amino-acid feature letter out of range": buf[:16 + 8 + ll0 + 2 * L0] + b"\x14" + buf[16 + 8 + ll0 + 2 * L0 + 1:],
+        "Mu letter out of range": buf[:16 + 8 + ll0 + L0] + b"\x24" + buf[16 + 8 + ll0 + L0 + 1:],
     }
     for what, data in cases.items():
         bad = os.path.join(tmpdir, "bad.rskdb")
