@@ -242,6 +242,83 @@ def prefilter_entry(ctx, name, what, seqs, pmc, reps=2):
             "pmc": pmc.get("k_prefilter") if name.startswith("config2") else None}
 
 
+def predicted_scaling(ctx, seqs, schemes=("window",), reps=2, worlds=(2, 4, 8)):
+    """What each rank of an N-GPU run of this bench would take, measured by running every rank's launches one after the
+    other on THIS GPU (kernel ms from the library's HIP events; no collective, no host overlap): per N the per-rank ms, the
+    slowest rank, and the strong-scaling efficiency t(1) / (N x slowest rank) it predicts.  (VERDICT r04 #3a: equal cells are
+    not equal time -- the thin range of the longest targets builds one LDS profile per <= 64 targets.)"""
+    import torch
+    import reseek_amd
+    from reseek_amd import shardplan
+    n = len(seqs)
+    lens = np.array([len(s) for s in seqs], np.float64)
+    HIT_MIN, HIT_CAP = 120, 1 << 22
+    rec = torch.zeros((HIT_CAP, 3), dtype=torch.int32, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    dbs = {}
+
+    def db_of(lo, hi):
+        if (lo, hi) not in dbs:
+            dbs[(lo, hi)] = reseek_amd.Db.from_mu_seqs(ctx, seqs[lo:hi])
+        return dbs[(lo, hi)]
+
+    def launch_ms(la):
+        q_lo, q_hi, t_lo, t_hi, tri = la
+        q, t = db_of(q_lo, q_hi), db_of(t_lo, t_hi)
+        out = torch.zeros((q_hi - q_lo, t_hi - t_lo), dtype=torch.int16, device="cuda")
+        v = []
+        for _ in range(reps + 1):
+            ctx.mu_gapless_hits_dev(q, t, tri, HIT_MIN, rec.data_ptr(), HIT_CAP, cnt.data_ptr(), d_scores_ptr=out.data_ptr(), ldo=t_hi - t_lo,
+                                    q_base=q_lo, t_base=t_lo)
+            torch.cuda.synchronize()
+            v.append(ctx.last_kernel_ms())
+        del out
+        return float(np.median(v[1:]))
+
+    t1 = launch_ms((0, n, 0, n, True))
+    res = {"one_gpu_kernel_ms": t1, "method": "every rank's launches run one after the other on one GPU, kernel ms from HIP events; "
+           "efficiency = t(1) / (N x slowest rank)"}
+    if "window" in schemes:
+        # the scheme bench.py --gpus N runs: every rank keeps the whole set and takes one window of target positions
+        full = db_of(0, n)
+        out = torch.zeros((n, n), dtype=torch.int16, device="cuda")
+        r = {}
+        for N in worlds:
+            ms, cells = [], []
+            for k in range(N):
+                lo, hi = ctx.mu_gapless_shard_window(full, k, N)
+                v = []
+                for _ in range(reps + 1):
+                    ctx.mu_gapless_hits_window_dev(full, lo, hi, HIT_MIN, rec.data_ptr(), HIT_CAP, cnt.data_ptr(), d_scores_ptr=out.data_ptr(), ldo=n)
+                    torch.cuda.synchronize()
+                    v.append(ctx.last_kernel_ms())
+                ms.append(float(np.median(v[1:])))
+                cells.append(ctx.mu_gapless_last_work()[1])
+            r["n%d" % N] = {"rank_ms": [round(x, 3) for x in ms], "max_rank_ms": round(max(ms), 3), "max_over_mean_ms": round(max(ms) / (sum(ms) / N), 4),
+                            "cells_max_over_mean": round(max(cells) * N / sum(cells), 4), "efficiency": round(t1 / (N * max(ms)), 4),
+                            "launches_per_rank": [1] * N, "launch_Tcells_per_s": [[round(c / (m * 1e9), 2)] for c, m in zip(cells, ms)]}
+        res["window"] = r
+        del out
+    for scheme in schemes:
+        if scheme == "window":
+            continue
+        r = {}
+        for N in worlds:
+            p = shardplan.plan(lens, N, scheme)
+            per = [[launch_ms(la) for la in rank] for rank in p]
+            ms = [sum(x) for x in per]
+            cells = shardplan.cell_shares(lens, N, scheme)
+            r["n%d" % N] = {"rank_ms": [round(x, 3) for x in ms], "max_rank_ms": round(max(ms), 3), "max_over_mean_ms": round(max(ms) / (sum(ms) / N), 4),
+                            "cells_max_over_mean": round(max(cells) * N, 4), "efficiency": round(t1 / (N * max(ms)), 4),
+                            "launches_per_rank": [len(rank) for rank in p],
+                            "launch_Tcells_per_s": [[round(shardplan.launch_cells(lens, la) / (m * 1e9), 2) for la, m in zip(rank, x)] for rank, x in zip(p, per)]}
+        res[scheme] = r
+        for d in list(dbs.values()):
+            d.close()
+        dbs.clear()
+    return res
+
+
 def config2_mu_letters():
     """Mu letters of the seeded 11,211-chain synthetic .bca (BASELINE configs[2]'s input; host featurisation, no GPU)"""
     import reseek_amd
@@ -594,55 +671,41 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     coll_dev = torch.device("cpu") if one_device else torch.device("cuda", local)
 
-    # N > 1: ONE SCOP40-shaped set on every rank (strong scaling, BASELINE metric "SCOP40 all-vs-all, 1/2/4/8 GPUs"); rank r
-    # scores the pairs (i <= j) whose target j lies in its range [lo, hi) of the length-sorted set, ranges balanced by DP
-    # cells: a rectangular launch chains[0:lo) x chains[lo:hi) plus the triangle of chains[lo:hi).  --weak: an independent
-    # set per rank (seed + rank), as in round 1.
+    # N > 1: ONE SCOP40-shaped set on every rank (strong scaling, BASELINE metric "SCOP40 all-vs-all, 1/2/4/8 GPUs").  Every rank
+    # keeps the whole set (41 MB) and scores the pairs whose later member, in the kernel's processing order, stands in the
+    # rank's WINDOW of positions (rsk_mu_gapless_shard_window: windows of equal modelled cost; rsk_mu_gapless_hits_window_dev:
+    # one launch of the same shape as the whole triangle -- the same rings against fewer targets).  r01-r04 gave a rank a target
+    # range of the length-sorted set as a rectangle + a small triangle of its own: measured r05 (predicted_scaling), the small
+    # triangles ran at 4-37 T cells/s against 41-44 and the rank of the longest chains took 1.29 x its share.  --weak: an
+    # independent set per rank (seed + rank), as in round 1.
     seqs = synth_mu_chains(0x5EED5EEC + (rank if args.weak else 0), args.chains or None)
     n = len(seqs)
     lens = np.array([len(s) for s in seqs], np.float64)
-    if world > 1 and not args.weak:
-        cum = np.concatenate([[0.0], np.cumsum(lens * np.cumsum(lens))])       # cells of the pairs (i <= j) up to target j
-        bounds = [int(np.searchsorted(cum, cum[-1] * r / world, side="left")) for r in range(world)] + [n]
-        lo, hi = bounds[rank], max(bounds[rank], bounds[rank + 1])
-    else:
-        lo, hi = 0, n
-    nb = hi - lo
-    # the shares of the DP cells the same cut gives every rank at N = 2 / 4 / 8 (an imbalance is visible without a profiler)
-    cumc = np.concatenate([[0.0], np.cumsum(lens * np.cumsum(lens))])
-    sharding_cells = {}
-    for N in (2, 4, 8):
-        bd = [int(np.searchsorted(cumc, cumc[-1] * r / N, side="left")) for r in range(N)] + [n]
-        share = [(cumc[bd[r + 1]] - cumc[bd[r]]) / cumc[-1] for r in range(N)]
-        sharding_cells["n%d" % N] = {"cell_share_per_rank": [round(x, 5) for x in share], "max_over_mean": round(max(share) * N, 4),
-                                     "target_ranges": [[bd[r], bd[r + 1]] for r in range(N)]}
+    windowed = world > 1 and not args.weak
     stream = torch.cuda.current_stream()
     ctx = reseek_amd.Ctx(local, stream=stream.cuda_stream)
-    db = reseek_amd.Db.from_mu_seqs(ctx, seqs[lo:hi]) if nb else None          # inputs resident in HBM before the timed region
-    dbq = reseek_amd.Db.from_mu_seqs(ctx, seqs[:lo]) if lo and nb else None
+    db = reseek_amd.Db.from_mu_seqs(ctx, seqs)                                  # inputs resident in HBM before the timed region
+    win = ctx.mu_gapless_shard_window(db, rank, world) if windowed else (0, n)
+    windows = [list(ctx.mu_gapless_shard_window(db, r, world)) for r in range(world)] if windowed else [[0, n]]
     if args.live_only:
         print(json.dumps({"roofline_live": live_kernels(ctx, seqs, db, reps=1)}))
         return
     if args.configs_only:
         print(json.dumps({"configs": config_shares(tuple(args.configs_only.split(",")))}))
         return
-    out = torch.zeros((max(nb, 1), max(nb, 1)), dtype=torch.int16, device="cuda")
-    outq = torch.zeros((max(lo, 1), max(nb, 1)), dtype=torch.int16, device="cuda") if dbq is not None else None
+    out = torch.zeros((n, n), dtype=torch.int16, device="cuda")               # the dense matrix of the whole set; a rank writes its pairs' cells
     summary = torch.zeros(2, dtype=torch.int64, device="cuda")
     # what a search keeps of the pair space: the kernel itself appends {query, target, score} (indices of the whole set)
     # for the pairs scoring >= HIT_MIN; the dense uint16 matrix is written as well (it is the contract's output)
     HIT_MIN, HIT_CAP = 120, 1 << 22
     rec = torch.zeros((HIT_CAP, 3), dtype=torch.int32, device="cuda")
-    recq = torch.zeros((HIT_CAP, 3), dtype=torch.int32, device="cuda") if dbq is not None else None
     cnt = torch.zeros(2, dtype=torch.int32, device="cuda")
 
     def step():
-        if dbq is not None:
-            ctx.mu_gapless_hits_dev(dbq, db, False, HIT_MIN, recq.data_ptr(), HIT_CAP, cnt[1:].data_ptr(), d_scores_ptr=outq.data_ptr(), ldo=nb,
-                                    q_base=0, t_base=lo)
-        if db is not None:
-            ctx.mu_gapless_hits_dev(db, db, True, HIT_MIN, rec.data_ptr(), HIT_CAP, cnt.data_ptr(), d_scores_ptr=out.data_ptr(), ldo=nb,
-                                    q_base=lo, t_base=lo)
+        if windowed:
+            ctx.mu_gapless_hits_window_dev(db, win[0], win[1], HIT_MIN, rec.data_ptr(), HIT_CAP, cnt.data_ptr(), d_scores_ptr=out.data_ptr(), ldo=n)
+        else:
+            ctx.mu_gapless_hits_dev(db, db, True, HIT_MIN, rec.data_ptr(), HIT_CAP, cnt.data_ptr(), d_scores_ptr=out.data_ptr(), ldo=n)
 
     def barrier():
         if dist is not None:
@@ -661,9 +724,7 @@ def main():
         from reseek_amd import dist as rdist
         torch.cuda.synchronize()
         c = cnt.cpu()
-        rows = rec[:min(int(c[0]), HIT_CAP)] if db is not None else rec[:0]
-        if recq is not None:
-            rows = torch.cat([rows, recq[:min(int(c[1]), HIT_CAP)]], dim=0)
+        rows = rec[:min(int(c[0]), HIT_CAP)]
         if one_device:
             gathered = rdist.gather_rows(rows.cpu().numpy(), dst=0, device=coll_dev, all_ranks=True)
         else:
@@ -672,26 +733,16 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     # per-launch kernel time (the library's HIP events on the launch stream) and work of this rank's launches, untimed pass
-    kernel_ms, pairs, cells, slots = 0.0, 0, 0, 0
-    if dbq is not None:
-        ctx.mu_gapless_hits_dev(dbq, db, False, HIT_MIN, recq.data_ptr(), HIT_CAP, cnt[1:].data_ptr(), d_scores_ptr=outq.data_ptr(), ldo=nb,
-                                q_base=0, t_base=lo)
-        torch.cuda.synchronize()
-        kernel_ms += ctx.last_kernel_ms()
-        w = ctx.mu_gapless_last_work()
-        pairs, cells, slots = pairs + w[0], cells + w[1], slots + w[2]
-    if db is not None:
-        ctx.mu_gapless_hits_dev(db, db, True, HIT_MIN, rec.data_ptr(), HIT_CAP, cnt.data_ptr(), d_scores_ptr=out.data_ptr(), ldo=nb,
-                                q_base=lo, t_base=lo)
-        torch.cuda.synchronize()
-        kernel_ms += ctx.last_kernel_ms()
-        w = ctx.mu_gapless_last_work()
-        pairs, cells, slots = pairs + w[0], cells + w[1], slots + w[2]
+    step()
+    torch.cuda.synchronize()
+    kernel_ms = ctx.last_kernel_ms()
+    pairs, cells, slots = ctx.mu_gapless_last_work()
+    hits_rank = int(cnt[0].item())
 
     # the same pass without the dense matrix (hit records only: what a search needs), untimed, for the record
     kernel_ms_hits_only = None
-    if db is not None and dbq is None:
-        ctx.mu_gapless_hits_dev(db, db, True, HIT_MIN, rec.data_ptr(), HIT_CAP, cnt.data_ptr(), q_base=lo, t_base=lo)
+    if not windowed:
+        ctx.mu_gapless_hits_dev(db, db, True, HIT_MIN, rec.data_ptr(), HIT_CAP, cnt.data_ptr())
         torch.cuda.synchronize()
         kernel_ms_hits_only = ctx.last_kernel_ms()
 
@@ -702,6 +753,20 @@ def main():
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     dt = float(tmax.item())
     total_cells, total_pairs = float(tot[0].item()), float(tot[1].item())
+    # N > 1: the gathered hit records must be the records of the whole triangle -- every pair in exactly one rank's window
+    # (VERDICT r04 #3c).  Rank 0 scores the whole triangle once more, untimed, and compares the counts; the per-rank counts
+    # must add up to the gathered total as well.
+    gather_check = None
+    if dist is not None and windowed:
+        hsum = torch.tensor([float(hits_rank)], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(hsum, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            ctx.mu_gapless_hits_dev(db, db, True, HIT_MIN, rec.data_ptr(), HIT_CAP, cnt.data_ptr())
+            torch.cuda.synchronize()
+            one_gpu_hits = int(cnt[0].item())
+            gather_check = {"gathered_all_ranks": int(summary[0].item()), "sum_of_rank_counts": int(hsum.item()), "one_gpu_hit_records": one_gpu_hits}
+            assert gather_check["gathered_all_ranks"] == one_gpu_hits == gather_check["sum_of_rank_counts"], \
+                "sharded hit records differ from the one-GPU triangle: %s" % gather_check
     search_n = None
     if dist is not None and not args.no_search and not args.weak:
         search_n = search_sharded_leg(ctx, seqs, rank, world, dist, coll_dev)
@@ -711,9 +776,8 @@ def main():
         k_cells_per_s = cells / (kernel_ms * 1e-3)
         nres = float(sum(len(s) for s in seqs))
         # algorithmic HBM bytes per launch: (LA + LB + 8) per pair, score-only
-        blk = lens[lo:hi]
-        alg_bytes = float((blk * (nb - np.arange(nb))).sum() + np.cumsum(blk[::-1])[::-1].sum() + 8.0 * pairs +
-                          (lens[:lo].sum() * nb + blk.sum() * lo))       # triangle of the block + rectangle above it
+        npairs_all = n * (n + 1) / 2.0
+        alg_bytes = float(lens.sum() * (n + 1) + 8.0 * npairs_all) * (pairs / npairs_all)      # sum over the pairs i <= j of LA + LB + 8; a window: its share of the pairs
         # HBM traffic per launch: rocprofv3 PMC counters of this same command (tools/prof_bench.sh -> tools/prof_traffic_json.py),
         # committed under profiles/ together with the sha256 of the kernel's source file: reported only while that file is
         # unchanged and the workload is the one that was profiled -- otherwise null, with the reason
@@ -742,15 +806,17 @@ def main():
             "config": {"workload": "BASELINE configs[1]: SCOP40-shaped (%d chains, %d residues%s) all-vs-all "
                                    "i<=j, swgaplessint kernel only" % (n, int(nres), " per GPU" if args.weak else ""),
                        "pairs_total": int(total_pairs), "cells_total": total_cells, "pairs_rank0": pairs, "cells_rank0": cells,
-                       "hit_records": {"min_score": HIT_MIN, "rank0_per_step": int(cnt.sum().item()),
+                       "hit_records": {"min_score": HIT_MIN, "rank0_per_step": hits_rank,
                                        "gathered_all_ranks": int(summary[0].item()) if dist is not None else None,
-                                       "note": "appended by the kernel (rsk_mu_gapless_hits_dev) next to the dense uint16 matrix"},
-                       "sharding_cells": sharding_cells,
+                                       "gather_check": gather_check,
+                                       "note": "appended by the kernel (rsk_mu_gapless_hits_dev / _window_dev) next to the dense uint16 matrix"},
+                       "windows": windows,
                        "collective_backend": (dist.get_backend() if dist is not None else None),
+                       "collective_world": (dist.get_world_size() if dist is not None else None),
                        "sharding": "one independent set per GPU (--weak)" if args.weak else
-                                   "one set; rank r takes the targets [lo, hi) of the triangle, ranges balanced by DP cells: "
-                                   "rectangle chains[0:lo) x chains[lo:hi) + triangle of chains[lo:hi); no data-path collective, "
-                                   "hit buffers gathered over RCCL"},
+                                   "one set on every rank; rank r scores the pairs whose later member (kernel processing order) stands in its "
+                                   "window of positions, windows of equal modelled cost (rsk_mu_gapless_shard_window), one launch per "
+                                   "rank and step (rsk_mu_gapless_hits_window_dev); no data-path collective, hit buffers gathered over RCCL"},
             "roofline": {
                 "bound": "valu", "kernel": "k_gapless_ring<16,16> (+<8,16>)",
                 "achieved": k_cells_per_s * GAPLESS_LANEOPS_PER_CELL / 1e12, "peak": PEAK_VALU_LANEOPS / 1e12, "unit": "T lane-ops/s",
@@ -775,6 +841,11 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(seqs)
+        if world == 1 and not args.chains:
+            try:
+                res["predicted_scaling"] = predicted_scaling(ctx, seqs)
+            except Exception as e:  # noqa: BLE001 -- the kernel metric above stands on its own
+                sys.stderr.write("bench: predicted-scaling leg failed: %s\n" % e)
         if not args.no_live and world == 1 and not args.chains:
             try:
                 del out

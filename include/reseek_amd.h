@@ -105,6 +105,18 @@ int rsk_mu_gapless_matrix_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, in
 int rsk_mu_gapless_hits_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int self_triangle, uint16_t *d_scores, size_t ldo,
                             uint32_t min_score, uint32_t q_base, uint32_t t_base, uint32_t *d_records, uint32_t capacity,
                             uint32_t *d_count);
+/* One rank's share of the self-search triangle (multi-GPU; SURVEY 8e -- the reference deals the pairs of RunSelf to threads
+ * through one locked counter, runself.cpp:72-99; here a rank's share is fixed up front).  Every rank keeps the WHOLE set.
+ * The set is processed in a fixed order (ring members first, chains too long for a ring last); a pair belongs to the rank
+ * whose window of positions [pos_lo, pos_hi) holds the pair's later member.  rsk_mu_gapless_shard_window cuts the positions
+ * into shard_count windows of equal modelled cost (the DP slots the kernel issues for them) -- host arithmetic, the same
+ * result on every rank; rsk_mu_gapless_hits_window_dev is rsk_mu_gapless_hits_dev(db, db, self_triangle = 1) restricted
+ * to a window: ONE launch of the same shape as the whole triangle (the same rings against fewer targets).  The windows of
+ * all shards score every unordered pair exactly once; records are {base + min, base + max, score}, the dense matrix (optional)
+ * is the n x n matrix of the whole set, of which a rank writes its pairs' cells [min][max]. */
+int rsk_mu_gapless_shard_window(const rsk_db *db, uint32_t shard_index, uint32_t shard_count, uint32_t *pos_lo, uint32_t *pos_hi);
+int rsk_mu_gapless_hits_window_dev(rsk_ctx *ctx, const rsk_db *db, uint32_t pos_lo, uint32_t pos_hi, uint16_t *d_scores, size_t ldo,
+                                   uint32_t min_score, uint32_t base, uint32_t *d_records, uint32_t capacity, uint32_t *d_count);
 /* Pair-list form with the position of the first strict maximum in row-major order (Besti/Bestj of
  * SWFastGapless_Int; RSK_NO_POS when the score is 0).  besti/bestj may be NULL.  Synchronous. */
 int rsk_mu_gapless_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, const uint32_t *iq,

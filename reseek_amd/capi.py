@@ -38,6 +38,9 @@ SIGNATURES = {
     "rsk_mu_gapless_matrix_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
     "rsk_mu_gapless_hits_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
                                           C.c_void_p, C.c_uint32, C.c_void_p]),
+    "rsk_mu_gapless_shard_window": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "rsk_mu_gapless_hits_window_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32,
+                                                 C.c_void_p, C.c_uint32, C.c_void_p]),
     "rsk_mu_gapless_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, u32p, u32p, C.c_size_t, i32p, u32p, u32p]),
     "rsk_mu_gapless_last_work": (C.c_int, [C.c_void_p, u64p, u64p, u64p]),
     "rsk_mu_sw_matrix_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
@@ -217,6 +220,16 @@ class Ctx:
         matrix is optional (d_scores_ptr = 0: not written)."""
         _check(lib().rsk_mu_gapless_hits_dev(self.h, q.h, t.h, int(self_triangle), C.c_void_p(d_scores_ptr) if d_scores_ptr else None, ldo,
                                              int(min_score), int(q_base), int(t_base), C.c_void_p(rec_ptr), int(capacity), C.c_void_p(count_ptr)))
+
+    def mu_gapless_shard_window(self, db, shard_index, shard_count):
+        lo, hi = C.c_uint32(), C.c_uint32()
+        _check(lib().rsk_mu_gapless_shard_window(db.h, int(shard_index), int(shard_count), C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+    def mu_gapless_hits_window_dev(self, db, pos_lo, pos_hi, min_score, rec_ptr, capacity, count_ptr, d_scores_ptr=0, ldo=0, base=0):
+        """rsk_mu_gapless_hits_window_dev: one rank's window of the self-search triangle (the whole set on every rank)"""
+        _check(lib().rsk_mu_gapless_hits_window_dev(self.h, db.h, int(pos_lo), int(pos_hi), C.c_void_p(d_scores_ptr) if d_scores_ptr else None, ldo,
+                                                    int(min_score), int(base), C.c_void_p(rec_ptr), int(capacity), C.c_void_p(count_ptr)))
 
     def mu_gapless_pairs(self, q, t, iq, it, positions=False):
         iq = np.ascontiguousarray(iq, np.uint32)

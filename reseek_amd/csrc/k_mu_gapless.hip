@@ -34,6 +34,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <cmath>
 #include <map>
 
 #include "rsk_dev_tables.h"
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(64 * NW) void k_gapless_ring(const rsk_ring *__rest
                                                           const uint32_t *__restrict__ t_len, uint32_t nt,
                                                           const uint32_t *__restrict__ t_perm,   // self triangle: processing order
                                                           const uint32_t *__restrict__ t_claim,  // positions of each aligned block, longest first
-                                                          uint32_t tb_size, int self_triangle,
+                                                          uint32_t tb_size, int self_triangle, uint32_t win_lo, uint32_t win_hi,
                                                           uint16_t *__restrict__ out, size_t ldo, gl_hits hits,
                                                           const uint8_t *__restrict__ q_mu, const uint32_t *__restrict__ q_off,
                                                           const uint32_t *__restrict__ q_len)
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(64 * NW) void k_gapless_ring(const rsk_ring *__rest
         t = __builtin_amdgcn_readfirstlane(t_claim[t]);                       // longest targets of the block first (LPT)
         const uint32_t tpos = t;                                              // position in the processing order
         if (self_triangle) {
-            if (t < rg.min_q) continue;                                       // positions before the ring's first member
+            if (t < rg.min_q || t < win_lo || t >= win_hi) continue;          // positions before the ring's first member / outside the shard's window
             t = __builtin_amdgcn_readfirstlane(t_perm[t]);                    // position -> chain
         }
         const uint32_t toff = __builtin_amdgcn_readfirstlane(t_off[t]);
@@ -499,7 +500,7 @@ __global__ __launch_bounds__(1024) void k_gapless_pairs(const uint8_t *__restric
 // ---------------------------------------------------------------------------------------------
 template <int D, int NW>
 static int launch_ring_class(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, const uint2 *d_work, uint32_t nwork, const uint32_t *d_claim,
-                             int self_triangle, uint16_t *d_scores, size_t ldo, uint32_t tb_size, const gl_hits &hits)
+                             int self_triangle, uint32_t win_lo, uint32_t win_hi, uint16_t *d_scores, size_t ldo, uint32_t tb_size, const gl_hits &hits)
 {
     if (nwork == 0) return RSK_OK;
     constexpr size_t lds = ring_lds_bytes<D, NW>();
@@ -511,14 +512,18 @@ static int launch_ring_class(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, con
     if (arc != RSK_OK) return arc;
     hipLaunchKernelGGL((k_gapless_ring<D, NW>), dim3(nwork), dim3(64 * NW), lds, ctx->stream, q->d_ring_tab, d_work,
                        q->d_ring_letters, q->d_ring_laneq, q->d_ring_qid, t->d_mu, t->d_off, t->d_len, t->n, q->d_ring_perm,
-                       d_claim, tb_size, self_triangle, d_scores, ldo, hits, q->d_mu, q->d_off, q->d_len);
+                       d_claim, tb_size, self_triangle, win_lo, win_hi, d_scores, ldo, hits, q->d_mu, q->d_off, q->d_len);
     RSK_HIP(hipGetLastError());
     return RSK_OK;
 }
 
 // Targets per work item.  An item costs one profile build (37 rows of the whole LDS, nothing else runs on the CU meanwhile),
 // so the blocks are as large as the launch allows while it still has several items per CU: measured on the 11,211-chain
-// triangle (935 rings), 128 / 256 / 512 / 1024 / 2048 targets: 45.1 / 43.6 / 42.9 / 42.6 / 43.0 ms.
+// triangle (935 rings), 128 / 256 / 512 / 1024 / 2048 targets: 45.1 / 43.6 / 42.9 / 42.6 / 43.0 ms.  (r05 tried a cost model --
+// rounds of items x (build + targets per wave + half a target of end-of-item spread) -- in its place: it picked 256-target
+// blocks for thin shards and was slower on 5 of 8 shards of the bench triangle.  Exchanging the roles of the two sets for a thin
+// target set -- the score is symmetric -- was 2.5 x slower still: long chains make poor ring members, a 1,024-slot sub-ring
+// holds one 700-residue chain and 320 idle slots, and chains beyond a ring go to the per-pair kernel.)
 static uint32_t ring_target_block(size_t nrings, uint32_t nt)
 {
     uint32_t tb = RING_TB_MAX;
@@ -550,15 +555,23 @@ static int build_claim_order(const rsk_db *db, const uint32_t *perm, std::map<ui
     return RSK_OK;
 }
 
+// win_lo / win_hi (self triangle only; 0 / n = everything): the launch scores the pairs whose LATER member in the processing
+// order (ring_perm) stands at a position in [win_lo, win_hi) -- one rank's share of the triangle (rsk_mu_gapless_shard_window).
+// Every rank keeps the whole set and runs the same rings against its window of targets: one launch of the same shape as the
+// whole triangle, instead of a rectangle plus a small triangle of its own chains (r04; measured r05 on the 8 shards of the bench
+// set: the small triangles ran at 4 - 37 T cells/s against 41 - 44 for the rectangles, the last rank took 1.29 x its cells).
 int rsk_launch_gapless_rings(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int self_triangle,
                              uint16_t *d_scores, size_t ldo, uint32_t min_score, uint32_t q_base, uint32_t t_base, uint32_t *d_rec,
-                             uint32_t capacity, uint32_t *d_count)
+                             uint32_t capacity, uint32_t *d_count, uint32_t win_lo, uint32_t win_hi)
 {
+    if (!self_triangle) { win_lo = 0; win_hi = t->n; }
+    win_hi = std::min(win_hi, t->n);
+    win_lo = std::min(win_lo, win_hi);
     gl_hits hits = {};
     hits.rec = d_rec; hits.count = d_count; hits.cap = capacity; hits.min_score = min_score; hits.q_base = q_base; hits.t_base = t_base;
     int rc = rsk_upload_mu_tables(ctx);
     if (rc != RSK_OK) return rc;
-    const uint32_t tb = ring_target_block(q->rings.size(), t->n);
+    const uint32_t tb = ring_target_block(q->rings.size(), win_hi - win_lo);
     const uint32_t *d_claim = nullptr;
     if (self_triangle) rc = build_claim_order(q, q->h_ring_perm.data(), const_cast<rsk_db *>(q)->tri_claims, const_cast<rsk_db *>(q)->claim_mutex, tb, &d_claim);
     else rc = build_claim_order(t, nullptr, const_cast<rsk_db *>(t)->nat_claims, const_cast<rsk_db *>(t)->claim_mutex, tb, &d_claim);
@@ -573,9 +586,11 @@ int rsk_launch_gapless_rings(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int
     }
     uint64_t pairs = 0, cells = 0, slots = 0;
     if (self_triangle) {                                  // the pair space of the contract: every unordered pair once
-        pairs = (uint64_t) q->n * (q->n + 1) / 2;
-        uint64_t suffix = 0;
-        for (uint32_t i = q->n; i-- > 0;) { suffix += q->len[i]; cells += (uint64_t) q->len[i] * suffix; }
+        // (a pair belongs to the window its later member's position lies in: position p closes p + 1 pairs)
+        for (uint32_t p = win_lo; p < win_hi; ++p) {
+            pairs += (uint64_t) p + 1;
+            cells += (uint64_t) t->len[q->h_ring_perm[p]] * pre_len[p + 1];
+        }
     } else {
         pairs = (uint64_t) q->n * t->n;
         cells = pre_len[t->n] * [&]() { uint64_t z = 0; for (uint32_t L : q->len) z += L; return z; }();
@@ -583,14 +598,14 @@ int rsk_launch_gapless_rings(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int
     uint32_t nD4 = 0, nD8 = 0;
     for (auto &r : q->rings) {
         (r.D == 8 ? nD4 : nD8)++;
-        const uint32_t ts = self_triangle ? r.min_q : 0;
-        slots += 128ull * r.D * (pre_slots[t->n] - pre_slots[ts]);
+        const uint32_t ts = std::min(win_hi, std::max(win_lo, self_triangle ? r.min_q : 0u));
+        slots += 128ull * r.D * (pre_slots[win_hi] - pre_slots[ts]);
     }
     {
         uint32_t pos = (uint32_t) (q->n - q->long_q.size());
         for (uint32_t lqi : q->long_q) {
-            const uint32_t ts = self_triangle ? pos : 0;
-            slots += (uint64_t) q->len[lqi] * (pre_len[t->n] - pre_len[ts]);
+            const uint32_t ts = std::min(win_hi, std::max(win_lo, self_triangle ? pos : 0u));
+            slots += (uint64_t) q->len[lqi] * (pre_len[win_hi] - pre_len[ts]);
             ++pos;
         }
     }
@@ -599,16 +614,18 @@ int rsk_launch_gapless_rings(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int
     // work list: one workgroup per (ring, block of targets); only blocks that contain work, the
     // expensive ones first.  Cached per (target set, triangle flag) in the query chain set.
     rsk_db *qm = const_cast<rsk_db *>(q);
-    if (qm->work_for != t->uid || qm->work_tri != self_triangle || qm->work_tb != tb) {
+    if (qm->work_for != t->uid || qm->work_tri != self_triangle || qm->work_tb != tb || qm->work_win_lo != win_lo || qm->work_win_hi != win_hi) {
         const uint32_t TB[2] = { tb, tb };             // targets per workgroup (the claim order is built for this block size)
         std::vector<uint2> w[2];
         std::vector<uint64_t> cost[2];
         for (uint32_t ri = 0; ri < q->rings.size(); ++ri) {
             const rsk_ring &r = q->rings[ri];
             const int c = r.D == 8 ? 0 : 1;
-            const uint32_t ts = self_triangle ? (r.min_q / TB[c]) * TB[c] : 0;
-            for (uint32_t t0 = ts; t0 < t->n; t0 += TB[c]) {
-                const uint32_t lo = std::max(t0, self_triangle ? r.min_q : 0u), hi = std::min(t->n, t0 + TB[c]);
+            const uint32_t first = std::max(win_lo, self_triangle ? r.min_q : 0u);
+            const uint32_t ts = (first / TB[c]) * TB[c];
+            for (uint32_t t0 = ts; t0 < win_hi; t0 += TB[c]) {
+                const uint32_t lo = std::max(t0, first), hi = std::min(win_hi, t0 + TB[c]);
+                if (hi <= lo) continue;
                 w[c].push_back(make_uint2(ri, t0));
                 cost[c].push_back(128ull * r.D * (pre_slots[hi] - pre_slots[lo]));
             }
@@ -635,7 +652,7 @@ int rsk_launch_gapless_rings(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int
             uint32_t pos = (uint32_t) (q->n - q->long_q.size());      // long chains close the processing order
             for (uint32_t lqi : q->long_q) {
                 if (self_triangle) {
-                    for (uint32_t p = pos; p < t->n; ++p) {           // symmetric score: stored at [min][max]
+                    for (uint32_t p = std::max(pos, win_lo); p < win_hi; ++p) {           // symmetric score: stored at [min][max]
                         const uint32_t tj = q->h_ring_perm[p];
                         iq.push_back(std::min(lqi, tj)); it.push_back(std::max(lqi, tj));
                     }
@@ -654,14 +671,16 @@ int rsk_launch_gapless_rings(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int
         qm->work_for = t->uid;
         qm->work_tri = self_triangle;
         qm->work_tb = tb;
+        qm->work_win_lo = win_lo;
+        qm->work_win_hi = win_hi;
     }
     (void) nD4; (void) nD8;
 
     RSK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-    rc = launch_ring_class<16, 16>(ctx, q, t, (const uint2 *) q->d_work + q->work_count[0], q->work_count[1], d_claim, self_triangle,
+    rc = launch_ring_class<16, 16>(ctx, q, t, (const uint2 *) q->d_work + q->work_count[0], q->work_count[1], d_claim, self_triangle, win_lo, win_hi,
                                   d_scores, ldo, tb, hits);
     if (rc != RSK_OK) return rc;
-    rc = launch_ring_class<8, 16>(ctx, q, t, (const uint2 *) q->d_work, q->work_count[0], d_claim, self_triangle, d_scores, ldo, tb, hits);
+    rc = launch_ring_class<8, 16>(ctx, q, t, (const uint2 *) q->d_work, q->work_count[0], d_claim, self_triangle, win_lo, win_hi, d_scores, ldo, tb, hits);
     if (rc != RSK_OK) return rc;
     // queries too long for a ring: per-pair kernel over (long q) x targets
     if (q->long_pairs) {                               // list built with the work list (cached per target set + triangle flag)

@@ -448,6 +448,55 @@ extern "C" int rsk_mu_gapless_hits_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_
     return rsk_launch_gapless_rings(ctx, q, t, self_triangle, d_scores, ldo, min_score, q_base, t_base, d_records, capacity, d_count);
 }
 
+extern "C" int rsk_mu_gapless_shard_window(const rsk_db *db, uint32_t shard_index, uint32_t shard_count, uint32_t *pos_lo, uint32_t *pos_hi)
+{
+    if (!db || !pos_lo || !pos_hi || shard_count == 0 || shard_index >= shard_count) { rsk_set_error("rsk_mu_gapless_shard_window: invalid argument"); return RSK_E_INVALID; }
+    int rc;
+    if (!db->rings_built) {
+        rsk_device_guard g(db->ctx->device);
+        if ((rc = rsk_build_rings(const_cast<rsk_db *>(db))) != RSK_OK) return rc;
+    }
+    // cost of target position p = its letters (in pairs) x the ring slots that walk it (rings whose first member stands at
+    // or before p) + its rows against the long chains at or before p: the slots the kernel issues for it
+    const uint32_t n = db->n;
+    std::vector<double> cum((size_t) n + 1, 0.0);
+    {
+        std::vector<uint64_t> ring_slots((size_t) n + 1, 0);
+        for (const rsk_ring &r : db->rings) ring_slots[r.min_q] += 128ull * r.D;
+        uint64_t slots = 0, long_rows = 0;
+        const uint32_t first_long = n - (uint32_t) db->long_q.size();
+        for (uint32_t p = 0; p < n; ++p) {
+            slots += ring_slots[p];
+            const uint32_t L = db->len[db->h_ring_perm[p]];
+            if (p >= first_long) long_rows += L;
+            cum[p + 1] = cum[p] + (double) ((L + 1) / 2 * 2) * (double) (slots + long_rows);
+        }
+    }
+    auto bound = [&](uint32_t r) -> uint32_t {
+        if (r == 0) return 0;
+        if (r >= shard_count) return n;
+        const double want = cum[n] * (double) r / (double) shard_count;
+        return (uint32_t) (std::lower_bound(cum.begin(), cum.end(), want) - cum.begin());
+    };
+    *pos_lo = std::min(bound(shard_index), n);
+    *pos_hi = std::max(*pos_lo, std::min(bound(shard_index + 1), n));
+    return RSK_OK;
+}
+
+extern "C" int rsk_mu_gapless_hits_window_dev(rsk_ctx *ctx, const rsk_db *db, uint32_t pos_lo, uint32_t pos_hi, uint16_t *d_scores, size_t ldo,
+                                              uint32_t min_score, uint32_t base, uint32_t *d_records, uint32_t capacity, uint32_t *d_count)
+{
+    if (!d_records || !d_count) { rsk_set_error("rsk_mu_gapless_hits_window_dev: NULL record buffer / counter"); return RSK_E_INVALID; }
+    int rc = gapless_dense_checks("rsk_mu_gapless_hits_window_dev", ctx, db, db, 1, d_scores, ldo);
+    if (rc != RSK_OK) return rc;
+    if (pos_lo > pos_hi || pos_hi > db->n) { rsk_set_error("rsk_mu_gapless_hits_window_dev: window [%u, %u) outside the set's %u positions", pos_lo, pos_hi, db->n); return RSK_E_INVALID; }
+    RSK_HIP(hipSetDevice(ctx->device));
+    if (!db->rings_built && (rc = rsk_build_rings(const_cast<rsk_db *>(db))) != RSK_OK) return rc;
+    RSK_HIP(hipMemsetAsync(d_count, 0, 4, ctx->stream));
+    if (pos_lo == pos_hi) { ctx->gl_pairs = ctx->gl_cells = ctx->gl_slots = 0; ctx->last_ms = 0.0f; return RSK_OK; }
+    return rsk_launch_gapless_rings(ctx, db, db, 1, d_scores, ldo, min_score, base, base, d_records, capacity, d_count, pos_lo, pos_hi);
+}
+
 extern "C" int rsk_mu_gapless_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, const uint32_t *iq,
                                     const uint32_t *it, size_t npairs, int32_t *scores, uint32_t *besti,
                                     uint32_t *bestj)

@@ -159,6 +159,7 @@ struct rsk_db {
     uint64_t work_for = 0;              // uid of the target set the list was built for
     int work_tri = -1;
     uint32_t work_tb = 0;               // targets per work item of the cached list
+    uint32_t work_win_lo = 0, work_win_hi = 0;   // ... and its window of target positions (rsk_launch_gapless_rings)
     void *d_work = nullptr;             // uint2 (ring, first target) entries, D = 4 class first
     uint32_t work_count[2] = { 0, 0 };
     uint32_t *d_long_iq = nullptr, *d_long_it = nullptr;   // (long query, target) pairs of the per-pair kernel, same cache key
@@ -180,7 +181,7 @@ struct rsk_db {
 // kernels (k_mu_gapless.hip)
 int rsk_launch_gapless_rings(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int self_triangle,
                              uint16_t *d_scores, size_t ldo, uint32_t min_score, uint32_t q_base, uint32_t t_base, uint32_t *d_rec,
-                             uint32_t capacity, uint32_t *d_count);
+                             uint32_t capacity, uint32_t *d_count, uint32_t win_lo = 0, uint32_t win_hi = 0xFFFFFFFFu);
 int rsk_launch_gapless_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, const uint32_t *d_iq,
                              const uint32_t *d_it, size_t npairs, int32_t *d_scores,
                              uint32_t *d_besti, uint32_t *d_bestj);

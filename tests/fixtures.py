@@ -238,3 +238,12 @@ def prefilter_tmp_tsv(tq, tt, ntargets_header=True):
         qs = by_t[t]
         lines.append("%d\t%d\t%s" % (t, len(qs), "\t".join(map(str, qs))))
     return "\n".join(lines) + "\n"
+
+
+def device_list(entries):
+    """A device list of `entries` contexts for rsk_search_opts.devices / RSK_DEVICES / -devices: DISTINCT devices wherever
+    the box has them (entry i -> device i mod device_count), device 0 repeated on a one-GPU box -- the multi-context tests use
+    every GPU that exists without being rewritten (VERDICT r04 #3b)."""
+    import torch
+    nd = max(1, torch.cuda.device_count())
+    return ",".join(str(i % nd) for i in range(entries))

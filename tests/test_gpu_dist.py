@@ -42,8 +42,13 @@ def test_bench_strong_scaling_world2_gloo_one_device():
     res = json.loads(line)
     assert res["n_gpus"] == 2 and res["scaling"] == "strong"
     n = 1500
-    assert res["config"]["pairs_total"] == n * (n + 1) // 2      # the shards partition the triangle
+    assert res["config"]["pairs_total"] == n * (n + 1) // 2      # the windows partition the triangle
     assert res["value"] > 0
+    w = res["config"]["windows"]
+    assert res["config"]["collective_world"] == 2 and len(w) == 2 and w[0][0] == 0 and w[0][1] == w[1][0] and w[1][1] == n
+    # bench.py itself compares the gathered records with a one-GPU pass of the whole triangle (and asserts)
+    gc = res["config"]["hit_records"]["gather_check"]
+    assert gc["gathered_all_ranks"] == gc["one_gpu_hit_records"] == gc["sum_of_rank_counts"] > 0
     # the hit records the kernels appended on both ranks (gathered) == the records of the unsharded run on the same set
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--chains", "1500", "--no-cpu-baseline",
                           "--no-search", "--no-live"], capture_output=True, text=True, cwd=ROOT, timeout=900)

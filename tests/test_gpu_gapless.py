@@ -145,6 +145,38 @@ def test_rectangular_query_vs_db(ctx):
     assert np.array_equal(got, want)
 
 
+def test_thin_target_set_of_long_chains(ctx):
+    """Many queries against a thin set of long targets (a rank's shard of the longest chains, reseek_amd/shardplan.py): dense
+    matrix and hit records with index bases against the oracle; includes a query and a target beyond a ring (per-pair
+    kernel) and a one-residue chain on each side."""
+    import torch
+    import reseek_amd
+    rng = np.random.default_rng(31)
+    qs = [rng.integers(0, 36, int(L)).astype(np.uint8) for L in np.concatenate([rng.integers(20, 260, 598), [1, 1100]])]
+    ts = [rng.integers(0, 36, int(L)).astype(np.uint8) for L in np.concatenate([rng.integers(400, 1000, 58), [1, 1300]])]
+    for k in range(0, 58, 5):
+        ts[k][:len(qs[k])] = qs[k]                               # planted copies: real hits
+    nq, nt = len(qs), len(ts)
+    ia, ib = np.meshgrid(np.arange(nq), np.arange(nt), indexing="ij")
+    want = ol.mu_gapless_pairs(qs + ts, ia.ravel(), ib.ravel() + nq).reshape(nq, nt)
+    q, t = reseek_amd.Db.from_mu_seqs(ctx, qs), reseek_amd.Db.from_mu_seqs(ctx, ts)
+    cap = 1 << 16
+    thr = 80
+    for _ in range(1):
+        dense = torch.full((nq, nt), -1, dtype=torch.int16, device="cuda")
+        rec = torch.zeros((cap, 3), dtype=torch.int32, device="cuda")
+        cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+        ctx.mu_gapless_hits_dev(q, t, False, thr, rec.data_ptr(), cap, cnt.data_ptr(), d_scores_ptr=dense.data_ptr(), ldo=nt, q_base=1000, t_base=5000)
+        torch.cuda.synchronize()
+        D = dense.cpu().numpy().view(np.uint16).astype(np.int32)
+        assert np.array_equal(D, want)
+        got = sorted(map(tuple, rec[:int(cnt.item())].cpu().numpy().tolist()))
+        qi, ti = np.nonzero(want >= thr)
+        assert got == sorted(zip((qi + 1000).tolist(), (ti + 5000).tolist(), want[qi, ti].tolist())) and len(got) >= 12
+    assert ctx.mu_gapless_last_work()[0] == nq * nt
+    q.close(); t.close()
+
+
 def test_low_complexity_high_scores(ctx):
     # identical poly-letter chains: score = 4 * L for letters whose self score is 4 (max of the matrix)
     seqs = [np.full(L, 1, np.uint8) for L in (50, 333, 1000, 1023)]
@@ -312,3 +344,59 @@ def test_device_hit_records_equal_the_thresholded_matrix():
     assert int(cnt.item()) == len(want)
     assert set(map(tuple, rec[:10].cpu().numpy().tolist())) <= set(want)
     db.close(); qa.close(); tb.close(); ctx.close()
+
+
+@pytest.mark.parametrize("shards", [2, 3, 8])
+def test_shard_windows_of_the_triangle_tile_it_exactly(shards):
+    """rsk_mu_gapless_shard_window / rsk_mu_gapless_hits_window_dev (multi-GPU share of the self search): the windows of all
+    shards are contiguous and cover the set's positions; the union of the shards' hit records equals the records of the whole
+    triangle, no pair twice; the union of the cells the shards write into the dense n x n matrix equals the whole triangle's
+    matrix (a cell two shards write -- two members of one ring -- gets the same value); pairs / cells of the shards add up to the triangle's; chains beyond a
+    ring (per-pair kernel) and an empty window included."""
+    import torch
+    import reseek_amd
+    rng = np.random.default_rng(41)
+    lens = np.concatenate([rng.integers(5, 400, 900), [1030, 1500, 9, 1]])
+    rng.shuffle(lens)
+    seqs = [rng.integers(0, 36, int(L)).astype(np.uint8) for L in lens]
+    for k in range(0, 300, 7):
+        src = seqs[k]
+        seqs[k + 1] = src[:len(seqs[k + 1])].copy() if len(src) >= len(seqs[k + 1]) else np.concatenate([src, seqs[k + 1][len(src):]])
+    ctx = reseek_amd.Ctx(0, stream=torch.cuda.current_stream().cuda_stream)
+    db = reseek_amd.Db.from_mu_seqs(ctx, seqs)
+    n = len(seqs)
+    thr, cap = 60, 1 << 17
+    rec = torch.zeros((cap, 3), dtype=torch.int32, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    full = torch.full((n, n), -1, dtype=torch.int16, device="cuda")
+    ctx.mu_gapless_hits_dev(db, db, True, thr, rec.data_ptr(), cap, cnt.data_ptr(), d_scores_ptr=full.data_ptr(), ldo=n, q_base=7, t_base=7)
+    torch.cuda.synchronize()
+    want = sorted(map(tuple, rec[:int(cnt.item())].cpu().numpy().tolist()))
+    F = full.cpu().numpy()
+    work_full = ctx.mu_gapless_last_work()
+    assert len(want) > 40
+    ii, jj = np.triu_indices(n)
+    assert (F[ii, jj] != -1).all()
+    wins = [ctx.mu_gapless_shard_window(db, k, shards) for k in range(shards)]
+    assert wins[0][0] == 0 and wins[-1][1] == n and all(a[1] == b[0] for a, b in zip(wins, wins[1:]))
+    got, pairs, cells = [], 0, 0
+    U = np.full((n, n), -1, np.int16)
+    for lo, hi in wins + [(5, 5)]:
+        part = torch.full((n, n), -1, dtype=torch.int16, device="cuda")
+        ctx.mu_gapless_hits_window_dev(db, lo, hi, thr, rec.data_ptr(), cap, cnt.data_ptr(), d_scores_ptr=part.data_ptr(), ldo=n, base=7)
+        torch.cuda.synchronize()
+        got += list(map(tuple, rec[:int(cnt.item())].cpu().numpy().tolist()))
+        w = ctx.mu_gapless_last_work()
+        pairs, cells = pairs + w[0], cells + w[1]
+        P = part.cpu().numpy()
+        wrote = P != -1
+        both = wrote & (U != -1)                                      # two members of one ring: scored from either side, the same value
+        assert np.array_equal(P[both], U[both])
+        U[wrote] = P[wrote]
+        if lo == hi:
+            assert not wrote.any() and w[0] == 0
+    assert sorted(got) == want and len(set((a, b) for a, b, _ in got)) == len(got)
+    assert np.array_equal(U[ii, jj], F[ii, jj])
+    assert (pairs, cells) == (work_full[0], work_full[1]) and pairs == n * (n + 1) // 2
+    db.close()
+    ctx.close()

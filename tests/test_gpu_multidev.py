@@ -1,6 +1,7 @@
 """SURVEY 8e from ONE process: a DBSearcher that drives several device contexts (DBSearcher::m_Devices / RSK_DEVICES /
 rsk_search_opts.devices) -- one context, one host thread and one shard of the pair space per list entry, hit lines into one
-file.  The GPU box has one device, so the list repeats device 0 ("0,0", "0,0,0"): the shards then run CONCURRENTLY on
+file.  The lists come from fixtures.device_list(k): k entries over the DISTINCT devices of the box where it has several, device 0
+repeated ("0,0", "0,0,0") on the one-GPU box, where the shards then run CONCURRENTLY on
 separate contexts and streams of that device, which is the part a single GPU can check (ranges, replication, concurrent
 writers, counters); nothing here depends on the entries being distinct devices.  The tables must equal the reference
 binary's goldens.  The C++ form of the same (tests/ref_shaped/search_main.cpp -devices, and the reference's own search.cpp
@@ -46,8 +47,9 @@ def golden(name):
     return ["\t".join(r) for r in fx.read_tsv(name)]
 
 
-@pytest.mark.parametrize("devices", ["0,0", "0,0,0"])
-def test_self_search_on_several_contexts(ctx, work, devices):
+@pytest.mark.parametrize("entries", [2, 3])
+def test_self_search_on_several_contexts(ctx, work, entries):
+    devices = fx.device_list(entries)
     out = os.path.join(work, "self.tsv")
     n, st = ctx.search(os.path.join(work, "q100.bca"), out, "sensitive", columns=COLS, devices=devices)
     assert table(out) == golden("hits_q100_sensitive.tsv.gz") and n == len(golden("hits_q100_sensitive.tsv.gz"))
@@ -58,8 +60,9 @@ def test_self_search_on_several_contexts(ctx, work, devices):
     assert table(out) == golden("hits_q100_verysensitive.tsv.gz") and st[0] == 5050
 
 
-@pytest.mark.parametrize("devices", ["0,0", "0,0,0"])
-def test_db_search_on_several_contexts(ctx, work, devices, monkeypatch):
+@pytest.mark.parametrize("entries", [2, 3])
+def test_db_search_on_several_contexts(ctx, work, entries, monkeypatch):
+    devices = fx.device_list(entries)
     out = os.path.join(work, "db.tsv")
     q = os.path.join(work, "q100.bca")
     n, st = ctx.search(q, out, "sensitive", db=q, columns=COLS, devices=devices)       # every context streams its own range of the -db file
@@ -76,7 +79,7 @@ def test_fast_db_two_stage_on_several_contexts(ctx, work):
     and merged hand-off file equal the reference's."""
     out = os.path.join(work, "fastdb.tsv")
     q = os.path.join(work, "q100.bca")
-    for devices in ("0,0", "0,0,0"):
+    for devices in (fx.device_list(2), fx.device_list(3)):
         n, st = ctx.search(q, out, "fast", db=q, columns=COLS, devices=devices, keeptmp=1)
         want = golden("hits_q100_db_q100_fast.tsv.gz")
         assert table(out) == want and n == len(want)
@@ -90,7 +93,7 @@ def test_fast_db_top_b_cut_is_the_single_device_one(ctx, work):
     lists go through the same replay as the single-device path: identical hit table and hand-off file for any device list."""
     q = os.path.join(work, "q100.bca")
     outs = []
-    for devices in (None, "0,0", "0,0,0"):
+    for devices in (None, fx.device_list(2), fx.device_list(3)):
         out = os.path.join(work, "rsb5_%s.tsv" % (devices or "one").replace(",", "_"))
         kw = {"devices": devices} if devices else {}
         n, st = ctx.search(q, out, "fast", db=q, columns=COLS, rsb_size=5, keeptmp=1, **kw)
@@ -134,9 +137,9 @@ def _run(exe, work, args, gold, env=None):
 def test_cpp_driver_with_a_device_list(work):
     exe = os.path.join(work, "search_main")
     _compile(os.path.join(ROOT, "tests", "ref_shaped", "search_main.cpp"), exe)
-    _run(exe, work, ["q100.bca", "-sensitive", "-devices", "0,0"], "hits_q100_sensitive.tsv.gz")
-    _run(exe, work, ["palms.bca", "-sensitive", "-devices", "0,0,0"], "hits_palms_sensitive.tsv.gz")
-    _run(exe, work, ["q100.bca", "-db", "q100.bca", "-sensitive", "-devices", "0,0"], "hits_q100_db_q100_sensitive.tsv.gz")
+    _run(exe, work, ["q100.bca", "-sensitive", "-devices", fx.device_list(2)], "hits_q100_sensitive.tsv.gz")
+    _run(exe, work, ["palms.bca", "-sensitive", "-devices", fx.device_list(3)], "hits_palms_sensitive.tsv.gz")
+    _run(exe, work, ["q100.bca", "-db", "q100.bca", "-sensitive", "-devices", fx.device_list(2)], "hits_q100_db_q100_sensitive.tsv.gz")
 
 
 def test_the_reference_search_cpp_runs_on_a_device_list(work):
@@ -145,8 +148,8 @@ def test_the_reference_search_cpp_runs_on_a_device_list(work):
     exe = os.path.join(ROOT, "oracle", "_ref", "search_refsrc")
     if not os.path.exists(exe):
         pytest.skip("oracle/_ref/search_refsrc not built (make -f oracle/Makefile.ref where /root/reference exists)")
-    _run(exe, work, ["q100.bca", "-sensitive"], "hits_q100_sensitive.tsv.gz", env={"RSK_DEVICES": "0,0"})
-    _run(exe, work, ["q100.bca", "-db", "q100.bca", "-sensitive"], "hits_q100_db_q100_sensitive.tsv.gz", env={"RSK_DEVICES": "0,0,0"})
+    _run(exe, work, ["q100.bca", "-sensitive"], "hits_q100_sensitive.tsv.gz", env={"RSK_DEVICES": fx.device_list(2)})
+    _run(exe, work, ["q100.bca", "-db", "q100.bca", "-sensitive"], "hits_q100_db_q100_sensitive.tsv.gz", env={"RSK_DEVICES": fx.device_list(3)})
 
 
 def test_the_callers_current_device_survives_a_several_device_search(ctx, work):

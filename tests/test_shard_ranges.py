@@ -72,3 +72,26 @@ def test_more_shards_than_chains_and_bad_arguments():
         capi.shard_range(0, L, 3, 3)
     with pytest.raises(RuntimeError):
         capi.shard_range(2, L, 0, 1)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+@pytest.mark.parametrize("scheme", ["targets", "fold"])
+def test_shardplan_launch_lists_tile_the_triangle(world, scheme):
+    """reseek_amd/shardplan.py (the rectangle + triangle cuts tools/exp/shard_times.py measures against the window scheme
+    bench.py runs): every pair i <= j in exactly one launch of one rank, cell shares within one target's worth of equal."""
+    from reseek_amd import shardplan as sp
+    for name, L in lengths_sets():
+        if len(L) < 100:
+            continue
+        Ls = np.sort(L)
+        p = sp.plan(Ls, world, scheme)
+        assert len(p) == world and sp.check_plan(len(Ls), p), (name, world, scheme)
+        shares = sp.cell_shares(Ls, world, scheme)
+        assert abs(sum(shares) - 1.0) < 1e-9
+        biggest = (np.cumsum(Ls.astype(np.float64)) * Ls).max() / sp.cell_prefix(Ls)[-1]
+        assert max(shares) - 1.0 / world <= 2 * biggest + 1e-9, (name, shares)
+    # a plan that loses or doubles a box is caught
+    L0 = np.sort(list(lengths_sets())[0][1])
+    bad = sp.plan(L0, 2, "targets")
+    bad[1] = bad[1][:-1]
+    assert not sp.check_plan(len(L0), bad)
