@@ -170,7 +170,7 @@ def _load_json(name):
         return None
 
 
-def _verified_pmc(name="r04_live_pmc.json"):
+def _verified_pmc(name="r05_live_pmc.json"):
     """Counter records of tools/prof_live.sh, per kernel -- only those whose kernel SOURCE file still has the sha256 it had
     when the counters were collected (a kernel edit must not leave stale counters in the bench line); the others read
     {"stale": reason}."""
@@ -341,7 +341,7 @@ def live_kernels(ctx, seqs, db, reps=3):
       k_sw_qp     float SW + trace, 64 queries x all chains (query-profile kernel; the -db / -verysensitive regime)
     Bounds: VALU issue (one wave64 instruction per 4 cycles per SIMD for mixed VOP2/VOP3/DPP streams, profiles/r02_ubench_valu.txt)
     and, for k_sw_float, the LDS (8 random ds_read_b32 per cell).  `pmc` = issue / LDS-busy fractions from the rocprofv3
-    counter passes of `bench.py --live-only` committed as profiles/r04_live_pmc.json (tools/prof_live.sh)."""
+    counter passes of `bench.py --live-only` committed as profiles/r05_live_pmc.json (tools/prof_live.sh)."""
     import torch
     import reseek_amd
     n = len(seqs)
@@ -408,6 +408,13 @@ def live_kernels(ctx, seqs, db, reps=3):
              "hbm": {"algorithmic_bytes": alg_, "trace_bytes": float(tb), "achieved_GBs": alg_ / ms_ * 1e3 / 1e9,
                      "frac": alg_ / ms_ * 1e3 / 1e9 / PEAK_HBM_GBS},
              "pmc": pmc.get(name)}
+        ck = (pmc.get(name) or {}).get("sustained_clock_ghz")
+        if ck:
+            # the nominal peak assumes 2.4 GHz; the counters give the clock the kernel actually held (power limit) and the share of
+            # its cycles in which a SIMD issued a VALU instruction
+            e["sustained_clock_ghz"] = ck
+            e["frac_at_sustained_clock"] = e["frac"] * 2.4 / ck
+            e["valu_issue_frac_of_cycles"] = (pmc.get(name) or {}).get("valu_issue_frac")
         if lds:
             # 8 ds_read_b32 gathers per cell; conflict-free LDS rate = 32 lanes/clk/CU
             peak_g = 256 * 32 * 2.4e9
@@ -422,7 +429,7 @@ def live_kernels(ctx, seqs, db, reps=3):
     order = np.random.default_rng(4).permutation(n)[:nq].astype(np.uint32)
     qa = np.repeat(order, n)
     qb = np.tile(np.arange(n, dtype=np.uint32), nq)
-    res.append(sw_entry("k_sw_qp", "float SW + trace, %d queries x %d chains (query-profile kernel)" % (nq, n), qa, qb, 0.0, 21.2, False))      # 254 VALU instructions per 12-row column in the ISA of the hot loop (R = 12 instance: 18.5 per cell for the recurrence, trace masks and best cell + ~32 per step; r04b: 278)
+    res.append(sw_entry("k_sw_qp", "float SW + trace, %d queries x %d chains (query-profile kernel)" % (nq, n), qa, qb, 0.0, 19.5, False))      # 234 VALU instructions per 12-row step in the ISA of the hot loop (R = 12 instance of the r05 8-lane geometry: 18 per cell for the recurrence, the five comparisons and the best cell + ~18 per step; r04: 254, r04b: 278)
     dbs.close()
     del out8, pq, pt
     torch.cuda.empty_cache()
@@ -640,6 +647,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--weak", action="store_true", help="N > 1: an independent SCOP40-shaped set per rank instead of shards of one")
     ap.add_argument("--no-search", action="store_true", help="skip the end-to-end -search legs (rank 0, 1 GPU only)")
+    ap.add_argument("--no-predict", action="store_true", help="skip the predicted-scaling leg (the N = 2 / 4 / 8 windows run one after the other on this GPU)")
     ap.add_argument("--no-live", action="store_true", help="skip the live-path kernel rooflines (rank 0, 1 GPU only)")
     ap.add_argument("--live-only", action="store_true", help="only the live-path kernels (the command tools/prof_live.sh profiles)")
     ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE configs[2..4] legs (rank 0, 1 GPU only)")
@@ -784,17 +792,17 @@ def main():
         traffic, traffic_src = None, None
         try:
             import hashlib
-            with open(os.path.join(ROOT, "profiles", "r04_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r05_traffic.json")) as f:
                 tj = json.load(f)
             with open(os.path.join(ROOT, tj["kernel_source"]), "rb") as f:
                 sha = hashlib.sha256(f.read()).hexdigest()
             if sha != tj["kernel_source_sha256"]:
-                traffic_src = "profiles/r04_traffic.json is STALE (%s changed since the counters were collected): re-run tools/prof_bench.sh" % tj["kernel_source"]
+                traffic_src = "profiles/r05_traffic.json is STALE (%s changed since the counters were collected): re-run tools/prof_bench.sh" % tj["kernel_source"]
             elif n != 11211 or args.chains or world != 1:
-                traffic_src = "profiles/r04_traffic.json holds the 1-GPU full-set workload only"
+                traffic_src = "profiles/r05_traffic.json holds the 1-GPU full-set workload only"
             else:
                 traffic = float(tj["traffic_bytes_per_launch"])
-                traffic_src = "profiles/r04_traffic.json (rocprofv3 PMC FETCH_SIZE x 2 + WRITE_SIZE per dispatch, same command; kernel source sha256 verified)"
+                traffic_src = "profiles/r05_traffic.json (rocprofv3 PMC FETCH_SIZE x 2 + WRITE_SIZE per dispatch, same command; kernel source sha256 verified)"
         except (OSError, ValueError, KeyError) as e:
             traffic_src = "no traffic record (%s)" % e
         res = {
@@ -841,7 +849,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(seqs)
-        if world == 1 and not args.chains:
+        if world == 1 and not args.chains and not args.no_predict:
             try:
                 res["predicted_scaling"] = predicted_scaling(ctx, seqs)
             except Exception as e:  # noqa: BLE001 -- the kernel metric above stands on its own

@@ -412,8 +412,13 @@ struct swq_item { uint32_t first, count, ncol, R; uint64_t tb_base; };
 // The update of row r is issued at the end of row r + 1's code (volatile, like the mask comparisons it follows): by then
 // row r + 1 has read its old diagonal value, so v127 is copied straight into that register -- the one move per cell the
 // diagonal rotation needs anyway.
+#ifndef SWQ_EXPERIMENT_NO_BEST
 #define SWQ_BEST64(acc, xm, xc, s, nj) \
     asm volatile("v_add_f32_e32 v127, %2, %3\n\tv_max_f64 %0, %0, v[126:127]" : "+v"(acc), "={v127}"(xm) : "v"(xc), "v"(s), "{v126}"(nj))
+#else   // timing experiment only (tools/exp): what the 64-bit maximum costs (results are wrong: no best cell)
+#define SWQ_BEST64(acc, xm, xc, s, nj) \
+    asm volatile("v_add_f32_e32 v127, %2, %3" : "+v"(acc), "={v127}"(xm) : "v"(xc), "v"(s), "{v126}"(nj))
+#endif
 
 typedef float swq_v2f __attribute__((ext_vector_type(2)));
 typedef float swq_v4f __attribute__((ext_vector_type(4)));

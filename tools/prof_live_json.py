@@ -51,6 +51,13 @@ for key, d in vals.items():
          "dispatch_ms_profiled": [x / 1e6 for x in d.get("dispatch_ns", [])]}
     if cyc > 0:
         e["cycles"] = cyc
+        # the clock the kernel sustained while it was profiled (MI355X_MICROARCH.md DVFS: effective clock = GRBM_GUI_ACTIVE / wall):
+        # a kernel at its power limit runs below the 2.4 GHz the nominal issue peak assumes
+        ns = d.get("dispatch_ns", [])
+        if ns:
+            e["sustained_clock_ghz"] = cyc / (sum(ns) / len(ns))
+        if "SQ_THREAD_CYCLES_VALU" in d and "SQ_INSTS_VALU" in d and d["SQ_INSTS_VALU"] > 0:
+            e["active_lanes_per_valu_inst"] = d["SQ_THREAD_CYCLES_VALU"] / d["SQ_INSTS_VALU"]
         if "SQ_INSTS_VALU" in d:
             e["valu_issue_frac"] = d["SQ_INSTS_VALU"] * 4.0 / (1024.0 * cyc)
         if "SQ_LDS_IDX_ACTIVE" in d:

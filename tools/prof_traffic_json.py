@@ -40,7 +40,7 @@ fk, wk = sum(fetch) / len(fetch), sum(write) / len(write)
 src_sha = hashlib.sha256(open(os.path.join(repo, SRC), "rb").read()).hexdigest()
 print(json.dumps({
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of tools/prof_bench.sh (bench.py --steps 5 --warmup 1 "
-              "--no-cpu-baseline --no-search --no-live)",
+              "--no-cpu-baseline --no-search --no-live --no-predict)",
     "kernel": KERNEL, "dispatches": {"fetch": len(fetch), "write": len(write)},
     "fetch_size_kb_per_dispatch": fk, "write_size_kb_per_dispatch": wk,
     "correction": "FETCH_SIZE doubled (gfx950 reports half of wide coalesced reads); WRITE_SIZE as reported",
