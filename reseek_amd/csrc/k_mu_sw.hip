@@ -342,57 +342,29 @@ __global__ __launch_bounds__(1024) void k_mu_sw(musw_args a)
 // In the self triangle the pair (A, B) of ranks (r, r + 1) takes the targets of rank >= r: B meets A once more as a target
 // (the same score lands in the same cell), everything else is the triangle.
 // ---------------------------------------------------------------------------------------------
-#define MUSW2_R 16
+#define MUSW2_RMAX 16
 #define MUSW_NOQ 0xFFFFFFFFu
+// Geometry of a query pair (r05): g strips of R rows, R = 4 .. 16 -- a template parameter of the batch loop, the workgroup
+// branches on its pair's R.  r02-r04 fixed R = 16 and g = ceil(L / 16): a pair of 174 residues took 11 lanes, a wave 5 targets
+// on 55 of its 64 lanes.  Now the host picks per query pair, between g0 = ceil(L / 16) and the next power of two, the (g, R =
+// ceil(L / g)) of least modelled cost (musw2_geometry: idle lanes 64 mod g, pad rows g R - L, the g - 1 columns of systolic
+// skew, ~10 instructions per step beside 7.5 per row): 16 lanes x 11 rows for that pair.  The kernel is issue-bound (PMC: a
+// VALU instruction in 99 % of the cycles at 2.37 GHz), so every idle lane-row is time.
 // GMAX = strips of the class's longest query pair: the profile is laid out for GMAX strips whatever the pair's own count, so
-// that the four b128 blocks of a letter row sit at IMMEDIATE offsets from one address (one v_mad per column instead of
+// that the b128 blocks of a letter row sit at IMMEDIATE offsets from one address (one v_mad per column instead of
 // a 64-bit multiply and three adds).
-template <int GMAX>
-__global__ __launch_bounds__(1024) void k_mu_sw2(musw_args a, const uint2 *__restrict__ qpairs)
+template <int GMAX, int R>
+__device__ __forceinline__ void musw2_batches(const musw_args &a, const uint2 it, const uint32_t p, const uint32_t qa, const uint32_t qb, const uint32_t g,
+                                              const int *prof, uint32_t *wg_item)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    // dword (c, k, st, w) = row 16*st + 4*k + w of query A (low half) and of query B (high half) against letter c:
-    // P[((c*4 + k)*GMAX + st)*4 + w]; a lane's four b128 reads per letter row are conflict-free across the strips of a group
-    int *prof = (int *) smem;
-    signed char *mat = (signed char *) (prof + (size_t) 37 * GMAX * 16);
-    uint32_t *wg_item = (uint32_t *) (mat + 1312);
-    const int tid = threadIdx.x, lane = tid & 63;
+    constexpr int NK = (R + 3) / 4;                  // b128 blocks of a strip's letter row
+    const int lane = threadIdx.x & 63;
     const uint32_t nwaves = blockDim.x >> 6;
-    for (int i = tid; i < 1296; i += blockDim.x) mat[i] = (signed char) c_mu_int[i];
-    uint32_t cur_p = 0xFFFFFFFFu, qa = 0, qb = MUSW_NOQ, g = 1;
-    const uint32_t nitems = *a.nitems;
+    const uint32_t ppw = 64 / g;                 // targets per wave, each against both queries
+    const uint32_t cnt = a.cnt[p];
+    const uint32_t chunk_end = min(cnt, it.y + ppw * nwaves * MUSW_CHUNK);
+    const uint32_t pr = lane / g, st = lane - pr * g;
     for (;;) {
-        __syncthreads();
-        if (tid == 0) { wg_item[0] = atomicAdd(a.counter, 1u); wg_item[1] = 0; }
-        __syncthreads();
-        const uint32_t item = wg_item[0];
-        if (item >= nitems) break;
-        const uint2 it = a.items[item];
-        const uint32_t p = it.x;
-        if (p != cur_p) {
-            cur_p = p;
-            qa = qpairs[p].x; qb = qpairs[p].y;
-            const uint32_t LA = a.q_len[qa], LBq = qb != MUSW_NOQ ? a.q_len[qb] : 0u;
-            g = (max(LA, LBq) + MUSW2_R - 1) / MUSW2_R;
-            const uint8_t *QA = a.q_mu + a.q_off[qa], *QB = a.q_mu + (qb != MUSW_NOQ ? a.q_off[qb] : 0u);
-            const uint32_t per_c = g * 16;
-            for (uint32_t idx = tid; idx < 37 * per_c; idx += blockDim.x) {
-                const uint32_t c = idx / per_c, rem = idx - c * per_c;
-                const uint32_t k = rem / (g * 4), rem2 = rem - k * (g * 4);
-                const uint32_t sst = rem2 >> 2, w = rem2 & 3;
-                const uint32_t i = sst * MUSW2_R + 4 * k + w;
-                int va = MUSW_PADSCORE, vb = MUSW_PADSCORE;
-                if (c < 36 && i < LA) va = mat[c * 36 + QA[a.reverse ? (LA - 1 - i) : i]];
-                if (c < 36 && i < LBq) vb = mat[c * 36 + QB[a.reverse ? (LBq - 1 - i) : i]];
-                prof[((c * 4 + k) * GMAX + sst) * 4 + w] = (int) (musw_half_bits(va) | (musw_half_bits(vb) << 16));
-            }
-            __syncthreads();
-        }
-        const uint32_t ppw = 64 / g;                 // targets per wave, each against both queries
-        const uint32_t cnt = a.cnt[p];
-        const uint32_t chunk_end = min(cnt, it.y + ppw * nwaves * MUSW_CHUNK);
-        const uint32_t pr = lane / g, st = lane - pr * g;
-        for (;;) {
         uint32_t bq = 0;
         if (lane == 0) bq = atomicAdd(&wg_item[1], 1u);
         bq = (uint32_t) __builtin_amdgcn_readfirstlane((int) bq);
@@ -410,9 +382,9 @@ __global__ __launch_bounds__(1024) void k_mu_sw2(musw_args a, const uint2 *__res
 #pragma unroll
         for (int s = 32; s >= 1; s >>= 1) ncol = max(ncol, (uint32_t) __shfl_xor((int) ncol, s, 64));
         if (ncol == 0) continue;
-        int HA[16], HB[16], E[16];
+        int HA[R], HB[R], E[R];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { HA[r] = 0; HB[r] = 0; E[r] = 0; }
+        for (int r = 0; r < R; ++r) { HA[r] = 0; HB[r] = 0; E[r] = 0; }
         int best = 0;
         int bot_h = 0, bot_f = 0;      // bottom row of this strip at its previous step: H and the outgoing F
         int diag_in = 0;               // H above the top row at the previous column
@@ -423,28 +395,29 @@ __global__ __launch_bounds__(1024) void k_mu_sw2(musw_args a, const uint2 *__res
         const int top_mask = st == 0 ? 0 : -1;       // the first strip has nothing above it: H = F = 0
         musw_letters tl;
         tl.start(B, LB, -(int) st);                  // strip st is st columns behind strip 0
-        auto step = [&](const int (&Hin)[16], int (&Hout)[16], unsigned c) {
+        auto step = [&](const int (&Hin)[R], int (&Hout)[R], unsigned c) {
             const int up_h = dpp_wave_shr1_and(bot_h, top_mask), up_f = dpp_wave_shr1_and(bot_f, top_mask);
             const unsigned row = __umul24(c, RS) + lane_prof;
-            v4i P[4];
+            v4i P[NK];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) P[k] = *(const v4i __attribute__((address_space(3))) *) (uintptr_t) (row + k * kstride);
+            for (int k = 0; k < NK; ++k) P[k] = *(const v4i __attribute__((address_space(3))) *) (uintptr_t) (row + k * kstride);
             int diag = diag_in;
             int F = up_f;
             diag_in = up_h;
             int hprev = 0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            for (int r = 0; r < R; ++r) {
                 const int h = pk_max3h(pk_addh(diag, P[r >> 2][r & 3]), E[r], F);
                 diag = Hin[r];
                 Hout[r] = h;
                 if (r & 1) best = pk_max3h(best, hprev, h);
+                else if (r == R - 1) best = pk_max3h(best, h, h);          // odd R: the last row on its own
                 hprev = h;
                 const int ho = pk_addh(h, nopen2);
                 E[r] = pk_max3h_0(pk_addh(E[r], next2), ho);
                 F = pk_max3h_0(pk_addh(F, next2), ho);
             }
-            bot_h = Hout[15];
+            bot_h = Hout[R - 1];
             bot_f = F;
         };
         // a step count that is not a multiple of 4 is rounded up: the extra steps only see pad letters / finished columns
@@ -471,7 +444,66 @@ __global__ __launch_bounds__(1024) void k_mu_sw2(musw_args a, const uint2 *__res
                 if (qb != MUSW_NOQ) a.out[(size_t) qb * a.ldo + t] = vb;
             }
         }
-        }   // batches
+    }   // batches
+}
+
+// qgeom[p] = g | R << 8 of query pair p (musw2_geometry on the host)
+template <int GMAX>
+__global__ __launch_bounds__(1024) void k_mu_sw2(musw_args a, const uint2 *__restrict__ qpairs, const uint32_t *__restrict__ qgeom)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // dword (c, k, st, w) = row R*st + 4*k + w of query A (low half) and of query B (high half) against letter c:
+    // P[((c*4 + k)*GMAX + st)*4 + w]; a lane's b128 reads per letter row are conflict-free across the strips of a group
+    int *prof = (int *) smem;
+    signed char *mat = (signed char *) (prof + (size_t) 37 * GMAX * 16);
+    uint32_t *wg_item = (uint32_t *) (mat + 1312);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 1296; i += blockDim.x) mat[i] = (signed char) c_mu_int[i];
+    uint32_t cur_p = 0xFFFFFFFFu, qa = 0, qb = MUSW_NOQ, g = 1, R = MUSW2_RMAX;
+    const uint32_t nitems = *a.nitems;
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) { wg_item[0] = atomicAdd(a.counter, 1u); wg_item[1] = 0; }
+        __syncthreads();
+        const uint32_t item = wg_item[0];
+        if (item >= nitems) break;
+        const uint2 it = a.items[item];
+        const uint32_t p = it.x;
+        if (p != cur_p) {
+            cur_p = p;
+            qa = qpairs[p].x; qb = qpairs[p].y;
+            g = qgeom[p] & 0xFFu; R = qgeom[p] >> 8;
+            const uint32_t LA = a.q_len[qa], LBq = qb != MUSW_NOQ ? a.q_len[qb] : 0u;
+            const uint8_t *QA = a.q_mu + a.q_off[qa], *QB = a.q_mu + (qb != MUSW_NOQ ? a.q_off[qb] : 0u);
+            const uint32_t nk = (R + 3) / 4, per_c = g * nk * 4;
+            for (uint32_t idx = tid; idx < 37 * per_c; idx += blockDim.x) {
+                const uint32_t c = idx / per_c, rem = idx - c * per_c;
+                const uint32_t k = rem / (g * 4), rem2 = rem - k * (g * 4);
+                const uint32_t sst = rem2 >> 2, w = rem2 & 3;
+                const uint32_t i = sst * R + 4 * k + w;
+                const bool row = 4 * k + w < R;                      // rows beyond the strip's R: pad
+                int va = MUSW_PADSCORE, vb = MUSW_PADSCORE;
+                if (c < 36 && row && i < LA) va = mat[c * 36 + QA[a.reverse ? (LA - 1 - i) : i]];
+                if (c < 36 && row && i < LBq) vb = mat[c * 36 + QB[a.reverse ? (LBq - 1 - i) : i]];
+                prof[((c * 4 + k) * GMAX + sst) * 4 + w] = (int) (musw_half_bits(va) | (musw_half_bits(vb) << 16));
+            }
+            __syncthreads();
+        }
+        switch (R) {
+        case 4: musw2_batches<GMAX, 4>(a, it, p, qa, qb, g, prof, wg_item); break;
+        case 5: musw2_batches<GMAX, 5>(a, it, p, qa, qb, g, prof, wg_item); break;
+        case 6: musw2_batches<GMAX, 6>(a, it, p, qa, qb, g, prof, wg_item); break;
+        case 7: musw2_batches<GMAX, 7>(a, it, p, qa, qb, g, prof, wg_item); break;
+        case 8: musw2_batches<GMAX, 8>(a, it, p, qa, qb, g, prof, wg_item); break;
+        case 9: musw2_batches<GMAX, 9>(a, it, p, qa, qb, g, prof, wg_item); break;
+        case 10: musw2_batches<GMAX, 10>(a, it, p, qa, qb, g, prof, wg_item); break;
+        case 11: musw2_batches<GMAX, 11>(a, it, p, qa, qb, g, prof, wg_item); break;
+        case 12: musw2_batches<GMAX, 12>(a, it, p, qa, qb, g, prof, wg_item); break;
+        case 13: musw2_batches<GMAX, 13>(a, it, p, qa, qb, g, prof, wg_item); break;
+        case 14: musw2_batches<GMAX, 14>(a, it, p, qa, qb, g, prof, wg_item); break;
+        case 15: musw2_batches<GMAX, 15>(a, it, p, qa, qb, g, prof, wg_item); break;
+        default: musw2_batches<GMAX, 16>(a, it, p, qa, qb, g, prof, wg_item); break;
+        }
     }
 }
 
@@ -795,6 +827,30 @@ static uint32_t item_exact_implicit(const rsk_db *q, uint32_t nt, int self_trian
 // The dense forward pass through k_mu_sw2: queries of <= 1024 residues are paired in order of length (virtual query p =
 // (A, B), virtual length 2 * max(LA, LB): the work-item kernels and the class geometry of k_mu_sw apply unchanged), the rest
 // -- and nothing else -- goes through k_mu_sw.  base.cnt / base.first describe the implicit lists per REAL query.
+// (g, R) of a query pair of L residues for k_mu_sw2: between g0 = ceil(L / 16) strips and the next power of two (<= 64), with
+// R = ceil(L / g) rows each, the geometry of least modelled time per useful cell against a 174-residue target (the mean
+// of SCOP40): step cost (10 + 7.5 R) instructions for R rows, times the idle shares -- lanes 64 mod g, pad rows g R - L, the
+// g - 1 columns of skew.  RSK_MUSW2_FIXED_R=1: the r04 geometry (R = 16, g = g0).
+static void musw2_geometry(uint32_t L, uint32_t *g_out, uint32_t *R_out)
+{
+    static const bool fixed = getenv("RSK_MUSW2_FIXED_R") != nullptr;
+    const uint32_t g0 = (L + MUSW2_RMAX - 1) / MUSW2_RMAX;
+    uint32_t cand[2] = { g0, g0 };
+    uint32_t p2 = 1;
+    while (p2 < g0) p2 *= 2;
+    if (p2 <= 64) cand[1] = p2;
+    double best = 0;
+    uint32_t bg = g0, bR = MUSW2_RMAX;
+    for (int k = 0; k < (fixed ? 1 : 2); ++k) {
+        const uint32_t g = cand[k];
+        const uint32_t R = fixed ? (uint32_t) MUSW2_RMAX : std::max<uint32_t>(4, (L + g - 1) / g);
+        const double lanes = (double) ((64 / g) * g) / 64.0, rows = (double) L / ((double) g * R), cols = 174.0 / (174.0 + g - 1);
+        const double cost = (10.0 + 7.5 * R) / R / (lanes * rows * cols);
+        if (k == 0 || cost < best) { best = cost; bg = g; bR = R; }
+    }
+    *g_out = bg; *R_out = bR;
+}
+
 static int run_mu_sw_querypairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, musw_args base, int self_triangle, musw_ws &ws)
 {
     const uint32_t nq = q->n, nt = t->n;
@@ -802,7 +858,7 @@ static int run_mu_sw_querypairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, 
     for (uint32_t i = 0; i < nq; ++i) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return q->len[x] < q->len[y]; });   // == rsk_build_len_perm's order
     std::vector<uint2> qp;
-    std::vector<uint32_t> vlen, vcnt, vfirst, cnt_old(nq, 0);
+    std::vector<uint32_t> vlen, vcnt, vfirst, vgeom, cnt_old(nq, 0);
     bool any_old = false;
     uint64_t nitems_ub = 16;
     bool has_class[3] = { false, false, false };
@@ -811,11 +867,17 @@ static int run_mu_sw_querypairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, 
         if (q->len[A] > 1024) { cnt_old[A] = self_triangle ? nt - t->h_len_rank[A] : nt; any_old = true; ++k; continue; }
         uint32_t Bq = MUSW_NOQ;
         if (k + 1 < nq && q->len[order[k + 1]] <= 1024) Bq = order[k + 1];
-        const uint32_t L = std::max(q->len[A], Bq != MUSW_NOQ ? q->len[Bq] : 0u), vl = 2 * std::max(L, 1u);
+        const uint32_t L = std::max(q->len[A], Bq != MUSW_NOQ ? q->len[Bq] : 0u);
+        uint32_t g, R;
+        musw2_geometry(std::max(L, 1u), &g, &R);
+        // the work-item kernels derive a query's strips from its length as ceil(length / 32): the pair's "virtual length" 32 g
+        // gives them the g chosen here (classes, waves per workgroup and LDS sizes follow from it as for k_mu_sw)
+        const uint32_t vl = MUSW_R * g;
         const uint32_t c = self_triangle ? nt - t->h_len_rank[A] : nt;
         qp.push_back(make_uint2(A, Bq));
         vlen.push_back(vl); vcnt.push_back(c); vfirst.push_back(self_triangle ? t->h_len_rank[A] : 0u);
-        const uint32_t g = (vl + MUSW_R - 1) / MUSW_R, lp = g * MUSW_R;
+        vgeom.push_back(g | (R << 8));
+        const uint32_t lp = g * MUSW_R;
         const int cls = lp <= 416 ? 0 : lp <= 1024 ? 1 : 2;
         has_class[cls] = true;
         const uint32_t per_wg = (64 / g) * musw_class_waves[cls] * MUSW_CHUNK;
@@ -826,9 +888,9 @@ static int run_mu_sw_querypairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, 
     const uint32_t npv = (uint32_t) qp.size();
     if (npv) {
         uint2 *d_qp = nullptr;
-        uint32_t *d_vlen = nullptr, *d_vcnt = nullptr, *d_vfirst = nullptr;
+        uint32_t *d_vlen = nullptr, *d_vcnt = nullptr, *d_vfirst = nullptr, *d_vgeom = nullptr;
         if ((rc = ws.alloc(&d_qp, npv)) != RSK_OK || (rc = ws.alloc(&d_vlen, npv)) != RSK_OK || (rc = ws.alloc(&d_vcnt, npv)) != RSK_OK ||
-            (rc = ws.alloc(&d_vfirst, npv)) != RSK_OK)
+            (rc = ws.alloc(&d_vfirst, npv)) != RSK_OK || (rc = ws.alloc(&d_vgeom, npv)) != RSK_OK)
             return rc;
         if ((rc = ws.alloc(&ws.item_start, (size_t) nq + 1)) != RSK_OK || (rc = ws.alloc(&ws.nitems, 1)) != RSK_OK ||
             (rc = ws.alloc(&ws.counter, 1)) != RSK_OK || (rc = ws.alloc(&ws.items, (size_t) std::min<uint64_t>(nitems_ub, 0xFFFFFFF0ull))) != RSK_OK)
@@ -839,6 +901,7 @@ static int run_mu_sw_querypairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, 
         RSK_HIP(hipMemcpy(d_vlen, vlen.data(), (size_t) npv * 4, hipMemcpyHostToDevice));
         RSK_HIP(hipMemcpy(d_vcnt, vcnt.data(), (size_t) npv * 4, hipMemcpyHostToDevice));
         RSK_HIP(hipMemcpy(d_vfirst, vfirst.data(), (size_t) npv * 4, hipMemcpyHostToDevice));
+        RSK_HIP(hipMemcpy(d_vgeom, vgeom.data(), (size_t) npv * 4, hipMemcpyHostToDevice));
         for (int cls = 0; cls < MUSW_NCLASS; ++cls) {
             if (!has_class[cls]) continue;
             RSK_HIP(hipMemsetAsync(ws.counter, 0, 4, ctx->stream));
@@ -862,9 +925,9 @@ static int run_mu_sw_querypairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, 
             const int wg_per_cu = std::max(1, std::min<int>(20 / (int) waves, (int) (163840 / lds)));
             static_assert(MUSW_NCLASS == 3, "one k_mu_sw2 instance per class");
             const dim3 grid(ctx->num_cus * wg_per_cu), block(64 * waves);
-            if (gmax == 13) hipLaunchKernelGGL(k_mu_sw2<13>, grid, block, lds, ctx->stream, a, (const uint2 *) d_qp);
-            else if (gmax == 32) hipLaunchKernelGGL(k_mu_sw2<32>, grid, block, lds, ctx->stream, a, (const uint2 *) d_qp);
-            else hipLaunchKernelGGL(k_mu_sw2<64>, grid, block, lds, ctx->stream, a, (const uint2 *) d_qp);
+            if (gmax == 13) hipLaunchKernelGGL(k_mu_sw2<13>, grid, block, lds, ctx->stream, a, (const uint2 *) d_qp, (const uint32_t *) d_vgeom);
+            else if (gmax == 32) hipLaunchKernelGGL(k_mu_sw2<32>, grid, block, lds, ctx->stream, a, (const uint2 *) d_qp, (const uint32_t *) d_vgeom);
+            else hipLaunchKernelGGL(k_mu_sw2<64>, grid, block, lds, ctx->stream, a, (const uint2 *) d_qp, (const uint32_t *) d_vgeom);
             RSK_HIP(hipGetLastError());
         }
     }
