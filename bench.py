@@ -429,7 +429,7 @@ def live_kernels(ctx, seqs, db, reps=3):
     order = np.random.default_rng(4).permutation(n)[:nq].astype(np.uint32)
     qa = np.repeat(order, n)
     qb = np.tile(np.arange(n, dtype=np.uint32), nq)
-    res.append(sw_entry("k_sw_qp", "float SW + trace, %d queries x %d chains (query-profile kernel)" % (nq, n), qa, qb, 0.0, 19.5, False))      # 234 VALU instructions per 12-row step in the ISA of the hot loop (R = 12 instance of the r05 8-lane geometry: 18 per cell for the recurrence, the five comparisons and the best cell + ~18 per step; r04: 254, r04b: 278)
+    res.append(sw_entry("k_sw_qp", "float SW + trace, %d queries x %d chains (query-profile kernel)" % (nq, n), qa, qb, 0.0, 21.2, False))      # 254 VALU instructions per 12-row column in the ISA of the hot loop (R = 12 instance: 18.5 per cell for the recurrence, trace masks and best cell + ~32 per step; r04b: 278)
     dbs.close()
     del out8, pq, pt
     torch.cuda.empty_cache()

@@ -827,26 +827,27 @@ static uint32_t item_exact_implicit(const rsk_db *q, uint32_t nt, int self_trian
 // The dense forward pass through k_mu_sw2: queries of <= 1024 residues are paired in order of length (virtual query p =
 // (A, B), virtual length 2 * max(LA, LB): the work-item kernels and the class geometry of k_mu_sw apply unchanged), the rest
 // -- and nothing else -- goes through k_mu_sw.  base.cnt / base.first describe the implicit lists per REAL query.
-// (g, R) of a query pair of L residues for k_mu_sw2: between g0 = ceil(L / 16) strips and the next power of two (<= 64), with
-// R = ceil(L / g) rows each, the geometry of least modelled time per useful cell against a 174-residue target (the mean
-// of SCOP40): step cost (10 + 7.5 R) instructions for R rows, times the idle shares -- lanes 64 mod g, pad rows g R - L, the
-// g - 1 columns of skew.  RSK_MUSW2_FIXED_R=1: the r04 geometry (R = 16, g = g0).
+// (g, R) of a query pair of L residues for k_mu_sw2: among g = ceil(L / 16) .. 64 strips of R = ceil(L / g) rows each, the
+// geometry of least modelled time per useful cell against a 174-residue target (the mean of SCOP40): step cost (8 + 7.5 R)
+// instructions for R rows, times the idle shares -- lanes 64 mod g, pad rows g R - L, the g - 1 columns of skew.
+// RSK_MUSW2_FIXED_R=1: the r04 geometry (R = 16, g = g0).
 static void musw2_geometry(uint32_t L, uint32_t *g_out, uint32_t *R_out)
 {
     static const bool fixed = getenv("RSK_MUSW2_FIXED_R") != nullptr;
+    static const bool pow2_only = getenv("RSK_MUSW2_POW2") != nullptr;      // r05a: g0 or the next power of two only
     const uint32_t g0 = (L + MUSW2_RMAX - 1) / MUSW2_RMAX;
-    uint32_t cand[2] = { g0, g0 };
     uint32_t p2 = 1;
     while (p2 < g0) p2 *= 2;
-    if (p2 <= 64) cand[1] = p2;
     double best = 0;
     uint32_t bg = g0, bR = MUSW2_RMAX;
-    for (int k = 0; k < (fixed ? 1 : 2); ++k) {
-        const uint32_t g = cand[k];
+    for (uint32_t g = g0; g <= 64; ++g) {
+        if (fixed && g != g0) break;
+        if (pow2_only && g != g0 && g != p2) continue;
         const uint32_t R = fixed ? (uint32_t) MUSW2_RMAX : std::max<uint32_t>(4, (L + g - 1) / g);
         const double lanes = (double) ((64 / g) * g) / 64.0, rows = (double) L / ((double) g * R), cols = 174.0 / (174.0 + g - 1);
-        const double cost = (10.0 + 7.5 * R) / R / (lanes * rows * cols);
-        if (k == 0 || cost < best) { best = cost; bg = g; bR = R; }
+        const double cost = (8.0 + 7.5 * R) / R / (lanes * rows * cols);
+        if (g == g0 || cost < best) { best = cost; bg = g; bR = R; }
+        if (R == 4) break;
     }
     *g_out = bg; *R_out = bR;
 }

@@ -369,20 +369,15 @@ __global__ __launch_bounds__(64 * SWF_WAVES) __attribute__((amdgpu_waves_per_eu(
 // the kernel ran at the HBM's random-line rate.  For the writer the row offsets are immediates either way.
 // ---------------------------------------------------------------------------------------------
 #define SWQ_RMIN 4
-#ifndef SWQ_RMAX
 #define SWQ_RMAX 12
-#endif
-#define SWQ_GS 8                                   // lanes (strips per pass) of a pair
-#define SWQ_SLOTS 16                               // 16-byte slots of a profile row per quad: two copies of the pass's 8 strips = one 256-byte bank row
+#define SWQ_GS 16                                  // lanes (strips per pass) of a pair
 #define SWQ_NPW (64 / SWQ_GS)                      // pairs per wave batch
 #define SWQ_NQ(R) (((R) + 3) / 4)                  // ds_read_b128 per feature and step
-#define SWQ_NPF(R) 1                               // passes per LDS profile
+#define SWQ_NPF(R) (4 / SWQ_NQ(R))                 // passes per LDS profile
 #define SWQ_COLB(R) ((R) * 32)                     // trace of one (step - row) column of a wave batch: R rows x 4 masks of 64 lanes
-#ifndef SWQ_NW
-#define SWQ_NW 16                                  // waves per workgroup: 4 per SIMD, <= 128 VGPRs
-#endif
+#define SWQ_NW 16
 #define SWQ_NFC 132                               // 20 + 7 * 16 (feature, step letter) combinations
-#define SWQ_LDS_BYTES ((size_t) SWQ_NFC * 4 * SWQ_SLOTS * 16 + 16)
+#define SWQ_LDS_BYTES ((size_t) SWQ_NFC * 4 * SWQ_GS * 16 + 16)
 
 // one workgroup item: `count` consecutive pairs (sorted order) of one group, R rows per lane.
 // A wave batch is 4 pairs, 16 lanes each; pass k covers the strips [16k, 16k + 16), the rows of consecutive passes meet
@@ -415,7 +410,7 @@ struct swq_item { uint32_t first, count, ncol, R; uint64_t tb_base; };
 #ifndef SWQ_EXPERIMENT_NO_BEST
 #define SWQ_BEST64(acc, xm, xc, s, nj) \
     asm volatile("v_add_f32_e32 v127, %2, %3\n\tv_max_f64 %0, %0, v[126:127]" : "+v"(acc), "={v127}"(xm) : "v"(xc), "v"(s), "{v126}"(nj))
-#else   // timing experiment only (tools/exp): what the 64-bit maximum costs (results are wrong: no best cell)
+#else   // timing experiment only (tools/exp/swq_pmc.sh): what the 64-bit maximum costs (results are wrong: no best cell)
 #define SWQ_BEST64(acc, xm, xc, s, nj) \
     asm volatile("v_add_f32_e32 v127, %2, %3" : "+v"(acc), "={v127}"(xm) : "v"(xc), "v"(s), "{v126}"(nj))
 #endif
@@ -424,26 +419,17 @@ typedef float swq_v2f __attribute__((ext_vector_type(2)));
 typedef float swq_v4f __attribute__((ext_vector_type(4)));
 typedef const volatile __attribute__((address_space(3))) swq_v4f *swq_ldsp;   // volatile: see the fetch in swq_group
 
-#ifdef SWQ_PROFILE   // timing experiment (tools/exp): where a wave's residency goes, in 10 ns ticks of the constant clock
-__device__ unsigned long long g_swq_prof[16];        // 0 wave total, 1 fill + barriers, 2 batches, 3 step loops, 4 waves, 5 item switches (time), 6 (count), 7 min start, 8 max end, 10 wgs
-#define SWQ_PROF_T() wall_clock64()
-#define SWQ_PROF_ADD(k, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_swq_prof[k], (unsigned long long) (v)); } while (0)
-#else
-#define SWQ_PROF_T() 0ull
-#define SWQ_PROF_ADD(k, v) do { } while (0)
-#endif
-
 template <bool T, int R>
 __device__ __forceinline__ void swq_group(const swf_args &a, const swq_item &it, float4 *qp4)
 {
     constexpr int NQ = SWQ_NQ(R), NPF = SWQ_NPF(R), G = SWQ_GS * NPF, COLB = SWQ_COLB(R);
-    constexpr uint32_t ROWB = NQ * SWQ_SLOTS * 16;   // bytes of a (f, c) row: a multiple of 256
+    constexpr uint32_t ROWB = NQ * G * 16;           // bytes of a (f, c) row: a multiple of 256
     const uint32_t strip_chain = T ? a.ib[it.first] : a.ia[it.first];
     const uint32_t LA = T ? a.b_len[strip_chain] : a.a_len[strip_chain];     // strip chain length
     const uint32_t gtot = (LA + R - 1) / R;        // strips of the whole chain
     const uint32_t nseg = (gtot + G - 1) / G;
     const uint32_t nbatch = (it.count + SWQ_NPW - 1) / SWQ_NPW;
-    uint32_t *next_batch = (uint32_t *) (qp4 + (size_t) SWQ_NFC * 4 * SWQ_SLOTS);
+    uint32_t *next_batch = (uint32_t *) (qp4 + (size_t) SWQ_NFC * 4 * SWQ_GS);
     const int lane = threadIdx.x & 63;
     const uint32_t pr = lane / SWQ_GS, st = lane % SWQ_GS;
     const float Open = a.open, Ext = a.ext;
@@ -454,7 +440,6 @@ __device__ __forceinline__ void swq_group(const swf_args &a, const swq_item &it,
     // this workgroup only -- an item runs on one CU, whose L1 is write-through and sees its own stores -- so they are plain
     // loads and stores ordered by s_waitcnt / the barrier.  (Agent-scope accesses go past the XCD's L2 on this part: measured, 31 ms instead of 23 for the 64-query
     // benchmark once most groups ran in two passes.)
-    const unsigned long long pt_fill0 = SWQ_PROF_T();
     if (seg) { __threadfence_block(); __syncthreads(); }
     {
         const uint8_t *sp = T ? (a.b_prof + a.b_off[strip_chain]) : (a.a_prof + a.a_off[strip_chain]);
@@ -462,40 +447,30 @@ __device__ __forceinline__ void swq_group(const swf_args &a, const swq_item &it,
         // float4 ((fc * NQ + quad) * G + strip) holds residues (sbase + strip) * R + quad * 4 + 0..3 of row fc: the
         // ds_read_b128 of the lanes of a pair are 16 B apart, and the NQ quads of a lane sit at immediate offsets
         // (quad * G * 16 B) from one address.  One record per thread and iteration.
-        // one thread per (row, quad, strip) record: the four letters (index clamped into the chain: no branch between the loads),
-        // the four table entries, then the pad selects; the record goes to both copies of the strip
-        const uint32_t per_fc = NQ * SWQ_GS, tot = SWQ_NFC * per_fc;
-#pragma unroll 2
+        const uint32_t per_fc = NQ * g, tot = SWQ_NFC * per_fc;
         for (uint32_t idx = threadIdx.x; idx < tot; idx += blockDim.x) {
             const uint32_t fc = idx / per_fc, rem = idx - fc * per_fc;
-            const uint32_t quad = rem / SWQ_GS, strip = rem % SWQ_GS;
+            const uint32_t quad = rem / g, strip = rem - quad * g;
             const uint32_t i = (sbase + strip) * R + quad * 4;
             const uint32_t f = fc < 20 ? 0 : ((fc - 20) >> 4) + 1;
             const uint32_t c = fc < 20 ? fc : ((fc - 20) & 15);
             const uint32_t as = f == 0 ? 20 : 16, tof = f == 0 ? 0 : 400 + (f - 1) * 256;
             const float padv = f == 0 ? -1e30f : 0.0f;      // rows below the chain end: S = -1e30, never a maximum
-            const uint8_t *fp = sp + (size_t) f * snpad;
-            uint32_t letter[4];
+            float v[4] = { padv, padv, padv, padv };
 #pragma unroll
-            for (int w = 0; w < 4; ++w) letter[w] = fp[min(i + w, LA - 1)];
-            float v[4];
-#pragma unroll
-            for (int w = 0; w < 4; ++w) v[w] = c_swf_tables.t[tof + (T ? c * as + letter[w] : letter[w] * as + c)];
-#pragma unroll
-            for (int w = 0; w < 4; ++w)
-                if (!(quad * 4 + w < (uint32_t) R && i + w < LA)) v[w] = padv;
-            const float4 rec4 = make_float4(v[0], v[1], v[2], v[3]);
-            float4 *dst = qp4 + (fc * NQ + quad) * SWQ_SLOTS + strip;
-            dst[0] = rec4;
-            dst[SWQ_GS] = rec4;
+            for (int w = 0; w < 4; ++w) {
+                if (quad * 4 + w < (uint32_t) R && i + w < LA) {
+                    const uint32_t letter = sp[(size_t) f * snpad + i + w];
+                    v[w] = c_swf_tables.t[tof + (T ? c * as + letter : letter * as + c)];
+                }
+            }
+            qp4[(fc * NQ + quad) * G + strip] = make_float4(v[0], v[1], v[2], v[3]);
         }
         if (threadIdx.x == 0) *next_batch = 0;
     }
     __syncthreads();
-    SWQ_PROF_ADD(1, SWQ_PROF_T() - pt_fill0);
     const uint32_t npass = (g + SWQ_GS - 1) / SWQ_GS;      // passes of this segment
     for (;;) {
-        const unsigned long long pt_b0 = SWQ_PROF_T();
         uint32_t b = 0;
         if (lane == 0) b = atomicAdd(next_batch, 1u);
         b = (uint32_t) __builtin_amdgcn_readfirstlane((int) b);
@@ -518,7 +493,7 @@ __device__ __forceinline__ void swq_group(const swf_args &a, const swq_item &it,
         const bool on = active && st < gl;
         const uint32_t i0 = (sbase + sp) * R;
         // this lane's float4 slot within a quad block, as an LDS byte address (and the same from feature 4's first row on)
-        const uint32_t qpl_lo = (uint32_t) (uintptr_t) ((swq_ldsp) qp4 + sp + ((pr >> 1) & 1u) * SWQ_GS);
+        const uint32_t qpl_lo = (uint32_t) (uintptr_t) ((swq_ldsp) qp4 + sp);
         const uint32_t qpl_hi = qpl_lo + (20 + 3 * 16) * ROWB;
         const bool first = seg == 0 && pass == 0;                        // the pass that holds row 0
         const bool last = sbase + pass * SWQ_GS + gl >= gtot;            // ... the last row
@@ -558,7 +533,6 @@ __device__ __forceinline__ void swq_group(const swf_args &a, const swq_item &it,
         const long long *bsrc = first ? (const long long *) (a.tb_off + p) : bnd2 + (size_t) ((gpass & 1) ^ 1) * LB;
         long long bnn = *bsrc;                     // boundary word of strip 0's column `col`
 
-        const unsigned long long pt_s0 = SWQ_PROF_T();
         for (uint32_t col = 0; col < ncol; ++col) {
             const int j = (int) col - (int) st;
             float in_m = dpp_shr1_f(hand_m);
@@ -598,27 +572,12 @@ __device__ __forceinline__ void swq_group(const swf_args &a, const swq_item &it,
                 float xc_p = 0.0f, S_p = 0.0f;                           // the row above: its best-cell update is still to come
                 const uint32_t nj = ~(uint32_t) j;
                 const unsigned long long *tcol = (const unsigned long long *) ((const char *) tblk + (size_t) col * COLB);
-                // volatile keeps each fetch one ds_read_b128 (the SLP vectoriser would split it into b64 halves) and in source
-                // order among the volatile asm statements of the rows: the fetch of quad q + 1 is issued BEFORE the rows of
-                // quad q, so that its LDS latency (and the drain of the scalar stores, which share lgkmcnt) runs under them
-                swq_v4f vb[2][8];
-#pragma unroll
-                for (int f = 0; f < 8; ++f) vb[0][f] = rec[f][0];
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
-#ifndef SWQ_NO_PREFETCH
-                    if (q + 1 < NQ) {
+                    // volatile keeps each fetch one ds_read_b128 (the SLP vectoriser would split it into b64 halves)
+                    swq_v4f v[8];
 #pragma unroll
-                        for (int f = 0; f < 8; ++f) vb[(q + 1) & 1][f] = rec[f][(q + 1) * SWQ_SLOTS];
-                    }
-                    swq_v4f *v = vb[q & 1];
-#else
-                    swq_v4f *v = vb[0];
-                    if (q > 0) {
-#pragma unroll
-                        for (int f = 0; f < 8; ++f) v[f] = rec[f][q * SWQ_SLOTS];
-                    }
-#endif
+                    for (int f = 0; f < 8; ++f) v[f] = rec[f][q * G];
                     swq_v2f Slo = v[0].lo, Shi = v[0].hi;              // v_pk_add_f32: two residues per add
 #pragma unroll
                     for (int f = 1; f < 8; ++f) {
@@ -674,7 +633,6 @@ __device__ __forceinline__ void swq_group(const swf_args &a, const swq_item &it,
             }
             carry_in = in_m;
         }
-        SWQ_PROF_ADD(3, SWQ_PROF_T() - pt_s0);
         if (!last && writes_bnd && on && LB > 0)   // the bottom row of the last column
             bnd[LB - 1] = (long long) ((unsigned long long) (uint32_t) __builtin_bit_cast(int, hand_m) |
                                        ((unsigned long long) (uint32_t) __builtin_bit_cast(int, hand_d) << 32));
@@ -719,7 +677,6 @@ __device__ __forceinline__ void swq_group(const swf_args &a, const swq_item &it,
             a.besti[p] = bi;
             a.bestj[p] = bj;
         }
-        SWQ_PROF_ADD(2, SWQ_PROF_T() - pt_b0);
     }
     }
 }
@@ -728,58 +685,22 @@ __device__ __forceinline__ void swq_group(const swf_args &a, const swq_item &it,
 // that one launch per orientation covers all the groups of a call -- a launch per R would end in nine tails of
 // one-workgroup-per-CU items.
 template <bool T>
-__global__ __launch_bounds__(64 * SWQ_NW) void k_sw_qp(swf_args a, const swq_item *items, uint32_t nitems, uint32_t *next_item)
+__global__ __launch_bounds__(64 * SWQ_NW) void k_sw_qp(swf_args a, const swq_item *items)
 {
-    // Persistent workgroups: the launch has one workgroup per CU (the LDS profile allows no second one), each takes item
-    // blockIdx.x and then claims further items, longest first, from a global counter.  (One workgroup per item left a CU
-    // idle for ~100 us between the last wave of an item and the first wave of the next: 7.5 % of the 64 x 11,211 benchmark.)
     extern __shared__ float4 qp4[];
-    uint32_t *claim = (uint32_t *) (qp4 + (size_t) SWQ_NFC * 4 * SWQ_SLOTS) + 1;
-#ifdef SWQ_PROFILE
-    const unsigned long long pt_w0 = SWQ_PROF_T();
-    if (threadIdx.x == 0) { atomicMin(&g_swq_prof[7], pt_w0); atomicAdd(&g_swq_prof[10], 1ull); }
-#endif
-    uint32_t k = blockIdx.x;
-    for (;;) {
-        const swq_item it = items[k];
-        switch (it.R) {
-        case 4: swq_group<T, 4>(a, it, qp4); break;
-        case 5: swq_group<T, 5>(a, it, qp4); break;
-        case 6: swq_group<T, 6>(a, it, qp4); break;
-        case 7: swq_group<T, 7>(a, it, qp4); break;
-        case 8: swq_group<T, 8>(a, it, qp4); break;
-        case 9: swq_group<T, 9>(a, it, qp4); break;
-        case 10: swq_group<T, 10>(a, it, qp4); break;
-        case 11: swq_group<T, 11>(a, it, qp4); break;
-        case 12: swq_group<T, 12>(a, it, qp4); break;
-#if SWQ_RMAX > 12
-        case 13: swq_group<T, 13>(a, it, qp4); break;
-        case 14: swq_group<T, 14>(a, it, qp4); break;
-        case 15: swq_group<T, 15>(a, it, qp4); break;
-        case 16: swq_group<T, 16>(a, it, qp4); break;
-#endif
-        default: break;
-        }
-        const unsigned long long pt_c0 = SWQ_PROF_T();
-        // every wave is done with this item's profile (and has read the previous claim) before the next one is taken
-        __threadfence_block();
-        __syncthreads();
-        if (threadIdx.x == 0) *claim = atomicAdd(next_item, 1u) + gridDim.x;
-        __syncthreads();
-        k = *claim;
-        SWQ_PROF_ADD(5, SWQ_PROF_T() - pt_c0);
-        SWQ_PROF_ADD(6, 1);
-        if (k >= nitems) break;
+    const swq_item it = items[blockIdx.x];
+    switch (it.R) {
+    case 4: swq_group<T, 4>(a, it, qp4); break;
+    case 5: swq_group<T, 5>(a, it, qp4); break;
+    case 6: swq_group<T, 6>(a, it, qp4); break;
+    case 7: swq_group<T, 7>(a, it, qp4); break;
+    case 8: swq_group<T, 8>(a, it, qp4); break;
+    case 9: swq_group<T, 9>(a, it, qp4); break;
+    case 10: swq_group<T, 10>(a, it, qp4); break;
+    case 11: swq_group<T, 11>(a, it, qp4); break;
+    default: swq_group<T, 12>(a, it, qp4); break;
     }
     asm volatile("s_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory");     // the trace masks sit in the scalar data cache
-#ifdef SWQ_PROFILE
-    {
-        const unsigned long long pt_w1 = SWQ_PROF_T();
-        SWQ_PROF_ADD(0, pt_w1 - pt_w0);
-        SWQ_PROF_ADD(4, 1);
-        if ((threadIdx.x & 63) == 0) atomicMax(&g_swq_prof[8], pt_w1);
-    }
-#endif
 }
 
 // TraceBackBitSW sw.cpp:8-77.  One thread per pair; path chars are written backwards into
@@ -1308,7 +1229,7 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
     const uint32_t min_lanes = getenv("RSK_SWQ_MIN_LANES") ? (uint32_t) atoi(getenv("RSK_SWQ_MIN_LANES")) : 4096;
     auto qp_bucket = [&](uint32_t count, uint32_t L) -> int {
         if (L == 0) return -1;
-        return (uint64_t) count * 16 >= min_lanes ? 0 : -1;
+        return (uint64_t) count * SWQ_GS >= min_lanes ? 0 : -1;
     };
     auto qp_ok = [&](uint32_t count, uint32_t L) { return qp_bucket(count, L) >= 0; };
     std::vector<uint32_t> cntA(dba->n, 0), cntB;
@@ -1372,7 +1293,7 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
     swf_blob hb;
     const size_t o_ia = hb.add(npairs * 4), o_ib = hb.add(npairs * 4), o_slot = hb.add(npairs * 4);
     const size_t o_tboff = hb.add((npairs + 1) * 8), o_pend = hb.add(npairs * 8), o_scoff = hb.add((npairs + 1) * 8);
-    const size_t o_bndoff = hb.add((npairs + 1) * 8), o_qpitem = hb.add(npairs * 4), o_qnext = hb.add(16);
+    const size_t o_bndoff = hb.add((npairs + 1) * 8), o_qpitem = hb.add(npairs * 4);
     std::vector<swq_item> qitems[2];
     std::vector<swf_item> items;
     uint32_t nitems_normal = 0;
@@ -1404,8 +1325,7 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
                     if (P == Pmin || cost < best_cost) { best_cost = cost; R = cand; }
                 }
             }
-            static const size_t chunk_mult = getenv("RSK_SWQ_CHUNK") ? (size_t) std::max(1, atoi(getenv("RSK_SWQ_CHUNK"))) : 2;
-            const size_t chunk = (size_t) SWQ_NPW * SWQ_NW * chunk_mult;
+            const size_t chunk = (size_t) SWQ_NPW * SWQ_NW * 2;
             for (size_t s = k; s < e; s += chunk) qitems[c].push_back(swq_item{ (uint32_t) s, (uint32_t) std::min(chunk, e - s), 0, R, 0 });
             k = e;
         }
@@ -1451,7 +1371,6 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
     uint64_t *tb_off = (uint64_t *) (H + o_tboff), *path_end = (uint64_t *) (H + o_pend), *sc_off = (uint64_t *) (H + o_scoff);
     uint64_t *bnd_off = (uint64_t *) (H + o_bndoff);
     uint32_t *qp_item = (uint32_t *) (H + o_qpitem);
-    memset(H + o_qnext, 0, 16);
     uint64_t tbo = 0, pe = 0, so = 0, bno = 0, cells = 0;
     // trace blocks of the query-profile items: one block of ncol columns per (segment, wave batch), see swq_item
     for (int c = 0; c < 2; ++c)
@@ -1540,7 +1459,6 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
     uint32_t *d_ia = (uint32_t *) (D + o_ia), *d_ib = (uint32_t *) (D + o_ib), *d_slot = (uint32_t *) (D + o_slot);
     uint64_t *d_tboff = (uint64_t *) (D + o_tboff), *d_pend = (uint64_t *) (D + o_pend), *d_scoff = (uint64_t *) (D + o_scoff);
     uint64_t *d_bndoff = (uint64_t *) (D + o_bndoff);
-    uint32_t *d_qnext = (uint32_t *) (D + o_qnext);            // item counters of the two k_sw_qp launches (zero in the staged blob)
     // device results: one blob, copied back in one piece
     swf_blob rb;
     const size_t r_score = rb.add(npairs * 4), r_loa = rb.add(npairs * 4), r_lob = rb.add(npairs * 4), r_plen = rb.add(npairs * 4);
@@ -1587,33 +1505,13 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
         });
         if (arc != RSK_OK) return arc;
     }
-#ifdef SWQ_PROFILE
-    {
-        unsigned long long z[16] = {};
-        z[7] = ~0ull;
-        RSK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_swq_prof), z, sizeof(z)));
-    }
-#endif
     for (int c = 0; c < 2; ++c) {
         if (qitems[c].empty()) continue;
         const swq_item *d_q = (const swq_item *) (D + o_q[c]);
-        const uint32_t nit = (uint32_t) qitems[c].size();
-        const dim3 grid(std::min<uint32_t>(nit, (uint32_t) std::max(1, ctx->num_cus))), block(64 * SWQ_NW);
-        if (c == 0) hipLaunchKernelGGL(k_sw_qp<false>, grid, block, SWQ_LDS_BYTES, ctx->stream, a, d_q, nit, d_qnext + c);
-        else hipLaunchKernelGGL(k_sw_qp<true>, grid, block, SWQ_LDS_BYTES, ctx->stream, a, d_q, nit, d_qnext + c);
+        const dim3 grid((unsigned) qitems[c].size()), block(64 * SWQ_NW);
+        if (c == 0) hipLaunchKernelGGL(k_sw_qp<false>, grid, block, SWQ_LDS_BYTES, ctx->stream, a, d_q);
+        else hipLaunchKernelGGL(k_sw_qp<true>, grid, block, SWQ_LDS_BYTES, ctx->stream, a, d_q);
     }
-#ifdef SWQ_PROFILE
-    {
-        unsigned long long z[16];
-        RSK_HIP(hipStreamSynchronize(ctx->stream));
-        RSK_HIP(hipMemcpyFromSymbol(z, HIP_SYMBOL(g_swq_prof), sizeof(z)));
-        const double wall = (double) (z[8] - z[7]) * 1e-5, nw = (double) std::max<unsigned long long>(z[4], 1);
-        fprintf(stderr, "[swq_prof] wall %.3f ms; %llu wgs, %llu waves, %llu item switches; per-wave sums / (waves x wall): fill+barrier %.4f batches %.4f "
-                "steps %.4f item switch %.4f; wave residency %.3f\n",
-                wall, z[10], z[4], z[6], z[1] * 1e-5 / (nw * wall), z[2] * 1e-5 / (nw * wall), z[3] * 1e-5 / (nw * wall), z[5] * 1e-5 / (nw * wall),
-                z[0] * 1e-5 / (nw * wall));
-    }
-#endif
     if (nitems_normal) {
         a.nitems = nitems_normal;
         hipLaunchKernelGGL(k_sw_float<false>, dim3((a.nitems + SWF_WAVES - 1) / SWF_WAVES), dim3(64 * SWF_WAVES), 0, ctx->stream, a, 0u);
