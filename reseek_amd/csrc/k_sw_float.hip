@@ -837,7 +837,8 @@ __global__ __launch_bounds__(256) void k_lddt(const char *paths, const uint64_t 
                                               const float *bx, const float *by, const float *bz,
                                               uint32_t npairs, uint32_t *scratch_pos, const uint64_t *scratch_off,
                                               float *frac_scratch, float *lddt_out, uint32_t *counts_out,
-                                              const float *score, float min_fwd_score, const uint8_t *a_seq, const uint8_t *b_seq)
+                                              const float *score, float min_fwd_score, const uint8_t *a_seq, const uint8_t *b_seq,
+                                              uint32_t *long_cnt, uint32_t *long_list)
 {
     // per wave: coordinates of A and B at the aligned columns ({ax, ay, az, bx} / {by, bz}) and per-column counters
     // (considered | preserved << 16; at most 4 * 255 each)
@@ -869,6 +870,13 @@ __global__ __launch_bounds__(256) void k_lddt(const char *paths, const uint64_t 
     // anyway (the host then needs neither chain's sequence for the pctid column)
     const uint8_t *SA = a_seq ? a_seq + a_off[ia[p]] : nullptr, *SB = b_seq ? b_seq + b_off[ib[p]] : nullptr;
     const unsigned long long lt = (1ull << lane) - 1ull;
+    const float *AX = ax + a_off[ia[p]], *AY = ay + a_off[ia[p]], *AZ = az + a_off[ia[p]];
+    const float *BX = bx + b_off[ib[p]], *BY = by + b_off[ib[p]], *BZ = bz + b_off[ib[p]];
+    // A path of at most LDDT_LDS_COLS characters has at most that many M columns: their coordinates go straight into the
+    // wave's staging while the path is expanded (r01-r04 wrote the column positions to scratch, fenced, and read them back
+    // for the staging loop: two dependent global round trips per pair).  Longer paths keep the scratch lists, which
+    // k_lddt_long reads.
+    const bool direct = len <= LDDT_LDS_COLS;
     for (uint32_t base = 0; base < len; base += 64) {
         const uint32_t c = base + lane;
         const char ch = c < len ? P[c] : 0;
@@ -876,9 +884,16 @@ __global__ __launch_bounds__(256) void k_lddt(const char *paths, const uint64_t 
         bool same = false;
         if (ch == 'M') {
             const uint32_t kM = nM + (uint32_t) __popcll(mM & lt), kD = nD + (uint32_t) __popcll(mD & lt), kI = nI + (uint32_t) __popcll(mI & lt);
-            posA[kM] = la0 + kM + kD;
-            posB[kM] = lb0 + kM + kI;
-            if (SA && SB) same = SA[la0 + kM + kD] == SB[lb0 + kM + kI];
+            const uint32_t a1 = la0 + kM + kD, b1 = lb0 + kM + kI;
+            if (direct) {
+                sc4[wv][kM] = make_float4(AX[a1], BX[b1], AY[a1], BY[b1]);        // (A, B) pairs per axis: the two distances run as packed fp32 ops
+                sc2[wv][kM] = make_float2(AZ[a1], BZ[b1]);
+                scnt[wv][kM] = 0;
+            } else {
+                posA[kM] = a1;
+                posB[kM] = b1;
+            }
+            if (SA && SB) same = SA[a1] == SB[b1];
         }
         nIdent += (uint32_t) __popcll(__ballot(same));
         nM += (uint32_t) __popcll(mM); nD += (uint32_t) __popcll(mD); nI += (uint32_t) __popcll(mI);
@@ -887,22 +902,31 @@ __global__ __launch_bounds__(256) void k_lddt(const char *paths, const uint64_t 
     if (lane == 0) { counts_out[4 * p] = nM; counts_out[4 * p + 1] = nD; counts_out[4 * p + 2] = nI; counts_out[4 * p + 3] = (SA && SB) ? nIdent : RSK_NO_POS; }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     if (ncols == 0) { if (lane == 0) lddt_out[p] = 0.0f; return; }
-    const float *AX = ax + a_off[ia[p]], *AY = ay + a_off[ia[p]], *AZ = az + a_off[ia[p]];
-    const float *BX = bx + b_off[ib[p]], *BY = by + b_off[ib[p]], *BZ = bz + b_off[ib[p]];
     const float R0sq = 15.0f * 15.0f;
-    if (ncols > LDDT_LDS_COLS && ncols <= LDDT_LONG_COLS) return;       // k_lddt_long: a whole workgroup per pair
+    if (ncols > LDDT_LDS_COLS && ncols <= LDDT_LONG_COLS) {
+        // k_lddt_long: a whole workgroup per pair, over the list this kernel appends to (class 0: <= 1024 columns, 1: <= 4096).
+        // (r02-r04 launched one workgroup per CANDIDATE -- every pair whose shorter chain allows > 256 columns, tens of
+        // thousands per batch of unrelated chains, nearly all of which returned at once: 2 ms per batch, 7 % of config 4.)
+        if (lane == 0) {
+            const uint32_t cls = ncols <= 1024 ? 0u : 1u;
+            long_list[(size_t) cls * npairs + atomicAdd(&long_cnt[cls], 1u)] = p;
+        }
+        return;
+    }
     const bool in_lds = ncols <= LDDT_LDS_COLS;
     if (in_lds) {
         // Every unordered column pair once: the ncols (ncols - 1) / 2 pairs, row-major (ci < cj), are cut into 64 equal
         // runs, one per lane; a pair within R0 adds (4, thresholds met) to the counters of BOTH columns (integers, so
         // the order of the additions is immaterial).  All lanes busy whatever ncols is, half the distance work.
-        for (uint32_t c = lane; c < ncols; c += 64) {
-            const uint32_t a1 = posA[c], b1 = posB[c];
-            sc4[wv][c] = make_float4(AX[a1], BX[b1], AY[a1], BY[b1]);        // (A, B) pairs per axis: the two distances run as packed fp32 ops
-            sc2[wv][c] = make_float2(AZ[a1], BZ[b1]);
-            scnt[wv][c] = 0;
+        if (!direct) {
+            for (uint32_t c = lane; c < ncols; c += 64) {
+                const uint32_t a1 = posA[c], b1 = posB[c];
+                sc4[wv][c] = make_float4(AX[a1], BX[b1], AY[a1], BY[b1]);
+                sc2[wv][c] = make_float2(AZ[a1], BZ[b1]);
+                scnt[wv][c] = 0;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         const uint32_t C = ncols;
         // Every unordered column pair once, in TILES of 64 x 64 columns (r04).  A lane keeps ONE column of the tile's first
         // block in registers for the whole tile; inside a block the partner is the column s places further on (cyclically:
@@ -996,6 +1020,8 @@ __global__ __launch_bounds__(256) void k_lddt(const char *paths, const uint64_t 
         float fr[LDDT_LDS_COLS / 64];
 #pragma unroll
         for (int k = 0; k < LDDT_LDS_COLS / 64; ++k) {
+            fr[k] = 0.0f;
+            if ((uint32_t) k * 64 >= ncols) continue;                    // (wave-uniform: no division for slots beyond the alignment)
             const uint32_t c = (uint32_t) k * 64 + lane;
             const uint32_t v = c < ncols ? scnt[wv][c] : 0u, cons = v & 0xFFFFu, pres = v >> 16;
             fr[k] = cons > 0 ? (float) pres / (float) cons : 0.0f;
@@ -1043,7 +1069,7 @@ __global__ __launch_bounds__(256) void k_lddt(const char *paths, const uint64_t 
 // Alignments of LDDT_LDS_COLS < columns <= LDDT_LONG_COLS (long homologous chains): the same unordered-pair scheme with a
 // whole workgroup per pair (k_lddt has expanded the path into scratch_pos and left the column count in counts_out).
 // Launched twice over host-built candidate lists: up to 1024 columns (32 KB of LDS) and up to 4096 (128 KB).
-__global__ __launch_bounds__(256) void k_lddt_long(const uint32_t *list, uint32_t nlist, uint32_t cap, const uint32_t *ia, const uint32_t *ib,
+__global__ __launch_bounds__(256) void k_lddt_long(const uint32_t *list, const uint32_t *nlist_dev, uint32_t cap, const uint32_t *ia, const uint32_t *ib,
                                                    const uint32_t *a_off, const uint32_t *b_off,
                                                    const float *ax, const float *ay, const float *az,
                                                    const float *bx, const float *by, const float *bz,
@@ -1055,12 +1081,12 @@ __global__ __launch_bounds__(256) void k_lddt_long(const uint32_t *list, uint32_
     float2 *c2 = (float2 *) (c4 + cap);
     uint32_t *cnt = (uint32_t *) (c2 + cap);
     float *frs = (float *) (cnt + cap);
-    if (blockIdx.x >= nlist) return;
-    const uint32_t p = list[blockIdx.x];                                // candidates: min(LA, LB) allows that many columns
-    if (score[p] < min_fwd_score || score[p] == 0.0f) return;
-    const uint32_t C = counts_out[4 * p];
-    if (C <= LDDT_LDS_COLS || C > cap) return;                          // k_lddt did it / the other launch does it
+    const uint32_t nlist = *nlist_dev;                                  // pairs k_lddt listed for this column class
     const int tid = threadIdx.x;
+    for (uint32_t li = blockIdx.x; li < nlist; li += gridDim.x) {
+    __syncthreads();                                                    // the previous pair's staging is done with
+    const uint32_t p = list[li];
+    const uint32_t C = counts_out[4 * p];
     const uint32_t *posA = scratch_pos + 2 * scratch_off[p];
     const uint32_t *posB = posA + (scratch_off[p + 1] - scratch_off[p]);
     const float *AX = ax + a_off[ia[p]], *AY = ay + a_off[ia[p]], *AZ = az + a_off[ia[p]];
@@ -1119,6 +1145,7 @@ __global__ __launch_bounds__(256) void k_lddt_long(const uint32_t *list, uint32_
         float total = 0.0f;
         for (uint32_t c = 0; c < C; ++c) total += frs[c];      // sequential, column order (lddt.cpp:111-121)
         lddt_out[p] = total / (float) C;
+    }
     }
 }
 
@@ -1357,13 +1384,13 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
     const size_t o_items = hb.add(items.size() * sizeof(swf_item) + 16);
     const size_t o_q[2] = { hb.add(qitems[0].size() * sizeof(swq_item) + 16), hb.add(qitems[1].size() * sizeof(swq_item) + 16) };
     // pairs (sorted order) whose alignment can exceed the per-wave LDDT staging: min(LA, LB) bounds the aligned columns
+    // (host bound only -- how many pairs CAN have that many columns; the pairs that do are listed by k_lddt on the device)
     std::vector<uint32_t> lddt_list[2];
-    if (want_stats && paths)
+    if (want_stats)
         for (size_t k = 0; k < npairs; ++k) {
             const uint32_t m = std::min(dba->len[ia[ord[k].idx]], dbb->len[ib[ord[k].idx]]);
             if (m > LDDT_LDS_COLS) lddt_list[m <= 1024 ? 0 : 1].push_back((uint32_t) k);
         }
-    const size_t o_lddt[2] = { hb.add(lddt_list[0].size() * 4 + 16), hb.add(lddt_list[1].size() * 4 + 16) };
     void *hpin = nullptr;
     if ((rc = rsk_pinned(ctx, 0, hb.bytes, &hpin)) != RSK_OK) return rc;
     char *H = (char *) hpin;
@@ -1432,7 +1459,6 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
     bnd_off[npairs] = bno;
     memcpy(H + o_items, items.data(), items.size() * sizeof(swf_item));
     for (int c = 0; c < 2; ++c) memcpy(H + o_q[c], qitems[c].data(), qitems[c].size() * sizeof(swq_item));
-    for (int c = 0; c < 2; ++c) memcpy(H + o_lddt[c], lddt_list[c].data(), lddt_list[c].size() * 4);
     if (tm.on) {
         uint64_t cc[4] = { 0, 0, 0, 0 };
         for (size_t k = 0; k < npairs; ++k) cc[ord[k].key >> 62] += (uint64_t) dba->len[ia[ord[k].idx]] * dbb->len[ib[ord[k].idx]];
@@ -1530,13 +1556,25 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
     if (want_stats) {
         if ((rc = dalloc((void **) &d_pos, 2 * so * 4)) != RSK_OK) return rc;
         if ((rc = dalloc((void **) &d_frac, so * 4)) != RSK_OK) return rc;
+        // pairs whose alignment has more columns than a wave stages (> 256): listed by k_lddt itself, two classes
+        uint32_t *d_long_cnt = nullptr, *d_long_list = nullptr;
+        const bool any_long = !lddt_list[0].empty() || !lddt_list[1].empty();     // (host bound: a pair's shorter chain allows > 256 columns)
+        if ((rc = dalloc((void **) &d_long_cnt, 16)) != RSK_OK) return rc;
+        if ((rc = dalloc((void **) &d_long_list, any_long ? 2 * npairs * 4 : 16)) != RSK_OK) return rc;
+        RSK_HIP(hipMemsetAsync(d_long_cnt, 0, 16, ctx->stream));
         hipLaunchKernelGGL(k_lddt, dim3((unsigned) ((npairs + 3) / 4)), dim3(256), 0, ctx->stream, d_paths, d_pstart, d_plen, d_loa, d_lob,
                            d_ia, d_ib, dba->d_off, dbb->d_off, dba->d_x, dba->d_y, dba->d_z, dbb->d_x, dbb->d_y, dbb->d_z,
-                           (uint32_t) npairs, d_pos, d_scoff, d_frac, d_lddt, d_counts, d_score, min_fwd_score, dba->d_seq, dbb->d_seq);
+                           (uint32_t) npairs, d_pos, d_scoff, d_frac, d_lddt, d_counts, d_score, min_fwd_score, dba->d_seq, dbb->d_seq,
+                           d_long_cnt, d_long_list);
         for (int c = 0; c < 2; ++c) {
-            const uint32_t nl = (uint32_t) lddt_list[c].size(), cap = c == 0 ? 1024u : (uint32_t) LDDT_LONG_COLS;
-            if (nl == 0) continue;
-            hipLaunchKernelGGL(k_lddt_long, dim3(nl), dim3(256), (size_t) cap * 32, ctx->stream, (const uint32_t *) (D + o_lddt[c]), nl, cap, d_ia,
+            // candidates of class 1 (shorter chain > 1024) may end with <= 1024 columns: both launches run whenever the host
+            // bound allows the class or a longer one; a launch is a few workgroups per CU that walk the device list
+            const size_t bound = c == 0 ? lddt_list[0].size() + lddt_list[1].size() : lddt_list[1].size();
+            const uint32_t cap = c == 0 ? 1024u : (uint32_t) LDDT_LONG_COLS;
+            if (bound == 0) continue;
+            const unsigned grid = (unsigned) std::min<size_t>(bound, (size_t) std::max(1, ctx->num_cus) * (c == 0 ? 4 : 1));
+            hipLaunchKernelGGL(k_lddt_long, dim3(grid), dim3(256), (size_t) cap * 32, ctx->stream, (const uint32_t *) (d_long_list + (size_t) c * npairs),
+                               (const uint32_t *) (d_long_cnt + c), cap, d_ia,
                                d_ib, dba->d_off, dbb->d_off, dba->d_x, dba->d_y, dba->d_z, dbb->d_x, dbb->d_y, dbb->d_z, d_pos, d_scoff, d_lddt,
                                d_counts, d_score, min_fwd_score);
         }
@@ -1662,24 +1700,28 @@ int rsk_paths_stats_pack(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *dbb, siz
         return rc;
     RSK_HIP(hipMemcpyAsync(d_scoff, sc_off.data(), (npairs + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     RSK_HIP(hipMemcpyAsync(d_ident, ident.data(), npairs * 4, hipMemcpyHostToDevice, ctx->stream));
-    for (int c = 0; c < 2; ++c)
-        if (!lddt_list[c].empty()) {
-            if ((rc = dalloc((void **) &d_list[c], lddt_list[c].size() * 4)) != RSK_OK) return rc;
-            RSK_HIP(hipMemcpyAsync(d_list[c], lddt_list[c].data(), lddt_list[c].size() * 4, hipMemcpyHostToDevice, ctx->stream));
-        }
+    (void) d_list;
+    uint32_t *d_long_cnt = nullptr, *d_long_list = nullptr;
+    const bool any_long = !lddt_list[0].empty() || !lddt_list[1].empty();
+    if ((rc = dalloc((void **) &d_long_cnt, 16)) != RSK_OK) return rc;
+    if ((rc = dalloc((void **) &d_long_list, any_long ? 2 * npairs * 4 : 16)) != RSK_OK) return rc;
+    RSK_HIP(hipMemsetAsync(d_long_cnt, 0, 16, ctx->stream));
     hipLaunchKernelGGL(k_lddt, dim3((unsigned) ((npairs + 3) / 4)), dim3(256), 0, ctx->stream, d_paths, d_pstart, d_plen, d_loa, d_lob, d_ia, d_ib,
                        dba->d_off, dbb->d_off, dba->d_x, dba->d_y, dba->d_z, dbb->d_x, dbb->d_y, dbb->d_z, (uint32_t) npairs, d_pos, d_scoff, d_frac,
-                       d_lddt, d_counts, d_score, min_fwd_score, dba->d_seq, dbb->d_seq);
+                       d_lddt, d_counts, d_score, min_fwd_score, dba->d_seq, dbb->d_seq, d_long_cnt, d_long_list);
     for (int c = 0; c < 2; ++c) {
-        const uint32_t nl = (uint32_t) lddt_list[c].size(), cap = c == 0 ? 1024u : (uint32_t) LDDT_LONG_COLS;
-        if (nl == 0) continue;
+        const size_t bound = c == 0 ? lddt_list[0].size() + lddt_list[1].size() : lddt_list[1].size();
+        const uint32_t cap = c == 0 ? 1024u : (uint32_t) LDDT_LONG_COLS;
+        if (bound == 0) continue;
         static std::atomic<int> lddt_attr[64];
         const int arc = rsk_once_per_device(lddt_attr, ctx->device, [&]() -> int {
             RSK_HIP(hipFuncSetAttribute((const void *) k_lddt_long, hipFuncAttributeMaxDynamicSharedMemorySize, LDDT_LONG_COLS * 32));
             return RSK_OK;
         });
         if (arc != RSK_OK) return arc;
-        hipLaunchKernelGGL(k_lddt_long, dim3(nl), dim3(256), (size_t) cap * 32, ctx->stream, d_list[c], nl, cap, d_ia, d_ib, dba->d_off, dbb->d_off,
+        const unsigned grid = (unsigned) std::min<size_t>(bound, (size_t) std::max(1, ctx->num_cus) * (c == 0 ? 4 : 1));
+        hipLaunchKernelGGL(k_lddt_long, dim3(grid), dim3(256), (size_t) cap * 32, ctx->stream, (const uint32_t *) (d_long_list + (size_t) c * npairs),
+                           (const uint32_t *) (d_long_cnt + c), cap, d_ia, d_ib, dba->d_off, dbb->d_off,
                            dba->d_x, dba->d_y, dba->d_z, dbb->d_x, dbb->d_y, dbb->d_z, d_pos, d_scoff, d_lddt, d_counts, d_score, min_fwd_score);
     }
     RSK_HIP(hipGetLastError());

@@ -125,6 +125,42 @@ def test_both_chains_longer_than_one_strip_group(ctx):
     db.close()
 
 
+def test_long_alignments_without_a_paths_buffer(ctx):
+    """rsk_align_pairs with paths = NULL (how DBSearcher::ComputeSelfRevScores and the test statistic of batches that keep
+    no paths call it): alignments of more than 256 / 1024 columns take k_lddt_long over the list k_lddt builds on the
+    device -- the statistics kernels run whether or not the caller wants the paths, so the list must be sized either way (r05
+    regression: illegal access at config-3 scale); scores equal the call with a paths buffer, whose LDDT / E-value equal the oracle."""
+    import copy
+    import ctypes as C
+    import reseek_amd
+    from reseek_amd import capi
+    base = fx.read_rskdb("q100_sensitive.rskdb.gz")[0]
+    rng = np.random.default_rng(12)
+    cs = []
+    for L in (300, 700, 1400, 90):
+        c = copy.copy(base)
+        c.mu = rng.integers(0, 36, L).astype(np.uint8)
+        c.prof = np.concatenate([rng.integers(0, 20, (1, L)), rng.integers(0, 16, (7, L))]).astype(np.uint8)
+        c.x = np.cumsum(rng.normal(0, 2.2, L)).astype(np.float32)
+        c.y = np.cumsum(rng.normal(0, 2.2, L)).astype(np.float32)
+        c.z = np.cumsum(rng.normal(0, 2.2, L)).astype(np.float32)
+        cs.append(c)
+    db = reseek_amd.Db.from_chains(ctx, cs)
+    ia = np.array([0, 1, 2, 3, 0, 2], np.uint32)          # self pairs: 300, 700, 1400 and 90 aligned columns; two unrelated pairs
+    ib = np.array([0, 1, 2, 3, 1, 3], np.uint32)
+    with_paths = ctx.align_pairs(db, db, ia, ib, min_fwd_score=0.0)
+    out = (capi.Aln * len(ia))()
+    capi._check(capi.lib().rsk_align_pairs(ctx.h, db.h, db.h, capi._p(ia, capi.u32p), capi._p(ib, capi.u32p), len(ia), capi.GAP_OPEN, capi.GAP_EXT,
+                                           0.0, out, None, 0))
+    for k, (al, path) in enumerate(with_paths):
+        assert bits(out[k].score) == bits(al.score) and (out[k].lo_a, out[k].lo_b) == (al.lo_a, al.lo_b), k      # (no paths: the statistics are not reported)
+        s, lo_i, lo_j, opath = ol.align_pair(cs[ia[k]].prof, cs[ib[k]].prof)
+        ok, st = ol.calc_evalue(s, 0.0, opath, lo_i, lo_j, cs[ia[k]], cs[ib[k]])
+        assert path == opath and bits(al.lddt) == bits(st.lddt) and bits(al.evalue) == bits(st.evalue), k
+    assert [al.path_len for al, _ in with_paths[:4]] == [300, 700, 1400, 90]
+    db.close()
+
+
 def test_tiny_and_ragged_chains(ctx):
     import reseek_amd
     chains = fx.read_rskdb("q100_sensitive.rskdb.gz")
