@@ -117,6 +117,24 @@ int rsk_mu_gapless_hits_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int 
 int rsk_mu_gapless_shard_window(const rsk_db *db, uint32_t shard_index, uint32_t shard_count, uint32_t *pos_lo, uint32_t *pos_hi);
 int rsk_mu_gapless_hits_window_dev(rsk_ctx *ctx, const rsk_db *db, uint32_t pos_lo, uint32_t pos_hi, uint16_t *d_scores, size_t ldo,
                                    uint32_t min_score, uint32_t base, uint32_t *d_records, uint32_t capacity, uint32_t *d_count);
+
+/* The path's one collective at the C-ABI: all-gather of the ranks' hit records over RCCL / xGMI.  The reference has
+ * none: it deals pairs to threads through one locked counter (runself.cpp:72-99) and its threads write hits under a lock
+ * (dbsearcher.cpp:98-106); one process per GPU exchanges the hit buffers instead.  Rank 0 calls rsk_comm_unique_id and hands
+ * the RSK_COMM_ID_BYTES bytes to the other ranks (a file, MPI, an environment variable: out of band, as with ncclUniqueId);
+ * every rank then calls rsk_comm_create(its context, id, rank, world).  rsk_gather_hits: every rank contributes n_local
+ * records of rec_bytes bytes from a device buffer of its context's GPU; on return *d_all (device memory owned by the
+ * communicator, valid until its next gather or rsk_comm_destroy) holds all ranks' records in rank order on EVERY rank, *n_all
+ * their number, counts[world] (optional) the per-rank numbers.  Collective: every rank must call it.  librccl.so is opened at
+ * run time; without it these calls return RSK_E_INVALID and everything else works. */
+#define RSK_COMM_ID_BYTES 128
+typedef struct rsk_comm rsk_comm;
+int rsk_comm_unique_id(unsigned char *id /* [RSK_COMM_ID_BYTES] */);
+int rsk_comm_create(rsk_ctx *ctx, const unsigned char *id, int rank, int world, rsk_comm **out);
+void rsk_comm_destroy(rsk_comm *c);
+int rsk_comm_rank(const rsk_comm *c);
+int rsk_comm_world(const rsk_comm *c);
+int rsk_gather_hits(rsk_comm *c, const void *d_local, uint64_t n_local, uint32_t rec_bytes, void **d_all, uint64_t *n_all, uint64_t *counts);
 /* Pair-list form with the position of the first strict maximum in row-major order (Besti/Bestj of
  * SWFastGapless_Int; RSK_NO_POS when the score is 0).  besti/bestj may be NULL.  Synchronous. */
 int rsk_mu_gapless_pairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, const uint32_t *iq,

@@ -41,6 +41,12 @@ SIGNATURES = {
     "rsk_mu_gapless_shard_window": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "rsk_mu_gapless_hits_window_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32,
                                                  C.c_void_p, C.c_uint32, C.c_void_p]),
+    "rsk_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "rsk_comm_create": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "rsk_comm_destroy": (None, [C.c_void_p]),
+    "rsk_comm_rank": (C.c_int, [C.c_void_p]),
+    "rsk_comm_world": (C.c_int, [C.c_void_p]),
+    "rsk_gather_hits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_void_p), u64p, u64p]),
     "rsk_mu_gapless_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, u32p, u32p, C.c_size_t, i32p, u32p, u32p]),
     "rsk_mu_gapless_last_work": (C.c_int, [C.c_void_p, u64p, u64p, u64p]),
     "rsk_mu_sw_matrix_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
@@ -230,6 +236,30 @@ class Ctx:
         """rsk_mu_gapless_hits_window_dev: one rank's window of the self-search triangle (the whole set on every rank)"""
         _check(lib().rsk_mu_gapless_hits_window_dev(self.h, db.h, int(pos_lo), int(pos_hi), C.c_void_p(d_scores_ptr) if d_scores_ptr else None, ldo,
                                                     int(min_score), int(base), C.c_void_p(rec_ptr), int(capacity), C.c_void_p(count_ptr)))
+
+    # ---- RCCL gather of hit records at the C-ABI (rsk_comm.hip) -----------------------------------
+    @staticmethod
+    def comm_unique_id():
+        buf = C.create_string_buffer(128)
+        _check(lib().rsk_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_create(self, uid, rank, world):
+        h = C.c_void_p()
+        _check(lib().rsk_comm_create(self.h, uid, int(rank), int(world), C.byref(h)))
+        return h
+
+    @staticmethod
+    def comm_destroy(comm):
+        lib().rsk_comm_destroy(comm)
+
+    @staticmethod
+    def gather_hits(comm, d_local_ptr, n_local, rec_bytes, world):
+        """-> (device pointer of the gathered records, total count, per-rank counts)"""
+        d_all, n_all = C.c_void_p(), C.c_uint64()
+        counts = (C.c_uint64 * world)()
+        _check(lib().rsk_gather_hits(comm, C.c_void_p(d_local_ptr) if d_local_ptr else None, int(n_local), int(rec_bytes), C.byref(d_all), C.byref(n_all), counts))
+        return d_all.value, n_all.value, list(counts)
 
     def mu_gapless_pairs(self, q, t, iq, it, positions=False):
         iq = np.ascontiguousarray(iq, np.uint32)

@@ -51,3 +51,43 @@ def test_bench_under_torchrun_world1_rccl():
     # the sharded whole-search leg ran through the same group
     assert res["search"]["hits_gathered"] > 0
     assert res["config"]["collective_world"] == 1 and res["config"]["windows"] == [[0, n]]
+
+
+def test_rsk_gather_hits_over_rccl_world1_through_the_c_abi():
+    """rsk_comm_* / rsk_gather_hits (reseek_amd/csrc/rsk_comm.hip): the hit-record gather of a multi-process C++ caller, no
+    Python collective involved -- a world-1 RCCL communicator on the box's GPU gathers the records the gapless kernel appended
+    (device to device), twice (the result buffer is reused), and an empty contribution."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    import reseek_amd
+    ctx = reseek_amd.Ctx(0, stream=torch.cuda.current_stream().cuda_stream)
+    uid = ctx.comm_unique_id()
+    assert len(uid) == 128
+    comm = ctx.comm_create(uid, 0, 1)
+    assert reseek_amd.capi.lib().rsk_comm_world(comm) == 1 and reseek_amd.capi.lib().rsk_comm_rank(comm) == 0
+    rng = np.random.default_rng(5)
+    seqs = [rng.integers(0, 36, int(L)).astype(np.uint8) for L in rng.integers(30, 300, 300)]
+    for k in range(0, 100, 5):
+        seqs[k + 1] = seqs[k][:len(seqs[k + 1])].copy() if len(seqs[k]) >= len(seqs[k + 1]) else seqs[k + 1]
+    db = reseek_amd.Db.from_mu_seqs(ctx, seqs)
+    cap = 1 << 14
+    rec = torch.zeros((cap, 3), dtype=torch.int32, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for thr in (60, 90):
+        ctx.mu_gapless_hits_dev(db, db, True, thr, rec.data_ptr(), cap, cnt.data_ptr())
+        torch.cuda.synchronize()
+        n = int(cnt.item())
+        assert n > 5
+        ptr, total, counts = ctx.gather_hits(comm, rec.data_ptr(), n, 12, 1)
+        torch.cuda.synchronize()
+        assert (total, counts) == (n, [n])
+        back = torch.zeros((n, 3), dtype=torch.int32, device="cuda")
+        hip = C.CDLL("libamdhip64.so")
+        assert hip.hipMemcpy(C.c_void_p(back.data_ptr()), C.c_void_p(ptr), C.c_size_t(n * 12), 3) == 0      # device to device
+        assert torch.equal(back, rec[:n])
+    ptr, total, counts = ctx.gather_hits(comm, 0, 0, 12, 1)
+    assert (total, counts) == (0, [0])
+    ctx.comm_destroy(comm)
+    db.close()
+    ctx.close()
