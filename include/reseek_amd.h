@@ -44,7 +44,7 @@ typedef struct rsk_db rsk_db;     /* a chain set resident in HBM as SoA */
 
 /* Bumped whenever a struct layout or a signature of this header changes (INTEGRATION.md lists the breaks):
  * 4 = rsk_search_opts leads with struct_size; rsk_shutdown added. */
-#define RSK_ABI_VERSION 4
+#define RSK_ABI_VERSION 5
 int rsk_abi_version(void);        /* the RSK_ABI_VERSION the library was built with */
 const char *rsk_version(void);
 const char *rsk_last_error(void);

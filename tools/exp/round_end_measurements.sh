@@ -2,8 +2,9 @@
 # round-end measurement set on the GPU box: full GPU test suite, profiles (bench / live / searches), the default bench line,
 # the full-size configs, the trace of a config-3-shaped search (loader vs search per batch)
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-T=${1:-r04}
+T=${1:-r05}
 mkdir -p gpurun_out
+export RSK_REQUIRE_REF=1
 timeout 3000 python -m pytest tests/ -x -q -m gpu 2>&1 | tail -5 > gpurun_out/${T}_gpu_tests.txt
 cat gpurun_out/${T}_gpu_tests.txt
 bash tools/exp/round_profiles.sh $T > gpurun_out/${T}_round_profiles.log 2>&1
