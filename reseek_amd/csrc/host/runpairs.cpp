@@ -499,24 +499,32 @@ void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOffset)
         uint64_t nmkf = 0, nskip = 0;
         // MKF pairs = either chain >= m_MKFL (both with k-mers): enumerated from the list of long chains,
         // not by walking the whole pair space
-        std::vector<uint32_t> longB;
-        for (uint j = 0; j < NB; ++j)
-            if (!S.m_DBMuKmersVec[j]->empty() && S.m_DBChains[j]->GetSeqLength() >= P.m_MKFL) longB.push_back(j);
-        for (uint i = 0; i < NA; ++i) {
-            if (SrcA.m_DBMuKmersVec[i]->empty()) continue;
-            const uint j0 = Self ? (i > joff ? i - joff : 0) : 0;
-            if (SrcA.m_DBChains[i]->GetSeqLength() >= P.m_MKFL) {
-                for (uint j = j0; j < NB; ++j) {
-                    if (S.m_DBMuKmersVec[j]->empty() || Skip(i, j)) continue;
-                    mkf.emplace_back(i, j); ++nmkf;
-                }
-            } else {
-                for (auto it = std::lower_bound(longB.begin(), longB.end(), j0); it != longB.end(); ++it) {
-                    if (Skip(i, *it)) continue;
-                    mkf.emplace_back(i, *it); ++nmkf;
+        // (the list -- 0.67 M pairs, ~5 ms of one host thread on the SCOP40-sized self search -- is not needed before the filter
+        // has run: it is built on a thread of its own under the filter kernels, r05)
+        auto build_mkf_list = [&]() {
+            std::vector<uint32_t> longB;
+            for (uint j = 0; j < NB; ++j)
+                if (!S.m_DBMuKmersVec[j]->empty() && S.m_DBChains[j]->GetSeqLength() >= P.m_MKFL) longB.push_back(j);
+            for (uint i = 0; i < NA; ++i) {
+                if (SrcA.m_DBMuKmersVec[i]->empty()) continue;
+                const uint j0 = Self ? (i > joff ? i - joff : 0) : 0;
+                if (SrcA.m_DBChains[i]->GetSeqLength() >= P.m_MKFL) {
+                    for (uint j = j0; j < NB; ++j) {
+                        if (S.m_DBMuKmersVec[j]->empty() || Skip(i, j)) continue;
+                        mkf.emplace_back(i, j); ++nmkf;
+                    }
+                } else {
+                    for (auto it = std::lower_bound(longB.begin(), longB.end(), j0); it != longB.end(); ++it) {
+                        if (Skip(i, *it)) continue;
+                        mkf.emplace_back(i, *it); ++nmkf;
+                    }
                 }
             }
-        }
+        };
+        const bool early = getenv("RSK_MKF_EARLY") && atoi(getenv("RSK_MKF_EARLY")) == 1;
+        std::future<void> mkf_list;
+        if (early) build_mkf_list();
+        else mkf_list = std::async(std::launch::async, build_mkf_list);      // (a future of std::async joins in its destructor: no exit path leaves the thread behind)
         if (S.m_Opts.noself) {
             if (Self) nskip = NA > joff ? std::min<uint64_t>(NB, NA - joff) : 0;      // the diagonal pairs this pass holds
             else {
@@ -532,9 +540,8 @@ void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOffset)
         // on a context of its own, under the filter kernels.  Measured (r04): no consistent gain -- 256 x 1,000,000: 15.3-17.4 s
         // against 14.8-16.8 s, the filter and the seeding kernels are both VALU-bound and share the SIMDs -- so the default
         // stays "beside the alignment job" (below); RSK_MKF_EARLY=1 starts it here.
-        const bool early = getenv("RSK_MKF_EARLY") && atoi(getenv("RSK_MKF_EARLY")) == 1;
         if (early) start_mkf_job();
-        tm.lap("  long-chain pair list");
+        tm.lap("  long-chain pair list (started)");
         // survivor lists: sized for 1/6 of the pairs (the presets pass 0.3 % of real SCOP40 pairs, 15 % of look-alike synthetic
         // structures; 8 bytes per slot, 5.3 GB for the largest filter tile), re-run with the exact count on overflow
         // (the kernel counts every survivor; it only stops storing at `cap`)
@@ -554,6 +561,7 @@ void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOffset)
             if (ns <= cap) break;
             cap = ns;
         }
+        if (mkf_list.valid()) mkf_list.get();
         tm.lap("  Mu filter kernels");
         // deterministic order (the device list is unordered): by A-side chain, then B-side chain -- the order the reference walks
         // its pairs in (runself.cpp:72-99, runquery.cpp:82) -- sorted on the device (8.7 M survivors through a host counting
