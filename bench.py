@@ -430,6 +430,56 @@ def live_kernels(ctx, seqs, db, reps=3):
     qa = np.repeat(order, n)
     qb = np.tile(np.arange(n, dtype=np.uint32), nq)
     res.append(sw_entry("k_sw_qp", "float SW + trace, %d queries x %d chains (query-profile kernel)" % (nq, n), qa, qb, 0.0, 21.2, False))      # 254 VALU instructions per 12-row column in the ISA of the hot loop (R = 12 instance: 18.5 per cell for the recurrence, trace masks and best cell + ~32 per step; r04b: 278)
+    # --- k_traceback and k_lddt (+ k_lddt_long): the stages behind the Smith-Waterman kernels, on STRUCTURES (the set above has
+    # iid profile letters: its alignments are a few columns long).  3,000 synthetic chains of tools/bench_search.py's generator
+    # (persistent random walks, SCOP40 lengths; the look-alike structures of the config legs), featurised by the library's
+    # DSS (host), 24 queries against all of them, every pair -- the -verysensitive regime of BASELINE configs[4].
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_search
+        from reseek_amd import capi
+        rng2 = np.random.default_rng(21)
+        slen = scop40_lengths()
+        slen = slen[rng2.choice(len(slen), 3000)]
+        recs = bench_search.gen_bca_chains(slen, rng2)
+        mus, profs, xs, ys, zs = [], [], [], [], []
+        for seq, ic, L in recs:
+            c = (np.frombuffer(ic, np.uint16).reshape(L, 3).astype(np.float32) / 10.0 - 1000.0)      # pdbchain.h:90
+            pr, mu = capi.dss_featurize(seq, c[:, 0], c[:, 1], c[:, 2])
+            mus.append(mu); profs.append(pr.reshape(-1)); xs.append(c[:, 0]); ys.append(c[:, 1]); zs.append(c[:, 2])
+        sdb = reseek_amd.Db(ctx, slen.astype(np.uint32), mu=np.concatenate(mus), prof=np.concatenate(profs),
+                            xyz=(np.concatenate(xs), np.concatenate(ys), np.concatenate(zs)), selfrev=np.zeros(len(slen), np.float32))
+        nq2, nt2 = 24, len(slen)
+        qa2, qb2 = np.repeat(np.arange(nq2, dtype=np.uint32), nt2), np.tile(np.arange(nt2, dtype=np.uint32), nq2)
+        ctx.align_pairs(sdb, sdb, qa2, qb2, min_fwd_score=0.0, collect=False)
+        tb_ms, st_ms = [], []
+        for _ in range(reps):
+            alns = ctx.align_pairs(sdb, sdb, qa2, qb2, min_fwd_score=0.0)
+            t_sw, t_tb, t_st = ctx.align_last_times()
+            tb_ms.append(t_tb); st_ms.append(t_st)
+        sdb.close()
+        tb_ms, st_ms = float(np.median(tb_ms)), float(np.median(st_ms))
+        plen = np.array([a.path_len for a, _ in alns], np.float64)
+        ncol = np.array([p.count("M") for _, p in alns], np.float64)
+        steps, longest = float(plen.sum()), float(plen.max())
+        tests = float((ncol * (ncol - 1) / 2).sum())
+        res.append({"kernel": "k_traceback", "what": "TraceBackBitSW of %d pairs (%d queries x %d synthetic structures, every pair): one thread per pair, one dependent 16-byte load per step" % (len(alns), nq2, nt2),
+                    "kernel_ms": tb_ms, "pairs": len(alns), "steps": steps, "longest_walk_steps": longest, "steps_per_s": steps / tb_ms * 1e3,
+                    "bound": "latency", "ns_per_step_of_the_longest_walk": tb_ms * 1e6 / max(longest, 1.0),
+                    "floor_ns_per_step": {"l2_hit": 212.0 / 2.4, "hbm_miss": 900.0 / 2.4},
+                    "frac": (longest * 212.0 / 2.4 * 1e-6) / tb_ms,
+                    "note": "every walker is resident at once (one wave per 64 pairs), so the kernel lasts as long as its longest walk; frac = "
+                            "(longest walk x L2-hit latency of a dependent load, ~212 cycles: MI355X_MICROARCH.md) / kernel time -- a trace block "
+                            "was just written by k_sw_qp (GBs per call) and is read from HBM (~900 cycles per miss), four steps of a diagonal share a line"})
+        res.append({"kernel": "k_lddt", "what": "GetLDDT_mu_fast of the same pairs (k_lddt: a wave per pair; alignments of > 256 columns: k_lddt_long, a workgroup per pair)",
+                    "kernel_ms": st_ms, "pairs": len(alns), "aligned_columns_mean": float(ncol.mean()), "column_pair_tests": tests,
+                    "bound": "valu", "valu_ops_per_test": 15.0, "unit": "T lane-ops/s", "achieved": tests * 15.0 / st_ms * 1e3 / 1e12,
+                    "peak": PEAK_VALU_LANEOPS / 1e12, "frac": tests * 15.0 / st_ms * 1e3 / PEAK_VALU_LANEOPS,
+                    "note": "work = the unordered column pairs, 15 VALU instructions per 64 tests (8 packed ops for the two squared distances, "
+                            "2 comparisons, partner address); beside them per pair: path expansion, the pairs within R0 (two correctly rounded "
+                            "square roots + thresholds, ~10 % of the tests), per-column fractions and the reference's sequential column sum"})
+    except Exception as e:  # noqa: BLE001
+        sys.stderr.write("bench: traceback / lddt live entries failed: %s\n" % e)
     dbs.close()
     del out8, pq, pt
     torch.cuda.empty_cache()

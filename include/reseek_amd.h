@@ -204,6 +204,10 @@ int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *a, const rsk_db *b, const uint32
                     char *paths, size_t paths_bytes);
 /* Pairs, DP cells (sum LA*LB) and trace bytes written to HBM by the last rsk_align_pairs call. */
 int rsk_align_last_work(rsk_ctx *ctx, uint64_t *pairs, uint64_t *cells, uint64_t *tb_bytes);
+/* Kernel times (ms, HIP events on the context's stream) of the stages of the last rsk_align_pairs call: the Smith-Waterman
+ * kernels (k_sw_qp / k_sw_float: SWFast sw.cpp:79), the traceback kernel (TraceBackBitSW sw.cpp:8) and the statistics kernels
+ * (GetLDDT_mu_fast lddt.cpp:63); -1 where a stage did not run.  Measurement only (bench.py roofline_live). */
+int rsk_align_last_times(rsk_ctx *ctx, float *sw_ms, float *traceback_ms, float *stats_ms);
 
 /* ---- D1: the reference's remaining dead-but-named kernels, pair-list form (host arrays) -------------
  * rsk_mu_pinop_pairs:         SWFastPinop swfastpinop.cpp:6 (int32 3-state local DP on IntScoreMx_Mu rows;

@@ -76,6 +76,7 @@ SIGNATURES["rsk_align_paths_bytes"] = (C.c_size_t, [C.c_void_p, C.c_void_p, u32p
 SIGNATURES["rsk_align_pairs"] = (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, u32p, u32p, C.c_size_t, C.c_float, C.c_float,
                                            C.c_float, C.POINTER(Aln), C.c_char_p, C.c_size_t])
 SIGNATURES["rsk_align_last_work"] = (C.c_int, [C.c_void_p, u64p, u64p, u64p])
+SIGNATURES["rsk_align_last_times"] = (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)])
 
 SIGNATURES["rsk_search_rskdb"] = (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_double, C.c_int,
                                             C.c_char_p, u64p, u64p])
@@ -311,6 +312,12 @@ class Ctx:
             return None
         raw = buf.raw
         return [(out[k], raw[out[k].path_off:out[k].path_off + out[k].path_len].decode()) for k in range(n)]
+
+    def align_last_times(self):
+        """-> (sw_ms, traceback_ms, stats_ms) of the last align_pairs call"""
+        a, b, c = C.c_float(), C.c_float(), C.c_float()
+        _check(lib().rsk_align_last_times(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     def align_last_work(self):
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()

@@ -375,7 +375,9 @@ __global__ __launch_bounds__(64 * SWF_WAVES) __attribute__((amdgpu_waves_per_eu(
 #define SWQ_NQ(R) (((R) + 3) / 4)                  // ds_read_b128 per feature and step
 #define SWQ_NPF(R) (4 / SWQ_NQ(R))                 // passes per LDS profile
 #define SWQ_COLB(R) ((R) * 32)                     // trace of one (step - row) column of a wave batch: R rows x 4 masks of 64 lanes
+#ifndef SWQ_NW
 #define SWQ_NW 16
+#endif
 #define SWQ_NFC 132                               // 20 + 7 * 16 (feature, step letter) combinations
 #define SWQ_LDS_BYTES ((size_t) SWQ_NFC * 4 * SWQ_GS * 16 + 16)
 
@@ -795,6 +797,9 @@ __global__ void k_traceback(const uint8_t *tb, const uint64_t *tb_off, const uin
             asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(q) : "v"(rec + (state == 0 ? 0 : 16)) : "memory");
             PATH_STORE();
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(q) :: "memory");
+            // (Measured and not kept, r05: on the first record of a 128-byte line, a request nobody waits for to the line before it --
+            // where a diagonal run goes next: 0.73-0.77 ms against 0.72-0.75 for 72,000 walks of up to 902 steps; the ~800 ns
+            // per step of the longest walk are not one HBM miss per line.)
             const uint32_t b0 = (lane < 32 ? q.x >> lane : q.y >> (lane - 32)) & 1u, b1 = (lane < 32 ? q.z >> lane : q.w >> (lane - 32)) & 1u;
             // state M: b0 = stop or I, b1 = stop or D
             md = b0; mi = b1; sm = b0 & b1; im = b0; dm = b1;
@@ -1553,6 +1558,8 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
                        d_ib, dbb->d_len, cl, d_score, d_bi, d_bj, (uint32_t) npairs, d_paths, d_pend, d_pstart, d_plen, d_loa, d_lob,
                        (const swq_item *) (D + o_q[0]), (const swq_item *) (D + o_q[1]), (const uint32_t *) (D + o_qpitem));
     RSK_HIP(hipGetLastError());
+    if (!ctx->ev_tb) { RSK_HIP(hipEventCreate(&ctx->ev_tb)); RSK_HIP(hipEventCreate(&ctx->ev_st)); }
+    RSK_HIP(hipEventRecord(ctx->ev_tb, ctx->stream));
     if (want_stats) {
         if ((rc = dalloc((void **) &d_pos, 2 * so * 4)) != RSK_OK) return rc;
         if ((rc = dalloc((void **) &d_frac, so * 4)) != RSK_OK) return rc;
@@ -1580,6 +1587,7 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
         }
         RSK_HIP(hipGetLastError());
     }
+    RSK_HIP(hipEventRecord(ctx->ev_st, ctx->stream));
     if (paths) {
         // pack the paths in the caller's order on the device
         hipLaunchKernelGGL(k_path_sizes, dim3((unsigned) ((npairs + 255) / 256)), dim3(256), 0, ctx->stream, d_slot, d_plen, (uint32_t) npairs, d_sizes);
@@ -1882,6 +1890,23 @@ extern "C" int rsk_gapless_float_pairs(rsk_ctx *ctx, const rsk_db *dba, const rs
     if (besti) RSK_HIP(hipMemcpyAsync(besti, d_bi, npairs * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (bestj) RSK_HIP(hipMemcpyAsync(bestj, d_bj, npairs * 4, hipMemcpyDeviceToHost, ctx->stream));
     RSK_HIP(hipStreamSynchronize(ctx->stream));
+    return RSK_OK;
+}
+
+// kernel times of the stages of the last rsk_align_pairs call on this context (HIP events on its stream): Smith-Waterman
+// kernels, traceback kernel, statistics kernels (LDDT); -1 where a stage did not run
+extern "C" int rsk_align_last_times(rsk_ctx *ctx, float *sw_ms, float *traceback_ms, float *stats_ms)
+{
+    if (!ctx) { rsk_set_error("rsk_align_last_times: ctx is NULL"); return RSK_E_INVALID; }
+    float a = -1.0f, b = -1.0f, c = -1.0f;
+    if (ctx->ev0 && ctx->ev1 && hipEventSynchronize(ctx->ev1) == hipSuccess) (void) hipEventElapsedTime(&a, ctx->ev0, ctx->ev1);
+    if (ctx->ev_tb && ctx->ev_st && hipEventSynchronize(ctx->ev_st) == hipSuccess) {
+        (void) hipEventElapsedTime(&b, ctx->ev1, ctx->ev_tb);
+        (void) hipEventElapsedTime(&c, ctx->ev_tb, ctx->ev_st);
+    }
+    if (sw_ms) *sw_ms = a;
+    if (traceback_ms) *traceback_ms = b;
+    if (stats_ms) *stats_ms = c;
     return RSK_OK;
 }
 
