@@ -460,18 +460,27 @@ extern "C" int rsk_mu_gapless_shard_window(const rsk_db *db, uint32_t shard_inde
     }
     // cost of target position p = its letters (in pairs) x the ring slots that walk it (rings whose first member stands at
     // or before p) + its rows against the long chains at or before p: the slots the kernel issues for it
+    // Two refinements of the model were measured (r05, per-rank kernel times of the bench set on one GPU) and are off by default:
+    // RSK_WINDOW_RAGGED = x charges every ring's ragged first work item (it begins at the ring's first member, in the middle of a
+    // target block) as x full 256-target items at that position -- the first of 8 windows holds a third of all ring starts and
+    // runs 9 % over the mean; x = 1 brings N = 8 from 0.874 to 0.893 predicted efficiency but N = 2 / 4 from 0.977 / 0.949 to
+    // 0.960 / 0.931 (the work moves to the last window, which is the slowest there).  RSK_WINDOW_LONGW = w weighs a row of the
+    // per-pair kernel (chains beyond a ring, all in the last window) w times a ring slot: no effect up to w = 8.
     const uint32_t n = db->n;
     std::vector<double> cum((size_t) n + 1, 0.0);
     {
+        static const double ragged = getenv("RSK_WINDOW_RAGGED") ? atof(getenv("RSK_WINDOW_RAGGED")) : 0.0;
+        static const double longw = getenv("RSK_WINDOW_LONGW") ? atof(getenv("RSK_WINDOW_LONGW")) : 1.0;      // a row of the per-pair kernel (chains beyond a ring) against a ring slot
         std::vector<uint64_t> ring_slots((size_t) n + 1, 0);
         for (const rsk_ring &r : db->rings) ring_slots[r.min_q] += 128ull * r.D;
+        const double mean_len = n ? (double) db->nres / (double) n : 0.0;
         uint64_t slots = 0, long_rows = 0;
         const uint32_t first_long = n - (uint32_t) db->long_q.size();
         for (uint32_t p = 0; p < n; ++p) {
             slots += ring_slots[p];
             const uint32_t L = db->len[db->h_ring_perm[p]];
             if (p >= first_long) long_rows += L;
-            cum[p + 1] = cum[p] + (double) ((L + 1) / 2 * 2) * (double) (slots + long_rows);
+            cum[p + 1] = cum[p] + (double) ((L + 1) / 2 * 2) * ((double) slots + longw * (double) long_rows) + ragged * 256.0 * mean_len * (double) ring_slots[p];
         }
     }
     auto bound = [&](uint32_t r) -> uint32_t {
