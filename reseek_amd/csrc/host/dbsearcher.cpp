@@ -344,6 +344,9 @@ void DSSAligner::AlignQueryTarget()
 void DSSAligner::AlignPairOnGpu()
 {
     if (!m_Ctx) m_Ctx = DefaultCtx();
+    // a batch of one on the aligner's context; aligners of several threads may share it (the reference keeps one DSSAligner
+    // per thread, dbsearcher.cpp:98-106; an rsk_ctx is not thread-safe)
+    std::lock_guard<std::mutex> lock(CtxMutex(m_Ctx));
     auto mk = [&](const PDBChain &C, const std::vector<std::vector<byte> > &Prof, const std::vector<byte> *Mu, float SelfRev) {
         const uint32_t L = C.GetSeqLength();
         std::vector<uint8_t> prof((size_t) L * RSK_NFEAT);

@@ -112,3 +112,18 @@ def test_per_pair_entry_points(work):
     aq = sorted(tuple(x[1:]) for x in rows if x[0] == "AlignQueryTarget")
     ab = sorted(tuple(x[1:]) for x in rows if x[0] == "AlignBags")
     assert aq == ab and aq
+
+
+def test_per_pair_entry_points_from_several_threads(work):
+    """The reference's threading model on the per-pair entry points (one DSSAligner per thread, rows dealt through a shared
+    counter: dbsearcher.cpp:98-106, runself.cpp:72-99) with all aligners on ONE device context: the host layer serialises
+    their batch-of-one calls per context (ADVICE r04: an rsk_ctx is not thread-safe; MuKmerFilter::Align used to seed on the
+    default context whatever its aligner's).  4 threads print exactly the rows of the one-thread run -- long-chain pairs
+    (MKF seeding, X-drop, chaining) included."""
+    one = subprocess.run([os.path.join(work, "pair_main"), "q100.bca", "16", "palms.bca", "6"], capture_output=True, text=True, cwd=work)
+    assert one.returncode == 0, one.stderr
+    want = sorted(ln for ln in one.stdout.splitlines() if ln.startswith("AlignQueryTarget\t"))
+    four = subprocess.run([os.path.join(work, "pair_main"), "-threads", "4", "q100.bca", "16", "palms.bca", "6"], capture_output=True, text=True, cwd=work)
+    assert four.returncode == 0, four.stderr
+    got = sorted(ln for ln in four.stdout.splitlines() if ln.startswith("AlignQueryTarget\t"))
+    assert got == want and len(got) >= 30
