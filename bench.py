@@ -196,6 +196,17 @@ def _verified_pmc(name="r05_live_pmc.json"):
     return out
 
 
+def _with_clock(e, pmc_entry):
+    """the nominal peak assumes 2.4 GHz; the counters give the clock the kernel actually held (a kernel at the chip's power limit
+    runs below it) and the share of its cycles in which a SIMD issued a VALU instruction"""
+    ck = (pmc_entry or {}).get("sustained_clock_ghz")
+    if ck and "frac" in e:
+        e["sustained_clock_ghz"] = ck
+        e["frac_at_sustained_clock"] = e["frac"] * 2.4 / ck
+        e["valu_issue_frac_of_cycles"] = (pmc_entry or {}).get("valu_issue_frac")
+    return e
+
+
 def prefilter_entry(ctx, name, what, seqs, pmc, reps=2):
     """One `roofline_live` entry for k_prefilter (prefiltermu.cpp:382, twohitdiag.cpp:368-398): the scan of every chain of
     `seqs` against the neighbourhood index of the same set (idxt, the `-fast -db` configuration).  Two byte models:
@@ -224,7 +235,7 @@ def prefilter_entry(ctx, name, what, seqs, pmc, reps=2):
     q.close()
     ours = 4.0 * items + 2.0 * cells + 12.0 * triples + nres
     survey = 14.0 * items + 2.0 * cells + nres
-    return {"kernel": "k_prefilter", "workload": name, "what": what, "kernel_ms": ms_, "chains": n, "index_postings": int(postings), "seed_items": int(items),
+    return _with_clock({"kernel": "k_prefilter", "workload": name, "what": what, "kernel_ms": ms_, "chains": n, "index_postings": int(postings), "seed_items": int(items),
             "seed_items_per_s": items / ms_ * 1e3, "twohit_diagonals": int(twohit), "diagonal_cells": int(cells), "result_triples": triples,
             # the diagonal scans are the larger share of the kernel time (RSK_PF_DEBUG=1 stops after the seed walk: 0.10 of 0.64 s on
             # the config-2 letters, 30 of 93 ms on SCOP40), so the entry's bound is the VALU one; the byte models follow under `hbm`
@@ -239,7 +250,7 @@ def prefilter_entry(ctx, name, what, seqs, pmc, reps=2):
                     "survey_model": {"bytes": survey, "achieved_GBs": survey / ms_ * 1e3 / 1e9, "frac": survey / ms_ * 1e3 / 1e9 / PEAK_HBM_GBS,
                                      "formula": "14 B x seed items + 2 B x diagonal cells + target letters (SURVEY 8d)"},
                     "posting_reads_GBs": 4.0 * items / ms_ * 1e3 / 1e9},
-            "pmc": pmc.get("k_prefilter") if name.startswith("config2") else None}
+            "pmc": pmc.get("k_prefilter") if name.startswith("config2") else None}, pmc.get("k_prefilter") if name.startswith("config2") else None)
 
 
 def predicted_scaling(ctx, seqs, schemes=("window",), reps=2, worlds=(2, 4, 8)):
@@ -369,8 +380,9 @@ def live_kernels(ctx, seqs, db, reps=3):
                 "frac": tri_cells * 3.75 / ms * 1e3 / PEAK_VALU_LANEOPS,
                 "hbm": {"algorithmic_bytes": alg, "achieved_GBs": alg / ms * 1e3 / 1e9, "frac": alg / ms * 1e3 / 1e9 / PEAK_HBM_GBS},
                 "pmc": pmc.get("k_mu_sw"),
-                "pmc_dispatch": "the counters are those of the LONGEST of the pass's three dispatches (k_mu_sw2 over the query pairs of the "
-                                "<= 416 class: ~188 of the pass's ~266 ms), not of the whole pass"})
+                "pmc_dispatch": "the counters are those of the LONGEST of the pass's dispatches (k_mu_sw2 over the query pairs of its "
+                                "largest class), not of the whole pass"})
+    _with_clock(res[-1], pmc.get("k_mu_sw"))
     # --- survivors of the -sensitive filter -> float SW (per-pair kernel)
     cap = 4_000_000
     pq = torch.zeros(cap, dtype=torch.int32, device="cuda")
@@ -408,13 +420,7 @@ def live_kernels(ctx, seqs, db, reps=3):
              "hbm": {"algorithmic_bytes": alg_, "trace_bytes": float(tb), "achieved_GBs": alg_ / ms_ * 1e3 / 1e9,
                      "frac": alg_ / ms_ * 1e3 / 1e9 / PEAK_HBM_GBS},
              "pmc": pmc.get(name)}
-        ck = (pmc.get(name) or {}).get("sustained_clock_ghz")
-        if ck:
-            # the nominal peak assumes 2.4 GHz; the counters give the clock the kernel actually held (power limit) and the share of
-            # its cycles in which a SIMD issued a VALU instruction
-            e["sustained_clock_ghz"] = ck
-            e["frac_at_sustained_clock"] = e["frac"] * 2.4 / ck
-            e["valu_issue_frac_of_cycles"] = (pmc.get(name) or {}).get("valu_issue_frac")
+        _with_clock(e, pmc.get(name))
         if lds:
             # 8 ds_read_b32 gathers per cell; conflict-free LDS rate = 32 lanes/clk/CU
             peak_g = 256 * 32 * 2.4e9
