@@ -343,8 +343,26 @@ __global__ __launch_bounds__(PF_THREADS) void k_prefilter(pf_args a)
                         if (hi - lo >= PF_LONGROW) {
                             const uint32_t e = atomicAdd(&s_rows, 1u);
                             rowq[3 * e] = p; rowq[3 * e + 1] = lo; rowq[3 * e + 2] = hi;
-                        } else
+                        } else {
+#ifndef PF_SHORTROW_SERIAL
+                            // short row pieces stay with the thread that owns the k-mer position: four postings requested before
+                            // the first is used (r04 walked them one dependent load at a time)
+                            uint32_t c = lo;
+                            for (; c + 4 <= hi; c += 4) {
+                                const uint32_t p0 = a.postings[c], p1 = a.postings[c + 1], p2 = a.postings[c + 2], p3 = a.postings[c + 3];
+                                item(p, p0); item(p, p1); item(p, p2); item(p, p3);
+                            }
+                            if (c < hi) {
+                                const uint32_t n = hi - c;
+                                const uint32_t p0 = a.postings[c], p1 = a.postings[n > 1 ? c + 1 : c], p2 = a.postings[n > 2 ? c + 2 : c];
+                                item(p, p0);
+                                if (n > 1) item(p, p1);
+                                if (n > 2) item(p, p2);
+                            }
+#else
                             for (uint32_t c = lo; c < hi; ++c) item(p, a.postings[c]);
+#endif
+                        }
                     }
                 }
             }
