@@ -677,18 +677,34 @@ int rsk_launch_gapless_rings(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int
     (void) nD4; (void) nD8;
 
     RSK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    // queries too long for a ring: per-pair kernel over (long q) x targets (list built with the work list, cached per target set +
+    // triangle flag).  A few dozen one-workgroup pairs: behind the ring kernels on one stream they were a 0.35 ms tail of a 42.8 ms
+    // launch -- and all of it on the LAST of N windows; on a side stream (forked here, joined before ev1) they run beside them.
+    const bool side = q->long_pairs && !getenv("RSK_GAPLESS_NO_SIDE_STREAM");
+    if (q->long_pairs) {
+        hipStream_t ps = ctx->stream;
+        if (side) {
+            if (!ctx->aux) {
+                RSK_HIP(hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
+                RSK_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+                RSK_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+            }
+            RSK_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+            RSK_HIP(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
+            ps = ctx->aux;
+        }
+        hipLaunchKernelGGL(k_gapless_pairs, dim3(q->long_pairs), dim3(1024), 0, ps, q->d_mu, q->d_off, q->d_len,
+                           t->d_mu, t->d_off, t->d_len, q->d_long_iq, q->d_long_it, q->long_pairs, (int32_t *) nullptr, (uint32_t *) nullptr,
+                           (uint32_t *) nullptr, d_scores, ldo, hits);
+        RSK_HIP(hipGetLastError());
+        if (side) RSK_HIP(hipEventRecord(ctx->ev_join, ctx->aux));
+    }
     rc = launch_ring_class<16, 16>(ctx, q, t, (const uint2 *) q->d_work + q->work_count[0], q->work_count[1], d_claim, self_triangle, win_lo, win_hi,
                                   d_scores, ldo, tb, hits);
     if (rc != RSK_OK) return rc;
     rc = launch_ring_class<8, 16>(ctx, q, t, (const uint2 *) q->d_work, q->work_count[0], d_claim, self_triangle, win_lo, win_hi, d_scores, ldo, tb, hits);
     if (rc != RSK_OK) return rc;
-    // queries too long for a ring: per-pair kernel over (long q) x targets
-    if (q->long_pairs) {                               // list built with the work list (cached per target set + triangle flag)
-        hipLaunchKernelGGL(k_gapless_pairs, dim3(q->long_pairs), dim3(1024), 0, ctx->stream, q->d_mu, q->d_off, q->d_len,
-                           t->d_mu, t->d_off, t->d_len, q->d_long_iq, q->d_long_it, q->long_pairs, (int32_t *) nullptr, (uint32_t *) nullptr,
-                           (uint32_t *) nullptr, d_scores, ldo, hits);
-        RSK_HIP(hipGetLastError());
-    }
+    if (side) RSK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     RSK_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     return RSK_OK;
 }

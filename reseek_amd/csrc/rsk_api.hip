@@ -177,6 +177,9 @@ extern "C" void rsk_ctx_destroy(rsk_ctx *ctx)
     if (ctx->ev0) (void) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void) hipEventDestroy(ctx->ev1);
     if (ctx->ev_wait) (void) hipEventDestroy(ctx->ev_wait);
+    if (ctx->ev_fork) (void) hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void) hipEventDestroy(ctx->ev_join);
+    if (ctx->aux) (void) hipStreamDestroy(ctx->aux);
     if (ctx->ev_tb) (void) hipEventDestroy(ctx->ev_tb);
     if (ctx->ev_st) (void) hipEventDestroy(ctx->ev_st);
     delete ctx;

@@ -28,6 +28,8 @@ struct rsk_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_wait = nullptr;   // blocking-sync event of rsk_stream_wait (created on first use)
+    hipStream_t aux = nullptr;      // side stream of the gapless launch (the per-pair kernel of chains beyond a ring runs beside the ring kernels)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_tb = nullptr, ev_st = nullptr;   // rsk_align_pairs: after the traceback kernel / after the statistics kernels (created on first use)
     uint64_t al_steps = 0, al_col_tests = 0;       // last rsk_align_pairs call with statistics: path characters walked, LDDT column-pair tests
     float last_ms = -1.0f;
