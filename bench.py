@@ -170,11 +170,19 @@ def _load_json(name):
         return None
 
 
-def _verified_pmc(name="r05_live_pmc.json"):
+def _latest_profile(suffix):
+    """newest profiles/rNN_<suffix> (the records are named per round)"""
+    import glob
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)))
+    return os.path.basename(c[-1]) if c else "r00_" + suffix
+
+
+def _verified_pmc(name=None):
     """Counter records of tools/prof_live.sh, per kernel -- only those whose kernel SOURCE file still has the sha256 it had
     when the counters were collected (a kernel edit must not leave stale counters in the bench line); the others read
     {"stale": reason}."""
     import hashlib
+    name = name or _latest_profile("live_pmc.json")
     rec = _load_json(name)
     if not rec:
         return {}
@@ -260,7 +268,6 @@ def predicted_scaling(ctx, seqs, schemes=("window",), reps=2, worlds=(2, 4, 8)):
     not equal time -- the thin range of the longest targets builds one LDS profile per <= 64 targets.)"""
     import torch
     import reseek_amd
-    from reseek_amd import shardplan
     n = len(seqs)
     lens = np.array([len(s) for s in seqs], np.float64)
     HIT_MIN, HIT_CAP = 120, 1 << 22
@@ -313,6 +320,8 @@ def predicted_scaling(ctx, seqs, schemes=("window",), reps=2, worlds=(2, 4, 8)):
     for scheme in schemes:
         if scheme == "window":
             continue
+        sys.path.insert(0, os.path.join(ROOT, "tools", "exp"))
+        import shardplan                        # the r04 rectangle + triangle cuts, kept for tools/exp/shard_times.py
         r = {}
         for N in worlds:
             p = shardplan.plan(lens, N, scheme)
@@ -352,7 +361,7 @@ def live_kernels(ctx, seqs, db, reps=3):
       k_sw_qp     float SW + trace, 64 queries x all chains (query-profile kernel; the -db / -verysensitive regime)
     Bounds: VALU issue (one wave64 instruction per 4 cycles per SIMD for mixed VOP2/VOP3/DPP streams, profiles/r02_ubench_valu.txt)
     and, for k_sw_float, the LDS (8 random ds_read_b32 per cell).  `pmc` = issue / LDS-busy fractions from the rocprofv3
-    counter passes of `bench.py --live-only` committed as profiles/r05_live_pmc.json (tools/prof_live.sh)."""
+    counter passes of `bench.py --live-only` committed as profiles/rNN_live_pmc.json (tools/prof_live.sh; the newest round's record is read)."""
     import torch
     import reseek_amd
     n = len(seqs)
@@ -661,7 +670,7 @@ def config_shares(which=("config2", "config3", "config4")):
                 os.remove(db)
     finally:
         ctx.close()
-    out["kernel_time_split"] = "rocprofv3 kernel traces of these three calls: profiles/r04_search_*_rocprofv3.txt (tools/prof_search.sh)"
+    out["kernel_time_split"] = "rocprofv3 kernel traces of these three calls: profiles/r06_search_*_rocprofv3.txt (tools/prof_search.sh)"
     out["reference_cores_on_this_box"] = cores
     return out
 
@@ -694,6 +703,145 @@ def search_sharded_leg(ctx, seqs, rank, world, dist, coll_dev):
                 "hits_gathered": int(nhits)}
 
 
+REQUIRED_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                 "dtype", "data", "config", "roofline")
+LINE_LIMIT = 4096
+
+
+def _r(x, nd=4):
+    return round(float(x), nd) if isinstance(x, (int, float)) and not isinstance(x, bool) else x
+
+
+def compact_line(res):
+    """The ONE line the driver parses: the contract's keys, `roofline` and `cpu_baseline` as small objects of
+    scalars, and scalar summaries of the other legs -- strict JSON, one line, < 4096 bytes whatever the legs produced.  Everything
+    long (`roofline_live`, `predicted_scaling`, `configs`, the notes) lives in the detail record (`emit_detail`)."""
+    cfg = res.get("config", {})
+    hr = cfg.get("hit_records") or {}
+    rf = res.get("roofline", {})
+    hbm = rf.get("hbm", {})
+    out = {k: res.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                   "vs_baseline", "dtype", "data")}
+    out["ms_per_step"] = _r(out["ms_per_step"], 4)
+    out["chain_pairs_per_sec"] = _r(res.get("chain_pairs_per_sec"), 1)
+    out["config"] = {"workload": str(cfg.get("workload", ""))[:200], "pairs_total": cfg.get("pairs_total"), "cells_total": cfg.get("cells_total"),
+                     "collective_backend": cfg.get("collective_backend"), "collective_world": cfg.get("collective_world"),
+                     "windows": cfg.get("windows") if len(cfg.get("windows") or []) <= 16 else None,
+                     "hit_records": {"min_score": hr.get("min_score"), "rank0_per_step": hr.get("rank0_per_step"),
+                                     "gathered_all_ranks": hr.get("gathered_all_ranks"), "gather_check": hr.get("gather_check")}}
+    out["roofline"] = {"bound": rf.get("bound"), "kernel": rf.get("kernel"), "achieved": _r(rf.get("achieved")), "peak": _r(rf.get("peak")),
+                       "unit": rf.get("unit"), "frac": _r(rf.get("frac")), "kernel_ms": _r(rf.get("kernel_ms")),
+                       "lane_ops_per_cell": rf.get("lane_ops_per_cell"), "frac_vs_guide_vop2_rate": _r(rf.get("frac_vs_guide_vop2_rate")),
+                       "traffic": rf.get("traffic"), "algorithmic_bytes": _r(hbm.get("algorithmic_bytes"), 0),
+                       "hbm_achieved_GBs": _r(hbm.get("achieved"), 1), "hbm_peak_GBs": hbm.get("peak"), "hbm_frac": _r(hbm.get("frac"))}
+    cb = res.get("cpu_baseline")
+    if cb:
+        out["cpu_baseline"] = {"value": _r(cb.get("value"), 1), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+                               "sample": str(cb.get("sample", ""))[:160]}
+    out["dtype_note"] = "integer scores n/2048 in packed f16 (exact on [0, 2048]); int32 rescoring at the ceiling"
+    se, sb, cf, ps = res.get("search"), res.get("search_bca"), res.get("configs") or {}, res.get("predicted_scaling") or {}
+    if se:
+        out["search_s"] = _r(se.get("seconds"))
+        out["search_chain_pairs_per_sec"] = _r(se.get("chain_pairs_per_sec"), 1)
+        if "hits_gathered" in se:
+            out["search_hits_gathered"] = se["hits_gathered"]
+    if sb:
+        out["search_bca_s"] = _r(sb.get("seconds"))
+        cbb = sb.get("cpu_baseline") or {}
+        out["speedup"] = _r(cbb.get("speedup_whole_call"), 1)
+        out["speedup_ref_cores"] = cbb.get("cores")
+        out["search_bca_identical_on_sample"] = (sb.get("hit_table_on_sample") or {}).get("identical")
+    for key, tag in (("config2_s", "config2_fast_db_11211x11211"), ("config3_s", "config3_share_256x125000_sensitive"),
+                     ("config4_s", "config4_share_1000x87500_verysensitive")):
+        e = cf.get(tag)
+        if e:
+            out[key] = _r(e.get("seconds"))
+            out[key[:-2] + "_identical_on_sample"] = (e.get("vs_reference_on_sample") or {}).get("identical")
+            if e.get("clock"):
+                out[key[:-2] + "_sclk_ghz"] = e["clock"].get("sclk_busy_mean_ghz")
+            if e.get("swqp_clock_ghz"):
+                out[key[:-2] + "_swqp_clock_ghz"] = _r(e["swqp_clock_ghz"], 3)
+    w = ps.get("window") or {}
+    for N in (2, 4, 8):
+        if "n%d" % N in w:
+            out["predicted_eff_n%d" % N] = w["n%d" % N].get("efficiency")
+    sp = ps.get("search") or {}
+    for N in (2, 4, 8):
+        if "n%d" % N in sp:
+            out["predicted_search_eff_n%d" % N] = sp["n%d" % N].get("efficiency")
+    if res.get("box"):
+        out["box"] = res["box"]
+    out["detail"] = res.get("detail_file")
+    line = json.dumps(out, allow_nan=False, separators=(",", ":"))
+    if len(line) >= LINE_LIMIT:                   # never let an over-long string field take the line over the limit
+        for k in ("dtype_note", "box"):
+            out.pop(k, None)
+        out["config"]["workload"] = out["config"]["workload"][:80]
+        out["config"]["windows"] = None
+        if "cpu_baseline" in out:
+            out["cpu_baseline"].pop("sample", None)
+        line = json.dumps(out, allow_nan=False, separators=(",", ":"))
+    assert len(line) < LINE_LIMIT and "\n" not in line, "bench line too long (%d bytes)" % len(line)
+    return line
+
+
+def _nan_to_none(o):
+    if isinstance(o, float) and (o != o or o in (float("inf"), float("-inf"))):
+        return None
+    if isinstance(o, dict):
+        return {k: _nan_to_none(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_nan_to_none(v) for v in o]
+    return o
+
+
+def emit_detail(res, path):
+    """Everything the compact line leaves out: the full record to `path` (under gpurun_out/: it travels back from the GPU box) and,
+    section by section, to EARLIER stdout lines prefixed `bench-detail` (not JSON lines: nothing but the last line starts with `{`)."""
+    res = _nan_to_none(res)
+    try:
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(res, f, allow_nan=False)
+        res["detail_file"] = os.path.relpath(path, ROOT) if path.startswith(ROOT) else path
+    except OSError as e:
+        sys.stderr.write("bench: could not write %s: %s\n" % (path, e))
+        res["detail_file"] = None
+    for k in ("roofline", "cpu_baseline", "predicted_scaling", "roofline_live", "search", "search_bca", "configs"):
+        if k in res:
+            print("bench-detail %s: %s" % (k, json.dumps(res[k], allow_nan=False)))
+    return res
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` outside torchrun (the reference fans out by itself: `-threads`,
+    runself.cpp:101-145): one process per GPU under torch.distributed.run on this node, rendezvous on 127.0.0.1, same arguments.
+    Fails loudly when the box has fewer than N devices (RSK_BENCH_ONE_DEVICE=1: all ranks on cuda:0 over gloo, a plumbing check
+    whose numbers mean nothing)."""
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (librsk has no CPU fallback)")
+    ndev = torch.cuda.device_count()
+    if n > ndev and os.environ.get("RSK_BENCH_ONE_DEVICE", "") != "1":
+        raise SystemExit("bench.py --gpus %d: this box has %d GPU(s) (set RSK_BENCH_ONE_DEVICE=1 to run all ranks on cuda:0 over gloo; "
+                         "such a run only checks the plumbing)" % (n, ndev))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cpus() // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -708,13 +856,21 @@ def main():
     ap.add_argument("--live-only", action="store_true", help="only the live-path kernels (the command tools/prof_live.sh profiles)")
     ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE configs[2..4] legs (rank 0, 1 GPU only)")
     ap.add_argument("--configs-only", default="", help="only these legs, e.g. config3,config4 (prints their JSON and exits)")
+    ap.add_argument("--detail", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"), help="where the full record goes (the last "
+                    "stdout line is the compact < 4 KB contract line)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args.gpus)                     # does not return
 
     import torch
     import reseek_amd
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch `python bench.py --gpus N`, or torchrun with --nproc-per-node N "
+                         "AND --gpus N)" % (args.gpus, world))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (librsk has no CPU fallback)")
@@ -848,24 +1004,25 @@ def main():
         traffic, traffic_src = None, None
         try:
             import hashlib
-            with open(os.path.join(ROOT, "profiles", "r05_traffic.json")) as f:
+            tname = _latest_profile("traffic.json")
+            with open(os.path.join(ROOT, "profiles", tname)) as f:
                 tj = json.load(f)
             with open(os.path.join(ROOT, tj["kernel_source"]), "rb") as f:
                 sha = hashlib.sha256(f.read()).hexdigest()
             if sha != tj["kernel_source_sha256"]:
-                traffic_src = "profiles/r05_traffic.json is STALE (%s changed since the counters were collected): re-run tools/prof_bench.sh" % tj["kernel_source"]
+                traffic_src = "profiles/%s is STALE (%s changed since the counters were collected): re-run tools/prof_bench.sh" % (tname, tj["kernel_source"])
             elif n != 11211 or args.chains or world != 1:
-                traffic_src = "profiles/r05_traffic.json holds the 1-GPU full-set workload only"
+                traffic_src = "profiles/%s holds the 1-GPU full-set workload only" % tname
             else:
                 traffic = float(tj["traffic_bytes_per_launch"])
-                traffic_src = "profiles/r05_traffic.json (rocprofv3 PMC FETCH_SIZE x 2 + WRITE_SIZE per dispatch, same command; kernel source sha256 verified)"
+                traffic_src = "profiles/%s (rocprofv3 PMC FETCH_SIZE x 2 + WRITE_SIZE per dispatch, same command; kernel source sha256 verified)" % tname
         except (OSError, ValueError, KeyError) as e:
             traffic_src = "no traffic record (%s)" % e
         res = {
             "metric": "aligned cells/sec (SCOP40-shaped all-vs-all, gapless int Mu kernel)",
             "value": cells_per_s, "unit": "cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None,
-            "dtype": "int (exact: integer scores n/2048 carried in packed f16, every sum exact on [0, 2048]; int32 rescoring at the 2048 ceiling)", "data": "synthetic",
+            "dtype": "int16-exact", "data": "synthetic",
             "chain_pairs_per_sec": total_pairs * args.steps / dt,
             "config": {"workload": "BASELINE configs[1]: SCOP40-shaped (%d chains, %d residues%s) all-vs-all "
                                    "i<=j, swgaplessint kernel only" % (n, int(nres), " per GPU" if args.weak else ""),
@@ -938,10 +1095,14 @@ def main():
                 res["configs"] = config_shares()
             except Exception as e:  # noqa: BLE001
                 sys.stderr.write("bench: configs[2..4] leg failed: %s\n" % e)
-        print(json.dumps(res))
+        res = emit_detail(res, args.detail)
+        final_line = compact_line(res)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        print(final_line, flush=True)              # the LAST line of stdout: the one the driver parses
 
 
 if __name__ == "__main__":

@@ -611,10 +611,27 @@ int rsk_launch_gapless_rings(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int
     }
     ctx->gl_pairs = pairs; ctx->gl_cells = cells; ctx->gl_slots = slots;
 
-    // work list: one workgroup per (ring, block of targets); only blocks that contain work, the
-    // expensive ones first.  Cached per (target set, triangle flag) in the query chain set.
+    // work list: one workgroup per (ring, block of targets); only blocks that contain work, the expensive ones first.  Cached in
+    // the query chain set per (target set, triangle flag, block size, window); the lookup, a rebuild and the launches that read the
+    // entry all happen under the set's mutex (launches are asynchronous: the lock is held for microseconds), and an entry that is
+    // evicted is hipFree'd, which waits for the kernels still reading it.
     rsk_db *qm = const_cast<rsk_db *>(q);
-    if (qm->work_for != t->uid || qm->work_tri != self_triangle || qm->work_tb != tb || qm->work_win_lo != win_lo || qm->work_win_hi != win_hi) {
+    std::lock_guard<std::mutex> work_lock(qm->claim_mutex);
+    rsk_db::gl_work *we = nullptr;
+    for (auto &e : qm->work_cache)
+        if (e.work_for == t->uid && e.work_tri == self_triangle && e.work_tb == tb && e.win_lo == win_lo && e.win_hi == win_hi) { we = &e; break; }
+    if (!we) {
+        if (qm->work_cache.size() < RSK_GL_WORK_ENTRIES) { qm->work_cache.emplace_back(); we = &qm->work_cache.back(); }
+        else {
+            we = &qm->work_cache[0];
+            for (auto &e : qm->work_cache) if (e.last_use < we->last_use) we = &e;
+        }
+        // the key is invalid from here until the rebuild has completed: a failure on the way cannot leave a stale hit
+        we->work_for = 0;
+        if (we->d_work) { (void) hipFree(we->d_work); we->d_work = nullptr; }
+        if (we->d_long_iq) { (void) hipFree(we->d_long_iq); we->d_long_iq = nullptr; }
+        if (we->d_long_it) { (void) hipFree(we->d_long_it); we->d_long_it = nullptr; }
+        we->long_pairs = 0; we->work_count[0] = we->work_count[1] = 0;
         const uint32_t TB[2] = { tb, tb };             // targets per workgroup (the claim order is built for this block size)
         std::vector<uint2> w[2];
         std::vector<uint64_t> cost[2];
@@ -635,18 +652,14 @@ int rsk_launch_gapless_rings(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int
             std::vector<uint32_t> order(w[c].size());
             for (uint32_t k = 0; k < order.size(); ++k) order[k] = k;
             std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[c][a] > cost[c][b]; });
-            qm->work_count[c] = (uint32_t) order.size();
+            we->work_count[c] = (uint32_t) order.size();
             for (uint32_t k : order) all.push_back(w[c][k]);
         }
-        if (qm->d_work) (void) hipFree(qm->d_work);
-        qm->d_work = nullptr;
         if (!all.empty()) {
-            { const int rc_ = rsk_db_malloc(qm, ctx, (void **) &qm->d_work, all.size() * sizeof(uint2)); if (rc_ != RSK_OK) return rc_; }
-            RSK_HIP(hipMemcpy(qm->d_work, all.data(), all.size() * sizeof(uint2), hipMemcpyHostToDevice));
+            { const int rc_ = rsk_db_malloc(qm, ctx, (void **) &we->d_work, all.size() * sizeof(uint2)); if (rc_ != RSK_OK) return rc_; }
+            RSK_HIP(hipMemcpy(we->d_work, all.data(), all.size() * sizeof(uint2), hipMemcpyHostToDevice));
         }
-        // queries too long for a ring: (long query, target) pairs of the per-pair kernel, part of the same cache
-        if (qm->d_long_iq) { (void) hipFree(qm->d_long_iq); (void) hipFree(qm->d_long_it); qm->d_long_iq = qm->d_long_it = nullptr; }
-        qm->long_pairs = 0;
+        // queries too long for a ring: (long query, target) pairs of the per-pair kernel, part of the same entry
         if (!q->long_q.empty()) {
             std::vector<uint32_t> iq, it;
             uint32_t pos = (uint32_t) (q->n - q->long_q.size());      // long chains close the processing order
@@ -661,50 +674,71 @@ int rsk_launch_gapless_rings(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int
                 ++pos;
             }
             if (!iq.empty()) {
-                { const int rc_ = rsk_db_malloc(qm, ctx, (void **) &qm->d_long_iq, iq.size() * 4); if (rc_ != RSK_OK) return rc_; }
-                { const int rc_ = rsk_db_malloc(qm, ctx, (void **) &qm->d_long_it, it.size() * 4); if (rc_ != RSK_OK) return rc_; }
-                RSK_HIP(hipMemcpy(qm->d_long_iq, iq.data(), iq.size() * 4, hipMemcpyHostToDevice));
-                RSK_HIP(hipMemcpy(qm->d_long_it, it.data(), it.size() * 4, hipMemcpyHostToDevice));
-                qm->long_pairs = (uint32_t) iq.size();
+                { const int rc_ = rsk_db_malloc(qm, ctx, (void **) &we->d_long_iq, iq.size() * 4); if (rc_ != RSK_OK) return rc_; }
+                { const int rc_ = rsk_db_malloc(qm, ctx, (void **) &we->d_long_it, it.size() * 4); if (rc_ != RSK_OK) return rc_; }
+                RSK_HIP(hipMemcpy(we->d_long_iq, iq.data(), iq.size() * 4, hipMemcpyHostToDevice));
+                RSK_HIP(hipMemcpy(we->d_long_it, it.data(), it.size() * 4, hipMemcpyHostToDevice));
+                we->long_pairs = (uint32_t) iq.size();
             }
         }
-        qm->work_for = t->uid;
-        qm->work_tri = self_triangle;
-        qm->work_tb = tb;
-        qm->work_win_lo = win_lo;
-        qm->work_win_hi = win_hi;
+        we->work_tri = self_triangle;
+        we->work_tb = tb;
+        we->win_lo = win_lo;
+        we->win_hi = win_hi;
+        we->work_for = t->uid;                          // published last
     }
+    we->last_use = ++qm->work_clock;
     (void) nD4; (void) nD8;
 
     RSK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-    // queries too long for a ring: per-pair kernel over (long q) x targets (list built with the work list, cached per target set +
-    // triangle flag).  A few dozen one-workgroup pairs: behind the ring kernels on one stream they were a 0.35 ms tail of a 42.8 ms
-    // launch -- and all of it on the LAST of N windows; on a side stream (forked here, joined before ev1) they run beside them.
-    const bool side = q->long_pairs && !getenv("RSK_GAPLESS_NO_SIDE_STREAM");
-    if (q->long_pairs) {
+    // queries too long for a ring: per-pair kernel over (long q) x targets.  A few dozen one-workgroup pairs: behind the ring
+    // kernels on one stream they were a 0.35 ms tail of a 42.8 ms launch -- and all of it on the LAST of N windows; on a side stream
+    // (forked here, joined before ev1) they run beside them.
+    bool side = we->long_pairs && !getenv("RSK_GAPLESS_NO_SIDE_STREAM");
+    if (side && !ctx->aux) {
+        // stream + both events into locals, published only when all three exist (a half-built set left ctx->aux
+        // non-null with null events on the next call); without them the per-pair kernel simply stays on the launch stream
+        hipStream_t st = nullptr;
+        hipEvent_t ef = nullptr, ej = nullptr;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&ef, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&ej, hipEventDisableTiming) == hipSuccess) {
+            ctx->aux = st; ctx->ev_fork = ef; ctx->ev_join = ej;
+        } else {
+            (void) hipGetLastError();
+            if (ej) (void) hipEventDestroy(ej);
+            if (ef) (void) hipEventDestroy(ef);
+            if (st) (void) hipStreamDestroy(st);
+            side = false;
+        }
+    }
+    bool forked = false;
+    // whatever happens after the fork, the launch stream waits for the side stream before this function returns: the caller may
+    // free or reuse d_rec / d_count / d_scores as soon as ITS stream is done
+    auto join = [&]() -> hipError_t { return forked ? hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0) : hipSuccess; };
+    if (we->long_pairs) {
         hipStream_t ps = ctx->stream;
         if (side) {
-            if (!ctx->aux) {
-                RSK_HIP(hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
-                RSK_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-                RSK_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-            }
             RSK_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
             RSK_HIP(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
             ps = ctx->aux;
         }
-        hipLaunchKernelGGL(k_gapless_pairs, dim3(q->long_pairs), dim3(1024), 0, ps, q->d_mu, q->d_off, q->d_len,
-                           t->d_mu, t->d_off, t->d_len, q->d_long_iq, q->d_long_it, q->long_pairs, (int32_t *) nullptr, (uint32_t *) nullptr,
+        hipLaunchKernelGGL(k_gapless_pairs, dim3(we->long_pairs), dim3(1024), 0, ps, q->d_mu, q->d_off, q->d_len,
+                           t->d_mu, t->d_off, t->d_len, we->d_long_iq, we->d_long_it, we->long_pairs, (int32_t *) nullptr, (uint32_t *) nullptr,
                            (uint32_t *) nullptr, d_scores, ldo, hits);
-        RSK_HIP(hipGetLastError());
-        if (side) RSK_HIP(hipEventRecord(ctx->ev_join, ctx->aux));
+        hipError_t le = hipGetLastError();
+        if (side) {
+            // the join event is recorded even if the launch failed: the stream then simply has nothing before it
+            if (hipEventRecord(ctx->ev_join, ctx->aux) == hipSuccess) forked = true;
+            else { (void) hipGetLastError(); (void) hipStreamSynchronize(ctx->aux); }
+        }
+        if (le != hipSuccess) { (void) join(); RSK_HIP(le); }
     }
-    rc = launch_ring_class<16, 16>(ctx, q, t, (const uint2 *) q->d_work + q->work_count[0], q->work_count[1], d_claim, self_triangle, win_lo, win_hi,
+    rc = launch_ring_class<16, 16>(ctx, q, t, (const uint2 *) we->d_work + we->work_count[0], we->work_count[1], d_claim, self_triangle, win_lo, win_hi,
                                   d_scores, ldo, tb, hits);
-    if (rc != RSK_OK) return rc;
-    rc = launch_ring_class<8, 16>(ctx, q, t, (const uint2 *) q->d_work, q->work_count[0], d_claim, self_triangle, win_lo, win_hi, d_scores, ldo, tb, hits);
-    if (rc != RSK_OK) return rc;
-    if (side) RSK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    if (rc != RSK_OK) { (void) join(); return rc; }
+    rc = launch_ring_class<8, 16>(ctx, q, t, (const uint2 *) we->d_work, we->work_count[0], d_claim, self_triangle, win_lo, win_hi, d_scores, ldo, tb, hits);
+    if (rc != RSK_OK) { (void) join(); return rc; }
+    RSK_HIP(join());
     RSK_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     return RSK_OK;
 }

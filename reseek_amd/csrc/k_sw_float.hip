@@ -1525,7 +1525,17 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
     a.tb = d_tb; a.tb_off = d_tboff;
     a.score = d_score; a.besti = d_bi; a.bestj = d_bj;
     a.bnd = d_bnd; a.bnd_off = d_bndoff;
+    // the four events rsk_align_last_times reads belong to THIS function alone and are valid only as a set (ev0 / ev1
+    // are shared with every other launch of the context)
+    ctx->al_times_valid = false;
+    if (!ctx->ev_tb) {
+        hipEvent_t e[4] = { nullptr, nullptr, nullptr, nullptr };
+        for (int k = 0; k < 4; ++k)
+            if (hipError_t ee = hipEventCreate(&e[k])) { for (int j = 0; j < k; ++j) (void) hipEventDestroy(e[j]); return rsk_hip_fail(ee, "hipEventCreate", __FILE__, __LINE__); }
+        ctx->ev_al0 = e[0]; ctx->ev_al1 = e[1]; ctx->ev_st = e[2]; ctx->ev_tb = e[3];
+    }
     RSK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    RSK_HIP(hipEventRecord(ctx->ev_al0, ctx->stream));
     {
         static std::atomic<int> attr_done[64];      // per device: the attribute belongs to the device's code object
         const int arc = rsk_once_per_device(attr_done, ctx->device, [&]() -> int {
@@ -1554,11 +1564,11 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
     }
     RSK_HIP(hipGetLastError());
     RSK_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    RSK_HIP(hipEventRecord(ctx->ev_al1, ctx->stream));
     hipLaunchKernelGGL(k_traceback, dim3((unsigned) ((npairs + 63) / 64)), dim3(64), 0, ctx->stream, d_tb, d_tboff, d_ia, dba->d_len,
                        d_ib, dbb->d_len, cl, d_score, d_bi, d_bj, (uint32_t) npairs, d_paths, d_pend, d_pstart, d_plen, d_loa, d_lob,
                        (const swq_item *) (D + o_q[0]), (const swq_item *) (D + o_q[1]), (const uint32_t *) (D + o_qpitem));
     RSK_HIP(hipGetLastError());
-    if (!ctx->ev_tb) { RSK_HIP(hipEventCreate(&ctx->ev_tb)); RSK_HIP(hipEventCreate(&ctx->ev_st)); }
     RSK_HIP(hipEventRecord(ctx->ev_tb, ctx->stream));
     if (want_stats) {
         if ((rc = dalloc((void **) &d_pos, 2 * so * 4)) != RSK_OK) return rc;
@@ -1588,6 +1598,7 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
         RSK_HIP(hipGetLastError());
     }
     RSK_HIP(hipEventRecord(ctx->ev_st, ctx->stream));
+    ctx->al_times_valid = true;
     if (paths) {
         // pack the paths in the caller's order on the device
         hipLaunchKernelGGL(k_path_sizes, dim3((unsigned) ((npairs + 255) / 256)), dim3(256), 0, ctx->stream, d_slot, d_plen, (uint32_t) npairs, d_sizes);
@@ -1899,9 +1910,10 @@ extern "C" int rsk_align_last_times(rsk_ctx *ctx, float *sw_ms, float *traceback
 {
     if (!ctx) { rsk_set_error("rsk_align_last_times: ctx is NULL"); return RSK_E_INVALID; }
     float a = -1.0f, b = -1.0f, c = -1.0f;
-    if (ctx->ev0 && ctx->ev1 && hipEventSynchronize(ctx->ev1) == hipSuccess) (void) hipEventElapsedTime(&a, ctx->ev0, ctx->ev1);
-    if (ctx->ev_tb && ctx->ev_st && hipEventSynchronize(ctx->ev_st) == hipSuccess) {
-        (void) hipEventElapsedTime(&b, ctx->ev1, ctx->ev_tb);
+    // -1 unless the last rsk_align_pairs call of this context recorded all four of its events
+    if (ctx->al_times_valid && ctx->ev_st && hipEventSynchronize(ctx->ev_st) == hipSuccess) {
+        (void) hipEventElapsedTime(&a, ctx->ev_al0, ctx->ev_al1);
+        (void) hipEventElapsedTime(&b, ctx->ev_al1, ctx->ev_tb);
         (void) hipEventElapsedTime(&c, ctx->ev_tb, ctx->ev_st);
     }
     if (sw_ms) *sw_ms = a;

@@ -180,6 +180,8 @@ extern "C" void rsk_ctx_destroy(rsk_ctx *ctx)
     if (ctx->ev_fork) (void) hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void) hipEventDestroy(ctx->ev_join);
     if (ctx->aux) (void) hipStreamDestroy(ctx->aux);
+    if (ctx->ev_al0) (void) hipEventDestroy(ctx->ev_al0);
+    if (ctx->ev_al1) (void) hipEventDestroy(ctx->ev_al1);
     if (ctx->ev_tb) (void) hipEventDestroy(ctx->ev_tb);
     if (ctx->ev_st) (void) hipEventDestroy(ctx->ev_st);
     delete ctx;
@@ -397,11 +399,16 @@ extern "C" void rsk_db_destroy(rsk_db *db)
 {
     if (!db) return;
     void *ptrs[] = { db->d_seq, db->d_len, db->d_off, db->d_mu, db->d_prof, db->d_x, db->d_y, db->d_z, db->d_selfrev,
-                     db->d_ring_tab, db->d_ring_letters, db->d_ring_laneq, db->d_ring_qid, db->d_ring_perm, db->d_work, db->d_prof_cb, db->d_prof_ra, db->d_pf_table, db->d_pf_postings, db->d_len_perm, db->d_len_rank, db->d_long_iq, db->d_long_it };
+                     db->d_ring_tab, db->d_ring_letters, db->d_ring_laneq, db->d_ring_qid, db->d_ring_perm, db->d_prof_cb, db->d_prof_ra, db->d_pf_table, db->d_pf_postings, db->d_len_perm, db->d_len_rank };
     for (void *p : ptrs)
         if (p) (void) hipFree(p);
     for (auto &kv : db->tri_claims) (void) hipFree(kv.second);
     for (auto &kv : db->nat_claims) (void) hipFree(kv.second);
+    for (auto &w : db->work_cache) {
+        if (w.d_work) (void) hipFree(w.d_work);
+        if (w.d_long_iq) (void) hipFree(w.d_long_iq);
+        if (w.d_long_it) (void) hipFree(w.d_long_it);
+    }
     delete db;
 }
 
@@ -507,7 +514,14 @@ extern "C" int rsk_mu_gapless_hits_window_dev(rsk_ctx *ctx, const rsk_db *db, ui
     RSK_HIP(hipSetDevice(ctx->device));
     if (!db->rings_built && (rc = rsk_build_rings(const_cast<rsk_db *>(db))) != RSK_OK) return rc;
     RSK_HIP(hipMemsetAsync(d_count, 0, 4, ctx->stream));
-    if (pos_lo == pos_hi) { ctx->gl_pairs = ctx->gl_cells = ctx->gl_slots = 0; ctx->last_ms = 0.0f; return RSK_OK; }
+    if (pos_lo == pos_hi) {
+        // an empty window launches nothing: record the two timing events back to back so that rsk_ctx_last_kernel_ms reports this
+        // call (0 ms), not the launch before it
+        ctx->gl_pairs = ctx->gl_cells = ctx->gl_slots = 0; ctx->last_ms = 0.0f;
+        RSK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+        RSK_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+        return RSK_OK;
+    }
     return rsk_launch_gapless_rings(ctx, db, db, 1, d_scores, ldo, min_score, base, base, d_records, capacity, d_count, pos_lo, pos_hi);
 }
 

@@ -159,6 +159,9 @@ extern "C" int rsk_gather_hits(rsk_comm *c, const void *d_local, uint64_t n_loca
         off += h[(size_t) r];
     }
     RSK_RCCL(g_rccl.GroupEnd(), "ncclGroupEnd");
+    // "on return *d_all holds all ranks' records" (include/reseek_amd.h): the broadcasts are queued on the context's stream, which may
+    // be a non-blocking user stream a plain hipMemcpy does not order with -- wait here
+    RSK_HIP(hipStreamSynchronize(ctx->stream));
     *d_all = c->d_all;
     *n_all = total;
     if (counts) memcpy(counts, h.data(), (size_t) c->world * 8);

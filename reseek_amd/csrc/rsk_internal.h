@@ -30,7 +30,10 @@ struct rsk_ctx {
     hipEvent_t ev_wait = nullptr;   // blocking-sync event of rsk_stream_wait (created on first use)
     hipStream_t aux = nullptr;      // side stream of the gapless launch (the per-pair kernel of chains beyond a ring runs beside the ring kernels)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    hipEvent_t ev_tb = nullptr, ev_st = nullptr;   // rsk_align_pairs: after the traceback kernel / after the statistics kernels (created on first use)
+    // rsk_align_pairs' own events (created together on first use): before / after the SW kernels, after the traceback kernel, after
+    // the statistics kernels; al_times_valid = all four were recorded by the context's last rsk_align_pairs call
+    hipEvent_t ev_al0 = nullptr, ev_al1 = nullptr, ev_tb = nullptr, ev_st = nullptr;
+    bool al_times_valid = false;
     uint64_t al_steps = 0, al_col_tests = 0;       // last rsk_align_pairs call with statistics: path characters walked, LDDT column-pair tests
     float last_ms = -1.0f;
     // accounting of the last gapless matrix call
@@ -123,6 +126,8 @@ struct rsk_ring {
     uint32_t qid_off;      // offset into d_ring_qid (nq uint32: global query index)
 };
 
+#define RSK_GL_WORK_ENTRIES 16
+
 struct rsk_db {
     rsk_ctx *ctx = nullptr;
     uint64_t uid = 0;          // unique per rsk_db_create (cache keys)
@@ -159,15 +164,23 @@ struct rsk_db {
     // the set with different partners cannot free an array the other one has handed to a launch.
     std::map<uint32_t, uint32_t *> tri_claims, nat_claims;
     std::mutex claim_mutex;
-    // gapless work list cache (valid for one target set + triangle flag)
-    uint64_t work_for = 0;              // uid of the target set the list was built for
-    int work_tri = -1;
-    uint32_t work_tb = 0;               // targets per work item of the cached list
-    uint32_t work_win_lo = 0, work_win_hi = 0;   // ... and its window of target positions (rsk_launch_gapless_rings)
-    void *d_work = nullptr;             // uint2 (ring, first target) entries, D = 4 class first
-    uint32_t work_count[2] = { 0, 0 };
-    uint32_t *d_long_iq = nullptr, *d_long_it = nullptr;   // (long query, target) pairs of the per-pair kernel, same cache key
-    uint32_t long_pairs = 0;
+    // gapless work list cache: a few entries keyed by (target set, triangle flag, block size, window) -- a rank's window, or the
+    // N windows a one-GPU prediction walks through, come back call after call.  Looked up, rebuilt and handed to the launches
+    // under claim_mutex (two contexts sharing a set with different partners / windows must not free each other's
+    // list between the check and the launch; an evicted entry is hipFree'd = after the kernels reading it).
+    struct gl_work {
+        uint64_t work_for = 0;          // uid of the target set the list was built for (0 = entry invalid)
+        int work_tri = -1;
+        uint32_t work_tb = 0;           // targets per work item
+        uint32_t win_lo = 0, win_hi = 0;
+        void *d_work = nullptr;         // uint2 (ring, first target) entries, D = 4 class first
+        uint32_t work_count[2] = { 0, 0 };
+        uint32_t *d_long_iq = nullptr, *d_long_it = nullptr;   // (long query, target) pairs of the per-pair kernel
+        uint32_t long_pairs = 0;
+        uint64_t last_use = 0;
+    };
+    std::vector<gl_work> work_cache;    // <= RSK_GL_WORK_ENTRIES
+    uint64_t work_clock = 0;
     // chains by increasing length (Mu SW filter: the targets a wave works on at once have similar lengths)
     uint32_t *d_len_perm = nullptr;     // perm[k] = chain index of rank k
     uint32_t *d_len_rank = nullptr;     // rank[chain]

@@ -55,3 +55,28 @@ def test_bench_strong_scaling_world2_gloo_one_device():
     assert one.returncode == 0, one.stderr[-2000:]
     r1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
     assert res["config"]["hit_records"]["gathered_all_ranks"] == r1["config"]["hit_records"]["rank0_per_step"] > 0
+
+
+def test_bench_gpus_2_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with NO torchrun in the command (`--gpus` was parsed and never read): bench.py
+    re-executes itself under torch.distributed.run with two ranks (RSK_BENCH_ONE_DEVICE=1: both on cuda:0 over gloo) and the line
+    says so; without that variable, and with fewer than N devices, it must refuse loudly."""
+    import torch
+    env = dict(os.environ, RSK_BENCH_ONE_DEVICE="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--chains", "1500", "--steps", "2"], capture_output=True,
+                       text=True, env=env, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    last = r.stdout.strip().splitlines()[-1]
+    assert len(last) < 4096
+    res = json.loads(last)
+    assert res["n_gpus"] == 2 and res["config"]["collective_world"] == 2 and res["steps"] == 2
+    gc = res["config"]["hit_records"]["gather_check"]
+    assert gc["gathered_all_ranks"] == gc["one_gpu_hit_records"] == gc["sum_of_rank_counts"] > 0
+    assert res["config"]["pairs_total"] == 1500 * 1501 // 2
+    if torch.cuda.device_count() < 2:
+        env.pop("RSK_BENCH_ONE_DEVICE")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--chains", "1500", "--steps", "2"], capture_output=True,
+                           text=True, env=env, cwd=ROOT, timeout=300)
+        assert r.returncode != 0 and "this box has 1 GPU" in r.stderr, r.stderr[-2000:]

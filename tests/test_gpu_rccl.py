@@ -49,7 +49,7 @@ def test_bench_under_torchrun_world1_rccl():
     # the records gathered over RCCL are the records the kernel appended
     assert res["config"]["hit_records"]["gathered_all_ranks"] == res["config"]["hit_records"]["rank0_per_step"] > 0
     # the sharded whole-search leg ran through the same group
-    assert res["search"]["hits_gathered"] > 0
+    assert res["search_hits_gathered"] > 0 and res["search_s"] > 0
     assert res["config"]["collective_world"] == 1 and res["config"]["windows"] == [[0, n]]
 
 

@@ -3,6 +3,8 @@ kind 0 = self search: shard r scores the pairs (i <= j) whose target j lies in [
 chains[0, lo) x chains[lo, hi) plus the triangle of chains[lo, hi) -- with equal DP cells per shard;
 kind 1 = -db search: contiguous chain ranges with equal residues.  The same function serves the one-process form
 (DBSearcher::m_Devices / RSK_DEVICES: one context per device) and the one-process-per-GPU form (shard_index / shard_count)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -77,9 +79,11 @@ def test_more_shards_than_chains_and_bad_arguments():
 @pytest.mark.parametrize("world", [1, 2, 3, 8])
 @pytest.mark.parametrize("scheme", ["targets", "fold"])
 def test_shardplan_launch_lists_tile_the_triangle(world, scheme):
-    """reseek_amd/shardplan.py (the rectangle + triangle cuts tools/exp/shard_times.py measures against the window scheme
+    """tools/exp/shardplan.py (the rectangle + triangle cuts tools/exp/shard_times.py measures against the window scheme
     bench.py runs): every pair i <= j in exactly one launch of one rank, cell shares within one target's worth of equal."""
-    from reseek_amd import shardplan as sp
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "exp"))
+    import shardplan as sp
     for name, L in lengths_sets():
         if len(L) < 100:
             continue

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """What N = 2 / 4 / 8 ranks of bench.py would each take, run one after the other on ONE GPU: kernel ms (HIP events of the
-library) of every rank's launches under the shard schemes of reseek_amd/shardplan.py.  usage: shard_times.py [scheme ...]"""
+library) of every rank's launches under the shard schemes of tools/exp/shardplan.py.  usage: shard_times.py [scheme ...]"""
 import json
 import os
 import sys
@@ -12,7 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 import reseek_amd  # noqa: E402
-from reseek_amd import shardplan  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import shardplan  # noqa: E402
 
 schemes = sys.argv[1:] or ["targets", "fold"]
 seqs = bench.synth_mu_chains(0x5EED5EEC, None)
