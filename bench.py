@@ -339,6 +339,55 @@ def predicted_scaling(ctx, seqs, schemes=("window",), reps=2, worlds=(2, 4, 8)):
     return res
 
 
+def predicted_search_scaling(seqs, worlds=(2, 4, 8), reps=2, bca_worlds=(8,)):
+    """`predicted_scaling.search`: what each rank of an N-GPU run of the LIVE self search would take -- the whole
+    `rsk_search -sensitive` call with shard_index k / shard_count N (RunSelfShard, host/dbsearcher.cpp; the reference deals the pairs
+    to threads through a locked counter, runself.cpp:72-99), every shard run one after the other on THIS GPU from the prepared
+    container (.rskdb: profiles and self-rev scores inside) and, for `bca_worlds`, from the .bca file (featurisation + self-rev of
+    the chains a shard needs inside every call: the part that does not shard).  Last of `reps` runs per shard; efficiency =
+    t(1) / (N x slowest shard); `hits_sum` must equal the unsharded call's hits."""
+    import torch
+    import reseek_amd
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_search
+    ctx = reseek_amd.Ctx(0, stream=torch.cuda.current_stream().cuda_stream)
+    res = {"method": "rsk_search shard_index k / shard_count N, shards one after the other on one GPU, wall seconds of the whole call "
+                     "(last of %d runs); efficiency = t(1) / (N x slowest shard)" % reps}
+    try:
+        with tempfile.TemporaryDirectory() as td:
+            db, out = os.path.join(td, "syn.rskdb"), os.path.join(td, "hits.tsv")
+            bench_search.write_rskdb(db, seqs, np.random.default_rng(5))
+            bca = os.path.join(td, "syn.bca")
+            bench_search.write_bca_records(bca, bench_search.gen_bca_chains(scop40_lengths(), np.random.default_rng(7)))
+
+            def shard_s(src, k, N, r):
+                dt, nh, st = 0.0, 0, None
+                for _ in range(r):
+                    t0 = time.perf_counter()
+                    nh, st = ctx.search(src, out, "sensitive", shard_index=k, shard_count=N)
+                    dt = time.perf_counter() - t0
+                return dt, int(nh), int(st[0])
+
+            for tag, src, ws, r in (("rskdb", db, worlds, reps), ("bca", bca, bca_worlds, max(1, reps - 1))):
+                t1, h1, p1 = shard_s(src, 0, 1, reps)
+                e = {"one_gpu_seconds": round(t1, 4), "hits": h1, "chain_pairs": p1}
+                for N in ws:
+                    v = [shard_s(src, k, N, r) for k in range(N)]
+                    secs = [x[0] for x in v]
+                    e["n%d" % N] = {"shard_seconds": [round(x, 4) for x in secs], "max_over_mean": round(max(secs) * N / sum(secs), 4),
+                                    "efficiency": round(t1 / (N * max(secs)), 4), "hits_sum": sum(x[1] for x in v),
+                                    "pairs_sum": sum(x[2] for x in v), "pairs_max_over_mean": round(max(x[2] for x in v) * N / max(1, sum(x[2] for x in v)), 4)}
+                    assert e["n%d" % N]["hits_sum"] == h1 and e["n%d" % N]["pairs_sum"] == p1, \
+                        "%s: the %d shards' hits / pairs do not add up to the unsharded call's: %s" % (tag, N, e)
+                res[tag] = e
+                if tag == "rskdb":
+                    for N in ws:
+                        res["n%d" % N] = e["n%d" % N]
+    finally:
+        ctx.close()
+    return res
+
+
 def config2_mu_letters():
     """Mu letters of the seeded 11,211-chain synthetic .bca (BASELINE configs[2]'s input; host featurisation, no GPU)"""
     import reseek_amd
@@ -856,6 +905,7 @@ def main():
     ap.add_argument("--live-only", action="store_true", help="only the live-path kernels (the command tools/prof_live.sh profiles)")
     ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE configs[2..4] legs (rank 0, 1 GPU only)")
     ap.add_argument("--configs-only", default="", help="only these legs, e.g. config3,config4 (prints their JSON and exits)")
+    ap.add_argument("--search-scaling-only", action="store_true", help="only predicted_scaling.search (prints its JSON and exits)")
     ap.add_argument("--detail", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"), help="where the full record goes (the last "
                     "stdout line is the compact < 4 KB contract line)")
     args = ap.parse_args()
@@ -912,6 +962,9 @@ def main():
         return
     if args.configs_only:
         print(json.dumps({"configs": config_shares(tuple(args.configs_only.split(",")))}))
+        return
+    if args.search_scaling_only:
+        print(json.dumps({"predicted_scaling": {"search": predicted_search_scaling(seqs, bca_worlds=(2, 4, 8))}}))
         return
     out = torch.zeros((n, n), dtype=torch.int16, device="cuda")               # the dense matrix of the whole set; a rank writes its pairs' cells
     summary = torch.zeros(2, dtype=torch.int64, device="cuda")
@@ -1090,6 +1143,11 @@ def main():
                 res["search_bca"] = search_vs_reference()
             except Exception as e:  # noqa: BLE001 -- the kernel metric above stands on its own
                 sys.stderr.write("bench: end-to-end search leg failed: %s\n" % e)
+            if not args.no_predict:
+                try:
+                    res.setdefault("predicted_scaling", {})["search"] = predicted_search_scaling(seqs)
+                except Exception as e:  # noqa: BLE001
+                    sys.stderr.write("bench: predicted search-scaling leg failed: %s\n" % e)
         if not args.no_configs and not args.no_search and world == 1 and not args.chains:
             try:
                 res["configs"] = config_shares()
