@@ -43,8 +43,8 @@ typedef struct rsk_ctx rsk_ctx;   /* one per process/GPU: device, stream, scratc
 typedef struct rsk_db rsk_db;     /* a chain set resident in HBM as SoA */
 
 /* Bumped whenever a struct layout or a signature of this header changes (INTEGRATION.md lists the breaks):
- * 4 = rsk_search_opts leads with struct_size; rsk_shutdown added. */
-#define RSK_ABI_VERSION 5
+ * 4 = rsk_search_opts leads with struct_size; rsk_shutdown added.  5 / 6: additive. */
+#define RSK_ABI_VERSION 6
 int rsk_abi_version(void);        /* the RSK_ABI_VERSION the library was built with */
 const char *rsk_version(void);
 const char *rsk_last_error(void);
@@ -429,6 +429,28 @@ typedef struct rsk_search_opts {
 } rsk_search_opts;
 int rsk_search(rsk_ctx *ctx, const char *query_path, const char *db_path, const rsk_search_opts *opts,
                const char *out_tsv, uint64_t *nhits, uint64_t *stats8);
+
+/* Counters of the search path since the last reset -- process-wide, the counterpart of the static statistics the reference keeps
+ * in DSSAligner (dssaligner.h:90-96: m_AlnCount, m_SWCount, m_MuFilterInputCount, ...), extended by what a GPU run needs to be
+ * read: how many Smith-Waterman pairs reached the E-value stage, what the streamed -db loader cost, how many host->device copies
+ * the chain-set uploads issued, and the clock k_sw_qp actually held (a power-limited kernel runs below the nominal 2.4 GHz).
+ * `struct_size` as in rsk_search_opts: the library writes no member beyond it. */
+typedef struct rsk_path_counters {
+    uint32_t struct_size;
+    uint64_t sw_pairs;            /* pairs through SWFast (sw.cpp:79) in rsk_align_pairs calls of the search drivers             */
+    uint64_t sw_pairs_scored;     /* ... whose score reached m_MinFwdScore: CalcEvalue ran (dssaligner.cpp:852-861)              */
+    uint64_t sw_pairs_rescored;   /* pairs the score-first route sent through the traced kernel (second pass)                   */
+    uint64_t upload_copies;       /* host->device copies issued by chain-set uploads (rsk_db_create)                              */
+    uint64_t upload_bytes;
+    uint64_t db_batches;          /* batches of a streamed -db file (runquery.cpp:82-125 in batches of chains)                   */
+    double loader_seconds;        /* loader thread, summed over the batches: read + DSS featurisation + self-rev + upload         */
+    double featurise_seconds;     /* ... of which LoadChains (DSS featurisation on the host threads + device densities)           */
+    double upload_seconds;        /* ... of which the upload of the batch                                                          */
+    uint64_t swqp_cycles;         /* k_sw_qp: shader cycles (s_memtime) summed over its workgroups                                */
+    uint64_t swqp_ref_ticks;      /* ... and 100 MHz ticks (s_memrealtime) over the same intervals: clock = cycles / ticks x 0.1 GHz */
+} rsk_path_counters;
+int rsk_path_counters_read(rsk_ctx *ctx, rsk_path_counters *out);      /* ctx names the device whose k_sw_qp clock words are read */
+int rsk_path_counters_reset(rsk_ctx *ctx);
 
 /* The shard bounds the searches use (pure host arithmetic, no device): kind 0 = self search, targets [lo, hi) of the
  * triangle of pairs (i <= j) such that every shard covers the same number of DP cells; kind 1 = -db search, a contiguous

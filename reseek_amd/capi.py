@@ -139,6 +139,14 @@ SIGNATURES["rsk_fast_shard_finish_exact"] = SIGNATURES["rsk_fast_shard_finish"]
 SIGNATURES["rsk_fast_shard_close"] = (None, [C.c_void_p])
 SIGNATURES["rsk_rsb_merge"] = (C.c_int, [u32p, u32p, u32p, C.c_size_t, C.c_uint32, C.c_uint32, u32p, u32p, u32p, C.POINTER(C.c_size_t)])
 SIGNATURES["rsk_dss_densities_host"] = (C.c_int, [f32p, f32p, f32p, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double)])
+class PathCounters(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("sw_pairs", C.c_uint64), ("sw_pairs_scored", C.c_uint64), ("sw_pairs_rescored", C.c_uint64),
+                ("upload_copies", C.c_uint64), ("upload_bytes", C.c_uint64), ("db_batches", C.c_uint64), ("loader_seconds", C.c_double),
+                ("featurise_seconds", C.c_double), ("upload_seconds", C.c_double), ("swqp_cycles", C.c_uint64), ("swqp_ref_ticks", C.c_uint64)]
+
+
+SIGNATURES["rsk_path_counters_read"] = (C.c_int, [C.c_void_p, C.POINTER(PathCounters)])
+SIGNATURES["rsk_path_counters_reset"] = (C.c_int, [C.c_void_p])
 SIGNATURES["rsk_shard_range"] = (C.c_int, [C.c_int, u32p, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)])
 SIGNATURES["rsk_bca_copy"] = (C.c_int, [C.c_char_p, C.c_char_p])
 SIGNATURES["rsk_bca_to_mu_fasta"] = (C.c_int, [C.c_char_p, C.c_char_p])
@@ -180,7 +188,12 @@ def lib():
             pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
-            fn = getattr(L, name)
+            try:
+                fn = getattr(L, name)
+            except AttributeError:
+                if os.environ.get("RSK_LIB"):          # an older build of the library in an A/B run (tools/exp/): symbols added since are absent
+                    continue
+                raise
             fn.restype = res
             fn.argtypes = args
         _lib = L
@@ -212,6 +225,24 @@ class Ctx:
 
     def last_kernel_ms(self):
         return lib().rsk_ctx_last_kernel_ms(self.h)
+
+    def path_counters(self, reset=False):
+        """rsk_path_counters_read -> dict (+ swqp_clock_ghz, scored_frac); {} with a library that predates the call (RSK_LIB)"""
+        if not hasattr(lib(), "rsk_path_counters_read") or lib().rsk_path_counters_read.argtypes is None:
+            return {}
+        c = PathCounters()
+        c.struct_size = C.sizeof(PathCounters)
+        _check(lib().rsk_path_counters_read(self.h, C.byref(c)))
+        d = {k: getattr(c, k) for k, _ in PathCounters._fields_ if k != "struct_size"}
+        d["swqp_clock_ghz"] = (d["swqp_cycles"] / d["swqp_ref_ticks"] * 0.1) if d["swqp_ref_ticks"] else None
+        d["scored_frac"] = (d["sw_pairs_scored"] / d["sw_pairs"]) if d["sw_pairs"] else None
+        if reset:
+            _check(lib().rsk_path_counters_reset(self.h))
+        return d
+
+    def path_counters_reset(self):
+        if hasattr(lib(), "rsk_path_counters_reset") and lib().rsk_path_counters_reset.argtypes is not None:
+            _check(lib().rsk_path_counters_reset(self.h))
 
     def close(self):
         if self.h:

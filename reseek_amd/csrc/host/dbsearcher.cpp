@@ -287,6 +287,8 @@ void DBSearcher::RunQuery(ChainReader2 &QCR)
     // the second (full) batch ready by the time the first has gone through the kernels.
     size_t nloaded = 0;
     auto load = [&]() -> std::unique_ptr<DBSearcher> {
+        const auto t_load = std::chrono::steady_clock::now();
+        auto ns_since = [](std::chrono::steady_clock::time_point t) { return (uint64_t) std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t).count(); };
         std::vector<PDBChain *> Chains;
         uint64_t nres = 0;
         const size_t maxc = nloaded++ == 0 ? std::max<size_t>(std::min<size_t>(m_StreamBatchChains, 1024), m_StreamBatchChains / 4) : m_StreamBatchChains;
@@ -303,13 +305,19 @@ void DBSearcher::RunQuery(ChainReader2 &QCR)
         Src->m_SelfRevQueryFlavour = true;               // runquery.cpp:43-44: the search params themselves
         Src->m_Opts = m_Opts;
         Src->m_Ctx = loader.c;
+        const auto t_feat = std::chrono::steady_clock::now();
         try {
             Src->LoadChains(Chains);
         } catch (...) {
             for (PDBChain *C : Chains) delete C;
             throw;
         }
-        Src->UploadToGpu();                              // here, beside the search of the previous batch (synchronous copies)
+        g_rsk_counters.featurise_ns += ns_since(t_feat);
+        const auto t_up = std::chrono::steady_clock::now();
+        Src->UploadToGpu();                              // here, beside the search of the previous batch
+        g_rsk_counters.upload_ns += ns_since(t_up);
+        g_rsk_counters.db_batches += 1;
+        g_rsk_counters.loader_ns += ns_since(t_load);
         return Src;
     };
     uint64_t pairs = 0, alns = 0, mkf = 0, fin = 0, fdis = 0;

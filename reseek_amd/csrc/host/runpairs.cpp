@@ -46,6 +46,13 @@ static void ReplayBatch(DBSearcher &S, DBSearcher &SrcA, DBSearcher &SrcB, const
     const size_t n = ia.size();
     if (n == 0) return;
     S.m_SWCount += n;
+    {
+        // rsk_path_counters: the pairs whose score reached m_MinFwdScore (CalcEvalue ran and set an E-value, dssaligner.cpp:852-861)
+        uint64_t scored = 0;
+        for (size_t p = 0; p < n; ++p) scored += out[p].evalue != FLT_MAX;
+        g_rsk_counters.sw_pairs += n;
+        g_rsk_counters.sw_pairs_scored += scored;
+    }
     // one pair's hit record -> DSSAligner result fields -> Reject / hit line(s), as runself.cpp:61-66 / runquery.cpp:72-73
     auto replay = [&](DSSAligner &DA, size_t p, auto &&OnHit) {
         if (out[p].path_len == 0) return;                                    // runself.cpp:61 / runquery.cpp:72

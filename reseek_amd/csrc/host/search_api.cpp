@@ -294,5 +294,47 @@ extern "C" int rsk_search(rsk_ctx *ctx, const char *query_path, const char *db_p
 
 extern "C" int rsk_abi_version(void) { return RSK_ABI_VERSION; }
 
+// ---- rsk_path_counters (the reference's static DSSAligner statistics, dssaligner.h:90-96, for a GPU run) ----------------------
+rsk_host_counters g_rsk_counters;
+
+extern "C" int rsk_path_counters_read(rsk_ctx *ctx, rsk_path_counters *out)
+{
+    if (!ctx || !out || out->struct_size < sizeof(uint32_t)) { rsk_set_error("rsk_path_counters_read: NULL argument / struct_size not set"); return RSK_E_INVALID; }
+    rsk_path_counters c;
+    memset(&c, 0, sizeof c);
+    c.sw_pairs = g_rsk_counters.sw_pairs.load();
+    c.sw_pairs_scored = g_rsk_counters.sw_pairs_scored.load();
+    c.sw_pairs_rescored = g_rsk_counters.sw_pairs_rescored.load();
+    c.upload_copies = g_rsk_counters.upload_copies.load();
+    c.upload_bytes = g_rsk_counters.upload_bytes.load();
+    c.db_batches = g_rsk_counters.db_batches.load();
+    c.loader_seconds = (double) g_rsk_counters.loader_ns.load() * 1e-9;
+    c.featurise_seconds = (double) g_rsk_counters.featurise_ns.load() * 1e-9;
+    c.upload_seconds = (double) g_rsk_counters.upload_ns.load() * 1e-9;
+    if (unsigned long long *w = rsk_swqp_clock_words(ctx->device)) {
+        rsk_device_guard g(ctx->device);
+        unsigned long long h[2] = { 0, 0 };
+        if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(h, w, 16, hipMemcpyDeviceToHost) != hipSuccess) return rsk_hip_fail(hipGetLastError(), "hipMemcpy (k_sw_qp clock words)", __FILE__, __LINE__);
+        c.swqp_cycles = h[0]; c.swqp_ref_ticks = h[1];
+    }
+    const uint32_t want = out->struct_size;
+    c.struct_size = (uint32_t) std::min<size_t>(want, sizeof c);
+    memcpy(out, &c, c.struct_size);                      // never beyond what the caller's header declares
+    return RSK_OK;
+}
+
+extern "C" int rsk_path_counters_reset(rsk_ctx *ctx)
+{
+    if (!ctx) { rsk_set_error("rsk_path_counters_reset: ctx is NULL"); return RSK_E_INVALID; }
+    g_rsk_counters.sw_pairs = 0; g_rsk_counters.sw_pairs_scored = 0; g_rsk_counters.sw_pairs_rescored = 0;
+    g_rsk_counters.upload_copies = 0; g_rsk_counters.upload_bytes = 0; g_rsk_counters.db_batches = 0;
+    g_rsk_counters.loader_ns = 0; g_rsk_counters.featurise_ns = 0; g_rsk_counters.upload_ns = 0;
+    if (unsigned long long *w = rsk_swqp_clock_words(ctx->device)) {
+        rsk_device_guard g(ctx->device);
+        if (hipDeviceSynchronize() != hipSuccess || hipMemset(w, 0, 16) != hipSuccess) return rsk_hip_fail(hipGetLastError(), "hipMemset (k_sw_qp clock words)", __FILE__, __LINE__);
+    }
+    return RSK_OK;
+}
+
 extern "C" void rsk_shutdown(void) { reseek_amd::SecondaryCtx::Trim(-1); }
 

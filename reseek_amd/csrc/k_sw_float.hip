@@ -112,6 +112,7 @@ struct swf_args {
     uint32_t *besti, *bestj;
     int *bnd;                // boundary rows of multi-group pairs: 2 ints (float bits) per step, at bnd + bnd_off[p]
     const uint64_t *bnd_off;
+    unsigned long long *clk; // k_sw_qp: {shader cycles, 100 MHz ticks} summed over the workgroups (rsk_path_counters), or NULL
 };
 
 __device__ __forceinline__ float dpp_shr1_f(float x)
@@ -691,6 +692,9 @@ __global__ __launch_bounds__(64 * SWQ_NW) void k_sw_qp(swf_args a, const swq_ite
 {
     extern __shared__ float4 qp4[];
     const swq_item it = items[blockIdx.x];
+    // the clock this kernel HOLDS (it runs at the board's power limit): shader cycles against the 100 MHz reference
+    // counter over the life of the workgroup, two atomics per workgroup (tens of thousands of cells each)
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     switch (it.R) {
     case 4: swq_group<T, 4>(a, it, qp4); break;
     case 5: swq_group<T, 5>(a, it, qp4); break;
@@ -703,6 +707,11 @@ __global__ __launch_bounds__(64 * SWQ_NW) void k_sw_qp(swf_args a, const swq_ite
     default: swq_group<T, 12>(a, it, qp4); break;
     }
     asm volatile("s_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory");     // the trace masks sit in the scalar data cache
+    if (a.clk && threadIdx.x == 0) {
+        const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        atomicAdd(a.clk, c1 - c0);
+        atomicAdd(a.clk + 1, r1 - r0);
+    }
 }
 
 // TraceBackBitSW sw.cpp:8-77.  One thread per pair; path chars are written backwards into
@@ -1525,6 +1534,7 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
     a.tb = d_tb; a.tb_off = d_tboff;
     a.score = d_score; a.besti = d_bi; a.bestj = d_bj;
     a.bnd = d_bnd; a.bnd_off = d_bndoff;
+    a.clk = rsk_swqp_clock_words(ctx->device);
     // the four events rsk_align_last_times reads belong to THIS function alone and are valid only as a set (ev0 / ev1
     // are shared with every other launch of the context)
     ctx->al_times_valid = false;
@@ -1906,6 +1916,22 @@ extern "C" int rsk_gapless_float_pairs(rsk_ctx *ctx, const rsk_db *dba, const rs
 
 // kernel times of the stages of the last rsk_align_pairs call on this context (HIP events on its stream): Smith-Waterman
 // kernels, traceback kernel, statistics kernels (LDDT); -1 where a stage did not run
+// {cycles, ticks} of k_sw_qp per device: allocated on first use, never freed (16 bytes), zeroed by rsk_path_counters_reset
+unsigned long long *rsk_swqp_clock_words(int device)
+{
+    static std::mutex m;
+    static unsigned long long *words[64];
+    if (device < 0 || device >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(m);
+    if (!words[device]) {
+        rsk_device_guard g(device);
+        unsigned long long *p = nullptr;
+        if (hipMalloc((void **) &p, 16) != hipSuccess || hipMemset(p, 0, 16) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
+        words[device] = p;
+    }
+    return words[device];
+}
+
 extern "C" int rsk_align_last_times(rsk_ctx *ctx, float *sw_ms, float *traceback_ms, float *stats_ms)
 {
     if (!ctx) { rsk_set_error("rsk_align_last_times: ctx is NULL"); return RSK_E_INVALID; }

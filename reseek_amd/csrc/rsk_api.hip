@@ -238,6 +238,8 @@ static int dev_upload(rsk_ctx *ctx, T **d, const T *h, size_t count, uint64_t &b
     if (rc != RSK_OK) return rc;
     RSK_HIP(hipMemcpy(*d, h, count * sizeof(T), hipMemcpyHostToDevice));
     bytes += count * sizeof(T);
+    g_rsk_counters.upload_copies += 1;
+    g_rsk_counters.upload_bytes += count * sizeof(T);
     return RSK_OK;
 }
 

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -114,6 +115,15 @@ int rsk_db_update_selfrev(rsk_db *db, const float *selfrev);   // completes a se
 void rsk_pool_free(rsk_ctx *ctx, void *p);
 void rsk_pool_release(rsk_ctx *ctx);
 int rsk_pinned(rsk_ctx *ctx, int slot, size_t bytes, void **p);
+
+// Process-wide counters behind rsk_path_counters_read (search_api.cpp); the k_sw_qp clock words live in device memory, two
+// uint64 per device (k_sw_float.hip: rsk_swqp_clock_words).
+struct rsk_host_counters {
+    std::atomic<uint64_t> sw_pairs{0}, sw_pairs_scored{0}, sw_pairs_rescored{0}, upload_copies{0}, upload_bytes{0}, db_batches{0};
+    std::atomic<uint64_t> loader_ns{0}, featurise_ns{0}, upload_ns{0};
+};
+extern rsk_host_counters g_rsk_counters;
+unsigned long long *rsk_swqp_clock_words(int device);      // device pointer to {cycles, ticks}; nullptr if the allocation failed
 
 // One "ring" of the gapless kernel: several query chains laid out on a circular array of
 // 128*D diagonal slots (see k_mu_gapless.hip).
