@@ -165,6 +165,17 @@ int rsk_mu_filter_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int self_t
                       int gap_ext, float omega, float omega_fwd, uint8_t *d_fwd, size_t ldo,
                       uint32_t *d_pairs_q, uint32_t *d_pairs_t, int32_t *d_pairs_fwd,
                       int32_t *d_pairs_rev, size_t capacity, uint32_t *d_npairs);
+/* One shard of the self-search triangle (r06; the reference deals the pairs of RunSelf to threads through one locked counter,
+ * runself.cpp:72-99): the filter over the pairs {a, b} of ONE set whose LONGER member (the later one of equal lengths) stands at a
+ * position in [rank_lo, rank_hi) of the set's length order (rsk_len_rank) -- the order the triangle mode walks its targets in, so a
+ * shard is one launch of the whole triangle's shape against fewer targets.  Every pair once, survivors as (lower index, higher
+ * index); d_fwd is the db->n x ldo matrix of rsk_mu_filter_dev's triangle mode (cells outside the window untouched).  The
+ * windows rsk_shard_range(kind 2) returns for shards 0 .. count-1 tile the triangle. */
+int rsk_mu_filter_window_dev(rsk_ctx *ctx, const rsk_db *db, uint32_t rank_lo, uint32_t rank_hi, int gap_open, int gap_ext,
+                             float omega, float omega_fwd, uint8_t *d_fwd, size_t ldo, uint32_t *d_pairs_q, uint32_t *d_pairs_t,
+                             int32_t *d_pairs_fwd, int32_t *d_pairs_rev, size_t capacity, uint32_t *d_npairs);
+/* rank[i] = position of chain i in the set's length order: a stable sort by chain length (equal lengths keep the chain order). */
+int rsk_len_rank(const rsk_db *db, uint32_t *rank);
 /* The survivor list of rsk_mu_filter_dev in a deterministic order: both device columns sorted in place by (d_major[k],
  * d_minor[k]) ascending -- the order the reference walks its pairs in (GetNextPairSelf runself.cpp:72-99,
  * runquery.cpp:82).  major_bound = an exclusive upper bound of the major index (0 = unknown): only its bits are sorted. */
@@ -416,7 +427,9 @@ typedef struct rsk_search_opts {
     int keeptmp;               /* -keeptmp: keep <out_tsv>.prefilter.tmp */
     uint32_t shard_index;      /* multi-GPU (one process per GPU): this process handles shard shard_index of       */
     uint32_t shard_count;      /* shard_count: -db mode = a contiguous range of DB chains balanced by residues;     */
-                               /* self search = the pairs (i <= j) whose j lies in a range balanced by DP cells.    */
+                               /* self search = the pairs whose longer chain stands in a window of the set's length  */
+                               /* order, windows of equal DP cells, + every shard_count-th long-chain pair (no Mu    */
+                               /* filter: the pairs (i <= j) whose j lies in a range balanced by DP cells).         */
                                /* The union of the shards' hit tables is the unsharded table.  0 or 1 = no shards. */
     const char *devices;       /* multi-GPU (ONE process): "0,1,2,3" = the call drives these devices, one context + host thread */
                                /* each, shards as above, one hits file (an id may repeat: several contexts on one device).  */
@@ -452,9 +465,11 @@ typedef struct rsk_path_counters {
 int rsk_path_counters_read(rsk_ctx *ctx, rsk_path_counters *out);      /* ctx names the device whose k_sw_qp clock words are read */
 int rsk_path_counters_reset(rsk_ctx *ctx);
 
-/* The shard bounds the searches use (pure host arithmetic, no device): kind 0 = self search, targets [lo, hi) of the
- * triangle of pairs (i <= j) such that every shard covers the same number of DP cells; kind 1 = -db search, a contiguous
- * range of chains with the same number of residues per shard.  The shards 0 .. count-1 tile [0, n) in order. */
+/* The shard bounds the searches use (pure host arithmetic, no device): kind 0 = self search without a Mu filter (or a set beyond
+ * one filter pass), targets [lo, hi) of the triangle of pairs (i <= j) such that every shard covers the same number of DP cells;
+ * kind 1 = -db search, a contiguous range of chains with the same number of residues per shard; kind 2 (r06) = self search with a
+ * Mu filter: a WINDOW [lo, hi) of positions of the set's length order (stable sort by length, rsk_len_rank), equal DP cells of
+ * the pairs each position closes with the positions before it.  The shards 0 .. count-1 tile [0, n) in order. */
 int rsk_shard_range(int kind, const uint32_t *lengths, uint64_t n, uint32_t index, uint32_t count, uint64_t *lo, uint64_t *hi);
 
 /* ---- `-search -fast -db` on several GPUs: the per-query top-B of the prefilter (RankedScoresBag,

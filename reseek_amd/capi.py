@@ -38,6 +38,9 @@ SIGNATURES = {
     "rsk_mu_gapless_matrix_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
     "rsk_mu_gapless_hits_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
                                           C.c_void_p, C.c_uint32, C.c_void_p]),
+    "rsk_mu_filter_window_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_size_t,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rsk_len_rank": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "rsk_mu_gapless_shard_window": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "rsk_mu_gapless_hits_window_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32,
                                                  C.c_void_p, C.c_uint32, C.c_void_p]),
@@ -314,6 +317,16 @@ class Ctx:
         _check(lib().rsk_mu_filter_dev(self.h, q.h, t.h, int(self_triangle), gap_open, gap_ext, omega, omega_fwd,
                                        C.c_void_p(d_fwd), ldo, C.c_void_p(d_pq), C.c_void_p(d_pt), C.c_void_p(d_pf),
                                        C.c_void_p(d_pr), capacity, C.c_void_p(d_n)))
+
+    def mu_filter_window_dev(self, db, rank_lo, rank_hi, omega, omega_fwd, d_fwd, ldo, d_pq, d_pt, d_pf, d_pr, capacity, d_n, gap_open=2, gap_ext=1):
+        """one shard of the self-search triangle: the pairs whose longer member stands at positions [rank_lo, rank_hi) of the length order"""
+        _check(lib().rsk_mu_filter_window_dev(self.h, db.h, int(rank_lo), int(rank_hi), gap_open, gap_ext, omega, omega_fwd, C.c_void_p(d_fwd), ldo,
+                                              C.c_void_p(d_pq), C.c_void_p(d_pt), C.c_void_p(d_pf), C.c_void_p(d_pr), capacity, C.c_void_p(d_n)))
+
+    def len_rank(self, db):
+        r = np.zeros(db.n if hasattr(db, "n") else len(db.lengths), np.uint32)
+        _check(lib().rsk_len_rank(db.h, _p(r, u32p)))
+        return r
 
     def pairs_sort_dev(self, d_major, d_minor, n, major_bound=0):
         """sorts the device pair list (two uint32 columns, device pointers) by (major, minor) in place"""

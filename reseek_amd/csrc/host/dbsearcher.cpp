@@ -187,12 +187,38 @@ void DBSearcher::MakeView(const DBSearcher &Src, uint Lo, uint Hi)
     m_DBSelfRevScores.assign(Src.m_DBSelfRevScores.begin() + Lo, Src.m_DBSelfRevScores.begin() + Hi);
 }
 
-// shard `Index` of `Count` of the self search: targets [Lo, Hi) chosen so that the cells of the triangle are balanced
+// Windows of the LENGTH ORDER of a set (stable sort by length = rsk_len_rank's order) with equal DP cells of the triangle: position
+// p of that order closes the pairs {chain at p, every chain at a position <= p}.
+void DBSearcher::SelfWindowRange(const uint32_t *Lens, uint64_t N, uint Index, uint Count, uint64_t &Lo, uint64_t &Hi)
+{
+    std::vector<uint32_t> Sorted(Lens, Lens + N);
+    std::stable_sort(Sorted.begin(), Sorted.end());
+    SelfShardRange(Sorted.data(), N, Index, Count, Lo, Hi);
+}
+
+// shard `Index` of `Count` of the self search (the reference: one locked pair counter for all threads, runself.cpp:72-99).
+// With a Mu filter and a set whose dense pair matrix fits one filter pass: a window of the set's length order + every Count-th
+// long-chain pair (RunPairs, SelfWindow) -- the whole set stays resident, one pass.  Otherwise (no filter: -verysensitive, every
+// pair costs its cells; or > ~65 k chains): targets [Lo, Hi) of the chain order with equal cells, as the rectangle
+// chains[0, Lo) x chains[Lo, Hi) plus the triangle of chains[Lo, Hi).
 void DBSearcher::RunSelfShard(uint Index, uint Count)
 {
     const uint N = GetDBChainCount();
     std::vector<uint32_t> Lens(N);
     for (uint j = 0; j < N; ++j) Lens[j] = m_DBChains[j]->GetSeqLength();
+    const bool Windows = m_Params->m_Omega > 0 && (uint64_t) N * N <= FilterTilePairs() && !m_HasOnAlnOverride &&
+                         !(getenv("RSK_SELF_SHARD_RANGES") && atoi(getenv("RSK_SELF_SHARD_RANGES")) == 1);
+    if (Windows) {
+        uint64_t Lo64, Hi64;
+        SelfWindowRange(Lens.data(), N, Index, Count, Lo64, Hi64);
+        SelfWindow W;
+        W.RankLo = (uint32_t) Lo64; W.RankHi = (uint32_t) Hi64; W.ShardIndex = Index; W.ShardCount = Count;
+        UploadToGpu();
+        const uint64_t Hits0 = m_HitCount, SW0 = m_SWCount;
+        RunPairs(*this, *this, true, -1, &W);
+        m_HitCount -= Hits0; m_SWCount -= SW0;      // (a shard reports its own counts, as the range form below)
+        return;
+    }
     uint64_t Lo64, Hi64;
     SelfShardRange(Lens.data(), N, Index, Count, Lo64, Hi64);
     const uint Lo = (uint) Lo64, Hi = (uint) Hi64;

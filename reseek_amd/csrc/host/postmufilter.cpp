@@ -347,6 +347,12 @@ void PostMuFilterPairs(const DSSParams &Params, DBSearcher &Q, DBSearcher &DB, c
                             [&](const std::vector<uint32_t> &bia, const std::vector<uint32_t> &bib, const std::vector<rsk_aln> &out, const char *paths) {
             const size_t n = bia.size();
             Q.m_SWCount += n;
+            {
+                uint64_t scored = 0;                       // rsk_path_counters: CalcEvalue ran (score >= m_MinFwdScore)
+                for (size_t p = 0; p < n; ++p) scored += out[p].evalue != FLT_MAX;
+                g_rsk_counters.sw_pairs += n;
+                g_rsk_counters.sw_pairs_scored += scored;
+            }
             for (size_t p = 0; p < n; ++p) {
                 // Accept (postmufilter.cpp:106-115) on the batch record: rejected pairs need no string work
                 if (!(out[p].evalue <= MaxEvalue || out[p].pvalue <= MaxPvalue || (out[p].evalue != FLT_MAX && out[p].ts >= MinTS))) continue;

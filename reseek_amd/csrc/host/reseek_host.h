@@ -440,6 +440,7 @@ public:
     // shard bounds (pure arithmetic): targets [Lo, Hi) of the self-search triangle with equal DP cells per shard; contiguous
     // chain ranges with equal residues per shard
     static void SelfShardRange(const uint32_t *Lens, uint64_t N, uint Index, uint Count, uint64_t &Lo, uint64_t &Hi);
+    static void SelfWindowRange(const uint32_t *Lens, uint64_t N, uint Index, uint Count, uint64_t &Lo, uint64_t &Hi);   // positions of the length order
     static void ResidueShardRange(const uint32_t *Lens, uint64_t N, uint Index, uint Count, uint64_t &Lo, uint64_t &Hi);
     void RunSelfShard(uint Index, uint Count);          // one rank's part of the self-search triangle
     bool Reject(DSSAligner &DA, bool Up) const;         // dbsearcher.cpp:258

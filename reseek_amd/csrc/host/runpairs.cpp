@@ -437,7 +437,15 @@ void RunMKFPairs(rsk_ctx *Ctx, const DSSParams &P, const std::string &Columns, D
 // Self with SelfOffset >= 0 is (part of) one SHARD of a self search: B = the chains [SelfOffset, SelfOffset + NB)
 // of the set, A = its chains [0, NA) with NA = SelfOffset (the rectangle above the shard's triangle) or up to
 // SelfOffset + NB; the pairs i <= SelfOffset + j are scored.
-void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOffset)
+// Win (r06; Self, SrcA = S, a Mu filter): one shard of the WHOLE set's triangle as a window of its length order.  The reference
+// deals the pairs of RunSelf to its threads one at a time through a locked counter (runself.cpp:72-99): any thread takes any
+// pair.  Here a rank takes (a) the pairs whose longer member stands in its window of the length order -- the order the
+// triangle mode of the Mu filter walks its targets in, so the shard's filter pass is ONE launch of the whole triangle's shape
+// against fewer targets, windows of equal DP cells -- and (b) every ShardCount-th pair of the long-chain list, whose pairs all
+// hold one of the few longest chains and would otherwise all fall to the last window.  (r01-r05: a target range of the chain
+// ORDER, as a rectangle + a small triangle, two passes each with its own filter, survivor lists and long-chain job: measured
+// r06 on the 11,211-chain set, N = 8: slowest shard 2.7 x the fastest, efficiency 0.33.)
+void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOffset, const SelfWindow *Win)
 {
     PhaseTimer tm;
     const DSSParams &P = *S.m_Params;
@@ -446,6 +454,13 @@ void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOffset)
     const bool UseMu = P.m_Omega > 0;            // LoadDB keeps Mu letters only when Omega > 0 (dbsearcher.cpp:249-251)
     const bool Tri = Self && SelfOffset < 0;     // the whole triangle in one call
     const uint joff = SelfOffset > 0 ? (uint) SelfOffset : 0;
+    if (Win && !(Tri && UseMu && &SrcA == &S && Win->RankLo <= Win->RankHi && Win->RankHi <= NB && Win->ShardCount >= 1))
+        throw std::runtime_error("RunPairs: a window needs the whole set's triangle and a Mu filter");
+    const std::vector<uint32_t> *Rank = nullptr; // length rank of the chains (window mode)
+    if (Win) {
+        check(rsk_build_len_perm(S.m_Db), "rsk_build_len_perm");
+        Rank = &S.m_Db->h_len_rank;
+    }
     auto InShard = [&](uint i, uint j) { return !Self || i <= joff + j; };
     auto IsMKF = [&](uint i, uint j) {           // DSSAligner::DoMKF dssaligner.cpp:715-732
         if (!UseMu) return false;
@@ -457,7 +472,8 @@ void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOffset)
         return Self ? (i == joff + j) : (SrcA.m_DBChains[i]->m_Label == S.m_DBChains[j]->m_Label);
     };
     uint64_t SelfTotal = 0;                      // pairs of this (shard of the) triangle
-    if (Self) for (uint j = 0; j < NB; ++j) SelfTotal += std::min<uint64_t>(NA, (uint64_t) joff + j + 1);
+    if (Self && !Win) for (uint j = 0; j < NB; ++j) SelfTotal += std::min<uint64_t>(NA, (uint64_t) joff + j + 1);
+    if (Win) SelfTotal = ((uint64_t) Win->RankHi * (Win->RankHi + 1) - (uint64_t) Win->RankLo * (Win->RankLo + 1)) / 2;      // position p closes p + 1 pairs
     std::vector<uint32_t> ia, ib;                // pairs for the full alignment
     std::vector<std::pair<uint32_t, uint32_t> > mkf;
     uint64_t npairs = 0;
@@ -508,6 +524,14 @@ void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOffset)
         // not by walking the whole pair space
         // (the list -- 0.67 M pairs, ~5 ms of one host thread on the SCOP40-sized self search -- is not needed before the filter
         // has run: it is built on a thread of its own under the filter kernels, r05)
+        uint64_t mkf_in_window = 0;              // window mode: long-chain pairs whose longer member stands in the window (they pass through the filter launch unused)
+        uint64_t mkf_ord = 0;                    // ... and the running position in the whole list, dealt round-robin to the shards
+        auto take_mkf = [&](uint i, uint j) {
+            if (!Win) { mkf.emplace_back(i, j); ++nmkf; return; }
+            const uint32_t rmax = std::max((*Rank)[i], (*Rank)[j]);
+            if (rmax >= Win->RankLo && rmax < Win->RankHi) ++mkf_in_window;
+            if (mkf_ord++ % Win->ShardCount == Win->ShardIndex) { mkf.emplace_back(i, j); ++nmkf; }
+        };
         auto build_mkf_list = [&]() {
             std::vector<uint32_t> longB;
             for (uint j = 0; j < NB; ++j)
@@ -518,12 +542,12 @@ void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOffset)
                 if (SrcA.m_DBChains[i]->GetSeqLength() >= P.m_MKFL) {
                     for (uint j = j0; j < NB; ++j) {
                         if (S.m_DBMuKmersVec[j]->empty() || Skip(i, j)) continue;
-                        mkf.emplace_back(i, j); ++nmkf;
+                        take_mkf(i, j);
                     }
                 } else {
                     for (auto it = std::lower_bound(longB.begin(), longB.end(), j0); it != longB.end(); ++it) {
                         if (Skip(i, *it)) continue;
-                        mkf.emplace_back(i, *it); ++nmkf;
+                        take_mkf(i, *it);
                     }
                 }
             }
@@ -533,7 +557,8 @@ void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOffset)
         if (early) build_mkf_list();
         else mkf_list = std::async(std::launch::async, build_mkf_list);      // (a future of std::async joins in its destructor: no exit path leaves the thread behind)
         if (S.m_Opts.noself) {
-            if (Self) nskip = NA > joff ? std::min<uint64_t>(NB, NA - joff) : 0;      // the diagonal pairs this pass holds
+            if (Win) nskip = Win->RankHi - Win->RankLo;                               // the diagonal pairs of the window's positions
+            else if (Self) nskip = NA > joff ? std::min<uint64_t>(NB, NA - joff) : 0;      // the diagonal pairs this pass holds
             else {
                 std::unordered_map<std::string, uint32_t> cntB;
                 for (uint j = 0; j < NB; ++j) ++cntB[S.m_DBChains[j]->m_Label];
@@ -560,6 +585,11 @@ void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOffset)
         for (;;) {
             ListQ.Make(ctx, cap * 4, "survivor list");
             ListT.Make(ctx, cap * 4, "survivor list");
+            if (Win)
+                check(rsk_mu_filter_window_dev(ctx, S.m_Db, Win->RankLo, Win->RankHi, P.m_ParaMuGapOpen, P.m_ParaMuGapExt, P.m_Omega, P.m_OmegaFwd,
+                                               Fwd.As<uint8_t>(), ldo, ListQ.As<uint32_t>(), ListT.As<uint32_t>(), nullptr, nullptr, cap, Count.As<uint32_t>()),
+                      "rsk_mu_filter_window_dev");
+            else
             check(rsk_mu_filter_dev(ctx, FilterQ, FilterT, Tri ? 1 : 0, P.m_ParaMuGapOpen, P.m_ParaMuGapExt, P.m_Omega, P.m_OmegaFwd, Fwd.As<uint8_t>(), ldo,
                                     ListQ.As<uint32_t>(), ListT.As<uint32_t>(), nullptr, nullptr, cap, Count.As<uint32_t>()),
                   "rsk_mu_filter_dev");
@@ -609,7 +639,9 @@ void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOffset)
             for (size_t sl = 0; sl < nsl; ++sl) { ia.insert(ia.end(), sa[sl].begin(), sa[sl].end()); ib.insert(ib.end(), sb[sl].begin(), sb[sl].end()); }
         }
         tm.lap("  alignment pair list");
-        npairs = total - nskip;
+        // window mode: the shard's pairs = its window's pairs that are not long-chain pairs + its share of the long-chain list
+        // (the shards' counts add up to the unsharded call's)
+        npairs = Win ? total - nskip - mkf_in_window + nmkf : total - nskip;
         S.m_MKFPairCount = nmkf;
         S.m_MuFilterInputCount = npairs - nmkf;
         S.m_MuFilterDiscardCount = S.m_MuFilterInputCount - ia.size();

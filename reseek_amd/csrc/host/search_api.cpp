@@ -5,8 +5,9 @@
 
 extern "C" int rsk_shard_range(int kind, const uint32_t *lengths, uint64_t n, uint32_t index, uint32_t count, uint64_t *lo, uint64_t *hi)
 {
-    if ((n && !lengths) || !lo || !hi || count == 0 || index >= count || kind < 0 || kind > 1) { rsk_set_error("rsk_shard_range: invalid argument"); return RSK_E_INVALID; }
+    if ((n && !lengths) || !lo || !hi || count == 0 || index >= count || kind < 0 || kind > 2) { rsk_set_error("rsk_shard_range: invalid argument"); return RSK_E_INVALID; }
     if (kind == 0) reseek_amd::DBSearcher::SelfShardRange(lengths, n, index, count, *lo, *hi);
+    else if (kind == 2) reseek_amd::DBSearcher::SelfWindowRange(lengths, n, index, count, *lo, *hi);
     else reseek_amd::DBSearcher::ResidueShardRange(lengths, n, index, count, *lo, *hi);
     return RSK_OK;
 }

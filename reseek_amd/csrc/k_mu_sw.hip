@@ -561,12 +561,16 @@ __device__ __forceinline__ uint32_t musw_waves(int cls) { return cls == 0 ? 4u :
 // and reversed-query alike); each unordered pair is computed once with the SHORTER chain (lower rank)
 // in the query role (fewer strips per pair, shorter systolic ramp), i.e. query q takes the targets of
 // rank >= rank[q].
-__global__ void k_musw_setup_implicit(uint32_t nq, uint32_t nt, int self_triangle, const uint32_t *rank, uint32_t *first, uint32_t *cnt)
+// [wlo, whi): a WINDOW of target positions (length ranks) of the triangle -- one shard of a self search (r06: every rank keeps the
+// whole set and takes the pairs whose longer member stands in its window; the whole triangle is [0, nt)).
+__global__ void k_musw_setup_implicit(uint32_t nq, uint32_t nt, int self_triangle, const uint32_t *rank, uint32_t *first, uint32_t *cnt,
+                                      uint32_t wlo, uint32_t whi)
 {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
-    first[q] = self_triangle ? rank[q] : 0;
-    cnt[q] = self_triangle ? nt - rank[q] : nt;
+    const uint32_t f = self_triangle ? max(rank[q], wlo) : 0u;
+    first[q] = f;
+    cnt[q] = self_triangle ? (whi > f ? whi - f : 0u) : nt;
 }
 
 // Single workgroup: for class `cls` compute per-query item counts, exclusive scan, write item_start[q] and *nitems.
@@ -852,9 +856,14 @@ static void musw2_geometry(uint32_t L, uint32_t *g_out, uint32_t *R_out)
     *g_out = bg; *R_out = bR;
 }
 
-static int run_mu_sw_querypairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, musw_args base, int self_triangle, musw_ws &ws)
+static int run_mu_sw_querypairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, musw_args base, int self_triangle, musw_ws &ws,
+                                uint32_t wlo = 0, uint32_t whi = 0xFFFFFFFFu)
 {
     const uint32_t nq = q->n, nt = t->n;
+    whi = std::min(whi, nt);
+    // targets of (real or paired) query A in triangle mode: the positions max(rank[A], wlo) .. whi - 1 of the length order
+    auto tri_first = [&](uint32_t A) { return std::max(t->h_len_rank[A], wlo); };
+    auto tri_cnt = [&](uint32_t A) { const uint32_t f = tri_first(A); return whi > f ? whi - f : 0u; };
     std::vector<uint32_t> order(nq);
     for (uint32_t i = 0; i < nq; ++i) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return q->len[x] < q->len[y]; });   // == rsk_build_len_perm's order
@@ -865,7 +874,7 @@ static int run_mu_sw_querypairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, 
     bool has_class[3] = { false, false, false };
     for (uint32_t k = 0; k < nq;) {
         const uint32_t A = order[k];
-        if (q->len[A] > 1024) { cnt_old[A] = self_triangle ? nt - t->h_len_rank[A] : nt; any_old = true; ++k; continue; }
+        if (q->len[A] > 1024) { cnt_old[A] = self_triangle ? tri_cnt(A) : nt; any_old = any_old || cnt_old[A]; ++k; continue; }
         uint32_t Bq = MUSW_NOQ;
         if (k + 1 < nq && q->len[order[k + 1]] <= 1024) Bq = order[k + 1];
         const uint32_t L = std::max(q->len[A], Bq != MUSW_NOQ ? q->len[Bq] : 0u);
@@ -874,9 +883,10 @@ static int run_mu_sw_querypairs(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, 
         // the work-item kernels derive a query's strips from its length as ceil(length / 32): the pair's "virtual length" 32 g
         // gives them the g chosen here (classes, waves per workgroup and LDS sizes follow from it as for k_mu_sw)
         const uint32_t vl = MUSW_R * g;
-        const uint32_t c = self_triangle ? nt - t->h_len_rank[A] : nt;
+        const uint32_t c = self_triangle ? tri_cnt(A) : nt;
+        if (c == 0) { k += Bq != MUSW_NOQ ? 2 : 1; continue; }            // (a window that ends before this pair's first target)
         qp.push_back(make_uint2(A, Bq));
-        vlen.push_back(vl); vcnt.push_back(c); vfirst.push_back(self_triangle ? t->h_len_rank[A] : 0u);
+        vlen.push_back(vl); vcnt.push_back(c); vfirst.push_back(self_triangle ? tri_first(A) : 0u);
         vgeom.push_back(g | (R << 8));
         const uint32_t lp = g * MUSW_R;
         const int cls = lp <= 416 ? 0 : lp <= 1024 ? 1 : 2;
@@ -1003,7 +1013,7 @@ extern "C" int rsk_mu_sw_matrix_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db 
     RSK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     if ((rc = rsk_build_len_perm(const_cast<rsk_db *>(t))) != RSK_OK) return rc;
     hipLaunchKernelGGL(k_musw_setup_implicit, dim3((q->n + 255) / 256), dim3(256), 0, ctx->stream, q->n, t->n, self_triangle,
-                       t->d_len_rank, ws.first, ws.cnt);
+                       t->d_len_rank, ws.first, ws.cnt, 0u, t->n);
     musw_args a = {};
     a.q_mu = q->d_mu; a.q_off = q->d_off; a.q_len = q->d_len;
     a.t_mu = t->d_mu; a.t_off = t->d_off; a.t_len = t->d_len;
@@ -1019,10 +1029,48 @@ extern "C" int rsk_mu_sw_matrix_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db 
     return RSK_OK;
 }
 
+static int mu_filter_impl(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int self_triangle, int gap_open, int gap_ext,
+                          float omega, float omega_fwd, uint8_t *d_fwd, size_t ldo, uint32_t *d_pairs_q,
+                          uint32_t *d_pairs_t, int32_t *d_pairs_fwd, int32_t *d_pairs_rev, size_t capacity,
+                          uint32_t *d_npairs, uint32_t wlo, uint32_t whi);
+
 extern "C" int rsk_mu_filter_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int self_triangle, int gap_open, int gap_ext,
                                  float omega, float omega_fwd, uint8_t *d_fwd, size_t ldo, uint32_t *d_pairs_q,
                                  uint32_t *d_pairs_t, int32_t *d_pairs_fwd, int32_t *d_pairs_rev, size_t capacity,
                                  uint32_t *d_npairs)
+{
+    return mu_filter_impl(ctx, q, t, self_triangle, gap_open, gap_ext, omega, omega_fwd, d_fwd, ldo, d_pairs_q, d_pairs_t, d_pairs_fwd, d_pairs_rev,
+                          capacity, d_npairs, 0u, 0xFFFFFFFFu);
+}
+
+// One shard of the self-search triangle as a WINDOW [rank_lo, rank_hi) of positions of the set's length order (stable sort by
+// length: rsk_len_rank): the pairs {a, b} whose LONGER member (the later one of equal lengths) stands in the window, each once,
+// survivors as (min index, max index).  The windows 0 .. N - 1 of rsk_self_window tile the triangle; one launch per window of
+// the same shape as the whole triangle's (the same query pairs against fewer targets).
+extern "C" int rsk_mu_filter_window_dev(rsk_ctx *ctx, const rsk_db *db, uint32_t rank_lo, uint32_t rank_hi, int gap_open, int gap_ext,
+                                        float omega, float omega_fwd, uint8_t *d_fwd, size_t ldo, uint32_t *d_pairs_q,
+                                        uint32_t *d_pairs_t, int32_t *d_pairs_fwd, int32_t *d_pairs_rev, size_t capacity,
+                                        uint32_t *d_npairs)
+{
+    if (db && (rank_lo > rank_hi || rank_hi > db->n)) { rsk_set_error("rsk_mu_filter_window_dev: window [%u, %u) outside the set's %u positions", rank_lo, rank_hi, db->n); return RSK_E_INVALID; }
+    return mu_filter_impl(ctx, db, db, 1, gap_open, gap_ext, omega, omega_fwd, d_fwd, ldo, d_pairs_q, d_pairs_t, d_pairs_fwd, d_pairs_rev,
+                          capacity, d_npairs, rank_lo, rank_hi);
+}
+
+// rank[i] = position of chain i in the set's length order (the order the triangle mode of the Mu filter walks its targets in)
+extern "C" int rsk_len_rank(const rsk_db *db, uint32_t *rank)
+{
+    if (!db || !rank) { rsk_set_error("rsk_len_rank: NULL argument"); return RSK_E_INVALID; }
+    const int rc = rsk_build_len_perm(const_cast<rsk_db *>(db));
+    if (rc != RSK_OK) return rc;
+    std::copy(db->h_len_rank.begin(), db->h_len_rank.end(), rank);
+    return RSK_OK;
+}
+
+static int mu_filter_impl(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t, int self_triangle, int gap_open, int gap_ext,
+                          float omega, float omega_fwd, uint8_t *d_fwd, size_t ldo, uint32_t *d_pairs_q,
+                          uint32_t *d_pairs_t, int32_t *d_pairs_fwd, int32_t *d_pairs_rev, size_t capacity,
+                          uint32_t *d_npairs, uint32_t wlo, uint32_t whi)
 {
     if (!ctx || !q || !t || !d_fwd || !d_pairs_q || !d_pairs_t || !d_npairs) { rsk_set_error("rsk_mu_filter_dev: NULL argument"); return RSK_E_INVALID; }
     if (!q->d_mu || !t->d_mu) { rsk_set_error("rsk_mu_filter_dev: chain set has no Mu letters"); return RSK_E_INVALID; }
@@ -1039,8 +1087,10 @@ extern "C" int rsk_mu_filter_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t,
     RSK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     RSK_HIP(hipMemsetAsync(d_npairs, 0, 4, ctx->stream));
     if ((rc = rsk_build_len_perm(const_cast<rsk_db *>(t))) != RSK_OK) return rc;
+    whi = std::min(whi, t->n);
+    wlo = std::min(wlo, whi);
     hipLaunchKernelGGL(k_musw_setup_implicit, dim3((nq + 255) / 256), dim3(256), 0, ctx->stream, nq, t->n, self_triangle, t->d_len_rank,
-                       ws.first, ws.cnt);
+                       ws.first, ws.cnt, wlo, whi);
     musw_args a = {};
     a.q_mu = q->d_mu; a.q_off = q->d_off; a.q_len = q->d_len;
     a.t_mu = t->d_mu; a.t_off = t->d_off; a.t_len = t->d_len;
@@ -1048,9 +1098,10 @@ extern "C" int rsk_mu_filter_dev(rsk_ctx *ctx, const rsk_db *q, const rsk_db *t,
     a.perm = t->d_len_perm; a.tri = self_triangle ? 1 : 0;
     a.reverse = 0; a.open = gap_open; a.ext = gap_ext;
     a.out = d_fwd; a.ldo = ldo;
-    const uint64_t total = self_triangle ? (uint64_t) nq * (nq + 1) / 2 : (uint64_t) nq * t->n;
-    const bool pairs2 = !(getenv("RSK_MUSW_QUERY_PAIRS") && atoi(getenv("RSK_MUSW_QUERY_PAIRS")) == 0);
-    if ((rc = pairs2 ? run_mu_sw_querypairs(ctx, q, t, a, self_triangle, ws)
+    // (position p of the length order closes p + 1 pairs of the triangle)
+    const uint64_t total = self_triangle ? ((uint64_t) whi * (whi + 1) - (uint64_t) wlo * (wlo + 1)) / 2 : (uint64_t) nq * t->n;
+    const bool pairs2 = !(getenv("RSK_MUSW_QUERY_PAIRS") && atoi(getenv("RSK_MUSW_QUERY_PAIRS")) == 0) || (self_triangle && (wlo != 0 || whi != t->n));
+    if ((rc = pairs2 ? run_mu_sw_querypairs(ctx, q, t, a, self_triangle, ws, wlo, whi)
                      : run_mu_sw_lists(ctx, q, t, a, item_exact_implicit(q, t->n, self_triangle), ws)) != RSK_OK)
         return rc;
     // candidates with fwd' >= OmegaFwd -> CSR lists

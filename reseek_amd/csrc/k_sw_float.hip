@@ -775,44 +775,70 @@ __global__ void k_traceback(const uint8_t *tb, const uint64_t *tb_off, const uin
     // characters are collected four at a time and stored as one aligned dword (a byte store per step made
     // this kernel store-request bound); `acc` holds the `nacc` characters below address w - nacc
     uint32_t acc = 0, nacc = 0;
-    for (;;) {
-        const uint32_t ch = state == 0 ? 'M' : (state == 1 ? 'D' : 'I');
-        ++n;
 #define PATH_STORE() do { \
         if (nacc == 0 && (w & 3) != 0) paths[--w] = (char) ch;            /* head: up to 3 bytes down to a dword boundary */ \
         else { \
             acc = (acc << 8) | ch; \
             if (++nacc == 4) { w -= 4; *(uint32_t *) (paths + w) = acc; nacc = 0; } \
         } } while (0)
-        const uint32_t ci = state == 2 ? i : i - 1, cj = state == 1 ? j : j - 1;       // 0-based cell (sw.cpp:33-70)
-        const uint32_t srow = rows_are_a ? ci : cj, step = rows_are_a ? cj : ci;
-        uint32_t dm, im, sm, md, mi;                  // only the bits of the current state are meaningful
-        if (cls < 2) {
-            // strip = srow / R through the reciprocal, corrected by one either way (rows per lane R = 4 .. 12 per item)
-            uint32_t strip = (uint32_t) (((float) srow + 0.5f) * inv);
-            if (strip * q_R > srow) --strip;
-            else if ((strip + 1) * q_R <= srow) ++strip;
-            const uint32_t r = srow - strip * q_R;
-            const uint32_t pass = strip / SWQ_GS, st = strip % SWQ_GS;      // pass over the whole chain
-            const uint32_t lane = q_lane0 + st, t = step + st;
-            const uint8_t *blk = T + (size_t) pass * q_pass_stride;
+    if (cls < 2) {
+        // k_sw_qp pairs.  The record of cell (strip row srow, wave step `step`) is
+        //     block(pass) + (step + st + R - 1 - r) * colb + r * 32,   strip = srow / R, r = srow % R, pass = strip / 16, st = strip % 16,
+        // and a step of the walk moves one row up and / or one wave step back: the address, r, st and the walker's mask bit (lane)
+        // are carried along and UPDATED (r06) -- one division per pair instead of a reciprocal, two corrections, a division by 16
+        // and two 64-bit multiply-adds per step (~100 instructions around one dependent 16-byte load; the kernel lasts as long
+        // as its longest walk: 805 ns per step, r05).  Which way the next cell lies depends only on the state the walk enters:
+        // M: (-1, -1), D: (-1, 0), I: (0, -1) in (i, j) -- whatever state it leaves (sw.cpp:33-70).
+        const uint32_t ci0 = i - 1, cj0 = j - 1;
+        const uint32_t srow0 = rows_are_a ? ci0 : cj0, step0 = rows_are_a ? cj0 : ci0;
+        const uint32_t strip0 = srow0 / q_R;
+        int r = (int) (srow0 - strip0 * q_R), st = (int) (strip0 % SWQ_GS), lane = (int) q_lane0 + st;
+        const int R1 = (int) q_R - 1, colb = (int) q_colb;
+        const uint8_t *rec = T + (size_t) (strip0 / SWQ_GS) * q_pass_stride + (size_t) (step0 + (uint32_t) st + q_R - 1 - (uint32_t) r) * q_colb + (uint32_t) r * 32u;
+        for (;;) {
+            const uint32_t ch = state == 0 ? 'M' : (state == 1 ? 'D' : 'I');
+            ++n;
             // the cell's masks {SM | IM, SM | (DM & ~IM), MD, MI}: state M needs the first two, D / I the second two: one
             // 16-byte load, issued before this step's path store (the wait that follows must not cover a store).
             // (Measured and not kept: a walker in state M fetching the records of rows r .. r - 3 of its diagonal at once
-            // and taking the next three steps from registers -- 2.15 vs 2.02 ms per 350 k-pair batch.)
-            const uint8_t *rec = blk + (size_t) (t + q_R - 1 - r) * q_colb + r * 32;
+            // and taking the next three steps from registers -- 2.15 vs 2.02 ms per 350 k-pair batch; r05: a request nobody waits
+            // for to the 128-byte line before the current one -- 0.73-0.77 against 0.72-0.75 ms for 72,000 walks.)
             typedef unsigned tb_v4u __attribute__((ext_vector_type(4)));
             tb_v4u q;
             asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(q) : "v"(rec + (state == 0 ? 0 : 16)) : "memory");
             PATH_STORE();
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(q) :: "memory");
-            // (Measured and not kept, r05: on the first record of a 128-byte line, a request nobody waits for to the line before it --
-            // where a diagonal run goes next: 0.73-0.77 ms against 0.72-0.75 for 72,000 walks of up to 902 steps; the ~800 ns
-            // per step of the longest walk are not one HBM miss per line.)
-            const uint32_t b0 = (lane < 32 ? q.x >> lane : q.y >> (lane - 32)) & 1u, b1 = (lane < 32 ? q.z >> lane : q.w >> (lane - 32)) & 1u;
-            // state M: b0 = stop or I, b1 = stop or D
-            md = b0; mi = b1; sm = b0 & b1; im = b0; dm = b1;
-        } else {
+            const uint32_t b0 = (uint32_t) ((((uint64_t) q.y << 32) | q.x) >> lane) & 1u, b1 = (uint32_t) ((((uint64_t) q.w << 32) | q.z) >> lane) & 1u;
+            uint32_t ns;
+            if (state == 0) {
+                if (b0 & b1) break;                   // SM; precedence as TraceBackBitSW reads its flags: stop, then I, then D
+                ns = b0 ? 2u : (b1 ? 1u : 0u);
+                --i; --j;
+            } else if (state == 1) {
+                ns = b0 ? 0u : 1u;                    // MD
+                --i;
+            } else {
+                ns = b1 ? 0u : 2u;                    // MI
+                --j;
+            }
+            state = ns;
+            const bool di = ns != 2u, dj = ns != 1u;
+            const bool drow = rows_are_a ? di : dj, dstp = rows_are_a ? dj : di;
+            const bool cross = drow && r == 0, wrap = cross && st == 0;      // into the strip above / into the pass before
+            const int dst = cross ? (wrap ? SWQ_GS - 1 : -1) : 0;
+            const int dr = drow ? (cross ? R1 : -1) : 0;
+            rec += (dst - dr - (int) dstp) * colb + dr * 32;
+            if (wrap) rec -= q_pass_stride;
+            r += dr; st += dst; lane += dst;
+        }
+    } else
+    for (;;) {
+        const uint32_t ch = state == 0 ? 'M' : (state == 1 ? 'D' : 'I');
+        ++n;
+        const uint32_t ci = state == 2 ? i : i - 1, cj = state == 1 ? j : j - 1;       // 0-based cell (sw.cpp:33-70)
+        const uint32_t srow = rows_are_a ? ci : cj, step = rows_are_a ? cj : ci;
+        uint32_t dm, im, sm, md, mi;                  // only the bits of the current state are meaningful
+        {
             const uint32_t sa = srow / SWF_R, r = srow - sa * SWF_R;
             const uint32_t rg = (uint32_t) (((float) sa + 0.5f) * inv), st = sa - rg * f_g;
             const uint32_t bits = T[(((size_t) rg * f_ld + step + st) * 64 + st) * 16 + (r ^ 3u)];

@@ -229,19 +229,57 @@ __global__ void k_db_derive(const uint8_t *prof, size_t npad, uint16_t *cb, uint
     ((uint4 *) ra)[r] = va;
 }
 
-template <class T>
-static int dev_upload(rsk_ctx *ctx, T **d, const T *h, size_t count, uint64_t &bytes)
-{
-    *d = nullptr;
-    if (count == 0) return RSK_OK;
-    const int rc = rsk_dev_malloc(ctx, (void **) d, count * sizeof(T) + 64);      // slack: kernels read whole dwords / strips past the last padded chain
-    if (rc != RSK_OK) return rc;
-    RSK_HIP(hipMemcpy(*d, h, count * sizeof(T), hipMemcpyHostToDevice));
-    bytes += count * sizeof(T);
-    g_rsk_counters.upload_copies += 1;
-    g_rsk_counters.upload_bytes += count * sizeof(T);
-    return RSK_OK;
-}
+// Host -> device staging of a chain set: the padded SoA arrays are packed by the host threads straight into ONE
+// page-locked buffer of the context (slot 2, grow-only, capped) and leave with ONE hipMemcpyAsync per array -- r01-r05 packed into
+// pageable vectors and called hipMemcpy on each, which the runtime cut into a staging copy per few MB: ~1,066 copyBuffer
+// dispatches per configs[3] run, 8 % of its traced GPU time.  While array k is on the wire the threads pack array k + 1; the
+// stream is waited for once at the end (or when the buffer is full: a set larger than the cap goes through it in pieces).
+#define RSK_UPLOAD_STAGE_MAX ((size_t) 512 << 20)
+struct rsk_uploader {
+    rsk_ctx *ctx;
+    char *base = nullptr;
+    size_t cap = 0, cur = 0;
+    uint64_t &hbm;
+    rsk_uploader(rsk_ctx *c, uint64_t &hbm_bytes) : ctx(c), hbm(hbm_bytes) {}
+    int begin(size_t total)
+    {
+        void *p = nullptr;
+        const int rc = rsk_pinned(ctx, 2, std::min(std::max<size_t>(total, 1), RSK_UPLOAD_STAGE_MAX), &p);
+        if (rc != RSK_OK) return rc;
+        base = (char *) p; cap = ctx->pin_bytes[2]; cur = 0;
+        return RSK_OK;
+    }
+    int flush() { RSK_HIP(hipStreamSynchronize(ctx->stream)); cur = 0; return RSK_OK; }
+    // device array of `bytes` (+ 64 bytes of slack: kernels read whole dwords / strips past the last padded chain) and the piece of
+    // the staging buffer that will be copied to it by send()
+    int reserve(void **d, size_t bytes, char **h)
+    {
+        *d = nullptr; *h = nullptr;
+        if (bytes == 0) return RSK_OK;
+        int rc = rsk_dev_malloc(ctx, d, bytes + 64);
+        if (rc != RSK_OK) return rc;
+        const size_t need = (bytes + 255) & ~(size_t) 255;
+        if (need > cap) {                                   // one array beyond the cap: a buffer of its own size after all
+            if ((rc = flush()) != RSK_OK) return rc;
+            void *p = nullptr;
+            if ((rc = rsk_pinned(ctx, 2, need, &p)) != RSK_OK) return rc;
+            base = (char *) p; cap = ctx->pin_bytes[2];
+        }
+        if (cur + need > cap && (rc = flush()) != RSK_OK) return rc;
+        *h = base + cur;
+        cur += need;
+        return RSK_OK;
+    }
+    int send(void *d, const char *h, size_t bytes)
+    {
+        if (bytes == 0) return RSK_OK;
+        RSK_HIP(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream));
+        hbm += bytes;
+        g_rsk_counters.upload_copies += 1;
+        g_rsk_counters.upload_bytes += bytes;
+        return RSK_OK;
+    }
+};
 
 extern "C" int rsk_db_create(rsk_ctx *ctx, uint32_t n, const uint32_t *lengths, const uint8_t *mu,
                              const uint8_t *prof, const float *x, const float *y, const float *z,
@@ -274,8 +312,20 @@ extern "C" int rsk_db_create(rsk_ctx *ctx, uint32_t n, const uint32_t *lengths, 
     db->nres = nres;
     db->npad = o;
     int rc;
-    if ((rc = dev_upload(ctx, &db->d_len, db->len.data(), n, db->hbm_bytes)) != RSK_OK) return rc;
-    if ((rc = dev_upload(ctx, &db->d_off, db->off.data(), (size_t) n + 1, db->hbm_bytes)) != RSK_OK) return rc;
+    rsk_uploader up(ctx, db->hbm_bytes);
+    {
+        const size_t total = (size_t) n * 8 + 4 + 256 * 9 + (mu ? (size_t) o + 64 : 0) + (prof ? (size_t) RSK_NFEAT * o : 0) + (x ? (size_t) 12 * o : 0) + (size_t) n * 4;
+        if ((rc = up.begin(total)) != RSK_OK) return rc;
+    }
+    // any error return below must not leave a copy in flight from the staging buffer the next call will overwrite
+    struct drain_on_exit { rsk_ctx *c; ~drain_on_exit() { (void) hipStreamSynchronize(c->stream); } } drain{ ctx };
+    char *h = nullptr;
+    if ((rc = up.reserve((void **) &db->d_len, (size_t) n * 4, &h)) != RSK_OK) return rc;
+    if (n) memcpy(h, db->len.data(), (size_t) n * 4);
+    if ((rc = up.send(db->d_len, h, (size_t) n * 4)) != RSK_OK) return rc;
+    if ((rc = up.reserve((void **) &db->d_off, ((size_t) n + 1) * 4, &h)) != RSK_OK) return rc;
+    memcpy(h, db->off.data(), ((size_t) n + 1) * 4);
+    if ((rc = up.send(db->d_off, h, ((size_t) n + 1) * 4)) != RSK_OK) return rc;
     // packing into the padded device layout runs on the host threads, chains are independent (src[i] = residues before chain i)
     std::vector<uint64_t> src((size_t) n + 1, 0);
     for (uint32_t i = 0; i < n; ++i) src[i + 1] = src[i] + lengths[i];
@@ -302,11 +352,14 @@ extern "C" int rsk_db_create(rsk_ctx *ctx, uint32_t n, const uint32_t *lengths, 
             rsk_set_error("rsk_db_create: Mu letter %u out of range in chain %u", c, i);
             return RSK_E_INVALID;
         }
-        if ((rc = dev_upload(ctx, &db->d_mu, db->h_mu.data(), db->h_mu.size(), db->hbm_bytes)) != RSK_OK) return rc;
+        // (the host keeps its copy for the ring construction of the gapless kernel; one byte per residue)
+        if ((rc = up.reserve((void **) &db->d_mu, db->h_mu.size(), &h)) != RSK_OK) return rc;
+        memcpy(h, db->h_mu.data(), db->h_mu.size());
+        if ((rc = up.send(db->d_mu, h, db->h_mu.size())) != RSK_OK) return rc;
     }
     if (prof) {
-        std::unique_ptr<uint8_t[]> hp_mem(new uint8_t[(size_t) RSK_NFEAT * o + 1]);   // not value-initialised: chains are copied, pads zeroed below
-        uint8_t *const hp = hp_mem.get();
+        if ((rc = up.reserve((void **) &db->d_prof, (size_t) RSK_NFEAT * o, &h)) != RSK_OK) return rc;
+        uint8_t *const hp = (uint8_t *) h;                            // chains are copied, pads zeroed below
         std::atomic<uint64_t> bad{UINT64_MAX};                        // (chain << 8) | feature of the first offender
         rsk_parallel_for(n, 512, [&](size_t lo, size_t hi) {
             for (size_t i = lo; i < hi; ++i)
@@ -333,9 +386,9 @@ extern "C" int rsk_db_create(rsk_ctx *ctx, uint32_t n, const uint32_t *lengths, 
             rsk_set_error("rsk_db_create: profile letter %u out of range (chain %u feature %d)", mx, i, f);
             return RSK_E_INVALID;
         }
-        if ((rc = dev_upload(ctx, &db->d_prof, hp, (size_t) RSK_NFEAT * o, db->hbm_bytes)) != RSK_OK) return rc;
+        if ((rc = up.send(db->d_prof, h, (size_t) RSK_NFEAT * o)) != RSK_OK) return rc;
         // the float-SW kernels read letter * 4 (column offsets) and letter * alphabet * 4 (row offsets) per feature,
-        // residue-major: derived on the device from the bytes just uploaded
+        // residue-major: derived on the device from the bytes just uploaded (same stream: behind the copy)
         const size_t nrec = ((size_t) o + 64) * 8;
         if ((rc = rsk_dev_malloc(ctx, (void **) &db->d_prof_cb, nrec * 2)) != RSK_OK) return rc;
         if ((rc = rsk_dev_malloc(ctx, (void **) &db->d_prof_ra, nrec * 2)) != RSK_OK) return rc;
@@ -345,28 +398,31 @@ extern "C" int rsk_db_create(rsk_ctx *ctx, uint32_t n, const uint32_t *lengths, 
         if (o) hipLaunchKernelGGL(k_db_derive, dim3((unsigned) ((o + 255) / 256)), dim3(256), 0, ctx->stream, db->d_prof, (size_t) o,
                                   db->d_prof_cb, db->d_prof_ra);
         RSK_HIP(hipGetLastError());
-        RSK_HIP(hipStreamSynchronize(ctx->stream));
     }
     if (x) {
-        std::unique_ptr<float[]> hx(new float[(size_t) o + 1]), hy(new float[(size_t) o + 1]), hz(new float[(size_t) o + 1]);
-        rsk_parallel_for(n, 512, [&](size_t lo, size_t hi) {
-            for (size_t i = lo; i < hi; ++i) {
-                memcpy(&hx[db->off[i]], x + src[i], 4 * (size_t) lengths[i]);
-                memcpy(&hy[db->off[i]], y + src[i], 4 * (size_t) lengths[i]);
-                memcpy(&hz[db->off[i]], z + src[i], 4 * (size_t) lengths[i]);
-                for (uint32_t k = db->off[i] + lengths[i]; k < db->off[i + 1]; ++k) hx[k] = hy[k] = hz[k] = 0.f;
-            }
-        });
-        if ((rc = dev_upload(ctx, &db->d_x, hx.get(), (size_t) o, db->hbm_bytes)) != RSK_OK) return rc;
-        if ((rc = dev_upload(ctx, &db->d_y, hy.get(), (size_t) o, db->hbm_bytes)) != RSK_OK) return rc;
-        if ((rc = dev_upload(ctx, &db->d_z, hz.get(), (size_t) o, db->hbm_bytes)) != RSK_OK) return rc;
+        const float *srcs[3] = { x, y, z };
+        float **dsts[3] = { &db->d_x, &db->d_y, &db->d_z };
+        for (int ax = 0; ax < 3; ++ax) {
+            if ((rc = up.reserve((void **) dsts[ax], (size_t) o * 4, &h)) != RSK_OK) return rc;
+            float *const hx = (float *) h;
+            const float *const sx = srcs[ax];
+            rsk_parallel_for(n, 512, [&](size_t lo, size_t hi) {
+                for (size_t i = lo; i < hi; ++i) {
+                    memcpy(&hx[db->off[i]], sx + src[i], 4 * (size_t) lengths[i]);
+                    for (uint32_t k = db->off[i] + lengths[i]; k < db->off[i + 1]; ++k) hx[k] = 0.f;
+                }
+            });
+            if ((rc = up.send(*dsts[ax], h, (size_t) o * 4)) != RSK_OK) return rc;
+        }
     }
     {
-        std::vector<float> sr(n, FLT_MAX);
-        if (selfrev) sr.assign(selfrev, selfrev + n);
-        db->h_selfrev = sr;
-        if ((rc = dev_upload(ctx, &db->d_selfrev, sr.data(), n, db->hbm_bytes)) != RSK_OK) return rc;
+        db->h_selfrev.assign(n, FLT_MAX);
+        if (selfrev) db->h_selfrev.assign(selfrev, selfrev + n);
+        if ((rc = up.reserve((void **) &db->d_selfrev, (size_t) n * 4, &h)) != RSK_OK) return rc;
+        if (n) memcpy(h, db->h_selfrev.data(), (size_t) n * 4);
+        if ((rc = up.send(db->d_selfrev, h, (size_t) n * 4)) != RSK_OK) return rc;
     }
+    RSK_HIP(hipStreamSynchronize(ctx->stream));             // the staging buffer belongs to the next call from here on
     *out = owner.release();
     return RSK_OK;
 }

@@ -227,3 +227,58 @@ def test_two_queries_per_register_equals_one(ctx, monkeypatch):
             assert two[2][i, j] == ol.mu_sw(seqs[i], ts[j])[0]
         for j in range(i, n, 3):
             assert two[0][i, j] == ol.mu_sw(seqs[i], seqs[j])[0]
+
+
+def test_filter_windows_tile_the_triangle(ctx):
+    """rsk_mu_filter_window_dev (r06: one shard of the self-search triangle = a window of the set's length order): the survivors of
+    the windows of N = 1, 2, 3, 8 shards (rsk_shard_range kind 2) are disjoint and their union is the whole triangle's survivor
+    set with the same (fwd, rev); every survivor's longer member (rsk_len_rank: the later one of equal lengths) stands in the
+    window that reported it; ragged windows (empty, one position, beyond a 1,100-residue chain of the slow class)."""
+    import torch
+    import reseek_amd
+    from reseek_amd import capi
+    rng = np.random.default_rng(33)
+    lens = np.concatenate([rng.integers(5, 400, 180), [1100, 1500, 7, 7, 7, 1024, 1025]])
+    rng.shuffle(lens)
+    base = [rng.integers(0, 36, int(L)).astype(np.uint8) for L in lens]
+    for k in range(0, 60, 2):                               # planted look-alikes so that pairs survive
+        src = base[k]
+        L = len(base[k + 1])
+        base[k + 1] = np.resize(src, L).copy()
+        base[k + 1][rng.integers(0, L, max(1, L // 5))] = rng.integers(0, 36, max(1, L // 5))
+    want, _, _ = run_filter(ctx, base, 12.0, 20.0, tri=True)
+    assert len(want) > 40
+    db = reseek_amd.Db.from_mu_seqs(ctx, base)
+    n = db.n
+    rank = ctx.len_rank(db)
+    assert sorted(rank) == list(range(n)) and all(lens[a] < lens[b] or (lens[a] == lens[b] and a < b) for a, b in zip(np.argsort(rank)[:-1], np.argsort(rank)[1:]))
+    cap = n * n
+    fwd = torch.zeros((n, n), dtype=torch.uint8, device="cuda")
+    pq, pt, pf, pr = (torch.zeros(cap, dtype=torch.int32, device="cuda") for _ in range(4))
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+
+    def window(lo, hi):
+        ctx.mu_filter_window_dev(db, lo, hi, 12.0, 20.0, fwd.data_ptr(), n, pq.data_ptr(), pt.data_ptr(), pf.data_ptr(), pr.data_ptr(), cap, cnt.data_ptr())
+        torch.cuda.synchronize()
+        k = int(cnt.item())
+        res = {(int(a), int(b)): (int(f), int(r)) for a, b, f, r in zip(pq[:k].cpu(), pt[:k].cpu(), pf[:k].cpu(), pr[:k].cpu())}
+        assert len(res) == k
+        for a, b in res:
+            assert a <= b and lo <= max(rank[a], rank[b]) < hi, (a, b, lo, hi)
+        assert ctx.mu_filter_last_work()[0] == (hi * (hi + 1) - lo * (lo + 1)) // 2
+        return res
+
+    for count in (1, 2, 3, 8):
+        got = {}
+        for r in range(count):
+            lo, hi = capi.shard_range(2, lens.astype(np.uint32), r, count)
+            w = window(lo, hi)
+            assert not (set(w) & set(got))
+            got.update(w)
+        assert got == want, count
+    assert window(5, 5) == {} and window(n, n) == {}
+    one = window(n - 1, n)                                  # the longest chain against everything
+    assert one == {k: v for k, v in want.items() if max(rank[k[0]], rank[k[1]]) == n - 1}
+    with pytest.raises(capi.RskError):
+        window(3, n + 1)
+    db.close()

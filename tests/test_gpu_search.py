@@ -5,6 +5,7 @@ import os
 import shutil
 import tempfile
 
+import numpy as np
 import pytest
 
 import fixtures as fx
@@ -193,11 +194,12 @@ def test_bca_fast_db_with_dbmu_and_options(ctx, tmpdir):
 
 
 def test_sharded_search_equals_unsharded(ctx, tmpdir):
-    """the union of the shards' hit tables is the unsharded table (self search: triangle cut by target
-    range; -db mode: DB chains cut by residues).  The shards run one after another on this single GPU."""
+    """the union of the shards' hit tables is the unsharded table (self search: windows of the set's length order +
+    the long-chain list dealt round-robin, r06; -db mode: DB chains cut by residues).  The shards run one after another on this
+    single GPU."""
     q = unpack_bca("q100.bca", tmpdir)
     for db, golden in ((None, "hits_q100_sensitive.tsv.gz"), (q, "hits_q100_db_q100_sensitive.tsv.gz")):
-        for count in (2, 3, 7):
+        for count in (2, 3, 7, 8):
             lines, pairs = [], 0
             for idx in range(count):
                 out = os.path.join(tmpdir, "shard_%s_%d_%d.tsv" % ("db" if db else "self", count, idx))
@@ -209,14 +211,41 @@ def test_sharded_search_equals_unsharded(ctx, tmpdir):
             want = ["\t".join(r) for r in fx.read_tsv(golden)]
             assert sorted(lines) == want
             assert pairs == (10000 if db else 5050)
-    # palms: shards with MKF pairs
+    # palms: shards with MKF pairs (every chain is long: the long-chain list IS the pair space, dealt round-robin), N = 4 and 8;
+    # the counters of the shards add up to the unsharded call's
     p = unpack_bca("palms.bca", tmpdir)
-    lines = []
-    for idx in range(4):
-        out = os.path.join(tmpdir, "shard_palms_%d.tsv" % idx)
-        ctx.search(p, out, "sensitive", columns=COLS, shard_index=idx, shard_count=4)
-        lines += open(out).read().splitlines()
-    assert sorted(lines) == ["\t".join(r) for r in fx.read_tsv("hits_palms_sensitive.tsv.gz")]
+    n1, st1 = ctx.search(p, os.path.join(tmpdir, "palms_one.tsv"), "sensitive", columns=COLS)
+    for count in (4, 8):
+        lines, st = [], np.zeros(8, np.int64)
+        for idx in range(count):
+            out = os.path.join(tmpdir, "shard_palms_%d.tsv" % idx)
+            _, s8 = ctx.search(p, out, "sensitive", columns=COLS, shard_index=idx, shard_count=count)
+            lines += open(out).read().splitlines()
+            st += np.array(s8, np.int64)
+        assert sorted(lines) == ["\t".join(r) for r in fx.read_tsv("hits_palms_sensitive.tsv.gz")]
+        assert list(st[:7]) == list(np.array(st1, np.int64)[:7]), (count, st, st1)
+    # the tail set (short chains + a few long ones: both kinds of pairs in every window), -noself, and the r01-r05 cut (target
+    # ranges of the chain order: still the route without a Mu filter and beyond one filter pass) through RSK_SELF_SHARD_RANGES
+    t = unpack_bca("taildb.bca", tmpdir)
+    for src in [x for x in (t, q) if x]:
+        for kw in ({}, {"noself": 1}):
+            one = os.path.join(tmpdir, "one.tsv")
+            n1, st1 = ctx.search(src, one, "sensitive", columns=COLS, **kw)
+            want = sorted(open(one).read().splitlines())
+            for env in (None, "1"):
+                if env:
+                    os.environ["RSK_SELF_SHARD_RANGES"] = env
+                try:
+                    lines, st = [], np.zeros(8, np.int64)
+                    for idx in range(8):
+                        out = os.path.join(tmpdir, "shard8_%d.tsv" % idx)
+                        _, s8 = ctx.search(src, out, "sensitive", columns=COLS, shard_index=idx, shard_count=8, **kw)
+                        lines += open(out).read().splitlines()
+                        st += np.array(s8, np.int64)
+                finally:
+                    os.environ.pop("RSK_SELF_SHARD_RANGES", None)
+                assert sorted(lines) == want, (src, kw, env)
+                assert list(st[:7]) == list(np.array(st1, np.int64)[:7]), (src, kw, env, st, st1)
     from reseek_amd import capi
     with pytest.raises(capi.RskError):
         ctx.search(q, os.path.join(tmpdir, "x.tsv"), "fast", db=q, shard_index=0, shard_count=2)

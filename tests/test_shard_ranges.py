@@ -73,7 +73,23 @@ def test_more_shards_than_chains_and_bad_arguments():
     with pytest.raises(RuntimeError):
         capi.shard_range(0, L, 3, 3)
     with pytest.raises(RuntimeError):
-        capi.shard_range(2, L, 0, 1)
+        capi.shard_range(3, L, 0, 1)
+
+
+@pytest.mark.parametrize("count", [1, 2, 3, 8])
+def test_self_windows_of_the_length_order(count):
+    """kind 2 (r06): windows of POSITIONS of the set's length order (stable sort by length) -- the shards of a self search with
+    a Mu filter.  They tile [0, n) in order and hold equal DP cells of the triangle: position p closes the pairs of the chain
+    there with every chain at a position <= p."""
+    for name, L in lengths_sets():
+        if len(L) < 100:
+            continue
+        Ls = np.sort(L, kind="stable").astype(np.float64)
+        cells = Ls * np.cumsum(Ls)                         # cells position p closes
+        got = [capi.shard_range(2, L, r, count) for r in range(count)]
+        assert got[0][0] == 0 and got[-1][1] == len(L) and all(got[r][1] == got[r + 1][0] for r in range(count - 1)), (name, got)
+        share = [cells[lo:hi].sum() / cells.sum() for lo, hi in got]
+        assert max(abs(x - 1.0 / count) for x in share) <= cells.max() / cells.sum() + 1e-12, (name, share)
 
 
 @pytest.mark.parametrize("world", [1, 2, 3, 8])
