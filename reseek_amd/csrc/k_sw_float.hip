@@ -869,7 +869,13 @@ __global__ void k_traceback(const uint8_t *tb, const uint64_t *tb_off, const uin
 // One wave per pair.  The reference accumulates, over the column pairs c < c' within R0, (4, thresholds met)
 // into both columns: integer counts, so any order of the additions gives the same per-column fractions.
 #define LDDT_LDS_COLS 256
+#define LDDT_SHORT_COLS 128
 #define LDDT_LONG_COLS 4096
+// Two instances over the same pair list (r06): <128, true> takes the pairs whose PATH has at most 128 characters -- the bulk of a
+// search against unrelated chains -- with half the staging per wave (20 KB of LDS per workgroup instead of 34: 8 waves per SIMD
+// instead of 4; the kernel waits for LDS / memory in 57 % of its wave cycles, r05 counters), <256, false> everything else and the
+// bookkeeping of the pairs below m_MinFwdScore.  A wave whose pair belongs to the other instance returns after two loads.
+template <int COLS, bool SHORT>
 __global__ __launch_bounds__(256) void k_lddt(const char *paths, const uint64_t *path_start, const uint32_t *path_len,
                                               const uint32_t *lo_a, const uint32_t *lo_b, const uint32_t *ia, const uint32_t *ib,
                                               const uint32_t *a_off, const uint32_t *b_off,
@@ -878,13 +884,13 @@ __global__ __launch_bounds__(256) void k_lddt(const char *paths, const uint64_t 
                                               uint32_t npairs, uint32_t *scratch_pos, const uint64_t *scratch_off,
                                               float *frac_scratch, float *lddt_out, uint32_t *counts_out,
                                               const float *score, float min_fwd_score, const uint8_t *a_seq, const uint8_t *b_seq,
-                                              uint32_t *long_cnt, uint32_t *long_list)
+                                              uint32_t *long_cnt, uint32_t *long_list, int split)
 {
     // per wave: coordinates of A and B at the aligned columns ({ax, ay, az, bx} / {by, bz}) and per-column counters
     // (considered | preserved << 16; at most 4 * 255 each)
-    __shared__ float4 sc4[4][LDDT_LDS_COLS];
-    __shared__ float2 sc2[4][LDDT_LDS_COLS];
-    __shared__ uint32_t scnt[4][LDDT_LDS_COLS];
+    __shared__ float4 sc4[4][COLS];
+    __shared__ float2 sc2[4][COLS];
+    __shared__ uint32_t scnt[4][COLS];
     __shared__ uint32_t sq_cols[4][128];            // queue of column pairs within R0: (ci | cj << 16), squared distances
     __shared__ float2 sq_d[4][128];
     // the wave's pair: the same for its 64 lanes, which the compiler cannot see in `threadIdx.x >> 6` -- without the
@@ -895,10 +901,11 @@ __global__ __launch_bounds__(256) void k_lddt(const char *paths, const uint64_t 
     const int lane = threadIdx.x & 63;
     // CalcEvalue leaves everything unset below m_MinFwdScore (dssaligner.cpp:861): no LDDT needed for those pairs
     if (score[p] < min_fwd_score || score[p] == 0.0f) {
-        if (lane == 0) { lddt_out[p] = 0.0f; counts_out[4 * p] = 0; counts_out[4 * p + 1] = 0; counts_out[4 * p + 2] = 0; counts_out[4 * p + 3] = RSK_NO_POS; }
+        if (!SHORT && lane == 0) { lddt_out[p] = 0.0f; counts_out[4 * p] = 0; counts_out[4 * p + 1] = 0; counts_out[4 * p + 2] = 0; counts_out[4 * p + 3] = RSK_NO_POS; }
         return;
     }
     const uint32_t len = path_len[p];
+    if (split && (SHORT ? len > (uint32_t) LDDT_SHORT_COLS : len <= (uint32_t) LDDT_SHORT_COLS)) return;      // the other instance's pair
     uint32_t *posA = scratch_pos + 2 * scratch_off[p];
     uint32_t *posB = posA + (scratch_off[p + 1] - scratch_off[p]);
     float *frac = frac_scratch + scratch_off[p];
@@ -916,7 +923,43 @@ __global__ __launch_bounds__(256) void k_lddt(const char *paths, const uint64_t 
     // wave's staging while the path is expanded (r01-r04 wrote the column positions to scratch, fenced, and read them back
     // for the staging loop: two dependent global round trips per pair).  Longer paths keep the scratch lists, which
     // k_lddt_long reads.
-    const bool direct = len <= LDDT_LDS_COLS;
+    const bool direct = len <= (uint32_t) COLS;
+    if (direct) {
+        // every character of the path at once, then every coordinate at once: two global round trips per PAIR (r01-r05 took the
+        // path 64 characters at a time, each step's coordinate loads behind its character load: two round trips per 64 characters)
+        constexpr int NCH = COLS / 64;
+        char ch[NCH];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const uint32_t c = (uint32_t) k * 64u + (uint32_t) lane;
+            ch[k] = c < len ? P[c] : (char) 0;
+        }
+        uint32_t kMs[NCH], a1s[NCH], b1s[NCH];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const unsigned long long mM = __ballot(ch[k] == 'M'), mD = __ballot(ch[k] == 'D'), mI = __ballot(ch[k] == 'I');
+            const uint32_t kM = nM + (uint32_t) __popcll(mM & lt), kD = nD + (uint32_t) __popcll(mD & lt), kI = nI + (uint32_t) __popcll(mI & lt);
+            kMs[k] = kM; a1s[k] = la0 + kM + kD; b1s[k] = lb0 + kM + kI;
+            nM += (uint32_t) __popcll(mM); nD += (uint32_t) __popcll(mD); nI += (uint32_t) __popcll(mI);
+        }
+        float4 v4[NCH];
+        float2 v2[NCH];
+        bool same[NCH];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            same[k] = false;
+            if (ch[k] == 'M') {
+                v4[k] = make_float4(AX[a1s[k]], BX[b1s[k]], AY[a1s[k]], BY[b1s[k]]);        // (A, B) pairs per axis: the two distances run as packed fp32 ops
+                v2[k] = make_float2(AZ[a1s[k]], BZ[b1s[k]]);
+                if (SA && SB) same[k] = SA[a1s[k]] == SB[b1s[k]];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            if (ch[k] == 'M') { sc4[wv][kMs[k]] = v4[k]; sc2[wv][kMs[k]] = v2[k]; scnt[wv][kMs[k]] = 0; }
+            nIdent += (uint32_t) __popcll(__ballot(same[k]));
+        }
+    } else
     for (uint32_t base = 0; base < len; base += 64) {
         const uint32_t c = base + lane;
         const char ch = c < len ? P[c] : 0;
@@ -925,14 +968,8 @@ __global__ __launch_bounds__(256) void k_lddt(const char *paths, const uint64_t 
         if (ch == 'M') {
             const uint32_t kM = nM + (uint32_t) __popcll(mM & lt), kD = nD + (uint32_t) __popcll(mD & lt), kI = nI + (uint32_t) __popcll(mI & lt);
             const uint32_t a1 = la0 + kM + kD, b1 = lb0 + kM + kI;
-            if (direct) {
-                sc4[wv][kM] = make_float4(AX[a1], BX[b1], AY[a1], BY[b1]);        // (A, B) pairs per axis: the two distances run as packed fp32 ops
-                sc2[wv][kM] = make_float2(AZ[a1], BZ[b1]);
-                scnt[wv][kM] = 0;
-            } else {
-                posA[kM] = a1;
-                posB[kM] = b1;
-            }
+            posA[kM] = a1;
+            posB[kM] = b1;
             if (SA && SB) same = SA[a1] == SB[b1];
         }
         nIdent += (uint32_t) __popcll(__ballot(same));
@@ -943,7 +980,7 @@ __global__ __launch_bounds__(256) void k_lddt(const char *paths, const uint64_t 
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     if (ncols == 0) { if (lane == 0) lddt_out[p] = 0.0f; return; }
     const float R0sq = 15.0f * 15.0f;
-    if (ncols > LDDT_LDS_COLS && ncols <= LDDT_LONG_COLS) {
+    if (ncols > (uint32_t) COLS && ncols <= LDDT_LONG_COLS) {
         // k_lddt_long: a whole workgroup per pair, over the list this kernel appends to (class 0: <= 1024 columns, 1: <= 4096).
         // (r02-r04 launched one workgroup per CANDIDATE -- every pair whose shorter chain allows > 256 columns, tens of
         // thousands per batch of unrelated chains, nearly all of which returned at once: 2 ms per batch, 7 % of config 4.)
@@ -953,7 +990,7 @@ __global__ __launch_bounds__(256) void k_lddt(const char *paths, const uint64_t 
         }
         return;
     }
-    const bool in_lds = ncols <= LDDT_LDS_COLS;
+    const bool in_lds = ncols <= (uint32_t) COLS;
     if (in_lds) {
         // Every unordered column pair once: the ncols (ncols - 1) / 2 pairs, row-major (ci < cj), are cut into 64 equal
         // runs, one per lane; a pair within R0 adds (4, thresholds met) to the counters of BOTH columns (integers, so
@@ -1057,9 +1094,9 @@ __global__ __launch_bounds__(256) void k_lddt(const char *paths, const uint64_t 
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         // per-column fractions in registers (column c in lane c % 64, slot c / 64), then the reference's sequential
         // sum in column order (lddt.cpp:111-121): one v_readlane + v_add per column instead of a dependent LDS read
-        float fr[LDDT_LDS_COLS / 64];
+        float fr[COLS / 64];
 #pragma unroll
-        for (int k = 0; k < LDDT_LDS_COLS / 64; ++k) {
+        for (int k = 0; k < COLS / 64; ++k) {
             fr[k] = 0.0f;
             if ((uint32_t) k * 64 >= ncols) continue;                    // (wave-uniform: no division for slots beyond the alignment)
             const uint32_t c = (uint32_t) k * 64 + lane;
@@ -1068,7 +1105,7 @@ __global__ __launch_bounds__(256) void k_lddt(const char *paths, const uint64_t 
         }
         float total = 0.0f;
 #pragma unroll
-        for (int k = 0; k < LDDT_LDS_COLS / 64; ++k) {
+        for (int k = 0; k < COLS / 64; ++k) {
             const uint32_t n = ncols > (uint32_t) k * 64 ? min(64u, ncols - (uint32_t) k * 64) : 0u;
             for (uint32_t c = 0; c < n; ++c)
                 total += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fr[k]), (int) c));
@@ -1615,10 +1652,17 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
         if ((rc = dalloc((void **) &d_long_cnt, 16)) != RSK_OK) return rc;
         if ((rc = dalloc((void **) &d_long_list, any_long ? 2 * npairs * 4 : 16)) != RSK_OK) return rc;
         RSK_HIP(hipMemsetAsync(d_long_cnt, 0, 16, ctx->stream));
-        hipLaunchKernelGGL(k_lddt, dim3((unsigned) ((npairs + 3) / 4)), dim3(256), 0, ctx->stream, d_paths, d_pstart, d_plen, d_loa, d_lob,
+        // RSK_LDDT_SPLIT=0: one instance for every pair (the r05 kernel's shape; A/B runs)
+        static const int lddt_split = !(getenv("RSK_LDDT_SPLIT") && atoi(getenv("RSK_LDDT_SPLIT")) == 0);
+        if (lddt_split)
+            hipLaunchKernelGGL((k_lddt<LDDT_SHORT_COLS, true>), dim3((unsigned) ((npairs + 3) / 4)), dim3(256), 0, ctx->stream, d_paths, d_pstart, d_plen, d_loa, d_lob,
+                               d_ia, d_ib, dba->d_off, dbb->d_off, dba->d_x, dba->d_y, dba->d_z, dbb->d_x, dbb->d_y, dbb->d_z,
+                               (uint32_t) npairs, d_pos, d_scoff, d_frac, d_lddt, d_counts, d_score, min_fwd_score, dba->d_seq, dbb->d_seq,
+                               d_long_cnt, d_long_list, 1);
+        hipLaunchKernelGGL((k_lddt<LDDT_LDS_COLS, false>), dim3((unsigned) ((npairs + 3) / 4)), dim3(256), 0, ctx->stream, d_paths, d_pstart, d_plen, d_loa, d_lob,
                            d_ia, d_ib, dba->d_off, dbb->d_off, dba->d_x, dba->d_y, dba->d_z, dbb->d_x, dbb->d_y, dbb->d_z,
                            (uint32_t) npairs, d_pos, d_scoff, d_frac, d_lddt, d_counts, d_score, min_fwd_score, dba->d_seq, dbb->d_seq,
-                           d_long_cnt, d_long_list);
+                           d_long_cnt, d_long_list, lddt_split);
         for (int c = 0; c < 2; ++c) {
             // candidates of class 1 (shorter chain > 1024) may end with <= 1024 columns: both launches run whenever the host
             // bound allows the class or a longer one; a launch is a few workgroups per CU that walk the device list
@@ -1761,9 +1805,10 @@ int rsk_paths_stats_pack(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *dbb, siz
     if ((rc = dalloc((void **) &d_long_cnt, 16)) != RSK_OK) return rc;
     if ((rc = dalloc((void **) &d_long_list, any_long ? 2 * npairs * 4 : 16)) != RSK_OK) return rc;
     RSK_HIP(hipMemsetAsync(d_long_cnt, 0, 16, ctx->stream));
-    hipLaunchKernelGGL(k_lddt, dim3((unsigned) ((npairs + 3) / 4)), dim3(256), 0, ctx->stream, d_paths, d_pstart, d_plen, d_loa, d_lob, d_ia, d_ib,
+    // (the long-chain path's alignments: the one-instance form)
+    hipLaunchKernelGGL((k_lddt<LDDT_LDS_COLS, false>), dim3((unsigned) ((npairs + 3) / 4)), dim3(256), 0, ctx->stream, d_paths, d_pstart, d_plen, d_loa, d_lob, d_ia, d_ib,
                        dba->d_off, dbb->d_off, dba->d_x, dba->d_y, dba->d_z, dbb->d_x, dbb->d_y, dbb->d_z, (uint32_t) npairs, d_pos, d_scoff, d_frac,
-                       d_lddt, d_counts, d_score, min_fwd_score, dba->d_seq, dbb->d_seq, d_long_cnt, d_long_list);
+                       d_lddt, d_counts, d_score, min_fwd_score, dba->d_seq, dbb->d_seq, d_long_cnt, d_long_list, 0);
     for (int c = 0; c < 2; ++c) {
         const size_t bound = c == 0 ? lddt_list[0].size() + lddt_list[1].size() : lddt_list[1].size();
         const uint32_t cap = c == 0 ? 1024u : (uint32_t) LDDT_LONG_COLS;

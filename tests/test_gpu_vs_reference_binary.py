@@ -2,7 +2,9 @@
 it travels with the snapshot like the built .so): fresh synthetic structure sets that no fixture has seen go through
 `reseek -search` (-threads 1, see tests/compare_with_reference.py for why) and through rsk_search; the sorted hit
 tables must be identical -- every mode, self and -db, prefilter path and long-chain (MKF / X-drop) pairs included.
-Skipped when the binary did not travel."""
+Each case also has a committed golden of that binary's one-thread table (tests/golden/refbin_goldens.json, made by
+tests/golden/make_refbin_goldens.py: row count + md5 of the sorted table + md5 of the seeded input files): where the binary did
+not travel the cases run against the goldens instead of skipping, where it did they check both."""
 import os
 import sys
 
@@ -17,8 +19,9 @@ REF = os.path.join(ROOT, "oracle", "_ref", "reseek")
 # tests skip -- unless RSK_REQUIRE_REF=1 (set by tools/exp/run_all_gpu_tests.sh), which turns the silent skip of the strongest
 # parity tests into a failure.
 REQUIRE_REF = os.environ.get("RSK_REQUIRE_REF", "") not in ("", "0")
-need_ref = pytest.mark.skipif(not os.path.exists(REF) and not REQUIRE_REF,
-                              reason="oracle/_ref/reseek was not built (no /root/reference at build time)")
+HAVE_GOLDENS = os.path.exists(os.path.join(fx.GOLDEN, "refbin_goldens.json"))
+need_ref = pytest.mark.skipif(not os.path.exists(REF) and not REQUIRE_REF and not HAVE_GOLDENS,
+                              reason="neither oracle/_ref/reseek nor tests/golden/refbin_goldens.json is present")
 
 
 def test_reference_binary_present_when_required():
@@ -34,6 +37,10 @@ def test_hit_table_equals_the_reference_binary(n, mode, ndb, seed):
     res = cwr.compare(n, mode, ndb, threads=1, seed=seed, long_chains=4 if mode != "verysensitive" else 0)
     assert res["identical"], res
     assert res["reference_rows"] > 0
+    assert "golden" in res and all(res["golden"].values()), res        # the committed one-thread table of the reference binary
+    if os.path.exists(REF):
+        # the golden route on its own (what a box without the binary runs)
+        assert cwr.compare(n, mode, ndb, threads=1, seed=seed, long_chains=4 if mode != "verysensitive" else 0, use_binary=False)["identical"]
     if mode != "verysensitive":
         assert res["long_chain_pairs"] > 0        # chains >= 600: MKF seeding + GPU X-drop extensions took part
 
@@ -48,5 +55,6 @@ def test_db_search_with_a_pdb_like_length_tail(n, mode, ndb, seed):
     res = cwr.compare(n, mode, ndb, threads=1, seed=seed, tail=True)
     assert res["identical"], res
     assert res["reference_rows"] > 0
+    assert "golden" in res and all(res["golden"].values()), res
     if mode == "sensitive":
         assert res["long_chain_pairs"] > 0
