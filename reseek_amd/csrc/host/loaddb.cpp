@@ -516,6 +516,7 @@ void DBSearcher::UploadToGpu()
 {
     if (m_Db) return;
     if (!m_Ctx) throw std::runtime_error("DBSearcher: no GPU context");
+    PhaseTimer tm("UploadToGpu");
     const uint n = GetDBChainCount();
     std::vector<uint32_t> len(n);
     std::vector<size_t> start((size_t) n + 1, 0);
@@ -534,8 +535,10 @@ void DBSearcher::UploadToGpu()
             memcpy(&z[o], m_DBChains[i]->m_Zs.data(), 4 * (size_t) L);
         }
     });
+    tm.lap("gather chain arrays");
     check(rsk_db_create(m_Ctx, n, len.data(), mu.get(), prof.get(), x.get(), y.get(), z.get(), m_DBSelfRevScores.data(), &m_Db),
           "rsk_db_create");
+    tm.lap("rsk_db_create");
     // residue characters: the statistics kernel counts the identical columns of an alignment (GetPctId) while it walks the path
     {
         std::unique_ptr<char[]> seq(new char[tot + 1]);
@@ -544,6 +547,7 @@ void DBSearcher::UploadToGpu()
         });
         check(rsk_db_set_seq(m_Db, seq.get()), "rsk_db_set_seq");
     }
+    tm.lap("residue characters");
 }
 
 }   // namespace reseek_amd

@@ -552,6 +552,8 @@ void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOffset, co
                 }
             }
         };
+        // (r06, window shards, N = 8 on the 11,211-chain set: with the job under the filter a shard took 82.9 ms against 80.0 ms behind it
+        // -- the seeding kernels take 22 ms instead of 7 beside the filter's and the filter is no shorter: the default stays)
         const bool early = getenv("RSK_MKF_EARLY") && atoi(getenv("RSK_MKF_EARLY")) == 1;
         std::future<void> mkf_list;
         if (early) build_mkf_list();

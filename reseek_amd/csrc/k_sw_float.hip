@@ -871,10 +871,9 @@ __global__ void k_traceback(const uint8_t *tb, const uint64_t *tb_off, const uin
 #define LDDT_LDS_COLS 256
 #define LDDT_SHORT_COLS 128
 #define LDDT_LONG_COLS 4096
-// Two instances over the same pair list (r06): <128, true> takes the pairs whose PATH has at most 128 characters -- the bulk of a
-// search against unrelated chains -- with half the staging per wave (20 KB of LDS per workgroup instead of 34: 8 waves per SIMD
-// instead of 4; the kernel waits for LDS / memory in 57 % of its wave cycles, r05 counters), <256, false> everything else and the
-// bookkeeping of the pairs below m_MinFwdScore.  A wave whose pair belongs to the other instance returns after two loads.
+// <256, false> is the instance the library launches.  <128, true> (RSK_LDDT_SPLIT=1, an experiment kept for A/B runs: measured
+// slower, see the launch) takes the pairs whose PATH has at most 128 characters with half the staging per wave; a wave whose pair
+// belongs to the other instance returns after two loads.
 template <int COLS, bool SHORT>
 __global__ __launch_bounds__(256) void k_lddt(const char *paths, const uint64_t *path_start, const uint32_t *path_len,
                                               const uint32_t *lo_a, const uint32_t *lo_b, const uint32_t *ia, const uint32_t *ib,
@@ -1652,8 +1651,11 @@ extern "C" int rsk_align_pairs(rsk_ctx *ctx, const rsk_db *dba, const rsk_db *db
         if ((rc = dalloc((void **) &d_long_cnt, 16)) != RSK_OK) return rc;
         if ((rc = dalloc((void **) &d_long_list, any_long ? 2 * npairs * 4 : 16)) != RSK_OK) return rc;
         RSK_HIP(hipMemsetAsync(d_long_cnt, 0, 16, ctx->stream));
-        // RSK_LDDT_SPLIT=0: one instance for every pair (the r05 kernel's shape; A/B runs)
-        static const int lddt_split = !(getenv("RSK_LDDT_SPLIT") && atoi(getenv("RSK_LDDT_SPLIT")) == 0);
+        // RSK_LDDT_SPLIT=1: the pairs with paths of <= 128 characters through an instance of their own (20 KB of LDS per workgroup: 7
+        // waves per SIMD instead of 4).  Measured r06, same box, alternating: 0.674 / 0.674 ms against 0.644 / 0.651 ms for the one
+        // instance on the 72,000-pair structure set, configs[4] share 5.37 / 5.26 s against 5.34 / 5.17 s -- more resident waves do
+        // not shorten the kernel (its waits are the LDS queue round trips of a step, not memory), a second launch costs: off.
+        static const int lddt_split = getenv("RSK_LDDT_SPLIT") && atoi(getenv("RSK_LDDT_SPLIT")) == 1;
         if (lddt_split)
             hipLaunchKernelGGL((k_lddt<LDDT_SHORT_COLS, true>), dim3((unsigned) ((npairs + 3) / 4)), dim3(256), 0, ctx->stream, d_paths, d_pstart, d_plen, d_loa, d_lob,
                                d_ia, d_ib, dba->d_off, dbb->d_off, dba->d_x, dba->d_y, dba->d_z, dbb->d_x, dbb->d_y, dbb->d_z,
