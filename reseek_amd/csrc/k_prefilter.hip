@@ -33,9 +33,17 @@
 #include "rsk_internal.h"
 #include "rsk_tables_data.h"
 
+#ifndef PF_THREADS
 #define PF_THREADS 512
+#endif
 #define PF_QSPAN 2048             // queries per span at most (LDS: info + best score per query)
-#define PF_BW 4096                // words of each diagonal bitmap (131,072 diagonals per span)
+#ifndef PF_BW
+#define PF_BW 4096
+#endif
+#ifndef PF_LDS_BUDGET
+#define PF_LDS_BUDGET 81000   // bytes of LDS a workgroup may use (two workgroups per CU)
+#endif
+//      PF_BW                     // words of each diagonal bitmap (131,072 diagonals per span)
 #define PF_LIST 4096              // two-hit diagonals scored per round
 #define PF_DICT 60466176u         // 36^5
 #define PF_LONGROW 64             // index row pieces from this length on are walked by a whole wave
@@ -262,6 +270,11 @@ __global__ __launch_bounds__(PF_THREADS) void k_prefilter(pf_args a)
             const uint32_t tsh = (uint32_t) ((uintptr_t) tp & 3);
             const uint32_t *tw = (const uint32_t *) (tp - tsh);
             uint32_t ta = *tw++;
+            // (Measured and not kept, r06: sixteen residues per iteration with the NEXT iteration's query dwords requested before
+            // this one's steps -- real SCOP40 letters 93.0 vs 91.6 ms, synthetic 650 vs 626 ms: the scans do not wait for the
+            // query letters, a diagonal is a chain of 3 dependent operations per cell and the lanes of a wave end with its
+            // longest diagonal.  Phase clocks of the workgroups (RSK_TRACE), real letters: span plan 9 %, seed walk 23-27 %,
+            // compaction + scans 62-67 %; 1,024 threads per workgroup with the same or doubled bitmaps: 126 / 108 ms.)
             for (; len >= 4; len -= 4, qp += 4, tp += 4) {
                 const uint32_t qw = *(const uint32_t *) qp;
                 const uint32_t tb = *tw++;
@@ -281,6 +294,10 @@ __global__ __launch_bounds__(PF_THREADS) void k_prefilter(pf_args a)
 
     unsigned long long my_items = 0, my_two = 0;
     uint32_t nspans = 0, nrounds = 0;
+    // phase clocks of the workgroup (shader cycles seen by its first wave between the barriers that end the phases): plan, clear,
+    // seed walk, compaction + scoring, triples -- RSK_TRACE prints their shares
+    unsigned long long ph[5] = { 0, 0, 0, 0, 0 }, ph_t = __builtin_amdgcn_s_memtime();
+    auto phase = [&](int k) { const unsigned long long now = __builtin_amdgcn_s_memtime(); ph[k] += now - ph_t; ph_t = now; };
     for (uint32_t qa = 0; qa < a.nq;) {
         // ---- plan the span [qa, qb): consecutive queries whose diagonals (QL + TL - 1 bits each, rounded up to whole
         // words so that a word belongs to one query) fit the bitmaps
@@ -311,9 +328,11 @@ __global__ __launch_bounds__(PF_THREADS) void k_prefilter(pf_args a)
         if (tid == 0) s_words = (info[nqs - 1] >> 16) + ((min((info[nqs - 1] & 0xFFFFu) + TL - 1, PF_MAXDIAG) + 31) >> 5);
         __syncthreads();
         const uint32_t nwords = s_words;
+        phase(0);
         for (uint32_t i = tid; i < nwords; i += PF_THREADS) { seen1[i] = 0; seen2[i] = 0; }
         __syncthreads();
         ++nspans;
+        phase(1);
 
         // ---- seed walk: every posting of the span's queries in the rows of this target's k-mers, once.  Row pieces of
         // >= PF_LONGROW postings are queued in LDS and split over the lanes of a wave (coalesced posting loads); shorter
@@ -379,6 +398,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_prefilter(pf_args a)
             }
             __syncthreads();
         }
+        phase(2);
         if (a.dbg == 1) { qa = qb; continue; }
 
         // ---- two-hit diagonals = set bits of seen2, compacted into the list in rounds of <= PF_LIST and scored
@@ -429,7 +449,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_prefilter(pf_args a)
             if (tot > PF_LIST) {
                 // more than a list of diagonals in 512 words: quarter blocks (128 words hold <= 4096 bits)
                 if (filled) { score_list(filled); filled = 0; }
-                for (int sub = 0; sub < 4; ++sub) {
+                for (int sub = 0; sub < PF_THREADS / 128; ++sub) {
                     const bool in = (tid >> 7) == sub;
                     uint32_t st;
                     const uint32_t ex2 = block_scan(in ? c : 0, st);
@@ -445,6 +465,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_prefilter(pf_args a)
         }
         if (filled) score_list(filled);
         __syncthreads();
+        phase(3);
 
         // ---- one (query, target, score) triple per query with a two-hit diagonal scoring > 0, one atomic per wave
         for (uint32_t i0 = 0; i0 < nqs; i0 += PF_THREADS) {
@@ -462,9 +483,12 @@ __global__ __launch_bounds__(PF_THREADS) void k_prefilter(pf_args a)
             }
         }
         __syncthreads();
+        phase(4);
         qa = qb;
     }
     if (a.stat) {
+        if (tid == 0)
+            for (int k = 0; k < 5; ++k) atomicAdd(a.stat + 8 + k, ph[k]);
         // wave-reduced statistics (RSK_TRACE / the work counters of the context)
 #pragma unroll
         for (int s = 32; s >= 1; s >>= 1) { my_items += __shfl_xor(my_items, s, 64); my_two += __shfl_xor(my_two, s, 64); my_cells += __shfl_xor(my_cells, s, 64); }
@@ -564,8 +588,8 @@ extern "C" int rsk_mu_prefilter_range_dev(rsk_ctx *ctx, const rsk_db *q, const r
     if ((rc = ws.alloc(&d_order, (size_t) std::max<uint32_t>(ntr, 1))) != RSK_OK) return rc;
     if (ntr) RSK_HIP(hipMemcpyAsync(d_order, order.data(), (size_t) ntr * 4, hipMemcpyHostToDevice, ctx->stream));
     unsigned long long *d_stat;
-    if ((rc = ws.alloc(&d_stat, 8)) != RSK_OK) return rc;
-    RSK_HIP(hipMemsetAsync(d_stat, 0, 64, ctx->stream));
+    if ((rc = ws.alloc(&d_stat, 16)) != RSK_OK) return rc;
+    RSK_HIP(hipMemsetAsync(d_stat, 0, 128, ctx->stream));
     RSK_HIP(hipMemsetAsync(d_n, 0, 4, ctx->stream));
     pf_args a = {};
     a.table = (const uint2 *) q->d_pf_table; a.postings = q->d_pf_postings;
@@ -579,7 +603,7 @@ extern "C" int rsk_mu_prefilter_range_dev(rsk_ctx *ctx, const rsk_db *q, const r
     for (uint32_t k = t_lo; k < t_hi; ++k) maxTL = std::max(maxTL, t->len[k]);
     // two workgroups per CU (the seed walk is latency-bound): each may use half of the 160 KB; target letters as far as
     // they fit (longer targets are read from HBM in place)
-    const uint32_t tl_cap = (uint32_t) std::min<size_t>(maxTL, (81000 - PF_LDS_FIXED - 48) & ~(size_t) 15);
+    const uint32_t tl_cap = (uint32_t) std::min<size_t>(maxTL, ((size_t) PF_LDS_BUDGET - PF_LDS_FIXED - 48) & ~(size_t) 15);
     a.tl_cap = tl_cap;
     a.dbg = getenv("RSK_PF_DEBUG") ? (uint32_t) atoi(getenv("RSK_PF_DEBUG")) : 0;
     const size_t lds = PF_LDS_FIXED + (((size_t) tl_cap + 8 + 31) & ~(size_t) 15);
@@ -590,8 +614,8 @@ extern "C" int rsk_mu_prefilter_range_dev(rsk_ctx *ctx, const rsk_db *q, const r
         RSK_HIP(hipGetLastError());
     }
     RSK_HIP(hipEventRecord(ctx->ev1, ctx->stream));
-    unsigned long long stat[8] = { 0 };
-    RSK_HIP(hipMemcpyAsync(stat, d_stat, 64, hipMemcpyDeviceToHost, ctx->stream));
+    unsigned long long stat[16] = { 0 };
+    RSK_HIP(hipMemcpyAsync(stat, d_stat, 128, hipMemcpyDeviceToHost, ctx->stream));
     RSK_HIP(hipStreamSynchronize(ctx->stream));
     ctx->pf_hits = stat[0];
     ctx->pf_postings = q->pf_postings;
@@ -600,6 +624,11 @@ extern "C" int rsk_mu_prefilter_range_dev(rsk_ctx *ctx, const rsk_db *q, const r
     if (getenv("RSK_TRACE"))
         fprintf(stderr, "[prefilter] index postings %zu, seed items %llu, two-hit diagonals %llu (%llu cells); query spans %llu, scoring rounds %llu (targets %u .. %u)\n",
                 q->pf_postings, stat[0], stat[1], stat[4], stat[2], stat[3], t_lo, t_hi);
+    if (getenv("RSK_TRACE")) {
+        const double tot = (double) (stat[8] + stat[9] + stat[10] + stat[11] + stat[12]) + 1e-9;
+        fprintf(stderr, "[prefilter] workgroup cycles: span plan %.1f %%, bitmap clear %.1f %%, seed walk %.1f %%, compaction + diagonal scans %.1f %%, triples %.1f %% (%.3g cycles per span)\n",
+                100.0 * stat[8] / tot, 100.0 * stat[9] / tot, 100.0 * stat[10] / tot, 100.0 * stat[11] / tot, 100.0 * stat[12] / tot, tot / (double) std::max<unsigned long long>(stat[2], 1));
+    }
     return RSK_OK;
 }
 
