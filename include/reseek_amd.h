@@ -443,6 +443,14 @@ typedef struct rsk_search_opts {
 int rsk_search(rsk_ctx *ctx, const char *query_path, const char *db_path, const rsk_search_opts *opts,
                const char *out_tsv, uint64_t *nhits, uint64_t *stats8);
 
+/* Chains of shard `shard_index` of `shard_count` of a .bca file (contiguous, balanced by residues: rsk_shard_range kind 1),
+ * featurised as LoadDB does per chain (DSS profiles + Mu letters dss.cpp:716, self-rev scores alignpair.cpp:7 under opts->mode;
+ * query_flavour != 0: the scores a -db search computes for its streamed chains, runquery.cpp:43) and written as an RSKDB1
+ * container, the prepared form rsk_search reads without featurising.  The ranks of a multi-GPU self search from a .bca file
+ * featurise one slice each and exchange the containers (reseek_amd/dist.py) instead of every rank featurising every chain. */
+int rsk_bca_to_rskdb(rsk_ctx *ctx, const char *in_bca, uint32_t shard_index, uint32_t shard_count, const rsk_search_opts *opts,
+                     int query_flavour, const char *out_rskdb, uint64_t *nchains);
+
 /* Counters of the search path since the last reset -- process-wide, the counterpart of the static statistics the reference keeps
  * in DSSAligner (dssaligner.h:90-96: m_AlnCount, m_SWCount, m_MuFilterInputCount, ...), extended by what a GPU run needs to be
  * read: how many Smith-Waterman pairs reached the E-value stage, what the streamed -db loader cost, how many host->device copies

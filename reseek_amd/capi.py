@@ -148,6 +148,7 @@ class PathCounters(C.Structure):
                 ("featurise_seconds", C.c_double), ("upload_seconds", C.c_double), ("swqp_cycles", C.c_uint64), ("swqp_ref_ticks", C.c_uint64)]
 
 
+SIGNATURES["rsk_bca_to_rskdb"] = (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(SearchOpts), C.c_int, C.c_char_p, C.POINTER(C.c_uint64)])
 SIGNATURES["rsk_path_counters_read"] = (C.c_int, [C.c_void_p, C.POINTER(PathCounters)])
 SIGNATURES["rsk_path_counters_reset"] = (C.c_int, [C.c_void_p])
 SIGNATURES["rsk_shard_range"] = (C.c_int, [C.c_int, u32p, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)])
@@ -390,6 +391,13 @@ class Ctx:
             else:
                 setattr(o, k, int(v))
         return o
+
+    def bca_to_rskdb(self, bca, out_rskdb, mode, shard_index=0, shard_count=1, query_flavour=False, **kw):
+        """featurise shard shard_index / shard_count of a .bca file (chains by residues) into an RSKDB1 container -> chains written"""
+        o = self._opts(mode, kw)
+        n = C.c_uint64()
+        _check(lib().rsk_bca_to_rskdb(self.h, bca.encode(), int(shard_index), int(shard_count), C.byref(o), int(bool(query_flavour)), out_rskdb.encode(), C.byref(n)))
+        return n.value
 
     def fast_shard_open(self, query, db, **kw):
         """-search -fast -db, stage 1 on target shard shard_index of shard_count -> FastShard (local top-B candidates)"""

@@ -481,6 +481,63 @@ void DBSearcher::LoadDB(const std::string &DBFN)
     tm.lap("read + build chains");
 }
 
+// The inverse of LoadDB's container route: header "RSKDB1\0\0", chain count, feature count, then per chain L, label length, label,
+// residue characters[L], Mu letters[L], profile[8][L], x[L], y[L], z[L] (float), self-rev score, k-mer count, k-mers.
+void DBSearcher::WriteRskdb(const std::string &FN) const
+{
+    FILE *f = fopen(FN.c_str(), "wb");
+    if (!f) throw std::runtime_error("WriteRskdb: cannot create " + FN);
+    struct Closer { FILE *f; ~Closer() { if (f) fclose(f); } } closer{ f };
+    std::string out;
+    const uint32_t n = GetDBChainCount(), nfeat = RSK_NFEAT;
+    out.append("RSKDB1\0\0", 8);
+    out.append((const char *) &n, 4);
+    out.append((const char *) &nfeat, 4);
+    for (uint32_t k = 0; k < n; ++k) {
+        const PDBChain &C = *m_DBChains[k];
+        const uint32_t L = C.GetSeqLength(), ll = (uint32_t) C.m_Label.size();
+        const std::vector<byte> &Mu = *m_DBMuLettersVec[k];
+        const std::vector<std::vector<byte> > &Prof = *m_DBProfiles[k];
+        if (Prof.size() != nfeat) throw std::runtime_error("WriteRskdb: chain without a profile");
+        out.append((const char *) &L, 4);
+        out.append((const char *) &ll, 4);
+        out.append(C.m_Label);
+        out.append(C.m_Seq.data(), L);
+        if (Mu.size() == L) out.append((const char *) Mu.data(), L);
+        else {
+            // (-verysensitive keeps no Mu letters, dbsearcher.cpp:249-251: the container's Mu row is what the featuriser gives)
+            std::vector<byte> M;
+            DSS D;
+            D.SetParams(*m_Params);
+            D.Init(C);
+            D.GetMuLetters(M);
+            out.append((const char *) M.data(), L);
+        }
+        for (uint32_t fi = 0; fi < nfeat; ++fi) out.append((const char *) Prof[fi].data(), L);
+        out.append((const char *) C.m_Xs.data(), 4 * (size_t) L);
+        out.append((const char *) C.m_Ys.data(), 4 * (size_t) L);
+        out.append((const char *) C.m_Zs.data(), 4 * (size_t) L);
+        const float sr = m_DBSelfRevScores[k];
+        out.append((const char *) &sr, 4);
+        std::vector<uint> Kmers;
+        {
+            std::vector<byte> M((const byte *) out.data() + out.size() - 4 - 12 * (size_t) L - (size_t) nfeat * L - L,
+                                (const byte *) out.data() + out.size() - 4 - 12 * (size_t) L - (size_t) nfeat * L);
+            GetMuKmers(M, Kmers);
+        }
+        const uint32_t nk = (uint32_t) Kmers.size();
+        out.append((const char *) &nk, 4);
+        out.append((const char *) Kmers.data(), 4 * (size_t) nk);
+        if (out.size() > ((size_t) 64 << 20)) {
+            if (fwrite(out.data(), 1, out.size(), f) != out.size()) throw std::runtime_error("WriteRskdb: short write to " + FN);
+            out.clear();
+        }
+    }
+    if (fwrite(out.data(), 1, out.size(), f) != out.size()) throw std::runtime_error("WriteRskdb: short write to " + FN);
+    closer.f = nullptr;
+    if (fclose(f) != 0) throw std::runtime_error("WriteRskdb: writing " + FN + " failed");
+}
+
 void DBSearcher::Setup()
 {
     if (!m_Ctx) m_Ctx = DefaultCtx();

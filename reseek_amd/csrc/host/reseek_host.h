@@ -428,6 +428,7 @@ public:
     // thread featurises batch k + 1 under batch k's kernels)
     uint m_StreamBatchChains = 1u << 15;
     uint64_t m_StreamBatchResidues = 8ull << 20;
+    void WriteRskdb(const std::string &FN) const;       // the loaded (featurised) chains as an RSKDB1 container: what LoadDB reads back
     void LoadChains(std::vector<PDBChain *> &Chains);   // take ownership, featurise on the host threads, self-rev scores on the GPU
     bool m_OwnsChains = true;
     void MakeView(const DBSearcher &Src, uint Lo, uint Hi);

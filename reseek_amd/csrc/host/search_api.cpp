@@ -293,6 +293,51 @@ extern "C" int rsk_search(rsk_ctx *ctx, const char *query_path, const char *db_p
     return search_impl(ctx, query_path, db_path, o, out_tsv, nhits, stats8);
 }
 
+// Chains [lo, hi) of a .bca file -- shard `shard_index` of `shard_count`, contiguous, balanced by residues -- featurised (DSS
+// profiles, Mu letters, self-rev scores: what LoadDB computes per chain, profileloader.cpp:59, under the call's mode and the
+// self-rev flavour the search will use) and written as an RSKDB1 container.  The ranks of a multi-GPU self search from a .bca
+// file featurise one slice each and exchange the containers (reseek_amd/dist.py: one all-gather of ~26 bytes per residue)
+// instead of every rank featurising every chain.
+extern "C" int rsk_bca_to_rskdb(rsk_ctx *ctx, const char *in_bca, uint32_t shard_index, uint32_t shard_count, const rsk_search_opts *opts,
+                                int query_flavour, const char *out_rskdb, uint64_t *nchains)
+{
+    if (!ctx || !in_bca || !opts || !out_rskdb) { rsk_set_error("rsk_bca_to_rskdb: NULL argument"); return RSK_E_INVALID; }
+    if (shard_count == 0) shard_count = 1;
+    if (shard_index >= shard_count) { rsk_set_error("rsk_bca_to_rskdb: shard_index >= shard_count"); return RSK_E_INVALID; }
+    SearchOptions o;
+    const int rc = reseek_amd::ParseSearchOpts(opts, o, "rsk_bca_to_rskdb");
+    if (rc != RSK_OK) return rc;
+    try {
+        DSSParams Params;
+        Params.SetDSSParams(o);
+        BCAData B;
+        B.Open(in_bca);
+        uint64_t Lo, Hi;
+        DBSearcher::ResidueShardRange(B.m_SeqLengths.data(), B.GetChainCount(), shard_index, shard_count, Lo, Hi);
+        ChainReader2 CR;
+        CR.OpenRange(in_bca, Lo, Hi);
+        std::vector<PDBChain *> Chains;
+        while (PDBChain *C = CR.GetNext()) Chains.push_back(C);
+        DBSearcher S;
+        S.m_Params = &Params;
+        S.m_Opts = o;
+        S.m_Ctx = ctx;
+        S.m_SelfRevQueryFlavour = query_flavour != 0;
+        try {
+            S.LoadChains(Chains);
+        } catch (...) {
+            for (PDBChain *C : Chains) delete C;
+            throw;
+        }
+        S.WriteRskdb(out_rskdb);
+        if (nchains) *nchains = S.GetDBChainCount();
+    } catch (const std::exception &e) {
+        rsk_set_error("rsk_bca_to_rskdb: %s", e.what());
+        return RSK_E_INVALID;
+    }
+    return RSK_OK;
+}
+
 extern "C" int rsk_abi_version(void) { return RSK_ABI_VERSION; }
 
 // ---- rsk_path_counters (the reference's static DSSAligner statistics, dssaligner.h:90-96, for a GPU run) ----------------------

@@ -87,11 +87,49 @@ def gather_text(text, dst=0, group=None, device=None):
     return b"".join(p.tobytes() for p in parts).decode()
 
 
+def merge_rskdb(parts):
+    """RSKDB1 containers (bytes / uint8 arrays: 8-byte magic, chain count, feature count, records) of consecutive chain slices -> one
+    container with the slices' chains in order"""
+    import struct
+    bodies, n, nfeat = [], 0, None
+    for p in parts:
+        b = p.tobytes() if hasattr(p, "tobytes") else bytes(p)
+        if len(b) < 16 or b[:8] != b"RSKDB1\0\0":
+            raise ValueError("merge_rskdb: not an RSKDB1 container")
+        k, f = struct.unpack("<II", b[8:16])
+        if nfeat is not None and f != nfeat:
+            raise ValueError("merge_rskdb: feature counts differ")
+        nfeat = f
+        n += k
+        bodies.append(b[16:])
+    return b"RSKDB1\0\0" + struct.pack("<II", n, nfeat if nfeat is not None else 8) + b"".join(bodies)
+
+
+def featurise_sharded(ctx, bca, out_rskdb, mode, group=None, device=None, **kw):
+    """One process per GPU, a self search from a .bca file: rank r featurises slice r of the chains (DSS profiles, Mu letters,
+    self-rev scores: rsk_bca_to_rskdb, contiguous slices balanced by residues), the slices' containers are all-gathered (~26 bytes
+    per residue: the exchange step of this path) and every rank writes the whole set as `out_rskdb`, the prepared form rsk_search
+    loads without featurising.  (Measured r06 on one GPU, 11,211 chains: every shard of 8 paid 0.27 s of load + featurisation +
+    self-rev for ALL chains against 0.24 s for its share of the pairs.)"""
+    import os
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    part = "%s.part%d" % (out_rskdb, rank)
+    ctx.bca_to_rskdb(bca, part, mode, shard_index=rank, shard_count=world, **{k: v for k, v in kw.items() if k in ("selfrev0",)})
+    raw = np.fromfile(part, dtype=np.uint8)
+    os.remove(part)
+    parts = _all_gather_padded(raw, group=group, device=device)
+    with open(out_rskdb, "wb") as f:
+        f.write(merge_rskdb(parts))
+    return sum(len(p) for p in parts)
+
+
 def search_sharded(ctx, query, out_tsv, mode, db=None, group=None, device=None, **kw):
     """One process per GPU: every rank runs its shard of the search, then the hit tables are gathered on rank 0, which
     writes `out_tsv`.  -db mode: a contiguous target range balanced by residues with the queries replicated; self
-    search: a target range of the triangle balanced by DP cells (rsk_search with shard_index = rank, shard_count = world
-    size): no collective on the data path.  -fast -db: the prefilter's per-query top-B is a reduction over all targets,
+    search: a window of the set's length order balanced by DP cells + every world-th long-chain pair (rsk_search with
+    shard_index = rank, shard_count = world size): no collective on the pair path; from a .bca file the ranks first featurise
+    one slice of the chains each and all-gather the prepared containers (featurise_sharded).  -fast -db: the prefilter's per-query top-B is a reduction over all targets,
     so the ranks exchange their prefilter triples once (all_gather) between the prefilter and the alignment stage
     (rsk_fast_shard_*): all of them by default -- every rank then replays the reference's bags over the union and the
     table is the single-GPU one --, or with exchange="topb" only the local top-B lists (own tie rule at the cut).
@@ -111,7 +149,15 @@ def search_sharded(ctx, query, out_tsv, mode, db=None, group=None, device=None, 
         finally:
             sh.close()
     else:
-        nhits, stats = ctx.search(query, part, mode, db=db, shard_index=rank, shard_count=world, **kw)
+        prepared = None
+        if db is None and query.endswith(".bca") and dist.is_initialized() and world > 1:
+            prepared = "%s.rank%d.all.rskdb" % (out_tsv, rank)
+            featurise_sharded(ctx, query, prepared, mode, group=group, device=device, **kw)
+        try:
+            nhits, stats = ctx.search(prepared or query, part, mode, db=db, shard_index=rank, shard_count=world, **kw)
+        finally:
+            if prepared and os.path.exists(prepared):
+                os.remove(prepared)
     with open(part) as f:
         text = f.read()
     os.remove(part)

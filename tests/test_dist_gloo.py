@@ -4,6 +4,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch.multiprocessing as mp
 
 from reseek_amd import dist as rdist
@@ -132,3 +133,16 @@ def test_gather_records_world3_gloo():
     want = np.concatenate([np.random.default_rng(7 + r).integers(0, 1 << 20, (0 if r == 1 else 11 + 50 * r, 3)).astype(np.int32) for r in range(world)])
     for r in range(world):
         assert np.array_equal(res[r], want)
+
+
+def test_merge_rskdb_containers():
+    """the prepared containers of consecutive chain slices (one per rank of a multi-GPU self search from a .bca file) -> one"""
+    import struct
+    from reseek_amd import dist as rdist
+    mk = lambda n, body: b"RSKDB1\0\0" + struct.pack("<II", n, 8) + body
+    assert rdist.merge_rskdb([mk(2, b"ab"), mk(0, b""), mk(3, b"cde")]) == mk(5, b"abcde")
+    assert rdist.merge_rskdb([np.frombuffer(mk(1, b"z"), np.uint8)]) == mk(1, b"z")
+    with pytest.raises(ValueError):
+        rdist.merge_rskdb([b"NOTRSKDB" + b"\0" * 8])
+    with pytest.raises(ValueError):
+        rdist.merge_rskdb([mk(1, b"a"), b"RSKDB1\0\0" + struct.pack("<II", 1, 7) + b"b"])

@@ -410,3 +410,36 @@ def test_malformed_rskdb_containers_are_errors(ctx, tmpdir):
         assert "LoadDB" in str(e.value), (what, str(e.value))
     n, _ = ctx.search_rskdb(src, out, "sensitive")
     assert n > 0
+
+
+def test_bca_to_rskdb_slices_and_prepared_search(ctx, tmpdir):
+    """rsk_bca_to_rskdb (r06): the featurised form of a .bca file -- what LoadDB computes per chain -- as the RSKDB1 container
+    rsk_search reads without featurising.  (a) a search from the prepared container writes the table of the search from the
+    .bca file (the reference's goldens), self search in every mode; (b) the containers of 1, 3 and 8 slices of the chains,
+    concatenated (reseek_amd.dist.merge_rskdb: what the ranks of a multi-GPU run all-gather), are byte-identical to the
+    one-slice container -- slices with long chains (palms: self-rev through the long-chain batch) included."""
+    from reseek_amd import dist as rdist
+    for name, golds in (("q100.bca", {"sensitive": "hits_q100_sensitive.tsv.gz", "fast": "hits_q100_fast.tsv.gz", "verysensitive": "hits_q100_verysensitive.tsv.gz"}),
+                        ("palms.bca", {"sensitive": "hits_palms_sensitive.tsv.gz"})):
+        src = unpack_bca(name, tmpdir)
+        for mode, gold in golds.items():
+            if not os.path.exists(os.path.join(fx.GOLDEN, gold)):
+                continue
+            whole = os.path.join(tmpdir, "whole_%s.rskdb" % mode)
+            n = ctx.bca_to_rskdb(src, whole, mode)
+            assert n > 0
+            out = os.path.join(tmpdir, "prepared.tsv")
+            nh, st = ctx.search(whole, out, mode, columns=COLS)
+            assert sorted(open(out).read().splitlines()) == ["\t".join(r) for r in fx.read_tsv(gold)], (name, mode)
+            for count in (3, 8):
+                parts = []
+                for k in range(count):
+                    part = os.path.join(tmpdir, "part%d.rskdb" % k)
+                    ctx.bca_to_rskdb(src, part, mode, shard_index=k, shard_count=count)
+                    parts.append(open(part, "rb").read())
+                assert rdist.merge_rskdb(parts) == open(whole, "rb").read(), (name, mode, count)
+    from reseek_amd import capi
+    with pytest.raises(capi.RskError):
+        ctx.bca_to_rskdb(os.path.join(tmpdir, "missing.bca"), os.path.join(tmpdir, "x.rskdb"), "sensitive")
+    with pytest.raises(capi.RskError):
+        ctx.bca_to_rskdb(src, os.path.join(tmpdir, "x.rskdb"), "sensitive", shard_index=3, shard_count=3)

@@ -43,17 +43,23 @@ def main():
         bca = os.path.join(td, "q100_rank%d.bca" % rank)
         with gzip.open(os.path.join(golden, "q100.bca.gz"), "rb") as f, open(bca, "wb") as g:
             g.write(f.read())
+        palms = os.path.join(td, "palms_rank%d.bca" % rank)
+        with gzip.open(os.path.join(golden, "palms.bca.gz"), "rb") as f, open(palms, "wb") as g:
+            g.write(f.read())
         ok = True
         # the last leg: bags of 5 overflow for nearly every query, the exchange has to reproduce the reference's cut
-        for mode, db, gold, kw in (("sensitive", None, "hits_q100_sensitive.tsv.gz", {}), ("sensitive", bca, "hits_q100_db_q100_sensitive.tsv.gz", {}),
-                                   ("fast", bca, "hits_q100_db_q100_fast.tsv.gz", {}), ("fast", bca, "hits_q100_db_q100_fast_rsb5.tsv.gz", {"rsb_size": 5})):
+        # (self searches from a .bca file with more than one rank: every rank featurises a slice of the chains, the prepared
+        # containers are all-gathered -- palms: every chain is long, self-rev scores through the long-chain device batch)
+        for q, mode, db, gold, kw in ((bca, "sensitive", None, "hits_q100_sensitive.tsv.gz", {}), (palms, "sensitive", None, "hits_palms_sensitive.tsv.gz", {}),
+                                      (bca, "sensitive", bca, "hits_q100_db_q100_sensitive.tsv.gz", {}),
+                                      (bca, "fast", bca, "hits_q100_db_q100_fast.tsv.gz", {}), (bca, "fast", bca, "hits_q100_db_q100_fast_rsb5.tsv.gz", {"rsb_size": 5})):
             out = os.path.join(td, "hits_rank%d.tsv" % rank)
-            n, st = rdist.search_sharded(ctx, bca, out, mode, db=db, columns=COLS, device=coll_dev, **kw)
+            n, st = rdist.search_sharded(ctx, q, out, mode, db=db, columns=COLS, device=coll_dev, **kw)
             if rank == 0:
                 got = sorted(open(out).read().splitlines())
                 want = sorted(gzip.open(os.path.join(golden, gold)).read().decode().splitlines())
                 ok = ok and got == want
-                print("world %d %s %s: %d hits, %s" % (world, mode, "db" if db else "self", len(got),
+                print("world %d %s %s %s: %d hits, %s" % (world, os.path.basename(q).split("_")[0], mode, "db" if db else "self", len(got),
                                                        "identical to the reference" if got == want else "MISMATCH"))
     if use_dist:
         if not one:
