@@ -421,8 +421,8 @@ def predicted_search_scaling(seqs, worlds=(2, 4, 8), reps=2, bca_worlds=(8,)):
     """`predicted_scaling.search`: what each rank of an N-GPU run of the LIVE self search would take -- the whole
     `rsk_search -sensitive` call with shard_index k / shard_count N (RunSelfShard, host/dbsearcher.cpp; the reference deals the pairs
     to threads through a locked counter, runself.cpp:72-99), every shard run one after the other on THIS GPU from the prepared
-    container (.rskdb: profiles and self-rev scores inside) and, for `bca_worlds`, from the .bca file (featurisation + self-rev of
-    the chains a shard needs inside every call: the part that does not shard).  Last of `reps` runs per shard; efficiency =
+    container (.rskdb: profiles and self-rev scores inside) and, for `bca_worlds`, from the .bca file: a rank featurises ONE slice of
+    the chains, the prepared containers are exchanged (reseek_amd.dist.featurise_sharded), then it searches its shard.  Last of `reps` runs per shard; efficiency =
     t(1) / (N x slowest shard); `hits_sum` must equal the unsharded call's hits."""
     import torch
     import reseek_amd
@@ -446,15 +446,39 @@ def predicted_search_scaling(seqs, worlds=(2, 4, 8), reps=2, bca_worlds=(8,)):
                     dt = time.perf_counter() - t0
                 return dt, int(nh), int(st[0])
 
+            from reseek_amd import dist as rdist
             for tag, src, ws, r in (("rskdb", db, worlds, reps), ("bca", bca, bca_worlds, max(1, reps - 1))):
                 t1, h1, p1 = shard_s(src, 0, 1, reps)
                 e = {"one_gpu_seconds": round(t1, 4), "hits": h1, "chain_pairs": p1}
                 for N in ws:
-                    v = [shard_s(src, k, N, r) for k in range(N)]
-                    secs = [x[0] for x in v]
+                    feat, exch_bytes, t_merge, shard_src = [0.0] * N, 0, 0.0, src
+                    if tag == "bca":
+                        # what reseek_amd.dist.search_sharded does with a .bca file: rank k featurises slice k of the chains
+                        # (rsk_bca_to_rskdb), the containers are all-gathered (not timed here: one GPU; `exchange_bytes` is what every
+                        # rank receives) and merged, then every rank searches its shard of the prepared set
+                        parts = []
+                        for k in range(N):
+                            part = os.path.join(td, "part%d.rskdb" % k)
+                            t0 = time.perf_counter()
+                            ctx.bca_to_rskdb(bca, part, "sensitive", shard_index=k, shard_count=N)
+                            feat[k] = time.perf_counter() - t0
+                            parts.append(np.fromfile(part, dtype=np.uint8))
+                            os.remove(part)
+                        t0 = time.perf_counter()
+                        shard_src = os.path.join(td, "all%d.rskdb" % N)
+                        with open(shard_src, "wb") as f:
+                            f.write(rdist.merge_rskdb(parts))
+                        t_merge = time.perf_counter() - t0
+                        exch_bytes = int(sum(len(x) for x in parts))
+                    v = [shard_s(shard_src, k, N, r) for k in range(N)]
+                    secs = [x[0] + feat[k] + t_merge for k, x in enumerate(v)]
                     e["n%d" % N] = {"shard_seconds": [round(x, 4) for x in secs], "max_over_mean": round(max(secs) * N / sum(secs), 4),
                                     "efficiency": round(t1 / (N * max(secs)), 4), "hits_sum": sum(x[1] for x in v),
                                     "pairs_sum": sum(x[2] for x in v), "pairs_max_over_mean": round(max(x[2] for x in v) * N / max(1, sum(x[2] for x in v)), 4)}
+                    if tag == "bca":
+                        e["n%d" % N].update({"featurise_slice_seconds": [round(x, 4) for x in feat], "merge_seconds": round(t_merge, 4),
+                                             "exchange_bytes": exch_bytes, "search_seconds": [round(x[0], 4) for x in v]})
+                        os.remove(shard_src)
                     assert e["n%d" % N]["hits_sum"] == h1 and e["n%d" % N]["pairs_sum"] == p1, \
                         "%s: the %d shards' hits / pairs do not add up to the unsharded call's: %s" % (tag, N, e)
                 res[tag] = e
@@ -906,6 +930,8 @@ def compact_line(res):
     for N in (2, 4, 8):
         if "n%d" % N in sp:
             out["predicted_search_eff_n%d" % N] = sp["n%d" % N].get("efficiency")
+    if "n8" in (sp.get("bca") or {}):
+        out["predicted_search_bca_eff_n8"] = sp["bca"]["n8"].get("efficiency")
     if res.get("box"):
         out["box"] = res["box"]
     out["detail"] = res.get("detail_file")

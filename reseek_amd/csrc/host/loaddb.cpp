@@ -579,22 +579,19 @@ void DBSearcher::UploadToGpu()
     std::vector<size_t> start((size_t) n + 1, 0);
     for (uint i = 0; i < n; ++i) { len[i] = m_DBChains[i]->GetSeqLength(); start[i + 1] = start[i] + len[i]; }
     const size_t tot = start[n];
-    std::unique_ptr<uint8_t[]> mu(new uint8_t[tot + 1]), prof(new uint8_t[tot * RSK_NFEAT + 1]);      // filled below, not value-initialised
-    std::unique_ptr<float[]> x(new float[tot + 1]), y(new float[tot + 1]), z(new float[tot + 1]);
-    rsk_parallel_for(n, 512, [&](size_t lo, size_t hi) {
-        for (size_t i = lo; i < hi; ++i) {
-            const uint L = len[i];
-            const size_t o = start[i];
-            memcpy(&mu[o], m_DBMuLettersVec[i]->data(), L);
-            for (int f = 0; f < RSK_NFEAT; ++f) memcpy(&prof[o * RSK_NFEAT + (size_t) f * L], (*m_DBProfiles[i])[f].data(), L);
-            memcpy(&x[o], m_DBChains[i]->m_Xs.data(), 4 * (size_t) L);
-            memcpy(&y[o], m_DBChains[i]->m_Ys.data(), 4 * (size_t) L);
-            memcpy(&z[o], m_DBChains[i]->m_Zs.data(), 4 * (size_t) L);
-        }
-    });
-    tm.lap("gather chain arrays");
-    check(rsk_db_create(m_Ctx, n, len.data(), mu.get(), prof.get(), x.get(), y.get(), z.get(), m_DBSelfRevScores.data(), &m_Db),
-          "rsk_db_create");
+    // the chains' vectors go straight into the set's staging buffer (r06; r01-r05 gathered them into flat arrays first: a second
+    // pass over every byte, 60 MB of fresh pages per 11,211 chains and their release)
+    rsk_chain_source from;
+    from.mu = [&](uint32_t i, uint8_t *dst) { memcpy(dst, m_DBMuLettersVec[i]->data(), len[i]); };
+    from.prof = [&](uint32_t i, int f, uint8_t *dst) { memcpy(dst, (*m_DBProfiles[i])[f].data(), len[i]); };
+    from.xyz = [&](uint32_t i, int ax, float *dst) {
+        const PDBChain &C = *m_DBChains[i];
+        memcpy(dst, (ax == 0 ? C.m_Xs : ax == 1 ? C.m_Ys : C.m_Zs).data(), 4 * (size_t) len[i]);
+    };
+    for (uint i = 0; i < n; ++i)
+        if (m_DBMuLettersVec[i]->size() != len[i] || m_DBProfiles[i]->size() != RSK_NFEAT || (*m_DBProfiles[i])[0].size() != len[i])
+            throw std::runtime_error("UploadToGpu: chain " + std::to_string(i) + " has no Mu letters / profile of its length");
+    check(rsk_db_create_from(m_Ctx, n, len.data(), from, m_DBSelfRevScores.data(), &m_Db), "rsk_db_create");
     tm.lap("rsk_db_create");
     // residue characters: the statistics kernel counts the identical columns of an alignment (GetPctId) while it walks the path
     {

@@ -281,13 +281,14 @@ struct rsk_uploader {
     }
 };
 
-extern "C" int rsk_db_create(rsk_ctx *ctx, uint32_t n, const uint32_t *lengths, const uint8_t *mu,
-                             const uint8_t *prof, const float *x, const float *y, const float *z,
-                             const float *selfrev, rsk_db **out)
+// The chains come through three copy functions (one chain's Mu letters / one feature row / one coordinate axis -> dst[L]): the C-ABI
+// entry point copies out of the caller's flat arrays, DBSearcher::UploadToGpu straight out of its per-chain vectors -- either way
+// every byte is written once, into the staging buffer (r01-r05: gathered into flat arrays first, then re-packed).
+int rsk_db_create_from(rsk_ctx *ctx, uint32_t n, const uint32_t *lengths, const rsk_chain_source &from, const float *selfrev, rsk_db **out)
 {
     if (!ctx || !out || (n && !lengths)) { rsk_set_error("rsk_db_create: NULL argument"); return RSK_E_INVALID; }
     *out = nullptr;
-    if ((x || y || z) && !(x && y && z)) { rsk_set_error("rsk_db_create: x,y,z must be given together"); return RSK_E_INVALID; }
+    const bool mu = (bool) from.mu, prof = (bool) from.prof, x = (bool) from.xyz;
     RSK_HIP(hipSetDevice(ctx->device));
     static std::atomic<uint64_t> next_uid{1};
     rsk_db *db = new rsk_db;
@@ -326,29 +327,26 @@ extern "C" int rsk_db_create(rsk_ctx *ctx, uint32_t n, const uint32_t *lengths, 
     if ((rc = up.reserve((void **) &db->d_off, ((size_t) n + 1) * 4, &h)) != RSK_OK) return rc;
     memcpy(h, db->off.data(), ((size_t) n + 1) * 4);
     if ((rc = up.send(db->d_off, h, ((size_t) n + 1) * 4)) != RSK_OK) return rc;
-    // packing into the padded device layout runs on the host threads, chains are independent (src[i] = residues before chain i)
-    std::vector<uint64_t> src((size_t) n + 1, 0);
-    for (uint32_t i = 0; i < n; ++i) src[i + 1] = src[i] + lengths[i];
+    // packing into the padded device layout runs on the host threads, chains are independent
     if (mu) {
         db->h_mu.assign((size_t) o + 64, (uint8_t) RSK_MU_NULL);
         std::atomic<uint32_t> bad{UINT32_MAX};
         rsk_parallel_for(n, 512, [&](size_t lo, size_t hi) {
             for (size_t i = lo; i < hi; ++i) {
-                const uint8_t *row = mu + src[i];
+                uint8_t *row = &db->h_mu[db->off[i]];
+                from.mu((uint32_t) i, row);
                 uint8_t mx = 0;
                 for (uint32_t k = 0; k < lengths[i]; ++k) mx = row[k] > mx ? row[k] : mx;
                 if (mx >= RSK_MU_ALPHA) {
                     uint32_t cur = bad.load();
                     while ((uint32_t) i < cur && !bad.compare_exchange_weak(cur, (uint32_t) i)) {}
-                    continue;
                 }
-                memcpy(&db->h_mu[db->off[i]], row, lengths[i]);
             }
         });
         if (bad.load() != UINT32_MAX) {
             const uint32_t i = bad.load();
             uint8_t c = 0;
-            for (uint32_t k = 0; k < lengths[i] && c < RSK_MU_ALPHA; ++k) c = mu[src[i] + k];
+            for (uint32_t k = 0; k < lengths[i] && c < RSK_MU_ALPHA; ++k) c = db->h_mu[db->off[i] + k];
             rsk_set_error("rsk_db_create: Mu letter %u out of range in chain %u", c, i);
             return RSK_E_INVALID;
         }
@@ -364,23 +362,22 @@ extern "C" int rsk_db_create(rsk_ctx *ctx, uint32_t n, const uint32_t *lengths, 
         rsk_parallel_for(n, 512, [&](size_t lo, size_t hi) {
             for (size_t i = lo; i < hi; ++i)
                 for (int f = 0; f < RSK_NFEAT; ++f) {
-                    const uint8_t *row = prof + (uint64_t) RSK_NFEAT * src[i] + (size_t) f * lengths[i];
+                    uint8_t *row = &hp[(size_t) f * o + db->off[i]];
+                    from.prof((uint32_t) i, f, row);
                     uint8_t mx = 0;
                     for (uint32_t k = 0; k < lengths[i]; ++k) mx = row[k] > mx ? row[k] : mx;
                     if (mx >= (f == 0 ? 20 : 16)) {
                         const uint64_t key = ((uint64_t) i << 8) | (uint64_t) f;
                         uint64_t cur = bad.load();
                         while (key < cur && !bad.compare_exchange_weak(cur, key)) {}
-                        continue;
                     }
-                    memcpy(&hp[(size_t) f * o + db->off[i]], row, lengths[i]);
-                    memset(&hp[(size_t) f * o + db->off[i] + lengths[i]], 0, db->off[i + 1] - db->off[i] - lengths[i]);
+                    memset(row + lengths[i], 0, db->off[i + 1] - db->off[i] - lengths[i]);
                 }
         });
         if (bad.load() != UINT64_MAX) {
             const uint32_t i = (uint32_t) (bad.load() >> 8);
             const int f = (int) (bad.load() & 255);
-            const uint8_t *row = prof + (uint64_t) RSK_NFEAT * src[i] + (size_t) f * lengths[i];
+            const uint8_t *row = &hp[(size_t) f * o + db->off[i]];
             uint8_t mx = 0;
             for (uint32_t k = 0; k < lengths[i]; ++k) mx = row[k] > mx ? row[k] : mx;
             rsk_set_error("rsk_db_create: profile letter %u out of range (chain %u feature %d)", mx, i, f);
@@ -400,15 +397,13 @@ extern "C" int rsk_db_create(rsk_ctx *ctx, uint32_t n, const uint32_t *lengths, 
         RSK_HIP(hipGetLastError());
     }
     if (x) {
-        const float *srcs[3] = { x, y, z };
         float **dsts[3] = { &db->d_x, &db->d_y, &db->d_z };
         for (int ax = 0; ax < 3; ++ax) {
             if ((rc = up.reserve((void **) dsts[ax], (size_t) o * 4, &h)) != RSK_OK) return rc;
             float *const hx = (float *) h;
-            const float *const sx = srcs[ax];
             rsk_parallel_for(n, 512, [&](size_t lo, size_t hi) {
                 for (size_t i = lo; i < hi; ++i) {
-                    memcpy(&hx[db->off[i]], sx + src[i], 4 * (size_t) lengths[i]);
+                    from.xyz((uint32_t) i, ax, &hx[db->off[i]]);
                     for (uint32_t k = db->off[i] + lengths[i]; k < db->off[i + 1]; ++k) hx[k] = 0.f;
                 }
             });
@@ -425,6 +420,23 @@ extern "C" int rsk_db_create(rsk_ctx *ctx, uint32_t n, const uint32_t *lengths, 
     RSK_HIP(hipStreamSynchronize(ctx->stream));             // the staging buffer belongs to the next call from here on
     *out = owner.release();
     return RSK_OK;
+}
+
+
+extern "C" int rsk_db_create(rsk_ctx *ctx, uint32_t n, const uint32_t *lengths, const uint8_t *mu,
+                             const uint8_t *prof, const float *x, const float *y, const float *z,
+                             const float *selfrev, rsk_db **out)
+{
+    if (!ctx || !out || (n && !lengths)) { rsk_set_error("rsk_db_create: NULL argument"); return RSK_E_INVALID; }
+    *out = nullptr;
+    if ((x || y || z) && !(x && y && z)) { rsk_set_error("rsk_db_create: x,y,z must be given together"); return RSK_E_INVALID; }
+    std::vector<uint64_t> src((size_t) n + 1, 0);                     // residues before chain i in the caller's flat arrays
+    for (uint32_t i = 0; i < n; ++i) src[i + 1] = src[i] + lengths[i];
+    rsk_chain_source from;
+    if (mu) from.mu = [&](uint32_t i, uint8_t *dst) { memcpy(dst, mu + src[i], lengths[i]); };
+    if (prof) from.prof = [&](uint32_t i, int f, uint8_t *dst) { memcpy(dst, prof + (uint64_t) RSK_NFEAT * src[i] + (size_t) f * lengths[i], lengths[i]); };
+    if (x) from.xyz = [&](uint32_t i, int ax, float *dst) { memcpy(dst, (ax == 0 ? x : ax == 1 ? y : z) + src[i], 4 * (size_t) lengths[i]); };
+    return rsk_db_create_from(ctx, n, lengths, from, selfrev, out);
 }
 
 // The self-rev scores of a chain set that was uploaded before they were known (DBSearcher::ComputeSelfRevScores aligns

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <atomic>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <string>
@@ -124,6 +125,15 @@ struct rsk_host_counters {
 };
 extern rsk_host_counters g_rsk_counters;
 unsigned long long *rsk_swqp_clock_words(int device);      // device pointer to {cycles, ticks}; nullptr if the allocation failed
+
+// rsk_db_create's internal form: the chains arrive through copy functions (chain i's Mu letters / feature row f / coordinate axis
+// -> dst[length of chain i]); a null function = the set has no such array.  Called from several host threads at once.
+struct rsk_chain_source {
+    std::function<void(uint32_t, uint8_t *)> mu;
+    std::function<void(uint32_t, int, uint8_t *)> prof;
+    std::function<void(uint32_t, int, float *)> xyz;
+};
+int rsk_db_create_from(rsk_ctx *ctx, uint32_t n, const uint32_t *lengths, const rsk_chain_source &from, const float *selfrev, struct rsk_db **out);
 
 // One "ring" of the gapless kernel: several query chains laid out on a circular array of
 // 128*D diagonal slots (see k_mu_gapless.hip).
