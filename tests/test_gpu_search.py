@@ -227,8 +227,8 @@ def test_sharded_search_equals_unsharded(ctx, tmpdir):
     # the tail set (short chains + a few long ones: both kinds of pairs in every window), -noself, and the r01-r05 cut (target
     # ranges of the chain order: still the route without a Mu filter and beyond one filter pass) through RSK_SELF_SHARD_RANGES
     t = unpack_bca("taildb.bca", tmpdir)
-    for src in [x for x in (t, q) if x]:
-        for kw in ({}, {"noself": 1}):
+    for src, kws in ((t, ({}, {"noself": 1})), (q, ({"noself": 1},))):
+        for kw in kws:
             one = os.path.join(tmpdir, "one.tsv")
             n1, st1 = ctx.search(src, one, "sensitive", columns=COLS, **kw)
             want = sorted(open(one).read().splitlines())

@@ -2,7 +2,7 @@
 # the round's profile set on the GPU box: bench command (trace + PMC + traffic), live kernels (trace + PMC), kernel traces
 # of the self search and of the three config-shaped searches -> gpurun_out/prof_<tag>/
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-T=${1:-r05}
+T=${1:-r06}
 bash tools/prof_bench.sh ${T}_bench > gpurun_out/${T}_prof_bench.log 2>&1
 bash tools/prof_live.sh ${T}_live > gpurun_out/${T}_prof_live.log 2>&1
 bash tools/prof_search.sh ${T}_search_self 0 sensitive > /dev/null 2>&1
