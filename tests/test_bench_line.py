@@ -12,7 +12,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
-FULL_RECORDS = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[3-9]*_bench*.json")))
+# the full (detail) records of the rounds; profiles/rNN_bench_line*.json are compact lines themselves
+FULL_RECORDS = sorted(p for p in glob.glob(os.path.join(ROOT, "profiles", "r0[3-9]*_bench*.json")) if "_line" not in os.path.basename(p))
+LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[6-9]*_bench_line*.json")))
 
 
 def _strict(line):
@@ -81,3 +83,19 @@ def test_detail_goes_to_earlier_lines_and_a_side_file(tmp_path, capsys):
         assert json.load(f)["value"] == full["value"]
     assert res["detail_file"] == p
     assert json.loads(bench.compact_line(res))["detail"] == p
+
+
+@pytest.mark.parametrize("path", LINES, ids=[os.path.basename(p) for p in LINES])
+def test_committed_lines_are_what_the_driver_can_parse(path):
+    """the last stdout line of the round's final bench runs, as committed: one strict-JSON line below 4 KB with the contract's keys"""
+    raw = open(path).read()
+    assert raw.count("\n") <= 1 and len(raw.encode()) < 4096
+    d = _strict(raw)
+    for k in bench.REQUIRED_KEYS:
+        assert k in d, k
+    assert d["dtype"] == "int16-exact" and d["n_gpus"] == (d["config"]["collective_world"] or 1)
+    if d["n_gpus"] == 1:
+        assert d["cpu_baseline"]["kind"] == "reference" and d["roofline"]["traffic"] is not None
+    else:
+        gc = d["config"]["hit_records"]["gather_check"]
+        assert gc["gathered_all_ranks"] == gc["one_gpu_hit_records"] == gc["sum_of_rank_counts"]
