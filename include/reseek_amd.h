@@ -428,7 +428,7 @@ typedef struct rsk_search_opts {
     uint32_t shard_index;      /* multi-GPU (one process per GPU): this process handles shard shard_index of       */
     uint32_t shard_count;      /* shard_count: -db mode = a contiguous range of DB chains balanced by residues;     */
                                /* self search = the pairs whose longer chain stands in a window of the set's length  */
-                               /* order, windows of equal DP cells, + every shard_count-th long-chain pair (no Mu    */
+                               /* order, windows of equal DP cells, + one shard_count-th of the long-chain pair list (no */
                                /* filter: the pairs (i <= j) whose j lies in a range balanced by DP cells).         */
                                /* The union of the shards' hit tables is the unsharded table.  0 or 1 = no shards. */
     const char *devices;       /* multi-GPU (ONE process): "0,1,2,3" = the call drives these devices, one context + host thread */

@@ -197,8 +197,8 @@ void DBSearcher::SelfWindowRange(const uint32_t *Lens, uint64_t N, uint Index, u
 }
 
 // shard `Index` of `Count` of the self search (the reference: one locked pair counter for all threads, runself.cpp:72-99).
-// With a Mu filter and a set whose dense pair matrix fits one filter pass: a window of the set's length order + every Count-th
-// long-chain pair (RunPairs, SelfWindow) -- the whole set stays resident, one pass.  Otherwise (no filter: -verysensitive, every
+// With a Mu filter and a set whose dense pair matrix fits one filter pass: a window of the set's length order + one Count-th
+// of the long-chain pair list (RunPairs, SelfWindow) -- the whole set stays resident, one pass.  Otherwise (no filter: -verysensitive, every
 // pair costs its cells; or > ~65 k chains): targets [Lo, Hi) of the chain order with equal cells, as the rectangle
 // chains[0, Lo) x chains[Lo, Hi) plus the triangle of chains[Lo, Hi).
 void DBSearcher::RunSelfShard(uint Index, uint Count)

@@ -144,7 +144,7 @@ struct DeviceTeam {
 // of the set, A = its chains [0, NA) with NA = SelfOffset (the rectangle above the shard's triangle) or up to
 // SelfOffset + NB; the pairs i <= SelfOffset + j are scored.
 // One shard of a self search as a WINDOW of the set's length order (r06): the pairs whose longer member stands at positions
-// [RankLo, RankHi), plus every ShardCount-th pair of the long-chain (MKF) list starting at ShardIndex.
+// [RankLo, RankHi), plus piece ShardIndex of ShardCount equal contiguous pieces of the long-chain (MKF) pair list.
 struct SelfWindow { uint32_t RankLo = 0, RankHi = 0, ShardIndex = 0, ShardCount = 1; };
 void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOffset = -1, const SelfWindow *Win = nullptr);
 

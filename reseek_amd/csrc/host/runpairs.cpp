@@ -441,7 +441,7 @@ void RunMKFPairs(rsk_ctx *Ctx, const DSSParams &P, const std::string &Columns, D
 // deals the pairs of RunSelf to its threads one at a time through a locked counter (runself.cpp:72-99): any thread takes any
 // pair.  Here a rank takes (a) the pairs whose longer member stands in its window of the length order -- the order the
 // triangle mode of the Mu filter walks its targets in, so the shard's filter pass is ONE launch of the whole triangle's shape
-// against fewer targets, windows of equal DP cells -- and (b) every ShardCount-th pair of the long-chain list, whose pairs all
+// against fewer targets, windows of equal DP cells -- and (b) one contiguous ShardCount-th of the long-chain list, whose pairs all
 // hold one of the few longest chains and would otherwise all fall to the last window.  (r01-r05: a target range of the chain
 // ORDER, as a rectangle + a small triangle, two passes each with its own filter, survivor lists and long-chain job: measured
 // r06 on the 11,211-chain set, N = 8: slowest shard 2.7 x the fastest, efficiency 0.33.)
@@ -525,12 +525,34 @@ void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOffset, co
         // (the list -- 0.67 M pairs, ~5 ms of one host thread on the SCOP40-sized self search -- is not needed before the filter
         // has run: it is built on a thread of its own under the filter kernels, r05)
         uint64_t mkf_in_window = 0;              // window mode: long-chain pairs whose longer member stands in the window (they pass through the filter launch unused)
-        uint64_t mkf_ord = 0;                    // ... and the running position in the whole list, dealt round-robin to the shards
+        // ... and the whole list, of which the shard takes one contiguous Count-th (the list is ordered by its first chain: a
+        // contiguous piece names an N-th of the chains as seeding queries, and the k-mer tables of the job -- one per query chain
+        // of the batch, 85 MB / 7-9 ms of kernels for all 11,211 chains -- shrink with it; dealt round-robin every shard built
+        // every table)
+        std::vector<std::pair<uint32_t, uint32_t> > mkf_all;
         auto take_mkf = [&](uint i, uint j) {
             if (!Win) { mkf.emplace_back(i, j); ++nmkf; return; }
             const uint32_t rmax = std::max((*Rank)[i], (*Rank)[j]);
             if (rmax >= Win->RankLo && rmax < Win->RankHi) ++mkf_in_window;
-            if (mkf_ord++ % Win->ShardCount == Win->ShardIndex) { mkf.emplace_back(i, j); ++nmkf; }
+            mkf_all.emplace_back(i, j);
+        };
+        auto deal_mkf = [&]() {
+            if (!Win) return;
+            // pairs whose FIRST chain is short (its partner is the long one): a contiguous piece; pairs of two long chains -- a few
+            // per cent of the list, but the ones whose seeds extend and chain -- every Count-th (as one contiguous piece they all fell
+            // to the last shard: 93 ms against 58-65 for the others at N = 8)
+            std::vector<std::pair<uint32_t, uint32_t> > both_long;
+            size_t w = 0;
+            for (size_t k = 0; k < mkf_all.size(); ++k) {
+                if (SrcA.m_DBChains[mkf_all[k].first]->GetSeqLength() >= P.m_MKFL) both_long.push_back(mkf_all[k]);
+                else mkf_all[w++] = mkf_all[k];
+            }
+            mkf_all.resize(w);
+            const uint64_t T = mkf_all.size(), lo = T * Win->ShardIndex / Win->ShardCount, hi = T * (Win->ShardIndex + 1) / Win->ShardCount;
+            mkf.assign(mkf_all.begin() + (ptrdiff_t) lo, mkf_all.begin() + (ptrdiff_t) hi);
+            for (size_t k = Win->ShardIndex; k < both_long.size(); k += Win->ShardCount) mkf.push_back(both_long[k]);
+            nmkf = mkf.size();
+            std::vector<std::pair<uint32_t, uint32_t> >().swap(mkf_all);
         };
         auto build_mkf_list = [&]() {
             std::vector<uint32_t> longB;
@@ -551,6 +573,7 @@ void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOffset, co
                     }
                 }
             }
+            deal_mkf();
         };
         // (r06, window shards, N = 8 on the 11,211-chain set: with the job under the filter a shard took 82.9 ms against 80.0 ms behind it
         // -- the seeding kernels take 22 ms instead of 7 beside the filter's and the filter is no shorter: the default stays)

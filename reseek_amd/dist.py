@@ -127,7 +127,7 @@ def featurise_sharded(ctx, bca, out_rskdb, mode, group=None, device=None, **kw):
 def search_sharded(ctx, query, out_tsv, mode, db=None, group=None, device=None, **kw):
     """One process per GPU: every rank runs its shard of the search, then the hit tables are gathered on rank 0, which
     writes `out_tsv`.  -db mode: a contiguous target range balanced by residues with the queries replicated; self
-    search: a window of the set's length order balanced by DP cells + every world-th long-chain pair (rsk_search with
+    search: a window of the set's length order balanced by DP cells + one world-th of the long-chain pair list (rsk_search with
     shard_index = rank, shard_count = world size): no collective on the pair path; from a .bca file the ranks first featurise
     one slice of the chains each and all-gather the prepared containers (featurise_sharded).  -fast -db: the prefilter's per-query top-B is a reduction over all targets,
     so the ranks exchange their prefilter triples once (all_gather) between the prefilter and the alignment stage

@@ -195,7 +195,7 @@ def test_bca_fast_db_with_dbmu_and_options(ctx, tmpdir):
 
 def test_sharded_search_equals_unsharded(ctx, tmpdir):
     """the union of the shards' hit tables is the unsharded table (self search: windows of the set's length order +
-    the long-chain list dealt round-robin, r06; -db mode: DB chains cut by residues).  The shards run one after another on this
+    the long-chain list in contiguous pieces, r06; -db mode: DB chains cut by residues).  The shards run one after another on this
     single GPU."""
     q = unpack_bca("q100.bca", tmpdir)
     for db, golden in ((None, "hits_q100_sensitive.tsv.gz"), (q, "hits_q100_db_q100_sensitive.tsv.gz")):
@@ -211,7 +211,7 @@ def test_sharded_search_equals_unsharded(ctx, tmpdir):
             want = ["\t".join(r) for r in fx.read_tsv(golden)]
             assert sorted(lines) == want
             assert pairs == (10000 if db else 5050)
-    # palms: shards with MKF pairs (every chain is long: the long-chain list IS the pair space, dealt round-robin), N = 4 and 8;
+    # palms: shards with MKF pairs (every chain is long: the long-chain list IS the pair space, cut into contiguous pieces), N = 4 and 8;
     # the counters of the shards add up to the unsharded call's
     p = unpack_bca("palms.bca", tmpdir)
     n1, st1 = ctx.search(p, os.path.join(tmpdir, "palms_one.tsv"), "sensitive", columns=COLS)
