@@ -96,20 +96,28 @@ struct SecondaryCtx {
     }
 };
 
+// Page-locked path buffers of the alignment batches (~120 MB each for 350 k pairs): ONE pool per process, kept between calls --
+// hipHostMalloc / hipHostFree cost ~0.1 ms per MB, and r01-r05 built and tore down a pool (four buffers) per pass over a
+// streamed database batch: ~60 ms of every 1.6-s pass of a -verysensitive search (r06 trace of configs[4]).  At most
+// PINNED_IDLE_MAX buffers stay parked; rsk_ctx_trim / rsk_shutdown release them (no HIP call from a static destructor).
 struct PinnedPool {
+    enum { PINNED_IDLE_MAX = 6 };
     std::mutex lock;
     std::vector<std::pair<char *, size_t> > idle;
     char *Get(size_t bytes, size_t &cap)
     {
         {
             std::lock_guard<std::mutex> g(lock);
+            // the smallest parked buffer that fits
+            size_t best = idle.size();
             for (size_t k = 0; k < idle.size(); ++k)
-                if (idle[k].second >= bytes) {
-                    char *p = idle[k].first;
-                    cap = idle[k].second;
-                    idle.erase(idle.begin() + k);
-                    return p;
-                }
+                if (idle[k].second >= bytes && (best == idle.size() || idle[k].second < idle[best].second)) best = k;
+            if (best < idle.size()) {
+                char *p = idle[best].first;
+                cap = idle[best].second;
+                idle.erase(idle.begin() + (ptrdiff_t) best);
+                return p;
+            }
             if (!idle.empty()) { (void) hipHostFree(idle.back().first); idle.pop_back(); }      // too small: replace it
         }
         void *p = nullptr;
@@ -120,9 +128,16 @@ struct PinnedPool {
     void Put(char *p, size_t cap)
     {
         std::lock_guard<std::mutex> g(lock);
+        if (idle.size() >= PINNED_IDLE_MAX) { (void) hipHostFree(p); return; }
         idle.emplace_back(p, cap);
     }
-    ~PinnedPool() { for (auto &b : idle) (void) hipHostFree(b.first); }
+    void Trim()
+    {
+        std::lock_guard<std::mutex> g(lock);
+        for (auto &b : idle) (void) hipHostFree(b.first);
+        idle.clear();
+    }
+    static PinnedPool &Shared() { static PinnedPool *p = new PinnedPool; return *p; }      // never destroyed: see above
 };
 
 // One context per entry of the device list, on streams of their own; parked between calls like every helper context.

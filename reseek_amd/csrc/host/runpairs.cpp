@@ -145,10 +145,27 @@ std::vector<std::pair<size_t, size_t> > AlignBatches(const SearchOptions &O, con
     std::vector<uint32_t> la(A.m_DBChains.size()), lb(B.m_DBChains.size());
     for (size_t i = 0; i < la.size(); ++i) la[i] = A.m_DBChains[i]->GetSeqLength();
     for (size_t j = 0; j < lb.size(); ++j) lb[j] = B.m_DBChains[j]->GetSeqLength();
-    for (size_t k = 0; k < ia.size(); ++k) {
-        const uint64_t c = (uint64_t) la[ia[k]] * lb[ib[k]];
-        if (k > b && (k - b >= maxp || cells + c > maxc)) { out.emplace_back(b, k); b = k; cells = 0; }
-        cells += c;
+    // The greedy cut below is sequential (a batch closes when the next pair would take it over either limit), and a streamed
+    // -verysensitive pass hands it 33 M pairs: the cells of chunks of 65,536 pairs are summed on the host threads first, and the
+    // sequential walk only enters the chunks a cut falls into (a chunk that fits whole is added whole: no pair of it can trigger
+    // either test) -- the same cuts, a fifth of the serial work.
+    const size_t n = ia.size(), CH = 65536, nch = (n + CH - 1) / CH;
+    std::vector<uint64_t> chsum(nch, 0);
+    rsk_parallel_for(nch, 4, [&](size_t lo, size_t hi) {
+        for (size_t ch = lo; ch < hi; ++ch) {
+            uint64_t sum = 0;
+            for (size_t k = ch * CH, e = std::min(n, k + CH); k < e; ++k) sum += (uint64_t) la[ia[k]] * lb[ib[k]];
+            chsum[ch] = sum;
+        }
+    });
+    for (size_t ch = 0; ch < nch; ++ch) {
+        const size_t k0 = ch * CH, k1 = std::min(n, k0 + CH);
+        if (k1 - 1 - b < maxp && cells + chsum[ch] <= maxc && (k0 > b || k0 == 0)) { cells += chsum[ch]; continue; }
+        for (size_t k = k0; k < k1; ++k) {
+            const uint64_t c = (uint64_t) la[ia[k]] * lb[ib[k]];
+            if (k > b && (k - b >= maxp || cells + c > maxc)) { out.emplace_back(b, k); b = k; cells = 0; }
+            cells += c;
+        }
     }
     if (b < ia.size()) out.emplace_back(b, ia.size());
     return out;
@@ -162,7 +179,7 @@ void ForEachAlignedBatch(const DSSParams &P, rsk_ctx *ctx, const SearchOptions &
                                                   const char *)> &OnBatch)
 {
     const auto batches = AlignBatches(O, SrcA, SrcB, ia, ib);
-    PinnedPool Pool;                                                     // outlives every batch of the loop below
+    PinnedPool &Pool = PinnedPool::Shared();                             // the process's pool: outlives every batch, and the call
     // Several GPU stages in flight while batch k is replayed, each on a context of its own (device pool, staging buffers,
     // stream): the host part of rsk_align_pairs (grouping the pairs, work items, statistics) is a quarter of a stage, with a
     // single stage in flight the GPU idles through it.  The chain sets are read-only here.

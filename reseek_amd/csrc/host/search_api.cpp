@@ -16,6 +16,7 @@ extern "C" void rsk_ctx_trim(rsk_ctx *ctx)
 {
     if (!ctx) return;
     reseek_amd::SecondaryCtx::Trim(ctx->device);
+    reseek_amd::PinnedPool::Shared().Trim();
     rsk_pool_release(ctx);
 }
 
@@ -382,5 +383,5 @@ extern "C" int rsk_path_counters_reset(rsk_ctx *ctx)
     return RSK_OK;
 }
 
-extern "C" void rsk_shutdown(void) { reseek_amd::SecondaryCtx::Trim(-1); }
+extern "C" void rsk_shutdown(void) { reseek_amd::SecondaryCtx::Trim(-1); reseek_amd::PinnedPool::Shared().Trim(); }
 
