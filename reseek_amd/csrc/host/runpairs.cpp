@@ -173,12 +173,65 @@ std::vector<std::pair<size_t, size_t> > AlignBatches(const SearchOptions &O, con
 
 // rsk_align_pairs over the batches of a pair list with the GPU stage of batch k + 1 running while `OnBatch` consumes
 // batch k on the calling thread (RunPairs: hit replay; PostMuFilter: Accept + hit lines).
+typedef std::function<void(const std::vector<uint32_t> &, const std::vector<uint32_t> &, const std::vector<rsk_aln> &, const char *)> OnBatchFn;
+typedef std::function<void(size_t, size_t, std::vector<uint32_t> &, std::vector<uint32_t> &)> FillPairsFn;      // pairs [b, e) of the list -> ia, ib
+static void ForEachBatchOf(const DSSParams &P, rsk_ctx *ctx, DBSearcher &SrcA, DBSearcher &SrcB, const std::vector<std::pair<size_t, size_t> > &batches,
+                           const FillPairsFn &fill, const OnBatchFn &OnBatch);
+
 void ForEachAlignedBatch(const DSSParams &P, rsk_ctx *ctx, const SearchOptions &O, DBSearcher &SrcA, DBSearcher &SrcB,
-                         const std::vector<uint32_t> &ia, const std::vector<uint32_t> &ib,
-                         const std::function<void(const std::vector<uint32_t> &, const std::vector<uint32_t> &, const std::vector<rsk_aln> &,
-                                                  const char *)> &OnBatch)
+                         const std::vector<uint32_t> &ia, const std::vector<uint32_t> &ib, const OnBatchFn &OnBatch)
 {
-    const auto batches = AlignBatches(O, SrcA, SrcB, ia, ib);
+    ForEachBatchOf(P, ctx, SrcA, SrcB, AlignBatches(O, SrcA, SrcB, ia, ib),
+                   [&](size_t b, size_t e, std::vector<uint32_t> &ba, std::vector<uint32_t> &bb) {
+                       ba.assign(ia.begin() + (ptrdiff_t) b, ia.begin() + (ptrdiff_t) e);
+                       bb.assign(ib.begin() + (ptrdiff_t) b, ib.begin() + (ptrdiff_t) e);
+                   },
+                   OnBatch);
+}
+
+// Every pair of a rectangle SrcA x SrcB in row-major order -- what a -verysensitive search (no Mu filter) aligns of a streamed
+// database batch: 33 M pairs per 32,768 chains against 1,000 queries -- WITHOUT the pair list: the cells of the first k pairs are
+// F(k) = (sum of B's lengths) x (lengths of A's rows before i) + la[i] x (B's lengths before j), i = k / NB, j = k % NB, so the
+// batch cuts of AlignBatches (close a batch when the next pair would take it over the pair or the cell limit) are binary
+// searches over F, and a stage writes its own slice of (i, j) when it starts.  (r01-r05 filled two 131-MB index arrays per
+// database batch, walked them for the cuts and released them: ~90 ms of every 1.6-s pass with the GPU idle.)
+void ForEachAlignedBatchDense(const DSSParams &P, rsk_ctx *ctx, const SearchOptions &O, DBSearcher &SrcA, DBSearcher &SrcB, const OnBatchFn &OnBatch)
+{
+    const size_t NA = SrcA.m_DBChains.size(), NB = SrcB.m_DBChains.size(), n = NA * NB;
+    const size_t maxp = std::max<size_t>(1, getenv("RSK_BATCH_PAIRS") ? (size_t) atoll(getenv("RSK_BATCH_PAIRS")) : O.batch_pairs);
+    const uint64_t maxc = getenv("RSK_BATCH_CELLS") ? std::max<uint64_t>(1, (uint64_t) atoll(getenv("RSK_BATCH_CELLS"))) : O.batch_cells;
+    std::vector<uint64_t> pla(NA + 1, 0), clb(NB + 1, 0);
+    std::vector<uint32_t> la(NA + 1, 0);
+    for (size_t i = 0; i < NA; ++i) { la[i] = SrcA.m_DBChains[i]->GetSeqLength(); pla[i + 1] = pla[i] + la[i]; }
+    for (size_t j = 0; j < NB; ++j) clb[j + 1] = clb[j] + SrcB.m_DBChains[j]->GetSeqLength();
+    const uint64_t SB = clb[NB];
+    auto F = [&](size_t k) -> uint64_t { const size_t i = NB ? k / NB : 0, j = NB ? k % NB : 0; return SB * pla[i] + (uint64_t) la[i] * clb[j]; };
+    std::vector<std::pair<size_t, size_t> > batches;
+    for (size_t b = 0; b < n;) {
+        size_t lo = b + 1, hi = std::min(n, b + maxp);                 // the batch ends at the largest e in [lo, hi] with F(e) - F(b) <= maxc (at least one pair)
+        const uint64_t Fb = F(b);
+        while (lo < hi) {
+            const size_t mid = lo + (hi - lo + 1) / 2;
+            if (F(mid) - Fb <= maxc) lo = mid; else hi = mid - 1;
+        }
+        batches.emplace_back(b, lo);
+        b = lo;
+    }
+    ForEachBatchOf(P, ctx, SrcA, SrcB, batches,
+                   [NB](size_t b, size_t e, std::vector<uint32_t> &ba, std::vector<uint32_t> &bb) {
+                       ba.resize(e - b); bb.resize(e - b);
+                       size_t i = b / NB, j = b % NB;
+                       for (size_t k = b; k < e; ++k) {
+                           ba[k - b] = (uint32_t) i; bb[k - b] = (uint32_t) j;
+                           if (++j == NB) { j = 0; ++i; }
+                       }
+                   },
+                   OnBatch);
+}
+
+static void ForEachBatchOf(const DSSParams &P, rsk_ctx *ctx, DBSearcher &SrcA, DBSearcher &SrcB, const std::vector<std::pair<size_t, size_t> > &batches,
+                           const FillPairsFn &fill, const OnBatchFn &OnBatch)
+{
     PinnedPool &Pool = PinnedPool::Shared();                             // the process's pool: outlives every batch, and the call
     // Several GPU stages in flight while batch k is replayed, each on a context of its own (device pool, staging buffers,
     // stream): the host part of rsk_align_pairs (grouping the pairs, work items, statistics) is a quarter of a stage, with a
@@ -195,8 +248,9 @@ void ForEachAlignedBatch(const DSSParams &P, rsk_ctx *ctx, const SearchOptions &
         const auto be = batches[k];
         rsk_ctx *c = ring[k % nctx];
         return std::async(std::launch::async, [&, be, c]() {
-            return AlignBatch(P, c, Pool, SrcA, SrcB, std::vector<uint32_t>(ia.begin() + be.first, ia.begin() + be.second),
-                              std::vector<uint32_t>(ib.begin() + be.first, ib.begin() + be.second));
+            std::vector<uint32_t> ba, bb;
+            fill(be.first, be.second, ba, bb);
+            return AlignBatch(P, c, Pool, SrcA, SrcB, std::move(ba), std::move(bb));
         });
     };
     std::deque<std::future<std::unique_ptr<AlignedBatch> > > q;
@@ -494,6 +548,7 @@ void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOffset, co
     std::vector<uint32_t> ia, ib;                // pairs for the full alignment
     std::vector<std::pair<uint32_t, uint32_t> > mkf;
     uint64_t npairs = 0;
+    bool Dense = false;                          // no Mu filter, no skipped pairs, not a self search: every pair of SrcA x S in row-major order
     // long-chain pairs: MKF path (dssaligner.cpp:809-813), one aligner per host thread as in the reference
     // (dbsearcher.cpp:98-106); BaseOnAln serialises the output under m_Lock.
     auto each_orientation = [&](DSSAligner &DA, uint i, uint j, auto &&fn) {
@@ -687,6 +742,10 @@ void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOffset, co
         S.m_MKFPairCount = nmkf;
         S.m_MuFilterInputCount = npairs - nmkf;
         S.m_MuFilterDiscardCount = S.m_MuFilterInputCount - ia.size();
+    } else if (!Self && !S.m_Opts.noself && !(getenv("RSK_DENSE_PAIR_LISTS") && atoi(getenv("RSK_DENSE_PAIR_LISTS")) == 1)) {
+        // the whole rectangle, row-major: no pair list (ForEachAlignedBatchDense)
+        Dense = true;
+        npairs = (uint64_t) NA * NB;
     } else {
         // every pair of the enumerated space (tens of millions for a query batch against a DB batch): row starts by a
         // prefix sum, rows filled on the host threads
@@ -718,10 +777,11 @@ void RunPairs(DBSearcher &S, DBSearcher &SrcA, bool Self, int64_t SelfOffset, co
     S.m_AlnCount = npairs - mkf.size();
     tm.lap("filter + pair lists");
     auto align = [&]() {
-        ForEachAlignedBatch(P, ctx, S.m_Opts, SrcA, S, ia, ib,
-                            [&](const std::vector<uint32_t> &bia, const std::vector<uint32_t> &bib, const std::vector<rsk_aln> &out, const char *paths) {
-                                ReplayBatch(S, SrcA, S, bia, bib, out, paths, Self, joff);
-                            });
+        const OnBatchFn on_batch = [&](const std::vector<uint32_t> &bia, const std::vector<uint32_t> &bib, const std::vector<rsk_aln> &out, const char *paths) {
+            ReplayBatch(S, SrcA, S, bia, bib, out, paths, Self, joff);
+        };
+        if (Dense) ForEachAlignedBatchDense(P, ctx, S.m_Opts, SrcA, S, on_batch);
+        else ForEachAlignedBatch(P, ctx, S.m_Opts, SrcA, S, ia, ib, on_batch);
     };
     if (!job.valid()) start_mkf_job();             // the default: beside the alignment job
     if (job.valid()) {

@@ -66,6 +66,29 @@ def test_config4_shape_verysensitive_db_real_chains(ctx, work):
     assert st[0] == 3200 and st[5] == 3200 and st[4] == 0       # every pair through SW + traceback, no filter, no MKF
 
 
+def test_dense_rectangle_batches_equal_the_pair_list_route(ctx, work, monkeypatch):
+    """A -verysensitive -db pass aligns every pair of (database batch) x (queries): r06 cuts its alignment batches from length
+    prefix sums (binary searches over the cells of the first k pairs) and lets every stage write its own slice of (i, j) instead of
+    filling two index arrays per database batch.  Same tables as the pair-list route (RSK_DENSE_PAIR_LISTS=1) and as the reference,
+    with batches of a few hundred pairs / few million cells so that cuts fall inside rows, at row ends and on single pairs."""
+    want32 = ["\t".join(r) for r in fx.read_tsv("hits_q32_db_q100_verysensitive.tsv.gz")]
+    wantt = ["\t".join(r) for r in fx.read_tsv("hits_tail_db_verysensitive.tsv.gz")]
+    for pairs, cells in (("777", None), ("100", "3000000"), ("1", None), (None, "200000")):
+        for dense in (None, "1"):
+            for k, v in (("RSK_BATCH_PAIRS", pairs), ("RSK_BATCH_CELLS", cells), ("RSK_DENSE_PAIR_LISTS", dense)):
+                if v is None:
+                    monkeypatch.delenv(k, raising=False)
+                else:
+                    monkeypatch.setenv(k, v)
+            if pairs != "1":
+                out = os.path.join(work, "dense32.tsv")
+                n, st = ctx.search(os.path.join(work, "q32.bca"), out, "verysensitive", db=os.path.join(work, "q100.bca"), columns=COLS)
+                assert sorted(open(out).read().splitlines()) == want32 and st[0] == 3200 and st[5] == 3200, (pairs, cells, dense)
+            out = os.path.join(work, "denset.tsv")
+            n, st = ctx.search(os.path.join(work, "tailq.bca"), out, "verysensitive", db=os.path.join(work, "taildb.bca"), columns=COLS)
+            assert sorted(open(out).read().splitlines()) == wantt and st[0] == 12 * 48, (pairs, cells, dense)
+
+
 def test_config4_shape_length_tail_to_5000(ctx, work):
     st = check(ctx, work, "tailq.bca", "taildb.bca", "verysensitive", "hits_tail_db_verysensitive.tsv.gz")
     assert st[0] == 12 * 48 and st[5] == 12 * 48
