@@ -447,7 +447,7 @@ def predicted_search_scaling(seqs, worlds=(2, 4, 8), reps=2, bca_worlds=(8,)):
                 return dt, int(nh), int(st[0])
 
             from reseek_amd import dist as rdist
-            for tag, src, ws, r in (("rskdb", db, worlds, reps), ("bca", bca, bca_worlds, max(1, reps - 1))):
+            for tag, src, ws, r in (("rskdb", db, worlds, reps), ("bca", bca, bca_worlds, reps)):
                 t1, h1, p1 = shard_s(src, 0, 1, reps)
                 e = {"one_gpu_seconds": round(t1, 4), "hits": h1, "chain_pairs": p1}
                 for N in ws:
